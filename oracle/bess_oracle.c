@@ -1,0 +1,1060 @@
+/* oracle/bess_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C99 restatement of the PDAS hot path of Mamba413/bess.  Every function cites
+ * the reference lines (under /root/reference) whose arithmetic it follows.  Nothing
+ * here is copied: the reference is Eigen/C++ with dense matrix temporaries, this file
+ * is scalar loops over the active columns only.  Summation order therefore differs
+ * from Eigen's, so coefficients agree to ~1e-12 relative, not bit for bit; selected
+ * supports, iteration counts and path decisions agree exactly on the pinned cases.
+ *
+ * Parity status: PINNED -- checked against the compiled reference in
+ * tests/test_oracle_vs_reference.py (when oracle/_ref/libbess_ref.so is present) and
+ * against committed golden vectors in tests/test_oracle_golden.py.
+ *
+ * Scope: singleton groups only (g_index = 0..p-1), model_type 1 (LM), 2 (logistic),
+ * 3 (Poisson), 4 (Cox); path_type 1 (sequential, with the lambda snake) and 2 (golden
+ * section).  Group sizes > 1, screening and the Powell path are out of scope
+ * (SURVEY.md section 8f).
+ */
+#include "bess_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ trace */
+
+typedef struct {
+  int *v;
+  int n, cap;
+} ivec;
+typedef struct {
+  double *v;
+  int n, cap;
+} dvec;
+
+static void ipush(ivec *a, int x) {
+  if (a->n == a->cap) {
+    a->cap = a->cap ? 2 * a->cap : 256;
+    a->v = (int *)realloc(a->v, (size_t)a->cap * sizeof(int));
+  }
+  a->v[a->n++] = x;
+}
+static void dpush(dvec *a, double x) {
+  if (a->n == a->cap) {
+    a->cap = a->cap ? 2 * a->cap : 256;
+    a->v = (double *)realloc(a->v, (size_t)a->cap * sizeof(double));
+  }
+  a->v[a->n++] = x;
+}
+
+static ivec t_meta, t_a;
+static dvec t_beta, t_coef0, t_loss, t_ic;
+
+int bess_oracle_trace_size(int which) {
+  switch (which) {
+    case 0: return t_meta.n;
+    case 1: return t_a.n;
+    case 2: return t_beta.n;
+    case 3: return t_coef0.n;
+    case 4: return t_loss.n;
+    case 5: return t_ic.n;
+  }
+  return -1;
+}
+void bess_oracle_trace_copy_int(int which, int *out) {
+  const ivec *a = which == 0 ? &t_meta : &t_a;
+  if (a->n) memcpy(out, a->v, (size_t)a->n * sizeof(int));
+}
+void bess_oracle_trace_copy_double(int which, double *out) {
+  const dvec *a = &t_beta;
+  if (which == 3) a = &t_coef0;
+  if (which == 4) a = &t_loss;
+  if (which == 5) a = &t_ic;
+  if (a->n) memcpy(out, a->v, (size_t)a->n * sizeof(double));
+}
+
+/* ------------------------------------------------------------------ data */
+
+typedef struct {
+  int n, p;
+  double *x; /* column-major n x p, normalised in place */
+  double *y, *w;
+  double *x_mean, *x_norm;
+  double y_mean;
+  int data_type, is_normal;
+} odata;
+
+#define XC(d, j) ((d)->x + (size_t)(j) * (size_t)(d)->n)
+
+/* Normalize / Normalize3 / Normalize4, src/normalize.cpp:20-85, dispatched as in
+ * Data::normalize, src/Data.h:79-93. */
+static void data_normalize(odata *d) {
+  int n = d->n, p = d->p, i, j;
+  double sn = sqrt((double)n);
+  if (d->data_type == 1 || d->data_type == 2) {
+    for (j = 0; j < p; j++) {
+      double s = 0.0, *c = XC(d, j);
+      for (i = 0; i < n; i++) s += d->w[i] * c[i];
+      d->x_mean[j] = s / (double)n;
+    }
+    if (d->data_type == 1) {
+      double s = 0.0;
+      for (i = 0; i < n; i++) s += d->y[i] * d->w[i];
+      d->y_mean = s / (double)n;
+    }
+    for (j = 0; j < p; j++) {
+      double *c = XC(d, j), m = d->x_mean[j];
+      for (i = 0; i < n; i++) c[i] = c[i] - m;
+    }
+    if (d->data_type == 1)
+      for (i = 0; i < n; i++) d->y[i] = d->y[i] - d->y_mean;
+  }
+  for (j = 0; j < p; j++) {
+    double s = 0.0, *c = XC(d, j);
+    for (i = 0; i < n; i++) s += d->w[i] * (c[i] * c[i]);
+    d->x_norm[j] = sqrt(s);
+  }
+  for (j = 0; j < p; j++) {
+    double *c = XC(d, j), nm = d->x_norm[j];
+    for (i = 0; i < n; i++) c[i] = sn * c[i] / nm;
+  }
+}
+
+/* Data::add_weight, src/Data.h:70-77 (LM only, src/bess.cpp:97). */
+static void data_add_weight(odata *d) {
+  int i, j;
+  for (i = 0; i < d->n; i++) {
+    double s = sqrt(d->w[i]);
+    for (j = 0; j < d->p; j++) XC(d, j)[i] = XC(d, j)[i] * s;
+    d->y[i] = d->y[i] * s;
+  }
+}
+
+/* ------------------------------------------------------------------ small linear algebra */
+
+int bess_oracle_sym_solve(const double *a, int k, const double *b, double *x) {
+  /* un-pivoted LDL^T of the lower triangle; stands in for Eigen's
+   * ColPivHouseholderQR (src/Algorithm.h:1134) and LDLT (:1171,1199,1299,1473) solves
+   * of definite k x k systems. */
+  int i, j, m, rc = 0;
+  double *l = (double *)malloc((size_t)k * (size_t)k * sizeof(double));
+  double *dg = (double *)malloc((size_t)k * sizeof(double));
+  for (j = 0; j < k; j++) {
+    double dj = a[(size_t)j * k + j];
+    for (m = 0; m < j; m++) dj -= l[(size_t)m * k + j] * l[(size_t)m * k + j] * dg[m];
+    dg[j] = dj;
+    if (dj == 0.0) {
+      rc = 1;
+      dj = DBL_MIN;
+    }
+    for (i = j + 1; i < k; i++) {
+      double s = a[(size_t)j * k + i];
+      for (m = 0; m < j; m++) s -= l[(size_t)m * k + i] * l[(size_t)m * k + j] * dg[m];
+      l[(size_t)j * k + i] = s / dj;
+    }
+  }
+  for (i = 0; i < k; i++) {
+    double s = b[i];
+    for (m = 0; m < i; m++) s -= l[(size_t)m * k + i] * x[m];
+    x[i] = s;
+  }
+  for (i = 0; i < k; i++) x[i] = x[i] / dg[i];
+  for (i = k - 1; i >= 0; i--) {
+    double s = x[i];
+    for (m = i + 1; m < k; m++) s -= l[(size_t)i * k + m] * x[m];
+    x[i] = s;
+  }
+  free(l);
+  free(dg);
+  return rc;
+}
+
+typedef struct {
+  double s;
+  int i;
+} spair;
+static int spair_cmp(const void *a, const void *b) {
+  const spair *x = (const spair *)a, *y = (const spair *)b;
+  if (x->s > y->s) return -1;
+  if (x->s < y->s) return 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+static int int_cmp(const void *a, const void *b) {
+  int x = *(const int *)a, y = *(const int *)b;
+  return (x > y) - (x < y);
+}
+
+void bess_oracle_max_k(const double *score, int len, int k, int *out) {
+  /* max_k, src/utilities.cpp:179-188 */
+  int i;
+  spair *s = (spair *)malloc((size_t)len * sizeof(spair));
+  for (i = 0; i < len; i++) {
+    s[i].s = score[i];
+    s[i].i = i;
+  }
+  qsort(s, (size_t)len, sizeof(spair), spair_cmp);
+  for (i = 0; i < k; i++) out[i] = s[i].i;
+  qsort(out, (size_t)k, sizeof(int), int_cmp);
+  free(s);
+}
+
+/* ------------------------------------------------------------------ Algorithm */
+
+typedef struct {
+  odata *d;
+  int model_type, algorithm_type, max_iter, warm_start;
+  int T0;
+  double lambda;
+  const int *rows; /* train mask (sorted row indices) */
+  int n_rows;
+  double *beta, *beta_init;
+  double coef0, coef0_init;
+  int l;
+  const double *xtx; /* group_XTX of the current training rows (LM) */
+  const int *always;
+  int n_always;
+} oalg;
+
+static double clamp30(double v) {
+  if (v > 30.0) return 30.0;
+  if (v < -30.0) return -30.0;
+  return v;
+}
+
+/* eta_i = sum_j x_ij beta_j over the non-zero beta_j, for i in rows */
+static void lin_pred(const odata *d, const double *beta, const int *rows, int n_rows, double *eta) {
+  int i, j;
+  for (i = 0; i < n_rows; i++) eta[i] = 0.0;
+  for (j = 0; j < d->p; j++) {
+    if (beta[j] != 0.0) {
+      const double *c = d->x + (size_t)j * (size_t)d->n;
+      double b = beta[j];
+      for (i = 0; i < n_rows; i++) eta[i] += c[rows[i]] * b;
+    }
+  }
+}
+
+static void select_top(oalg *a, double *bd, int *A) {
+  /* slice_assignment + max_k, src/utilities.cpp:179-199 */
+  int i;
+  for (i = 0; i < a->n_always; i++) bd[a->always[i]] = DBL_MAX;
+  bess_oracle_max_k(bd, a->d->p, a->T0, A);
+}
+
+/* GroupPdasLm::get_A, src/Algorithm.h:1097-1129 with Phi / invPhi for 1x1 groups,
+ * src/utilities.cpp:142-151, 167-177. */
+static void lm_get_A(oalg *a, int *A) {
+  const odata *d = a->d;
+  int nt = a->n_rows, p = d->p, i, j;
+  double *r = (double *)malloc((size_t)nt * sizeof(double));
+  double *bd = (double *)malloc((size_t)p * sizeof(double));
+  lin_pred(d, a->beta, a->rows, nt, r);
+  for (i = 0; i < nt; i++) r[i] = d->y[a->rows[i]] - r[i] - a->coef0;
+  for (j = 0; j < p; j++) {
+    const double *c = d->x + (size_t)j * (size_t)d->n;
+    double s = 0.0, dj, phi, inv, t;
+    for (i = 0; i < nt; i++) s += c[a->rows[i]] * r[i];
+    dj = s / (double)nt - 2.0 * a->lambda * a->beta[j];
+    phi = sqrt(2.0 * a->lambda + a->xtx[j] / (double)nt);
+    inv = 1.0 / phi;
+    t = phi * a->beta[j] + inv * dj;
+    bd[j] = t * t;
+  }
+  select_top(a, bd, A);
+  free(r);
+  free(bd);
+}
+
+/* GroupPdasLm::primary_model_fit, src/Algorithm.h:1131-1135 */
+static void lm_fit(oalg *a, const int *A, int k, double *bA) {
+  const odata *d = a->d;
+  int nt = a->n_rows, i, u, v;
+  double *g = (double *)malloc((size_t)k * (size_t)k * sizeof(double));
+  double *c = (double *)malloc((size_t)k * sizeof(double));
+  for (u = 0; u < k; u++) {
+    const double *cu = d->x + (size_t)A[u] * (size_t)d->n;
+    double s = 0.0;
+    for (i = 0; i < nt; i++) s += cu[a->rows[i]] * d->y[a->rows[i]];
+    c[u] = s;
+    for (v = 0; v <= u; v++) {
+      const double *cv = d->x + (size_t)A[v] * (size_t)d->n;
+      s = 0.0;
+      for (i = 0; i < nt; i++) s += cu[a->rows[i]] * cv[a->rows[i]];
+      if (u == v) s += a->lambda;
+      g[(size_t)v * k + u] = s;
+    }
+  }
+  bess_oracle_sym_solve(g, k, c, bA);
+  free(g);
+  free(c);
+}
+
+/* Weighted normal equations of an IRLS step on the design [1, X_A]:
+ * (2*lambda*diag(0,1,..,1) + Z'WZ) b = Z'W z, src/Algorithm.h:1171,1199 (logistic),
+ * :1299 (Poisson). */
+static void irls_solve(oalg *a, const int *A, int k, const double *W, const double *z, double *b) {
+  const odata *d = a->d;
+  int nt = a->n_rows, m = k + 1, i, u, v;
+  double *g = (double *)malloc((size_t)m * (size_t)m * sizeof(double));
+  double *c = (double *)malloc((size_t)m * sizeof(double));
+  for (u = 0; u < m; u++) {
+    const double *cu = u ? d->x + (size_t)A[u - 1] * (size_t)d->n : NULL;
+    double s = 0.0;
+    for (i = 0; i < nt; i++) s += (cu ? cu[a->rows[i]] : 1.0) * W[i] * z[i];
+    c[u] = s;
+    for (v = 0; v <= u; v++) {
+      const double *cv = v ? d->x + (size_t)A[v - 1] * (size_t)d->n : NULL;
+      s = 0.0;
+      for (i = 0; i < nt; i++) s += (cu ? cu[a->rows[i]] : 1.0) * W[i] * (cv ? cv[a->rows[i]] : 1.0);
+      if (u == v && u > 0) s += 2.0 * a->lambda;
+      g[(size_t)v * m + u] = s;
+    }
+  }
+  bess_oracle_sym_solve(g, m, c, b);
+  free(g);
+  free(c);
+}
+
+/* eta_i = b[0] + sum_u x_{i,A[u]} b[u+1] */
+static void design_eta(const oalg *a, const int *A, int k, const double *b, double *eta) {
+  const odata *d = a->d;
+  int nt = a->n_rows, i, u;
+  for (i = 0; i < nt; i++) eta[i] = 0.0;
+  for (u = 0; u < k; u++) {
+    const double *c = d->x + (size_t)A[u] * (size_t)d->n;
+    for (i = 0; i < nt; i++) eta[i] += c[a->rows[i]] * b[u + 1];
+  }
+  for (i = 0; i < nt; i++) eta[i] += b[0];
+}
+
+/* GroupPdasLogistic::primary_model_fit, src/Algorithm.h:1148-1204; pi(), src/logistic.cpp:15-59.
+ * Cold start, <= 1+30 solves, returns the iterate BEFORE the last solve. */
+static void logistic_fit(oalg *a, const int *A, int k, double *bA, double *coef0) {
+  const odata *d = a->d;
+  int nt = a->n_rows, m = k + 1, i, j;
+  double *b0 = (double *)calloc((size_t)m, sizeof(double));
+  double *b1 = (double *)calloc((size_t)m, sizeof(double));
+  double *eta = (double *)malloc((size_t)nt * sizeof(double));
+  double *Pi = (double *)malloc((size_t)nt * sizeof(double));
+  double *W = (double *)malloc((size_t)nt * sizeof(double));
+  double *Z = (double *)malloc((size_t)nt * sizeof(double));
+  double ll0 = 0.0, ll1;
+  design_eta(a, A, k, b0, eta);
+  for (i = 0; i < nt; i++) {
+    double e = exp(clamp30(eta[i])), yi = d->y[a->rows[i]];
+    Pi[i] = e / (1.0 + e);
+    ll0 += (yi * log(Pi[i]) + (1.0 - yi) * log(1.0 - Pi[i])) * d->w[a->rows[i]];
+    W[i] = Pi[i] * (1.0 - Pi[i]);
+    Z[i] = eta[i] + (yi - Pi[i]) / W[i];
+    W[i] = W[i] * d->w[a->rows[i]];
+  }
+  irls_solve(a, A, k, W, Z, b1);
+  for (j = 0; j < 30; j++) {
+    design_eta(a, A, k, b1, eta);
+    ll1 = 0.0;
+    for (i = 0; i < nt; i++) {
+      double e = exp(clamp30(eta[i])), yi = d->y[a->rows[i]];
+      Pi[i] = e / (1.0 + e);
+      ll1 += (yi * log(Pi[i]) + (1.0 - yi) * log(1.0 - Pi[i])) * d->w[a->rows[i]];
+    }
+    if (fabs(ll0 - ll1) / (0.1 + fabs(ll1)) < 1e-6) break;
+    memcpy(b0, b1, (size_t)m * sizeof(double));
+    ll0 = ll1;
+    for (i = 0; i < nt; i++) {
+      double yi = d->y[a->rows[i]];
+      W[i] = Pi[i] * (1.0 - Pi[i]);
+      if (W[i] < 0.001) W[i] = 0.001;
+      Z[i] = eta[i] + (yi - Pi[i]) / W[i]; /* eta is the un-clamped X*beta0, :1193 */
+      W[i] = W[i] * d->w[a->rows[i]];
+    }
+    irls_solve(a, A, k, W, Z, b1);
+  }
+  for (i = 0; i < k; i++) bA[i] = b0[i + 1];
+  *coef0 = b0[0];
+  free(b0);
+  free(b1);
+  free(eta);
+  free(Pi);
+  free(W);
+  free(Z);
+}
+
+/* GroupPdasLogistic::get_A, src/Algorithm.h:1206-1263 (1x1 groups) */
+static void logistic_get_A(oalg *a, int *A) {
+  const odata *d = a->d;
+  int nt = a->n_rows, p = d->p, i, j;
+  double *g = (double *)malloc((size_t)nt * sizeof(double));
+  double *h = (double *)malloc((size_t)nt * sizeof(double));
+  double *bd = (double *)malloc((size_t)p * sizeof(double));
+  lin_pred(d, a->beta, a->rows, nt, g);
+  for (i = 0; i < nt; i++) {
+    double e = exp(clamp30(g[i] + a->coef0)), pr = e / (e + 1.0), wi = d->w[a->rows[i]];
+    g[i] = wi * (d->y[a->rows[i]] - pr);
+    h[i] = wi * pr * (1.0 - pr);
+  }
+  for (j = 0; j < p; j++) {
+    const double *c = d->x + (size_t)j * (size_t)d->n;
+    double s1 = 0.0, s2 = 0.0, dj, phi, inv, t;
+    for (i = 0; i < nt; i++) {
+      double xv = c[a->rows[i]];
+      s1 += xv * g[i];
+      s2 += (xv * h[i]) * xv;
+    }
+    dj = s1 - 2.0 * a->lambda * a->beta[j];
+    phi = sqrt(s2 + 2.0 * a->lambda);
+    inv = 1.0 / phi;
+    t = phi * a->beta[j] + inv * dj;
+    bd[j] = t * t;
+  }
+  select_top(a, bd, A);
+  free(g);
+  free(h);
+  free(bd);
+}
+
+/* GroupPdasPoisson::primary_model_fit, src/Algorithm.h:1273-1322.  Warm start from
+ * (coef0, beta_A) -- but Algorithm::fit zeroes beta_A first (:157), so only coef0
+ * survives. */
+static void poisson_fit(oalg *a, const int *A, int k, double *bA, double *coef0) {
+  const odata *d = a->d;
+  int nt = a->n_rows, m = k + 1, i, j;
+  double *b0 = (double *)calloc((size_t)m, sizeof(double));
+  double *eta = (double *)malloc((size_t)nt * sizeof(double));
+  double *ee = (double *)malloc((size_t)nt * sizeof(double));
+  double *W = (double *)malloc((size_t)nt * sizeof(double));
+  double *Z = (double *)malloc((size_t)nt * sizeof(double));
+  double ll0 = 1e5, ll1;
+  for (i = 0; i < k; i++) b0[i + 1] = bA[i];
+  b0[0] = *coef0;
+  design_eta(a, A, k, b0, eta);
+  for (i = 0; i < nt; i++) ee[i] = exp(eta[i]);
+  for (j = 0; j < 50; j++) {
+    for (i = 0; i < nt; i++) {
+      W[i] = ee[i] * d->w[a->rows[i]];
+      Z[i] = eta[i] + (d->y[a->rows[i]] - ee[i]) / ee[i];
+    }
+    irls_solve(a, A, k, W, Z, b0);
+    design_eta(a, A, k, b0, eta);
+    ll1 = 0.0;
+    for (i = 0; i < nt; i++) {
+      eta[i] = clamp30(eta[i]);
+      ee[i] = exp(eta[i]);
+      if (ee[i] < 0.001) ee[i] = 0.001;
+      ll1 += (d->y[a->rows[i]] * eta[i] - ee[i]) * d->w[a->rows[i]];
+    }
+    if (fabs(ll0 - ll1) / fabs(0.1 + ll0) < 1e-6) break;
+    ll0 = ll1;
+  }
+  for (i = 0; i < k; i++) bA[i] = b0[i + 1];
+  *coef0 = b0[0];
+  free(b0);
+  free(eta);
+  free(ee);
+  free(W);
+  free(Z);
+}
+
+/* GroupPdasPoisson::get_A, src/Algorithm.h:1324-1367 (no eta clamp) */
+static void poisson_get_A(oalg *a, int *A) {
+  const odata *d = a->d;
+  int nt = a->n_rows, p = d->p, i, j;
+  double *g = (double *)malloc((size_t)nt * sizeof(double));
+  double *h = (double *)malloc((size_t)nt * sizeof(double));
+  double *bd = (double *)malloc((size_t)p * sizeof(double));
+  lin_pred(d, a->beta, a->rows, nt, g);
+  for (i = 0; i < nt; i++) {
+    double e = exp(g[i] + a->coef0), wi = d->w[a->rows[i]];
+    g[i] = (d->y[a->rows[i]] - e) * wi;
+    h[i] = e * wi;
+  }
+  for (j = 0; j < p; j++) {
+    const double *c = d->x + (size_t)j * (size_t)d->n;
+    double s1 = 0.0, s2 = 0.0, dj, phi, inv, t;
+    for (i = 0; i < nt; i++) {
+      double xv = c[a->rows[i]];
+      s1 += xv * g[i];
+      s2 += (xv * h[i]) * xv;
+    }
+    dj = s1 - 2.0 * a->lambda * a->beta[j];
+    phi = sqrt(s2 + 2.0 * a->lambda);
+    inv = 1.0 / phi;
+    t = phi * a->beta[j] + inv * dj;
+    bd[j] = t * t;
+  }
+  select_top(a, bd, A);
+  free(g);
+  free(h);
+  free(bd);
+}
+
+/* loglik_cox, src/coxph.cpp:16-40, on an arbitrary sorted row subset */
+static double cox_loglik(const odata *d, const double *eta_in, const int *rows, int nr) {
+  int i;
+  double cum = 0.0, s = 0.0;
+  for (i = nr - 1; i >= 0; i--) {
+    double e = exp(clamp30(eta_in[i]));
+    cum = (i == nr - 1) ? e : cum + e;
+    s += (log(e / cum) * d->y[rows[i]]) * d->w[rows[i]];
+  }
+  return s;
+}
+
+/* GroupPdasCox::primary_model_fit, src/Algorithm.h:1377-1490.  The reference forms the
+ * risk-set sums with a dense n x n upper-triangular ones matrix (:1386,1425-1428);
+ * here they are reverse running sums -- the same numbers in O(nk^2). */
+static void cox_fit(oalg *a, const int *A, int k, double *bA) {
+  const odata *d = a->d;
+  int nt = a->n_rows, i, u, v, l, m;
+  double *b0 = (double *)calloc((size_t)k + 1, sizeof(double));
+  double *b1 = (double *)calloc((size_t)k + 1, sizeof(double));
+  double *bz = (double *)calloc((size_t)k + 1, sizeof(double)); /* design_eta wants an intercept slot */
+  double *eta = (double *)malloc((size_t)nt * sizeof(double));
+  double *th = (double *)malloc((size_t)nt * sizeof(double));
+  double *s0 = (double *)malloc((size_t)nt * sizeof(double));
+  double *xa = (double *)malloc((size_t)nt * (size_t)(k ? k : 1) * sizeof(double)); /* S1/S0, column-major */
+  double *g = (double *)malloc((size_t)(k ? k : 1) * sizeof(double));
+  double *h = (double *)malloc((size_t)(k ? k : 1) * (size_t)(k ? k : 1) * sizeof(double));
+  double *dd = (double *)malloc((size_t)(k ? k : 1) * sizeof(double));
+  double ll0 = 1e5, ll1;
+  for (l = 1; l <= 30; l++) {
+    double step;
+    for (u = 0; u < k; u++) bz[u + 1] = b0[u];
+    design_eta(a, A, k, bz, eta);
+    for (i = 0; i < nt; i++) th[i] = exp(clamp30(eta[i]));
+    for (i = nt - 1; i >= 0; i--) s0[i] = (i == nt - 1) ? th[i] : s0[i + 1] + th[i];
+    for (u = 0; u < k; u++) {
+      const double *cu = d->x + (size_t)A[u] * (size_t)d->n;
+      double acc = 0.0, gs = 0.0;
+      for (i = nt - 1; i >= 0; i--) {
+        acc += cu[a->rows[i]] * th[i];
+        xa[(size_t)u * nt + i] = acc / s0[i];
+      }
+      for (i = 0; i < nt; i++)
+        gs += (cu[a->rows[i]] - xa[(size_t)u * nt + i]) * (d->w[a->rows[i]] * d->y[a->rows[i]]);
+      g[u] = gs + 2.0 * a->lambda * b0[u];
+    }
+    for (u = 0; u < k; u++) {
+      const double *cu = d->x + (size_t)A[u] * (size_t)d->n;
+      for (v = u; v < k; v++) {
+        const double *cv = d->x + (size_t)A[v] * (size_t)d->n;
+        double acc = 0.0, hs = 0.0;
+        for (i = nt - 1; i >= 0; i--) {
+          acc += (th[i] * cu[a->rows[i]]) * cv[a->rows[i]];
+          hs += (acc / s0[i] - xa[(size_t)u * nt + i] * xa[(size_t)v * nt + i]) *
+                (d->w[a->rows[i]] * d->y[a->rows[i]]);
+        }
+        hs = -hs;
+        if (u == v) hs += 2.0 * a->lambda;
+        h[(size_t)u * k + v] = hs;
+        h[(size_t)v * k + u] = hs;
+      }
+    }
+    bess_oracle_sym_solve(h, k, g, dd);
+    m = 1;
+    step = 0.5;
+    for (u = 0; u < k; u++) b1[u] = b0[u] - step * dd[u];
+    for (u = 0; u < k; u++) bz[u + 1] = b1[u];
+    design_eta(a, A, k, bz, eta);
+    ll1 = cox_loglik(d, eta, a->rows, nt);
+    while (ll0 > ll1 && m < 5) {
+      m = m + 1;
+      step = pow(0.5, (double)m);
+      for (u = 0; u < k; u++) b1[u] = b0[u] - step * dd[u];
+      for (u = 0; u < k; u++) bz[u + 1] = b1[u];
+      design_eta(a, A, k, bz, eta);
+      ll1 = cox_loglik(d, eta, a->rows, nt);
+    }
+    if (fabs(ll0 - ll1) / fabs(0.1 + ll0) < 1e-5) break;
+    memcpy(b0, b1, (size_t)k * sizeof(double));
+    ll0 = ll1;
+  }
+  for (u = 0; u < k; u++) bA[u] = b0[u];
+  free(b0);
+  free(b1);
+  free(bz);
+  free(eta);
+  free(th);
+  free(s0);
+  free(xa);
+  free(g);
+  free(h);
+  free(dd);
+}
+
+/* GroupPdasCox::get_A, algorithm_type 1/5 branch, src/Algorithm.h:1569-1640 */
+static void cox_get_A(oalg *a, int *A) {
+  const odata *d = a->d;
+  int nt = a->n_rows, p = d->p, i, j;
+  double *th = (double *)malloc((size_t)nt * sizeof(double));
+  double *s0 = (double *)malloc((size_t)nt * sizeof(double));
+  double *bd = (double *)malloc((size_t)p * sizeof(double));
+  lin_pred(d, a->beta, a->rows, nt, th);
+  for (i = 0; i < nt; i++) th[i] = d->w[a->rows[i]] * exp(clamp30(th[i]));
+  for (i = nt - 1; i >= 0; i--) s0[i] = (i == nt - 1) ? th[i] : s0[i + 1] + th[i];
+  for (j = 0; j < p; j++) {
+    const double *c = d->x + (size_t)j * (size_t)d->n;
+    double a1 = 0.0, a2 = 0.0, l1 = 0.0, l2 = 0.0, dj, t;
+    for (i = nt - 1; i >= 0; i--) {
+      double xv = c[a->rows[i]], xt = th[i] * xv, q1, q2;
+      a1 += xt;
+      a2 += xv * xt;
+      if (d->y[a->rows[i]] != 0.0) {
+        q1 = a1 / s0[i];
+        q2 = a2 / s0[i] - q1 * q1;
+        l1 += (xv - q1) * d->w[a->rows[i]];
+        l2 += q2 * d->w[a->rows[i]];
+      }
+    }
+    l1 = -l1 + 2.0 * a->lambda * a->beta[j];
+    l2 = l2 + 2.0 * a->lambda;
+    dj = -l1 / l2;
+    t = fabs(a->beta[j] + dj);
+    bd[j] = t * sqrt(l2);
+  }
+  select_top(a, bd, A);
+  free(th);
+  free(s0);
+  free(bd);
+}
+
+/* Algorithm::fit, src/Algorithm.h:113-171 */
+static void alg_fit(oalg *a) {
+  int T0 = a->T0, p = a->d->p, i, ll, l;
+  int *A = (int *)calloc((size_t)(T0 ? T0 : 1), sizeof(int));
+  int *Alist = (int *)calloc((size_t)(T0 ? T0 : 1) * (size_t)(a->max_iter + 2), sizeof(int));
+  double *bA = (double *)malloc((size_t)(T0 ? T0 : 1) * sizeof(double));
+  memcpy(a->beta, a->beta_init, (size_t)p * sizeof(double));
+  a->coef0 = a->coef0_init;
+  for (l = 1; l <= a->max_iter; l++) {
+    int off, same = 0;
+    a->l = l;
+    if (a->model_type == 1)
+      lm_get_A(a, A);
+    else if (a->model_type == 2)
+      logistic_get_A(a, A);
+    else if (a->model_type == 3)
+      poisson_get_A(a, A);
+    else
+      cox_get_A(a, A);
+    ipush(&t_meta, l);
+    ipush(&t_meta, T0);
+    ipush(&t_meta, a->n_rows);
+    off = t_a.n;
+    ipush(&t_meta, off);
+    for (i = 0; i < T0; i++) ipush(&t_a, A[i]);
+    memcpy(Alist + (size_t)l * T0, A, (size_t)T0 * sizeof(int));
+    for (i = 0; i < T0; i++) bA[i] = 0.0;
+    if (a->model_type == 1)
+      lm_fit(a, A, T0, bA);
+    else if (a->model_type == 2)
+      logistic_fit(a, A, T0, bA, &a->coef0);
+    else if (a->model_type == 3)
+      poisson_fit(a, A, T0, bA, &a->coef0);
+    else
+      cox_fit(a, A, T0, bA);
+    for (i = 0; i < T0; i++) dpush(&t_beta, bA[i]);
+    dpush(&t_coef0, a->coef0);
+    for (i = 0; i < p; i++) a->beta[i] = 0.0;
+    for (i = 0; i < T0; i++) a->beta[A[i]] = bA[i];
+    for (ll = 0; ll < l && !same; ll++) same = memcmp(A, Alist + (size_t)ll * T0, (size_t)T0 * sizeof(int)) == 0;
+    if (same) break;
+  }
+  if (l > a->max_iter) a->l = a->max_iter + 1;
+  free(A);
+  free(Alist);
+  free(bA);
+}
+
+/* ------------------------------------------------------------------ Metric */
+
+typedef struct {
+  int ic_type, is_cv, K;
+  int **train, **test;
+  int *n_train, *n_test;
+  double **cv_init; /* K x p, cv_initial_model_param, src/Metric.h:22,39-47 */
+  double **cv_xtx;  /* K x p, cal_cv_group_XTX, src/Metric.h:108-129 (LM) */
+  int depth;
+} ometric;
+
+/* loss of (beta, coef0) on a row subset: the four train_loss / test_loss bodies,
+ * src/Metric.h:145-148,190 (LM), :266-290,338-351 (logistic), :426-440,489 (Poisson via
+ * loglik_poisson, src/poisson.cpp:15-45), :565-568,609 (Cox). */
+static double subset_loss(const oalg *a, const int *rows, int nr, int is_test) {
+  const odata *d = a->d;
+  int i;
+  double s = 0.0;
+  double *eta = (double *)malloc((size_t)(nr ? nr : 1) * sizeof(double));
+  lin_pred(d, a->beta, rows, nr, eta);
+  if (a->model_type == 1) {
+    for (i = 0; i < nr; i++) {
+      double r = d->y[rows[i]] - eta[i];
+      s += r * r;
+    }
+    s = is_test ? s / (double)(2 * nr) : s / (double)nr;
+  } else if (a->model_type == 2) {
+    double cl = is_test ? 25.0 : 30.0;
+    for (i = 0; i < nr; i++) {
+      double v = eta[i] + a->coef0, e, pr, yi = d->y[rows[i]];
+      if (v > cl) v = cl;
+      if (v < -cl) v = -cl;
+      e = exp(v);
+      pr = e / (e + 1.0);
+      s += d->w[rows[i]] * (yi * log(pr) + (1.0 - yi) * log(1.0 - pr));
+    }
+    s = -2.0 * s;
+  } else if (a->model_type == 3) {
+    for (i = 0; i < nr; i++) {
+      double v = clamp30(eta[i] + a->coef0), yi = d->y[rows[i]], t = 0.0, jj;
+      if (yi != 1.0)
+        for (jj = 1.0; jj <= yi; jj = jj + 1.0) t = t + log(jj);
+      s += (yi * v - exp(v) - t) * d->w[rows[i]];
+    }
+    s = is_test ? -s : -2.0 * s;
+  } else {
+    s = -2.0 * cox_loglik(d, eta, rows, nr);
+  }
+  free(eta);
+  return s;
+}
+
+static int *g_full_rows; /* 0..n-1 */
+
+static double metric_train_loss(ometric *m, oalg *a) {
+  double v = subset_loss(a, g_full_rows, a->d->n, 0);
+  if (m->depth == 0) dpush(&t_loss, v);
+  return v;
+}
+
+/* test_loss with CV: src/Metric.h:150-195 (LM), :292-355, :442-494, :570-614 */
+static double metric_test_loss(ometric *m, oalg *a) {
+  int k, j, p = a->d->p;
+  double s = 0.0;
+  for (k = 0; k < m->K; k++) {
+    if (a->warm_start) memcpy(a->beta_init, m->cv_init[k], (size_t)p * sizeof(double));
+    a->rows = m->train[k];
+    a->n_rows = m->n_train[k];
+    if (a->model_type == 1) a->xtx = m->cv_xtx[k];
+    alg_fit(a);
+    if (a->warm_start)
+      for (j = 0; j < p; j++) m->cv_init[k][j] = a->beta[j];
+    s += subset_loss(a, m->test[k], m->n_test[k], 1);
+  }
+  return s / (double)m->K;
+}
+
+/* ic: src/Metric.h:197-256 (LM: n*log(loss) + c*T0), :357-416, :496-555, :616-675 (loss + c*T0) */
+static double metric_ic(ometric *m, oalg *a) {
+  double v, n = (double)a->d->n, p = (double)a->d->p, c = 0.0, loss;
+  m->depth++;
+  if (m->is_cv) {
+    v = metric_test_loss(m, a);
+  } else if (m->ic_type < 1 || m->ic_type > 4) {
+    v = 0.0;
+  } else {
+    loss = metric_train_loss(m, a);
+    if (m->ic_type == 1) c = 2.0;
+    if (m->ic_type == 2) c = log(n);
+    if (m->ic_type == 3) c = log(p) * log(log(n));
+    if (m->ic_type == 4) c = log(n) + 2.0 * log(p);
+    v = (a->model_type == 1 ? n * log(loss) : loss) + c * (double)a->T0;
+  }
+  m->depth--;
+  if (m->depth == 0) dpush(&t_ic, v);
+  return v;
+}
+
+/* ------------------------------------------------------------------ paths */
+
+typedef struct {
+  double *beta; /* p */
+  double coef0, loss, ic;
+} opoint;
+
+static void denorm(const odata *d, double *beta, double *coef0) {
+  /* src/path.cpp:76-110 and :330-373 */
+  int j;
+  double dot = 0.0, sn = sqrt((double)d->n);
+  if (!d->is_normal) return;
+  for (j = 0; j < d->p; j++) {
+    beta[j] = sn * beta[j] / d->x_norm[j];
+    dot += beta[j] * d->x_mean[j];
+  }
+  if (d->data_type == 1)
+    *coef0 = d->y_mean - dot;
+  else if (d->data_type == 2)
+    *coef0 = *coef0 - dot;
+}
+
+static void run_fit(oalg *a, int T0, double lambda, const double *beta_init, double coef0_init, const double *xtx) {
+  a->rows = g_full_rows;
+  a->n_rows = a->d->n;
+  a->T0 = T0;
+  a->lambda = lambda;
+  memcpy(a->beta_init, beta_init, (size_t)a->d->p * sizeof(double));
+  a->coef0_init = coef0_init;
+  a->xtx = xtx;
+  alg_fit(a);
+}
+
+/* sequential_path, src/path.cpp:25-132 */
+static void seq_path(oalg *a, ometric *m, const double *xtx, const int *seq, int ns, const double *lam, int nl,
+                     opoint *best) {
+  int p = a->d->p, i, j, bi = 0, bj = 0;
+  double *beta_init = (double *)calloc((size_t)p, sizeof(double)), coef0_init = 0.0;
+  double *betas = (double *)calloc((size_t)p * (size_t)ns * (size_t)nl, sizeof(double));
+  double *c0 = (double *)calloc((size_t)ns * (size_t)nl, sizeof(double));
+  double *ls = (double *)calloc((size_t)ns * (size_t)nl, sizeof(double));
+  double *ic = (double *)calloc((size_t)ns * (size_t)nl, sizeof(double));
+  for (i = 0; i < ns; i++) {
+    int step = (i % 2 == 0) ? 1 : -1;
+    for (j = (i % 2 == 0) ? 0 : nl - 1; j < nl && j >= 0; j += step) {
+      size_t q = (size_t)j * ns + i;
+      run_fit(a, seq[i], lam[j], beta_init, coef0_init, xtx);
+      if (a->warm_start) {
+        memcpy(beta_init, a->beta, (size_t)p * sizeof(double));
+        coef0_init = a->coef0;
+      }
+      memcpy(betas + q * p, a->beta, (size_t)p * sizeof(double));
+      c0[q] = a->coef0;
+      ls[q] = metric_train_loss(m, a);
+      ic[q] = metric_ic(m, a);
+    }
+  }
+  /* minCoeff over a column-major (ns x nl) matrix: first minimum in storage order */
+  for (j = 0; j < nl; j++)
+    for (i = 0; i < ns; i++)
+      if (ic[(size_t)j * ns + i] < ic[(size_t)bj * ns + bi]) {
+        bi = i;
+        bj = j;
+      }
+  memcpy(best->beta, betas + ((size_t)bj * ns + bi) * p, (size_t)p * sizeof(double));
+  best->coef0 = c0[(size_t)bj * ns + bi];
+  best->loss = ls[(size_t)bj * ns + bi];
+  best->ic = ic[(size_t)bj * ns + bi];
+  denorm(a->d, best->beta, &best->coef0);
+  free(beta_init);
+  free(betas);
+  free(c0);
+  free(ls);
+  free(ic);
+}
+
+static int iround(double v) { return (int)round(v); }
+
+/* gs_path, src/path.cpp:134-389.  lambda is never set there (stays 0). */
+static void gs_path(oalg *a, ometric *m, const double *xtx, int s_min, int s_max, opoint *best) {
+  int p = a->d->p, Tmin = s_min, Tmax = s_max, T1, T2, T;
+  double *beta_init = (double *)calloc((size_t)p, sizeof(double)), coef0_init = 0.0;
+  double ic1, ic2, icT1, icT2, best_ic = DBL_MAX;
+  T1 = iround(0.618 * Tmin + 0.382 * Tmax);
+  T2 = iround(0.382 * Tmin + 0.618 * Tmax);
+
+#define GS_FIT(T)                                                \
+  do {                                                           \
+    run_fit(a, (T), 0.0, beta_init, coef0_init, xtx);            \
+    if (a->warm_start) {                                         \
+      memcpy(beta_init, a->beta, (size_t)p * sizeof(double));    \
+      coef0_init = a->coef0;                                     \
+    }                                                            \
+  } while (0)
+
+  GS_FIT(T1);
+  metric_train_loss(m, a);
+  ic1 = metric_ic(m, a);
+  icT1 = ic1;
+  GS_FIT(T2);
+  metric_train_loss(m, a);
+  ic2 = metric_ic(m, a);
+  icT2 = metric_ic(m, a); /* evaluated twice, :204 and :210 */
+  while (T1 != T2) {
+    if (icT1 < icT2) {
+      Tmax = T2;
+      T2 = T1;
+      ic2 = ic1;
+      icT2 = ic1;
+      T1 = iround(0.618 * Tmin + 0.382 * Tmax);
+      GS_FIT(T1);
+      metric_train_loss(m, a);
+      ic1 = metric_ic(m, a);
+      icT1 = metric_ic(m, a);
+    } else {
+      Tmin = T1;
+      T1 = T2;
+      ic1 = ic2;
+      icT1 = ic2;
+      T2 = iround(0.382 * Tmin + 0.618 * Tmax);
+      GS_FIT(T2);
+      metric_train_loss(m, a);
+      ic2 = metric_ic(m, a);
+      icT2 = metric_ic(m, a);
+    }
+  }
+  memset(best->beta, 0, (size_t)p * sizeof(double));
+  best->coef0 = 0.0;
+  best->loss = 0.0;
+  for (T = Tmin; T <= Tmax; T++) {
+    double v;
+    GS_FIT(T);
+    v = metric_ic(m, a);
+    if (v < best_ic) {
+      /* read AFTER ic(): under CV this is the last fold's fit, :314-319 */
+      memcpy(best->beta, a->beta, (size_t)p * sizeof(double));
+      best->coef0 = a->coef0;
+      best->loss = metric_train_loss(m, a);
+      best_ic = v;
+    }
+  }
+  best->ic = best_ic;
+  /* gs_path de-normalises with "data_type == 1 ... else" (:330-342): data_type 3 also
+   * subtracts beta.x_mean, which is zero there (Normalize4 never sets x_mean). */
+  if (a->d->is_normal) {
+    int j;
+    double dot = 0.0, sn = sqrt((double)a->d->n);
+    for (j = 0; j < p; j++) {
+      best->beta[j] = sn * best->beta[j] / a->d->x_norm[j];
+      dot += best->beta[j] * a->d->x_mean[j];
+    }
+    best->coef0 = a->d->data_type == 1 ? a->d->y_mean - dot : best->coef0 - dot;
+  }
+  free(beta_init);
+#undef GS_FIT
+}
+
+/* ------------------------------------------------------------------ driver */
+
+/* bessCpp, src/bess.cpp:37-214 (no screening) */
+int bess_oracle_run(const double *x, int n, int p, const double *y, const double *weight, int data_type,
+                    int is_normal, int algorithm_type, int model_type, int max_iter, int path_type,
+                    int is_warm_start, int ic_type, int is_cv, int K, const int *cv_fold_id, const int *sequence,
+                    int sequence_len, const double *lambda_seq, int lambda_len, int s_min, int s_max,
+                    const int *always_select, int always_len, double *beta_out, double *coef0_out,
+                    double *train_loss_out, double *ic_out) {
+  odata d;
+  oalg a;
+  ometric m;
+  opoint best;
+  double *xtx;
+  int i, j, k;
+  if (n < 1 || p < 1 || model_type < 1 || model_type > 4) return 1;
+  if (is_cv && (cv_fold_id == NULL || K < 2)) return 2;
+  if (path_type == 1) {
+    for (i = 0; i < sequence_len; i++)
+      if (sequence[i] < 0 || sequence[i] > p) return 3;
+    if (sequence_len < 1 || lambda_len < 1) return 3;
+  } else if (s_min < 0 || s_max > p || s_min > s_max) {
+    return 3;
+  }
+  t_meta.n = t_a.n = t_beta.n = t_coef0.n = t_loss.n = t_ic.n = 0;
+
+  d.n = n;
+  d.p = p;
+  d.data_type = data_type;
+  d.is_normal = is_normal;
+  d.x = (double *)malloc((size_t)n * (size_t)p * sizeof(double));
+  d.y = (double *)malloc((size_t)n * sizeof(double));
+  d.w = (double *)malloc((size_t)n * sizeof(double));
+  d.x_mean = (double *)calloc((size_t)p, sizeof(double));
+  d.x_norm = (double *)calloc((size_t)p, sizeof(double));
+  d.y_mean = 0.0;
+  for (i = 0; i < n; i++) {
+    for (j = 0; j < p; j++) d.x[(size_t)j * n + i] = x[(size_t)i * p + j];
+    d.y[i] = y[i];
+    d.w[i] = weight[i];
+  }
+  if (is_normal) data_normalize(&d);
+  if (model_type == 1) data_add_weight(&d);
+
+  g_full_rows = (int *)malloc((size_t)n * sizeof(int));
+  for (i = 0; i < n; i++) g_full_rows[i] = i;
+
+  memset(&a, 0, sizeof(a));
+  a.d = &d;
+  a.model_type = model_type;
+  a.algorithm_type = algorithm_type;
+  a.max_iter = max_iter;
+  a.warm_start = is_warm_start;
+  a.beta = (double *)calloc((size_t)p, sizeof(double));
+  a.beta_init = (double *)calloc((size_t)p, sizeof(double));
+  a.always = always_select;
+  a.n_always = always_len;
+
+  /* group_XTX on the full data, src/path.cpp:37 -> src/utilities.cpp:153-165 (LM only) */
+  xtx = (double *)calloc((size_t)p, sizeof(double));
+  if (model_type == 1)
+    for (j = 0; j < p; j++) {
+      double s = 0.0, *c = XC(&d, j);
+      for (i = 0; i < n; i++) s += c[i] * c[i];
+      xtx[j] = s;
+    }
+
+  memset(&m, 0, sizeof(m));
+  m.ic_type = ic_type;
+  m.is_cv = is_cv;
+  m.K = K;
+  if (is_cv) {
+    m.train = (int **)calloc((size_t)K, sizeof(int *));
+    m.test = (int **)calloc((size_t)K, sizeof(int *));
+    m.n_train = (int *)calloc((size_t)K, sizeof(int));
+    m.n_test = (int *)calloc((size_t)K, sizeof(int));
+    m.cv_init = (double **)calloc((size_t)K, sizeof(double *));
+    m.cv_xtx = (double **)calloc((size_t)K, sizeof(double *));
+    for (k = 0; k < K; k++) {
+      m.train[k] = (int *)malloc((size_t)n * sizeof(int));
+      m.test[k] = (int *)malloc((size_t)n * sizeof(int));
+      for (i = 0; i < n; i++) {
+        if (cv_fold_id[i] == k)
+          m.test[k][m.n_test[k]++] = i;
+        else
+          m.train[k][m.n_train[k]++] = i;
+      }
+      m.cv_init[k] = (double *)calloc((size_t)p, sizeof(double));
+      m.cv_xtx[k] = (double *)calloc((size_t)p, sizeof(double));
+      if (model_type == 1)
+        for (j = 0; j < p; j++) {
+          double s = 0.0, *c = XC(&d, j);
+          for (i = 0; i < m.n_train[k]; i++) s += c[m.train[k][i]] * c[m.train[k][i]];
+          m.cv_xtx[k][j] = s;
+        }
+    }
+  }
+
+  best.beta = (double *)calloc((size_t)p, sizeof(double));
+  if (path_type == 1)
+    seq_path(&a, &m, xtx, sequence, sequence_len, lambda_seq, lambda_len, &best);
+  else
+    gs_path(&a, &m, xtx, s_min, s_max, &best);
+
+  memcpy(beta_out, best.beta, (size_t)p * sizeof(double));
+  *coef0_out = best.coef0;
+  *train_loss_out = best.loss;
+  *ic_out = best.ic;
+
+  if (is_cv) {
+    for (k = 0; k < K; k++) {
+      free(m.train[k]);
+      free(m.test[k]);
+      free(m.cv_init[k]);
+      free(m.cv_xtx[k]);
+    }
+    free(m.train);
+    free(m.test);
+    free(m.n_train);
+    free(m.n_test);
+    free(m.cv_init);
+    free(m.cv_xtx);
+  }
+  free(best.beta);
+  free(xtx);
+  free(a.beta);
+  free(a.beta_init);
+  free(g_full_rows);
+  g_full_rows = NULL;
+  free(d.x);
+  free(d.y);
+  free(d.w);
+  free(d.x_mean);
+  free(d.x_norm);
+  return 0;
+}

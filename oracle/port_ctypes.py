@@ -1,0 +1,134 @@
+"""ctypes loader for oracle/libbess_oracle.so (the plain-C restatement, bess_oracle.c).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_LIB = os.path.join(_HERE, "libbess_oracle.so")
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I = ctypes.POINTER(ctypes.c_int)
+_i = ctypes.c_int
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "port"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(PORT_LIB):
+            build()
+        _lib = ctypes.CDLL(PORT_LIB)
+        _lib.bess_oracle_run.restype = _i
+        _lib.bess_oracle_run.argtypes = (
+            [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _I, _i]
+            + [_D, _D, _D, _D])
+        _lib.bess_oracle_trace_size.restype = _i
+        _lib.bess_oracle_trace_size.argtypes = [_i]
+        _lib.bess_oracle_trace_copy_int.restype = None
+        _lib.bess_oracle_trace_copy_int.argtypes = [_i, _I]
+        _lib.bess_oracle_trace_copy_double.restype = None
+        _lib.bess_oracle_trace_copy_double.argtypes = [_i, _D]
+        _lib.bess_oracle_max_k.restype = None
+        _lib.bess_oracle_max_k.argtypes = [_D, _i, _i, _I]
+        _lib.bess_oracle_sym_solve.restype = _i
+        _lib.bess_oracle_sym_solve.argtypes = [_D, _i, _D, _D]
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_D)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_I)
+
+
+def parse_trace(size_fn, copy_int, copy_double):
+    """Shared by the oracle and the compiled-reference harness: flat trace -> list of fits."""
+    def geti(which):
+        n = size_fn(which)
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        copy_int(which, _ip(a))
+        return a[:n]
+
+    def getd(which):
+        n = size_fn(which)
+        a = np.zeros(max(n, 1), dtype=np.float64)
+        copy_double(which, _dp(a))
+        return a[:n]
+
+    meta = geti(0).reshape(-1, 4)
+    a_flat = geti(1)
+    beta_flat = getd(2)
+    coef0_calls = getd(3)
+    fits = []
+    for c, (l, T0, train_n, off) in enumerate(meta):
+        if l == 1:
+            fits.append({"T0": int(T0), "train_n": int(train_n), "iters": [], "betas": [], "coef0s": []})
+        nxt = meta[c + 1][3] if c + 1 < len(meta) else a_flat.size
+        fits[-1]["iters"].append(a_flat[off:nxt].copy())
+        fits[-1]["betas"].append(beta_flat[off:nxt].copy())
+        fits[-1]["coef0s"].append(float(coef0_calls[c]))
+    return fits, getd(4), getd(5)
+
+
+def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, model_type=1, max_iter=20, path_type=1,
+          is_warm_start=True, ic_type=4, is_cv=False, K=5, cv_fold_id=None, sequence=(1,), lambda_seq=(0.0,),
+          s_min=1, s_max=1, g_index=None, always_select=()):
+    """Same signature and return value as oracle.ref_ctypes.trace."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n, p = x.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    weight = np.ones(n) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+    if g_index is not None and not np.array_equal(np.asarray(g_index), np.arange(p)):
+        raise ValueError("the oracle covers singleton groups only")
+    sequence = np.ascontiguousarray(sequence, dtype=np.int32)
+    lambda_seq = np.ascontiguousarray(lambda_seq, dtype=np.float64)
+    always_select = np.ascontiguousarray(always_select, dtype=np.int32)
+    fold_ptr = None
+    if cv_fold_id is not None:
+        cv_fold_id = np.ascontiguousarray(cv_fold_id, dtype=np.int32)
+        fold_ptr = _ip(cv_fold_id)
+    beta = np.zeros(p)
+    coef0 = np.zeros(1)
+    loss = np.zeros(1)
+    ic = np.zeros(1)
+    L = lib()
+    rc = L.bess_oracle_run(_dp(x), n, p, _dp(y), _dp(weight), data_type, int(is_normal), algorithm_type, model_type,
+                           max_iter, path_type, int(is_warm_start), ic_type, int(is_cv), K, fold_ptr, _ip(sequence),
+                           sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max, _ip(always_select),
+                           always_select.size, _dp(beta), _dp(coef0), _dp(loss), _dp(ic))
+    if rc != 0:
+        raise ValueError("bess_oracle_run rejected its arguments (code %d)" % rc)
+    fits, loss_calls, ic_calls = parse_trace(L.bess_oracle_trace_size, L.bess_oracle_trace_copy_int,
+                                             L.bess_oracle_trace_copy_double)
+    return {"beta": beta, "coef0": float(coef0[0]), "train_loss": float(loss[0]), "ic": float(ic[0]),
+            "fits": fits, "loss_calls": loss_calls, "ic_calls": ic_calls}
+
+
+def max_k(score, k):
+    score = np.ascontiguousarray(score, dtype=np.float64)
+    out = np.zeros(max(k, 1), dtype=np.int32)
+    lib().bess_oracle_max_k(_dp(score), score.size, k, _ip(out))
+    return out[:k]
+
+
+def sym_solve(a, b):
+    """a: k x k symmetric (lower triangle read), b: k."""
+    a = np.asfortranarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    k = b.size
+    x = np.zeros(max(k, 1))
+    lib().bess_oracle_sym_solve(a.ctypes.data_as(_D), k, _dp(b), _dp(x))
+    return x[:k]

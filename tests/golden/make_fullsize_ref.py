@@ -1,0 +1,82 @@
+"""Generate full-size golden vectors from the compiled reference (oracle/_ref/libbess_ref.so).
+
+Run once in the build container (it needs /root/reference to have been compiled by
+`make -C oracle ref`); takes hours of one CPU core and ~25 GB for config 2:
+
+    python tests/golden/make_fullsize_ref.py lm        # BASELINE configs[1], k = 1..200
+    python tests/golden/make_fullsize_ref.py logistic  # BASELINE configs[2], k = 1..100
+
+Output: tests/golden/fullsize_<name>.npz holding, for every candidate of the warm-start
+chain, the active set of every PDAS iteration, the fitted coefficients, the loss and the
+information criterion.  Inputs are NOT stored: they are regenerated bit-identically from
+bess_amd/synth.py (numpy PCG64 with a fixed seed).
+"""
+import importlib.util
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+synth = _load("synth", os.path.join(ROOT, "bess_amd", "synth.py"))
+ref = _load("ref_ctypes", os.path.join(ROOT, "oracle", "ref_ctypes.py"))
+
+
+def pack(t, extra):
+    fits = t["fits"]
+    out = dict(extra)
+    out["best_beta_idx"] = np.nonzero(t["beta"])[0].astype(np.int32)
+    out["best_beta_val"] = t["beta"][np.nonzero(t["beta"])[0]]
+    out["best_coef0"] = t["coef0"]
+    out["best_train_loss"] = t["train_loss"]
+    out["best_ic"] = t["ic"]
+    out["loss_calls"] = t["loss_calls"]
+    out["ic_calls"] = t["ic_calls"]
+    out["fit_T0"] = np.array([f["T0"] for f in fits], dtype=np.int32)
+    out["fit_train_n"] = np.array([f["train_n"] for f in fits], dtype=np.int32)
+    out["fit_iters"] = np.array([len(f["iters"]) for f in fits], dtype=np.int32)
+    out["A_flat"] = np.concatenate([a for f in fits for a in f["iters"]]).astype(np.int32)
+    out["beta_flat"] = np.concatenate([b for f in fits for b in f["betas"]])
+    out["coef0_flat"] = np.array([c for f in fits for c in f["coef0s"]])
+    return out
+
+
+def main():
+    which = sys.argv[1]
+    kmax = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    small = os.environ.get("BESS_GOLDEN_SMALL")  # smoke-test the script itself on a tiny shape
+    if which == "lm":
+        kmax = kmax or 200
+        X, y, support, beta = synth.make_lm(2000, 500, 10) if small else synth.make_lm()
+        t0 = time.time()
+        t = ref.trace(X, y, data_type=1, model_type=1, ic_type=3, sequence=np.arange(1, kmax + 1))
+        extra = {"n": X.shape[0], "p": X.shape[1], "seed": synth.SEED_LM, "true_support": support, "ic_type": 3}
+    elif which == "logistic":
+        kmax = kmax or 100
+        X, y, support, beta = synth.make_logistic(2000, 500, 10) if small else synth.make_logistic()
+        t0 = time.time()
+        t = ref.trace(X, y, data_type=2, model_type=2, ic_type=3, sequence=np.arange(1, kmax + 1))
+        extra = {"n": X.shape[0], "p": X.shape[1], "seed": synth.SEED_LOGISTIC, "true_support": support, "ic_type": 3}
+    else:
+        raise SystemExit("unknown config " + which)
+    extra["ref_wall_seconds"] = time.time() - t0
+    extra["kmax"] = kmax
+    out = "/tmp/small_%s.npz" % which if small else os.path.join(HERE, "fullsize_%s.npz" % which)
+    np.savez_compressed(out, **pack(t, extra))
+    print("done", which, "in", extra["ref_wall_seconds"], "s")
+
+
+if __name__ == "__main__":
+    main()
