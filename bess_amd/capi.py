@@ -1,0 +1,341 @@
+"""ctypes binding of libbessx.so (the C ABI declared in include/bessx.h).
+
+This is plumbing only: every function forwards to the HIP library.  There is no Python or
+NumPy fallback -- if the library is missing or no GPU is visible the call raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbessx.so")
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I = ctypes.POINTER(ctypes.c_int)
+_i = ctypes.c_int
+_d = ctypes.c_double
+_ll = ctypes.c_longlong
+_vp = ctypes.c_void_p
+
+# names every build of libbessx.so must export (checked by tests/test_abi.py against include/bessx.h)
+SYMBOLS = [
+    "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_session_create",
+    "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_sequential_path", "bessx_session_gs_path",
+    "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
+    "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
+    "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
+    "bessx_op_chol_solve", "bessx_op_normalize", "bessx_op_stream_copy_gbps",
+]
+
+
+class BessxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libbessx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Problem(ctypes.Structure):
+    _fields_ = [("n", _i), ("p", _i), ("x", _D), ("x_col_major", _i), ("y", _D), ("weight", _D), ("data_type", _i),
+                ("is_normal", _i), ("model_type", _i), ("algorithm_type", _i), ("max_iter", _i),
+                ("is_warm_start", _i), ("always_select", _I), ("always_select_len", _i), ("device", _i)]
+
+
+class PathResult(ctypes.Structure):
+    _fields_ = [("beta", _D), ("coef0", _d), ("train_loss", _d), ("ic", _d), ("lambda_", _d), ("best_T0", _i),
+                ("best_iters", _i), ("capacity", _i), ("n_candidates", _i), ("cand_T0", _I), ("cand_lambda", _D),
+                ("cand_iters", _I), ("cand_train_loss", _D), ("cand_ic", _D), ("cand_coef0", _D),
+                ("cand_support", _I), ("cand_beta", _D), ("max_T0", _i), ("device_seconds", _d), ("n_fits", _ll),
+                ("n_pdas_iters", _ll)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libbessx.so; raises ImportError loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "bess_amd: %s is missing. Build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C bess_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.bessx_last_error.restype = ctypes.c_char_p
+        L.bessx_device_info.argtypes = [ctypes.c_char_p, _i]
+        L.bessx_pywrap_bess.argtypes = (
+            [_D, _i, _i, _D, _i, _i, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _i, _D, _i, _I, _i, _D, _i]
+            + [_i, _i, _i, _d, _d, _d, _i, _i, _i, _i, _I, _i, _d]
+            + [_D, _i, _D, _i, _D, _i, _D, _i, _D, _D, _i, _D, _i, _D, _i, _I, _i, _I])
+        L.bessx_session_create.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(Problem)]
+        L.bessx_session_destroy.argtypes = [_vp]
+        L.bessx_session_destroy.restype = None
+        L.bessx_session_set_cv.argtypes = [_vp, _i, _I, ctypes.c_uint]
+        L.bessx_session_sequential_path.argtypes = [_vp, _I, _i, _D, _i, _i, _i, ctypes.POINTER(PathResult)]
+        L.bessx_session_gs_path.argtypes = [_vp, _i, _i, _i, _i, ctypes.POINTER(PathResult)]
+        L.bessx_session_trace_enable.argtypes = [_vp, _i]
+        L.bessx_session_trace_size.argtypes = [_vp, _i]
+        L.bessx_session_trace_copy_int.argtypes = [_vp, _i, _I]
+        L.bessx_session_trace_copy_double.argtypes = [_vp, _i, _D]
+        L.bessx_session_get_normalization.argtypes = [_vp, _D, _D, _D]
+        L.bessx_session_score_pass_stats.argtypes = [_vp, _i, _D, ctypes.POINTER(_ll), _D]
+        L.bessx_session_enable_kernel_timing.argtypes = [_vp, _i]
+        L.bessx_session_fit.argtypes = [_vp, _i, _d, _i, _I, _D, _i, _d, _I, _D, _D, _I, _D, _D]
+        L.bessx_op_xtv.argtypes = [_D, _i, _i, _i, _D, _D, _D, _D]
+        L.bessx_op_topk.argtypes = [_D, _i, _i, _I]
+        L.bessx_op_gram.argtypes = [_D, _i, _i, _i, _I, _i, _D, _D]
+        L.bessx_op_chol_solve.argtypes = [_D, _i, _D, _D]
+        L.bessx_op_normalize.argtypes = [_D, _i, _i, _D, _D, _i, _i, _i, _D, _D, _D]
+        L.bessx_op_stream_copy_gbps.argtypes = [_ll, _i, _D]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BessxError(rc, lib().bessx_last_error().decode("utf-8", "replace"))
+
+
+def _dp(a):
+    return a.ctypes.data_as(_D) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(_I) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def device_info():
+    buf = ctypes.create_string_buffer(512)
+    _check(lib().bessx_device_info(buf, 512))
+    return buf.value.decode()
+
+
+def pywrap_bess(x, y, data_type, weight, is_normal, algorithm_type, model_type, max_iter, exchange_num, path_type,
+                is_warm_start, ic_type, is_cv, K, g_index, state, sequence, lambda_sequence, s_min, s_max, K_max,
+                epsilon, lambda_min, lambda_max, n_lambda, is_screening, screening_size, powell_path, always_select,
+                tao, beta_out_len, coef0_out_len=1, train_loss_out_len=1, ic_out_len=1, aic_out_len=1,
+                bic_out_len=1, gic_out_len=1, A_out_len=None):
+    """Same 38 positional arguments and 10-tuple result as the reference's SWIG wrapper
+    (python/src/bess.i:17-30, called at python/bess/linear.py:360-375):
+    (beta, coef0, train_loss, ic, nullloss, aic, bic, gic, A_out, l_out)."""
+    x = _f64(x)
+    n, p = x.shape
+    y = _f64(y).reshape(-1)
+    weight = _f64(weight)
+    state = _f64(state)
+    g_index = _i32(g_index)
+    sequence = _i32(sequence)
+    lambda_sequence = _f64(lambda_sequence)
+    always_select = _i32(always_select)
+    if A_out_len is None:
+        A_out_len = p
+    beta = np.zeros(beta_out_len)
+    coef0, loss, ic, nullloss = np.zeros(coef0_out_len), np.zeros(train_loss_out_len), np.zeros(ic_out_len), np.zeros(1)
+    aic, bic, gic = np.zeros(aic_out_len), np.zeros(bic_out_len), np.zeros(gic_out_len)
+    a_out = np.zeros(A_out_len, dtype=np.int32)
+    l_out = np.zeros(1, dtype=np.int32)
+    _check(lib().bessx_pywrap_bess(
+        _dp(x), n, p, _dp(y), y.size, data_type, _dp(weight), weight.size, int(is_normal), algorithm_type, model_type,
+        max_iter, exchange_num, path_type, int(is_warm_start), ic_type, int(is_cv), K, _ip(g_index), g_index.size,
+        _dp(state), state.size, _ip(sequence), sequence.size, _dp(lambda_sequence), lambda_sequence.size, s_min, s_max,
+        K_max, epsilon, lambda_min, lambda_max, n_lambda, int(is_screening), screening_size, powell_path,
+        _ip(always_select), always_select.size, tao, _dp(beta), beta.size, _dp(coef0), coef0.size, _dp(loss),
+        loss.size, _dp(ic), ic.size, _dp(nullloss), _dp(aic), aic.size, _dp(bic), bic.size, _dp(gic), gic.size,
+        _ip(a_out), a_out.size, _ip(l_out)))
+    return beta, coef0, loss, ic, float(nullloss[0]), aic, bic, gic, a_out, int(l_out[0])
+
+
+class Session:
+    """The state bessCpp builds (Data + Algorithm + Metric, src/bess.cpp:61-165), resident in HBM."""
+
+    def __init__(self, x, y, weight=None, data_type=1, is_normal=True, model_type=1, algorithm_type=1, max_iter=20,
+                 is_warm_start=True, always_select=(), x_col_major=False, device=-1):
+        x = np.asfortranarray(x, dtype=np.float64) if x_col_major else _f64(x)
+        self.n, self.p = x.shape
+        y = _f64(y).reshape(-1)
+        if y.size != self.n:
+            raise ValueError("X.shape(0) should be equal to y.size")
+        w = None if weight is None else _f64(weight)
+        al = _i32(always_select)
+        pb = Problem(self.n, self.p, _dp(x), int(x_col_major), _dp(y), _dp(w), data_type, int(is_normal), model_type,
+                     algorithm_type, max_iter, int(is_warm_start), _ip(al), al.size, device)
+        h = _vp()
+        _check(lib().bessx_session_create(ctypes.byref(h), ctypes.byref(pb)))
+        self._h = h
+        self.K = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bessx_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_cv(self, K, fold_id=None, seed=123):
+        f = None if fold_id is None else _i32(fold_id)
+        _check(lib().bessx_session_set_cv(self._h, K, _ip(f), seed))
+        self.K = K
+
+    def trace_enable(self, on=True):
+        _check(lib().bessx_session_trace_enable(self._h, int(on)))
+
+    def enable_kernel_timing(self, on=True):
+        _check(lib().bessx_session_enable_kernel_timing(self._h, int(on)))
+
+    def score_pass_stats(self, reset=False):
+        sec, nb, cnt = _d(0), _d(0), _ll(0)
+        _check(lib().bessx_session_score_pass_stats(self._h, int(reset), ctypes.byref(sec), ctypes.byref(cnt),
+                                                    ctypes.byref(nb)))
+        return {"seconds": sec.value, "launches": cnt.value, "algorithmic_bytes": nb.value}
+
+    def normalization(self):
+        xm, xn, ym = np.zeros(self.p), np.zeros(self.p), _d(0)
+        _check(lib().bessx_session_get_normalization(self._h, _dp(xm), _dp(xn), ctypes.byref(ym)))
+        return xm, xn, ym.value
+
+    def _run(self, call, capacity, max_T0):
+        beta = np.zeros(self.p)
+        arr = {
+            "cand_T0": np.zeros(capacity, dtype=np.int32), "cand_lambda": np.zeros(capacity),
+            "cand_iters": np.zeros(capacity, dtype=np.int32), "cand_train_loss": np.zeros(capacity),
+            "cand_ic": np.zeros(capacity), "cand_coef0": np.zeros(capacity),
+            "cand_support": np.full((capacity, max_T0), -1, dtype=np.int32), "cand_beta": np.zeros((capacity, max_T0)),
+        }
+        res = PathResult()
+        res.beta = _dp(beta)
+        res.capacity = capacity
+        res.max_T0 = max_T0
+        for k, v in arr.items():
+            setattr(res, k, _ip(v) if v.dtype == np.int32 else _dp(v))
+        _check(call(ctypes.byref(res)))
+        nc = min(res.n_candidates, capacity)
+        out = {"beta": beta, "coef0": res.coef0, "train_loss": res.train_loss, "ic": res.ic, "lambda": res.lambda_,
+               "best_T0": res.best_T0, "best_iters": res.best_iters, "n_candidates": res.n_candidates,
+               "device_seconds": res.device_seconds, "n_fits": res.n_fits, "n_pdas_iters": res.n_pdas_iters}
+        for k, v in arr.items():
+            out[k] = v[:nc]
+        out["trace"] = self._trace()
+        return out
+
+    def sequential_path(self, sequence, lambda_seq=(0.0,), ic_type=4, is_cv=False):
+        seq = _i32(sequence)
+        lam = _f64(lambda_seq)
+        L = lib()
+        return self._run(lambda r: L.bessx_session_sequential_path(self._h, _ip(seq), seq.size, _dp(lam), lam.size,
+                                                                   ic_type, int(is_cv), r),
+                         seq.size * lam.size, int(seq.max()) if seq.size else 1)
+
+    def gs_path(self, s_min, s_max, ic_type=4, is_cv=False):
+        L = lib()
+        return self._run(lambda r: L.bessx_session_gs_path(self._h, s_min, s_max, ic_type, int(is_cv), r),
+                         2 * (s_max - s_min + 1) + 64, max(s_max, 1))
+
+    def fit(self, T0, lam=0.0, fold=-1, init_idx=(), init_val=(), init_coef0=0.0):
+        ii, iv = _i32(init_idx), _f64(init_val)
+        sup, b = np.zeros(T0, dtype=np.int32), np.zeros(T0)
+        c0, tr, te, it = _d(0), _d(0), _d(0), _i(0)
+        _check(lib().bessx_session_fit(self._h, T0, lam, fold, _ip(ii), _dp(iv), ii.size, init_coef0, _ip(sup),
+                                       _dp(b), ctypes.byref(c0), ctypes.byref(it), ctypes.byref(tr),
+                                       ctypes.byref(te)))
+        return {"support": sup, "beta": b, "coef0": c0.value, "iters": it.value, "train_loss": tr.value,
+                "test_loss": te.value}
+
+    def _trace(self):
+        L = lib()
+
+        def geti(which):
+            n = L.bessx_session_trace_size(self._h, which)
+            a = np.zeros(max(n, 1), dtype=np.int32)
+            _check(L.bessx_session_trace_copy_int(self._h, which, _ip(a)))
+            return a[:n]
+
+        def getd(which):
+            n = L.bessx_session_trace_size(self._h, which)
+            a = np.zeros(max(n, 1))
+            _check(L.bessx_session_trace_copy_double(self._h, which, _dp(a)))
+            return a[:n]
+
+        meta = geti(0).reshape(-1, 4)
+        if meta.shape[0] == 0:
+            return None
+        a_flat, beta_flat, coef0_calls = geti(1), getd(2), getd(3)
+        fits = []
+        for c, (l, T0, train_n, off) in enumerate(meta):
+            if l == 1:
+                fits.append({"T0": int(T0), "train_n": int(train_n), "iters": [], "betas": [], "coef0s": []})
+            nxt = meta[c + 1][3] if c + 1 < len(meta) else a_flat.size
+            fits[-1]["iters"].append(a_flat[off:nxt].copy())
+            fits[-1]["betas"].append(beta_flat[off:nxt].copy())
+            fits[-1]["coef0s"].append(float(coef0_calls[c]))
+        return {"fits": fits, "loss_calls": getd(4), "ic_calls": getd(5)}
+
+
+# ---- single-kernel entry points (parity tests) -------------------------------------------------
+def op_xtv(x, v, v2=None):
+    x = np.asfortranarray(x, dtype=np.float64)
+    n, p = x.shape
+    v = _f64(v)
+    out, out2 = np.zeros(p), np.zeros(p)
+    v2a = None if v2 is None else _f64(v2)
+    _check(lib().bessx_op_xtv(_dp(x), n, p, n, _dp(v), _dp(v2a), _dp(out), _dp(out2)))
+    return (out, out2) if v2 is not None else out
+
+
+def op_topk(score, k):
+    score = _f64(score)
+    out = np.zeros(max(k, 1), dtype=np.int32)
+    _check(lib().bessx_op_topk(_dp(score), score.size, k, _ip(out)))
+    return out[:k]
+
+
+def op_gram(x, cols, w=None):
+    x = np.asfortranarray(x, dtype=np.float64)
+    n, p = x.shape
+    cols = _i32(cols)
+    wa = None if w is None else _f64(w)
+    out = np.zeros((cols.size, cols.size), order="F")
+    _check(lib().bessx_op_gram(_dp(x), n, p, n, _ip(cols), cols.size, _dp(wa), _dp(out)))
+    return np.array(out)
+
+
+def op_chol_solve(a, b):
+    a = np.asfortranarray(a, dtype=np.float64)
+    b = _f64(b)
+    sol = np.zeros(b.size)
+    _check(lib().bessx_op_chol_solve(_dp(a), b.size, _dp(b), _dp(sol)))
+    return sol
+
+
+def op_normalize(x, y, weight, data_type, is_normal=True, add_weight=False):
+    x = np.array(x, dtype=np.float64, order="F")
+    n, p = x.shape
+    y = np.array(y, dtype=np.float64)
+    w = _f64(weight)
+    xm, xn, ym = np.zeros(p), np.zeros(p), _d(0)
+    _check(lib().bessx_op_normalize(_dp(x), n, p, _dp(y), _dp(w), data_type, int(is_normal), int(add_weight),
+                                    _dp(xm), _dp(xn), ctypes.byref(ym)))
+    return x, y, xm, xn, ym.value
+
+
+def op_stream_copy_gbps(nbytes=1 << 30, repeats=10):
+    g = _d(0)
+    _check(lib().bessx_op_stream_copy_gbps(nbytes, repeats, ctypes.byref(g)))
+    return g.value

@@ -1,0 +1,66 @@
+// bessx_dev.h -- internal interface between the HIP kernels (bessx_kernels.hip) and the host-side
+// solver (bessx_host.cpp).  Not part of the C ABI (that is include/bessx.h).
+#ifndef BESSX_DEV_H
+#define BESSX_DEV_H
+
+#include <hip/hip_runtime.h>
+
+namespace bessx {
+
+// Device-resident control block of one Algorithm::fit (src/Algorithm.h:113-171).  The host enqueues
+// PDAS iteration "slots" speculatively; every kernel of slot s runs only if l == s-1 && !done, so
+// slots issued after convergence fall through in a few microseconds without a host round trip.
+struct FitCtrl {
+  int done;        // active set repeated: Algorithm::fit returned
+  int l;           // PDAS iterations committed so far (Algorithm::l)
+  int T0;          // sparsity level of this fit
+  int k_cur;       // support size of the current beta
+  int irls_done;   // GLM sub-model fit converged (per PDAS iteration)
+  int irls_steps;  // IRLS / Newton steps taken in the current PDAS iteration
+  int info;        // non-zero: a k x k solve produced a non-finite value
+  int pad_;
+  double coef0;    // current intercept
+  double ll0;      // GLM: log-likelihood of the previous iterate
+};
+
+constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
+struct GramTask {
+  int I, J0, nJ, pad_;
+};
+
+hipError_t launch_transpose_in(const double *src, int rows, int p, double *X, long ld, long r0, hipStream_t st);
+hipError_t launch_normalize(double *X, long ld, int n, int p, double *y, const double *w, int data_type,
+                            int is_normal, int add_weight, double *x_mean, double *x_norm, double *y_mean,
+                            hipStream_t st);
+hipError_t launch_xtv(const double *X, long ld, int p, int U, const double *v, const double *v2, double *part,
+                      double *part2, const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
+                        const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
+                        double *bd, const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
+                       hipStream_t st);
+bool topk_supported(int len, int k);
+hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
+                       int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
+                       double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);
+hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
+                       const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
+                       hipStream_t st);
+hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
+                            double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
+                            hipStream_t st);
+hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
+                         int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
+                         double *hist_coef0, int hist_stride, hipStream_t st);
+hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
+                           const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
+                           double *sse, hipStream_t st);
+hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
+hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
+hipError_t launch_fill(double *a, long n, double v, hipStream_t st);
+hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int rhs_col, int *cols,
+                            const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_copy(const double *src, double *dst, long n, hipStream_t st);
+
+}  // namespace bessx
+#endif

@@ -1,0 +1,1313 @@
+// bessx_host.cpp -- host side of libbessx.so: the session (Data + Algorithm + Metric of the reference's
+// bessCpp, resident on the GPU), Algorithm::fit as speculatively enqueued device iterations, the
+// path drivers, and the extern "C" ABI of include/bessx.h.
+//
+// The control flow mirrors the reference so that the two can be read side by side
+// (/root/reference): Algorithm::fit src/Algorithm.h:113-171, Metric::{train_loss,test_loss,ic}
+// src/Metric.h:138-676, sequential_path / gs_path src/path.cpp:25-389, bessCpp src/bess.cpp:37-214.
+// All arithmetic on n- or p-sized data happens in the HIP kernels of bessx_kernels.hip; nothing here
+// falls back to a CPU computation.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/bessx.h"
+#include "bessx_dev.h"
+
+namespace bessx {
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPX(expr)                                                                                  \
+  do {                                                                                              \
+    hipError_t e__ = (expr);                                                                        \
+    if (e__ != hipSuccess)                                                                          \
+      return fail(BESSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__) + " (" __FILE__ \
+                                                                                      ":" +          \
+                                     std::to_string(__LINE__) + ")");                               \
+  } while (0)
+
+struct SparseVec {
+  std::vector<int> idx;
+  std::vector<double> val;
+  void clear() {
+    idx.clear();
+    val.clear();
+  }
+};
+
+struct Trace {
+  bool on = false;
+  std::vector<int> meta, a_flat;
+  std::vector<double> beta_flat, coef0_calls, loss_calls, ic_calls;
+  void clear() {
+    meta.clear();
+    a_flat.clear();
+    beta_flat.clear();
+    coef0_calls.clear();
+    loss_calls.clear();
+    ic_calls.clear();
+  }
+};
+
+static constexpr int T0_CAP = 254;  // m + 1 <= 256 in k_chol, with room for an intercept
+
+}  // namespace bessx
+
+using namespace bessx;
+
+struct bessx_session {
+  // problem
+  int n = 0, p = 0;
+  long ld = 0;
+  int U = 1, nrb = 0;
+  int data_type = 1, is_normal = 1, model_type = 1, algorithm_type = 1, max_iter = 20, warm_start = 1;
+  int device = 0;
+  hipStream_t st = nullptr;
+  // device data
+  double *X = nullptr, *y = nullptr, *w = nullptr, *aux = nullptr;
+  double *x_mean = nullptr, *x_norm = nullptr, *y_mean_d = nullptr;
+  unsigned char *always = nullptr;
+  // row sets: index 0 = all rows, 1..K = CV training rows of fold k-1
+  std::vector<double *> mask, xtx, xty;
+  std::vector<int> n_train;
+  int K = 0;
+  // work space
+  double *r = nullptr, *part = nullptr, *part2 = nullptr, *bd = nullptr, *beta_dense = nullptr, *sol = nullptr;
+  double *tmpv = nullptr;
+  int *A_new = nullptr, *cand = nullptr, *hist = nullptr, *gcols = nullptr, *info = nullptr;
+  double *hist_beta = nullptr, *hist_coef0 = nullptr;
+  int hist_stride = T0_CAP + 2;
+  GramTask *gtasks = nullptr;
+  std::vector<int> gtask_off, gtask_cnt;  // per mt
+  double *gpart = nullptr, *Gt = nullptr;
+  size_t gpart_elems = 0;
+  int *init_idx_d = nullptr;
+  double *init_val_d = nullptr;
+  // result block: one D2H copy per host round trip
+  unsigned char *resblk = nullptr;
+  size_t res_bytes = 0;
+  FitCtrl *ctrl = nullptr;
+  double *sse = nullptr, *b_cur = nullptr;
+  int *A_cur = nullptr;
+  int n_sse_blk = 0;
+  unsigned char *res_h = nullptr;    // pinned
+  unsigned char *stage_h = nullptr;  // pinned staging for init vectors
+  // host statistics
+  std::vector<double> x_mean_h, x_norm_h;
+  double y_mean_h = 0.0;
+  // Algorithm state (reference member names in comments)
+  SparseVec beta;                 // Algorithm::beta
+  double coef0 = 0.0;             // Algorithm::coef0
+  SparseVec beta_init;            // Algorithm::beta_init
+  double coef0_init = 0.0;        // Algorithm::coef0_init
+  int sparsity_level = 0;         // Algorithm::sparsity_level
+  double lambda_level = 0.0;      // Algorithm::lambda_level
+  int cur_rows = 0;               // Algorithm::train_mask (0 = all rows, k+1 = fold k)
+  int l = 0;                      // Algorithm::l
+  double sse_train = 0.0, sse_test = 0.0;  // of the last fit
+  std::vector<SparseVec> cv_init; // Metric::cv_initial_model_param
+  std::vector<int> n_test;
+  // instrumentation
+  Trace trace;
+  int metric_depth = 0;
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  double k1_seconds = 0.0, k1_bytes = 0.0;
+  long long k1_launches = 0;
+  long long n_fits = 0, n_iters = 0;
+};
+
+namespace bessx {
+
+template <class T>
+static hipError_t dmalloc(T **ptr, size_t count) {
+  return hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(count, 1) * sizeof(T));
+}
+
+static void session_free(bessx_session *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->st) (void)hipStreamSynchronize(s->st);
+  auto F = [](void *q) {
+    if (q) (void)hipFree(q);
+  };
+  F(s->X);
+  F(s->y);
+  F(s->w);
+  F(s->aux);
+  F(s->x_mean);
+  F(s->x_norm);
+  F(s->y_mean_d);
+  F(s->always);
+  for (auto q : s->mask) F(q);
+  for (auto q : s->xtx) F(q);
+  for (auto q : s->xty) F(q);
+  F(s->r);
+  F(s->part);
+  F(s->part2);
+  F(s->bd);
+  F(s->beta_dense);
+  F(s->sol);
+  F(s->tmpv);
+  F(s->A_new);
+  F(s->cand);
+  F(s->hist);
+  F(s->gcols);
+  F(s->info);
+  F(s->hist_beta);
+  F(s->hist_coef0);
+  F(s->gtasks);
+  F(s->gpart);
+  F(s->Gt);
+  F(s->init_idx_d);
+  F(s->init_val_d);
+  F(s->resblk);
+  if (s->res_h) (void)hipHostFree(s->res_h);
+  if (s->stage_h) (void)hipHostFree(s->stage_h);
+  for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+  if (s->st) (void)hipStreamDestroy(s->st);
+  delete s;
+}
+
+// timing of the dominant kernel: event pairs on the session stream, resolved lazily
+static int k1_begin(bessx_session *s, hipEvent_t *a, hipEvent_t *b) {
+  if (!s->timing) return 0;
+  if (s->ev_used + 2 > s->ev_pool.size()) {
+    for (int i = 0; i < 64; i++) {
+      hipEvent_t e;
+      HIPX(hipEventCreate(&e));
+      s->ev_pool.push_back(e);
+    }
+  }
+  *a = s->ev_pool[s->ev_used++];
+  *b = s->ev_pool[s->ev_used++];
+  HIPX(hipEventRecord(*a, s->st));
+  return 0;
+}
+
+// after a stream synchronisation: fold the recorded pairs into the statistics.  A pair whose
+// kernel fell through its gate (a speculative slot after convergence) is a real launch of
+// near-zero work; it is excluded by the `counted` list the caller keeps.
+static int k1_collect(bessx_session *s, const std::vector<std::pair<size_t, bool>> &pairs) {
+  if (!s->timing) return 0;
+  for (auto &pr : pairs) {
+    if (!pr.second) continue;
+    float ms = 0.f;
+    HIPX(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.first + 1]));
+    s->k1_seconds += (double)ms * 1e-3;
+    s->k1_launches += 1;
+    s->k1_bytes += 8.0 * (double)s->n * (double)s->p;
+  }
+  s->ev_used = 0;
+  return 0;
+}
+
+static void build_gram_tasks(int mt, std::vector<GramTask> &out) {
+  for (int I = 0; I < mt; I++) {
+    int J = 0, left = I + 1;
+    for (int run = GRAM_JC; run >= 1; run >>= 1)
+      while (left >= run) {
+        out.push_back(GramTask{I, J, run, 0});
+        J += run;
+        left -= run;
+      }
+  }
+}
+
+static void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab) {
+  long target = 4096;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2 waves x 2
+  long ns = std::max<long>(1, target / std::max(ntask, 1));
+  ns = std::min<long>(ns, std::max<long>(1, s->ld / 64));
+  long rps = (s->ld + ns - 1) / ns;
+  rps = (rps + 15) / 16 * 16;
+  ns = (s->ld + rps - 1) / rps;
+  *rows_per_slab = (int)rps;
+  *nslab = (int)ns;
+}
+
+// upload x (row- or column-major host memory) into the padded column-major device matrix
+static int upload_x(bessx_session *s, const double *x, int col_major) {
+  const int n = s->n, p = s->p;
+  HIPX(hipMemsetAsync(s->X, 0, (size_t)s->ld * p * sizeof(double), s->st));
+  if (col_major) {
+    HIPX(hipMemcpy2DAsync(s->X, (size_t)s->ld * sizeof(double), x, (size_t)n * sizeof(double),
+                          (size_t)n * sizeof(double), (size_t)p, hipMemcpyHostToDevice, s->st));
+    HIPX(hipStreamSynchronize(s->st));
+    return 0;
+  }
+  // row-major: stage chunks of rows and transpose on the device
+  size_t chunk_rows = std::max<size_t>(64, ((size_t)256 << 20) / ((size_t)p * sizeof(double)));
+  chunk_rows = std::min<size_t>(chunk_rows, (size_t)n);
+  double *stage = nullptr;
+  HIPX(dmalloc(&stage, chunk_rows * (size_t)p));
+  for (size_t r0 = 0; r0 < (size_t)n; r0 += chunk_rows) {
+    size_t rows = std::min(chunk_rows, (size_t)n - r0);
+    hipError_t e = hipMemcpyAsync(stage, x + r0 * (size_t)p, rows * (size_t)p * sizeof(double),
+                                  hipMemcpyHostToDevice, s->st);
+    if (e == hipSuccess) e = launch_transpose_in(stage, (int)rows, p, s->X, s->ld, (long)r0, s->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+    if (e != hipSuccess) {
+      (void)hipFree(stage);
+      return fail(BESSX_ERR_HIP, std::string("upload_x: ") + hipGetErrorString(e));
+    }
+  }
+  HIPX(hipFree(stage));
+  return 0;
+}
+
+// X^T (m*y) and column sums of squares on a row set (group_XTX for 1x1 groups,
+// src/utilities.cpp:153-165 and src/Metric.h:108-129): one pass of the two-accumulator K1 kernel.
+static int prepare_rowset(bessx_session *s, int rs) {
+  const double *m = s->mask[rs];
+  // tmpv = m*y (or y), v2 = m (or ones on data rows = aux column 1)
+  if (launch_vec_mul(s->y, m, s->ld, s->tmpv, s->st) != hipSuccess) return fail(BESSX_ERR_HIP, "vec_mul");
+  const double *v2 = m ? m : s->aux + s->ld;
+  hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->tmpv, v2, s->part, s->part2, nullptr, 0, s->st);
+  if (e == hipSuccess) e = launch_part_sum(s->part, s->nrb, s->p, s->xty[rs], s->st);
+  if (e == hipSuccess) e = launch_part_sum(s->part2, s->nrb, s->p, s->xtx[rs], s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("prepare_rowset: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// Algorithm::fit (src/Algorithm.h:113-171), LM: GroupPdasLm::get_A / primary_model_fit (:1097-1135)
+// --------------------------------------------------------------------------------------------
+static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs,
+                           std::vector<std::pair<size_t, bool>> &k1_pairs) {
+  const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
+  const int ntask = s->gtask_cnt[mt], ntiles = mt * (mt + 1) / 2;
+  int rps, nslab;
+  gram_geometry(s, ntask, &rps, &nslab);
+  if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (int rc = k1_begin(s, &ea, &eb)) return rc;
+  hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->r, nullptr, s->part, nullptr, s->ctrl, slot, s->st);
+  if (s->timing && e == hipSuccess) {
+    e = hipEventRecord(eb, s->st);
+    k1_pairs.push_back({s->ev_used - 2, false});
+  }
+  if (e == hipSuccess)
+    e = launch_score(s->part, nullptr, s->nrb, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
+                     s->always, s->bd, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->st);
+  if (e == hipSuccess)
+    e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, s->gtasks + s->gtask_off[mt], ntask, nslab,
+                    s->gpart, ntiles, s->Gt, s->ctrl, slot, 0, s->st);
+  if (e == hipSuccess)
+    e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
+  if (e == hipSuccess)
+    e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+                      s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+  if (e == hipSuccess)
+    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r, s->sse,
+                        s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int read_results(bessx_session *s) {
+  HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
+  HIPX(hipStreamSynchronize(s->st));
+  return 0;
+}
+
+// One Algorithm::fit with the state set by the update_* style members of the session.
+static int algorithm_fit(bessx_session *s) {
+  const int T0 = s->sparsity_level, rs = s->cur_rows;
+  const double lambda = s->lambda_level;
+  if (T0 < 1 || T0 > std::min(s->p, T0_CAP))
+    return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, min(p, " +
+                                   std::to_string(T0_CAP) + ")]");
+  if (!topk_supported(s->p, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: p too large for this sparsity level");
+  if (s->model_type != 1) return fail(BESSX_ERR_UNSUPPORTED, "model_type " + std::to_string(s->model_type) + " is not built yet");
+  // warm start: this->beta = beta_init; this->coef0 = coef0_init (src/Algorithm.h:147-148)
+  const int k_init = (int)s->beta_init.idx.size();
+  if (k_init > T0_CAP) return fail(BESSX_ERR_ARG, "initial support too large");
+  int *st_idx = reinterpret_cast<int *>(s->stage_h);
+  double *st_val = reinterpret_cast<double *>(s->stage_h + 4096);
+  for (int i = 0; i < k_init; i++) {
+    st_idx[i] = s->beta_init.idx[i];
+    st_val[i] = s->beta_init.val[i];
+  }
+  if (k_init) {
+    HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
+  }
+  hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur,
+                                  s->b_cur, s->beta_dense, s->p, s->hist, s->st);
+  if (e == hipSuccess)
+    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r, s->sse, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("fit begin: ") + hipGetErrorString(e));
+
+  const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
+  int slot = 1, batch = 3;
+  std::vector<std::pair<size_t, bool>> k1_pairs;
+  while (true) {
+    int first = slot;
+    for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
+      if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, k1_pairs)) return rc;
+    if (int rc = read_results(s)) return rc;
+    // slots first..l really ran K1; later ones fell through their gate
+    for (size_t i = 0; i < k1_pairs.size(); i++) k1_pairs[i].second = (first + (int)i) <= hc->l;
+    if (int rc = k1_collect(s, k1_pairs)) return rc;
+    k1_pairs.clear();
+    if (hc->done || slot > s->max_iter) break;
+    batch = 2;
+  }
+  if (hc->info) return fail(BESSX_ERR_NUMERIC, "non-finite value in the k x k solve (singular Gram matrix?)");
+  // results
+  const double *sse_h = reinterpret_cast<const double *>(s->res_h + ((unsigned char *)s->sse - s->resblk));
+  const double *b_h = reinterpret_cast<const double *>(s->res_h + ((unsigned char *)s->b_cur - s->resblk));
+  const int *a_h = reinterpret_cast<const int *>(s->res_h + ((unsigned char *)s->A_cur - s->resblk));
+  s->beta.idx.assign(a_h, a_h + T0);
+  s->beta.val.assign(b_h, b_h + T0);
+  s->coef0 = hc->coef0;
+  s->l = hc->done ? hc->l : s->max_iter + 1;
+  double tr = 0.0, te = 0.0;
+  for (int b = 0; b < s->n_sse_blk; b++) {
+    tr += sse_h[2 * b];
+    te += sse_h[2 * b + 1];
+  }
+  s->sse_train = tr;
+  s->sse_test = te;
+  s->n_fits += 1;
+  s->n_iters += hc->l;
+  if (s->trace.on) {
+    const int L = hc->l;
+    std::vector<int> hh((size_t)(L + 1) * s->hist_stride);
+    std::vector<double> hb((size_t)(L + 1) * s->hist_stride), hc0(L + 1);
+    HIPX(hipMemcpy(hh.data(), s->hist, hh.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPX(hipMemcpy(hb.data(), s->hist_beta, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPX(hipMemcpy(hc0.data(), s->hist_coef0, hc0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int it = 1; it <= L; it++) {
+      s->trace.meta.push_back(it);
+      s->trace.meta.push_back(T0);
+      s->trace.meta.push_back(s->n_train[rs]);
+      s->trace.meta.push_back((int)s->trace.a_flat.size());
+      for (int i = 0; i < T0; i++) {
+        s->trace.a_flat.push_back(hh[(size_t)it * s->hist_stride + i]);
+        s->trace.beta_flat.push_back(hb[(size_t)it * s->hist_stride + i]);
+      }
+      s->trace.coef0_calls.push_back(hc0[it]);
+    }
+  }
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// Metric (src/Metric.h).  Values come from sums the residual kernel already produced.
+// --------------------------------------------------------------------------------------------
+static double metric_train_loss_value(const bessx_session *s) {
+  // LmMetric::train_loss, src/Metric.h:145-148: ||y - X beta||^2 / n on ALL rows
+  return (s->sse_train + s->sse_test) / (double)s->n;
+}
+
+static int metric_train_loss(bessx_session *s, double *out) {
+  *out = metric_train_loss_value(s);
+  if (s->metric_depth == 0 && s->trace.on) s->trace.loss_calls.push_back(*out);
+  return 0;
+}
+
+// test_loss under CV: K fold fits, src/Metric.h:150-195
+static int metric_test_loss(bessx_session *s, double *out) {
+  double acc = 0.0;
+  for (int k = 0; k < s->K; k++) {
+    if (s->warm_start) s->beta_init = s->cv_init[k];  // update_beta_init(cv_initial_model_param.row(k))
+    s->cur_rows = k + 1;                               // update_train_mask + update_group_XTX
+    if (int rc = algorithm_fit(s)) return rc;
+    if (s->warm_start) s->cv_init[k] = s->beta;
+    acc += s->sse_test / (double)(2 * s->n_test[k]);   // :190
+  }
+  *out = acc / (double)s->K;
+  return 0;
+}
+
+// ic: src/Metric.h:197-256 (LM)
+static int metric_ic(bessx_session *s, int ic_type, int is_cv, double *out) {
+  s->metric_depth++;
+  int rc = 0;
+  if (is_cv) {
+    rc = metric_test_loss(s, out);
+  } else {
+    double n = (double)s->n, p = (double)s->p, c = 0.0, loss = metric_train_loss_value(s);
+    if (ic_type == 1) c = 2.0;
+    if (ic_type == 2) c = std::log(n);
+    if (ic_type == 3) c = std::log(p) * std::log(std::log(n));
+    if (ic_type == 4) c = std::log(n) + 2.0 * std::log(p);
+    *out = (ic_type >= 1 && ic_type <= 4) ? n * std::log(loss) + c * (double)s->sparsity_level : 0.0;
+  }
+  s->metric_depth--;
+  if (rc == 0 && s->metric_depth == 0 && s->trace.on) s->trace.ic_calls.push_back(*out);
+  return rc;
+}
+
+// --------------------------------------------------------------------------------------------
+// paths (src/path.cpp)
+// --------------------------------------------------------------------------------------------
+struct Candidate {
+  int T0;
+  double lambda;
+  SparseVec beta;
+  double coef0, loss, ic;
+  int iters;
+};
+
+static void denormalize(const bessx_session *s, SparseVec &b, double &coef0, bool gs_variant) {
+  // src/path.cpp:76-110 (sequential) and :330-342 (golden section: data_type 3 also takes the "else")
+  if (!s->is_normal) return;
+  double dot = 0.0, sn = std::sqrt((double)s->n);
+  for (size_t i = 0; i < b.idx.size(); i++) {
+    b.val[i] = sn * b.val[i] / s->x_norm_h[b.idx[i]];
+    dot += b.val[i] * s->x_mean_h[b.idx[i]];
+  }
+  if (s->data_type == 1)
+    coef0 = s->y_mean_h - dot;
+  else if (s->data_type == 2 || gs_variant)
+    coef0 = coef0 - dot;
+}
+
+static int run_fit(bessx_session *s, int T0, double lambda, const SparseVec &beta_init, double coef0_init) {
+  s->cur_rows = 0;  // update_train_mask(full_mask) + update_group_XTX(full_group_XTX)
+  s->sparsity_level = T0;
+  s->lambda_level = lambda;
+  s->beta_init = beta_init;
+  s->coef0_init = coef0_init;
+  return algorithm_fit(s);
+}
+
+static void store_candidate(bessx_session *s, bessx_path_result *res, const Candidate &c, bool gs_variant) {
+  int i = res->n_candidates++;
+  if (i >= res->capacity) return;
+  SparseVec b = c.beta;
+  double c0 = c.coef0;
+  denormalize(s, b, c0, gs_variant);
+  if (res->cand_T0) res->cand_T0[i] = c.T0;
+  if (res->cand_lambda) res->cand_lambda[i] = c.lambda;
+  if (res->cand_iters) res->cand_iters[i] = c.iters;
+  if (res->cand_train_loss) res->cand_train_loss[i] = c.loss;
+  if (res->cand_ic) res->cand_ic[i] = c.ic;
+  if (res->cand_coef0) res->cand_coef0[i] = c0;
+  for (int j = 0; j < res->max_T0; j++) {
+    bool has = j < (int)b.idx.size();
+    if (res->cand_support) res->cand_support[(size_t)i * res->max_T0 + j] = has ? b.idx[j] : -1;
+    if (res->cand_beta) res->cand_beta[(size_t)i * res->max_T0 + j] = has ? b.val[j] : 0.0;
+  }
+}
+
+static void store_best(bessx_session *s, bessx_path_result *res, const Candidate &c, bool gs_variant) {
+  SparseVec b = c.beta;
+  double c0 = c.coef0;
+  denormalize(s, b, c0, gs_variant);
+  if (res->beta) {
+    std::fill(res->beta, res->beta + s->p, 0.0);
+    for (size_t i = 0; i < b.idx.size(); i++) res->beta[b.idx[i]] = b.val[i];
+  }
+  res->coef0 = c0;
+  res->train_loss = c.loss;
+  res->ic = c.ic;
+  res->lambda = c.lambda;
+  res->best_T0 = c.T0;
+  res->best_iters = c.iters;
+}
+
+static int sequential_path(bessx_session *s, const int *seq, int ns, const double *lam, int nl, int ic_type,
+                           int is_cv, bessx_path_result *res) {
+  // src/path.cpp:25-132
+  SparseVec beta_init;
+  double coef0_init = 0.0;
+  std::vector<Candidate> grid((size_t)ns * nl);
+  for (int i = 0; i < ns; i++) {
+    int step = (i % 2 == 0) ? 1 : -1;
+    for (int j = (i % 2 == 0) ? 0 : nl - 1; j < nl && j >= 0; j += step) {
+      if (int rc = run_fit(s, seq[i], lam[j], beta_init, coef0_init)) return rc;
+      if (s->warm_start) {
+        beta_init = s->beta;
+        coef0_init = s->coef0;
+      }
+      Candidate &c = grid[(size_t)j * ns + i];
+      c.T0 = seq[i];
+      c.lambda = lam[j];
+      c.beta = s->beta;
+      c.coef0 = s->coef0;
+      c.iters = s->l;
+      if (int rc = metric_train_loss(s, &c.loss)) return rc;
+      if (int rc = metric_ic(s, ic_type, is_cv, &c.ic)) return rc;
+      store_candidate(s, res, c, false);
+    }
+  }
+  size_t best = 0;  // minCoeff over the column-major (ns x nl) matrix: first minimum in storage order
+  for (size_t q = 0; q < grid.size(); q++)
+    if (grid[q].ic < grid[best].ic) best = q;
+  store_best(s, res, grid[best], false);
+  return 0;
+}
+
+static int gs_path(bessx_session *s, int s_min, int s_max, int ic_type, int is_cv, bessx_path_result *res) {
+  // src/path.cpp:134-389; lambda stays at its constructor default 0
+  SparseVec beta_init;
+  double coef0_init = 0.0;
+  int Tmin = s_min, Tmax = s_max;
+  int T1 = (int)std::round(0.618 * Tmin + 0.382 * Tmax), T2 = (int)std::round(0.382 * Tmin + 0.618 * Tmax);
+  double ic1 = 0, ic2 = 0, icT1 = 0, icT2 = 0;
+  auto fit_point = [&](int T, double *ic_first, double *ic_second) -> int {
+    if (int rc = run_fit(s, T, 0.0, beta_init, coef0_init)) return rc;
+    if (s->warm_start) {
+      beta_init = s->beta;
+      coef0_init = s->coef0;
+    }
+    Candidate c;
+    c.T0 = T;
+    c.lambda = 0.0;
+    c.beta = s->beta;
+    c.coef0 = s->coef0;
+    c.iters = s->l;
+    if (int rc = metric_train_loss(s, &c.loss)) return rc;
+    if (int rc = metric_ic(s, ic_type, is_cv, &c.ic)) return rc;
+    store_candidate(s, res, c, true);
+    *ic_first = c.ic;
+    if (ic_second)
+      if (int rc = metric_ic(s, ic_type, is_cv, ic_second)) return rc;  // evaluated twice, :204+:210 etc.
+    return 0;
+  };
+  if (int rc = fit_point(T1, &ic1, nullptr)) return rc;
+  icT1 = ic1;
+  if (int rc = fit_point(T2, &ic2, &icT2)) return rc;
+  while (T1 != T2) {
+    if (icT1 < icT2) {
+      Tmax = T2;
+      T2 = T1;
+      ic2 = ic1;
+      icT2 = ic1;
+      T1 = (int)std::round(0.618 * Tmin + 0.382 * Tmax);
+      if (int rc = fit_point(T1, &ic1, &icT1)) return rc;
+    } else {
+      Tmin = T1;
+      T1 = T2;
+      ic1 = ic2;
+      icT1 = ic2;
+      T2 = (int)std::round(0.382 * Tmin + 0.618 * Tmax);
+      if (int rc = fit_point(T2, &ic2, &icT2)) return rc;
+    }
+  }
+  Candidate best;
+  best.T0 = 0;
+  best.lambda = 0.0;
+  best.coef0 = 0.0;
+  best.loss = 0.0;
+  best.ic = DBL_MAX;
+  best.iters = 0;
+  for (int T = Tmin; T <= Tmax; T++) {
+    if (int rc = run_fit(s, T, 0.0, beta_init, coef0_init)) return rc;
+    if (s->warm_start) {
+      beta_init = s->beta;
+      coef0_init = s->coef0;
+    }
+    int iters_full = s->l;
+    double v;
+    if (int rc = metric_ic(s, ic_type, is_cv, &v)) return rc;
+    if (v < best.ic) {
+      // read AFTER ic(): under CV these are the last fold's fit, src/path.cpp:314-319
+      best.T0 = T;
+      best.beta = s->beta;
+      best.coef0 = s->coef0;
+      if (int rc = metric_train_loss(s, &best.loss)) return rc;
+      best.ic = v;
+      best.iters = iters_full;
+      store_candidate(s, res, best, true);
+    }
+  }
+  store_best(s, res, best, true);
+  return 0;
+}
+
+static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *lam, int nl, int s_min,
+                    int s_max, int ic_type, int is_cv, bessx_path_result *res) {
+  if (!s || !res) return fail(BESSX_ERR_ARG, "null session or result");
+  if (is_cv && s->K < 2) return fail(BESSX_ERR_ARG, "is_cv needs bessx_session_set_cv first");
+  HIPX(hipSetDevice(s->device));
+  s->trace.clear();
+  s->metric_depth = 0;
+  for (auto &v : s->cv_init) v.clear();
+  res->n_candidates = 0;
+  s->n_fits = 0;
+  s->n_iters = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  int rc = gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res) : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res);
+  auto t1 = std::chrono::steady_clock::now();
+  res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
+  res->n_fits = s->n_fits;
+  res->n_pdas_iters = s->n_iters;
+  return rc;
+}
+
+}  // namespace bessx
+
+namespace {
+struct Scratch {
+  std::vector<void *> ptrs;
+  ~Scratch() {
+    for (void *q : ptrs) (void)hipFree(q);
+  }
+  template <class T>
+  hipError_t alloc(T **out, size_t count) {
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(out), std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(*out);
+    return e;
+  }
+};
+
+int need_device() {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1)
+    return fail(BESSX_ERR_HIP, "no HIP device visible: libbessx has no CPU path");
+  return 0;
+}
+
+// copy a column-major (n x p, leading dimension ld_in) host matrix into a zero-padded device matrix
+int upload_padded(Scratch &sc, const double *x, int n, int p, int ld_in, int U, double **dX, long *ld_out) {
+  long rb = 128L * U;
+  long ld = ((long)n + rb - 1) / rb * rb;
+  HIPX(sc.alloc(dX, (size_t)ld * p));
+  HIPX(hipMemset(*dX, 0, (size_t)ld * p * sizeof(double)));
+  HIPX(hipMemcpy2D(*dX, (size_t)ld * sizeof(double), x, (size_t)ld_in * sizeof(double), (size_t)n * sizeof(double),
+                   (size_t)p, hipMemcpyHostToDevice));
+  *ld_out = ld;
+  return 0;
+}
+
+int upload_vec_padded(Scratch &sc, const double *v, int n, long ld, double **dv) {
+  std::vector<double> tmp((size_t)ld, 0.0);
+  if (v) std::copy(v, v + n, tmp.begin());
+  HIPX(sc.alloc(dv, (size_t)ld));
+  HIPX(hipMemcpy(*dv, tmp.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+}  // namespace
+
+// ==============================================================================================
+// extern "C"
+// ==============================================================================================
+extern "C" {
+
+const char *bessx_last_error(void) { return g_err.c_str(); }
+
+int bessx_device_info(char *buf, int buf_len) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1) return fail(BESSX_ERR_HIP, "no HIP device visible");
+  int dev = 0;
+  HIPX(hipGetDevice(&dev));
+  hipDeviceProp_t pr;
+  HIPX(hipGetDeviceProperties(&pr, dev));
+  std::snprintf(buf, (size_t)buf_len, "%s arch=%s CUs=%d LDS/block=%zu HBM=%.1f GiB clock=%d MHz", pr.name,
+                pr.gcnArchName, pr.multiProcessorCount, (size_t)pr.sharedMemPerBlock,
+                (double)pr.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), pr.clockRate / 1000);
+  return BESSX_OK;
+}
+
+int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
+  if (!out || !pb || !pb->x || !pb->y) return fail(BESSX_ERR_ARG, "null argument");
+  if (pb->n < 1 || pb->p < 1) return fail(BESSX_ERR_ARG, "n and p must be positive");
+  if (pb->model_type < 1 || pb->model_type > 4) return fail(BESSX_ERR_ARG, "model_type must be 1..4");
+  if (pb->algorithm_type != 1 && pb->algorithm_type != 5 && pb->algorithm_type != 2 && pb->algorithm_type != 3)
+    return fail(BESSX_ERR_ARG, "algorithm_type must be 1, 2, 3 or 5 (src/bess.cpp:93)");
+  if (pb->data_type < 1 || pb->data_type > 3) return fail(BESSX_ERR_ARG, "data_type must be 1..3");
+  if (pb->max_iter < 1) return fail(BESSX_ERR_ARG, "max_iter must be >= 1");
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1)
+    return fail(BESSX_ERR_HIP, "no HIP device visible: libbessx has no CPU path");
+  bessx_session *s = new bessx_session();
+  int dev = pb->device;
+  if (dev < 0) (void)hipGetDevice(&dev);
+  s->device = dev;
+  auto bail = [&](int rc) {
+    std::string keep = g_err;
+    session_free(s);
+    g_err = keep;
+    return rc;
+  };
+#define TRY(expr)                     \
+  do {                                \
+    int rc__ = (expr);                \
+    if (rc__) return bail(rc__);      \
+  } while (0)
+#define HIPT(expr)                                                                             \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return bail(fail(BESSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)));    \
+  } while (0)
+  HIPT(hipSetDevice(dev));
+  HIPT(hipStreamCreate(&s->st));
+  const int n = pb->n, p = pb->p;
+  s->n = n;
+  s->p = p;
+  s->data_type = pb->data_type;
+  s->is_normal = pb->is_normal ? 1 : 0;
+  s->model_type = pb->model_type;
+  s->algorithm_type = pb->algorithm_type;
+  s->max_iter = pb->max_iter;
+  s->warm_start = pb->is_warm_start ? 1 : 0;
+  s->U = n >= 4096 ? 8 : (n >= 2048 ? 4 : (n >= 1024 ? 2 : 1));
+  const long rb = 128L * s->U;
+  s->ld = ((long)n + rb - 1) / rb * rb;
+  s->nrb = (int)(s->ld / rb);
+  const long ld = s->ld;
+  HIPT(dmalloc(&s->X, (size_t)ld * p));
+  HIPT(dmalloc(&s->y, (size_t)ld));
+  HIPT(dmalloc(&s->w, (size_t)ld));
+  HIPT(dmalloc(&s->aux, (size_t)ld * 3));
+  HIPT(dmalloc(&s->x_mean, (size_t)p));
+  HIPT(dmalloc(&s->x_norm, (size_t)p));
+  HIPT(dmalloc(&s->y_mean_d, 1));
+  HIPT(dmalloc(&s->always, (size_t)p));
+  HIPT(dmalloc(&s->r, (size_t)ld));
+  HIPT(dmalloc(&s->tmpv, (size_t)ld));
+  HIPT(dmalloc(&s->part, (size_t)s->nrb * p));
+  HIPT(dmalloc(&s->part2, (size_t)s->nrb * p));
+  HIPT(dmalloc(&s->bd, (size_t)p));
+  HIPT(dmalloc(&s->beta_dense, (size_t)p));
+  HIPT(dmalloc(&s->sol, 256));
+  HIPT(dmalloc(&s->A_new, 256));
+  HIPT(dmalloc(&s->cand, 32768));
+  HIPT(dmalloc(&s->hist, (size_t)(s->max_iter + 2) * s->hist_stride));
+  HIPT(dmalloc(&s->hist_beta, (size_t)(s->max_iter + 2) * s->hist_stride));
+  HIPT(dmalloc(&s->hist_coef0, (size_t)(s->max_iter + 2)));
+  HIPT(dmalloc(&s->gcols, 256));
+  HIPT(dmalloc(&s->init_idx_d, 256));
+  HIPT(dmalloc(&s->init_val_d, 256));
+  HIPT(dmalloc(&s->Gt, (size_t)136 * 256));
+  s->gpart_elems = (size_t)6 << 20;  // 48 MB of fp64 partial tiles
+  HIPT(dmalloc(&s->gpart, s->gpart_elems));
+  // Gram task lists for every tile count
+  {
+    std::vector<GramTask> all;
+    s->gtask_off.assign(17, 0);
+    s->gtask_cnt.assign(17, 0);
+    for (int mt = 1; mt <= 16; mt++) {
+      s->gtask_off[mt] = (int)all.size();
+      build_gram_tasks(mt, all);
+      s->gtask_cnt[mt] = (int)all.size() - s->gtask_off[mt];
+    }
+    HIPT(dmalloc(&s->gtasks, all.size()));
+    HIPT(hipMemcpy(s->gtasks, all.data(), all.size() * sizeof(GramTask), hipMemcpyHostToDevice));
+  }
+  // result block
+  s->n_sse_blk = (int)((ld + 255) / 256);
+  {
+    size_t off = 0;
+    size_t o_ctrl = off;
+    off += 64;
+    size_t o_sse = off;
+    off += (size_t)2 * s->n_sse_blk * sizeof(double);
+    size_t o_b = off;
+    off += 256 * sizeof(double);
+    size_t o_a = off;
+    off += 256 * sizeof(int);
+    s->res_bytes = off;
+    HIPT(hipMalloc(reinterpret_cast<void **>(&s->resblk), off));
+    HIPT(hipMemset(s->resblk, 0, off));
+    s->ctrl = reinterpret_cast<FitCtrl *>(s->resblk + o_ctrl);
+    s->sse = reinterpret_cast<double *>(s->resblk + o_sse);
+    s->b_cur = reinterpret_cast<double *>(s->resblk + o_b);
+    s->A_cur = reinterpret_cast<int *>(s->resblk + o_a);
+    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->res_h), off));
+    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), 8192));
+  }
+  static_assert(sizeof(FitCtrl) <= 64, "FitCtrl must fit its slot of the result block");
+  // data
+  TRY(upload_x(s, pb->x, pb->x_col_major));
+  {
+    std::vector<double> tmp((size_t)ld, 0.0);
+    std::copy(pb->y, pb->y + n, tmp.begin());
+    HIPT(hipMemcpy(s->y, tmp.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
+    std::fill(tmp.begin(), tmp.end(), 0.0);
+    for (int i = 0; i < n; i++) tmp[i] = pb->weight ? pb->weight[i] : 1.0;
+    HIPT(hipMemcpy(s->w, tmp.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
+    // aux: column 0 zeros, column 1 ones on the data rows, column 2 working response
+    HIPT(hipMemset(s->aux, 0, (size_t)ld * 3 * sizeof(double)));
+    std::fill(tmp.begin(), tmp.end(), 0.0);
+    std::fill(tmp.begin(), tmp.begin() + n, 1.0);
+    HIPT(hipMemcpy(s->aux + ld, tmp.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<unsigned char> fl((size_t)p, 0);
+    for (int i = 0; i < pb->always_select_len; i++) {
+      int a = pb->always_select[i];
+      if (a < 0 || a >= p) return bail(fail(BESSX_ERR_ARG, "always_select index out of range"));
+      fl[a] = 1;
+    }
+    HIPT(hipMemcpy(s->always, fl.data(), (size_t)p, hipMemcpyHostToDevice));
+  }
+  HIPT(hipMemset(s->x_mean, 0, (size_t)p * sizeof(double)));
+  HIPT(hipMemset(s->x_norm, 0, (size_t)p * sizeof(double)));
+  {
+    // Data::normalize + add_weight (LM only, src/bess.cpp:97)
+    hipError_t e = launch_normalize(s->X, ld, n, p, s->y, s->w, s->data_type, s->is_normal, s->model_type == 1,
+                                    s->x_mean, s->x_norm, s->y_mean_d, s->st);
+    if (e != hipSuccess) return bail(fail(BESSX_ERR_HIP, std::string("normalize: ") + hipGetErrorString(e)));
+    HIPT(hipStreamSynchronize(s->st));
+    s->x_mean_h.assign((size_t)p, 0.0);
+    s->x_norm_h.assign((size_t)p, 0.0);
+    HIPT(hipMemcpy(s->x_mean_h.data(), s->x_mean, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+    HIPT(hipMemcpy(s->x_norm_h.data(), s->x_norm, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+    HIPT(hipMemcpy(&s->y_mean_h, s->y_mean_d, sizeof(double), hipMemcpyDeviceToHost));
+  }
+  // row set 0: all rows
+  s->mask.push_back(nullptr);
+  s->n_train.push_back(n);
+  double *q = nullptr;
+  HIPT(dmalloc(&q, (size_t)p));
+  s->xtx.push_back(q);
+  HIPT(dmalloc(&q, (size_t)p));
+  s->xty.push_back(q);
+  if (s->model_type == 1) TRY(prepare_rowset(s, 0));
+  HIPT(hipStreamSynchronize(s->st));
+#undef TRY
+#undef HIPT
+  *out = s;
+  return BESSX_OK;
+}
+
+void bessx_session_destroy(bessx_session *s) { session_free(s); }
+
+int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned seed) {
+  if (!s || K < 2 || K > s->n) return fail(BESSX_ERR_ARG, "set_cv: bad arguments");
+  HIPX(hipSetDevice(s->device));
+  const int n = s->n, p = s->p;
+  std::vector<int> fold((size_t)n);
+  if (fold_id) {
+    for (int i = 0; i < n; i++) {
+      if (fold_id[i] < 0 || fold_id[i] >= K) return fail(BESSX_ERR_ARG, "set_cv: fold id out of range");
+      fold[i] = fold_id[i];
+    }
+  } else {
+    // Metric::set_cv_train_test_mask, src/Metric.h:49-78, with a reproducible generator
+    std::vector<int> perm((size_t)n);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::mt19937 g(seed);
+    std::shuffle(perm.begin(), perm.end(), g);
+    int size = n / K;
+    for (int k = 0; k < K; k++) {
+      int b = k * size, e = (k == K - 1) ? n : (k + 1) * size;
+      for (int i = b; i < e; i++) fold[perm[i]] = k;
+    }
+  }
+  // drop previous folds
+  for (size_t i = 1; i < s->mask.size(); i++) {
+    (void)hipFree(s->mask[i]);
+    (void)hipFree(s->xtx[i]);
+    (void)hipFree(s->xty[i]);
+  }
+  s->mask.resize(1);
+  s->xtx.resize(1);
+  s->xty.resize(1);
+  s->n_train.resize(1);
+  s->n_test.assign(K, 0);
+  s->K = K;
+  s->cv_init.assign(K, SparseVec());
+  std::vector<double> m((size_t)s->ld);
+  for (int k = 0; k < K; k++) {
+    std::fill(m.begin(), m.end(), 0.0);
+    int nt = 0;
+    for (int i = 0; i < n; i++) {
+      if (fold[i] != k) {
+        m[i] = 1.0;
+        nt++;
+      }
+    }
+    s->n_test[k] = n - nt;
+    if (nt < 1 || n - nt < 1) return fail(BESSX_ERR_ARG, "set_cv: empty train or test fold");
+    double *dm = nullptr, *q1 = nullptr, *q2 = nullptr;
+    HIPX(dmalloc(&dm, (size_t)s->ld));
+    HIPX(hipMemcpy(dm, m.data(), (size_t)s->ld * sizeof(double), hipMemcpyHostToDevice));
+    HIPX(dmalloc(&q1, (size_t)p));
+    HIPX(dmalloc(&q2, (size_t)p));
+    s->mask.push_back(dm);
+    s->xtx.push_back(q1);
+    s->xty.push_back(q2);
+    s->n_train.push_back(nt);
+    if (s->model_type == 1)
+      if (int rc = prepare_rowset(s, k + 1)) return rc;
+  }
+  HIPX(hipStreamSynchronize(s->st));
+  return BESSX_OK;
+}
+
+int bessx_session_sequential_path(bessx_session *s, const int *sequence, int sequence_len, const double *lambda_seq,
+                                  int lambda_len, int ic_type, int is_cv, bessx_path_result *res) {
+  if (!sequence || sequence_len < 1 || !lambda_seq || lambda_len < 1)
+    return fail(BESSX_ERR_ARG, "sequential_path: empty sequence");
+  return run_path(s, false, sequence, sequence_len, lambda_seq, lambda_len, 0, 0, ic_type, is_cv, res);
+}
+
+int bessx_session_gs_path(bessx_session *s, int s_min, int s_max, int ic_type, int is_cv, bessx_path_result *res) {
+  if (s_min < 1 || s_max < s_min) return fail(BESSX_ERR_ARG, "gs_path: need 1 <= s_min <= s_max");
+  return run_path(s, true, nullptr, 0, nullptr, 0, s_min, s_max, ic_type, is_cv, res);
+}
+
+int bessx_session_trace_enable(bessx_session *s, int on) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  s->trace.on = on != 0;
+  return BESSX_OK;
+}
+
+int bessx_session_trace_size(bessx_session *s, int which) {
+  if (!s) return -1;
+  switch (which) {
+    case 0: return (int)s->trace.meta.size();
+    case 1: return (int)s->trace.a_flat.size();
+    case 2: return (int)s->trace.beta_flat.size();
+    case 3: return (int)s->trace.coef0_calls.size();
+    case 4: return (int)s->trace.loss_calls.size();
+    case 5: return (int)s->trace.ic_calls.size();
+  }
+  return -1;
+}
+
+int bessx_session_trace_copy_int(bessx_session *s, int which, int *out) {
+  if (!s || !out) return fail(BESSX_ERR_ARG, "null argument");
+  const std::vector<int> &v = which == 0 ? s->trace.meta : s->trace.a_flat;
+  if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(int));
+  return BESSX_OK;
+}
+
+int bessx_session_trace_copy_double(bessx_session *s, int which, double *out) {
+  if (!s || !out) return fail(BESSX_ERR_ARG, "null argument");
+  const std::vector<double> *v = &s->trace.beta_flat;
+  if (which == 3) v = &s->trace.coef0_calls;
+  if (which == 4) v = &s->trace.loss_calls;
+  if (which == 5) v = &s->trace.ic_calls;
+  if (!v->empty()) std::memcpy(out, v->data(), v->size() * sizeof(double));
+  return BESSX_OK;
+}
+
+int bessx_session_get_normalization(bessx_session *s, double *x_mean, double *x_norm, double *y_mean) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  if (x_mean) std::copy(s->x_mean_h.begin(), s->x_mean_h.end(), x_mean);
+  if (x_norm) std::copy(s->x_norm_h.begin(), s->x_norm_h.end(), x_norm);
+  if (y_mean) *y_mean = s->y_mean_h;
+  return BESSX_OK;
+}
+
+int bessx_session_enable_kernel_timing(bessx_session *s, int on) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  s->timing = on != 0;
+  return BESSX_OK;
+}
+
+int bessx_session_score_pass_stats(bessx_session *s, int reset, double *seconds, long long *launches,
+                                   double *algorithmic_bytes) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  if (seconds) *seconds = s->k1_seconds;
+  if (launches) *launches = s->k1_launches;
+  if (algorithmic_bytes) *algorithmic_bytes = s->k1_bytes;
+  if (reset) {
+    s->k1_seconds = 0.0;
+    s->k1_launches = 0;
+    s->k1_bytes = 0.0;
+  }
+  return BESSX_OK;
+}
+
+int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx, const double *init_val,
+                      int init_len, double init_coef0, int *support, double *beta, double *coef0, int *iters,
+                      double *train_loss, double *test_loss) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  if (fold >= s->K) return fail(BESSX_ERR_ARG, "fold index out of range");
+  HIPX(hipSetDevice(s->device));
+  s->cur_rows = fold < 0 ? 0 : fold + 1;
+  s->sparsity_level = T0;
+  s->lambda_level = lambda;
+  s->beta_init.clear();
+  for (int i = 0; i < init_len; i++) {
+    if (init_idx[i] < 0 || init_idx[i] >= s->p) return fail(BESSX_ERR_ARG, "init index out of range");
+    s->beta_init.idx.push_back(init_idx[i]);
+    s->beta_init.val.push_back(init_val[i]);
+  }
+  s->coef0_init = init_coef0;
+  if (int rc = algorithm_fit(s)) return rc;
+  for (int i = 0; i < T0; i++) {
+    if (support) support[i] = s->beta.idx[i];
+    if (beta) beta[i] = s->beta.val[i];
+  }
+  if (coef0) *coef0 = s->coef0;
+  if (iters) *iters = s->l;
+  if (train_loss) *train_loss = metric_train_loss_value(s);
+  if (test_loss) *test_loss = fold < 0 ? 0.0 : s->sse_test / (double)(2 * s->n_test[fold]);
+  return BESSX_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// pywrap_bess drop-in (src/bess.cpp:218-281 -> bessCpp :37-214)
+// ----------------------------------------------------------------------------------------------
+int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int data_type, double *weight,
+                      int weight_len, int is_normal, int algorithm_type, int model_type, int max_iter,
+                      int exchange_num, int path_type, int is_warm_start, int ic_type, int is_cv, int K, int *gindex,
+                      int gindex_len, double *state, int state_len, int *sequence, int sequence_len,
+                      double *lambda_sequence, int lambda_sequence_len, int s_min, int s_max, int K_max,
+                      double epsilon, double lambda_min, double lambda_max, int n_lambda, int is_screening,
+                      int screening_size, int powell_path, int *always_select, int always_select_len, double tao,
+                      double *beta_out, int beta_out_len, double *coef0_out, int coef0_out_len,
+                      double *train_loss_out, int train_loss_out_len, double *ic_out, int ic_out_len,
+                      double *nullloss_out, double *aic_out, int aic_out_len, double *bic_out, int bic_out_len,
+                      double *gic_out, int gic_out_len, int *A_out, int A_out_len, int *l_out) {
+  (void)exchange_num; (void)state; (void)state_len; (void)K_max; (void)epsilon; (void)lambda_min; (void)lambda_max;
+  (void)n_lambda; (void)screening_size; (void)powell_path; (void)tao;  // dead on the live reference paths
+  (void)coef0_out_len; (void)train_loss_out_len; (void)ic_out_len;
+  if (!x || !y || !beta_out || !coef0_out || !train_loss_out || !ic_out) return fail(BESSX_ERR_ARG, "null argument");
+  if (y_len != x_row || (weight && weight_len != x_row)) return fail(BESSX_ERR_ARG, "length of y / weight != rows of x");
+  if (beta_out_len < x_col) return fail(BESSX_ERR_ARG, "beta_out too short");
+  if (is_screening) return fail(BESSX_ERR_UNSUPPORTED, "screening (src/screening.cpp) is outside the hot path");
+  if (gindex_len != x_col) return fail(BESSX_ERR_UNSUPPORTED, "group selection (group size > 1) is not built yet");
+  for (int j = 0; j < gindex_len; j++)
+    if (gindex[j] != j) return fail(BESSX_ERR_UNSUPPORTED, "group selection (group size > 1) is not built yet");
+  if (path_type != 1 && (algorithm_type == 5 || algorithm_type == 3))
+    return fail(BESSX_ERR_UNSUPPORTED, "Powell path (pgs_path, src/path.cpp:1138) is not built yet");
+  bessx_problem pb;
+  std::memset(&pb, 0, sizeof(pb));
+  pb.n = x_row;
+  pb.p = x_col;
+  pb.x = x;
+  pb.x_col_major = 0;
+  pb.y = y;
+  pb.weight = weight;
+  pb.data_type = data_type;
+  pb.is_normal = is_normal;
+  pb.model_type = model_type;
+  pb.algorithm_type = algorithm_type;
+  pb.max_iter = max_iter;
+  pb.is_warm_start = is_warm_start;
+  pb.always_select = always_select;
+  pb.always_select_len = always_select_len;
+  pb.device = -1;
+  bessx_session *s = nullptr;
+  if (int rc = bessx_session_create(&s, &pb)) return rc;
+  int rc = 0;
+  if (is_cv) rc = bessx_session_set_cv(s, K, nullptr, 123u);
+  bessx_path_result res;
+  std::memset(&res, 0, sizeof(res));
+  res.beta = beta_out;
+  if (rc == 0) {
+    if (path_type == 1)
+      rc = bessx_session_sequential_path(s, sequence, sequence_len, lambda_sequence, lambda_sequence_len, ic_type,
+                                         is_cv, &res);
+    else
+      rc = bessx_session_gs_path(s, s_min, s_max, ic_type, is_cv, &res);
+  }
+  if (rc == 0) {
+    *coef0_out = res.coef0;
+    *train_loss_out = res.train_loss;
+    *ic_out = res.ic;
+    if (nullloss_out) *nullloss_out = 0.0;
+    if (aic_out && aic_out_len > 0) aic_out[0] = 0.0;
+    if (bic_out && bic_out_len > 0) bic_out[0] = 0.0;
+    if (gic_out && gic_out_len > 0) gic_out[0] = 0.0;
+    if (A_out) {
+      int k = 0;
+      for (int j = 0; j < x_col && k < A_out_len; j++)
+        if (beta_out[j] != 0.0) A_out[k++] = j;
+      for (; k < A_out_len; k++) A_out[k] = -1;
+    }
+    if (l_out) *l_out = res.best_iters;
+  }
+  std::string keep = g_err;
+  bessx_session_destroy(s);
+  g_err = keep;
+  return rc;
+}
+
+// ----------------------------------------------------------------------------------------------
+// single-kernel entry points for parity tests
+// ----------------------------------------------------------------------------------------------
+int bessx_op_xtv(const double *x, int n, int p, int ld, const double *v, const double *v2, double *out,
+                 double *out2) {
+  if (int rc = need_device()) return rc;
+  if (!x || !v || !out || n < 1 || p < 1 || ld < n) return fail(BESSX_ERR_ARG, "op_xtv: bad arguments");
+  Scratch sc;
+  const int U = n >= 4096 ? 8 : (n >= 2048 ? 4 : (n >= 1024 ? 2 : 1));
+  double *dX, *dv, *dv2 = nullptr, *part, *part2 = nullptr, *dout;
+  long ldd;
+  if (int rc = upload_padded(sc, x, n, p, ld, U, &dX, &ldd)) return rc;
+  if (int rc = upload_vec_padded(sc, v, n, ldd, &dv)) return rc;
+  if (v2)
+    if (int rc = upload_vec_padded(sc, v2, n, ldd, &dv2)) return rc;
+  int nrb = (int)(ldd / (128L * U));
+  HIPX(sc.alloc(&part, (size_t)nrb * p));
+  HIPX(sc.alloc(&part2, (size_t)nrb * p));
+  HIPX(sc.alloc(&dout, (size_t)p));
+  HIPX(launch_xtv(dX, ldd, p, U, dv, dv2, part, part2, nullptr, 0, nullptr));
+  HIPX(launch_part_sum(part, nrb, p, dout, nullptr));
+  HIPX(hipMemcpy(out, dout, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+  if (v2 && out2) {
+    HIPX(launch_part_sum(part2, nrb, p, dout, nullptr));
+    HIPX(hipMemcpy(out2, dout, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return BESSX_OK;
+}
+
+int bessx_op_topk(const double *score, int len, int k, int *out_idx) {
+  if (int rc = need_device()) return rc;
+  if (!score || !out_idx || len < 1 || k < 0 || k > len) return fail(BESSX_ERR_ARG, "op_topk: bad arguments");
+  if (k == 0) return BESSX_OK;
+  if (!topk_supported(len, k)) return fail(BESSX_ERR_UNSUPPORTED, "op_topk: len / k combination needs a third level");
+  Scratch sc;
+  double *ds;
+  int *dout, *dcand;
+  HIPX(sc.alloc(&ds, (size_t)len));
+  HIPX(sc.alloc(&dout, (size_t)k));
+  HIPX(sc.alloc(&dcand, (size_t)32768));
+  HIPX(hipMemcpy(ds, score, (size_t)len * sizeof(double), hipMemcpyHostToDevice));
+  HIPX(launch_topk(ds, len, k, dout, dcand, nullptr, 0, nullptr));
+  HIPX(hipMemcpy(out_idx, dout, (size_t)k * sizeof(int), hipMemcpyDeviceToHost));
+  return BESSX_OK;
+}
+
+int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m, const double *w, double *out) {
+  if (int rc = need_device()) return rc;
+  if (!x || !cols || !out || n < 1 || p < 1 || ld < n || m < 1 || m > 255) return fail(BESSX_ERR_ARG, "op_gram: bad arguments");
+  for (int i = 0; i < m; i++)
+    if (cols[i] < 0 || cols[i] >= p) return fail(BESSX_ERR_ARG, "op_gram: column index out of range");
+  Scratch sc;
+  const int U = 1;
+  double *dX, *dw = nullptr, *daux, *gpart, *Gt;
+  long ldd;
+  if (int rc = upload_padded(sc, x, n, p, ld, U, &dX, &ldd)) return rc;
+  if (w)
+    if (int rc = upload_vec_padded(sc, w, n, ldd, &dw)) return rc;
+  HIPX(sc.alloc(&daux, (size_t)ldd * 3));
+  HIPX(hipMemset(daux, 0, (size_t)ldd * 3 * sizeof(double)));
+  const int mt = (m + 15) / 16, mp = mt * 16, ntiles = mt * (mt + 1) / 2;
+  std::vector<int> hc(mp, -1);
+  std::copy(cols, cols + m, hc.begin());
+  int *dcols;
+  HIPX(sc.alloc(&dcols, (size_t)mp));
+  HIPX(hipMemcpy(dcols, hc.data(), (size_t)mp * sizeof(int), hipMemcpyHostToDevice));
+  std::vector<GramTask> tasks;
+  build_gram_tasks(mt, tasks);
+  GramTask *dt;
+  HIPX(sc.alloc(&dt, tasks.size()));
+  HIPX(hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(GramTask), hipMemcpyHostToDevice));
+  bessx_session fake;
+  fake.ld = ldd;
+  int rps, nslab;
+  gram_geometry(&fake, (int)tasks.size(), &rps, &nslab);
+  HIPX(sc.alloc(&gpart, (size_t)nslab * ntiles * 256));
+  HIPX(sc.alloc(&Gt, (size_t)ntiles * 256));
+  HIPX(launch_gram(dX, daux, ldd, dcols, dw, rps, dt, (int)tasks.size(), nslab, gpart, ntiles, Gt, nullptr, 0, 0,
+                   nullptr));
+  std::vector<double> ht((size_t)ntiles * 256);
+  HIPX(hipMemcpy(ht.data(), Gt, ht.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int I = 0; I < mt; I++)
+    for (int J = 0; J <= I; J++) {
+      int t = I * (I + 1) / 2 + J;
+      for (int lane = 0; lane < 64; lane++)
+        for (int r = 0; r < 4; r++) {
+          int row = I * 16 + (lane >> 4) + 4 * r, col = J * 16 + (lane & 15);
+          if (row < m && col < m) {
+            double v = ht[(size_t)t * 256 + lane * 4 + r];
+            out[(size_t)col * m + row] = v;
+            if (I != J) out[(size_t)row * m + col] = v;
+          }
+        }
+    }
+  return BESSX_OK;
+}
+
+int bessx_op_chol_solve(const double *a, int m, const double *b, double *sol) {
+  if (int rc = need_device()) return rc;
+  if (!a || !b || !sol || m < 1 || m > 255) return fail(BESSX_ERR_ARG, "op_chol_solve: need 1 <= m <= 255");
+  Scratch sc;
+  const int mt = (m + 1 + 15) / 16, ntiles = mt * (mt + 1) / 2;
+  std::vector<double> ht((size_t)ntiles * 256, 0.0);
+  for (int I = 0; I < mt; I++)
+    for (int J = 0; J <= I; J++) {
+      int t = I * (I + 1) / 2 + J;
+      for (int lane = 0; lane < 64; lane++)
+        for (int r = 0; r < 4; r++) {
+          int row = I * 16 + (lane >> 4) + 4 * r, col = J * 16 + (lane & 15);
+          if (row < m && col < m) ht[(size_t)t * 256 + lane * 4 + r] = a[(size_t)col * m + row];
+        }
+    }
+  double *Gt, *drhs, *dsol;
+  int *dinfo;
+  HIPX(sc.alloc(&Gt, ht.size()));
+  HIPX(sc.alloc(&drhs, (size_t)m));
+  HIPX(sc.alloc(&dsol, (size_t)m));
+  HIPX(sc.alloc(&dinfo, 1));
+  HIPX(hipMemset(dinfo, 0, sizeof(int)));
+  HIPX(hipMemcpy(Gt, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPX(hipMemcpy(drhs, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+  HIPX(launch_chol(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, 0, nullptr));
+  HIPX(hipMemcpy(sol, dsol, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+  int info = 0;
+  HIPX(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+  if (info) return fail(BESSX_ERR_NUMERIC, "op_chol_solve: non-finite solution");
+  return BESSX_OK;
+}
+
+int bessx_op_normalize(double *x, int n, int p, double *y, const double *weight, int data_type, int is_normal,
+                       int add_weight, double *x_mean, double *x_norm, double *y_mean) {
+  if (int rc = need_device()) return rc;
+  if (!x || !y || !weight || n < 1 || p < 1) return fail(BESSX_ERR_ARG, "op_normalize: bad arguments");
+  Scratch sc;
+  double *dX, *dy, *dw, *dm, *dn, *dym;
+  long ldd;
+  if (int rc = upload_padded(sc, x, n, p, n, 1, &dX, &ldd)) return rc;
+  if (int rc = upload_vec_padded(sc, y, n, ldd, &dy)) return rc;
+  if (int rc = upload_vec_padded(sc, weight, n, ldd, &dw)) return rc;
+  HIPX(sc.alloc(&dm, (size_t)p));
+  HIPX(sc.alloc(&dn, (size_t)p));
+  HIPX(sc.alloc(&dym, 1));
+  HIPX(hipMemset(dm, 0, (size_t)p * sizeof(double)));
+  HIPX(hipMemset(dn, 0, (size_t)p * sizeof(double)));
+  HIPX(launch_normalize(dX, ldd, n, p, dy, dw, data_type, is_normal, add_weight, dm, dn, dym, nullptr));
+  HIPX(hipMemcpy2D(x, (size_t)n * sizeof(double), dX, (size_t)ldd * sizeof(double), (size_t)n * sizeof(double),
+                   (size_t)p, hipMemcpyDeviceToHost));
+  HIPX(hipMemcpy(y, dy, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  if (x_mean) HIPX(hipMemcpy(x_mean, dm, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+  if (x_norm) HIPX(hipMemcpy(x_norm, dn, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+  if (y_mean) HIPX(hipMemcpy(y_mean, dym, sizeof(double), hipMemcpyDeviceToHost));
+  return BESSX_OK;
+}
+
+int bessx_op_stream_copy_gbps(long long bytes, int repeats, double *gbps) {
+  if (int rc = need_device()) return rc;
+  if (bytes < (1 << 20) || repeats < 1 || !gbps) return fail(BESSX_ERR_ARG, "op_stream_copy: bad arguments");
+  Scratch sc;
+  double *a, *b;
+  size_t n = (size_t)bytes / 16 * 2;
+  HIPX(sc.alloc(&a, n));
+  HIPX(sc.alloc(&b, n));
+  HIPX(hipMemset(a, 1, n * sizeof(double)));
+  hipEvent_t e0, e1;
+  HIPX(hipEventCreate(&e0));
+  HIPX(hipEventCreate(&e1));
+  HIPX(launch_copy(a, b, (long)n, nullptr));
+  HIPX(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < repeats; i++) HIPX(launch_copy(a, b, (long)n, nullptr));
+  HIPX(hipEventRecord(e1, nullptr));
+  HIPX(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPX(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbps = 2.0 * (double)n * 8.0 * repeats / ((double)ms * 1e-3) / 1e9;
+  return BESSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1005 @@
+// bessx_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4) behind libbessx.so.
+//
+// Kernel inventory (K-numbers are SURVEY.md section 2.3; reference lines are under /root/reference):
+//   k_transpose_in   upload helper: row-major host chunk -> column-major padded X
+//   k_col_stats / k_col_scale   K11  Normalize*/add_weight      src/normalize.cpp:20-85, src/Data.h:70-77
+//   k_xtv            K1/K2  d = X^T v (and sum x^2 h)            src/Algorithm.h:1109,1236,1240-1246
+//   k_score_*        sacrifice scores bd                        src/Algorithm.h:1112-1126,1238-1260
+//   k_topk           K4  max_k                                  src/utilities.cpp:179-188
+//   k_gram           K6  X_A^T diag(w) X_A on fp64 MFMA         src/Algorithm.h:1134,1171,1199,1299
+//   k_gram_reduce    fixed-order sum of the row-slab partials
+//   k_chol           K7  Cholesky + triangular solves, one WG   src/Algorithm.h:1134 (QR), :1171 (LDLT)
+//   k_resid_lm       r = m*(y - X_A b_A - c), SSE (train / test) src/Algorithm.h:1109, src/Metric.h:147,190
+//   k_fit_begin / k_commit   Algorithm::fit bookkeeping          src/Algorithm.h:141-170
+//
+// Conventions: X is column-major with leading dimension ld (a multiple of 1024 rows when
+// n >= 4096), pad rows are zero.  All reductions use a fixed tree: results are bitwise
+// reproducible run to run (no floating-point atomics anywhere).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "bessx_dev.h"
+
+namespace bessx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Block-wide sum for 256-thread blocks, fixed order; result valid in thread 0.
+__device__ __forceinline__ double block_sum_256(double v, double *sm /*>=4*/) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// upload: transpose a row-major chunk (rows x p) into column-major X[:, r0 : r0+rows]
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_transpose_in(const double *__restrict__ src, int rows, int p,
+                                                      double *__restrict__ X, long ld, long r0) {
+  __shared__ double tile[64][65];
+  int bj = blockIdx.x * 64, bi = blockIdx.y * 64;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows of 64 per pass
+  for (int r = ty; r < 64; r += 4) {
+    int i = bi + r, j = bj + tx;
+    tile[r][tx] = (i < rows && j < p) ? src[(size_t)i * p + j] : 0.0;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    int j = bj + c, i = bi + tx;
+    if (j < p && i < rows) X[(size_t)j * ld + r0 + i] = tile[tx][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K11: column statistics and rescale.  One 256-thread block per column.
+//   mode 1/2 (data_type 1,2): mean_j = (w . x_j)/n, centre, norm_j = sqrt(w . x_j^2), x_j <- sqrt(n) x_j / norm_j
+//   mode 3 (data_type 3): no centring.  Then (LM) every row is multiplied by sqrt(w_i).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_col_normalize(double *__restrict__ X, long ld, int n, int p,
+                                                       const double *__restrict__ w, int centre, int do_scale,
+                                                       int add_weight, double *__restrict__ x_mean,
+                                                       double *__restrict__ x_norm) {
+  __shared__ double sm[4];
+  __shared__ double bc;
+  int j = blockIdx.x;
+  double *c = X + (size_t)j * ld;
+  double mean = 0.0, nm = 1.0;
+  if (do_scale) {
+    if (centre) {
+      double s = 0.0;
+      for (int i = threadIdx.x; i < n; i += 256) s += w[i] * c[i];
+      s = block_sum_256(s, sm);
+      if (threadIdx.x == 0) bc = s / (double)n;
+      __syncthreads();
+      mean = bc;
+      __syncthreads();
+    }
+    double s2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      double v = c[i] - mean;
+      s2 += w[i] * (v * v);
+    }
+    s2 = block_sum_256(s2, sm);
+    if (threadIdx.x == 0) bc = sqrt(s2);
+    __syncthreads();
+    nm = bc;
+    if (threadIdx.x == 0) {
+      x_mean[j] = mean;
+      x_norm[j] = nm;
+    }
+  }
+  double sn = sqrt((double)n);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double v = c[i];
+    if (do_scale) v = sn * (v - mean) / nm;
+    if (add_weight) v = v * sqrt(w[i]);
+    c[i] = v;
+  }
+}
+
+// y statistics for data_type 1: y_mean = (y . w)/n ; y <- y - y_mean ; (LM) y <- y*sqrt(w).  Single block.
+__global__ void __launch_bounds__(256) k_y_prepare(double *__restrict__ y, int n, const double *__restrict__ w,
+                                                   int centre, int add_weight, double *__restrict__ y_mean) {
+  __shared__ double sm[4];
+  __shared__ double bc;
+  double mean = 0.0;
+  if (centre) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += y[i] * w[i];
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) bc = s / (double)n;
+    __syncthreads();
+    mean = bc;
+  }
+  if (threadIdx.x == 0) *y_mean = mean;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double v = y[i] - mean;
+    if (add_weight) v = v * sqrt(w[i]);
+    y[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 / K2: streaming X^T v.  The dominant kernel of every PDAS iteration (HBM bound).
+//
+// Work decomposition: a task = one wave x (row block rb of 128*U rows) x (CG consecutive columns).
+// The wave keeps its 128*U-row slice of v in registers (2*U doubles per lane), streams the CG column
+// slices with 16-byte loads straight into registers (no LDS: every byte of X is used exactly once,
+// cdna guide "GEMV: load straight to VGPRs"), keeps one accumulator per column and folds the 64 lanes
+// with a butterfly that halves the live accumulators at each step (CG + 2 shuffles instead of 6*CG).
+// part[rb][j] receives the row-block partial; k_score_* adds the row blocks in fixed order.
+// Gate: runs only while ctrl says the PDAS loop of this fit has not converged (see k_commit).
+// ------------------------------------------------------------------------------------------
+template <int U, int CG, bool TWO>
+__global__ void __launch_bounds__(256) k_xtv(const double *__restrict__ X, long ld, int p, int nrb,
+                                             const double *__restrict__ v, const double *__restrict__ v2,
+                                             double *__restrict__ part, double *__restrict__ part2,
+                                             const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ncg = (p + CG - 1) / CG;
+  const long cg = wid / nrb;
+  const int rb = (int)(wid - cg * nrb);
+  if (cg >= ncg) return;
+  const long row0 = (long)rb * (128 * U) + lane * 2;
+  d2 vr[U], vr2[TWO ? U : 1];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    vr[u] = *reinterpret_cast<const d2 *>(v + row0 + u * 128);
+    if (TWO) vr2[u] = *reinterpret_cast<const d2 *>(v2 + row0 + u * 128);
+  }
+  double acc[CG], acc2[TWO ? CG : 1];
+  const int j0 = (int)cg * CG;
+#pragma unroll
+  for (int c = 0; c < CG; c++) {
+    int j = j0 + c;
+    j = j < p ? j : p - 1;  // tail group: recompute the last column, result discarded below
+    const double *col = X + (size_t)j * ld + row0;
+    d2 xv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) xv[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(col + u * 128));
+    double a = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      a = fma(xv[u].x, vr[u].x, a);
+      a = fma(xv[u].y, vr[u].y, a);
+      if (TWO) {
+        a2 = fma(xv[u].x * xv[u].x, vr2[u].x, a2);
+        a2 = fma(xv[u].y * xv[u].y, vr2[u].y, a2);
+      }
+    }
+    acc[c] = a;
+    if (TWO) acc2[c] = a2;
+  }
+  // butterfly: after the step with offset o the lanes with (lane & o) == 0 keep the lower half of
+  // the surviving columns.  CG is a power of two <= 16, so steps use offsets 32,16,8,4 (then 2,1 plain).
+  int colbits = 0;
+#pragma unroll
+  for (int h = CG / 2, o = 32; h >= 1; h >>= 1, o >>= 1) {
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < h; i++) {
+      double keep = up ? acc[i + h] : acc[i];
+      double send = up ? acc[i] : acc[i + h];
+      acc[i] = keep + __shfl_xor(send, o);
+      if (TWO) {
+        double keep2 = up ? acc2[i + h] : acc2[i];
+        double send2 = up ? acc2[i] : acc2[i + h];
+        acc2[i] = keep2 + __shfl_xor(send2, o);
+      }
+    }
+    colbits += up ? h : 0;
+  }
+  constexpr int REM = 64 / CG;  // lanes still holding partials of the same column
+  double s = acc[0], s2 = TWO ? acc2[0] : 0.0;
+#pragma unroll
+  for (int o = REM / 2; o >= 1; o >>= 1) {
+    s += __shfl_xor(s, o);
+    if (TWO) s2 += __shfl_xor(s2, o);
+  }
+  const int j = j0 + colbits;
+  if ((lane & (REM - 1)) == 0 && j < p) {
+    part[(size_t)rb * p + j] = s;
+    if (TWO) part2[(size_t)rb * p + j] = s2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// sacrifice scores.  LM: src/Algorithm.h:1109-1126 with 1x1 Phi (src/utilities.cpp:142-151,167-177).
+//   d_j = (sum_rb part[rb][j]) / n_t - 2 lambda beta_j ; phi_j = sqrt(2 lambda + xtx_j / n_t)
+//   bd_j = (phi_j beta_j + d_j / phi_j)^2 ; always_select -> DBL_MAX
+// GLM (logistic / Poisson), src/Algorithm.h:1236-1260, 1341-1364: d_j = s1 - 2 lambda beta_j,
+//   phi_j = sqrt(s2 + 2 lambda).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_score(const double *__restrict__ part, const double *__restrict__ part2,
+                                               int nrb, int p, const double *__restrict__ beta_dense,
+                                               const double *__restrict__ xtx, double n_t, double lambda, int glm,
+                                               const unsigned char *__restrict__ always, double *__restrict__ bd,
+                                               const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int rb = 0; rb < nrb; rb++) {
+    s1 += part[(size_t)rb * p + j];
+    if (glm) s2 += part2[(size_t)rb * p + j];
+  }
+  double b = beta_dense[j], d, phi;
+  if (glm) {
+    d = s1 - 2.0 * lambda * b;
+    phi = sqrt(s2 + 2.0 * lambda);
+  } else {
+    d = s1 / n_t - 2.0 * lambda * b;
+    phi = sqrt(2.0 * lambda + xtx[j] / n_t);
+  }
+  double inv = 1.0 / phi;
+  double t = phi * b + inv * d;
+  double v = t * t;
+  if (always != nullptr && always[j]) v = DBL_MAX;
+  bd[j] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: max_k (src/utilities.cpp:179-188).  One 1024-thread workgroup selects the k largest of
+// len <= 32768 non-negative doubles (ties -> lower index) and writes their indices ascending.
+// Keys are the raw bit patterns (monotone for non-negative doubles; NaN sorts above +inf).
+// The threshold (k-th largest key) is found bit by bit with ballot/popcount counting, the
+// selection is a block-wide ordered compaction.  idx_in (optional) gives the original index of
+// every element (second level of the two-level selection for len > 32768).
+// ------------------------------------------------------------------------------------------
+constexpr int TOPK_E = 32;  // keys per thread
+
+__device__ __forceinline__ unsigned long long score_key(double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? 0ull : b;  // -0.0 / negative (never produced) -> smallest
+}
+
+__global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score, const int *__restrict__ idx_in,
+                                               int len_total, int chunk, int k, int *__restrict__ out,
+                                               int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
+                                               int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  __shared__ int wcnt[2][16];
+  __shared__ int wsum[16];
+  __shared__ int wsum2[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = blockIdx.x * chunk;
+  const int len = min(chunk, len_total - base);
+  const int kk = min(k, len);
+  const int E = (len + 1023) / 1024;  // <= TOPK_E
+  const int e0 = tid * E;
+  unsigned long long key[TOPK_E];
+#pragma unroll
+  for (int e = 0; e < TOPK_E; e++) {
+    int i = e0 + e;
+    bool ok = e < E && i < len;
+    int src = ok ? (idx_in ? idx_in[base + i] : base + i) : 0;
+    key[e] = ok ? score_key(score[src]) : 0ull;
+  }
+  // threshold search: largest T with count(key >= T) >= kk.  Padding keys are 0 and never count
+  // because a candidate is always >= 1.
+  unsigned long long T = 0ull;
+  int par = 0;
+  for (int bit = 62; bit >= 0; bit--) {
+    const unsigned long long cand = T | (1ull << bit);
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < TOPK_E; e++) c += __popcll(__ballot(key[e] >= cand));
+    if (lane == 0) wcnt[par][wave] = c;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) tot += wcnt[par][w];
+    if (tot >= kk) T = cand;
+    par ^= 1;
+  }
+  // per-thread counts of keys > T and == T (valid elements only; T == 0 means "everything ties at 0")
+  int ngt = 0, neq = 0;
+#pragma unroll
+  for (int e = 0; e < TOPK_E; e++) {
+    bool ok = e < E && (e0 + e) < len;
+    ngt += (ok && key[e] > T) ? 1 : 0;
+    neq += (ok && key[e] == T) ? 1 : 0;
+  }
+  // exclusive block scans of neq and (later) of the selected count
+  auto block_excl_scan = [&](int v, int *ws, int &total) -> int {
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+      int s = ws[w];
+      off += (w < wave) ? s : 0;
+      tot += s;
+    }
+    total = tot;
+    __syncthreads();
+    return off + inc - v;
+  };
+  int tot_eq, tot_gt_dummy;
+  // total gt
+  int gt_before = block_excl_scan(ngt, wsum, tot_gt_dummy);
+  (void)gt_before;
+  const int need_eq = kk - tot_gt_dummy;  // how many ties to take, lowest indices first
+  int eq_before = block_excl_scan(neq, wsum2, tot_eq);
+  int take_eq = min(max(need_eq - eq_before, 0), neq);
+  int nsel = ngt + take_eq, tot_sel;
+  int pos = block_excl_scan(nsel, wsum, tot_sel);
+  int *o = out + (size_t)blockIdx.x * k;
+  int eq_seen = 0;
+#pragma unroll
+  for (int e = 0; e < TOPK_E; e++) {
+    bool ok = e < E && (e0 + e) < len;
+    bool sel = ok && key[e] > T;
+    if (ok && key[e] == T) {
+      sel = eq_seen < take_eq;
+      eq_seen++;
+    }
+    if (sel) {
+      o[pos] = idx_in ? idx_in[base + e0 + e] : base + e0 + e;
+      pos++;
+    }
+  }
+  if (tid == 0 && out_count != nullptr) out_count[blockIdx.x] = kk;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: Gram of the active panel on the fp64 matrix cores.
+//   G[a][b] = sum_i w_i * c_a[i] * c_b[i]   for the mp = 16*mt "Gram columns" c_0..c_{mp-1}
+// (pointers in colptr: columns of X, the all-ones / working-response vectors of the IRLS design,
+// or a zero vector for padding).  Only tiles (I,J), J <= I, are formed.
+//
+// One wave = one task (tile row I, up to GRAM_JC tiles J0..J0+nJ-1, row slab s); waves are fully
+// independent (no LDS, no barriers).  v_mfma_f64_16x16x4_f64 sums over 4 "k" rows per issue; which
+// physical row a k-slot means is free as long as A and B agree, so lane (c = lane&15, q = lane>>4)
+// loads the 4 consecutive rows row0+4q..row0+4q+3 of its column (32 contiguous bytes, 128 B per
+// column per 16-row step) and feeds element t of that vector to the t-th of 4 MFMAs.
+// C/D layout of the f64 MFMA: lane l, reg r holds D[row = (l>>4) + 4r][col = l&15]
+// (cdna guide section 3: "f64 MFMA does NOT use the f32 maps").
+// ------------------------------------------------------------------------------------------
+// A Gram column is named by an int: idx >= 0 -> column idx of X; idx < 0 -> column (-idx-1) of the
+// auxiliary matrix aux (same ld): aux column 0 = zeros (padding), 1 = ones on the data rows (intercept),
+// 2 = the IRLS working response.  Both bases are kernel arguments, so the loads stay global_load.
+__device__ __forceinline__ const double *gram_col(const double *__restrict__ X, const double *__restrict__ aux,
+                                                  long ld, int idx) {
+  return idx >= 0 ? X + (size_t)idx * ld : aux + (size_t)(-idx - 1) * ld;
+}
+
+template <int NJ, bool WEIGHTED>
+__device__ __forceinline__ void gram_body(const double *__restrict__ X, const double *__restrict__ aux, long ld,
+                                          const int *__restrict__ cols, const double *__restrict__ w,
+                                          const GramTask tk, long r_begin, long r_end, double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15, q = lane >> 4;
+  const double *pa = gram_col(X, aux, ld, cols[tk.I * 16 + c]) + 4 * q;
+  const double *pb[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; jj++) pb[jj] = gram_col(X, aux, ld, cols[(tk.J0 + jj) * 16 + c]) + 4 * q;
+  d4 acc[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; jj++) acc[jj] = d4{0.0, 0.0, 0.0, 0.0};
+  for (long r = r_begin; r < r_end; r += 16) {
+    d2 a0 = *reinterpret_cast<const d2 *>(pa + r), a1 = *reinterpret_cast<const d2 *>(pa + r + 2);
+    double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
+    if (WEIGHTED) {
+      d2 w0 = *reinterpret_cast<const d2 *>(w + r + 4 * q), w1 = *reinterpret_cast<const d2 *>(w + r + 4 * q + 2);
+      ax *= w0.x;
+      ay *= w0.y;
+      az *= w1.x;
+      aw *= w1.y;
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+      d2 b0 = *reinterpret_cast<const d2 *>(pb[jj] + r), b1 = *reinterpret_cast<const d2 *>(pb[jj] + r + 2);
+      double bx = b0.x, by = b0.y, bz = b1.x, bw = b1.y;
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc[jj], 0, 0, 0);
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc[jj], 0, 0, 0);
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, acc[jj], 0, 0, 0);
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, bw, acc[jj], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < NJ; jj++) {
+    const int t = tk.I * (tk.I + 1) / 2 + tk.J0 + jj;
+    *reinterpret_cast<d4 *>(out + (size_t)t * 256 + lane * 4) = acc[jj];
+  }
+}
+
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, const double *__restrict__ aux, long ld,
+                                              const int *__restrict__ cols, const double *__restrict__ w,
+                                              int rows_per_slab, const GramTask *__restrict__ tasks, int ntask,
+                                              int nslab, double *__restrict__ part, int ntiles,
+                                              const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+  if (ctrl != nullptr) {
+    if (ctrl->done || ctrl->l != slot - 1) return;
+    if (gate_mode == 1 && ctrl->irls_done) return;
+  }
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int slab = (int)(wid / ntask);
+  if (slab >= nslab) return;
+  const GramTask tk = tasks[wid - (long)slab * ntask];
+  const long r_begin = (long)slab * rows_per_slab;
+  const long r_end = min(r_begin + rows_per_slab, ld);
+  double *out = part + (size_t)slab * ntiles * 256;
+  switch (tk.nJ) {  // wave-uniform: tasks are cut into runs of 8, 4, 2 or 1 tiles of one tile row
+    case 8: gram_body<8, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
+    case 4: gram_body<4, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
+    case 2: gram_body<2, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
+    default: gram_body<1, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
+  }
+}
+
+// Sum the row-slab partials in slab order: Gt[t][e] = sum_s part[s][t][e].  One thread per element.
+__global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ part, int nslab, int ntiles,
+                                                     double *__restrict__ Gt, const FitCtrl *__restrict__ ctrl,
+                                                     int slot, int gate_mode) {
+  if (ctrl != nullptr) {
+    if (ctrl->done || ctrl->l != slot - 1) return;
+    if (gate_mode == 1 && ctrl->irls_done) return;
+  }
+  size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t tot = (size_t)ntiles * 256;
+  if (e >= tot) return;
+  double s = 0.0;
+  for (int sl = 0; sl < nslab; sl++) s += part[(size_t)sl * tot + e];
+  Gt[e] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: Cholesky factorisation and both triangular solves of the (m x m) normal equations in ONE
+// 512-thread workgroup, m + 1 <= 16*mt <= 256.
+//
+// Data placement: the lower triangle lives in REGISTERS for the whole factorisation, as 16x16 tiles
+// in the f64-MFMA accumulator layout, dealt round-robin to the 8 waves (<= 17 tiles = 136 VGPRs per
+// lane).  Per block column b: the owners publish the panel tiles (I,b) to LDS; wave 0 factors the
+// 16x16 diagonal block in LDS; one thread per sub-diagonal row does the 16-step substitution against
+// it; every wave then updates its own trailing tiles with 4 MFMAs per tile, operands read from the
+// LDS panel.  The right-hand side rides along as row mp-1 of the matrix, so the forward solve is the
+// factorisation itself; the backward solve walks the block columns in reverse with the L tiles still
+// in registers (per-tile 16-vector products folded with two shuffles).
+// ------------------------------------------------------------------------------------------
+constexpr int CH_W = 8;                                                   // waves
+constexpr int CH_MT = 16;                                                 // max tile rows
+constexpr int CH_SLOTS = (CH_MT * (CH_MT + 1) / 2 + CH_W - 1) / CH_W;     // 17
+constexpr int CH_LDT = 17;                                                // padded tile row stride (doubles)
+
+__device__ __forceinline__ void tile_of(int t, int &I, int &J) {
+  int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((i + 1) * (i + 2) / 2 <= t) i++;
+  while (i * (i + 1) / 2 > t) i--;
+  I = i;
+  J = t - i * (i + 1) / 2;
+}
+
+__global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int m, int mt, double ridge,
+                                              int ridge_skip0, const double *__restrict__ rhs,
+                                              const int *__restrict__ rhs_gather, double *__restrict__ sol,
+                                              int *__restrict__ info, const FitCtrl *__restrict__ ctrl, int slot,
+                                              int gate_mode) {
+  if (ctrl != nullptr) {
+    if (ctrl->done || ctrl->l != slot - 1) return;
+    if (gate_mode == 1 && ctrl->irls_done) return;
+  }
+  // LDS images are addressed by integer offsets.  The single-wave phases below pass data between
+  // lanes through LDS; WAVE_SYNC orders them (LDS executes one wave's DS operations in order; the
+  // fence keeps the compiler from moving accesses across it and drains lgkmcnt).
+  constexpr int TS = 16 * CH_LDT;             // doubles per padded tile
+  __shared__ double Psh[2 * CH_MT * TS];      // panel tiles, double buffered
+  __shared__ double Lsh[CH_MT * TS];          // factored diagonal blocks
+  __shared__ double z[CH_MT * 16];            // right-hand side / solution
+#define WAVE_SYNC()                                          \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile indices live in SGPRs
+  const int lc = lane & 15, lq = lane >> 4;
+  const int mp = mt * 16, ntiles = mt * (mt + 1) / 2;
+  d4 acc[CH_SLOTS];
+  int tI[CH_SLOTS], tJ[CH_SLOTS];
+#pragma unroll
+  for (int s = 0; s < CH_SLOTS; s++) {
+    int t = s * CH_W + wave;
+    tI[s] = -1;
+    tJ[s] = -1;
+    acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+    if (t < ntiles) {
+      tile_of(t, tI[s], tJ[s]);
+      d4 g = *reinterpret_cast<const d4 *>(Gt + (size_t)t * 256 + lane * 4);
+      double gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int row = tI[s] * 16 + lq + 4 * r, col = tJ[s] * 16 + lc;
+        double v = gv[r];
+        if (row == col && row < m && !(ridge_skip0 && row == 0)) v += ridge;
+        if (rhs != nullptr) {
+          // right-hand side supplied separately (LM: gathered X^T y): it becomes row mp-1
+          if (row >= m || col >= m) v = (row == col) ? 1.0 : 0.0;
+          if (row == mp - 1 && col < m) v = rhs[rhs_gather ? rhs_gather[col] : col];
+        } else {
+          // right-hand side is Gram column mp-1 already (IRLS); only fix the padding
+          bool rpad = row >= m && row != mp - 1, cpad = col >= m && col != mp - 1;
+          if (rpad || cpad) v = (row == col) ? 1.0 : 0.0;
+          if (row == mp - 1 && col == mp - 1) v = 1.0;
+        }
+        gv[r] = v;
+      }
+      acc[s] = d4{gv[0], gv[1], gv[2], gv[3]};
+    }
+  }
+  for (int b = 0; b < mt; b++) {
+    const int pb = (b & 1) * CH_MT * TS;  // panel buffer base
+    // 1. publish panel tiles (I, b)
+#pragma unroll
+    for (int s = 0; s < CH_SLOTS; s++)
+      if (tJ[s] == b) {
+        const int o = pb + tI[s] * TS + lq * CH_LDT + lc;
+        Psh[o] = acc[s].x;
+        Psh[o + 4 * CH_LDT] = acc[s].y;
+        Psh[o + 8 * CH_LDT] = acc[s].z;
+        Psh[o + 12 * CH_LDT] = acc[s].w;
+      }
+    __syncthreads();
+    // 2. factor the diagonal block in LDS (wave 0), keep a copy in Lsh
+    if (wave == 0) {
+      const int D = pb + b * TS;
+      for (int j = 0; j < 16; j++) {
+        double d = sqrt(Psh[D + j * CH_LDT + j]);
+        WAVE_SYNC();
+        if (lane == j) Psh[D + j * CH_LDT + j] = d;
+        if (lane > j && lane < 16) Psh[D + lane * CH_LDT + j] = Psh[D + lane * CH_LDT + j] / d;
+        WAVE_SYNC();
+        // trailing update of the lower triangle of the block: element (i, c), j < c <= i < 16
+        for (int e = lane; e < 256; e += 64) {
+          int i = e >> 4, cc = e & 15;
+          if (cc > j && cc <= i)
+            Psh[D + i * CH_LDT + cc] = Psh[D + i * CH_LDT + cc] - Psh[D + i * CH_LDT + j] * Psh[D + cc * CH_LDT + j];
+        }
+        WAVE_SYNC();
+      }
+      for (int e = lane; e < 256; e += 64)
+        Lsh[b * TS + (e >> 4) * CH_LDT + (e & 15)] = Psh[D + (e >> 4) * CH_LDT + (e & 15)];
+    }
+    __syncthreads();
+    // 3. rows below the block: x * Lbb^T = p, one thread per row, in place in LDS
+    if (tid < (mt - b - 1) * 16) {
+      const int pr = pb + (b + 1 + (tid >> 4)) * TS + (tid & 15) * CH_LDT;
+      const int L = b * TS;
+      for (int j = 0; j < 16; j++) {
+        double sacc = Psh[pr + j];
+        for (int t = 0; t < j; t++) sacc -= Psh[pr + t] * Lsh[L + j * CH_LDT + t];
+        Psh[pr + j] = sacc / Lsh[L + j * CH_LDT + j];
+      }
+    }
+    __syncthreads();
+    // 4. owners take the finished panel tile back; everyone updates its trailing tiles
+#pragma unroll
+    for (int s = 0; s < CH_SLOTS; s++) {
+      if (tJ[s] == b) {
+        const int o = pb + tI[s] * TS + lq * CH_LDT + lc;
+        acc[s] = d4{Psh[o], Psh[o + 4 * CH_LDT], Psh[o + 8 * CH_LDT], Psh[o + 12 * CH_LDT]};
+      } else if (tJ[s] > b) {
+        const int oi = pb + tI[s] * TS + lc * CH_LDT + lq;
+        const int oj = pb + tJ[s] * TS + lc * CH_LDT + lq;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+          double av = -Psh[oi + k4 * 4], bv = Psh[oj + k4 * 4];
+          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[s], 0, 0, 0);
+        }
+      }
+    }
+    // no barrier: the next step publishes into the other panel buffer, and three barriers separate
+    // this step's reads from the next write of this buffer.
+  }
+  // ---- backward solve  L^T x = y, y = row mp-1 of L (lanes 48..63, reg 3 of the tiles (mt-1, J))
+#pragma unroll
+  for (int s = 0; s < CH_SLOTS; s++)
+    if (tI[s] == mt - 1 && lq == 3) z[tJ[s] * 16 + lc] = acc[s].w;
+  __syncthreads();
+  if (tid == 0) z[mp - 1] = 0.0;  // the augmented row itself is not an unknown
+  __syncthreads();
+  for (int b = mt - 1; b >= 0; b--) {
+    if (wave == 0) {
+      const int zz = b * 16, L = b * TS;
+      for (int j = 15; j >= 0; j--) {
+        double xj = (b == mt - 1 && j == 15) ? 0.0 : z[zz + j] / Lsh[L + j * CH_LDT + j];
+        WAVE_SYNC();
+        if (lane == j) z[zz + j] = xj;
+        if (lane < j) z[zz + lane] = z[zz + lane] - Lsh[L + j * CH_LDT + lane] * xj;
+        WAVE_SYNC();
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < CH_SLOTS; s++) {
+      if (tI[s] == b && tJ[s] < b) {
+        const int zb = b * 16 + lq;
+        double v = acc[s].x * z[zb] + acc[s].y * z[zb + 4] + acc[s].z * z[zb + 8] + acc[s].w * z[zb + 12];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lq == 0) z[tJ[s] * 16 + lc] = z[tJ[s] * 16 + lc] - v;
+      }
+    }
+    __syncthreads();
+  }
+  bool bad = false;
+  if (tid < m) {
+    double v = z[tid];
+    sol[tid] = v;
+    bad = !(fabs(v) <= DBL_MAX);
+  }
+  if (__syncthreads_or(bad) && tid == 0 && info != nullptr) *info = 1;
+#undef WAVE_SYNC
+}
+
+// ------------------------------------------------------------------------------------------
+// Algorithm::fit bookkeeping (src/Algorithm.h:141-170) on the device.
+// ------------------------------------------------------------------------------------------
+// Start of a fit: beta <- beta_init (sparse), A_list.col(0) = 0, l = 0.
+__global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, int T0, int k_init,
+                                                   const int *__restrict__ init_idx,
+                                                   const double *__restrict__ init_val, double coef0_init,
+                                                   int *__restrict__ A_cur, double *__restrict__ b_cur,
+                                                   double *__restrict__ beta_dense, int *__restrict__ hist) {
+  // beta_dense was zeroed by a memset node just before this launch
+  for (int i = threadIdx.x; i < k_init; i += 256) {
+    A_cur[i] = init_idx[i];
+    b_cur[i] = init_val[i];
+    beta_dense[init_idx[i]] = init_val[i];
+  }
+  for (int i = threadIdx.x; i < T0; i += 256) hist[i] = 0;
+  if (threadIdx.x == 0) {
+    ctrl->done = 0;
+    ctrl->l = 0;
+    ctrl->T0 = T0;
+    ctrl->k_cur = k_init;
+    ctrl->coef0 = coef0_init;
+    ctrl->irls_done = 0;
+    ctrl->irls_steps = 0;
+    ctrl->info = 0;
+  }
+}
+
+// End of a PDAS iteration: beta <- 0; beta[A] = beta_A; A_list.col(l) = A; stop if A == A_list.col(ll), ll < l.
+// sol holds the solved coefficients; with an intercept (GLM) sol[0] is coef0 and sol[1..] the slopes.
+__global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int slot, int T0,
+                                                const int *__restrict__ A_new, const double *__restrict__ sol,
+                                                int has_intercept, int *__restrict__ A_cur,
+                                                double *__restrict__ b_cur, double *__restrict__ beta_dense,
+                                                int *__restrict__ hist, double *__restrict__ hist_beta,
+                                                double *__restrict__ hist_coef0, int hist_stride) {
+  if (ctrl->done || ctrl->l != slot - 1) return;
+  if (has_intercept && !ctrl->irls_done) return;  // IRLS still running: host will re-issue
+  __shared__ int same_any;
+  const int l = slot;
+  const int kc = ctrl->k_cur;
+  if (threadIdx.x == 0) same_any = 0;
+  for (int i = threadIdx.x; i < kc; i += 256) beta_dense[A_cur[i]] = 0.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < T0; i += 256) {
+    int a = A_new[i];
+    double b = sol[i + (has_intercept ? 1 : 0)];
+    A_cur[i] = a;
+    b_cur[i] = b;
+    beta_dense[a] = b;
+    hist[(size_t)l * hist_stride + i] = a;
+    hist_beta[(size_t)l * hist_stride + i] = b;
+  }
+  __syncthreads();
+  // compare with every earlier column (including the all-zero column 0)
+  for (int ll = 0; ll < l; ll++) {
+    int diff = 0;
+    for (int i = threadIdx.x; i < T0; i += 256) diff |= (hist[(size_t)ll * hist_stride + i] != A_new[i]);
+    diff = __syncthreads_or(diff);
+    if (!diff && threadIdx.x == 0) same_any = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (has_intercept) ctrl->coef0 = sol[0];
+    hist_coef0[l] = ctrl->coef0;
+    ctrl->k_cur = T0;
+    ctrl->l = l;
+    ctrl->done = same_any;
+    ctrl->irls_done = 0;
+    ctrl->irls_steps = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LM residual for the current beta: e_i = y_i - sum_a X[i,A_a] b_a - coef0 ; r_i = mask_i * e_i,
+// plus the two sums of squares needed by LmMetric (src/Metric.h:147 train, :190 CV test):
+//   sse[2*blk] = sum mask_i e_i^2, sse[2*blk+1] = sum (1-mask_i) e_i^2   (pad rows excluded).
+// when = slot  -> runs iff this slot's k_commit ran (ctrl->l == slot);  when = 0 -> start of fit.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_resid_lm(const double *__restrict__ X, long ld, int n,
+                                                  const double *__restrict__ y, const double *__restrict__ mask,
+                                                  const FitCtrl *__restrict__ ctrl, int when,
+                                                  const int *__restrict__ A_cur, const double *__restrict__ b_cur,
+                                                  double *__restrict__ r, double *__restrict__ sse) {
+  if (ctrl->l != when) return;
+  __shared__ double sm[4];
+  const int kc = ctrl->k_cur;
+  const double c0 = ctrl->coef0;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  double e = 0.0, mk = 0.0;
+  bool in = i < n;
+  if (in) {
+    double s = 0.0;
+    for (int a = 0; a < kc; a++) s = fma(X[(size_t)A_cur[a] * ld + i], b_cur[a], s);
+    e = y[i] - s - c0;
+    mk = mask ? mask[i] : 1.0;
+    r[i] = mk * e;
+  } else if (i < ld) {
+    r[i] = 0.0;
+  }
+  double s_tr = block_sum_256(in ? mk * e * e : 0.0, sm);
+  double s_te = block_sum_256(in ? (1.0 - mk) * e * e : 0.0, sm);
+  if (threadIdx.x == 0) {
+    sse[2 * blockIdx.x] = s_tr;
+    sse[2 * blockIdx.x + 1] = s_te;
+  }
+}
+
+// column sums of squares / cross products on a masked row set: out[j] = sum_i m_i x_ij^2 (xtx) --
+// group_XTX for 1x1 groups (src/utilities.cpp:153-165, src/Metric.h:108-129) -- via k_xtv with
+// v2 = mask; and X^T (m*y) via k_xtv with v = m*y.  Helper: v_out = a * b elementwise (or copy).
+__global__ void __launch_bounds__(256) k_vec_mul(const double *__restrict__ a, const double *__restrict__ b, long n,
+                                                 double *__restrict__ out) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = b ? a[i] * b[i] : a[i];
+}
+
+__global__ void __launch_bounds__(256) k_part_sum(const double *__restrict__ part, int nrb, int p,
+                                                  double *__restrict__ out) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  double s = 0.0;
+  for (int rb = 0; rb < nrb; rb++) s += part[(size_t)rb * p + j];
+  out[j] = s;
+}
+
+__global__ void __launch_bounds__(256) k_fill(double *__restrict__ a, long n, double v) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+// Gram column table: optional intercept, the new active columns, zero padding, optional working response.
+__global__ void __launch_bounds__(256) k_gram_cols(const int *__restrict__ A_new, int T0, int mp, int intercept,
+                                                   int rhs_col, int *__restrict__ cols,
+                                                   const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  // layout: [ones?] A_new[0..T0) zero padding ... [working response at mp-1 ?]
+  for (int i = threadIdx.x; i < mp; i += 256) {
+    int v = -1;  // aux column 0: zeros
+    int a = i - intercept;
+    if (intercept && i == 0) v = -2;
+    else if (a >= 0 && a < T0) v = A_new[a];
+    if (rhs_col && i == mp - 1) v = -3;
+    cols[i] = v;
+  }
+}
+
+// streaming copy used to measure the practical HBM ceiling
+__global__ void __launch_bounds__(256) k_copy(const d2 *__restrict__ src, d2 *__restrict__ dst, long n2) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  long stride = (long)gridDim.x * 256;
+  for (; i < n2; i += stride) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+#define LAUNCH_CHECK()                         \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return e__;         \
+  } while (0)
+
+hipError_t launch_transpose_in(const double *src, int rows, int p, double *X, long ld, long r0, hipStream_t st) {
+  dim3 grid((p + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(k_transpose_in, grid, dim3(256), 0, st, src, rows, p, X, ld, r0);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_normalize(double *X, long ld, int n, int p, double *y, const double *w, int data_type,
+                            int is_normal, int add_weight, double *x_mean, double *x_norm, double *y_mean,
+                            hipStream_t st) {
+  int centre = is_normal && (data_type == 1 || data_type == 2);
+  if (is_normal || add_weight) {
+    hipLaunchKernelGGL(k_col_normalize, dim3(p), dim3(256), 0, st, X, ld, n, p, w, centre, is_normal, add_weight,
+                       x_mean, x_norm);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_y_prepare, dim3(1), dim3(256), 0, st, y, n, w, (int)(is_normal && data_type == 1), add_weight,
+                     y_mean);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+int xtv_rows_per_block(int U) { return 128 * U; }
+
+template <int U, bool TWO>
+static hipError_t launch_xtv_t(const double *X, long ld, int p, const double *v, const double *v2, double *part,
+                               double *part2, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  constexpr int CG = 16;
+  int nrb = (int)(ld / (128 * U));
+  long nwaves = (long)nrb * ((p + CG - 1) / CG);
+  int nblk = (int)((nwaves + 3) / 4);
+  hipLaunchKernelGGL((k_xtv<U, CG, TWO>), dim3(nblk), dim3(256), 0, st, X, ld, p, nrb, v, v2, part, part2, ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_xtv(const double *X, long ld, int p, int U, const double *v, const double *v2, double *part,
+                      double *part2, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  bool two = v2 != nullptr;
+  switch (U) {
+    case 8: return two ? launch_xtv_t<8, true>(X, ld, p, v, v2, part, part2, ctrl, slot, st)
+                       : launch_xtv_t<8, false>(X, ld, p, v, v2, part, part2, ctrl, slot, st);
+    case 4: return two ? launch_xtv_t<4, true>(X, ld, p, v, v2, part, part2, ctrl, slot, st)
+                       : launch_xtv_t<4, false>(X, ld, p, v, v2, part, part2, ctrl, slot, st);
+    case 2: return two ? launch_xtv_t<2, true>(X, ld, p, v, v2, part, part2, ctrl, slot, st)
+                       : launch_xtv_t<2, false>(X, ld, p, v, v2, part, part2, ctrl, slot, st);
+    default: return two ? launch_xtv_t<1, true>(X, ld, p, v, v2, part, part2, ctrl, slot, st)
+                        : launch_xtv_t<1, false>(X, ld, p, v, v2, part, part2, ctrl, slot, st);
+  }
+}
+
+hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
+                        const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
+                        double *bd, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_score, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, beta_dense, xtx, n_t,
+                     lambda, glm, always, bd, ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// two-level selection: chunks of <= 32768 scores each keep their k best, a final block selects from the
+// concatenated candidates (already in ascending index order).  cand must hold nchunk*k ints.
+hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
+                       hipStream_t st) {
+  const int chunk = 1024 * TOPK_E;
+  if (len <= chunk) {
+    hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, st, score, (const int *)nullptr, len, chunk, k, out,
+                       (int *)nullptr, ctrl, slot);
+    LAUNCH_CHECK();
+    return hipSuccess;
+  }
+  int nchunk = (len + chunk - 1) / chunk;
+  long ncand = (long)nchunk * k;
+  if (ncand > chunk || k > chunk) return hipErrorInvalidValue;  // would need a third level
+  // every chunk is full except possibly the last; a short last chunk would leave holes in cand, so it
+  // is only allowed when it still holds >= k scores (checked by the caller via topk_supported()).
+  hipLaunchKernelGGL(k_topk, dim3(nchunk), dim3(1024), 0, st, score, (const int *)nullptr, len, chunk, k, cand,
+                     (int *)nullptr, ctrl, slot);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, st, score, (const int *)cand, (int)ncand, chunk, k, out,
+                     (int *)nullptr, ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+bool topk_supported(int len, int k) {
+  const int chunk = 1024 * TOPK_E;
+  if (len <= chunk) return k <= len;
+  int nchunk = (len + chunk - 1) / chunk;
+  int last = len - (nchunk - 1) * chunk;
+  return k <= last && (long)nchunk * k <= chunk;
+}
+
+hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
+                       int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
+                       double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st) {
+  long nwaves = (long)ntask * nslab;
+  int nblk = (int)((nwaves + 3) / 4);
+  if (w)
+    hipLaunchKernelGGL(k_gram<true>, dim3(nblk), dim3(256), 0, st, X, aux, ld, cols, w, rows_per_slab, tasks, ntask,
+                       nslab, part, ntiles, ctrl, slot, gate_mode);
+  else
+    hipLaunchKernelGGL(k_gram<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, cols, w, rows_per_slab, tasks, ntask,
+                       nslab, part, ntiles, ctrl, slot, gate_mode);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 255) / 256), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
+                     slot, gate_mode);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
+                       const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
+                       hipStream_t st) {
+  if (mt < 1 || mt > CH_MT || m + 1 > mt * 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_chol, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info,
+                     ctrl, slot, gate_mode);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
+                            double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
+                            hipStream_t st) {
+  hipError_t e = hipMemsetAsync(beta_dense, 0, (size_t)p * sizeof(double), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fit_begin, dim3(1), dim3(256), 0, st, ctrl, T0, k_init, init_idx, init_val, coef0_init, A_cur,
+                     b_cur, beta_dense, hist);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
+                         int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
+                         double *hist_coef0, int hist_stride, hipStream_t st) {
+  hipLaunchKernelGGL(k_commit, dim3(1), dim3(256), 0, st, ctrl, slot, T0, A_new, sol, has_intercept, A_cur, b_cur,
+                     beta_dense, hist, hist_beta, hist_coef0, hist_stride);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
+                           const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
+                           double *sse, hipStream_t st) {
+  int nblk = (int)((ld + 255) / 256);
+  hipLaunchKernelGGL(k_resid_lm, dim3(nblk), dim3(256), 0, st, X, ld, n, y, mask, ctrl, when, A_cur, b_cur, r, sse);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_vec_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n, out);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_part_sum, dim3((p + 255) / 256), dim3(256), 0, st, part, nrb, p, out);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_fill(double *a, long n, double v, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, n, v);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int rhs_col, int *cols,
+                            const FitCtrl *ctrl, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_gram_cols, dim3(1), dim3(256), 0, st, A_new, T0, mp, intercept, rhs_col, cols, ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_copy(const double *src, double *dst, long n, hipStream_t st) {
+  hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, st, reinterpret_cast<const d2 *>(src),
+                     reinterpret_cast<d2 *>(dst), n / 2);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+}  // namespace bessx

@@ -1,0 +1,178 @@
+/* include/bessx.h -- C ABI of libbessx.so, the MI355X-native PDAS best-subset solver.
+ *
+ * This is the drop-in boundary for the hot path of Mamba413/bess (reference paths are
+ * relative to /root/reference).  Plain pointers and sizes only; no C++/torch types.
+ * Every entry point returns 0 (BESSX_OK) or an error code; bessx_last_error() gives the
+ * message for the calling thread.  The library never falls back to a CPU path: if no
+ * HIP device is usable every compute entry point fails with BESSX_ERR_HIP.
+ *
+ * Layers (each cites the reference interface it replaces):
+ *   1. bessx_pywrap_bess      <- pywrap_bess, src/bess.h:35-51 (what SWIG binds, python/src/bess.i:17-30)
+ *   2. bessx_session_*        <- bessCpp, src/bess.h:20-33: Data + Algorithm* + Metric* set-up
+ *                                (src/bess.cpp:61-165) kept resident on the GPU, then
+ *                                sequential_path / gs_path (src/path.h:22-25)
+ *   3. bessx_session_fit      <- Algorithm::fit + the update_* setters, src/Algorithm.h:77-171
+ *   4. bessx_op_*             <- single Eigen call sites of the hot loop;
+ *                                exported so that every HIP kernel can be parity-tested alone.
+ */
+#ifndef BESSX_H
+#define BESSX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  BESSX_OK = 0,
+  BESSX_ERR_ARG = 1,         /* invalid argument (the reference would crash or read out of bounds) */
+  BESSX_ERR_HIP = 2,         /* HIP runtime / device failure, or no device */
+  BESSX_ERR_UNSUPPORTED = 3, /* valid for the reference, not built here (groups > 1, screening, Powell path) */
+  BESSX_ERR_NUMERIC = 4      /* non-finite pivot in a k x k solve */
+};
+
+const char *bessx_last_error(void);
+
+/* Device / build information: writes a NUL-terminated description (device name, CU count,
+ * code-object arch) into buf.  Fails with BESSX_ERR_HIP when no GPU is visible. */
+int bessx_device_info(char *buf, int buf_len);
+
+/* ---------------------------------------------------------------------------------------
+ * 1. Drop-in for pywrap_bess (src/bess.h:35-51, src/bess.cpp:218-281).
+ *    Identical argument list (bool -> int).  x is row-major x_row * x_col.  Writes
+ *    beta_out[0..x_col), *coef0_out, *train_loss_out, *ic_out exactly like the reference
+ *    (src/bess.cpp:277-280); additionally fills the slots the reference leaves
+ *    uninitialised: *nullloss_out (Data::get_nullloss, src/Data.h:120-130),
+ *    A_out[0..k) = selected support, *l_out = PDAS iterations of the selected candidate;
+ *    aic/bic/gic_out are set to 0.
+ *    Differences, all documented in INTEGRATION.md: is_cv draws folds from a fixed-seed
+ *    generator instead of std::random_device; invalid codes return BESSX_ERR_ARG instead of
+ *    dereferencing a null Algorithm* (src/bess.cpp:93-116).
+ * ------------------------------------------------------------------------------------- */
+int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int data_type, double *weight,
+                      int weight_len, int is_normal, int algorithm_type, int model_type, int max_iter,
+                      int exchange_num, int path_type, int is_warm_start, int ic_type, int is_cv, int K, int *gindex,
+                      int gindex_len, double *state, int state_len, int *sequence, int sequence_len,
+                      double *lambda_sequence, int lambda_sequence_len, int s_min, int s_max, int K_max,
+                      double epsilon, double lambda_min, double lambda_max, int n_lambda, int is_screening,
+                      int screening_size, int powell_path, int *always_select, int always_select_len, double tao,
+                      double *beta_out, int beta_out_len, double *coef0_out, int coef0_out_len,
+                      double *train_loss_out, int train_loss_out_len, double *ic_out, int ic_out_len,
+                      double *nullloss_out, double *aic_out, int aic_out_len, double *bic_out, int bic_out_len,
+                      double *gic_out, int gic_out_len, int *A_out, int A_out_len, int *l_out);
+
+/* ---------------------------------------------------------------------------------------
+ * 2. Session: the state bessCpp builds (src/bess.cpp:61-165), resident in HBM.
+ * ------------------------------------------------------------------------------------- */
+typedef struct bessx_session bessx_session;
+
+typedef struct {
+  int n, p;
+  const double *x;   /* host pointer */
+  int x_col_major;   /* 0: row-major n x p (NumPy / pywrap_bess); 1: column-major (R / bessCpp MatrixXd) */
+  const double *y;   /* n; for Cox: status, rows already sorted by time (python/bess/linear.py:257-263) */
+  const double *weight; /* n, or NULL for all ones */
+  int data_type;     /* 1 centre x,y + scale; 2 centre x + scale; 3 scale only (src/Data.h:79-93) */
+  int is_normal;
+  int model_type;    /* 1 LM, 2 logistic, 3 Poisson, 4 Cox (src/bess.cpp:95-111) */
+  int algorithm_type;/* 1 PDAS, 5 L0L2 (same code path, lambda from the path); 2/3 need groups of size 1 */
+  int max_iter;      /* PDAS iterations per fit (Algorithm::max_iter) */
+  int is_warm_start;
+  const int *always_select; /* indices kept in every active set (Algorithm::always_select), may be NULL */
+  int always_select_len;
+  int device;        /* HIP device ordinal, or -1 for the current device */
+} bessx_problem;
+
+int bessx_session_create(bessx_session **out, const bessx_problem *prob);
+void bessx_session_destroy(bessx_session *s);
+
+/* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)
+ * gives the test fold of row i; fold_id == NULL draws a permutation from mt19937(seed) and cuts
+ * it into K contiguous chunks exactly as src/Metric.h:66-78 does. */
+int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned seed);
+
+/* Results of a path run.  All pointers are caller-allocated; any of the *_all pointers may be
+ * NULL to skip that output.  Candidates are stored in evaluation order. */
+typedef struct {
+  double *beta;       /* p: best model, de-normalised (src/path.cpp:76-131, :330-388) */
+  double coef0, train_loss, ic, lambda;
+  int best_T0, best_iters;
+  int capacity;       /* candidate slots available in the arrays below */
+  int n_candidates;   /* out: candidates evaluated (may exceed capacity; extra ones are not stored) */
+  int *cand_T0;       /* capacity */
+  double *cand_lambda;/* capacity */
+  int *cand_iters;    /* capacity: PDAS iterations (Algorithm::l) of the full-data fit */
+  double *cand_train_loss, *cand_ic, *cand_coef0; /* capacity each; coef0 and beta are de-normalised
+                                                     like beta_all / coef0_all of the R build */
+  int *cand_support;  /* capacity * max_T0 (row per candidate, ascending, -1 padded) */
+  double *cand_beta;  /* capacity * max_T0: coefficients matching cand_support */
+  int max_T0;         /* row length of cand_support / cand_beta */
+  double device_seconds; /* out: wall time of the path on the device side (host clock around the loop) */
+  long long n_fits, n_pdas_iters; /* out: Algorithm::fit calls (incl. CV folds) and get_A calls */
+} bessx_path_result;
+
+/* sequential_path (src/path.cpp:25-132): sizes x lambdas in snake order, warm-start chain. */
+int bessx_session_sequential_path(bessx_session *s, const int *sequence, int sequence_len,
+                                  const double *lambda_seq, int lambda_len, int ic_type, int is_cv,
+                                  bessx_path_result *res);
+/* gs_path (src/path.cpp:134-389): integer golden section on [s_min, s_max] then exhaustive sweep. */
+int bessx_session_gs_path(bessx_session *s, int s_min, int s_max, int ic_type, int is_cv, bessx_path_result *res);
+
+/* Optional trace of every PDAS iteration of every fit of the LAST path run, same layout as the
+ * oracle's (oracle/bess_oracle.h): which = 0 geta_meta(int x4: l, T0, train_n, offset) 1 a_flat(int)
+ * 2 beta_flat(double) 3 coef0_calls(double) 4 loss_calls(double) 5 ic_calls(double). */
+int bessx_session_trace_enable(bessx_session *s, int on);
+int bessx_session_trace_size(bessx_session *s, int which);
+int bessx_session_trace_copy_int(bessx_session *s, int which, int *out);
+int bessx_session_trace_copy_double(bessx_session *s, int which, double *out);
+
+/* Normalisation results (Data::x_mean / x_norm / y_mean, src/Data.h:26-29). */
+int bessx_session_get_normalization(bessx_session *s, double *x_mean, double *x_norm, double *y_mean);
+
+/* Timing of the dominant kernel (the X^T r score pass, K1) accumulated since the last reset:
+ * HIP events recorded on the session's stream around every launch.  Used by bench.py for the
+ * roofline line.  seconds = sum of launch durations, launches = count, bytes = algorithmic
+ * bytes (8 * n * p per launch; doubled accumulators read the same bytes). */
+int bessx_session_score_pass_stats(bessx_session *s, int reset, double *seconds, long long *launches,
+                                   double *algorithmic_bytes);
+int bessx_session_enable_kernel_timing(bessx_session *s, int on);
+
+/* ---------------------------------------------------------------------------------------
+ * 3. One Algorithm::fit (src/Algorithm.h:113-171) on the resident data.
+ *    fold = -1: all rows; else the training rows of that CV fold (update_train_mask +
+ *    update_group_XTX, src/Metric.h:182-183).  init_* is the warm start (update_beta_init /
+ *    update_coef0_init) as a sparse vector.  Outputs: support[T0] ascending, beta[T0], coef0,
+ *    iters (Algorithm::l), train_loss = the family's train_loss on ALL rows (src/Metric.h:145,266,
+ *    426,565), test_loss = the family's CV test loss on the fold's test rows (0 when fold < 0).
+ * ------------------------------------------------------------------------------------- */
+int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx,
+                      const double *init_val, int init_len, double init_coef0, int *support, double *beta,
+                      double *coef0, int *iters, double *train_loss, double *test_loss);
+
+/* ---------------------------------------------------------------------------------------
+ * 4. Single-kernel entry points (host buffers in, host buffers out; each call uploads,
+ *    launches on the current device and synchronises).  They exist for parity tests.
+ * ------------------------------------------------------------------------------------- */
+/* K1: out[j] = sum_i x[i,j] * v[i]  (X^T v; src/Algorithm.h:1109,1236,1341).  x column-major, ld >= n.
+ * If v2 != NULL also out2[j] = sum_i x[i,j]^2 * v2[i] (K2; src/Algorithm.h:1240-1246). */
+int bessx_op_xtv(const double *x, int n, int p, int ld, const double *v, const double *v2, double *out,
+                 double *out2);
+/* K4: max_k (src/utilities.cpp:179-188): the k largest scores, indices ascending, ties -> lower index. */
+int bessx_op_topk(const double *score, int len, int k, int *out_idx);
+/* K6: out (m x m, column-major, full symmetric) = X_A^T diag(w) X_A for the m columns cols[] of x;
+ * w may be NULL (src/Algorithm.h:1134,1171,1199,1299). */
+int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m, const double *w, double *out);
+/* K7: solve the SPD system a * sol = b (a m x m column-major), Cholesky in one workgroup
+ * (stands in for ColPivHouseholderQR / LDLT solves, src/Algorithm.h:1134,1171,1199,1299,1473). */
+int bessx_op_chol_solve(const double *a, int m, const double *b, double *sol);
+/* K11: Normalize / Normalize3 / Normalize4 + add_weight (src/normalize.cpp:20-85, src/Data.h:70-77)
+ * on a column-major copy of x; returns the transformed x, y and the statistics. */
+int bessx_op_normalize(double *x, int n, int p, double *y, const double *weight, int data_type, int is_normal,
+                       int add_weight, double *x_mean, double *x_norm, double *y_mean);
+/* Device-to-device streaming copy rate in GB/s (read+write bytes / time): the measured HBM ceiling
+ * quoted next to the spec peak in bench.py. */
+int bessx_op_stream_copy_gbps(long long bytes, int repeats, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BESSX_H */

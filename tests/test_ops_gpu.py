@@ -1,0 +1,97 @@
+"""Parity of every HIP kernel, called alone through the C ABI (bessx_op_*), against NumPy / the
+plain-C oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from oracle import port_ctypes as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,p", [(97, 8), (130, 33), (1024, 17), (2500, 100), (5000, 257), (9000, 64)])
+def test_xtv_matches_numpy(gpu, n, p):
+    rng = np.random.default_rng(n * 1000 + p)
+    x = rng.standard_normal((n, p))
+    v = rng.standard_normal(n)
+    h = rng.uniform(0.1, 1.0, n)
+    want = x.T @ v
+    got = gpu.op_xtv(x, v)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    g1, g2 = gpu.op_xtv(x, v, h)
+    np.testing.assert_allclose(g1, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    np.testing.assert_allclose(g2, (x * x).T @ h, rtol=1e-12)
+    # bitwise reproducible run to run (fixed reduction tree, no atomics)
+    assert np.array_equal(got, gpu.op_xtv(x, v))
+
+
+@pytest.mark.parametrize("length,k", [(8, 3), (8, 8), (1000, 1), (1000, 37), (10000, 200), (20000, 150), (32768, 254),
+                                      (70000, 50), (100000, 200)])
+def test_topk_matches_oracle(gpu, length, k):
+    rng = np.random.default_rng(length + k)
+    s = rng.standard_normal(length) ** 2
+    got = gpu.op_topk(s, k)
+    assert np.array_equal(got, P.max_k(s, k))
+
+
+def test_topk_ties_and_specials(gpu):
+    s = np.array([1.0, 5.0, 5.0, 0.0, 5.0, 2.0, np.finfo(float).max, 5.0, 0.0, 1.0])
+    for k in range(1, 11):
+        assert np.array_equal(gpu.op_topk(s, k), P.max_k(s, k)), k
+    z = np.zeros(5000)
+    assert np.array_equal(gpu.op_topk(z, 7), np.arange(7))
+    s = np.arange(40000, dtype=float) % 97  # many ties across both selection levels
+    assert np.array_equal(gpu.op_topk(s, 120), P.max_k(s, 120))
+
+
+@pytest.mark.parametrize("n,p,m", [(97, 8, 3), (500, 40, 16), (1000, 60, 17), (3000, 300, 100), (5000, 400, 200),
+                                   (4096, 300, 255)])
+def test_gram_matches_numpy(gpu, n, p, m):
+    rng = np.random.default_rng(n + p + m)
+    x = rng.standard_normal((n, p))
+    cols = np.sort(rng.choice(p, m, replace=False))
+    w = rng.uniform(0.0, 2.0, n)
+    xa = x[:, cols]
+    g = gpu.op_gram(x, cols)
+    np.testing.assert_allclose(g, xa.T @ xa, rtol=1e-12, atol=1e-10)
+    gw = gpu.op_gram(x, cols, w)
+    np.testing.assert_allclose(gw, xa.T @ (xa * w[:, None]), rtol=1e-12, atol=1e-10)
+    assert np.array_equal(g, g.T)
+
+
+@pytest.mark.parametrize("m", [1, 2, 15, 16, 17, 31, 32, 100, 129, 200, 255])
+def test_chol_solve_matches_oracle(gpu, m):
+    rng = np.random.default_rng(m)
+    a = rng.standard_normal((m + 20, m))
+    g = a.T @ a + 0.1 * np.eye(m)
+    b = rng.standard_normal(m)
+    got = gpu.op_chol_solve(g, b)
+    want = P.sym_solve(g, b)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * np.abs(want).max())
+    np.testing.assert_allclose(g @ got, b, rtol=0, atol=1e-9 * max(1.0, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("data_type", [1, 2, 3])
+def test_normalize_matches_reference_formulas(gpu, data_type):
+    rng = np.random.default_rng(data_type)
+    n, p = 333, 21
+    x = rng.standard_normal((n, p)) * rng.uniform(0.5, 3, p) + rng.uniform(-2, 2, p)
+    y = rng.standard_normal(n) + 3
+    w = rng.uniform(0.5, 2.0, n)
+    xs, ys, xm, xn, ym = gpu.op_normalize(x, y, w, data_type, True, data_type == 1)
+    # src/normalize.cpp:20-85 restated with NumPy
+    xc = x.copy()
+    mean = (w @ xc) / n if data_type in (1, 2) else np.zeros(p)
+    xc = xc - mean
+    norm = np.sqrt(w @ (xc * xc))
+    xc = np.sqrt(n) * xc / norm
+    yc = y - (y @ w) / n if data_type == 1 else y.copy()
+    if data_type == 1:  # add_weight, src/Data.h:70-77
+        xc = xc * np.sqrt(w)[:, None]
+        yc = yc * np.sqrt(w)
+    np.testing.assert_allclose(xs, xc, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(ys, yc, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(xn, norm, rtol=1e-13)
+    if data_type in (1, 2):
+        np.testing.assert_allclose(xm, mean, rtol=1e-12, atol=1e-14)
+    if data_type == 1:
+        assert abs(ym - (y @ w) / n) < 1e-13
