@@ -18,9 +18,11 @@ struct FitCtrl {
   int irls_done;   // GLM sub-model fit converged (per PDAS iteration)
   int irls_steps;  // IRLS / Newton steps taken in the current PDAS iteration
   int info;        // non-zero: a k x k solve produced a non-finite value
-  int pad_;
+  int same_prev;   // this slot's active set equals the previous iteration's: solve + residual skipped
   double coef0;    // current intercept
   double ll0;      // GLM: log-likelihood of the previous iterate
+  int d_fresh;     // the score-pass partial sums in memory were computed from the CURRENT coefficients
+  int pad_;
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -34,6 +36,8 @@ hipError_t launch_normalize(double *X, long ld, int n, int p, double *y, const d
                             hipStream_t st);
 hipError_t launch_xtv(const double *X, long ld, int p, int U, const double *v, const double *v2, double *part,
                       double *part2, const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_xtv_variant(int variant, const double *X, long ld, int p, const double *v, double *part,
+                              hipStream_t st);
 hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
                         const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
                         double *bd, const FitCtrl *ctrl, int slot, hipStream_t st);
@@ -58,8 +62,8 @@ hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, con
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);
-hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int rhs_col, int *cols,
-                            const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int rhs_col, int *cols, FitCtrl *ctrl,
+                            int slot, const int *A_cur, int allow_skip, hipStream_t st);
 hipError_t launch_copy(const double *src, double *dst, long n, hipStream_t st);
 
 }  // namespace bessx

@@ -84,10 +84,17 @@ struct bessx_session {
   unsigned char *always = nullptr;
   // row sets: index 0 = all rows, 1..K = CV training rows of fold k-1
   std::vector<double *> mask, xtx, xty;
+  std::vector<double *> part_rs, r_rs;  // per row set: score-pass partial sums and residual of its last fit
+  struct RsCache {
+    bool valid = false;  // part_rs / r_rs belong to exactly (beta, coef0) below
+    SparseVec beta;
+    double coef0 = 0.0;
+  };
+  std::vector<RsCache> cache;
   std::vector<int> n_train;
   int K = 0;
   // work space
-  double *r = nullptr, *part = nullptr, *part2 = nullptr, *bd = nullptr, *beta_dense = nullptr, *sol = nullptr;
+  double *part2 = nullptr, *bd = nullptr, *beta_dense = nullptr, *sol = nullptr;
   double *tmpv = nullptr;
   int *A_new = nullptr, *cand = nullptr, *hist = nullptr, *gcols = nullptr, *info = nullptr;
   double *hist_beta = nullptr, *hist_coef0 = nullptr;
@@ -158,8 +165,8 @@ static void session_free(bessx_session *s) {
   for (auto q : s->mask) F(q);
   for (auto q : s->xtx) F(q);
   for (auto q : s->xty) F(q);
-  F(s->r);
-  F(s->part);
+  for (auto q : s->part_rs) F(q);
+  for (auto q : s->r_rs) F(q);
   F(s->part2);
   F(s->bd);
   F(s->beta_dense);
@@ -207,7 +214,7 @@ static int k1_begin(bessx_session *s, hipEvent_t *a, hipEvent_t *b) {
 static int k1_collect(bessx_session *s, const std::vector<std::pair<size_t, bool>> &pairs) {
   if (!s->timing) return 0;
   for (auto &pr : pairs) {
-    if (!pr.second) continue;
+    if (!pr.second || pr.first == (size_t)-1) continue;
     float ms = 0.f;
     HIPX(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.first + 1]));
     s->k1_seconds += (double)ms * 1e-3;
@@ -278,8 +285,8 @@ static int prepare_rowset(bessx_session *s, int rs) {
   // tmpv = m*y (or y), v2 = m (or ones on data rows = aux column 1)
   if (launch_vec_mul(s->y, m, s->ld, s->tmpv, s->st) != hipSuccess) return fail(BESSX_ERR_HIP, "vec_mul");
   const double *v2 = m ? m : s->aux + s->ld;
-  hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->tmpv, v2, s->part, s->part2, nullptr, 0, s->st);
-  if (e == hipSuccess) e = launch_part_sum(s->part, s->nrb, s->p, s->xty[rs], s->st);
+  hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->tmpv, v2, s->part_rs[rs], s->part2, nullptr, 0, s->st);
+  if (e == hipSuccess) e = launch_part_sum(s->part_rs[rs], s->nrb, s->p, s->xty[rs], s->st);
   if (e == hipSuccess) e = launch_part_sum(s->part2, s->nrb, s->p, s->xtx[rs], s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("prepare_rowset: ") + hipGetErrorString(e));
   return 0;
@@ -288,25 +295,32 @@ static int prepare_rowset(bessx_session *s, int rs) {
 // --------------------------------------------------------------------------------------------
 // Algorithm::fit (src/Algorithm.h:113-171), LM: GroupPdasLm::get_A / primary_model_fit (:1097-1135)
 // --------------------------------------------------------------------------------------------
-static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs,
+static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
                            std::vector<std::pair<size_t, bool>> &k1_pairs) {
   const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
   const int ntask = s->gtask_cnt[mt], ntiles = mt * (mt + 1) / 2;
   int rps, nslab;
   gram_geometry(s, ntask, &rps, &nslab);
   if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
-  hipEvent_t ea = nullptr, eb = nullptr;
-  if (int rc = k1_begin(s, &ea, &eb)) return rc;
-  hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->r, nullptr, s->part, nullptr, s->ctrl, slot, s->st);
-  if (s->timing && e == hipSuccess) {
-    e = hipEventRecord(eb, s->st);
-    k1_pairs.push_back({s->ev_used - 2, false});
+  hipError_t e = hipSuccess;
+  if (!skip_k1) {
+    // skip_k1: the partial sums of this row set were computed from exactly the coefficients this fit
+    // starts from (the previous fit ended on a repeated active set) -- get_A would recompute them bit for bit.
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (int rc = k1_begin(s, &ea, &eb)) return rc;
+    e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], nullptr, s->part_rs[rs], nullptr, s->ctrl, slot, s->st);
+    if (s->timing && e == hipSuccess) {
+      e = hipEventRecord(eb, s->st);
+      k1_pairs.push_back({s->ev_used - 2, false});
+    }
+  } else if (s->timing) {
+    k1_pairs.push_back({(size_t)-1, false});
   }
   if (e == hipSuccess)
-    e = launch_score(s->part, nullptr, s->nrb, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
-                     s->always, s->bd, s->ctrl, slot, s->st);
+    e = launch_score(s->part_rs[rs], nullptr, s->nrb, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs],
+                     lambda, 0, s->always, s->bd, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
   if (e == hipSuccess)
     e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, s->gtasks + s->gtask_off[mt], ntask, nslab,
                     s->gpart, ntiles, s->Gt, s->ctrl, slot, 0, s->st);
@@ -316,8 +330,8 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
     e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
                       s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
   if (e == hipSuccess)
-    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r, s->sse,
-                        s->st);
+    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
+                        s->sse, s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot: ") + hipGetErrorString(e));
   return 0;
 }
@@ -350,10 +364,18 @@ static int algorithm_fit(bessx_session *s) {
     HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, s->st));
     HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
   }
+  // Reuse across fits: when this fit starts from exactly the coefficients the last fit on this row set
+  // ended with, and that fit ended on a repeated active set, the residual and the score-pass sums in
+  // memory are the ones get_A would recompute (src/Algorithm.h:1109 depends only on beta, coef0 and the rows).
+  bessx_session::RsCache &cc = s->cache[rs];
+  const bool use_cache = cc.valid && cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx &&
+                         cc.beta.val == s->beta_init.val;
+  cc.valid = false;
   hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur,
                                   s->b_cur, s->beta_dense, s->p, s->hist, s->st);
-  if (e == hipSuccess)
-    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r, s->sse, s->st);
+  if (e == hipSuccess && !use_cache)
+    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
+                        s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("fit begin: ") + hipGetErrorString(e));
 
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
@@ -362,7 +384,7 @@ static int algorithm_fit(bessx_session *s) {
   while (true) {
     int first = slot;
     for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
-      if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, k1_pairs)) return rc;
+      if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
     if (int rc = read_results(s)) return rc;
     // slots first..l really ran K1; later ones fell through their gate
     for (size_t i = 0; i < k1_pairs.size(); i++) k1_pairs[i].second = (first + (int)i) <= hc->l;
@@ -387,6 +409,9 @@ static int algorithm_fit(bessx_session *s) {
   }
   s->sse_train = tr;
   s->sse_test = te;
+  cc.valid = hc->done && hc->d_fresh;
+  cc.beta = s->beta;
+  cc.coef0 = s->coef0;
   s->n_fits += 1;
   s->n_iters += hc->l;
   if (s->trace.on) {
@@ -645,6 +670,7 @@ static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const dou
   s->trace.clear();
   s->metric_depth = 0;
   for (auto &v : s->cv_init) v.clear();
+  for (auto &c : s->cache) c.valid = false;
   res->n_candidates = 0;
   s->n_fits = 0;
   s->n_iters = 0;
@@ -777,9 +803,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->x_norm, (size_t)p));
   HIPT(dmalloc(&s->y_mean_d, 1));
   HIPT(dmalloc(&s->always, (size_t)p));
-  HIPT(dmalloc(&s->r, (size_t)ld));
   HIPT(dmalloc(&s->tmpv, (size_t)ld));
-  HIPT(dmalloc(&s->part, (size_t)s->nrb * p));
   HIPT(dmalloc(&s->part2, (size_t)s->nrb * p));
   HIPT(dmalloc(&s->bd, (size_t)p));
   HIPT(dmalloc(&s->beta_dense, (size_t)p));
@@ -875,6 +899,12 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   s->xtx.push_back(q);
   HIPT(dmalloc(&q, (size_t)p));
   s->xty.push_back(q);
+  HIPT(dmalloc(&q, (size_t)s->nrb * p));
+  s->part_rs.push_back(q);
+  HIPT(dmalloc(&q, (size_t)ld));
+  HIPT(hipMemset(q, 0, (size_t)ld * sizeof(double)));
+  s->r_rs.push_back(q);
+  s->cache.assign(1, bessx_session::RsCache());
   if (s->model_type == 1) TRY(prepare_rowset(s, 0));
   HIPT(hipStreamSynchronize(s->st));
 #undef TRY
@@ -912,10 +942,15 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     (void)hipFree(s->mask[i]);
     (void)hipFree(s->xtx[i]);
     (void)hipFree(s->xty[i]);
+    (void)hipFree(s->part_rs[i]);
+    (void)hipFree(s->r_rs[i]);
   }
   s->mask.resize(1);
   s->xtx.resize(1);
   s->xty.resize(1);
+  s->part_rs.resize(1);
+  s->r_rs.resize(1);
+  s->cache.assign(K + 1, bessx_session::RsCache());
   s->n_train.resize(1);
   s->n_test.assign(K, 0);
   s->K = K;
@@ -932,14 +967,19 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     }
     s->n_test[k] = n - nt;
     if (nt < 1 || n - nt < 1) return fail(BESSX_ERR_ARG, "set_cv: empty train or test fold");
-    double *dm = nullptr, *q1 = nullptr, *q2 = nullptr;
+    double *dm = nullptr, *q1 = nullptr, *q2 = nullptr, *q3 = nullptr, *q4 = nullptr;
     HIPX(dmalloc(&dm, (size_t)s->ld));
     HIPX(hipMemcpy(dm, m.data(), (size_t)s->ld * sizeof(double), hipMemcpyHostToDevice));
     HIPX(dmalloc(&q1, (size_t)p));
     HIPX(dmalloc(&q2, (size_t)p));
+    HIPX(dmalloc(&q3, (size_t)s->nrb * p));
+    HIPX(dmalloc(&q4, (size_t)s->ld));
+    HIPX(hipMemset(q4, 0, (size_t)s->ld * sizeof(double)));
     s->mask.push_back(dm);
     s->xtx.push_back(q1);
     s->xty.push_back(q2);
+    s->part_rs.push_back(q3);
+    s->r_rs.push_back(q4);
     s->n_train.push_back(nt);
     if (s->model_type == 1)
       if (int rc = prepare_rowset(s, k + 1)) return rc;
@@ -1282,6 +1322,34 @@ int bessx_op_normalize(double *x, int n, int p, double *y, const double *weight,
   if (x_mean) HIPX(hipMemcpy(x_mean, dm, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
   if (x_norm) HIPX(hipMemcpy(x_norm, dn, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
   if (y_mean) HIPX(hipMemcpy(y_mean, dym, sizeof(double), hipMemcpyDeviceToHost));
+  return BESSX_OK;
+}
+
+int bessx_op_xtv_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms) {
+  if (int rc = need_device()) return rc;
+  if (n < 1 || p < 1 || repeats < 1 || !gbps) return fail(BESSX_ERR_ARG, "op_xtv_bench: bad arguments");
+  Scratch sc;
+  const long ld = ((long)n + 1023) / 1024 * 1024;  // valid for every variant (multiple of 128*U)
+  double *dX, *dv, *part;
+  HIPX(sc.alloc(&dX, (size_t)ld * p));
+  HIPX(sc.alloc(&dv, (size_t)ld));
+  HIPX(sc.alloc(&part, (size_t)(ld / 128) * p));
+  HIPX(launch_fill(dX, ld * (long)p, 1.0, nullptr));
+  HIPX(launch_fill(dv, ld, 0.5, nullptr));
+  hipEvent_t e0, e1;
+  HIPX(hipEventCreate(&e0));
+  HIPX(hipEventCreate(&e1));
+  HIPX(launch_xtv_variant(variant, dX, ld, p, dv, part, nullptr));
+  HIPX(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < repeats; i++) HIPX(launch_xtv_variant(variant, dX, ld, p, dv, part, nullptr));
+  HIPX(hipEventRecord(e1, nullptr));
+  HIPX(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPX(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbps = 8.0 * (double)n * (double)p * repeats / ((double)ms * 1e-3) / 1e9;
+  if (avg_ms) *avg_ms = ms / repeats;
   return BESSX_OK;
 }
 

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_y_prepare(double *__restrict__ y, int n
 // part[rb][j] receives the row-block partial; k_score_* adds the row blocks in fixed order.
 // Gate: runs only while ctrl says the PDAS loop of this fit has not converged (see k_commit).
 // ------------------------------------------------------------------------------------------
-template <int U, int CG, bool TWO>
+template <int U, int CG, bool TWO, bool NT = true>
 __global__ void __launch_bounds__(256) k_xtv(const double *__restrict__ X, long ld, int p, int nrb,
                                              const double *__restrict__ v, const double *__restrict__ v2,
                                              double *__restrict__ part, double *__restrict__ part2,
@@ -174,7 +174,9 @@ __global__ void __launch_bounds__(256) k_xtv(const double *__restrict__ X, long 
     const double *col = X + (size_t)j * ld + row0;
     d2 xv[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) xv[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(col + u * 128));
+    for (int u = 0; u < U; u++)
+      xv[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2 *>(col + u * 128))
+                 : *reinterpret_cast<const d2 *>(col + u * 128);
     double a = 0.0, a2 = 0.0;
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
                                               int nslab, double *__restrict__ part, int ntiles,
                                               const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
   if (ctrl != nullptr) {
-    if (ctrl->done || ctrl->l != slot - 1) return;
+    if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
     if (gate_mode == 1 && ctrl->irls_done) return;
   }
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -453,20 +455,30 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
   }
 }
 
-// Sum the row-slab partials in slab order: Gt[t][e] = sum_s part[s][t][e].  One thread per element.
+// Sum the row-slab partials: Gt[t][e] = sum_s part[s][t][e].  A block owns 32 consecutive elements; its
+// 8 thread groups each add every 8th slab, then the 8 group sums are added in group order (fixed tree).
 __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ part, int nslab, int ntiles,
                                                      double *__restrict__ Gt, const FitCtrl *__restrict__ ctrl,
                                                      int slot, int gate_mode) {
   if (ctrl != nullptr) {
-    if (ctrl->done || ctrl->l != slot - 1) return;
+    if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
     if (gate_mode == 1 && ctrl->irls_done) return;
   }
-  size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  size_t tot = (size_t)ntiles * 256;
-  if (e >= tot) return;
+  __shared__ double sm[8][33];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const size_t tot = (size_t)ntiles * 256;
+  const size_t e = (size_t)blockIdx.x * 32 + el;
   double s = 0.0;
-  for (int sl = 0; sl < nslab; sl++) s += part[(size_t)sl * tot + e];
-  Gt[e] = s;
+  if (e < tot)
+    for (int sl = g; sl < nslab; sl += 8) s += part[(size_t)sl * tot + e];
+  sm[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < tot) {
+    double t = sm[0][el];
+#pragma unroll
+    for (int q = 1; q < 8; q++) t += sm[q][el];
+    Gt[e] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -501,7 +513,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
                                               int *__restrict__ info, const FitCtrl *__restrict__ ctrl, int slot,
                                               int gate_mode) {
   if (ctrl != nullptr) {
-    if (ctrl->done || ctrl->l != slot - 1) return;
+    if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
     if (gate_mode == 1 && ctrl->irls_done) return;
   }
   // LDS images are addressed by integer offsets.  The single-wave phases below pass data between
@@ -682,6 +694,8 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
     ctrl->irls_done = 0;
     ctrl->irls_steps = 0;
     ctrl->info = 0;
+    ctrl->same_prev = 0;
+    ctrl->d_fresh = 0;
   }
 }
 
@@ -694,9 +708,24 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
                                                 int *__restrict__ hist, double *__restrict__ hist_beta,
                                                 double *__restrict__ hist_coef0, int hist_stride) {
   if (ctrl->done || ctrl->l != slot - 1) return;
+  const int l = slot;
+  if (ctrl->same_prev) {
+    // A == A_list.col(l-1): the re-fit reproduces the current coefficients; record and stop
+    for (int i = threadIdx.x; i < T0; i += 256) {
+      hist[(size_t)l * hist_stride + i] = A_cur[i];
+      hist_beta[(size_t)l * hist_stride + i] = b_cur[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      hist_coef0[l] = ctrl->coef0;
+      ctrl->l = l;
+      ctrl->done = 1;
+      ctrl->d_fresh = 1;  // the score-pass sums in memory belong to the final coefficients
+    }
+    return;
+  }
   if (has_intercept && !ctrl->irls_done) return;  // IRLS still running: host will re-issue
   __shared__ int same_any;
-  const int l = slot;
   const int kc = ctrl->k_cur;
   if (threadIdx.x == 0) same_any = 0;
   for (int i = threadIdx.x; i < kc; i += 256) beta_dense[A_cur[i]] = 0.0;
@@ -725,6 +754,7 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
     ctrl->k_cur = T0;
     ctrl->l = l;
     ctrl->done = same_any;
+    ctrl->d_fresh = 0;  // coefficients changed after the last score pass
     ctrl->irls_done = 0;
     ctrl->irls_steps = 0;
   }
@@ -741,7 +771,7 @@ __global__ void __launch_bounds__(256) k_resid_lm(const double *__restrict__ X, 
                                                   const FitCtrl *__restrict__ ctrl, int when,
                                                   const int *__restrict__ A_cur, const double *__restrict__ b_cur,
                                                   double *__restrict__ r, double *__restrict__ sse) {
-  if (ctrl->l != when) return;
+  if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;  // same_prev: beta, r and the sums are unchanged
   __shared__ double sm[4];
   const int kc = ctrl->k_cur;
   const double c0 = ctrl->coef0;
@@ -789,10 +819,22 @@ __global__ void __launch_bounds__(256) k_fill(double *__restrict__ a, long n, do
 }
 
 // Gram column table: optional intercept, the new active columns, zero padding, optional working response.
+// It also sets ctrl->same_prev: the new active set equals the one of the previous PDAS iteration of this fit
+// (l >= 1).  Then the restricted fit would reproduce the current coefficients bit for bit (same columns, same
+// rows, same lambda), so Gram, solve and residual are skipped and k_commit only records the iteration.
 __global__ void __launch_bounds__(256) k_gram_cols(const int *__restrict__ A_new, int T0, int mp, int intercept,
-                                                   int rhs_col, int *__restrict__ cols,
-                                                   const FitCtrl *__restrict__ ctrl, int slot) {
+                                                   int rhs_col, int *__restrict__ cols, FitCtrl *__restrict__ ctrl,
+                                                   int slot, const int *__restrict__ A_cur, int allow_skip) {
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  if (ctrl != nullptr) {
+    int diff = 1;
+    if (allow_skip && ctrl->l >= 1 && ctrl->k_cur == T0) {
+      diff = 0;
+      for (int i = threadIdx.x; i < T0; i += 256) diff |= (A_new[i] != A_cur[i]);
+    }
+    diff = __syncthreads_or(diff);
+    if (threadIdx.x == 0) ctrl->same_prev = diff ? 0 : 1;
+  }
   // layout: [ones?] A_new[0..T0) zero padding ... [working response at mp-1 ?]
   for (int i = threadIdx.x; i < mp; i += 256) {
     int v = -1;  // aux column 0: zeros
@@ -871,6 +913,36 @@ hipError_t launch_xtv(const double *X, long ld, int p, int U, const double *v, c
   }
 }
 
+// tuning aid: run one geometry variant of the score pass (U rows-per-lane factor, CG columns per wave,
+// nontemporal or plain loads) on its own
+template <int U, int CG, bool NT>
+static hipError_t launch_xtv_variant_t(const double *X, long ld, int p, const double *v, double *part, hipStream_t st) {
+  int nrb = (int)(ld / (128 * U));
+  long nwaves = (long)nrb * ((p + CG - 1) / CG);
+  int nblk = (int)((nwaves + 3) / 4);
+  hipLaunchKernelGGL((k_xtv<U, CG, false, NT>), dim3(nblk), dim3(256), 0, st, X, ld, p, nrb, v, (const double *)nullptr,
+                     part, (double *)nullptr, (const FitCtrl *)nullptr, 0);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_xtv_variant(int variant, const double *X, long ld, int p, const double *v, double *part,
+                              hipStream_t st) {
+  switch (variant) {
+    case 0: return launch_xtv_variant_t<8, 16, true>(X, ld, p, v, part, st);
+    case 1: return launch_xtv_variant_t<8, 16, false>(X, ld, p, v, part, st);
+    case 2: return launch_xtv_variant_t<8, 8, true>(X, ld, p, v, part, st);
+    case 3: return launch_xtv_variant_t<8, 8, false>(X, ld, p, v, part, st);
+    case 4: return launch_xtv_variant_t<4, 16, true>(X, ld, p, v, part, st);
+    case 5: return launch_xtv_variant_t<4, 16, false>(X, ld, p, v, part, st);
+    case 6: return launch_xtv_variant_t<4, 8, true>(X, ld, p, v, part, st);
+    case 7: return launch_xtv_variant_t<2, 16, true>(X, ld, p, v, part, st);
+    case 8: return launch_xtv_variant_t<8, 4, true>(X, ld, p, v, part, st);
+    case 9: return launch_xtv_variant_t<4, 4, true>(X, ld, p, v, part, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
                         const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
                         double *bd, const FitCtrl *ctrl, int slot, hipStream_t st) {
@@ -925,7 +997,7 @@ hipError_t launch_gram(const double *X, const double *aux, long ld, const int *c
     hipLaunchKernelGGL(k_gram<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, cols, w, rows_per_slab, tasks, ntask,
                        nslab, part, ntiles, ctrl, slot, gate_mode);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 255) / 256), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
+  hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 31) / 32), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
                      slot, gate_mode);
   LAUNCH_CHECK();
   return hipSuccess;
@@ -988,9 +1060,10 @@ hipError_t launch_fill(double *a, long n, double v, hipStream_t st) {
   return hipSuccess;
 }
 
-hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int rhs_col, int *cols,
-                            const FitCtrl *ctrl, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_gram_cols, dim3(1), dim3(256), 0, st, A_new, T0, mp, intercept, rhs_col, cols, ctrl, slot);
+hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int rhs_col, int *cols, FitCtrl *ctrl,
+                            int slot, const int *A_cur, int allow_skip, hipStream_t st) {
+  hipLaunchKernelGGL(k_gram_cols, dim3(1), dim3(256), 0, st, A_new, T0, mp, intercept, rhs_col, cols, ctrl, slot,
+                     A_cur, allow_skip);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -168,6 +168,9 @@ int bessx_op_chol_solve(const double *a, int m, const double *b, double *sol);
  * on a column-major copy of x; returns the transformed x, y and the statistics. */
 int bessx_op_normalize(double *x, int n, int p, double *y, const double *weight, int data_type, int is_normal,
                        int add_weight, double *x_mean, double *x_norm, double *y_mean);
+/* Tuning aid for K1: run geometry variant `variant` of the score pass `repeats` times on an n x p matrix
+ * generated on the device and report algorithmic GB/s (8*n*p bytes per launch) and the mean launch time. */
+int bessx_op_xtv_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms);
 /* Device-to-device streaming copy rate in GB/s (read+write bytes / time): the measured HBM ceiling
  * quoted next to the spec peak in bench.py. */
 int bessx_op_stream_copy_gbps(long long bytes, int repeats, double *gbps);
