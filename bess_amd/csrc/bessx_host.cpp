@@ -379,7 +379,7 @@ static int algorithm_fit(bessx_session *s) {
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("fit begin: ") + hipGetErrorString(e));
 
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
-  int slot = 1, batch = 3;
+  int slot = 1, batch = 2;  // warm-started fits usually stop after 2 iterations
   std::vector<std::pair<size_t, bool>> k1_pairs;
   while (true) {
     int first = slot;

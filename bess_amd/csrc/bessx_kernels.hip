@@ -17,6 +17,7 @@
 // reproducible run to run (no floating-point atomics anywhere).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 
@@ -236,13 +237,23 @@ __global__ void __launch_bounds__(256) k_score(const double *__restrict__ part, 
                                                const unsigned char *__restrict__ always, double *__restrict__ bd,
                                                const FitCtrl *__restrict__ ctrl, int slot) {
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
-  int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= p) return;
+  // 64 columns per block; the 4 thread groups each add every 4th row block, then the 4 group sums
+  // are added in group order (fixed tree).
+  __shared__ double sm1[4][65], sm2[4][65];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int rb = 0; rb < nrb; rb++) {
-    s1 += part[(size_t)rb * p + j];
-    if (glm) s2 += part2[(size_t)rb * p + j];
-  }
+  if (j < p)
+    for (int rb = g; rb < nrb; rb += 4) {
+      s1 += part[(size_t)rb * p + j];
+      if (glm) s2 += part2[(size_t)rb * p + j];
+    }
+  sm1[g][cl] = s1;
+  sm2[g][cl] = s2;
+  __syncthreads();
+  if (g != 0 || j >= p) return;
+  s1 = ((sm1[0][cl] + sm1[1][cl]) + sm1[2][cl]) + sm1[3][cl];
+  s2 = ((sm2[0][cl] + sm2[1][cl]) + sm2[2][cl]) + sm2[3][cl];
   double b = beta_dense[j], d, phi;
   if (glm) {
     d = s1 - 2.0 * lambda * b;
@@ -273,6 +284,7 @@ __device__ __forceinline__ unsigned long long score_key(double v) {
   return (b >> 63) ? 0ull : b;  // -0.0 / negative (never produced) -> smallest
 }
 
+template <int EB>  // keys per thread this instance can hold (bucket of ceil(len / 1024))
 __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score, const int *__restrict__ idx_in,
                                                int len_total, int chunk, int k, int *__restrict__ out,
                                                int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
@@ -285,25 +297,27 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
   const int base = blockIdx.x * chunk;
   const int len = min(chunk, len_total - base);
   const int kk = min(k, len);
-  const int E = (len + 1023) / 1024;  // <= TOPK_E
+  const int E = (len + 1023) / 1024;  // <= EB
   const int e0 = tid * E;
-  unsigned long long key[TOPK_E];
+  unsigned long long key[EB];
 #pragma unroll
-  for (int e = 0; e < TOPK_E; e++) {
+  for (int e = 0; e < EB; e++) {
     int i = e0 + e;
     bool ok = e < E && i < len;
     int src = ok ? (idx_in ? idx_in[base + i] : base + i) : 0;
     key[e] = ok ? score_key(score[src]) : 0ull;
   }
-  // threshold search: largest T with count(key >= T) >= kk.  Padding keys are 0 and never count
-  // because a candidate is always >= 1.
+  // Threshold search: build T bit by bit, keeping count(key >= T) >= kk.  As soon as the count is
+  // EXACTLY kk the set {key >= T} is the answer and the remaining bits need not be resolved (for
+  // continuous scores that happens ~log2(len) bits below the leading bit).  Padding keys are 0 and
+  // never count because a candidate is always >= 1.
   unsigned long long T = 0ull;
   int par = 0;
   for (int bit = 62; bit >= 0; bit--) {
     const unsigned long long cand = T | (1ull << bit);
     int c = 0;
 #pragma unroll
-    for (int e = 0; e < TOPK_E; e++) c += __popcll(__ballot(key[e] >= cand));
+    for (int e = 0; e < EB; e++) c += __popcll(__ballot(key[e] >= cand));
     if (lane == 0) wcnt[par][wave] = c;
     __syncthreads();
     int tot = 0;
@@ -311,11 +325,12 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     for (int w = 0; w < 16; w++) tot += wcnt[par][w];
     if (tot >= kk) T = cand;
     par ^= 1;
+    if (tot == kk) break;  // uniform: every thread computed the same tot
   }
   // per-thread counts of keys > T and == T (valid elements only; T == 0 means "everything ties at 0")
   int ngt = 0, neq = 0;
 #pragma unroll
-  for (int e = 0; e < TOPK_E; e++) {
+  for (int e = 0; e < EB; e++) {
     bool ok = e < E && (e0 + e) < len;
     ngt += (ok && key[e] > T) ? 1 : 0;
     neq += (ok && key[e] == T) ? 1 : 0;
@@ -333,19 +348,17 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     int off = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) {
-      int s = ws[w];
-      off += (w < wave) ? s : 0;
-      tot += s;
+      int sv = ws[w];
+      off += (w < wave) ? sv : 0;
+      tot += sv;
     }
     total = tot;
     __syncthreads();
     return off + inc - v;
   };
-  int tot_eq, tot_gt_dummy;
-  // total gt
-  int gt_before = block_excl_scan(ngt, wsum, tot_gt_dummy);
-  (void)gt_before;
-  const int need_eq = kk - tot_gt_dummy;  // how many ties to take, lowest indices first
+  int tot_eq, tot_gt;
+  (void)block_excl_scan(ngt, wsum, tot_gt);
+  const int need_eq = kk - tot_gt;  // how many ties to take, lowest indices first
   int eq_before = block_excl_scan(neq, wsum2, tot_eq);
   int take_eq = min(max(need_eq - eq_before, 0), neq);
   int nsel = ngt + take_eq, tot_sel;
@@ -353,7 +366,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
   int *o = out + (size_t)blockIdx.x * k;
   int eq_seen = 0;
 #pragma unroll
-  for (int e = 0; e < TOPK_E; e++) {
+  for (int e = 0; e < EB; e++) {
     bool ok = e < E && (e0 + e) < len;
     bool sel = ok && key[e] > T;
     if (ok && key[e] == T) {
@@ -766,32 +779,53 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
 //   sse[2*blk] = sum mask_i e_i^2, sse[2*blk+1] = sum (1-mask_i) e_i^2   (pad rows excluded).
 // when = slot  -> runs iff this slot's k_commit ran (ctrl->l == slot);  when = 0 -> start of fit.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_resid_lm(const double *__restrict__ X, long ld, int n,
+__global__ void __launch_bounds__(128) k_resid_lm(const double *__restrict__ X, long ld, int n,
                                                   const double *__restrict__ y, const double *__restrict__ mask,
                                                   const FitCtrl *__restrict__ ctrl, int when,
                                                   const int *__restrict__ A_cur, const double *__restrict__ b_cur,
                                                   double *__restrict__ r, double *__restrict__ sse) {
   if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;  // same_prev: beta, r and the sums are unchanged
-  __shared__ double sm[4];
+  __shared__ double sm[2][2];
   const int kc = ctrl->k_cur;
   const double c0 = ctrl->coef0;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  double e = 0.0, mk = 0.0;
-  bool in = i < n;
-  if (in) {
-    double s = 0.0;
-    for (int a = 0; a < kc; a++) s = fma(X[(size_t)A_cur[a] * ld + i], b_cur[a], s);
-    e = y[i] - s - c0;
-    mk = mask ? mask[i] : 1.0;
-    r[i] = mk * e;
-  } else if (i < ld) {
-    r[i] = 0.0;
+  // 128 threads x 2 rows: block b owns rows [256 b, 256 b + 256); ld is a multiple of 128 rows
+  const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  double s_tr = 0.0, s_te = 0.0;
+  if (i < ld) {
+    d2 acc0 = d2{0.0, 0.0}, acc1 = d2{0.0, 0.0}, acc2 = d2{0.0, 0.0}, acc3 = d2{0.0, 0.0};
+    int a = 0;
+    for (; a + 4 <= kc; a += 4) {
+      const d2 x0 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a] * ld + i);
+      const d2 x1 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a + 1] * ld + i);
+      const d2 x2 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a + 2] * ld + i);
+      const d2 x3 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a + 3] * ld + i);
+      acc0 += x0 * b_cur[a];
+      acc1 += x1 * b_cur[a + 1];
+      acc2 += x2 * b_cur[a + 2];
+      acc3 += x3 * b_cur[a + 3];
+    }
+    for (; a < kc; a++) acc0 += *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a] * ld + i) * b_cur[a];
+    const d2 sx = (acc0 + acc1) + (acc2 + acc3);
+    const d2 yv = *reinterpret_cast<const d2 *>(y + i);
+    d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
+    const bool in0 = i < n, in1 = i + 1 < n;  // pad rows: y = 0, x = 0, but coef0 must not leak into r
+    d2 e = d2{in0 ? yv.x - sx.x - c0 : 0.0, in1 ? yv.y - sx.y - c0 : 0.0};
+    if (!in0) mk.x = 0.0;
+    if (!in1) mk.y = 0.0;
+    *reinterpret_cast<d2 *>(r + i) = mk * e;
+    s_tr = mk.x * e.x * e.x + mk.y * e.y * e.y;
+    s_te = (in0 ? (1.0 - mk.x) * e.x * e.x : 0.0) + (in1 ? (1.0 - mk.y) * e.y * e.y : 0.0);
   }
-  double s_tr = block_sum_256(in ? mk * e * e : 0.0, sm);
-  double s_te = block_sum_256(in ? (1.0 - mk) * e * e : 0.0, sm);
+  s_tr = wave_sum(s_tr);
+  s_te = wave_sum(s_te);
+  if ((threadIdx.x & 63) == 0) {
+    sm[threadIdx.x >> 6][0] = s_tr;
+    sm[threadIdx.x >> 6][1] = s_te;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    sse[2 * blockIdx.x] = s_tr;
-    sse[2 * blockIdx.x + 1] = s_te;
+    sse[2 * blockIdx.x] = sm[0][0] + sm[1][0];
+    sse[2 * blockIdx.x + 1] = sm[0][1] + sm[1][1];
   }
 }
 
@@ -946,7 +980,7 @@ hipError_t launch_xtv_variant(int variant, const double *X, long ld, int p, cons
 hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
                         const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
                         double *bd, const FitCtrl *ctrl, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_score, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, beta_dense, xtx, n_t,
+  hipLaunchKernelGGL(k_score, dim3((p + 63) / 64), dim3(256), 0, st, part, part2, nrb, p, beta_dense, xtx, n_t,
                      lambda, glm, always, bd, ctrl, slot);
   LAUNCH_CHECK();
   return hipSuccess;
@@ -954,27 +988,39 @@ hipError_t launch_score(const double *part, const double *part2, int nrb, int p,
 
 // two-level selection: chunks of <= 32768 scores each keep their k best, a final block selects from the
 // concatenated candidates (already in ascending index order).  cand must hold nchunk*k ints.
+static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_in, int len, int chunk, int k,
+                                  int *out, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  const int per = (std::min(len, chunk) + 1023) / 1024;
+#define TOPK_GO(EB)                                                                                              \
+  hipLaunchKernelGGL(k_topk<EB>, dim3(nblk), dim3(1024), 0, st, score, idx_in, len, chunk, k, out, (int *)nullptr, \
+                     ctrl, slot)
+  if (per <= 2)
+    TOPK_GO(2);
+  else if (per <= 4)
+    TOPK_GO(4);
+  else if (per <= 8)
+    TOPK_GO(8);
+  else if (per <= 16)
+    TOPK_GO(16);
+  else
+    TOPK_GO(32);
+#undef TOPK_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
                        hipStream_t st) {
   const int chunk = 1024 * TOPK_E;
-  if (len <= chunk) {
-    hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, st, score, (const int *)nullptr, len, chunk, k, out,
-                       (int *)nullptr, ctrl, slot);
-    LAUNCH_CHECK();
-    return hipSuccess;
-  }
+  if (len <= chunk) return launch_topk_one(1, score, nullptr, len, chunk, k, out, ctrl, slot, st);
   int nchunk = (len + chunk - 1) / chunk;
   long ncand = (long)nchunk * k;
   if (ncand > chunk || k > chunk) return hipErrorInvalidValue;  // would need a third level
   // every chunk is full except possibly the last; a short last chunk would leave holes in cand, so it
   // is only allowed when it still holds >= k scores (checked by the caller via topk_supported()).
-  hipLaunchKernelGGL(k_topk, dim3(nchunk), dim3(1024), 0, st, score, (const int *)nullptr, len, chunk, k, cand,
-                     (int *)nullptr, ctrl, slot);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, st, score, (const int *)cand, (int)ncand, chunk, k, out,
-                     (int *)nullptr, ctrl, slot);
-  LAUNCH_CHECK();
-  return hipSuccess;
+  hipError_t e = launch_topk_one(nchunk, score, nullptr, len, chunk, k, cand, ctrl, slot, st);
+  if (e != hipSuccess) return e;
+  return launch_topk_one(1, score, cand, (int)ncand, chunk, k, out, ctrl, slot, st);
 }
 
 bool topk_supported(int len, int k) {
@@ -1037,7 +1083,7 @@ hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, con
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
                            double *sse, hipStream_t st) {
   int nblk = (int)((ld + 255) / 256);
-  hipLaunchKernelGGL(k_resid_lm, dim3(nblk), dim3(256), 0, st, X, ld, n, y, mask, ctrl, when, A_cur, b_cur, r, sse);
+  hipLaunchKernelGGL(k_resid_lm, dim3(nblk), dim3(128), 0, st, X, ld, n, y, mask, ctrl, when, A_cur, b_cur, r, sse);
   LAUNCH_CHECK();
   return hipSuccess;
 }
