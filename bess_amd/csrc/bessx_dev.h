@@ -22,7 +22,7 @@ struct FitCtrl {
   double coef0;    // current intercept
   double ll0;      // GLM: log-likelihood of the previous iterate
   int d_fresh;     // the score-pass partial sums in memory were computed from the CURRENT coefficients
-  int pad_;
+  int irls_last;   // IRLS steps the last committed sub-model fit took (host sizes its next batch from it)
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -59,6 +59,17 @@ hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, cons
 hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
                            double *sse, hipStream_t st);
+hipError_t launch_glm_eta_gh(int fam, const double *X, long ld, int n, const double *y, const double *w,
+                             const double *mask, const double *logfact, const FitCtrl *ctrl, int when,
+                             const int *A_cur, const double *b_cur, double *g, double *h, double *stats,
+                             hipStream_t st);
+hipError_t launch_glm_irls_begin(const FitCtrl *ctrl, int slot, int fam, int m, double *bcur, double *bprev,
+                                 hipStream_t st);
+hipError_t launch_glm_irls_prep(int fam, const double *X, long ld, int n, const double *y, const double *w,
+                                const double *mask, const FitCtrl *ctrl, int slot, int t, const int *A_new, int T0,
+                                const double *bcur, double *Wv, double *z, double *llpart, hipStream_t st);
+hipError_t launch_glm_irls_check(FitCtrl *ctrl, int slot, int t, int fam, const double *llpart, int nblk, int m,
+                                 double *bcur, double *bprev, hipStream_t st);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);

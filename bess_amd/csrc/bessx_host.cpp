@@ -85,6 +85,10 @@ struct bessx_session {
   // row sets: index 0 = all rows, 1..K = CV training rows of fold k-1
   std::vector<double *> mask, xtx, xty;
   std::vector<double *> part_rs, r_rs;  // per row set: score-pass partial sums and residual of its last fit
+  std::vector<double *> part2_rs, h_rs; // GLM: curvature partial sums and curvature weights (r_rs holds g)
+  double *logfact = nullptr;            // Poisson: sum_{j<=y_i} log j (src/poisson.cpp:27-41)
+  double *Wv = nullptr, *llpart = nullptr, *bcur = nullptr, *bprev = nullptr;  // IRLS work space
+  int irls_guess = 8;
   struct RsCache {
     bool valid = false;  // part_rs / r_rs belong to exactly (beta, coef0) below
     SparseVec beta;
@@ -167,6 +171,13 @@ static void session_free(bessx_session *s) {
   for (auto q : s->xty) F(q);
   for (auto q : s->part_rs) F(q);
   for (auto q : s->r_rs) F(q);
+  for (auto q : s->part2_rs) F(q);
+  for (auto q : s->h_rs) F(q);
+  F(s->logfact);
+  F(s->Wv);
+  F(s->llpart);
+  F(s->bcur);
+  F(s->bprev);
   F(s->part2);
   F(s->bd);
   F(s->beta_dense);
@@ -336,6 +347,82 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
   return 0;
 }
 
+
+// --------------------------------------------------------------------------------------------
+// GLM families: GroupPdasLogistic / GroupPdasPoisson get_A + primary_model_fit
+// (src/Algorithm.h:1148-1263, :1273-1367).  One PDAS iteration = score pass (two accumulators) -> top-k
+// -> IRLS on [1, X_A] as a chain of (prep, check, weighted Gram, Cholesky) steps that stops itself on the
+// device -> commit -> gradient / loss pass for the new coefficients.
+// --------------------------------------------------------------------------------------------
+static int glm_geometry(bessx_session *s, int T0, int *mt, int *mp, int *ntask, int *ntiles, int *rps, int *nslab) {
+  *mt = (T0 + 2 + 15) / 16;  // intercept + T0 columns + the working response
+  *mp = *mt * 16;
+  *ntask = s->gtask_cnt[*mt];
+  *ntiles = *mt * (*mt + 1) / 2;
+  gram_geometry(s, *ntask, rps, nslab);
+  if ((size_t)*nslab * *ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
+  return 0;
+}
+
+static int enqueue_glm_head(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
+                            std::vector<std::pair<size_t, bool>> &k1_pairs) {
+  const int fam = s->model_type;
+  int mt, mp, ntask, ntiles, rps, nslab;
+  if (int rc = glm_geometry(s, T0, &mt, &mp, &ntask, &ntiles, &rps, &nslab)) return rc;
+  hipError_t e = hipSuccess;
+  if (!skip_k1) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (int rc = k1_begin(s, &ea, &eb)) return rc;
+    e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], s->h_rs[rs], s->part_rs[rs], s->part2_rs[rs], s->ctrl, slot,
+                   s->st);
+    if (s->timing && e == hipSuccess) {
+      e = hipEventRecord(eb, s->st);
+      k1_pairs.push_back({s->ev_used - 2, false});
+    }
+  } else if (s->timing) {
+    k1_pairs.push_back({(size_t)-1, false});
+  }
+  if (e == hipSuccess)
+    e = launch_score(s->part_rs[rs], s->part2_rs[rs], s->nrb, s->p, s->beta_dense, nullptr, (double)s->n_train[rs],
+                     lambda, 1, s->always, s->bd, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+  // a repeated active set reproduces the logistic fit (cold start); Poisson restarts from the new intercept
+  if (e == hipSuccess)
+    e = launch_gram_cols(s->A_new, T0, mp, 1, 1, s->gcols, s->ctrl, slot, s->A_cur, fam == 2 ? 1 : 0, s->st);
+  if (e == hipSuccess) e = launch_glm_irls_begin(s->ctrl, slot, fam, T0 + 1, s->bcur, s->bprev, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_head: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, double lambda, int rs) {
+  const int fam = s->model_type;
+  int mt, mp, ntask, ntiles, rps, nslab;
+  if (int rc = glm_geometry(s, T0, &mt, &mp, &ntask, &ntiles, &rps, &nslab)) return rc;
+  double *z = s->aux + 2 * s->ld;
+  hipError_t e = launch_glm_irls_prep(fam, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, slot, t, s->A_new, T0,
+                                      s->bcur, s->Wv, z, s->llpart, s->st);
+  if (e == hipSuccess)
+    e = launch_glm_irls_check(s->ctrl, slot, t, fam, s->llpart, s->n_sse_blk, T0 + 1, s->bcur, s->bprev, s->st);
+  if (e == hipSuccess)
+    e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->Wv, rps, s->gtasks + s->gtask_off[mt], ntask, nslab, s->gpart,
+                    ntiles, s->Gt, s->ctrl, slot, 1, s->st);
+  if (e == hipSuccess)
+    e = launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot, 1,
+                    s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_irls_step: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int enqueue_glm_tail(bessx_session *s, int slot, int T0, int rs) {
+  hipError_t e = launch_commit(s->ctrl, slot, T0, s->A_new, s->bprev, 1, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+                               s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+  if (e == hipSuccess)
+    e = launch_glm_eta_gh(s->model_type, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->logfact, s->ctrl, slot,
+                          s->A_cur, s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_tail: ") + hipGetErrorString(e));
+  return 0;
+}
+
 static int read_results(bessx_session *s) {
   HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
   HIPX(hipStreamSynchronize(s->st));
@@ -350,7 +437,8 @@ static int algorithm_fit(bessx_session *s) {
     return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, min(p, " +
                                    std::to_string(T0_CAP) + ")]");
   if (!topk_supported(s->p, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: p too large for this sparsity level");
-  if (s->model_type != 1) return fail(BESSX_ERR_UNSUPPORTED, "model_type " + std::to_string(s->model_type) + " is not built yet");
+  if (s->model_type == 4) return fail(BESSX_ERR_UNSUPPORTED, "model_type 4 (Cox) is not built yet");
+  const bool glm = s->model_type != 1;
   // warm start: this->beta = beta_init; this->coef0 = coef0_init (src/Algorithm.h:147-148)
   const int k_init = (int)s->beta_init.idx.size();
   if (k_init > T0_CAP) return fail(BESSX_ERR_ARG, "initial support too large");
@@ -373,15 +461,20 @@ static int algorithm_fit(bessx_session *s) {
   cc.valid = false;
   hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur,
                                   s->b_cur, s->beta_dense, s->p, s->hist, s->st);
-  if (e == hipSuccess && !use_cache)
-    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
-                        s->st);
+  if (e == hipSuccess && !use_cache) {
+    if (!glm)
+      e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
+                          s->st);
+    else
+      e = launch_glm_eta_gh(s->model_type, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->logfact, s->ctrl, 0,
+                            s->A_cur, s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
+  }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("fit begin: ") + hipGetErrorString(e));
 
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
   int slot = 1, batch = 2;  // warm-started fits usually stop after 2 iterations
   std::vector<std::pair<size_t, bool>> k1_pairs;
-  while (true) {
+  while (!glm) {
     int first = slot;
     for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
       if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
@@ -392,6 +485,30 @@ static int algorithm_fit(bessx_session *s) {
     k1_pairs.clear();
     if (hc->done || slot > s->max_iter) break;
     batch = 2;
+  }
+  while (glm && slot <= s->max_iter) {
+    // one PDAS iteration per round: the IRLS chain is enqueued in guessed batches and stops itself
+    const int tmax = s->model_type == 2 ? 30 : 50;
+    if (int rc = enqueue_glm_head(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
+    int t = 0, steps_used = 0;
+    while (true) {
+      int upto = std::min(tmax, t + std::max(2, s->irls_guess) - 1);
+      for (; t <= upto; t++)
+        if (int rc = enqueue_glm_irls_step(s, slot, t, T0, lambda, rs)) return rc;
+      if (int rc = enqueue_glm_tail(s, slot, T0, rs)) return rc;
+      if (int rc = read_results(s)) return rc;
+      if (hc->l == slot) {  // committed (IRLS finished, or the active set repeated)
+        steps_used = hc->irls_last;
+        break;
+      }
+      if (t > tmax) return fail(BESSX_ERR_NUMERIC, "IRLS chain did not terminate");
+    }
+    for (size_t i = 0; i < k1_pairs.size(); i++) k1_pairs[i].second = true;
+    if (int rc = k1_collect(s, k1_pairs)) return rc;
+    k1_pairs.clear();
+    if (steps_used > 0) s->irls_guess = std::min(tmax + 1, steps_used + 1);
+    slot++;
+    if (hc->done) break;
   }
   if (hc->info) return fail(BESSX_ERR_NUMERIC, "non-finite value in the k x k solve (singular Gram matrix?)");
   // results
@@ -440,8 +557,16 @@ static int algorithm_fit(bessx_session *s) {
 // Metric (src/Metric.h).  Values come from sums the residual kernel already produced.
 // --------------------------------------------------------------------------------------------
 static double metric_train_loss_value(const bessx_session *s) {
-  // LmMetric::train_loss, src/Metric.h:145-148: ||y - X beta||^2 / n on ALL rows
-  return (s->sse_train + s->sse_test) / (double)s->n;
+  // LmMetric::train_loss, src/Metric.h:145-148: ||y - X beta||^2 / n on ALL rows (train + test rows of the mask)
+  if (s->model_type == 1) return (s->sse_train + s->sse_test) / (double)s->n;
+  // Logistic / Poisson train_loss, src/Metric.h:266-290, :426-440: -2 * (sum over ALL rows), kept in sse_train
+  return -2.0 * s->sse_train;
+}
+
+static double metric_fold_test_loss(const bessx_session *s, int k) {
+  if (s->model_type == 1) return s->sse_test / (double)(2 * s->n_test[k]);  // src/Metric.h:190
+  if (s->model_type == 2) return -2.0 * s->sse_test;                        // :349-351 (clamp +-25)
+  return -s->sse_test;                                                      // :489 Poisson
 }
 
 static int metric_train_loss(bessx_session *s, double *out) {
@@ -458,7 +583,7 @@ static int metric_test_loss(bessx_session *s, double *out) {
     s->cur_rows = k + 1;                               // update_train_mask + update_group_XTX
     if (int rc = algorithm_fit(s)) return rc;
     if (s->warm_start) s->cv_init[k] = s->beta;
-    acc += s->sse_test / (double)(2 * s->n_test[k]);   // :190
+    acc += metric_fold_test_loss(s, k);
   }
   *out = acc / (double)s->K;
   return 0;
@@ -476,7 +601,9 @@ static int metric_ic(bessx_session *s, int ic_type, int is_cv, double *out) {
     if (ic_type == 2) c = std::log(n);
     if (ic_type == 3) c = std::log(p) * std::log(std::log(n));
     if (ic_type == 4) c = std::log(n) + 2.0 * std::log(p);
-    *out = (ic_type >= 1 && ic_type <= 4) ? n * std::log(loss) + c * (double)s->sparsity_level : 0.0;
+    // LM: n log(loss) + c T0 (src/Metric.h:205-229); the other families: loss + c T0 (:365-389, :504-528, :624-648)
+    const double base = s->model_type == 1 ? n * std::log(loss) : loss;
+    *out = (ic_type >= 1 && ic_type <= 4) ? base + c * (double)s->sparsity_level : 0.0;
   }
   s->metric_depth--;
   if (rc == 0 && s->metric_depth == 0 && s->trace.on) s->trace.ic_calls.push_back(*out);
@@ -904,6 +1031,29 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&q, (size_t)ld));
   HIPT(hipMemset(q, 0, (size_t)ld * sizeof(double)));
   s->r_rs.push_back(q);
+  HIPT(dmalloc(&q, (size_t)s->nrb * p));
+  s->part2_rs.push_back(q);
+  HIPT(dmalloc(&q, (size_t)ld));
+  HIPT(hipMemset(q, 0, (size_t)ld * sizeof(double)));
+  s->h_rs.push_back(q);
+  HIPT(dmalloc(&s->Wv, (size_t)ld));
+  HIPT(hipMemset(s->Wv, 0, (size_t)ld * sizeof(double)));
+  HIPT(dmalloc(&s->llpart, (size_t)s->n_sse_blk));
+  HIPT(dmalloc(&s->bcur, 512));
+  HIPT(dmalloc(&s->bprev, 512));
+  HIPT(dmalloc(&s->logfact, (size_t)ld));
+  {
+    // sum_{j=1..y} log j per row, the loop of loglik_poisson (src/poisson.cpp:27-41); only Poisson reads it
+    std::vector<double> lf((size_t)ld, 0.0);
+    if (s->model_type == 3)
+      for (int i = 0; i < n; i++) {
+        double t = 0.0;
+        if (pb->y[i] != 1.0)
+          for (double j = 1.0; j <= pb->y[i]; j = j + 1.0) t = t + std::log(j);
+        lf[i] = t;
+      }
+    HIPT(hipMemcpy(s->logfact, lf.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
+  }
   s->cache.assign(1, bessx_session::RsCache());
   if (s->model_type == 1) TRY(prepare_rowset(s, 0));
   HIPT(hipStreamSynchronize(s->st));
@@ -944,12 +1094,16 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     (void)hipFree(s->xty[i]);
     (void)hipFree(s->part_rs[i]);
     (void)hipFree(s->r_rs[i]);
+    (void)hipFree(s->part2_rs[i]);
+    (void)hipFree(s->h_rs[i]);
   }
   s->mask.resize(1);
   s->xtx.resize(1);
   s->xty.resize(1);
   s->part_rs.resize(1);
   s->r_rs.resize(1);
+  s->part2_rs.resize(1);
+  s->h_rs.resize(1);
   s->cache.assign(K + 1, bessx_session::RsCache());
   s->n_train.resize(1);
   s->n_test.assign(K, 0);
@@ -980,6 +1134,11 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     s->xty.push_back(q2);
     s->part_rs.push_back(q3);
     s->r_rs.push_back(q4);
+    HIPX(dmalloc(&q3, (size_t)s->nrb * p));
+    HIPX(dmalloc(&q4, (size_t)s->ld));
+    HIPX(hipMemset(q4, 0, (size_t)s->ld * sizeof(double)));
+    s->part2_rs.push_back(q3);
+    s->h_rs.push_back(q4);
     s->n_train.push_back(nt);
     if (s->model_type == 1)
       if (int rc = prepare_rowset(s, k + 1)) return rc;
@@ -1088,7 +1247,7 @@ int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const i
   if (coef0) *coef0 = s->coef0;
   if (iters) *iters = s->l;
   if (train_loss) *train_loss = metric_train_loss_value(s);
-  if (test_loss) *test_loss = fold < 0 ? 0.0 : s->sse_test / (double)(2 * s->n_test[fold]);
+  if (test_loss) *test_loss = fold < 0 ? 0.0 : metric_fold_test_loss(s, fold);
   return BESSX_OK;
 }
 

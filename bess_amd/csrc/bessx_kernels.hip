@@ -769,6 +769,7 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
     ctrl->done = same_any;
     ctrl->d_fresh = 0;  // coefficients changed after the last score pass
     ctrl->irls_done = 0;
+    ctrl->irls_last = ctrl->irls_steps;
     ctrl->irls_steps = 0;
   }
 }
@@ -826,6 +827,222 @@ __global__ void __launch_bounds__(128) k_resid_lm(const double *__restrict__ X, 
   if (threadIdx.x == 0) {
     sse[2 * blockIdx.x] = sm[0][0] + sm[1][0];
     sse[2 * blockIdx.x + 1] = sm[0][1] + sm[1][1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GLM families (logistic: src/Algorithm.h:1138-1264, src/logistic.cpp:15-59; Poisson: :1266-1368).
+// FAM = 2 logistic, 3 Poisson.  Rows are handled two per thread (16-byte loads) like k_resid_lm.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double clampv(double v, double c) { return v > c ? c : (v < -c ? -c : v); }
+
+// linear predictor of two consecutive rows over k columns (optionally offset by one for an intercept slot)
+__device__ __forceinline__ d2 lin_pred2(const double *__restrict__ X, long ld, long i, const int *__restrict__ A,
+                                        const double *__restrict__ b, int k) {
+  d2 acc0 = d2{0.0, 0.0}, acc1 = d2{0.0, 0.0}, acc2 = d2{0.0, 0.0}, acc3 = d2{0.0, 0.0};
+  int a = 0;
+  for (; a + 4 <= k; a += 4) {
+    const d2 x0 = *reinterpret_cast<const d2 *>(X + (size_t)A[a] * ld + i);
+    const d2 x1 = *reinterpret_cast<const d2 *>(X + (size_t)A[a + 1] * ld + i);
+    const d2 x2 = *reinterpret_cast<const d2 *>(X + (size_t)A[a + 2] * ld + i);
+    const d2 x3 = *reinterpret_cast<const d2 *>(X + (size_t)A[a + 3] * ld + i);
+    acc0 += x0 * b[a];
+    acc1 += x1 * b[a + 1];
+    acc2 += x2 * b[a + 2];
+    acc3 += x3 * b[a + 3];
+  }
+  for (; a < k; a++) acc0 += *reinterpret_cast<const d2 *>(X + (size_t)A[a] * ld + i) * b[a];
+  return (acc0 + acc1) + (acc2 + acc3);
+}
+
+__device__ __forceinline__ void block_pair_sum_128(double a, double b, double *out2) {
+  __shared__ double smp[2][2];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    smp[threadIdx.x >> 6][0] = a;
+    smp[threadIdx.x >> 6][1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out2[0] = smp[0][0] + smp[1][0];
+    out2[1] = smp[0][1] + smp[1][1];
+  }
+}
+
+// get_A front half: gradient / curvature weights of the CURRENT coefficients, plus the loss sums.
+//   logistic (:1223-1235): eta clamp +-30, pr = e/(e+1), g = w (y - pr), h = w pr (1 - pr)
+//   Poisson  (:1338-1340): no clamp, g = (y - e) w, h = e w                 (training rows only: x mask)
+// stats[2 blk]   = sum over ALL rows of the train_loss summand (src/Metric.h:266-290, :426-440 / poisson.cpp:15-45)
+// stats[2 blk+1] = sum over the fold's TEST rows of the CV summand (:338-351 clamp +-25; :489)
+template <int FAM>
+__global__ void __launch_bounds__(128) k_glm_eta_gh(const double *__restrict__ X, long ld, int n,
+                                                    const double *__restrict__ y, const double *__restrict__ w,
+                                                    const double *__restrict__ mask,
+                                                    const double *__restrict__ logfact,
+                                                    const FitCtrl *__restrict__ ctrl, int when,
+                                                    const int *__restrict__ A_cur, const double *__restrict__ b_cur,
+                                                    double *__restrict__ g, double *__restrict__ h,
+                                                    double *__restrict__ stats) {
+  if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;
+  const int kc = ctrl->k_cur;
+  const double c0 = ctrl->coef0;
+  const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  double s_all = 0.0, s_te = 0.0;
+  if (i < ld) {
+    const d2 sx = lin_pred2(X, ld, i, A_cur, b_cur, kc);
+    const d2 yv = *reinterpret_cast<const d2 *>(y + i), wv = *reinterpret_cast<const d2 *>(w + i);
+    const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
+    double gg[2], hh[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const bool in = i + q < n;
+      const double eta = (q ? sx.y : sx.x) + c0, yy = q ? yv.y : yv.x, ww = q ? wv.y : wv.x, mm = q ? mk.y : mk.x;
+      double gq = 0.0, hq = 0.0;
+      if (in) {
+        if (FAM == 2) {
+          double e = exp(clampv(eta, 30.0)), pr = e / (e + 1.0);
+          gq = ww * (yy - pr) * mm;
+          hq = ww * pr * (1.0 - pr) * mm;
+          s_all += ww * (yy * log(pr) + (1.0 - yy) * log(1.0 - pr));
+          if (mm == 0.0) {
+            double e2 = exp(clampv(eta, 25.0)), p2 = e2 / (e2 + 1.0);
+            s_te += ww * (yy * log(p2) + (1.0 - yy) * log(1.0 - p2));
+          }
+        } else {
+          double e = exp(eta);
+          gq = (yy - e) * ww * mm;
+          hq = e * ww * mm;
+          double v = clampv(eta, 30.0), sv = (yy * v - exp(v) - logfact[i + q]) * ww;
+          s_all += sv;
+          if (mm == 0.0) s_te += sv;
+        }
+      }
+      gg[q] = gq;
+      hh[q] = hq;
+    }
+    *reinterpret_cast<d2 *>(g + i) = d2{gg[0], gg[1]};
+    *reinterpret_cast<d2 *>(h + i) = d2{hh[0], hh[1]};
+  }
+  block_pair_sum_128(s_all, s_te, stats + 2 * blockIdx.x);
+}
+
+// IRLS step t, front half: working weights and response at the iterate bcur on the design [1, X_Anew].
+//   logistic (:1160-1166 for t = 0, :1177-1194 for t >= 1): Pi = sigma(clamp eta); W = Pi(1-Pi), floored at
+//     0.001 only for t >= 1; z = eta + (y - Pi)/W with the UN-clamped eta; ll = sum w [y log Pi + (1-y) log(1-Pi)]
+//   Poisson (:1286-1314): t = 0 uses eta, exp(eta) as they are; t >= 1 clamps eta to +-30 and floors
+//     exp(eta) at 0.001; W = e w; z = eta + (y - e)/e; ll = sum w (y eta - e)
+// Writes Wv = W * w * mask (0 on pad rows), z, and the per-block log-likelihood partial.
+template <int FAM>
+__global__ void __launch_bounds__(128) k_glm_irls_prep(const double *__restrict__ X, long ld, int n,
+                                                       const double *__restrict__ y, const double *__restrict__ w,
+                                                       const double *__restrict__ mask,
+                                                       const FitCtrl *__restrict__ ctrl, int slot, int t,
+                                                       const int *__restrict__ A_new, int T0,
+                                                       const double *__restrict__ bcur, double *__restrict__ Wv,
+                                                       double *__restrict__ z, double *__restrict__ llpart) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
+  const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  double ll = 0.0;
+  if (i < ld) {
+    const d2 sx = lin_pred2(X, ld, i, A_new, bcur + 1, T0);
+    const double b0 = bcur[0];
+    const d2 yv = *reinterpret_cast<const d2 *>(y + i), wv = *reinterpret_cast<const d2 *>(w + i);
+    const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
+    double Wq[2], zq[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const bool in = i + q < n;
+      const double yy = q ? yv.y : yv.x, ww = q ? wv.y : wv.x, mm = q ? mk.y : mk.x;
+      double eta = (q ? sx.y : sx.x) + b0, Wt = 0.0, zt = 0.0;
+      if (in) {
+        if (FAM == 2) {
+          double e = exp(clampv(eta, 30.0)), Pi = e / (1.0 + e);
+          ll += (yy * log(Pi) + (1.0 - yy) * log(1.0 - Pi)) * ww * mm;
+          double W = Pi * (1.0 - Pi);
+          if (t > 0 && W < 0.001) W = 0.001;
+          zt = eta + (yy - Pi) / W;
+          Wt = W * ww * mm;
+        } else {
+          double e;
+          if (t == 0) {
+            e = exp(eta);
+          } else {
+            eta = clampv(eta, 30.0);
+            e = exp(eta);
+            if (e < 0.001) e = 0.001;
+            ll += (yy * eta - e) * ww * mm;
+          }
+          zt = eta + (yy - e) / e;
+          Wt = e * ww * mm;
+        }
+      }
+      Wq[q] = Wt;
+      zq[q] = zt;
+    }
+    *reinterpret_cast<d2 *>(Wv + i) = d2{Wq[0], Wq[1]};
+    *reinterpret_cast<d2 *>(z + i) = d2{zq[0], zq[1]};
+  }
+  __shared__ double sm[2];
+  ll = wave_sum(ll);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ll;
+  __syncthreads();
+  if (threadIdx.x == 0) llpart[blockIdx.x] = sm[0] + sm[1];
+}
+
+// IRLS step t, convergence test (single block).  Logistic (:1181): |ll0 - ll1| / (0.1 + |ll1|) < 1e-6, result =
+// iterate BEFORE the last solve, at most 30 tests; Poisson (:1315): |ll0 - ll1| / |0.1 + ll0| < 1e-6 with
+// ll0 = 1e5 initially, result = the latest iterate, at most 50 solves.  On exit with irls_done the
+// result sits in bprev (what k_commit reads).
+__global__ void __launch_bounds__(256) k_glm_irls_check(FitCtrl *__restrict__ ctrl, int slot, int t, int fam,
+                                                        const double *__restrict__ llpart, int nblk, int m,
+                                                        double *__restrict__ bcur, double *__restrict__ bprev) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
+  __shared__ double sm[4];
+  __shared__ int fin;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += llpart[b];
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) {
+    int done = 0;
+    if (fam == 2) {
+      if (t == 0) {
+        ctrl->ll0 = s;
+      } else {
+        if (fabs(ctrl->ll0 - s) / (0.1 + fabs(s)) < 1e-6) done = 1;  // result: bprev (iterate before last solve)
+        if (!done) ctrl->ll0 = s;
+      }
+      fin = done ? 2 : ((t == 30) ? 1 : 0);  // 2: keep bprev; 1: bprev <- bcur then stop; 0: bprev <- bcur, go on
+    } else {
+      if (t == 0) {
+        ctrl->ll0 = 1e5;
+      } else {
+        if (fabs(ctrl->ll0 - s) / fabs(0.1 + ctrl->ll0) < 1e-6) done = 1;
+        if (!done) ctrl->ll0 = s;
+      }
+      fin = (done || t == 50) ? 1 : 0;  // result is always the latest iterate
+    }
+  }
+  __syncthreads();
+  const int f = fin;
+  if (f != 2)
+    for (int i = threadIdx.x; i < m; i += 256) bprev[i] = bcur[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ctrl->irls_steps = t + 1;
+    if (f != 0) ctrl->irls_done = 1;
+  }
+}
+
+// start of the sub-model fit of one PDAS iteration: logistic starts from zero (:1155), Poisson from
+// (coef0, 0) (:1283-1285 after Algorithm::fit zeroed beta_A, :157)
+__global__ void __launch_bounds__(256) k_glm_irls_begin(const FitCtrl *__restrict__ ctrl, int slot, int fam, int m,
+                                                        double *__restrict__ bcur, double *__restrict__ bprev) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
+  for (int i = threadIdx.x; i < m; i += 256) {
+    double v = (fam == 3 && i == 0) ? ctrl->coef0 : 0.0;
+    bcur[i] = v;
+    bprev[i] = v;
   }
 }
 
@@ -1084,6 +1301,54 @@ hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, con
                            double *sse, hipStream_t st) {
   int nblk = (int)((ld + 255) / 256);
   hipLaunchKernelGGL(k_resid_lm, dim3(nblk), dim3(128), 0, st, X, ld, n, y, mask, ctrl, when, A_cur, b_cur, r, sse);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+template <int FAM>
+static hipError_t launch_glm_eta_gh_t(const double *X, long ld, int n, const double *y, const double *w,
+                                      const double *mask, const double *logfact, const FitCtrl *ctrl, int when,
+                                      const int *A_cur, const double *b_cur, double *g, double *h, double *stats,
+                                      hipStream_t st) {
+  int nblk = (int)((ld + 255) / 256);
+  hipLaunchKernelGGL(k_glm_eta_gh<FAM>, dim3(nblk), dim3(128), 0, st, X, ld, n, y, w, mask, logfact, ctrl, when,
+                     A_cur, b_cur, g, h, stats);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_glm_eta_gh(int fam, const double *X, long ld, int n, const double *y, const double *w,
+                             const double *mask, const double *logfact, const FitCtrl *ctrl, int when,
+                             const int *A_cur, const double *b_cur, double *g, double *h, double *stats,
+                             hipStream_t st) {
+  return fam == 2 ? launch_glm_eta_gh_t<2>(X, ld, n, y, w, mask, logfact, ctrl, when, A_cur, b_cur, g, h, stats, st)
+                  : launch_glm_eta_gh_t<3>(X, ld, n, y, w, mask, logfact, ctrl, when, A_cur, b_cur, g, h, stats, st);
+}
+
+hipError_t launch_glm_irls_begin(const FitCtrl *ctrl, int slot, int fam, int m, double *bcur, double *bprev,
+                                 hipStream_t st) {
+  hipLaunchKernelGGL(k_glm_irls_begin, dim3(1), dim3(256), 0, st, ctrl, slot, fam, m, bcur, bprev);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_glm_irls_prep(int fam, const double *X, long ld, int n, const double *y, const double *w,
+                                const double *mask, const FitCtrl *ctrl, int slot, int t, const int *A_new, int T0,
+                                const double *bcur, double *Wv, double *z, double *llpart, hipStream_t st) {
+  int nblk = (int)((ld + 255) / 256);
+  if (fam == 2)
+    hipLaunchKernelGGL(k_glm_irls_prep<2>, dim3(nblk), dim3(128), 0, st, X, ld, n, y, w, mask, ctrl, slot, t, A_new,
+                       T0, bcur, Wv, z, llpart);
+  else
+    hipLaunchKernelGGL(k_glm_irls_prep<3>, dim3(nblk), dim3(128), 0, st, X, ld, n, y, w, mask, ctrl, slot, t, A_new,
+                       T0, bcur, Wv, z, llpart);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_glm_irls_check(FitCtrl *ctrl, int slot, int t, int fam, const double *llpart, int nblk, int m,
+                                 double *bcur, double *bprev, hipStream_t st) {
+  hipLaunchKernelGGL(k_glm_irls_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, fam, llpart, nblk, m, bcur, bprev);
   LAUNCH_CHECK();
   return hipSuccess;
 }

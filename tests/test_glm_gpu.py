@@ -1,0 +1,77 @@
+"""Logistic and Poisson PDAS + IRLS on the GPU against the plain-C oracle: identical active sets at every
+PDAS iteration; coefficients within 1e-6 relative (IRLS iterates are compared after the same number of
+steps, so the tolerance covers summation-order differences only)."""
+import numpy as np
+import pytest
+
+from bess_amd import synth
+from oracle import port_ctypes as P
+from helpers import assert_same_trace
+from test_lm_gpu import run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def check(capi, X, y, kw, what, beta_rtol=1e-6):
+    want = P.trace(X, y, **kw)
+    got = run_gpu(capi, X, y, kw)
+    assert_same_trace(got["trace"], want, beta_rtol=beta_rtol, what=what)
+    sup_w = np.nonzero(want["beta"])[0]
+    assert np.array_equal(np.nonzero(got["beta"])[0], sup_w), what
+    np.testing.assert_allclose(got["beta"][sup_w], want["beta"][sup_w], rtol=beta_rtol)
+    np.testing.assert_allclose([got["coef0"], got["train_loss"], got["ic"]],
+                               [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-7, atol=1e-9)
+
+
+LOGIT = dict(data_type=2, model_type=2)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("seq", dict(ic_type=3, sequence=np.arange(1, 21))),
+    ("gs", dict(ic_type=4, path_type=2, s_min=1, s_max=30)),
+    ("nowarm", dict(ic_type=2, sequence=np.arange(1, 13), is_warm_start=False)),
+    ("lambda", dict(ic_type=3, sequence=np.arange(1, 9), lambda_seq=[0.0, 0.05])),
+    ("always", dict(ic_type=3, sequence=np.arange(2, 10), always_select=[3])),
+])
+def test_logistic_paths(gpu, name, kw):
+    X, y, _, _ = synth.make_logistic(1000, 200, 8)
+    check(gpu, X, y, dict(LOGIT, **kw), "logistic " + name)
+
+
+def test_logistic_cv_and_weights(gpu):
+    X, y, _, _ = synth.make_logistic(1000, 200, 8)
+    fold = synth.make_cv_folds(1000, 5)
+    check(gpu, X, y, dict(LOGIT, is_cv=True, K=5, cv_fold_id=fold, sequence=np.arange(1, 13)), "logistic cv")
+    w = np.random.default_rng(1).uniform(0.5, 2, 1000)
+    check(gpu, X, y, dict(LOGIT, ic_type=3, sequence=np.arange(1, 11), weight=w), "logistic weighted")
+
+
+def test_logistic_bigger(gpu):
+    X, y, _, _ = synth.make_logistic(6000, 500, 20, seed=11)
+    check(gpu, X, y, dict(LOGIT, ic_type=3, sequence=np.arange(1, 41)), "logistic 6000x500")
+
+
+def _poisson_data(n=800, p=150, seed=5):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p))
+    b = np.zeros(p)
+    b[:5] = [0.3, -0.4, 0.5, 0.2, -0.3]
+    return X, rng.poisson(np.exp(X @ b)).astype(float)
+
+
+POIS = dict(data_type=2, model_type=3)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("seq", dict(ic_type=3, sequence=np.arange(1, 13))),
+    ("gs", dict(ic_type=4, path_type=2, s_min=1, s_max=20)),
+])
+def test_poisson_paths(gpu, name, kw):
+    X, y = _poisson_data()
+    check(gpu, X, y, dict(POIS, **kw), "poisson " + name)
+
+
+def test_poisson_cv(gpu):
+    X, y = _poisson_data()
+    check(gpu, X, y, dict(POIS, is_cv=True, K=5, cv_fold_id=synth.make_cv_folds(800, 5), sequence=np.arange(1, 9)),
+          "poisson cv")
