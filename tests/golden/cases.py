@@ -1,0 +1,102 @@
+"""The golden cases: seeded inputs + the argument set of each reference run (shared by make_golden.py, which
+produced tests/golden/ref_small.npz from the compiled reference, and by the tests that replay them)."""
+import importlib.util
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def _synth():
+    spec = importlib.util.spec_from_file_location("bess_synth", os.path.join(ROOT, "bess_amd", "synth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def prostate():
+    M = np.loadtxt(os.path.join(HERE, "prostate.csv"), delimiter=",", skiprows=1)
+    return M[:, :8].copy(), M[:, 8].copy()
+
+
+def readme_lm():
+    """The reference's docstring example, python/bess/linear.py:441-465 (legacy NumPy seeding)."""
+    rs = np.random.RandomState(12345)
+    x = rs.normal(0, 1, 100 * 150).reshape((100, 150))
+    beta = np.hstack((np.array([1, 1, -1, -1, -1]), np.zeros(145)))
+    noise = rs.normal(0, 1, 100)
+    return x, np.matmul(x, beta) + noise
+
+
+def poisson_data(n=800, p=150, seed=5):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p))
+    b = np.zeros(p)
+    b[:5] = [0.3, -0.4, 0.5, 0.2, -0.3]
+    return X, rng.poisson(np.exp(X @ b)).astype(float)
+
+
+def all_cases():
+    S = _synth()
+    c = {}
+    Xp, yp = prostate()
+    c["prostate_seq_gic"] = (Xp, yp, dict(ic_type=3, sequence=np.arange(1, 9)))
+    c["prostate_one_k3"] = (Xp, yp, dict(ic_type=3, sequence=[3]))
+    c["prostate_gs_gic"] = (Xp, yp, dict(ic_type=3, path_type=2, s_min=1, s_max=8))
+    c["prostate_seq_ebic"] = (Xp, yp, dict(ic_type=4, sequence=np.arange(1, 9)))
+    c["prostate_nonorm"] = (Xp, yp, dict(ic_type=3, sequence=[3], is_normal=False))
+    Xr, yr = readme_lm()
+    c["readme_seq5"] = (Xr, yr, dict(ic_type=4, sequence=[5]))
+    c["readme_seq1_9"] = (Xr, yr, dict(ic_type=4, sequence=np.arange(1, 10)))
+    c["readme_gs20"] = (Xr, yr, dict(ic_type=4, path_type=2, s_min=1, s_max=20))
+    X, y, _, _ = S.make_lm(1000, 300, 10)
+    fold = S.make_cv_folds(1000, 5)
+    w = np.random.default_rng(1).uniform(0.5, 2, 1000)
+    c["lm_seq"] = (X, y, dict(ic_type=3, sequence=np.arange(1, 31)))
+    c["lm_seq_nowarm"] = (X, y, dict(ic_type=4, sequence=np.arange(1, 21), is_warm_start=False))
+    c["lm_gs"] = (X, y, dict(ic_type=3, path_type=2, s_min=1, s_max=40))
+    c["lm_seq_cv"] = (X, y, dict(is_cv=True, K=5, cv_fold_id=fold, sequence=np.arange(1, 21)))
+    c["lm_gs_cv"] = (X, y, dict(is_cv=True, K=5, cv_fold_id=fold, path_type=2, s_min=1, s_max=40))
+    c["lm_lambda"] = (X, y, dict(ic_type=3, sequence=np.arange(1, 11), lambda_seq=[0.0, 0.01, 0.1]))
+    c["lm_weight"] = (X, y, dict(ic_type=3, sequence=np.arange(1, 16), weight=w))
+    c["lm_nonorm"] = (X, y, dict(ic_type=3, sequence=np.arange(1, 16), is_normal=False))
+    c["lm_always"] = (X, y, dict(ic_type=3, sequence=np.arange(3, 16), always_select=[5, 7]))
+    X, y, _, _ = S.make_logistic(1000, 200, 8)
+    L = dict(data_type=2, model_type=2)
+    c["logit_seq"] = (X, y, dict(L, ic_type=3, sequence=np.arange(1, 21)))
+    c["logit_gs"] = (X, y, dict(L, ic_type=4, path_type=2, s_min=1, s_max=30))
+    c["logit_cv"] = (X, y, dict(L, is_cv=True, K=5, cv_fold_id=fold, sequence=np.arange(1, 13)))
+    c["logit_weight"] = (X, y, dict(L, ic_type=3, sequence=np.arange(1, 11), weight=w))
+    X, y = poisson_data()
+    Pm = dict(data_type=2, model_type=3)
+    c["poisson_seq"] = (X, y, dict(Pm, ic_type=3, sequence=np.arange(1, 13)))
+    c["poisson_cv"] = (X, y, dict(Pm, is_cv=True, K=5, cv_fold_id=S.make_cv_folds(800, 5), sequence=np.arange(1, 9)))
+    X, _, st, _, _ = S.make_cox(600, 100, 6)
+    C = dict(data_type=3, model_type=4)
+    c["cox_seq"] = (X, st, dict(C, ic_type=3, sequence=np.arange(1, 13)))
+    c["cox_gs"] = (X, st, dict(C, ic_type=4, path_type=2, s_min=1, s_max=20))
+    c["cox_cv"] = (X, st, dict(C, is_cv=True, K=5, cv_fold_id=S.make_cv_folds(600, 5), sequence=np.arange(1, 9)))
+    c["cox_weight"] = (X, st, dict(C, ic_type=3, sequence=np.arange(1, 9), weight=w[:600]))
+    return c
+
+
+def load_golden(name):
+    """Golden trace of one case in the same dict shape the oracle / GPU loaders return."""
+    z = np.load(os.path.join(HERE, "ref_small.npz"))
+    T0, tn, ni = z[name + "/fit_T0"], z[name + "/fit_train_n"], z[name + "/fit_iters"]
+    A, B, C0 = z[name + "/A_flat"], z[name + "/beta_flat"], z[name + "/coef0_flat"]
+    fits, off, it = [], 0, 0
+    for f in range(len(T0)):
+        fit = {"T0": int(T0[f]), "train_n": int(tn[f]), "iters": [], "betas": [], "coef0s": []}
+        for _ in range(int(ni[f])):
+            fit["iters"].append(A[off:off + T0[f]])
+            fit["betas"].append(B[off:off + T0[f]])
+            fit["coef0s"].append(float(C0[it]))
+            off += int(T0[f])
+            it += 1
+        fits.append(fit)
+    sc = z[name + "/scalars"]
+    return {"beta": z[name + "/beta"], "coef0": float(sc[0]), "train_loss": float(sc[1]), "ic": float(sc[2]),
+            "fits": fits, "loss_calls": z[name + "/loss_calls"], "ic_calls": z[name + "/ic_calls"]}

@@ -1,0 +1,90 @@
+"""GPU vs the committed golden vectors of the compiled reference (tests/golden/ref_small.npz): every LM /
+logistic / Poisson (and, once built, Cox) case -- active set of every PDAS iteration bit-exact, coefficients
+within 1e-6 relative (north_star tolerance), IC and loss values within 1e-8; plus the drop-in entry points
+(pywrap_bess through ctypes and through the pybind11 module, and the estimator classes)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import cases  # noqa: E402
+from helpers import assert_same_trace  # noqa: E402
+from test_lm_gpu import run_gpu  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+CASES = cases.all_cases()
+BUILT = [n for n in sorted(CASES) if CASES[n][2].get("model_type", 1) in (1, 2, 3)]  # Cox: see test_cox_gpu.py once built
+
+
+@pytest.mark.parametrize("name", BUILT)
+def test_gpu_matches_reference_golden(gpu, name):
+    X, y, kw = CASES[name]
+    want = cases.load_golden(name)
+    got = run_gpu(gpu, X, y, kw)
+    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what=name)
+    sup = np.nonzero(want["beta"])[0]
+    assert np.array_equal(np.nonzero(got["beta"])[0], sup)
+    np.testing.assert_allclose(got["beta"][sup], want["beta"][sup], rtol=1e-6)
+    np.testing.assert_allclose([got["coef0"], got["train_loss"], got["ic"]],
+                               [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-7, atol=1e-9)
+
+
+def _pywrap_args(X, y, data_type=1, model_type=1, sequence=(3,), ic_type=3, path_type=1, s_min=0, s_max=0):
+    n, p = X.shape
+    return (X, y, data_type, np.ones(n), True, 1, model_type, 20, 0, path_type, True, ic_type, False, 5, np.arange(p),
+            np.ones(n), list(sequence), [0.0], s_min, s_max, 0, 1e-4, 0.0, 0.0, 100, False, 1, 1, [], 0.0, p, 1, 1, 1,
+            1, 1, 1, p)
+
+
+def test_pywrap_bess_ctypes_and_pybind(gpu):
+    X, y = cases.prostate()
+    want = cases.load_golden("prostate_one_k3")
+    from bess_amd import _cbess
+    for fn in (gpu.pywrap_bess, _cbess.pywrap_bess):
+        r = fn(*_pywrap_args(X, y))
+        beta, coef0, loss, ic, _, _, _, _, a_out, l_out = r
+        np.testing.assert_allclose(beta, want["beta"], rtol=1e-6, atol=1e-12)
+        assert abs(coef0[0] - want["coef0"]) < 1e-7 and abs(ic[0] - want["ic"]) < 1e-7
+        assert abs(loss[0] - want["train_loss"]) < 1e-9
+        assert list(a_out[:3]) == [0, 1, 4] and l_out == 3
+    r = gpu.pywrap_bess(*_pywrap_args(X, y, path_type=2, s_min=1, s_max=8))
+    assert list(np.nonzero(r[0])[0]) == [0, 1, 4]
+
+
+def test_estimator_classes_readme_example(gpu):
+    import bess_amd
+    X, y = cases.readme_lm()
+    want = cases.load_golden("readme_seq5")
+    m = bess_amd.PdasLm(path_type="seq", sequence=[5])
+    m.fit(X=X, y=y)
+    assert list(np.nonzero(m.beta)[0]) == [0, 1, 2, 3, 4]
+    np.testing.assert_allclose(m.beta, want["beta"], rtol=1e-6, atol=1e-12)
+    assert abs(m.coef0[0] - want["coef0"]) < 1e-8 and abs(m.ic[0] - want["ic"]) < 1e-8
+    np.testing.assert_allclose(m.predict(X), X @ want["beta"] + want["coef0"], rtol=1e-6)
+    m = bess_amd.PdasLm(path_type="seq")  # default sequence 1..min(p, n/log n)
+    m.fit(X=X, y=y)
+    assert list(np.nonzero(m.beta)[0]) == [0, 1, 2, 3, 4]
+    m = bess_amd.PdasLm(path_type="pgs", s_max=20)
+    m.fit(X=X, y=y)
+    assert list(np.nonzero(m.beta)[0]) == [0, 1, 2, 3, 4] and abs(m.ic[0] - want["ic"]) < 1e-8
+
+
+def test_unsupported_and_invalid_requests_fail_loudly(gpu):
+    X, y = cases.prostate()
+    a = list(_pywrap_args(X, y))
+    bad = list(a)
+    bad[25] = True  # is_screening
+    with pytest.raises(gpu.BessxError) as e:
+        gpu.pywrap_bess(*bad)
+    assert e.value.code == 3
+    bad = list(a)
+    bad[14] = np.array([0, 2, 4, 6])  # group index: groups of size 2
+    with pytest.raises(gpu.BessxError):
+        gpu.pywrap_bess(*bad)
+    bad = list(a)
+    bad[16] = [9]  # sparsity level > p
+    with pytest.raises(gpu.BessxError) as e:
+        gpu.pywrap_bess(*bad)
+    assert e.value.code == 1

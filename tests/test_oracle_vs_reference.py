@@ -1,0 +1,35 @@
+"""CPU, build container only: the plain-C oracle against the compiled reference (oracle/_ref/libbess_ref.so)
+on fresh random problems that are NOT among the committed golden cases (different seeds, shapes, options).
+Skipped where the compiled reference is absent."""
+import numpy as np
+import pytest
+
+from bess_amd import synth
+from helpers import assert_same_trace
+from oracle import port_ctypes as P
+from oracle import ref_ctypes as R
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="compiled reference (oracle/_ref) not present")
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_lm_random(seed):
+    rng = np.random.default_rng(seed)
+    n, p = int(rng.integers(150, 600)), int(rng.integers(20, 200))
+    X, y, _, _ = synth.make_lm(n, p, min(6, p // 3), seed=seed)
+    kmax = min(p, 12)
+    for kw in (dict(ic_type=int(rng.integers(1, 5)), sequence=np.arange(1, kmax + 1)),
+               dict(ic_type=3, path_type=2, s_min=1, s_max=kmax),
+               dict(is_cv=True, K=4, cv_fold_id=synth.make_cv_folds(n, 4, seed=seed), sequence=np.arange(1, 7)),
+               dict(ic_type=2, sequence=[kmax, 3, 5], lambda_seq=[0.02, 0.0], max_iter=3)):
+        assert_same_trace(P.trace(X, y, **kw), R.trace(X, y, **kw), beta_rtol=1e-8, what="lm %d %r" % (seed, kw))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_glm_random(seed):
+    X, y, _, _ = synth.make_logistic(700, 90, 5, seed=seed)
+    kw = dict(data_type=2, model_type=2, ic_type=3, sequence=np.arange(1, 10))
+    assert_same_trace(P.trace(X, y, **kw), R.trace(X, y, **kw), beta_rtol=1e-8, what="logit %d" % seed)
+    Xc, _, st, _, _ = synth.make_cox(400, 60, 4, seed=seed)
+    kw = dict(data_type=3, model_type=4, ic_type=3, sequence=np.arange(1, 8))
+    assert_same_trace(P.trace(Xc, st, **kw), R.trace(Xc, st, **kw), beta_rtol=1e-8, what="cox %d" % seed)
