@@ -13,6 +13,8 @@ independent candidate chains: every rank holds a replica of X and solves the sam
 path for its OWN response vector (same X beta, rank-specific noise seed), i.e. N independent
 best-subset problems per step.  There is no data-path collective; the per-candidate IC curves are
 all-gathered over RCCL at the end of each step (8 B per candidate), as north_star prescribes.
+--shard kpath switches to strong scaling instead: ONE problem, s.list cut into N contiguous warm-start
+chains (bess_amd/dist.py partition), IC curve all-gathered, best k picked on every rank.
 
 Prints ONE JSON line on rank 0.
 """
@@ -74,11 +76,13 @@ def main():
     ap.add_argument("--kmax", type=int, default=200)
     ap.add_argument("--k-true", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=["replica", "kpath"], default="replica")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from bess_amd import capi
+    from bess_amd import dist as bdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -96,8 +100,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    X, y = make_problem(args.n, args.p, args.k_true, rank)
+    kpath = args.shard == "kpath" and distributed
+    X, y = make_problem(args.n, args.p, args.k_true, 0 if kpath else rank)
     seq = np.arange(1, args.kmax + 1)
+    if kpath:
+        lo, hi = bdist.partition(args.kmax, world, rank)
+        seq = seq[lo:hi]
     t0 = time.time()
     sess = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True)
     torch.cuda.synchronize()
@@ -115,11 +123,10 @@ def main():
     for _ in range(args.steps):
         out = sess.sequential_path(seq, ic_type=3)
         pdas_iters += out["n_pdas_iters"]
-        if distributed:  # gather the IC curve: the only collective of the path
-            mine = torch.tensor(out["cand_ic"], device="cuda")
-            gathered = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(gathered, mine)
-            ic_curves = gathered
+        if kpath:  # gather the IC curve: the only collective of the path
+            ic_curves = bdist.gather_curve(out["cand_ic"], args.kmax, world, rank, device="cuda")[None, :]
+        elif distributed:
+            ic_curves = bdist.gather_rows(out["cand_ic"], world, device="cuda")
     barrier()
     dt = time.time() - t0
     if distributed:
@@ -130,7 +137,7 @@ def main():
     sess.enable_kernel_timing(False)
 
     if rank == 0:
-        n_cand = args.kmax * args.steps * world
+        n_cand = args.kmax * args.steps * (1 if kpath else world)
         value = n_cand / dt
         avg_launch = k1["seconds"] / max(k1["launches"], 1)
         alg_bytes_launch = 8.0 * args.n * args.p
@@ -145,7 +152,7 @@ def main():
         line = {
             "metric": "candidate subsets solved/sec (n=50k,p=10k,k<=200 LM)", "value": value,
             "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if kpath else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: LM sequential path, Gaussian X n=%d p=%d, s.list=1..%d, GIC, "
                                    "warm start, max_iter=20, is_normal" % (args.n, args.p, args.kmax),
@@ -155,12 +162,13 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,
                          "avg_launch_ms": 1e3 * avg_launch, "launches_timed": k1["launches"]},
-            "pdas_iterations_per_candidate": pdas_iters / float(args.kmax * args.steps),
+            "pdas_iterations_per_candidate": pdas_iters / float(len(seq) * args.steps),
             "upload_and_normalise_seconds": upload_s,
             "selected_k": int(out["best_T0"]), "selected_ic": float(out["ic"]),
         }
         if ic_curves is not None:
-            line["ic_curves_gathered"] = len(ic_curves)
+            line["ic_curves_gathered"] = int(ic_curves.shape[0])
+            line["best_k_per_problem"] = [int(bdist.select_best(c)) + 1 for c in ic_curves]
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(X, y)

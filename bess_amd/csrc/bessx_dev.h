@@ -23,6 +23,10 @@ struct FitCtrl {
   double ll0;      // GLM: log-likelihood of the previous iterate
   int d_fresh;     // the score-pass partial sums in memory were computed from the CURRENT coefficients
   int irls_last;   // IRLS steps the last committed sub-model fit took (host sizes its next batch from it)
+  // Cox Newton line search (src/Algorithm.h:1474-1481)
+  int ls_done;     // step halving finished for the current Newton step
+  int ls_m;        // accepted exponent m (step 0.5^m)
+  double ll1;      // partial log-likelihood at the trial point
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -54,7 +58,7 @@ hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_i
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
                             hipStream_t st);
 hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
-                         int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
+                         int wait_chain, int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
                          double *hist_coef0, int hist_stride, hipStream_t st);
 hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
@@ -70,6 +74,30 @@ hipError_t launch_glm_irls_prep(int fam, const double *X, long ld, int n, const 
                                 const double *bcur, double *Wv, double *z, double *llpart, hipStream_t st);
 hipError_t launch_glm_irls_check(FitCtrl *ctrl, int slot, int t, int fam, const double *llpart, int nblk, int m,
                                  double *bcur, double *bprev, hipStream_t st);
+// Cox (src/Algorithm.h:1370-1650, src/coxph.cpp:16-40)
+struct CoxBufs {
+  double *E, *TH, *ET, *S0, *RS0, *SALL, *STEST;      // state pass: exp(eta), w*exp*mask, test-row exp, scans
+  double *EW, *WD;                                     // w*[delta!=0]*mask (get_A), w*delta*mask (fit)
+  double *ETA0, *THF, *S0F, *RS0F, *VG, *WG1, *UD, *TH1, *S1;  // Newton work vectors
+  double *M;                                           // n x k matrix S1/S0 (ld x 256)
+  double *g, *u, *b0;                                  // k-vectors: gradient, Newton direction, iterate
+  double *Gt2;                                         // second Gram (M^T diag(w delta) M) in tile layout
+  double *llpart;
+};
+hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,
+                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, CoxBufs cb,
+                            double *stats, hipStream_t st);
+hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb, CoxBufs cb, double *part,
+                                 double *part2, const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_cox_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
+                            double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
+                            hipStream_t st);
+hipError_t launch_cox_newton_begin(FitCtrl *ctrl, int slot, int k, CoxBufs cb, int *idcols, hipStream_t st);
+hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, int n, const double *mask,
+                                  FitCtrl *ctrl, int slot, int t, const int *A_new, int k, double lambda,
+                                  const int *gcols, const int *idcols, int mt, const GramTask *tasks, int ntask,
+                                  int rps, int nslab, double *gpart, int ntiles, double *Gt, CoxBufs cb,
+                                  hipStream_t st);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);

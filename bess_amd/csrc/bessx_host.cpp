@@ -89,6 +89,10 @@ struct bessx_session {
   double *logfact = nullptr;            // Poisson: sum_{j<=y_i} log j (src/poisson.cpp:27-41)
   double *Wv = nullptr, *llpart = nullptr, *bcur = nullptr, *bprev = nullptr;  // IRLS work space
   int irls_guess = 8;
+  int cox_state_rs = -1;
+  CoxBufs cox = {};                     // Cox work space (model_type 4 only)
+  std::vector<void *> cox_allocs;
+  int *idcols = nullptr;
   struct RsCache {
     bool valid = false;  // part_rs / r_rs belong to exactly (beta, coef0) below
     SparseVec beta;
@@ -178,6 +182,8 @@ static void session_free(bessx_session *s) {
   F(s->llpart);
   F(s->bcur);
   F(s->bprev);
+  for (auto q : s->cox_allocs) F(q);
+  F(s->idcols);
   F(s->part2);
   F(s->bd);
   F(s->beta_dense);
@@ -338,7 +344,7 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
   if (e == hipSuccess)
     e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
   if (e == hipSuccess)
-    e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+    e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
                       s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
   if (e == hipSuccess)
     e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
@@ -414,12 +420,65 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
 }
 
 static int enqueue_glm_tail(bessx_session *s, int slot, int T0, int rs) {
-  hipError_t e = launch_commit(s->ctrl, slot, T0, s->A_new, s->bprev, 1, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+  hipError_t e = launch_commit(s->ctrl, slot, T0, s->A_new, s->bprev, 1, 1, s->A_cur, s->b_cur, s->beta_dense, s->hist,
                                s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
   if (e == hipSuccess)
     e = launch_glm_eta_gh(s->model_type, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->logfact, s->ctrl, slot,
                           s->A_cur, s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_tail: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// Cox: GroupPdasCox::get_A (two passes over X: block sums, then per-column suffix scans with carries) and
+// primary_model_fit (damped Newton with step halving, everything gated on the device).
+// --------------------------------------------------------------------------------------------
+static int enqueue_cox_head(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
+                            std::vector<std::pair<size_t, bool>> &k1_pairs) {
+  const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
+  hipError_t e = hipSuccess;
+  if (!skip_k1) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (int rc = k1_begin(s, &ea, &eb)) return rc;
+    e = launch_cox_score_pass(s->X, s->ld, s->p, s->U, s->nrb, s->cox, s->part_rs[rs], s->part2_rs[rs], s->ctrl, slot,
+                              s->st);
+    if (s->timing && e == hipSuccess) {
+      e = hipEventRecord(eb, s->st);
+      k1_pairs.push_back({s->ev_used - 2, false});
+    }
+  } else if (s->timing) {
+    k1_pairs.push_back({(size_t)-1, false});
+  }
+  if (e == hipSuccess)
+    e = launch_cox_score(s->part_rs[rs], s->part2_rs[rs], s->nrb, s->p, s->beta_dense, lambda, s->always, s->bd,
+                         s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
+  if (e == hipSuccess) e = launch_cox_newton_begin(s->ctrl, slot, T0, s->cox, s->idcols, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cox_head: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int enqueue_cox_newton(bessx_session *s, int slot, int t, int T0, double lambda, int rs) {
+  const int mt = (T0 + 1 + 15) / 16;
+  const int ntask = s->gtask_cnt[mt], ntiles = mt * (mt + 1) / 2;
+  int rps, nslab;
+  gram_geometry(s, ntask, &rps, &nslab);
+  if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
+  hipError_t e = launch_cox_newton_step(s->X, s->aux, s->ld, s->n, s->mask[rs], s->ctrl, slot, t, s->A_new, T0, lambda,
+                                        s->gcols, s->idcols, mt, s->gtasks + s->gtask_off[mt], ntask, rps, nslab,
+                                        s->gpart, ntiles, s->Gt, s->cox, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cox_newton: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int enqueue_cox_tail(bessx_session *s, int slot, int T0, int rs) {
+  hipError_t e = launch_commit(s->ctrl, slot, T0, s->A_new, s->cox.b0, 0, 1, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+                               s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+  if (e == hipSuccess)
+    e = launch_cox_state(s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->cox,
+                         s->sse, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cox_tail: ") + hipGetErrorString(e));
   return 0;
 }
 
@@ -437,8 +496,8 @@ static int algorithm_fit(bessx_session *s) {
     return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, min(p, " +
                                    std::to_string(T0_CAP) + ")]");
   if (!topk_supported(s->p, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: p too large for this sparsity level");
-  if (s->model_type == 4) return fail(BESSX_ERR_UNSUPPORTED, "model_type 4 (Cox) is not built yet");
-  const bool glm = s->model_type != 1;
+  const bool glm = s->model_type != 1;  // sub-model fit is an iteration chain (IRLS or Newton)
+  const bool cox = s->model_type == 4;
   // warm start: this->beta = beta_init; this->coef0 = coef0_init (src/Algorithm.h:147-148)
   const int k_init = (int)s->beta_init.idx.size();
   if (k_init > T0_CAP) return fail(BESSX_ERR_ARG, "initial support too large");
@@ -456,8 +515,10 @@ static int algorithm_fit(bessx_session *s) {
   // ended with, and that fit ended on a repeated active set, the residual and the score-pass sums in
   // memory are the ones get_A would recompute (src/Algorithm.h:1109 depends only on beta, coef0 and the rows).
   bessx_session::RsCache &cc = s->cache[rs];
+  // (Cox keeps its state vectors once per session, not per row set, so it only reuses within one row set.)
   const bool use_cache = cc.valid && cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx &&
-                         cc.beta.val == s->beta_init.val;
+                         cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs);
+  if (cox) s->cox_state_rs = rs;
   cc.valid = false;
   hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur,
                                   s->b_cur, s->beta_dense, s->p, s->hist, s->st);
@@ -465,6 +526,9 @@ static int algorithm_fit(bessx_session *s) {
     if (!glm)
       e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                           s->st);
+    else if (cox)
+      e = launch_cox_state(s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->cox,
+                           s->sse, s->st);
     else
       e = launch_glm_eta_gh(s->model_type, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->logfact, s->ctrl, 0,
                             s->A_cur, s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
@@ -488,14 +552,19 @@ static int algorithm_fit(bessx_session *s) {
   }
   while (glm && slot <= s->max_iter) {
     // one PDAS iteration per round: the IRLS chain is enqueued in guessed batches and stops itself
-    const int tmax = s->model_type == 2 ? 30 : 50;
-    if (int rc = enqueue_glm_head(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
-    int t = 0, steps_used = 0;
+    const int tmax = s->model_type == 2 ? 30 : (cox ? 30 : 50);
+    if (cox) {
+      if (int rc = enqueue_cox_head(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
+    } else {
+      if (int rc = enqueue_glm_head(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
+    }
+    int t = cox ? 1 : 0, steps_used = 0;  // IRLS steps are numbered from 0, Newton steps from 1 (:1411)
     while (true) {
       int upto = std::min(tmax, t + std::max(2, s->irls_guess) - 1);
       for (; t <= upto; t++)
-        if (int rc = enqueue_glm_irls_step(s, slot, t, T0, lambda, rs)) return rc;
-      if (int rc = enqueue_glm_tail(s, slot, T0, rs)) return rc;
+        if (int rc = cox ? enqueue_cox_newton(s, slot, t, T0, lambda, rs) : enqueue_glm_irls_step(s, slot, t, T0, lambda, rs))
+          return rc;
+      if (int rc = cox ? enqueue_cox_tail(s, slot, T0, rs) : enqueue_glm_tail(s, slot, T0, rs)) return rc;
       if (int rc = read_results(s)) return rc;
       if (hc->l == slot) {  // committed (IRLS finished, or the active set repeated)
         steps_used = hc->irls_last;
@@ -559,13 +628,14 @@ static int algorithm_fit(bessx_session *s) {
 static double metric_train_loss_value(const bessx_session *s) {
   // LmMetric::train_loss, src/Metric.h:145-148: ||y - X beta||^2 / n on ALL rows (train + test rows of the mask)
   if (s->model_type == 1) return (s->sse_train + s->sse_test) / (double)s->n;
-  // Logistic / Poisson train_loss, src/Metric.h:266-290, :426-440: -2 * (sum over ALL rows), kept in sse_train
+  // Logistic / Poisson / Cox train_loss, src/Metric.h:266-290, :426-440, :565-568: -2 * (sum over ALL rows),
+  // the sum being kept in sse_train
   return -2.0 * s->sse_train;
 }
 
 static double metric_fold_test_loss(const bessx_session *s, int k) {
   if (s->model_type == 1) return s->sse_test / (double)(2 * s->n_test[k]);  // src/Metric.h:190
-  if (s->model_type == 2) return -2.0 * s->sse_test;                        // :349-351 (clamp +-25)
+  if (s->model_type == 2 || s->model_type == 4) return -2.0 * s->sse_test;  // :349-351 (clamp +-25), :609 Cox
   return -s->sse_test;                                                      // :489 Poisson
 }
 
@@ -964,7 +1034,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   {
     size_t off = 0;
     size_t o_ctrl = off;
-    off += 64;
+    off += 128;
     size_t o_sse = off;
     off += (size_t)2 * s->n_sse_blk * sizeof(double);
     size_t o_b = off;
@@ -981,7 +1051,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->res_h), off));
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), 8192));
   }
-  static_assert(sizeof(FitCtrl) <= 64, "FitCtrl must fit its slot of the result block");
+  static_assert(sizeof(FitCtrl) <= 128, "FitCtrl must fit its slot of the result block");
   // data
   TRY(upload_x(s, pb->x, pb->x_col_major));
   {
@@ -1055,6 +1125,27 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipMemcpy(s->logfact, lf.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
   }
   s->cache.assign(1, bessx_session::RsCache());
+  HIPT(dmalloc(&s->idcols, 256));
+  if (s->model_type == 4) {
+    auto V = [&](double **dst, size_t count) -> hipError_t {
+      hipError_t e = dmalloc(dst, count);
+      if (e == hipSuccess) {
+        s->cox_allocs.push_back(*dst);
+        e = hipMemset(*dst, 0, count * sizeof(double));
+      }
+      return e;
+    };
+    CoxBufs &c = s->cox;
+    double **vecs[] = {&c.E, &c.TH, &c.ET, &c.S0, &c.RS0, &c.SALL, &c.STEST, &c.EW, &c.WD, &c.ETA0, &c.THF, &c.S0F,
+                       &c.RS0F, &c.VG, &c.WG1, &c.UD, &c.TH1, &c.S1};
+    for (auto v : vecs) HIPT(V(v, (size_t)ld));
+    HIPT(V(&c.M, (size_t)ld * 256));
+    HIPT(V(&c.g, 256));
+    HIPT(V(&c.u, 256));
+    HIPT(V(&c.b0, 256));
+    HIPT(V(&c.Gt2, (size_t)136 * 256));
+    HIPT(V(&c.llpart, (size_t)(n + 255) / 256 + 1));
+  }
   if (s->model_type == 1) TRY(prepare_rowset(s, 0));
   HIPT(hipStreamSynchronize(s->st));
 #undef TRY

@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
                                               const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
   if (ctrl != nullptr) {
     if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
-    if (gate_mode == 1 && ctrl->irls_done) return;
+    if (gate_mode >= 1 && ctrl->irls_done) return;
   }
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int slab = (int)(wid / ntask);
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ 
                                                      int slot, int gate_mode) {
   if (ctrl != nullptr) {
     if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
-    if (gate_mode == 1 && ctrl->irls_done) return;
+    if (gate_mode >= 1 && ctrl->irls_done) return;
   }
   __shared__ double sm[8][33];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
                                               int gate_mode) {
   if (ctrl != nullptr) {
     if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
-    if (gate_mode == 1 && ctrl->irls_done) return;
+    if (gate_mode >= 1 && ctrl->irls_done) return;
   }
   // LDS images are addressed by integer offsets.  The single-wave phases below pass data between
   // lanes through LDS; WAVE_SYNC orders them (LDS executes one wave's DS operations in order; the
@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
 // sol holds the solved coefficients; with an intercept (GLM) sol[0] is coef0 and sol[1..] the slopes.
 __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int slot, int T0,
                                                 const int *__restrict__ A_new, const double *__restrict__ sol,
-                                                int has_intercept, int *__restrict__ A_cur,
+                                                int has_intercept, int wait_chain, int *__restrict__ A_cur,
                                                 double *__restrict__ b_cur, double *__restrict__ beta_dense,
                                                 int *__restrict__ hist, double *__restrict__ hist_beta,
                                                 double *__restrict__ hist_coef0, int hist_stride) {
@@ -737,7 +737,7 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
     }
     return;
   }
-  if (has_intercept && !ctrl->irls_done) return;  // IRLS still running: host will re-issue
+  if (wait_chain && !ctrl->irls_done) return;  // IRLS / Newton chain still running: the host re-issues
   __shared__ int same_any;
   const int kc = ctrl->k_cur;
   if (threadIdx.x == 0) same_any = 0;
@@ -1046,6 +1046,444 @@ __global__ void __launch_bounds__(256) k_glm_irls_begin(const FitCtrl *__restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Cox proportional hazards (rows sorted by time, y = status).  GroupPdasCox, src/Algorithm.h:1370-1650;
+// loglik_cox, src/coxph.cpp:16-40.  The reference builds risk-set sums with a dense n x n triangular
+// matrix (:1386) and two n x p temporaries (:1576-1577); here they are suffix scans.
+// ------------------------------------------------------------------------------------------
+
+// Single-block scan of up to three vectors at once (suffix: out_i = sum_{j >= i} in_j; prefix otherwise).
+// 1024 threads, each owns a contiguous chunk: chunk sums -> block scan -> rescan.  Fixed order, no atomics.
+// recip (optional) receives 1 / out0.
+__global__ void __launch_bounds__(1024) k_scan3(const double *__restrict__ in0, const double *__restrict__ in1,
+                                                const double *__restrict__ in2, double *__restrict__ out0,
+                                                double *__restrict__ out1, double *__restrict__ out2,
+                                                double *__restrict__ recip, long n, int suffix, int nvec,
+                                                const FitCtrl *__restrict__ ctrl, int gate, int slot, int t) {
+  if (ctrl != nullptr) {
+    if (gate == 1 && (ctrl->l != slot || (slot > 0 && ctrl->same_prev))) return;  // state pass after commit `slot`
+    if (gate == 2 && (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done ||
+                      ctrl->irls_steps != t - 1))
+      return;  // Newton step t
+    if (gate == 3 && (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done ||
+                      ctrl->irls_steps != t - 1 || ctrl->ls_done))
+      return;  // line-search evaluation inside Newton step t
+  }
+  __shared__ double wtot[3][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long chunk = (n + 1023) / 1024;
+  // suffix: thread 0 owns the LAST chunk so that "earlier threads" always means "already accumulated"
+  const long c0 = suffix ? n - (long)(tid + 1) * chunk : (long)tid * chunk;
+  const double *in[3] = {in0, in1, in2};
+  double *out[3] = {out0, out1, out2};
+  double tot[3] = {0.0, 0.0, 0.0};
+  for (int v = 0; v < 3; v++) {
+    if (v >= nvec) break;
+    double s = 0.0;
+    for (long q = 0; q < chunk; q++) {
+      long i = suffix ? c0 + chunk - 1 - q : c0 + q;
+      if (i >= 0 && i < n) s += in[v][i];
+    }
+    tot[v] = s;
+  }
+  // exclusive scan over threads (thread order = accumulation order)
+  double excl[3];
+  for (int v = 0; v < 3; v++) {
+    if (v >= nvec) break;
+    double inc = tot[v];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      double tt = __shfl_up(inc, o);
+      if (lane >= o) inc += tt;
+    }
+    if (lane == 63) wtot[v][wave] = inc;
+    __syncthreads();
+    double off = 0.0;
+    for (int w = 0; w < wave; w++) off += wtot[v][w];
+    excl[v] = off + inc - tot[v];
+    __syncthreads();
+  }
+  for (int v = 0; v < 3; v++) {
+    if (v >= nvec) break;
+    double s = excl[v];
+    for (long q = 0; q < chunk; q++) {
+      long i = suffix ? c0 + chunk - 1 - q : c0 + q;
+      if (i >= 0 && i < n) {
+        s += in[v][i];
+        out[v][i] = s;
+        // rows after the last training row of a CV fold have an empty risk set: keep their reciprocal finite
+        if (v == 0 && recip != nullptr) recip[i] = s != 0.0 ? 1.0 / s : 0.0;
+      }
+    }
+  }
+}
+
+// State pass for the CURRENT coefficients: e = exp(clamp(x beta)); TH = w e mask (get_A theta, :1587),
+// ET = e (1 - mask) (test rows of a CV fold), EW = w [delta != 0] mask (:1621-1630), WD = w delta mask (:1429).
+__global__ void __launch_bounds__(128) k_cox_eta(const double *__restrict__ X, long ld, int n,
+                                                 const double *__restrict__ y, const double *__restrict__ w,
+                                                 const double *__restrict__ mask, const FitCtrl *__restrict__ ctrl,
+                                                 int when, const int *__restrict__ A_cur,
+                                                 const double *__restrict__ b_cur, double *__restrict__ E,
+                                                 double *__restrict__ TH, double *__restrict__ ET,
+                                                 double *__restrict__ EW, double *__restrict__ WD) {
+  if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;
+  const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  if (i >= ld) return;
+  const d2 sx = lin_pred2(X, ld, i, A_cur, b_cur, ctrl->k_cur);
+  const d2 yv = *reinterpret_cast<const d2 *>(y + i), wv = *reinterpret_cast<const d2 *>(w + i);
+  const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
+  double e[2], th[2], et[2], ew[2], wd[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const bool in = i + q < n;
+    const double eta = q ? sx.y : sx.x, yy = q ? yv.y : yv.x, ww = q ? wv.y : wv.x, mm = q ? mk.y : mk.x;
+    const double ex = in ? exp(clampv(eta, 30.0)) : 0.0;
+    e[q] = ex;
+    th[q] = ww * ex * mm;
+    et[q] = in ? ex * (1.0 - mm) : 0.0;
+    ew[q] = (in && yy != 0.0) ? ww * mm : 0.0;
+    wd[q] = in ? ww * yy * mm : 0.0;
+  }
+  *reinterpret_cast<d2 *>(E + i) = d2{e[0], e[1]};
+  *reinterpret_cast<d2 *>(TH + i) = d2{th[0], th[1]};
+  *reinterpret_cast<d2 *>(ET + i) = d2{et[0], et[1]};
+  *reinterpret_cast<d2 *>(EW + i) = d2{ew[0], ew[1]};
+  *reinterpret_cast<d2 *>(WD + i) = d2{wd[0], wd[1]};
+}
+
+// loss sums: stats[2b] = sum_all w delta log(e / S_all) (CoxMetric::train_loss, src/Metric.h:565-568),
+// stats[2b+1] = the same over the fold's test rows with the test-row risk sets (:609)
+__global__ void __launch_bounds__(128) k_cox_loss(long ld, int n, const double *__restrict__ y,
+                                                  const double *__restrict__ w, const double *__restrict__ mask,
+                                                  const FitCtrl *__restrict__ ctrl, int when,
+                                                  const double *__restrict__ E, const double *__restrict__ SALL,
+                                                  const double *__restrict__ STEST, double *__restrict__ stats) {
+  if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;
+  const long i0 = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  double s_all = 0.0, s_te = 0.0;
+  for (int q = 0; q < 2; q++) {
+    long i = i0 + q;
+    if (i < n && y[i] != 0.0) {
+      double t = w[i] * y[i];
+      s_all += t * log(E[i] / SALL[i]);
+      if (mask != nullptr && mask[i] == 0.0) s_te += t * log(E[i] / STEST[i]);
+    }
+  }
+  block_pair_sum_128(s_all, s_te, stats + 2 * blockIdx.x);
+}
+
+// carries for the second pass: part[rb][j] <- sum_{rb' > rb} part[rb'][j] (both accumulators)
+__global__ void __launch_bounds__(256) k_cox_carry(double *__restrict__ part, double *__restrict__ part2, int nrb,
+                                                   int p, const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  double a1 = 0.0, a2 = 0.0;
+  for (int rb = nrb - 1; rb >= 0; rb--) {
+    double t1 = part[(size_t)rb * p + j], t2 = part2[(size_t)rb * p + j];
+    part[(size_t)rb * p + j] = a1;
+    part2[(size_t)rb * p + j] = a2;
+    a1 += t1;
+    a2 += t2;
+  }
+}
+
+// K3: second pass of the Cox score: per-column suffix scans inside one row block with the carry of the
+// later blocks, accumulating  l1 = sum_i ew_i (x_ij - a_ij),  l2 = sum_i ew_i (b_ij - a_ij^2)  where
+// a_ij = (sum_{i'>=i} theta x)/S0_i, b_ij = (sum_{i'>=i} theta x^2)/S0_i   (src/Algorithm.h:1593-1630).
+// A wave owns 64 columns x one row block.  32-row sub-tiles are loaded coalesced (256 contiguous bytes per
+// column), transposed through a private LDS tile, and then every lane walks ITS column row by row from the
+// bottom, so the scan needs no cross-lane traffic; theta, 1/S0 and ew are wave-uniform per row.
+constexpr int CS_ROWS = 32, CS_RS = 33;  // sub-tile rows, padded LDS row stride (doubles)
+template <int U>
+__global__ void __launch_bounds__(256) k_cox_colscan(const double *__restrict__ X, long ld, int p, int nrb,
+                                                     const double *__restrict__ TH, const double *__restrict__ RS0,
+                                                     const double *__restrict__ EW, double *__restrict__ part,
+                                                     double *__restrict__ part2, const FitCtrl *__restrict__ ctrl,
+                                                     int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  __shared__ double tile[4][64 * CS_RS];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long wid = (long)blockIdx.x * 4 + wv;
+  const int ncg = (p + 63) / 64;
+  const long cg = wid / nrb;
+  const int rb = (int)(wid - cg * nrb);
+  if (cg >= ncg) return;
+  const int j0 = (int)cg * 64;
+  const int jmine = min(j0 + lane, p - 1);
+  double a1 = part[(size_t)rb * p + jmine], a2 = part2[(size_t)rb * p + jmine];
+  double l1 = 0.0, l2 = 0.0;
+  constexpr int NSUB = 128 * U / CS_ROWS;
+  const long rbase = (long)rb * (128 * U);
+  const int c4 = lane >> 4, seg = lane & 15;
+  d2 nxt[16];
+  auto load_sub = [&](int sub) {
+    const long r0 = rbase + (long)sub * CS_ROWS + 2 * seg;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      int j = min(j0 + 4 * it + c4, p - 1);
+      nxt[it] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(X + (size_t)j * ld + r0));
+    }
+  };
+  load_sub(NSUB - 1);
+  for (int sub = NSUB - 1; sub >= 0; sub--) {
+    // registers -> private LDS tile [column][row]
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int o = (4 * it + c4) * CS_RS + 2 * seg;
+      tile[wv][o] = nxt[it].x;
+      tile[wv][o + 1] = nxt[it].y;
+    }
+    if (sub > 0) load_sub(sub - 1);  // next tile's loads fly while this one is scanned
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const long r0 = rbase + (long)sub * CS_ROWS;
+    for (int r = CS_ROWS - 1; r >= 0; r--) {
+      const double th = TH[r0 + r], ew = EW[r0 + r];  // wave-uniform
+      const double x = tile[wv][lane * CS_RS + r];
+      const double t = th * x;
+      a1 += t;
+      a2 += x * t;
+      if (ew != 0.0) {
+        const double rs = RS0[r0 + r];
+        const double q1 = a1 * rs;
+        l1 += (x - q1) * ew;
+        l2 += (a2 * rs - q1 * q1) * ew;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (j0 + lane < p) {
+    part[(size_t)rb * p + j0 + lane] = l1;
+    part2[(size_t)rb * p + j0 + lane] = l2;
+  }
+}
+
+// Cox sacrifice score (:1629-1634): l1 = -sum + 2 lambda beta, l2 = sum + 2 lambda, bd = |beta - l1/l2| sqrt(l2)
+__global__ void __launch_bounds__(256) k_cox_score(const double *__restrict__ part, const double *__restrict__ part2,
+                                                   int nrb, int p, const double *__restrict__ beta_dense,
+                                                   double lambda, const unsigned char *__restrict__ always,
+                                                   double *__restrict__ bd, const FitCtrl *__restrict__ ctrl,
+                                                   int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int rb = 0; rb < nrb; rb++) {
+    s1 += part[(size_t)rb * p + j];
+    s2 += part2[(size_t)rb * p + j];
+  }
+  const double b = beta_dense[j];
+  const double l1 = -s1 + 2.0 * lambda * b, l2 = s2 + 2.0 * lambda;
+  const double d = -l1 / l2;
+  double v = fabs(b + d) * sqrt(l2);
+  if (always != nullptr && always[j]) v = DBL_MAX;
+  bd[j] = v;
+}
+
+// ---- Newton iteration of the restricted fit (:1377-1490) ------------------------------------
+#define COX_NEWTON_GATE(ctrl, slot, t) \
+  ((ctrl)->done || (ctrl)->l != (slot)-1 || (ctrl)->same_prev || (ctrl)->irls_done || (ctrl)->irls_steps != (t)-1)
+
+__global__ void __launch_bounds__(256) k_cox_newton_begin(FitCtrl *__restrict__ ctrl, int slot, int k,
+                                                          double *__restrict__ b0, int *__restrict__ idcols) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
+  for (int i = threadIdx.x; i < k; i += 256) b0[i] = 0.0;
+  for (int i = threadIdx.x; i < 256; i += 256) idcols[i] = i < k ? i : -1;  // Gram columns of M, zero padding
+  if (threadIdx.x == 0) {
+    ctrl->ll0 = 1e5;  // :1393
+    ctrl->ls_done = 0;
+    ctrl->ls_m = 0;
+  }
+}
+
+// eta0 = X_A b0, theta = exp(clamp eta0) on the training rows (no weights here, :1415-1423)
+__global__ void __launch_bounds__(128) k_cox_fit_eta(const double *__restrict__ X, long ld, int n,
+                                                     const double *__restrict__ mask,
+                                                     const FitCtrl *__restrict__ ctrl, int slot, int t,
+                                                     const int *__restrict__ A_new, int k,
+                                                     const double *__restrict__ b0, double *__restrict__ ETA0,
+                                                     double *__restrict__ THF) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  if (i >= ld) return;
+  const d2 sx = lin_pred2(X, ld, i, A_new, b0, k);
+  const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
+  *reinterpret_cast<d2 *>(ETA0 + i) = sx;
+  *reinterpret_cast<d2 *>(THF + i) =
+      d2{i < n ? exp(clampv(sx.x, 30.0)) * mk.x : 0.0, i + 1 < n ? exp(clampv(sx.y, 30.0)) * mk.y : 0.0};
+}
+
+// C_i = prefix sum of w delta / S0 ;  VG = w delta - theta C (so that g = X_A^T VG, :1429) ; WG1 = theta C
+// (weights of the first Hessian Gram).  Single block, same chunked scan as k_scan3.
+__global__ void __launch_bounds__(1024) k_cox_cscan(const double *__restrict__ WD, const double *__restrict__ RS0F,
+                                                    const double *__restrict__ THF, double *__restrict__ VG,
+                                                    double *__restrict__ WG1, long n, long ld,
+                                                    const FitCtrl *__restrict__ ctrl, int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  __shared__ double wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long chunk = (n + 1023) / 1024, c0 = (long)tid * chunk;
+  double tot = 0.0;
+  for (long q = 0; q < chunk; q++) {
+    long i = c0 + q;
+    if (i < n && WD[i] != 0.0) tot += WD[i] * RS0F[i];
+  }
+  double inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double tt = __shfl_up(inc, o);
+    if (lane >= o) inc += tt;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  double off = 0.0;
+  for (int w = 0; w < wave; w++) off += wtot[w];
+  double s = off + inc - tot;
+  for (long q = 0; q < chunk; q++) {
+    long i = c0 + q;
+    if (i < n) {
+      if (WD[i] != 0.0) s += WD[i] * RS0F[i];
+      const double tc = THF[i] * s;
+      VG[i] = WD[i] - tc;
+      WG1[i] = tc;
+    }
+  }
+  for (long i = n + tid; i < ld; i += 1024) {
+    VG[i] = 0.0;
+    WG1[i] = 0.0;
+  }
+}
+
+// One block per active column a: M[:, a] = suffix(theta x_a) / S0 (the n x k matrix S1/S0, :1426-1428) and
+// g_a = x_a . VG + 2 lambda b0_a (:1429).
+__global__ void __launch_bounds__(1024) k_cox_M(const double *__restrict__ X, long ld, long n,
+                                                const int *__restrict__ A_new, const double *__restrict__ THF,
+                                                const double *__restrict__ RS0F, const double *__restrict__ VG,
+                                                const double *__restrict__ b0, double lambda,
+                                                double *__restrict__ M, double *__restrict__ g,
+                                                const FitCtrl *__restrict__ ctrl, int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  __shared__ double wtot[16], gtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = blockIdx.x;
+  const double *x = X + (size_t)A_new[a] * ld;
+  double *m = M + (size_t)a * ld;
+  const long chunk = (n + 1023) / 1024, c0 = n - (long)(tid + 1) * chunk;
+  double tot = 0.0, gs = 0.0;
+  for (long q = 0; q < chunk; q++) {
+    long i = c0 + chunk - 1 - q;
+    if (i >= 0 && i < n) {
+      tot += THF[i] * x[i];
+      gs += x[i] * VG[i];
+    }
+  }
+  double inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double tt = __shfl_up(inc, o);
+    if (lane >= o) inc += tt;
+  }
+  gs = wave_sum(gs);
+  if (lane == 63) wtot[wave] = inc;
+  if (lane == 0) gtot[wave] = gs;
+  __syncthreads();
+  double off = 0.0;
+  for (int w = 0; w < wave; w++) off += wtot[w];
+  double s = off + inc - tot;
+  for (long q = 0; q < chunk; q++) {
+    long i = c0 + chunk - 1 - q;
+    if (i >= 0 && i < n) {
+      s += THF[i] * x[i];
+      m[i] = s * RS0F[i];
+    }
+  }
+  for (long i = n + tid; i < ld; i += 1024) m[i] = 0.0;
+  if (tid == 0) {
+    double gg = 0.0;
+    for (int w = 0; w < 16; w++) gg += gtot[w];
+    g[a] = gg + 2.0 * lambda * b0[a];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tile_sub(double *__restrict__ a, const double *__restrict__ b, long n,
+                                                  const FitCtrl *__restrict__ ctrl, int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = a[i] - b[i];
+}
+
+// UD = X_A u  (direction of the linear predictor; beta1 = beta0 + 0.5^m u with u = -h^{-1} g, :1473-1474)
+__global__ void __launch_bounds__(128) k_cox_dir(const double *__restrict__ X, long ld,
+                                                 const FitCtrl *__restrict__ ctrl, int slot, int t,
+                                                 const int *__restrict__ A_new, int k, const double *__restrict__ u,
+                                                 double *__restrict__ UD) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  if (i >= ld) return;
+  *reinterpret_cast<d2 *>(UD + i) = lin_pred2(X, ld, i, A_new, u, k);
+}
+
+// trial point of the step halving: theta1 = exp(clamp(eta0 + 0.5^m UD)) on the training rows
+__global__ void __launch_bounds__(256) k_cox_ls_eval(long ld, int n, const double *__restrict__ mask,
+                                                     const FitCtrl *__restrict__ ctrl, int slot, int t, int m,
+                                                     const double *__restrict__ ETA0, const double *__restrict__ UD,
+                                                     double *__restrict__ TH1) {
+  if (COX_NEWTON_GATE(ctrl, slot, t) || ctrl->ls_done) return;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ld) return;
+  const double step = pow(0.5, (double)m);
+  const double mm = mask ? mask[i] : 1.0;
+  TH1[i] = i < n ? exp(clampv(ETA0[i] + step * UD[i], 30.0)) * mm : 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_cox_llpart(long n, const double *__restrict__ WD,
+                                                    const double *__restrict__ TH1, const double *__restrict__ S1,
+                                                    double *__restrict__ llpart, const FitCtrl *__restrict__ ctrl,
+                                                    int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t) || ctrl->ls_done) return;
+  __shared__ double sm[4];
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (i < n && WD[i] != 0.0) v = WD[i] * log(TH1[i] / S1[i]);
+  v = block_sum_256(v, sm);
+  if (threadIdx.x == 0) llpart[blockIdx.x] = v;
+}
+
+// while (loglik0 > loglik1 && m < 5) m++  (:1476-1481)
+__global__ void __launch_bounds__(256) k_cox_ls_check(FitCtrl *__restrict__ ctrl, int slot, int t, int m,
+                                                      const double *__restrict__ llpart, int nblk) {
+  if (COX_NEWTON_GATE(ctrl, slot, t) || ctrl->ls_done) return;
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += llpart[b];
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) {
+    ctrl->ll1 = s;
+    ctrl->ls_m = m;
+    if (!(ctrl->ll0 > s && m < 5)) ctrl->ls_done = 1;
+  }
+}
+
+// end of Newton step t (:1482-1487): stop if the relative change is < 1e-5, else beta0 <- beta1
+__global__ void __launch_bounds__(256) k_cox_newton_check(FitCtrl *__restrict__ ctrl, int slot, int t, int k,
+                                                          double *__restrict__ b0, const double *__restrict__ u) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  const double ll0 = ctrl->ll0, ll1 = ctrl->ll1;
+  const bool conv = fabs(ll0 - ll1) / fabs(0.1 + ll0) < 1e-5;
+  const double step = pow(0.5, (double)ctrl->ls_m);
+  if (!conv)
+    for (int i = threadIdx.x; i < k; i += 256) b0[i] = b0[i] + step * u[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!conv) ctrl->ll0 = ll1;
+    ctrl->irls_steps = t;
+    ctrl->ls_done = 0;
+    if (conv || t == 30) ctrl->irls_done = 1;
+  }
+}
+
 // column sums of squares / cross products on a masked row set: out[j] = sum_i m_i x_ij^2 (xtx) --
 // group_XTX for 1x1 groups (src/utilities.cpp:153-165, src/Metric.h:108-129) -- via k_xtv with
 // v2 = mask; and X^T (m*y) via k_xtv with v = m*y.  Helper: v_out = a * b elementwise (or copy).
@@ -1288,9 +1726,10 @@ hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_i
 }
 
 hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
-                         int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
+                         int wait_chain, int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
                          double *hist_coef0, int hist_stride, hipStream_t st) {
-  hipLaunchKernelGGL(k_commit, dim3(1), dim3(256), 0, st, ctrl, slot, T0, A_new, sol, has_intercept, A_cur, b_cur,
+  hipLaunchKernelGGL(k_commit, dim3(1), dim3(256), 0, st, ctrl, slot, T0, A_new, sol, has_intercept, wait_chain, A_cur,
+                     b_cur,
                      beta_dense, hist, hist_beta, hist_coef0, hist_stride);
   LAUNCH_CHECK();
   return hipSuccess;
@@ -1349,6 +1788,113 @@ hipError_t launch_glm_irls_prep(int fam, const double *X, long ld, int n, const 
 hipError_t launch_glm_irls_check(FitCtrl *ctrl, int slot, int t, int fam, const double *llpart, int nblk, int m,
                                  double *bcur, double *bprev, hipStream_t st) {
   hipLaunchKernelGGL(k_glm_irls_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, fam, llpart, nblk, m, bcur, bprev);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,
+                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, CoxBufs cb,
+                            double *stats, hipStream_t st) {
+  int nblk = (int)((ld + 255) / 256);
+  hipLaunchKernelGGL(k_cox_eta, dim3(nblk), dim3(128), 0, st, X, ld, n, y, w, mask, ctrl, when, A_cur, b_cur, cb.E,
+                     cb.TH, cb.ET, cb.EW, cb.WD);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, st, (const double *)cb.TH, (const double *)cb.E,
+                     (const double *)cb.ET, cb.S0, cb.SALL, cb.STEST, cb.RS0, (long)n, 1, mask ? 3 : 2, ctrl, 1, when,
+                     0);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cox_loss, dim3(nblk), dim3(128), 0, st, ld, n, y, w, mask, ctrl, when, (const double *)cb.E,
+                     (const double *)cb.SALL, (const double *)cb.STEST, stats);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb, CoxBufs cb, double *part,
+                                 double *part2, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  hipError_t e = launch_xtv(X, ld, p, U, cb.TH, cb.TH, part, part2, ctrl, slot, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cox_carry, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, ctrl, slot);
+  LAUNCH_CHECK();
+  long nwaves = (long)nrb * ((p + 63) / 64);
+  int nblk = (int)((nwaves + 3) / 4);
+#define CS_GO(UU)                                                                                            \
+  hipLaunchKernelGGL(k_cox_colscan<UU>, dim3(nblk), dim3(256), 0, st, X, ld, p, nrb, (const double *)cb.TH, \
+                     (const double *)cb.RS0, (const double *)cb.EW, part, part2, ctrl, slot)
+  switch (U) {
+    case 8: CS_GO(8); break;
+    case 4: CS_GO(4); break;
+    case 2: CS_GO(2); break;
+    default: CS_GO(1); break;
+  }
+#undef CS_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cox_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
+                            double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_cox_score, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, beta_dense, lambda,
+                     always, bd, ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cox_newton_begin(FitCtrl *ctrl, int slot, int k, CoxBufs cb, int *idcols, hipStream_t st) {
+  hipLaunchKernelGGL(k_cox_newton_begin, dim3(1), dim3(256), 0, st, ctrl, slot, k, cb.b0, idcols);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, int n, const double *mask,
+                                  FitCtrl *ctrl, int slot, int t, const int *A_new, int k, double lambda,
+                                  const int *gcols, const int *idcols, int mt, const GramTask *tasks, int ntask,
+                                  int rps, int nslab, double *gpart, int ntiles, double *Gt, CoxBufs cb,
+                                  hipStream_t st) {
+  const int nb2 = (int)((ld + 255) / 256);
+  hipLaunchKernelGGL(k_cox_fit_eta, dim3(nb2), dim3(128), 0, st, X, ld, n, mask, (const FitCtrl *)ctrl, slot, t,
+                     A_new, k, (const double *)cb.b0, cb.ETA0, cb.THF);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, st, (const double *)cb.THF, (const double *)nullptr,
+                     (const double *)nullptr, cb.S0F, (double *)nullptr, (double *)nullptr, cb.RS0F, (long)n, 1, 1,
+                     (const FitCtrl *)ctrl, 2, slot, t);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cox_cscan, dim3(1), dim3(1024), 0, st, (const double *)cb.WD, (const double *)cb.RS0F,
+                     (const double *)cb.THF, cb.VG, cb.WG1, (long)n, ld, (const FitCtrl *)ctrl, slot, t);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cox_M, dim3(k), dim3(1024), 0, st, X, ld, (long)n, A_new, (const double *)cb.THF,
+                     (const double *)cb.RS0F, (const double *)cb.VG, (const double *)cb.b0, lambda, cb.M, cb.g,
+                     (const FitCtrl *)ctrl, slot, t);
+  LAUNCH_CHECK();
+  // Hessian: -h = X_A^T diag(theta C) X_A - M^T diag(w delta) M  (from :1458-1470)
+  hipError_t e = launch_gram(X, aux, ld, gcols, cb.WG1, rps, tasks, ntask, nslab, gpart, ntiles, Gt, ctrl, slot, 2, st);
+  if (e != hipSuccess) return e;
+  e = launch_gram(cb.M, aux, ld, idcols, cb.WD, rps, tasks, ntask, nslab, gpart, ntiles, cb.Gt2, ctrl, slot, 2, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_tile_sub, dim3((ntiles * 256 + 255) / 256), dim3(256), 0, st, Gt, (const double *)cb.Gt2,
+                     (long)ntiles * 256, (const FitCtrl *)ctrl, slot, t);
+  LAUNCH_CHECK();
+  e = launch_chol(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, ctrl, slot, 2, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cox_dir, dim3(nb2), dim3(128), 0, st, X, ld, (const FitCtrl *)ctrl, slot, t, A_new, k,
+                     (const double *)cb.u, cb.UD);
+  LAUNCH_CHECK();
+  const int nb1 = (int)((ld + 255) / 256), nbn = (n + 255) / 256;
+  for (int m = 1; m <= 5; m++) {
+    hipLaunchKernelGGL(k_cox_ls_eval, dim3(nb1), dim3(256), 0, st, ld, n, mask, (const FitCtrl *)ctrl, slot, t, m,
+                       (const double *)cb.ETA0, (const double *)cb.UD, cb.TH1);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, st, (const double *)cb.TH1, (const double *)nullptr,
+                       (const double *)nullptr, cb.S1, (double *)nullptr, (double *)nullptr, (double *)nullptr,
+                       (long)n, 1, 1, (const FitCtrl *)ctrl, 3, slot, t);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cox_llpart, dim3(nbn), dim3(256), 0, st, (long)n, (const double *)cb.WD,
+                       (const double *)cb.TH1, (const double *)cb.S1, cb.llpart, (const FitCtrl *)ctrl, slot, t);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cox_ls_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, m, (const double *)cb.llpart, nbn);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_cox_newton_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, k, cb.b0, (const double *)cb.u);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -1,0 +1,35 @@
+"""Cox PDAS on the GPU (two-pass suffix-scan score, device-gated Newton with step halving) against the plain-C
+oracle.  Supports must agree at every PDAS iteration; coefficients within 1e-6 relative -- the Newton iterates are
+compared after the same number of steps (the trace would differ in length otherwise)."""
+import numpy as np
+import pytest
+
+from bess_amd import synth
+from test_glm_gpu import check
+
+pytestmark = pytest.mark.gpu
+COX = dict(data_type=3, model_type=4)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("seq", dict(ic_type=3, sequence=np.arange(1, 13))),
+    ("gs", dict(ic_type=4, path_type=2, s_min=1, s_max=20)),
+    ("nowarm", dict(ic_type=2, sequence=np.arange(1, 9), is_warm_start=False)),
+])
+def test_cox_paths(gpu, name, kw):
+    X, _, status, _, _ = synth.make_cox(600, 100, 6)
+    check(gpu, X, status, dict(COX, **kw), "cox " + name)
+
+
+def test_cox_cv_and_weights(gpu):
+    X, _, status, _, _ = synth.make_cox(600, 100, 6)
+    check(gpu, X, status, dict(COX, is_cv=True, K=5, cv_fold_id=synth.make_cv_folds(600, 5), sequence=np.arange(1, 9)),
+          "cox cv")
+    w = np.random.default_rng(1).uniform(0.5, 2, 600)
+    check(gpu, X, status, dict(COX, ic_type=3, sequence=np.arange(1, 9), weight=w), "cox weighted")
+
+
+@pytest.mark.parametrize("n,p", [(2500, 300), (5000, 130)])
+def test_cox_bigger(gpu, n, p):
+    X, _, status, _, _ = synth.make_cox(n, p, 8, seed=n)
+    check(gpu, X, status, dict(COX, ic_type=3, sequence=np.arange(1, 17)), "cox %dx%d" % (n, p))

@@ -15,7 +15,7 @@ from test_lm_gpu import run_gpu  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 CASES = cases.all_cases()
-BUILT = [n for n in sorted(CASES) if CASES[n][2].get("model_type", 1) in (1, 2, 3)]  # Cox: see test_cox_gpu.py once built
+BUILT = [n for n in sorted(CASES) if CASES[n][2].get("model_type", 1) in (1, 2, 3, 4)]
 
 
 @pytest.mark.parametrize("name", BUILT)
