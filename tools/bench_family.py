@@ -1,0 +1,55 @@
+"""Timing of the other BASELINE configs on one GPU (not the driver's bench.py, which is configs[1]):
+  python tools/bench_family.py logistic [n p kmax]     configs[2]  default 100000 5000 100
+  python tools/bench_family.py cox [n p kmax]          configs[4]  default 200000 20000 150
+  python tools/bench_family.py lmcv [n p smax]         configs[3]  default 50000 10000 200  (gs_path + 5-fold CV)
+Prints one JSON line: candidates/s, PDAS iterations, score-pass timing (HIP events inside the library)."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from bess_amd import capi, synth  # noqa: E402
+
+
+def main():
+    fam = sys.argv[1]
+    a = [int(v) for v in sys.argv[2:]]
+    t0 = time.time()
+    if fam == "logistic":
+        n, p, kmax = (a + [100000, 5000, 100][len(a):])[:3]
+        X, y, _, _ = synth.make_logistic(n, p, 50)
+        sess = capi.Session(X, y, data_type=2, model_type=2)
+        run = lambda: sess.sequential_path(np.arange(1, kmax + 1), ic_type=3)  # noqa: E731
+    elif fam == "cox":
+        n, p, kmax = (a + [200000, 20000, 150][len(a):])[:3]
+        X, _, st, _, _ = synth.make_cox(n, p, 75)
+        sess = capi.Session(X, st, data_type=3, model_type=4)
+        run = lambda: sess.sequential_path(np.arange(1, kmax + 1), ic_type=3)  # noqa: E731
+    elif fam == "lmcv":
+        n, p, kmax = (a + [50000, 10000, 200][len(a):])[:3]
+        X, y, _, _ = synth.make_lm(n, p, 100)
+        sess = capi.Session(X, y, data_type=1, model_type=1)
+        sess.set_cv(5, synth.make_cv_folds(n, 5))
+        run = lambda: sess.gs_path(1, kmax, ic_type=3, is_cv=True)  # noqa: E731
+    else:
+        raise SystemExit("unknown family")
+    setup = time.time() - t0
+    del X
+    sess.enable_kernel_timing(True)
+    sess.score_pass_stats(reset=True)
+    t0 = time.time()
+    out = run()
+    dt = time.time() - t0
+    k1 = sess.score_pass_stats()
+    ncand = out["n_candidates"]
+    print(json.dumps({"family": fam, "n": n, "p": p, "kmax": kmax, "seconds": dt, "candidates": ncand,
+                      "candidates_per_s": ncand / dt, "fits": out["n_fits"], "pdas_iters": out["n_pdas_iters"],
+                      "score_pass_launches": k1["launches"], "score_pass_avg_ms": 1e3 * k1["seconds"] / max(k1["launches"], 1),
+                      "score_pass_alg_GBps": (k1["algorithmic_bytes"] / k1["seconds"] / 1e9) if k1["seconds"] else None,
+                      "selected_k": out["best_T0"], "ic": out["ic"], "setup_seconds": setup}))
+
+
+if __name__ == "__main__":
+    main()
