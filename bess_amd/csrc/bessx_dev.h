@@ -27,6 +27,8 @@ struct FitCtrl {
   int ls_done;     // step halving finished for the current Newton step
   int ls_m;        // accepted exponent m (step 0.5^m)
   double ll1;      // partial log-likelihood at the trial point
+  int gram_full;   // LM Gram cache: 1 = form the whole Gram this slot, 0 = only the rows of the new columns
+  int pad2_;
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -50,13 +52,19 @@ hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand,
 bool topk_supported(int len, int k);
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
-                       double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);
+                       double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st, int tile_base = 0);
+hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, int *cols, const double *w,
+                                 const int *A_new, int T0, int mt, const GramTask *tasks_full, int ntask_full,
+                                 int rps_full, int nslab_full, const GramTask *tasks_inc, int ntask_inc, int rps_inc,
+                                 int nslab_inc, double *part, double *Gt, double *Rt, int *src, double *gbuf0,
+                                 double *gbuf1, int *Ac, int *meta, FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
                        hipStream_t st);
 hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
                             hipStream_t st);
+hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st);
 hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
                          int wait_chain, int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
                          double *hist_coef0, int hist_stride, hipStream_t st);

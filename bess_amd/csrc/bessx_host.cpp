@@ -90,6 +90,7 @@ struct bessx_session {
   double *Wv = nullptr, *llpart = nullptr, *bcur = nullptr, *bprev = nullptr;  // IRLS work space
   int irls_guess = 8;
   int cox_state_rs = -1;
+  int dev_state_rs = -1;                // row set of the fit whose final coefficients sit in A_cur/b_cur/beta_dense
   CoxBufs cox = {};                     // Cox work space (model_type 4 only)
   std::vector<void *> cox_allocs;
   int *idcols = nullptr;
@@ -109,6 +110,14 @@ struct bessx_session {
   int hist_stride = T0_CAP + 2;
   GramTask *gtasks = nullptr;
   std::vector<int> gtask_off, gtask_cnt;  // per mt
+  std::vector<int> gtask_inc_off, gtask_inc_cnt;  // per mt: tasks of the extra tile row (incremental LM Gram)
+  struct GramCache {
+    double *g0 = nullptr, *g1 = nullptr;
+    int *A = nullptr, *meta = nullptr;
+  };
+  std::vector<GramCache> gcache;  // per row set
+  double *Rt = nullptr;
+  int *gsrc = nullptr;
   double *gpart = nullptr, *Gt = nullptr;
   size_t gpart_elems = 0;
   int *init_idx_d = nullptr;
@@ -197,6 +206,14 @@ static void session_free(bessx_session *s) {
   F(s->hist_beta);
   F(s->hist_coef0);
   F(s->gtasks);
+  for (auto &c : s->gcache) {
+    F(c.g0);
+    F(c.g1);
+    F(c.A);
+    F(c.meta);
+  }
+  F(s->Rt);
+  F(s->gsrc);
   F(s->gpart);
   F(s->Gt);
   F(s->init_idx_d);
@@ -239,6 +256,17 @@ static int k1_collect(bessx_session *s, const std::vector<std::pair<size_t, bool
     s->k1_bytes += 8.0 * (double)s->n * (double)s->p;
   }
   s->ev_used = 0;
+  return 0;
+}
+
+static int alloc_gram_cache(bessx_session *s) {
+  bessx_session::GramCache c;
+  HIPX(dmalloc(&c.g0, (size_t)256 * 256));
+  HIPX(dmalloc(&c.g1, (size_t)256 * 256));
+  HIPX(dmalloc(&c.A, 256));
+  HIPX(dmalloc(&c.meta, 2));
+  HIPX(hipMemset(c.meta, 0, 2 * sizeof(int)));
+  s->gcache.push_back(c);
   return 0;
 }
 
@@ -338,9 +366,16 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
                      lambda, 0, s->always, s->bd, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
-  if (e == hipSuccess)
-    e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, s->gtasks + s->gtask_off[mt], ntask, nslab,
-                    s->gpart, ntiles, s->Gt, s->ctrl, slot, 0, s->st);
+  if (e == hipSuccess) {
+    int rps_i, nslab_i;
+    const int ntask_i = s->gtask_inc_cnt[mt];
+    gram_geometry(s, ntask_i * 3, &rps_i, &nslab_i);  // a third of the usual wave count: the extra row is cheap
+    bessx_session::GramCache &gc = s->gcache[rs];
+    e = launch_gram_lm_cached(s->X, s->aux, s->ld, s->gcols, s->mask[rs], s->A_new, T0, mt,
+                              s->gtasks + s->gtask_off[mt], ntask, rps, nslab, s->gtasks + s->gtask_inc_off[mt],
+                              ntask_i, rps_i, nslab_i, s->gpart, s->Gt, s->Rt, s->gsrc, gc.g0, gc.g1, gc.A, gc.meta,
+                              s->ctrl, slot, s->st);
+  }
   if (e == hipSuccess)
     e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
   if (e == hipSuccess)
@@ -501,16 +536,6 @@ static int algorithm_fit(bessx_session *s) {
   // warm start: this->beta = beta_init; this->coef0 = coef0_init (src/Algorithm.h:147-148)
   const int k_init = (int)s->beta_init.idx.size();
   if (k_init > T0_CAP) return fail(BESSX_ERR_ARG, "initial support too large");
-  int *st_idx = reinterpret_cast<int *>(s->stage_h);
-  double *st_val = reinterpret_cast<double *>(s->stage_h + 4096);
-  for (int i = 0; i < k_init; i++) {
-    st_idx[i] = s->beta_init.idx[i];
-    st_val[i] = s->beta_init.val[i];
-  }
-  if (k_init) {
-    HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, s->st));
-    HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
-  }
   // Reuse across fits: when this fit starts from exactly the coefficients the last fit on this row set
   // ended with, and that fit ended on a repeated active set, the residual and the score-pass sums in
   // memory are the ones get_A would recompute (src/Algorithm.h:1109 depends only on beta, coef0 and the rows).
@@ -520,8 +545,25 @@ static int algorithm_fit(bessx_session *s) {
                          cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs);
   if (cox) s->cox_state_rs = rs;
   cc.valid = false;
-  hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur,
-                                  s->b_cur, s->beta_dense, s->p, s->hist, s->st);
+  hipError_t e = hipSuccess;
+  if (use_cache && s->dev_state_rs == rs) {
+    // the device still holds exactly these coefficients (previous fit of the chain): no upload, no re-initialisation
+    e = launch_fit_continue(s->ctrl, T0, s->hist, s->st);
+  } else {
+    int *st_idx = reinterpret_cast<int *>(s->stage_h);
+    double *st_val = reinterpret_cast<double *>(s->stage_h + 4096);
+    for (int i = 0; i < k_init; i++) {
+      st_idx[i] = s->beta_init.idx[i];
+      st_val[i] = s->beta_init.val[i];
+    }
+    if (k_init) {
+      HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, s->st));
+      HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
+    }
+    e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur, s->b_cur,
+                         s->beta_dense, s->p, s->hist, s->st);
+  }
+  s->dev_state_rs = rs;
   if (e == hipSuccess && !use_cache) {
     if (!glm)
       e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
@@ -1010,7 +1052,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->hist, (size_t)(s->max_iter + 2) * s->hist_stride));
   HIPT(dmalloc(&s->hist_beta, (size_t)(s->max_iter + 2) * s->hist_stride));
   HIPT(dmalloc(&s->hist_coef0, (size_t)(s->max_iter + 2)));
-  HIPT(dmalloc(&s->gcols, 256));
+  HIPT(dmalloc(&s->gcols, 256 + 16));
+  HIPT(dmalloc(&s->Rt, (size_t)16 * 256));
+  HIPT(dmalloc(&s->gsrc, 256));
   HIPT(dmalloc(&s->init_idx_d, 256));
   HIPT(dmalloc(&s->init_val_d, 256));
   HIPT(dmalloc(&s->Gt, (size_t)136 * 256));
@@ -1021,10 +1065,22 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     std::vector<GramTask> all;
     s->gtask_off.assign(17, 0);
     s->gtask_cnt.assign(17, 0);
+    s->gtask_inc_off.assign(17, 0);
+    s->gtask_inc_cnt.assign(17, 0);
     for (int mt = 1; mt <= 16; mt++) {
       s->gtask_off[mt] = (int)all.size();
       build_gram_tasks(mt, all);
       s->gtask_cnt[mt] = (int)all.size() - s->gtask_off[mt];
+      // extra tile row I = mt against the tiles J = 0..mt-1, in runs of 8/4/2/1
+      s->gtask_inc_off[mt] = (int)all.size();
+      int J = 0, left = mt;
+      for (int run = GRAM_JC; run >= 1; run >>= 1)
+        while (left >= run) {
+          all.push_back(GramTask{mt, J, run, 0});
+          J += run;
+          left -= run;
+        }
+      s->gtask_inc_cnt[mt] = (int)all.size() - s->gtask_inc_off[mt];
     }
     HIPT(dmalloc(&s->gtasks, all.size()));
     HIPT(hipMemcpy(s->gtasks, all.data(), all.size() * sizeof(GramTask), hipMemcpyHostToDevice));
@@ -1125,6 +1181,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipMemcpy(s->logfact, lf.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
   }
   s->cache.assign(1, bessx_session::RsCache());
+  TRY(alloc_gram_cache(s));
   HIPT(dmalloc(&s->idcols, 256));
   if (s->model_type == 4) {
     auto V = [&](double **dst, size_t count) -> hipError_t {
@@ -1187,7 +1244,12 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     (void)hipFree(s->r_rs[i]);
     (void)hipFree(s->part2_rs[i]);
     (void)hipFree(s->h_rs[i]);
+    (void)hipFree(s->gcache[i].g0);
+    (void)hipFree(s->gcache[i].g1);
+    (void)hipFree(s->gcache[i].A);
+    (void)hipFree(s->gcache[i].meta);
   }
+  s->gcache.resize(1);
   s->mask.resize(1);
   s->xtx.resize(1);
   s->xty.resize(1);
@@ -1230,6 +1292,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     HIPX(hipMemset(q4, 0, (size_t)s->ld * sizeof(double)));
     s->part2_rs.push_back(q3);
     s->h_rs.push_back(q4);
+    if (int rc = alloc_gram_cache(s)) return rc;
     s->n_train.push_back(nt);
     if (s->model_type == 1)
       if (int rc = prepare_rowset(s, k + 1)) return rc;
@@ -1499,7 +1562,7 @@ int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m,
   HIPX(sc.alloc(&gpart, (size_t)nslab * ntiles * 256));
   HIPX(sc.alloc(&Gt, (size_t)ntiles * 256));
   HIPX(launch_gram(dX, daux, ldd, dcols, dw, rps, dt, (int)tasks.size(), nslab, gpart, ntiles, Gt, nullptr, 0, 0,
-                   nullptr));
+                   nullptr, 0));
   std::vector<double> ht((size_t)ntiles * 256);
   HIPX(hipMemcpy(ht.data(), Gt, ht.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (int I = 0; I < mt; I++)

@@ -406,7 +406,8 @@ __device__ __forceinline__ const double *gram_col(const double *__restrict__ X, 
 template <int NJ, bool WEIGHTED>
 __device__ __forceinline__ void gram_body(const double *__restrict__ X, const double *__restrict__ aux, long ld,
                                           const int *__restrict__ cols, const double *__restrict__ w,
-                                          const GramTask tk, long r_begin, long r_end, double *__restrict__ out) {
+                                          const GramTask tk, long r_begin, long r_end, double *__restrict__ out,
+                                          int tile_base) {
   const int lane = threadIdx.x & 63;
   const int c = lane & 15, q = lane >> 4;
   const double *pa = gram_col(X, aux, ld, cols[tk.I * 16 + c]) + 4 * q;
@@ -438,7 +439,7 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ X, const do
   }
 #pragma unroll
   for (int jj = 0; jj < NJ; jj++) {
-    const int t = tk.I * (tk.I + 1) / 2 + tk.J0 + jj;
+    const int t = tk.I * (tk.I + 1) / 2 + tk.J0 + jj - tile_base;
     *reinterpret_cast<d4 *>(out + (size_t)t * 256 + lane * 4) = acc[jj];
   }
 }
@@ -448,10 +449,13 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
                                               const int *__restrict__ cols, const double *__restrict__ w,
                                               int rows_per_slab, const GramTask *__restrict__ tasks, int ntask,
                                               int nslab, double *__restrict__ part, int ntiles,
-                                              const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+                                              const FitCtrl *__restrict__ ctrl, int slot, int gate_mode,
+                                              int tile_base) {
   if (ctrl != nullptr) {
     if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
-    if (gate_mode >= 1 && ctrl->irls_done) return;
+    if ((gate_mode == 1 || gate_mode == 2) && ctrl->irls_done) return;
+    if (gate_mode == 3 && !ctrl->gram_full) return;  // LM: whole Gram only when the cache cannot be used
+    if (gate_mode == 4 && ctrl->gram_full) return;   // LM: new rows only
   }
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int slab = (int)(wid / ntask);
@@ -461,10 +465,10 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
   const long r_end = min(r_begin + rows_per_slab, ld);
   double *out = part + (size_t)slab * ntiles * 256;
   switch (tk.nJ) {  // wave-uniform: tasks are cut into runs of 8, 4, 2 or 1 tiles of one tile row
-    case 8: gram_body<8, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
-    case 4: gram_body<4, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
-    case 2: gram_body<2, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
-    default: gram_body<1, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out); break;
+    case 8: gram_body<8, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out, tile_base); break;
+    case 4: gram_body<4, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out, tile_base); break;
+    case 2: gram_body<2, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out, tile_base); break;
+    default: gram_body<1, WEIGHTED>(X, aux, ld, cols, w, tk, r_begin, r_end, out, tile_base); break;
   }
 }
 
@@ -475,7 +479,9 @@ __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ 
                                                      int slot, int gate_mode) {
   if (ctrl != nullptr) {
     if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
-    if (gate_mode >= 1 && ctrl->irls_done) return;
+    if ((gate_mode == 1 || gate_mode == 2) && ctrl->irls_done) return;
+    if (gate_mode == 3 && !ctrl->gram_full) return;
+    if (gate_mode == 4 && ctrl->gram_full) return;
   }
   __shared__ double sm[8][33];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -495,6 +501,110 @@ __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Incremental Gram for the LM fit.  X_A^T diag(mask) X_A depends only on the columns and the row set, never on
+// the coefficients, and consecutive active sets of a warm-started path differ in a column or two.  Every row set
+// keeps the Gram of its last solved active set (dense, symmetric, 256 x 256, double buffered) with its sorted
+// column list.  k_gram_plan maps the new active set onto it; if at most 16 columns are new only their rows are
+// formed (one extra tile row of k_gram) and k_gram_assemble builds the MFMA-layout tiles for k_chol from cache +
+// new rows; otherwise the whole Gram is formed as before.  Either way the cache is refreshed.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gram_plan(const int *__restrict__ A_new, int T0, int mp,
+                                                   const int *__restrict__ Ac, const int *__restrict__ meta,
+                                                   int *__restrict__ src, int *__restrict__ cols,
+                                                   FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kc = meta[0];
+  int pos = -1, isnew = 0;
+  if (tid < T0) {
+    const int a = A_new[tid];
+    int lo = 0, hi = kc - 1;
+    while (lo <= hi) {
+      int mid = (lo + hi) >> 1, v = Ac[mid];
+      if (v == a) {
+        pos = mid;
+        break;
+      }
+      if (v < a)
+        lo = mid + 1;
+      else
+        hi = mid - 1;
+    }
+    isnew = pos < 0 ? 1 : 0;
+  }
+  int inc = isnew;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int off = 0, nn = 0;
+  for (int w = 0; w < 4; w++) {
+    off += (w < wave) ? wsum[w] : 0;
+    nn += wsum[w];
+  }
+  const int q = off + inc - isnew;  // rank of this column among the new ones
+  if (tid < T0) {
+    src[tid] = isnew ? -1 - q : pos;
+    if (isnew && q < 16) cols[mp + q] = A_new[tid];
+  }
+  if (tid >= nn && tid < 16) cols[mp + tid] = -1;  // unused rows of the extra tile read the zero column
+  if (tid == 0) ctrl->gram_full = (kc == 0 || nn > 16) ? 1 : 0;
+}
+
+// Build the tiles k_chol reads (incremental case) and refresh the cache (both cases).
+__global__ void __launch_bounds__(256) k_gram_assemble(double *__restrict__ Gt, const double *__restrict__ Rt,
+                                                       const int *__restrict__ src, int T0, double *gbuf0,
+                                                       double *gbuf1, const int *__restrict__ meta,
+                                                       const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
+  // meta[1] names the current buffer; it only flips when k_gram_cache_commit really ran (device-side truth)
+  const double *Gold = meta[1] ? gbuf1 : gbuf0;
+  double *Gnew = meta[1] ? gbuf0 : gbuf1;
+  const int t = blockIdx.x, lane = threadIdx.x >> 2, r = threadIdx.x & 3;
+  int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= t) I++;
+  while (I * (I + 1) / 2 > t) I--;
+  const int J = t - I * (I + 1) / 2;
+  const int a = I * 16 + (lane >> 4) + 4 * r, b = J * 16 + (lane & 15);
+  const size_t e = (size_t)t * 256 + lane * 4 + r;
+  if (a >= T0 || b >= T0) {
+    if (!ctrl->gram_full) Gt[e] = 0.0;
+    return;
+  }
+  double v;
+  if (ctrl->gram_full) {
+    v = Gt[e];
+  } else {
+    const int sa = src[a], sb = src[b];
+    if (sa >= 0 && sb >= 0) {
+      v = Gold[(size_t)sb * 256 + sa];
+    } else {
+      // element (new row q, column c of the new active set) of the extra tile row, MFMA C/D layout
+      const int q = sa < 0 ? -1 - sa : -1 - sb, c = sa < 0 ? b : a;
+      v = Rt[(size_t)(c >> 4) * 256 + (((q & 3) << 4) + (c & 15)) * 4 + (q >> 2)];
+    }
+    Gt[e] = v;
+  }
+  Gnew[(size_t)b * 256 + a] = v;
+  Gnew[(size_t)a * 256 + b] = v;
+}
+
+__global__ void __launch_bounds__(256) k_gram_cache_commit(const int *__restrict__ A_new, int T0,
+                                                           int *__restrict__ Ac, int *__restrict__ meta,
+                                                           const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
+  for (int i = threadIdx.x; i < T0; i += 256) Ac[i] = A_new[i];
+  if (threadIdx.x == 0) {
+    meta[0] = T0;
+    meta[1] ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K7: Cholesky factorisation and both triangular solves of the (m x m) normal equations in ONE
 // 512-thread workgroup, m + 1 <= 16*mt <= 256.
 //
@@ -509,8 +619,21 @@ __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ 
 // ------------------------------------------------------------------------------------------
 constexpr int CH_W = 8;                                                   // waves
 constexpr int CH_MT = 16;                                                 // max tile rows
-constexpr int CH_SLOTS = (CH_MT * (CH_MT + 1) / 2 + CH_W - 1) / CH_W;     // 17
 constexpr int CH_LDT = 17;                                                // padded tile row stride (doubles)
+
+// broadcast the value lane `src` (compile-time constant after unrolling) holds to the whole wave via SGPRs
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// element idx (lane-dependent) of a register array without dynamic indexing
+__device__ __forceinline__ double bcast_pick16(const double (&a)[16], int idx) {
+  double r = a[0];
+#pragma unroll
+  for (int i = 1; i < 16; i++) r = (idx == i) ? a[i] : r;
+  return r;
+}
 
 __device__ __forceinline__ void tile_of(int t, int &I, int &J) {
   int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -520,6 +643,7 @@ __device__ __forceinline__ void tile_of(int t, int &I, int &J) {
   J = t - i * (i + 1) / 2;
 }
 
+template <int CH_SLOTS>  // register tiles per wave: 5 (mt <= 8), 10 (mt <= 12), 17 (mt <= 16)
 __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int m, int mt, double ridge,
                                               int ridge_skip0, const double *__restrict__ rhs,
                                               const int *__restrict__ rhs_gather, double *__restrict__ sol,
@@ -527,7 +651,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
                                               int gate_mode) {
   if (ctrl != nullptr) {
     if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
-    if (gate_mode >= 1 && ctrl->irls_done) return;
+    if ((gate_mode == 1 || gate_mode == 2) && ctrl->irls_done) return;
   }
   // LDS images are addressed by integer offsets.  The single-wave phases below pass data between
   // lanes through LDS; WAVE_SYNC orders them (LDS executes one wave's DS operations in order; the
@@ -536,6 +660,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
   __shared__ double Psh[2 * CH_MT * TS];      // panel tiles, double buffered
   __shared__ double Lsh[CH_MT * TS];          // factored diagonal blocks
   __shared__ double z[CH_MT * 16];            // right-hand side / solution
+  __shared__ double Rsh[CH_MT * 16];          // reciprocals of the diagonal of L
 #define WAVE_SYNC()                                          \
   do {                                                       \
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   \
@@ -590,35 +715,48 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
         Psh[o + 12 * CH_LDT] = acc[s].w;
       }
     __syncthreads();
-    // 2. factor the diagonal block in LDS (wave 0), keep a copy in Lsh
-    if (wave == 0) {
-      const int D = pb + b * TS;
+    // 2+3. EVERY wave factors the 16x16 diagonal block redundantly in registers (lane holds row lane&15;
+    // pivots and multipliers are broadcast with v_readlane, so the 16-step chain needs no LDS round trips and no
+    // barrier before the substitution), then does the 16-step substitution x * Lbb^T = p for its own rows with
+    // the L entries as scalar operands.  Wave 0 also stores Lbb (for the backward solve and the owner of tile (b,b)).
+    {
+      const int D = pb + b * TS, rr = lane & 15;
+      double Lr[16], rinv[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) Lr[c] = Psh[D + rr * CH_LDT + c];
+#pragma unroll
       for (int j = 0; j < 16; j++) {
-        double d = sqrt(Psh[D + j * CH_LDT + j]);
-        WAVE_SYNC();
-        if (lane == j) Psh[D + j * CH_LDT + j] = d;
-        if (lane > j && lane < 16) Psh[D + lane * CH_LDT + j] = Psh[D + lane * CH_LDT + j] / d;
-        WAVE_SYNC();
-        // trailing update of the lower triangle of the block: element (i, c), j < c <= i < 16
-        for (int e = lane; e < 256; e += 64) {
-          int i = e >> 4, cc = e & 15;
-          if (cc > j && cc <= i)
-            Psh[D + i * CH_LDT + cc] = Psh[D + i * CH_LDT + cc] - Psh[D + i * CH_LDT + j] * Psh[D + cc * CH_LDT + j];
-        }
-        WAVE_SYNC();
+        const double pjj = bcast_lane(Lr[j], j);
+        const double d = sqrt(pjj);
+        rinv[j] = bcast_lane(1.0 / d, 0);  // wave-uniform: keep it in SGPRs
+        if (wave == 0 && lane == j) Rsh[b * 16 + j] = rinv[j];
+        const double lij = (rr == j) ? d : Lr[j] * rinv[j];  // rows < j hold unused upper-triangle values
+        Lr[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, bcast_lane(lij, c), Lr[c]);
       }
-      for (int e = lane; e < 256; e += 64)
-        Lsh[b * TS + (e >> 4) * CH_LDT + (e & 15)] = Psh[D + (e >> 4) * CH_LDT + (e & 15)];
-    }
-    __syncthreads();
-    // 3. rows below the block: x * Lbb^T = p, one thread per row, in place in LDS
-    if (tid < (mt - b - 1) * 16) {
-      const int pr = pb + (b + 1 + (tid >> 4)) * TS + (tid & 15) * CH_LDT;
-      const int L = b * TS;
-      for (int j = 0; j < 16; j++) {
-        double sacc = Psh[pr + j];
-        for (int t = 0; t < j; t++) sacc -= Psh[pr + t] * Lsh[L + j * CH_LDT + t];
-        Psh[pr + j] = sacc / Lsh[L + j * CH_LDT + j];
+      if (wave == 0 && lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          Psh[D + rr * CH_LDT + c] = Lr[c];
+          Lsh[b * TS + rr * CH_LDT + c] = Lr[c];
+        }
+      }
+      const int nrows = (mt - b - 1) * 16;
+      if (tid < nrows) {
+        const int pr = pb + (b + 1 + (tid >> 4)) * TS + (tid & 15) * CH_LDT;
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = Psh[pr + j];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          double sacc = x[j];
+#pragma unroll
+          for (int t = 0; t < j; t++) sacc = fma(-x[t], bcast_lane(Lr[t], j), sacc);  // L[j][t] lives in lane j
+          x[j] = sacc * rinv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) Psh[pr + j] = x[j];
       }
     }
     __syncthreads();
@@ -650,14 +788,19 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
   __syncthreads();
   for (int b = mt - 1; b >= 0; b--) {
     if (wave == 0) {
-      const int zz = b * 16, L = b * TS;
+      // lane i (< 16) holds z_i and COLUMN i of Lbb, so L[j][i] is a compile-time register of lane i
+      const int zz = b * 16, L = b * TS, ci = lane & 15;
+      double Lc[16], zi = z[zz + ci];
+#pragma unroll
+      for (int r = 0; r < 16; r++) Lc[r] = Lsh[L + r * CH_LDT + ci];
+      const double ri = Rsh[zz + ci];
+#pragma unroll
       for (int j = 15; j >= 0; j--) {
-        double xj = (b == mt - 1 && j == 15) ? 0.0 : z[zz + j] / Lsh[L + j * CH_LDT + j];
-        WAVE_SYNC();
-        if (lane == j) z[zz + j] = xj;
-        if (lane < j) z[zz + lane] = z[zz + lane] - Lsh[L + j * CH_LDT + lane] * xj;
-        WAVE_SYNC();
+        double xj = bcast_lane(zi, j) * bcast_lane(ri, j);
+        if (b == mt - 1 && j == 15) xj = 0.0;  // the augmented row is not an unknown
+        zi = (ci == j) ? xj : ((ci < j) ? fma(-Lc[j], xj, zi) : zi);
       }
+      if (lane < 16) z[zz + ci] = zi;
     }
     __syncthreads();
 #pragma unroll
@@ -704,6 +847,22 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
     ctrl->T0 = T0;
     ctrl->k_cur = k_init;
     ctrl->coef0 = coef0_init;
+    ctrl->irls_done = 0;
+    ctrl->irls_steps = 0;
+    ctrl->info = 0;
+    ctrl->same_prev = 0;
+    ctrl->d_fresh = 0;
+  }
+}
+
+// Start of a fit whose initial coefficients ARE the device state left by the previous fit (warm-start chain on
+// one row set): nothing to upload, only the loop bookkeeping is reset.
+__global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl, int T0, int *__restrict__ hist) {
+  for (int i = threadIdx.x; i < T0; i += 256) hist[i] = 0;
+  if (threadIdx.x == 0) {
+    ctrl->done = 0;
+    ctrl->l = 0;
+    ctrl->T0 = T0;
     ctrl->irls_done = 0;
     ctrl->irls_steps = 0;
     ctrl->info = 0;
@@ -1688,18 +1847,43 @@ bool topk_supported(int len, int k) {
 
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
-                       double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st) {
+                       double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st, int tile_base) {
   long nwaves = (long)ntask * nslab;
   int nblk = (int)((nwaves + 3) / 4);
   if (w)
     hipLaunchKernelGGL(k_gram<true>, dim3(nblk), dim3(256), 0, st, X, aux, ld, cols, w, rows_per_slab, tasks, ntask,
-                       nslab, part, ntiles, ctrl, slot, gate_mode);
+                       nslab, part, ntiles, ctrl, slot, gate_mode, tile_base);
   else
     hipLaunchKernelGGL(k_gram<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, cols, w, rows_per_slab, tasks, ntask,
-                       nslab, part, ntiles, ctrl, slot, gate_mode);
+                       nslab, part, ntiles, ctrl, slot, gate_mode, tile_base);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 31) / 32), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
                      slot, gate_mode);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// LM Gram with the per-row-set cache.  tasks_full / tasks_inc: task lists for the whole lower triangle and for the
+// extra tile row (I = mt); gbuf[0/1]: the two dense cache buffers, meta[1] says which one is current.
+hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, int *cols, const double *w,
+                                 const int *A_new, int T0, int mt, const GramTask *tasks_full, int ntask_full,
+                                 int rps_full, int nslab_full, const GramTask *tasks_inc, int ntask_inc, int rps_inc,
+                                 int nslab_inc, double *part, double *Gt, double *Rt, int *src, double *gbuf0,
+                                 double *gbuf1, int *Ac, int *meta, FitCtrl *ctrl, int slot, hipStream_t st) {
+  const int mp = mt * 16, ntiles = mt * (mt + 1) / 2;
+  hipLaunchKernelGGL(k_gram_plan, dim3(1), dim3(256), 0, st, A_new, T0, mp, (const int *)Ac, (const int *)meta, src,
+                     cols, ctrl, slot);
+  LAUNCH_CHECK();
+  hipError_t e = launch_gram(X, aux, ld, cols, w, rps_full, tasks_full, ntask_full, nslab_full, part, ntiles, Gt, ctrl,
+                             slot, 3, st, 0);
+  if (e != hipSuccess) return e;
+  e = launch_gram(X, aux, ld, cols, w, rps_inc, tasks_inc, ntask_inc, nslab_inc, part, mt, Rt, ctrl, slot, 4, st,
+                  ntiles);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_gram_assemble, dim3(ntiles), dim3(256), 0, st, Gt, (const double *)Rt, (const int *)src, T0,
+                     gbuf0, gbuf1, (const int *)meta, (const FitCtrl *)ctrl, slot);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gram_cache_commit, dim3(1), dim3(256), 0, st, A_new, T0, Ac, meta, (const FitCtrl *)ctrl, slot);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -1708,8 +1892,15 @@ hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
                        hipStream_t st) {
   if (mt < 1 || mt > CH_MT || m + 1 > mt * 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_chol, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info,
-                     ctrl, slot, gate_mode);
+  if (mt <= 8)
+    hipLaunchKernelGGL(k_chol<5>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info,
+                       ctrl, slot, gate_mode);
+  else if (mt <= 12)
+    hipLaunchKernelGGL(k_chol<10>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
+                       info, ctrl, slot, gate_mode);
+  else
+    hipLaunchKernelGGL(k_chol<17>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
+                       info, ctrl, slot, gate_mode);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -1721,6 +1912,12 @@ hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_i
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fit_begin, dim3(1), dim3(256), 0, st, ctrl, T0, k_init, init_idx, init_val, coef0_init, A_cur,
                      b_cur, beta_dense, hist);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st) {
+  hipLaunchKernelGGL(k_fit_continue, dim3(1), dim3(256), 0, st, ctrl, T0, hist);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -1867,9 +2064,9 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                      (const FitCtrl *)ctrl, slot, t);
   LAUNCH_CHECK();
   // Hessian: -h = X_A^T diag(theta C) X_A - M^T diag(w delta) M  (from :1458-1470)
-  hipError_t e = launch_gram(X, aux, ld, gcols, cb.WG1, rps, tasks, ntask, nslab, gpart, ntiles, Gt, ctrl, slot, 2, st);
+  hipError_t e = launch_gram(X, aux, ld, gcols, cb.WG1, rps, tasks, ntask, nslab, gpart, ntiles, Gt, ctrl, slot, 2, st, 0);
   if (e != hipSuccess) return e;
-  e = launch_gram(cb.M, aux, ld, idcols, cb.WD, rps, tasks, ntask, nslab, gpart, ntiles, cb.Gt2, ctrl, slot, 2, st);
+  e = launch_gram(cb.M, aux, ld, idcols, cb.WD, rps, tasks, ntask, nslab, gpart, ntiles, cb.Gt2, ctrl, slot, 2, st, 0);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_tile_sub, dim3((ntiles * 256 + 255) / 256), dim3(256), 0, st, Gt, (const double *)cb.Gt2,
                      (long)ntiles * 256, (const FitCtrl *)ctrl, slot, t);
