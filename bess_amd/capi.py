@@ -22,6 +22,7 @@ _vp = ctypes.c_void_p
 SYMBOLS = [
     "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_session_create",
     "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_sequential_path", "bessx_session_gs_path",
+    "bessx_session_pgs_path",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
@@ -73,6 +74,7 @@ def lib():
         L.bessx_session_set_cv.argtypes = [_vp, _i, _I, ctypes.c_uint]
         L.bessx_session_sequential_path.argtypes = [_vp, _I, _i, _D, _i, _i, _i, ctypes.POINTER(PathResult)]
         L.bessx_session_gs_path.argtypes = [_vp, _i, _i, _i, _i, ctypes.POINTER(PathResult)]
+        L.bessx_session_pgs_path.argtypes = [_vp, _i, _i, _d, _d, _i, _i, _i, _i, ctypes.POINTER(PathResult)]
         L.bessx_session_trace_enable.argtypes = [_vp, _i]
         L.bessx_session_trace_size.argtypes = [_vp, _i]
         L.bessx_session_trace_copy_int.argtypes = [_vp, _i, _I]
@@ -248,6 +250,11 @@ class Session:
         L = lib()
         return self._run(lambda r: L.bessx_session_gs_path(self._h, s_min, s_max, ic_type, int(is_cv), r),
                          2 * (s_max - s_min + 1) + 64, max(s_max, 1))
+
+    def pgs_path(self, s_min, s_max, lambda_min, lambda_max, n_lambda=100, powell_path=1, ic_type=4, is_cv=False):
+        L = lib()
+        return self._run(lambda r: L.bessx_session_pgs_path(self._h, s_min, s_max, lambda_min, lambda_max, n_lambda,
+                                                            powell_path, ic_type, int(is_cv), r), 128, max(s_max, 1))
 
     def fit(self, T0, lam=0.0, fold=-1, init_idx=(), init_val=(), init_coef0=0.0):
         ii, iv = _i32(init_idx), _f64(init_val)

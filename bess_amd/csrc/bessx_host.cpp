@@ -901,8 +901,346 @@ static int gs_path(bessx_session *s, int s_min, int s_max, int ic_type, int is_c
   return 0;
 }
 
+// --------------------------------------------------------------------------------------------
+// Powell path for the L0L2 / bsrr types: pgs_path with golden-section or sequential line searches over
+// (s, log lambda), src/path.cpp:391-1309.  Pure host control over algorithm_fit(); the ic_sequence matrix the
+// reference fills on the side (returned only by the R build as ic_mat) is not kept.
+// --------------------------------------------------------------------------------------------
+namespace powell {
+
+static int sgn(double a) { return a > 0 ? 1 : (a < 0 ? -1 : 0); }
+static double det2(const double a[2], const double b[2]) { return a[0] * b[1] - a[1] * b[0]; }
+
+static bool line_intersection(double l1[2][2], double l2[2][2], double out[2]) {  // :414-440
+  double xd[2] = {l1[0][0] - l1[1][0], l2[0][0] - l2[1][0]}, yd[2] = {l1[0][1] - l1[1][1], l2[0][1] - l2[1][1]};
+  double div = det2(xd, yd);
+  if (div == 0) return false;
+  double d[2] = {det2(l1[0], l1[1]), det2(l2[0], l2[1])};
+  out[0] = det2(d, xd) / div;
+  out[1] = det2(d, yd) / div;
+  return true;
+}
+
+static void cal_intersections(const double p[2], const double u[2], int s_min, int s_max, double lmin, double lmax,
+                              double a[2], double b[2]) {  // :445-577
+  double l0[2][2] = {{p[0], p[1]}, {p[0] + u[0], p[1] + u[1]}};
+  double ls[4][2][2] = {{{(double)s_min, lmin}, {(double)s_min, lmax}},
+                        {{(double)s_max, lmin}, {(double)s_max, lmax}},
+                        {{(double)s_min, lmin}, {(double)s_max, lmin}},
+                        {{(double)s_min, lmax}, {(double)s_max, lmax}}};
+  double is[4][2];
+  bool ok[4];
+  for (int i = 0; i < 4; i++) ok[i] = line_intersection(l0, ls[i], is[i]);
+  for (int i = 0; i < 4; i++)
+    if (ok[i] && (is[i][0] < s_min - 0.0001 || is[i][0] > s_max + 0.0001 || is[i][1] < lmin - 0.001 ||
+                  is[i][1] > lmax + 0.001))
+      ok[i] = false;
+  for (int i = 0; i < 4; i++)
+    if (ok[i])
+      for (int j = i + 1; j < 4; j++)
+        if (ok[j] && std::fabs(is[i][0] - is[j][0]) < 0.0001 && std::fabs(is[i][1] - is[j][1]) < 0.0001) ok[j] = false;
+  int j = 0;
+  for (int i = 0; i < 4; i++)
+    if (ok[i]) {
+      if (j == 2) j += 1;
+      if (j == 1) {
+        b[0] = is[i][0];
+        b[1] = is[i][1];
+        j += 1;
+      }
+      if (j == 0) {
+        a[0] = is[i][0];
+        a[1] = is[i][1];
+        j += 1;
+      }
+    }
+}
+
+struct Search {
+  bessx_session *s;
+  int ic_type, is_cv;
+  SparseVec beta_init;
+  double coef0_init = 0.0;
+  int fit(int T0, double lambda) {
+    if (int rc = run_fit(s, T0, lambda, beta_init, coef0_init)) return rc;
+    if (s->warm_start) {
+      beta_init = s->beta;
+      coef0_init = s->coef0;
+    }
+    return 0;
+  }
+};
+
+struct Point {  // what a line search reports back
+  SparseVec beta;
+  double coef0 = 0, loss = 0, ic = 0;
+};
+
+#define PW_TRY(expr)              \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__) return rc__;        \
+  } while (0)
+
+// golden_section_search, :579-935
+static int golden_section_search(bessx_session *s, int ic_type, int is_cv, const double p[2], const double u[2],
+                                 int s_min, int s_max, double lmin, double lmax, double best_arg[2], Point &out) {
+  Search ps{s, ic_type, is_cv, SparseVec(), 0.0};
+  SparseVec bt1, bt2;
+  double lt1 = 0, lt2 = 0, c01 = 0, c02 = 0, closs, dloss, a[2] = {0, 0}, b[2] = {0, 0}, c[2], d[2], h[2];
+  const double s_tol = 2, ltol = (lmax - lmin) / 200;
+  const double invphi = (std::pow(5, 0.5) - 1.0) / 2.0, invphi2 = (3.0 - std::pow(5, 0.5)) / 2.0;
+  cal_intersections(p, u, s_min, s_max, lmin, lmax, a, b);
+  h[0] = b[0] - a[0];
+  h[1] = b[1] - a[1];
+  c[0] = a[0] + invphi2 * h[0];
+  c[1] = a[1] + invphi2 * h[1];
+  d[0] = a[0] + invphi * h[0];
+  d[1] = a[1] + invphi * h[1];
+  if (h[0] > 0.0001) {
+    c[0] = (int)c[0];
+    d[0] = std::ceil(d[0]);
+  } else if (h[0] < -0.0001) {
+    c[0] = std::ceil(c[0]);
+    d[0] = (int)d[0];
+  } else {
+    c[0] = std::round(c[0]);
+    d[0] = std::round(d[0]);
+  }
+  PW_TRY(ps.fit((int)c[0], std::exp(c[1])));
+  PW_TRY(metric_ic(s, ic_type, is_cv, &closs));
+  c01 = s->coef0;
+  bt1 = s->beta;
+  PW_TRY(metric_train_loss(s, &lt1));
+  PW_TRY(ps.fit((int)d[0], std::exp(d[1])));
+  PW_TRY(metric_ic(s, ic_type, is_cv, &dloss));
+  c02 = s->coef0;
+  bt2 = s->beta;
+  PW_TRY(metric_train_loss(s, &lt2));
+  int tt = 0;
+  for (;;) {
+    if ((std::fabs((invphi2 - invphi) * h[0]) <= s_tol && std::fabs((invphi2 - invphi) * h[1]) < ltol) || tt == 50) {
+      double min_loss, tmp;
+      if (closs < dloss) {
+        best_arg[0] = c[0];
+        best_arg[1] = c[1];
+        min_loss = closs;
+        out.beta = bt1;
+        out.coef0 = c01;
+        out.ic = closs;
+        out.loss = lt1;
+      } else {
+        best_arg[0] = d[0];
+        best_arg[1] = d[1];
+        min_loss = dloss;
+        out.beta = bt2;
+        out.coef0 = c02;
+        out.ic = dloss;
+        out.loss = lt2;
+      }
+      for (int i = 1; i < std::fabs((invphi2 - invphi) * h[0]); i++) {
+        PW_TRY(ps.fit((int)(c[0] + sgn(h[0]) * i), std::exp(c[1])));
+        PW_TRY(metric_ic(s, ic_type, is_cv, &tmp));
+        if (tmp < min_loss) {
+          best_arg[0] = c[0] + sgn(h[0]) * i;
+          best_arg[1] = c[1];
+          min_loss = tmp;
+          out.beta = s->beta;
+          out.coef0 = s->coef0;
+          PW_TRY(metric_train_loss(s, &out.loss));
+          out.ic = min_loss;
+        }
+      }
+      return 0;
+    }
+    if (tt >= 100) return 0;
+    tt++;
+    if (closs < dloss) {
+      // the stored model of d (bt2, c02, lt2) is deliberately NOT moved along with the point (:762-766)
+      b[0] = d[0];
+      b[1] = d[1];
+      d[0] = c[0];
+      d[1] = c[1];
+      dloss = closs;
+      h[0] = b[0] - a[0];
+      h[1] = b[1] - a[1];
+      c[0] = a[0] + invphi2 * h[0];
+      c[1] = a[1] + invphi2 * h[1];
+      c[0] = h[0] > 0.0001 ? (double)(int)c[0] : (h[0] < -0.0001 ? std::ceil(c[0]) : std::round(c[0]));
+      PW_TRY(ps.fit((int)c[0], std::exp(c[1])));
+      PW_TRY(metric_ic(s, ic_type, is_cv, &closs));
+      c01 = s->coef0;
+      bt1 = s->beta;
+      PW_TRY(metric_train_loss(s, &lt1));
+    } else {
+      a[0] = c[0];
+      a[1] = c[1];
+      c[0] = d[0];
+      c[1] = d[1];
+      closs = dloss;
+      h[0] = b[0] - a[0];
+      h[1] = b[1] - a[1];
+      d[0] = a[0] + invphi * h[0];
+      d[1] = a[1] + invphi * h[1];
+      d[0] = h[0] > 0.0001 ? std::ceil(d[0]) : (h[0] < -0.0001 ? (double)(int)d[0] : std::round(d[0]));
+      PW_TRY(ps.fit((int)d[0], std::exp(d[1])));
+      PW_TRY(metric_ic(s, ic_type, is_cv, &dloss));
+      c02 = s->coef0;
+      bt2 = s->beta;
+      PW_TRY(metric_train_loss(s, &lt2));
+    }
+  }
+}
+
+static int gdc_int(int a, int b) {  // GDC, :937-953
+  int Max = a > b ? a : b, Min = (a == Max) ? b : a, z = Min;
+  while (Max % Min != 0) {
+    z = Max % Min;
+    Max = Min;
+    Min = z;
+  }
+  return z;
+}
+
+// seq_search, :954-1137 (u is normalised in place like the reference does)
+static int seq_search(bessx_session *s, int ic_type, int is_cv, double p[2], double u[2], int s_min, int s_max,
+                      double lmin, double lmax, double best_arg[2], Point &out, int nlambda) {
+  Search ps{s, ic_type, is_cv, SparseVec(), 0.0};
+  const double d_lambda = (lmax - lmin) / (nlambda - 1);
+  const size_t cap = (size_t)(s_max - s_min + 1) * nlambda + 2;
+  int k_lambda = (int)std::fabs(std::round(u[1] / d_lambda));
+  if (std::fabs(u[0]) != 1 && k_lambda != 1) {
+    if (k_lambda == 0 && u[0] != 0) {
+      u[0] = u[0] / std::fabs(u[0]);
+    } else if (u[0] == 0 && k_lambda != 0) {
+      u[1] = u[1] / k_lambda;
+    } else if (!(k_lambda == 0 && (int)u[0] == 0)) {  // the reference divides by zero there
+      int g = gdc_int(k_lambda, std::abs((int)u[0]));
+      if (g) {
+        u[0] = std::round(u[0] / g);
+        u[1] = u[1] / g;
+      }
+    }
+  }
+  std::vector<Point> f1, f2;
+  auto eval = [&](int T0, double lambda, std::vector<Point> &dst) -> int {
+    PW_TRY(ps.fit(T0, lambda));
+    Point q;
+    PW_TRY(metric_ic(s, ic_type, is_cv, &q.ic));
+    q.beta = s->beta;
+    q.coef0 = s->coef0;
+    PW_TRY(metric_train_loss(s, &q.loss));
+    dst.push_back(q);
+    return 0;
+  };
+  PW_TRY(eval((int)(p[0]), std::exp(p[1]), f1));
+  f2.push_back(f1[0]);
+  SparseVec beta_warm = ps.beta_init;
+  double coef0_warm = ps.coef0_init;
+  for (int i = 1; (p[0] + i * u[0] <= s_max) && (p[1] + i * u[1] <= lmax + d_lambda * 1e-4) &&
+                  (p[0] + i * u[0] >= s_min) && (p[1] + i * u[1] >= lmin - d_lambda * 1e-4) && f1.size() < cap;
+       i++)
+    PW_TRY(eval((int)(p[0] + i * u[0]), std::exp(p[1] + i * u[1]), f1));
+  ps.beta_init = beta_warm;
+  ps.coef0_init = coef0_warm;
+  for (int j = 1; (p[0] - j * u[0] <= s_max) && (p[1] - j * u[1] <= lmax + d_lambda * 1e-4) &&
+                  (p[0] - j * u[0] >= s_min) && (p[1] - j * u[1] >= lmin - d_lambda * 1e-4) && f2.size() < cap;
+       j++)
+    PW_TRY(eval((int)(p[0] - j * u[0]), std::exp(p[1] - j * u[1]), f2));
+  size_t m1 = 0, m2 = 0;
+  for (size_t q = 1; q < f1.size(); q++)
+    if (f1[q].ic < f1[m1].ic) m1 = q;
+  for (size_t q = 1; q < f2.size(); q++)
+    if (f2[q].ic < f2[m2].ic) m2 = q;
+  int minpos;
+  if (f1[m1].ic < f2[m2].ic) {
+    minpos = (int)m1;
+    out = f1[m1];
+  } else {
+    minpos = -(int)m2;
+    out = f2[m2];
+  }
+  best_arg[0] = p[0] + minpos * u[0];
+  best_arg[1] = p[1] + minpos * u[1];
+  return 0;
+}
+
+}  // namespace powell
+
+// pgs_path, :1138-1309
+static int pgs_path(bessx_session *s, int s_min, int s_max, double lmin, double lmax, int powell_path, int nlambda,
+                    int ic_type, int is_cv, bessx_path_result *res) {
+  using namespace powell;
+  if (powell_path == 1) nlambda = 100;
+  double P[3][2] = {{(double)s_min, lmin}, {0, 0}, {0, 0}};
+  double U[2][2] = {{0., (lmax - lmin) / (nlambda - 1)}, {1., 0.}};
+  std::vector<Candidate> all;
+  Point pt;
+  auto search = [&](double *pin, double *uu, double *pout) -> int {
+    return powell_path == 1 ? golden_section_search(s, ic_type, is_cv, pin, uu, s_min, s_max, lmin, lmax, pout, pt)
+                            : seq_search(s, ic_type, is_cv, pin, uu, s_min, s_max, lmin, lmax, pout, pt, nlambda);
+  };
+  auto record = [&](size_t idx, double lam) {
+    if (all.size() <= idx) all.resize(idx + 1);
+    Candidate &c = all[idx];
+    c.T0 = (int)pt.beta.idx.size();
+    c.lambda = lam;
+    c.beta = pt.beta;
+    c.coef0 = pt.coef0;
+    c.loss = pt.loss;
+    c.ic = pt.ic;
+    c.iters = 0;
+  };
+  int ttt = 0;
+  PW_TRY(search(P[0], U[1], P[0]));
+  record(ttt, std::exp(P[0][1]));
+  while (ttt < 11) {
+    ttt++;
+    for (int i = 0; i < 2; i++) {
+      PW_TRY(search(P[i], U[i], P[i + 1]));
+      record(ttt, std::exp(P[i + 1][1]));
+      ttt++;
+    }
+    U[0][0] = U[1][0];
+    U[0][1] = U[1][1];
+    U[1][0] = P[2][0] - P[0][0];
+    U[1][1] = P[2][1] - P[0][1];
+    if (!(std::fabs(U[1][0]) <= 0.0001 && std::fabs(U[1][1]) <= 0.0001) && ttt < 11) {
+      PW_TRY(search(P[0], U[1], P[0]));
+      record(ttt, std::exp(P[0][1]));
+    } else {
+      // final fit at P[0]; beta_init / coef0_init are whatever the last search left in the algorithm (:1221-1225)
+      s->cur_rows = 0;
+      s->sparsity_level = (int)P[0][0];
+      s->lambda_level = std::exp(P[0][1]);
+      PW_TRY(algorithm_fit(s));
+      pt.beta = s->beta;
+      pt.coef0 = s->coef0;
+      PW_TRY(metric_train_loss(s, &pt.loss));
+      PW_TRY(metric_ic(s, ic_type, is_cv, &pt.ic));
+      record(ttt, std::exp(P[0][1]));
+      all[ttt].iters = s->l;
+      ttt++;
+      size_t mi = 0;
+      for (size_t k = 1; k < (size_t)ttt; k++)
+        if (all[k].ic < all[mi].ic) mi = k;
+      if (all[mi].ic == all[ttt - 1].ic) mi = ttt - 1;
+      for (int k = 0; k < ttt; k++) store_candidate(s, res, all[k], false);
+      store_best(s, res, all[mi], false);
+      return 0;
+    }
+  }
+  return fail(BESSX_ERR_NUMERIC, "powell end wrong (src/path.cpp:1298-1308)");
+}
+#undef PW_TRY
+
+struct PgsArgs {
+  double lmin, lmax;
+  int powell_path, nlambda;
+};
+
 static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *lam, int nl, int s_min,
-                    int s_max, int ic_type, int is_cv, bessx_path_result *res) {
+                    int s_max, int ic_type, int is_cv, bessx_path_result *res, const PgsArgs *pgs = nullptr) {
   if (!s || !res) return fail(BESSX_ERR_ARG, "null session or result");
   if (is_cv && s->K < 2) return fail(BESSX_ERR_ARG, "is_cv needs bessx_session_set_cv first");
   HIPX(hipSetDevice(s->device));
@@ -914,7 +1252,9 @@ static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const dou
   s->n_fits = 0;
   s->n_iters = 0;
   auto t0 = std::chrono::steady_clock::now();
-  int rc = gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res) : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res);
+  int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
+           : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
+                : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res);
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
   res->n_fits = s->n_fits;
@@ -1313,6 +1653,16 @@ int bessx_session_gs_path(bessx_session *s, int s_min, int s_max, int ic_type, i
   return run_path(s, true, nullptr, 0, nullptr, 0, s_min, s_max, ic_type, is_cv, res);
 }
 
+int bessx_session_pgs_path(bessx_session *s, int s_min, int s_max, double lambda_min, double lambda_max, int n_lambda,
+                           int powell_path, int ic_type, int is_cv, bessx_path_result *res) {
+  if (s_min < 1 || s_max < s_min) return fail(BESSX_ERR_ARG, "pgs_path: need 1 <= s_min <= s_max");
+  if (powell_path != 1 && powell_path != 2) return fail(BESSX_ERR_ARG, "pgs_path: powell_path must be 1 or 2");
+  if (powell_path == 2 && n_lambda < 2) return fail(BESSX_ERR_ARG, "pgs_path: n_lambda must be >= 2");
+  // bessCpp, src/bess.cpp:176-177
+  PgsArgs a{std::log(std::max(lambda_min, 1e-5)), std::log(std::max(lambda_max, 1e-5)), powell_path, n_lambda};
+  return run_path(s, true, nullptr, 0, nullptr, 0, s_min, s_max, ic_type, is_cv, res, &a);
+}
+
 int bessx_session_trace_enable(bessx_session *s, int on) {
   if (!s) return fail(BESSX_ERR_ARG, "null session");
   s->trace.on = on != 0;
@@ -1419,8 +1769,8 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
                       double *train_loss_out, int train_loss_out_len, double *ic_out, int ic_out_len,
                       double *nullloss_out, double *aic_out, int aic_out_len, double *bic_out, int bic_out_len,
                       double *gic_out, int gic_out_len, int *A_out, int A_out_len, int *l_out) {
-  (void)exchange_num; (void)state; (void)state_len; (void)K_max; (void)epsilon; (void)lambda_min; (void)lambda_max;
-  (void)n_lambda; (void)screening_size; (void)powell_path; (void)tao;  // dead on the live reference paths
+  (void)exchange_num; (void)state; (void)state_len; (void)K_max; (void)epsilon; (void)screening_size;
+  (void)tao;  // dead on the live reference paths
   (void)coef0_out_len; (void)train_loss_out_len; (void)ic_out_len;
   if (!x || !y || !beta_out || !coef0_out || !train_loss_out || !ic_out) return fail(BESSX_ERR_ARG, "null argument");
   if (y_len != x_row || (weight && weight_len != x_row)) return fail(BESSX_ERR_ARG, "length of y / weight != rows of x");
@@ -1429,8 +1779,6 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
   if (gindex_len != x_col) return fail(BESSX_ERR_UNSUPPORTED, "group selection (group size > 1) is not built yet");
   for (int j = 0; j < gindex_len; j++)
     if (gindex[j] != j) return fail(BESSX_ERR_UNSUPPORTED, "group selection (group size > 1) is not built yet");
-  if (path_type != 1 && (algorithm_type == 5 || algorithm_type == 3))
-    return fail(BESSX_ERR_UNSUPPORTED, "Powell path (pgs_path, src/path.cpp:1138) is not built yet");
   bessx_problem pb;
   std::memset(&pb, 0, sizeof(pb));
   pb.n = x_row;
@@ -1459,6 +1807,8 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
     if (path_type == 1)
       rc = bessx_session_sequential_path(s, sequence, sequence_len, lambda_sequence, lambda_sequence_len, ic_type,
                                          is_cv, &res);
+    else if (algorithm_type == 5 || algorithm_type == 3)  // src/bess.cpp:174-180
+      rc = bessx_session_pgs_path(s, s_min, s_max, lambda_min, lambda_max, n_lambda, powell_path, ic_type, is_cv, &res);
     else
       rc = bessx_session_gs_path(s, s_min, s_max, ic_type, is_cv, &res);
   }

@@ -10,7 +10,7 @@
  *   1. bessx_pywrap_bess      <- pywrap_bess, src/bess.h:35-51 (what SWIG binds, python/src/bess.i:17-30)
  *   2. bessx_session_*        <- bessCpp, src/bess.h:20-33: Data + Algorithm* + Metric* set-up
  *                                (src/bess.cpp:61-165) kept resident on the GPU, then
- *                                sequential_path / gs_path (src/path.h:22-25)
+ *                                sequential_path / gs_path / pgs_path (src/path.h:22-44)
  *   3. bessx_session_fit      <- Algorithm::fit + the update_* setters, src/Algorithm.h:77-171
  *   4. bessx_op_*             <- single Eigen call sites of the hot loop;
  *                                exported so that every HIP kernel can be parity-tested alone.
@@ -26,7 +26,7 @@ enum {
   BESSX_OK = 0,
   BESSX_ERR_ARG = 1,         /* invalid argument (the reference would crash or read out of bounds) */
   BESSX_ERR_HIP = 2,         /* HIP runtime / device failure, or no device */
-  BESSX_ERR_UNSUPPORTED = 3, /* valid for the reference, not built here (groups > 1, screening, Powell path) */
+  BESSX_ERR_UNSUPPORTED = 3, /* valid for the reference, not built here (groups of size > 1, screening) */
   BESSX_ERR_NUMERIC = 4      /* non-finite pivot in a k x k solve */
 };
 
@@ -116,6 +116,13 @@ int bessx_session_sequential_path(bessx_session *s, const int *sequence, int seq
                                   bessx_path_result *res);
 /* gs_path (src/path.cpp:134-389): integer golden section on [s_min, s_max] then exhaustive sweep. */
 int bessx_session_gs_path(bessx_session *s, int s_min, int s_max, int ic_type, int is_cv, bessx_path_result *res);
+
+/* pgs_path (src/path.cpp:1138-1309): Powell search over (s, log lambda) for the L0L2 / bsrr types; line searches
+ * by golden section (powell_path 1, n_lambda forced to 100) or on the lambda grid (powell_path 2).  lambda_min /
+ * lambda_max are floored at 1e-5 as bessCpp does (src/bess.cpp:176-177).  Candidates = the best point of every
+ * line search plus the final re-fit; res->lambda receives the chosen lambda. */
+int bessx_session_pgs_path(bessx_session *s, int s_min, int s_max, double lambda_min, double lambda_max, int n_lambda,
+                           int powell_path, int ic_type, int is_cv, bessx_path_result *res);
 
 /* Optional trace of every PDAS iteration of every fit of the LAST path run, same layout as the
  * oracle's (oracle/bess_oracle.h): which = 0 geta_meta(int x4: l, T0, train_n, offset) 1 a_flat(int)

@@ -922,6 +922,393 @@ static void gs_path(oalg *a, ometric *m, const double *xtx, int s_min, int s_max
 #undef GS_FIT
 }
 
+/* ------------------------------------------------------------------ Powell path (L0L2 / bsrr)
+ * pgs_path, golden_section_search, seq_search and their geometry helpers, src/path.cpp:391-1309.
+ * The ic_sequence matrix those functions fill is returned only by the R build (ic_mat) and never read back,
+ * so it is not kept here (the reference even indexes it out of range, e.g. :651 uses int(c[0]) as the row
+ * of an (s_max - s_min + 1)-row matrix). */
+
+static int sgn(double a) { return a > 0 ? 1 : (a < 0 ? -1 : 0); } /* :391-405 */
+static double det2(const double a[2], const double b[2]) { return a[0] * b[1] - a[1] * b[0]; }
+
+static void line_intersection(double l1[2][2], double l2[2][2], double out[2], int *ok) { /* :414-440 */
+  double xd[2], yd[2], d[2], div;
+  xd[0] = l1[0][0] - l1[1][0];
+  xd[1] = l2[0][0] - l2[1][0];
+  yd[0] = l1[0][1] - l1[1][1];
+  yd[1] = l2[0][1] - l2[1][1];
+  div = det2(xd, yd);
+  if (div == 0) {
+    *ok = 0;
+    return;
+  }
+  d[0] = det2(l1[0], l1[1]);
+  d[1] = det2(l2[0], l2[1]);
+  out[0] = det2(d, xd) / div;
+  out[1] = det2(d, yd) / div;
+  *ok = 1;
+}
+
+static void cal_intersections(const double p[2], const double u[2], int s_min, int s_max, double lmin, double lmax,
+                              double a[2], double b[2]) { /* :445-577 */
+  double l0[2][2], ls[4][2][2], is[4][2];
+  int ok[4], i, j;
+  l0[0][0] = p[0];
+  l0[0][1] = p[1];
+  l0[1][0] = p[0] + u[0];
+  l0[1][1] = p[1] + u[1];
+  ls[0][0][0] = s_min; ls[0][0][1] = lmin; ls[0][1][0] = s_min; ls[0][1][1] = lmax;
+  ls[1][0][0] = s_max; ls[1][0][1] = lmin; ls[1][1][0] = s_max; ls[1][1][1] = lmax;
+  ls[2][0][0] = s_min; ls[2][0][1] = lmin; ls[2][1][0] = s_max; ls[2][1][1] = lmin;
+  ls[3][0][0] = s_min; ls[3][0][1] = lmax; ls[3][1][0] = s_max; ls[3][1][1] = lmax;
+  for (i = 0; i < 4; i++) line_intersection(l0, ls[i], is[i], &ok[i]);
+  for (i = 0; i < 4; i++)
+    if (ok[i] && ((is[i][0] < s_min - 0.0001) | (is[i][0] > s_max + 0.0001) | (is[i][1] < lmin - 0.001) |
+                  (is[i][1] > lmax + 0.001)))
+      ok[i] = 0;
+  for (i = 0; i < 4; i++)
+    if (ok[i])
+      for (j = i + 1; j < 4; j++)
+        if (ok[j] && fabs(is[i][0] - is[j][0]) < 0.0001 && fabs(is[i][1] - is[j][1]) < 0.0001) ok[j] = 0;
+  j = 0;
+  for (i = 0; i < 4; i++)
+    if (ok[i]) {
+      if (j == 2) j += 1;
+      if (j == 1) {
+        b[0] = is[i][0];
+        b[1] = is[i][1];
+        j += 1;
+      }
+      if (j == 0) {
+        a[0] = is[i][0];
+        a[1] = is[i][1];
+        j += 1;
+      }
+    }
+}
+
+typedef struct {
+  oalg *a;
+  ometric *m;
+  const double *xtx;
+  double *beta_init; /* the search's own warm-start vector */
+  double coef0_init;
+} psearch;
+
+static void ps_fit(psearch *ps, int T0, double lambda) {
+  run_fit(ps->a, T0, lambda, ps->beta_init, ps->coef0_init, ps->xtx);
+  if (ps->a->warm_start) {
+    memcpy(ps->beta_init, ps->a->beta, (size_t)ps->a->d->p * sizeof(double));
+    ps->coef0_init = ps->a->coef0;
+  }
+}
+
+/* golden_section_search, :579-935 */
+static void golden_section_search(oalg *al, ometric *m, const double *xtx, const double p[2], const double u[2],
+                                  int s_min, int s_max, double lmin, double lmax, double best_arg[2], double *beta1,
+                                  double *coef01, double *loss1, double *ic1) {
+  int P = al->d->p, tt = 0, i;
+  psearch ps;
+  double *bt1 = (double *)calloc((size_t)P, sizeof(double)), *bt2 = (double *)calloc((size_t)P, sizeof(double));
+  double lt1 = 0, lt2 = 0, c01 = 0, c02 = 0, closs, dloss, a[2] = {0, 0}, b[2] = {0, 0}, c[2], d[2], h[2];
+  const double s_tol = 2, ltol = (lmax - lmin) / 200;
+  const double invphi = (pow(5, 0.5) - 1.0) / 2.0, invphi2 = (3.0 - pow(5, 0.5)) / 2.0;
+  ps.a = al;
+  ps.m = m;
+  ps.xtx = xtx;
+  ps.beta_init = (double *)calloc((size_t)P, sizeof(double));
+  ps.coef0_init = 0.0;
+  cal_intersections(p, u, s_min, s_max, lmin, lmax, a, b);
+  h[0] = b[0] - a[0];
+  h[1] = b[1] - a[1];
+  c[0] = a[0] + invphi2 * h[0];
+  c[1] = a[1] + invphi2 * h[1];
+  d[0] = a[0] + invphi * h[0];
+  d[1] = a[1] + invphi * h[1];
+  if (h[0] > 0.0001) {
+    c[0] = (int)c[0];
+    d[0] = ceil(d[0]);
+  } else if (h[0] < -0.0001) {
+    c[0] = ceil(c[0]);
+    d[0] = (int)d[0];
+  } else {
+    c[0] = round(c[0]);
+    d[0] = round(d[0]);
+  }
+  ps_fit(&ps, (int)c[0], exp(c[1]));
+  closs = metric_ic(m, al);
+  c01 = al->coef0;
+  memcpy(bt1, al->beta, (size_t)P * sizeof(double));
+  lt1 = metric_train_loss(m, al);
+  ps_fit(&ps, (int)d[0], exp(d[1]));
+  dloss = metric_ic(m, al);
+  c02 = al->coef0;
+  memcpy(bt2, al->beta, (size_t)P * sizeof(double));
+  lt2 = metric_train_loss(m, al);
+  for (;;) {
+    if ((fabs((invphi2 - invphi) * h[0]) <= s_tol && fabs((invphi2 - invphi) * h[1]) < ltol) || tt == 50) {
+      double min_loss, tmp;
+      if (closs < dloss) {
+        best_arg[0] = c[0];
+        best_arg[1] = c[1];
+        min_loss = closs;
+        memcpy(beta1, bt1, (size_t)P * sizeof(double));
+        *coef01 = c01;
+        *ic1 = closs;
+        *loss1 = lt1;
+      } else {
+        best_arg[0] = d[0];
+        best_arg[1] = d[1];
+        min_loss = dloss;
+        memcpy(beta1, bt2, (size_t)P * sizeof(double));
+        *coef01 = c02;
+        *ic1 = dloss;
+        *loss1 = lt2;
+      }
+      for (i = 1; i < fabs((invphi2 - invphi) * h[0]); i++) {
+        ps_fit(&ps, (int)(c[0] + sgn(h[0]) * i), exp(c[1]));
+        tmp = metric_ic(m, al);
+        if (tmp < min_loss) {
+          best_arg[0] = c[0] + sgn(h[0]) * i;
+          best_arg[1] = c[1];
+          min_loss = tmp;
+          memcpy(beta1, al->beta, (size_t)P * sizeof(double));
+          *coef01 = al->coef0;
+          *loss1 = metric_train_loss(m, al);
+          *ic1 = min_loss;
+        }
+      }
+      break;
+    }
+    if (tt >= 100) break;
+    tt++;
+    if (closs < dloss) {
+      b[0] = d[0];
+      b[1] = d[1];
+      d[0] = c[0];
+      d[1] = c[1];
+      dloss = closs;
+      /* the reference keeps beta_temp2 / coef0_temp2 / train_loss_temp2 of the OLD d here (:762-766) */
+      h[0] = b[0] - a[0];
+      h[1] = b[1] - a[1];
+      c[0] = a[0] + invphi2 * h[0];
+      c[1] = a[1] + invphi2 * h[1];
+      if (h[0] > 0.0001)
+        c[0] = (int)c[0];
+      else if (h[0] < -0.0001)
+        c[0] = ceil(c[0]);
+      else
+        c[0] = round(c[0]);
+      ps_fit(&ps, (int)c[0], exp(c[1]));
+      closs = metric_ic(m, al);
+      c01 = al->coef0;
+      memcpy(bt1, al->beta, (size_t)P * sizeof(double));
+      lt1 = metric_train_loss(m, al);
+    } else {
+      a[0] = c[0];
+      a[1] = c[1];
+      c[0] = d[0];
+      c[1] = d[1];
+      closs = dloss;
+      h[0] = b[0] - a[0];
+      h[1] = b[1] - a[1];
+      d[0] = a[0] + invphi * h[0];
+      d[1] = a[1] + invphi * h[1];
+      if (h[0] > 0.0001)
+        d[0] = ceil(d[0]);
+      else if (h[0] < -0.0001)
+        d[0] = (int)d[0];
+      else
+        d[0] = round(d[0]);
+      ps_fit(&ps, (int)d[0], exp(d[1]));
+      dloss = metric_ic(m, al);
+      c02 = al->coef0;
+      memcpy(bt2, al->beta, (size_t)P * sizeof(double));
+      lt2 = metric_train_loss(m, al);
+    }
+  }
+  free(bt1);
+  free(bt2);
+  free(ps.beta_init);
+}
+
+static int gdc_int(int a, int b) { /* GDC, :937-953 */
+  int Max = a > b ? a : b, Min = (a == Max) ? b : a, z = Min;
+  while (Max % Min != 0) {
+    z = Max % Min;
+    Max = Min;
+    Min = z;
+  }
+  return z;
+}
+
+/* seq_search, :954-1137.  u is modified in place like the reference does. */
+static void seq_search(oalg *al, ometric *m, const double *xtx, double p[2], double u[2], int s_min, int s_max,
+                       double lmin, double lmax, double best_arg[2], double *beta1, double *coef01, double *loss1,
+                       double *ic1, int nlambda) {
+  int P = al->d->p, i = 0, j = 0, cap = (s_max - s_min + 1) * nlambda + 2, k_lambda, mp1 = 0, mp2 = 0, q, minpos;
+  psearch ps;
+  double d_lambda = (lmax - lmin) / (nlambda - 1), coef0_warm;
+  double *b1 = (double *)calloc((size_t)P * cap, sizeof(double)), *b2 = (double *)calloc((size_t)P * cap, sizeof(double));
+  double *c1 = (double *)calloc((size_t)cap, sizeof(double)), *c2 = (double *)calloc((size_t)cap, sizeof(double));
+  double *l1 = (double *)calloc((size_t)cap, sizeof(double)), *l2 = (double *)calloc((size_t)cap, sizeof(double));
+  double *i1 = (double *)calloc((size_t)cap, sizeof(double)), *i2 = (double *)calloc((size_t)cap, sizeof(double));
+  double *beta_warm = (double *)calloc((size_t)P, sizeof(double));
+  ps.a = al;
+  ps.m = m;
+  ps.xtx = xtx;
+  ps.beta_init = (double *)calloc((size_t)P, sizeof(double));
+  ps.coef0_init = 0.0;
+  k_lambda = (int)fabs(round(u[1] / d_lambda));
+  if (fabs(u[0]) != 1 && k_lambda != 1) {
+    if (k_lambda == 0 && u[0] != 0) {
+      u[0] = u[0] / fabs(u[0]);
+    } else if (u[0] == 0 && k_lambda != 0) {
+      u[1] = u[1] / k_lambda;
+    } else if (!(k_lambda == 0 && (int)u[0] == 0)) { /* the reference divides by zero there */
+      int g = gdc_int(k_lambda, abs((int)u[0]));
+      if (g) {
+        u[0] = round(u[0] / g);
+        u[1] = u[1] / g;
+      }
+    }
+  }
+  ps_fit(&ps, (int)(p[0] + i * u[0]), exp(p[1] + i * u[1]));
+  i1[i] = metric_ic(m, al);
+  memcpy(b1, al->beta, (size_t)P * sizeof(double));
+  c1[i] = al->coef0;
+  l1[i] = metric_train_loss(m, al);
+  i2[j] = i1[i];
+  memcpy(b2, b1, (size_t)P * sizeof(double));
+  c2[j] = c1[i];
+  l2[j] = l1[i];
+  i++;
+  j++;
+  memcpy(beta_warm, ps.beta_init, (size_t)P * sizeof(double));
+  coef0_warm = ps.coef0_init;
+  while ((p[0] + i * u[0] <= s_max) && (p[1] + i * u[1] <= lmax + d_lambda * 1e-4) && (p[0] + i * u[0] >= s_min) &&
+         (p[1] + i * u[1] >= lmin - d_lambda * 1e-4) && i < cap) {
+    ps_fit(&ps, (int)(p[0] + i * u[0]), exp(p[1] + i * u[1]));
+    i1[i] = metric_ic(m, al);
+    memcpy(b1 + (size_t)i * P, al->beta, (size_t)P * sizeof(double));
+    c1[i] = al->coef0;
+    l1[i] = metric_train_loss(m, al);
+    i++;
+  }
+  memcpy(ps.beta_init, beta_warm, (size_t)P * sizeof(double));
+  ps.coef0_init = coef0_warm;
+  while ((p[0] - j * u[0] <= s_max) && (p[1] - j * u[1] <= lmax + d_lambda * 1e-4) && (p[0] - j * u[0] >= s_min) &&
+         (p[1] - j * u[1] >= lmin - d_lambda * 1e-4) && j < cap) {
+    ps_fit(&ps, (int)(p[0] - j * u[0]), exp(p[1] - j * u[1]));
+    i2[j] = metric_ic(m, al);
+    memcpy(b2 + (size_t)j * P, al->beta, (size_t)P * sizeof(double));
+    c2[j] = al->coef0;
+    l2[j] = metric_train_loss(m, al);
+    j++;
+  }
+  for (q = 1; q < i; q++)
+    if (i1[q] < i1[mp1]) mp1 = q;
+  for (q = 1; q < j; q++)
+    if (i2[q] < i2[mp2]) mp2 = q;
+  if (i1[mp1] < i2[mp2]) {
+    minpos = mp1;
+    *ic1 = i1[mp1];
+    *loss1 = l1[mp1];
+    memcpy(beta1, b1 + (size_t)mp1 * P, (size_t)P * sizeof(double));
+    *coef01 = c1[mp1];
+  } else {
+    minpos = -mp2;
+    *ic1 = i2[mp2];
+    *loss1 = l2[mp2];
+    memcpy(beta1, b2 + (size_t)mp2 * P, (size_t)P * sizeof(double));
+    *coef01 = c2[mp2];
+  }
+  best_arg[0] = p[0] + minpos * u[0];
+  best_arg[1] = p[1] + minpos * u[1];
+  free(b1); free(b2); free(c1); free(c2); free(l1); free(l2); free(i1); free(i2); free(beta_warm);
+  free(ps.beta_init);
+}
+
+/* pgs_path, :1138-1309 */
+static int pgs_path(oalg *al, ometric *m, const double *xtx, int s_min, int s_max, double lmin, double lmax,
+                    int powell_path, int nlambda, opoint *best, double *lambda_out) {
+  int P = al->d->p, ttt = 0, i, k, mi = 0, rc = 1;
+  double Pp[3][2], U[2][2], ct = 0, lt = 0, it = 0;
+  double *bt = (double *)calloc((size_t)P, sizeof(double));
+  double *ball = (double *)calloc((size_t)P * 100, sizeof(double));
+  double call[100], lall[100], iall[100], lam[100];
+  if (powell_path == 1) nlambda = 100;
+  Pp[0][0] = (double)s_min;
+  Pp[0][1] = lmin;
+  U[1][0] = 1.;
+  U[1][1] = 0.;
+  U[0][0] = 0.;
+  U[0][1] = (lmax - lmin) / (nlambda - 1);
+#define SEARCH(pin, uu, pout)                                                                                  \
+  do {                                                                                                         \
+    if (powell_path == 1)                                                                                      \
+      golden_section_search(al, m, xtx, pin, uu, s_min, s_max, lmin, lmax, pout, bt, &ct, &lt, &it);           \
+    else                                                                                                       \
+      seq_search(al, m, xtx, pin, uu, s_min, s_max, lmin, lmax, pout, bt, &ct, &lt, &it, nlambda);             \
+  } while (0)
+#define RECORD(idx, lamv)                                         \
+  do {                                                            \
+    memcpy(ball + (size_t)(idx)*P, bt, (size_t)P * sizeof(double)); \
+    call[idx] = ct;                                               \
+    lall[idx] = lt;                                               \
+    iall[idx] = it;                                               \
+    lam[idx] = (lamv);                                            \
+  } while (0)
+  SEARCH(Pp[0], U[1], Pp[0]);
+  RECORD(ttt, exp(Pp[0][1]));
+  while (ttt < 11) {
+    ttt++;
+    for (i = 0; i < 2; i++) {
+      SEARCH(Pp[i], U[i], Pp[i + 1]);
+      RECORD(ttt, exp(Pp[i + 1][1]));
+      ttt++;
+    }
+    U[0][0] = U[1][0];
+    U[0][1] = U[1][1];
+    U[1][0] = Pp[2][0] - Pp[0][0];
+    U[1][1] = Pp[2][1] - Pp[0][1];
+    if ((!(fabs(U[1][0]) <= 0.0001 && fabs(U[1][1]) <= 0.0001)) && ttt < 11) {
+      SEARCH(Pp[0], U[1], Pp[0]);
+      RECORD(ttt, exp(Pp[0][1]));
+    } else {
+      /* final fit at P[0]; beta_init / coef0_init are whatever the last search left in the algorithm (:1221-1225) */
+      al->rows = g_full_rows;
+      al->n_rows = al->d->n;
+      al->T0 = (int)Pp[0][0];
+      al->lambda = exp(Pp[0][1]);
+      al->xtx = xtx;
+      alg_fit(al);
+      memcpy(ball + (size_t)ttt * P, al->beta, (size_t)P * sizeof(double));
+      call[ttt] = al->coef0;
+      lall[ttt] = metric_train_loss(m, al);
+      iall[ttt] = metric_ic(m, al);
+      lam[ttt] = exp(Pp[0][1]);
+      ttt++;
+      for (k = 0; k < ttt; k++) denorm(al->d, ball + (size_t)k * P, &call[k]);
+      for (k = 1; k < ttt; k++)
+        if (iall[k] < iall[mi]) mi = k;
+      if (iall[mi] == iall[ttt - 1]) mi = ttt - 1;
+      memcpy(best->beta, ball + (size_t)mi * P, (size_t)P * sizeof(double));
+      best->coef0 = call[mi];
+      best->loss = lall[mi];
+      best->ic = iall[mi];
+      *lambda_out = lam[mi];
+      rc = 0;
+      break;
+    }
+  }
+#undef SEARCH
+#undef RECORD
+  free(bt);
+  free(ball);
+  return rc; /* 1: "powell end wrong" (:1298-1308) */
+}
+
 /* ------------------------------------------------------------------ driver */
 
 /* bessCpp, src/bess.cpp:37-214 (no screening) */
@@ -931,6 +1318,21 @@ int bess_oracle_run(const double *x, int n, int p, const double *y, const double
                     int sequence_len, const double *lambda_seq, int lambda_len, int s_min, int s_max,
                     const int *always_select, int always_len, double *beta_out, double *coef0_out,
                     double *train_loss_out, double *ic_out) {
+  return bess_oracle_run2(x, n, p, y, weight, data_type, is_normal, algorithm_type, model_type, max_iter, path_type,
+                          is_warm_start, ic_type, is_cv, K, cv_fold_id, sequence, sequence_len, lambda_seq,
+                          lambda_len, s_min, s_max, 0.0, 0.0, 100, 1, always_select, always_len, beta_out, coef0_out,
+                          train_loss_out, ic_out, NULL);
+}
+
+/* As bess_oracle_run plus the Powell-path arguments of bessCpp (src/bess.cpp:174-180): path_type 3 runs
+ * pgs_path with log_lambda = log(max(lambda, 1e-5)). */
+int bess_oracle_run2(const double *x, int n, int p, const double *y, const double *weight, int data_type,
+                     int is_normal, int algorithm_type, int model_type, int max_iter, int path_type,
+                     int is_warm_start, int ic_type, int is_cv, int K, const int *cv_fold_id, const int *sequence,
+                     int sequence_len, const double *lambda_seq, int lambda_len, int s_min, int s_max,
+                     double lambda_min, double lambda_max, int nlambda, int powell_path, const int *always_select,
+                     int always_len, double *beta_out, double *coef0_out, double *train_loss_out, double *ic_out,
+                     double *lambda_out) {
   odata d;
   oalg a;
   ometric m;
@@ -946,6 +1348,7 @@ int bess_oracle_run(const double *x, int n, int p, const double *y, const double
   } else if (s_min < 0 || s_max > p || s_min > s_max) {
     return 3;
   }
+  if (path_type == 3 && (s_min < 1 || nlambda < 2)) return 3;
   t_meta.n = t_a.n = t_beta.n = t_coef0.n = t_loss.n = t_ic.n = 0;
 
   d.n = n;
@@ -1021,10 +1424,17 @@ int bess_oracle_run(const double *x, int n, int p, const double *y, const double
   }
 
   best.beta = (double *)calloc((size_t)p, sizeof(double));
-  if (path_type == 1)
+  best.coef0 = best.loss = best.ic = 0.0;
+  if (path_type == 1) {
     seq_path(&a, &m, xtx, sequence, sequence_len, lambda_seq, lambda_len, &best);
-  else
+  } else if (path_type == 3) {
+    double lam = 0.0;
+    double lo = log(lambda_min > 1e-5 ? lambda_min : 1e-5), hi = log(lambda_max > 1e-5 ? lambda_max : 1e-5);
+    pgs_path(&a, &m, xtx, s_min, s_max, lo, hi, powell_path, nlambda, &best, &lam);
+    if (lambda_out) *lambda_out = lam;
+  } else {
     gs_path(&a, &m, xtx, s_min, s_max, &best);
+  }
 
   memcpy(beta_out, best.beta, (size_t)p * sizeof(double));
   *coef0_out = best.coef0;

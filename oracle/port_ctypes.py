@@ -15,6 +15,7 @@ PORT_LIB = os.path.join(_HERE, "libbess_oracle.so")
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)
 _i = ctypes.c_int
+_d = ctypes.c_double
 
 _lib = None
 
@@ -33,6 +34,10 @@ def lib():
         _lib.bess_oracle_run.argtypes = (
             [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _I, _i]
             + [_D, _D, _D, _D])
+        _lib.bess_oracle_run2.restype = _i
+        _lib.bess_oracle_run2.argtypes = (
+            [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _d, _d, _i, _i,
+             _I, _i] + [_D, _D, _D, _D, _D])
         _lib.bess_oracle_trace_size.restype = _i
         _lib.bess_oracle_trace_size.argtypes = [_i]
         _lib.bess_oracle_trace_copy_int.restype = None
@@ -85,7 +90,8 @@ def parse_trace(size_fn, copy_int, copy_double):
 
 def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, model_type=1, max_iter=20, path_type=1,
           is_warm_start=True, ic_type=4, is_cv=False, K=5, cv_fold_id=None, sequence=(1,), lambda_seq=(0.0,),
-          s_min=1, s_max=1, g_index=None, always_select=()):
+          s_min=1, s_max=1, g_index=None, always_select=(), lambda_min=0.0, lambda_max=0.0, nlambda=100,
+          powell_path=1):
     """Same signature and return value as oracle.ref_ctypes.trace."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     n, p = x.shape
@@ -105,16 +111,18 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
     loss = np.zeros(1)
     ic = np.zeros(1)
     L = lib()
-    rc = L.bess_oracle_run(_dp(x), n, p, _dp(y), _dp(weight), data_type, int(is_normal), algorithm_type, model_type,
-                           max_iter, path_type, int(is_warm_start), ic_type, int(is_cv), K, fold_ptr, _ip(sequence),
-                           sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max, _ip(always_select),
-                           always_select.size, _dp(beta), _dp(coef0), _dp(loss), _dp(ic))
+    lam_out = np.zeros(1)
+    rc = L.bess_oracle_run2(_dp(x), n, p, _dp(y), _dp(weight), data_type, int(is_normal), algorithm_type, model_type,
+                            max_iter, path_type, int(is_warm_start), ic_type, int(is_cv), K, fold_ptr, _ip(sequence),
+                            sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max, lambda_min, lambda_max,
+                            nlambda, powell_path, _ip(always_select), always_select.size, _dp(beta), _dp(coef0),
+                            _dp(loss), _dp(ic), _dp(lam_out))
     if rc != 0:
         raise ValueError("bess_oracle_run rejected its arguments (code %d)" % rc)
     fits, loss_calls, ic_calls = parse_trace(L.bess_oracle_trace_size, L.bess_oracle_trace_copy_int,
                                              L.bess_oracle_trace_copy_double)
     return {"beta": beta, "coef0": float(coef0[0]), "train_loss": float(loss[0]), "ic": float(ic[0]),
-            "fits": fits, "loss_calls": loss_calls, "ic_calls": ic_calls}
+            "lambda": float(lam_out[0]), "fits": fits, "loss_calls": loss_calls, "ic_calls": ic_calls}
 
 
 def max_k(score, k):

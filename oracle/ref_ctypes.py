@@ -40,6 +40,10 @@ def lib():
             [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _I, _i, _I, _i]
             + [_D, _D, _D, _D]
         )
+        _lib.bess_ref_trace2.restype = _i
+        _lib.bess_ref_trace2.argtypes = (
+            [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _d, _d, _i, _i,
+             _I, _i, _I, _i] + [_D, _D, _D, _D, _D])
         _lib.bess_ref_trace_size.restype = _i
         _lib.bess_ref_trace_size.argtypes = [_i]
         _lib.bess_ref_trace_copy_int.restype = None
@@ -87,8 +91,9 @@ def pywrap_bess(x, y, data_type, weight, is_normal, algorithm_type, model_type, 
 
 def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, model_type=1, max_iter=20, path_type=1,
           is_warm_start=True, ic_type=4, is_cv=False, K=5, cv_fold_id=None, sequence=(1,), lambda_seq=(0.0,),
-          s_min=1, s_max=1, g_index=None, always_select=()):
-    """Run one reference path through the tracing harness.
+          s_min=1, s_max=1, g_index=None, always_select=(), lambda_min=0.0, lambda_max=0.0, nlambda=100,
+          powell_path=1):
+    """Run one reference path through the tracing harness (path_type 3 = Powell path pgs_path).
 
     Returns a dict: best model (beta, coef0, train_loss, ic) plus the trace
       fits: list of dicts {T0, train_n, iters: [A arrays], betas: [beta_A arrays], coef0s: [...]}
@@ -111,10 +116,12 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
     loss = np.zeros(1)
     ic = np.zeros(1)
     L = lib()
-    rc = L.bess_ref_trace(_dp(x), n, p, _dp(y), _dp(weight), data_type, int(is_normal), algorithm_type, model_type,
-                          max_iter, path_type, int(is_warm_start), ic_type, int(is_cv), K, fold_ptr, _ip(sequence),
-                          sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max, _ip(g_index), g_index.size,
-                          _ip(always_select), always_select.size, _dp(beta), _dp(coef0), _dp(loss), _dp(ic))
+    lam_out = np.zeros(1)
+    rc = L.bess_ref_trace2(_dp(x), n, p, _dp(y), _dp(weight), data_type, int(is_normal), algorithm_type, model_type,
+                           max_iter, path_type, int(is_warm_start), ic_type, int(is_cv), K, fold_ptr, _ip(sequence),
+                           sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max, lambda_min, lambda_max,
+                           nlambda, powell_path, _ip(g_index), g_index.size, _ip(always_select), always_select.size,
+                           _dp(beta), _dp(coef0), _dp(loss), _dp(ic), _dp(lam_out))
     if rc != 0:
         raise RuntimeError("bess_ref_trace failed")
 
@@ -142,4 +149,4 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
         fits[-1]["betas"].append(beta_flat[off:nxt].copy())
         fits[-1]["coef0s"].append(float(coef0_calls[c]))
     return {"beta": beta, "coef0": float(coef0[0]), "train_loss": float(loss[0]), "ic": float(ic[0]),
-            "fits": fits, "loss_calls": getd(4), "ic_calls": getd(5)}
+            "lambda": float(lam_out[0]), "fits": fits, "loss_calls": getd(4), "ic_calls": getd(5)}

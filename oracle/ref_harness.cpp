@@ -124,12 +124,35 @@ void bess_ref_pywrap(double *x, int x_row, int x_col, double *y, int y_len, int 
 // Run one reference path with tracing.  x is row-major n x p (as pywrap_bess takes it).
 // cv_fold_id: NULL -> the reference's own (random) folds; else fold index in [0,K) per row.
 // Returns 0 on success.  Best-model outputs are what the reference's path function returns.
+int bess_ref_trace2(const double *x, int n, int p, const double *y, const double *weight, int data_type,
+                    int is_normal, int algorithm_type, int model_type, int max_iter, int path_type, int is_warm_start,
+                    int ic_type, int is_cv, int K, const int *cv_fold_id, const int *sequence, int sequence_len,
+                    const double *lambda_seq, int lambda_len, int s_min, int s_max, double lambda_min,
+                    double lambda_max, int nlambda, int powell_path, const int *g_index, int g_len,
+                    const int *always_select, int always_len, double *beta_out, double *coef0_out,
+                    double *train_loss_out, double *ic_out, double *lambda_out);
+
 int bess_ref_trace(const double *x, int n, int p, const double *y, const double *weight, int data_type, int is_normal,
                    int algorithm_type, int model_type, int max_iter, int path_type, int is_warm_start, int ic_type,
                    int is_cv, int K, const int *cv_fold_id, const int *sequence, int sequence_len,
                    const double *lambda_seq, int lambda_len, int s_min, int s_max, const int *g_index, int g_len,
                    const int *always_select, int always_len, double *beta_out, double *coef0_out,
                    double *train_loss_out, double *ic_out) {
+  return bess_ref_trace2(x, n, p, y, weight, data_type, is_normal, algorithm_type, model_type, max_iter, path_type,
+                         is_warm_start, ic_type, is_cv, K, cv_fold_id, sequence, sequence_len, lambda_seq, lambda_len,
+                         s_min, s_max, 0.0, 0.0, 100, 1, g_index, g_len, always_select, always_len, beta_out,
+                         coef0_out, train_loss_out, ic_out, nullptr);
+}
+
+// path_type 3: the reference's Powell path pgs_path (src/path.cpp:1138-1309), called exactly as bessCpp does
+// (src/bess.cpp:174-180: log(max(lambda, 1e-5))).
+int bess_ref_trace2(const double *x, int n, int p, const double *y, const double *weight, int data_type,
+                    int is_normal, int algorithm_type, int model_type, int max_iter, int path_type, int is_warm_start,
+                    int ic_type, int is_cv, int K, const int *cv_fold_id, const int *sequence, int sequence_len,
+                    const double *lambda_seq, int lambda_len, int s_min, int s_max, double lambda_min,
+                    double lambda_max, int nlambda, int powell_path, const int *g_index, int g_len,
+                    const int *always_select, int always_len, double *beta_out, double *coef0_out,
+                    double *train_loss_out, double *ic_out, double *lambda_out) {
   g_trace.clear();
   Eigen::MatrixXd X(n, p);
   for (int i = 0; i < n; i++)
@@ -194,10 +217,20 @@ int bess_ref_trace(const double *x, int n, int p, const double *y, const double 
   }
 
   List result;
-  if (path_type == 1)
+  if (path_type == 1) {
     result = sequential_path(data, algorithm, metric, SEQ, LAM);
-  else
+  } else if (path_type == 3) {
+    double log_lambda_min = log(max(lambda_min, 1e-5));
+    double log_lambda_max = log(max(lambda_max, 1e-5));
+    result = pgs_path(data, algorithm, metric, s_min, s_max, log_lambda_min, log_lambda_max, powell_path, nlambda);
+    if (lambda_out) {
+      double lam = 0.0;
+      result.get_value_by_name("lambda", lam);
+      *lambda_out = lam;
+    }
+  } else {
     result = gs_path(data, algorithm, metric, s_min, s_max, 0, 0.);
+  }
 
   Eigen::VectorXd beta;
   double coef0, train_loss, ic;

@@ -63,6 +63,18 @@ def all_cases():
     c["lm_weight"] = (X, y, dict(ic_type=3, sequence=np.arange(1, 16), weight=w))
     c["lm_nonorm"] = (X, y, dict(ic_type=3, sequence=np.arange(1, 16), is_normal=False))
     c["lm_always"] = (X, y, dict(ic_type=3, sequence=np.arange(3, 16), always_select=[5, 7]))
+    # Powell path of the L0L2 / bsrr types (pgs_path, src/path.cpp:1138-1309)
+    Xs, ys, _, _ = S.make_lm(400, 60, 6)
+    PW = dict(algorithm_type=5, path_type=3, s_min=1)
+    c["lm_powell_gs"] = (Xs, ys, dict(PW, ic_type=3, s_max=12, lambda_min=0.001, lambda_max=10.0, nlambda=10,
+                                      powell_path=1))
+    c["lm_powell_seq"] = (Xs, ys, dict(PW, ic_type=4, s_max=20, lambda_min=0.01, lambda_max=100.0, nlambda=20,
+                                       powell_path=2))
+    c["lm_powell_cv"] = (Xs, ys, dict(PW, is_cv=True, K=4, cv_fold_id=S.make_cv_folds(400, 4), s_max=10,
+                                      lambda_min=0.01, lambda_max=10.0, nlambda=10, powell_path=1))
+    Xq, yq, _, _ = S.make_logistic(500, 50, 5)
+    c["logit_powell_seq"] = (Xq, yq, dict(PW, data_type=2, model_type=2, ic_type=3, s_max=10, lambda_min=0.01,
+                                          lambda_max=5.0, nlambda=8, powell_path=2))
     X, y, _, _ = S.make_logistic(1000, 200, 8)
     L = dict(data_type=2, model_type=2)
     c["logit_seq"] = (X, y, dict(L, ic_type=3, sequence=np.arange(1, 21)))
@@ -99,4 +111,5 @@ def load_golden(name):
         fits.append(fit)
     sc = z[name + "/scalars"]
     return {"beta": z[name + "/beta"], "coef0": float(sc[0]), "train_loss": float(sc[1]), "ic": float(sc[2]),
+            "lambda": float(sc[3]) if len(sc) > 3 else 0.0,
             "fits": fits, "loss_calls": z[name + "/loss_calls"], "ic_calls": z[name + "/ic_calls"]}

@@ -26,7 +26,7 @@ from oracle import ref_ctypes as R  # noqa: E402
 def flatten(prefix, t, out):
     fits = t["fits"]
     out[prefix + "/beta"] = t["beta"]
-    out[prefix + "/scalars"] = np.array([t["coef0"], t["train_loss"], t["ic"]])
+    out[prefix + "/scalars"] = np.array([t["coef0"], t["train_loss"], t["ic"], t.get("lambda", 0.0)])
     out[prefix + "/loss_calls"] = t["loss_calls"]
     out[prefix + "/ic_calls"] = t["ic_calls"]
     out[prefix + "/fit_T0"] = np.array([f["T0"] for f in fits], dtype=np.int32)

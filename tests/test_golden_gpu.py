@@ -29,6 +29,20 @@ def test_gpu_matches_reference_golden(gpu, name):
     np.testing.assert_allclose(got["beta"][sup], want["beta"][sup], rtol=1e-6)
     np.testing.assert_allclose([got["coef0"], got["train_loss"], got["ic"]],
                                [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-7, atol=1e-9)
+    if kw.get("path_type") == 3:
+        assert abs(got["lambda"] - want["lambda"]) <= 1e-12 * want["lambda"]
+
+
+def test_pywrap_routes_l0l2_search_to_the_powell_path(gpu):
+    """bessCpp sends path_type 2 with algorithm_type 5 to pgs_path (src/bess.cpp:174-180)."""
+    X, y, kw = CASES["lm_powell_gs"]
+    want = cases.load_golden("lm_powell_gs")
+    n, p = X.shape
+    r = gpu.pywrap_bess(X, y, 1, np.ones(n), True, 5, 1, 20, 0, 2, True, kw["ic_type"], False, 5, np.arange(p),
+                        np.ones(n), [1], [0.0], kw["s_min"], kw["s_max"], 0, 1e-4, kw["lambda_min"], kw["lambda_max"],
+                        kw["nlambda"], False, 1, kw["powell_path"], [], 0.0, p)
+    np.testing.assert_allclose(r[0], want["beta"], rtol=1e-6, atol=1e-12)
+    assert abs(r[3][0] - want["ic"]) < 1e-7 * abs(want["ic"])
 
 
 def _pywrap_args(X, y, data_type=1, model_type=1, sequence=(3,), ic_type=3, path_type=1, s_min=0, s_max=0):

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 def run_gpu(capi, X, y, kw):
     s = capi.Session(X, y, weight=kw.get("weight"), data_type=kw.get("data_type", 1),
                      is_normal=kw.get("is_normal", True), model_type=kw.get("model_type", 1),
+                     algorithm_type=kw.get("algorithm_type", 1),
                      max_iter=kw.get("max_iter", 20), is_warm_start=kw.get("is_warm_start", True),
                      always_select=kw.get("always_select", ()))
     s.trace_enable(True)
@@ -21,6 +22,9 @@ def run_gpu(capi, X, y, kw):
     if kw.get("path_type", 1) == 1:
         out = s.sequential_path(kw["sequence"], kw.get("lambda_seq", (0.0,)), kw.get("ic_type", 4),
                                 kw.get("is_cv", False))
+    elif kw["path_type"] == 3:
+        out = s.pgs_path(kw["s_min"], kw["s_max"], kw["lambda_min"], kw["lambda_max"], kw.get("nlambda", 100),
+                         kw.get("powell_path", 1), kw.get("ic_type", 4), kw.get("is_cv", False))
     else:
         out = s.gs_path(kw["s_min"], kw["s_max"], kw.get("ic_type", 4), kw.get("is_cv", False))
     s.close()
