@@ -1,0 +1,69 @@
+"""BASELINE configs[1] at FULL size (n=50000, p=10000) on the GPU.
+
+1. Size-independent properties of the path (no oracle needed): run-to-run bitwise determinism, every fit stopped
+   because its active set repeated (nearly always a fixed point of the PDAS map), the training loss
+   decreases along the nested part of the path, the IC matches its formula, the true support is recovered at
+   k = k_true, and the golden-section path selects the same model as the exhaustive sequential path.
+2. If tests/golden/fullsize_lm.npz is present (generated in the build container from the COMPILED REFERENCE by
+   tests/golden/make_fullsize_ref.py -- about two CPU-hours), the active set of every PDAS iteration of all 200
+   candidates, the coefficients, losses and ICs are compared with it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bess_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fullsize_lm.npz")
+
+
+@pytest.fixture(scope="module")
+def full(gpu):
+    X, y, support, beta = synth.make_lm()
+    s = gpu.Session(X, y)
+    s.trace_enable(True)
+    out = s.sequential_path(np.arange(1, 201), ic_type=3)
+    yield gpu, s, out, support, (X, y)
+    s.close()
+
+
+def test_properties_at_full_size(full):
+    gpu, s, out, support, _ = full
+    n, p = 50000, 10000
+    again = s.sequential_path(np.arange(1, 201), ic_type=3)
+    assert np.array_equal(out["cand_support"], again["cand_support"])
+    assert np.array_equal(out["cand_beta"], again["cand_beta"]) and np.array_equal(out["cand_ic"], again["cand_ic"])
+    fits = out["trace"]["fits"]
+    assert len(fits) == 200
+    for f in fits:  # Algorithm::fit stopped because the last active set had been seen before in this fit
+        assert 2 <= len(f["iters"]) <= 20
+        assert any(np.array_equal(f["iters"][-1], prev) for prev in f["iters"][:-1])
+    assert sum(np.array_equal(f["iters"][-1], f["iters"][-2]) for f in fits) >= 150  # mostly a fixed point; the rest are 2-cycles
+    loss = out["cand_train_loss"]
+    assert np.all(np.diff(loss[:100]) < 0)  # every true variable lowers the loss
+    c = np.log(p) * np.log(np.log(n))
+    np.testing.assert_allclose(out["cand_ic"], n * np.log(loss) + c * np.arange(1, 201), rtol=1e-12)
+    assert np.array_equal(np.sort(out["cand_support"][99][:100]), support)  # k = k_true recovers the truth
+    assert out["best_T0"] == 100
+    gs = s.gs_path(1, 200, ic_type=3)
+    assert gs["best_T0"] == 100 and np.array_equal(np.nonzero(gs["beta"])[0], support)
+    np.testing.assert_allclose(gs["beta"][support], out["beta"][support], rtol=1e-9)
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="full-size golden vectors of the compiled reference not generated")
+def test_matches_compiled_reference_at_full_size(full):
+    _, _, out, _, _ = full
+    g = np.load(GOLD)
+    kmax = int(g["kmax"])
+    fits = out["trace"]["fits"][:kmax]
+    assert list(g["fit_iters"]) == [len(f["iters"]) for f in fits]
+    got_A = np.concatenate([a for f in fits for a in f["iters"]])
+    assert np.array_equal(got_A, g["A_flat"])  # bit-exact supports, every iteration of every candidate
+    got_b = np.concatenate([b for f in fits for b in f["betas"]])
+    np.testing.assert_allclose(got_b, g["beta_flat"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(out["trace"]["ic_calls"][:kmax], g["ic_calls"], rtol=1e-9)
+    np.testing.assert_allclose(out["trace"]["loss_calls"][:kmax], g["loss_calls"], rtol=1e-9)
+    assert np.array_equal(np.nonzero(out["beta"])[0], g["best_beta_idx"])
+    np.testing.assert_allclose(out["beta"][g["best_beta_idx"]], g["best_beta_val"], rtol=1e-6)
