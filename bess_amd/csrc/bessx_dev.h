@@ -61,6 +61,9 @@ hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, in
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
                        hipStream_t st);
+hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
+                           const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
+                           const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);
 hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
                             hipStream_t st);

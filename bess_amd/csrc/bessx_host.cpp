@@ -64,7 +64,8 @@ struct Trace {
   }
 };
 
-static constexpr int T0_CAP = 254;  // m + 1 <= 256 in k_chol, with room for an intercept
+static constexpr int T0_FAST = 254;  // fast path: m + 1 <= 256 lives in the registers of k_chol (with an intercept)
+static constexpr int T0_CAP = 2046;  // blocked global-memory Cholesky beyond that: m + 2 <= 2048
 
 }  // namespace bessx
 
@@ -107,7 +108,13 @@ struct bessx_session {
   double *tmpv = nullptr;
   int *A_new = nullptr, *cand = nullptr, *hist = nullptr, *gcols = nullptr, *info = nullptr;
   double *hist_beta = nullptr, *hist_coef0 = nullptr;
-  int hist_stride = T0_CAP + 2;
+  int cap = 0;          // largest sparsity level this session accepts: min(p, T0_CAP)
+  int capA = 0;         // array length for T0-sized buffers: cap + 2 rounded up to a tile multiple
+  int hist_stride = 0;
+  double *rdiag = nullptr, *zbig = nullptr;  // work space of the blocked Cholesky
+  std::vector<std::pair<int, GramTask *>> big_tasks;  // task lists for mt > 16, built on demand
+  std::vector<int> big_task_cnt;
+  size_t cox_M_cols = 0;
   GramTask *gtasks = nullptr;
   std::vector<int> gtask_off, gtask_cnt;  // per mt
   std::vector<int> gtask_inc_off, gtask_inc_cnt;  // per mt: tasks of the extra tile row (incremental LM Gram)
@@ -206,6 +213,9 @@ static void session_free(bessx_session *s) {
   F(s->hist_beta);
   F(s->hist_coef0);
   F(s->gtasks);
+  for (auto &bt : s->big_tasks) F(bt.second);
+  F(s->rdiag);
+  F(s->zbig);
   for (auto &c : s->gcache) {
     F(c.g0);
     F(c.g1);
@@ -282,10 +292,37 @@ static void build_gram_tasks(int mt, std::vector<GramTask> &out) {
   }
 }
 
-static void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab) {
+// task list of the whole lower triangle for any tile count (lists for mt <= 16 are prebuilt)
+static int gram_tasks_for(bessx_session *s, int mt, const GramTask **tasks, int *ntask) {
+  if (mt <= 16) {
+    *tasks = s->gtasks + s->gtask_off[mt];
+    *ntask = s->gtask_cnt[mt];
+    return 0;
+  }
+  for (size_t i = 0; i < s->big_tasks.size(); i++)
+    if (s->big_tasks[i].first == mt) {
+      *tasks = s->big_tasks[i].second;
+      *ntask = s->big_task_cnt[i];
+      return 0;
+    }
+  std::vector<GramTask> t;
+  build_gram_tasks(mt, t);
+  GramTask *d = nullptr;
+  HIPX(dmalloc(&d, t.size()));
+  HIPX(hipMemcpy(d, t.data(), t.size() * sizeof(GramTask), hipMemcpyHostToDevice));
+  s->big_tasks.push_back({mt, d});
+  s->big_task_cnt.push_back((int)t.size());
+  *tasks = d;
+  *ntask = (int)t.size();
+  return 0;
+}
+
+static void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab, int ntiles = 0) {
   long target = 4096;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2 waves x 2
   long ns = std::max<long>(1, target / std::max(ntask, 1));
   ns = std::min<long>(ns, std::max<long>(1, s->ld / 64));
+  if (ntiles > 0 && s->gpart_elems > 0)  // the slab partials must fit the workspace
+    ns = std::max<long>(1, std::min<long>(ns, (long)(s->gpart_elems / ((size_t)ntiles * 256))));
   long rps = (s->ld + ns - 1) / ns;
   rps = (rps + 15) / 16 * 16;
   ns = (s->ld + rps - 1) / rps;
@@ -343,9 +380,11 @@ static int prepare_rowset(bessx_session *s, int rs) {
 static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
                            std::vector<std::pair<size_t, bool>> &k1_pairs) {
   const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
-  const int ntask = s->gtask_cnt[mt], ntiles = mt * (mt + 1) / 2;
-  int rps, nslab;
-  gram_geometry(s, ntask, &rps, &nslab);
+  const int ntiles = mt * (mt + 1) / 2;
+  const GramTask *tasks_full = nullptr;
+  int ntask = 0, rps, nslab;
+  if (int rc = gram_tasks_for(s, mt, &tasks_full, &ntask)) return rc;
+  gram_geometry(s, ntask, &rps, &nslab, ntiles);
   if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
   hipError_t e = hipSuccess;
   if (!skip_k1) {
@@ -366,18 +405,25 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
                      lambda, 0, s->always, s->bd, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
-  if (e == hipSuccess) {
+  if (e == hipSuccess && mt > 16) {
+    // beyond the register-resident solver: whole Gram every time, blocked Cholesky in global memory
+    e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, tasks_full, ntask, nslab, s->gpart, ntiles, s->Gt,
+                    s->ctrl, slot, 0, s->st, 0);
+    if (e == hipSuccess)
+      e = launch_chol_big(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->rdiag, s->zbig,
+                          s->ctrl, slot, 0, s->st);
+  } else if (e == hipSuccess) {
     int rps_i, nslab_i;
     const int ntask_i = s->gtask_inc_cnt[mt];
     gram_geometry(s, ntask_i * 3, &rps_i, &nslab_i);  // a third of the usual wave count: the extra row is cheap
     bessx_session::GramCache &gc = s->gcache[rs];
     e = launch_gram_lm_cached(s->X, s->aux, s->ld, s->gcols, s->mask[rs], s->A_new, T0, mt,
-                              s->gtasks + s->gtask_off[mt], ntask, rps, nslab, s->gtasks + s->gtask_inc_off[mt],
+                              tasks_full, ntask, rps, nslab, s->gtasks + s->gtask_inc_off[mt],
                               ntask_i, rps_i, nslab_i, s->gpart, s->Gt, s->Rt, s->gsrc, gc.g0, gc.g1, gc.A, gc.meta,
                               s->ctrl, slot, s->st);
+    if (e == hipSuccess)
+      e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
   }
-  if (e == hipSuccess)
-    e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
   if (e == hipSuccess)
     e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
                       s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
@@ -398,9 +444,10 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
 static int glm_geometry(bessx_session *s, int T0, int *mt, int *mp, int *ntask, int *ntiles, int *rps, int *nslab) {
   *mt = (T0 + 2 + 15) / 16;  // intercept + T0 columns + the working response
   *mp = *mt * 16;
-  *ntask = s->gtask_cnt[*mt];
+  const GramTask *tk = nullptr;
+  if (int rc = gram_tasks_for(s, *mt, &tk, ntask)) return rc;
   *ntiles = *mt * (*mt + 1) / 2;
-  gram_geometry(s, *ntask, rps, nslab);
+  gram_geometry(s, *ntask, rps, nslab, *ntiles);
   if ((size_t)*nslab * *ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
   return 0;
 }
@@ -444,12 +491,17 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
                                       s->bcur, s->Wv, z, s->llpart, s->st);
   if (e == hipSuccess)
     e = launch_glm_irls_check(s->ctrl, slot, t, fam, s->llpart, s->n_sse_blk, T0 + 1, s->bcur, s->bprev, s->st);
+  const GramTask *tk = nullptr;
+  int ntk = 0;
+  if (int rc = gram_tasks_for(s, mt, &tk, &ntk)) return rc;
   if (e == hipSuccess)
-    e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->Wv, rps, s->gtasks + s->gtask_off[mt], ntask, nslab, s->gpart,
-                    ntiles, s->Gt, s->ctrl, slot, 1, s->st);
+    e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->Wv, rps, tk, ntask, nslab, s->gpart, ntiles, s->Gt, s->ctrl,
+                    slot, 1, s->st);
   if (e == hipSuccess)
-    e = launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot, 1,
-                    s->st);
+    e = mt <= 16 ? launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl,
+                               slot, 1, s->st)
+                 : launch_chol_big(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info,
+                                   s->rdiag, s->zbig, s->ctrl, slot, 1, s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_irls_step: ") + hipGetErrorString(e));
   return 0;
 }
@@ -498,7 +550,7 @@ static int enqueue_cox_newton(bessx_session *s, int slot, int t, int T0, double 
   const int mt = (T0 + 1 + 15) / 16;
   const int ntask = s->gtask_cnt[mt], ntiles = mt * (mt + 1) / 2;
   int rps, nslab;
-  gram_geometry(s, ntask, &rps, &nslab);
+  gram_geometry(s, ntask, &rps, &nslab, ntiles);
   if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
   hipError_t e = launch_cox_newton_step(s->X, s->aux, s->ld, s->n, s->mask[rs], s->ctrl, slot, t, s->A_new, T0, lambda,
                                         s->gcols, s->idcols, mt, s->gtasks + s->gtask_off[mt], ntask, rps, nslab,
@@ -527,15 +579,17 @@ static int read_results(bessx_session *s) {
 static int algorithm_fit(bessx_session *s) {
   const int T0 = s->sparsity_level, rs = s->cur_rows;
   const double lambda = s->lambda_level;
-  if (T0 < 1 || T0 > std::min(s->p, T0_CAP))
+  if (T0 < 1 || T0 > s->cap)
     return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, min(p, " +
                                    std::to_string(T0_CAP) + ")]");
+  if (s->model_type == 4 && T0 > T0_FAST)
+    return fail(BESSX_ERR_UNSUPPORTED, "Cox: sparsity levels above " + std::to_string(T0_FAST) + " are not built yet");
   if (!topk_supported(s->p, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: p too large for this sparsity level");
   const bool glm = s->model_type != 1;  // sub-model fit is an iteration chain (IRLS or Newton)
   const bool cox = s->model_type == 4;
   // warm start: this->beta = beta_init; this->coef0 = coef0_init (src/Algorithm.h:147-148)
   const int k_init = (int)s->beta_init.idx.size();
-  if (k_init > T0_CAP) return fail(BESSX_ERR_ARG, "initial support too large");
+  if (k_init > s->cap) return fail(BESSX_ERR_ARG, "initial support too large");
   // Reuse across fits: when this fit starts from exactly the coefficients the last fit on this row set
   // ended with, and that fit ended on a repeated active set, the residual and the score-pass sums in
   // memory are the ones get_A would recompute (src/Algorithm.h:1109 depends only on beta, coef0 and the rows).
@@ -551,7 +605,7 @@ static int algorithm_fit(bessx_session *s) {
     e = launch_fit_continue(s->ctrl, T0, s->hist, s->st);
   } else {
     int *st_idx = reinterpret_cast<int *>(s->stage_h);
-    double *st_val = reinterpret_cast<double *>(s->stage_h + 4096);
+    double *st_val = reinterpret_cast<double *>(s->stage_h + (size_t)s->capA * sizeof(int));
     for (int i = 0; i < k_init; i++) {
       st_idx[i] = s->beta_init.idx[i];
       st_val[i] = s->beta_init.val[i];
@@ -1386,19 +1440,27 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->part2, (size_t)s->nrb * p));
   HIPT(dmalloc(&s->bd, (size_t)p));
   HIPT(dmalloc(&s->beta_dense, (size_t)p));
-  HIPT(dmalloc(&s->sol, 256));
-  HIPT(dmalloc(&s->A_new, 256));
+  s->cap = std::min(p, T0_CAP);
+  s->capA = (s->cap + 2 + 15) / 16 * 16;
+  s->capA = std::max(s->capA, 256);
+  s->hist_stride = s->capA;
+  const int capA = s->capA, mt_max = capA / 16;
+  HIPT(dmalloc(&s->sol, (size_t)capA));
+  HIPT(dmalloc(&s->A_new, (size_t)capA));
+  HIPT(dmalloc(&s->rdiag, (size_t)capA));
+  HIPT(dmalloc(&s->zbig, (size_t)capA));
   HIPT(dmalloc(&s->cand, 32768));
   HIPT(dmalloc(&s->hist, (size_t)(s->max_iter + 2) * s->hist_stride));
   HIPT(dmalloc(&s->hist_beta, (size_t)(s->max_iter + 2) * s->hist_stride));
   HIPT(dmalloc(&s->hist_coef0, (size_t)(s->max_iter + 2)));
-  HIPT(dmalloc(&s->gcols, 256 + 16));
+  HIPT(dmalloc(&s->gcols, (size_t)capA + 16));
   HIPT(dmalloc(&s->Rt, (size_t)16 * 256));
   HIPT(dmalloc(&s->gsrc, 256));
-  HIPT(dmalloc(&s->init_idx_d, 256));
-  HIPT(dmalloc(&s->init_val_d, 256));
-  HIPT(dmalloc(&s->Gt, (size_t)136 * 256));
-  s->gpart_elems = (size_t)6 << 20;  // 48 MB of fp64 partial tiles
+  HIPT(dmalloc(&s->init_idx_d, (size_t)capA));
+  HIPT(dmalloc(&s->init_val_d, (size_t)capA));
+  HIPT(dmalloc(&s->Gt, (size_t)mt_max * (mt_max + 1) / 2 * 256));
+  // fp64 partial tiles of the row slabs: 48 MB, or at least 8 slabs of the largest Gram this session can form
+  s->gpart_elems = std::max<size_t>((size_t)6 << 20, (size_t)8 * mt_max * (mt_max + 1) / 2 * 256);
   HIPT(dmalloc(&s->gpart, s->gpart_elems));
   // Gram task lists for every tile count
   {
@@ -1434,9 +1496,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     size_t o_sse = off;
     off += (size_t)2 * s->n_sse_blk * sizeof(double);
     size_t o_b = off;
-    off += 256 * sizeof(double);
+    off += (size_t)capA * sizeof(double);
     size_t o_a = off;
-    off += 256 * sizeof(int);
+    off += (size_t)capA * sizeof(int);
     s->res_bytes = off;
     HIPT(hipMalloc(reinterpret_cast<void **>(&s->resblk), off));
     HIPT(hipMemset(s->resblk, 0, off));
@@ -1445,7 +1507,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     s->b_cur = reinterpret_cast<double *>(s->resblk + o_b);
     s->A_cur = reinterpret_cast<int *>(s->resblk + o_a);
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->res_h), off));
-    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), 8192));
+    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), (size_t)capA * (sizeof(int) + sizeof(double))));
   }
   static_assert(sizeof(FitCtrl) <= 128, "FitCtrl must fit its slot of the result block");
   // data
@@ -1505,8 +1567,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->Wv, (size_t)ld));
   HIPT(hipMemset(s->Wv, 0, (size_t)ld * sizeof(double)));
   HIPT(dmalloc(&s->llpart, (size_t)s->n_sse_blk));
-  HIPT(dmalloc(&s->bcur, 512));
-  HIPT(dmalloc(&s->bprev, 512));
+  HIPT(dmalloc(&s->bcur, (size_t)capA + 16));
+  HIPT(dmalloc(&s->bprev, (size_t)capA + 16));
   HIPT(dmalloc(&s->logfact, (size_t)ld));
   {
     // sum_{j=1..y} log j per row, the loop of loglik_poisson (src/poisson.cpp:27-41); only Poisson reads it
@@ -1882,7 +1944,7 @@ int bessx_op_topk(const double *score, int len, int k, int *out_idx) {
 
 int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m, const double *w, double *out) {
   if (int rc = need_device()) return rc;
-  if (!x || !cols || !out || n < 1 || p < 1 || ld < n || m < 1 || m > 255) return fail(BESSX_ERR_ARG, "op_gram: bad arguments");
+  if (!x || !cols || !out || n < 1 || p < 1 || ld < n || m < 1 || m > T0_CAP) return fail(BESSX_ERR_ARG, "op_gram: bad arguments");
   for (int i = 0; i < m; i++)
     if (cols[i] < 0 || cols[i] >= p) return fail(BESSX_ERR_ARG, "op_gram: column index out of range");
   Scratch sc;
@@ -1933,7 +1995,7 @@ int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m,
 
 int bessx_op_chol_solve(const double *a, int m, const double *b, double *sol) {
   if (int rc = need_device()) return rc;
-  if (!a || !b || !sol || m < 1 || m > 255) return fail(BESSX_ERR_ARG, "op_chol_solve: need 1 <= m <= 255");
+  if (!a || !b || !sol || m < 1 || m > T0_CAP) return fail(BESSX_ERR_ARG, "op_chol_solve: need 1 <= m <= 2046");
   Scratch sc;
   const int mt = (m + 1 + 15) / 16, ntiles = mt * (mt + 1) / 2;
   std::vector<double> ht((size_t)ntiles * 256, 0.0);
@@ -1955,7 +2017,14 @@ int bessx_op_chol_solve(const double *a, int m, const double *b, double *sol) {
   HIPX(hipMemset(dinfo, 0, sizeof(int)));
   HIPX(hipMemcpy(Gt, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPX(hipMemcpy(drhs, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
-  HIPX(launch_chol(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, 0, nullptr));
+  if (mt <= 16) {
+    HIPX(launch_chol(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, 0, nullptr));
+  } else {
+    double *rd, *zz;
+    HIPX(sc.alloc(&rd, (size_t)mt * 16));
+    HIPX(sc.alloc(&zz, (size_t)mt * 16));
+    HIPX(launch_chol_big(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, rd, zz, nullptr, 0, 0, nullptr));
+  }
   HIPX(hipMemcpy(sol, dsol, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
   int info = 0;
   HIPX(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));

@@ -826,6 +826,158 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
 }
 
 // ------------------------------------------------------------------------------------------
+// K7, large systems (m + 1 > 256): blocked right-looking Cholesky on the tile-layout matrix in global memory
+// (it stays L2 resident), one small launch per phase of a block column.  Correct for any size; the in-register
+// kernel above is the fast path for the BASELINE sizes (k <= 254).  Same augmented-row trick for the right-hand side.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_elem(int row, int col) { return ((((row & 3) << 4) | col) << 2) | (row >> 2); }
+__device__ __forceinline__ size_t tile_id(int I, int J) { return (size_t)I * (I + 1) / 2 + J; }
+
+#define BIG_GATE(ctrl, slot, gate_mode)                                              \
+  if ((ctrl) != nullptr) {                                                           \
+    if ((ctrl)->done || (ctrl)->l != (slot)-1 || (ctrl)->same_prev) return;          \
+    if (((gate_mode) == 1 || (gate_mode) == 2) && (ctrl)->irls_done) return;         \
+  }
+
+// apply ridge / padding / right-hand-side row to the reduced Gram tiles in place (what k_chol does while loading)
+__global__ void __launch_bounds__(256) k_bc_prepare(double *__restrict__ Gt, int m, int mt, double ridge,
+                                                    int ridge_skip0, const double *__restrict__ rhs,
+                                                    const int *__restrict__ rhs_gather,
+                                                    const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+  BIG_GATE(ctrl, slot, gate_mode);
+  const int t = blockIdx.x, lane = threadIdx.x >> 2, r = threadIdx.x & 3, mp = mt * 16;
+  int I, J;
+  tile_of(t, I, J);
+  const int row = I * 16 + (lane >> 4) + 4 * r, col = J * 16 + (lane & 15);
+  double v = Gt[(size_t)t * 256 + threadIdx.x];
+  if (row == col && row < m && !(ridge_skip0 && row == 0)) v += ridge;
+  if (rhs != nullptr) {
+    if (row >= m || col >= m) v = (row == col) ? 1.0 : 0.0;
+    if (row == mp - 1 && col < m) v = rhs[rhs_gather ? rhs_gather[col] : col];
+  } else {
+    bool rpad = row >= m && row != mp - 1, cpad = col >= m && col != mp - 1;
+    if (rpad || cpad) v = (row == col) ? 1.0 : 0.0;
+    if (row == mp - 1 && col == mp - 1) v = 1.0;
+  }
+  Gt[(size_t)t * 256 + threadIdx.x] = v;
+}
+
+// block column b: every wave factors tile (b,b) redundantly in registers, wave I-b then substitutes its panel tile
+// (I,b) (16 rows, one lane each); the wave of I == b stores the factor and the reciprocal diagonal.
+__global__ void __launch_bounds__(64) k_bc_panel(double *__restrict__ Gt, double *__restrict__ rdiag, int mt, int b,
+                                                 const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+  BIG_GATE(ctrl, slot, gate_mode);
+  const int lane = threadIdx.x, rr = lane & 15, I = b + blockIdx.x;
+  const double *D = Gt + tile_id(b, b) * 256;
+  double Lr[16], rinv[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) Lr[c] = D[tile_elem(rr, c)];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const double d = sqrt(bcast_lane(Lr[j], j));
+    rinv[j] = bcast_lane(1.0 / d, 0);
+    const double lij = (rr == j) ? d : Lr[j] * rinv[j];
+    Lr[j] = lij;
+#pragma unroll
+    for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, bcast_lane(lij, c), Lr[c]);
+    if (I == b && lane == j) rdiag[b * 16 + j] = rinv[j];
+  }
+  double *T = Gt + tile_id(I, b) * 256;
+  if (I == b) {
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) T[tile_elem(rr, c)] = Lr[c];
+    }
+    return;
+  }
+  double x[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = T[tile_elem(rr, j)];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    double sacc = x[j];
+#pragma unroll
+    for (int t = 0; t < j; t++) sacc = fma(-x[t], bcast_lane(Lr[t], j), sacc);
+    x[j] = sacc * rinv[j];
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) T[tile_elem(rr, j)] = x[j];
+  }
+}
+
+// trailing update of step b: tile (I,J) -= L(I,b) L(J,b)^T for b < J <= I, one wave per tile, 4 fp64 MFMAs
+__global__ void __launch_bounds__(64) k_bc_update(double *__restrict__ Gt, int mt, int b,
+                                                  const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+  BIG_GATE(ctrl, slot, gate_mode);
+  const int lane = threadIdx.x, lc = lane & 15, lq = lane >> 4;
+  int Ir, Jr;
+  tile_of(blockIdx.x, Ir, Jr);  // enumerate the lower triangle of the trailing (mt-b-1) x (mt-b-1) tile grid
+  const int I = b + 1 + Ir, J = b + 1 + Jr;
+  const double *A = Gt + tile_id(I, b) * 256, *B = Gt + tile_id(J, b) * 256;
+  double *C = Gt + tile_id(I, J) * 256;
+  d4 acc = *reinterpret_cast<const d4 *>(C + lane * 4);
+#pragma unroll
+  for (int k4 = 0; k4 < 4; k4++) {
+    double av = -A[tile_elem(lc, k4 * 4 + lq)], bv = B[tile_elem(lc, k4 * 4 + lq)];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  *reinterpret_cast<d4 *>(C + lane * 4) = acc;
+}
+
+// backward solve, block b: z_b <- Lbb^{-T} z_b, then z_c -= L(b,c)^T z_b for c < b.  One 512-thread block.
+// step == mt - 1 first copies y (= row mp-1 of L) into z.
+__global__ void __launch_bounds__(512) k_bc_back(const double *__restrict__ Gt, const double *__restrict__ rdiag,
+                                                 double *__restrict__ z, int mt, int b, int m,
+                                                 double *__restrict__ sol, int *__restrict__ info,
+                                                 const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+  BIG_GATE(ctrl, slot, gate_mode);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mp = mt * 16;
+  if (b == mt - 1) {
+    for (int c = tid; c < mp; c += 512) {
+      const int J = c >> 4;
+      z[c] = (c == mp - 1) ? 0.0 : Gt[tile_id(mt - 1, J) * 256 + tile_elem(15, c & 15)];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    const double *D = Gt + tile_id(b, b) * 256;
+    const int ci = lane & 15;
+    double Lc[16], zi = z[b * 16 + ci];
+#pragma unroll
+    for (int r = 0; r < 16; r++) Lc[r] = D[tile_elem(r, ci)];
+    const double ri = rdiag[b * 16 + ci];
+#pragma unroll
+    for (int j = 15; j >= 0; j--) {
+      double xj = bcast_lane(zi, j) * bcast_lane(ri, j);
+      if (b == mt - 1 && j == 15) xj = 0.0;
+      zi = (ci == j) ? xj : ((ci < j) ? fma(-Lc[j], xj, zi) : zi);
+    }
+    if (lane < 16) z[b * 16 + ci] = zi;
+  }
+  __syncthreads();
+  const int lc = lane & 15, lq = lane >> 4;
+  for (int c = wave; c < b; c += 8) {
+    const d4 t = *reinterpret_cast<const d4 *>(Gt + tile_id(b, c) * 256 + lane * 4);
+    const int zb = b * 16 + lq;
+    double v = t.x * z[zb] + t.y * z[zb + 4] + t.z * z[zb + 8] + t.w * z[zb + 12];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lq == 0) z[c * 16 + lc] -= v;
+  }
+  if (b == 0) {
+    __syncthreads();
+    bool bad = false;
+    for (int i = tid; i < m; i += 512) {
+      double v = z[i];
+      sol[i] = v;
+      bad |= !(fabs(v) <= DBL_MAX);
+    }
+    if (__syncthreads_or(bad) && tid == 0 && info != nullptr) *info = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Algorithm::fit bookkeeping (src/Algorithm.h:141-170) on the device.
 // ------------------------------------------------------------------------------------------
 // Start of a fit: beta <- beta_init (sparse), A_list.col(0) = 0, l = 0.
@@ -1891,7 +2043,8 @@ hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, in
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
                        hipStream_t st) {
-  if (mt < 1 || mt > CH_MT || m + 1 > mt * 16) return hipErrorInvalidValue;
+  if (mt < 1 || m + 1 > mt * 16) return hipErrorInvalidValue;
+  if (mt > CH_MT) return hipErrorInvalidValue;  // callers route larger systems to launch_chol_big
   if (mt <= 8)
     hipLaunchKernelGGL(k_chol<5>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info,
                        ctrl, slot, gate_mode);
@@ -1902,6 +2055,32 @@ hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_
     hipLaunchKernelGGL(k_chol<17>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
                        info, ctrl, slot, gate_mode);
   LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// Blocked Cholesky for m + 1 > 256.  Gt is overwritten by its factor; rdiag (>= 16*mt) and z (>= 16*mt) are work space.
+hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
+                           const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
+                           const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st) {
+  if (mt < 1 || m + 1 > mt * 16) return hipErrorInvalidValue;
+  const int ntiles = mt * (mt + 1) / 2;
+  hipLaunchKernelGGL(k_bc_prepare, dim3(ntiles), dim3(256), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather,
+                     ctrl, slot, gate_mode);
+  LAUNCH_CHECK();
+  for (int b = 0; b < mt; b++) {
+    hipLaunchKernelGGL(k_bc_panel, dim3(mt - b), dim3(64), 0, st, Gt, rdiag, mt, b, ctrl, slot, gate_mode);
+    LAUNCH_CHECK();
+    const int nt = (mt - b - 1) * (mt - b) / 2;
+    if (nt > 0) {
+      hipLaunchKernelGGL(k_bc_update, dim3(nt), dim3(64), 0, st, Gt, mt, b, ctrl, slot, gate_mode);
+      LAUNCH_CHECK();
+    }
+  }
+  for (int b = mt - 1; b >= 0; b--) {
+    hipLaunchKernelGGL(k_bc_back, dim3(1), dim3(512), 0, st, (const double *)Gt, (const double *)rdiag, z, mt, b, m,
+                       sol, info, ctrl, slot, gate_mode);
+    LAUNCH_CHECK();
+  }
   return hipSuccess;
 }
 

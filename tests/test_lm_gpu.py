@@ -83,3 +83,15 @@ def test_lm_shapes(gpu, n, p, kmax):
 def test_lm_large_k(gpu):
     X, y, _, _ = synth.make_lm(3000, 600, 100, seed=5)
     check(gpu, X, y, dict(ic_type=3, sequence=np.array([1, 50, 100, 150, 200, 254])), "large k")
+
+
+def test_lm_beyond_register_solver(gpu):
+    """Sparsity levels above 254 take the blocked global-memory Cholesky (the reference's default sequence goes up
+    to min(p, n / log n), python/bess/linear.py:285-287)."""
+    X, y, _, _ = synth.make_lm(2500, 900, 40, seed=9)
+    check(gpu, X, y, dict(ic_type=3, sequence=np.array([250, 254, 255, 256, 300, 400])), "k > 254")
+
+
+def test_logistic_beyond_register_solver(gpu):
+    X, y, _, _ = synth.make_logistic(3000, 500, 10, seed=3)
+    check(gpu, X, y, dict(data_type=2, model_type=2, ic_type=3, sequence=np.array([253, 254, 260])), "logit k > 253")

@@ -44,7 +44,7 @@ def test_topk_ties_and_specials(gpu):
 
 
 @pytest.mark.parametrize("n,p,m", [(97, 8, 3), (500, 40, 16), (1000, 60, 17), (3000, 300, 100), (5000, 400, 200),
-                                   (4096, 300, 255)])
+                                   (4096, 300, 255), (3000, 700, 600)])
 def test_gram_matches_numpy(gpu, n, p, m):
     rng = np.random.default_rng(n + p + m)
     x = rng.standard_normal((n, p))
@@ -58,15 +58,15 @@ def test_gram_matches_numpy(gpu, n, p, m):
     assert np.array_equal(g, g.T)
 
 
-@pytest.mark.parametrize("m", [1, 2, 15, 16, 17, 31, 32, 100, 129, 200, 255])
+@pytest.mark.parametrize("m", [1, 2, 15, 16, 17, 31, 32, 100, 129, 200, 255, 256, 300, 511, 1000])
 def test_chol_solve_matches_oracle(gpu, m):
     rng = np.random.default_rng(m)
     a = rng.standard_normal((m + 20, m))
     g = a.T @ a + 0.1 * np.eye(m)
     b = rng.standard_normal(m)
-    got = gpu.op_chol_solve(g, b)
+    got = gpu.op_chol_solve(g, b)  # m <= 255: register-resident kernel; above: blocked global-memory Cholesky
     want = P.sym_solve(g, b)
-    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * np.abs(want).max())
+    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-10 * np.abs(want).max())
     np.testing.assert_allclose(g @ got, b, rtol=0, atol=1e-9 * max(1.0, np.abs(b).max()))
 
 
