@@ -84,6 +84,9 @@ typedef struct {
   double *x_mean, *x_norm;
   double y_mean;
   int data_type, is_normal;
+  /* groups (Data::g_index / g_size / g_num, src/Data.h:59-67): group g owns columns gidx[g] .. gidx[g]+gsz[g]-1 */
+  int N, gmax;
+  int *gidx, *gsz, *goff; /* goff: offset of the g x g block of group g in block arrays */
 } odata;
 
 #define XC(d, j) ((d)->x + (size_t)(j) * (size_t)(d)->n)
@@ -240,31 +243,133 @@ static void select_top(oalg *a, double *bd, int *A) {
   /* slice_assignment + max_k, src/utilities.cpp:179-199 */
   int i;
   for (i = 0; i < a->n_always; i++) bd[a->always[i]] = DBL_MAX;
-  bess_oracle_max_k(bd, a->d->p, a->T0, A);
+  bess_oracle_max_k(bd, a->d->N, a->T0, A);
+}
+
+/* symmetric eigen-decomposition by cyclic Jacobi: a (s x s, column-major) -> eigenvalues ev, eigenvectors v */
+static void jacobi_eig(double *a, int s, double *ev, double *v) {
+  int i, j, k, sweep;
+  for (i = 0; i < s; i++)
+    for (j = 0; j < s; j++) v[(size_t)j * s + i] = i == j ? 1.0 : 0.0;
+  for (sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, dg = 0.0;
+    for (i = 0; i < s; i++)
+      for (j = 0; j < s; j++) {
+        if (i != j) off += a[(size_t)j * s + i] * a[(size_t)j * s + i];
+        else dg += a[(size_t)j * s + i] * a[(size_t)j * s + i];
+      }
+    if (off <= 1e-32 * dg || off == 0.0) break;
+    for (i = 0; i < s - 1; i++)
+      for (j = i + 1; j < s; j++) {
+        double apq = a[(size_t)j * s + i], app, aqq, theta, t, c, sn;
+        if (apq == 0.0) continue;
+        app = a[(size_t)i * s + i];
+        aqq = a[(size_t)j * s + j];
+        theta = (aqq - app) / (2.0 * apq);
+        t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        c = 1.0 / sqrt(t * t + 1.0);
+        sn = t * c;
+        for (k = 0; k < s; k++) {
+          double akp = a[(size_t)i * s + k], akq = a[(size_t)j * s + k];
+          a[(size_t)i * s + k] = c * akp - sn * akq;
+          a[(size_t)j * s + k] = sn * akp + c * akq;
+        }
+        for (k = 0; k < s; k++) {
+          double apk = a[(size_t)k * s + i], aqk = a[(size_t)k * s + j];
+          a[(size_t)k * s + i] = c * apk - sn * aqk;
+          a[(size_t)k * s + j] = sn * apk + c * aqk;
+        }
+        for (k = 0; k < s; k++) {
+          double vkp = v[(size_t)i * s + k], vkq = v[(size_t)j * s + k];
+          v[(size_t)i * s + k] = c * vkp - sn * vkq;
+          v[(size_t)j * s + k] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  for (i = 0; i < s; i++) ev[i] = a[(size_t)i * s + i];
+}
+
+/* Per-group sacrifice bd_g = || Phi_g beta_g + Phi_g^{-1} d_g ||^2 / size(g), Phi_g = sqrtm(M_g)
+ * (src/Algorithm.h:1112-1123, :1238-1257; Phi / invPhi: src/utilities.cpp:142-151, 167-177).
+ * mblk holds the symmetric blocks M_g (column-major, at goff[g]); dcol the per-column d. */
+static void group_scores(const oalg *a, const double *mblk, const double *dcol, double *bd) {
+  const odata *d = a->d;
+  int g, i, j, k, gm = d->gmax;
+  double *m = (double *)malloc((size_t)gm * gm * sizeof(double)), *v = (double *)malloc((size_t)gm * gm * sizeof(double));
+  double *ev = (double *)malloc((size_t)gm * sizeof(double)), *t = (double *)malloc((size_t)gm * sizeof(double));
+  for (g = 0; g < d->N; g++) {
+    int s = d->gsz[g], c0 = d->gidx[g];
+    if (s == 1) {
+      double phi = sqrt(mblk[d->goff[g]]), inv = 1.0 / phi, tt = phi * a->beta[c0] + inv * dcol[c0];
+      bd[g] = tt * tt;
+      continue;
+    }
+    memcpy(m, mblk + d->goff[g], (size_t)s * s * sizeof(double));
+    jacobi_eig(m, s, ev, v);
+    for (i = 0; i < s; i++) t[i] = 0.0;
+    for (k = 0; k < s; k++) {
+      /* component of beta_g and d_g along eigenvector k */
+      double pb = 0.0, pd = 0.0, sq = sqrt(ev[k]), coef;
+      for (j = 0; j < s; j++) {
+        pb += v[(size_t)k * s + j] * a->beta[c0 + j];
+        pd += v[(size_t)k * s + j] * dcol[c0 + j];
+      }
+      coef = sq * pb + pd / sq;
+      for (i = 0; i < s; i++) t[i] += v[(size_t)k * s + i] * coef;
+    }
+    {
+      double ss = 0.0;
+      for (i = 0; i < s; i++) ss += t[i] * t[i];
+      bd[g] = ss / (double)s;
+    }
+  }
+  free(m);
+  free(v);
+  free(ev);
+  free(t);
+}
+
+/* find_ind, src/utilities.cpp:113-130: groups -> columns (all p columns when every group is selected) */
+static int expand_groups(const odata *d, const int *A, int T0, int *cols) {
+  int i, j, k = 0;
+  if (T0 == d->N) {
+    for (j = 0; j < d->p; j++) cols[j] = j;
+    return d->p;
+  }
+  for (i = 0; i < T0; i++)
+    for (j = 0; j < d->gsz[A[i]]; j++) cols[k++] = d->gidx[A[i]] + j;
+  return k;
 }
 
 /* GroupPdasLm::get_A, src/Algorithm.h:1097-1129 with Phi / invPhi for 1x1 groups,
  * src/utilities.cpp:142-151, 167-177. */
 static void lm_get_A(oalg *a, int *A) {
   const odata *d = a->d;
-  int nt = a->n_rows, p = d->p, i, j;
+  int nt = a->n_rows, p = d->p, i, j, g, nb = d->goff[d->N];
   double *r = (double *)malloc((size_t)nt * sizeof(double));
-  double *bd = (double *)malloc((size_t)p * sizeof(double));
+  double *dc = (double *)malloc((size_t)p * sizeof(double));
+  double *bd = (double *)malloc((size_t)d->N * sizeof(double));
+  double *mb = (double *)malloc((size_t)nb * sizeof(double));
   lin_pred(d, a->beta, a->rows, nt, r);
   for (i = 0; i < nt; i++) r[i] = d->y[a->rows[i]] - r[i] - a->coef0;
   for (j = 0; j < p; j++) {
     const double *c = d->x + (size_t)j * (size_t)d->n;
-    double s = 0.0, dj, phi, inv, t;
+    double s = 0.0;
     for (i = 0; i < nt; i++) s += c[a->rows[i]] * r[i];
-    dj = s / (double)nt - 2.0 * a->lambda * a->beta[j];
-    phi = sqrt(2.0 * a->lambda + a->xtx[j] / (double)nt);
-    inv = 1.0 / phi;
-    t = phi * a->beta[j] + inv * dj;
-    bd[j] = t * t;
+    dc[j] = s / (double)nt - 2.0 * a->lambda * a->beta[j];
   }
+  /* Phi_g^2 = 2 lambda I + X_g^T X_g / n (src/utilities.cpp:147) */
+  for (g = 0; g < d->N; g++) {
+    int sz = d->gsz[g];
+    for (i = 0; i < sz * sz; i++) mb[d->goff[g] + i] = a->xtx[d->goff[g] + i] / (double)nt;
+    for (i = 0; i < sz; i++) mb[d->goff[g] + i * sz + i] += 2.0 * a->lambda;
+  }
+  group_scores(a, mb, dc, bd);
   select_top(a, bd, A);
   free(r);
+  free(dc);
   free(bd);
+  free(mb);
 }
 
 /* GroupPdasLm::primary_model_fit, src/Algorithm.h:1131-1135 */
@@ -382,36 +487,52 @@ static void logistic_fit(oalg *a, const int *A, int k, double *bA, double *coef0
 }
 
 /* GroupPdasLogistic::get_A, src/Algorithm.h:1206-1263 (1x1 groups) */
+/* shared tail of the GLM get_A: d = X^T g - 2 lambda beta, M_g = X_g^T diag(h) X_g + 2 lambda I */
+static void glm_scores(oalg *a, const double *g, const double *h, int *A) {
+  const odata *d = a->d;
+  int nt = a->n_rows, p = d->p, i, j, u, v, gg, nb = d->goff[d->N];
+  double *dc = (double *)malloc((size_t)p * sizeof(double));
+  double *bd = (double *)malloc((size_t)d->N * sizeof(double));
+  double *mb = (double *)malloc((size_t)nb * sizeof(double));
+  for (j = 0; j < p; j++) {
+    const double *c = d->x + (size_t)j * (size_t)d->n;
+    double s1 = 0.0;
+    for (i = 0; i < nt; i++) s1 += c[a->rows[i]] * g[i];
+    dc[j] = s1 - 2.0 * a->lambda * a->beta[j];
+  }
+  for (gg = 0; gg < d->N; gg++) {
+    int sz = d->gsz[gg], c0 = d->gidx[gg];
+    for (u = 0; u < sz; u++)
+      for (v = 0; v <= u; v++) {
+        const double *cu = d->x + (size_t)(c0 + u) * (size_t)d->n, *cv = d->x + (size_t)(c0 + v) * (size_t)d->n;
+        double s2 = 0.0;
+        for (i = 0; i < nt; i++) s2 += (cu[a->rows[i]] * h[i]) * cv[a->rows[i]];
+        if (u == v) s2 += 2.0 * a->lambda;
+        mb[d->goff[gg] + (size_t)v * sz + u] = s2;
+        mb[d->goff[gg] + (size_t)u * sz + v] = s2;
+      }
+  }
+  group_scores(a, mb, dc, bd);
+  select_top(a, bd, A);
+  free(dc);
+  free(bd);
+  free(mb);
+}
+
 static void logistic_get_A(oalg *a, int *A) {
   const odata *d = a->d;
-  int nt = a->n_rows, p = d->p, i, j;
+  int nt = a->n_rows, i;
   double *g = (double *)malloc((size_t)nt * sizeof(double));
   double *h = (double *)malloc((size_t)nt * sizeof(double));
-  double *bd = (double *)malloc((size_t)p * sizeof(double));
   lin_pred(d, a->beta, a->rows, nt, g);
   for (i = 0; i < nt; i++) {
     double e = exp(clamp30(g[i] + a->coef0)), pr = e / (e + 1.0), wi = d->w[a->rows[i]];
     g[i] = wi * (d->y[a->rows[i]] - pr);
     h[i] = wi * pr * (1.0 - pr);
   }
-  for (j = 0; j < p; j++) {
-    const double *c = d->x + (size_t)j * (size_t)d->n;
-    double s1 = 0.0, s2 = 0.0, dj, phi, inv, t;
-    for (i = 0; i < nt; i++) {
-      double xv = c[a->rows[i]];
-      s1 += xv * g[i];
-      s2 += (xv * h[i]) * xv;
-    }
-    dj = s1 - 2.0 * a->lambda * a->beta[j];
-    phi = sqrt(s2 + 2.0 * a->lambda);
-    inv = 1.0 / phi;
-    t = phi * a->beta[j] + inv * dj;
-    bd[j] = t * t;
-  }
-  select_top(a, bd, A);
+  glm_scores(a, g, h, A);
   free(g);
   free(h);
-  free(bd);
 }
 
 /* GroupPdasPoisson::primary_model_fit, src/Algorithm.h:1273-1322.  Warm start from
@@ -459,34 +580,18 @@ static void poisson_fit(oalg *a, const int *A, int k, double *bA, double *coef0)
 /* GroupPdasPoisson::get_A, src/Algorithm.h:1324-1367 (no eta clamp) */
 static void poisson_get_A(oalg *a, int *A) {
   const odata *d = a->d;
-  int nt = a->n_rows, p = d->p, i, j;
+  int nt = a->n_rows, i;
   double *g = (double *)malloc((size_t)nt * sizeof(double));
   double *h = (double *)malloc((size_t)nt * sizeof(double));
-  double *bd = (double *)malloc((size_t)p * sizeof(double));
   lin_pred(d, a->beta, a->rows, nt, g);
   for (i = 0; i < nt; i++) {
     double e = exp(g[i] + a->coef0), wi = d->w[a->rows[i]];
     g[i] = (d->y[a->rows[i]] - e) * wi;
     h[i] = e * wi;
   }
-  for (j = 0; j < p; j++) {
-    const double *c = d->x + (size_t)j * (size_t)d->n;
-    double s1 = 0.0, s2 = 0.0, dj, phi, inv, t;
-    for (i = 0; i < nt; i++) {
-      double xv = c[a->rows[i]];
-      s1 += xv * g[i];
-      s2 += (xv * h[i]) * xv;
-    }
-    dj = s1 - 2.0 * a->lambda * a->beta[j];
-    phi = sqrt(s2 + 2.0 * a->lambda);
-    inv = 1.0 / phi;
-    t = phi * a->beta[j] + inv * dj;
-    bd[j] = t * t;
-  }
-  select_top(a, bd, A);
+  glm_scores(a, g, h, A);
   free(g);
   free(h);
-  free(bd);
 }
 
 /* loglik_cox, src/coxph.cpp:16-40, on an arbitrary sorted row subset */
@@ -621,10 +726,11 @@ static void cox_get_A(oalg *a, int *A) {
 
 /* Algorithm::fit, src/Algorithm.h:113-171 */
 static void alg_fit(oalg *a) {
-  int T0 = a->T0, p = a->d->p, i, ll, l;
+  int T0 = a->T0, p = a->d->p, i, ll, l, K;
   int *A = (int *)calloc((size_t)(T0 ? T0 : 1), sizeof(int));
   int *Alist = (int *)calloc((size_t)(T0 ? T0 : 1) * (size_t)(a->max_iter + 2), sizeof(int));
-  double *bA = (double *)malloc((size_t)(T0 ? T0 : 1) * sizeof(double));
+  int *cols = (int *)malloc((size_t)p * sizeof(int));
+  double *bA = (double *)malloc((size_t)p * sizeof(double));
   memcpy(a->beta, a->beta_init, (size_t)p * sizeof(double));
   a->coef0 = a->coef0_init;
   for (l = 1; l <= a->max_iter; l++) {
@@ -638,32 +744,35 @@ static void alg_fit(oalg *a) {
       poisson_get_A(a, A);
     else
       cox_get_A(a, A);
+    K = expand_groups(a->d, A, T0, cols); /* find_ind + X_seg, :155-156 */
+    /* the trace stores the EXPANDED column list (aligned with the coefficients of the fit) */
     ipush(&t_meta, l);
     ipush(&t_meta, T0);
     ipush(&t_meta, a->n_rows);
     off = t_a.n;
     ipush(&t_meta, off);
-    for (i = 0; i < T0; i++) ipush(&t_a, A[i]);
+    for (i = 0; i < K; i++) ipush(&t_a, cols[i]);
     memcpy(Alist + (size_t)l * T0, A, (size_t)T0 * sizeof(int));
-    for (i = 0; i < T0; i++) bA[i] = 0.0;
+    for (i = 0; i < K; i++) bA[i] = 0.0;
     if (a->model_type == 1)
-      lm_fit(a, A, T0, bA);
+      lm_fit(a, cols, K, bA);
     else if (a->model_type == 2)
-      logistic_fit(a, A, T0, bA, &a->coef0);
+      logistic_fit(a, cols, K, bA, &a->coef0);
     else if (a->model_type == 3)
-      poisson_fit(a, A, T0, bA, &a->coef0);
+      poisson_fit(a, cols, K, bA, &a->coef0);
     else
-      cox_fit(a, A, T0, bA);
-    for (i = 0; i < T0; i++) dpush(&t_beta, bA[i]);
+      cox_fit(a, cols, K, bA);
+    for (i = 0; i < K; i++) dpush(&t_beta, bA[i]);
     dpush(&t_coef0, a->coef0);
     for (i = 0; i < p; i++) a->beta[i] = 0.0;
-    for (i = 0; i < T0; i++) a->beta[A[i]] = bA[i];
+    for (i = 0; i < K; i++) a->beta[cols[i]] = bA[i];
     for (ll = 0; ll < l && !same; ll++) same = memcmp(A, Alist + (size_t)ll * T0, (size_t)T0 * sizeof(int)) == 0;
     if (same) break;
   }
   if (l > a->max_iter) a->l = a->max_iter + 1;
   free(A);
   free(Alist);
+  free(cols);
   free(bA);
 }
 
@@ -753,11 +862,15 @@ static double metric_ic(ometric *m, oalg *a) {
   } else if (m->ic_type < 1 || m->ic_type > 4) {
     v = 0.0;
   } else {
+    /* LM picks the group formula by algorithm_type (src/Metric.h:205,230), the other families by
+     * g_index.size() == p (:365, :504, :624); the group formula uses log(g_num) and group_df = sparsity level */
+    int grouped = a->model_type == 1 ? !(a->algorithm_type == 1 || a->algorithm_type == 5) : (a->d->N != a->d->p);
+    double pp = grouped ? (double)a->d->N : p;
     loss = metric_train_loss(m, a);
     if (m->ic_type == 1) c = 2.0;
     if (m->ic_type == 2) c = log(n);
-    if (m->ic_type == 3) c = log(p) * log(log(n));
-    if (m->ic_type == 4) c = log(n) + 2.0 * log(p);
+    if (m->ic_type == 3) c = log(pp) * log(log(n));
+    if (m->ic_type == 4) c = log(n) + 2.0 * log(pp);
     v = (a->model_type == 1 ? n * log(loss) : loss) + c * (double)a->T0;
   }
   m->depth--;
@@ -1311,6 +1424,22 @@ static int pgs_path(oalg *al, ometric *m, const double *xtx, int s_min, int s_ma
 
 /* ------------------------------------------------------------------ driver */
 
+/* group_XTX, src/utilities.cpp:153-165: X_g^T X_g on a row subset, one block per group */
+static void group_xtx(const odata *d, const int *rows, int nr, double *out) {
+  int g, u, v, i;
+  for (g = 0; g < d->N; g++) {
+    int sz = d->gsz[g], c0 = d->gidx[g];
+    for (u = 0; u < sz; u++)
+      for (v = 0; v <= u; v++) {
+        const double *cu = d->x + (size_t)(c0 + u) * (size_t)d->n, *cv = d->x + (size_t)(c0 + v) * (size_t)d->n;
+        double s = 0.0;
+        for (i = 0; i < nr; i++) s += cu[rows[i]] * cv[rows[i]];
+        out[d->goff[g] + (size_t)v * sz + u] = s;
+        out[d->goff[g] + (size_t)u * sz + v] = s;
+      }
+  }
+}
+
 /* bessCpp, src/bess.cpp:37-214 (no screening) */
 int bess_oracle_run(const double *x, int n, int p, const double *y, const double *weight, int data_type,
                     int is_normal, int algorithm_type, int model_type, int max_iter, int path_type,
@@ -1333,7 +1462,23 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
                      double lambda_min, double lambda_max, int nlambda, int powell_path, const int *always_select,
                      int always_len, double *beta_out, double *coef0_out, double *train_loss_out, double *ic_out,
                      double *lambda_out) {
+  return bess_oracle_run3(x, n, p, y, weight, data_type, is_normal, algorithm_type, model_type, max_iter, path_type,
+                          is_warm_start, ic_type, is_cv, K, cv_fold_id, sequence, sequence_len, lambda_seq, lambda_len,
+                          s_min, s_max, lambda_min, lambda_max, nlambda, powell_path, NULL, 0, always_select,
+                          always_len, beta_out, coef0_out, train_loss_out, ic_out, lambda_out);
+}
+
+/* As bess_oracle_run2 plus the group structure: g_index[g] = first column of group g (ascending, g_index[0] = 0),
+ * NULL = every column its own group.  Sparsity levels and always_select then count / name groups. */
+int bess_oracle_run3(const double *x, int n, int p, const double *y, const double *weight, int data_type,
+                     int is_normal, int algorithm_type, int model_type, int max_iter, int path_type,
+                     int is_warm_start, int ic_type, int is_cv, int K, const int *cv_fold_id, const int *sequence,
+                     int sequence_len, const double *lambda_seq, int lambda_len, int s_min, int s_max,
+                     double lambda_min, double lambda_max, int nlambda, int powell_path, const int *g_index, int g_len,
+                     const int *always_select, int always_len, double *beta_out, double *coef0_out,
+                     double *train_loss_out, double *ic_out, double *lambda_out) {
   odata d;
+  int gq;
   oalg a;
   ometric m;
   opoint best;
@@ -1341,11 +1486,16 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
   int i, j, k;
   if (n < 1 || p < 1 || model_type < 1 || model_type > 4) return 1;
   if (is_cv && (cv_fold_id == NULL || K < 2)) return 2;
+  if (g_index == NULL) g_len = p;
+  if (g_len < 1 || g_len > p || (g_index != NULL && g_index[0] != 0)) return 4;
+  for (i = 1; g_index != NULL && i < g_len; i++)
+    if (g_index[i] <= g_index[i - 1] || g_index[i] >= p) return 4;
+  if (model_type == 4 && g_len != p) return 4; /* Cox with groups of size > 1: not restated */
   if (path_type == 1) {
     for (i = 0; i < sequence_len; i++)
-      if (sequence[i] < 0 || sequence[i] > p) return 3;
+      if (sequence[i] < 0 || sequence[i] > g_len) return 3;
     if (sequence_len < 1 || lambda_len < 1) return 3;
-  } else if (s_min < 0 || s_max > p || s_min > s_max) {
+  } else if (s_min < 0 || s_max > g_len || s_min > s_max) {
     return 3;
   }
   if (path_type == 3 && (s_min < 1 || nlambda < 2)) return 3;
@@ -1361,6 +1511,18 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
   d.x_mean = (double *)calloc((size_t)p, sizeof(double));
   d.x_norm = (double *)calloc((size_t)p, sizeof(double));
   d.y_mean = 0.0;
+  d.N = g_len;
+  d.gidx = (int *)malloc((size_t)g_len * sizeof(int));
+  d.gsz = (int *)malloc((size_t)g_len * sizeof(int));
+  d.goff = (int *)malloc((size_t)(g_len + 1) * sizeof(int));
+  d.gmax = 1;
+  d.goff[0] = 0;
+  for (gq = 0; gq < g_len; gq++) {
+    d.gidx[gq] = g_index ? g_index[gq] : gq;
+    d.gsz[gq] = (gq + 1 < g_len ? (g_index ? g_index[gq + 1] : gq + 1) : p) - d.gidx[gq];
+    if (d.gsz[gq] > d.gmax) d.gmax = d.gsz[gq];
+    d.goff[gq + 1] = d.goff[gq] + d.gsz[gq] * d.gsz[gq];
+  }
   for (i = 0; i < n; i++) {
     for (j = 0; j < p; j++) d.x[(size_t)j * n + i] = x[(size_t)i * p + j];
     d.y[i] = y[i];
@@ -1384,13 +1546,8 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
   a.n_always = always_len;
 
   /* group_XTX on the full data, src/path.cpp:37 -> src/utilities.cpp:153-165 (LM only) */
-  xtx = (double *)calloc((size_t)p, sizeof(double));
-  if (model_type == 1)
-    for (j = 0; j < p; j++) {
-      double s = 0.0, *c = XC(&d, j);
-      for (i = 0; i < n; i++) s += c[i] * c[i];
-      xtx[j] = s;
-    }
+  xtx = (double *)calloc((size_t)d.goff[d.N], sizeof(double));
+  if (model_type == 1) group_xtx(&d, g_full_rows, n, xtx);
 
   memset(&m, 0, sizeof(m));
   m.ic_type = ic_type;
@@ -1413,13 +1570,8 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
           m.train[k][m.n_train[k]++] = i;
       }
       m.cv_init[k] = (double *)calloc((size_t)p, sizeof(double));
-      m.cv_xtx[k] = (double *)calloc((size_t)p, sizeof(double));
-      if (model_type == 1)
-        for (j = 0; j < p; j++) {
-          double s = 0.0, *c = XC(&d, j);
-          for (i = 0; i < m.n_train[k]; i++) s += c[m.train[k][i]] * c[m.train[k][i]];
-          m.cv_xtx[k][j] = s;
-        }
+      m.cv_xtx[k] = (double *)calloc((size_t)d.goff[d.N], sizeof(double));
+      if (model_type == 1) group_xtx(&d, m.train[k], m.n_train[k], m.cv_xtx[k]);
     }
   }
 
@@ -1466,5 +1618,8 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
   free(d.w);
   free(d.x_mean);
   free(d.x_norm);
+  free(d.gidx);
+  free(d.gsz);
+  free(d.goff);
   return 0;
 }

@@ -39,6 +39,17 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
                      int always_len, double *beta_out, double *coef0_out, double *train_loss_out, double *ic_out,
                      double *lambda_out);
 
+/* As bess_oracle_run2 plus the group structure (Data::g_index, src/Data.h:59-67): g_index[g] = first column of
+ * group g, NULL = singleton groups.  Sparsity levels and always_select then count / name GROUPS; the trace stores
+ * the expanded column list of every iteration.  Cox with groups of size > 1 is not restated (returns 4). */
+int bess_oracle_run3(const double *x, int n, int p, const double *y, const double *weight, int data_type,
+                     int is_normal, int algorithm_type, int model_type, int max_iter, int path_type,
+                     int is_warm_start, int ic_type, int is_cv, int K, const int *cv_fold_id, const int *sequence,
+                     int sequence_len, const double *lambda_seq, int lambda_len, int s_min, int s_max,
+                     double lambda_min, double lambda_max, int nlambda, int powell_path, const int *g_index, int g_len,
+                     const int *always_select, int always_len, double *beta_out, double *coef0_out,
+                     double *train_loss_out, double *ic_out, double *lambda_out);
+
 /* Trace of the last bess_oracle_run (same layout as oracle/ref_harness.cpp):
  * which: 0 geta_meta (int, 4 per get_A call: l, T0, train_n, offset into a_flat)
  *        1 a_flat (int)   2 beta_flat (double)   3 coef0_calls (double)

@@ -34,6 +34,10 @@ def lib():
         _lib.bess_oracle_run.argtypes = (
             [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _I, _i]
             + [_D, _D, _D, _D])
+        _lib.bess_oracle_run3.restype = _i
+        _lib.bess_oracle_run3.argtypes = (
+            [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _d, _d, _i, _i,
+             _I, _i, _I, _i] + [_D, _D, _D, _D, _D])
         _lib.bess_oracle_run2.restype = _i
         _lib.bess_oracle_run2.argtypes = (
             [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _d, _d, _i, _i,
@@ -97,8 +101,10 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
     n, p = x.shape
     y = np.ascontiguousarray(y, dtype=np.float64)
     weight = np.ones(n) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
-    if g_index is not None and not np.array_equal(np.asarray(g_index), np.arange(p)):
-        raise ValueError("the oracle covers singleton groups only")
+    g_ptr, g_len = None, 0
+    if g_index is not None:
+        g_index = np.ascontiguousarray(g_index, dtype=np.int32)
+        g_ptr, g_len = _ip(g_index), g_index.size
     sequence = np.ascontiguousarray(sequence, dtype=np.int32)
     lambda_seq = np.ascontiguousarray(lambda_seq, dtype=np.float64)
     always_select = np.ascontiguousarray(always_select, dtype=np.int32)
@@ -112,11 +118,11 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
     ic = np.zeros(1)
     L = lib()
     lam_out = np.zeros(1)
-    rc = L.bess_oracle_run2(_dp(x), n, p, _dp(y), _dp(weight), data_type, int(is_normal), algorithm_type, model_type,
+    rc = L.bess_oracle_run3(_dp(x), n, p, _dp(y), _dp(weight), data_type, int(is_normal), algorithm_type, model_type,
                             max_iter, path_type, int(is_warm_start), ic_type, int(is_cv), K, fold_ptr, _ip(sequence),
                             sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max, lambda_min, lambda_max,
-                            nlambda, powell_path, _ip(always_select), always_select.size, _dp(beta), _dp(coef0),
-                            _dp(loss), _dp(ic), _dp(lam_out))
+                            nlambda, powell_path, g_ptr, g_len, _ip(always_select), always_select.size, _dp(beta),
+                            _dp(coef0), _dp(loss), _dp(ic), _dp(lam_out))
     if rc != 0:
         raise ValueError("bess_oracle_run rejected its arguments (code %d)" % rc)
     fits, loss_calls, ic_calls = parse_trace(L.bess_oracle_trace_size, L.bess_oracle_trace_copy_int,

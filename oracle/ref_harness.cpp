@@ -64,7 +64,10 @@ struct TracedAlgorithm : public Base {
     g_trace.geta_meta.push_back(T0);
     g_trace.geta_meta.push_back(train_n);
     g_trace.geta_meta.push_back((int)g_trace.a_flat.size());
-    for (int i = 0; i < A_out.size(); i++) g_trace.a_flat.push_back(A_out(i));
+    // store the EXPANDED column list (find_ind, src/utilities.cpp:113-130), which lines up with the coefficient
+    // vector primary_model_fit returns; for singleton groups this is A_out itself
+    Eigen::VectorXi ind = find_ind(A_out, index, gsize, (int)X.cols(), N);
+    for (int i = 0; i < ind.size(); i++) g_trace.a_flat.push_back(ind(i));
   }
 
   void primary_model_fit(Eigen::MatrixXd X, Eigen::VectorXd y, Eigen::VectorXd weights, Eigen::VectorXd &beta,
