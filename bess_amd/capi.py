@@ -39,7 +39,8 @@ class BessxError(RuntimeError):
 class Problem(ctypes.Structure):
     _fields_ = [("n", _i), ("p", _i), ("x", _D), ("x_col_major", _i), ("y", _D), ("weight", _D), ("data_type", _i),
                 ("is_normal", _i), ("model_type", _i), ("algorithm_type", _i), ("max_iter", _i),
-                ("is_warm_start", _i), ("always_select", _I), ("always_select_len", _i), ("device", _i)]
+                ("is_warm_start", _i), ("always_select", _I), ("always_select_len", _i), ("device", _i),
+                ("group_index", _I), ("group_index_len", _i)]
 
 
 class PathResult(ctypes.Structure):
@@ -160,7 +161,7 @@ class Session:
     """The state bessCpp builds (Data + Algorithm + Metric, src/bess.cpp:61-165), resident in HBM."""
 
     def __init__(self, x, y, weight=None, data_type=1, is_normal=True, model_type=1, algorithm_type=1, max_iter=20,
-                 is_warm_start=True, always_select=(), x_col_major=False, device=-1):
+                 is_warm_start=True, always_select=(), x_col_major=False, device=-1, g_index=None):
         x = np.asfortranarray(x, dtype=np.float64) if x_col_major else _f64(x)
         self.n, self.p = x.shape
         y = _f64(y).reshape(-1)
@@ -168,8 +169,13 @@ class Session:
             raise ValueError("X.shape(0) should be equal to y.size")
         w = None if weight is None else _f64(weight)
         al = _i32(always_select)
+        gi = None if g_index is None else _i32(g_index)
+        self._gsize_max = 1
+        if gi is not None and gi.size:
+            self._gsize_max = int(np.max(np.diff(np.append(gi, self.p))))
         pb = Problem(self.n, self.p, _dp(x), int(x_col_major), _dp(y), _dp(w), data_type, int(is_normal), model_type,
-                     algorithm_type, max_iter, int(is_warm_start), _ip(al), al.size, device)
+                     algorithm_type, max_iter, int(is_warm_start), _ip(al), al.size, device, _ip(gi),
+                     0 if gi is None else gi.size)
         h = _vp()
         _check(lib().bessx_session_create(ctypes.byref(h), ctypes.byref(pb)))
         self._h = h
@@ -244,17 +250,18 @@ class Session:
         L = lib()
         return self._run(lambda r: L.bessx_session_sequential_path(self._h, _ip(seq), seq.size, _dp(lam), lam.size,
                                                                    ic_type, int(is_cv), r),
-                         seq.size * lam.size, int(seq.max()) if seq.size else 1)
+                         seq.size * lam.size, min(self.p, (int(seq.max()) if seq.size else 1) * self._gsize_max))
 
     def gs_path(self, s_min, s_max, ic_type=4, is_cv=False):
         L = lib()
         return self._run(lambda r: L.bessx_session_gs_path(self._h, s_min, s_max, ic_type, int(is_cv), r),
-                         2 * (s_max - s_min + 1) + 64, max(s_max, 1))
+                         2 * (s_max - s_min + 1) + 64, min(self.p, max(s_max, 1) * self._gsize_max))
 
     def pgs_path(self, s_min, s_max, lambda_min, lambda_max, n_lambda=100, powell_path=1, ic_type=4, is_cv=False):
         L = lib()
         return self._run(lambda r: L.bessx_session_pgs_path(self._h, s_min, s_max, lambda_min, lambda_max, n_lambda,
-                                                            powell_path, ic_type, int(is_cv), r), 128, max(s_max, 1))
+                                                            powell_path, ic_type, int(is_cv), r), 128,
+                         min(self.p, max(s_max, 1) * self._gsize_max))
 
     def fit(self, T0, lam=0.0, fold=-1, init_idx=(), init_val=(), init_coef0=0.0):
         ii, iv = _i32(init_idx), _f64(init_val)

@@ -109,6 +109,17 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                                   const int *gcols, const int *idcols, int mt, const GramTask *tasks, int ntask,
                                   int rps, int nslab, double *gpart, int ntiles, double *Gt, CoxBufs cb,
                                   hipStream_t st);
+hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const double *w1, const double *w2, int N,
+                                const int *gidx, const int *gsz, const int *goff, double *mblk, double *dcol,
+                                hipStream_t st);
+hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
+                              const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
+                              double lambda, const double *beta_dense, const unsigned char *always, double *bd,
+                              hipStream_t st);
+hipError_t launch_commit_group(FitCtrl *ctrl, int slot, int T0, const int *G_new, int K, const int *cols,
+                               const double *sol, int has_intercept, int wait_chain, int *A_cur, double *b_cur,
+                               double *beta_dense, int *hist, double *hist_beta, double *hist_coef0, int hist_stride,
+                               hipStream_t st);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);

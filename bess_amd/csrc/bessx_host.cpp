@@ -90,6 +90,13 @@ struct bessx_session {
   double *logfact = nullptr;            // Poisson: sum_{j<=y_i} log j (src/poisson.cpp:27-41)
   double *Wv = nullptr, *llpart = nullptr, *bcur = nullptr, *bprev = nullptr;  // IRLS work space
   int irls_guess = 8;
+  // groups (Data::g_index / g_size, src/Data.h:59-67); grouped == some group has more than one column
+  bool grouped = false;
+  int N = 0, gmax = 1;
+  std::vector<int> gidx_h, gsz_h, goff_h;
+  int *gidx = nullptr, *gsz = nullptr, *goff = nullptr, *gcols_new = nullptr;
+  double *mblk = nullptr, *dcol = nullptr;
+  std::vector<double *> gxtx_rs;  // per row set: X_g^T diag(mask) X_g blocks (LM)
   int cox_state_rs = -1;
   int dev_state_rs = -1;                // row set of the fit whose final coefficients sit in A_cur/b_cur/beta_dense
   CoxBufs cox = {};                     // Cox work space (model_type 4 only)
@@ -198,6 +205,13 @@ static void session_free(bessx_session *s) {
   F(s->llpart);
   F(s->bcur);
   F(s->bprev);
+  F(s->gidx);
+  F(s->gsz);
+  F(s->goff);
+  F(s->gcols_new);
+  F(s->mblk);
+  F(s->dcol);
+  for (auto q : s->gxtx_rs) F(q);
   for (auto q : s->cox_allocs) F(q);
   F(s->idcols);
   F(s->part2);
@@ -370,6 +384,9 @@ static int prepare_rowset(bessx_session *s, int rs) {
   hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->tmpv, v2, s->part_rs[rs], s->part2, nullptr, 0, s->st);
   if (e == hipSuccess) e = launch_part_sum(s->part_rs[rs], s->nrb, s->p, s->xty[rs], s->st);
   if (e == hipSuccess) e = launch_part_sum(s->part2, s->nrb, s->p, s->xtx[rs], s->st);
+  if (e == hipSuccess && s->grouped)  // group_XTX blocks, src/utilities.cpp:153-165
+    e = launch_group_moments(s->gmax, s->X, s->ld, s->n, m, nullptr, s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs],
+                             nullptr, s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("prepare_rowset: ") + hipGetErrorString(e));
   return 0;
 }
@@ -575,8 +592,184 @@ static int read_results(bessx_session *s) {
   return 0;
 }
 
+static int read_results(bessx_session *s);
+
+// --------------------------------------------------------------------------------------------
+// Group mode (some group has more than one column): Algorithm::fit with per-group sacrifices.  The host reads the
+// selected group ids back after the top-k to expand them into columns (find_ind, src/utilities.cpp:113-130), so
+// this loop synchronises twice per PDAS iteration and uses none of the speculative / cached fast paths.
+// --------------------------------------------------------------------------------------------
+static int algorithm_fit_grouped(bessx_session *s) {
+  const int T0 = s->sparsity_level, rs = s->cur_rows, fam = s->model_type;
+  const double lambda = s->lambda_level;
+  if (T0 < 1 || T0 > s->N) return fail(BESSX_ERR_ARG, "sparsity level (number of groups) outside [1, number of groups]");
+  if (fam == 4) return fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 is not built yet");
+  if (!topk_supported(s->N, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: too many groups for this sparsity level");
+  const bool glm = fam != 1;
+  // beta <- beta_init
+  const int k_init = (int)s->beta_init.idx.size();
+  if (k_init > s->cap) return fail(BESSX_ERR_ARG, "initial support too large");
+  int *st_idx = reinterpret_cast<int *>(s->stage_h);
+  double *st_val = reinterpret_cast<double *>(s->stage_h + (size_t)s->capA * sizeof(int));
+  for (int i = 0; i < k_init; i++) {
+    st_idx[i] = s->beta_init.idx[i];
+    st_val[i] = s->beta_init.val[i];
+  }
+  if (k_init) {
+    HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
+  }
+  hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur, s->b_cur,
+                                  s->beta_dense, s->p, s->hist, s->st);
+  if (e == hipSuccess) {
+    if (!glm)
+      e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
+                          s->st);
+    else
+      e = launch_glm_eta_gh(fam, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->logfact, s->ctrl, 0, s->A_cur,
+                            s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
+  }
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit begin: ") + hipGetErrorString(e));
+  s->dev_state_rs = -1;
+  s->cache[rs].valid = false;
+  const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
+  std::vector<int> G(T0), cols;
+  std::vector<std::vector<int>> cols_hist;
+  int slot = 1;
+  for (; slot <= s->max_iter; slot++) {
+    // ---- get_A: per-group sacrifices and top-k over the groups
+    if (!glm) {
+      e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], nullptr, s->part_rs[rs], nullptr, nullptr, 0, s->st);
+      if (e == hipSuccess)
+        e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->part_rs[rs], s->nrb, s->p, 1,
+                               (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st);
+    } else {
+      e = launch_group_moments(s->gmax, s->X, s->ld, s->n, s->h_rs[rs], s->r_rs[rs], s->N, s->gidx, s->gsz, s->goff,
+                               s->mblk, s->dcol, s->st);
+      if (e == hipSuccess)
+        e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->mblk, s->dcol, nullptr, 0, s->p, 0, 1.0, lambda,
+                               s->beta_dense, s->always, s->bd, s->st);
+    }
+    if (e == hipSuccess) e = launch_topk(s->bd, s->N, T0, s->A_new, s->cand, nullptr, 0, s->st);
+    if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group get_A: ") + hipGetErrorString(e));
+    HIPX(hipMemcpyAsync(G.data(), s->A_new, (size_t)T0 * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    HIPX(hipStreamSynchronize(s->st));
+    // ---- find_ind
+    cols.clear();
+    if (T0 == s->N) {
+      for (int j = 0; j < s->p; j++) cols.push_back(j);
+    } else {
+      for (int g : G)
+        for (int j = 0; j < s->gsz_h[g]; j++) cols.push_back(s->gidx_h[g] + j);
+    }
+    const int K = (int)cols.size();
+    if (K + 2 > s->capA) return fail(BESSX_ERR_ARG, "selected groups span more columns than this session's capacity");
+    cols_hist.push_back(cols);
+    HIPX(hipMemcpyAsync(s->gcols_new, cols.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice, s->st));
+    // ---- primary_model_fit on the expanded columns
+    if (!glm) {
+      const int mt = (K + 1 + 15) / 16, mp = mt * 16, ntiles = mt * (mt + 1) / 2;
+      const GramTask *tk = nullptr;
+      int ntask = 0, rps, nslab;
+      if (int rc = gram_tasks_for(s, mt, &tk, &ntask)) return rc;
+      gram_geometry(s, ntask, &rps, &nslab, ntiles);
+      e = launch_gram_cols(s->gcols_new, K, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 0, s->st);
+      if (e == hipSuccess)
+        e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, tk, ntask, nslab, s->gpart, ntiles, s->Gt,
+                        s->ctrl, slot, 0, s->st, 0);
+      if (e == hipSuccess)
+        e = mt <= 16 ? launch_chol(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info, s->ctrl,
+                                   slot, 0, s->st)
+                     : launch_chol_big(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info,
+                                       s->rdiag, s->zbig, s->ctrl, slot, 0, s->st);
+      if (e == hipSuccess)
+        e = launch_commit_group(s->ctrl, slot, T0, s->A_new, K, s->gcols_new, s->sol, 0, 0, s->A_cur, s->b_cur,
+                                s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+      if (e == hipSuccess)
+        e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
+                            s->sse, s->st);
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit: ") + hipGetErrorString(e));
+      if (int rc = read_results(s)) return rc;
+    } else {
+      int mt, mp, ntask, ntiles, rps, nslab;
+      if (int rc = glm_geometry(s, K, &mt, &mp, &ntask, &ntiles, &rps, &nslab)) return rc;
+      e = launch_gram_cols(s->gcols_new, K, mp, 1, 1, s->gcols, s->ctrl, slot, s->A_cur, 0, s->st);
+      if (e == hipSuccess) e = launch_glm_irls_begin(s->ctrl, slot, fam, K + 1, s->bcur, s->bprev, s->st);
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group irls begin: ") + hipGetErrorString(e));
+      const int tmax = fam == 2 ? 30 : 50;
+      int t = 0;
+      // the IRLS step kernels take (column list, count): hand them the expanded columns through A_new's slot
+      int *saved = s->A_new;
+      s->A_new = s->gcols_new;
+      int rc = 0;
+      while (true) {
+        int upto = std::min(tmax, t + std::max(2, s->irls_guess) - 1);
+        for (; t <= upto && rc == 0; t++) rc = enqueue_glm_irls_step(s, slot, t, K, lambda, rs);
+        if (rc) break;
+        e = launch_commit_group(s->ctrl, slot, T0, saved, K, s->gcols_new, s->bprev, 1, 1, s->A_cur, s->b_cur,
+                                s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+        if (e == hipSuccess)
+          e = launch_glm_eta_gh(fam, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->logfact, s->ctrl, slot, s->A_cur,
+                                s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
+        if (e != hipSuccess) {
+          rc = fail(BESSX_ERR_HIP, std::string("group glm tail: ") + hipGetErrorString(e));
+          break;
+        }
+        rc = read_results(s);
+        if (rc || hc->l == slot) break;
+        if (t > tmax) {
+          rc = fail(BESSX_ERR_NUMERIC, "IRLS chain did not terminate");
+          break;
+        }
+      }
+      s->A_new = saved;
+      if (rc) return rc;
+      if (hc->irls_last > 0) s->irls_guess = std::min(tmax + 1, hc->irls_last + 1);
+    }
+    if (hc->done) break;
+  }
+  if (hc->info) return fail(BESSX_ERR_NUMERIC, "non-finite value in the k x k solve (singular Gram matrix?)");
+  const int K = hc->k_cur;
+  const double *sse_h = reinterpret_cast<const double *>(s->res_h + ((unsigned char *)s->sse - s->resblk));
+  const double *b_h = reinterpret_cast<const double *>(s->res_h + ((unsigned char *)s->b_cur - s->resblk));
+  const int *a_h = reinterpret_cast<const int *>(s->res_h + ((unsigned char *)s->A_cur - s->resblk));
+  s->beta.idx.assign(a_h, a_h + K);
+  s->beta.val.assign(b_h, b_h + K);
+  s->coef0 = hc->coef0;
+  s->l = hc->done ? hc->l : s->max_iter + 1;
+  double tr = 0.0, te = 0.0;
+  for (int b = 0; b < s->n_sse_blk; b++) {
+    tr += sse_h[2 * b];
+    te += sse_h[2 * b + 1];
+  }
+  s->sse_train = tr;
+  s->sse_test = te;
+  s->n_fits += 1;
+  s->n_iters += hc->l;
+  if (s->trace.on) {
+    const int L = hc->l;
+    std::vector<double> hb((size_t)(L + 1) * s->hist_stride), hc0(L + 1);
+    HIPX(hipMemcpy(hb.data(), s->hist_beta, hb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPX(hipMemcpy(hc0.data(), s->hist_coef0, hc0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int it = 1; it <= L; it++) {
+      const std::vector<int> &cc = cols_hist[it - 1];
+      s->trace.meta.push_back(it);
+      s->trace.meta.push_back(T0);
+      s->trace.meta.push_back(s->n_train[rs]);
+      s->trace.meta.push_back((int)s->trace.a_flat.size());
+      for (size_t i = 0; i < cc.size(); i++) {
+        s->trace.a_flat.push_back(cc[i]);
+        s->trace.beta_flat.push_back(hb[(size_t)it * s->hist_stride + i]);
+      }
+      s->trace.coef0_calls.push_back(hc0[it]);
+    }
+  }
+  return 0;
+}
+
 // One Algorithm::fit with the state set by the update_* style members of the session.
 static int algorithm_fit(bessx_session *s) {
+  if (s->grouped) return algorithm_fit_grouped(s);
   const int T0 = s->sparsity_level, rs = s->cur_rows;
   const double lambda = s->lambda_level;
   if (T0 < 1 || T0 > s->cap)
@@ -762,7 +955,10 @@ static int metric_ic(bessx_session *s, int ic_type, int is_cv, double *out) {
   if (is_cv) {
     rc = metric_test_loss(s, out);
   } else {
-    double n = (double)s->n, p = (double)s->p, c = 0.0, loss = metric_train_loss_value(s);
+    // LM picks the group formula by algorithm_type (src/Metric.h:205,230), the others by g_index.size() == p
+    // (:365, :504, :624); the group formula uses log(g_num) and group_df = the sparsity level
+    const bool gf = s->model_type == 1 ? !(s->algorithm_type == 1 || s->algorithm_type == 5) : (s->N != s->p);
+    double n = (double)s->n, p = gf ? (double)s->N : (double)s->p, c = 0.0, loss = metric_train_loss_value(s);
     if (ic_type == 1) c = 2.0;
     if (ic_type == 2) c = std::log(n);
     if (ic_type == 3) c = std::log(p) * std::log(std::log(n));
@@ -1423,6 +1619,27 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   s->algorithm_type = pb->algorithm_type;
   s->max_iter = pb->max_iter;
   s->warm_start = pb->is_warm_start ? 1 : 0;
+  {
+    // groups: Data::g_index / g_size / g_num (src/Data.h:59-67)
+    const int gl = (pb->group_index && pb->group_index_len > 0) ? pb->group_index_len : p;
+    s->N = gl;
+    s->gidx_h.resize(gl);
+    s->gsz_h.resize(gl);
+    s->goff_h.resize(gl + 1);
+    s->goff_h[0] = 0;
+    for (int g = 0; g < gl; g++) {
+      const int a = pb->group_index && pb->group_index_len > 0 ? pb->group_index[g] : g;
+      const int b = g + 1 < gl ? (pb->group_index && pb->group_index_len > 0 ? pb->group_index[g + 1] : g + 1) : p;
+      if ((g == 0 && a != 0) || b <= a || b > p) return bail(fail(BESSX_ERR_ARG, "group_index must start at 0 and increase strictly"));
+      s->gidx_h[g] = a;
+      s->gsz_h[g] = b - a;
+      s->gmax = std::max(s->gmax, b - a);
+      s->goff_h[g + 1] = s->goff_h[g] + (b - a) * (b - a);
+    }
+    s->grouped = s->gmax > 1;
+    if (s->gmax > 16) return bail(fail(BESSX_ERR_UNSUPPORTED, "group sizes above 16 are not built"));
+    if (s->grouped && s->model_type == 4) return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 is not built yet"));
+  }
   s->U = n >= 4096 ? 8 : (n >= 2048 ? 4 : (n >= 1024 ? 2 : 1));
   const long rb = 128L * s->U;
   s->ld = ((long)n + rb - 1) / rb * rb;
@@ -1527,7 +1744,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     std::vector<unsigned char> fl((size_t)p, 0);
     for (int i = 0; i < pb->always_select_len; i++) {
       int a = pb->always_select[i];
-      if (a < 0 || a >= p) return bail(fail(BESSX_ERR_ARG, "always_select index out of range"));
+      if (a < 0 || a >= s->N) return bail(fail(BESSX_ERR_ARG, "always_select index out of range"));
       fl[a] = 1;
     }
     HIPT(hipMemcpy(s->always, fl.data(), (size_t)p, hipMemcpyHostToDevice));
@@ -1583,6 +1800,19 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipMemcpy(s->logfact, lf.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
   }
   s->cache.assign(1, bessx_session::RsCache());
+  if (s->grouped) {
+    HIPT(dmalloc(&s->gidx, (size_t)s->N));
+    HIPT(dmalloc(&s->gsz, (size_t)s->N));
+    HIPT(dmalloc(&s->goff, (size_t)s->N + 1));
+    HIPT(hipMemcpy(s->gidx, s->gidx_h.data(), (size_t)s->N * sizeof(int), hipMemcpyHostToDevice));
+    HIPT(hipMemcpy(s->gsz, s->gsz_h.data(), (size_t)s->N * sizeof(int), hipMemcpyHostToDevice));
+    HIPT(hipMemcpy(s->goff, s->goff_h.data(), ((size_t)s->N + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPT(dmalloc(&s->gcols_new, (size_t)s->capA));
+    HIPT(dmalloc(&s->mblk, (size_t)s->goff_h[s->N]));
+    HIPT(dmalloc(&s->dcol, (size_t)p));
+    HIPT(dmalloc(&q, (size_t)s->goff_h[s->N]));
+    s->gxtx_rs.push_back(q);
+  }
   TRY(alloc_gram_cache(s));
   HIPT(dmalloc(&s->idcols, 256));
   if (s->model_type == 4) {
@@ -1652,6 +1882,8 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     (void)hipFree(s->gcache[i].meta);
   }
   s->gcache.resize(1);
+  for (size_t i = 1; i < s->gxtx_rs.size(); i++) (void)hipFree(s->gxtx_rs[i]);
+  if (!s->gxtx_rs.empty()) s->gxtx_rs.resize(1);
   s->mask.resize(1);
   s->xtx.resize(1);
   s->xty.resize(1);
@@ -1695,6 +1927,11 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     s->part2_rs.push_back(q3);
     s->h_rs.push_back(q4);
     if (int rc = alloc_gram_cache(s)) return rc;
+    if (s->grouped) {
+      double *qg = nullptr;
+      HIPX(dmalloc(&qg, (size_t)s->goff_h[s->N]));
+      s->gxtx_rs.push_back(qg);
+    }
     s->n_train.push_back(nt);
     if (s->model_type == 1)
       if (int rc = prepare_rowset(s, k + 1)) return rc;
@@ -1838,9 +2075,7 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
   if (y_len != x_row || (weight && weight_len != x_row)) return fail(BESSX_ERR_ARG, "length of y / weight != rows of x");
   if (beta_out_len < x_col) return fail(BESSX_ERR_ARG, "beta_out too short");
   if (is_screening) return fail(BESSX_ERR_UNSUPPORTED, "screening (src/screening.cpp) is outside the hot path");
-  if (gindex_len != x_col) return fail(BESSX_ERR_UNSUPPORTED, "group selection (group size > 1) is not built yet");
-  for (int j = 0; j < gindex_len; j++)
-    if (gindex[j] != j) return fail(BESSX_ERR_UNSUPPORTED, "group selection (group size > 1) is not built yet");
+  if (!gindex || gindex_len < 1 || gindex_len > x_col) return fail(BESSX_ERR_ARG, "bad group index");
   bessx_problem pb;
   std::memset(&pb, 0, sizeof(pb));
   pb.n = x_row;
@@ -1858,6 +2093,8 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
   pb.always_select = always_select;
   pb.always_select_len = always_select_len;
   pb.device = -1;
+  pb.group_index = gindex;
+  pb.group_index_len = gindex_len;
   bessx_session *s = nullptr;
   if (int rc = bessx_session_create(&s, &pb)) return rc;
   int rc = 0;

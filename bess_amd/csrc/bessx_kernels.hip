@@ -1142,6 +1142,195 @@ __global__ void __launch_bounds__(128) k_resid_lm(const double *__restrict__ X, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Group selection (group size > 1; GroupPdas* with real groups).
+// Per group g (columns c0 .. c0+s-1): bd_g = || Phi_g beta_g + Phi_g^{-1} d_g ||^2 / s with Phi_g = sqrtm(M_g),
+//   LM:  M_g = 2 lambda I + X_g^T X_g / n_t (src/utilities.cpp:142-151), d = X^T r / n_t - 2 lambda beta
+//   GLM: M_g = X_g^T diag(h) X_g + 2 lambda I, d = X^T g - 2 lambda beta   (src/Algorithm.h:1238-1257, 1342-1361)
+// k_group_moments forms the s x s blocks (and optionally X_g^T w2) in one pass over the group's columns;
+// k_group_score takes the symmetric square root by a Jacobi eigen-decomposition, one thread per group.
+// ------------------------------------------------------------------------------------------
+constexpr int GRP_MAX = 16;  // largest group size built
+
+template <int S>
+__global__ void __launch_bounds__(256) k_group_moments(const double *__restrict__ X, long ld, int n,
+                                                       const double *__restrict__ w1, const double *__restrict__ w2,
+                                                       const int *__restrict__ gidx, const int *__restrict__ gsz,
+                                                       const int *__restrict__ goff, double *__restrict__ mblk,
+                                                       double *__restrict__ dcol) {
+  __shared__ double sm[4];
+  const int g = blockIdx.x, s = gsz[g], c0 = gidx[g];
+  double acc[S * (S + 1) / 2], dacc[S];
+#pragma unroll
+  for (int q = 0; q < S * (S + 1) / 2; q++) acc[q] = 0.0;
+#pragma unroll
+  for (int u = 0; u < S; u++) dacc[u] = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double xv[S];
+#pragma unroll
+    for (int u = 0; u < S; u++) xv[u] = u < s ? X[(size_t)(c0 + u) * ld + i] : 0.0;
+    const double a = w1 ? w1[i] : 1.0, b = w2 ? w2[i] : 0.0;
+    int q = 0;
+#pragma unroll
+    for (int u = 0; u < S; u++) {
+      const double xa = xv[u] * a;
+      dacc[u] = fma(xv[u], b, dacc[u]);
+#pragma unroll
+      for (int v = 0; v <= u; v++) {
+        acc[q] = fma(xa, xv[v], acc[q]);
+        q++;
+      }
+    }
+  }
+  int q = 0;
+#pragma unroll
+  for (int u = 0; u < S; u++) {
+    double dv = block_sum_256(dacc[u], sm);
+    if (threadIdx.x == 0 && u < s && w2 != nullptr) dcol[c0 + u] = dv;
+#pragma unroll
+    for (int v = 0; v <= u; v++) {
+      double mv = block_sum_256(acc[q++], sm);
+      if (threadIdx.x == 0 && u < s) {
+        mblk[goff[g] + v * s + u] = mv;
+        mblk[goff[g] + u * s + v] = mv;
+      }
+    }
+  }
+}
+
+// lm != 0: dcol is taken from the score-pass partials (sum over row blocks / n_t); else dcol holds X^T g already.
+__global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict__ gidx, const int *__restrict__ gsz,
+                                                    const int *__restrict__ goff, const double *__restrict__ mblk,
+                                                    const double *__restrict__ dcol, const double *__restrict__ part,
+                                                    int nrb, int p, int lm, double n_t, double lambda,
+                                                    const double *__restrict__ beta_dense,
+                                                    const unsigned char *__restrict__ always,
+                                                    double *__restrict__ bd) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= N) return;
+  const int s = gsz[g], c0 = gidx[g];
+  double a[GRP_MAX * GRP_MAX], v[GRP_MAX * GRP_MAX], dv[GRP_MAX], bv[GRP_MAX], t[GRP_MAX];
+  for (int u = 0; u < s; u++) {
+    double d;
+    if (lm) {
+      double sacc = 0.0;
+      for (int rb = 0; rb < nrb; rb++) sacc += part[(size_t)rb * p + c0 + u];
+      d = sacc / n_t;
+    } else {
+      d = dcol[c0 + u];
+    }
+    bv[u] = beta_dense[c0 + u];
+    dv[u] = d - 2.0 * lambda * bv[u];
+    t[u] = 0.0;
+    for (int w = 0; w < s; w++) {
+      double m = mblk[goff[g] + w * s + u];
+      if (lm) m = m / n_t;
+      if (u == w) m += 2.0 * lambda;
+      a[w * s + u] = m;
+      v[w * s + u] = (u == w) ? 1.0 : 0.0;
+    }
+  }
+  double res;
+  if (s == 1) {
+    const double phi = sqrt(a[0]), inv = 1.0 / phi, tt = phi * bv[0] + inv * dv[0];
+    res = tt * tt;
+  } else {
+    // cyclic Jacobi on the symmetric s x s block
+    for (int sweep = 0; sweep < 60; sweep++) {
+      double off = 0.0, dg = 0.0;
+      for (int i = 0; i < s; i++)
+        for (int j = 0; j < s; j++) {
+          double e = a[j * s + i];
+          if (i != j) off += e * e;
+          else dg += e * e;
+        }
+      if (off <= 1e-32 * dg || off == 0.0) break;
+      for (int i = 0; i < s - 1; i++)
+        for (int j = i + 1; j < s; j++) {
+          const double apq = a[j * s + i];
+          if (apq == 0.0) continue;
+          const double theta = (a[j * s + j] - a[i * s + i]) / (2.0 * apq);
+          const double tq = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(tq * tq + 1.0), sn = tq * c;
+          for (int k = 0; k < s; k++) {
+            const double akp = a[i * s + k], akq = a[j * s + k];
+            a[i * s + k] = c * akp - sn * akq;
+            a[j * s + k] = sn * akp + c * akq;
+          }
+          for (int k = 0; k < s; k++) {
+            const double apk = a[k * s + i], aqk = a[k * s + j];
+            a[k * s + i] = c * apk - sn * aqk;
+            a[k * s + j] = sn * apk + c * aqk;
+          }
+          for (int k = 0; k < s; k++) {
+            const double vkp = v[i * s + k], vkq = v[j * s + k];
+            v[i * s + k] = c * vkp - sn * vkq;
+            v[j * s + k] = sn * vkp + c * vkq;
+          }
+        }
+    }
+    for (int k = 0; k < s; k++) {
+      double pb = 0.0, pd = 0.0;
+      for (int j = 0; j < s; j++) {
+        pb += v[k * s + j] * bv[j];
+        pd += v[k * s + j] * dv[j];
+      }
+      const double sq = sqrt(a[k * s + k]), coef = sq * pb + pd / sq;
+      for (int i = 0; i < s; i++) t[i] += v[k * s + i] * coef;
+    }
+    double ss = 0.0;
+    for (int i = 0; i < s; i++) ss += t[i] * t[i];
+    res = ss / (double)s;
+  }
+  if (always != nullptr && always[g]) res = DBL_MAX;
+  bd[g] = res;
+}
+
+// commit of a group-mode iteration: history on the T0 group ids, coefficients on the K expanded columns
+__global__ void __launch_bounds__(256) k_commit_group(FitCtrl *__restrict__ ctrl, int slot, int T0,
+                                                      const int *__restrict__ G_new, int K,
+                                                      const int *__restrict__ cols, const double *__restrict__ sol,
+                                                      int has_intercept, int wait_chain, int *__restrict__ A_cur,
+                                                      double *__restrict__ b_cur, double *__restrict__ beta_dense,
+                                                      int *__restrict__ hist, double *__restrict__ hist_beta,
+                                                      double *__restrict__ hist_coef0, int hist_stride) {
+  if (ctrl->done || ctrl->l != slot - 1) return;
+  if (wait_chain && !ctrl->irls_done) return;
+  __shared__ int same_any;
+  const int l = slot, kc = ctrl->k_cur;
+  if (threadIdx.x == 0) same_any = 0;
+  for (int i = threadIdx.x; i < kc; i += 256) beta_dense[A_cur[i]] = 0.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const int a = cols[i];
+    const double b = sol[i + (has_intercept ? 1 : 0)];
+    A_cur[i] = a;
+    b_cur[i] = b;
+    beta_dense[a] = b;
+    hist_beta[(size_t)l * hist_stride + i] = b;
+  }
+  for (int i = threadIdx.x; i < T0; i += 256) hist[(size_t)l * hist_stride + i] = G_new[i];
+  __syncthreads();
+  for (int ll = 0; ll < l; ll++) {
+    int diff = 0;
+    for (int i = threadIdx.x; i < T0; i += 256) diff |= (hist[(size_t)ll * hist_stride + i] != G_new[i]);
+    diff = __syncthreads_or(diff);
+    if (!diff && threadIdx.x == 0) same_any = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (has_intercept) ctrl->coef0 = sol[0];
+    hist_coef0[l] = ctrl->coef0;
+    ctrl->k_cur = K;
+    ctrl->l = l;
+    ctrl->done = same_any;
+    ctrl->d_fresh = 0;
+    ctrl->irls_done = 0;
+    ctrl->irls_last = ctrl->irls_steps;
+    ctrl->irls_steps = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // GLM families (logistic: src/Algorithm.h:1138-1264, src/logistic.cpp:15-59; Poisson: :1266-1368).
 // FAM = 2 logistic, 3 Poisson.  Rows are handled two per thread (16-byte loads) like k_resid_lm.
 // ------------------------------------------------------------------------------------------
@@ -2271,6 +2460,44 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
     LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_cox_newton_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, k, cb.b0, (const double *)cb.u);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const double *w1, const double *w2, int N,
+                                const int *gidx, const int *gsz, const int *goff, double *mblk, double *dcol,
+                                hipStream_t st) {
+#define GM_GO(S) \
+  hipLaunchKernelGGL(k_group_moments<S>, dim3(N), dim3(256), 0, st, X, ld, n, w1, w2, gidx, gsz, goff, mblk, dcol)
+  if (smax <= 2)
+    GM_GO(2);
+  else if (smax <= 4)
+    GM_GO(4);
+  else if (smax <= 8)
+    GM_GO(8);
+  else
+    GM_GO(16);
+#undef GM_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
+                              const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
+                              double lambda, const double *beta_dense, const unsigned char *always, double *bd,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(k_group_score, dim3((N + 63) / 64), dim3(64), 0, st, N, gidx, gsz, goff, mblk, dcol, part, nrb, p,
+                     lm, n_t, lambda, beta_dense, always, bd);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_commit_group(FitCtrl *ctrl, int slot, int T0, const int *G_new, int K, const int *cols,
+                               const double *sol, int has_intercept, int wait_chain, int *A_cur, double *b_cur,
+                               double *beta_dense, int *hist, double *hist_beta, double *hist_coef0, int hist_stride,
+                               hipStream_t st) {
+  hipLaunchKernelGGL(k_commit_group, dim3(1), dim3(256), 0, st, ctrl, slot, T0, G_new, K, cols, sol, has_intercept,
+                     wait_chain, A_cur, b_cur, beta_dense, hist, hist_beta, hist_coef0, hist_stride);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -80,6 +80,10 @@ typedef struct {
   const int *always_select; /* indices kept in every active set (Algorithm::always_select), may be NULL */
   int always_select_len;
   int device;        /* HIP device ordinal, or -1 for the current device */
+  const int *group_index; /* Data::g_index (src/Data.h:59-67): first column of every group, ascending from 0; NULL or
+                             length p = every column its own group.  With groups, sparsity levels and always_select
+                             count / name GROUPS.  Group sizes up to 16; Cox needs singleton groups. */
+  int group_index_len;
 } bessx_problem;
 
 int bessx_session_create(bessx_session **out, const bessx_problem *prob);

@@ -38,9 +38,44 @@ def poisson_data(n=800, p=150, seed=5):
     return X, rng.poisson(np.exp(X @ b)).astype(float)
 
 
+def group_data(n=500, p=60, seed=7):
+    """Columns in 17 groups of sizes 1..10, correlated inside a group; three groups carry signal."""
+    rng = np.random.default_rng(seed)
+    gi = np.array([0, 3, 5, 6, 10, 15, 16, 20, 24, 30, 31, 33, 40, 45, 50, 52, 57])
+    X = rng.standard_normal((n, p))
+    for g in range(len(gi)):
+        lo, hi = gi[g], (gi[g + 1] if g + 1 < len(gi) else p)
+        X[:, lo:hi] += 0.5 * rng.standard_normal((n, 1))
+    beta = np.zeros(p)
+    beta[3:5] = [1.5, -1.0]
+    beta[20:24] = [0.8, 0.8, -0.6, 0.5]
+    beta[45:50] = 0.7
+    y = X @ beta + rng.standard_normal(n)
+    eta = np.clip(X @ beta * 0.8, -30, 30)
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float)
+    yp = rng.poisson(np.exp(np.clip(X @ beta * 0.3, -5, 3))).astype(float)
+    return X, y, yb, yp, gi
+
+
 def all_cases():
     S = _synth()
     c = {}
+    # group selection (GroupPdas*, group sizes 1..10)
+    Xg, yg, ybg, ypg, gi = group_data()
+    G = dict(algorithm_type=2, g_index=gi)
+    c["grp_lm_seq"] = (Xg, yg, dict(G, ic_type=3, sequence=np.arange(1, 9)))
+    c["grp_lm_gs"] = (Xg, yg, dict(G, ic_type=4, path_type=2, s_min=1, s_max=10))
+    c["grp_lm_l0l2"] = (Xg, yg, dict(algorithm_type=3, g_index=gi, ic_type=3, sequence=np.arange(1, 6),
+                                     lambda_seq=[0.0, 0.05]))
+    c["grp_lm_cv"] = (Xg, yg, dict(G, is_cv=True, K=4, cv_fold_id=S.make_cv_folds(500, 4), sequence=np.arange(1, 7)))
+    c["grp_lm_all"] = (Xg, yg, dict(G, ic_type=3, sequence=[len(gi)]))
+    c["grp_lm_always"] = (Xg, yg, dict(G, ic_type=3, sequence=np.arange(2, 7), always_select=[4]))
+    c["grp_logit_seq"] = (Xg, ybg, dict(G, data_type=2, model_type=2, ic_type=3, sequence=np.arange(1, 8)))
+    c["grp_logit_cv"] = (Xg, ybg, dict(G, data_type=2, model_type=2, is_cv=True, K=4,
+                                       cv_fold_id=S.make_cv_folds(500, 4), sequence=np.arange(1, 6)))
+    c["grp_poisson_seq"] = (Xg, ypg, dict(G, data_type=2, model_type=3, ic_type=3, sequence=np.arange(1, 8)))
+    c["grp_lm_powell"] = (Xg, yg, dict(algorithm_type=3, g_index=gi, ic_type=3, path_type=3, s_min=1, s_max=8,
+                                       lambda_min=0.01, lambda_max=5.0, nlambda=8, powell_path=2))
     Xp, yp = prostate()
     c["prostate_seq_gic"] = (Xp, yp, dict(ic_type=3, sequence=np.arange(1, 9)))
     c["prostate_one_k3"] = (Xp, yp, dict(ic_type=3, sequence=[3]))
@@ -99,14 +134,16 @@ def load_golden(name):
     z = np.load(os.path.join(HERE, "ref_small.npz"))
     T0, tn, ni = z[name + "/fit_T0"], z[name + "/fit_train_n"], z[name + "/fit_iters"]
     A, B, C0 = z[name + "/A_flat"], z[name + "/beta_flat"], z[name + "/coef0_flat"]
+    ilen = z[name + "/iter_len"]  # columns per iteration (= T0 for singleton groups, sum of group sizes otherwise)
     fits, off, it = [], 0, 0
     for f in range(len(T0)):
         fit = {"T0": int(T0[f]), "train_n": int(tn[f]), "iters": [], "betas": [], "coef0s": []}
         for _ in range(int(ni[f])):
-            fit["iters"].append(A[off:off + T0[f]])
-            fit["betas"].append(B[off:off + T0[f]])
+            k = int(ilen[it])
+            fit["iters"].append(A[off:off + k])
+            fit["betas"].append(B[off:off + k])
             fit["coef0s"].append(float(C0[it]))
-            off += int(T0[f])
+            off += k
             it += 1
         fits.append(fit)
     sc = z[name + "/scalars"]

@@ -32,6 +32,7 @@ def flatten(prefix, t, out):
     out[prefix + "/fit_T0"] = np.array([f["T0"] for f in fits], dtype=np.int32)
     out[prefix + "/fit_train_n"] = np.array([f["train_n"] for f in fits], dtype=np.int32)
     out[prefix + "/fit_iters"] = np.array([len(f["iters"]) for f in fits], dtype=np.int32)
+    out[prefix + "/iter_len"] = np.array([len(a) for f in fits for a in f["iters"]], dtype=np.int32)
     out[prefix + "/A_flat"] = np.concatenate([a for f in fits for a in f["iters"]]).astype(np.int32)
     out[prefix + "/beta_flat"] = np.concatenate([b for f in fits for b in f["betas"]])
     out[prefix + "/coef0_flat"] = np.array([c for f in fits for c in f["coef0s"]])

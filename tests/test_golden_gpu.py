@@ -85,6 +85,20 @@ def test_estimator_classes_readme_example(gpu):
     assert list(np.nonzero(m.beta)[0]) == [0, 1, 2, 3, 4] and abs(m.ic[0] - want["ic"]) < 1e-8
 
 
+def test_group_estimator_class(gpu):
+    """GroupPdasLm with a `group` label per column (python/bess/linear.py:238-253 turns labels into g_index)."""
+    import bess_amd
+    X, y, _, _, gi = cases.group_data()
+    want = cases.load_golden("grp_lm_seq")
+    labels = np.zeros(X.shape[1], dtype=int)
+    for g, lo in enumerate(gi):
+        labels[lo:] = g
+    m = bess_amd.GroupPdasLm(path_type="seq", sequence=list(range(1, 9)), ic_type="gic")
+    m.fit(X, y, group=labels)
+    np.testing.assert_allclose(m.beta, want["beta"], rtol=1e-6, atol=1e-12)
+    assert abs(m.ic[0] - want["ic"]) < 1e-7 * abs(want["ic"])
+
+
 def test_unsupported_and_invalid_requests_fail_loudly(gpu):
     X, y = cases.prostate()
     a = list(_pywrap_args(X, y))
@@ -94,9 +108,17 @@ def test_unsupported_and_invalid_requests_fail_loudly(gpu):
         gpu.pywrap_bess(*bad)
     assert e.value.code == 3
     bad = list(a)
-    bad[14] = np.array([0, 2, 4, 6])  # group index: groups of size 2
-    with pytest.raises(gpu.BessxError):
+    bad[14] = np.array([0, 4, 2, 6])  # group index must increase
+    with pytest.raises(gpu.BessxError) as e:
         gpu.pywrap_bess(*bad)
+    assert e.value.code == 1
+    Xw = np.random.default_rng(0).standard_normal((60, 40))
+    bad = list(_pywrap_args(Xw, Xw[:, 0]))
+    bad[14] = np.array([0, 20])  # a group of 20 columns: larger than the built maximum of 16
+    bad[16] = [1]
+    with pytest.raises(gpu.BessxError) as e:
+        gpu.pywrap_bess(*bad)
+    assert e.value.code == 3
     bad = list(a)
     bad[16] = [9]  # sparsity level > p
     with pytest.raises(gpu.BessxError) as e:

@@ -15,7 +15,7 @@ def run_gpu(capi, X, y, kw):
                      is_normal=kw.get("is_normal", True), model_type=kw.get("model_type", 1),
                      algorithm_type=kw.get("algorithm_type", 1),
                      max_iter=kw.get("max_iter", 20), is_warm_start=kw.get("is_warm_start", True),
-                     always_select=kw.get("always_select", ()))
+                     always_select=kw.get("always_select", ()), g_index=kw.get("g_index"))
     s.trace_enable(True)
     if kw.get("is_cv"):
         s.set_cv(kw["K"], kw["cv_fold_id"])
