@@ -120,6 +120,11 @@ hipError_t launch_commit_group(FitCtrl *ctrl, int slot, int T0, const int *G_new
                                const double *sol, int has_intercept, int wait_chain, int *A_cur, double *b_cur,
                                double *beta_dense, int *hist, double *hist_beta, double *hist_coef0, int hist_stride,
                                hipStream_t st);
+hipError_t launch_screen_score_lm(const double *sxy, const double *sxx, int p, const unsigned char *always,
+                                  double *score, hipStream_t st);
+hipError_t launch_screen_logit(const double *X, long ld, int n, int p, const double *y, const double *w,
+                               double *state, int *done, const unsigned char *always, double *score, hipStream_t st);
+hipError_t launch_gather_cols(const double *X, long ld, const int *A, int pnew, double *X2, hipStream_t st);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);

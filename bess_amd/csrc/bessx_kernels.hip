@@ -1984,6 +1984,87 @@ __global__ void __launch_bounds__(256) k_cox_newton_check(FitCtrl *__restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Screening (SIS), src/screening.cpp:26-105, singleton groups: marginal fit per column on the RAW data.
+//   LM:       score_j = (x_j.y / x_j.x_j)^2 from one two-accumulator score pass (k_xtv) -> k_screen_score_lm
+//   logistic: logit_fit (src/logistic.cpp:61-157): 2-parameter IRLS per column; one block per column and pass,
+//             the block also solves the 2x2 system and applies the convergence rule, so no host round trips.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_screen_score_lm(const double *__restrict__ sxy, const double *__restrict__ sxx,
+                                                         int p, const unsigned char *__restrict__ always,
+                                                         double *__restrict__ score) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  const double b = sxy[j] / sxx[j];
+  score[j] = (always != nullptr && always[j]) ? DBL_MAX : b * b;
+}
+
+// state per column: st[0..1] = beta0, st[2..3] = beta1, st[4] = ll0; done[j] != 0 once converged.
+__global__ void __launch_bounds__(256) k_screen_logit_pass(const double *__restrict__ X, long ld, int n,
+                                                           const double *__restrict__ y, const double *__restrict__ w,
+                                                           int t, double *__restrict__ state, int *__restrict__ done) {
+  const int j = blockIdx.x;
+  if (done[j]) return;
+  __shared__ double sm[4];
+  double *st = state + (size_t)j * 5;
+  const double *x = X + (size_t)j * ld;
+  const double ba = t == 0 ? st[0] : st[2], bb = t == 0 ? st[1] : st[3];
+  double ll = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, t0 = 0.0, t1 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double xi = x[i], yi = y[i], wi = w[i];
+    const double eta = ba + xi * bb, e = exp(clampv(eta, 30.0)), Pi = e / (1.0 + e);
+    ll += (yi * log(Pi) + (1.0 - yi) * log(1.0 - Pi)) * wi;
+    double W = Pi * (1.0 - Pi);
+    const double z = eta + (yi - Pi) / W;
+    W = W * wi;
+    s0 += W;
+    s1 += W * xi;
+    s2 += (W * xi) * xi;
+    t0 += W * z;
+    t1 += (W * xi) * z;
+  }
+  ll = block_sum_256(ll, sm);
+  s0 = block_sum_256(s0, sm);
+  s1 = block_sum_256(s1, sm);
+  s2 = block_sum_256(s2, sm);
+  t0 = block_sum_256(t0, sm);
+  t1 = block_sum_256(t1, sm);
+  if (threadIdx.x == 0) {
+    if (t == 0) {
+      st[4] = ll;
+    } else {
+      if (fabs(st[4] - ll) / (0.1 + fabs(ll)) < 1e-6) {
+        done[j] = 1;  // result: beta0, the iterate before the last solve
+        return;
+      }
+      st[0] = st[2];
+      st[1] = st[3];
+      st[4] = ll;
+    }
+    const double det = s0 * s2 - s1 * s1;
+    st[2] = (s2 * t0 - s1 * t1) / det;
+    st[3] = (s0 * t1 - s1 * t0) / det;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_screen_score_logit(const double *__restrict__ state, int p,
+                                                            const unsigned char *__restrict__ always,
+                                                            double *__restrict__ score) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  const double b = state[(size_t)j * 5 + 1];
+  score[j] = (always != nullptr && always[j]) ? DBL_MAX : b * b;
+}
+
+// X2[:, q] = X[:, A[q]]   (x_A of src/screening.cpp:82-87)
+__global__ void __launch_bounds__(256) k_gather_cols(const double *__restrict__ X, long ld, const int *__restrict__ A,
+                                                     double *__restrict__ X2) {
+  const double *src = X + (size_t)A[blockIdx.y] * ld;
+  double *dst = X2 + (size_t)blockIdx.y * ld;
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i < ld) *reinterpret_cast<d2 *>(dst + i) = *reinterpret_cast<const d2 *>(src + i);
+}
+
 // column sums of squares / cross products on a masked row set: out[j] = sum_i m_i x_ij^2 (xtx) --
 // group_XTX for 1x1 groups (src/utilities.cpp:153-165, src/Metric.h:108-129) -- via k_xtv with
 // v2 = mask; and X^T (m*y) via k_xtv with v = m*y.  Helper: v_out = a * b elementwise (or copy).
@@ -2498,6 +2579,34 @@ hipError_t launch_commit_group(FitCtrl *ctrl, int slot, int T0, const int *G_new
                                hipStream_t st) {
   hipLaunchKernelGGL(k_commit_group, dim3(1), dim3(256), 0, st, ctrl, slot, T0, G_new, K, cols, sol, has_intercept,
                      wait_chain, A_cur, b_cur, beta_dense, hist, hist_beta, hist_coef0, hist_stride);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_screen_score_lm(const double *sxy, const double *sxx, int p, const unsigned char *always,
+                                  double *score, hipStream_t st) {
+  hipLaunchKernelGGL(k_screen_score_lm, dim3((p + 255) / 256), dim3(256), 0, st, sxy, sxx, p, always, score);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_screen_logit(const double *X, long ld, int n, int p, const double *y, const double *w,
+                               double *state, int *done, const unsigned char *always, double *score, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(state, 0, (size_t)p * 5 * sizeof(double), st);
+  if (e == hipSuccess) e = hipMemsetAsync(done, 0, (size_t)p * sizeof(int), st);
+  if (e != hipSuccess) return e;
+  for (int t = 0; t <= 30; t++) {  // the solve before the loop + 30 loop iterations (src/logistic.cpp:135-155)
+    hipLaunchKernelGGL(k_screen_logit_pass, dim3(p), dim3(256), 0, st, X, ld, n, y, w, t, state, done);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_screen_score_logit, dim3((p + 255) / 256), dim3(256), 0, st, (const double *)state, p, always,
+                     score);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_gather_cols(const double *X, long ld, const int *A, int pnew, double *X2, hipStream_t st) {
+  hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((ld / 2 + 255) / 256), pnew), dim3(256), 0, st, X, ld, A, X2);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -1422,6 +1422,128 @@ static int pgs_path(oalg *al, ometric *m, const double *xtx, int s_min, int s_ma
   return rc; /* 1: "powell end wrong" (:1298-1308) */
 }
 
+/* ------------------------------------------------------------------ screening (SIS)
+ * screening(), src/screening.cpp:26-105, for singleton groups: one marginal fit per column on the RAW data (it runs
+ * before Data::normalize, src/bess.cpp:57-61), score = coefficient^2, the screening_size best columns are kept.
+ *   LM:       least squares without intercept (colPivHouseholderQr of one column, :44)   beta = x.y / x.x
+ *   logistic: logit_fit, src/logistic.cpp:61-157 (n > p branch): IRLS with intercept, NO floor on W, returns the
+ *             iterate before the last solve
+ *   Cox:      cox_fit, src/coxph.cpp:42-109: damped Newton with step halving, clamp +-50, no ridge
+ * Poisson is not restated: poisson_fit multiplies two n-vectors as matrices (src/poisson.cpp:113), which is
+ * undefined behaviour in the reference build. */
+static double screen_logit(const double *x, const double *y, const double *w, int n) {
+  double b0[2] = {0, 0}, b1[2] = {0, 0}, ll0 = 0.0, ll1;
+  double s0, s1, s2, t0, t1, det;
+  int i, j;
+  for (j = -1; j < 30; j++) {
+    /* j == -1: the solve before the loop (:135-146) */
+    const double *b = j < 0 ? b0 : b1;
+    ll1 = 0.0;
+    s0 = s1 = s2 = t0 = t1 = 0.0;
+    for (i = 0; i < n; i++) {
+      double eta = b[0] + x[i] * b[1], e = exp(clamp30(eta)), Pi = e / (1.0 + e), W, z;
+      ll1 += (y[i] * log(Pi) + (1.0 - y[i]) * log(1.0 - Pi)) * w[i];
+      W = Pi * (1.0 - Pi);
+      z = eta + (y[i] - Pi) / W;
+      W = W * w[i];
+      s0 += W;
+      s1 += W * x[i];
+      s2 += (W * x[i]) * x[i];
+      t0 += W * z;
+      t1 += (W * x[i]) * z;
+    }
+    if (j < 0) {
+      ll0 = ll1;
+    } else {
+      if (fabs(ll0 - ll1) / (0.1 + fabs(ll1)) < 1e-6) break;
+      b0[0] = b1[0];
+      b0[1] = b1[1];
+      ll0 = ll1;
+    }
+    det = s0 * s2 - s1 * s1;
+    b1[0] = (s2 * t0 - s1 * t1) / det;
+    b1[1] = (s0 * t1 - s1 * t0) / det;
+  }
+  return b0[1];
+}
+
+static double clamp50(double v) { return v > 50 ? 50 : (v < -50 ? -50 : v); }
+
+static double screen_cox_ll(const double *x, const double *st, const double *w, int n, double b) {
+  int i;
+  double cum = 0.0, s = 0.0;
+  for (i = n - 1; i >= 0; i--) {
+    double e = exp(clamp30(x[i] * b)); /* loglik_cox clamps at +-30, src/coxph.cpp:20-30 */
+    cum = (i == n - 1) ? e : cum + e;
+    s += (log(e / cum) * st[i]) * w[i];
+  }
+  return s;
+}
+
+static double screen_cox(const double *x, const double *st, const double *w, int n) {
+  double b0 = 0.0, b1 = 0.0, ll0 = 1e5, ll1;
+  int i, l, m;
+  for (l = 1; l <= 30; l++) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, g = 0.0, h = 0.0, d;
+    for (i = n - 1; i >= 0; i--) {
+      double th = exp(clamp50(x[i] * b0)), q1;
+      a0 += th;
+      a1 += th * x[i];
+      a2 += (th * x[i]) * x[i];
+      q1 = a1 / a0;
+      g += (x[i] - q1) * (w[i] * st[i]);
+      h += (a2 / a0 - q1 * q1) * (w[i] * st[i]);
+    }
+    h = -h;
+    d = g / h;
+    m = 1;
+    b1 = b0 - 0.5 * d;
+    ll1 = screen_cox_ll(x, st, w, n, b1);
+    while (ll0 > ll1 && m < 5) {
+      m = m + 1;
+      b1 = b0 - pow(0.5, (double)m) * d;
+      ll1 = screen_cox_ll(x, st, w, n, b1);
+    }
+    if (fabs(ll0 - ll1) / fabs(0.1 + ll0) < 1e-5) break;
+    b0 = b1;
+    ll0 = ll1;
+  }
+  return b0;
+}
+
+int bess_oracle_screening(const double *x, int n, int p, const double *y, const double *weight, int model_type,
+                          int screening_size, const int *always_select, int always_len, int *screening_A) {
+  double *col = (double *)malloc((size_t)n * sizeof(double)), *score = (double *)malloc((size_t)p * sizeof(double));
+  int i, j;
+  if (model_type == 3 || screening_size < 1 || screening_size > p) {
+    free(col);
+    free(score);
+    return 1;
+  }
+  for (j = 0; j < p; j++) {
+    double b;
+    for (i = 0; i < n; i++) col[i] = x[(size_t)i * p + j];
+    if (model_type == 1) {
+      double sxy = 0.0, sxx = 0.0;
+      for (i = 0; i < n; i++) {
+        sxy += col[i] * y[i];
+        sxx += col[i] * col[i];
+      }
+      b = sxy / sxx;
+    } else if (model_type == 2) {
+      b = screen_logit(col, y, weight, n);
+    } else {
+      b = screen_cox(col, y, weight, n);
+    }
+    score[j] = b * b;
+  }
+  for (i = 0; i < always_len; i++) score[always_select[i]] = DBL_MAX;
+  bess_oracle_max_k(score, p, screening_size, screening_A);
+  free(col);
+  free(score);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ driver */
 
 /* group_XTX, src/utilities.cpp:153-165: X_g^T X_g on a row subset, one block per group */

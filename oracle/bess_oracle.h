@@ -58,6 +58,12 @@ int bess_oracle_trace_size(int which);
 void bess_oracle_trace_copy_int(int which, int *out);
 void bess_oracle_trace_copy_double(int which, double *out);
 
+/* screening(), src/screening.cpp:26-105, singleton groups, model_type 1 (LM), 2 (logistic), 4 (Cox): marginal fit
+ * per column of the raw row-major x, the screening_size columns with the largest squared coefficient (ascending
+ * indices) are written to screening_A.  Returns 1 for Poisson (undefined behaviour in the reference). */
+int bess_oracle_screening(const double *x, int n, int p, const double *y, const double *weight, int model_type,
+                          int screening_size, const int *always_select, int always_len, int *screening_A);
+
 /* Small building blocks exposed so that single HIP kernels can be checked in isolation. */
 
 /* max_k (src/utilities.cpp:179-188): indices of the k largest scores, ascending.

@@ -48,6 +48,8 @@ def lib():
         _lib.bess_oracle_trace_copy_int.argtypes = [_i, _I]
         _lib.bess_oracle_trace_copy_double.restype = None
         _lib.bess_oracle_trace_copy_double.argtypes = [_i, _D]
+        _lib.bess_oracle_screening.restype = _i
+        _lib.bess_oracle_screening.argtypes = [_D, _i, _i, _D, _D, _i, _i, _I, _i, _I]
         _lib.bess_oracle_max_k.restype = None
         _lib.bess_oracle_max_k.argtypes = [_D, _i, _i, _I]
         _lib.bess_oracle_sym_solve.restype = _i
@@ -129,6 +131,37 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
                                              L.bess_oracle_trace_copy_double)
     return {"beta": beta, "coef0": float(coef0[0]), "train_loss": float(loss[0]), "ic": float(ic[0]),
             "lambda": float(lam_out[0]), "fits": fits, "loss_calls": loss_calls, "ic_calls": ic_calls}
+
+
+def screening(x, y, weight, model_type, screening_size, always_select=()):
+    """screening(), src/screening.cpp:26-105: indices of the kept columns (ascending)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n, p = x.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    w = np.ones(n) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+    al = np.ascontiguousarray(always_select, dtype=np.int32)
+    out = np.zeros(screening_size, dtype=np.int32)
+    rc = lib().bess_oracle_screening(_dp(x), n, p, _dp(y), _dp(w), model_type, screening_size, _ip(al), al.size,
+                                     _ip(out))
+    if rc != 0:
+        raise ValueError("bess_oracle_screening rejected its arguments")
+    return out
+
+
+def trace_screened(x, y, screening_size, **kw):
+    """bessCpp with is_screening (src/bess.cpp:57-61, 186-209): screen, run the path on the kept columns, scatter
+    the coefficients back.  always_select is re-indexed like src/screening.cpp:90-102."""
+    A = screening(x, y, kw.get("weight"), kw.get("model_type", 1), screening_size, kw.get("always_select", ()))
+    kw = dict(kw)
+    if len(kw.get("always_select", ())):
+        kw["always_select"] = [int(np.where(A == a)[0][0]) for a in kw["always_select"]]
+    t = trace(np.ascontiguousarray(np.asarray(x)[:, A]), y, **kw)
+    beta = np.zeros(np.asarray(x).shape[1])
+    beta[A] = t["beta"]
+    t["beta_screened"] = t["beta"]
+    t["beta"] = beta
+    t["screening_A"] = A
+    return t
 
 
 def max_k(score, k):

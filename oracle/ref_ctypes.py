@@ -44,6 +44,8 @@ def lib():
         _lib.bess_ref_trace2.argtypes = (
             [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _d, _d, _i, _i,
              _I, _i, _I, _i] + [_D, _D, _D, _D, _D])
+        _lib.bess_ref_screening.restype = _i
+        _lib.bess_ref_screening.argtypes = [_D, _i, _i, _D, _D, _i, _i, _I, _i, _I]
         _lib.bess_ref_trace_size.restype = _i
         _lib.bess_ref_trace_size.argtypes = [_i]
         _lib.bess_ref_trace_copy_int.restype = None
@@ -150,3 +152,15 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
         fits[-1]["coef0s"].append(float(coef0_calls[c]))
     return {"beta": beta, "coef0": float(coef0[0]), "train_loss": float(loss[0]), "ic": float(ic[0]),
             "lambda": float(lam_out[0]), "fits": fits, "loss_calls": getd(4), "ic_calls": getd(5)}
+
+
+def screening(x, y, weight, model_type, screening_size, always_select=()):
+    """The reference's screening() (src/screening.cpp:26-105): kept column indices."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n, p = x.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    w = np.ones(n) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+    al = np.ascontiguousarray(always_select, dtype=np.int32)
+    out = np.zeros(screening_size, dtype=np.int32)
+    lib().bess_ref_screening(_dp(x), n, p, _dp(y), _dp(w), model_type, screening_size, _ip(al), al.size, _ip(out))
+    return out

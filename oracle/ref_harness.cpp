@@ -33,6 +33,7 @@
 #include "path.h"
 #include "utilities.h"
 #include "bess.h"
+#include "screening.h"
 
 namespace {
 
@@ -247,6 +248,25 @@ int bess_ref_trace2(const double *x, int n, int p, const double *y, const double
   *ic_out = ic;
   delete algorithm;
   delete metric;
+  return 0;
+}
+
+// The reference's screening() alone (src/screening.cpp:26-105): returns the kept column indices.
+int bess_ref_screening(const double *x, int n, int p, const double *y, const double *weight, int model_type,
+                       int screening_size, const int *always_select, int always_len, int *screening_A) {
+  Eigen::MatrixXd X(n, p);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < p; j++) X(i, j) = x[(size_t)i * p + j];
+  Eigen::VectorXd Y(n), W(n);
+  for (int i = 0; i < n; i++) {
+    Y(i) = y[i];
+    W(i) = weight[i];
+  }
+  Eigen::VectorXi G(p), AS(always_len);
+  for (int j = 0; j < p; j++) G(j) = j;
+  for (int i = 0; i < always_len; i++) AS(i) = always_select[i];
+  Eigen::VectorXi A = screening(X, Y, W, model_type, screening_size, G, AS);
+  for (int i = 0; i < A.size(); i++) screening_A[i] = A(i);
   return 0;
 }
 
