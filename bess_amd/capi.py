@@ -22,7 +22,7 @@ _vp = ctypes.c_void_p
 SYMBOLS = [
     "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_session_create",
     "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_sequential_path", "bessx_session_gs_path",
-    "bessx_session_pgs_path",
+    "bessx_session_pgs_path", "bessx_session_get_screening",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
@@ -40,7 +40,8 @@ class Problem(ctypes.Structure):
     _fields_ = [("n", _i), ("p", _i), ("x", _D), ("x_col_major", _i), ("y", _D), ("weight", _D), ("data_type", _i),
                 ("is_normal", _i), ("model_type", _i), ("algorithm_type", _i), ("max_iter", _i),
                 ("is_warm_start", _i), ("always_select", _I), ("always_select_len", _i), ("device", _i),
-                ("group_index", _I), ("group_index_len", _i)]
+                ("group_index", _I), ("group_index_len", _i),
+                ("is_screening", _i), ("screening_size", _i)]
 
 
 class PathResult(ctypes.Structure):
@@ -72,6 +73,8 @@ def lib():
         L.bessx_session_create.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(Problem)]
         L.bessx_session_destroy.argtypes = [_vp]
         L.bessx_session_destroy.restype = None
+        L.bessx_session_get_screening.argtypes = [_vp, _I, _i]
+        L.bessx_session_get_screening.restype = _i
         L.bessx_session_set_cv.argtypes = [_vp, _i, _I, ctypes.c_uint]
         L.bessx_session_sequential_path.argtypes = [_vp, _I, _i, _D, _i, _i, _i, ctypes.POINTER(PathResult)]
         L.bessx_session_gs_path.argtypes = [_vp, _i, _i, _i, _i, ctypes.POINTER(PathResult)]
@@ -161,7 +164,8 @@ class Session:
     """The state bessCpp builds (Data + Algorithm + Metric, src/bess.cpp:61-165), resident in HBM."""
 
     def __init__(self, x, y, weight=None, data_type=1, is_normal=True, model_type=1, algorithm_type=1, max_iter=20,
-                 is_warm_start=True, always_select=(), x_col_major=False, device=-1, g_index=None):
+                 is_warm_start=True, always_select=(), x_col_major=False, device=-1, g_index=None,
+                 is_screening=False, screening_size=0):
         x = np.asfortranarray(x, dtype=np.float64) if x_col_major else _f64(x)
         self.n, self.p = x.shape
         y = _f64(y).reshape(-1)
@@ -175,11 +179,18 @@ class Session:
             self._gsize_max = int(np.max(np.diff(np.append(gi, self.p))))
         pb = Problem(self.n, self.p, _dp(x), int(x_col_major), _dp(y), _dp(w), data_type, int(is_normal), model_type,
                      algorithm_type, max_iter, int(is_warm_start), _ip(al), al.size, device, _ip(gi),
-                     0 if gi is None else gi.size)
+                     0 if gi is None else gi.size, int(is_screening), int(screening_size))
         h = _vp()
         _check(lib().bessx_session_create(ctypes.byref(h), ctypes.byref(pb)))
         self._h = h
         self.K = 0
+        self.p_kept = lib().bessx_session_get_screening(h, None, 0)  # columns the session works on
+
+    def screening(self):
+        """screening_A: original column of every kept column."""
+        a = np.zeros(self.p_kept, dtype=np.int32)
+        lib().bessx_session_get_screening(self._h, _ip(a), a.size)
+        return a
 
     def close(self):
         if getattr(self, "_h", None):
@@ -216,7 +227,7 @@ class Session:
         return {"seconds": sec.value, "launches": cnt.value, "algorithmic_bytes": nb.value}
 
     def normalization(self):
-        xm, xn, ym = np.zeros(self.p), np.zeros(self.p), _d(0)
+        xm, xn, ym = np.zeros(self.p_kept), np.zeros(self.p_kept), _d(0)
         _check(lib().bessx_session_get_normalization(self._h, _dp(xm), _dp(xn), ctypes.byref(ym)))
         return xm, xn, ym.value
 

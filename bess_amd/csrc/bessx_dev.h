@@ -124,6 +124,8 @@ hipError_t launch_screen_score_lm(const double *sxy, const double *sxx, int p, c
                                   double *score, hipStream_t st);
 hipError_t launch_screen_logit(const double *X, long ld, int n, int p, const double *y, const double *w,
                                double *state, int *done, const unsigned char *always, double *score, hipStream_t st);
+hipError_t launch_screen_cox(const double *X, long ld, int n, int p, const double *st_, const double *w,
+                             const unsigned char *always, double *score, hipStream_t st);
 hipError_t launch_gather_cols(const double *X, long ld, const int *A, int pnew, double *X2, hipStream_t st);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);

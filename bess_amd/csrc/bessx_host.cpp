@@ -72,6 +72,8 @@ static constexpr int T0_CAP = 2046;  // blocked global-memory Cholesky beyond th
 using namespace bessx;
 
 struct bessx_session {
+  int p_full = 0;                 // columns of the caller's x (p = columns kept by the screening)
+  std::vector<int> screen_map;    // kept column -> original column; empty without screening
   // problem
   int n = 0, p = 0;
   long ld = 0;
@@ -1006,6 +1008,8 @@ static int run_fit(bessx_session *s, int T0, double lambda, const SparseVec &bet
   return algorithm_fit(s);
 }
 
+static inline int caller_col(const bessx_session *s, int j) { return s->screen_map.empty() ? j : s->screen_map[j]; }
+
 static void store_candidate(bessx_session *s, bessx_path_result *res, const Candidate &c, bool gs_variant) {
   int i = res->n_candidates++;
   if (i >= res->capacity) return;
@@ -1020,7 +1024,7 @@ static void store_candidate(bessx_session *s, bessx_path_result *res, const Cand
   if (res->cand_coef0) res->cand_coef0[i] = c0;
   for (int j = 0; j < res->max_T0; j++) {
     bool has = j < (int)b.idx.size();
-    if (res->cand_support) res->cand_support[(size_t)i * res->max_T0 + j] = has ? b.idx[j] : -1;
+    if (res->cand_support) res->cand_support[(size_t)i * res->max_T0 + j] = has ? caller_col(s, b.idx[j]) : -1;
     if (res->cand_beta) res->cand_beta[(size_t)i * res->max_T0 + j] = has ? b.val[j] : 0.0;
   }
 }
@@ -1030,8 +1034,8 @@ static void store_best(bessx_session *s, bessx_path_result *res, const Candidate
   double c0 = c.coef0;
   denormalize(s, b, c0, gs_variant);
   if (res->beta) {
-    std::fill(res->beta, res->beta + s->p, 0.0);
-    for (size_t i = 0; i < b.idx.size(); i++) res->beta[b.idx[i]] = b.val[i];
+    std::fill(res->beta, res->beta + s->p_full, 0.0);  // beta_screening_A of src/bess.cpp:186-197
+    for (size_t i = 0; i < b.idx.size(); i++) res->beta[caller_col(s, b.idx[i])] = b.val[i];
   }
   res->coef0 = c0;
   res->train_loss = c.loss;
@@ -1610,9 +1614,115 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   } while (0)
   HIPT(hipSetDevice(dev));
   HIPT(hipStreamCreate(&s->st));
-  const int n = pb->n, p = pb->p;
+  const int n = pb->n;
   s->n = n;
-  s->p = p;
+  s->p = pb->p;
+  s->p_full = pb->p;
+  s->U = n >= 4096 ? 8 : (n >= 2048 ? 4 : (n >= 1024 ? 2 : 1));
+  const long rb = 128L * s->U;
+  s->ld = ((long)n + rb - 1) / rb * rb;
+  s->nrb = (int)(s->ld / rb);
+  const long ld = s->ld;
+  std::vector<int> always_sel;
+  for (int i = 0; i < pb->always_select_len; i++) always_sel.push_back(pb->always_select[i]);
+  bool x_ready = false;
+  if (pb->is_screening) {
+    // screening(), src/screening.cpp:26-105, before anything else touches the data (src/bess.cpp:57-61)
+    const int pf = pb->p, ss = pb->screening_size;
+    if (pb->group_index && pb->group_index_len > 0 && pb->group_index_len != pf)
+      return bail(fail(BESSX_ERR_UNSUPPORTED, "screening with groups of size > 1 is not built"));
+    if (pb->model_type == 3)
+      return bail(fail(BESSX_ERR_UNSUPPORTED, "Poisson screening: poisson_fit is undefined behaviour in the reference (src/poisson.cpp:113)"));
+    if (ss < 1 || ss > pf) return bail(fail(BESSX_ERR_ARG, "screening_size must be in 1..p"));
+    if (!topk_supported(pf, ss)) return bail(fail(BESSX_ERR_UNSUPPORTED, "screening_size too large for the top-k kernel"));
+    std::vector<unsigned char> fl((size_t)pf, 0);
+    for (int a : always_sel) {
+      if (a < 0 || a >= pf) return bail(fail(BESSX_ERR_ARG, "always_select index out of range"));
+      fl[a] = 1;
+    }
+    double *Xraw = nullptr, *yw = nullptr, *scr = nullptr;
+    int *ibuf = nullptr;
+    unsigned char *fl_d = nullptr;
+    auto drop = [&]() {
+      (void)hipFree(Xraw);
+      (void)hipFree(yw);
+      (void)hipFree(scr);
+      (void)hipFree(ibuf);
+      (void)hipFree(fl_d);
+      s->X = nullptr;
+    };
+#define HIPS(expr)                                                                            \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      drop();                                                                                 \
+      return bail(fail(BESSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)));   \
+    }                                                                                         \
+  } while (0)
+    HIPS(dmalloc(&Xraw, (size_t)ld * pf));
+    s->X = Xraw;
+    {
+      int rc = upload_x(s, pb->x, pb->x_col_major);
+      if (rc) {
+        drop();
+        return bail(rc);
+      }
+    }
+    // yw: y | weight | ones, padded with zeros;  scr: score | partial sums / per-column solver state
+    const size_t scr_len = (size_t)pf * 3 + std::max((size_t)2 * s->nrb * pf, (size_t)5 * pf);
+    HIPS(dmalloc(&yw, (size_t)ld * 3));
+    HIPS(dmalloc(&scr, scr_len));
+    HIPS(dmalloc(&ibuf, (size_t)pf + ss + 32768));
+    HIPS(dmalloc(&fl_d, (size_t)pf));
+    HIPS(hipMemcpy(fl_d, fl.data(), (size_t)pf, hipMemcpyHostToDevice));
+    {
+      std::vector<double> tmp((size_t)ld * 3, 0.0);
+      for (int i = 0; i < n; i++) {
+        tmp[i] = pb->y[i];
+        tmp[(size_t)ld + i] = pb->weight ? pb->weight[i] : 1.0;
+        tmp[(size_t)2 * ld + i] = 1.0;
+      }
+      HIPS(hipMemcpy(yw, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    double *score = scr, *sxy = scr + pf, *sxx = scr + 2 * (size_t)pf, *work = scr + 3 * (size_t)pf;
+    int *done = ibuf, *keep = ibuf + pf, *cand = ibuf + pf + ss;
+    if (pb->model_type == 1) {
+      // beta_j = x_j.y / x_j.x_j: the closed form of lm_fit on one column (src/screening.cpp:44-47), one score pass
+      HIPS(launch_xtv(Xraw, ld, pf, s->U, yw, yw + 2 * ld, work, work + (size_t)s->nrb * pf, nullptr, 0, s->st));
+      HIPS(launch_part_sum(work, s->nrb, pf, sxy, s->st));
+      HIPS(launch_part_sum(work + (size_t)s->nrb * pf, s->nrb, pf, sxx, s->st));
+      HIPS(launch_screen_score_lm(sxy, sxx, pf, fl_d, score, s->st));
+    } else if (pb->model_type == 2) {
+      HIPS(launch_screen_logit(Xraw, ld, n, pf, yw, yw + ld, work, done, fl_d, score, s->st));
+    } else {
+      HIPS(launch_screen_cox(Xraw, ld, n, pf, yw, yw + ld, fl_d, score, s->st));
+    }
+    HIPS(launch_topk(score, pf, ss, keep, cand, nullptr, 0, s->st));
+    HIPS(hipStreamSynchronize(s->st));
+    s->screen_map.assign((size_t)ss, 0);
+    HIPS(hipMemcpy(s->screen_map.data(), keep, (size_t)ss * sizeof(int), hipMemcpyDeviceToHost));
+    double *X2 = nullptr;
+    HIPS(dmalloc(&X2, (size_t)ld * ss));
+    {
+      hipError_t e = launch_gather_cols(Xraw, ld, keep, ss, X2, s->st);
+      if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+      if (e != hipSuccess) {
+        (void)hipFree(X2);
+        drop();
+        return bail(fail(BESSX_ERR_HIP, std::string("gather_cols: ") + hipGetErrorString(e)));
+      }
+    }
+    drop();
+#undef HIPS
+    s->X = X2;
+    s->p = ss;
+    x_ready = true;
+    // always_select re-indexed into the kept columns (src/screening.cpp:90-102)
+    for (int &a : always_sel) {
+      a = (int)(std::lower_bound(s->screen_map.begin(), s->screen_map.end(), a) - s->screen_map.begin());
+    }
+  }
+  const int p = s->p;
   s->data_type = pb->data_type;
   s->is_normal = pb->is_normal ? 1 : 0;
   s->model_type = pb->model_type;
@@ -1621,15 +1731,16 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   s->warm_start = pb->is_warm_start ? 1 : 0;
   {
     // groups: Data::g_index / g_size / g_num (src/Data.h:59-67)
-    const int gl = (pb->group_index && pb->group_index_len > 0) ? pb->group_index_len : p;
+    const bool have_groups = pb->group_index && pb->group_index_len > 0 && !pb->is_screening;
+    const int gl = have_groups ? pb->group_index_len : p;
     s->N = gl;
     s->gidx_h.resize(gl);
     s->gsz_h.resize(gl);
     s->goff_h.resize(gl + 1);
     s->goff_h[0] = 0;
     for (int g = 0; g < gl; g++) {
-      const int a = pb->group_index && pb->group_index_len > 0 ? pb->group_index[g] : g;
-      const int b = g + 1 < gl ? (pb->group_index && pb->group_index_len > 0 ? pb->group_index[g + 1] : g + 1) : p;
+      const int a = have_groups ? pb->group_index[g] : g;
+      const int b = g + 1 < gl ? (have_groups ? pb->group_index[g + 1] : g + 1) : p;
       if ((g == 0 && a != 0) || b <= a || b > p) return bail(fail(BESSX_ERR_ARG, "group_index must start at 0 and increase strictly"));
       s->gidx_h[g] = a;
       s->gsz_h[g] = b - a;
@@ -1640,12 +1751,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     if (s->gmax > 16) return bail(fail(BESSX_ERR_UNSUPPORTED, "group sizes above 16 are not built"));
     if (s->grouped && s->model_type == 4) return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 is not built yet"));
   }
-  s->U = n >= 4096 ? 8 : (n >= 2048 ? 4 : (n >= 1024 ? 2 : 1));
-  const long rb = 128L * s->U;
-  s->ld = ((long)n + rb - 1) / rb * rb;
-  s->nrb = (int)(s->ld / rb);
-  const long ld = s->ld;
-  HIPT(dmalloc(&s->X, (size_t)ld * p));
+  if (!x_ready) HIPT(dmalloc(&s->X, (size_t)ld * p));
   HIPT(dmalloc(&s->y, (size_t)ld));
   HIPT(dmalloc(&s->w, (size_t)ld));
   HIPT(dmalloc(&s->aux, (size_t)ld * 3));
@@ -1728,7 +1834,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   }
   static_assert(sizeof(FitCtrl) <= 128, "FitCtrl must fit its slot of the result block");
   // data
-  TRY(upload_x(s, pb->x, pb->x_col_major));
+  if (!x_ready) TRY(upload_x(s, pb->x, pb->x_col_major));
   {
     std::vector<double> tmp((size_t)ld, 0.0);
     std::copy(pb->y, pb->y + n, tmp.begin());
@@ -1742,8 +1848,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     std::fill(tmp.begin(), tmp.begin() + n, 1.0);
     HIPT(hipMemcpy(s->aux + ld, tmp.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice));
     std::vector<unsigned char> fl((size_t)p, 0);
-    for (int i = 0; i < pb->always_select_len; i++) {
-      int a = pb->always_select[i];
+    for (int a : always_sel) {
       if (a < 0 || a >= s->N) return bail(fail(BESSX_ERR_ARG, "always_select index out of range"));
       fl[a] = 1;
     }
@@ -2026,6 +2131,12 @@ int bessx_session_score_pass_stats(bessx_session *s, int reset, double *seconds,
   return BESSX_OK;
 }
 
+int bessx_session_get_screening(const bessx_session *s, int *columns, int cap) {
+  if (!s) return 0;
+  for (int j = 0; j < s->p && j < cap && columns; j++) columns[j] = caller_col(s, j);
+  return s->p;
+}
+
 int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx, const double *init_val,
                       int init_len, double init_coef0, int *support, double *beta, double *coef0, int *iters,
                       double *train_loss, double *test_loss) {
@@ -2068,13 +2179,12 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
                       double *train_loss_out, int train_loss_out_len, double *ic_out, int ic_out_len,
                       double *nullloss_out, double *aic_out, int aic_out_len, double *bic_out, int bic_out_len,
                       double *gic_out, int gic_out_len, int *A_out, int A_out_len, int *l_out) {
-  (void)exchange_num; (void)state; (void)state_len; (void)K_max; (void)epsilon; (void)screening_size;
+  (void)exchange_num; (void)state; (void)state_len; (void)K_max; (void)epsilon;
   (void)tao;  // dead on the live reference paths
   (void)coef0_out_len; (void)train_loss_out_len; (void)ic_out_len;
   if (!x || !y || !beta_out || !coef0_out || !train_loss_out || !ic_out) return fail(BESSX_ERR_ARG, "null argument");
   if (y_len != x_row || (weight && weight_len != x_row)) return fail(BESSX_ERR_ARG, "length of y / weight != rows of x");
   if (beta_out_len < x_col) return fail(BESSX_ERR_ARG, "beta_out too short");
-  if (is_screening) return fail(BESSX_ERR_UNSUPPORTED, "screening (src/screening.cpp) is outside the hot path");
   if (!gindex || gindex_len < 1 || gindex_len > x_col) return fail(BESSX_ERR_ARG, "bad group index");
   bessx_problem pb;
   std::memset(&pb, 0, sizeof(pb));
@@ -2095,6 +2205,8 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
   pb.device = -1;
   pb.group_index = gindex;
   pb.group_index_len = gindex_len;
+  pb.is_screening = is_screening ? 1 : 0;
+  pb.screening_size = screening_size;
   bessx_session *s = nullptr;
   if (int rc = bessx_session_create(&s, &pb)) return rc;
   int rc = 0;

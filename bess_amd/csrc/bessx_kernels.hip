@@ -2056,6 +2056,109 @@ __global__ void __launch_bounds__(256) k_screen_score_logit(const double *__rest
   score[j] = (always != nullptr && always[j]) ? DBL_MAX : b * b;
 }
 
+// Cox marginal fit, cox_fit (src/coxph.cpp:97-172) on one column: the whole damped Newton loop of a column runs in
+// one block; the risk-set sums are block scans over the rows taken from the last (rows are sorted by time).
+__device__ __forceinline__ double wave_scan_incl(double v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  return v;
+}
+
+__device__ double screen_cox_ll(const double *__restrict__ x, const double *__restrict__ st,
+                                const double *__restrict__ w, int n, double b, double *sm /*>=8*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double carry = 0.0, s = 0.0;
+  for (int base = 0; base < n; base += 256) {
+    const int r = base + threadIdx.x, i = n - 1 - r;
+    const double e = r < n ? exp(clampv(x[i] * b, 30.0)) : 0.0;
+    double c = wave_scan_incl(e);
+    if (lane == 63) sm[wv] = c;
+    __syncthreads();
+    double pre = carry;
+    for (int q = 0; q < wv; q++) pre += sm[q];
+    carry += ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    c += pre;
+    if (r < n) s += (log(e / c) * st[i]) * w[i];
+    __syncthreads();
+  }
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) sm[4] = s;
+  __syncthreads();
+  s = sm[4];
+  __syncthreads();
+  return s;
+}
+
+__global__ void __launch_bounds__(256) k_screen_cox(const double *__restrict__ X, long ld, int n,
+                                                    const double *__restrict__ st, const double *__restrict__ w,
+                                                    const unsigned char *__restrict__ always,
+                                                    double *__restrict__ score) {
+  const int j = blockIdx.x;
+  if (always != nullptr && always[j]) {
+    if (threadIdx.x == 0) score[j] = DBL_MAX;
+    return;
+  }
+  __shared__ double sm[16];
+  const double *x = X + (size_t)j * ld;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double b0 = 0.0, ll0 = 1e5;
+  for (int l = 1; l <= 30; l++) {
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0, g = 0.0, h = 0.0;
+    for (int base = 0; base < n; base += 256) {
+      const int r = base + threadIdx.x, i = n - 1 - r;
+      const double xi = r < n ? x[i] : 0.0;
+      const double th = r < n ? exp(clampv(xi * b0, 50.0)) : 0.0;
+      double a0 = wave_scan_incl(th), a1 = wave_scan_incl(th * xi), a2 = wave_scan_incl((th * xi) * xi);
+      if (lane == 63) {
+        sm[wv] = a0;
+        sm[4 + wv] = a1;
+        sm[8 + wv] = a2;
+      }
+      __syncthreads();
+      double p0 = c0, p1 = c1, p2 = c2;
+      for (int q = 0; q < wv; q++) {
+        p0 += sm[q];
+        p1 += sm[4 + q];
+        p2 += sm[8 + q];
+      }
+      c0 += ((sm[0] + sm[1]) + sm[2]) + sm[3];
+      c1 += ((sm[4] + sm[5]) + sm[6]) + sm[7];
+      c2 += ((sm[8] + sm[9]) + sm[10]) + sm[11];
+      a0 += p0;
+      a1 += p1;
+      a2 += p2;
+      if (r < n) {
+        const double q1 = a1 / a0, ws = w[i] * st[i];
+        g += (xi - q1) * ws;
+        h += (a2 / a0 - q1 * q1) * ws;
+      }
+      __syncthreads();
+    }
+    g = block_sum_256(g, sm);
+    h = block_sum_256(h, sm);
+    if (threadIdx.x == 0) sm[12] = g / (-h);
+    __syncthreads();
+    const double d = sm[12];
+    __syncthreads();
+    int m = 1;
+    double b1 = b0 - 0.5 * d;
+    double ll1 = screen_cox_ll(x, st, w, n, b1, sm);
+    while (ll0 > ll1 && m < 5) {
+      m = m + 1;
+      b1 = b0 - pow(0.5, (double)m) * d;
+      ll1 = screen_cox_ll(x, st, w, n, b1, sm);
+    }
+    if (fabs(ll0 - ll1) / fabs(0.1 + ll0) < 1e-5) break;
+    b0 = b1;
+    ll0 = ll1;
+  }
+  if (threadIdx.x == 0) score[j] = b0 * b0;
+}
+
 // X2[:, q] = X[:, A[q]]   (x_A of src/screening.cpp:82-87)
 __global__ void __launch_bounds__(256) k_gather_cols(const double *__restrict__ X, long ld, const int *__restrict__ A,
                                                      double *__restrict__ X2) {
@@ -2601,6 +2704,13 @@ hipError_t launch_screen_logit(const double *X, long ld, int n, int p, const dou
   }
   hipLaunchKernelGGL(k_screen_score_logit, dim3((p + 255) / 256), dim3(256), 0, st, (const double *)state, p, always,
                      score);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_screen_cox(const double *X, long ld, int n, int p, const double *st_, const double *w,
+                             const unsigned char *always, double *score, hipStream_t st) {
+  hipLaunchKernelGGL(k_screen_cox, dim3(p), dim3(256), 0, st, X, ld, n, st_, w, always, score);
   LAUNCH_CHECK();
   return hipSuccess;
 }

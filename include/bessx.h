@@ -84,10 +84,22 @@ typedef struct {
                              length p = every column its own group.  With groups, sparsity levels and always_select
                              count / name GROUPS.  Group sizes up to 16; Cox needs singleton groups. */
   int group_index_len;
+  int is_screening;   /* sure independence screening before the path (screening(), src/screening.cpp:26-105; called at
+                         src/bess.cpp:57-61): keep the screening_size columns with the largest squared marginal
+                         coefficient on the raw data plus always_select.  LM, logistic and Cox with singleton
+                         groups; Poisson is refused (the reference's poisson_fit is undefined behaviour there,
+                         src/poisson.cpp:113).  The session then lives on the kept columns: sparsity levels, traces,
+                         bessx_session_fit and bessx_session_get_normalization index them 0..screening_size-1
+                         (bessx_session_get_screening gives the map); every bessx_path_result is written in the
+                         ORIGINAL column numbering, like src/bess.cpp:186-209. */
+  int screening_size;
 } bessx_problem;
 
 int bessx_session_create(bessx_session **out, const bessx_problem *prob);
 void bessx_session_destroy(bessx_session *s);
+/* screening_A of src/screening.cpp:68: original column of every kept column (ascending).  Returns the number of
+ * kept columns (= p when the session was created without screening, map = identity); writes min(count, cap). */
+int bessx_session_get_screening(const bessx_session *s, int *columns, int cap);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)
  * gives the test fold of row i; fold_id == NULL draws a permutation from mt19937(seed) and cuts

@@ -129,6 +129,38 @@ def all_cases():
     return c
 
 
+def screening_cases():
+    """is_screening=True runs of pywrap_bess (src/bess.cpp:57-61, 186-209): name -> (X, y, screening_size, kwargs).
+    Golden: the kept columns (screening_A) and the model pywrap_bess returned, in ref_small.npz under scr/<name>/."""
+    S = _synth()
+    c = {}
+    X, y, _, _ = S.make_lm(600, 400, 8)
+    w = np.random.default_rng(2).uniform(0.5, 2, 600)
+    c["scr_lm_seq"] = (X, y, 60, dict(ic_type=3, sequence=np.arange(1, 16)))
+    c["scr_lm_gs"] = (X, y, 100, dict(ic_type=4, path_type=2, s_min=1, s_max=20))
+    c["scr_lm_always"] = (X, y, 50, dict(ic_type=3, sequence=np.arange(3, 12), always_select=[17, 399]))
+    c["scr_lm_weight"] = (X, y, 80, dict(ic_type=3, sequence=np.arange(1, 12), weight=w))
+    Xr, yr = readme_lm()
+    c["scr_readme"] = (Xr, yr, 30, dict(ic_type=4, sequence=np.arange(1, 10)))
+    X, y, _, _ = S.make_logistic(700, 300, 6)
+    L = dict(data_type=2, model_type=2)
+    c["scr_logit_seq"] = (X, y, 50, dict(L, ic_type=3, sequence=np.arange(1, 11)))
+    c["scr_logit_weight"] = (X, y, 40, dict(L, ic_type=3, sequence=np.arange(1, 9), weight=np.random.default_rng(3).uniform(0.5, 2, 700)))
+    c["scr_logit_always"] = (X, y, 30, dict(L, ic_type=3, sequence=np.arange(2, 9), always_select=[250]))
+    X, _, st, _, _ = S.make_cox(500, 200, 5)
+    C = dict(data_type=3, model_type=4)
+    c["scr_cox_seq"] = (X, st, 40, dict(C, ic_type=3, sequence=np.arange(1, 9)))
+    c["scr_cox_always"] = (X, st, 25, dict(C, ic_type=3, sequence=np.arange(2, 8), always_select=[150]))
+    return c
+
+
+def load_screening_golden(name):
+    z = np.load(os.path.join(HERE, "ref_small.npz"))
+    sc = z["scr/" + name + "/scalars"]
+    return {"A": z["scr/" + name + "/A"], "beta": z["scr/" + name + "/beta"], "coef0": float(sc[0]),
+            "train_loss": float(sc[1]), "ic": float(sc[2])}
+
+
 def load_golden(name):
     """Golden trace of one case in the same dict shape the oracle / GPU loaders return."""
     z = np.load(os.path.join(HERE, "ref_small.npz"))

@@ -5,7 +5,8 @@ Writes
   tests/golden/prostate.csv      the reference's own data set data/prostate.RData (BASELINE configs[0]) as CSV
   tests/golden/ref_small.npz     expected outputs of the reference for the cases in cases.py: the active set of
                                  every PDAS iteration of every fit, the fitted coefficients, every loss / IC value
-                                 the path function asked for, and the model it returned.
+                                 the path function asked for, and the model it returned; for the screening
+                                 cases the kept columns and the model pywrap_bess(is_screening=True) returned.
 Inputs of the synthetic cases are not stored: cases.py regenerates them from fixed seeds.
 """
 import os
@@ -51,6 +52,20 @@ def main():
         flatten(name, t, out)
         print("%-24s fits=%4d iters=%5d best ic=%.10g" % (name, len(t["fits"]), sum(len(f["iters"]) for f in t["fits"]),
                                                          t["ic"]))
+    for name, (X, y, ss, kw) in cases.screening_cases().items():
+        n, p = X.shape
+        w = kw.get("weight")
+        w = np.ones(n) if w is None else w
+        al = kw.get("always_select", [])
+        A = R.screening(X, y, w, kw.get("model_type", 1), ss, al)
+        beta, coef0, loss, ic = R.pywrap_bess(
+            X, y, kw.get("data_type", 1), w, True, 1, kw.get("model_type", 1), 20, 5, kw.get("path_type", 1), True,
+            kw.get("ic_type", 4), False, 5, np.arange(p, dtype=np.int32), [0.0], kw.get("sequence", [1]), [0.0],
+            kw.get("s_min", 1), kw.get("s_max", 1), 1, 1e-4, 0.0, 0.0, 1, True, ss, 1, al, 0.0)
+        out["scr/" + name + "/A"] = np.asarray(A, dtype=np.int32)
+        out["scr/" + name + "/beta"] = np.asarray(beta)
+        out["scr/" + name + "/scalars"] = np.array([coef0, loss, ic])
+        print("%-24s kept=%3d nnz=%2d ic=%.10g" % (name, len(A), int(np.count_nonzero(beta)), ic))
     np.savez_compressed(os.path.join(HERE, "ref_small.npz"), **out)
 
 

@@ -103,10 +103,10 @@ def test_unsupported_and_invalid_requests_fail_loudly(gpu):
     X, y = cases.prostate()
     a = list(_pywrap_args(X, y))
     bad = list(a)
-    bad[25] = True  # is_screening
+    bad[25], bad[26] = True, 9  # is_screening with screening_size > p
     with pytest.raises(gpu.BessxError) as e:
         gpu.pywrap_bess(*bad)
-    assert e.value.code == 3
+    assert e.value.code == 1
     bad = list(a)
     bad[14] = np.array([0, 4, 2, 6])  # group index must increase
     with pytest.raises(gpu.BessxError) as e:

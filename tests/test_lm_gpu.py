@@ -15,8 +15,10 @@ def run_gpu(capi, X, y, kw):
                      is_normal=kw.get("is_normal", True), model_type=kw.get("model_type", 1),
                      algorithm_type=kw.get("algorithm_type", 1),
                      max_iter=kw.get("max_iter", 20), is_warm_start=kw.get("is_warm_start", True),
-                     always_select=kw.get("always_select", ()), g_index=kw.get("g_index"))
+                     always_select=kw.get("always_select", ()), g_index=kw.get("g_index"),
+                     is_screening=kw.get("screening_size", 0) > 0, screening_size=kw.get("screening_size", 0))
     s.trace_enable(True)
+    kept = s.screening()
     if kw.get("is_cv"):
         s.set_cv(kw["K"], kw["cv_fold_id"])
     if kw.get("path_type", 1) == 1:
@@ -28,6 +30,7 @@ def run_gpu(capi, X, y, kw):
     else:
         out = s.gs_path(kw["s_min"], kw["s_max"], kw.get("ic_type", 4), kw.get("is_cv", False))
     s.close()
+    out["screening_A"] = kept
     return out
 
 

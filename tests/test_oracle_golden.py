@@ -26,6 +26,21 @@ def test_oracle_matches_golden(name):
                                [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-9, atol=1e-11)
 
 
+SCR = cases.screening_cases()
+
+
+@pytest.mark.parametrize("name", sorted(SCR))
+def test_oracle_screening_matches_golden(name):
+    """screening() + bessCpp's un-screening of beta (src/screening.cpp:26-105, src/bess.cpp:57-61, 186-209)."""
+    X, y, ss, kw = SCR[name]
+    want = cases.load_screening_golden(name)
+    got = P.trace_screened(X, y, ss, **kw)
+    assert np.array_equal(got["screening_A"], want["A"])
+    np.testing.assert_allclose(got["beta"], want["beta"], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose([got["coef0"], got["train_loss"], got["ic"]],
+                               [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-9, atol=1e-11)
+
+
 def test_known_answers_from_survey():
     """Values recorded independently in SURVEY.md section 8c (prostate, README example)."""
     g = cases.load_golden("prostate_one_k3")
