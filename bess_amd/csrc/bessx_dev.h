@@ -28,7 +28,12 @@ struct FitCtrl {
   int ls_m;        // accepted exponent m (step 0.5^m)
   double ll1;      // partial log-likelihood at the trial point
   int gram_full;   // LM Gram cache: 1 = form the whole Gram this slot, 0 = only the rows of the new columns
-  int pad2_;
+  // covariance-update mode (LM): see the k_cov_* kernels
+  int cov_nfill;   // columns (padded to a multiple of 32) whose X^T X columns this slot has to form; 0 = all cached
+  int cov_stall;   // more columns than the slot's panel launch covers: the fit is parked (l = -1 - l) until the
+                   // host has issued the larger fill
+  int cov_groups;  // 32-column panel groups (passes over X) this fit has formed so far (host statistics)
+  int cov_miss;    // internal error flag: an active column was not in the Gram column cache
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -48,7 +53,7 @@ hipError_t launch_score(const double *part, const double *part2, int nrb, int p,
                         const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
                         double *bd, const FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
-                       hipStream_t st);
+                       hipStream_t st, const int *run_flag = nullptr);
 bool topk_supported(int len, int k);
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
@@ -127,6 +132,20 @@ hipError_t launch_screen_logit(const double *X, long ld, int n, int p, const dou
 hipError_t launch_screen_cox(const double *X, long ld, int n, int p, const double *st_, const double *w,
                              const unsigned char *always, double *score, hipStream_t st);
 hipError_t launch_gather_cols(const double *X, long ld, const int *A, int pnew, double *X2, hipStream_t st);
+// covariance-update mode (LM)
+hipError_t launch_cov_need(const int *list, int len, const double *bd, double *bd2, int p, int *slot_of, int *meta,
+                           int C, int *fcols, FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
+                                int groups_cap, FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
+int cov_streamed_tiles_per_wave();
+hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
+                            const int *slot_of, double *G, int g0, int ngroups, int rows_per_slab, int nslab,
+                            double *part, const FitCtrl *ctrl, int slot, int big, hipStream_t st);
+hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
+                        const double *b_cur, double *d_out, int *meta, const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int *A_new, int T0, int mt, double *Gt,
+                           int *meta, const FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);

@@ -106,6 +106,7 @@ struct bessx_session {
   int *idcols = nullptr;
   struct RsCache {
     bool valid = false;  // part_rs / r_rs belong to exactly (beta, coef0) below
+    bool cov_layout = false;  // part_rs holds d itself (covariance mode), not row-block partial sums
     SparseVec beta;
     double coef0 = 0.0;
   };
@@ -132,6 +133,19 @@ struct bessx_session {
     int *A = nullptr, *meta = nullptr;
   };
   std::vector<GramCache> gcache;  // per row set
+  // covariance-update mode of the LM score pass (see the k_cov_* kernels): per row set a cache of p-vectors
+  // X^T diag(mask) x_a for the columns met so far
+  struct CovCache {
+    double *G = nullptr;
+    int *slot_of = nullptr, *meta = nullptr;
+  };
+  std::vector<CovCache> cov;
+  bool cov_mode = false;
+  int cov_C = 0;              // cache capacity in columns
+  int cov_rps = 0, cov_nslab = 0;
+  double *cov_part = nullptr, *bd2 = nullptr;
+  int *cov_fcols = nullptr, *cov_extras = nullptr;
+  long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
   double *Rt = nullptr;
   int *gsrc = nullptr;
   double *gpart = nullptr, *Gt = nullptr;
@@ -238,6 +252,15 @@ static void session_free(bessx_session *s) {
     F(c.A);
     F(c.meta);
   }
+  for (auto &c : s->cov) {
+    F(c.G);
+    F(c.slot_of);
+    F(c.meta);
+  }
+  F(s->cov_part);
+  F(s->bd2);
+  F(s->cov_fcols);
+  F(s->cov_extras);
   F(s->Rt);
   F(s->gsrc);
   F(s->gpart);
@@ -293,6 +316,32 @@ static int alloc_gram_cache(bessx_session *s) {
   HIPX(dmalloc(&c.meta, 2));
   HIPX(hipMemset(c.meta, 0, 2 * sizeof(int)));
   s->gcache.push_back(c);
+  return 0;
+}
+
+static constexpr int COV_R = 32;        // columns per panel group (matches the kernels)
+static constexpr int COV_SLOT_GROUPS = 2;  // groups an ordinary PDAS slot launches
+
+static int alloc_cov_cache(bessx_session *s) {
+  bessx_session::CovCache c;
+  HIPX(dmalloc(&c.G, (size_t)s->p * s->cov_C));
+  HIPX(dmalloc(&c.slot_of, (size_t)s->p));
+  HIPX(dmalloc(&c.meta, 4));
+  HIPX(hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int)));
+  HIPX(hipMemset(c.meta, 0, 4 * sizeof(int)));
+  s->cov.push_back(c);
+  return 0;
+}
+
+// forget every cached quantity that outlives a fit: a path call starts from nothing, like bessCpp
+static int reset_path_caches(bessx_session *s) {
+  for (auto &c : s->cache) c.valid = false;
+  s->dev_state_rs = -1;
+  for (auto &g : s->gcache) HIPX(hipMemsetAsync(g.meta, 0, 2 * sizeof(int), s->st));
+  for (auto &c : s->cov) {
+    HIPX(hipMemsetAsync(c.slot_of, 0xff, (size_t)s->p * sizeof(int), s->st));
+    HIPX(hipMemsetAsync(c.meta, 0, 4 * sizeof(int), s->st));
+  }
   return 0;
 }
 
@@ -460,6 +509,66 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
 // -> IRLS on [1, X_A] as a chain of (prep, check, weighted Gram, Cholesky) steps that stops itself on the
 // device -> commit -> gradient / loss pass for the new coefficients.
 // --------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------
+// LM slot in covariance-update mode: the same PDAS iteration, with X^T r taken from the cached Gram columns.
+// --------------------------------------------------------------------------------------------
+static int enqueue_cov_fill(bessx_session *s, int rs, int g0, int ngroups, int slot, int big) {
+  bessx_session::CovCache &cv = s->cov[rs];
+  hipError_t e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, cv.slot_of, cv.G, g0, ngroups,
+                                  s->cov_rps, s->cov_nslab, s->cov_part, s->ctrl, slot, big, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// solve + commit + residual of a slot whose active columns are all cached
+static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs) {
+  const int mt = (T0 + 1 + 15) / 16;
+  bessx_session::CovCache &cv = s->cov[rs];
+  hipError_t e = launch_cov_gram(cv.G, s->p, cv.slot_of, s->A_new, T0, mt, s->Gt, cv.meta, s->ctrl, slot, s->st);
+  if (e == hipSuccess) {
+    if (mt > 16)
+      e = launch_chol_big(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->rdiag, s->zbig,
+                          s->ctrl, slot, 0, s->st);
+    else
+      e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
+  }
+  if (e == hipSuccess)
+    e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+                      s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+  if (e == hipSuccess)
+    e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
+                        s->sse, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cov_tail: ") + hipGetErrorString(e));
+  return 0;
+}
+
+static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d) {
+  const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
+  bessx_session::CovCache &cv = s->cov[rs];
+  hipError_t e = hipSuccess;
+  if (!skip_d)
+    e = launch_cov_d(cv.G, s->p, cv.slot_of, s->xty[rs], s->A_cur, s->b_cur, s->part_rs[rs], cv.meta, s->ctrl, slot,
+                     s->st);
+  if (e == hipSuccess)
+    e = launch_score(s->part_rs[rs], nullptr, 1, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
+                     s->always, s->bd, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
+  // speculation needs a top-32 of the uncached scores
+  const bool spec = topk_supported(s->p, COV_R) && s->p >= 2 * COV_R;
+  if (e == hipSuccess)
+    e = launch_cov_need(s->A_new, T0, spec ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C, s->cov_fcols,
+                        s->ctrl, slot, s->st);
+  if (e == hipSuccess && spec)
+    e = launch_topk(s->bd2, s->p, COV_R, s->cov_extras, s->cand, nullptr, 0, s->st, cv.meta + 2);
+  if (e == hipSuccess)
+    e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, COV_SLOT_GROUPS, s->ctrl, slot,
+                             s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot_cov: ") + hipGetErrorString(e));
+  if (int rc = enqueue_cov_fill(s, rs, 0, COV_SLOT_GROUPS, slot, 0)) return rc;
+  return enqueue_cov_tail(s, slot, T0, lambda, rs);
+}
+
 static int glm_geometry(bessx_session *s, int T0, int *mt, int *mp, int *ntask, int *ntiles, int *rps, int *nslab) {
   *mt = (T0 + 2 + 15) / 16;  // intercept + T0 columns + the working response
   *mp = *mt * 16;
@@ -790,8 +899,11 @@ static int algorithm_fit(bessx_session *s) {
   // memory are the ones get_A would recompute (src/Algorithm.h:1109 depends only on beta, coef0 and the rows).
   bessx_session::RsCache &cc = s->cache[rs];
   // (Cox keeps its state vectors once per session, not per row set, so it only reuses within one row set.)
+  // covariance-update form of the score pass for this fit (LM; the cache must be able to hold the active set)
+  const bool cov = s->cov_mode && !glm && T0 + 2 * COV_R <= s->cov_C && k_init + 2 * COV_R <= s->cov_C;
   const bool use_cache = cc.valid && cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx &&
-                         cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs);
+                         cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs) &&
+                         (glm || cc.cov_layout == cov);
   if (cox) s->cox_state_rs = rs;
   cc.valid = false;
   hipError_t e = hipSuccess;
@@ -825,11 +937,44 @@ static int algorithm_fit(bessx_session *s) {
                             s->A_cur, s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
   }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("fit begin: ") + hipGetErrorString(e));
+  if (cov && !use_cache && k_init > 0) {
+    // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones
+    bessx_session::CovCache &cv = s->cov[rs];
+    const int ngroups = (k_init + COV_R - 1) / COV_R;
+    e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C, s->cov_fcols, s->ctrl, 0,
+                        s->st);
+    if (e == hipSuccess)
+      e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, ngroups, s->ctrl, 0, s->st);
+    if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov begin: ") + hipGetErrorString(e));
+    for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS)
+      if (int rc = enqueue_cov_fill(s, rs, g0, std::min(COV_SLOT_GROUPS, ngroups - g0), 0, 0)) return rc;
+  }
 
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
   int slot = 1, batch = 2;  // warm-started fits usually stop after 2 iterations
   std::vector<std::pair<size_t, bool>> k1_pairs;
-  while (!glm) {
+  while (!glm && cov) {
+    for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
+      if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1)) return rc;
+    if (int rc = read_results(s)) return rc;
+    if (hc->cov_stall) {
+      // the slot needs more Gram columns than its panel launch covers (cold cache): the device parked the fit
+      // (l = -1 - l); form all of them, wake it up and finish the slot
+      const int stalled = -1 - hc->l + 1, ngroups = hc->cov_nfill / COV_R;
+      for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS)
+        if (int rc = enqueue_cov_fill(s, rs, g0, std::min(COV_SLOT_GROUPS, ngroups - g0), 0, 1)) return rc;
+      HIPX(launch_cov_resume(s->ctrl, s->st));
+      if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
+      slot = stalled + 1;
+      continue;
+    }
+    if (hc->done || slot > s->max_iter) break;
+  }
+  if (cov) {
+    s->cov_panel_groups += hc->cov_groups;
+    if (hc->cov_miss) return fail(BESSX_ERR_NUMERIC, "internal error: an active column was missing from the Gram column cache");
+  }
+  while (!glm && !cov) {
     int first = slot;
     for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
       if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
@@ -887,6 +1032,7 @@ static int algorithm_fit(bessx_session *s) {
   s->sse_train = tr;
   s->sse_test = te;
   cc.valid = hc->done && hc->d_fresh;
+  cc.cov_layout = cov;
   cc.beta = s->beta;
   cc.coef0 = s->coef0;
   s->n_fits += 1;
@@ -1501,11 +1647,11 @@ static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const dou
   s->trace.clear();
   s->metric_depth = 0;
   for (auto &v : s->cv_init) v.clear();
-  for (auto &c : s->cache) c.valid = false;
   res->n_candidates = 0;
   s->n_fits = 0;
   s->n_iters = 0;
   auto t0 = std::chrono::steady_clock::now();
+  if (int rc0 = reset_path_caches(s)) return rc0;  // a path call starts cold, like a bessCpp call
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
                 : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res);
@@ -1919,6 +2065,44 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     s->gxtx_rs.push_back(q);
   }
   TRY(alloc_gram_cache(s));
+  {
+    // covariance-update mode: LM with singleton groups, unless the caller or BESSX_SCORE_MODE asks for the
+    // streaming form (1) -- 2 insists on it (error if it cannot be set up), 0 = automatic
+    int mode = pb->score_mode;
+    if (mode == 0)
+      if (const char *ev = std::getenv("BESSX_SCORE_MODE")) mode = std::atoi(ev);
+    if (mode < 0 || mode > 2) return bail(fail(BESSX_ERR_ARG, "score_mode must be 0 (auto), 1 (streaming) or 2 (covariance)"));
+    const bool eligible = s->model_type == 1 && !s->grouped;
+    if (mode == 2 && !eligible)
+      return bail(fail(BESSX_ERR_ARG, "covariance score mode exists for LM with singleton groups only"));
+    if (eligible && mode != 1) {
+      // capacity: every column if p is small, else a few active sets' worth, within 1 GiB per row set
+      long C = std::min<long>(((long)p + 31) / 32 * 32 + 2 * COV_R, 2560);
+      const long budget = ((long)1 << 30) / ((long)p * 8);
+      C = std::min(C, budget / 32 * 32);
+      if (const char *ev = std::getenv("BESSX_COV_CAP"))  // test hook: a small cache exercises the restart path
+        C = std::min<long>(C, std::max(0, std::atoi(ev)) / 32 * 32);
+      if (C >= 3 * COV_R) {
+        s->cov_mode = true;
+        s->cov_C = (int)C;
+        const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
+        long ns = std::max<long>(1, (2048 + njg - 1) / njg);
+        ns = std::min<long>(ns, std::max<long>(1, ld / 64));
+        long rps = (ld + ns - 1) / ns;
+        rps = (rps + 15) / 16 * 16;
+        ns = (ld + rps - 1) / rps;
+        s->cov_rps = (int)rps;
+        s->cov_nslab = (int)ns;
+        HIPT(dmalloc(&s->cov_part, (size_t)COV_SLOT_GROUPS * ns * njg * cov_streamed_tiles_per_wave() * 2 * 256));
+        HIPT(dmalloc(&s->bd2, (size_t)p));
+        HIPT(dmalloc(&s->cov_fcols, (size_t)s->capA + 4 * COV_R));
+        HIPT(dmalloc(&s->cov_extras, (size_t)COV_R));
+        TRY(alloc_cov_cache(s));
+      } else if (mode == 2) {
+        return bail(fail(BESSX_ERR_ARG, "covariance score mode: p too large for the Gram column cache"));
+      }
+    }
+  }
   HIPT(dmalloc(&s->idcols, 256));
   if (s->model_type == 4) {
     auto V = [&](double **dst, size_t count) -> hipError_t {
@@ -1987,6 +2171,12 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     (void)hipFree(s->gcache[i].meta);
   }
   s->gcache.resize(1);
+  for (size_t i = 1; i < s->cov.size(); i++) {
+    (void)hipFree(s->cov[i].G);
+    (void)hipFree(s->cov[i].slot_of);
+    (void)hipFree(s->cov[i].meta);
+  }
+  if (!s->cov.empty()) s->cov.resize(1);
   for (size_t i = 1; i < s->gxtx_rs.size(); i++) (void)hipFree(s->gxtx_rs[i]);
   if (!s->gxtx_rs.empty()) s->gxtx_rs.resize(1);
   s->mask.resize(1);
@@ -2032,6 +2222,8 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     s->part2_rs.push_back(q3);
     s->h_rs.push_back(q4);
     if (int rc = alloc_gram_cache(s)) return rc;
+    if (s->cov_mode)
+      if (int rc = alloc_cov_cache(s)) return rc;
     if (s->grouped) {
       double *qg = nullptr;
       HIPX(dmalloc(&qg, (size_t)s->goff_h[s->N]));

@@ -288,8 +288,9 @@ template <int EB>  // keys per thread this instance can hold (bucket of ceil(len
 __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score, const int *__restrict__ idx_in,
                                                int len_total, int chunk, int k, int *__restrict__ out,
                                                int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
-                                               int slot) {
+                                               int slot, const int *__restrict__ run_flag) {
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  if (run_flag != nullptr && *run_flag == 0) return;
   __shared__ int wcnt[2][16];
   __shared__ int wsum[16];
   __shared__ int wsum2[16];
@@ -1004,6 +1005,10 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
     ctrl->info = 0;
     ctrl->same_prev = 0;
     ctrl->d_fresh = 0;
+    ctrl->cov_nfill = 0;
+    ctrl->cov_stall = 0;
+    ctrl->cov_groups = 0;
+    ctrl->cov_miss = 0;
   }
 }
 
@@ -1020,6 +1025,10 @@ __global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl
     ctrl->info = 0;
     ctrl->same_prev = 0;
     ctrl->d_fresh = 0;
+    ctrl->cov_nfill = 0;
+    ctrl->cov_stall = 0;
+    ctrl->cov_groups = 0;
+    ctrl->cov_miss = 0;
   }
 }
 
@@ -2219,6 +2228,279 @@ __global__ void __launch_bounds__(256) k_gram_cols(const int *__restrict__ A_new
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Covariance-update form of the LM score pass.
+//
+// get_A (src/Algorithm.h:1097-1127) needs d = X^T (m (y - X_A b_A)) for ALL p columns at every PDAS iteration; the
+// streaming form (k_xtv) reads the whole of X for it.  But d = X^T(m y) - sum_{a in A} (X^T diag(m) x_a) b_a, and
+// the vectors g_a = X^T diag(m) x_a depend only on the column a and the row set.  Every row set keeps a cache
+// G[:, slot] of those p-vectors; a PDAS iteration whose active columns are all cached costs one p x |A| GEMV over
+// G (k_cov_d) and a gather of the |A| x |A| Gram for the solve (k_cov_gram) -- X is not read at all.  Missing columns
+// are formed 32 at a time by ONE pass over X on the fp64 matrix cores (k_cov_panel: X^T diag(m) X_S, S = the missing
+// columns plus the best-scoring uncached ones, which are the likeliest to enter next), so a warm-started path
+// streams X a dozen times instead of once per iteration.
+//
+//   k_cov_need       which columns of the wanted set are not cached; masked score copy for the speculation
+//   k_topk           (run only on a miss) the 32 best uncached columns
+//   k_cov_fill_list  final fill list, cache slots; parks the fit if the list exceeds what the slot's panel covers
+//   k_cov_panel      part[slab][j tile][rhs tile] = X_j^T diag(m) X_S on a row slab (MFMA f64 16x16x4)
+//   k_cov_reduce     fixed-order sum over slabs, scatter into G
+//   k_cov_d / k_cov_gram   the GEMV and the Gram gather
+// ------------------------------------------------------------------------------------------
+constexpr int COV_R = 32;   // right-hand-side columns per panel group (two MFMA tiles)
+constexpr int COV_NJ = 4;   // streamed 16-column tiles per wave
+
+__device__ __forceinline__ bool cov_gate(const FitCtrl *ctrl, int slot) {
+  if (ctrl->done) return false;
+  if (slot == 0) return ctrl->l == 0;  // start of a fit
+  return ctrl->l == slot - 1 && !ctrl->same_prev;
+}
+
+// meta: [0] columns cached, [1] missing columns of this request, [2] run flag of the speculative top-k
+__global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, int len,
+                                                  const double *__restrict__ bd, double *__restrict__ bd2, int p,
+                                                  int *__restrict__ slot_of, int *__restrict__ meta, int C,
+                                                  int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot) {
+  if (!cov_gate(ctrl, slot)) {
+    if (threadIdx.x == 0) meta[2] = 0;
+    return;
+  }
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int count = meta[0];
+  if (count + len + COV_R > C) {  // no room: start the cache over (uniform branch)
+    for (int j = tid; j < p; j += 256) slot_of[j] = -1;
+    count = 0;
+    __syncthreads();
+  }
+  int nm = 0;
+  for (int base = 0; base < len; base += 256) {
+    const int i = base + tid;
+    const int col = i < len ? list[i] : -1;
+    const int miss = (col >= 0 && slot_of[col] < 0) ? 1 : 0;
+    int inc = miss;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      off += (w < wave) ? wsum[w] : 0;
+      tot += wsum[w];
+    }
+    if (miss) fcols[nm + off + inc - 1] = col;
+    nm += tot;
+    __syncthreads();
+  }
+  const bool spec = nm > 0 && bd != nullptr;
+  if (tid == 0) {
+    meta[0] = count;
+    meta[1] = nm;
+    meta[2] = spec ? 1 : 0;
+    ctrl->cov_nfill = 0;
+    ctrl->cov_stall = 0;
+  }
+  if (spec) {
+    for (int j = tid; j < p; j += 256) bd2[j] = slot_of[j] >= 0 ? -1.0 : bd[j];
+    __syncthreads();
+    for (int i = tid; i < nm; i += 256) bd2[fcols[i]] = -1.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, const int *__restrict__ extras,
+                                                       const double *__restrict__ bd2, int *__restrict__ slot_of,
+                                                       int *__restrict__ meta, int groups_cap,
+                                                       FitCtrl *__restrict__ ctrl, int slot) {
+  if (!cov_gate(ctrl, slot)) return;
+  const int nm = meta[1];
+  if (nm == 0) return;
+  const int tid = threadIdx.x;
+  const int count = meta[0], spec = meta[2];
+  // room for speculative columns: fill up to the next multiple of 32 that leaves at least 16 of them
+  const int room = spec ? min(((nm + 16 + COV_R - 1) / COV_R) * COV_R - nm, COV_R) : 0;
+  __shared__ int s_ne;
+  if (tid < 64) {
+    const bool valid = spec && tid < COV_R && bd2[extras[tid]] >= 0.0;  // a genuine uncached column
+    const unsigned long long bal = __ballot(valid);
+    const int rank = __popcll(bal & ((1ull << tid) - 1ull));
+    if (valid && rank < room) fcols[nm + rank] = extras[tid];
+    if (tid == 0) s_ne = min((int)__popcll(bal), room);
+  }
+  __syncthreads();
+  const int tot = nm + s_ne, padded = (tot + COV_R - 1) / COV_R * COV_R;
+  for (int i = tot + tid; i < padded; i += 256) fcols[i] = -1;
+  for (int i = tid; i < tot; i += 256) slot_of[fcols[i]] = count + i;
+  if (tid == 0) {
+    meta[0] = count + tot;
+    ctrl->cov_nfill = padded;
+    ctrl->cov_groups += padded / COV_R;
+    if (padded > groups_cap * COV_R) {
+      ctrl->cov_stall = 1;
+      ctrl->l = -1 - ctrl->l;  // park: every gated kernel of this and the following slots falls through
+    }
+  }
+}
+
+__global__ void k_cov_resume(FitCtrl *__restrict__ ctrl) {
+  if (ctrl->cov_stall) {
+    ctrl->cov_stall = 0;
+    ctrl->l = -1 - ctrl->l;
+  }
+}
+
+// One wave: COV_NJ streamed tiles x 2 right-hand-side tiles on one row slab.  big = 1: issued by the host for a
+// parked fit (no slot gate), covers groups g0 .. g0+ngroups-1.
+template <bool MASKED>
+__global__ void __launch_bounds__(256) k_cov_panel(const double *__restrict__ X, const double *__restrict__ aux,
+                                                   long ld, int p, const double *__restrict__ mask,
+                                                   const int *__restrict__ fcols, int g0, int ngroups,
+                                                   int rows_per_slab, int nslab, int njg,
+                                                   double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
+                                                   int slot, int big) {
+  if (big) {
+    if (!ctrl->cov_stall) return;
+  } else {
+    if (!cov_gate(ctrl, slot) || ctrl->cov_stall) return;
+  }
+  const int nfill = ctrl->cov_nfill;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long per_group = (long)nslab * njg;
+  const int gl = (int)(wid / per_group);
+  if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
+  const int rem = (int)(wid - (long)gl * per_group);
+  const int slab = rem / njg, jg = rem - slab * njg;
+  const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+  const double *pb[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ni++) pb[ni] = gram_col(X, aux, ld, fcols[(g0 + gl) * COV_R + ni * 16 + c]) + 4 * q;
+  const double *pa[COV_NJ];
+#pragma unroll
+  for (int t = 0; t < COV_NJ; t++) {
+    const int j = (jg * COV_NJ + t) * 16 + c;
+    pa[t] = gram_col(X, aux, ld, j < p ? j : -1) + 4 * q;
+  }
+  d4 acc[COV_NJ][2];
+#pragma unroll
+  for (int t = 0; t < COV_NJ; t++) {
+    acc[t][0] = d4{0.0, 0.0, 0.0, 0.0};
+    acc[t][1] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  for (long r = r_begin; r < r_end; r += 16) {
+    double b[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+      const d2 b0 = *reinterpret_cast<const d2 *>(pb[ni] + r), b1 = *reinterpret_cast<const d2 *>(pb[ni] + r + 2);
+      b[ni][0] = b0.x;
+      b[ni][1] = b0.y;
+      b[ni][2] = b1.x;
+      b[ni][3] = b1.y;
+    }
+    if (MASKED) {
+      const d2 m0 = *reinterpret_cast<const d2 *>(mask + r + 4 * q), m1 = *reinterpret_cast<const d2 *>(mask + r + 4 * q + 2);
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++) {
+        b[ni][0] *= m0.x;
+        b[ni][1] *= m0.y;
+        b[ni][2] *= m1.x;
+        b[ni][3] *= m1.y;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < COV_NJ; t++) {
+      const d2 a0 = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pa[t] + r));
+      const d2 a1 = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pa[t] + r + 2));
+      const double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
+#pragma unroll
+      for (int ni = 0; ni < 2; ni++) {
+        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[ni][0], acc[t][ni], 0, 0, 0);
+        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b[ni][1], acc[t][ni], 0, 0, 0);
+        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b[ni][2], acc[t][ni], 0, 0, 0);
+        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b[ni][3], acc[t][ni], 0, 0, 0);
+      }
+    }
+  }
+  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
+  double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)jg * COV_NJ * 2) * 256;
+#pragma unroll
+  for (int t = 0; t < COV_NJ; t++)
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) *reinterpret_cast<d4 *>(out + (size_t)(t * 2 + ni) * 256 + lane * 4) = acc[t][ni];
+}
+
+// G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
+__global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
+                                                    int njg, int p, const int *__restrict__ fcols,
+                                                    const int *__restrict__ slot_of, double *__restrict__ G,
+                                                    const FitCtrl *__restrict__ ctrl, int slot, int big) {
+  if (big) {
+    if (!ctrl->cov_stall) return;
+  } else {
+    if (!cov_gate(ctrl, slot) || ctrl->cov_stall) return;
+  }
+  const int gl = blockIdx.y;
+  if (gl >= ngroups || (g0 + gl) * COV_R >= ctrl->cov_nfill) return;
+  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
+  const int tile = blockIdx.x, e = threadIdx.x;
+  double s = 0.0;
+  for (int sl = 0; sl < nslab; sl++) s += part[(((size_t)gl * nslab + sl) * tiles_per_slab + tile) * 256 + e];
+  const int jt = tile >> 1, ni = tile & 1, lane = e >> 2, reg = e & 3;
+  const int j = jt * 16 + (lane >> 4) + 4 * reg;
+  const int col = fcols[(g0 + gl) * COV_R + ni * 16 + (lane & 15)];
+  if (j < p && col >= 0) G[(size_t)slot_of[col] * p + j] = s;
+}
+
+// d_j = (X^T m y)_j - sum_i G[j, slot(A_i)] b_i ; 64 columns per block, the sum over i cut in 4 interleaved parts
+__global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int p, const int *__restrict__ slot_of,
+                                               const double *__restrict__ xty, const int *__restrict__ A_cur,
+                                               const double *__restrict__ b_cur, double *__restrict__ d_out,
+                                               int *__restrict__ meta, const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl->done || ctrl->l != slot - 1) return;
+  __shared__ double sm[4][64];
+  const int kc = ctrl->k_cur;
+  const int jj = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jj;
+  double acc = 0.0;
+  if (j < p)
+    for (int i = g; i < kc; i += 4) {
+      const int sl = slot_of[A_cur[i]];
+      if (sl >= 0)
+        acc += G[(size_t)sl * p + j] * b_cur[i];
+      else
+        const_cast<FitCtrl *>(ctrl)->cov_miss = 1;  // must not happen: active columns are cached before use
+    }
+  sm[g][jj] = acc;
+  __syncthreads();
+  if (g == 0 && j < p) d_out[j] = xty[j] - (((sm[0][jj] + sm[1][jj]) + sm[2][jj]) + sm[3][jj]);
+}
+
+// Gram tiles of the new active set in the layout k_chol / k_bc_* read (see k_gram_assemble)
+__global__ void __launch_bounds__(256) k_cov_gram(const double *__restrict__ G, int p,
+                                                  const int *__restrict__ slot_of, const int *__restrict__ A_new,
+                                                  int T0, double *__restrict__ Gt, int *__restrict__ meta,
+                                                  const FitCtrl *__restrict__ ctrl, int slot) {
+  if (!cov_gate(ctrl, slot)) return;
+  const int t = blockIdx.x, lane = threadIdx.x >> 2, r = threadIdx.x & 3;
+  int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= t) I++;
+  while (I * (I + 1) / 2 > t) I--;
+  const int J = t - I * (I + 1) / 2;
+  const int a = I * 16 + (lane >> 4) + 4 * r, b = J * 16 + (lane & 15);
+  double v = 0.0;
+  if (a < T0 && b < T0) {
+    const int sl = slot_of[A_new[b]];
+    if (sl >= 0)
+      v = G[(size_t)sl * p + A_new[a]];
+    else
+      const_cast<FitCtrl *>(ctrl)->cov_miss = 1;
+  }
+  Gt[(size_t)t * 256 + lane * 4 + r] = v;
+}
+
 // streaming copy used to measure the practical HBM ceiling
 __global__ void __launch_bounds__(256) k_copy(const d2 *__restrict__ src, d2 *__restrict__ dst, long n2) {
   long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -2328,11 +2610,12 @@ hipError_t launch_score(const double *part, const double *part2, int nrb, int p,
 // two-level selection: chunks of <= 32768 scores each keep their k best, a final block selects from the
 // concatenated candidates (already in ascending index order).  cand must hold nchunk*k ints.
 static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_in, int len, int chunk, int k,
-                                  int *out, const FitCtrl *ctrl, int slot, hipStream_t st) {
+                                  int *out, const FitCtrl *ctrl, int slot, hipStream_t st,
+                                  const int *run_flag = nullptr) {
   const int per = (std::min(len, chunk) + 1023) / 1024;
 #define TOPK_GO(EB)                                                                                              \
   hipLaunchKernelGGL(k_topk<EB>, dim3(nblk), dim3(1024), 0, st, score, idx_in, len, chunk, k, out, (int *)nullptr, \
-                     ctrl, slot)
+                     ctrl, slot, run_flag)
   if (per <= 2)
     TOPK_GO(2);
   else if (per <= 4)
@@ -2349,17 +2632,17 @@ static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_
 }
 
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
-                       hipStream_t st) {
+                       hipStream_t st, const int *run_flag) {
   const int chunk = 1024 * TOPK_E;
-  if (len <= chunk) return launch_topk_one(1, score, nullptr, len, chunk, k, out, ctrl, slot, st);
+  if (len <= chunk) return launch_topk_one(1, score, nullptr, len, chunk, k, out, ctrl, slot, st, run_flag);
   int nchunk = (len + chunk - 1) / chunk;
   long ncand = (long)nchunk * k;
   if (ncand > chunk || k > chunk) return hipErrorInvalidValue;  // would need a third level
   // every chunk is full except possibly the last; a short last chunk would leave holes in cand, so it
   // is only allowed when it still holds >= k scores (checked by the caller via topk_supported()).
-  hipError_t e = launch_topk_one(nchunk, score, nullptr, len, chunk, k, cand, ctrl, slot, st);
+  hipError_t e = launch_topk_one(nchunk, score, nullptr, len, chunk, k, cand, ctrl, slot, st, run_flag);
   if (e != hipSuccess) return e;
-  return launch_topk_one(1, score, cand, (int)ncand, chunk, k, out, ctrl, slot, st);
+  return launch_topk_one(1, score, cand, (int)ncand, chunk, k, out, ctrl, slot, st, run_flag);
 }
 
 bool topk_supported(int len, int k) {
@@ -2743,6 +3026,64 @@ hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int
                             int slot, const int *A_cur, int allow_skip, hipStream_t st) {
   hipLaunchKernelGGL(k_gram_cols, dim3(1), dim3(256), 0, st, A_new, T0, mp, intercept, rhs_col, cols, ctrl, slot,
                      A_cur, allow_skip);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_need(const int *list, int len, const double *bd, double *bd2, int p, int *slot_of, int *meta,
+                           int C, int *fcols, FitCtrl *ctrl, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_need, dim3(1), dim3(256), 0, st, list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
+                                int groups_cap, FitCtrl *ctrl, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_fill_list, dim3(1), dim3(256), 0, st, fcols, extras, bd2, slot_of, meta, groups_cap, ctrl,
+                     slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_resume, dim3(1), dim3(1), 0, st, ctrl);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+int cov_streamed_tiles_per_wave() { return COV_NJ; }
+
+hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
+                            const int *slot_of, double *G, int g0, int ngroups, int rows_per_slab, int nslab,
+                            double *part, const FitCtrl *ctrl, int slot, int big, hipStream_t st) {
+  const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
+  const long nwaves = (long)ngroups * nslab * njg;
+  const int nblk = (int)((nwaves + 3) / 4);
+  if (mask)
+    hipLaunchKernelGGL(k_cov_panel<true>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
+                       rows_per_slab, nslab, njg, part, ctrl, slot, big);
+  else
+    hipLaunchKernelGGL(k_cov_panel<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
+                       rows_per_slab, nslab, njg, part, ctrl, slot, big);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, (const double *)part, g0,
+                     ngroups, nslab, njg, p, fcols, slot_of, G, ctrl, slot, big);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
+                        const double *b_cur, double *d_out, int *meta, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_d, dim3((p + 63) / 64), dim3(256), 0, st, G, p, slot_of, xty, A_cur, b_cur, d_out, meta,
+                     ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int *A_new, int T0, int mt, double *Gt,
+                           int *meta, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_gram, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, G, p, slot_of, A_new, T0, Gt, meta, ctrl,
+                     slot);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -93,6 +93,11 @@ typedef struct {
                          (bessx_session_get_screening gives the map); every bessx_path_result is written in the
                          ORIGINAL column numbering, like src/bess.cpp:186-209. */
   int screening_size;
+  int score_mode;     /* how the LM score pass X^T r of get_A is evaluated: 0 = automatic
+                         (environment variable BESSX_SCORE_MODE, else covariance updates when they apply),
+                         1 = streaming: every PDAS iteration reads X once, 2 = covariance updates: cached Gram
+                         columns X^T x_a, X is read only when a new column enters.  Same results either way up to
+                         summation order. */
 } bessx_problem;
 
 int bessx_session_create(bessx_session **out, const bessx_problem *prob);

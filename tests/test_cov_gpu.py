@@ -1,0 +1,75 @@
+"""GPU: the two evaluations of the LM score pass -- streaming (score_mode 1: X is read at every PDAS iteration) and
+covariance updates (score_mode 2: cached Gram columns, X read only when a column is new) -- walk through exactly
+the same active sets as the oracle, on warm and cold paths, CV folds, a cold start that overflows a slot's panel,
+a cache small enough to be restarted, and sparsity levels beyond the register-resident solver."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import cases  # noqa: E402
+from helpers import assert_same_trace  # noqa: E402
+from test_lm_gpu import run_gpu  # noqa: E402
+from oracle import port_ctypes as P  # noqa: E402
+from bess_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = cases.all_cases()
+LM_GOLD = [n for n in sorted(GOLD) if GOLD[n][2].get("model_type", 1) == 1 and "g_index" not in GOLD[n][2]]
+
+
+def both_modes(gpu, X, y, kw, want, what):
+    out = {}
+    for mode in (1, 2):
+        got = run_gpu(gpu, X, y, dict(kw, score_mode=mode))
+        assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="%s mode %d" % (what, mode))
+        sup = np.nonzero(want["beta"])[0]
+        assert np.array_equal(np.nonzero(got["beta"])[0], sup)
+        np.testing.assert_allclose(got["beta"][sup], want["beta"][sup], rtol=1e-6)
+        np.testing.assert_allclose([got["coef0"], got["train_loss"], got["ic"]],
+                                   [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-7, atol=1e-9)
+        out[mode] = got
+    return out
+
+
+@pytest.mark.parametrize("name", LM_GOLD)
+def test_both_score_modes_match_reference_golden(gpu, name):
+    X, y, kw = GOLD[name]
+    both_modes(gpu, X, y, kw, cases.load_golden(name), name)
+
+
+def test_cold_start_overflows_the_slot_panel(gpu):
+    """No warm start at k = 100..104: the first iteration of every fit needs > 64 uncached columns."""
+    X, y, _, _ = synth.make_lm(1500, 2000, 30)
+    kw = dict(ic_type=3, sequence=[100, 101, 104], is_warm_start=False)
+    both_modes(gpu, X, y, kw, P.trace(X, y, **kw), "cold")
+
+
+def test_small_cache_is_restarted(gpu, monkeypatch):
+    X, y, _, _ = synth.make_lm(1200, 3000, 25)
+    kw = dict(ic_type=3, sequence=np.arange(1, 61))
+    want = P.trace(X, y, **kw)
+    monkeypatch.setenv("BESSX_COV_CAP", "160")
+    got = run_gpu(gpu, X, y, dict(kw, score_mode=2))
+    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="small cache")
+    kw = dict(is_cv=True, K=3, cv_fold_id=synth.make_cv_folds(1200, 3), path_type=2, s_min=1, s_max=60)
+    got = run_gpu(gpu, X, y, dict(kw, score_mode=2))
+    assert_same_trace(got["trace"], P.trace(X, y, **kw), beta_rtol=1e-6, what="small cache gs cv")
+
+
+def test_large_sparsity_levels_in_covariance_mode(gpu):
+    X, y, _, _ = synth.make_lm(3000, 1200, 40)
+    kw = dict(ic_type=3, sequence=[250, 300, 301, 420])
+    both_modes(gpu, X, y, kw, P.trace(X, y, **kw), "large k")
+
+
+def test_score_mode_argument(gpu):
+    X, y, _, _ = synth.make_logistic(300, 40, 3)
+    with pytest.raises(gpu.BessxError) as e:
+        gpu.Session(X, y, data_type=2, model_type=2, score_mode=2)
+    assert e.value.code == 1
+    with pytest.raises(gpu.BessxError) as e:
+        gpu.Session(X, y, score_mode=7)
+    assert e.value.code == 1

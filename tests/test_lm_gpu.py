@@ -16,7 +16,8 @@ def run_gpu(capi, X, y, kw):
                      algorithm_type=kw.get("algorithm_type", 1),
                      max_iter=kw.get("max_iter", 20), is_warm_start=kw.get("is_warm_start", True),
                      always_select=kw.get("always_select", ()), g_index=kw.get("g_index"),
-                     is_screening=kw.get("screening_size", 0) > 0, screening_size=kw.get("screening_size", 0))
+                     is_screening=kw.get("screening_size", 0) > 0, screening_size=kw.get("screening_size", 0),
+                     score_mode=kw.get("score_mode", 0))
     s.trace_enable(True)
     kept = s.screening()
     if kw.get("is_cv"):

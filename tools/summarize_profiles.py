@@ -1,0 +1,74 @@
+"""Turn rocprofv3 output directories (gpurun_out/, scratch) into the committed summaries under profiles/.
+
+  python tools/summarize_profiles.py stats  <dir of --kernel-trace --stats run>  profiles/<name>.csv
+  python tools/summarize_profiles.py pmc    <dir of --pmc FETCH_SIZE run> <dir of --pmc WRITE_SIZE run> \
+                                            profiles/pmc_traffic.json  [kernel substring, default k_xtv<8, 16, false]
+
+Commands the directories come from (one gpurun call, each profiler pass its own process; --pmc never together
+with the sys/hip/hsa traces):
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --kmax 20
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --kmax 20
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of a wide coalesced
+streaming read, so the fetch figure is doubled; both counters are in KB.
+"""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit("no *%s under %s" % (suffix, d))
+    return hits[0]
+
+
+def stats(src, dst):
+    rows = list(csv.reader(open(find(src, "kernel_stats.csv"))))
+    with open(dst, "w", newline="") as f:
+        csv.writer(f).writerows(rows)
+    print("wrote %s (%d kernels)" % (dst, len(rows) - 1))
+
+
+def counter_values(d, kernel, counter):
+    vals = []
+    with open(find(d, "counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    return vals
+
+
+def pmc(fetch_dir, write_dir, dst, kernel):
+    fv = counter_values(fetch_dir, kernel, "FETCH_SIZE")
+    wv = counter_values(write_dir, kernel, "WRITE_SIZE")
+    # gated launches that returned at once move (almost) nothing: keep the dispatches that streamed X
+    big = [v for v in fv if v > 0.5 * max(fv)]
+    out = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
+                  "python3 bench.py --steps 1 --warmup 0 --kmax 20",
+        "kernel": kernel,
+        "FETCH_SIZE_KB_median": statistics.median(big),
+        "WRITE_SIZE_KB_median": statistics.median([v for v in wv if v > 0.5 * max(wv)]),
+        "dispatches": len(big),
+        "correction": "gfx950: FETCH_SIZE counts half of the bytes of a wide coalesced streaming read "
+                      "(MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
+    }
+    out["k_xtv_hbm_bytes_per_launch"] = 1024.0 * (2.0 * out["FETCH_SIZE_KB_median"] + out["WRITE_SIZE_KB_median"])
+    out["algorithmic_bytes_per_launch"] = 8.0 * 50000 * 10000
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 4 and sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 5 and sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "k_xtv<8, 16, false")
+    else:
+        raise SystemExit(__doc__)
