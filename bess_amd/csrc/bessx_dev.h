@@ -29,11 +29,13 @@ struct FitCtrl {
   double ll1;      // partial log-likelihood at the trial point
   int gram_full;   // LM Gram cache: 1 = form the whole Gram this slot, 0 = only the rows of the new columns
   // covariance-update mode (LM): see the k_cov_* kernels
-  int cov_nfill;   // columns (padded to a multiple of 32) whose X^T X columns this slot has to form; 0 = all cached
-  int cov_stall;   // more columns than the slot's panel launch covers: the fit is parked (l = -1 - l) until the
-                   // host has issued the larger fill
+  int cov_nfill;   // length of the current fill list (a multiple of 32): missing + speculative columns
+  int cov_stall;   // the new active set has uncached columns: the fit is parked (l = -1 - l) until the host has
+                   // issued the fill
   int cov_groups;  // 32-column panel groups (passes over X) this fit has formed so far (host statistics)
   int cov_miss;    // internal error flag: an active column was not in the Gram column cache
+  int cov_nmiss;   // columns of the requested set that are not cached (set by k_cov_need)
+  int pad3_;
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -134,14 +136,16 @@ hipError_t launch_screen_cox(const double *X, long ld, int n, int p, const doubl
 hipError_t launch_gather_cols(const double *X, long ld, const int *A, int pnew, double *X2, hipStream_t st);
 // covariance-update mode (LM)
 hipError_t launch_cov_need(const int *list, int len, const double *bd, double *bd2, int p, int *slot_of, int *meta,
-                           int C, int *fcols, FitCtrl *ctrl, int slot, hipStream_t st);
+                           int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st);
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                int groups_cap, FitCtrl *ctrl, int slot, hipStream_t st);
+                                FitCtrl *ctrl, int parked, hipStream_t st);
 hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
 int cov_streamed_tiles_per_wave();
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
-                            const int *slot_of, double *G, int g0, int ngroups, int rows_per_slab, int nslab,
-                            double *part, const FitCtrl *ctrl, int slot, int big, hipStream_t st);
+                            int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
+                            int parked, hipStream_t st);
+hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
+                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st);
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
                         const double *b_cur, double *d_out, int *meta, const FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int *A_new, int T0, int mt, double *Gt,

@@ -146,6 +146,7 @@ struct bessx_session {
   double *cov_part = nullptr, *bd2 = nullptr;
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
+  std::vector<std::pair<size_t, int>> cov_timed;  // (event index, first group) of the timed panel launches
   double *Rt = nullptr;
   int *gsrc = nullptr;
   double *gpart = nullptr, *Gt = nullptr;
@@ -304,6 +305,24 @@ static int k1_collect(bessx_session *s, const std::vector<std::pair<size_t, bool
     s->k1_launches += 1;
     s->k1_bytes += 8.0 * (double)s->n * (double)s->p;
   }
+  s->ev_used = 0;
+  return 0;
+}
+
+// the same for the panel launches of the covariance mode: a launch covers up to 2 groups of 32 columns, each group
+// is one pass over X; nfill = length of the fill list the launches worked on
+static int cov_collect(bessx_session *s, int nfill) {
+  if (!s->timing) return 0;
+  for (auto &pr : s->cov_timed) {
+    const int real = std::min(2, std::max(0, nfill / 32 - pr.second));
+    if (real == 0) continue;
+    float ms = 0.f;
+    HIPX(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.first + 1]));
+    s->k1_seconds += (double)ms * 1e-3;
+    s->k1_launches += 1;
+    s->k1_bytes += 8.0 * (double)s->n * (double)s->p * real;
+  }
+  s->cov_timed.clear();
   s->ev_used = 0;
   return 0;
 }
@@ -512,11 +531,26 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
 // --------------------------------------------------------------------------------------------
 // LM slot in covariance-update mode: the same PDAS iteration, with X^T r taken from the cached Gram columns.
 // --------------------------------------------------------------------------------------------
-static int enqueue_cov_fill(bessx_session *s, int rs, int g0, int ngroups, int slot, int big) {
+// Form the Gram columns of the fill list, 2 groups of 32 columns per launch pair (the slab partials of a launch
+// share one work space).  parked = 1: for a parked fit, 0: start of a fit.  The panel kernel is the one kernel
+// of this mode that reads X: its launches are timed like the streaming score pass (k1_*).
+static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
   bessx_session::CovCache &cv = s->cov[rs];
-  hipError_t e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, cv.slot_of, cv.G, g0, ngroups,
-                                  s->cov_rps, s->cov_nslab, s->cov_part, s->ctrl, slot, big, s->st);
-  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
+  for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS) {
+    const int ng = std::min(COV_SLOT_GROUPS, ngroups - g0);
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (int rc = k1_begin(s, &ea, &eb)) return rc;
+    hipError_t e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, g0, ng, s->cov_rps,
+                                    s->cov_nslab, s->cov_part, s->ctrl, parked, s->st);
+    if (s->timing && e == hipSuccess) {
+      e = hipEventRecord(eb, s->st);
+      s->cov_timed.push_back({s->ev_used - 2, g0});
+    }
+    if (e == hipSuccess)
+      e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, s->ctrl, parked,
+                            s->st);
+    if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
+  }
   return 0;
 }
 
@@ -542,8 +576,9 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
   return 0;
 }
 
+static bool cov_speculates(const bessx_session *s) { return topk_supported(s->p, COV_R) && s->p >= 2 * COV_R; }
+
 static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d) {
-  const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
   if (!skip_d)
@@ -553,20 +588,31 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
     e = launch_score(s->part_rs[rs], nullptr, 1, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
                      s->always, s->bd, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
-  // speculation needs a top-32 of the uncached scores
-  const bool spec = topk_supported(s->p, COV_R) && s->p >= 2 * COV_R;
+  // repeated-set test + cache lookup; parks the fit when a column of A_new is not cached
   if (e == hipSuccess)
-    e = launch_cov_need(s->A_new, T0, spec ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C, s->cov_fcols,
-                        s->ctrl, slot, s->st);
-  if (e == hipSuccess && spec)
-    e = launch_topk(s->bd2, s->p, COV_R, s->cov_extras, s->cand, nullptr, 0, s->st, cv.meta + 2);
-  if (e == hipSuccess)
-    e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, COV_SLOT_GROUPS, s->ctrl, slot,
-                             s->st);
+    e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C,
+                        s->cov_fcols, s->ctrl, slot, s->A_cur, s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot_cov: ") + hipGetErrorString(e));
-  if (int rc = enqueue_cov_fill(s, rs, 0, COV_SLOT_GROUPS, slot, 0)) return rc;
   return enqueue_cov_tail(s, slot, T0, lambda, rs);
+}
+
+// A parked fit (hc = the control block just read back): fill list, Gram columns, wake-up, rest of the slot.
+static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int rs, int *next_slot) {
+  bessx_session::CovCache &cv = s->cov[rs];
+  const int stalled = -1 - hc->l + 1, nm = hc->cov_nmiss;
+  const bool spec = cov_speculates(s);
+  hipError_t e = hipSuccess;
+  if (spec) e = launch_topk(s->bd2, s->p, COV_R, s->cov_extras, s->cand, nullptr, 0, s->st);
+  if (e == hipSuccess) e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark: ") + hipGetErrorString(e));
+  // upper bound of the list length (the device drops speculative columns that turn out to be cached already)
+  const int room = spec ? std::min(((nm + 16 + COV_R - 1) / COV_R) * COV_R - nm, COV_R) : 0;
+  const int ngroups = (nm + room + COV_R - 1) / COV_R;
+  if (int rc = enqueue_cov_fill(s, rs, ngroups, 1)) return rc;
+  HIPX(launch_cov_resume(s->ctrl, s->st));
+  if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
+  *next_slot = stalled + 1;
+  return 0;
 }
 
 static int glm_geometry(bessx_session *s, int T0, int *mt, int *mp, int *ntask, int *ntiles, int *rps, int *nslab) {
@@ -940,14 +986,12 @@ static int algorithm_fit(bessx_session *s) {
   if (cov && !use_cache && k_init > 0) {
     // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones
     bessx_session::CovCache &cv = s->cov[rs];
-    const int ngroups = (k_init + COV_R - 1) / COV_R;
     e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C, s->cov_fcols, s->ctrl, 0,
-                        s->st);
+                        s->A_cur, s->st);
     if (e == hipSuccess)
-      e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, ngroups, s->ctrl, 0, s->st);
+      e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 0, s->st);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov begin: ") + hipGetErrorString(e));
-    for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS)
-      if (int rc = enqueue_cov_fill(s, rs, g0, std::min(COV_SLOT_GROUPS, ngroups - g0), 0, 0)) return rc;
+    if (int rc = enqueue_cov_fill(s, rs, (k_init + COV_R - 1) / COV_R, 0)) return rc;
   }
 
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
@@ -957,15 +1001,9 @@ static int algorithm_fit(bessx_session *s) {
     for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
       if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1)) return rc;
     if (int rc = read_results(s)) return rc;
+    if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
     if (hc->cov_stall) {
-      // the slot needs more Gram columns than its panel launch covers (cold cache): the device parked the fit
-      // (l = -1 - l); form all of them, wake it up and finish the slot
-      const int stalled = -1 - hc->l + 1, ngroups = hc->cov_nfill / COV_R;
-      for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS)
-        if (int rc = enqueue_cov_fill(s, rs, g0, std::min(COV_SLOT_GROUPS, ngroups - g0), 0, 1)) return rc;
-      HIPX(launch_cov_resume(s->ctrl, s->st));
-      if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
-      slot = stalled + 1;
+      if (int rc = cov_unpark(s, hc, T0, lambda, rs, &slot)) return rc;
       continue;
     }
     if (hc->done || slot > s->max_iter) break;

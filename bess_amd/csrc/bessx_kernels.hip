@@ -1009,6 +1009,7 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
     ctrl->cov_stall = 0;
     ctrl->cov_groups = 0;
     ctrl->cov_miss = 0;
+    ctrl->cov_nmiss = 0;
   }
 }
 
@@ -1029,6 +1030,7 @@ __global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl
     ctrl->cov_stall = 0;
     ctrl->cov_groups = 0;
     ctrl->cov_miss = 0;
+    ctrl->cov_nmiss = 0;
   }
 }
 
@@ -2256,17 +2258,30 @@ __device__ __forceinline__ bool cov_gate(const FitCtrl *ctrl, int slot) {
   return ctrl->l == slot - 1 && !ctrl->same_prev;
 }
 
-// meta: [0] columns cached, [1] missing columns of this request, [2] run flag of the speculative top-k
+// meta: [0] columns cached, [1] missing columns of this request, [2] speculation wanted for this request.
+// slot > 0: the request is the new active set of a PDAS iteration.  The kernel first does what k_gram_cols does in
+// the streaming form (repeated active set -> same_prev), then looks the columns up.  If some are missing the fit is
+// PARKED (cov_stall = 1, l = -1 - l: every gated kernel of this and the following slots falls through) and the host,
+// which sees the flag in its next read-back, issues the fill and the rest of the slot.  slot == 0: start of a fit,
+// the request is the initial support and the host has already queued a fill for it.
 __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, int len,
                                                   const double *__restrict__ bd, double *__restrict__ bd2, int p,
                                                   int *__restrict__ slot_of, int *__restrict__ meta, int C,
-                                                  int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot) {
-  if (!cov_gate(ctrl, slot)) {
-    if (threadIdx.x == 0) meta[2] = 0;
-    return;
-  }
+                                                  int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
+                                                  const int *__restrict__ A_cur) {
+  if (ctrl->done || (slot == 0 ? ctrl->l != 0 : ctrl->l != slot - 1)) return;
   __shared__ int wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (slot > 0) {
+    int diff = 1;
+    if (ctrl->l >= 1 && ctrl->k_cur == len) {
+      diff = 0;
+      for (int i = tid; i < len; i += 256) diff |= (list[i] != A_cur[i]);
+    }
+    diff = __syncthreads_or(diff);
+    if (tid == 0) ctrl->same_prev = diff ? 0 : 1;
+    if (!diff) return;  // A == A_list.col(l-1): nothing to solve, nothing to look up
+  }
   int count = meta[0];
   if (count + len + COV_R > C) {  // no room: start the cache over (uniform branch)
     for (int j = tid; j < p; j += 256) slot_of[j] = -1;
@@ -2301,8 +2316,11 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
     meta[0] = count;
     meta[1] = nm;
     meta[2] = spec ? 1 : 0;
-    ctrl->cov_nfill = 0;
-    ctrl->cov_stall = 0;
+    ctrl->cov_nmiss = nm;
+    if (nm > 0 && slot > 0) {
+      ctrl->cov_stall = 1;
+      ctrl->l = -1 - ctrl->l;
+    }
   }
   if (spec) {
     for (int j = tid; j < p; j += 256) bd2[j] = slot_of[j] >= 0 ? -1.0 : bd[j];
@@ -2311,16 +2329,21 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
   }
 }
 
+// Final fill list: the missing columns, then speculative ones (the best-scoring uncached columns, `extras`) up to
+// the next multiple of 32 that leaves room for at least 16 of them; cache slots are handed out here.
+// parked = 1: issued by the host for a parked fit; 0: start of a fit (slot 0).
 __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, const int *__restrict__ extras,
                                                        const double *__restrict__ bd2, int *__restrict__ slot_of,
-                                                       int *__restrict__ meta, int groups_cap,
-                                                       FitCtrl *__restrict__ ctrl, int slot) {
-  if (!cov_gate(ctrl, slot)) return;
+                                                       int *__restrict__ meta, FitCtrl *__restrict__ ctrl,
+                                                       int parked) {
+  if (parked ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int nm = meta[1];
-  if (nm == 0) return;
   const int tid = threadIdx.x;
+  if (nm == 0) {
+    if (tid == 0) ctrl->cov_nfill = 0;
+    return;
+  }
   const int count = meta[0], spec = meta[2];
-  // room for speculative columns: fill up to the next multiple of 32 that leaves at least 16 of them
   const int room = spec ? min(((nm + 16 + COV_R - 1) / COV_R) * COV_R - nm, COV_R) : 0;
   __shared__ int s_ne;
   if (tid < 64) {
@@ -2336,12 +2359,9 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
   for (int i = tid; i < tot; i += 256) slot_of[fcols[i]] = count + i;
   if (tid == 0) {
     meta[0] = count + tot;
+    meta[1] = 0;
     ctrl->cov_nfill = padded;
     ctrl->cov_groups += padded / COV_R;
-    if (padded > groups_cap * COV_R) {
-      ctrl->cov_stall = 1;
-      ctrl->l = -1 - ctrl->l;  // park: every gated kernel of this and the following slots falls through
-    }
   }
 }
 
@@ -2361,11 +2381,7 @@ __global__ void __launch_bounds__(256) k_cov_panel(const double *__restrict__ X,
                                                    int rows_per_slab, int nslab, int njg,
                                                    double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
                                                    int slot, int big) {
-  if (big) {
-    if (!ctrl->cov_stall) return;
-  } else {
-    if (!cov_gate(ctrl, slot) || ctrl->cov_stall) return;
-  }
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int nfill = ctrl->cov_nfill;
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long per_group = (long)nslab * njg;
@@ -2437,11 +2453,7 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
                                                     int njg, int p, const int *__restrict__ fcols,
                                                     const int *__restrict__ slot_of, double *__restrict__ G,
                                                     const FitCtrl *__restrict__ ctrl, int slot, int big) {
-  if (big) {
-    if (!ctrl->cov_stall) return;
-  } else {
-    if (!cov_gate(ctrl, slot) || ctrl->cov_stall) return;
-  }
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int gl = blockIdx.y;
   if (gl >= ngroups || (g0 + gl) * COV_R >= ctrl->cov_nfill) return;
   const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
@@ -3031,16 +3043,16 @@ hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int
 }
 
 hipError_t launch_cov_need(const int *list, int len, const double *bd, double *bd2, int p, int *slot_of, int *meta,
-                           int C, int *fcols, FitCtrl *ctrl, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_need, dim3(1), dim3(256), 0, st, list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot);
+                           int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_need, dim3(1), dim3(256), 0, st, list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot,
+                     A_cur);
   LAUNCH_CHECK();
   return hipSuccess;
 }
 
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                int groups_cap, FitCtrl *ctrl, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_fill_list, dim3(1), dim3(256), 0, st, fcols, extras, bd2, slot_of, meta, groups_cap, ctrl,
-                     slot);
+                                FitCtrl *ctrl, int parked, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_fill_list, dim3(1), dim3(256), 0, st, fcols, extras, bd2, slot_of, meta, ctrl, parked);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3054,20 +3066,26 @@ hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st) {
 int cov_streamed_tiles_per_wave() { return COV_NJ; }
 
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
-                            const int *slot_of, double *G, int g0, int ngroups, int rows_per_slab, int nslab,
-                            double *part, const FitCtrl *ctrl, int slot, int big, hipStream_t st) {
+                            int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
+                            int parked, hipStream_t st) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
   const long nwaves = (long)ngroups * nslab * njg;
   const int nblk = (int)((nwaves + 3) / 4);
   if (mask)
     hipLaunchKernelGGL(k_cov_panel<true>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
-                       rows_per_slab, nslab, njg, part, ctrl, slot, big);
+                       rows_per_slab, nslab, njg, part, ctrl, 0, parked);
   else
     hipLaunchKernelGGL(k_cov_panel<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
-                       rows_per_slab, nslab, njg, part, ctrl, slot, big);
+                       rows_per_slab, nslab, njg, part, ctrl, 0, parked);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, (const double *)part, g0,
-                     ngroups, nslab, njg, p, fcols, slot_of, G, ctrl, slot, big);
+  return hipSuccess;
+}
+
+hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
+                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st) {
+  const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
+  hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, part, g0, ngroups, nslab, njg, p,
+                     fcols, slot_of, G, ctrl, 0, parked);
   LAUNCH_CHECK();
   return hipSuccess;
 }
