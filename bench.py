@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--k-true", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", choices=["replica", "kpath"], default="replica")
+    ap.add_argument("--score-mode", choices=["auto", "streaming", "covariance"], default="auto",
+                    help="evaluation of the LM score pass (include/bessx.h, bessx_problem.score_mode)")
+    ap.add_argument("--no-streaming-leg", action="store_true",
+                    help="skip the extra (untimed-by-contract) measurement of the streaming score pass at N=1")
     args = ap.parse_args()
 
     import torch
@@ -112,7 +116,10 @@ def main():
         lo, hi = bdist.partition(args.kmax, world, rank)
         seq = seq[lo:hi]
     t0 = time.time()
-    sess = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True)
+    mode = {"auto": 0, "streaming": 1, "covariance": 2}[args.score_mode]
+    sess = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
+                        score_mode=mode)
+    covariance = sess.score_mode() == 2
     torch.cuda.synchronize()
     upload_s = time.time() - t0
 
@@ -141,19 +148,30 @@ def main():
     k1 = sess.score_pass_stats()
     sess.enable_kernel_timing(False)
 
-    if rank == 0:
-        n_cand = args.kmax * args.steps * (1 if kpath else world)
-        value = n_cand / dt
-        avg_launch = k1["seconds"] / max(k1["launches"], 1)
-        alg_bytes_launch = 8.0 * args.n * args.p
-        achieved = alg_bytes_launch / avg_launch / 1e9 if k1["launches"] else 0.0
+    def roofline_of(stats, cov):
+        """HBM roofline of the kernel that streams X: algorithmic bytes (8 n p per pass over X) / its HIP-event time."""
+        passes = stats["algorithmic_bytes"] / (8.0 * args.n * args.p)
+        per_pass = stats["seconds"] / passes if passes else 0.0
+        achieved = 8.0 * args.n * args.p / per_pass / 1e9 if passes else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and (args.n, args.p) == (50000, 10000):
             try:
-                traffic = json.load(open(tpath)).get("k_xtv_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_cov_panel_hbm_bytes_per_pass" if cov else
+                                                     "k_xtv_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        kern = ("k_cov_panel_lds (X^T diag(m) X_S on the fp64 matrix cores: 32 new Gram columns per pass over X)"
+                if cov else "k_xtv<8,16,false> (X^T r score pass)")
+        return {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": 8.0 * args.n * args.p, "avg_launch_ms": 1e3 * per_pass,
+                "launches_timed": stats["launches"], "passes_over_X_timed": passes}
+
+    if rank == 0:
+        n_cand = args.kmax * args.steps * (1 if kpath else world)
+        value = n_cand / dt
+        roof = roofline_of(k1, covariance)
         line = {
             "metric": "candidate subsets solved/sec (n=50k,p=10k,k<=200 LM)", "value": value,
             "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,15 +180,34 @@ def main():
             "config": {"workload": "configs[1]: LM sequential path, Gaussian X n=%d p=%d, s.list=1..%d, GIC, "
                                    "warm start, max_iter=20, is_normal" % (args.n, args.p, args.kmax),
                        "candidates_per_step_per_gpu": args.kmax, "units_sharded": "independent candidate chains "
-                       "(one response vector per rank on a replicated X)", "collective": "all_gather of the IC curve"},
-            "roofline": {"bound": "hbm", "kernel": "k_xtv<8,16,false> (X^T r score pass)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "avg_launch_ms": 1e3 * avg_launch, "launches_timed": k1["launches"]},
+                       "(one response vector per rank on a replicated X)", "collective": "all_gather of the IC curve",
+                       "score_pass": "covariance updates (cached Gram columns)" if covariance else "streaming"},
+            "roofline": roof,
+            "passes_over_X_per_candidate": roof["passes_over_X_timed"] / float(len(seq) * args.steps),
             "pdas_iterations_per_candidate": pdas_iters / float(len(seq) * args.steps),
             "upload_and_normalise_seconds": upload_s,
             "selected_k": int(out["best_T0"]), "selected_ic": float(out["ic"]),
         }
+        if covariance and world == 1 and not args.no_streaming_leg:
+            # the other evaluation of the same path (every PDAS iteration reads X once), for comparison
+            sess.close()
+            s2 = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
+                              score_mode=1)
+            s2.sequential_path(seq, ic_type=3)
+            s2.enable_kernel_timing(True)
+            s2.score_pass_stats(reset=True)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            o2 = s2.sequential_path(seq, ic_type=3)
+            torch.cuda.synchronize()
+            d2 = time.time() - t1
+            st2 = s2.score_pass_stats()
+            s2.close()
+            line["streaming_score_pass"] = {
+                "value": len(seq) / d2, "unit": "candidates/s", "steps": 1, "roofline": roofline_of(st2, False),
+                "passes_over_X_per_candidate": st2["launches"] / float(len(seq)),
+                "same_selection": bool(int(o2["best_T0"]) == int(out["best_T0"]) and
+                                       np.array_equal(np.nonzero(o2["beta"])[0], np.nonzero(out["beta"])[0]))}
         if ic_curves is not None:
             line["ic_curves_gathered"] = int(ic_curves.shape[0])
             line["best_k_per_problem"] = [int(bdist.select_best(c)) + 1 for c in ic_curves]

@@ -143,6 +143,8 @@ struct bessx_session {
   bool cov_mode = false;
   int cov_C = 0;              // cache capacity in columns
   int cov_rps = 0, cov_nslab = 0;
+  int cov_variant = 2;        // panel kernel: 2 = LDS-staged, single tile (3 blocks per CU); 1 = double-buffered
+                              // tile (1 block per CU); 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
   double *cov_part = nullptr, *bd2 = nullptr;
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
@@ -541,7 +543,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
     hipEvent_t ea = nullptr, eb = nullptr;
     if (int rc = k1_begin(s, &ea, &eb)) return rc;
     hipError_t e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, g0, ng, s->cov_rps,
-                                    s->cov_nslab, s->cov_part, s->ctrl, parked, s->st);
+                                    s->cov_nslab, s->cov_part, s->ctrl, parked, s->st, s->cov_variant);
     if (s->timing && e == hipSuccess) {
       e = hipEventRecord(eb, s->st);
       s->cov_timed.push_back({s->ev_used - 2, g0});
@@ -2124,11 +2126,26 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         s->cov_mode = true;
         s->cov_C = (int)C;
         const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
-        long ns = std::max<long>(1, (2048 + njg - 1) / njg);
-        ns = std::min<long>(ns, std::max<long>(1, ld / 64));
-        long rps = (ld + ns - 1) / ns;
-        rps = (rps + 15) / 16 * 16;
-        ns = (ld + rps - 1) / rps;
+        // row slabs: the staged panel kernel runs one 256-thread block per CU at a time (100 KB of LDS), so pick
+        // the slab count whose block count wastes the least of the last round of 256 blocks
+        long ns = 1, rps = ld;
+        if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(2, std::atoi(ev)));
+        {
+          // blocks resident at a time: 256 CUs x (1 for the double-buffered tile, 3 for the single one)
+          const long conc = s->cov_variant == 1 ? 256 : 768;
+          double best = 1e300;
+          const long ns_max = std::max<long>(1, std::min<long>(64, ld / 256));
+          for (long t = 1; t <= ns_max; t++) {
+            const long r = ((ld + t - 1) / t + 63) / 64 * 64, used = (ld + r - 1) / r;
+            const long blocks = (long)njg * used;
+            const double cost = (double)((blocks + conc - 1) / conc) * (double)r * (blocks < conc ? 2.0 : 1.0);
+            if (cost < best) {
+              best = cost;
+              ns = used;
+              rps = r;
+            }
+          }
+        }
         s->cov_rps = (int)rps;
         s->cov_nslab = (int)ns;
         HIPT(dmalloc(&s->cov_part, (size_t)COV_SLOT_GROUPS * ns * njg * cov_streamed_tiles_per_wave() * 2 * 256));
@@ -2136,6 +2153,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         HIPT(dmalloc(&s->cov_fcols, (size_t)s->capA + 4 * COV_R));
         HIPT(dmalloc(&s->cov_extras, (size_t)COV_R));
         TRY(alloc_cov_cache(s));
+        HIPT(cov_panel_prepare());
       } else if (mode == 2) {
         return bail(fail(BESSX_ERR_ARG, "covariance score mode: p too large for the Gram column cache"));
       }
@@ -2360,6 +2378,8 @@ int bessx_session_score_pass_stats(bessx_session *s, int reset, double *seconds,
   }
   return BESSX_OK;
 }
+
+int bessx_session_score_mode(const bessx_session *s) { return s && s->cov_mode ? 2 : 1; }
 
 int bessx_session_get_screening(const bessx_session *s, int *columns, int cap) {
   if (!s) return 0;

@@ -2448,6 +2448,102 @@ __global__ void __launch_bounds__(256) k_cov_panel(const double *__restrict__ X,
     for (int ni = 0; ni < 2; ni++) *reinterpret_cast<d4 *>(out + (size_t)(t * 2 + ni) * 256 + lane * 4) = acc[t][ni];
 }
 
+// LDS-staged variant: one BLOCK (4 waves) = 64 streamed columns x 32 right-hand-side columns on one row slab.
+// Global loads are coalesced the way the streaming score pass does it -- a wave instruction reads 512 contiguous
+// bytes of each of two columns (64 rows) -- into registers, then to a double-buffered LDS tile [column][row]
+// (row stride padded to 66 doubles: conflict-free 16-byte reads in the MFMA operand layout).  Wave w multiplies
+// streamed tile w with both right-hand-side tiles.  Loads of chunk k+1 are in flight while chunk k is multiplied;
+// one barrier per chunk.
+constexpr int CP_RB = 64;            // rows per chunk
+constexpr int CP_LD = CP_RB + 2;     // padded row stride of a column in LDS (doubles)
+constexpr int CP_COLS = 64 + COV_R;  // columns staged per chunk
+template <bool MASKED, bool DB>
+__global__ void __launch_bounds__(256) k_cov_panel_lds(const double *__restrict__ X, const double *__restrict__ aux,
+                                                       long ld, int p, const double *__restrict__ mask,
+                                                       const int *__restrict__ fcols, int g0, int ngroups,
+                                                       int rows_per_slab, int nslab, int njg,
+                                                       double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
+                                                       int big) {
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
+  const int nfill = ctrl->cov_nfill;
+  const long per_group = (long)nslab * njg;
+  const int gl = (int)(blockIdx.x / per_group);
+  if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
+  const int rem = (int)(blockIdx.x - (long)gl * per_group);
+  const int slab = rem / njg, jg = rem - slab * njg;
+  extern __shared__ double smem[];  // [2][CP_COLS][CP_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
+  // this thread's 12 loads per chunk: unit u = i*256 + tid -> column u/32 of the staged set, rows 2*(u%32)..+1
+  const int ru = tid & 31, cbase = tid >> 5;
+  const double *src[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const int cc = i * 8 + cbase;
+    int col;
+    if (cc < 64) {
+      const int j = jg * 64 + cc;
+      col = j < p ? j : -1;
+    } else {
+      col = fcols[(g0 + gl) * COV_R + cc - 64];
+    }
+    src[i] = gram_col(X, aux, ld, col) + 2 * ru;
+  }
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + CP_RB - 1) / CP_RB);
+  d2 stage[12], mstage;
+  auto load_chunk = [&](long r) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) stage[i] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src[i] + r));
+#pragma unroll
+    for (int i = 8; i < 12; i++) stage[i] = *reinterpret_cast<const d2 *>(src[i] + r);
+    if (MASKED) mstage = *reinterpret_cast<const d2 *>(mask + r + 2 * ru);
+  };
+  auto store_chunk = [&](int buf) {
+    double *dst = smem + (size_t)buf * CP_COLS * CP_LD + 2 * ru;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      d2 v = stage[i];
+      if (MASKED && i >= 8) v = v * mstage;
+      *reinterpret_cast<d2 *>(dst + (size_t)(i * 8 + cbase) * CP_LD) = v;
+    }
+  };
+  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+  load_chunk(r_begin);
+  store_chunk(0);
+  __syncthreads();
+  for (int k = 0; k < nchunk; k++) {
+    const bool more = k + 1 < nchunk;
+    if (more) load_chunk(r_begin + (long)(k + 1) * CP_RB);
+    const double *buf = smem + (DB ? (size_t)(k & 1) * CP_COLS * CP_LD : 0);
+    const double *pa = buf + (size_t)(wv * 16 + c) * CP_LD + 4 * q;
+    const double *pb0 = buf + (size_t)(64 + c) * CP_LD + 4 * q, *pb1 = buf + (size_t)(80 + c) * CP_LD + 4 * q;
+#pragma unroll
+    for (int s = 0; s < CP_RB / 16; s++) {
+      const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * s), a1 = *reinterpret_cast<const d2 *>(pa + 16 * s + 2);
+      const d2 x0 = *reinterpret_cast<const d2 *>(pb0 + 16 * s), x1 = *reinterpret_cast<const d2 *>(pb0 + 16 * s + 2);
+      const d2 y0 = *reinterpret_cast<const d2 *>(pb1 + 16 * s), y1 = *reinterpret_cast<const d2 *>(pb1 + 16 * s + 2);
+      const double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
+      const double b0x = x0.x, b0y = x0.y, b0z = x1.x, b0w = x1.y;
+      const double b1x = y0.x, b1y = y0.y, b1z = y1.x, b1w = y1.y;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b1x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b0y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b1y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b0z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b1z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b0w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b1w, acc1, 0, 0, 0);
+    }
+    if (!DB) __syncthreads();  // single buffer: everybody has finished reading before it is overwritten
+    if (more) store_chunk(DB ? ((k + 1) & 1) : 0);
+    __syncthreads();
+  }
+  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
+  double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
+  *reinterpret_cast<d4 *>(out + lane * 4) = acc0;
+  *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
+}
+
 // G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
 __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
                                                     int njg, int p, const int *__restrict__ fcols,
@@ -3067,8 +3163,28 @@ int cov_streamed_tiles_per_wave() { return COV_NJ; }
 
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
-                            int parked, hipStream_t st) {
+                            int parked, hipStream_t st, int variant) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
+  if (variant >= 1) {
+    // LDS-staged: one block per (group, slab, 64-column group); 1 = double-buffered LDS tile, 2 = single buffer
+    // (half the LDS: three blocks share a CU and hide each other's barriers)
+    const size_t lds = (size_t)(variant == 1 ? 2 : 1) * CP_COLS * CP_LD * sizeof(double);
+    const long nblk = (long)ngroups * nslab * njg;
+#define PANEL_GO(M, D)                                                                                              \
+  hipLaunchKernelGGL((k_cov_panel_lds<M, D>), dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0, \
+                     ngroups, rows_per_slab, nslab, njg, part, ctrl, parked)
+    if (mask && variant == 1)
+      PANEL_GO(true, true);
+    else if (mask)
+      PANEL_GO(true, false);
+    else if (variant == 1)
+      PANEL_GO(false, true);
+    else
+      PANEL_GO(false, false);
+#undef PANEL_GO
+    LAUNCH_CHECK();
+    return hipSuccess;
+  }
   const long nwaves = (long)ngroups * nslab * njg;
   const int nblk = (int)((nwaves + 3) / 4);
   if (mask)
@@ -3079,6 +3195,16 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
                        rows_per_slab, nslab, njg, part, ctrl, 0, parked);
   LAUNCH_CHECK();
   return hipSuccess;
+}
+
+// one-time opt-in to more than 64 KB of dynamic LDS for the staged panel kernel
+hipError_t cov_panel_prepare() {
+  const int lds = (int)((size_t)2 * CP_COLS * CP_LD * sizeof(double));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<false, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,

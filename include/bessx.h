@@ -105,6 +105,8 @@ void bessx_session_destroy(bessx_session *s);
 /* screening_A of src/screening.cpp:68: original column of every kept column (ascending).  Returns the number of
  * kept columns (= p when the session was created without screening, map = identity); writes min(count, cap). */
 int bessx_session_get_screening(const bessx_session *s, int *columns, int cap);
+/* 1 = streaming score pass, 2 = covariance updates: what bessx_problem.score_mode resolved to for this session. */
+int bessx_session_score_mode(const bessx_session *s);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)
  * gives the test fold of row i; fold_id == NULL draws a permutation from mt19937(seed) and cuts
