@@ -65,9 +65,22 @@ hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, in
                                  int rps_full, int nslab_full, const GramTask *tasks_inc, int ntask_inc, int rps_inc,
                                  int nslab_inc, double *part, double *Gt, double *Rt, int *src, double *gbuf0,
                                  double *gbuf1, int *Ac, int *meta, FitCtrl *ctrl, int slot, hipStream_t st);
+// k_chol in the covariance mode of the LM fit: Gram gathered from the column cache, k_commit's work at the end
+struct CholFuse {
+  const double *G;
+  const int *slot_of;
+  int p;
+  int T0;
+  FitCtrl *ctrl;
+  int *A_cur;
+  double *b_cur, *beta_dense;
+  int *hist;
+  double *hist_beta, *hist_coef0;
+  int hist_stride;
+};
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
-                       hipStream_t st);
+                       hipStream_t st, const CholFuse *fuse = nullptr);
 hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                            const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);
@@ -80,7 +93,7 @@ hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, cons
                          double *hist_coef0, int hist_stride, hipStream_t st);
 hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
-                           double *sse, hipStream_t st);
+                           double *sse, hipStream_t st, int mode = 0);
 hipError_t launch_glm_eta_gh(int fam, const double *X, long ld, int n, const double *y, const double *w,
                              const double *mask, const double *logfact, const FitCtrl *ctrl, int when,
                              const int *A_cur, const double *b_cur, double *g, double *h, double *stats,
@@ -148,9 +161,14 @@ hipError_t cov_panel_prepare();
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
                              int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st);
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
-                        const double *b_cur, double *d_out, int *meta, const FitCtrl *ctrl, int slot, hipStream_t st);
+                        const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,
+                        double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
+                        hipStream_t st);
 hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int *A_new, int T0, int mt, double *Gt,
                            int *meta, const FitCtrl *ctrl, int slot, hipStream_t st);
+hipError_t launch_publish(const unsigned char *dev, unsigned char *host, int ctrl_bytes, size_t off_sse, int n_sse,
+                          size_t off_b, size_t off_a, int kcopy, unsigned long long *seq_host, unsigned long long seq,
+                          hipStream_t st);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cmath>
@@ -163,6 +164,8 @@ struct bessx_session {
   int *A_cur = nullptr;
   int n_sse_blk = 0;
   unsigned char *res_h = nullptr;    // pinned
+  bool publish = true;               // results handed over by k_publish (else: asynchronous copy + synchronise)
+  unsigned long long *pub_flag = nullptr, pub_seq = 0;  // pinned sequence number k_publish releases
   unsigned char *stage_h = nullptr;  // pinned staging for init vectors
   // host statistics
   std::vector<double> x_mean_h, x_norm_h;
@@ -272,6 +275,7 @@ static void session_free(bessx_session *s) {
   F(s->init_val_d);
   F(s->resblk);
   if (s->res_h) (void)hipHostFree(s->res_h);
+  if (s->pub_flag) (void)hipHostFree(s->pub_flag);
   if (s->stage_h) (void)hipHostFree(s->stage_h);
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -560,20 +564,25 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
 static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs) {
   const int mt = (T0 + 1 + 15) / 16;
   bessx_session::CovCache &cv = s->cov[rs];
-  hipError_t e = launch_cov_gram(cv.G, s->p, cv.slot_of, s->A_new, T0, mt, s->Gt, cv.meta, s->ctrl, slot, s->st);
-  if (e == hipSuccess) {
-    if (mt > 16)
+  hipError_t e = hipSuccess;
+  if (mt > 16) {
+    e = launch_cov_gram(cv.G, s->p, cv.slot_of, s->A_new, T0, mt, s->Gt, cv.meta, s->ctrl, slot, s->st);
+    if (e == hipSuccess)
       e = launch_chol_big(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->rdiag, s->zbig,
                           s->ctrl, slot, 0, s->st);
-    else
-      e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
+    if (e == hipSuccess)
+      e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+                        s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+  } else {
+    // one launch: Gram gathered from the cache while loading, Cholesky + both solves, then the commit
+    CholFuse fz = {cv.G,     cv.slot_of,    s->p,    T0,           s->ctrl,       s->A_cur,
+                   s->b_cur, s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride};
+    e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
+                    &fz);
   }
-  if (e == hipSuccess)
-    e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
-                      s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
-  if (e == hipSuccess)
+  if (e == hipSuccess)  // only the final coefficients' sums of squares are needed: runs iff the fit ended here
     e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
-                        s->sse, s->st);
+                        s->sse, s->st, 1);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cov_tail: ") + hipGetErrorString(e));
   return 0;
 }
@@ -583,10 +592,10 @@ static bool cov_speculates(const bessx_session *s) { return topk_supported(s->p,
 static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d) {
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
-  if (!skip_d)
-    e = launch_cov_d(cv.G, s->p, cv.slot_of, s->xty[rs], s->A_cur, s->b_cur, s->part_rs[rs], cv.meta, s->ctrl, slot,
-                     s->st);
-  if (e == hipSuccess)
+  if (!skip_d)  // d and the sacrifice scores in one kernel
+    e = launch_cov_d(cv.G, s->p, cv.slot_of, s->xty[rs], s->A_cur, s->b_cur, s->part_rs[rs], s->beta_dense, s->xtx[rs],
+                     (double)s->n_train[rs], lambda, s->always, s->bd, s->ctrl, slot, s->st);
+  else  // d of exactly these coefficients is in memory (previous fit of the chain); lambda may have changed
     e = launch_score(s->part_rs[rs], nullptr, 1, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
                      s->always, s->bd, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
@@ -745,13 +754,42 @@ static int enqueue_cox_tail(bessx_session *s, int slot, int T0, int rs) {
   return 0;
 }
 
-static int read_results(bessx_session *s) {
-  HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
-  HIPX(hipStreamSynchronize(s->st));
+// Results of the kernels queued so far.  kcopy >= 0: only the first kcopy coefficients / indices are wanted and
+// the block is published by a kernel into pinned memory (k_publish) while the host spins on its sequence number --
+// no copy engine, no interrupt.  kcopy < 0 (or BESSX_PUBLISH=0): plain asynchronous copy + stream synchronisation.
+static int read_results(bessx_session *s, int kcopy = -1) {
+  if (kcopy < 0 || !s->publish) {
+    HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
+    HIPX(hipStreamSynchronize(s->st));
+    return 0;
+  }
+  const unsigned long long want = ++s->pub_seq;
+  volatile unsigned long long *flag = s->pub_flag;
+  HIPX(launch_publish(s->resblk, s->res_h, 128, (size_t)((unsigned char *)s->sse - s->resblk), 2 * s->n_sse_blk,
+                      (size_t)((unsigned char *)s->b_cur - s->resblk), (size_t)((unsigned char *)s->A_cur - s->resblk),
+                      std::min(kcopy, s->capA), s->pub_flag, want, s->st));
+  for (unsigned spins = 1;; spins++) {
+    if (*flag == want) break;
+    if ((spins & 0x3ff) == 0) {
+      hipError_t q = hipStreamQuery(s->st);
+      if (q == hipSuccess) {
+        if (*flag == want) break;
+        // finished but the flag is not visible: fall back to the copy path
+        HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
+        HIPX(hipStreamSynchronize(s->st));
+        return 0;
+      }
+      if (q != hipErrorNotReady) return fail(BESSX_ERR_HIP, std::string("read_results: ") + hipGetErrorString(q));
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return 0;
 }
 
-static int read_results(bessx_session *s);
+static int read_results(bessx_session *s, int kcopy);
 
 // --------------------------------------------------------------------------------------------
 // Group mode (some group has more than one column): Algorithm::fit with per-group sacrifices.  The host reads the
@@ -973,7 +1011,7 @@ static int algorithm_fit(bessx_session *s) {
                          s->beta_dense, s->p, s->hist, s->st);
   }
   s->dev_state_rs = rs;
-  if (e == hipSuccess && !use_cache) {
+  if (e == hipSuccess && !use_cache && !cov) {
     if (!glm)
       e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                           s->st);
@@ -1002,13 +1040,19 @@ static int algorithm_fit(bessx_session *s) {
   while (!glm && cov) {
     for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
       if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1)) return rc;
-    if (int rc = read_results(s)) return rc;
+    if (int rc = read_results(s, T0)) return rc;
     if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
     if (hc->cov_stall) {
       if (int rc = cov_unpark(s, hc, T0, lambda, rs, &slot)) return rc;
       continue;
     }
     if (hc->done || slot > s->max_iter) break;
+  }
+  if (cov && !hc->done) {
+    // out of iterations: the sums of squares of the last coefficients have not been formed yet
+    HIPX(launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, hc->l, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
+                         s->st, 2));
+    if (int rc = read_results(s, T0)) return rc;
   }
   if (cov) {
     s->cov_panel_groups += hc->cov_groups;
@@ -1018,7 +1062,7 @@ static int algorithm_fit(bessx_session *s) {
     int first = slot;
     for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
       if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
-    if (int rc = read_results(s)) return rc;
+    if (int rc = read_results(s, T0)) return rc;
     // slots first..l really ran K1; later ones fell through their gate
     for (size_t i = 0; i < k1_pairs.size(); i++) k1_pairs[i].second = (first + (int)i) <= hc->l;
     if (int rc = k1_collect(s, k1_pairs)) return rc;
@@ -1041,7 +1085,7 @@ static int algorithm_fit(bessx_session *s) {
         if (int rc = cox ? enqueue_cox_newton(s, slot, t, T0, lambda, rs) : enqueue_glm_irls_step(s, slot, t, T0, lambda, rs))
           return rc;
       if (int rc = cox ? enqueue_cox_tail(s, slot, T0, rs) : enqueue_glm_tail(s, slot, T0, rs)) return rc;
-      if (int rc = read_results(s)) return rc;
+      if (int rc = read_results(s, T0)) return rc;
       if (hc->l == slot) {  // committed (IRLS finished, or the active set repeated)
         steps_used = hc->irls_last;
         break;
@@ -2016,6 +2060,10 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     s->b_cur = reinterpret_cast<double *>(s->resblk + o_b);
     s->A_cur = reinterpret_cast<int *>(s->resblk + o_a);
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->res_h), off));
+    std::memset(s->res_h, 0, off);
+    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->pub_flag), 64));
+    *s->pub_flag = 0ull;
+    if (const char *ev = std::getenv("BESSX_PUBLISH")) s->publish = std::atoi(ev) != 0;
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), (size_t)capA * (sizeof(int) + sizeof(double))));
   }
   static_assert(sizeof(FitCtrl) <= 128, "FitCtrl must fit its slot of the result block");

@@ -644,14 +644,31 @@ __device__ __forceinline__ void tile_of(int t, int &I, int &J) {
   J = t - i * (i + 1) / 2;
 }
 
+__device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot, int T0,
+                                            const int *__restrict__ A_new, const double *__restrict__ sol,
+                                            int has_intercept, int wait_chain, int *__restrict__ A_cur,
+                                            double *__restrict__ b_cur, double *__restrict__ beta_dense,
+                                            int *__restrict__ hist, double *__restrict__ hist_beta,
+                                            double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh);
+
+// fz.G != nullptr (covariance mode of the LM fit): the Gram entries are gathered from the column cache
+// (G[row A_a, column slot_of[A_b]]) instead of read from Gt, and the kernel ends with the work of k_commit -- two
+// launches less per PDAS iteration.
 template <int CH_SLOTS>  // register tiles per wave: 5 (mt <= 8), 10 (mt <= 12), 17 (mt <= 16)
 __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int m, int mt, double ridge,
                                               int ridge_skip0, const double *__restrict__ rhs,
                                               const int *__restrict__ rhs_gather, double *__restrict__ sol,
                                               int *__restrict__ info, const FitCtrl *__restrict__ ctrl, int slot,
-                                              int gate_mode) {
+                                              int gate_mode, const CholFuse fz) {
+  __shared__ int same_any_sh;
   if (ctrl != nullptr) {
-    if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
+    if (ctrl->done || ctrl->l != slot - 1) return;
+    if (ctrl->same_prev) {
+      if (fz.G != nullptr)
+        commit_body(fz.ctrl, slot, fz.T0, rhs_gather, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist,
+                    fz.hist_beta, fz.hist_coef0, fz.hist_stride, &same_any_sh);
+      return;
+    }
     if ((gate_mode == 1 || gate_mode == 2) && ctrl->irls_done) return;
   }
   // LDS images are addressed by integer offsets.  The single-wave phases below pass data between
@@ -673,6 +690,15 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
   const int mp = mt * 16, ntiles = mt * (mt + 1) / 2;
   d4 acc[CH_SLOTS];
   int tI[CH_SLOTS], tJ[CH_SLOTS];
+  __shared__ int sA[CH_MT * 16], sS[CH_MT * 16];  // gather mode: active columns and their cache slots
+  if (fz.G != nullptr) {
+    for (int i = tid; i < m; i += 512) {
+      const int a = rhs_gather[i];
+      sA[i] = a;
+      sS[i] = fz.slot_of[a];
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int s = 0; s < CH_SLOTS; s++) {
     int t = s * CH_W + wave;
@@ -681,8 +707,24 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
     acc[s] = d4{0.0, 0.0, 0.0, 0.0};
     if (t < ntiles) {
       tile_of(t, tI[s], tJ[s]);
-      d4 g = *reinterpret_cast<const d4 *>(Gt + (size_t)t * 256 + lane * 4);
-      double gv[4] = {g.x, g.y, g.z, g.w};
+      double gv[4];
+      if (fz.G != nullptr) {
+        const int col = tJ[s] * 16 + lc;
+        const int sl = col < m ? sS[col] : 0;
+        if (sl < 0) fz.ctrl->cov_miss = 1;  // must not happen: the active columns were cached before this launch
+        const double *gcol = fz.G + (size_t)(sl < 0 ? 0 : sl) * fz.p;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = tI[s] * 16 + lq + 4 * r;
+          gv[r] = (row < m && col < m && sl >= 0) ? gcol[sA[row]] : 0.0;
+        }
+      } else {
+        const d4 g = *reinterpret_cast<const d4 *>(Gt + (size_t)t * 256 + lane * 4);
+        gv[0] = g.x;
+        gv[1] = g.y;
+        gv[2] = g.z;
+        gv[3] = g.w;
+      }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         int row = tI[s] * 16 + lq + 4 * r, col = tJ[s] * 16 + lc;
@@ -823,6 +865,9 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
     bad = !(fabs(v) <= DBL_MAX);
   }
   if (__syncthreads_or(bad) && tid == 0 && info != nullptr) *info = 1;
+  if (fz.G != nullptr)  // sol is visible to the whole block after the barrier above
+    commit_body(fz.ctrl, slot, fz.T0, rhs_gather, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+                fz.hist_coef0, fz.hist_stride, &same_any_sh);
 #undef WAVE_SYNC
 }
 
@@ -1036,17 +1081,18 @@ __global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl
 
 // End of a PDAS iteration: beta <- 0; beta[A] = beta_A; A_list.col(l) = A; stop if A == A_list.col(ll), ll < l.
 // sol holds the solved coefficients; with an intercept (GLM) sol[0] is coef0 and sol[1..] the slopes.
-__global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int slot, int T0,
-                                                const int *__restrict__ A_new, const double *__restrict__ sol,
-                                                int has_intercept, int wait_chain, int *__restrict__ A_cur,
-                                                double *__restrict__ b_cur, double *__restrict__ beta_dense,
-                                                int *__restrict__ hist, double *__restrict__ hist_beta,
-                                                double *__restrict__ hist_coef0, int hist_stride) {
-  if (ctrl->done || ctrl->l != slot - 1) return;
+// body of k_commit for any block size (also the tail of the fused k_chol of the covariance mode)
+__device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot, int T0,
+                                            const int *__restrict__ A_new, const double *__restrict__ sol,
+                                            int has_intercept, int wait_chain, int *__restrict__ A_cur,
+                                            double *__restrict__ b_cur, double *__restrict__ beta_dense,
+                                            int *__restrict__ hist, double *__restrict__ hist_beta,
+                                            double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh) {
+  const int nt = blockDim.x;
   const int l = slot;
   if (ctrl->same_prev) {
     // A == A_list.col(l-1): the re-fit reproduces the current coefficients; record and stop
-    for (int i = threadIdx.x; i < T0; i += 256) {
+    for (int i = threadIdx.x; i < T0; i += nt) {
       hist[(size_t)l * hist_stride + i] = A_cur[i];
       hist_beta[(size_t)l * hist_stride + i] = b_cur[i];
     }
@@ -1060,12 +1106,11 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
     return;
   }
   if (wait_chain && !ctrl->irls_done) return;  // IRLS / Newton chain still running: the host re-issues
-  __shared__ int same_any;
   const int kc = ctrl->k_cur;
-  if (threadIdx.x == 0) same_any = 0;
-  for (int i = threadIdx.x; i < kc; i += 256) beta_dense[A_cur[i]] = 0.0;
+  if (threadIdx.x == 0) *same_any_sh = 0;
+  for (int i = threadIdx.x; i < kc; i += nt) beta_dense[A_cur[i]] = 0.0;
   __syncthreads();
-  for (int i = threadIdx.x; i < T0; i += 256) {
+  for (int i = threadIdx.x; i < T0; i += nt) {
     int a = A_new[i];
     double b = sol[i + (has_intercept ? 1 : 0)];
     A_cur[i] = a;
@@ -1078,9 +1123,9 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
   // compare with every earlier column (including the all-zero column 0)
   for (int ll = 0; ll < l; ll++) {
     int diff = 0;
-    for (int i = threadIdx.x; i < T0; i += 256) diff |= (hist[(size_t)ll * hist_stride + i] != A_new[i]);
+    for (int i = threadIdx.x; i < T0; i += nt) diff |= (hist[(size_t)ll * hist_stride + i] != A_new[i]);
     diff = __syncthreads_or(diff);
-    if (!diff && threadIdx.x == 0) same_any = 1;
+    if (!diff && threadIdx.x == 0) *same_any_sh = 1;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1088,12 +1133,24 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
     hist_coef0[l] = ctrl->coef0;
     ctrl->k_cur = T0;
     ctrl->l = l;
-    ctrl->done = same_any;
+    ctrl->done = *same_any_sh;
     ctrl->d_fresh = 0;  // coefficients changed after the last score pass
     ctrl->irls_done = 0;
     ctrl->irls_last = ctrl->irls_steps;
     ctrl->irls_steps = 0;
   }
+}
+
+__global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int slot, int T0,
+                                                const int *__restrict__ A_new, const double *__restrict__ sol,
+                                                int has_intercept, int wait_chain, int *__restrict__ A_cur,
+                                                double *__restrict__ b_cur, double *__restrict__ beta_dense,
+                                                int *__restrict__ hist, double *__restrict__ hist_beta,
+                                                double *__restrict__ hist_coef0, int hist_stride) {
+  if (ctrl->done || ctrl->l != slot - 1) return;
+  __shared__ int same_any;
+  commit_body(ctrl, slot, T0, A_new, sol, has_intercept, wait_chain, A_cur, b_cur, beta_dense, hist, hist_beta,
+              hist_coef0, hist_stride, &same_any);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1102,33 +1159,33 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
 //   sse[2*blk] = sum mask_i e_i^2, sse[2*blk+1] = sum (1-mask_i) e_i^2   (pad rows excluded).
 // when = slot  -> runs iff this slot's k_commit ran (ctrl->l == slot);  when = 0 -> start of fit.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_resid_lm(const double *__restrict__ X, long ld, int n,
+__global__ void __launch_bounds__(512) k_resid_lm(const double *__restrict__ X, long ld, int n,
                                                   const double *__restrict__ y, const double *__restrict__ mask,
                                                   const FitCtrl *__restrict__ ctrl, int when,
                                                   const int *__restrict__ A_cur, const double *__restrict__ b_cur,
-                                                  double *__restrict__ r, double *__restrict__ sse) {
-  if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;  // same_prev: beta, r and the sums are unchanged
+                                                  double *__restrict__ r, double *__restrict__ sse, int mode) {
+  // mode 0 (streaming score pass: r feeds the next pass): after every commit; same_prev: beta, r, sums unchanged.
+  // mode 1 (covariance updates: only the sums of squares of the FINAL coefficients are needed): when the fit ended
+  // in this slot; mode 2: the fit ran out of iterations without ending (host issues it after the last slot).
+  if (mode == 0 && (ctrl->l != when || (when > 0 && ctrl->same_prev))) return;
+  if (mode == 1 && (ctrl->l != when || !ctrl->done)) return;
+  if (mode == 2 && (ctrl->l != when || ctrl->done)) return;
+  __shared__ d2 part[3][128];
   __shared__ double sm[2][2];
   const int kc = ctrl->k_cur;
   const double c0 = ctrl->coef0;
-  // 128 threads x 2 rows: block b owns rows [256 b, 256 b + 256); ld is a multiple of 128 rows
-  const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
+  // block b owns rows [256 b, 256 b + 256) (ld is a multiple of 128 rows): 128 row threads x 2 rows, times 4 thread
+  // groups that each take every 4th active column; the 4 partial sums are added in group order (fixed tree)
+  const int rt = threadIdx.x & 127, g = threadIdx.x >> 7;
+  const long i = ((long)blockIdx.x * 128 + rt) * 2;
+  d2 acc = d2{0.0, 0.0};
+  if (i < ld)
+    for (int a = g; a < kc; a += 4) acc += *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a] * ld + i) * b_cur[a];
+  if (g > 0) part[g - 1][rt] = acc;
+  __syncthreads();
   double s_tr = 0.0, s_te = 0.0;
-  if (i < ld) {
-    d2 acc0 = d2{0.0, 0.0}, acc1 = d2{0.0, 0.0}, acc2 = d2{0.0, 0.0}, acc3 = d2{0.0, 0.0};
-    int a = 0;
-    for (; a + 4 <= kc; a += 4) {
-      const d2 x0 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a] * ld + i);
-      const d2 x1 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a + 1] * ld + i);
-      const d2 x2 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a + 2] * ld + i);
-      const d2 x3 = *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a + 3] * ld + i);
-      acc0 += x0 * b_cur[a];
-      acc1 += x1 * b_cur[a + 1];
-      acc2 += x2 * b_cur[a + 2];
-      acc3 += x3 * b_cur[a + 3];
-    }
-    for (; a < kc; a++) acc0 += *reinterpret_cast<const d2 *>(X + (size_t)A_cur[a] * ld + i) * b_cur[a];
-    const d2 sx = (acc0 + acc1) + (acc2 + acc3);
+  if (g == 0 && i < ld) {
+    const d2 sx = ((acc + part[0][rt]) + part[1][rt]) + part[2][rt];
     const d2 yv = *reinterpret_cast<const d2 *>(y + i);
     d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
     const bool in0 = i < n, in1 = i + 1 < n;  // pad rows: y = 0, x = 0, but coef0 must not leak into r
@@ -1141,7 +1198,7 @@ __global__ void __launch_bounds__(128) k_resid_lm(const double *__restrict__ X, 
   }
   s_tr = wave_sum(s_tr);
   s_te = wave_sum(s_te);
-  if ((threadIdx.x & 63) == 0) {
+  if (g == 0 && (threadIdx.x & 63) == 0) {
     sm[threadIdx.x >> 6][0] = s_tr;
     sm[threadIdx.x >> 6][1] = s_te;
   }
@@ -2562,11 +2619,15 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
   if (j < p && col >= 0) G[(size_t)slot_of[col] * p + j] = s;
 }
 
-// d_j = (X^T m y)_j - sum_i G[j, slot(A_i)] b_i ; 64 columns per block, the sum over i cut in 4 interleaved parts
+// d_j = (X^T m y)_j - sum_i G[j, slot(A_i)] b_i ; 64 columns per block, the sum over i cut in 4 interleaved parts.
+// The sacrifice score of k_score (LM branch) is formed in the same kernel: bd_j = (phi b_j + d_j / phi)^2 with
+// d_j / n_t - 2 lambda b_j and phi = sqrt(2 lambda + x_j.x_j / n_t).
 __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int p, const int *__restrict__ slot_of,
                                                const double *__restrict__ xty, const int *__restrict__ A_cur,
                                                const double *__restrict__ b_cur, double *__restrict__ d_out,
-                                               int *__restrict__ meta, const FitCtrl *__restrict__ ctrl, int slot) {
+                                               const double *__restrict__ beta_dense, const double *__restrict__ xtx,
+                                               double n_t, double lambda, const unsigned char *__restrict__ always,
+                                               double *__restrict__ bd, const FitCtrl *__restrict__ ctrl, int slot) {
   if (ctrl->done || ctrl->l != slot - 1) return;
   __shared__ double sm[4][64];
   const int kc = ctrl->k_cur;
@@ -2583,7 +2644,18 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
     }
   sm[g][jj] = acc;
   __syncthreads();
-  if (g == 0 && j < p) d_out[j] = xty[j] - (((sm[0][jj] + sm[1][jj]) + sm[2][jj]) + sm[3][jj]);
+  if (g == 0 && j < p) {
+    const double s1 = xty[j] - (((sm[0][jj] + sm[1][jj]) + sm[2][jj]) + sm[3][jj]);
+    d_out[j] = s1;
+    const double b = beta_dense[j];
+    const double d = s1 / n_t - 2.0 * lambda * b;
+    const double phi = sqrt(2.0 * lambda + xtx[j] / n_t);
+    const double inv = 1.0 / phi;
+    const double t = phi * b + inv * d;
+    double v = t * t;
+    if (always != nullptr && always[j]) v = DBL_MAX;
+    bd[j] = v;
+  }
 }
 
 // Gram tiles of the new active set in the layout k_chol / k_bc_* read (see k_gram_assemble)
@@ -2607,6 +2679,28 @@ __global__ void __launch_bounds__(256) k_cov_gram(const double *__restrict__ G, 
       const_cast<FitCtrl *>(ctrl)->cov_miss = 1;
   }
   Gt[(size_t)t * 256 + lane * 4 + r] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Hand the result block of a fit to the host without a copy engine round trip: the block (control words, the
+// per-256-row sums of squares, the first kcopy coefficients and indices) is written straight into pinned host
+// memory at the same offsets, then a sequence number is released at system scope; the host spins on it.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_publish(const unsigned char *__restrict__ dev, unsigned char *host,
+                                                 int ctrl_bytes, size_t off_sse, int n_sse, size_t off_b, size_t off_a,
+                                                 int kcopy, unsigned long long *seq_host, unsigned long long seq) {
+  const int tid = threadIdx.x;
+  const unsigned long long *d8 = reinterpret_cast<const unsigned long long *>(dev);
+  unsigned long long *h8 = reinterpret_cast<unsigned long long *>(host);
+  for (int i = tid; i < ctrl_bytes / 8; i += 256) h8[i] = d8[i];
+  for (int i = tid; i < n_sse; i += 256) h8[off_sse / 8 + i] = d8[off_sse / 8 + i];
+  for (int i = tid; i < kcopy; i += 256) h8[off_b / 8 + i] = d8[off_b / 8 + i];
+  const int *d4 = reinterpret_cast<const int *>(dev + off_a);
+  int *h4 = reinterpret_cast<int *>(host + off_a);
+  for (int i = tid; i < kcopy; i += 256) h4[i] = d4[i];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // streaming copy used to measure the practical HBM ceiling
@@ -2806,18 +2900,20 @@ hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, in
 
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
-                       hipStream_t st) {
+                       hipStream_t st, const CholFuse *fuse) {
   if (mt < 1 || m + 1 > mt * 16) return hipErrorInvalidValue;
   if (mt > CH_MT) return hipErrorInvalidValue;  // callers route larger systems to launch_chol_big
+  CholFuse fz = {};
+  if (fuse) fz = *fuse;
   if (mt <= 8)
     hipLaunchKernelGGL(k_chol<5>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info,
-                       ctrl, slot, gate_mode);
+                       ctrl, slot, gate_mode, fz);
   else if (mt <= 12)
     hipLaunchKernelGGL(k_chol<10>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
-                       info, ctrl, slot, gate_mode);
+                       info, ctrl, slot, gate_mode, fz);
   else
     hipLaunchKernelGGL(k_chol<17>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
-                       info, ctrl, slot, gate_mode);
+                       info, ctrl, slot, gate_mode, fz);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -2877,9 +2973,10 @@ hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, cons
 
 hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
-                           double *sse, hipStream_t st) {
+                           double *sse, hipStream_t st, int mode) {
   int nblk = (int)((ld + 255) / 256);
-  hipLaunchKernelGGL(k_resid_lm, dim3(nblk), dim3(128), 0, st, X, ld, n, y, mask, ctrl, when, A_cur, b_cur, r, sse);
+  hipLaunchKernelGGL(k_resid_lm, dim3(nblk), dim3(512), 0, st, X, ld, n, y, mask, ctrl, when, A_cur, b_cur, r, sse,
+                     mode);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3217,9 +3314,11 @@ hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const 
 }
 
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
-                        const double *b_cur, double *d_out, int *meta, const FitCtrl *ctrl, int slot, hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_d, dim3((p + 63) / 64), dim3(256), 0, st, G, p, slot_of, xty, A_cur, b_cur, d_out, meta,
-                     ctrl, slot);
+                        const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,
+                        double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_d, dim3((p + 63) / 64), dim3(256), 0, st, G, p, slot_of, xty, A_cur, b_cur, d_out,
+                     beta_dense, xtx, n_t, lambda, always, bd, ctrl, slot);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3228,6 +3327,15 @@ hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int
                            int *meta, const FitCtrl *ctrl, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_cov_gram, dim3(mt * (mt + 1) / 2), dim3(256), 0, st, G, p, slot_of, A_new, T0, Gt, meta, ctrl,
                      slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_publish(const unsigned char *dev, unsigned char *host, int ctrl_bytes, size_t off_sse, int n_sse,
+                          size_t off_b, size_t off_a, int kcopy, unsigned long long *seq_host, unsigned long long seq,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, dev, host, ctrl_bytes, off_sse, n_sse, off_b, off_a, kcopy,
+                     seq_host, seq);
   LAUNCH_CHECK();
   return hipSuccess;
 }
