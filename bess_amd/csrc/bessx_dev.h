@@ -35,7 +35,7 @@ struct FitCtrl {
   int cov_groups;  // 32-column panel groups (passes over X) this fit has formed so far (host statistics)
   int cov_miss;    // internal error flag: an active column was not in the Gram column cache
   int cov_nmiss;   // columns of the requested set that are not cached (set by k_cov_need)
-  int pad3_;
+  int serial;      // which fit this block describes (set by k_fit_continue; the host checks it for chained fits)
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -87,7 +87,8 @@ hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_sk
 hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
                             hipStream_t st);
-hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st);
+hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st, int serial = 0, int chained = 0,
+                               int parent = 0);
 hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
                          int wait_chain, int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
                          double *hist_coef0, int hist_stride, hipStream_t st);

@@ -165,7 +165,24 @@ struct bessx_session {
   int n_sse_blk = 0;
   unsigned char *res_h = nullptr;    // pinned
   bool publish = true;               // results handed over by k_publish (else: asynchronous copy + synchronise)
-  unsigned long long *pub_flag = nullptr, pub_seq = 0;  // pinned sequence number k_publish releases
+  unsigned long long *pub_flag = nullptr, pub_seq = 0;  // pinned sequence numbers k_publish releases (one per buffer)
+  unsigned char *res_buf[2] = {nullptr, nullptr};       // the two pinned result blocks; res_h points at the current one
+  // Chained warm-start fits (covariance mode): the path function announces the fit that will follow (hint); the
+  // first batch of that fit is queued behind the current one before the host waits for the current result.
+  struct Hint {
+    bool on = false;
+    int T0 = 0;
+    double lambda = 0.0;
+  } hint;
+  struct Ahead {
+    bool armed = false;
+    int T0 = 0, rs = 0, serial = 0, buf = 0;
+    double lambda = 0.0;
+    unsigned long long seq = 0;
+  } ahead;
+  bool chain = true;   // BESSX_CHAIN=0 switches the chaining off
+  long long chain_queued = 0, chain_hits = 0, chain_dead = 0, chain_mismatch = 0;
+  int fit_serial = 0;
   unsigned char *stage_h = nullptr;  // pinned staging for init vectors
   // host statistics
   std::vector<double> x_mean_h, x_norm_h;
@@ -202,6 +219,9 @@ static hipError_t dmalloc(T **ptr, size_t count) {
 
 static void session_free(bessx_session *s) {
   if (!s) return;
+  if (std::getenv("BESSX_DEBUG"))
+    std::fprintf(stderr, "[bessx] chained fits: queued %lld, used %lld, not started %lld, mismatched %lld\n",
+                 s->chain_queued, s->chain_hits, s->chain_dead, s->chain_mismatch);
   (void)hipSetDevice(s->device);
   if (s->st) (void)hipStreamSynchronize(s->st);
   auto F = [](void *q) {
@@ -274,7 +294,8 @@ static void session_free(bessx_session *s) {
   F(s->init_idx_d);
   F(s->init_val_d);
   F(s->resblk);
-  if (s->res_h) (void)hipHostFree(s->res_h);
+  for (auto q : s->res_buf)
+    if (q) (void)hipHostFree(q);
   if (s->pub_flag) (void)hipHostFree(s->pub_flag);
   if (s->stage_h) (void)hipHostFree(s->stage_h);
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
@@ -360,6 +381,11 @@ static int alloc_cov_cache(bessx_session *s) {
 
 // forget every cached quantity that outlives a fit: a path call starts from nothing, like bessCpp
 static int reset_path_caches(bessx_session *s) {
+  if (s->ahead.armed) {
+    s->ahead.armed = false;
+    HIPX(hipStreamSynchronize(s->st));
+  }
+  s->hint.on = false;
   for (auto &c : s->cache) c.valid = false;
   s->dev_state_rs = -1;
   for (auto &g : s->gcache) HIPX(hipMemsetAsync(g.meta, 0, 2 * sizeof(int), s->st));
@@ -757,27 +783,24 @@ static int enqueue_cox_tail(bessx_session *s, int slot, int T0, int rs) {
 // Results of the kernels queued so far.  kcopy >= 0: only the first kcopy coefficients / indices are wanted and
 // the block is published by a kernel into pinned memory (k_publish) while the host spins on its sequence number --
 // no copy engine, no interrupt.  kcopy < 0 (or BESSX_PUBLISH=0): plain asynchronous copy + stream synchronisation.
-static int read_results(bessx_session *s, int kcopy = -1) {
-  if (kcopy < 0 || !s->publish) {
-    HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
-    HIPX(hipStreamSynchronize(s->st));
-    return 0;
-  }
-  const unsigned long long want = ++s->pub_seq;
-  volatile unsigned long long *flag = s->pub_flag;
-  HIPX(launch_publish(s->resblk, s->res_h, 128, (size_t)((unsigned char *)s->sse - s->resblk), 2 * s->n_sse_blk,
+static int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq) {
+  *seq = ++s->pub_seq;
+  HIPX(launch_publish(s->resblk, s->res_buf[buf], 128, (size_t)((unsigned char *)s->sse - s->resblk), 2 * s->n_sse_blk,
                       (size_t)((unsigned char *)s->b_cur - s->resblk), (size_t)((unsigned char *)s->A_cur - s->resblk),
-                      std::min(kcopy, s->capA), s->pub_flag, want, s->st));
+                      std::min(kcopy, s->capA), s->pub_flag + 8 * buf, *seq, s->st));
+  return 0;
+}
+
+static int publish_wait(bessx_session *s, int buf, unsigned long long want) {
+  volatile unsigned long long *flag = s->pub_flag + 8 * buf;
+  s->res_h = s->res_buf[buf];
   for (unsigned spins = 1;; spins++) {
-    if (*flag == want) break;
+    if (*flag >= want) break;
     if ((spins & 0x3ff) == 0) {
       hipError_t q = hipStreamQuery(s->st);
       if (q == hipSuccess) {
-        if (*flag == want) break;
-        // finished but the flag is not visible: fall back to the copy path
-        HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
-        HIPX(hipStreamSynchronize(s->st));
-        return 0;
+        if (*flag >= want) break;
+        return fail(BESSX_ERR_HIP, "read_results: the published result block did not become visible");
       }
       if (q != hipErrorNotReady) return fail(BESSX_ERR_HIP, std::string("read_results: ") + hipGetErrorString(q));
     }
@@ -789,6 +812,17 @@ static int read_results(bessx_session *s, int kcopy = -1) {
   return 0;
 }
 
+static int read_results(bessx_session *s, int kcopy = -1) {
+  if (kcopy < 0 || !s->publish) {
+    s->res_h = s->res_buf[0];
+    HIPX(hipMemcpyAsync(s->res_h, s->resblk, s->res_bytes, hipMemcpyDeviceToHost, s->st));
+    HIPX(hipStreamSynchronize(s->st));
+    return 0;
+  }
+  unsigned long long want = 0;
+  if (int rc = publish_enqueue(s, kcopy, 0, &want)) return rc;
+  return publish_wait(s, 0, want);
+}
 static int read_results(bessx_session *s, int kcopy);
 
 // --------------------------------------------------------------------------------------------
@@ -964,6 +998,27 @@ static int algorithm_fit_grouped(bessx_session *s) {
   return 0;
 }
 
+// Queue the first batch of the fit the path function announced (hint) behind the fit `parent`: it starts on the
+// device only if that fit ends on a repeated active set with fresh score sums (k_fit_continue, chained).
+static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, int rs, int parent, int buf, int batch) {
+  const int Tn = hint.T0;
+  if (!(hint.on && s->chain && s->publish && s->warm_start && !s->trace.on && rs == 0 && s->cov_mode && Tn >= 1 &&
+        Tn <= s->cap && Tn + 2 * COV_R <= s->cov_C && topk_supported(s->p, Tn)))
+    return 0;
+  bessx_session::Ahead &ah = s->ahead;
+  s->chain_queued++;
+  ah.armed = true;
+  ah.T0 = Tn;
+  ah.lambda = hint.lambda;
+  ah.rs = rs;
+  ah.serial = ++s->fit_serial;
+  ah.buf = buf;
+  HIPX(launch_fit_continue(s->ctrl, Tn, s->hist, s->st, ah.serial, 1, parent));
+  for (int b = 0, sl = 1; b < batch && sl <= s->max_iter; b++, sl++)
+    if (int rc = enqueue_lm_slot_cov(s, sl, Tn, hint.lambda, rs, sl == 1)) return rc;
+  return publish_enqueue(s, Tn, buf, &ah.seq);
+}
+
 // One Algorithm::fit with the state set by the update_* style members of the session.
 static int algorithm_fit(bessx_session *s) {
   if (s->grouped) return algorithm_fit_grouped(s);
@@ -987,15 +1042,46 @@ static int algorithm_fit(bessx_session *s) {
   // (Cox keeps its state vectors once per session, not per row set, so it only reuses within one row set.)
   // covariance-update form of the score pass for this fit (LM; the cache must be able to hold the active set)
   const bool cov = s->cov_mode && !glm && T0 + 2 * COV_R <= s->cov_C && k_init + 2 * COV_R <= s->cov_C;
-  const bool use_cache = cc.valid && cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx &&
-                         cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs) &&
-                         (glm || cc.cov_layout == cov);
+  bool use_cache = cc.valid && cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx &&
+                   cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs) && (glm || cc.cov_layout == cov);
   if (cox) s->cox_state_rs = rs;
   cc.valid = false;
+  // A chained fit may already be queued (or finished) behind the previous one: it is this fit if the path function
+  // asked for exactly what it announced; otherwise the device state can no longer be trusted to be the previous
+  // fit's result and everything is set up again from the host's copy.
+  const bessx_session::Hint hint = s->hint;
+  s->hint.on = false;
+  bool ahead_hit = false;
+  int my_buf = 0, ahead_serial = 0;
+  if (s->ahead.armed) {
+    s->ahead.armed = false;
+    const bessx_session::Ahead mine = s->ahead;
+    if (cov && use_cache && s->dev_state_rs == rs && mine.T0 == T0 && mine.lambda == lambda && mine.rs == rs &&
+        !s->trace.on) {
+      // keep the chain going: the fit after this one goes in before this one's result is awaited
+      if (int rc = enqueue_chained(s, hint, rs, mine.serial, mine.buf ^ 1, 2)) return rc;
+      if (int rc = publish_wait(s, mine.buf, mine.seq)) return rc;
+      // serial mismatch: the device did not start this fit (its gate failed); the state is still the previous
+      // fit's, the fit chained behind it cannot have started either
+      ahead_hit = reinterpret_cast<const FitCtrl *>(s->res_h)->serial == mine.serial;
+      if (!ahead_hit) s->ahead.armed = false;
+      (ahead_hit ? s->chain_hits : s->chain_dead)++;
+      my_buf = mine.buf;
+      ahead_serial = mine.serial;
+    } else {
+      HIPX(hipStreamSynchronize(s->st));
+      s->dev_state_rs = -1;
+      use_cache = false;
+      s->chain_mismatch++;
+    }
+  }
+  const int my_serial = ahead_hit ? ahead_serial : ++s->fit_serial;
   hipError_t e = hipSuccess;
-  if (use_cache && s->dev_state_rs == rs) {
+  if (ahead_hit) {
+    // nothing to queue: the first batch of this fit is running or done
+  } else if (use_cache && s->dev_state_rs == rs) {
     // the device still holds exactly these coefficients (previous fit of the chain): no upload, no re-initialisation
-    e = launch_fit_continue(s->ctrl, T0, s->hist, s->st);
+    e = launch_fit_continue(s->ctrl, T0, s->hist, s->st, my_serial, 0);
   } else {
     int *st_idx = reinterpret_cast<int *>(s->stage_h);
     double *st_val = reinterpret_cast<double *>(s->stage_h + (size_t)s->capA * sizeof(int));
@@ -1037,11 +1123,29 @@ static int algorithm_fit(bessx_session *s) {
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
   int slot = 1, batch = 2;  // warm-started fits usually stop after 2 iterations
   std::vector<std::pair<size_t, bool>> k1_pairs;
+  bool have_results = ahead_hit;
+  if (ahead_hit) slot = 1 + std::min(batch, s->max_iter);
   while (!glm && cov) {
-    for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
-      if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1)) return rc;
-    if (int rc = read_results(s, T0)) return rc;
+    if (!have_results) {
+      const bool first_batch = slot == 1;
+      for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
+        if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1)) return rc;
+      if (!s->publish) {
+        if (int rc = read_results(s, T0)) return rc;
+      } else {
+        unsigned long long seq = 0;
+        if (int rc = publish_enqueue(s, T0, my_buf, &seq)) return rc;
+        // chain the announced next fit of the warm-start path behind this one before waiting for this one
+        if (first_batch)
+          if (int rc = enqueue_chained(s, hint, rs, my_serial, my_buf ^ 1, batch)) return rc;
+        if (int rc = publish_wait(s, my_buf, seq)) return rc;
+      }
+    }
+    have_results = false;
+    hc = reinterpret_cast<const FitCtrl *>(s->res_h);
     if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
+    // the chained fit only starts if this one ended here with fresh score sums
+    if (s->ahead.armed && !(hc->done && hc->d_fresh && !hc->info)) s->ahead.armed = false;
     if (hc->cov_stall) {
       if (int rc = cov_unpark(s, hc, T0, lambda, rs, &slot)) return rc;
       continue;
@@ -1053,6 +1157,7 @@ static int algorithm_fit(bessx_session *s) {
     HIPX(launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, hc->l, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                          s->st, 2));
     if (int rc = read_results(s, T0)) return rc;
+    hc = reinterpret_cast<const FitCtrl *>(s->res_h);
   }
   if (cov) {
     s->cov_panel_groups += hc->cov_groups;
@@ -1284,6 +1389,19 @@ static int sequential_path(bessx_session *s, const int *seq, int ns, const doubl
   for (int i = 0; i < ns; i++) {
     int step = (i % 2 == 0) ? 1 : -1;
     for (int j = (i % 2 == 0) ? 0 : nl - 1; j < nl && j >= 0; j += step) {
+      {
+        // announce the fit that follows in the snake order (src/path.cpp:36-50): it can be chained on the device
+        int jn = j + step, in = i;
+        if (jn < 0 || jn >= nl) {
+          in = i + 1;
+          jn = (in % 2 == 0) ? 0 : nl - 1;
+        }
+        s->hint.on = in < ns && !is_cv;
+        if (s->hint.on) {
+          s->hint.T0 = seq[in];
+          s->hint.lambda = lam[jn];
+        }
+      }
       if (int rc = run_fit(s, seq[i], lam[j], beta_init, coef0_init)) return rc;
       if (s->warm_start) {
         beta_init = s->beta;
@@ -2059,11 +2177,17 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     s->sse = reinterpret_cast<double *>(s->resblk + o_sse);
     s->b_cur = reinterpret_cast<double *>(s->resblk + o_b);
     s->A_cur = reinterpret_cast<int *>(s->resblk + o_a);
-    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->res_h), off));
-    std::memset(s->res_h, 0, off);
-    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->pub_flag), 64));
-    *s->pub_flag = 0ull;
+    for (int b = 0; b < 2; b++) {
+      HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->res_buf[b]), off));
+      std::memset(s->res_buf[b], 0, off);
+    }
+    s->res_h = s->res_buf[0];
+    HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->pub_flag), 128));
+    s->pub_flag[0] = 0ull;
+    s->pub_flag[8] = 0ull;  // second buffer's flag, its own cache line
     if (const char *ev = std::getenv("BESSX_PUBLISH")) s->publish = std::atoi(ev) != 0;
+    if (const char *ev = std::getenv("BESSX_CHAIN")) s->chain = std::atoi(ev) != 0;
+    if (!s->publish) s->chain = false;
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), (size_t)capA * (sizeof(int) + sizeof(double))));
   }
   static_assert(sizeof(FitCtrl) <= 128, "FitCtrl must fit its slot of the result block");

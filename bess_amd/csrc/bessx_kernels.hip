@@ -1060,8 +1060,16 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
 
 // Start of a fit whose initial coefficients ARE the device state left by the previous fit (warm-start chain on
 // one row set): nothing to upload, only the loop bookkeeping is reset.
-__global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl, int T0, int *__restrict__ hist) {
+// chained = 1: queued BEHIND the previous fit of a warm-start chain before the host has seen its result; it only
+// starts if that fit has ended on a repeated active set with its score-pass sums fresh (exactly the condition under
+// which the host would have issued it), otherwise it -- and with it all its slots -- does nothing.
+__global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl, int T0, int *__restrict__ hist,
+                                                      int serial, int chained, int parent) {
+  if (chained && !(ctrl->serial == parent && ctrl->done && ctrl->d_fresh && ctrl->l >= 0 && !ctrl->cov_stall &&
+                   !ctrl->info))
+    return;
   for (int i = threadIdx.x; i < T0; i += 256) hist[i] = 0;
+  __syncthreads();
   if (threadIdx.x == 0) {
     ctrl->done = 0;
     ctrl->l = 0;
@@ -1076,6 +1084,7 @@ __global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl
     ctrl->cov_groups = 0;
     ctrl->cov_miss = 0;
     ctrl->cov_nmiss = 0;
+    ctrl->serial = serial;
   }
 }
 
@@ -2955,8 +2964,9 @@ hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_i
   return hipSuccess;
 }
 
-hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st) {
-  hipLaunchKernelGGL(k_fit_continue, dim3(1), dim3(256), 0, st, ctrl, T0, hist);
+hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st, int serial, int chained,
+                               int parent) {
+  hipLaunchKernelGGL(k_fit_continue, dim3(1), dim3(256), 0, st, ctrl, T0, hist, serial, chained, parent);
   LAUNCH_CHECK();
   return hipSuccess;
 }
