@@ -54,9 +54,21 @@ hipError_t launch_xtv_variant(int variant, const double *X, long ld, int p, cons
 hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
                         const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
                         double *bd, const FitCtrl *ctrl, int slot, hipStream_t st);
+// k_topk2 can end with the work of k_cov_need (covariance form of the LM fit) when the scores fit one chunk
+struct TopkNeed {
+  const double *bd;
+  double *bd2;
+  int p;
+  int C;
+  int *slot_of, *meta, *fcols;
+  FitCtrl *ctrl;
+  const int *A_cur;
+};
+bool topk_can_fuse_need(int len);
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
-                       hipStream_t st, const int *run_flag = nullptr);
+                       hipStream_t st, const int *run_flag = nullptr, const TopkNeed *need = nullptr);
 bool topk_supported(int len, int k);
+void topk_set_variant(int v);  // test / benchmark hook: 0 = bit-by-bit search, 1 = radix search (default)
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
                        double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st, int tile_base = 0);

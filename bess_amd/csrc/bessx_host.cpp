@@ -624,11 +624,18 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   else  // d of exactly these coefficients is in memory (previous fit of the chain); lambda may have changed
     e = launch_score(s->part_rs[rs], nullptr, 1, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
                      s->always, s->bd, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
-  // repeated-set test + cache lookup; parks the fit when a column of A_new is not cached
-  if (e == hipSuccess)
-    e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C,
-                        s->cov_fcols, s->ctrl, slot, s->A_cur, s->st);
+  // top-k, then the repeated-set test + cache lookup (parks the fit when a column of A_new is not cached) -- in the
+  // same launch when the scores fit one chunk of the selection kernel
+  if (e == hipSuccess && topk_can_fuse_need(s->p)) {
+    TopkNeed nd = {cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, s->cov_C, cv.slot_of, cv.meta, s->cov_fcols,
+                   s->ctrl, s->A_cur};
+    e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
+  } else if (e == hipSuccess) {
+    e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+    if (e == hipSuccess)
+      e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C,
+                          s->cov_fcols, s->ctrl, slot, s->A_cur, s->st);
+  }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot_cov: ") + hipGetErrorString(e));
   return enqueue_cov_tail(s, slot, T0, lambda, rs);
 }
@@ -2710,6 +2717,43 @@ int bessx_op_topk(const double *score, int len, int k, int *out_idx) {
   HIPX(hipMemcpy(ds, score, (size_t)len * sizeof(double), hipMemcpyHostToDevice));
   HIPX(launch_topk(ds, len, k, dout, dcand, nullptr, 0, nullptr));
   HIPX(hipMemcpy(out_idx, dout, (size_t)k * sizeof(int), hipMemcpyDeviceToHost));
+  return BESSX_OK;
+}
+
+int bessx_op_topk_bench(int len, int k, int variant, int repeats, double *avg_us) {
+  if (int rc = need_device()) return rc;
+  if (len < 1 || k < 1 || k > len || repeats < 1 || !avg_us) return fail(BESSX_ERR_ARG, "op_topk_bench: bad arguments");
+  if (!topk_supported(len, k)) return fail(BESSX_ERR_UNSUPPORTED, "op_topk_bench: len / k combination needs a third level");
+  Scratch sc;
+  double *ds;
+  int *dout, *dcand;
+  HIPX(sc.alloc(&ds, (size_t)len));
+  HIPX(sc.alloc(&dout, (size_t)k));
+  HIPX(sc.alloc(&dcand, (size_t)32768));
+  std::vector<double> h((size_t)len);
+  std::mt19937_64 g(7);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  for (auto &v : h) {
+    const double z = nd(g);
+    v = z * z;
+  }
+  HIPX(hipMemcpy(ds, h.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice));
+  topk_set_variant(variant);
+  hipEvent_t e0, e1;
+  HIPX(hipEventCreate(&e0));
+  HIPX(hipEventCreate(&e1));
+  hipError_t e = launch_topk(ds, len, k, dout, dcand, nullptr, 0, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+  for (int i = 0; i < repeats && e == hipSuccess; i++) e = launch_topk(ds, len, k, dout, dcand, nullptr, 0, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  topk_set_variant(1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIPX(e);
+  *avg_us = 1e3 * (double)ms / repeats;
   return BESSX_OK;
 }
 

@@ -284,11 +284,19 @@ __device__ __forceinline__ unsigned long long score_key(double v) {
   return (b >> 63) ? 0ull : b;  // -0.0 / negative (never produced) -> smallest
 }
 
+template <int NT>
+__device__ void cov_need_body(const int *__restrict__ list, int len, const double *__restrict__ bd,
+                              double *__restrict__ bd2, int p, int *__restrict__ slot_of, int *__restrict__ meta, int C,
+                              int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
+                              const int *__restrict__ A_cur);
+
+// nd.slot_of != nullptr (covariance form of the LM fit, single chunk): the kernel ends with the work of k_cov_need on
+// the indices it has just selected -- one launch less per PDAS iteration.
 template <int EB>  // keys per thread this instance can hold (bucket of ceil(len / 1024))
 __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score, const int *__restrict__ idx_in,
                                                int len_total, int chunk, int k, int *__restrict__ out,
                                                int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
-                                               int slot, const int *__restrict__ run_flag) {
+                                               int slot, const int *__restrict__ run_flag, const TopkNeed nd) {
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
   if (run_flag != nullptr && *run_flag == 0) return;
   __shared__ int wcnt[2][16];
@@ -380,6 +388,10 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     }
   }
   if (tid == 0 && out_count != nullptr) out_count[blockIdx.x] = kk;
+  if (nd.slot_of != nullptr) {
+    __syncthreads();  // the selected indices are visible to the whole block
+    cov_need_body<1024>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2330,19 +2342,18 @@ __device__ __forceinline__ bool cov_gate(const FitCtrl *ctrl, int slot) {
 // PARKED (cov_stall = 1, l = -1 - l: every gated kernel of this and the following slots falls through) and the host,
 // which sees the flag in its next read-back, issues the fill and the rest of the slot.  slot == 0: start of a fit,
 // the request is the initial support and the host has already queued a fill for it.
-__global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, int len,
-                                                  const double *__restrict__ bd, double *__restrict__ bd2, int p,
-                                                  int *__restrict__ slot_of, int *__restrict__ meta, int C,
-                                                  int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
-                                                  const int *__restrict__ A_cur) {
-  if (ctrl->done || (slot == 0 ? ctrl->l != 0 : ctrl->l != slot - 1)) return;
-  __shared__ int wsum[4];
+template <int NT>
+__device__ void cov_need_body(const int *__restrict__ list, int len, const double *__restrict__ bd,
+                              double *__restrict__ bd2, int p, int *__restrict__ slot_of, int *__restrict__ meta, int C,
+                              int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
+                              const int *__restrict__ A_cur) {
+  __shared__ int wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (slot > 0) {
     int diff = 1;
     if (ctrl->l >= 1 && ctrl->k_cur == len) {
       diff = 0;
-      for (int i = tid; i < len; i += 256) diff |= (list[i] != A_cur[i]);
+      for (int i = tid; i < len; i += NT) diff |= (list[i] != A_cur[i]);
     }
     diff = __syncthreads_or(diff);
     if (tid == 0) ctrl->same_prev = diff ? 0 : 1;
@@ -2350,12 +2361,12 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
   }
   int count = meta[0];
   if (count + len + COV_R > C) {  // no room: start the cache over (uniform branch)
-    for (int j = tid; j < p; j += 256) slot_of[j] = -1;
+    for (int j = tid; j < p; j += NT) slot_of[j] = -1;
     count = 0;
     __syncthreads();
   }
   int nm = 0;
-  for (int base = 0; base < len; base += 256) {
+  for (int base = 0; base < len; base += NT) {
     const int i = base + tid;
     const int col = i < len ? list[i] : -1;
     const int miss = (col >= 0 && slot_of[col] < 0) ? 1 : 0;
@@ -2369,7 +2380,7 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
     __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < NT / 64; w++) {
       off += (w < wave) ? wsum[w] : 0;
       tot += wsum[w];
     }
@@ -2389,10 +2400,19 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
     }
   }
   if (spec) {
-    for (int j = tid; j < p; j += 256) bd2[j] = slot_of[j] >= 0 ? -1.0 : bd[j];
+    for (int j = tid; j < p; j += NT) bd2[j] = slot_of[j] >= 0 ? -1.0 : bd[j];
     __syncthreads();
-    for (int i = tid; i < nm; i += 256) bd2[fcols[i]] = -1.0;
+    for (int i = tid; i < nm; i += NT) bd2[fcols[i]] = -1.0;
   }
+}
+
+__global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, int len,
+                                                  const double *__restrict__ bd, double *__restrict__ bd2, int p,
+                                                  int *__restrict__ slot_of, int *__restrict__ meta, int C,
+                                                  int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
+                                                  const int *__restrict__ A_cur) {
+  if (ctrl->done || (slot == 0 ? ctrl->l != 0 : ctrl->l != slot - 1)) return;
+  cov_need_body<256>(list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot, A_cur);
 }
 
 // Final fill list: the missing columns, then speculative ones (the best-scoring uncached columns, `extras`) up to
@@ -2820,13 +2840,17 @@ hipError_t launch_score(const double *part, const double *part2, int nrb, int p,
 
 // two-level selection: chunks of <= 32768 scores each keep their k best, a final block selects from the
 // concatenated candidates (already in ascending index order).  cand must hold nchunk*k ints.
+void topk_set_variant(int) {}  // one selection kernel; kept for the benchmark entry point
+
 static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_in, int len, int chunk, int k,
                                   int *out, const FitCtrl *ctrl, int slot, hipStream_t st,
-                                  const int *run_flag = nullptr) {
+                                  const int *run_flag = nullptr, const TopkNeed *need = nullptr) {
+  TopkNeed nd = {};
+  if (need) nd = *need;
   const int per = (std::min(len, chunk) + 1023) / 1024;
 #define TOPK_GO(EB)                                                                                              \
   hipLaunchKernelGGL(k_topk<EB>, dim3(nblk), dim3(1024), 0, st, score, idx_in, len, chunk, k, out, (int *)nullptr, \
-                     ctrl, slot, run_flag)
+                     ctrl, slot, run_flag, nd)
   if (per <= 2)
     TOPK_GO(2);
   else if (per <= 4)
@@ -2842,10 +2866,13 @@ static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_
   return hipSuccess;
 }
 
+bool topk_can_fuse_need(int len) { return len <= 1024 * TOPK_E; }
+
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
-                       hipStream_t st, const int *run_flag) {
+                       hipStream_t st, const int *run_flag, const TopkNeed *need) {
   const int chunk = 1024 * TOPK_E;
-  if (len <= chunk) return launch_topk_one(1, score, nullptr, len, chunk, k, out, ctrl, slot, st, run_flag);
+  if (len <= chunk) return launch_topk_one(1, score, nullptr, len, chunk, k, out, ctrl, slot, st, run_flag, need);
+  if (need != nullptr) return hipErrorInvalidValue;  // callers check topk_can_fuse_need()
   int nchunk = (len + chunk - 1) / chunk;
   long ncand = (long)nchunk * k;
   if (ncand > chunk || k > chunk) return hipErrorInvalidValue;  // would need a third level
