@@ -640,6 +640,31 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+// broadcast lane j (0..15, a constant after unrolling) of every 16-lane row to the whole row: DPP row_newbcast,
+// two VALU moves per double, no trip through SGPRs
+__device__ __forceinline__ int dpp_row_share(int v, int j) {
+  switch (j & 15) {
+    case 0: return __builtin_amdgcn_update_dpp(0, v, 0x150, 0xF, 0xF, false);
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x151, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x152, 0xF, 0xF, false);
+    case 3: return __builtin_amdgcn_update_dpp(0, v, 0x153, 0xF, 0xF, false);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x154, 0xF, 0xF, false);
+    case 5: return __builtin_amdgcn_update_dpp(0, v, 0x155, 0xF, 0xF, false);
+    case 6: return __builtin_amdgcn_update_dpp(0, v, 0x156, 0xF, 0xF, false);
+    case 7: return __builtin_amdgcn_update_dpp(0, v, 0x157, 0xF, 0xF, false);
+    case 8: return __builtin_amdgcn_update_dpp(0, v, 0x158, 0xF, 0xF, false);
+    case 9: return __builtin_amdgcn_update_dpp(0, v, 0x159, 0xF, 0xF, false);
+    case 10: return __builtin_amdgcn_update_dpp(0, v, 0x15A, 0xF, 0xF, false);
+    case 11: return __builtin_amdgcn_update_dpp(0, v, 0x15B, 0xF, 0xF, false);
+    case 12: return __builtin_amdgcn_update_dpp(0, v, 0x15C, 0xF, 0xF, false);
+    case 13: return __builtin_amdgcn_update_dpp(0, v, 0x15D, 0xF, 0xF, false);
+    case 14: return __builtin_amdgcn_update_dpp(0, v, 0x15E, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xF, 0xF, false);
+  }
+}
+__device__ __forceinline__ double row_bcast16(double v, int j) {
+  return __hiloint2double(dpp_row_share(__double2hiint(v), j), dpp_row_share(__double2loint(v), j));
+}
 // element idx (lane-dependent) of a register array without dynamic indexing
 __device__ __forceinline__ double bcast_pick16(const double (&a)[16], int idx) {
   double r = a[0];
@@ -711,32 +736,48 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
     }
     __syncthreads();
   }
+  // tiles are dealt round-robin: slot s of this wave is tile t = 8 s + wave of the packed lower triangle.  All
+  // loads are issued first (they land in the accumulators), the fix-ups follow.
+  {
+    int ti, tj;
+    tile_of(wave, ti, tj);
+#pragma unroll
+    for (int s = 0; s < CH_SLOTS; s++) {
+      const bool have = s * CH_W + wave < ntiles;
+      tI[s] = have ? ti : -1;
+      tJ[s] = have ? tj : -1;
+      tj += CH_W;
+      while (tj > ti) {
+        tj -= ti + 1;
+        ti++;
+      }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < CH_SLOTS; s++) {
-    int t = s * CH_W + wave;
-    tI[s] = -1;
-    tJ[s] = -1;
     acc[s] = d4{0.0, 0.0, 0.0, 0.0};
-    if (t < ntiles) {
-      tile_of(t, tI[s], tJ[s]);
-      double gv[4];
+    if (tI[s] >= 0) {
       if (fz.G != nullptr) {
         const int col = tJ[s] * 16 + lc;
         const int sl = col < m ? sS[col] : 0;
         if (sl < 0) fz.ctrl->cov_miss = 1;  // must not happen: the active columns were cached before this launch
         const double *gcol = fz.G + (size_t)(sl < 0 ? 0 : sl) * fz.p;
+        double gv[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = tI[s] * 16 + lq + 4 * r;
           gv[r] = (row < m && col < m && sl >= 0) ? gcol[sA[row]] : 0.0;
         }
+        acc[s] = d4{gv[0], gv[1], gv[2], gv[3]};
       } else {
-        const d4 g = *reinterpret_cast<const d4 *>(Gt + (size_t)t * 256 + lane * 4);
-        gv[0] = g.x;
-        gv[1] = g.y;
-        gv[2] = g.z;
-        gv[3] = g.w;
+        acc[s] = *reinterpret_cast<const d4 *>(Gt + (size_t)(s * CH_W + wave) * 256 + lane * 4);
       }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < CH_SLOTS; s++) {
+    if (tI[s] >= 0) {
+      double gv[4] = {acc[s].x, acc[s].y, acc[s].z, acc[s].w};
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         int row = tI[s] * 16 + lq + 4 * r, col = tJ[s] * 16 + lc;
@@ -771,24 +812,30 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
       }
     __syncthreads();
     // 2+3. EVERY wave factors the 16x16 diagonal block redundantly in registers (lane holds row lane&15;
-    // pivots and multipliers are broadcast with v_readlane, so the 16-step chain needs no LDS round trips and no
-    // barrier before the substitution), then does the 16-step substitution x * Lbb^T = p for its own rows with
-    // the L entries as scalar operands.  Wave 0 also stores Lbb (for the backward solve and the owner of tile (b,b)).
+    // pivots and multipliers are broadcast inside each 16-lane row with DPP row_newbcast, so the 16-step chain needs
+    // no LDS round trips, no SGPR traffic and no barrier before the substitution; 1/sqrt(pivot) comes from v_rsq_f64
+    // + two Newton steps instead of a square root and a division), then does the 16-step substitution
+    // x * Lbb^T = p for its own rows with the L entries broadcast the same way.  Wave 0 also stores Lbb (for the backward solve and the owner of tile (b,b)).
     {
       const int D = pb + b * TS, rr = lane & 15;
-      double Lr[16], rinv[16];
+      double Lr[16], rinv_mine = 0.0;  // lane j keeps 1 / L[j][j]
 #pragma unroll
       for (int c = 0; c < 16; c++) Lr[c] = Psh[D + rr * CH_LDT + c];
 #pragma unroll
       for (int j = 0; j < 16; j++) {
-        const double pjj = bcast_lane(Lr[j], j);
-        const double d = sqrt(pjj);
-        rinv[j] = bcast_lane(1.0 / d, 0);  // wave-uniform: keep it in SGPRs
-        if (wave == 0 && lane == j) Rsh[b * 16 + j] = rinv[j];
-        const double lij = (rr == j) ? d : Lr[j] * rinv[j];  // rows < j hold unused upper-triangle values
+        const double pjj = row_bcast16(Lr[j], j);
+        // 1/sqrt(pjj): hardware estimate + two Newton steps; sqrt(pjj) from it with one correction
+        double r = __builtin_amdgcn_rsq(pjj);
+        r = fma(0.5 * r, fma(-pjj * r, r, 1.0), r);
+        r = fma(0.5 * r, fma(-pjj * r, r, 1.0), r);
+        double d = pjj * r;
+        d = fma(fma(-d, d, pjj), 0.5 * r, d);
+        if (rr == j) rinv_mine = r;
+        if (wave == 0 && lane == j) Rsh[b * 16 + j] = r;
+        const double lij = (rr == j) ? d : Lr[j] * r;  // rows < j hold unused upper-triangle values
         Lr[j] = lij;
 #pragma unroll
-        for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, bcast_lane(lij, c), Lr[c]);
+        for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, row_bcast16(lij, c), Lr[c]);
       }
       if (wave == 0 && lane < 16) {
 #pragma unroll
@@ -798,7 +845,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
         }
       }
       const int nrows = (mt - b - 1) * 16;
-      if (tid < nrows) {
+      if (tid < nrows) {  // a multiple of 16: every 16-lane row is either fully active or idle
         const int pr = pb + (b + 1 + (tid >> 4)) * TS + (tid & 15) * CH_LDT;
         double x[16];
 #pragma unroll
@@ -807,8 +854,8 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
         for (int j = 0; j < 16; j++) {
           double sacc = x[j];
 #pragma unroll
-          for (int t = 0; t < j; t++) sacc = fma(-x[t], bcast_lane(Lr[t], j), sacc);  // L[j][t] lives in lane j
-          x[j] = sacc * rinv[j];
+          for (int t = 0; t < j; t++) sacc = fma(-x[t], row_bcast16(Lr[t], j), sacc);  // L[j][t] lives in lane j
+          x[j] = sacc * row_bcast16(rinv_mine, j);
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) Psh[pr + j] = x[j];

@@ -4,9 +4,10 @@
    because its active set repeated (nearly always a fixed point of the PDAS map), the training loss
    decreases along the nested part of the path, the IC matches its formula, the true support is recovered at
    k = k_true, and the golden-section path selects the same model as the exhaustive sequential path.
-2. If tests/golden/fullsize_lm.npz is present (generated in the build container from the COMPILED REFERENCE by
-   tests/golden/make_fullsize_ref.py -- about two CPU-hours), the active set of every PDAS iteration of all 200
-   candidates, the coefficients, losses and ICs are compared with it.
+2. tests/golden/fullsize_lm.npz (generated in the build container from the COMPILED REFERENCE by
+   tests/golden/make_fullsize_ref.py: 10038 s of one CPU core for the 200 candidates): the active set of every
+   PDAS iteration (421) of all 200 candidates, the coefficients, losses and ICs are compared with it, in both
+   score-pass forms.
 """
 import os
 
@@ -19,10 +20,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "fullsize_lm.npz")
 
 
-@pytest.fixture(scope="module")
-def full(gpu):
+@pytest.fixture(scope="module", params=[2, 1], ids=["covariance", "streaming"])
+def full(gpu, request):
+    """Both evaluations of the score pass (include/bessx.h, score_mode) at full size."""
     X, y, support, beta = synth.make_lm()
-    s = gpu.Session(X, y)
+    s = gpu.Session(X, y, score_mode=request.param)
     s.trace_enable(True)
     out = s.sequential_path(np.arange(1, 201), ic_type=3)
     yield gpu, s, out, support, (X, y)
