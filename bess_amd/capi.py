@@ -26,7 +26,7 @@ SYMBOLS = [
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
-    "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench",
+    "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
         L.bessx_op_stream_copy_gbps.argtypes = [_ll, _i, _D]
         L.bessx_op_xtv_bench.argtypes = [_i, _i, _i, _i, _D, _D]
         L.bessx_op_topk_bench.argtypes = [_i, _i, _i, _i, _D]
+        L.bessx_op_chol_bench.argtypes = [_i, _i, _D]
         _lib = L
     return _lib
 
@@ -372,6 +373,12 @@ def op_stream_copy_gbps(nbytes=1 << 30, repeats=10):
     g = _d(0)
     _check(lib().bessx_op_stream_copy_gbps(nbytes, repeats, ctypes.byref(g)))
     return g.value
+
+
+def op_chol_bench(m, repeats=200):
+    us = _d(0)
+    _check(lib().bessx_op_chol_bench(m, repeats, ctypes.byref(us)))
+    return us.value
 
 
 def op_topk_bench(length, k, variant=1, repeats=200):

@@ -2847,6 +2847,50 @@ int bessx_op_chol_solve(const double *a, int m, const double *b, double *sol) {
   return BESSX_OK;
 }
 
+int bessx_op_chol_bench(int m, int repeats, double *avg_us) {
+  if (int rc = need_device()) return rc;
+  if (m < 1 || m > T0_FAST || repeats < 1 || !avg_us) return fail(BESSX_ERR_ARG, "op_chol_bench: need 1 <= m <= 254");
+  Scratch sc;
+  const int mt = (m + 1 + 15) / 16, ntiles = mt * (mt + 1) / 2;
+  // a well conditioned matrix: 4 I + small symmetric off-diagonal entries
+  std::vector<double> ht((size_t)ntiles * 256, 0.0);
+  for (int I = 0; I < mt; I++)
+    for (int J = 0; J <= I; J++) {
+      int t = I * (I + 1) / 2 + J;
+      for (int lane = 0; lane < 64; lane++)
+        for (int r = 0; r < 4; r++) {
+          int row = I * 16 + (lane >> 4) + 4 * r, col = J * 16 + (lane & 15);
+          if (row < m && col < m)
+            ht[(size_t)t * 256 + lane * 4 + r] = row == col ? 4.0 : 0.01 * std::cos(0.37 * (row + 1) * (col + 1));
+        }
+    }
+  double *Gt, *drhs, *dsol;
+  int *dinfo;
+  HIPX(sc.alloc(&Gt, ht.size()));
+  HIPX(sc.alloc(&drhs, (size_t)m));
+  HIPX(sc.alloc(&dsol, (size_t)m));
+  HIPX(sc.alloc(&dinfo, 1));
+  HIPX(hipMemset(dinfo, 0, sizeof(int)));
+  HIPX(hipMemcpy(Gt, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPX(launch_fill(drhs, m, 1.0, nullptr));
+  hipEvent_t e0, e1;
+  HIPX(hipEventCreate(&e0));
+  HIPX(hipEventCreate(&e1));
+  hipError_t e = launch_chol(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, 0, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+  for (int i = 0; i < repeats && e == hipSuccess; i++)
+    e = launch_chol(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, 0, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIPX(e);
+  *avg_us = 1e3 * (double)ms / repeats;
+  return BESSX_OK;
+}
+
 int bessx_op_normalize(double *x, int n, int p, double *y, const double *weight, int data_type, int is_normal,
                        int add_weight, double *x_mean, double *x_norm, double *y_mean) {
   if (int rc = need_device()) return rc;

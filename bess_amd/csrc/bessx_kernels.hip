@@ -691,7 +691,7 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
 // fz.G != nullptr (covariance mode of the LM fit): the Gram entries are gathered from the column cache
 // (G[row A_a, column slot_of[A_b]]) instead of read from Gt, and the kernel ends with the work of k_commit -- two
 // launches less per PDAS iteration.
-template <int CH_SLOTS>  // register tiles per wave: 5 (mt <= 8), 10 (mt <= 12), 17 (mt <= 16)
+template <int CH_SLOTS>  // register tiles per wave: 5 (mt <= 8), 7 (<= 10), 10 (<= 12), 14 (<= 14), 17 (<= 16)
 __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int m, int mt, double ridge,
                                               int ridge_skip0, const double *__restrict__ rhs,
                                               const int *__restrict__ rhs_gather, double *__restrict__ sol,
@@ -741,11 +741,13 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
   {
     int ti, tj;
     tile_of(wave, ti, tj);
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
 #pragma unroll
     for (int s = 0; s < CH_SLOTS; s++) {
       const bool have = s * CH_W + wave < ntiles;
-      tI[s] = have ? ti : -1;
-      tJ[s] = have ? tj : -1;
+      tI[s] = __builtin_amdgcn_readfirstlane(have ? ti : -1);  // wave-uniform: keep the tile indices in SGPRs
+      tJ[s] = __builtin_amdgcn_readfirstlane(have ? tj : -1);
       tj += CH_W;
       while (tj > ti) {
         tj -= ti + 1;
@@ -817,48 +819,93 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
     // + two Newton steps instead of a square root and a division), then does the 16-step substitution
     // x * Lbb^T = p for its own rows with the L entries broadcast the same way.  Wave 0 also stores Lbb (for the backward solve and the owner of tile (b,b)).
     {
-      const int D = pb + b * TS, rr = lane & 15;
-      double Lr[16], rinv_mine = 0.0;  // lane j keeps 1 / L[j][j]
-#pragma unroll
-      for (int c = 0; c < 16; c++) Lr[c] = Psh[D + rr * CH_LDT + c];
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
-        const double pjj = row_bcast16(Lr[j], j);
-        // 1/sqrt(pjj): hardware estimate + two Newton steps; sqrt(pjj) from it with one correction
-        double r = __builtin_amdgcn_rsq(pjj);
-        r = fma(0.5 * r, fma(-pjj * r, r, 1.0), r);
-        r = fma(0.5 * r, fma(-pjj * r, r, 1.0), r);
-        double d = pjj * r;
-        d = fma(fma(-d, d, pjj), 0.5 * r, d);
-        if (rr == j) rinv_mine = r;
-        if (wave == 0 && lane == j) Rsh[b * 16 + j] = r;
-        const double lij = (rr == j) ? d : Lr[j] * r;  // rows < j hold unused upper-triangle values
-        Lr[j] = lij;
-#pragma unroll
-        for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, row_bcast16(lij, c), Lr[c]);
-      }
-      if (wave == 0 && lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          Psh[D + rr * CH_LDT + c] = Lr[c];
-          Lsh[b * TS + rr * CH_LDT + c] = Lr[c];
-        }
-      }
-      const int nrows = (mt - b - 1) * 16;
-      if (tid < nrows) {  // a multiple of 16: every 16-lane row is either fully active or idle
-        const int pr = pb + (b + 1 + (tid >> 4)) * TS + (tid & 15) * CH_LDT;
-        double x[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = Psh[pr + j];
-#pragma unroll
+      if constexpr (CH_SLOTS <= 10) {
+        // DPP form: fewer instructions, but the broadcast values live in VGPRs -- affordable up to 10 tile slots
+        const int D = pb + b * TS, rr = lane & 15;
+        double Lr[16], rinv_mine = 0.0;  // lane j keeps 1 / L[j][j]
+  #pragma unroll
+        for (int c = 0; c < 16; c++) Lr[c] = Psh[D + rr * CH_LDT + c];
+  #pragma unroll
         for (int j = 0; j < 16; j++) {
-          double sacc = x[j];
-#pragma unroll
-          for (int t = 0; t < j; t++) sacc = fma(-x[t], row_bcast16(Lr[t], j), sacc);  // L[j][t] lives in lane j
-          x[j] = sacc * row_bcast16(rinv_mine, j);
+          const double pjj = row_bcast16(Lr[j], j);
+          // 1/sqrt(pjj): hardware estimate + two Newton steps; sqrt(pjj) from it with one correction
+          double r = __builtin_amdgcn_rsq(pjj);
+          r = fma(0.5 * r, fma(-pjj * r, r, 1.0), r);
+          r = fma(0.5 * r, fma(-pjj * r, r, 1.0), r);
+          double d = pjj * r;
+          d = fma(fma(-d, d, pjj), 0.5 * r, d);
+          if (rr == j) rinv_mine = r;
+          if (wave == 0 && lane == j) Rsh[b * 16 + j] = r;
+          const double lij = (rr == j) ? d : Lr[j] * r;  // rows < j hold unused upper-triangle values
+          Lr[j] = lij;
+  #pragma unroll
+          for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, row_bcast16(lij, c), Lr[c]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of later steps from being hoisted (VGPR pressure)
         }
-#pragma unroll
-        for (int j = 0; j < 16; j++) Psh[pr + j] = x[j];
+        if (wave == 0 && lane < 16) {
+  #pragma unroll
+          for (int c = 0; c < 16; c++) {
+            Psh[D + rr * CH_LDT + c] = Lr[c];
+            Lsh[b * TS + rr * CH_LDT + c] = Lr[c];
+          }
+        }
+        const int nrows = (mt - b - 1) * 16;
+        if (tid < nrows) {  // a multiple of 16: every 16-lane row is either fully active or idle
+          const int pr = pb + (b + 1 + (tid >> 4)) * TS + (tid & 15) * CH_LDT;
+          double x[16];
+  #pragma unroll
+          for (int j = 0; j < 16; j++) x[j] = Psh[pr + j];
+  #pragma unroll
+          for (int j = 0; j < 16; j++) {
+            double sacc = x[j];
+  #pragma unroll
+            for (int t = 0; t < j; t++) sacc = fma(-x[t], row_bcast16(Lr[t], j), sacc);  // L[j][t] lives in lane j
+            x[j] = sacc * row_bcast16(rinv_mine, j);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+  #pragma unroll
+          for (int j = 0; j < 16; j++) Psh[pr + j] = x[j];
+        }
+      } else {
+        // 17 tile slots leave no VGPRs to spare: broadcasts go through SGPRs (v_readlane), sqrt + reciprocal
+        const int D = pb + b * TS, rr = lane & 15;
+        double Lr[16], rinv[16];
+  #pragma unroll
+        for (int c = 0; c < 16; c++) Lr[c] = Psh[D + rr * CH_LDT + c];
+  #pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const double pjj = bcast_lane(Lr[j], j);
+          const double d = sqrt(pjj);
+          rinv[j] = bcast_lane(1.0 / d, 0);  // wave-uniform: keep it in SGPRs
+          if (wave == 0 && lane == j) Rsh[b * 16 + j] = rinv[j];
+          const double lij = (rr == j) ? d : Lr[j] * rinv[j];  // rows < j hold unused upper-triangle values
+          Lr[j] = lij;
+  #pragma unroll
+          for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, bcast_lane(lij, c), Lr[c]);
+        }
+        if (wave == 0 && lane < 16) {
+  #pragma unroll
+          for (int c = 0; c < 16; c++) {
+            Psh[D + rr * CH_LDT + c] = Lr[c];
+            Lsh[b * TS + rr * CH_LDT + c] = Lr[c];
+          }
+        }
+        const int nrows = (mt - b - 1) * 16;
+        if (tid < nrows) {
+          const int pr = pb + (b + 1 + (tid >> 4)) * TS + (tid & 15) * CH_LDT;
+          double x[16];
+  #pragma unroll
+          for (int j = 0; j < 16; j++) x[j] = Psh[pr + j];
+  #pragma unroll
+          for (int j = 0; j < 16; j++) {
+            double sacc = x[j];
+  #pragma unroll
+            for (int t = 0; t < j; t++) sacc = fma(-x[t], bcast_lane(Lr[t], j), sacc);  // L[j][t] lives in lane j
+            x[j] = sacc * rinv[j];
+          }
+  #pragma unroll
+          for (int j = 0; j < 16; j++) Psh[pr + j] = x[j];
+        }
       }
     }
     __syncthreads();
@@ -2988,15 +3035,21 @@ hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_
   if (mt > CH_MT) return hipErrorInvalidValue;  // callers route larger systems to launch_chol_big
   CholFuse fz = {};
   if (fuse) fz = *fuse;
+  // register tiles per wave = ceil(mt (mt + 1) / 2 / 8): the smallest instance that fits (fewer live accumulators)
+#define CHOL_GO(S)                                                                                                   \
+  hipLaunchKernelGGL(k_chol<S>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info, \
+                     ctrl, slot, gate_mode, fz)
   if (mt <= 8)
-    hipLaunchKernelGGL(k_chol<5>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info,
-                       ctrl, slot, gate_mode, fz);
+    CHOL_GO(5);
+  else if (mt <= 10)
+    CHOL_GO(7);
   else if (mt <= 12)
-    hipLaunchKernelGGL(k_chol<10>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
-                       info, ctrl, slot, gate_mode, fz);
+    CHOL_GO(10);
+  else if (mt <= 14)
+    CHOL_GO(14);
   else
-    hipLaunchKernelGGL(k_chol<17>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
-                       info, ctrl, slot, gate_mode, fz);
+    CHOL_GO(17);
+#undef CHOL_GO
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -190,6 +190,8 @@ int bessx_op_xtv(const double *x, int n, int p, int ld, const double *v, const d
 int bessx_op_topk(const double *score, int len, int k, int *out_idx);
 /* timing of the top-k kernel on synthetic chi-square scores; variant 0 = bit-by-bit search, 1 = radix search */
 int bessx_op_topk_bench(int len, int k, int variant, int repeats, double *avg_us);
+/* timing of the register-resident Cholesky solve (k_chol) for an m x m system, 1 <= m <= 254 */
+int bessx_op_chol_bench(int m, int repeats, double *avg_us);
 /* K6: out (m x m, column-major, full symmetric) = X_A^T diag(w) X_A for the m columns cols[] of x;
  * w may be NULL (src/Algorithm.h:1134,1171,1199,1299). */
 int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m, const double *w, double *out);
