@@ -2752,30 +2752,50 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
                                                double n_t, double lambda, const unsigned char *__restrict__ always,
                                                double *__restrict__ bd, const FitCtrl *__restrict__ ctrl, int slot) {
   if (ctrl->done || ctrl->l != slot - 1) return;
-  __shared__ double sm[4][64];
+  // 32 columns x 8 thread groups per block; group g adds the active columns i = g, g+8, ... (two interleaved
+  // accumulators), the 8 partial sums are added in group order: a fixed summation tree.
+  constexpr int CHUNK = 512;  // active columns staged per round: cache slots and coefficients go through LDS
+  __shared__ int s_sl[CHUNK];
+  __shared__ double s_b[CHUNK];
+  __shared__ double sm[8][32];
   const int kc = ctrl->k_cur;
-  const int jj = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + jj;
-  double acc = 0.0;
-  if (j < p)
-    for (int i = g; i < kc; i += 4) {
-      const int sl = slot_of[A_cur[i]];
-      if (sl >= 0)
-        acc += G[(size_t)sl * p + j] * b_cur[i];
-      else
-        const_cast<FitCtrl *>(ctrl)->cov_miss = 1;  // must not happen: active columns are cached before use
+  const int jj = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jj;
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int base = 0; base < kc; base += CHUNK) {
+    const int cnt = min(CHUNK, kc - base);
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const int sl = slot_of[A_cur[base + i]];
+      if (sl < 0) const_cast<FitCtrl *>(ctrl)->cov_miss = 1;  // must not happen: active columns are cached before use
+      s_sl[i] = sl;
+      s_b[i] = sl < 0 ? 0.0 : b_cur[base + i];
     }
-  sm[g][jj] = acc;
+    __syncthreads();
+    if (j < p) {
+      int i = g;
+      for (; i + 8 < cnt; i += 16) {
+        const double g0 = G[(size_t)max(s_sl[i], 0) * p + j], g1 = G[(size_t)max(s_sl[i + 8], 0) * p + j];
+        acc0 = fma(g0, s_b[i], acc0);
+        acc1 = fma(g1, s_b[i + 8], acc1);
+      }
+      if (i < cnt) acc0 = fma(G[(size_t)max(s_sl[i], 0) * p + j], s_b[i], acc0);
+    }
+    __syncthreads();
+  }
+  sm[g][jj] = acc0 + acc1;
   __syncthreads();
   if (g == 0 && j < p) {
-    const double s1 = xty[j] - (((sm[0][jj] + sm[1][jj]) + sm[2][jj]) + sm[3][jj]);
+    double t = sm[0][jj];
+#pragma unroll
+    for (int q = 1; q < 8; q++) t += sm[q][jj];
+    const double s1 = xty[j] - t;
     d_out[j] = s1;
     const double b = beta_dense[j];
     const double d = s1 / n_t - 2.0 * lambda * b;
     const double phi = sqrt(2.0 * lambda + xtx[j] / n_t);
     const double inv = 1.0 / phi;
-    const double t = phi * b + inv * d;
-    double v = t * t;
+    const double tt = phi * b + inv * d;
+    double v = tt * tt;
     if (always != nullptr && always[j]) v = DBL_MAX;
     bd[j] = v;
   }
@@ -3454,7 +3474,7 @@ hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double
                         const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,
                         double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
                         hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_d, dim3((p + 63) / 64), dim3(256), 0, st, G, p, slot_of, xty, A_cur, b_cur, d_out,
+  hipLaunchKernelGGL(k_cov_d, dim3((p + 31) / 32), dim3(256), 0, st, G, p, slot_of, xty, A_cur, b_cur, d_out,
                      beta_dense, xtx, n_t, lambda, always, bd, ctrl, slot);
   LAUNCH_CHECK();
   return hipSuccess;
