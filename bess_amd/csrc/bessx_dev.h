@@ -36,6 +36,9 @@ struct FitCtrl {
   int cov_miss;    // internal error flag: an active column was not in the Gram column cache
   int cov_nmiss;   // columns of the requested set that are not cached (set by k_cov_need)
   int serial;      // which fit this block describes (set by k_fit_continue; the host checks it for chained fits)
+  int sse_valid;   // sse_dot / sse_nrm belong to the current coefficients (set by the fused k_chol)
+  double sse_dot;  // beta . X^T(m y) of the last solve
+  double sse_nrm;  // |beta|^2 of the last solve
 };
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
@@ -106,7 +109,8 @@ hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, cons
                          double *hist_coef0, int hist_stride, hipStream_t st);
 hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
-                           double *sse, hipStream_t st, int mode = 0);
+                           double *sse, hipStream_t st, int mode = 0, int kc_given = 0, double c0_given = 0.0);
+hipError_t launch_dot(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_glm_eta_gh(int fam, const double *X, long ld, int n, const double *y, const double *w,
                              const double *mask, const double *logfact, const FitCtrl *ctrl, int when,
                              const int *A_cur, const double *b_cur, double *g, double *h, double *stats,

@@ -113,6 +113,7 @@ struct bessx_session {
   };
   std::vector<RsCache> cache;
   std::vector<int> n_train;
+  std::vector<double> yy_h;  // per row set: sum m_i y_i^2 of the prepared response (LM loss from the solved system)
   int K = 0;
   // work space
   double *part2 = nullptr, *bd = nullptr, *beta_dense = nullptr, *sol = nullptr;
@@ -485,6 +486,15 @@ static int prepare_rowset(bessx_session *s, int rs) {
   const double *v2 = m ? m : s->aux + s->ld;
   hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->tmpv, v2, s->part_rs[rs], s->part2, nullptr, 0, s->st);
   if (e == hipSuccess) e = launch_part_sum(s->part_rs[rs], s->nrb, s->p, s->xty[rs], s->st);
+  if (e == hipSuccess) {
+    // y . (m y): the loss of an LM fit is y.y - beta.q - ridge |beta|^2 once (G + ridge I) beta = q is solved
+    e = launch_dot(s->tmpv, s->y, s->ld, s->bd, s->st);  // bd is scratch here
+    double v = 0.0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&v, s->bd, sizeof(double), hipMemcpyDeviceToHost, s->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+    if ((int)s->yy_h.size() <= rs) s->yy_h.resize(rs + 1, 0.0);
+    s->yy_h[rs] = v;
+  }
   if (e == hipSuccess) e = launch_part_sum(s->part2, s->nrb, s->p, s->xtx[rs], s->st);
   if (e == hipSuccess && s->grouped)  // group_XTX blocks, src/utilities.cpp:153-165
     e = launch_group_moments(s->gmax, s->X, s->ld, s->n, m, nullptr, s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs],
@@ -606,7 +616,9 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
                     &fz);
   }
-  if (e == hipSuccess)  // only the final coefficients' sums of squares are needed: runs iff the fit ended here
+  // CV row sets need the sums of squares over the test rows too: one pass over the active columns for the final
+  // coefficients (runs iff the fit ended here).  On all rows the loss comes from the solved system (k_chol).
+  if (e == hipSuccess && (rs != 0 || mt > 16))
     e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
                         s->sse, s->st, 1);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cov_tail: ") + hipGetErrorString(e));
@@ -1159,7 +1171,7 @@ static int algorithm_fit(bessx_session *s) {
     }
     if (hc->done || slot > s->max_iter) break;
   }
-  if (cov && !hc->done) {
+  if (cov && !hc->done && (rs != 0 || (T0 + 1 + 15) / 16 > 16)) {
     // out of iterations: the sums of squares of the last coefficients have not been formed yet
     HIPX(launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, hc->l, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                          s->st, 2));
@@ -1221,9 +1233,37 @@ static int algorithm_fit(bessx_session *s) {
   s->coef0 = hc->coef0;
   s->l = hc->done ? hc->l : s->max_iter + 1;
   double tr = 0.0, te = 0.0;
-  for (int b = 0; b < s->n_sse_blk; b++) {
-    tr += sse_h[2 * b];
-    te += sse_h[2 * b + 1];
+  const int mt_fit = (T0 + 1 + 15) / 16;
+  if (cov && rs == 0 && mt_fit <= 16) {
+    // all rows, covariance form: no residual was formed.  (G + lambda I) beta = q was solved by k_chol, so
+    // |y - X beta|^2 = y.y - beta.q - lambda |beta|^2.  If no solve of this fit produced the coefficients (a fit that
+    // repeats its starting set at once) or the difference cancels badly (a near-perfect fit), one pass over the
+    // active columns with the final coefficients gives the sum directly.
+    const double yy = s->yy_h[0];
+    tr = yy - hc->sse_dot - lambda * hc->sse_nrm;
+    if (!hc->sse_valid || !(tr > 1e-6 * yy)) {
+      HIPX(hipStreamSynchronize(s->st));  // a chained fit may be running on the device state: use the host's copy
+      int *st_idx = reinterpret_cast<int *>(s->stage_h);
+      double *st_val = reinterpret_cast<double *>(s->stage_h + (size_t)s->capA * sizeof(int));
+      for (int i = 0; i < T0; i++) {
+        st_idx[i] = s->beta.idx[i];
+        st_val[i] = s->beta.val[i];
+      }
+      HIPX(hipMemcpy(s->init_idx_d, st_idx, T0 * sizeof(int), hipMemcpyHostToDevice));
+      HIPX(hipMemcpy(s->init_val_d, st_val, T0 * sizeof(double), hipMemcpyHostToDevice));
+      HIPX(launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->init_idx_d, s->init_val_d, s->tmpv,
+                           s->sse, s->st, 3, T0, s->coef0));
+      std::vector<double> part((size_t)2 * s->n_sse_blk);
+      HIPX(hipMemcpyAsync(part.data(), s->sse, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->st));
+      HIPX(hipStreamSynchronize(s->st));
+      tr = 0.0;
+      for (int b = 0; b < s->n_sse_blk; b++) tr += part[2 * b];
+    }
+  } else {
+    for (int b = 0; b < s->n_sse_blk; b++) {
+      tr += sse_h[2 * b];
+      te += sse_h[2 * b + 1];
+    }
   }
   s->sse_train = tr;
   s->sse_test = te;

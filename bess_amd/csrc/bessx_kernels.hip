@@ -971,9 +971,37 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
     bad = !(fabs(v) <= DBL_MAX);
   }
   if (__syncthreads_or(bad) && tid == 0 && info != nullptr) *info = 1;
-  if (fz.G != nullptr)  // sol is visible to the whole block after the barrier above
+  if (fz.G != nullptr) {  // sol is visible to the whole block after the barrier above
+    // beta . X^T(m y) and |beta|^2 of the solved system: with (G + ridge I) beta = q the residual sum of squares is
+    // y.y - beta.q - ridge |beta|^2, so the host needs no pass over X for the loss (fixed-order block sums)
+    double t1 = 0.0, t2 = 0.0;
+    if (tid < m) {
+      const double v = z[tid];
+      t1 = v * rhs[rhs_gather[tid]];
+      t2 = v * v;
+    }
+    t1 = wave_sum(t1);
+    t2 = wave_sum(t2);
+    __syncthreads();
+    if (lane == 0) {
+      Rsh[wave] = t1;
+      Rsh[8 + wave] = t2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < CH_W; w++) {
+        a1 += Rsh[w];
+        a2 += Rsh[8 + w];
+      }
+      fz.ctrl->sse_dot = a1;
+      fz.ctrl->sse_nrm = a2;
+      fz.ctrl->sse_valid = 1;
+    }
     commit_body(fz.ctrl, slot, fz.T0, rhs_gather, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
                 fz.hist_coef0, fz.hist_stride, &same_any_sh);
+  }
 #undef WAVE_SYNC
 }
 
@@ -1161,6 +1189,7 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
     ctrl->cov_groups = 0;
     ctrl->cov_miss = 0;
     ctrl->cov_nmiss = 0;
+    ctrl->sse_valid = 0;
   }
 }
 
@@ -1190,6 +1219,7 @@ __global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl
     ctrl->cov_groups = 0;
     ctrl->cov_miss = 0;
     ctrl->cov_nmiss = 0;
+    ctrl->sse_valid = 0;
     ctrl->serial = serial;
   }
 }
@@ -1278,17 +1308,19 @@ __global__ void __launch_bounds__(512) k_resid_lm(const double *__restrict__ X, 
                                                   const double *__restrict__ y, const double *__restrict__ mask,
                                                   const FitCtrl *__restrict__ ctrl, int when,
                                                   const int *__restrict__ A_cur, const double *__restrict__ b_cur,
-                                                  double *__restrict__ r, double *__restrict__ sse, int mode) {
+                                                  double *__restrict__ r, double *__restrict__ sse, int mode,
+                                                  int kc_given, double c0_given) {
   // mode 0 (streaming score pass: r feeds the next pass): after every commit; same_prev: beta, r, sums unchanged.
   // mode 1 (covariance updates: only the sums of squares of the FINAL coefficients are needed): when the fit ended
   // in this slot; mode 2: the fit ran out of iterations without ending (host issues it after the last slot).
   if (mode == 0 && (ctrl->l != when || (when > 0 && ctrl->same_prev))) return;
   if (mode == 1 && (ctrl->l != when || !ctrl->done)) return;
   if (mode == 2 && (ctrl->l != when || ctrl->done)) return;
+  // mode 3: unconditional (host issues it for the rare fit whose loss cannot be taken from the solved system)
   __shared__ d2 part[3][128];
   __shared__ double sm[2][2];
-  const int kc = ctrl->k_cur;
-  const double c0 = ctrl->coef0;
+  const int kc = mode == 3 ? kc_given : ctrl->k_cur;  // mode 3: coefficients handed in by the host
+  const double c0 = mode == 3 ? c0_given : ctrl->coef0;
   // block b owns rows [256 b, 256 b + 256) (ld is a multiple of 128 rows): 128 row threads x 2 rows, times 4 thread
   // groups that each take every 4th active column; the 4 partial sums are added in group order (fixed tree)
   const int rt = threadIdx.x & 127, g = threadIdx.x >> 7;
@@ -2846,6 +2878,16 @@ __global__ void __launch_bounds__(256) k_publish(const unsigned char *__restrict
   if (tid == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// out[0] = sum_i a_i b_i (b may be null: sum a_i^2... no: sum a_i a_i), one block, fixed order
+__global__ void __launch_bounds__(256) k_dot(const double *__restrict__ a, const double *__restrict__ b, long n,
+                                             double *__restrict__ out) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) s = fma(a[i], b ? b[i] : a[i], s);
+  s = block_sum_256(s, sm);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
 // streaming copy used to measure the practical HBM ceiling
 __global__ void __launch_bounds__(256) k_copy(const d2 *__restrict__ src, d2 *__restrict__ dst, long n2) {
   long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -3130,10 +3172,10 @@ hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, cons
 
 hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
-                           double *sse, hipStream_t st, int mode) {
+                           double *sse, hipStream_t st, int mode, int kc_given, double c0_given) {
   int nblk = (int)((ld + 255) / 256);
   hipLaunchKernelGGL(k_resid_lm, dim3(nblk), dim3(512), 0, st, X, ld, n, y, mask, ctrl, when, A_cur, b_cur, r, sse,
-                     mode);
+                     mode, kc_given, c0_given);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3493,6 +3535,12 @@ hipError_t launch_publish(const unsigned char *dev, unsigned char *host, int ctr
                           hipStream_t st) {
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, dev, host, ctrl_bytes, off_sse, n_sse, off_b, off_a, kcopy,
                      seq_host, seq);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_dot(const double *a, const double *b, long n, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_dot, dim3(1), dim3(256), 0, st, a, b, n, out);
   LAUNCH_CHECK();
   return hipSuccess;
 }
