@@ -3011,10 +3011,20 @@ static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_
     TOPK_GO(2);
   else if (per <= 4)
     TOPK_GO(4);
+  else if (per <= 6)
+    TOPK_GO(6);
   else if (per <= 8)
     TOPK_GO(8);
+  else if (per <= 10)
+    TOPK_GO(10);
+  else if (per <= 12)
+    TOPK_GO(12);
   else if (per <= 16)
     TOPK_GO(16);
+  else if (per <= 20)
+    TOPK_GO(20);
+  else if (per <= 24)
+    TOPK_GO(24);
   else
     TOPK_GO(32);
 #undef TOPK_GO
