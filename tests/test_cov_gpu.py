@@ -65,6 +65,23 @@ def test_large_sparsity_levels_in_covariance_mode(gpu):
     both_modes(gpu, X, y, kw, P.trace(X, y, **kw), "large k")
 
 
+def test_wide_matrix_two_level_topk(gpu):
+    """p > 32768: the selection kernel runs in two levels and the cache lookup is its own launch."""
+    X, y, _, _ = synth.make_lm(600, 40000, 12)
+    kw = dict(ic_type=3, sequence=np.arange(1, 21))
+    both_modes(gpu, X, y, kw, P.trace(X, y, **kw), "wide")
+
+
+def test_chained_fits_on_a_lambda_grid_and_short_paths(gpu):
+    """The chained warm-start path (snake order over a lambda grid, max_iter = 1 and 2, a single candidate)."""
+    X, y, _, _ = synth.make_lm(900, 400, 9)
+    for kw in (dict(ic_type=3, sequence=np.arange(1, 13), lambda_seq=[0.0, 0.02, 0.2, 1.0]),
+               dict(ic_type=3, sequence=np.arange(1, 13), max_iter=1),
+               dict(ic_type=3, sequence=np.arange(1, 13), max_iter=2),
+               dict(ic_type=4, sequence=[7])):
+        both_modes(gpu, X, y, kw, P.trace(X, y, **kw), "chain %r" % (sorted(kw),))
+
+
 def test_score_mode_argument(gpu):
     X, y, _, _ = synth.make_logistic(300, 40, 3)
     with pytest.raises(gpu.BessxError) as e:
