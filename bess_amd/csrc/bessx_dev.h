@@ -131,7 +131,9 @@ struct CoxBufs {
   double *g, *u, *b0;                                  // k-vectors: gradient, Newton direction, iterate
   double *Gt2;                                         // second Gram (M^T diag(w delta) M) in tile layout
   double *llpart;
+  double *SCR;                                         // block totals of the multi-block scans
 };
+size_t cox_scan_scratch_doubles(long ld);
 hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,
                             const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, CoxBufs cb,
                             double *stats, hipStream_t st);

@@ -2398,6 +2398,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(V(&c.b0, 256));
     HIPT(V(&c.Gt2, (size_t)136 * 256));
     HIPT(V(&c.llpart, (size_t)(n + 255) / 256 + 1));
+    HIPT(V(&c.SCR, cox_scan_scratch_doubles(ld)));
   }
   if (s->model_type == 1) TRY(prepare_rowset(s, 0));
   HIPT(hipStreamSynchronize(s->st));
