@@ -485,8 +485,8 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
   }
 }
 
-// Sum the row-slab partials: Gt[t][e] = sum_s part[s][t][e].  A block owns 32 consecutive elements; its
-// 8 thread groups each add every 8th slab, then the 8 group sums are added in group order (fixed tree).
+// Sum the row-slab partials: Gt[t][e] = sum_s part[s][t][e].  A block owns 16 consecutive elements; its 16 thread
+// groups each add every 16th slab, then the 16 group sums are added in group order (fixed tree).
 __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ part, int nslab, int ntiles,
                                                      double *__restrict__ Gt, const FitCtrl *__restrict__ ctrl,
                                                      int slot, int gate_mode) {
@@ -496,19 +496,19 @@ __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ 
     if (gate_mode == 3 && !ctrl->gram_full) return;
     if (gate_mode == 4 && ctrl->gram_full) return;
   }
-  __shared__ double sm[8][33];
-  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  __shared__ double sm[16][17];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
   const size_t tot = (size_t)ntiles * 256;
-  const size_t e = (size_t)blockIdx.x * 32 + el;
+  const size_t e = (size_t)blockIdx.x * 16 + el;
   double s = 0.0;
   if (e < tot)
-    for (int sl = g; sl < nslab; sl += 8) s += part[(size_t)sl * tot + e];
+    for (int sl = g; sl < nslab; sl += 16) s += part[(size_t)sl * tot + e];
   sm[g][el] = s;
   __syncthreads();
   if (g == 0 && e < tot) {
     double t = sm[0][el];
 #pragma unroll
-    for (int q = 1; q < 8; q++) t += sm[q][el];
+    for (int q = 1; q < 16; q++) t += sm[q][el];
     Gt[e] = t;
   }
 }
@@ -3130,7 +3130,7 @@ hipError_t launch_gram(const double *X, const double *aux, long ld, const int *c
     hipLaunchKernelGGL(k_gram<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, cols, w, rows_per_slab, tasks, ntask,
                        nslab, part, ntiles, ctrl, slot, gate_mode, tile_base);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 31) / 32), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
+  hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 15) / 16), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
                      slot, gate_mode);
   LAUNCH_CHECK();
   return hipSuccess;
