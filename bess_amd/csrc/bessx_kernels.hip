@@ -2202,57 +2202,111 @@ __global__ void __launch_bounds__(128) k_cox_dir(const double *__restrict__ X, l
 }
 
 // trial point of the step halving: theta1 = exp(clamp(eta0 + 0.5^m UD)) on the training rows
-__global__ void __launch_bounds__(256) k_cox_ls_eval(long ld, int n, const double *__restrict__ mask,
-                                                     const FitCtrl *__restrict__ ctrl, int slot, int t, int m,
-                                                     const double *__restrict__ ETA0, const double *__restrict__ UD,
-                                                     double *__restrict__ TH1) {
-  if (COX_NEWTON_GATE(ctrl, slot, t) || ctrl->ls_done) return;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= ld) return;
-  const double step = pow(0.5, (double)m);
-  const double mm = mask ? mask[i] : 1.0;
-  TH1[i] = i < n ? exp(clampv(ETA0[i] + step * UD[i], 30.0)) * mm : 0.0;
+// Step-halving line search of one Newton step (:1474-1481), all five trial points beta0 + 0.5^m u (m = 1..5) at once:
+// the partial log-likelihood of trial m is sum_i w_i delta_i log(theta_i / S0_i) with theta = exp(clamp(eta0 + 0.5^m ud))
+// and S0 its suffix sum.  Same two-launch scan as above over five vectors that are never stored (theta is recomputed
+// in the second launch); k_cox_ls5_check then applies the reference's rule -- m = 1; while (ll0 > ll1 && m < 5) m++ --
+// and finishes the Newton step (:1482-1487).  3 launches per Newton step instead of 26.
+__device__ __forceinline__ double cox_trial_theta(double eta0, double ud, double mk, int m) {
+  const double step = m == 1 ? 0.5 : (m == 2 ? 0.25 : (m == 3 ? 0.125 : (m == 4 ? 0.0625 : 0.03125)));
+  return exp(clampv(eta0 + step * ud, 30.0)) * mk;
 }
 
-__global__ void __launch_bounds__(256) k_cox_llpart(long n, const double *__restrict__ WD,
-                                                    const double *__restrict__ TH1, const double *__restrict__ S1,
-                                                    double *__restrict__ llpart, const FitCtrl *__restrict__ ctrl,
-                                                    int slot, int t) {
-  if (COX_NEWTON_GATE(ctrl, slot, t) || ctrl->ls_done) return;
+__global__ void __launch_bounds__(SC_T) k_cox_ls5_tot(long n, const double *__restrict__ mask,
+                                                      const double *__restrict__ ETA0, const double *__restrict__ UD,
+                                                      double *__restrict__ scr, const FitCtrl *__restrict__ ctrl,
+                                                      int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   __shared__ double sm[4];
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  double v = 0.0;
-  if (i < n && WD[i] != 0.0) v = WD[i] * log(TH1[i] / S1[i]);
-  v = block_sum_256(v, sm);
-  if (threadIdx.x == 0) llpart[blockIdx.x] = v;
-}
-
-// while (loglik0 > loglik1 && m < 5) m++  (:1476-1481)
-__global__ void __launch_bounds__(256) k_cox_ls_check(FitCtrl *__restrict__ ctrl, int slot, int t, int m,
-                                                      const double *__restrict__ llpart, int nblk) {
-  if (COX_NEWTON_GATE(ctrl, slot, t) || ctrl->ls_done) return;
-  __shared__ double sm[4];
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 256) s += llpart[b];
-  s = block_sum_256(s, sm);
-  if (threadIdx.x == 0) {
-    ctrl->ll1 = s;
-    ctrl->ls_m = m;
-    if (!(ctrl->ll0 > s && m < 5)) ctrl->ls_done = 1;
+  const long r0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < SC_E; q++) {
+    const long r = r0 + q;
+    if (r < n) {
+      const long i = n - 1 - r;
+      const double e0 = ETA0[i], ud = UD[i], mk = mask ? mask[i] : 1.0;
+#pragma unroll
+      for (int m = 1; m <= 5; m++) s[m - 1] += cox_trial_theta(e0, ud, mk, m);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    double bt;
+    (void)block_excl_256(s[m], sm, &bt);
+    if (threadIdx.x == 0) scr[(size_t)m * gridDim.x + blockIdx.x] = bt;
   }
 }
 
-// end of Newton step t (:1482-1487): stop if the relative change is < 1e-5, else beta0 <- beta1
-__global__ void __launch_bounds__(256) k_cox_newton_check(FitCtrl *__restrict__ ctrl, int slot, int t, int k,
-                                                          double *__restrict__ b0, const double *__restrict__ u) {
+__global__ void __launch_bounds__(SC_T) k_cox_ls5_apply(long n, const double *__restrict__ mask,
+                                                        const double *__restrict__ ETA0,
+                                                        const double *__restrict__ UD, const double *__restrict__ WD,
+                                                        const double *__restrict__ scr, double *__restrict__ llp,
+                                                        const FitCtrl *__restrict__ ctrl, int slot, int t) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
-  const double ll0 = ctrl->ll0, ll1 = ctrl->ll1;
+  __shared__ double sm[4];
+  const long r0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
+  double th[5][SC_E], wd[SC_E];
+#pragma unroll
+  for (int q = 0; q < SC_E; q++) {
+    const long r = r0 + q;
+    wd[q] = 0.0;
+#pragma unroll
+    for (int m = 0; m < 5; m++) th[m][q] = 0.0;
+    if (r < n) {
+      const long i = n - 1 - r;
+      const double e0 = ETA0[i], ud = UD[i], mk = mask ? mask[i] : 1.0;
+      wd[q] = WD[i];
+#pragma unroll
+      for (int m = 1; m <= 5; m++) th[m - 1][q] = cox_trial_theta(e0, ud, mk, m);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    double carry = 0.0;
+    for (int j = 0; j < (int)blockIdx.x; j++) carry += scr[(size_t)m * gridDim.x + j];
+    double tt = 0.0;
+#pragma unroll
+    for (int q = 0; q < SC_E; q++) tt += th[m][q];
+    double sfx = carry + block_excl_256(tt, sm, nullptr);
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < SC_E; q++) {
+      sfx += th[m][q];
+      if (wd[q] != 0.0) v += wd[q] * log(th[m][q] / sfx);
+    }
+    double bt;
+    (void)block_excl_256(v, sm, &bt);
+    if (threadIdx.x == 0) llp[(size_t)m * gridDim.x + blockIdx.x] = bt;
+  }
+}
+
+// line-search decision + end of Newton step t: stop if the relative change is < 1e-5, else beta0 <- beta1
+__global__ void __launch_bounds__(256) k_cox_ls5_check(FitCtrl *__restrict__ ctrl, int slot, int t, int k,
+                                                       const double *__restrict__ llp, int nblk,
+                                                       double *__restrict__ b0, const double *__restrict__ u) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  __shared__ double sm[4];
+  __shared__ double ll1s[5];
+  for (int m = 0; m < 5; m++) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += llp[(size_t)m * nblk + b];
+    s = block_sum_256(s, sm);
+    if (threadIdx.x == 0) ll1s[m] = s;
+  }
+  __syncthreads();
+  const double ll0 = ctrl->ll0;
+  int m = 1;
+  while (ll0 > ll1s[m - 1] && m < 5) m++;
+  const double ll1 = ll1s[m - 1];
   const bool conv = fabs(ll0 - ll1) / fabs(0.1 + ll0) < 1e-5;
-  const double step = pow(0.5, (double)ctrl->ls_m);
+  const double step = pow(0.5, (double)m);
   if (!conv)
     for (int i = threadIdx.x; i < k; i += 256) b0[i] = b0[i] + step * u[i];
   __syncthreads();
   if (threadIdx.x == 0) {
+    ctrl->ll1 = ll1;
+    ctrl->ls_m = m;
     if (!conv) ctrl->ll0 = ll1;
     ctrl->irls_steps = t;
     ctrl->ls_done = 0;
@@ -3412,24 +3466,19 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
   hipLaunchKernelGGL(k_cox_dir, dim3(nb2), dim3(128), 0, st, X, ld, (const FitCtrl *)ctrl, slot, t, A_new, k,
                      (const double *)cb.u, cb.UD);
   LAUNCH_CHECK();
-  const int nb1 = (int)((ld + 255) / 256), nbn = (n + 255) / 256;
-  for (int m = 1; m <= 5; m++) {
-    hipLaunchKernelGGL(k_cox_ls_eval, dim3(nb1), dim3(256), 0, st, ld, n, mask, (const FitCtrl *)ctrl, slot, t, m,
-                       (const double *)cb.ETA0, (const double *)cb.UD, cb.TH1);
+  {
+    const int nbs = (int)(((long)n + SC_B - 1) / SC_B);
+    hipLaunchKernelGGL(k_cox_ls5_tot, dim3(nbs), dim3(SC_T), 0, st, (long)n, mask, (const double *)cb.ETA0,
+                       (const double *)cb.UD, cb.SCR, (const FitCtrl *)ctrl, slot, t);
     LAUNCH_CHECK();
-    {
-      hipError_t es = launch_scan3(cb.TH1, nullptr, nullptr, cb.S1, nullptr, nullptr, nullptr, (long)n, 1, 1, cb.SCR,
-                                   (const FitCtrl *)ctrl, 3, slot, t, st);
-      if (es != hipSuccess) return es;
-    }
-    hipLaunchKernelGGL(k_cox_llpart, dim3(nbn), dim3(256), 0, st, (long)n, (const double *)cb.WD,
-                       (const double *)cb.TH1, (const double *)cb.S1, cb.llpart, (const FitCtrl *)ctrl, slot, t);
+    hipLaunchKernelGGL(k_cox_ls5_apply, dim3(nbs), dim3(SC_T), 0, st, (long)n, mask, (const double *)cb.ETA0,
+                       (const double *)cb.UD, (const double *)cb.WD, (const double *)cb.SCR, cb.SCR + (size_t)5 * nbs,
+                       (const FitCtrl *)ctrl, slot, t);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cox_ls_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, m, (const double *)cb.llpart, nbn);
+    hipLaunchKernelGGL(k_cox_ls5_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, k, (const double *)(cb.SCR + (size_t)5 * nbs),
+                       nbs, cb.b0, (const double *)cb.u);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_cox_newton_check, dim3(1), dim3(256), 0, st, ctrl, slot, t, k, cb.b0, (const double *)cb.u);
-  LAUNCH_CHECK();
   return hipSuccess;
 }
 
