@@ -437,6 +437,7 @@ static int gram_tasks_for(bessx_session *s, int mt, const GramTask **tasks, int 
 static void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab, int ntiles = 0) {
   long target = 4096;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2 waves x 2
   long ns = std::max<long>(1, target / std::max(ntask, 1));
+  ns = std::min<long>(ns, 192);  // more slabs only make the fixed-order reduction of the partials longer
   ns = std::min<long>(ns, std::max<long>(1, s->ld / 64));
   if (ntiles > 0 && s->gpart_elems > 0)  // the slab partials must fit the workspace
     ns = std::max<long>(1, std::min<long>(ns, (long)(s->gpart_elems / ((size_t)ntiles * 256))));
