@@ -24,7 +24,7 @@ struct FitCtrl {
   int d_fresh;     // the score-pass partial sums in memory were computed from the CURRENT coefficients
   int irls_last;   // IRLS steps the last committed sub-model fit took (host sizes its next batch from it)
   // Cox Newton line search (src/Algorithm.h:1474-1481)
-  int ls_done;     // step halving finished for the current Newton step
+  int fast_same;   // covariance form: k_cov_d found the selection unchanged (consumed by the next k_topk)
   int ls_m;        // accepted exponent m (step 0.5^m)
   double ll1;      // partial log-likelihood at the trial point
   int gram_full;   // LM Gram cache: 1 = form the whole Gram this slot, 0 = only the rows of the new columns
@@ -66,6 +66,8 @@ struct TopkNeed {
   int *slot_of, *meta, *fcols;
   FitCtrl *ctrl;
   const int *A_cur;
+  const double *bmm;  // per-block (min inside, max outside) scores left by k_cov_d, nbmm pairs
+  int nbmm;
 };
 bool topk_can_fuse_need(int len);
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
@@ -92,6 +94,7 @@ struct CholFuse {
   int *hist;
   double *hist_beta, *hist_coef0;
   int hist_stride;
+  unsigned char *inA;  // membership flags of the active set (repeated-set shortcut of k_cov_d)
 };
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
@@ -101,12 +104,12 @@ hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_sk
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);
 hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
-                            hipStream_t st);
+                            hipStream_t st, unsigned char *inA = nullptr);
 hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st, int serial = 0, int chained = 0,
                                int parent = 0);
 hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
                          int wait_chain, int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
-                         double *hist_coef0, int hist_stride, hipStream_t st);
+                         double *hist_coef0, int hist_stride, hipStream_t st, unsigned char *inA = nullptr);
 hipError_t launch_resid_lm(const double *X, long ld, int n, const double *y, const double *mask,
                            const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, double *r,
                            double *sse, hipStream_t st, int mode = 0, int kc_given = 0, double c0_given = 0.0);
@@ -181,8 +184,8 @@ hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const 
                              int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st);
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
                         const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,
-                        double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
-                        hipStream_t st);
+                        double lambda, const unsigned char *always, double *bd, const unsigned char *inA, double *bmm,
+                        const FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int *A_new, int T0, int mt, double *Gt,
                            int *meta, const FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_publish(const unsigned char *dev, unsigned char *host, int ctrl_bytes, size_t off_sse, int n_sse,

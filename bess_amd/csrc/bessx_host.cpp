@@ -148,6 +148,8 @@ struct bessx_session {
   int cov_variant = 2;        // panel kernel: 2 = LDS-staged, single tile (3 blocks per CU); 1 = double-buffered
                               // tile (1 block per CU); 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
   double *cov_part = nullptr, *bd2 = nullptr;
+  unsigned char *inA = nullptr;        // 1 for the columns of the current active set
+  double *cov_bmm = nullptr;           // per-block min / max of k_cov_d's repeated-set shortcut
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
   std::vector<std::pair<size_t, int>> cov_timed;  // (event index, first group) of the timed panel launches
@@ -286,6 +288,8 @@ static void session_free(bessx_session *s) {
   }
   F(s->cov_part);
   F(s->bd2);
+  F(s->inA);
+  F(s->cov_bmm);
   F(s->cov_fcols);
   F(s->cov_extras);
   F(s->Rt);
@@ -556,7 +560,7 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
   }
   if (e == hipSuccess)
     e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
-                      s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+                      s->hist_beta, s->hist_coef0, s->hist_stride, s->st, s->inA);
   if (e == hipSuccess)
     e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
                         s->sse, s->st);
@@ -609,11 +613,11 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
                           s->ctrl, slot, 0, s->st);
     if (e == hipSuccess)
       e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
-                        s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+                        s->hist_beta, s->hist_coef0, s->hist_stride, s->st, s->inA);
   } else {
     // one launch: Gram gathered from the cache while loading, Cholesky + both solves, then the commit
-    CholFuse fz = {cv.G,     cv.slot_of,    s->p,    T0,           s->ctrl,       s->A_cur,
-                   s->b_cur, s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride};
+    CholFuse fz = {cv.G,     cv.slot_of,    s->p,    T0,           s->ctrl,       s->A_cur,      s->b_cur,
+                   s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->inA};
     e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
                     &fz);
   }
@@ -633,7 +637,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   hipError_t e = hipSuccess;
   if (!skip_d)  // d and the sacrifice scores in one kernel
     e = launch_cov_d(cv.G, s->p, cv.slot_of, s->xty[rs], s->A_cur, s->b_cur, s->part_rs[rs], s->beta_dense, s->xtx[rs],
-                     (double)s->n_train[rs], lambda, s->always, s->bd, s->ctrl, slot, s->st);
+                     (double)s->n_train[rs], lambda, s->always, s->bd, s->inA, s->cov_bmm, s->ctrl, slot, s->st);
   else  // d of exactly these coefficients is in memory (previous fit of the chain); lambda may have changed
     e = launch_score(s->part_rs[rs], nullptr, 1, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
                      s->always, s->bd, s->ctrl, slot, s->st);
@@ -641,7 +645,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   // same launch when the scores fit one chunk of the selection kernel
   if (e == hipSuccess && topk_can_fuse_need(s->p)) {
     TopkNeed nd = {cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, s->cov_C, cv.slot_of, cv.meta, s->cov_fcols,
-                   s->ctrl, s->A_cur};
+                   s->ctrl, s->A_cur, s->cov_bmm, (s->p + 31) / 32};
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
   } else if (e == hipSuccess) {
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
@@ -1114,7 +1118,7 @@ static int algorithm_fit(bessx_session *s) {
       HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
     }
     e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur, s->b_cur,
-                         s->beta_dense, s->p, s->hist, s->st);
+                         s->beta_dense, s->p, s->hist, s->st, s->inA);
   }
   s->dev_state_rs = rs;
   if (e == hipSuccess && !use_cache && !cov) {
@@ -2370,6 +2374,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         s->cov_nslab = (int)ns;
         HIPT(dmalloc(&s->cov_part, (size_t)COV_SLOT_GROUPS * ns * njg * cov_streamed_tiles_per_wave() * 2 * 256));
         HIPT(dmalloc(&s->bd2, (size_t)p));
+        HIPT(dmalloc(&s->inA, (size_t)p));
+        HIPT(hipMemset(s->inA, 0, (size_t)p));
+        HIPT(dmalloc(&s->cov_bmm, (size_t)2 * ((p + 31) / 32)));
         HIPT(dmalloc(&s->cov_fcols, (size_t)s->capA + 4 * COV_R));
         HIPT(dmalloc(&s->cov_extras, (size_t)COV_R));
         TRY(alloc_cov_cache(s));

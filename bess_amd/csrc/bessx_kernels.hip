@@ -300,6 +300,42 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
   if (run_flag != nullptr && *run_flag == 0) return;
   __shared__ int wcnt[2][16];
+  if (nd.slot_of != nullptr && nd.ctrl->fast_same) {
+    // k_cov_d left, per block of 32 columns, the smallest score inside the current active set and the largest
+    // outside it.  If every inside score beats every outside score (and the set has the wanted size, and this is
+    // not the first iteration of the fit) the selection returns the same set, A == A_list.col(l-1): nothing to
+    // search, nothing to look up.
+    __shared__ double rmn[16], rmx[16];
+    double mn = DBL_MAX, mx = -1.0;
+    for (int b = threadIdx.x; b < nd.nbmm; b += 1024) {
+      mn = fmin(mn, nd.bmm[2 * b]);
+      mx = fmax(mx, nd.bmm[2 * b + 1]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      mn = fmin(mn, __shfl_xor(mn, o));
+      mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      rmn[threadIdx.x >> 6] = mn;
+      rmx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    mn = rmn[0];
+    mx = rmx[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) {
+      mn = fmin(mn, rmn[w]);
+      mx = fmax(mx, rmx[w]);
+    }
+    const bool same = nd.ctrl->l >= 1 && nd.ctrl->k_cur == k && mn > mx;  // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      nd.ctrl->fast_same = 0;
+      if (same) nd.ctrl->same_prev = 1;
+    }
+    if (same) return;
+  }
   __shared__ int wsum[16];
   __shared__ int wsum2[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -686,7 +722,8 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
                                             int has_intercept, int wait_chain, int *__restrict__ A_cur,
                                             double *__restrict__ b_cur, double *__restrict__ beta_dense,
                                             int *__restrict__ hist, double *__restrict__ hist_beta,
-                                            double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh);
+                                            double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh,
+                                            unsigned char *__restrict__ inA);
 
 // fz.G != nullptr (covariance mode of the LM fit): the Gram entries are gathered from the column cache
 // (G[row A_a, column slot_of[A_b]]) instead of read from Gt, and the kernel ends with the work of k_commit -- two
@@ -703,7 +740,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
     if (ctrl->same_prev) {
       if (fz.G != nullptr)
         commit_body(fz.ctrl, slot, fz.T0, rhs_gather, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist,
-                    fz.hist_beta, fz.hist_coef0, fz.hist_stride, &same_any_sh);
+                    fz.hist_beta, fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
       return;
     }
     if ((gate_mode == 1 || gate_mode == 2) && ctrl->irls_done) return;
@@ -1000,7 +1037,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
       fz.ctrl->sse_valid = 1;
     }
     commit_body(fz.ctrl, slot, fz.T0, rhs_gather, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
-                fz.hist_coef0, fz.hist_stride, &same_any_sh);
+                fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
   }
 #undef WAVE_SYNC
 }
@@ -1165,12 +1202,14 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
                                                    const int *__restrict__ init_idx,
                                                    const double *__restrict__ init_val, double coef0_init,
                                                    int *__restrict__ A_cur, double *__restrict__ b_cur,
-                                                   double *__restrict__ beta_dense, int *__restrict__ hist) {
-  // beta_dense was zeroed by a memset node just before this launch
+                                                   double *__restrict__ beta_dense, int *__restrict__ hist,
+                                                   unsigned char *__restrict__ inA) {
+  // beta_dense (and inA) were zeroed by memset nodes just before this launch
   for (int i = threadIdx.x; i < k_init; i += 256) {
     A_cur[i] = init_idx[i];
     b_cur[i] = init_val[i];
     beta_dense[init_idx[i]] = init_val[i];
+    if (inA != nullptr) inA[init_idx[i]] = 1;
   }
   for (int i = threadIdx.x; i < T0; i += 256) hist[i] = 0;
   if (threadIdx.x == 0) {
@@ -1190,6 +1229,7 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
     ctrl->cov_miss = 0;
     ctrl->cov_nmiss = 0;
     ctrl->sse_valid = 0;
+    ctrl->fast_same = 0;
   }
 }
 
@@ -1220,6 +1260,7 @@ __global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl
     ctrl->cov_miss = 0;
     ctrl->cov_nmiss = 0;
     ctrl->sse_valid = 0;
+    ctrl->fast_same = 0;
     ctrl->serial = serial;
   }
 }
@@ -1232,7 +1273,9 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
                                             int has_intercept, int wait_chain, int *__restrict__ A_cur,
                                             double *__restrict__ b_cur, double *__restrict__ beta_dense,
                                             int *__restrict__ hist, double *__restrict__ hist_beta,
-                                            double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh) {
+                                            double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh,
+                                            unsigned char *__restrict__ inA) {
+  // inA (optional): membership flags of the current active set, kept for the repeated-set shortcut of k_cov_d
   const int nt = blockDim.x;
   const int l = slot;
   if (ctrl->same_prev) {
@@ -1253,7 +1296,10 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
   if (wait_chain && !ctrl->irls_done) return;  // IRLS / Newton chain still running: the host re-issues
   const int kc = ctrl->k_cur;
   if (threadIdx.x == 0) *same_any_sh = 0;
-  for (int i = threadIdx.x; i < kc; i += nt) beta_dense[A_cur[i]] = 0.0;
+  for (int i = threadIdx.x; i < kc; i += nt) {
+    beta_dense[A_cur[i]] = 0.0;
+    if (inA != nullptr) inA[A_cur[i]] = 0;
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < T0; i += nt) {
     int a = A_new[i];
@@ -1261,6 +1307,7 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
     A_cur[i] = a;
     b_cur[i] = b;
     beta_dense[a] = b;
+    if (inA != nullptr) inA[a] = 1;
     hist[(size_t)l * hist_stride + i] = a;
     hist_beta[(size_t)l * hist_stride + i] = b;
   }
@@ -1291,11 +1338,12 @@ __global__ void __launch_bounds__(256) k_commit(FitCtrl *__restrict__ ctrl, int 
                                                 int has_intercept, int wait_chain, int *__restrict__ A_cur,
                                                 double *__restrict__ b_cur, double *__restrict__ beta_dense,
                                                 int *__restrict__ hist, double *__restrict__ hist_beta,
-                                                double *__restrict__ hist_coef0, int hist_stride) {
+                                                double *__restrict__ hist_coef0, int hist_stride,
+                                                unsigned char *__restrict__ inA) {
   if (ctrl->done || ctrl->l != slot - 1) return;
   __shared__ int same_any;
   commit_body(ctrl, slot, T0, A_new, sol, has_intercept, wait_chain, A_cur, b_cur, beta_dense, hist, hist_beta,
-              hist_coef0, hist_stride, &same_any);
+              hist_coef0, hist_stride, &same_any, inA);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1779,9 +1827,6 @@ __device__ __forceinline__ bool cox_scan_gate_closed(const FitCtrl *ctrl, int ga
   if (gate == 1) return ctrl->l != slot || (slot > 0 && ctrl->same_prev);  // state pass after commit `slot`
   if (gate == 2)  // Newton step t
     return ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t - 1;
-  if (gate == 3)  // line-search evaluation inside Newton step t
-    return ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t - 1 ||
-           ctrl->ls_done;
   return false;
 }
 
@@ -2037,7 +2082,6 @@ __global__ void __launch_bounds__(256) k_cox_newton_begin(FitCtrl *__restrict__ 
   for (int i = threadIdx.x; i < 256; i += 256) idcols[i] = i < k ? i : -1;  // Gram columns of M, zero padding
   if (threadIdx.x == 0) {
     ctrl->ll0 = 1e5;  // :1393
-    ctrl->ls_done = 0;
     ctrl->ls_m = 0;
   }
 }
@@ -2309,7 +2353,6 @@ __global__ void __launch_bounds__(256) k_cox_ls5_check(FitCtrl *__restrict__ ctr
     ctrl->ls_m = m;
     if (!conv) ctrl->ll0 = ll1;
     ctrl->irls_steps = t;
-    ctrl->ls_done = 0;
     if (conv || t == 30) ctrl->irls_done = 1;
   }
 }
@@ -2897,7 +2940,8 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
                                                const double *__restrict__ b_cur, double *__restrict__ d_out,
                                                const double *__restrict__ beta_dense, const double *__restrict__ xtx,
                                                double n_t, double lambda, const unsigned char *__restrict__ always,
-                                               double *__restrict__ bd, const FitCtrl *__restrict__ ctrl, int slot) {
+                                               double *__restrict__ bd, const unsigned char *__restrict__ inA,
+                                               double *__restrict__ bmm, const FitCtrl *__restrict__ ctrl, int slot) {
   if (ctrl->done || ctrl->l != slot - 1) return;
   // 32 columns x 8 thread groups per block; group g adds the active columns i = g, g+8, ... (two interleaved
   // accumulators), the 8 partial sums are added in group order: a fixed summation tree.
@@ -2945,6 +2989,26 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
     double v = tt * tt;
     if (always != nullptr && always[j]) v = DBL_MAX;
     bd[j] = v;
+    // repeated-set shortcut: smallest score inside the current active set, largest outside, per block
+    sm[1][jj] = inA[j] ? v : DBL_MAX;
+    sm[2][jj] = inA[j] ? -1.0 : v;
+  } else if (g == 0) {
+    sm[1][jj] = DBL_MAX;
+    sm[2][jj] = -1.0;
+  }
+  __syncthreads();
+  // If every score of the current active set beats every score outside it, max_k returns the same set.  Each block
+  // leaves its two extremes in bmm; the selection kernel that follows combines them (min / max are exact, so the
+  // order does not matter) and skips its search when the test holds.  fast_same = 1 marks bmm as fresh.
+  if (threadIdx.x == 0) {
+    double mn = DBL_MAX, mx = -1.0;
+    for (int q = 0; q < 32; q++) {
+      mn = fmin(mn, sm[1][q]);
+      mx = fmax(mx, sm[2][q]);
+    }
+    bmm[2 * blockIdx.x] = mn;
+    bmm[2 * blockIdx.x + 1] = mx;
+    if (blockIdx.x == 0) const_cast<FitCtrl *>(ctrl)->fast_same = 1;
   }
 }
 
@@ -3269,11 +3333,12 @@ hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_sk
 
 hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
-                            hipStream_t st) {
+                            hipStream_t st, unsigned char *inA) {
   hipError_t e = hipMemsetAsync(beta_dense, 0, (size_t)p * sizeof(double), st);
+  if (e == hipSuccess && inA != nullptr) e = hipMemsetAsync(inA, 0, (size_t)p, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fit_begin, dim3(1), dim3(256), 0, st, ctrl, T0, k_init, init_idx, init_val, coef0_init, A_cur,
-                     b_cur, beta_dense, hist);
+                     b_cur, beta_dense, hist, inA);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3287,10 +3352,9 @@ hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st,
 
 hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,
                          int wait_chain, int *A_cur, double *b_cur, double *beta_dense, int *hist, double *hist_beta,
-                         double *hist_coef0, int hist_stride, hipStream_t st) {
+                         double *hist_coef0, int hist_stride, hipStream_t st, unsigned char *inA) {
   hipLaunchKernelGGL(k_commit, dim3(1), dim3(256), 0, st, ctrl, slot, T0, A_new, sol, has_intercept, wait_chain, A_cur,
-                     b_cur,
-                     beta_dense, hist, hist_beta, hist_coef0, hist_stride);
+                     b_cur, beta_dense, hist, hist_beta, hist_coef0, hist_stride, inA);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3661,10 +3725,10 @@ hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const 
 
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
                         const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,
-                        double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
-                        hipStream_t st) {
+                        double lambda, const unsigned char *always, double *bd, const unsigned char *inA, double *bmm,
+                        const FitCtrl *ctrl, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_cov_d, dim3((p + 31) / 32), dim3(256), 0, st, G, p, slot_of, xty, A_cur, b_cur, d_out,
-                     beta_dense, xtx, n_t, lambda, always, bd, ctrl, slot);
+                     beta_dense, xtx, n_t, lambda, always, bd, inA, bmm, ctrl, slot);
   LAUNCH_CHECK();
   return hipSuccess;
 }
