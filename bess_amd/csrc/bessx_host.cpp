@@ -108,6 +108,7 @@ struct bessx_session {
   struct RsCache {
     bool valid = false;  // part_rs / r_rs belong to exactly (beta, coef0) below
     bool cov_layout = false;  // part_rs holds d itself (covariance mode), not row-block partial sums
+    double lambda = 0.0;      // covariance mode: the scores in bd were formed with this lambda
     SparseVec beta;
     double coef0 = 0.0;
   };
@@ -632,10 +633,15 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
 
 static bool cov_speculates(const bessx_session *s) { return topk_supported(s->p, COV_R) && s->p >= 2 * COV_R; }
 
-static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d) {
+// skip_d: d of exactly the starting coefficients is in memory (previous fit of the chain); scores_ok: so are the
+// sacrifice scores (same lambda), nothing to recompute before the selection.
+static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d,
+                               bool scores_ok = false) {
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
-  if (!skip_d)  // d and the sacrifice scores in one kernel
+  if (skip_d && scores_ok) {
+    // the last k_cov_d of the previous fit left bd for these coefficients and this lambda
+  } else if (!skip_d)  // d and the sacrifice scores in one kernel
     e = launch_cov_d(cv.G, s->p, cv.slot_of, s->xty[rs], s->A_cur, s->b_cur, s->part_rs[rs], s->beta_dense, s->xtx[rs],
                      (double)s->n_train[rs], lambda, s->always, s->bd, s->inA, s->cov_bmm, s->ctrl, slot, s->st);
   else  // d of exactly these coefficients is in memory (previous fit of the chain); lambda may have changed
@@ -1024,7 +1030,8 @@ static int algorithm_fit_grouped(bessx_session *s) {
 
 // Queue the first batch of the fit the path function announced (hint) behind the fit `parent`: it starts on the
 // device only if that fit ends on a repeated active set with fresh score sums (k_fit_continue, chained).
-static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, int rs, int parent, int buf, int batch) {
+static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, int rs, int parent, int buf, int batch,
+                           double parent_lambda) {
   const int Tn = hint.T0;
   if (!(hint.on && s->chain && s->publish && s->warm_start && !s->trace.on && rs == 0 && s->cov_mode && Tn >= 1 &&
         Tn <= s->cap && Tn + 2 * COV_R <= s->cov_C && topk_supported(s->p, Tn)))
@@ -1039,7 +1046,7 @@ static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, in
   ah.buf = buf;
   HIPX(launch_fit_continue(s->ctrl, Tn, s->hist, s->st, ah.serial, 1, parent));
   for (int b = 0, sl = 1; b < batch && sl <= s->max_iter; b++, sl++)
-    if (int rc = enqueue_lm_slot_cov(s, sl, Tn, hint.lambda, rs, sl == 1)) return rc;
+    if (int rc = enqueue_lm_slot_cov(s, sl, Tn, hint.lambda, rs, sl == 1, hint.lambda == parent_lambda)) return rc;
   return publish_enqueue(s, Tn, buf, &ah.seq);
 }
 
@@ -1083,7 +1090,7 @@ static int algorithm_fit(bessx_session *s) {
     if (cov && use_cache && s->dev_state_rs == rs && mine.T0 == T0 && mine.lambda == lambda && mine.rs == rs &&
         !s->trace.on) {
       // keep the chain going: the fit after this one goes in before this one's result is awaited
-      if (int rc = enqueue_chained(s, hint, rs, mine.serial, mine.buf ^ 1, 2)) return rc;
+      if (int rc = enqueue_chained(s, hint, rs, mine.serial, mine.buf ^ 1, 2, lambda)) return rc;
       if (int rc = publish_wait(s, mine.buf, mine.seq)) return rc;
       // serial mismatch: the device did not start this fit (its gate failed); the state is still the previous
       // fit's, the fit chained behind it cannot have started either
@@ -1100,6 +1107,9 @@ static int algorithm_fit(bessx_session *s) {
     }
   }
   const int my_serial = ahead_hit ? ahead_serial : ++s->fit_serial;
+  // bd is one buffer for all row sets: it still holds this row set's scores only if its previous fit was the last
+  // thing the device ran (the condition of the upload-free start below)
+  const bool scores_ok = cov && use_cache && s->dev_state_rs == rs && cc.cov_layout && cc.lambda == lambda;
   hipError_t e = hipSuccess;
   if (ahead_hit) {
     // nothing to queue: the first batch of this fit is running or done
@@ -1153,7 +1163,7 @@ static int algorithm_fit(bessx_session *s) {
     if (!have_results) {
       const bool first_batch = slot == 1;
       for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
-        if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1)) return rc;
+        if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1, scores_ok)) return rc;
       if (!s->publish) {
         if (int rc = read_results(s, T0)) return rc;
       } else {
@@ -1161,7 +1171,7 @@ static int algorithm_fit(bessx_session *s) {
         if (int rc = publish_enqueue(s, T0, my_buf, &seq)) return rc;
         // chain the announced next fit of the warm-start path behind this one before waiting for this one
         if (first_batch)
-          if (int rc = enqueue_chained(s, hint, rs, my_serial, my_buf ^ 1, batch)) return rc;
+          if (int rc = enqueue_chained(s, hint, rs, my_serial, my_buf ^ 1, batch, lambda)) return rc;
         if (int rc = publish_wait(s, my_buf, seq)) return rc;
       }
     }
@@ -1274,6 +1284,7 @@ static int algorithm_fit(bessx_session *s) {
   s->sse_test = te;
   cc.valid = hc->done && hc->d_fresh;
   cc.cov_layout = cov;
+  cc.lambda = lambda;
   cc.beta = s->beta;
   cc.coef0 = s->coef0;
   s->n_fits += 1;
