@@ -99,6 +99,8 @@ struct CholFuse {
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
                        hipStream_t st, const CholFuse *fuse = nullptr);
+hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
+                     int slot, const CholFuse *fuse, int maxit, hipStream_t st);
 hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                            const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);

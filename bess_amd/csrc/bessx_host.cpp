@@ -144,6 +144,8 @@ struct bessx_session {
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
+  bool cov_cg = true;          // solve by k_cg (falls back to k_chol per slot); BESSX_COV_SOLVER=chol switches it off
+  long long cov_cg_fallbacks = 0;
   int cov_C = 0;              // cache capacity in columns
   int cov_rps = 0, cov_nslab = 0;
   int cov_variant = 2;        // panel kernel: 2 = LDS-staged, single tile (3 blocks per CU); 1 = double-buffered
@@ -224,8 +226,9 @@ static hipError_t dmalloc(T **ptr, size_t count) {
 static void session_free(bessx_session *s) {
   if (!s) return;
   if (std::getenv("BESSX_DEBUG"))
-    std::fprintf(stderr, "[bessx] chained fits: queued %lld, used %lld, not started %lld, mismatched %lld\n",
-                 s->chain_queued, s->chain_hits, s->chain_dead, s->chain_mismatch);
+    std::fprintf(stderr, "[bessx] chained fits: queued %lld, used %lld, not started %lld, mismatched %lld; "
+                 "CG solves handed to Cholesky: %lld\n",
+                 s->chain_queued, s->chain_hits, s->chain_dead, s->chain_mismatch, s->cov_cg_fallbacks);
   (void)hipSetDevice(s->device);
   if (s->st) (void)hipStreamSynchronize(s->st);
   auto F = [](void *q) {
@@ -603,7 +606,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
 }
 
 // solve + commit + residual of a slot whose active columns are all cached
-static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs) {
+static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, bool force_chol = false) {
   const int mt = (T0 + 1 + 15) / 16;
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
@@ -616,11 +619,16 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
       e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
                         s->hist_beta, s->hist_coef0, s->hist_stride, s->st, s->inA);
   } else {
-    // one launch: Gram gathered from the cache while loading, Cholesky + both solves, then the commit
+    // one launch: Gram gathered from the cache while loading, the solve, then the commit.  The solve is conjugate
+    // gradients warm-started from the previous coefficients (k_cg); if its true residual does not reach 1e-13 it
+    // parks the fit (cov_stall = 2) and the Cholesky kernel is issued for the slot (force_chol).
     CholFuse fz = {cv.G,     cv.slot_of,    s->p,    T0,           s->ctrl,       s->A_cur,      s->b_cur,
                    s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->inA};
-    e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
-                    &fz);
+    if (s->cov_cg && !force_chol)
+      e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st);
+    else
+      e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
+                      &fz);
   }
   // CV row sets need the sums of squares over the test rows too: one pass over the active columns for the final
   // coefficients (runs iff the fit ended here).  On all rows the loss comes from the solved system (k_chol).
@@ -667,6 +675,14 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
 static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int rs, int *next_slot) {
   bessx_session::CovCache &cv = s->cov[rs];
   const int stalled = -1 - hc->l + 1, nm = hc->cov_nmiss;
+  if (hc->cov_stall == 2) {
+    // the conjugate-gradient solve did not reach its residual target: Cholesky for this slot
+    s->cov_cg_fallbacks++;
+    HIPX(launch_cov_resume(s->ctrl, s->st));
+    if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs, true)) return rc;
+    *next_slot = stalled + 1;
+    return 0;
+  }
   const bool spec = cov_speculates(s);
   hipError_t e = hipSuccess;
   if (spec) e = launch_topk(s->bd2, s->p, COV_R, s->cov_extras, s->cand, nullptr, 0, s->st);
@@ -2392,6 +2408,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         HIPT(dmalloc(&s->cov_extras, (size_t)COV_R));
         TRY(alloc_cov_cache(s));
         HIPT(cov_panel_prepare());
+        if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
       } else if (mode == 2) {
         return bail(fail(BESSX_ERR_ARG, "covariance score mode: p too large for the Gram column cache"));
       }

@@ -1043,6 +1043,191 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
 }
 
 // ------------------------------------------------------------------------------------------
+// K7', covariance form of the LM fit: the k x k normal equations by conjugate gradients instead of a factorisation.
+//
+// After normalisation the Gram of an active set is n (I + small), and the solve is warm-started from the previous
+// coefficients (beta_dense[A_new]: exact for the columns that stay, 0 for the new ones), so the residual drops to
+// rounding level in a handful of steps, each one a symmetric k x k matrix-vector product with the tiles held in
+// registers (same tile dealing and gather as k_chol) -- no sequential pivot chain.  Every reduction has a fixed
+// order.  The iterate is accepted only if the TRUE residual |q - (G + ridge I) x| <= 1e-13 |q| (recomputed, not the
+// recurrence); otherwise (ill-conditioned design, iteration cap) the fit is parked with cov_stall = 2 and the host
+// issues the Cholesky kernel for this slot.  Ends with the loss terms and k_commit's work like the fused k_chol.
+// ------------------------------------------------------------------------------------------
+template <int CH_SLOTS>
+__global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const double *__restrict__ rhs,
+                                            const int *__restrict__ A_new, double *__restrict__ sol,
+                                            const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit) {
+  __shared__ int same_any_sh;
+  if (ctrl->done || ctrl->l != slot - 1) return;
+  if (ctrl->same_prev) {
+    commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+                fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+    return;
+  }
+  __shared__ int sA[CH_MT * 16], sS[CH_MT * 16];
+  __shared__ double pv[CH_MT * 16];
+  __shared__ double yw[CH_W][CH_MT * 16];
+  __shared__ double red[2][CH_W];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lc = lane & 15, lq = lane >> 4;
+  const int mp = mt * 16, ntiles = mt * (mt + 1) / 2;
+  for (int i = tid; i < mp; i += 512) {
+    const int a = i < m ? A_new[i] : 0;
+    sA[i] = a;
+    sS[i] = i < m ? fz.slot_of[a] : 0;
+  }
+  __syncthreads();
+  d4 acc[CH_SLOTS];
+  int tI[CH_SLOTS], tJ[CH_SLOTS];
+  {
+    int ti, tj;
+    tile_of(wave, ti, tj);
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
+#pragma unroll
+    for (int s = 0; s < CH_SLOTS; s++) {
+      const bool have = s * CH_W + wave < ntiles;
+      tI[s] = __builtin_amdgcn_readfirstlane(have ? ti : -1);
+      tJ[s] = __builtin_amdgcn_readfirstlane(have ? tj : -1);
+      tj += CH_W;
+      while (tj > ti) {
+        tj -= ti + 1;
+        ti++;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < CH_SLOTS; s++) {
+    acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+    if (tI[s] >= 0) {
+      const int col = tJ[s] * 16 + lc;
+      const int sl = col < m ? sS[col] : 0;
+      if (sl < 0) fz.ctrl->cov_miss = 1;
+      const double *gcol = fz.G + (size_t)(sl < 0 ? 0 : sl) * fz.p;
+      double gv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = tI[s] * 16 + lq + 4 * r;
+        gv[r] = (row < m && col < m && sl >= 0) ? gcol[sA[row]] : 0.0;
+      }
+      acc[s] = d4{gv[0], gv[1], gv[2], gv[3]};
+    }
+  }
+  const bool own = tid < m;  // thread t owns element t of every k-vector
+  // block-wide dot product, fixed order; every thread gets the value
+  int rb = 0;
+  auto dot = [&](double a, double b) -> double {
+    double v = wave_sum(own ? a * b : 0.0);
+    if (lane == 0) red[rb][wave] = v;
+    __syncthreads();
+    double t = red[rb][0];
+#pragma unroll
+    for (int w = 1; w < CH_W; w++) t += red[rb][w];
+    rb ^= 1;
+    return t;
+  };
+  // y = G v for the vector v (one element per owning thread); symmetric product from the lower-triangle tiles
+  auto matvec = [&](double v) -> double {
+    if (tid < mp) pv[tid] = own ? v : 0.0;
+#pragma unroll
+    for (int q = 0; q < CH_MT * 16 / 64; q++) yw[wave][lane + 64 * q] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < CH_SLOTS; s++) {
+      if (tI[s] >= 0) {
+        const int I = tI[s], J = tJ[s];
+        // (a) rows of tile row I: y[I*16 + lq + 4r] += sum_lc T[r] * v[J*16 + lc]; reduce-scatter over the 16 lanes
+        const double pj = pv[J * 16 + lc];
+        double v0 = acc[s].x * pj, v1 = acc[s].y * pj, v2 = acc[s].z * pj, v3 = acc[s].w * pj;
+        {
+          const bool hi = (lc & 8) != 0;
+          const double s0 = hi ? v0 : v2, s1 = hi ? v1 : v3;  // what the partner keeps
+          const double r0 = __shfl_xor(s0, 8), r1 = __shfl_xor(s1, 8);
+          v0 = (hi ? v2 : v0) + r0;
+          v1 = (hi ? v3 : v1) + r1;
+        }
+        {
+          const bool hi = (lc & 4) != 0;
+          const double s0 = hi ? v0 : v1;
+          const double r0 = __shfl_xor(s0, 4);
+          v0 = (hi ? v1 : v0) + r0;
+        }
+        v0 += __shfl_xor(v0, 2);
+        v0 += __shfl_xor(v0, 1);
+        if ((lc & 3) == 0) {
+          const int r = ((lc >> 3) & 1) * 2 + ((lc >> 2) & 1);
+          yw[wave][I * 16 + lq + 4 * r] += v0;
+        }
+        // (b) columns of the tile (off-diagonal tiles only): y[J*16 + lc] += sum_rows T[row][lc] * v[I*16 + row]
+        if (I != J) {
+          const int ib = I * 16 + lq;
+          double w0 = acc[s].x * pv[ib] + acc[s].y * pv[ib + 4] + acc[s].z * pv[ib + 8] + acc[s].w * pv[ib + 12];
+          w0 += __shfl_xor(w0, 16);
+          w0 += __shfl_xor(w0, 32);
+          if (lq == 0) yw[wave][J * 16 + lc] += w0;
+        }
+      }
+    }
+    __syncthreads();
+    double y = 0.0;
+    if (tid < mp) {
+#pragma unroll
+      for (int w = 0; w < CH_W; w++) y += yw[w][tid];
+    }
+    __syncthreads();
+    return y;
+  };
+  const double q_t = own ? rhs[sA[tid]] : 0.0;
+  double x_t = own ? fz.beta_dense[sA[tid]] : 0.0;  // warm start: previous coefficients of the columns that stay
+  const double qq = dot(q_t, q_t);
+  double r_t = q_t - (matvec(x_t) + ridge * x_t);
+  double p_t = r_t;
+  double rs = dot(r_t, r_t);
+  const double tol2 = 1e-30;  // recurrence residual target: |r| <= 1e-15 |q|
+  bool ok = false;
+  int it = 0;
+  for (int round = 0; round < 3 && !ok; round++) {
+    for (; it < maxit && rs > tol2 * qq; it++) {
+      const double ap = matvec(p_t) + ridge * p_t;
+      const double pap = dot(p_t, ap);
+      const double alpha = rs / pap;
+      x_t = fma(alpha, p_t, x_t);
+      r_t = fma(-alpha, ap, r_t);
+      const double rs_new = dot(r_t, r_t);
+      const double bt = rs_new / rs;
+      p_t = fma(bt, p_t, r_t);
+      rs = rs_new;
+    }
+    // the recurrence drifts: accept only on the recomputed residual
+    r_t = q_t - (matvec(x_t) + ridge * x_t);
+    rs = dot(r_t, r_t);
+    ok = rs <= 1e-26 * qq;  // also catches NaN (singular / indefinite matrix): comparison fails
+    p_t = r_t;
+    if (it >= maxit) break;
+  }
+  if (!ok) {
+    if (tid == 0) {  // park the fit: the host issues the Cholesky kernel for this slot
+      fz.ctrl->cov_stall = 2;
+      fz.ctrl->l = -1 - fz.ctrl->l;
+    }
+    return;
+  }
+  if (own) sol[tid] = x_t;
+  {
+    const double a1 = dot(x_t, q_t), a2 = dot(x_t, x_t);
+    if (tid == 0) {
+      fz.ctrl->sse_dot = a1;
+      fz.ctrl->sse_nrm = a2;
+      fz.ctrl->sse_valid = 1;
+    }
+  }
+  __syncthreads();
+  commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+              fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+}
+
+// ------------------------------------------------------------------------------------------
 // K7, large systems (m + 1 > 256): blocked right-looking Cholesky on the tile-layout matrix in global memory
 // (it stays L2 resident), one small launch per phase of a block column.  Correct for any size; the in-register
 // kernel above is the fast path for the BASELINE sizes (k <= 254).  Same augmented-row trick for the right-hand side.
@@ -3301,6 +3486,28 @@ hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_
   else
     CHOL_GO(17);
 #undef CHOL_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// Conjugate-gradient solve of the covariance form (k_cg); falls back to k_chol through the parked-fit protocol.
+hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
+                     int slot, const CholFuse *fuse, int maxit, hipStream_t st) {
+  if (mt < 1 || m > mt * 16 || mt > CH_MT || fuse == nullptr) return hipErrorInvalidValue;
+  const CholFuse fz = *fuse;
+#define CG_GO(S) \
+  hipLaunchKernelGGL(k_cg<S>, dim3(1), dim3(512), 0, st, m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit)
+  if (mt <= 8)
+    CG_GO(5);
+  else if (mt <= 10)
+    CG_GO(7);
+  else if (mt <= 12)
+    CG_GO(10);
+  else if (mt <= 14)
+    CG_GO(14);
+  else
+    CG_GO(17);
+#undef CG_GO
   LAUNCH_CHECK();
   return hipSuccess;
 }
