@@ -22,7 +22,7 @@ _vp = ctypes.c_void_p
 SYMBOLS = [
     "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_session_create",
     "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_sequential_path", "bessx_session_gs_path",
-    "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_score_mode",
+    "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
@@ -73,6 +73,8 @@ def lib():
         L.bessx_session_create.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(Problem)]
         L.bessx_session_destroy.argtypes = [_vp]
         L.bessx_session_destroy.restype = None
+        L.bessx_session_counter.argtypes = [_vp, _i]
+        L.bessx_session_counter.restype = ctypes.c_longlong
         L.bessx_session_score_mode.argtypes = [_vp]
         L.bessx_session_score_mode.restype = _i
         L.bessx_session_get_screening.argtypes = [_vp, _I, _i]
@@ -193,6 +195,11 @@ class Session:
     def score_mode(self):
         """1 = streaming score pass, 2 = covariance updates (what bessx_problem.score_mode = 0 resolved to)."""
         return int(lib().bessx_session_score_mode(self._h))
+
+    def counters(self):
+        """Diagnostics of the covariance form (bessx_session_counter)."""
+        names = ("chained_fits", "cg_fallbacks", "passes_over_X", "chained_queued")
+        return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in enumerate(names)}
 
     def screening(self):
         """screening_A: original column of every kept column."""

@@ -622,8 +622,8 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     // one launch: Gram gathered from the cache while loading, the solve, then the commit.  The solve is conjugate
     // gradients warm-started from the previous coefficients (k_cg); if its true residual does not reach 1e-13 it
     // parks the fit (cov_stall = 2) and the Cholesky kernel is issued for the slot (force_chol).
-    CholFuse fz = {cv.G,     cv.slot_of,    s->p,    T0,           s->ctrl,       s->A_cur,      s->b_cur,
-                   s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->inA};
+    CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
+                   s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs]};
     if (s->cov_cg && !force_chol)
       e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st);
     else
@@ -632,7 +632,7 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
   }
   // CV row sets need the sums of squares over the test rows too: one pass over the active columns for the final
   // coefficients (runs iff the fit ended here).  On all rows the loss comes from the solved system (k_chol).
-  if (e == hipSuccess && (rs != 0 || mt > 16))
+  if (e == hipSuccess && (rs != 0 || mt > 16 || !s->cov_cg))
     e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
                         s->sse, s->st, 1);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cov_tail: ") + hipGetErrorString(e));
@@ -1202,7 +1202,7 @@ static int algorithm_fit(bessx_session *s) {
     }
     if (hc->done || slot > s->max_iter) break;
   }
-  if (cov && !hc->done && (rs != 0 || (T0 + 1 + 15) / 16 > 16)) {
+  if (cov && !hc->done && (rs != 0 || (T0 + 1 + 15) / 16 > 16 || !s->cov_cg)) {
     // out of iterations: the sums of squares of the last coefficients have not been formed yet
     HIPX(launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, hc->l, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                          s->st, 2));
@@ -1265,11 +1265,12 @@ static int algorithm_fit(bessx_session *s) {
   s->l = hc->done ? hc->l : s->max_iter + 1;
   double tr = 0.0, te = 0.0;
   const int mt_fit = (T0 + 1 + 15) / 16;
-  if (cov && rs == 0 && mt_fit <= 16) {
-    // all rows, covariance form: no residual was formed.  (G + lambda I) beta = q was solved by k_chol, so
-    // |y - X beta|^2 = y.y - beta.q - lambda |beta|^2.  If no solve of this fit produced the coefficients (a fit that
-    // repeats its starting set at once) or the difference cancels badly (a near-perfect fit), one pass over the
-    // active columns with the final coefficients gives the sum directly.
+  if (cov && rs == 0 && mt_fit <= 16 && s->cov_cg) {
+    // all rows, covariance form, solve by k_cg: no residual was formed.  |y - X beta|^2 = y.y - beta.(q + rho) -
+    // lambda |beta|^2 with rho the residual of the normal equations (k_cg hands over both dot products, and clears
+    // sse_valid when the cancellation is not harmless).  If the last solve came from the Cholesky fallback, or the
+    // difference cancels badly (near-perfect or ill-conditioned fit), one pass over the active columns with the
+    // final coefficients gives the sum directly.
     const double yy = s->yy_h[0];
     tr = yy - hc->sse_dot - lambda * hc->sse_nrm;
     if (!hc->sse_valid || !(tr > 1e-6 * yy)) {
@@ -2636,6 +2637,17 @@ int bessx_session_score_pass_stats(bessx_session *s, int reset, double *seconds,
 }
 
 int bessx_session_score_mode(const bessx_session *s) { return s && s->cov_mode ? 2 : 1; }
+
+long long bessx_session_counter(const bessx_session *s, int which) {
+  if (!s) return -1;
+  switch (which) {
+    case 0: return s->chain_hits;
+    case 1: return s->cov_cg_fallbacks;
+    case 2: return s->cov_panel_groups;
+    case 3: return s->chain_queued;
+    default: return -1;
+  }
+}
 
 int bessx_session_get_screening(const bessx_session *s, int *columns, int cap) {
   if (!s) return 0;

@@ -1009,33 +1009,9 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
   }
   if (__syncthreads_or(bad) && tid == 0 && info != nullptr) *info = 1;
   if (fz.G != nullptr) {  // sol is visible to the whole block after the barrier above
-    // beta . X^T(m y) and |beta|^2 of the solved system: with (G + ridge I) beta = q the residual sum of squares is
-    // y.y - beta.q - ridge |beta|^2, so the host needs no pass over X for the loss (fixed-order block sums)
-    double t1 = 0.0, t2 = 0.0;
-    if (tid < m) {
-      const double v = z[tid];
-      t1 = v * rhs[rhs_gather[tid]];
-      t2 = v * v;
-    }
-    t1 = wave_sum(t1);
-    t2 = wave_sum(t2);
-    __syncthreads();
-    if (lane == 0) {
-      Rsh[wave] = t1;
-      Rsh[8 + wave] = t2;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-      for (int w = 0; w < CH_W; w++) {
-        a1 += Rsh[w];
-        a2 += Rsh[8 + w];
-      }
-      fz.ctrl->sse_dot = a1;
-      fz.ctrl->sse_nrm = a2;
-      fz.ctrl->sse_valid = 1;
-    }
+    // the loss of this solve comes from a residual pass (k_resid_lm): only k_cg has the true residual of the
+    // normal equations at hand that makes the solved-system formula an identity
+    if (tid == 0) fz.ctrl->sse_valid = 0;
     commit_body(fz.ctrl, slot, fz.T0, rhs_gather, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
                 fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
   }
@@ -1215,11 +1191,29 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
   }
   if (own) sol[tid] = x_t;
   {
-    const double a1 = dot(x_t, q_t), a2 = dot(x_t, x_t);
+    // loss terms: |y - X b|^2 = y.y - b.(q + rho) - ridge |b|^2 with rho = q - (G + ridge I) b the residual just
+    // recomputed (an identity, not an approximation).  It is only handed to the host when the cancellation is
+    // harmless: the sum of the magnitudes of the terms times the unit roundoff stays below 1e-10 of the result.
+    // Error of the evaluation: rounding of the three terms (their magnitudes a3, yy) and of the cached Gram entries
+    // themselves, which enters through b' dG b ~ eps * max diag(G) * |b|^2 (dominant when collinear columns blow
+    // the coefficients up).
+    const double qr = q_t + r_t;
+    const double a1 = dot(x_t, qr), a2 = dot(x_t, x_t), a3 = dot(fabs(x_t), fabs(qr));
+    double gd = (own && sS[tid] >= 0) ? fz.G[(size_t)sS[tid] * fz.p + sA[tid]] : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) gd = fmax(gd, __shfl_xor(gd, o));
+    if (lane == 0) red[rb][wave] = gd;
+    __syncthreads();
+    gd = red[rb][0];
+#pragma unroll
+    for (int w = 1; w < CH_W; w++) gd = fmax(gd, red[rb][w]);
+    rb ^= 1;
     if (tid == 0) {
+      const double tr = fz.yy - a1 - ridge * a2;
       fz.ctrl->sse_dot = a1;
       fz.ctrl->sse_nrm = a2;
-      fz.ctrl->sse_valid = 1;
+      fz.ctrl->sse_valid =
+          (tr > 1e-6 * fz.yy && 4e-16 * (a3 + (ridge + gd) * a2 + fz.yy) <= 1e-10 * tr) ? 1 : 0;
     }
   }
   __syncthreads();

@@ -107,6 +107,10 @@ void bessx_session_destroy(bessx_session *s);
 int bessx_session_get_screening(const bessx_session *s, int *columns, int cap);
 /* 1 = streaming score pass, 2 = covariance updates: what bessx_problem.score_mode resolved to for this session. */
 int bessx_session_score_mode(const bessx_session *s);
+/* Diagnostics of the covariance form since the session was created: which = 0 fits that ran chained behind their
+ * predecessor, 1 conjugate-gradient solves handed to the Cholesky kernel, 2 passes over X (32-column panel groups),
+ * 3 chained fits queued.  -1 for an unknown id. */
+long long bessx_session_counter(const bessx_session *s, int which);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)
  * gives the test fold of row i; fold_id == NULL draws a permutation from mt19937(seed) and cuts

@@ -82,6 +82,32 @@ def test_chained_fits_on_a_lambda_grid_and_short_paths(gpu):
         both_modes(gpu, X, y, kw, P.trace(X, y, **kw), "chain %r" % (sorted(kw),))
 
 
+def test_conjugate_gradients_hand_ill_conditioned_systems_to_cholesky(gpu, monkeypatch):
+    """Nearly collinear columns: the CG solve cannot reach its residual target and parks the fit; the Cholesky
+    kernel finishes the slot.  Same active sets as the oracle either way; BESSX_COV_SOLVER=chol never uses CG."""
+    rng = np.random.default_rng(11)
+    n, p = 1500, 300
+    z = rng.standard_normal((n, 6))
+    X = np.repeat(z, 50, axis=1) + 1e-4 * rng.standard_normal((n, p))  # 6 clusters of 50 almost equal columns
+    y = X[:, 0] - 2 * X[:, 60] + 1.5 * X[:, 130] + rng.standard_normal(n)
+    kw = dict(ic_type=3, sequence=np.arange(1, 25))
+    want = P.trace(X, y, **kw)
+    s = gpu.Session(X, y, score_mode=2)
+    s.trace_enable(True)
+    got = s.sequential_path(kw["sequence"], (0.0,), 3, False)
+    fell_back = s.counters()["cg_fallbacks"]
+    s.close()
+    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="collinear cg")
+    assert fell_back > 0
+    monkeypatch.setenv("BESSX_COV_SOLVER", "chol")
+    s = gpu.Session(X, y, score_mode=2)
+    s.trace_enable(True)
+    got = s.sequential_path(kw["sequence"], (0.0,), 3, False)
+    assert s.counters()["cg_fallbacks"] == 0
+    s.close()
+    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="collinear chol")
+
+
 def test_score_mode_argument(gpu):
     X, y, _, _ = synth.make_logistic(300, 40, 3)
     with pytest.raises(gpu.BessxError) as e:
