@@ -701,6 +701,24 @@ __device__ __forceinline__ int dpp_row_share(int v, int j) {
 __device__ __forceinline__ double row_bcast16(double v, int j) {
   return __hiloint2double(dpp_row_share(__double2hiint(v), j), dpp_row_share(__double2loint(v), j));
 }
+// sum over the 16 lanes of a DPP row, result in every lane: mirror, half mirror, then the two quad swaps
+__device__ __forceinline__ double dpp_mov64(double v, const int ctrl_sel) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); break;  // row_mirror
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); break;  // quad_perm [1,0,3,2]
+  }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16(double v) {
+  v += dpp_mov64(v, 0);
+  v += dpp_mov64(v, 1);
+  v += dpp_mov64(v, 2);
+  v += dpp_mov64(v, 3);
+  return v;
+}
 // element idx (lane-dependent) of a register array without dynamic indexing
 __device__ __forceinline__ double bcast_pick16(const double (&a)[16], int idx) {
   double r = a[0];
@@ -1042,8 +1060,8 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
   }
   __shared__ int sA[CH_MT * 16], sS[CH_MT * 16];
   __shared__ double pv[CH_MT * 16];
-  __shared__ double yw[CH_W][CH_MT * 16];
-  __shared__ double red[2][CH_W];
+  __shared__ double yw[2][CH_W][CH_MT * 16];
+  __shared__ double red[2][CH_W], red2[2][CH_W];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lc = lane & 15, lq = lane >> 4;
@@ -1091,49 +1109,57 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
     }
   }
   const bool own = tid < m;  // thread t owns element t of every k-vector
-  // block-wide dot product, fixed order; every thread gets the value
+  // block-wide dot products (two at once), fixed order; every thread gets the values.  One barrier: the buffers
+  // alternate, and a buffer is rewritten only after another barrier has been passed by everybody.
   int rb = 0;
-  auto dot = [&](double a, double b) -> double {
-    double v = wave_sum(own ? a * b : 0.0);
-    if (lane == 0) red[rb][wave] = v;
+  auto dot2 = [&](double a, double b, double c, double d, double &ab, double &cd) {
+    // wave sums: the 16 lanes of a row in the VALU (DPP), then the four rows
+    double v = row_sum16(own ? a * b : 0.0), u = row_sum16(own ? c * d : 0.0);
+    v += __shfl_xor(v, 16);
+    u += __shfl_xor(u, 16);
+    v += __shfl_xor(v, 32);
+    u += __shfl_xor(u, 32);
+    if (lane == 0) {
+      red[rb][wave] = v;
+      red2[rb][wave] = u;
+    }
     __syncthreads();
-    double t = red[rb][0];
+    double t = red[rb][0], t2 = red2[rb][0];
 #pragma unroll
-    for (int w = 1; w < CH_W; w++) t += red[rb][w];
+    for (int w = 1; w < CH_W; w++) {
+      t += red[rb][w];
+      t2 += red2[rb][w];
+    }
     rb ^= 1;
-    return t;
+    ab = t;
+    cd = t2;
   };
-  // y = G v for the vector v (one element per owning thread); symmetric product from the lower-triangle tiles
+  auto dot = [&](double a, double b) -> double {
+    double x1, x2;
+    dot2(a, b, 0.0, 0.0, x1, x2);
+    return x1;
+  };
+  // y = G v for the vector v (one element per owning thread); symmetric product from the lower-triangle tiles.
+  // Two barriers: the per-wave partial results alternate between two buffers.
+  int yb = 0;
   auto matvec = [&](double v) -> double {
     if (tid < mp) pv[tid] = own ? v : 0.0;
+    double(*yy)[CH_MT * 16] = yw[yb];
 #pragma unroll
-    for (int q = 0; q < CH_MT * 16 / 64; q++) yw[wave][lane + 64 * q] = 0.0;
+    for (int q = 0; q < CH_MT * 16 / 64; q++) yy[wave][lane + 64 * q] = 0.0;
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < CH_SLOTS; s++) {
       if (tI[s] >= 0) {
         const int I = tI[s], J = tJ[s];
-        // (a) rows of tile row I: y[I*16 + lq + 4r] += sum_lc T[r] * v[J*16 + lc]; reduce-scatter over the 16 lanes
+        // (a) rows of tile row I: y[I*16 + lq + 4r] += sum_lc T[r] * v[J*16 + lc]; the sum over the 16 lanes of a
+        // row stays in the VALU (DPP mirror / quad permutes), lane lc = r of each row then owns output row r
         const double pj = pv[J * 16 + lc];
-        double v0 = acc[s].x * pj, v1 = acc[s].y * pj, v2 = acc[s].z * pj, v3 = acc[s].w * pj;
-        {
-          const bool hi = (lc & 8) != 0;
-          const double s0 = hi ? v0 : v2, s1 = hi ? v1 : v3;  // what the partner keeps
-          const double r0 = __shfl_xor(s0, 8), r1 = __shfl_xor(s1, 8);
-          v0 = (hi ? v2 : v0) + r0;
-          v1 = (hi ? v3 : v1) + r1;
-        }
-        {
-          const bool hi = (lc & 4) != 0;
-          const double s0 = hi ? v0 : v1;
-          const double r0 = __shfl_xor(s0, 4);
-          v0 = (hi ? v1 : v0) + r0;
-        }
-        v0 += __shfl_xor(v0, 2);
-        v0 += __shfl_xor(v0, 1);
-        if ((lc & 3) == 0) {
-          const int r = ((lc >> 3) & 1) * 2 + ((lc >> 2) & 1);
-          yw[wave][I * 16 + lq + 4 * r] += v0;
+        const double v0 = row_sum16(acc[s].x * pj), v1 = row_sum16(acc[s].y * pj);
+        const double v2 = row_sum16(acc[s].z * pj), v3 = row_sum16(acc[s].w * pj);
+        if (lc < 4) {
+          const double mine = lc == 0 ? v0 : (lc == 1 ? v1 : (lc == 2 ? v2 : v3));
+          yy[wave][I * 16 + lq + 4 * lc] += mine;
         }
         // (b) columns of the tile (off-diagonal tiles only): y[J*16 + lc] += sum_rows T[row][lc] * v[I*16 + row]
         if (I != J) {
@@ -1141,7 +1167,7 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
           double w0 = acc[s].x * pv[ib] + acc[s].y * pv[ib + 4] + acc[s].z * pv[ib + 8] + acc[s].w * pv[ib + 12];
           w0 += __shfl_xor(w0, 16);
           w0 += __shfl_xor(w0, 32);
-          if (lq == 0) yw[wave][J * 16 + lc] += w0;
+          if (lq == 0) yy[wave][J * 16 + lc] += w0;
         }
       }
     }
@@ -1149,9 +1175,9 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
     double y = 0.0;
     if (tid < mp) {
 #pragma unroll
-      for (int w = 0; w < CH_W; w++) y += yw[w][tid];
+      for (int w = 0; w < CH_W; w++) y += yy[w][tid];
     }
-    __syncthreads();
+    yb ^= 1;
     return y;
   };
   const double q_t = own ? rhs[sA[tid]] : 0.0;
@@ -1160,25 +1186,22 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
   double r_t = q_t - (matvec(x_t) + ridge * x_t);
   double p_t = r_t;
   double rs = dot(r_t, r_t);
-  const double tol2 = 1e-30;  // recurrence residual target: |r| <= 1e-15 |q|
   bool ok = false;
   int it = 0;
   for (int round = 0; round < 3 && !ok; round++) {
-    for (; it < maxit && rs > tol2 * qq; it++) {
+    for (; it < maxit && rs > 1e-30 * qq; it++) {  // recurrence residual target: |r| <= 1e-15 |q|
       const double ap = matvec(p_t) + ridge * p_t;
-      const double pap = dot(p_t, ap);
-      const double alpha = rs / pap;
+      const double alpha = rs / dot(p_t, ap);
       x_t = fma(alpha, p_t, x_t);
       r_t = fma(-alpha, ap, r_t);
       const double rs_new = dot(r_t, r_t);
-      const double bt = rs_new / rs;
-      p_t = fma(bt, p_t, r_t);
+      p_t = fma(rs_new / rs, p_t, r_t);
       rs = rs_new;
     }
-    // the recurrence drifts: accept only on the recomputed residual
+    // the recurrence drifts: accept only on the recomputed residual |q - (G + ridge I) x| <= 1e-13 |q|
     r_t = q_t - (matvec(x_t) + ridge * x_t);
     rs = dot(r_t, r_t);
-    ok = rs <= 1e-26 * qq;  // also catches NaN (singular / indefinite matrix): comparison fails
+    ok = rs <= 1e-26 * qq;  // also catches NaN (singular / indefinite matrix): the comparison fails
     p_t = r_t;
     if (it >= maxit) break;
   }
