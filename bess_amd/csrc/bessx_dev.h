@@ -181,10 +181,16 @@ hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
 int cov_streamed_tiles_per_wave();
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
-                            int parked, hipStream_t st, int variant = 2);
+                            int parked, hipStream_t st, int variant = 2, const int *bgm = nullptr);
 hipError_t cov_panel_prepare();
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
-                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st);
+                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st,
+                             const int *bgm = nullptr);
+// background (speculative) fill on a second stream
+hipError_t launch_cov_bg_select(const double *bd, const int *slot_of, int p, double *bd2, hipStream_t st);
+hipError_t launch_cov_bg_list(const int *extras, const double *bd2, const int *slot_of, const int *meta, int C,
+                              int reserve, int *fcols, int *bgm, hipStream_t st);
+hipError_t launch_cov_bg_publish(const int *fcols, const int *bgm, int *slot_of, int *meta, hipStream_t st);
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
                         const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,
                         double lambda, const unsigned char *always, double *bd, const unsigned char *inA, double *bmm,
@@ -193,7 +199,7 @@ hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int
                            int *meta, const FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_publish(const unsigned char *dev, unsigned char *host, int ctrl_bytes, size_t off_sse, int n_sse,
                           size_t off_b, size_t off_a, int kcopy, unsigned long long *seq_host, unsigned long long seq,
-                          hipStream_t st);
+                          hipStream_t st, const int *count_ptr = nullptr);
 hipError_t launch_vec_mul(const double *a, const double *b, long n, double *out, hipStream_t st);
 hipError_t launch_part_sum(const double *part, int nrb, int p, double *out, hipStream_t st);
 hipError_t launch_fill(double *a, long n, double v, hipStream_t st);

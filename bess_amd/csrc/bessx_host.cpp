@@ -144,6 +144,23 @@ struct bessx_session {
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
+  // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
+  // kernel could have the rest of the GPU.  Measured on configs[1] it does not pay: the panel blocks delay the
+  // chain's small kernels by about what the avoided foreground fills would have cost, and a speculation made more
+  // than ~20 candidates ahead rarely hits.  Kept as an option (BESSX_COV_BG=1), off by default.
+  bool cov_bg = false;
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_main = nullptr, ev_bg = nullptr;
+  bool bg_inflight = false;
+  double *bd2_bg = nullptr, *part_bg = nullptr;
+  int *extras_bg = nullptr, *fcols_bg = nullptr, *bgm = nullptr, *cand_bg = nullptr;
+  int cov_count_seen = 0;      // row set 0: columns cached according to the last published result block
+  int cov_fg_pending = 0;      // ... plus what foreground fills queued since then can add at most
+  int bg_outstanding = 0;      // ... plus 32 per background fill not yet known to have finished
+  int cov_count_ub = 0;        // = the sum of the three: an upper bound of the cached columns at any time
+  int cov_target = 0;          // cached columns worth having for the path in progress (0 = no background fills)
+  int cov_spare = 96;          // background fills keep this many columns cached beyond the active set (BESSX_COV_SPARE)
+  long long cov_bg_fills = 0;
   bool cov_cg = true;          // solve by k_cg (falls back to k_chol per slot); BESSX_COV_SOLVER=chol switches it off
   long long cov_cg_fallbacks = 0;
   int cov_C = 0;              // cache capacity in columns
@@ -294,6 +311,16 @@ static void session_free(bessx_session *s) {
   F(s->bd2);
   F(s->inA);
   F(s->cov_bmm);
+  if (s->st2) (void)hipStreamSynchronize(s->st2);
+  F(s->bd2_bg);
+  F(s->part_bg);
+  F(s->extras_bg);
+  F(s->fcols_bg);
+  F(s->bgm);
+  F(s->cand_bg);
+  if (s->ev_main) (void)hipEventDestroy(s->ev_main);
+  if (s->ev_bg) (void)hipEventDestroy(s->ev_bg);
+  if (s->st2) (void)hipStreamDestroy(s->st2);
   F(s->cov_fcols);
   F(s->cov_extras);
   F(s->Rt);
@@ -395,6 +422,11 @@ static int reset_path_caches(bessx_session *s) {
     HIPX(hipStreamSynchronize(s->st));
   }
   s->hint.on = false;
+  if (s->st2) {
+    HIPX(hipStreamSynchronize(s->st2));
+    s->bg_inflight = false;
+  }
+  s->cov_count_ub = s->cov_count_seen = s->cov_fg_pending = s->bg_outstanding = 0;
   for (auto &c : s->cache) c.valid = false;
   s->dev_state_rs = -1;
   for (auto &g : s->gcache) HIPX(hipMemsetAsync(g.meta, 0, 2 * sizeof(int), s->st));
@@ -605,6 +637,50 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
   return 0;
 }
 
+static bool cov_speculates(const bessx_session *s);
+
+// Background fill for row set 0: the 32 best-scoring uncached columns (scores as they are when the kernels run),
+// their Gram columns, and only then their publication in slot_of.  after_main: wait for everything queued on the
+// main stream so far (a foreground fill allocates slots too; the two never overlap).
+static int cov_bg_enqueue(bessx_session *s, int T0, bool after_main) {
+  if (!s->cov_bg || !s->cov_mode || s->cov_target <= 0 || !cov_speculates(s)) return 0;
+  const int reserve = s->cov_target + 2 * COV_R;  // never fill the cache so far that the foreground would restart it
+  if (s->cov_count_ub + COV_R + reserve > s->cov_C || s->cov_count_ub >= s->cov_target + s->cov_spare) return 0;
+  bessx_session::CovCache &cv = s->cov[0];
+  if (s->bg_inflight) HIPX(hipStreamWaitEvent(s->st2, s->ev_bg, 0));  // (same stream: already ordered; harmless)
+  if (after_main) {
+    HIPX(hipEventRecord(s->ev_main, s->st));
+    HIPX(hipStreamWaitEvent(s->st2, s->ev_main, 0));
+  }
+  hipError_t e = launch_cov_bg_select(s->bd, cv.slot_of, s->p, s->bd2_bg, s->st2);
+  if (e == hipSuccess) e = launch_topk(s->bd2_bg, s->p, COV_R, s->extras_bg, s->cand_bg, nullptr, 0, s->st2);
+  if (e == hipSuccess)
+    e = launch_cov_bg_list(s->extras_bg, s->bd2_bg, cv.slot_of, cv.meta, s->cov_C, reserve, s->fcols_bg, s->bgm, s->st2);
+  if (e == hipSuccess)
+    e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[0], s->fcols_bg, 0, 1, s->cov_rps, s->cov_nslab, s->part_bg,
+                         s->ctrl, 2, s->st2, s->cov_variant, s->bgm);
+  if (e == hipSuccess)
+    e = launch_cov_reduce(s->part_bg, s->p, s->fcols_bg, cv.slot_of, cv.G, 0, 1, s->cov_nslab, s->ctrl, 2, s->st2, s->bgm);
+  if (e == hipSuccess) e = launch_cov_bg_publish(s->fcols_bg, s->bgm, cv.slot_of, cv.meta, s->st2);
+  if (e == hipSuccess) e = hipEventRecord(s->ev_bg, s->st2);
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_bg_enqueue: ") + hipGetErrorString(e));
+  s->bg_inflight = true;
+  s->bg_outstanding++;
+  s->cov_count_ub += COV_R;
+  s->cov_bg_fills++;
+  s->cov_panel_groups++;
+  return 0;
+}
+
+// the main stream is about to allocate cache slots (foreground fill): let a background fill in flight finish first
+static int cov_bg_fence_main(bessx_session *s) {
+  if (s->bg_inflight) {
+    HIPX(hipStreamWaitEvent(s->st, s->ev_bg, 0));
+    s->bg_inflight = false;
+  }
+  return 0;
+}
+
 // solve + commit + residual of a slot whose active columns are all cached
 static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, bool force_chol = false) {
   const int mt = (T0 + 1 + 15) / 16;
@@ -684,6 +760,12 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
     return 0;
   }
   const bool spec = cov_speculates(s);
+  if (rs == 0) {
+    if (int rc = cov_bg_fence_main(s)) return rc;
+    const int add = spec ? ((nm + 16 + COV_R - 1) / COV_R) * COV_R : (nm + COV_R - 1) / COV_R * COV_R;
+    s->cov_fg_pending += add;
+    s->cov_count_ub += add;
+  }
   hipError_t e = hipSuccess;
   if (spec) e = launch_topk(s->bd2, s->p, COV_R, s->cov_extras, s->cand, nullptr, 0, s->st);
   if (e == hipSuccess) e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st);
@@ -695,6 +777,11 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
   HIPX(launch_cov_resume(s->ctrl, s->st));
   if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
   *next_slot = stalled + 1;
+  // the chain goes on with single-workgroup kernels: use the idle CUs to form the next likely columns now
+  if (rs == 0) {
+    if (int rc = cov_bg_enqueue(s, T0, true)) return rc;
+    if (int rc = cov_bg_enqueue(s, T0, false)) return rc;
+  }
   return 0;
 }
 
@@ -833,7 +920,8 @@ static int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long l
   *seq = ++s->pub_seq;
   HIPX(launch_publish(s->resblk, s->res_buf[buf], 128, (size_t)((unsigned char *)s->sse - s->resblk), 2 * s->n_sse_blk,
                       (size_t)((unsigned char *)s->b_cur - s->resblk), (size_t)((unsigned char *)s->A_cur - s->resblk),
-                      std::min(kcopy, s->capA), s->pub_flag + 8 * buf, *seq, s->st));
+                      std::min(kcopy, s->capA), s->pub_flag + 8 * buf, *seq, s->st,
+                      s->cov_mode ? s->cov[0].meta : nullptr));
   return 0;
 }
 
@@ -1162,6 +1250,11 @@ static int algorithm_fit(bessx_session *s) {
   if (cov && !use_cache && k_init > 0) {
     // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones
     bessx_session::CovCache &cv = s->cov[rs];
+    if (rs == 0) {
+      if (int rc = cov_bg_fence_main(s)) return rc;
+      s->cov_fg_pending += k_init;
+      s->cov_count_ub += k_init;
+    }
     e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C, s->cov_fcols, s->ctrl, 0,
                         s->A_cur, s->st);
     if (e == hipSuccess)
@@ -1193,12 +1286,26 @@ static int algorithm_fit(bessx_session *s) {
     }
     have_results = false;
     hc = reinterpret_cast<const FitCtrl *>(s->res_h);
+    if (rs == 0 && s->publish) {
+      // the published block carries the cache's column count; foreground fills queued before it are included
+      if (s->bg_inflight && hipEventQuery(s->ev_bg) == hipSuccess) {
+        s->bg_inflight = false;
+        s->bg_outstanding = 0;
+      }
+      s->cov_count_seen = (int)s->pub_flag[8 * (s->res_h == s->res_buf[1] ? 1 : 0) + 1];
+      s->cov_fg_pending = 0;
+      s->cov_count_ub = s->cov_count_seen + COV_R * s->bg_outstanding;
+    }
     if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
     // the chained fit only starts if this one ended here with fresh score sums
     if (s->ahead.armed && !(hc->done && hc->d_fresh && !hc->info)) s->ahead.armed = false;
     if (hc->cov_stall) {
       if (int rc = cov_unpark(s, hc, T0, lambda, rs, &slot)) return rc;
       continue;
+    }
+    if (rs == 0 && s->cov_target > 0 && !s->bg_inflight && s->cov_count_ub - T0 < s->cov_spare) {
+      // few spare columns cached beyond the active set: form the next likely ones before they are missed
+      if (int rc = cov_bg_enqueue(s, T0, false)) return rc;
     }
     if (hc->done || slot > s->max_iter) break;
   }
@@ -1934,9 +2041,22 @@ static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const dou
   s->n_iters = 0;
   auto t0 = std::chrono::steady_clock::now();
   if (int rc0 = reset_path_caches(s)) return rc0;  // a path call starts cold, like a bessCpp call
+  // columns worth caching ahead of need: the largest sparsity level of this path (no CV: row set 0 only)
+  s->cov_target = 0;
+  if (s->cov_bg && s->cov_mode && !is_cv && s->warm_start) {
+    int tmax = gs ? s_max : 0;
+    for (int i = 0; i < ns && !gs; i++) tmax = std::max(tmax, seq[i]);
+    s->cov_target = std::min(s->p, std::max(tmax, 1) + 16);
+  }
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
                 : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res);
+  s->cov_target = 0;
+  if (s->st2) {  // background fills still in flight belong to this call
+    hipError_t eb = hipStreamSynchronize(s->st2);
+    s->bg_inflight = false;
+    if (rc == 0 && eb != hipSuccess) rc = fail(BESSX_ERR_HIP, std::string("background fill: ") + hipGetErrorString(eb));
+  }
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
   res->n_fits = s->n_fits;
@@ -2041,7 +2161,11 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       return bail(fail(BESSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)));    \
   } while (0)
   HIPT(hipSetDevice(dev));
-  HIPT(hipStreamCreate(&s->st));
+  {
+    int lo = 0, hi = 0;
+    HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
+  }
   const int n = pb->n;
   s->n = n;
   s->p = pb->p;
@@ -2409,6 +2533,25 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         HIPT(dmalloc(&s->cov_extras, (size_t)COV_R));
         TRY(alloc_cov_cache(s));
         HIPT(cov_panel_prepare());
+        if (const char *ev = std::getenv("BESSX_COV_BG")) s->cov_bg = std::atoi(ev) != 0;
+        if (const char *ev = std::getenv("BESSX_COV_SPARE")) s->cov_spare = std::max(0, std::atoi(ev));
+        if (s->cov_bg) {
+          {
+            // lowest priority: the chain's small kernels on the main stream must never queue behind panel blocks
+            int lo = 0, hi = 0;
+            HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPT(hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, lo));
+          }
+          HIPT(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
+          HIPT(hipEventCreateWithFlags(&s->ev_bg, hipEventDisableTiming));
+          HIPT(dmalloc(&s->bd2_bg, (size_t)p));
+          HIPT(dmalloc(&s->part_bg, (size_t)ns * njg * cov_streamed_tiles_per_wave() * 2 * 256));
+          HIPT(dmalloc(&s->extras_bg, (size_t)COV_R));
+          HIPT(dmalloc(&s->fcols_bg, (size_t)2 * COV_R));
+          HIPT(dmalloc(&s->bgm, 4));
+          HIPT(hipMemset(s->bgm, 0, 4 * sizeof(int)));
+          HIPT(dmalloc(&s->cand_bg, 32768));
+        }
         if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
       } else if (mode == 2) {
         return bail(fail(BESSX_ERR_ARG, "covariance score mode: p too large for the Gram column cache"));
@@ -2645,6 +2788,7 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 1: return s->cov_cg_fallbacks;
     case 2: return s->cov_panel_groups;
     case 3: return s->chain_queued;
+    case 4: return s->cov_bg_fills;
     default: return -1;
   }
 }

@@ -2846,7 +2846,8 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
     if (!diff) return;  // A == A_list.col(l-1): nothing to solve, nothing to look up
   }
   int count = meta[0];
-  if (count + len + COV_R > C) {  // no room: start the cache over (uniform branch)
+  const bool restart = count + len + COV_R > C;  // no room: start the cache over (uniform branch)
+  if (restart) {
     for (int j = tid; j < p; j += NT) slot_of[j] = -1;
     count = 0;
     __syncthreads();
@@ -2876,7 +2877,7 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
   }
   const bool spec = nm > 0 && bd != nullptr;
   if (tid == 0) {
-    meta[0] = count;
+    if (restart) meta[0] = 0;  // (otherwise untouched: a background fill may be adding columns concurrently)
     meta[1] = nm;
     meta[2] = spec ? 1 : 0;
     ctrl->cov_nmiss = nm;
@@ -2952,9 +2953,9 @@ __global__ void __launch_bounds__(256) k_cov_panel(const double *__restrict__ X,
                                                    const int *__restrict__ fcols, int g0, int ngroups,
                                                    int rows_per_slab, int nslab, int njg,
                                                    double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
-                                                   int slot, int big) {
-  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
-  const int nfill = ctrl->cov_nfill;
+                                                   int slot, int big, const int *__restrict__ bgm) {
+  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
+  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long per_group = (long)nslab * njg;
   const int gl = (int)(wid / per_group);
@@ -3035,9 +3036,9 @@ __global__ void __launch_bounds__(256) k_cov_panel_lds(const double *__restrict_
                                                        const int *__restrict__ fcols, int g0, int ngroups,
                                                        int rows_per_slab, int nslab, int njg,
                                                        double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
-                                                       int big) {
-  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
-  const int nfill = ctrl->cov_nfill;
+                                                       int big, const int *__restrict__ bgm) {
+  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
+  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
   const long per_group = (long)nslab * njg;
   const int gl = (int)(blockIdx.x / per_group);
   if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
@@ -3120,18 +3121,61 @@ __global__ void __launch_bounds__(256) k_cov_panel_lds(const double *__restrict_
 __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
                                                     int njg, int p, const int *__restrict__ fcols,
                                                     const int *__restrict__ slot_of, double *__restrict__ G,
-                                                    const FitCtrl *__restrict__ ctrl, int slot, int big) {
-  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
+                                                    const FitCtrl *__restrict__ ctrl, int slot, int big,
+                                                    const int *__restrict__ bgm) {
+  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
   const int gl = blockIdx.y;
-  if (gl >= ngroups || (g0 + gl) * COV_R >= ctrl->cov_nfill) return;
+  if (gl >= ngroups || (g0 + gl) * COV_R >= (big == 2 ? bgm[0] : ctrl->cov_nfill)) return;
   const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
   const int tile = blockIdx.x, e = threadIdx.x;
   double s = 0.0;
   for (int sl = 0; sl < nslab; sl++) s += part[(((size_t)gl * nslab + sl) * tiles_per_slab + tile) * 256 + e];
   const int jt = tile >> 1, ni = tile & 1, lane = e >> 2, reg = e & 3;
   const int j = jt * 16 + (lane >> 4) + 4 * reg;
-  const int col = fcols[(g0 + gl) * COV_R + ni * 16 + (lane & 15)];
-  if (j < p && col >= 0) G[(size_t)slot_of[col] * p + j] = s;
+  const int ci = (g0 + gl) * COV_R + ni * 16 + (lane & 15);
+  const int col = fcols[ci];
+  // background fill: the columns are not visible in slot_of yet (k_cov_bg_publish does that last); their cache
+  // slots are bgm[1] + position in the list
+  if (j < p && col >= 0) G[(size_t)(big == 2 ? bgm[1] + ci : slot_of[col]) * p + j] = s;
+}
+
+// ---- background (speculative) fill, issued on a second stream while the PDAS chain keeps the first one busy with
+// its single-workgroup kernels: scores of the uncached columns -> top 32 -> Gram columns -> publication.
+// bgm: [0] list length (0 or a multiple of 32), [1] first cache slot, [2] columns in the list.
+__global__ void __launch_bounds__(256) k_cov_bg_mask(const double *__restrict__ bd, const int *__restrict__ slot_of,
+                                                     int p, double *__restrict__ bd2) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < p) bd2[j] = slot_of[j] >= 0 ? -1.0 : bd[j];  // (bd may be mid-update: the choice is only a guess)
+}
+
+__global__ void __launch_bounds__(64) k_cov_bg_list(const int *__restrict__ extras, const double *__restrict__ bd2,
+                                                    const int *__restrict__ slot_of, const int *__restrict__ meta,
+                                                    int C, int reserve, int *__restrict__ fcols,
+                                                    int *__restrict__ bgm) {
+  const int tid = threadIdx.x;
+  const int count = meta[0];
+  const bool valid = tid < COV_R && bd2[extras[tid]] >= 0.0 && slot_of[extras[tid]] < 0;
+  const unsigned long long bal = __ballot(valid);
+  const int rank = __popcll(bal & ((1ull << tid) - 1ull)), tot = (int)__popcll(bal);
+  const bool room = count + COV_R + reserve <= C;  // never so full that the foreground would restart the cache
+  if (tid < COV_R) fcols[tid] = -1;
+  __syncthreads();
+  if (room && valid) fcols[rank] = extras[tid];
+  if (tid == 0) {
+    bgm[0] = (room && tot > 0) ? COV_R : 0;
+    bgm[1] = count;
+    bgm[2] = room ? tot : 0;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_cov_bg_publish(const int *__restrict__ fcols, const int *__restrict__ bgm,
+                                                       int *__restrict__ slot_of, int *__restrict__ meta) {
+  const int tid = threadIdx.x, tot = bgm[2], base = bgm[1];
+  if (bgm[0] == 0 || meta[0] != base) return;  // nothing filled, or the foreground allocated in between
+  if (tid < tot) slot_of[fcols[tid]] = base + tid;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) meta[0] = base + tot;
 }
 
 // d_j = (X^T m y)_j - sum_i G[j, slot(A_i)] b_i ; 64 columns per block, the sum over i cut in 4 interleaved parts.
@@ -3244,8 +3288,11 @@ __global__ void __launch_bounds__(256) k_cov_gram(const double *__restrict__ G, 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_publish(const unsigned char *__restrict__ dev, unsigned char *host,
                                                  int ctrl_bytes, size_t off_sse, int n_sse, size_t off_b, size_t off_a,
-                                                 int kcopy, unsigned long long *seq_host, unsigned long long seq) {
+                                                 int kcopy, unsigned long long *seq_host, unsigned long long seq,
+                                                 const int *__restrict__ count_ptr) {
   const int tid = threadIdx.x;
+  // (covariance form) columns in the Gram column cache right now, next to the sequence number
+  if (tid == 0 && count_ptr != nullptr) seq_host[1] = (unsigned long long)count_ptr[0];
   const unsigned long long *d8 = reinterpret_cast<const unsigned long long *>(dev);
   unsigned long long *h8 = reinterpret_cast<unsigned long long *>(host);
   for (int i = tid; i < ctrl_bytes / 8; i += 256) h8[i] = d8[i];
@@ -3894,7 +3941,7 @@ int cov_streamed_tiles_per_wave() { return COV_NJ; }
 
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
-                            int parked, hipStream_t st, int variant) {
+                            int parked, hipStream_t st, int variant, const int *bgm) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
   if (variant >= 1) {
     // LDS-staged: one block per (group, slab, 64-column group); 1 = double-buffered LDS tile, 2 = single buffer
@@ -3903,7 +3950,7 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
     const long nblk = (long)ngroups * nslab * njg;
 #define PANEL_GO(M, D)                                                                                              \
   hipLaunchKernelGGL((k_cov_panel_lds<M, D>), dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0, \
-                     ngroups, rows_per_slab, nslab, njg, part, ctrl, parked)
+                     ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm)
     if (mask && variant == 1)
       PANEL_GO(true, true);
     else if (mask)
@@ -3920,10 +3967,10 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
   const int nblk = (int)((nwaves + 3) / 4);
   if (mask)
     hipLaunchKernelGGL(k_cov_panel<true>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
-                       rows_per_slab, nslab, njg, part, ctrl, 0, parked);
+                       rows_per_slab, nslab, njg, part, ctrl, 0, parked, bgm);
   else
     hipLaunchKernelGGL(k_cov_panel<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
-                       rows_per_slab, nslab, njg, part, ctrl, 0, parked);
+                       rows_per_slab, nslab, njg, part, ctrl, 0, parked, bgm);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3939,10 +3986,29 @@ hipError_t cov_panel_prepare() {
 }
 
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
-                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st) {
+                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st, const int *bgm) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
   hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, part, g0, ngroups, nslab, njg, p,
-                     fcols, slot_of, G, ctrl, 0, parked);
+                     fcols, slot_of, G, ctrl, 0, parked, bgm);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_bg_select(const double *bd, const int *slot_of, int p, double *bd2, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_bg_mask, dim3((p + 255) / 256), dim3(256), 0, st, bd, slot_of, p, bd2);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_bg_list(const int *extras, const double *bd2, const int *slot_of, const int *meta, int C,
+                              int reserve, int *fcols, int *bgm, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_bg_list, dim3(1), dim3(64), 0, st, extras, bd2, slot_of, meta, C, reserve, fcols, bgm);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_bg_publish(const int *fcols, const int *bgm, int *slot_of, int *meta, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_bg_publish, dim3(1), dim3(64), 0, st, fcols, bgm, slot_of, meta);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3967,9 +4033,9 @@ hipError_t launch_cov_gram(const double *G, int p, const int *slot_of, const int
 
 hipError_t launch_publish(const unsigned char *dev, unsigned char *host, int ctrl_bytes, size_t off_sse, int n_sse,
                           size_t off_b, size_t off_a, int kcopy, unsigned long long *seq_host, unsigned long long seq,
-                          hipStream_t st) {
+                          hipStream_t st, const int *count_ptr) {
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, dev, host, ctrl_bytes, off_sse, n_sse, off_b, off_a, kcopy,
-                     seq_host, seq);
+                     seq_host, seq, count_ptr);
   LAUNCH_CHECK();
   return hipSuccess;
 }
