@@ -108,6 +108,26 @@ def test_conjugate_gradients_hand_ill_conditioned_systems_to_cholesky(gpu, monke
     assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="collinear chol")
 
 
+@pytest.mark.parametrize("knob", ["BESSX_CHAIN=0", "BESSX_PUBLISH=0", "BESSX_COV_SOLVER=chol", "BESSX_COV_BG=1",
+                                  "BESSX_PANEL_VARIANT=0", "BESSX_PANEL_VARIANT=1"])
+def test_runtime_knobs_do_not_change_results(gpu, monkeypatch, knob):
+    """Every optional mechanism of the covariance form can be switched off (or, for the background fills, on): the
+    candidates, their supports and their ICs stay the same."""
+    X, y, _, _ = synth.make_lm(1500, 2500, 15)
+    seq = np.arange(1, 41)
+    with gpu.Session(X, y, score_mode=2) as s:
+        base = s.sequential_path(seq, ic_type=3)
+    name, val = knob.split("=")
+    monkeypatch.setenv(name, val)
+    with gpu.Session(X, y, score_mode=2) as s:
+        alt = s.sequential_path(seq, ic_type=3)
+        again = s.sequential_path(seq, ic_type=3)
+    for o in (alt, again):
+        assert np.array_equal(o["cand_support"], base["cand_support"])
+        np.testing.assert_allclose(o["cand_ic"], base["cand_ic"], rtol=1e-10)
+        np.testing.assert_allclose(o["cand_beta"], base["cand_beta"], rtol=1e-8, atol=1e-12)
+
+
 def test_score_mode_argument(gpu):
     X, y, _, _ = synth.make_logistic(300, 40, 3)
     with pytest.raises(gpu.BessxError) as e:
