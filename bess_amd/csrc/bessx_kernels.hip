@@ -3424,7 +3424,7 @@ hipError_t launch_score(const double *part, const double *part2, int nrb, int p,
 
 // two-level selection: chunks of <= 32768 scores each keep their k best, a final block selects from the
 // concatenated candidates (already in ascending index order).  cand must hold nchunk*k ints.
-void topk_set_variant(int) {}  // one selection kernel; kept for the benchmark entry point
+void topk_set_variant(int) {}  // reserved: one selection kernel exists
 
 static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_in, int len, int chunk, int k,
                                   int *out, const FitCtrl *ctrl, int slot, hipStream_t st,

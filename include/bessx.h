@@ -192,7 +192,7 @@ int bessx_op_xtv(const double *x, int n, int p, int ld, const double *v, const d
                  double *out2);
 /* K4: max_k (src/utilities.cpp:179-188): the k largest scores, indices ascending, ties -> lower index. */
 int bessx_op_topk(const double *score, int len, int k, int *out_idx);
-/* timing of the top-k kernel on synthetic chi-square scores; variant 0 = bit-by-bit search, 1 = radix search */
+/* timing of the top-k kernel (k_topk) on synthetic chi-square scores; `variant` is reserved (one kernel exists) */
 int bessx_op_topk_bench(int len, int k, int variant, int repeats, double *avg_us);
 /* timing of the register-resident Cholesky solve (k_chol) for an m x m system, 1 <= m <= 254 */
 int bessx_op_chol_bench(int m, int repeats, double *avg_us);
