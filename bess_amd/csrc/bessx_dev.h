@@ -181,7 +181,7 @@ hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
 int cov_streamed_tiles_per_wave();
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
-                            int parked, hipStream_t st, int variant = 2, const int *bgm = nullptr);
+                            int parked, hipStream_t st, int variant = 3, const int *bgm = nullptr);
 hipError_t cov_panel_prepare();
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
                              int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st,

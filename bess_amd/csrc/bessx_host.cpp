@@ -165,8 +165,9 @@ struct bessx_session {
   long long cov_cg_fallbacks = 0;
   int cov_C = 0;              // cache capacity in columns
   int cov_rps = 0, cov_nslab = 0;
-  int cov_variant = 2;        // panel kernel: 2 = LDS-staged, single tile (3 blocks per CU); 1 = double-buffered
-                              // tile (1 block per CU); 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
+  int cov_variant = 3;        // panel kernel: 3 = LDS tile, loads two chunks ahead (2 blocks per CU); 2 = LDS tile,
+                              // one chunk ahead (3 blocks per CU); 1 = double-buffered tile (1 block per CU);
+                              // 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
   double *cov_part = nullptr, *bd2 = nullptr;
   unsigned char *inA = nullptr;        // 1 for the columns of the current active set
   double *cov_bmm = nullptr;           // per-block min / max of k_cov_d's repeated-set shortcut
@@ -2505,10 +2506,10 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         // row slabs: the staged panel kernel runs one 256-thread block per CU at a time (100 KB of LDS), so pick
         // the slab count whose block count wastes the least of the last round of 256 blocks
         long ns = 1, rps = ld;
-        if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(2, std::atoi(ev)));
+        if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(3, std::atoi(ev)));
         {
           // blocks resident at a time: 256 CUs x (1 for the double-buffered tile, 3 for the single one)
-          const long conc = s->cov_variant == 1 ? 256 : 768;
+          const long conc = s->cov_variant == 1 ? 256 : (s->cov_variant == 3 ? 512 : 768);
           double best = 1e300;
           const long ns_max = std::max<long>(1, std::min<long>(64, ld / 256));
           for (long t = 1; t <= ns_max; t++) {

@@ -3117,6 +3117,106 @@ __global__ void __launch_bounds__(256) k_cov_panel_lds(const double *__restrict_
   *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
 }
 
+// Same kernel with the loads running TWO chunks ahead (two register stages, one LDS tile): more bytes in flight
+// per CU at the same LDS footprint (3 blocks per CU).
+template <bool MASKED>
+__global__ void __launch_bounds__(256) k_cov_panel_lds2(const double *__restrict__ X, const double *__restrict__ aux,
+                                                        long ld, int p, const double *__restrict__ mask,
+                                                        const int *__restrict__ fcols, int g0, int ngroups,
+                                                        int rows_per_slab, int nslab, int njg,
+                                                        double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
+                                                        int big, const int *__restrict__ bgm) {
+  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
+  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
+  const long per_group = (long)nslab * njg;
+  const int gl = (int)(blockIdx.x / per_group);
+  if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
+  const int rem = (int)(blockIdx.x - (long)gl * per_group);
+  const int slab = rem / njg, jg = rem - slab * njg;
+  extern __shared__ double smem[];  // [CP_COLS][CP_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
+  const int ru = tid & 31, cbase = tid >> 5;
+  const double *src[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const int cc = i * 8 + cbase;
+    int col;
+    if (cc < 64) {
+      const int j = jg * 64 + cc;
+      col = j < p ? j : -1;
+    } else {
+      col = fcols[(g0 + gl) * COV_R + cc - 64];
+    }
+    src[i] = gram_col(X, aux, ld, col) + 2 * ru;
+  }
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + CP_RB - 1) / CP_RB);
+  d2 stA[12], stB[12], mA, mB;
+#define CP_LOAD(st, ms, r)                                                                                     \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 8; i++) st[i] =                                                      \
+        __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src[i] + (r)));                                \
+    _Pragma("unroll") for (int i = 8; i < 12; i++) st[i] = *reinterpret_cast<const d2 *>(src[i] + (r));        \
+    if (MASKED) ms = *reinterpret_cast<const d2 *>(mask + (r) + 2 * ru);                                       \
+  } while (0)
+#define CP_STORE(st, ms)                                                                                       \
+  do {                                                                                                         \
+    double *dst = smem + 2 * ru;                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 12; i++) {                                                           \
+      d2 v = st[i];                                                                                            \
+      if (MASKED && i >= 8) v = v * ms;                                                                        \
+      *reinterpret_cast<d2 *>(dst + (size_t)(i * 8 + cbase) * CP_LD) = v;                                      \
+    }                                                                                                          \
+  } while (0)
+  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+  const double *pa = smem + (size_t)(wv * 16 + c) * CP_LD + 4 * q;
+  const double *pb0 = smem + (size_t)(64 + c) * CP_LD + 4 * q, *pb1 = smem + (size_t)(80 + c) * CP_LD + 4 * q;
+  auto compute = [&]() {
+#pragma unroll
+    for (int s = 0; s < CP_RB / 16; s++) {
+      const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * s), a1 = *reinterpret_cast<const d2 *>(pa + 16 * s + 2);
+      const d2 x0 = *reinterpret_cast<const d2 *>(pb0 + 16 * s), x1 = *reinterpret_cast<const d2 *>(pb0 + 16 * s + 2);
+      const d2 y0 = *reinterpret_cast<const d2 *>(pb1 + 16 * s), y1 = *reinterpret_cast<const d2 *>(pb1 + 16 * s + 2);
+      const double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
+      const double b0x = x0.x, b0y = x0.y, b0z = x1.x, b0w = x1.y;
+      const double b1x = y0.x, b1y = y0.y, b1z = y1.x, b1w = y1.y;
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b1x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b0y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b1y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b0z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b1z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b0w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b1w, acc1, 0, 0, 0);
+    }
+  };
+  // LDS = chunk k, stage A = chunk k+1, stage B = chunk k+2 (in flight)
+  CP_LOAD(stA, mA, r_begin);
+  CP_STORE(stA, mA);
+  if (nchunk > 1) CP_LOAD(stA, mA, r_begin + CP_RB);
+  if (nchunk > 2) CP_LOAD(stB, mB, r_begin + 2 * CP_RB);
+  __syncthreads();
+  for (int k = 0; k < nchunk; k += 2) {
+    compute();
+    __syncthreads();
+    if (k + 1 < nchunk) CP_STORE(stA, mA);
+    __syncthreads();
+    if (k + 3 < nchunk) CP_LOAD(stA, mA, r_begin + (long)(k + 3) * CP_RB);
+    if (k + 1 >= nchunk) break;
+    compute();
+    __syncthreads();
+    if (k + 2 < nchunk) CP_STORE(stB, mB);
+    __syncthreads();
+    if (k + 4 < nchunk) CP_LOAD(stB, mB, r_begin + (long)(k + 4) * CP_RB);
+  }
+#undef CP_LOAD
+#undef CP_STORE
+  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
+  double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
+  *reinterpret_cast<d4 *>(out + lane * 4) = acc0;
+  *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
+}
+
 // G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
 __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
                                                     int njg, int p, const int *__restrict__ fcols,
@@ -3951,6 +4051,16 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
 #define PANEL_GO(M, D)                                                                                              \
   hipLaunchKernelGGL((k_cov_panel_lds<M, D>), dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0, \
                      ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm)
+    if (variant == 3) {
+      if (mask)
+        hipLaunchKernelGGL(k_cov_panel_lds2<true>, dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0,
+                           ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
+      else
+        hipLaunchKernelGGL(k_cov_panel_lds2<false>, dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols,
+                           g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
+      LAUNCH_CHECK();
+      return hipSuccess;
+    }
     if (mask && variant == 1)
       PANEL_GO(true, true);
     else if (mask)
