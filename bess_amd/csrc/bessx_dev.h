@@ -68,6 +68,8 @@ struct TopkNeed {
   const int *A_cur;
   const double *bmm;  // per-block (min inside, max outside) scores left by k_cov_d, nbmm pairs
   int nbmm;
+  const unsigned char *inA;  // membership flags of the current active set
+  int inc1;                  // the scores are those on which the previous fit (one size smaller) ended: arg-max path
 };
 bool topk_can_fuse_need(int len);
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,

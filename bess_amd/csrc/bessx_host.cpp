@@ -109,6 +109,7 @@ struct bessx_session {
     bool valid = false;  // part_rs / r_rs belong to exactly (beta, coef0) below
     bool cov_layout = false;  // part_rs holds d itself (covariance mode), not row-block partial sums
     double lambda = 0.0;      // covariance mode: the scores in bd were formed with this lambda
+    int T0 = 0;               // ... by a fit of this sparsity level
     SparseVec beta;
     double coef0 = 0.0;
   };
@@ -720,8 +721,10 @@ static bool cov_speculates(const bessx_session *s) { return topk_supported(s->p,
 
 // skip_d: d of exactly the starting coefficients is in memory (previous fit of the chain); scores_ok: so are the
 // sacrifice scores (same lambda), nothing to recompute before the selection.
+// grow1: ... and the previous fit (same row set, the last thing the device ran) had sparsity level T0 - 1 and ended
+// with A_cur = max_k of these very scores: the first selection is A_cur plus one arg-max (k_topk).
 static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d,
-                               bool scores_ok = false) {
+                               bool scores_ok = false, bool grow1 = false) {
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
   if (skip_d && scores_ok) {
@@ -736,7 +739,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   // same launch when the scores fit one chunk of the selection kernel
   if (e == hipSuccess && topk_can_fuse_need(s->p)) {
     TopkNeed nd = {cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, s->cov_C, cv.slot_of, cv.meta, s->cov_fcols,
-                   s->ctrl, s->A_cur, s->cov_bmm, (s->p + 31) / 32};
+                   s->ctrl, s->A_cur, s->cov_bmm, (s->p + 31) / 32, s->inA, (slot == 1 && grow1) ? 1 : 0};
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
   } else if (e == hipSuccess) {
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
@@ -1136,7 +1139,7 @@ static int algorithm_fit_grouped(bessx_session *s) {
 // Queue the first batch of the fit the path function announced (hint) behind the fit `parent`: it starts on the
 // device only if that fit ends on a repeated active set with fresh score sums (k_fit_continue, chained).
 static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, int rs, int parent, int buf, int batch,
-                           double parent_lambda) {
+                           double parent_lambda, int parent_T0) {
   const int Tn = hint.T0;
   if (!(hint.on && s->chain && s->publish && s->warm_start && !s->trace.on && rs == 0 && s->cov_mode && Tn >= 1 &&
         Tn <= s->cap && Tn + 2 * COV_R <= s->cov_C && topk_supported(s->p, Tn)))
@@ -1151,7 +1154,9 @@ static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, in
   ah.buf = buf;
   HIPX(launch_fit_continue(s->ctrl, Tn, s->hist, s->st, ah.serial, 1, parent));
   for (int b = 0, sl = 1; b < batch && sl <= s->max_iter; b++, sl++)
-    if (int rc = enqueue_lm_slot_cov(s, sl, Tn, hint.lambda, rs, sl == 1, hint.lambda == parent_lambda)) return rc;
+    if (int rc = enqueue_lm_slot_cov(s, sl, Tn, hint.lambda, rs, sl == 1, hint.lambda == parent_lambda,
+                                     hint.lambda == parent_lambda && Tn == parent_T0 + 1))
+      return rc;
   return publish_enqueue(s, Tn, buf, &ah.seq);
 }
 
@@ -1195,7 +1200,7 @@ static int algorithm_fit(bessx_session *s) {
     if (cov && use_cache && s->dev_state_rs == rs && mine.T0 == T0 && mine.lambda == lambda && mine.rs == rs &&
         !s->trace.on) {
       // keep the chain going: the fit after this one goes in before this one's result is awaited
-      if (int rc = enqueue_chained(s, hint, rs, mine.serial, mine.buf ^ 1, 2, lambda)) return rc;
+      if (int rc = enqueue_chained(s, hint, rs, mine.serial, mine.buf ^ 1, 2, lambda, T0)) return rc;
       if (int rc = publish_wait(s, mine.buf, mine.seq)) return rc;
       // serial mismatch: the device did not start this fit (its gate failed); the state is still the previous
       // fit's, the fit chained behind it cannot have started either
@@ -1273,7 +1278,9 @@ static int algorithm_fit(bessx_session *s) {
     if (!have_results) {
       const bool first_batch = slot == 1;
       for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
-        if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1, scores_ok)) return rc;
+        if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1, scores_ok,
+                                         scores_ok && cc.T0 + 1 == T0))
+          return rc;
       if (!s->publish) {
         if (int rc = read_results(s, T0)) return rc;
       } else {
@@ -1281,7 +1288,7 @@ static int algorithm_fit(bessx_session *s) {
         if (int rc = publish_enqueue(s, T0, my_buf, &seq)) return rc;
         // chain the announced next fit of the warm-start path behind this one before waiting for this one
         if (first_batch)
-          if (int rc = enqueue_chained(s, hint, rs, my_serial, my_buf ^ 1, batch, lambda)) return rc;
+          if (int rc = enqueue_chained(s, hint, rs, my_serial, my_buf ^ 1, batch, lambda, T0)) return rc;
         if (int rc = publish_wait(s, my_buf, seq)) return rc;
       }
     }
@@ -1410,6 +1417,7 @@ static int algorithm_fit(bessx_session *s) {
   cc.valid = hc->done && hc->d_fresh;
   cc.cov_layout = cov;
   cc.lambda = lambda;
+  cc.T0 = T0;
   cc.beta = s->beta;
   cc.coef0 = s->coef0;
   s->n_fits += 1;

@@ -300,6 +300,67 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
   if (run_flag != nullptr && *run_flag == 0) return;
   __shared__ int wcnt[2][16];
+  if (nd.slot_of != nullptr && nd.inc1 && nd.ctrl->l == 0 && nd.ctrl->k_cur + 1 == k && gridDim.x == 1) {
+    // First iteration of a fit chained behind a fit of size k-1 whose last iteration confirmed A_cur = max_k(bd, k-1)
+    // on exactly these scores: max_k(bd, k) is A_cur plus the best score outside it (ties -> lower index, the same
+    // total order).  An arg-max instead of a selection.
+    __shared__ unsigned long long bk[16];
+    __shared__ int bi[16];
+    unsigned long long best = 0ull;
+    int besti = 0x7fffffff;
+    for (int i = threadIdx.x; i < len_total; i += 1024) {
+      if (!nd.inA[i]) {
+        const unsigned long long key = score_key(score[i]);
+        if (key > best || (key == best && i < besti)) {
+          best = key;
+          besti = i;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long ok = __shfl_xor(best, o);
+      const int oi = __shfl_xor(besti, o);
+      if (ok > best || (ok == best && oi < besti)) {
+        best = ok;
+        besti = oi;
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+      bk[threadIdx.x >> 6] = best;
+      bi[threadIdx.x >> 6] = besti;
+    }
+    __syncthreads();
+    best = bk[0];
+    besti = bi[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++)
+      if (bk[w] > best || (bk[w] == best && bi[w] < besti)) {
+        best = bk[w];
+        besti = bi[w];
+      }
+    // ordered insertion of besti into the sorted A_cur
+    const int *A_old = nd.A_cur;
+    for (int i = threadIdx.x; i < k - 1; i += 1024) {
+      const int a = A_old[i];
+      out[i + (a > besti ? 1 : 0)] = a;
+    }
+    if (threadIdx.x == 0) {
+      int lo = 0, hi = k - 1;  // first position whose element exceeds besti
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A_old[mid] < besti)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      out[lo] = besti;
+      nd.ctrl->fast_same = 0;
+    }
+    __syncthreads();
+    cov_need_body<1024>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
+    return;
+  }
   if (nd.slot_of != nullptr && nd.ctrl->fast_same) {
     // k_cov_d left, per block of 32 columns, the smallest score inside the current active set and the largest
     // outside it.  If every inside score beats every outside score (and the set has the wanted size, and this is
