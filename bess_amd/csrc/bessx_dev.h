@@ -98,6 +98,7 @@ struct CholFuse {
   int hist_stride;
   unsigned char *inA;  // membership flags of the active set (repeated-set shortcut of k_cov_d)
   double yy;           // y.(m y) of the row set (loss from the solved system, k_cg)
+  const double *d;     // X^T (m r) of the current coefficients (start value of entering columns, k_cg)
 };
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,

@@ -701,7 +701,8 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     // gradients warm-started from the previous coefficients (k_cg); if its true residual does not reach 1e-13 it
     // parks the fit (cov_stall = 2) and the Cholesky kernel is issued for the slot (force_chol).
     CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
-                   s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs]};
+                   s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
+                   s->part_rs[rs]};
     if (s->cov_cg && !force_chol)
       e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st);
     else

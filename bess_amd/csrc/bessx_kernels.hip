@@ -1242,7 +1242,14 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
     return y;
   };
   const double q_t = own ? rhs[sA[tid]] : 0.0;
-  double x_t = own ? fz.beta_dense[sA[tid]] : 0.0;  // warm start: previous coefficients of the columns that stay
+  // warm start: previous coefficients of the columns that stay; a column that enters starts from its one-variable
+  // update d_j / (G_jj + ridge) (d = X^T r of the current coefficients is what the scores were made of)
+  double x_t = 0.0;
+  if (own) {
+    x_t = fz.beta_dense[sA[tid]];
+    if (x_t == 0.0 && fz.d != nullptr && sS[tid] >= 0)
+      x_t = fz.d[sA[tid]] / (fz.G[(size_t)sS[tid] * fz.p + sA[tid]] + ridge);
+  }
   const double qq = dot(q_t, q_t);
   double r_t = q_t - (matvec(x_t) + ridge * x_t);
   double p_t = r_t;
