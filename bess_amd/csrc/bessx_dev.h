@@ -142,7 +142,7 @@ struct CoxBufs {
   double *llpart;
   double *SCR;                                         // block totals of the multi-block scans
 };
-size_t cox_scan_scratch_doubles(long ld);
+size_t cox_scan_scratch_doubles(long ld, int kmax);
 hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,
                             const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, CoxBufs cb,
                             double *stats, hipStream_t st);
@@ -156,7 +156,7 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                                   FitCtrl *ctrl, int slot, int t, const int *A_new, int k, double lambda,
                                   const int *gcols, const int *idcols, int mt, const GramTask *tasks, int ntask,
                                   int rps, int nslab, double *gpart, int ntiles, double *Gt, CoxBufs cb,
-                                  hipStream_t st);
+                                  hipStream_t st, double *rdiag, double *zbig);
 hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const double *w1, const double *w2, int N,
                                 const int *gidx, const int *gsz, const int *goff, double *mblk, double *dcol,
                                 hipStream_t st);

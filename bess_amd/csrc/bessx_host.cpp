@@ -869,6 +869,35 @@ static int enqueue_glm_tail(bessx_session *s, int slot, int T0, int rs) {
 // Cox: GroupPdasCox::get_A (two passes over X: block sums, then per-column suffix scans with carries) and
 // primary_model_fit (damped Newton with step halving, everything gated on the device).
 // --------------------------------------------------------------------------------------------
+// Cox work space for sparsity levels above 254: the n x k matrix M = S1/S0, the second Gram and the scan scratch grow
+// to the tile-rounded size of the level asked for (once; the largest level of a path comes first only by luck, so the
+// growth is geometric).
+static int cox_reserve(bessx_session *s, int T0) {
+  const size_t need = (size_t)((T0 + 1 + 15) / 16) * 16;
+  if (need <= s->cox_M_cols) return 0;
+  size_t cols = std::min<size_t>((size_t)s->capA, std::max(need, 2 * s->cox_M_cols));
+  CoxBufs &c = s->cox;
+  HIPX(hipStreamSynchronize(s->st));
+  auto regrow = [&](double **ptr, size_t count) -> hipError_t {
+    for (auto &q : s->cox_allocs)
+      if (q == *ptr) {
+        (void)hipFree(*ptr);
+        *ptr = nullptr;
+        hipError_t e = dmalloc(ptr, count);
+        q = *ptr;
+        if (e == hipSuccess) e = hipMemset(*ptr, 0, count * sizeof(double));
+        return e;
+      }
+    return hipErrorInvalidValue;
+  };
+  const size_t mt = cols / 16;
+  HIPX(regrow(&c.M, (size_t)s->ld * cols));
+  HIPX(regrow(&c.Gt2, mt * (mt + 1) / 2 * 256));
+  HIPX(regrow(&c.SCR, cox_scan_scratch_doubles(s->ld, (int)cols)));
+  s->cox_M_cols = cols;
+  return 0;
+}
+
 static int enqueue_cox_head(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
                             std::vector<std::pair<size_t, bool>> &k1_pairs) {
   const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
@@ -897,13 +926,16 @@ static int enqueue_cox_head(bessx_session *s, int slot, int T0, double lambda, i
 
 static int enqueue_cox_newton(bessx_session *s, int slot, int t, int T0, double lambda, int rs) {
   const int mt = (T0 + 1 + 15) / 16;
-  const int ntask = s->gtask_cnt[mt], ntiles = mt * (mt + 1) / 2;
+  const GramTask *tk = nullptr;
+  int ntask = 0;
+  if (int rc = gram_tasks_for(s, mt, &tk, &ntask)) return rc;
+  const int ntiles = mt * (mt + 1) / 2;
   int rps, nslab;
   gram_geometry(s, ntask, &rps, &nslab, ntiles);
   if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
   hipError_t e = launch_cox_newton_step(s->X, s->aux, s->ld, s->n, s->mask[rs], s->ctrl, slot, t, s->A_new, T0, lambda,
-                                        s->gcols, s->idcols, mt, s->gtasks + s->gtask_off[mt], ntask, rps, nslab,
-                                        s->gpart, ntiles, s->Gt, s->cox, s->st);
+                                        s->gcols, s->idcols, mt, tk, ntask, rps, nslab, s->gpart, ntiles, s->Gt, s->cox,
+                                        s->st, s->rdiag, s->zbig);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cox_newton: ") + hipGetErrorString(e));
   return 0;
 }
@@ -1169,8 +1201,8 @@ static int algorithm_fit(bessx_session *s) {
   if (T0 < 1 || T0 > s->cap)
     return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, min(p, " +
                                    std::to_string(T0_CAP) + ")]");
-  if (s->model_type == 4 && T0 > T0_FAST)
-    return fail(BESSX_ERR_UNSUPPORTED, "Cox: sparsity levels above " + std::to_string(T0_FAST) + " are not built yet");
+  if (s->model_type == 4)
+    if (int rc = cox_reserve(s, T0)) return rc;
   if (!topk_supported(s->p, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: p too large for this sparsity level");
   const bool glm = s->model_type != 1;  // sub-model fit is an iteration chain (IRLS or Newton)
   const bool cox = s->model_type == 4;
@@ -2568,7 +2600,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       }
     }
   }
-  HIPT(dmalloc(&s->idcols, 256));
+  HIPT(dmalloc(&s->idcols, (size_t)capA + 16));
   if (s->model_type == 4) {
     auto V = [&](double **dst, size_t count) -> hipError_t {
       hipError_t e = dmalloc(dst, count);
@@ -2582,13 +2614,15 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     double **vecs[] = {&c.E, &c.TH, &c.ET, &c.S0, &c.RS0, &c.SALL, &c.STEST, &c.EW, &c.WD, &c.ETA0, &c.THF, &c.S0F,
                        &c.RS0F, &c.VG, &c.WG1, &c.UD, &c.TH1, &c.S1};
     for (auto v : vecs) HIPT(V(v, (size_t)ld));
-    HIPT(V(&c.M, (size_t)ld * 256));
-    HIPT(V(&c.g, 256));
-    HIPT(V(&c.u, 256));
-    HIPT(V(&c.b0, 256));
+    // k-sized work space: for sparsity levels up to 254 now, grown by cox_reserve() when a larger one is asked for
+    s->cox_M_cols = 256;
+    HIPT(V(&c.M, (size_t)ld * s->cox_M_cols));
+    HIPT(V(&c.g, (size_t)capA));
+    HIPT(V(&c.u, (size_t)capA));
+    HIPT(V(&c.b0, (size_t)capA));
     HIPT(V(&c.Gt2, (size_t)136 * 256));
     HIPT(V(&c.llpart, (size_t)(n + 255) / 256 + 1));
-    HIPT(V(&c.SCR, cox_scan_scratch_doubles(ld)));
+    HIPT(V(&c.SCR, cox_scan_scratch_doubles(ld, 256)));
   }
   if (s->model_type == 1) TRY(prepare_rowset(s, 0));
   HIPT(hipStreamSynchronize(s->st));

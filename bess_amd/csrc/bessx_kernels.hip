@@ -2345,11 +2345,11 @@ __global__ void __launch_bounds__(256) k_cox_score(const double *__restrict__ pa
 #define COX_NEWTON_GATE(ctrl, slot, t) \
   ((ctrl)->done || (ctrl)->l != (slot)-1 || (ctrl)->same_prev || (ctrl)->irls_done || (ctrl)->irls_steps != (t)-1)
 
-__global__ void __launch_bounds__(256) k_cox_newton_begin(FitCtrl *__restrict__ ctrl, int slot, int k,
+__global__ void __launch_bounds__(256) k_cox_newton_begin(FitCtrl *__restrict__ ctrl, int slot, int k, int mp,
                                                           double *__restrict__ b0, int *__restrict__ idcols) {
   if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
   for (int i = threadIdx.x; i < k; i += 256) b0[i] = 0.0;
-  for (int i = threadIdx.x; i < 256; i += 256) idcols[i] = i < k ? i : -1;  // Gram columns of M, zero padding
+  for (int i = threadIdx.x; i < mp; i += 256) idcols[i] = i < k ? i : -1;  // Gram columns of M, zero padding
   if (threadIdx.x == 0) {
     ctrl->ll0 = 1e5;  // :1393
     ctrl->ls_m = 0;
@@ -3868,7 +3868,9 @@ static hipError_t launch_scan3(const double *in0, const double *in1, const doubl
   return hipSuccess;
 }
 
-size_t cox_scan_scratch_doubles(long ld) { return (size_t)(2 * 256 + 4) * (size_t)((ld + SC_B - 1) / SC_B); }
+size_t cox_scan_scratch_doubles(long ld, int kmax) {
+  return (size_t)(2 * std::max(kmax, 8) + 16) * (size_t)((ld + SC_B - 1) / SC_B);
+}
 
 hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,
                             const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, CoxBufs cb,
@@ -3920,7 +3922,8 @@ hipError_t launch_cox_score(const double *part, const double *part2, int nrb, in
 }
 
 hipError_t launch_cox_newton_begin(FitCtrl *ctrl, int slot, int k, CoxBufs cb, int *idcols, hipStream_t st) {
-  hipLaunchKernelGGL(k_cox_newton_begin, dim3(1), dim3(256), 0, st, ctrl, slot, k, cb.b0, idcols);
+  const int mp = (k + 1 + 15) / 16 * 16;
+  hipLaunchKernelGGL(k_cox_newton_begin, dim3(1), dim3(256), 0, st, ctrl, slot, k, mp, cb.b0, idcols);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -3929,7 +3932,7 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                                   FitCtrl *ctrl, int slot, int t, const int *A_new, int k, double lambda,
                                   const int *gcols, const int *idcols, int mt, const GramTask *tasks, int ntask,
                                   int rps, int nslab, double *gpart, int ntiles, double *Gt, CoxBufs cb,
-                                  hipStream_t st) {
+                                  hipStream_t st, double *rdiag, double *zbig) {
   const int nb2 = (int)((ld + 255) / 256);
   hipLaunchKernelGGL(k_cox_fit_eta, dim3(nb2), dim3(128), 0, st, X, ld, n, mask, (const FitCtrl *)ctrl, slot, t,
                      A_new, k, (const double *)cb.b0, cb.ETA0, cb.THF);
@@ -3964,7 +3967,9 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
   hipLaunchKernelGGL(k_tile_sub, dim3((ntiles * 256 + 255) / 256), dim3(256), 0, st, Gt, (const double *)cb.Gt2,
                      (long)ntiles * 256, (const FitCtrl *)ctrl, slot, t);
   LAUNCH_CHECK();
-  e = launch_chol(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, ctrl, slot, 2, st);
+  e = mt <= CH_MT ? launch_chol(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, ctrl, slot, 2, st)
+                  : launch_chol_big(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, rdiag, zbig, ctrl, slot,
+                                    2, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_cox_dir, dim3(nb2), dim3(128), 0, st, X, ld, (const FitCtrl *)ctrl, slot, t, A_new, k,
                      (const double *)cb.u, cb.UD);

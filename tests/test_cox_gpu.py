@@ -33,3 +33,10 @@ def test_cox_cv_and_weights(gpu):
 def test_cox_bigger(gpu, n, p):
     X, _, status, _, _ = synth.make_cox(n, p, 8, seed=n)
     check(gpu, X, status, dict(COX, ic_type=3, sequence=np.arange(1, 17)), "cox %dx%d" % (n, p))
+
+
+def test_cox_sparsity_levels_above_254(gpu):
+    """Beyond the register-resident solver: the n x k work space grows on demand and the Newton system is solved by
+    the blocked Cholesky (the reference's default s.list reaches min(p, n / log n))."""
+    X, _, status, _, _ = synth.make_cox(1200, 400, 10, seed=77)
+    check(gpu, X, status, dict(COX, ic_type=3, sequence=[250, 256, 300]), "cox k>254")
