@@ -1108,8 +1108,9 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
 // recurrence); otherwise (ill-conditioned design, iteration cap) the fit is parked with cov_stall = 2 and the host
 // issues the Cholesky kernel for this slot.  Ends with the loss terms and k_commit's work like the fused k_chol.
 // ------------------------------------------------------------------------------------------
-template <int CH_SLOTS>
-__global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const double *__restrict__ rhs,
+// NW = waves of the workgroup: 8, or 1 for systems of at most 64 unknowns (no block barriers at all then).
+template <int CH_SLOTS, int NW>
+__global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, const double *__restrict__ rhs,
                                             const int *__restrict__ A_new, double *__restrict__ sol,
                                             const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit) {
   __shared__ int same_any_sh;
@@ -1119,20 +1120,30 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
                 fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
     return;
   }
+  // one wave: LDS traffic of a wave is in order, a fence keeps the compiler from reordering it
+#define CG_SYNC()                                            \
+  do {                                                       \
+    if (NW == 1) {                                           \
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+      __builtin_amdgcn_wave_barrier();                       \
+    } else {                                                 \
+      __syncthreads();                                       \
+    }                                                        \
+  } while (0)
   __shared__ int sA[CH_MT * 16], sS[CH_MT * 16];
   __shared__ double pv[CH_MT * 16];
-  __shared__ double yw[2][CH_W][CH_MT * 16];
-  __shared__ double red[2][CH_W], red2[2][CH_W];
+  __shared__ double yw[2][NW][CH_MT * 16];
+  __shared__ double red[2][NW], red2[2][NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lc = lane & 15, lq = lane >> 4;
   const int mp = mt * 16, ntiles = mt * (mt + 1) / 2;
-  for (int i = tid; i < mp; i += 512) {
+  for (int i = tid; i < mp; i += 64 * NW) {
     const int a = i < m ? A_new[i] : 0;
     sA[i] = a;
     sS[i] = i < m ? fz.slot_of[a] : 0;
   }
-  __syncthreads();
+  CG_SYNC();
   d4 acc[CH_SLOTS];
   int tI[CH_SLOTS], tJ[CH_SLOTS];
   {
@@ -1142,10 +1153,10 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
     tj = __builtin_amdgcn_readfirstlane(tj);
 #pragma unroll
     for (int s = 0; s < CH_SLOTS; s++) {
-      const bool have = s * CH_W + wave < ntiles;
+      const bool have = s * NW + wave < ntiles;
       tI[s] = __builtin_amdgcn_readfirstlane(have ? ti : -1);
       tJ[s] = __builtin_amdgcn_readfirstlane(have ? tj : -1);
-      tj += CH_W;
+      tj += NW;
       while (tj > ti) {
         tj -= ti + 1;
         ti++;
@@ -1184,10 +1195,10 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
       red[rb][wave] = v;
       red2[rb][wave] = u;
     }
-    __syncthreads();
+    CG_SYNC();
     double t = red[rb][0], t2 = red2[rb][0];
 #pragma unroll
-    for (int w = 1; w < CH_W; w++) {
+    for (int w = 1; w < NW; w++) {
       t += red[rb][w];
       t2 += red2[rb][w];
     }
@@ -1208,7 +1219,7 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
     double(*yy)[CH_MT * 16] = yw[yb];
 #pragma unroll
     for (int q = 0; q < CH_MT * 16 / 64; q++) yy[wave][lane + 64 * q] = 0.0;
-    __syncthreads();
+    CG_SYNC();
 #pragma unroll
     for (int s = 0; s < CH_SLOTS; s++) {
       if (tI[s] >= 0) {
@@ -1232,11 +1243,11 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
         }
       }
     }
-    __syncthreads();
+    CG_SYNC();
     double y = 0.0;
     if (tid < mp) {
 #pragma unroll
-      for (int w = 0; w < CH_W; w++) y += yy[w][tid];
+      for (int w = 0; w < NW; w++) y += yy[w][tid];
     }
     yb ^= 1;
     return y;
@@ -1294,10 +1305,10 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) gd = fmax(gd, __shfl_xor(gd, o));
     if (lane == 0) red[rb][wave] = gd;
-    __syncthreads();
+    CG_SYNC();
     gd = red[rb][0];
 #pragma unroll
-    for (int w = 1; w < CH_W; w++) gd = fmax(gd, red[rb][w]);
+    for (int w = 1; w < NW; w++) gd = fmax(gd, red[rb][w]);
     rb ^= 1;
     if (tid == 0) {
       const double tr = fz.yy - a1 - ridge * a2;
@@ -1307,10 +1318,12 @@ __global__ void __launch_bounds__(512) k_cg(int m, int mt, double ridge, const d
           (tr > 1e-6 * fz.yy && 4e-16 * (a3 + (ridge + gd) * a2 + fz.yy) <= 1e-10 * tr) ? 1 : 0;
     }
   }
-  __syncthreads();
+  CG_SYNC();
   commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
               fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
 }
+
+#undef CG_SYNC
 
 // ------------------------------------------------------------------------------------------
 // K7, large systems (m + 1 > 256): blocked right-looking Cholesky on the tile-layout matrix in global memory
@@ -3727,18 +3740,20 @@ hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *
                      int slot, const CholFuse *fuse, int maxit, hipStream_t st) {
   if (mt < 1 || m > mt * 16 || mt > CH_MT || fuse == nullptr) return hipErrorInvalidValue;
   const CholFuse fz = *fuse;
-#define CG_GO(S) \
-  hipLaunchKernelGGL(k_cg<S>, dim3(1), dim3(512), 0, st, m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit)
+#define CG_GO(S, W)                                                                                                  \
+  hipLaunchKernelGGL((k_cg<S, W>), dim3(1), dim3(64 * W), 0, st, m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit)
+  // (a one-wave instance for <= 64 unknowns, CG_GO(10, 1), was measured slower: the gather and the tile loop
+  // serialise)
   if (mt <= 8)
-    CG_GO(5);
+    CG_GO(5, 8);
   else if (mt <= 10)
-    CG_GO(7);
+    CG_GO(7, 8);
   else if (mt <= 12)
-    CG_GO(10);
+    CG_GO(10, 8);
   else if (mt <= 14)
-    CG_GO(14);
+    CG_GO(14, 8);
   else
-    CG_GO(17);
+    CG_GO(17, 8);
 #undef CG_GO
   LAUNCH_CHECK();
   return hipSuccess;
