@@ -25,7 +25,7 @@ SYMBOLS = [
     "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
-    "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
+    "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_session_reset_caches", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench",
 ]
 
@@ -91,6 +91,7 @@ def lib():
         L.bessx_session_score_pass_stats.argtypes = [_vp, _i, _D, ctypes.POINTER(_ll), _D]
         L.bessx_session_enable_kernel_timing.argtypes = [_vp, _i]
         L.bessx_session_fit.argtypes = [_vp, _i, _d, _i, _I, _D, _i, _d, _I, _D, _D, _I, _D, _D]
+        L.bessx_session_reset_caches.argtypes = [_vp]
         L.bessx_op_xtv.argtypes = [_D, _i, _i, _i, _D, _D, _D, _D]
         L.bessx_op_topk.argtypes = [_D, _i, _i, _I]
         L.bessx_op_gram.argtypes = [_D, _i, _i, _i, _I, _i, _D, _D]
@@ -298,6 +299,10 @@ class Session:
                                        ctypes.byref(te)))
         return {"support": sup, "beta": b, "coef0": c0.value, "iters": it.value, "train_loss": tr.value,
                 "test_loss": te.value}
+
+    def reset_caches(self):
+        """Start cold, like a path call does (bessx_session_reset_caches)."""
+        _check(lib().bessx_session_reset_caches(self._h))
 
     def _trace(self):
         L = lib()

@@ -2843,6 +2843,13 @@ int bessx_session_get_screening(const bessx_session *s, int *columns, int cap) {
   return s->p;
 }
 
+int bessx_session_reset_caches(bessx_session *s) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  HIPX(hipSetDevice(s->device));
+  for (auto &v : s->cv_init) v.clear();
+  return reset_path_caches(s);
+}
+
 int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx, const double *init_val,
                       int init_len, double init_coef0, int *support, double *beta, double *coef0, int *iters,
                       double *train_loss, double *test_loss) {

@@ -46,3 +46,215 @@ def gather_rows(local_values, world, device=None):
 def select_best(curve):
     """argmin with the reference's tie rule: the first minimum wins (Eigen minCoeff, src/path.cpp:113)."""
     return int(np.argmin(curve))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Cross-validated paths with the fold fits dealt to ranks (SURVEY.md 8e, BASELINE configs[3]).
+#
+# Under CV one candidate (s, lambda) = the full-data Algorithm::fit + K fold fits (Metric::test_loss,
+# src/Metric.h:150-195).  Every fold is its own warm-start chain (cv_initial_model_param.row(k), :177-188) and the
+# full-data fits are another one (src/path.cpp:60-64, :173-177); a fold fit reads nothing of the full-data fit of
+# the same candidate (its coef0_init is the one the path handed to that fit, i.e. the PREVIOUS candidate's).  So the
+# K + 1 chains are the independent units: unit u lives on rank u % world for the whole path, which keeps every
+# chain exactly as the single-process path runs it -- the results do not depend on the number of ranks.  X is
+# replicated; the only communication is one all-gather of the K + 1 small fit records per evaluation.
+# ------------------------------------------------------------------------------------------------------------
+class _NoComm:
+    """world = 1: the all-gather is the identity."""
+
+    def all_gather(self, mine, world):
+        return [mine]
+
+
+class _TorchComm:
+    def __init__(self, device=None):
+        self.device = device
+
+    def all_gather(self, mine, world):
+        import torch
+        import torch.distributed as dist
+        t = torch.as_tensor(mine, dtype=torch.float64, device=self.device)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.cpu().numpy() for o in out]
+
+
+class FoldShardedCV:
+    """sequential_path / gs_path under cross-validation (src/path.cpp:25-389 with Metric::is_cv) over `world`
+    ranks.  `session` is this rank's solver on the replicated data with the folds already set
+    (bess_amd.capi.Session after set_cv): it needs fit(T0, lam, fold, init_idx, init_val, init_coef0) ->
+    {support, beta, coef0, iters, train_loss, test_loss}, normalization(), n, p.  Returns the same dictionary
+    keys as Session.gs_path / Session.sequential_path on every rank."""
+
+    HEAD = 5  # record = [T0, iters, coef0, train_loss, test_loss, support[T0 ...], beta[T0 ...]]
+
+    def __init__(self, session, K, world=1, rank=0, is_warm_start=True, data_type=1, is_normal=True, device=None):
+        self.s, self.K, self.world, self.rank = session, int(K), int(world), int(rank)
+        self.warm = bool(is_warm_start)
+        self.data_type, self.is_normal = data_type, is_normal
+        self.comm = _TorchComm(device) if world > 1 else _NoComm()
+        self.units = [u for u in range(self.K + 1) if u % self.world == self.rank]  # unit K = the full-data chain
+        self.per_rank = -(-(self.K + 1) // self.world)
+        self.cv_init = {k: (np.zeros(0, np.int32), np.zeros(0)) for k in range(self.K)}  # cv_initial_model_param
+        self.n_fits = 0
+        self.n_pdas_iters = 0
+        self.evaluations = 0
+        if hasattr(session, "reset_caches"):
+            session.reset_caches()  # a path starts cold, like a bessCpp call
+
+    # -- one evaluation round: the units of this rank, then the all-gather of the records ------------------
+    def _round(self, T0, lam, want_full, want_folds, full_init, coef0_init):
+        reclen = self.HEAD + 2 * T0
+        mine = np.full((self.per_rank, reclen), np.nan)
+        row = 0
+        for u in self.units:
+            if u == self.K:
+                if not want_full:
+                    continue
+                r = self.s.fit(T0, lam, -1, full_init[0], full_init[1], coef0_init)
+            else:
+                if not want_folds:
+                    continue
+                init = self.cv_init[u] if self.warm else (np.zeros(0, np.int32), np.zeros(0))
+                r = self.s.fit(T0, lam, u, init[0], init[1], coef0_init)
+                if self.warm:
+                    self.cv_init[u] = (r["support"].copy(), r["beta"].copy())
+            mine[row, :self.HEAD] = (u, r["iters"], r["coef0"], r["train_loss"], r["test_loss"])
+            mine[row, self.HEAD:self.HEAD + T0] = r["support"]
+            mine[row, self.HEAD + T0:] = r["beta"]
+            row += 1
+        recs = {}
+        for block in self.comm.all_gather(mine, self.world):
+            for rec in block:
+                if not np.isnan(rec[0]):
+                    recs[int(rec[0])] = {"iters": int(rec[1]), "coef0": float(rec[2]), "train_loss": float(rec[3]),
+                                         "test_loss": float(rec[4]),
+                                         "support": rec[self.HEAD:self.HEAD + T0].astype(np.int32),
+                                         "beta": rec[self.HEAD + T0:].copy()}
+        self.evaluations += 1
+        self.n_fits += len(recs)
+        self.n_pdas_iters += sum(r["iters"] for r in recs.values())
+        return recs
+
+    @staticmethod
+    def _cv_loss(recs, K):
+        acc = 0.0
+        for k in range(K):  # fold order, like the single-process path
+            acc += recs[k]["test_loss"]
+        return acc / K
+
+    def _denorm(self, sup, beta, coef0, gs_variant):
+        """src/path.cpp:76-110 (sequential) / :330-342 (golden section)."""
+        beta = np.array(beta, dtype=np.float64)
+        if not self.is_normal:
+            return beta, coef0
+        xm, xn, ym = self.s.normalization()
+        beta = np.sqrt(float(self.s.n)) * beta / xn[sup]
+        dot = float(np.dot(beta, xm[sup]))
+        if self.data_type == 1:
+            coef0 = ym - dot
+        elif self.data_type == 2 or gs_variant:
+            coef0 = coef0 - dot
+        return beta, coef0
+
+    def _result(self, cands, best, gs_variant):
+        out = {k: [] for k in ("cand_T0", "cand_lambda", "cand_iters", "cand_train_loss", "cand_ic", "cand_coef0",
+                               "cand_support", "cand_beta")}
+        for c in cands:
+            b, c0 = self._denorm(c["support"], c["beta"], c["coef0"], gs_variant)
+            out["cand_T0"].append(c["T0"])
+            out["cand_lambda"].append(c["lambda"])
+            out["cand_iters"].append(c["iters"])
+            out["cand_train_loss"].append(c["loss"])
+            out["cand_ic"].append(c["ic"])
+            out["cand_coef0"].append(c0)
+            out["cand_support"].append(np.asarray(c["support"]))
+            out["cand_beta"].append(b)
+        b, c0 = self._denorm(best["support"], best["beta"], best["coef0"], gs_variant)
+        beta = np.zeros(self.s.p)
+        beta[best["support"]] = b
+        out.update({"beta": beta, "coef0": c0, "train_loss": best["loss"], "ic": best["ic"],
+                    "lambda": best["lambda"], "best_T0": best["T0"], "best_iters": best["iters"],
+                    "n_candidates": len(cands), "n_fits": self.n_fits, "n_pdas_iters": self.n_pdas_iters,
+                    "evaluations": self.evaluations})
+        for k in ("cand_T0", "cand_iters"):
+            out[k] = np.asarray(out[k], dtype=np.int32)
+        for k in ("cand_lambda", "cand_train_loss", "cand_ic", "cand_coef0"):
+            out[k] = np.asarray(out[k], dtype=np.float64)
+        return out
+
+    # -- sequential_path, src/path.cpp:25-132 --------------------------------------------------------------
+    def sequential_path(self, sequence, lambda_seq=(0.0,)):
+        seq, lam = [int(v) for v in sequence], [float(v) for v in lambda_seq]
+        ns, nl = len(seq), len(lam)
+        full_init, coef0_init = (np.zeros(0, np.int32), np.zeros(0)), 0.0
+        grid, cands = {}, []
+        for i in range(ns):
+            order = range(nl) if i % 2 == 0 else range(nl - 1, -1, -1)  # snake order, :50
+            for j in order:
+                recs = self._round(seq[i], lam[j], True, True, full_init, coef0_init)
+                full = recs[self.K]
+                if self.warm:
+                    full_init, coef0_init = (full["support"], full["beta"]), full["coef0"]
+                c = {"T0": seq[i], "lambda": lam[j], "support": full["support"], "beta": full["beta"],
+                     "coef0": full["coef0"], "iters": full["iters"], "loss": full["train_loss"],
+                     "ic": self._cv_loss(recs, self.K)}
+                grid[j * ns + i] = c
+                cands.append(c)
+        best = grid[0]
+        for q in range(ns * nl):  # minCoeff over the column-major (ns x nl) matrix: first minimum, :113
+            if grid[q]["ic"] < best["ic"]:
+                best = grid[q]
+        return self._result(cands, best, False)
+
+    # -- gs_path, src/path.cpp:134-389 ---------------------------------------------------------------------
+    def gs_path(self, s_min, s_max):
+        st = {"full_init": (np.zeros(0, np.int32), np.zeros(0)), "coef0_init": 0.0}
+        cands = []
+
+        def fit_point(T, twice):
+            # the full-data fit and the first ic() are independent: one round; the second ic() (:204+:210,
+            # :245+:253, :286+:294) continues the fold chains, a second round without the full-data unit
+            coef0_prev = st["coef0_init"]
+            recs = self._round(T, 0.0, True, True, st["full_init"], coef0_prev)
+            full = recs[self.K]
+            if self.warm:
+                st["full_init"], st["coef0_init"] = (full["support"], full["beta"]), full["coef0"]
+            first = self._cv_loss(recs, self.K)
+            cands.append({"T0": T, "lambda": 0.0, "support": full["support"], "beta": full["beta"],
+                          "coef0": full["coef0"], "iters": full["iters"], "loss": full["train_loss"], "ic": first})
+            second = None
+            if twice:
+                second = self._cv_loss(self._round(T, 0.0, False, True, None, coef0_prev), self.K)
+            return first, second
+
+        rnd = lambda v: int(np.floor(v + 0.5)) if v >= 0 else -int(np.floor(-v + 0.5))  # std::round
+        Tmin, Tmax = int(s_min), int(s_max)
+        T1, T2 = rnd(0.618 * Tmin + 0.382 * Tmax), rnd(0.382 * Tmin + 0.618 * Tmax)
+        ic1, _ = fit_point(T1, False)
+        icT1 = ic1
+        ic2, icT2 = fit_point(T2, True)
+        while T1 != T2:
+            if icT1 < icT2:
+                Tmax, T2, ic2, icT2 = T2, T1, ic1, ic1
+                T1 = rnd(0.618 * Tmin + 0.382 * Tmax)
+                ic1, icT1 = fit_point(T1, True)
+            else:
+                Tmin, T1, ic1, icT1 = T1, T2, ic2, ic2
+                T2 = rnd(0.382 * Tmin + 0.618 * Tmax)
+                ic2, icT2 = fit_point(T2, True)
+        best = {"T0": 0, "lambda": 0.0, "support": np.zeros(0, np.int32), "beta": np.zeros(0), "coef0": 0.0,
+                "loss": 0.0, "ic": np.finfo(np.float64).max, "iters": 0}
+        for T in range(Tmin, Tmax + 1):
+            coef0_prev = st["coef0_init"]
+            recs = self._round(T, 0.0, True, True, st["full_init"], coef0_prev)
+            full = recs[self.K]
+            if self.warm:
+                st["full_init"], st["coef0_init"] = (full["support"], full["beta"]), full["coef0"]
+            v = self._cv_loss(recs, self.K)
+            if v < best["ic"]:
+                last = recs[self.K - 1]  # read AFTER ic(): the last fold's fit, src/path.cpp:314-319
+                best = {"T0": T, "lambda": 0.0, "support": last["support"], "beta": last["beta"],
+                        "coef0": last["coef0"], "loss": last["train_loss"], "ic": v, "iters": full["iters"]}
+                cands.append(best)
+        return self._result(cands, best, True)

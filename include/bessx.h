@@ -178,6 +178,10 @@ int bessx_session_enable_kernel_timing(bessx_session *s, int on);
  *    iters (Algorithm::l), train_loss = the family's train_loss on ALL rows (src/Metric.h:145,266,
  *    426,565), test_loss = the family's CV test loss on the fold's test rows (0 when fold < 0).
  * ------------------------------------------------------------------------------------- */
+/* Forget everything a previous fit left on the device beyond the data (score sums, cached Gram columns, fold
+ * warm starts): the state a path call starts from (a bessCpp call starts from nothing).  A caller that builds its own
+ * path out of bessx_session_fit (bess_amd/dist.py) calls this first, so that a repeated path does not reuse work. */
+int bessx_session_reset_caches(bessx_session *s);
 int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx,
                       const double *init_val, int init_len, double init_coef0, int *support, double *beta,
                       double *coef0, int *iters, double *train_loss, double *test_loss);

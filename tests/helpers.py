@@ -28,3 +28,50 @@ def assert_same_trace(got, want, beta_rtol=1e-6, what=""):
         np.testing.assert_allclose(a["coef0s"], b["coef0s"], rtol=beta_rtol, atol=beta_rtol * 1e-3)
     np.testing.assert_allclose(got["ic_calls"], want["ic_calls"], rtol=1e-9, atol=1e-9, err_msg=what + " ic values")
     np.testing.assert_allclose(got["loss_calls"], want["loss_calls"], rtol=1e-9, atol=1e-12, err_msg=what + " loss values")
+
+
+class NumpyLmSession:
+    """CPU stand-in for bess_amd.capi.Session in the multi-rank HOST-LOGIC tests (gloo): the LM fit primitive
+    (Algorithm::fit with GroupPdasLm::get_A / primary_model_fit, src/Algorithm.h:113-171, :1097-1135, singleton
+    groups, unit weights) in NumPy on the normalised data (Normalize, src/normalize.cpp:20-46).  Test
+    infrastructure only; the results of the paths built on it are checked against the pinned plain-C oracle."""
+
+    def __init__(self, X, y, fold_id, K, max_iter=20):
+        X = np.array(X, dtype=np.float64)
+        self.n, self.p = X.shape
+        self.x_mean = X.mean(axis=0)
+        self.y_mean = float(np.mean(y))
+        X = X - self.x_mean
+        self.x_norm = np.sqrt((X * X).sum(axis=0))
+        self.X = np.sqrt(self.n) * X / self.x_norm
+        self.y = np.asarray(y, dtype=np.float64) - self.y_mean
+        self.fold_id, self.K, self.max_iter = np.asarray(fold_id), K, max_iter
+
+    def normalization(self):
+        return self.x_mean, self.x_norm, self.y_mean
+
+    def fit(self, T0, lam=0.0, fold=-1, init_idx=(), init_val=(), init_coef0=0.0):
+        train = np.ones(self.n, bool) if fold < 0 else self.fold_id != fold
+        Xt, yt = self.X[train], self.y[train]
+        nt = Xt.shape[0]
+        phi = np.sqrt(2 * lam + (Xt * Xt).sum(axis=0) / nt)
+        beta = np.zeros(self.p)
+        beta[np.asarray(init_idx, dtype=int)] = init_val
+        seen = [np.zeros(T0, dtype=np.int64)]
+        for l in range(1, self.max_iter + 1):
+            d = Xt.T @ (yt - Xt @ beta - init_coef0) / nt - 2 * lam * beta
+            bd = (phi * beta + d * (1.0 / phi)) ** 2
+            A = np.sort(np.lexsort((np.arange(self.p), -bd))[:T0])
+            XA = Xt[:, A]
+            bA = np.linalg.solve(XA.T @ XA + lam * np.eye(T0), XA.T @ yt)
+            beta = np.zeros(self.p)
+            beta[A] = bA
+            stop = any(np.array_equal(A, a) for a in seen)
+            seen.append(A)
+            if stop:
+                break
+        res = self.y - self.X @ beta
+        test = ~train
+        return {"support": A.astype(np.int32), "beta": bA, "coef0": float(init_coef0), "iters": l,
+                "train_loss": float(res @ res) / self.n,
+                "test_loss": float(res[test] @ res[test]) / (2 * max(int(test.sum()), 1)) if fold >= 0 else 0.0}

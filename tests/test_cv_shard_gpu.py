@@ -1,0 +1,59 @@
+"""Fold-sharded cross-validated paths (bess_amd.dist.FoldShardedCV, SURVEY 8e / BASELINE configs[3]) on the GPU:
+built on bessx_session_fit, they must reproduce the library's own single-process gs_path / sequential_path under
+CV exactly (same chains, same order of operations), and therefore the oracle's."""
+import numpy as np
+import pytest
+
+from bess_amd import synth
+from bess_amd import dist as bdist
+from oracle import port_ctypes as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(capi, X, y, fold, path, **skw):
+    with capi.Session(X, y, **skw) as s:
+        s.set_cv(5, fold)
+        ref = s.gs_path(1, 30, ic_type=3, is_cv=True) if path == "gs" else \
+            s.sequential_path(np.arange(1, 16), ic_type=3, is_cv=True)
+    with capi.Session(X, y, **skw) as s:
+        s.set_cv(5, fold)
+        cv = bdist.FoldShardedCV(s, 5, data_type=skw.get("data_type", 1))
+        out = cv.gs_path(1, 30) if path == "gs" else cv.sequential_path(np.arange(1, 16))
+    return ref, out
+
+
+@pytest.mark.parametrize("path", ["gs", "seq"])
+@pytest.mark.parametrize("score_mode", [1, 2])
+def test_lm_cv_paths_from_the_fit_primitive(gpu, path, score_mode):
+    X, y, _, _ = synth.make_lm(1000, 300, 10)
+    fold = synth.make_cv_folds(1000, 5)
+    ref, out = _both(gpu, X, y, fold, path, score_mode=score_mode)
+    assert out["best_T0"] == ref["best_T0"] and out["n_fits"] == ref["n_fits"]
+    assert out["n_pdas_iters"] == ref["n_pdas_iters"]
+    np.testing.assert_array_equal(out["cand_T0"], ref["cand_T0"])
+    np.testing.assert_allclose(out["cand_ic"], ref["cand_ic"], rtol=1e-12)
+    np.testing.assert_array_equal(np.nonzero(out["beta"])[0], np.nonzero(ref["beta"])[0])
+    np.testing.assert_allclose(out["beta"], ref["beta"], rtol=1e-10)
+    np.testing.assert_allclose([out["coef0"], out["train_loss"], out["ic"]],
+                               [ref["coef0"], ref["train_loss"], ref["ic"]], rtol=1e-10)
+    kw = dict(path_type=2, s_min=1, s_max=30) if path == "gs" else dict(sequence=np.arange(1, 16))
+    want = P.trace(X, y, ic_type=3, is_cv=True, K=5, cv_fold_id=fold, **kw)
+    sup = np.nonzero(want["beta"])[0]
+    assert np.array_equal(np.nonzero(out["beta"])[0], sup)
+    np.testing.assert_allclose(out["beta"][sup], want["beta"][sup], rtol=1e-6)
+    np.testing.assert_allclose([out["coef0"], out["train_loss"], out["ic"]],
+                               [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-8)
+
+
+def test_logistic_cv_gs_path_from_the_fit_primitive(gpu):
+    """The fold fits of a logistic candidate start from the intercept the path handed to the full-data fit
+    (the previous candidate's), which the records carry between ranks."""
+    X, y, _, _ = synth.make_logistic(1500, 200, 6, seed=4)
+    fold = synth.make_cv_folds(1500, 5)
+    ref, out = _both(gpu, X, y, fold, "gs", data_type=2, model_type=2)
+    assert out["best_T0"] == ref["best_T0"] and out["n_fits"] == ref["n_fits"]
+    np.testing.assert_allclose(out["cand_ic"], ref["cand_ic"], rtol=1e-10)
+    np.testing.assert_allclose(out["beta"], ref["beta"], rtol=1e-8)
+    np.testing.assert_allclose([out["coef0"], out["train_loss"], out["ic"]],
+                               [ref["coef0"], ref["train_loss"], ref["ic"]], rtol=1e-8)

@@ -54,3 +54,65 @@ def test_kpath_sharded_over_two_ranks(tmp_path):
                            P.trace(X, y, ic_type=3, sequence=seq[hi:])["ic_calls"]])
     np.testing.assert_allclose(curve, want, rtol=0, atol=0)
     assert bdist.select_best(curve) == int(np.argmin(want))
+
+
+# ---- cross-validated paths with the fold fits dealt to ranks (bess_amd.dist.FoldShardedCV) ----------------
+def _cv_problem():
+    from bess_amd import synth
+    X, y, _, _ = synth.make_lm(300, 60, 5)
+    return X, y, synth.make_cv_folds(300, 5)
+
+
+def _cv_worker(rank, world, port, path, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from bess_amd import dist as bdist
+    from helpers import NumpyLmSession
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    X, y, fold = _cv_problem()
+    cv = bdist.FoldShardedCV(NumpyLmSession(X, y, fold, 5), 5, world, rank)
+    out = cv.gs_path(1, 20) if path == "gs" else cv.sequential_path(np.arange(1, 13))
+    np.savez(out_path + ".%d.npz" % rank, beta=out["beta"], scal=[out["coef0"], out["train_loss"], out["ic"]],
+             cand_ic=out["cand_ic"], cand_T0=out["cand_T0"], n_fits=out["n_fits"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("path,world", [("gs", 2), ("seq", 2), ("gs", 3)])
+def test_cv_folds_sharded_over_ranks(tmp_path, path, world):
+    """K fold chains + the full-data chain on `world` gloo ranks: every rank ends with the same model, and it is the
+    one the pinned oracle's single-process gs_path / sequential_path under CV selects (same folds)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import port_ctypes as P
+    out = str(tmp_path / "cv")
+    mp.spawn(_cv_worker, args=(world, 29531 + world + (7 if path == "gs" else 0), path, out), nprocs=world, join=True)
+    X, y, fold = _cv_problem()
+    kw = dict(path_type=2, s_min=1, s_max=20) if path == "gs" else dict(sequence=np.arange(1, 13))
+    want = P.trace(X, y, is_cv=True, K=5, cv_fold_id=fold, **kw)
+    got = [np.load(out + ".%d.npz" % r) for r in range(world)]
+    for g in got[1:]:
+        for k in ("beta", "scal", "cand_ic", "cand_T0"):
+            np.testing.assert_array_equal(g[k], got[0][k])
+    sup = np.nonzero(want["beta"])[0]
+    assert np.array_equal(np.nonzero(got[0]["beta"])[0], sup)
+    np.testing.assert_allclose(got[0]["beta"][sup], want["beta"][sup], rtol=1e-8)
+    np.testing.assert_allclose(got[0]["scal"], [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-9)
+    # one CV value per candidate stored, in evaluation order, equal to the oracle's first ic() of that point
+    assert int(got[0]["n_fits"]) == len(want["fits"])
+
+
+def test_cv_sharding_is_independent_of_world_size():
+    """world = 1 (no process group) gives the same path as the oracle too: the unit -> rank map changes nothing."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from bess_amd import dist as bdist
+    from helpers import NumpyLmSession
+    from oracle import port_ctypes as P
+    X, y, fold = _cv_problem()
+    out = bdist.FoldShardedCV(NumpyLmSession(X, y, fold, 5), 5).gs_path(1, 20)
+    want = P.trace(X, y, is_cv=True, K=5, cv_fold_id=fold, path_type=2, s_min=1, s_max=20)
+    assert np.array_equal(np.nonzero(out["beta"])[0], np.nonzero(want["beta"])[0])
+    np.testing.assert_allclose([out["coef0"], out["train_loss"], out["ic"]],
+                               [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-9)
