@@ -141,6 +141,8 @@ struct CoxBufs {
   double *Gt2;                                         // second Gram (M^T diag(w delta) M) in tile layout
   double *llpart;
   double *SCR;                                         // block totals of the multi-block scans
+  double *C1, *CU, *CV, *C2;                           // one-pass score: prefix sums of ew/S0, u, ew - u, ew/S0^2
+  int one_pass;                                        // score pass reads X once (k_cox_score1p)
 };
 size_t cox_scan_scratch_doubles(long ld, int kmax);
 hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,

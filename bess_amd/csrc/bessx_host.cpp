@@ -341,6 +341,12 @@ static void session_free(bessx_session *s) {
   delete s;
 }
 
+// doubles in the score-pass partial sums of one row set
+static size_t part_elems(const bessx_session *s) {
+  const size_t plane = (size_t)s->nrb * (size_t)s->p;
+  return (s->model_type == 4 && s->cox.one_pass) ? 5 * plane + (size_t)s->nrb : plane;
+}
+
 // timing of the dominant kernel: event pairs on the session stream, resolved lazily
 static int k1_begin(bessx_session *s, hipEvent_t *a, hipEvent_t *b) {
   if (!s->timing) return 0;
@@ -915,8 +921,8 @@ static int enqueue_cox_head(bessx_session *s, int slot, int T0, double lambda, i
     k1_pairs.push_back({(size_t)-1, false});
   }
   if (e == hipSuccess)
-    e = launch_cox_score(s->part_rs[rs], s->part2_rs[rs], s->nrb, s->p, s->beta_dense, lambda, s->always, s->bd,
-                         s->ctrl, slot, s->st);
+    e = launch_cox_score(s->part_rs[rs], s->cox.one_pass ? nullptr : s->part2_rs[rs], s->nrb, s->p, s->beta_dense,
+                         lambda, s->always, s->bd, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
   if (e == hipSuccess) e = launch_cox_newton_begin(s->ctrl, slot, T0, s->cox, s->idcols, s->st);
@@ -2480,7 +2486,13 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   s->xtx.push_back(q);
   HIPT(dmalloc(&q, (size_t)p));
   s->xty.push_back(q);
-  HIPT(dmalloc(&q, (size_t)s->nrb * p));
+  // Cox: the score pass reads X once and leaves five partial sums per (row block, column) + one per block
+  // (k_cox_score1p); BESSX_COX_SCORE=2pass keeps the totals / carry / rescan form (two reads of X)
+  if (s->model_type == 4) {
+    const char *ev = std::getenv("BESSX_COX_SCORE");
+    s->cox.one_pass = !(ev && std::string(ev) == "2pass");
+  }
+  HIPT(dmalloc(&q, part_elems(s)));
   s->part_rs.push_back(q);
   HIPT(dmalloc(&q, (size_t)ld));
   HIPT(hipMemset(q, 0, (size_t)ld * sizeof(double)));
@@ -2614,6 +2626,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     double **vecs[] = {&c.E, &c.TH, &c.ET, &c.S0, &c.RS0, &c.SALL, &c.STEST, &c.EW, &c.WD, &c.ETA0, &c.THF, &c.S0F,
                        &c.RS0F, &c.VG, &c.WG1, &c.UD, &c.TH1, &c.S1};
     for (auto v : vecs) HIPT(V(v, (size_t)ld));
+    double **vecs1[] = {&c.C1, &c.CU, &c.CV, &c.C2};
+    for (auto v : vecs1) HIPT(V(v, (size_t)ld));
     // k-sized work space: for sparsity levels up to 254 now, grown by cox_reserve() when a larger one is asked for
     s->cox_M_cols = 256;
     HIPT(V(&c.M, (size_t)ld * s->cox_M_cols));
@@ -2708,7 +2722,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     HIPX(hipMemcpy(dm, m.data(), (size_t)s->ld * sizeof(double), hipMemcpyHostToDevice));
     HIPX(dmalloc(&q1, (size_t)p));
     HIPX(dmalloc(&q2, (size_t)p));
-    HIPX(dmalloc(&q3, (size_t)s->nrb * p));
+    HIPX(dmalloc(&q3, part_elems(s)));
     HIPX(dmalloc(&q4, (size_t)s->ld));
     HIPX(hipMemset(q4, 0, (size_t)s->ld * sizeof(double)));
     s->mask.push_back(dm);

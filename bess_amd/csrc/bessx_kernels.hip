@@ -2332,6 +2332,141 @@ __global__ void __launch_bounds__(256) k_cox_colscan(const double *__restrict__ 
   }
 }
 
+// ---- K3, one-pass form of the Cox score --------------------------------------------------------------------
+// The same sums with the order of summation exchanged so that X is read ONCE and no carry has to be known while it
+// is read.  With S1_j(i) = sum_{l>=i} theta_l x_lj, rs = 1/S0, ew as above:
+//   sum_i ew_i a_ij           = sum_l u_l x_lj,      u_l = theta_l C1_l,  C1_l = sum_{i<=l} ew_i rs_i   (prefix scan)
+//   sum_i ew_i S2_j(i) rs_i   = sum_l u_l x_lj^2
+//   l1 sum = sum_l x_lj (ew_l - u_l),      l2 sum = sum_l u_l x_lj^2 - Q_j,   Q_j = sum_i c2_i S1_j(i)^2, c2 = ew rs^2
+// and inside row block b, S1_j(i) = loc_j(i) + car_j(b) (suffix sum within the block + total of the later blocks):
+//   Q_j = sum_b [ P2_j(b) + 2 car_j(b) P1_j(b) + car_j(b)^2 P0(b) ],
+//   P2 = sum_{i in b} c2_i loc_j(i)^2,  P1 = sum c2_i loc_j(i),  P0 = sum c2_i,  car_j(b) = sum_{b' > b} T_j(b').
+// k_cox_uv prepares u, v = ew - u, c2 (n-vectors, after the S0 scan and the prefix scan of ew rs); k_cox_score1p
+// walks every column of a row block bottom-up exactly like k_cox_colscan and leaves T, P1, P2 and the two plain
+// sums per (block, column) plus P0 per block; k_cox_score_1p folds the blocks (carry in block order).
+__global__ void __launch_bounds__(256) k_cox_c1(long ld, const double *__restrict__ EW, const double *__restrict__ RS0,
+                                                double *__restrict__ C1in, const FitCtrl *__restrict__ ctrl,
+                                                int when) {
+  if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ld) return;
+  const double ew = EW[i];
+  C1in[i] = ew != 0.0 ? ew * RS0[i] : 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_cox_uv(long ld, const double *__restrict__ EW, const double *__restrict__ RS0,
+                                                const double *__restrict__ TH, const double *__restrict__ C1,
+                                                double *__restrict__ CU, double *__restrict__ CV,
+                                                double *__restrict__ C2, const FitCtrl *__restrict__ ctrl, int when) {
+  if (ctrl->l != when || (when > 0 && ctrl->same_prev)) return;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ld) return;
+  const double ew = EW[i], th = TH[i];
+  const double u = th != 0.0 ? th * C1[i] : 0.0;
+  const double rs = ew != 0.0 ? RS0[i] : 0.0;
+  CU[i] = u;
+  CV[i] = ew - u;
+  C2[i] = ew * rs * rs;
+}
+
+// out: 5 arrays of nrb x p (T, P1, P2, sum x v, sum u x^2) followed by P0[nrb]
+template <int U>
+__global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ X, long ld, int p, int nrb,
+                                                     const double *__restrict__ TH, const double *__restrict__ CU,
+                                                     const double *__restrict__ CV, const double *__restrict__ C2,
+                                                     double *__restrict__ out, const FitCtrl *__restrict__ ctrl,
+                                                     int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  __shared__ double tile[4][64 * CS_RS];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long wid = (long)blockIdx.x * 4 + wv;
+  const int ncg = (p + 63) / 64;
+  const long cg = wid / nrb;
+  const int rb = (int)(wid - cg * nrb);
+  if (cg >= ncg) return;
+  const int j0 = (int)cg * 64;
+  double loc = 0.0, g1 = 0.0, g2 = 0.0, p1 = 0.0, p2 = 0.0, p0 = 0.0;
+  constexpr int NSUB = 128 * U / CS_ROWS;
+  const long rbase = (long)rb * (128 * U);
+  const int c4 = lane >> 4, seg = lane & 15;
+  d2 nxt[16];
+  auto load_sub = [&](int sub) {
+    const long r0 = rbase + (long)sub * CS_ROWS + 2 * seg;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      int j = min(j0 + 4 * it + c4, p - 1);
+      nxt[it] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(X + (size_t)j * ld + r0));
+    }
+  };
+  load_sub(NSUB - 1);
+  for (int sub = NSUB - 1; sub >= 0; sub--) {
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int o = (4 * it + c4) * CS_RS + 2 * seg;
+      tile[wv][o] = nxt[it].x;
+      tile[wv][o + 1] = nxt[it].y;
+    }
+    if (sub > 0) load_sub(sub - 1);  // next tile's loads fly while this one is scanned
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const long r0 = rbase + (long)sub * CS_ROWS;
+    for (int r = CS_ROWS - 1; r >= 0; r--) {
+      // wave-uniform (scalar loads; staging them through LDS measured the same)
+      const double th = TH[r0 + r], u = CU[r0 + r], v = CV[r0 + r], c2 = C2[r0 + r];
+      const double x = tile[wv][lane * CS_RS + r];
+      loc = fma(th, x, loc);
+      g1 = fma(x, v, g1);
+      g2 = fma(u * x, x, g2);
+      const double m = c2 * loc;  // c2 = 0 on rows without an event: no branch needed
+      p1 += m;
+      p2 = fma(m, loc, p2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const size_t plane = (size_t)nrb * p;
+  if (j0 + lane < p) {
+    const size_t o = (size_t)rb * p + j0 + lane;
+    out[o] = loc;
+    out[plane + o] = p1;
+    out[2 * plane + o] = p2;
+    out[3 * plane + o] = g1;
+    out[4 * plane + o] = g2;
+  }
+  if (cg == 0) {  // P0 of this row block, by the wave of its first column group (fixed order)
+    for (int r = lane; r < 128 * U; r += 64) p0 += C2[rbase + r];
+    p0 = wave_sum(p0);
+    if (lane == 0) out[5 * plane + rb] = p0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_cox_score_1p(const double *__restrict__ part, int nrb, int p,
+                                                      const double *__restrict__ beta_dense, double lambda,
+                                                      const unsigned char *__restrict__ always,
+                                                      double *__restrict__ bd, const FitCtrl *__restrict__ ctrl,
+                                                      int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  const size_t plane = (size_t)nrb * p;
+  double car = 0.0, q = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int rb = nrb - 1; rb >= 0; rb--) {
+    const size_t o = (size_t)rb * p + j;
+    const double p0 = part[5 * plane + rb];
+    q += part[2 * plane + o] + car * (2.0 * part[plane + o] + car * p0);
+    car += part[o];
+    s1 += part[3 * plane + o];
+    s2 += part[4 * plane + o];
+  }
+  s2 -= q;
+  const double b = beta_dense[j];
+  const double l1 = -s1 + 2.0 * lambda * b, l2 = s2 + 2.0 * lambda;
+  const double d = -l1 / l2;
+  double v = fabs(b + d) * sqrt(l2);
+  if (always != nullptr && always[j]) v = DBL_MAX;
+  bd[j] = v;
+}
+
 // Cox sacrifice score (:1629-1634): l1 = -sum + 2 lambda beta, l2 = sum + 2 lambda, bd = |beta - l1/l2| sqrt(l2)
 __global__ void __launch_bounds__(256) k_cox_score(const double *__restrict__ part, const double *__restrict__ part2,
                                                    int nrb, int p, const double *__restrict__ beta_dense,
@@ -3902,11 +4037,39 @@ hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, co
   hipLaunchKernelGGL(k_cox_loss, dim3(nblk), dim3(128), 0, st, ld, n, y, w, mask, ctrl, when, (const double *)cb.E,
                      (const double *)cb.SALL, (const double *)cb.STEST, stats);
   LAUNCH_CHECK();
+  if (cb.one_pass) {  // vectors of the one-pass score (k_cox_score1p)
+    const int nb2 = (int)((ld + 255) / 256);
+    hipLaunchKernelGGL(k_cox_c1, dim3(nb2), dim3(256), 0, st, ld, (const double *)cb.EW, (const double *)cb.RS0, cb.CV,
+                       ctrl, when);  // CV holds ew / S0 until k_cox_uv overwrites it
+    LAUNCH_CHECK();
+    hipError_t es = launch_scan3(cb.CV, nullptr, nullptr, cb.C1, nullptr, nullptr, nullptr, (long)n, 0, 1, cb.SCR, ctrl,
+                                 1, when, 0, st);
+    if (es != hipSuccess) return es;
+    hipLaunchKernelGGL(k_cox_uv, dim3(nb2), dim3(256), 0, st, ld, (const double *)cb.EW, (const double *)cb.RS0,
+                       (const double *)cb.TH, (const double *)cb.C1, cb.CU, cb.CV, cb.C2, ctrl, when);
+    LAUNCH_CHECK();
+  }
   return hipSuccess;
 }
 
 hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb, CoxBufs cb, double *part,
                                  double *part2, const FitCtrl *ctrl, int slot, hipStream_t st) {
+  if (cb.one_pass) {
+    long nw = (long)nrb * ((p + 63) / 64);
+    int nb = (int)((nw + 3) / 4);
+#define CS1_GO(UU)                                                                                            \
+  hipLaunchKernelGGL(k_cox_score1p<UU>, dim3(nb), dim3(256), 0, st, X, ld, p, nrb, (const double *)cb.TH,     \
+                     (const double *)cb.CU, (const double *)cb.CV, (const double *)cb.C2, part, ctrl, slot)
+    switch (U) {
+      case 8: CS1_GO(8); break;
+      case 4: CS1_GO(4); break;
+      case 2: CS1_GO(2); break;
+      default: CS1_GO(1); break;
+    }
+#undef CS1_GO
+    LAUNCH_CHECK();
+    return hipSuccess;
+  }
   hipError_t e = launch_xtv(X, ld, p, U, cb.TH, cb.TH, part, part2, ctrl, slot, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_cox_carry, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, ctrl, slot);
@@ -3930,8 +4093,12 @@ hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb
 hipError_t launch_cox_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
                             double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
                             hipStream_t st) {
-  hipLaunchKernelGGL(k_cox_score, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, beta_dense, lambda,
-                     always, bd, ctrl, slot);
+  if (part2 == nullptr)  // one-pass layout (k_cox_score1p)
+    hipLaunchKernelGGL(k_cox_score_1p, dim3((p + 255) / 256), dim3(256), 0, st, part, nrb, p, beta_dense, lambda,
+                       always, bd, ctrl, slot);
+  else
+    hipLaunchKernelGGL(k_cox_score, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, beta_dense, lambda,
+                       always, bd, ctrl, slot);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -40,3 +40,24 @@ def test_cox_sparsity_levels_above_254(gpu):
     the blocked Cholesky (the reference's default s.list reaches min(p, n / log n))."""
     X, _, status, _, _ = synth.make_cox(1200, 400, 10, seed=77)
     check(gpu, X, status, dict(COX, ic_type=3, sequence=[250, 256, 300]), "cox k>254")
+
+
+def test_cox_score_pass_forms_agree(gpu, monkeypatch):
+    """BESSX_COX_SCORE=2pass (block totals, carry, rescan: X read twice) and the default one-pass form (summation
+    order exchanged, X read once) give the same path: supports at every iteration, coefficients, IC values."""
+    X, _, status, _, _ = synth.make_cox(3000, 260, 8, seed=12)
+    fold = synth.make_cv_folds(3000, 5)
+    outs = []
+    for form in ("1pass", "2pass"):
+        monkeypatch.setenv("BESSX_COX_SCORE", form)
+        with gpu.Session(X, status, data_type=3, model_type=4) as s:
+            s.set_cv(5, fold)
+            s.trace_enable(True)
+            outs.append((s.sequential_path(np.arange(1, 21), ic_type=3),
+                         s.sequential_path(np.arange(1, 7), ic_type=3, is_cv=True)))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a["cand_support"], b["cand_support"])
+        np.testing.assert_array_equal(a["cand_iters"], b["cand_iters"])
+        assert a["n_pdas_iters"] == b["n_pdas_iters"]
+        np.testing.assert_allclose(a["cand_beta"], b["cand_beta"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-10)
