@@ -99,11 +99,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libbessx has no CPU path")
+    # rehearsal of the N-rank path on a box with ONE GPU (never what the driver runs): all ranks share device 0 and
+    # the IC curves travel over gloo -- BESSX_BENCH_ONE_DEVICE=1 BESSX_BENCH_BACKEND=gloo
+    if os.environ.get("BESSX_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BESSX_BENCH_BACKEND", "nccl")
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if distributed:
@@ -119,7 +128,7 @@ def main():
     t0 = time.time()
     mode = {"auto": 0, "streaming": 1, "covariance": 2}[args.score_mode]
     sess = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
-                        score_mode=mode)
+                        score_mode=mode, device=local_rank)
     covariance = sess.score_mode() == 2
     torch.cuda.synchronize()
     upload_s = time.time() - t0
@@ -137,13 +146,13 @@ def main():
         out = sess.sequential_path(seq, ic_type=3)
         pdas_iters += out["n_pdas_iters"]
         if kpath:  # gather the IC curve: the only collective of the path
-            ic_curves = bdist.gather_curve(out["cand_ic"], args.kmax, world, rank, device="cuda")[None, :]
+            ic_curves = bdist.gather_curve(out["cand_ic"], args.kmax, world, rank, device=comm_dev)[None, :]
         elif distributed:
-            ic_curves = bdist.gather_rows(out["cand_ic"], world, device="cuda")
+            ic_curves = bdist.gather_rows(out["cand_ic"], world, device=comm_dev)
     barrier()
     dt = time.time() - t0
     if distributed:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     k1 = sess.score_pass_stats()
@@ -199,7 +208,7 @@ def main():
             # the other evaluation of the same path (every PDAS iteration reads X once), for comparison
             sess.close()
             s2 = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
-                              score_mode=1)
+                              score_mode=1, device=local_rank)
             s2.sequential_path(seq, ic_type=3)
             s2.enable_kernel_timing(True)
             s2.score_pass_stats(reset=True)
