@@ -99,6 +99,8 @@ struct CholFuse {
   unsigned char *inA;  // membership flags of the active set (repeated-set shortcut of k_cov_d)
   double yy;           // y.(m y) of the row set (loss from the solved system, k_cg)
   const double *d;     // X^T (m r) of the current coefficients (start value of entering columns, k_cg)
+  const double *GS;    // slot-indexed Gram of the cached columns (CS x CS), or nullptr (k_cgr gathers from it)
+  int CS;
 };
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
@@ -191,6 +193,8 @@ hipError_t cov_panel_prepare();
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
                              int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st,
                              const int *bgm = nullptr);
+hipError_t launch_cov_compact(const double *G, int p, const int *slot_of, const int *fcols, int g0, int ngroups,
+                              double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st);
 // background (speculative) fill on a second stream
 hipError_t launch_cov_bg_select(const double *bd, const int *slot_of, int p, double *bd2, hipStream_t st);
 hipError_t launch_cov_bg_list(const int *extras, const double *bd2, const int *slot_of, const int *meta, int C,

@@ -142,6 +142,7 @@ struct bessx_session {
   struct CovCache {
     double *G = nullptr;
     int *slot_of = nullptr, *meta = nullptr;
+    double *GS = nullptr;  // COV_CS x COV_CS: Gram entries between cached columns, indexed by cache slot (L2-sized)
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
@@ -308,6 +309,7 @@ static void session_free(bessx_session *s) {
     F(c.G);
     F(c.slot_of);
     F(c.meta);
+    F(c.GS);
   }
   F(s->cov_part);
   F(s->bd2);
@@ -411,12 +413,15 @@ static int alloc_gram_cache(bessx_session *s) {
 
 static constexpr int COV_R = 32;        // columns per panel group (matches the kernels)
 static constexpr int COV_SLOT_GROUPS = 2;  // groups an ordinary PDAS slot launches
+static constexpr int COV_CS = 512;         // side of the slot-indexed Gram of the cached columns (2 MiB)
 
 static int alloc_cov_cache(bessx_session *s) {
   bessx_session::CovCache c;
   HIPX(dmalloc(&c.G, (size_t)s->p * s->cov_C));
   HIPX(dmalloc(&c.slot_of, (size_t)s->p));
   HIPX(dmalloc(&c.meta, 4));
+  HIPX(dmalloc(&c.GS, (size_t)COV_CS * COV_CS));
+  HIPX(hipMemset(c.GS, 0, (size_t)COV_CS * COV_CS * sizeof(double)));
   HIPX(hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int)));
   HIPX(hipMemset(c.meta, 0, 4 * sizeof(int)));
   s->cov.push_back(c);
@@ -640,6 +645,8 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
     if (e == hipSuccess)
       e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, s->ctrl, parked,
                             s->st);
+    if (e == hipSuccess && !s->cov_bg)  // entries between cached columns, by slot: what the solve gathers from
+      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, COV_CS, s->ctrl, parked, s->st);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
   }
   return 0;
@@ -708,7 +715,7 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     // parks the fit (cov_stall = 2) and the Cholesky kernel is issued for the slot (force_chol).
     CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
                    s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
-                   s->part_rs[rs]};
+                   s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, COV_CS};
     if (s->cov_cg && !force_chol)
       e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st);
     else
@@ -2689,6 +2696,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     (void)hipFree(s->cov[i].G);
     (void)hipFree(s->cov[i].slot_of);
     (void)hipFree(s->cov[i].meta);
+    (void)hipFree(s->cov[i].GS);
   }
   if (!s->cov.empty()) s->cov.resize(1);
   for (size_t i = 1; i < s->gxtx_rs.size(); i++) (void)hipFree(s->gxtx_rs[i]);

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
+#include <string>
 
 #include "bessx_dev.h"
 
@@ -1109,10 +1111,25 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
 // issues the Cholesky kernel for this slot.  Ends with the loss terms and k_commit's work like the fused k_chol.
 // ------------------------------------------------------------------------------------------
 // NW = waves of the workgroup: 8, or 1 for systems of at most 64 unknowns (no block barriers at all then).
+#ifdef BESSX_CG_PROFILE
+__device__ unsigned long long g_cg_prof[16];
+#define CGP(i)                                                         \
+  do {                                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+    if (threadIdx.x == 0) {                                            \
+      unsigned long long now_ = wall_clock64();                        \
+      atomicAdd(&g_cg_prof[i], now_ - tprev_);                         \
+      tprev_ = now_;                                                   \
+    }                                                                  \
+  } while (0)
+#else
+#define CGP(i)
+#endif
 template <int CH_SLOTS, int NW>
 __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, const double *__restrict__ rhs,
                                             const int *__restrict__ A_new, double *__restrict__ sol,
-                                            const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit) {
+                                            const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
+                                            const double tol) {
   __shared__ int same_any_sh;
   if (ctrl->done || ctrl->l != slot - 1) return;
   if (ctrl->same_prev) {
@@ -1120,6 +1137,10 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
                 fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
     return;
   }
+#ifdef BESSX_CG_PROFILE
+  unsigned long long tprev_ = wall_clock64();
+  if (threadIdx.x == 0) atomicAdd(&g_cg_prof[15], 1ull);
+#endif
   // one wave: LDS traffic of a wave is in order, a fence keeps the compiler from reordering it
 #define CG_SYNC()                                            \
   do {                                                       \
@@ -1144,6 +1165,7 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
     sS[i] = i < m ? fz.slot_of[a] : 0;
   }
   CG_SYNC();
+  CGP(0);
   d4 acc[CH_SLOTS];
   int tI[CH_SLOTS], tJ[CH_SLOTS];
   {
@@ -1180,6 +1202,7 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
       acc[s] = d4{gv[0], gv[1], gv[2], gv[3]};
     }
   }
+  CGP(1);
   const bool own = tid < m;  // thread t owns element t of every k-vector
   // block-wide dot products (two at once), fixed order; every thread gets the values.  One barrier: the buffers
   // alternate, and a buffer is rewritten only after another barrier has been passed by everybody.
@@ -1261,14 +1284,16 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
     if (x_t == 0.0 && fz.d != nullptr && sS[tid] >= 0)
       x_t = fz.d[sA[tid]] / (fz.G[(size_t)sS[tid] * fz.p + sA[tid]] + ridge);
   }
+  CGP(2);
   const double qq = dot(q_t, q_t);
   double r_t = q_t - (matvec(x_t) + ridge * x_t);
   double p_t = r_t;
   double rs = dot(r_t, r_t);
+  CGP(3);
   bool ok = false;
   int it = 0;
   for (int round = 0; round < 3 && !ok; round++) {
-    for (; it < maxit && rs > 1e-30 * qq; it++) {  // recurrence residual target: |r| <= 1e-15 |q|
+    for (; it < maxit && rs > 1e-4 * tol * tol * qq; it++) {  // recurrence residual target: |r| <= tol / 100 |q|
       const double ap = matvec(p_t) + ridge * p_t;
       const double alpha = rs / dot(p_t, ap);
       x_t = fma(alpha, p_t, x_t);
@@ -1280,10 +1305,14 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
     // the recurrence drifts: accept only on the recomputed residual |q - (G + ridge I) x| <= 1e-13 |q|
     r_t = q_t - (matvec(x_t) + ridge * x_t);
     rs = dot(r_t, r_t);
-    ok = rs <= 1e-26 * qq;  // also catches NaN (singular / indefinite matrix): the comparison fails
+    ok = rs <= tol * tol * qq;  // also catches NaN (singular / indefinite matrix): the comparison fails
     p_t = r_t;
     if (it >= maxit) break;
   }
+  CGP(4);
+#ifdef BESSX_CG_PROFILE
+  if (threadIdx.x == 0) atomicAdd(&g_cg_prof[14], (unsigned long long)it);
+#endif
   if (!ok) {
     if (tid == 0) {  // park the fit: the host issues the Cholesky kernel for this slot
       fz.ctrl->cov_stall = 2;
@@ -1319,11 +1348,250 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
     }
   }
   CG_SYNC();
+  CGP(5);
   commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
               fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+  CGP(6);
 }
 
 #undef CG_SYNC
+
+// ------------------------------------------------------------------------------------------
+// K7'', the same conjugate-gradient solve with the matrix dealt by ROWS instead of MFMA tiles (systems of at most
+// 64 * RPT rows and 8 * NCW columns, i.e. up to 192 unknowns; larger ones keep k_cg).
+//
+// Wave w holds columns [w * nc, (w + 1) * nc) of ALL rows: lane l owns rows l, l + 64, ... (RPT of them), NCW matrix
+// elements per row in registers.  A product y = G v is then: v to LDS, barrier, every lane multiplies its row
+// segments with the broadcast v_j (no cross-lane traffic at all), the 8 segment partials go to LDS, barrier, every
+// wave sums the 8 partials of all rows in fixed order.  Because every wave ends up with the WHOLE vector (x, r, p
+// are kept replicated in all 8 waves), the dot products are wave-local DPP reductions -- no third barrier, and every
+// wave computes bit-identical scalars.  Two barriers per CG step instead of four, no 16-lane row sums per tile.
+// Same warm start, same acceptance test on the recomputed residual, same loss identity and commit as k_cg.
+// ------------------------------------------------------------------------------------------
+template <int RPT, int NCW>
+__global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const double *__restrict__ rhs,
+                                             const int *__restrict__ A_new, double *__restrict__ sol,
+                                             const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
+                                             const double tol) {
+  __shared__ int same_any_sh;
+  if (ctrl->done || ctrl->l != slot - 1) return;
+  if (ctrl->same_prev) {
+    commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+                fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+    return;
+  }
+#ifdef BESSX_CG_PROFILE
+  unsigned long long tprev_ = wall_clock64();
+  if (threadIdx.x == 0) atomicAdd(&g_cg_prof[15], 1ull);
+#endif
+  constexpr int R = 64 * RPT;
+  __shared__ int sA[R], sS[R];
+  __shared__ double pv[R], qs[R], xs[R], gds[R];
+  __shared__ double part[8][R];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < R; i += 512) {
+    const int a = i < m ? A_new[i] : 0;
+    sA[i] = a;
+    sS[i] = i < m ? fz.slot_of[a] : 0;
+  }
+  __syncthreads();
+  CGP(0);
+  const int c0 = wave * nc;
+  // right-hand side, warm start (previous coefficients of the columns that stay; a column that enters starts from
+  // its one-variable update d_j / (G_jj + ridge)) and the diagonal: independent loads, issued ahead of the gather
+  double q0[RPT], x0[RPT], gd0[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int row = lane + 64 * r;
+    const bool own = wave == 0 && row < m;
+    const int a = own ? sA[row] : 0, sl = own ? sS[row] : -1;
+    const double qv = own ? rhs[a] : 0.0, bv = own ? fz.beta_dense[a] : 0.0;
+    const double dv = (own && fz.d != nullptr) ? fz.d[a] : 0.0;
+    const double gv = sl >= 0 ? fz.G[(size_t)sl * fz.p + a] : 0.0;
+    q0[r] = qv;
+    gd0[r] = gv;
+    x0[r] = (own && bv == 0.0 && fz.d != nullptr && sl >= 0) ? dv / (gv + ridge) : bv;
+  }
+  double g[RPT][NCW];
+#pragma unroll
+  for (int c = 0; c < NCW; c++) {
+    const int col = c0 + c;
+    const bool cok = c < nc && col < m;
+    const int sl = cok ? sS[col] : 0;  // wave-uniform
+    if (cok && sl < 0) fz.ctrl->cov_miss = 1;
+    const double *gcol = fz.G + (size_t)(sl < 0 ? 0 : sl) * fz.p;
+    const bool small = fz.GS != nullptr && sl < fz.CS;  // uniform
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int row = lane + 64 * r;
+      double v = 0.0;
+      if (cok && sl >= 0 && row < m) {
+        const int sr = sS[row];
+        // both slots inside the slot-indexed copy (L2-resident, neighbouring rows share lines): read it from there
+        v = (small && sr >= 0 && sr < fz.CS) ? fz.GS[(size_t)sl * fz.CS + sr] : gcol[sA[row]];
+      }
+      g[r][c] = v;
+    }
+  }
+  CGP(1);
+  // wave-local sum over all R rows (every wave holds every row): fixed order, identical in all waves
+  auto wsum = [&](double v) -> double {
+    v = row_sum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+  };
+  auto dot = [&](const double (&a)[RPT], const double (&b)[RPT]) -> double {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) t = fma(a[r], b[r], t);
+    return wsum(t);
+  };
+  // y = G v for the vector in pv (visible to the block)
+  auto matvec_pv = [&](double (&y)[RPT]) {
+    double acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) acc[r] = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCW; c++) {
+      if (c < nc) {  // uniform
+        const double vj = pv[min(c0 + c, R - 1)];  // broadcast read
+#pragma unroll
+        for (int r = 0; r < RPT; r++) acc[r] = fma(g[r][c], vj, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; r++) part[wave][lane + 64 * r] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      double t = part[0][lane + 64 * r];
+#pragma unroll
+      for (int w = 1; w < 8; w++) t += part[w][lane + 64 * r];
+      y[r] = t;
+    }
+  };
+  auto matvec = [&](const double (&v)[RPT], double (&y)[RPT]) {
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < RPT; r++) pv[lane + 64 * r] = v[r];
+    }
+    __syncthreads();
+    matvec_pv(y);
+  };
+  // q, x and the diagonal live in LDS (x is advanced by wave 0 only): the registers belong to the matrix
+  double r_t[RPT], p_t[RPT], ap[RPT];
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int row = lane + 64 * r;
+      qs[row] = q0[r];
+      xs[row] = x0[r];
+      gds[row] = gd0[r];
+      pv[row] = x0[r];
+    }
+  }
+  __syncthreads();
+  CGP(2);
+  double qq;
+  {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) t = fma(qs[lane + 64 * r], qs[lane + 64 * r], t);
+    qq = wsum(t);
+  }
+  matvec_pv(ap);  // pv = x
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int row = lane + 64 * r;
+    r_t[r] = qs[row] - (ap[r] + ridge * xs[row]);
+    p_t[r] = r_t[r];
+  }
+  double rs = dot(r_t, r_t);
+  CGP(3);
+  bool ok = false;
+  int it = 0;
+  for (int round = 0; round < 3 && !ok; round++) {
+    for (; it < maxit && rs > 1e-4 * tol * tol * qq; it++) {  // recurrence residual target: |r| <= tol / 100 |q|
+      matvec(p_t, ap);
+#pragma unroll
+      for (int r = 0; r < RPT; r++) ap[r] = fma(ridge, p_t[r], ap[r]);
+      const double alpha = rs / dot(p_t, ap);
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < RPT; r++) xs[lane + 64 * r] = fma(alpha, p_t[r], xs[lane + 64 * r]);
+      }
+#pragma unroll
+      for (int r = 0; r < RPT; r++) r_t[r] = fma(-alpha, ap[r], r_t[r]);
+      const double rs_new = dot(r_t, r_t);
+      const double bt = rs_new / rs;
+#pragma unroll
+      for (int r = 0; r < RPT; r++) p_t[r] = fma(bt, p_t[r], r_t[r]);
+      rs = rs_new;
+    }
+    // the recurrence drifts: accept only on the recomputed residual |q - (G + ridge I) x| <= tol |q|
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < RPT; r++) pv[lane + 64 * r] = xs[lane + 64 * r];
+    }
+    __syncthreads();
+    matvec_pv(ap);
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int row = lane + 64 * r;
+      r_t[r] = qs[row] - (ap[r] + ridge * xs[row]);
+      p_t[r] = r_t[r];
+    }
+    rs = dot(r_t, r_t);
+    ok = rs <= tol * tol * qq;  // also catches NaN (singular / indefinite matrix): the comparison fails
+    if (it >= maxit) break;
+  }
+  CGP(4);
+#ifdef BESSX_CG_PROFILE
+  if (threadIdx.x == 0) atomicAdd(&g_cg_prof[14], (unsigned long long)it);
+#endif
+  if (!ok) {
+    if (tid == 0) {  // park the fit: the host issues the Cholesky kernel for this slot
+      fz.ctrl->cov_stall = 2;
+      fz.ctrl->l = -1 - fz.ctrl->l;
+    }
+    return;
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < RPT; r++)
+      if (lane + 64 * r < m) sol[lane + 64 * r] = xs[lane + 64 * r];
+  }
+  if (wave == 0) {
+    // loss terms, as in k_cg: |y - X b|^2 = y.y - b.(q + rho) - ridge |b|^2 with rho the residual just recomputed
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0, gd = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const int row = lane + 64 * r;
+      const double x = xs[row], qr = qs[row] + r_t[r];
+      t1 = fma(x, qr, t1);
+      t2 = fma(x, x, t2);
+      t3 = fma(fabs(x), fabs(qr), t3);
+      gd = fmax(gd, gds[row]);
+    }
+    const double a1 = wsum(t1), a2 = wsum(t2), a3 = wsum(t3);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) gd = fmax(gd, __shfl_xor(gd, o));
+    if (tid == 0) {
+      const double tr = fz.yy - a1 - ridge * a2;
+      fz.ctrl->sse_dot = a1;
+      fz.ctrl->sse_nrm = a2;
+      fz.ctrl->sse_valid =
+          (tr > 1e-6 * fz.yy && 4e-16 * (a3 + (ridge + gd) * a2 + fz.yy) <= 1e-10 * tr) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  CGP(5);
+  commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+              fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+  CGP(6);
+}
 
 // ------------------------------------------------------------------------------------------
 // K7, large systems (m + 1 > 256): blocked right-looking Cholesky on the tile-layout matrix in global memory
@@ -3455,6 +3723,30 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
   if (j < p && col >= 0) G[(size_t)(big == 2 ? bgm[1] + ci : slot_of[col]) * p + j] = s;
 }
 
+// After a fill: the Gram entries between the columns just cached and every cached column, written into the small
+// slot-indexed matrix GS (both triangles) that the row-dealt solve gathers from -- a few hundred KB that stay in L2,
+// instead of k^2 reads scattered over the p x C cache.
+__global__ void __launch_bounds__(256) k_cov_compact(const double *__restrict__ G, int p,
+                                                     const int *__restrict__ slot_of,
+                                                     const int *__restrict__ fcols, int g0, double *__restrict__ GS,
+                                                     int CS, const FitCtrl *__restrict__ ctrl, int big) {
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
+  const int gl = blockIdx.y;
+  if ((g0 + gl) * COV_R >= ctrl->cov_nfill) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int t = j < p ? slot_of[j] : -1;
+  if (t < 0 || t >= CS) return;
+  for (int c = 0; c < COV_R; c++) {
+    const int col = fcols[(g0 + gl) * COV_R + c];
+    if (col < 0) continue;
+    const int sc = slot_of[col];
+    if (sc < 0 || sc >= CS) continue;
+    const double v = G[(size_t)sc * p + j];
+    GS[(size_t)sc * CS + t] = v;
+    GS[(size_t)t * CS + sc] = v;
+  }
+}
+
 // ---- background (speculative) fill, issued on a second stream while the PDAS chain keeps the first one busy with
 // its single-workgroup kernels: scores of the uncached columns -> top 32 -> Gram columns -> publication.
 // bgm: [0] list length (0 or a multiple of 32), [1] first cache slot, [2] columns in the list.
@@ -3871,12 +4163,47 @@ hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_
 }
 
 // Conjugate-gradient solve of the covariance form (k_cg); falls back to k_chol through the parked-fit protocol.
+#ifdef BESSX_CG_PROFILE
+extern "C" __attribute__((visibility("default"))) int bessx_debug_cg_profile(unsigned long long *out, int reset) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cg_prof), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_cg_prof), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
                      int slot, const CholFuse *fuse, int maxit, hipStream_t st) {
   if (mt < 1 || m > mt * 16 || mt > CH_MT || fuse == nullptr) return hipErrorInvalidValue;
   const CholFuse fz = *fuse;
+  // accepted relative residual of the normal equations, |q - (G + ridge I) x| <= tol |q| (BESSX_CG_TOL, default 1e-13)
+  static const double tol = [] {
+    const char *ev = std::getenv("BESSX_CG_TOL");
+    const double v = ev ? std::atof(ev) : 0.0;
+    return (v >= 1e-15 && v <= 1e-6) ? v : 1e-13;
+  }();
+  // systems of up to 192 unknowns: the matrix dealt by rows (k_cgr); BESSX_CG_LAYOUT=tiles keeps k_cg throughout
+  static const bool by_rows = [] {
+    const char *ev = std::getenv("BESSX_CG_LAYOUT");
+    return !(ev && std::string(ev) == "tiles");
+  }();
+  if (by_rows && m <= 192) {
+    const int nc = (m + 7) / 8;
+#define CGR_GO(RP, NW_)                                                                                           \
+  hipLaunchKernelGGL((k_cgr<RP, NW_>), dim3(1), dim3(512), 0, st, m, nc, ridge, rhs, A_new, sol, ctrl, slot, fz, \
+                     maxit, tol)
+    if (m <= 64)
+      CGR_GO(1, 8);
+    else if (m <= 128)
+      CGR_GO(2, 16);
+    else
+      CGR_GO(3, 24);
+#undef CGR_GO
+    LAUNCH_CHECK();
+    return hipSuccess;
+  }
 #define CG_GO(S, W)                                                                                                  \
-  hipLaunchKernelGGL((k_cg<S, W>), dim3(1), dim3(64 * W), 0, st, m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit)
+  hipLaunchKernelGGL((k_cg<S, W>), dim3(1), dim3(64 * W), 0, st, m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, \
+                     tol)
   // (a one-wave instance for <= 64 unknowns, CG_GO(10, 1), was measured slower: the gather and the tile loop
   // serialise)
   if (mt <= 8)
@@ -4355,6 +4682,14 @@ hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const 
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
   hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, part, g0, ngroups, nslab, njg, p,
                      fcols, slot_of, G, ctrl, 0, parked, bgm);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_compact(const double *G, int p, const int *slot_of, const int *fcols, int g0, int ngroups,
+                              double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_compact, dim3((p + 255) / 256, ngroups), dim3(256), 0, st, G, p, slot_of, fcols, g0, GS, CS,
+                     ctrl, parked);
   LAUNCH_CHECK();
   return hipSuccess;
 }
