@@ -57,6 +57,20 @@ hipError_t launch_xtv_variant(int variant, const double *X, long ld, int p, cons
 hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
                         const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
                         double *bd, const FitCtrl *ctrl, int slot, hipStream_t st);
+// What k_publish copies into the pinned result block; the last kernel of a batch of slots can do it itself (on = 1).
+struct PubArgs {
+  const unsigned char *dev;
+  unsigned char *host;
+  int ctrl_bytes;
+  size_t off_sse;
+  int n_sse;
+  size_t off_b, off_a;
+  int kcopy;
+  unsigned long long *seq_host;
+  unsigned long long seq;
+  const int *count_ptr;
+  int on;
+};
 // k_topk2 can end with the work of k_cov_need (covariance form of the LM fit) when the scores fit one chunk
 struct TopkNeed {
   const double *bd;
@@ -70,6 +84,16 @@ struct TopkNeed {
   int nbmm;
   const unsigned char *inA;  // membership flags of the current active set
   int inc1;                  // the scores are those on which the previous fit (one size smaller) ended: arg-max path
+  // fused k_fit_continue(chained): this launch opens a fit chained behind fit `cont_parent` (cont_on = 1)
+  int cont_on, cont_serial, cont_parent;
+  // fused commit of a repeated active set (the record-and-stop branch of k_commit): commit_on = 1
+  int commit_on;
+  int *cm_A_cur;
+  double *cm_b_cur, *cm_beta_dense;
+  int *cm_hist;
+  double *cm_hist_beta, *cm_hist_coef0;
+  int cm_hist_stride;
+  unsigned char *cm_inA;
 };
 bool topk_can_fuse_need(int len);
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
@@ -101,6 +125,7 @@ struct CholFuse {
   const double *d;     // X^T (m r) of the current coefficients (start value of entering columns, k_cg)
   const double *GS;    // slot-indexed Gram of the cached columns (CS x CS), or nullptr (k_cgr gathers from it)
   int CS;
+  PubArgs pub;         // pub.on: this launch closes a batch of slots and publishes the result block (k_cg / k_cgr)
 };
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,

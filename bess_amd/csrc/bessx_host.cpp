@@ -146,6 +146,7 @@ struct bessx_session {
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
+  bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
   // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
   // kernel could have the rest of the GPU.  Measured on configs[1] it does not pay: the panel blocks delay the
   // chain's small kernels by about what the avoided foreground fills would have cost, and a speculation made more
@@ -696,8 +697,21 @@ static int cov_bg_fence_main(bessx_session *s) {
   return 0;
 }
 
+// Fusions of the small kernels around a slot (BESSX_FUSE=0 turns them off):
+//  * pub: the slot closes a batch -- its solve kernel publishes the result block itself (*pub_fused = true) instead
+//    of a k_publish launch behind it;
+//  * the selection kernel records a repeated active set itself (TopkNeed.commit_on) and opens a chained fit
+//    (TopkNeed.cont_on) instead of a k_fit_continue launch in front of it.
+struct SlotFuse {
+  const PubArgs *pub = nullptr;
+  bool pub_fused = false;
+  int cont_serial = 0, cont_parent = 0;
+  bool cont = false, cont_fused = false;
+};
+
 // solve + commit + residual of a slot whose active columns are all cached
-static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, bool force_chol = false) {
+static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, bool force_chol = false,
+                            SlotFuse *sf = nullptr) {
   const int mt = (T0 + 1 + 15) / 16;
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
@@ -715,7 +729,12 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     // parks the fit (cov_stall = 2) and the Cholesky kernel is issued for the slot (force_chol).
     CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
                    s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
-                   s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, COV_CS};
+                   s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, COV_CS, PubArgs{}};
+    // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
+    if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
+      fz.pub = *sf->pub;
+      sf->pub_fused = true;
+    }
     if (s->cov_cg && !force_chol)
       e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st);
     else
@@ -738,7 +757,7 @@ static bool cov_speculates(const bessx_session *s) { return topk_supported(s->p,
 // grow1: ... and the previous fit (same row set, the last thing the device ran) had sparsity level T0 - 1 and ended
 // with A_cur = max_k of these very scores: the first selection is A_cur plus one arg-max (k_topk).
 static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d,
-                               bool scores_ok = false, bool grow1 = false) {
+                               bool scores_ok = false, bool grow1 = false, SlotFuse *sf = nullptr) {
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
   if (skip_d && scores_ok) {
@@ -754,6 +773,22 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   if (e == hipSuccess && topk_can_fuse_need(s->p)) {
     TopkNeed nd = {cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, s->cov_C, cv.slot_of, cv.meta, s->cov_fcols,
                    s->ctrl, s->A_cur, s->cov_bmm, (s->p + 31) / 32, s->inA, (slot == 1 && grow1) ? 1 : 0};
+    nd.cm_A_cur = s->A_cur;
+    nd.cm_b_cur = s->b_cur;
+    nd.cm_beta_dense = s->beta_dense;
+    nd.cm_hist = s->hist;
+    nd.cm_hist_beta = s->hist_beta;
+    nd.cm_hist_coef0 = s->hist_coef0;
+    nd.cm_hist_stride = s->hist_stride;
+    nd.cm_inA = s->inA;
+    nd.commit_on = (s->fuse && (T0 + 1 + 15) / 16 <= 16) ? 1 : 0;  // (beyond: launch_commit does it, unfused)
+    if (sf && sf->cont && s->fuse && slot == 1 && skip_d && scores_ok) {
+      // nothing runs before the selection in this slot: it opens the chained fit itself
+      nd.cont_on = 1;
+      nd.cont_serial = sf->cont_serial;
+      nd.cont_parent = sf->cont_parent;
+      sf->cont_fused = true;
+    }
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
   } else if (e == hipSuccess) {
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
@@ -762,7 +797,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
                           s->cov_fcols, s->ctrl, slot, s->A_cur, s->st);
   }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot_cov: ") + hipGetErrorString(e));
-  return enqueue_cov_tail(s, slot, T0, lambda, rs);
+  return enqueue_cov_tail(s, slot, T0, lambda, rs, false, sf);
 }
 
 // A parked fit (hc = the control block just read back): fill list, Gram columns, wake-up, rest of the slot.
@@ -966,13 +1001,32 @@ static int enqueue_cox_tail(bessx_session *s, int slot, int T0, int rs) {
 // Results of the kernels queued so far.  kcopy >= 0: only the first kcopy coefficients / indices are wanted and
 // the block is published by a kernel into pinned memory (k_publish) while the host spins on its sequence number --
 // no copy engine, no interrupt.  kcopy < 0 (or BESSX_PUBLISH=0): plain asynchronous copy + stream synchronisation.
-static int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq) {
+// what a publication of the result block into pinned buffer `buf` copies; takes the next sequence number
+static PubArgs publish_args(bessx_session *s, int kcopy, int buf, unsigned long long *seq) {
   *seq = ++s->pub_seq;
-  HIPX(launch_publish(s->resblk, s->res_buf[buf], 128, (size_t)((unsigned char *)s->sse - s->resblk), 2 * s->n_sse_blk,
-                      (size_t)((unsigned char *)s->b_cur - s->resblk), (size_t)((unsigned char *)s->A_cur - s->resblk),
-                      std::min(kcopy, s->capA), s->pub_flag + 8 * buf, *seq, s->st,
-                      s->cov_mode ? s->cov[0].meta : nullptr));
+  PubArgs pa = {s->resblk,
+                s->res_buf[buf],
+                128,
+                (size_t)((unsigned char *)s->sse - s->resblk),
+                2 * s->n_sse_blk,
+                (size_t)((unsigned char *)s->b_cur - s->resblk),
+                (size_t)((unsigned char *)s->A_cur - s->resblk),
+                std::min(kcopy, s->capA),
+                s->pub_flag + 8 * buf,
+                *seq,
+                s->cov_mode ? s->cov[0].meta : nullptr,
+                1};
+  return pa;
+}
+
+static int publish_launch(bessx_session *s, const PubArgs &pa) {
+  HIPX(launch_publish(pa.dev, pa.host, pa.ctrl_bytes, pa.off_sse, pa.n_sse, pa.off_b, pa.off_a, pa.kcopy, pa.seq_host,
+                      pa.seq, s->st, pa.count_ptr));
   return 0;
+}
+
+static int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq) {
+  return publish_launch(s, publish_args(s, kcopy, buf, seq));
 }
 
 static int publish_wait(bessx_session *s, int buf, unsigned long long want) {
@@ -1198,12 +1252,27 @@ static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, in
   ah.rs = rs;
   ah.serial = ++s->fit_serial;
   ah.buf = buf;
-  HIPX(launch_fit_continue(s->ctrl, Tn, s->hist, s->st, ah.serial, 1, parent));
-  for (int b = 0, sl = 1; b < batch && sl <= s->max_iter; b++, sl++)
+  // the first selection can open the fit itself when no kernel precedes it in slot 1 (same lambda: the scores stand)
+  const bool cont_fusable = s->fuse && hint.lambda == parent_lambda && topk_can_fuse_need(s->p);
+  if (!cont_fusable) HIPX(launch_fit_continue(s->ctrl, Tn, s->hist, s->st, ah.serial, 1, parent));
+  const PubArgs pa = publish_args(s, Tn, buf, &ah.seq);
+  bool published = false;
+  for (int b = 0, sl = 1; b < batch && sl <= s->max_iter; b++, sl++) {
+    SlotFuse sf;
+    const bool last = b + 1 == batch || sl == s->max_iter;
+    if (last) sf.pub = &pa;
+    if (sl == 1 && cont_fusable) {
+      sf.cont = true;
+      sf.cont_serial = ah.serial;
+      sf.cont_parent = parent;
+    }
     if (int rc = enqueue_lm_slot_cov(s, sl, Tn, hint.lambda, rs, sl == 1, hint.lambda == parent_lambda,
-                                     hint.lambda == parent_lambda && Tn == parent_T0 + 1))
+                                     hint.lambda == parent_lambda && Tn == parent_T0 + 1, &sf))
       return rc;
-  return publish_enqueue(s, Tn, buf, &ah.seq);
+    if (sl == 1 && cont_fusable && !sf.cont_fused) return fail(BESSX_ERR_HIP, "internal: chained fit was not opened");
+    published = published || sf.pub_fused;
+  }
+  return published ? 0 : publish_launch(s, pa);
 }
 
 // One Algorithm::fit with the state set by the update_* style members of the session.
@@ -1323,15 +1392,23 @@ static int algorithm_fit(bessx_session *s) {
   while (!glm && cov) {
     if (!have_results) {
       const bool first_batch = slot == 1;
-      for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
+      unsigned long long seq = 0;
+      PubArgs pa = {};
+      if (s->publish) pa = publish_args(s, T0, my_buf, &seq);
+      bool published = false;
+      for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++) {
+        SlotFuse sf;
+        if (s->publish && (b + 1 == batch || slot == s->max_iter)) sf.pub = &pa;
         if (int rc = enqueue_lm_slot_cov(s, slot, T0, lambda, rs, use_cache && slot == 1, scores_ok,
-                                         scores_ok && cc.T0 + 1 == T0))
+                                         scores_ok && cc.T0 + 1 == T0, &sf))
           return rc;
+        published = published || sf.pub_fused;
+      }
       if (!s->publish) {
         if (int rc = read_results(s, T0)) return rc;
       } else {
-        unsigned long long seq = 0;
-        if (int rc = publish_enqueue(s, T0, my_buf, &seq)) return rc;
+        if (!published)
+          if (int rc = publish_launch(s, pa)) return rc;
         // chain the announced next fit of the warm-start path behind this one before waiting for this one
         if (first_batch)
           if (int rc = enqueue_chained(s, hint, rs, my_serial, my_buf ^ 1, batch, lambda, T0)) return rc;
@@ -2614,6 +2691,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
           HIPT(dmalloc(&s->cand_bg, 32768));
         }
         if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
+        if (const char *ev = std::getenv("BESSX_FUSE")) s->fuse = std::string(ev) != "0";
       } else if (mode == 2) {
         return bail(fail(BESSX_ERR_ARG, "covariance score mode: p too large for the Gram column cache"));
       }

@@ -39,6 +39,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// The work of k_publish as the tail of another single-block kernel: every thread of the block calls it after a
+// barrier that follows the last write to the result block.  Plain (volatile) reads: the block was written by this
+// very kernel.
+__device__ __forceinline__ void publish_body(const PubArgs &pa) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (tid == 0 && pa.count_ptr != nullptr) pa.seq_host[1] = (unsigned long long)pa.count_ptr[0];
+  const volatile unsigned long long *d8 = reinterpret_cast<const volatile unsigned long long *>(pa.dev);
+  unsigned long long *h8 = reinterpret_cast<unsigned long long *>(pa.host);
+  for (int i = tid; i < pa.ctrl_bytes / 8; i += nt) h8[i] = d8[i];
+  for (int i = tid; i < pa.n_sse; i += nt) h8[pa.off_sse / 8 + i] = d8[pa.off_sse / 8 + i];
+  for (int i = tid; i < pa.kcopy; i += nt) h8[pa.off_b / 8 + i] = d8[pa.off_b / 8 + i];
+  const volatile int *d4 = reinterpret_cast<const volatile int *>(pa.dev + pa.off_a);
+  int *h4 = reinterpret_cast<int *>(pa.host + pa.off_a);
+  for (int i = tid; i < pa.kcopy; i += nt) h4[i] = d4[i];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(pa.seq_host, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Block-wide sum for 256-thread blocks, fixed order; result valid in thread 0.
 __device__ __forceinline__ double block_sum_256(double v, double *sm /*>=4*/) {
   v = wave_sum(v);
@@ -292,6 +311,14 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
                               int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
                               const int *__restrict__ A_cur);
 
+__device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot, int T0,
+                                            const int *__restrict__ A_new, const double *__restrict__ sol,
+                                            int has_intercept, int wait_chain, int *__restrict__ A_cur,
+                                            double *__restrict__ b_cur, double *__restrict__ beta_dense,
+                                            int *__restrict__ hist, double *__restrict__ hist_beta,
+                                            double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh,
+                                            unsigned char *__restrict__ inA);
+
 // nd.slot_of != nullptr (covariance form of the LM fit, single chunk): the kernel ends with the work of k_cov_need on
 // the indices it has just selected -- one launch less per PDAS iteration.
 template <int EB>  // keys per thread this instance can hold (bucket of ceil(len / 1024))
@@ -299,7 +326,36 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
                                                int len_total, int chunk, int k, int *__restrict__ out,
                                                int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
                                                int slot, const int *__restrict__ run_flag, const TopkNeed nd) {
-  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  if (nd.cont_on) {
+    // k_fit_continue(chained) as the prologue of the first kernel of the chained fit: it only starts if the fit
+    // before it (serial cont_parent) ended here on a repeated set with fresh score sums
+    FitCtrl *c = nd.ctrl;
+    const bool go = c->serial == nd.cont_parent && c->done && c->d_fresh && c->l >= 0 && !c->cov_stall && !c->info;
+    if (!go) return;  // uniform
+    for (int i = threadIdx.x; i < k; i += 1024) nd.cm_hist[i] = 0;
+    __syncthreads();  // every thread has read the old block
+    if (threadIdx.x == 0) {
+      c->done = 0;
+      c->l = 0;
+      c->T0 = k;
+      c->irls_done = 0;
+      c->irls_steps = 0;
+      c->info = 0;
+      c->same_prev = 0;
+      c->d_fresh = 0;
+      c->cov_nfill = 0;
+      c->cov_stall = 0;
+      c->cov_groups = 0;
+      c->cov_miss = 0;
+      c->cov_nmiss = 0;
+      c->sse_valid = 0;
+      c->fast_same = 0;
+      c->serial = nd.cont_serial;
+    }
+    __syncthreads();
+  } else if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) {
+    return;
+  }
   if (run_flag != nullptr && *run_flag == 0) return;
   __shared__ int wcnt[2][16];
   if (nd.slot_of != nullptr && nd.inc1 && nd.ctrl->l == 0 && nd.ctrl->k_cur + 1 == k && gridDim.x == 1) {
@@ -397,7 +453,17 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
       nd.ctrl->fast_same = 0;
       if (same) nd.ctrl->same_prev = 1;
     }
-    if (same) return;
+    if (same) {
+      if (nd.commit_on) {
+        // ... and record the iteration right here (the record-and-stop branch of k_commit): the solve kernel queued
+        // behind this one then falls through its gate instead of doing a launch's worth of bookkeeping
+        __shared__ int same_any_sh;
+        __syncthreads();
+        commit_body(nd.ctrl, slot, k, out, nullptr, 0, 0, nd.cm_A_cur, nd.cm_b_cur, nd.cm_beta_dense, nd.cm_hist,
+                    nd.cm_hist_beta, nd.cm_hist_coef0, nd.cm_hist_stride, &same_any_sh, nd.cm_inA);
+      }
+      return;
+    }
   }
   __shared__ int wsum[16];
   __shared__ int wsum2[16];
@@ -1126,10 +1192,10 @@ __device__ unsigned long long g_cg_prof[16];
 #define CGP(i)
 #endif
 template <int CH_SLOTS, int NW>
-__global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, const double *__restrict__ rhs,
-                                            const int *__restrict__ A_new, double *__restrict__ sol,
-                                            const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
-                                            const double tol) {
+__device__ __forceinline__ void cg_body(int m, int mt, double ridge, const double *__restrict__ rhs,
+                                        const int *__restrict__ A_new, double *__restrict__ sol,
+                                        const FitCtrl *__restrict__ ctrl, int slot, const CholFuse &fz, int maxit,
+                                        const double tol) {
   __shared__ int same_any_sh;
   if (ctrl->done || ctrl->l != slot - 1) return;
   if (ctrl->same_prev) {
@@ -1356,6 +1422,18 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
 
 #undef CG_SYNC
 
+template <int CH_SLOTS, int NW>
+__global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, const double *__restrict__ rhs,
+                                            const int *__restrict__ A_new, double *__restrict__ sol,
+                                            const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
+                                            const double tol) {
+  cg_body<CH_SLOTS, NW>(m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
+  if (fz.pub.on) {  // last kernel of a batch of slots: publish the result block, whatever the body did
+    __syncthreads();
+    publish_body(fz.pub);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K7'', the same conjugate-gradient solve with the matrix dealt by ROWS instead of MFMA tiles (systems of at most
 // 64 * RPT rows and 8 * NCW columns, i.e. up to 192 unknowns; larger ones keep k_cg).
@@ -1369,10 +1447,10 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
 // Same warm start, same acceptance test on the recomputed residual, same loss identity and commit as k_cg.
 // ------------------------------------------------------------------------------------------
 template <int RPT, int NCW>
-__global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const double *__restrict__ rhs,
-                                             const int *__restrict__ A_new, double *__restrict__ sol,
-                                             const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
-                                             const double tol) {
+__device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const double *__restrict__ rhs,
+                                         const int *__restrict__ A_new, double *__restrict__ sol,
+                                         const FitCtrl *__restrict__ ctrl, int slot, const CholFuse &fz, int maxit,
+                                         const double tol) {
   __shared__ int same_any_sh;
   if (ctrl->done || ctrl->l != slot - 1) return;
   if (ctrl->same_prev) {
@@ -1591,6 +1669,18 @@ __global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const 
   commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
               fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
   CGP(6);
+}
+
+template <int RPT, int NCW>
+__global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const double *__restrict__ rhs,
+                                             const int *__restrict__ A_new, double *__restrict__ sol,
+                                             const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
+                                             const double tol) {
+  cgr_body<RPT, NCW>(m, nc, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
+  if (fz.pub.on) {  // last kernel of a batch of slots: publish the result block, whatever the body did
+    __syncthreads();
+    publish_body(fz.pub);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
