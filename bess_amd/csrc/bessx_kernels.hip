@@ -26,6 +26,41 @@
 #include "bessx_dev.h"
 
 namespace bessx {
+#ifdef BESSX_KTRACE
+// development aid: start time stamp (100 MHz wall clock) of every traced kernel, in launch order
+__device__ unsigned long long g_ktrace[1 << 16];
+__device__ unsigned int g_ktrace_n;
+#define KT(id)                                                                   \
+  do {                                                                           \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                \
+      const unsigned n_ = atomicAdd(&g_ktrace_n, 1u);                            \
+      if (n_ < (1u << 16)) g_ktrace[n_] = (wall_clock64() << 8) | (unsigned)(id); \
+    }                                                                            \
+  } while (0)
+#else
+#define KT(id)
+#endif
+#ifdef BESSX_KTRACE
+__device__ unsigned long long g_phase[32];
+#define PH_BEGIN() unsigned long long tph_ = wall_clock64()
+#define PH(i)                                                   \
+  do {                                                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if (threadIdx.x == 0) {                                     \
+      unsigned long long now_ = wall_clock64();                 \
+      atomicAdd(&g_phase[i], now_ - tph_);                      \
+      tph_ = now_;                                              \
+    }                                                           \
+  } while (0)
+#define PH_COUNT()                                          \
+  do {                                                        \
+    if (threadIdx.x == 0) atomicAdd(&g_phase[31], 1ull);      \
+  } while (0)
+#else
+#define PH_BEGIN()
+#define PH(i)
+#define PH_COUNT()
+#endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -326,6 +361,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
                                                int len_total, int chunk, int k, int *__restrict__ out,
                                                int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
                                                int slot, const int *__restrict__ run_flag, const TopkNeed nd) {
+  KT(1);
   if (nd.cont_on) {
     // k_fit_continue(chained) as the prologue of the first kernel of the chained fit: it only starts if the fit
     // before it (serial cont_parent) ended here on a repeated set with fresh score sums
@@ -364,17 +400,31 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     // total order).  An arg-max instead of a selection.
     __shared__ unsigned long long bk[16];
     __shared__ int bi[16];
+    PH_BEGIN();
     unsigned long long best = 0ull;
     int besti = 0x7fffffff;
-    for (int i = threadIdx.x; i < len_total; i += 1024) {
-      if (!nd.inA[i]) {
-        const unsigned long long key = score_key(score[i]);
-        if (key > best || (key == best && i < besti)) {
+    {
+      // all loads first (independent), then the comparisons: a load behind a branch per element serialises
+      double sc[EB];
+      unsigned char ia[EB];
+#pragma unroll
+      for (int e = 0; e < EB; e++) {
+        const int i = threadIdx.x + e * 1024;
+        const bool in = i < len_total;
+        sc[e] = in ? score[i] : 0.0;
+        ia[e] = in ? nd.inA[i] : (unsigned char)1;
+      }
+#pragma unroll
+      for (int e = 0; e < EB; e++) {
+        const int i = threadIdx.x + e * 1024;
+        const unsigned long long key = score_key(sc[e]);
+        if (!ia[e] && (key > best || (key == best && i < besti))) {
           best = key;
           besti = i;
         }
       }
     }
+    PH(0);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       const unsigned long long ok = __shfl_xor(best, o);
@@ -397,26 +447,30 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
         best = bk[w];
         besti = bi[w];
       }
-    // ordered insertion of besti into the sorted A_cur
+    PH(1);
+    // ordered insertion of besti into the sorted A_cur; its position = number of smaller elements, counted by the
+    // block (a binary search by one thread is a chain of dependent global loads)
     const int *A_old = nd.A_cur;
-    for (int i = threadIdx.x; i < k - 1; i += 1024) {
-      const int a = A_old[i];
-      out[i + (a > besti ? 1 : 0)] = a;
+    int lo = 0;
+    for (int base = 0; base < k - 1; base += 1024) {  // uniform trip count
+      const int i = base + threadIdx.x;
+      int smaller = 0;
+      if (i < k - 1) {
+        const int a = A_old[i];
+        out[i + (a > besti ? 1 : 0)] = a;
+        smaller = a < besti ? 1 : 0;
+      }
+      lo += __syncthreads_count(smaller);
     }
     if (threadIdx.x == 0) {
-      int lo = 0, hi = k - 1;  // first position whose element exceeds besti
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (A_old[mid] < besti)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
       out[lo] = besti;
       nd.ctrl->fast_same = 0;
     }
     __syncthreads();
+    PH(2);
     cov_need_body<1024>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
+    PH(3);
+    PH_COUNT();
     return;
   }
   if (nd.slot_of != nullptr && nd.ctrl->fast_same) {
@@ -1427,6 +1481,7 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
                                             const int *__restrict__ A_new, double *__restrict__ sol,
                                             const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
                                             const double tol) {
+  KT(3);
   cg_body<CH_SLOTS, NW>(m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
   if (fz.pub.on) {  // last kernel of a batch of slots: publish the result block, whatever the body did
     __syncthreads();
@@ -1676,6 +1731,7 @@ __global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const 
                                              const int *__restrict__ A_new, double *__restrict__ sol,
                                              const FitCtrl *__restrict__ ctrl, int slot, const CholFuse fz, int maxit,
                                              const double tol) {
+  KT(2);
   cgr_body<RPT, NCW>(m, nc, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
   if (fz.pub.on) {  // last kernel of a batch of slots: publish the result block, whatever the body did
     __syncthreads();
@@ -1845,6 +1901,7 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
                                                    int *__restrict__ A_cur, double *__restrict__ b_cur,
                                                    double *__restrict__ beta_dense, int *__restrict__ hist,
                                                    unsigned char *__restrict__ inA) {
+  KT(13);
   // beta_dense (and inA) were zeroed by memset nodes just before this launch
   for (int i = threadIdx.x; i < k_init; i += 256) {
     A_cur[i] = init_idx[i];
@@ -1881,6 +1938,7 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
 // which the host would have issued it), otherwise it -- and with it all its slots -- does nothing.
 __global__ void __launch_bounds__(256) k_fit_continue(FitCtrl *__restrict__ ctrl, int T0, int *__restrict__ hist,
                                                       int serial, int chained, int parent) {
+  KT(8);
   if (chained && !(ctrl->serial == parent && ctrl->done && ctrl->d_fresh && ctrl->l >= 0 && !ctrl->cov_stall &&
                    !ctrl->info))
     return;
@@ -3472,6 +3530,7 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
                                                   int *__restrict__ slot_of, int *__restrict__ meta, int C,
                                                   int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
                                                   const int *__restrict__ A_cur) {
+  KT(12);
   if (ctrl->done || (slot == 0 ? ctrl->l != 0 : ctrl->l != slot - 1)) return;
   cov_need_body<256>(list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot, A_cur);
 }
@@ -3483,6 +3542,7 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
                                                        const double *__restrict__ bd2, int *__restrict__ slot_of,
                                                        int *__restrict__ meta, FitCtrl *__restrict__ ctrl,
                                                        int parked) {
+  KT(10);
   if (parked ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int nm = meta[1];
   const int tid = threadIdx.x;
@@ -3513,6 +3573,7 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
 }
 
 __global__ void k_cov_resume(FitCtrl *__restrict__ ctrl) {
+  KT(11);
   if (ctrl->cov_stall) {
     ctrl->cov_stall = 0;
     ctrl->l = -1 - ctrl->l;
@@ -3700,6 +3761,7 @@ __global__ void __launch_bounds__(256) k_cov_panel_lds2(const double *__restrict
                                                         int rows_per_slab, int nslab, int njg,
                                                         double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
                                                         int big, const int *__restrict__ bgm) {
+  KT(5);
   if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
   const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
   const long per_group = (long)nslab * njg;
@@ -3797,6 +3859,7 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
                                                     const int *__restrict__ slot_of, double *__restrict__ G,
                                                     const FitCtrl *__restrict__ ctrl, int slot, int big,
                                                     const int *__restrict__ bgm) {
+  KT(6);
   if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
   const int gl = blockIdx.y;
   if (gl >= ngroups || (g0 + gl) * COV_R >= (big == 2 ? bgm[0] : ctrl->cov_nfill)) return;
@@ -3820,6 +3883,7 @@ __global__ void __launch_bounds__(256) k_cov_compact(const double *__restrict__ 
                                                      const int *__restrict__ slot_of,
                                                      const int *__restrict__ fcols, int g0, double *__restrict__ GS,
                                                      int CS, const FitCtrl *__restrict__ ctrl, int big) {
+  KT(7);
   if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int gl = blockIdx.y;
   if ((g0 + gl) * COV_R >= ctrl->cov_nfill) return;
@@ -3886,6 +3950,7 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
                                                double n_t, double lambda, const unsigned char *__restrict__ always,
                                                double *__restrict__ bd, const unsigned char *__restrict__ inA,
                                                double *__restrict__ bmm, const FitCtrl *__restrict__ ctrl, int slot) {
+  KT(4);
   if (ctrl->done || ctrl->l != slot - 1) return;
   // 32 columns x 8 thread groups per block; group g adds the active columns i = g, g+8, ... (two interleaved
   // accumulators), the 8 partial sums are added in group order: a fixed summation tree.
@@ -3988,6 +4053,7 @@ __global__ void __launch_bounds__(256) k_publish(const unsigned char *__restrict
                                                  int ctrl_bytes, size_t off_sse, int n_sse, size_t off_b, size_t off_a,
                                                  int kcopy, unsigned long long *seq_host, unsigned long long seq,
                                                  const int *__restrict__ count_ptr) {
+  KT(9);
   const int tid = threadIdx.x;
   // (covariance form) columns in the Gram column cache right now, next to the sequence number
   if (tid == 0 && count_ptr != nullptr) seq_host[1] = (unsigned long long)count_ptr[0];
@@ -4261,6 +4327,25 @@ extern "C" __attribute__((visibility("default"))) int bessx_debug_cg_profile(uns
   return 0;
 }
 #endif
+#ifdef BESSX_KTRACE
+extern "C" __attribute__((visibility("default"))) int bessx_debug_phase(unsigned long long *out, int reset) {
+  unsigned long long z[32] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(z)) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+extern "C" __attribute__((visibility("default"))) int bessx_debug_ktrace(unsigned long long *out, int cap, int reset) {
+  unsigned int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ktrace_n), sizeof(n)) != hipSuccess) return -1;
+  const unsigned int m = n < (unsigned)cap ? n : (unsigned)cap;
+  if (m && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktrace), (size_t)m * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ktrace_n), &z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return (int)m;
+}
+#endif
 hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
                      int slot, const CholFuse *fuse, int maxit, hipStream_t st) {
   if (mt < 1 || m > mt * 16 || mt > CH_MT || fuse == nullptr) return hipErrorInvalidValue;
@@ -4276,7 +4361,7 @@ hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *
     const char *ev = std::getenv("BESSX_CG_LAYOUT");
     return !(ev && std::string(ev) == "tiles");
   }();
-  if (by_rows && m <= 192) {
+  if (by_rows && m <= 208) {
     const int nc = (m + 7) / 8;
 #define CGR_GO(RP, NW_)                                                                                           \
   hipLaunchKernelGGL((k_cgr<RP, NW_>), dim3(1), dim3(512), 0, st, m, nc, ridge, rhs, A_new, sol, ctrl, slot, fz, \
@@ -4285,8 +4370,10 @@ hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *
       CGR_GO(1, 8);
     else if (m <= 128)
       CGR_GO(2, 16);
-    else
+    else if (m <= 192)
       CGR_GO(3, 24);
+    else
+      CGR_GO(4, 26);
 #undef CGR_GO
     LAUNCH_CHECK();
     return hipSuccess;

@@ -1,0 +1,26 @@
+import sys, ctypes, collections, numpy as np
+sys.path.insert(0,'.')
+from bess_amd import capi, synth
+X,y,_,_=synth.make_lm()
+L=capi.lib()
+cap=1<<16
+buf=(ctypes.c_ulonglong*cap)()
+names={1:'topk',2:'cgr',3:'cg',4:'cov_d',5:'panel',6:'reduce',7:'compact',8:'continue',9:'publish',10:'fill_list',11:'resume',12:'need',13:'begin'}
+import time
+with capi.Session(X,y) as s:
+    s.sequential_path(np.arange(1,201), ic_type=3)
+    L.bessx_debug_ktrace(buf,cap,1)
+    ph=(ctypes.c_ulonglong*32)(); L.bessx_debug_phase(ph,1)
+    t0=time.time(); s.sequential_path(np.arange(1,201), ic_type=3); wall=time.time()-t0
+    n=L.bessx_debug_ktrace(buf,cap,1)
+    ph=(ctypes.c_ulonglong*32)(); L.bessx_debug_phase(ph,1)
+    print("phases (us per call, %d calls):"%ph[31], [round(ph[i]*0.01/max(ph[31],1),2) for i in range(8)])
+ev=[(buf[i]&255, (buf[i]>>8)*0.01) for i in range(n)]  # us
+ev.sort(key=lambda e:e[1])
+print("events",n,"wall ms",wall*1e3,"span ms",(ev[-1][1]-ev[0][1])/1e3)
+tot=collections.defaultdict(float); cnt=collections.Counter()
+for (k,t),(k2,t2) in zip(ev,ev[1:]):
+    tot[k]+=t2-t; cnt[k]+=1
+for k,v in sorted(tot.items(),key=lambda x:-x[1]): print("%-10s %5d launches  %8.3f ms  avg %6.2f us"%(names.get(k,k),cnt[k],v/1e3,v/cnt[k]))
+mid=n//2
+for (k,t),(k2,t2) in list(zip(ev,ev[1:]))[mid:mid+24]: print("%-10s %7.2f us"%(names.get(k,k),t2-t))
