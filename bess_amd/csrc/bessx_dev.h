@@ -130,8 +130,10 @@ struct CholFuse {
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
                        hipStream_t st, const CholFuse *fuse = nullptr);
+// tol: accepted relative residual |q - (G + ridge I) x| <= tol |q|; by_rows: systems of up to 208 unknowns use the
+// row-dealt kernel (k_cgr), otherwise / beyond the tile-dealt one (k_cg)
 hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
-                     int slot, const CholFuse *fuse, int maxit, hipStream_t st);
+                     int slot, const CholFuse *fuse, int maxit, hipStream_t st, double tol = 1e-13, bool by_rows = true);
 hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                            const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);

@@ -146,6 +146,8 @@ struct bessx_session {
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
+  double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
+  bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
   bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
   // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
   // kernel could have the rest of the GPU.  Measured on configs[1] it does not pay: the panel blocks delay the
@@ -736,7 +738,8 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
       sf->pub_fused = true;
     }
     if (s->cov_cg && !force_chol)
-      e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st);
+      e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st, s->cg_tol,
+                    s->cg_by_rows);
     else
       e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
                       &fz);
@@ -2674,7 +2677,20 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         if (const char *ev = std::getenv("BESSX_COV_BG")) s->cov_bg = std::atoi(ev) != 0;
         if (const char *ev = std::getenv("BESSX_COV_SPARE")) s->cov_spare = std::max(0, std::atoi(ev));
         if (s->cov_bg) {
-          {
+          const char *mk = std::getenv("BESSX_COV_BG_MASK");
+          int ncu = 0;
+          (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
+          if (!(mk && std::atoi(mk) == 0) && ncu >= 64 && ncu % 32 == 0) {
+            // The panel blocks of a background fill must never hold a compute unit the chain's small kernels are
+            // waiting for: the second stream is confined to a subset of the CUs that leaves 4 CUs of every XCD free
+            // under either numbering of the mask bits (bit i = XCD i % 8, CU i / 8, or XCD i / 32, CU i % 32).
+            std::vector<uint32_t> mask((size_t)ncu / 32, 0xffffffffu);
+            int w = 28;  // CUs per group of 32 the fills may use (BESSX_COV_BG_W): fewer = gentler on the chain
+            if (const char *ev = std::getenv("BESSX_COV_BG_W")) w = std::min(28, std::max(1, std::atoi(ev)));
+            for (int i = 0; i < ncu; i++)
+              if (i < 32 || i % 32 < 4 || i % 32 >= 4 + w) mask[i / 32] &= ~(1u << (i % 32));
+            HIPT(hipExtStreamCreateWithCUMask(&s->st2, (uint32_t)mask.size(), mask.data()));
+          } else {
             // lowest priority: the chain's small kernels on the main stream must never queue behind panel blocks
             int lo = 0, hi = 0;
             HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -2692,6 +2708,11 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         }
         if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
         if (const char *ev = std::getenv("BESSX_FUSE")) s->fuse = std::string(ev) != "0";
+        if (const char *ev = std::getenv("BESSX_CG_LAYOUT")) s->cg_by_rows = std::string(ev) != "tiles";
+        if (const char *ev = std::getenv("BESSX_CG_TOL")) {
+          const double v = std::atof(ev);
+          if (v >= 1e-15 && v <= 1e-6) s->cg_tol = v;
+        }
       } else if (mode == 2) {
         return bail(fail(BESSX_ERR_ARG, "covariance score mode: p too large for the Gram column cache"));
       }

@@ -4347,20 +4347,9 @@ extern "C" __attribute__((visibility("default"))) int bessx_debug_ktrace(unsigne
 }
 #endif
 hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
-                     int slot, const CholFuse *fuse, int maxit, hipStream_t st) {
+                     int slot, const CholFuse *fuse, int maxit, hipStream_t st, double tol, bool by_rows) {
   if (mt < 1 || m > mt * 16 || mt > CH_MT || fuse == nullptr) return hipErrorInvalidValue;
   const CholFuse fz = *fuse;
-  // accepted relative residual of the normal equations, |q - (G + ridge I) x| <= tol |q| (BESSX_CG_TOL, default 1e-13)
-  static const double tol = [] {
-    const char *ev = std::getenv("BESSX_CG_TOL");
-    const double v = ev ? std::atof(ev) : 0.0;
-    return (v >= 1e-15 && v <= 1e-6) ? v : 1e-13;
-  }();
-  // systems of up to 192 unknowns: the matrix dealt by rows (k_cgr); BESSX_CG_LAYOUT=tiles keeps k_cg throughout
-  static const bool by_rows = [] {
-    const char *ev = std::getenv("BESSX_CG_LAYOUT");
-    return !(ev && std::string(ev) == "tiles");
-  }();
   if (by_rows && m <= 208) {
     const int nc = (m + 7) / 8;
 #define CGR_GO(RP, NW_)                                                                                           \

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-REF_LIB = os.path.join(_HERE, "_ref", "libbess_ref.so")
+# BESS_REF_LIB selects another build of the same sources (oracle/Makefile: ref_fast), for CPU timing only
+REF_LIB = os.environ.get("BESS_REF_LIB") or os.path.join(_HERE, "_ref", "libbess_ref.so")
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)
