@@ -172,6 +172,7 @@ struct CoxBufs {
   double *SCR;                                         // block totals of the multi-block scans
   double *C1, *CU, *CV, *C2;                           // one-pass score: prefix sums of ew/S0, u, ew - u, ew/S0^2
   int one_pass;                                        // score pass reads X once (k_cox_score1p)
+  int need_uv;                                         // CU / CV wanted although the score is not one-pass (groups)
 };
 size_t cox_scan_scratch_doubles(long ld, int kmax);
 hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,
@@ -190,7 +191,12 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                                   hipStream_t st, double *rdiag, double *zbig);
 hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const double *w1, const double *w2, int N,
                                 const int *gidx, const int *gsz, const int *goff, double *mblk, double *dcol,
-                                hipStream_t st);
+                                hipStream_t st, int cshift = 0);
+hipError_t launch_iota(int *a, int n, hipStream_t st);
+hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxBufs cb, const int *allcols, int mcols,
+                                    int smax, int N, const int *gidx_h, const int *gsz_h, const int *gidx,
+                                    const int *gsz, const int *goff, long mblk_len, double *mblk, double *mblk2,
+                                    double *dcol, hipStream_t st);
 hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
                               const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
                               double lambda, const double *beta_dense, const unsigned char *always, double *bd,

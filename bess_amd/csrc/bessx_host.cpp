@@ -99,6 +99,8 @@ struct bessx_session {
   std::vector<int> gidx_h, gsz_h, goff_h;
   int *gidx = nullptr, *gsz = nullptr, *goff = nullptr, *gcols_new = nullptr;
   double *mblk = nullptr, *dcol = nullptr;
+  double *mblk2 = nullptr;  // Cox with groups: second term of the per-group blocks
+  int *allcols = nullptr;   // 0 .. p-1 (column lists of the panels of the Cox group branch)
   std::vector<double *> gxtx_rs;  // per row set: X_g^T diag(mask) X_g blocks (LM)
   int cox_state_rs = -1;
   int dev_state_rs = -1;                // row set of the fit whose final coefficients sit in A_cur/b_cur/beta_dense
@@ -283,6 +285,8 @@ static void session_free(bessx_session *s) {
   F(s->gcols_new);
   F(s->mblk);
   F(s->dcol);
+  F(s->mblk2);
+  F(s->allcols);
   for (auto q : s->gxtx_rs) F(q);
   for (auto q : s->cox_allocs) F(q);
   F(s->idcols);
@@ -1075,7 +1079,10 @@ static int algorithm_fit_grouped(bessx_session *s) {
   const int T0 = s->sparsity_level, rs = s->cur_rows, fam = s->model_type;
   const double lambda = s->lambda_level;
   if (T0 < 1 || T0 > s->N) return fail(BESSX_ERR_ARG, "sparsity level (number of groups) outside [1, number of groups]");
-  if (fam == 4) return fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 is not built yet");
+  if (fam == 4 && !(s->algorithm_type == 2 || s->algorithm_type == 3))
+    return fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 exists only for algorithm_type 2 / 3 (the group "
+                                       "branch of GroupPdasCox::get_A)");
+  const bool cox = fam == 4;
   if (!topk_supported(s->N, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: too many groups for this sparsity level");
   const bool glm = fam != 1;
   // beta <- beta_init
@@ -1097,11 +1104,15 @@ static int algorithm_fit_grouped(bessx_session *s) {
     if (!glm)
       e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                           s->st);
+    else if (cox)
+      e = launch_cox_state(s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->cox, s->sse,
+                           s->st);
     else
       e = launch_glm_eta_gh(fam, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->logfact, s->ctrl, 0, s->A_cur,
                             s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
   }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit begin: ") + hipGetErrorString(e));
+  if (cox) s->cox_state_rs = -1;  // the ungrouped path's per-row-set reuse does not apply here
   s->dev_state_rs = -1;
   s->cache[rs].valid = false;
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
@@ -1115,6 +1126,14 @@ static int algorithm_fit_grouped(bessx_session *s) {
       if (e == hipSuccess)
         e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->part_rs[rs], s->nrb, s->p, 1,
                                (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st);
+    } else if (cox) {
+      // X_g^T h X_g without the n x n Hessian of src/Algorithm.h:1536-1546 (launch_cox_group_moments)
+      e = launch_cox_group_moments(s->X, s->ld, s->n, s->p, s->cox, s->allcols, (int)std::min<size_t>(s->cox_M_cols, 256),
+                                   s->gmax, s->N, s->gidx_h.data(), s->gsz_h.data(), s->gidx, s->gsz, s->goff,
+                                   (long)s->goff_h[s->N], s->mblk, s->mblk2, s->dcol, s->st);
+      if (e == hipSuccess)
+        e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->mblk, s->dcol, nullptr, 0, s->p, 0, 1.0, lambda,
+                               s->beta_dense, s->always, s->bd, s->st);
     } else {
       e = launch_group_moments(s->gmax, s->X, s->ld, s->n, s->h_rs[rs], s->r_rs[rs], s->N, s->gidx, s->gsz, s->goff,
                                s->mblk, s->dcol, s->st);
@@ -1162,6 +1181,41 @@ static int algorithm_fit_grouped(bessx_session *s) {
                             s->sse, s->st);
       if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit: ") + hipGetErrorString(e));
       if (int rc = read_results(s)) return rc;
+    } else if (cox) {
+      // GroupPdasCox::primary_model_fit on the expanded columns: the Newton chain of the ungrouped path
+      if (int rc = cox_reserve(s, K)) return rc;
+      const int mp = (K + 1 + 15) / 16 * 16;
+      e = launch_gram_cols(s->gcols_new, K, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 0, s->st);
+      if (e == hipSuccess) e = launch_cox_newton_begin(s->ctrl, slot, K, s->cox, s->idcols, s->st);
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group cox begin: ") + hipGetErrorString(e));
+      const int tmax = 30;
+      int t = 1;  // Newton steps are numbered from 1 (:1411)
+      int *saved = s->A_new;
+      s->A_new = s->gcols_new;  // the step kernels take (column list, count)
+      int rc = 0;
+      while (true) {
+        int upto = std::min(tmax, t + std::max(2, s->irls_guess) - 1);
+        for (; t <= upto && rc == 0; t++) rc = enqueue_cox_newton(s, slot, t, K, lambda, rs);
+        if (rc) break;
+        e = launch_commit_group(s->ctrl, slot, T0, saved, K, s->gcols_new, s->cox.b0, 0, 1, s->A_cur, s->b_cur,
+                                s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+        if (e == hipSuccess)
+          e = launch_cox_state(s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->cox,
+                               s->sse, s->st);
+        if (e != hipSuccess) {
+          rc = fail(BESSX_ERR_HIP, std::string("group cox tail: ") + hipGetErrorString(e));
+          break;
+        }
+        rc = read_results(s);
+        if (rc || hc->l == slot) break;
+        if (t > tmax) {
+          rc = fail(BESSX_ERR_NUMERIC, "Newton chain did not terminate");
+          break;
+        }
+      }
+      s->A_new = saved;
+      if (rc) return rc;
+      if (hc->irls_last > 0) s->irls_guess = std::min(tmax + 1, hc->irls_last + 1);
     } else {
       int mt, mp, ntask, ntiles, rps, nslab;
       if (int rc = glm_geometry(s, K, &mt, &mp, &ntask, &ntiles, &rps, &nslab)) return rc;
@@ -2436,7 +2490,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     }
     s->grouped = s->gmax > 1;
     if (s->gmax > 16) return bail(fail(BESSX_ERR_UNSUPPORTED, "group sizes above 16 are not built"));
-    if (s->grouped && s->model_type == 4) return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 is not built yet"));
+    if (s->grouped && s->model_type == 4 && !(pb->algorithm_type == 2 || pb->algorithm_type == 3))
+      return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 exists only for algorithm_type 2 / 3 (the "
+                                              "group branch of GroupPdasCox::get_A, src/Algorithm.h:1497-1568)"));
   }
   if (!x_ready) HIPT(dmalloc(&s->X, (size_t)ld * p));
   HIPT(dmalloc(&s->y, (size_t)ld));
@@ -2578,6 +2634,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   if (s->model_type == 4) {
     const char *ev = std::getenv("BESSX_COX_SCORE");
     s->cox.one_pass = !(ev && std::string(ev) == "2pass");
+    s->cox.need_uv = s->grouped ? 1 : 0;
   }
   HIPT(dmalloc(&q, part_elems(s)));
   s->part_rs.push_back(q);
@@ -2618,6 +2675,11 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(dmalloc(&s->gcols_new, (size_t)s->capA));
     HIPT(dmalloc(&s->mblk, (size_t)s->goff_h[s->N]));
     HIPT(dmalloc(&s->dcol, (size_t)p));
+    if (s->model_type == 4) {
+      HIPT(dmalloc(&s->mblk2, (size_t)s->goff_h[s->N]));
+      HIPT(dmalloc(&s->allcols, (size_t)p));
+      HIPT(launch_iota(s->allcols, p, s->st));
+    }
     HIPT(dmalloc(&q, (size_t)s->goff_h[s->N]));
     s->gxtx_rs.push_back(q);
   }

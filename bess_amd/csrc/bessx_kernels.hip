@@ -2118,9 +2118,12 @@ __global__ void __launch_bounds__(256) k_group_moments(const double *__restrict_
                                                        const double *__restrict__ w1, const double *__restrict__ w2,
                                                        const int *__restrict__ gidx, const int *__restrict__ gsz,
                                                        const int *__restrict__ goff, double *__restrict__ mblk,
-                                                       double *__restrict__ dcol) {
+                                                       double *__restrict__ dcol, int cshift) {
+  // cshift: X holds a panel of columns starting at global column cshift (the Cox group branch forms the suffix
+  // sums of a panel at a time); mblk / dcol stay indexed by the global group / column
   __shared__ double sm[4];
   const int g = blockIdx.x, s = gsz[g], c0 = gidx[g];
+  const int cx = c0 - cshift;
   double acc[S * (S + 1) / 2], dacc[S];
 #pragma unroll
   for (int q = 0; q < S * (S + 1) / 2; q++) acc[q] = 0.0;
@@ -2129,7 +2132,7 @@ __global__ void __launch_bounds__(256) k_group_moments(const double *__restrict_
   for (int i = threadIdx.x; i < n; i += 256) {
     double xv[S];
 #pragma unroll
-    for (int u = 0; u < S; u++) xv[u] = u < s ? X[(size_t)(c0 + u) * ld + i] : 0.0;
+    for (int u = 0; u < S; u++) xv[u] = u < s ? X[(size_t)(cx + u) * ld + i] : 0.0;
     const double a = w1 ? w1[i] : 1.0, b = w2 ? w2[i] : 0.0;
     int q = 0;
 #pragma unroll
@@ -2997,7 +3000,7 @@ __global__ void __launch_bounds__(SC_T) k_cox_M_tot(const double *__restrict__ X
                                                     const int *__restrict__ A_new, const double *__restrict__ THF,
                                                     const double *__restrict__ VG, double *__restrict__ scr,
                                                     const FitCtrl *__restrict__ ctrl, int slot, int t) {
-  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  if (ctrl != nullptr && COX_NEWTON_GATE(ctrl, slot, t)) return;  // ctrl == nullptr: ungated (group branch of get_A)
   __shared__ double sm[4];
   const int a = blockIdx.y, k = gridDim.y, nb = gridDim.x;
   const double *x = X + (size_t)A_new[a] * ld;
@@ -3027,7 +3030,7 @@ __global__ void __launch_bounds__(SC_T) k_cox_M_apply(const double *__restrict__
                                                       double lambda, const double *__restrict__ scr,
                                                       double *__restrict__ M, double *__restrict__ g,
                                                       const FitCtrl *__restrict__ ctrl, int slot, int t) {
-  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  if (ctrl != nullptr && COX_NEWTON_GATE(ctrl, slot, t)) return;
   __shared__ double sm[4];
   const int a = blockIdx.y, k = gridDim.y, nb = gridDim.x;
   const double *x = X + (size_t)A_new[a] * ld;
@@ -4530,7 +4533,7 @@ hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, co
   hipLaunchKernelGGL(k_cox_loss, dim3(nblk), dim3(128), 0, st, ld, n, y, w, mask, ctrl, when, (const double *)cb.E,
                      (const double *)cb.SALL, (const double *)cb.STEST, stats);
   LAUNCH_CHECK();
-  if (cb.one_pass) {  // vectors of the one-pass score (k_cox_score1p)
+  if (cb.one_pass || cb.need_uv) {  // vectors of the one-pass score (k_cox_score1p) / of the group branch of get_A
     const int nb2 = (int)((ld + 255) / 256);
     hipLaunchKernelGGL(k_cox_c1, dim3(nb2), dim3(256), 0, st, ld, (const double *)cb.EW, (const double *)cb.RS0, cb.CV,
                        ctrl, when);  // CV holds ew / S0 until k_cox_uv overwrites it
@@ -4667,9 +4670,10 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
 
 hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const double *w1, const double *w2, int N,
                                 const int *gidx, const int *gsz, const int *goff, double *mblk, double *dcol,
-                                hipStream_t st) {
-#define GM_GO(S) \
-  hipLaunchKernelGGL(k_group_moments<S>, dim3(N), dim3(256), 0, st, X, ld, n, w1, w2, gidx, gsz, goff, mblk, dcol)
+                                hipStream_t st, int cshift) {
+#define GM_GO(S)                                                                                                  \
+  hipLaunchKernelGGL(k_group_moments<S>, dim3(N), dim3(256), 0, st, X, ld, n, w1, w2, gidx, gsz, goff, mblk, dcol, \
+                     cshift)
   if (smax <= 2)
     GM_GO(2);
   else if (smax <= 4)
@@ -4679,6 +4683,59 @@ hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const
   else
     GM_GO(16);
 #undef GM_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+__global__ void __launch_bounds__(256) k_iota(int *__restrict__ a, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = i;
+}
+__global__ void __launch_bounds__(256) k_vec_sub(double *__restrict__ a, const double *__restrict__ b, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] -= b[i];
+}
+hipError_t launch_iota(int *a, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, st, a, n);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// GroupPdasCox::get_A, group branch (src/Algorithm.h:1497-1568) without the n x n Hessian.  With theta = w exp(eta),
+// S0 its suffix sums, c2_i = sum_{k<=i} y_k w_k / S0_k:  h = diag(c2 theta) - [c3(min(i,j)) theta_i theta_j], and
+// sum_{i,j} x_i c3(min(i,j)) theta_i theta_j x_j^T = sum_m (y_m w_m / S0_m^2) S1(m) S1(m)^T with S1 the suffix sums
+// of theta x (exchange of the order of summation, as in the singleton branch).  So per group
+//   X_g^T h X_g = X_g^T diag(u) X_g - M_g^T diag(y w) M_g,   u = theta c2,  M = S1 / S0,
+//   d = X^T (y w - u) - 2 lambda beta   (:1547-1548),
+// i.e. two passes of k_group_moments: over X with (u, y w - u), and over the suffix-sum matrix M of one panel of
+// whole groups (at most `mcols` columns) at a time with weights y w.  u and y w - u are the vectors CU and CV of the
+// one-pass score (status in {0, 1}: w [delta != 0] = w delta).
+hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxBufs cb, const int *allcols, int mcols,
+                                    int smax, int N, const int *gidx_h, const int *gsz_h, const int *gidx,
+                                    const int *gsz, const int *goff, long mblk_len, double *mblk, double *mblk2,
+                                    double *dcol, hipStream_t st) {
+  hipError_t e = launch_group_moments(smax, X, ld, n, cb.CU, cb.CV, N, gidx, gsz, goff, mblk, dcol, st, 0);
+  if (e != hipSuccess) return e;
+  const int nb = (int)((n + SC_B - 1) / SC_B);
+  for (int g0 = 0; g0 < N;) {
+    int g1 = g0, np = 0;
+    while (g1 < N && np + gsz_h[g1] <= mcols) np += gsz_h[g1++];
+    if (g1 == g0) return hipErrorInvalidValue;  // a group wider than the work space
+    const int j0 = gidx_h[g0];
+    hipLaunchKernelGGL(k_cox_M_tot, dim3(nb, np), dim3(SC_T), 0, st, X, ld, (long)n, allcols + j0,
+                       (const double *)cb.TH, (const double *)cb.VG, cb.SCR, (const FitCtrl *)nullptr, 0, 0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cox_M_apply, dim3(nb, np), dim3(SC_T), 0, st, X, ld, (long)n, allcols + j0,
+                       (const double *)cb.TH, (const double *)cb.RS0, (const double *)cb.b0, 0.0,
+                       (const double *)cb.SCR, cb.M, cb.g, (const FitCtrl *)nullptr, 0, 0);
+    LAUNCH_CHECK();
+    e = launch_group_moments(smax, cb.M, ld, n, cb.WD, nullptr, g1 - g0, gidx + g0, gsz + g0, goff + g0, mblk2, nullptr,
+                             st, j0);
+    if (e != hipSuccess) return e;
+    g0 = g1;
+  }
+  hipLaunchKernelGGL(k_vec_sub, dim3((int)((mblk_len + 255) / 256)), dim3(256), 0, st, mblk, (const double *)mblk2,
+                     mblk_len);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -82,7 +82,8 @@ typedef struct {
   int device;        /* HIP device ordinal, or -1 for the current device */
   const int *group_index; /* Data::g_index (src/Data.h:59-67): first column of every group, ascending from 0; NULL or
                              length p = every column its own group.  With groups, sparsity levels and always_select
-                             count / name GROUPS.  Group sizes up to 16; Cox needs singleton groups. */
+                             count / name GROUPS.  Group sizes up to 16; Cox with real groups needs algorithm_type 2 / 3
+                             (the group branch of GroupPdasCox::get_A, src/Algorithm.h:1497-1568). */
   int group_index_len;
   int is_screening;   /* sure independence screening before the path (screening(), src/screening.cpp:26-105; called at
                          src/bess.cpp:57-61): keep the screening_size columns with the largest squared marginal

@@ -724,6 +724,79 @@ static void cox_get_A(oalg *a, int *A) {
   free(bd);
 }
 
+/* GroupPdasCox::get_A, algorithm_type 2/3 branch, src/Algorithm.h:1497-1568: the n x n Hessian h of the negative
+ * partial log-likelihood with respect to the linear predictor is built exactly as the reference does
+ * (h(i,j) = -cum_theta3(min(i,j)) theta_i theta_j off the diagonal, cum_theta2(i) theta_i added on it), then the
+ * per-group blocks X_g^T h X_g + 2 lambda I, their square roots and the sacrifices as in the other families. */
+static void cox_get_A_group(oalg *a, int *A) {
+  const odata *d = a->d;
+  int nt = a->n_rows, p = d->p, i, j, u, v, gg, nb = d->goff[d->N];
+  double *th = (double *)malloc((size_t)nt * sizeof(double));
+  double *c1 = (double *)malloc((size_t)nt * sizeof(double));
+  double *c2 = (double *)malloc((size_t)nt * sizeof(double));
+  double *c3 = (double *)malloc((size_t)nt * sizeof(double));
+  double *g = (double *)malloc((size_t)nt * sizeof(double));
+  double *h = (double *)malloc((size_t)nt * (size_t)nt * sizeof(double));
+  double *hx = (double *)malloc((size_t)nt * sizeof(double));
+  double *dc = (double *)malloc((size_t)p * sizeof(double));
+  double *bd = (double *)malloc((size_t)d->N * sizeof(double));
+  double *mb = (double *)malloc((size_t)nb * sizeof(double));
+  lin_pred(d, a->beta, a->rows, nt, th);
+  for (i = 0; i < nt; i++) th[i] = d->w[a->rows[i]] * exp(clamp30(th[i])); /* :1512-1520 */
+  for (i = nt - 1; i >= 0; i--) c1[i] = (i == nt - 1) ? th[i] : c1[i + 1] + th[i]; /* cum_theta */
+  for (i = 0; i < nt; i++) {
+    double yw = d->y[a->rows[i]] * d->w[a->rows[i]];
+    c2[i] = yw / c1[i] + (i ? c2[i - 1] : 0.0);          /* cum_theta2, :1526-1530 */
+    c3[i] = yw / pow(c1[i], 2) + (i ? c3[i - 1] : 0.0);  /* cum_theta3, :1531-1535 */
+  }
+  for (i = 0; i < nt; i++)
+    for (j = i; j < nt; j++) { /* :1536-1545: upper triangle from row i, mirrored */
+      double val = -c3[i] * th[i] * th[j];
+      h[(size_t)i * nt + j] = val;
+      h[(size_t)j * nt + i] = val;
+    }
+  for (i = 0; i < nt; i++) h[(size_t)i * nt + i] += c2[i] * th[i]; /* :1546 */
+  for (i = 0; i < nt; i++) g[i] = d->w[a->rows[i]] * d->y[a->rows[i]] - c2[i] * th[i]; /* :1547 */
+  for (j = 0; j < p; j++) {
+    const double *c = d->x + (size_t)j * (size_t)d->n;
+    double s1 = 0.0;
+    for (i = 0; i < nt; i++) s1 += c[a->rows[i]] * g[i];
+    dc[j] = s1 - 2.0 * a->lambda * a->beta[j]; /* :1548 */
+  }
+  for (gg = 0; gg < d->N; gg++) { /* :1549-1558 */
+    int sz = d->gsz[gg], c0 = d->gidx[gg];
+    for (v = 0; v < sz; v++) {
+      const double *cv = d->x + (size_t)(c0 + v) * (size_t)d->n;
+      for (i = 0; i < nt; i++) { /* hx = h x_v */
+        double s2 = 0.0;
+        const double *hr = h + (size_t)i * nt;
+        for (j = 0; j < nt; j++) s2 += hr[j] * cv[a->rows[j]];
+        hx[i] = s2;
+      }
+      for (u = v; u < sz; u++) {
+        const double *cu = d->x + (size_t)(c0 + u) * (size_t)d->n;
+        double s2 = 0.0;
+        for (i = 0; i < nt; i++) s2 += cu[a->rows[i]] * hx[i];
+        if (u == v) s2 += 2.0 * a->lambda;
+        mb[d->goff[gg] + (size_t)v * sz + u] = s2;
+        mb[d->goff[gg] + (size_t)u * sz + v] = s2;
+      }
+    }
+  }
+  group_scores(a, mb, dc, bd);
+  select_top(a, bd, A);
+  free(th);
+  free(c1);
+  free(c2);
+  free(c3);
+  free(g);
+  free(h);
+  free(hx);
+  free(dc);
+  free(bd);
+  free(mb);
+}
+
 /* Algorithm::fit, src/Algorithm.h:113-171 */
 static void alg_fit(oalg *a) {
   int T0 = a->T0, p = a->d->p, i, ll, l, K;
@@ -742,6 +815,8 @@ static void alg_fit(oalg *a) {
       logistic_get_A(a, A);
     else if (a->model_type == 3)
       poisson_get_A(a, A);
+    else if (a->algorithm_type == 2 || a->algorithm_type == 3)
+      cox_get_A_group(a, A);
     else
       cox_get_A(a, A);
     K = expand_groups(a->d, A, T0, cols); /* find_ind + X_seg, :155-156 */
@@ -1612,7 +1687,8 @@ int bess_oracle_run3(const double *x, int n, int p, const double *y, const doubl
   if (g_len < 1 || g_len > p || (g_index != NULL && g_index[0] != 0)) return 4;
   for (i = 1; g_index != NULL && i < g_len; i++)
     if (g_index[i] <= g_index[i - 1] || g_index[i] >= p) return 4;
-  if (model_type == 4 && g_len != p) return 4; /* Cox with groups of size > 1: not restated */
+  if (model_type == 4 && g_len != p && !(algorithm_type == 2 || algorithm_type == 3))
+    return 4; /* Cox with real groups exists only in the group branch of get_A (algorithm_type 2 / 3) */
   if (path_type == 1) {
     for (i = 0; i < sequence_len; i++)
       if (sequence[i] < 0 || sequence[i] > g_len) return 3;

@@ -41,7 +41,8 @@ int bess_oracle_run2(const double *x, int n, int p, const double *y, const doubl
 
 /* As bess_oracle_run2 plus the group structure (Data::g_index, src/Data.h:59-67): g_index[g] = first column of
  * group g, NULL = singleton groups.  Sparsity levels and always_select then count / name GROUPS; the trace stores
- * the expanded column list of every iteration.  Cox with groups of size > 1 is not restated (returns 4). */
+ * the expanded column list of every iteration.  Cox takes the group branch of its get_A (src/Algorithm.h:1497-1568,
+ * the explicit n x n Hessian: small n only) when algorithm_type is 2 or 3, like the reference. */
 int bess_oracle_run3(const double *x, int n, int p, const double *y, const double *weight, int data_type,
                      int is_normal, int algorithm_type, int model_type, int max_iter, int path_type,
                      int is_warm_start, int ic_type, int is_cv, int K, const int *cv_fold_id, const int *sequence,

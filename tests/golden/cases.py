@@ -57,6 +57,25 @@ def group_data(n=500, p=60, seed=7):
     return X, y, yb, yp, gi
 
 
+def cox_group_data(n=400, p=54, seed=17):
+    """Survival data (rows sorted by time, y = status) with 18 groups of sizes 1..6; three groups carry signal."""
+    rng = np.random.default_rng(seed)
+    gi = np.array([0, 1, 4, 6, 10, 11, 15, 20, 21, 25, 30, 31, 36, 40, 44, 46, 50, 51])
+    X = rng.standard_normal((n, p))
+    for g in range(len(gi)):
+        lo, hi = gi[g], (gi[g + 1] if g + 1 < len(gi) else p)
+        X[:, lo:hi] += 0.4 * rng.standard_normal((n, 1))
+    beta = np.zeros(p)
+    beta[1:4] = [0.8, -0.6, 0.5]
+    beta[15:20] = 0.4
+    beta[36:40] = [-0.7, 0.5, 0.5, -0.4]
+    time = np.power(-np.log(rng.uniform(size=n)) / np.exp(X @ beta), 0.5)
+    ctime = np.quantile(time, 0.7) * 2.0 * rng.uniform(size=n)
+    status = (time < ctime).astype(float)
+    order = np.argsort(np.minimum(time, ctime), kind="stable")
+    return np.ascontiguousarray(X[order]), status[order], gi
+
+
 def all_cases():
     S = _synth()
     c = {}
@@ -76,6 +95,13 @@ def all_cases():
     c["grp_poisson_seq"] = (Xg, ypg, dict(G, data_type=2, model_type=3, ic_type=3, sequence=np.arange(1, 8)))
     c["grp_lm_powell"] = (Xg, yg, dict(algorithm_type=3, g_index=gi, ic_type=3, path_type=3, s_min=1, s_max=8,
                                        lambda_min=0.01, lambda_max=5.0, nlambda=8, powell_path=2))
+    # Cox with groups: the group branch of GroupPdasCox::get_A (algorithm_type 2 / 3, src/Algorithm.h:1497-1568)
+    Xcg, stg, gic = cox_group_data()
+    GC = dict(data_type=3, model_type=4, algorithm_type=2, g_index=gic)
+    c["grp_cox_seq"] = (Xcg, stg, dict(GC, ic_type=3, sequence=np.arange(1, 8)))
+    c["grp_cox_cv"] = (Xcg, stg, dict(GC, is_cv=True, K=4, cv_fold_id=S.make_cv_folds(Xcg.shape[0], 4),
+                                      sequence=np.arange(1, 6)))
+    c["grp_cox_l0l2"] = (Xcg, stg, dict(GC, algorithm_type=3, ic_type=4, sequence=np.arange(1, 5), lambda_seq=[0.0, 0.05]))
     Xp, yp = prostate()
     c["prostate_seq_gic"] = (Xp, yp, dict(ic_type=3, sequence=np.arange(1, 9)))
     c["prostate_one_k3"] = (Xp, yp, dict(ic_type=3, sequence=[3]))

@@ -61,3 +61,44 @@ def test_cox_score_pass_forms_agree(gpu, monkeypatch):
         assert a["n_pdas_iters"] == b["n_pdas_iters"]
         np.testing.assert_allclose(a["cand_beta"], b["cand_beta"], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-10)
+
+
+# ---- Cox with groups of size > 1: the group branch of GroupPdasCox::get_A (algorithm_type 2 / 3) --------------
+def _cox_groups(seed, n=500, p=64):
+    X, _, status, _, _ = synth.make_cox(n, p, 5, seed=seed)
+    rng = np.random.default_rng(seed)
+    cuts = np.sort(rng.choice(np.arange(1, p), 19, replace=False))
+    return X, status, np.concatenate([[0], cuts]).astype(np.int32)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("seq", dict(algorithm_type=2, ic_type=3, sequence=np.arange(1, 8))),
+    ("l0l2", dict(algorithm_type=3, ic_type=4, sequence=np.arange(1, 5), lambda_seq=[0.0, 0.05])),
+    ("gs", dict(algorithm_type=2, ic_type=3, path_type=2, s_min=1, s_max=10)),
+    ("nowarm", dict(algorithm_type=2, ic_type=2, sequence=np.arange(1, 6), is_warm_start=False)),
+])
+def test_cox_group_selection(gpu, name, kw):
+    """X_g^T h X_g formed from two weighted group moments (over X and over the suffix-sum matrix) instead of the
+    reference's n x n Hessian: same groups at every PDAS iteration as the oracle, which builds the Hessian."""
+    X, status, gi = _cox_groups(31)
+    check(gpu, X, status, dict(COX, g_index=gi, **kw), "cox groups " + name)
+
+
+def test_cox_group_selection_cv_weights_and_wide_panels(gpu):
+    X, status, gi = _cox_groups(32)
+    check(gpu, X, status, dict(COX, algorithm_type=2, g_index=gi, is_cv=True, K=4, cv_fold_id=synth.make_cv_folds(500, 4),
+                               sequence=np.arange(1, 5)), "cox groups cv")
+    w = np.random.default_rng(2).uniform(0.5, 2, 500)
+    check(gpu, X, status, dict(COX, algorithm_type=2, g_index=gi, ic_type=3, sequence=np.arange(1, 6), weight=w),
+          "cox groups weighted")
+    # more than 256 columns: the suffix-sum matrix is formed one panel of whole groups at a time
+    Xw, _, stw, _, _ = synth.make_cox(400, 700, 6, seed=33)
+    giw = np.arange(0, 700, 5).astype(np.int32)
+    check(gpu, Xw, stw, dict(COX, algorithm_type=2, g_index=giw, ic_type=3, sequence=np.arange(1, 6)), "cox groups wide")
+
+
+def test_cox_groups_need_the_group_algorithm(gpu):
+    X, status, gi = _cox_groups(34)
+    with pytest.raises(gpu.BessxError) as e:
+        gpu.Session(X, status, data_type=3, model_type=4, algorithm_type=1, g_index=gi)
+    assert e.value.code == 3

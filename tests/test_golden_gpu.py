@@ -99,6 +99,23 @@ def test_group_estimator_class(gpu):
     assert abs(m.ic[0] - want["ic"]) < 1e-7 * abs(want["ic"])
 
 
+def test_group_cox_estimator_class(gpu):
+    """GroupPdasCox: y = (time, status); the wrapper sorts the rows by time (python/bess/linear.py:257-263)."""
+    import bess_amd
+    X, status, gi = cases.cox_group_data()
+    want = cases.load_golden("grp_cox_seq")
+    labels = np.zeros(X.shape[1], dtype=int)
+    for g, lo in enumerate(gi):
+        labels[lo:] = g
+    n = X.shape[0]
+    perm = np.random.default_rng(3).permutation(n)  # hand the rows over unsorted, with their times
+    y = np.column_stack([np.arange(n, dtype=float), status])[perm]
+    m = bess_amd.GroupPdasCox(path_type="seq", sequence=list(range(1, 8)), ic_type="gic")
+    m.fit(X[perm], y, group=labels)
+    np.testing.assert_allclose(m.beta, want["beta"], rtol=1e-6, atol=1e-12)
+    assert abs(m.ic[0] - want["ic"]) < 1e-7 * abs(want["ic"])
+
+
 def test_unsupported_and_invalid_requests_fail_loudly(gpu):
     X, y = cases.prostate()
     a = list(_pywrap_args(X, y))

@@ -33,3 +33,19 @@ def test_glm_random(seed):
     Xc, _, st, _, _ = synth.make_cox(400, 60, 4, seed=seed)
     kw = dict(data_type=3, model_type=4, ic_type=3, sequence=np.arange(1, 8))
     assert_same_trace(P.trace(Xc, st, **kw), R.trace(Xc, st, **kw), beta_rtol=1e-8, what="cox %d" % seed)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_cox_group_branch_random(seed):
+    """GroupPdasCox::get_A for algorithm_type 2 / 3 (explicit n x n Hessian in both the reference and the oracle)."""
+    rng = np.random.default_rng(seed)
+    X, _, st, _, _ = synth.make_cox(300, 48, 4, seed=seed)
+    cuts = np.sort(rng.choice(np.arange(1, 48), 15, replace=False))
+    gi = np.concatenate([[0], cuts]).astype(np.int32)
+    for kw in (dict(algorithm_type=2, g_index=gi, ic_type=3, sequence=np.arange(1, 6)),
+               dict(algorithm_type=3, g_index=gi, ic_type=4, sequence=np.arange(1, 4), lambda_seq=[0.0, 0.1]),
+               dict(algorithm_type=2, ic_type=3, sequence=np.arange(1, 6)),  # singleton groups, group formula
+               dict(algorithm_type=2, g_index=gi, is_cv=True, K=3, cv_fold_id=synth.make_cv_folds(300, 3, seed=seed),
+                    sequence=np.arange(1, 4))):
+        kw = dict(kw, data_type=3, model_type=4)
+        assert_same_trace(P.trace(X, st, **kw), R.trace(X, st, **kw), beta_rtol=1e-8, what="cox groups %d" % seed)
