@@ -100,6 +100,9 @@ hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand,
                        hipStream_t st, const int *run_flag = nullptr, const TopkNeed *need = nullptr);
 bool topk_supported(int len, int k);
 void topk_set_variant(int v);  // test / benchmark hook: 0 = bit-by-bit search, 1 = radix search (default)
+void gram_set_variant(int v);  // 1 = LDS-staged Gram kernel where it applies (default), 0 = k_gram throughout
+bool gram_lds_applies(int ntiles, int tile_base);
+hipError_t gram_lds_prepare();
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
                        double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st, int tile_base = 0);

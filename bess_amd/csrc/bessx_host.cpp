@@ -495,6 +495,21 @@ static int gram_tasks_for(bessx_session *s, int mt, const GramTask **tasks, int 
 }
 
 static void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab, int ntiles = 0) {
+  if (ntiles > 0 && gram_lds_applies(ntiles, 0) && s->ld >= 64) {
+    // LDS-staged kernel: one block per slab computes every tile; slabs are whole 64-row chunks, about one block
+    // (4 or 8 waves) per CU
+    // (4-wave instance, up to 8 tile rows: two blocks fit a CU; measured 512 >= 256 > 128 slabs on configs[2])
+    static const long want = [] {
+      const char *ev = std::getenv("BESSX_GRAM_SLABS");
+      return ev ? std::max(1L, std::atol(ev)) : 0L;
+    }();
+    long ns = std::min<long>(want > 0 ? want : (ntiles <= 36 ? 512 : 256), s->ld / 64);
+    if (s->gpart_elems > 0) ns = std::max<long>(1, std::min<long>(ns, (long)(s->gpart_elems / ((size_t)ntiles * 256))));
+    long rps = ((s->ld + ns - 1) / ns + 63) / 64 * 64;
+    *rows_per_slab = (int)rps;
+    *nslab = (int)((s->ld + rps - 1) / rps);
+    return;
+  }
   long target = 4096;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2 waves x 2
   long ns = std::max<long>(1, target / std::max(ntask, 1));
   ns = std::min<long>(ns, 192);  // more slabs only make the fixed-order reduction of the partials longer
@@ -2354,6 +2369,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     int lo = 0, hi = 0;
     HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
+    HIPT(gram_lds_prepare());
+    if (const char *ev = std::getenv("BESSX_GRAM")) gram_set_variant(std::string(ev) == "direct" ? 0 : 1);
   }
   const int n = pb->n;
   s->n = n;
@@ -3231,6 +3248,8 @@ int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m,
     if (cols[i] < 0 || cols[i] >= p) return fail(BESSX_ERR_ARG, "op_gram: column index out of range");
   Scratch sc;
   const int U = 1;
+  HIPX(gram_lds_prepare());
+  if (const char *ev = std::getenv("BESSX_GRAM")) gram_set_variant(std::string(ev) == "direct" ? 0 : 1);
   double *dX, *dw = nullptr, *daux, *gpart, *Gt;
   long ldd;
   if (int rc = upload_padded(sc, x, n, p, ld, U, &dX, &ldd)) return rc;

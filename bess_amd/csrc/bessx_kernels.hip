@@ -649,11 +649,33 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ X, const do
   d4 acc[NJ];
 #pragma unroll
   for (int jj = 0; jj < NJ; jj++) acc[jj] = d4{0.0, 0.0, 0.0, 0.0};
+  // Software pipeline: the loads of the next 16 rows are issued before the MFMAs of the current ones.  A slab is a
+  // few hundred rows and a wave often has its SIMD to itself, so nothing else hides the load latency.
+  d2 a0, a1, w0 = d2{1.0, 1.0}, w1 = d2{1.0, 1.0}, b0[NJ], b1[NJ];
+  auto load = [&](long r, d2 &xa0, d2 &xa1, d2 &xw0, d2 &xw1, d2 (&xb0)[NJ], d2 (&xb1)[NJ]) {
+    xa0 = *reinterpret_cast<const d2 *>(pa + r);
+    xa1 = *reinterpret_cast<const d2 *>(pa + r + 2);
+    if (WEIGHTED) {
+      xw0 = *reinterpret_cast<const d2 *>(w + r + 4 * q);
+      xw1 = *reinterpret_cast<const d2 *>(w + r + 4 * q + 2);
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+      xb0[jj] = *reinterpret_cast<const d2 *>(pb[jj] + r);
+      xb1[jj] = *reinterpret_cast<const d2 *>(pb[jj] + r + 2);
+    }
+  };
+  if (r_begin < r_end) load(r_begin, a0, a1, w0, w1, b0, b1);
   for (long r = r_begin; r < r_end; r += 16) {
-    d2 a0 = *reinterpret_cast<const d2 *>(pa + r), a1 = *reinterpret_cast<const d2 *>(pa + r + 2);
+    d2 na0 = a0, na1 = a1, nw0 = w0, nw1 = w1, nb0[NJ], nb1[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+      nb0[jj] = b0[jj];
+      nb1[jj] = b1[jj];
+    }
+    if (r + 16 < r_end) load(r + 16, na0, na1, nw0, nw1, nb0, nb1);
     double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
     if (WEIGHTED) {
-      d2 w0 = *reinterpret_cast<const d2 *>(w + r + 4 * q), w1 = *reinterpret_cast<const d2 *>(w + r + 4 * q + 2);
       ax *= w0.x;
       ay *= w0.y;
       az *= w1.x;
@@ -661,12 +683,19 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ X, const do
     }
 #pragma unroll
     for (int jj = 0; jj < NJ; jj++) {
-      d2 b0 = *reinterpret_cast<const d2 *>(pb[jj] + r), b1 = *reinterpret_cast<const d2 *>(pb[jj] + r + 2);
-      double bx = b0.x, by = b0.y, bz = b1.x, bw = b1.y;
-      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc[jj], 0, 0, 0);
-      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc[jj], 0, 0, 0);
-      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, bz, acc[jj], 0, 0, 0);
-      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, bw, acc[jj], 0, 0, 0);
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0[jj].x, acc[jj], 0, 0, 0);
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b0[jj].y, acc[jj], 0, 0, 0);
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b1[jj].x, acc[jj], 0, 0, 0);
+      acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b1[jj].y, acc[jj], 0, 0, 0);
+    }
+    a0 = na0;
+    a1 = na1;
+    w0 = nw0;
+    w1 = nw1;
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+      b0[jj] = nb0[jj];
+      b1[jj] = nb1[jj];
     }
   }
 #pragma unroll
@@ -706,6 +735,117 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
 
 // Sum the row-slab partials: Gt[t][e] = sum_s part[s][t][e].  A block owns 16 consecutive elements; its 16 thread
 // groups each add every 16th slab, then the 16 group sums are added in group order (fixed tree).
+// K6, LDS-staged form (full lower triangle, mt <= 12).  k_gram's waves each read "their" tile row plus a run of
+// other tile columns straight from memory, so a column tile of X_A is fetched once per task that touches it:
+// (tasks + tiles) / mt times, 41 / 7 at k = 100 -- from MALL / HBM, since X_A (90 MB at n = 100k, k = 100) is far
+// beyond L2.  Here one block owns a row slab and ALL tiles: 64 rows of every active column are staged once into LDS
+// (coalesced 16-byte loads, next chunk in flight while the current one is multiplied), the waves read their MFMA
+// operands from LDS.  Traffic = the active columns once; the rest is MFMA time.  Same output layout as k_gram.
+__device__ __forceinline__ void tile_of(int t, int &I, int &J);
+constexpr int GL_RB = 64, GL_LD = GL_RB + 2;
+template <int NW, int TPW, int NPASS, bool WEIGHTED>
+__global__ void __launch_bounds__(64 * NW) k_gram_lds(const double *__restrict__ X, const double *__restrict__ aux,
+                                                      long ld, const int *__restrict__ cols,
+                                                      const double *__restrict__ w, int rows_per_slab, int nslab,
+                                                      int mt, double *__restrict__ part, int ntiles,
+                                                      const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+  if (ctrl != nullptr) {
+    if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev) return;
+    if ((gate_mode == 1 || gate_mode == 2) && ctrl->irls_done) return;
+    if (gate_mode == 3 && !ctrl->gram_full) return;
+    if (gate_mode == 4 && ctrl->gram_full) return;
+  }
+  extern __shared__ double smem[];  // [mp][GL_LD], then the 64 weights of the chunk
+  constexpr int NT = 64 * NW, CPP = NT / 32;  // columns staged per pass
+  const int mp = mt * 16;
+  double *wch = smem + (size_t)mp * GL_LD;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ru = tid & 31, cb = tid >> 5;
+  const int slab = blockIdx.x;
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + GL_RB - 1) / GL_RB);
+  const double *src[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; i++) {
+    const int col = i * CPP + cb;
+    src[i] = gram_col(X, aux, ld, col < mp ? cols[col] : cols[0]) + 2 * ru;
+  }
+  d2 st[NPASS], wst = d2{0.0, 0.0};
+  auto load = [&](long r0) {
+    const bool in = r0 + 2 * ru < r_end;  // slabs end on multiples of 16 rows: a row pair is in or out as a whole
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      st[i] = d2{0.0, 0.0};
+      if (in && i * CPP + cb < mp) st[i] = *reinterpret_cast<const d2 *>(src[i] + r0);
+    }
+    if (WEIGHTED && tid < 32) wst = in ? *reinterpret_cast<const d2 *>(w + r0 + 2 * ru) : d2{0.0, 0.0};
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int col = i * CPP + cb;
+      if (col < mp) *reinterpret_cast<d2 *>(smem + (size_t)col * GL_LD + 2 * ru) = st[i];
+    }
+    if (WEIGHTED && tid < 32) *reinterpret_cast<d2 *>(wch + 2 * ru) = wst;
+  };
+  int tI[TPW], tJ[TPW];
+  d4 acc[TPW];
+#pragma unroll
+  for (int ts = 0; ts < TPW; ts++) {
+    const int t = wv + NW * ts;
+    int I = -1, J = -1;
+    if (t < ntiles) tile_of(t, I, J);
+    tI[ts] = __builtin_amdgcn_readfirstlane(I);
+    tJ[ts] = __builtin_amdgcn_readfirstlane(J);
+    acc[ts] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+  auto compute = [&]() {
+#pragma unroll
+    for (int ts = 0; ts < TPW; ts++) {
+      if (tI[ts] >= 0) {  // wave-uniform
+        const double *pa = smem + (size_t)(tI[ts] * 16 + c) * GL_LD + 4 * q;
+        const double *pb = smem + (size_t)(tJ[ts] * 16 + c) * GL_LD + 4 * q;
+#pragma unroll
+        for (int sx = 0; sx < GL_RB / 16; sx++) {
+          const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * sx), a1 = *reinterpret_cast<const d2 *>(pa + 16 * sx + 2);
+          const d2 b0 = *reinterpret_cast<const d2 *>(pb + 16 * sx), b1 = *reinterpret_cast<const d2 *>(pb + 16 * sx + 2);
+          double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
+          if (WEIGHTED) {
+            const d2 w0 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q);
+            const d2 w1 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q + 2);
+            ax *= w0.x;
+            ay *= w0.y;
+            az *= w1.x;
+            aw *= w1.y;
+          }
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0.x, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b0.y, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b1.x, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b1.y, acc[ts], 0, 0, 0);
+        }
+      }
+    }
+  };
+  if (nchunk > 0) {
+    load(r_begin);
+    store();
+    if (nchunk > 1) load(r_begin + GL_RB);
+    __syncthreads();
+    for (int k = 0; k < nchunk; k++) {
+      compute();
+      __syncthreads();
+      if (k + 1 < nchunk) store();
+      __syncthreads();
+      if (k + 2 < nchunk) load(r_begin + (long)(k + 2) * GL_RB);
+    }
+  }
+  double *out = part + (size_t)slab * ntiles * 256;
+#pragma unroll
+  for (int ts = 0; ts < TPW; ts++)
+    if (tI[ts] >= 0) *reinterpret_cast<d4 *>(out + (size_t)(wv + NW * ts) * 256 + lane * 4) = acc[ts];
+}
+
 __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ part, int nslab, int ntiles,
                                                      double *__restrict__ Gt, const FitCtrl *__restrict__ ctrl,
                                                      int slot, int gate_mode) {
@@ -4252,9 +4392,54 @@ bool topk_supported(int len, int k) {
   return k <= last && (long)nchunk * k <= chunk;
 }
 
+static int g_gram_variant = 1;  // 1 = LDS-staged kernel where it applies (default), 0 = k_gram throughout
+void gram_set_variant(int v) { g_gram_variant = v; }
+// the LDS-staged kernel forms whole lower triangles of at most 12 tile rows (the callers size the slabs for it:
+// gram_lds_slabs())
+bool gram_lds_applies(int ntiles, int tile_base) {
+  return g_gram_variant == 1 && tile_base == 0 && ntiles <= 12 * 13 / 2;
+}
+hipError_t gram_lds_prepare() {
+  // dynamic LDS beyond 64 KB has to be requested once per kernel instance
+  hipError_t e = hipSuccess;
+  const int big = (12 * 16 * GL_LD + GL_RB) * (int)sizeof(double);
+#define GL_ATTR(K) \
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+  GL_ATTR((k_gram_lds<4, 9, 16, true>));
+  GL_ATTR((k_gram_lds<4, 9, 16, false>));
+  GL_ATTR((k_gram_lds<8, 10, 12, true>));
+  GL_ATTR((k_gram_lds<8, 10, 12, false>));
+#undef GL_ATTR
+  return e;
+}
+
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
                        double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st, int tile_base) {
+  if (gram_lds_applies(ntiles, tile_base)) {
+    int mt = 1;
+    while (mt * (mt + 1) / 2 < ntiles) mt++;
+    const size_t lds = ((size_t)mt * 16 * GL_LD + GL_RB) * sizeof(double);
+#define GL_GO(NW_, TPW_, NP_)                                                                                       \
+  do {                                                                                                              \
+    if (w)                                                                                                          \
+      hipLaunchKernelGGL((k_gram_lds<NW_, TPW_, NP_, true>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld, cols, \
+                         w, rows_per_slab, nslab, mt, part, ntiles, ctrl, slot, gate_mode);                         \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_gram_lds<NW_, TPW_, NP_, false>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld,      \
+                         cols, w, rows_per_slab, nslab, mt, part, ntiles, ctrl, slot, gate_mode);                   \
+  } while (0)
+    if (mt <= 8)
+      GL_GO(4, 9, 16);
+    else
+      GL_GO(8, 10, 12);
+#undef GL_GO
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 15) / 16), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
+                       slot, gate_mode);
+    LAUNCH_CHECK();
+    return hipSuccess;
+  }
   long nwaves = (long)ntask * nslab;
   int nblk = (int)((nwaves + 3) / 4);
   if (w)
