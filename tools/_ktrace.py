@@ -24,3 +24,13 @@ for (k,t),(k2,t2) in zip(ev,ev[1:]):
 for k,v in sorted(tot.items(),key=lambda x:-x[1]): print("%-10s %5d launches  %8.3f ms  avg %6.2f us"%(names.get(k,k),cnt[k],v/1e3,v/cnt[k]))
 mid=n//2
 for (k,t),(k2,t2) in list(zip(ev,ev[1:]))[mid:mid+24]: print("%-10s %7.2f us"%(names.get(k,k),t2-t))
+# durations of the launch that follows a repeated-set selection (the publishing solve kernel): 8-9 us = publish only,
+# more = the device waited for the host to queue the next fit
+seq=list(zip(ev,ev[1:]))
+pub=[]
+for i in range(1,len(seq)):
+    (k,t),(k2,t2)=seq[i]
+    (kp,tp),(_,tpe)=seq[i-1]
+    if k==2 and kp==1 and (tpe-tp)<3.0: pub.append(t2-t)
+import numpy as np
+pub=np.array(pub); print("publishing launches",len(pub),"median %.1f us"%np.median(pub),"sum %.2f ms"%(pub.sum()/1e3), "over 12us:",int((pub>12).sum()), "excess ms %.2f"%((pub[pub>12]-9).sum()/1e3))
