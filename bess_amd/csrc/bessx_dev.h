@@ -84,6 +84,7 @@ struct TopkNeed {
   int nbmm;
   const unsigned char *inA;  // membership flags of the current active set
   int inc1;                  // the scores are those on which the previous fit (one size smaller) ended: arg-max path
+  int bmm_fresh;             // ... and bmm (block maxima + their columns) comes from the k_cov_d that made them
   // fused k_fit_continue(chained): this launch opens a fit chained behind fit `cont_parent` (cont_on = 1)
   int cont_on, cont_serial, cont_parent;
   // fused commit of a repeated active set (the record-and-stop branch of k_commit): commit_on = 1

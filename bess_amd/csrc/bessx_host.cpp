@@ -177,7 +177,8 @@ struct bessx_session {
                               // 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
   double *cov_part = nullptr, *bd2 = nullptr;
   unsigned char *inA = nullptr;        // 1 for the columns of the current active set
-  double *cov_bmm = nullptr;           // per-block min / max of k_cov_d's repeated-set shortcut
+  double *cov_bmm = nullptr;           // per-block min / max of k_cov_d's repeated-set shortcut (+ arg-max columns)
+  int bmm_owner = -1;                  // row set of the k_cov_d launch that wrote cov_bmm last
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
   std::vector<std::pair<size_t, int>> cov_timed;  // (event index, first group) of the timed panel launches
@@ -785,16 +786,22 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   if (skip_d && scores_ok) {
     // the last k_cov_d of the previous fit left bd for these coefficients and this lambda
   } else if (!skip_d)  // d and the sacrifice scores in one kernel
+  {
     e = launch_cov_d(cv.G, s->p, cv.slot_of, s->xty[rs], s->A_cur, s->b_cur, s->part_rs[rs], s->beta_dense, s->xtx[rs],
                      (double)s->n_train[rs], lambda, s->always, s->bd, s->inA, s->cov_bmm, s->ctrl, slot, s->st);
-  else  // d of exactly these coefficients is in memory (previous fit of the chain); lambda may have changed
+    s->bmm_owner = rs;
+  }
+  else {  // d of exactly these coefficients is in memory (previous fit of the chain); lambda may have changed
     e = launch_score(s->part_rs[rs], nullptr, 1, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs], lambda, 0,
                      s->always, s->bd, s->ctrl, slot, s->st);
+    s->bmm_owner = -1;  // the block maxima no longer belong to the scores in bd
+  }
   // top-k, then the repeated-set test + cache lookup (parks the fit when a column of A_new is not cached) -- in the
   // same launch when the scores fit one chunk of the selection kernel
   if (e == hipSuccess && topk_can_fuse_need(s->p)) {
     TopkNeed nd = {cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, s->cov_C, cv.slot_of, cv.meta, s->cov_fcols,
-                   s->ctrl, s->A_cur, s->cov_bmm, (s->p + 31) / 32, s->inA, (slot == 1 && grow1) ? 1 : 0};
+                   s->ctrl, s->A_cur, s->cov_bmm, (s->p + 31) / 32, s->inA, (slot == 1 && grow1) ? 1 : 0,
+                   (slot == 1 && grow1 && s->bmm_owner == rs) ? 1 : 0};
     nd.cm_A_cur = s->A_cur;
     nd.cm_b_cur = s->b_cur;
     nd.cm_beta_dense = s->beta_dense;
@@ -2748,7 +2755,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         HIPT(dmalloc(&s->bd2, (size_t)p));
         HIPT(dmalloc(&s->inA, (size_t)p));
         HIPT(hipMemset(s->inA, 0, (size_t)p));
-        HIPT(dmalloc(&s->cov_bmm, (size_t)2 * ((p + 31) / 32)));
+        HIPT(dmalloc(&s->cov_bmm, (size_t)3 * ((p + 31) / 32)));
         HIPT(dmalloc(&s->cov_fcols, (size_t)s->capA + 4 * COV_R));
         HIPT(dmalloc(&s->cov_extras, (size_t)COV_R));
         TRY(alloc_cov_cache(s));

@@ -403,7 +403,21 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     PH_BEGIN();
     unsigned long long best = 0ull;
     int besti = 0x7fffffff;
-    {
+    if (nd.bmm != nullptr && nd.bmm_fresh) {
+      // the k_cov_d that produced these scores left, per block of 32 columns, the largest score outside the active
+      // set and its column: the arg-max over p scores is the arg-max over p / 32 block maxima (same total order)
+      for (int b = threadIdx.x; b < nd.nbmm; b += 1024) {
+        const double v = nd.bmm[2 * b + 1];
+        if (v >= 0.0) {
+          const unsigned long long key = score_key(v);
+          const int i = (int)nd.bmm[2 * nd.nbmm + b];
+          if (key > best || (key == best && i < besti)) {
+            best = key;
+            besti = i;
+          }
+        }
+      }
+    } else {
       // all loads first (independent), then the comparisons: a load behind a branch per element serialises
       double sc[EB];
       unsigned char ia[EB];
@@ -4152,14 +4166,21 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
   // If every score of the current active set beats every score outside it, max_k returns the same set.  Each block
   // leaves its two extremes in bmm; the selection kernel that follows combines them (min / max are exact, so the
   // order does not matter) and skips its search when the test holds.  fast_same = 1 marks bmm as fresh.
+  // (third section of bmm: the column of that largest outside score, lowest index on ties -- the arg-max selection
+  // of a fit chained one size up reads the block maxima instead of all p scores)
   if (threadIdx.x == 0) {
     double mn = DBL_MAX, mx = -1.0;
+    int mi = 0x7fffffff;
     for (int q = 0; q < 32; q++) {
       mn = fmin(mn, sm[1][q]);
-      mx = fmax(mx, sm[2][q]);
+      if (sm[2][q] > mx) {
+        mx = sm[2][q];
+        mi = blockIdx.x * 32 + q;
+      }
     }
     bmm[2 * blockIdx.x] = mn;
     bmm[2 * blockIdx.x + 1] = mx;
+    bmm[2 * gridDim.x + blockIdx.x] = (double)mi;
     if (blockIdx.x == 0) const_cast<FitCtrl *>(ctrl)->fast_same = 1;
   }
 }
