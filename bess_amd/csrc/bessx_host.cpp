@@ -495,8 +495,9 @@ static int gram_tasks_for(bessx_session *s, int mt, const GramTask **tasks, int 
   return 0;
 }
 
-static void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab, int ntiles = 0) {
-  if (ntiles > 0 && gram_lds_applies(ntiles, 0) && s->ld >= 64) {
+static void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab, int ntiles = 0,
+                          bool allow_lds = true) {
+  if (allow_lds && ntiles > 0 && gram_lds_applies(ntiles, 0) && s->ld >= 64) {
     // LDS-staged kernel: one block per slab computes every tile; slabs are whole 64-row chunks, about one block
     // (4 or 8 waves) per CU
     // (4-wave instance, up to 8 tile rows: two blocks fit a CU; measured 512 >= 256 > 128 slabs on configs[2])
@@ -590,7 +591,7 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
   const GramTask *tasks_full = nullptr;
   int ntask = 0, rps, nslab;
   if (int rc = gram_tasks_for(s, mt, &tasks_full, &ntask)) return rc;
-  gram_geometry(s, ntask, &rps, &nslab, ntiles);
+  gram_geometry(s, ntask, &rps, &nslab, ntiles, mt > 16);  // (the cached LM Gram keeps k_gram: gates 3 / 4)
   if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
   hipError_t e = hipSuccess;
   if (!skip_k1) {

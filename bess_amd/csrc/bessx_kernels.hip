@@ -749,15 +749,14 @@ __global__ void __launch_bounds__(256) k_gram(const double *__restrict__ X, cons
 
 // Sum the row-slab partials: Gt[t][e] = sum_s part[s][t][e].  A block owns 16 consecutive elements; its 16 thread
 // groups each add every 16th slab, then the 16 group sums are added in group order (fixed tree).
-// K6, LDS-staged form (full lower triangle, mt <= 12).  k_gram's waves each read "their" tile row plus a run of
+// K6, LDS-staged form (full lower triangle, mt <= 16).  k_gram's waves each read "their" tile row plus a run of
 // other tile columns straight from memory, so a column tile of X_A is fetched once per task that touches it:
 // (tasks + tiles) / mt times, 41 / 7 at k = 100 -- from MALL / HBM, since X_A (90 MB at n = 100k, k = 100) is far
 // beyond L2.  Here one block owns a row slab and ALL tiles: 64 rows of every active column are staged once into LDS
 // (coalesced 16-byte loads, next chunk in flight while the current one is multiplied), the waves read their MFMA
 // operands from LDS.  Traffic = the active columns once; the rest is MFMA time.  Same output layout as k_gram.
 __device__ __forceinline__ void tile_of(int t, int &I, int &J);
-constexpr int GL_RB = 64, GL_LD = GL_RB + 2;
-template <int NW, int TPW, int NPASS, bool WEIGHTED>
+template <int NW, int TPW, int NPASS, int GL_RB, bool WEIGHTED>
 __global__ void __launch_bounds__(64 * NW) k_gram_lds(const double *__restrict__ X, const double *__restrict__ aux,
                                                       long ld, const int *__restrict__ cols,
                                                       const double *__restrict__ w, int rows_per_slab, int nslab,
@@ -769,21 +768,27 @@ __global__ void __launch_bounds__(64 * NW) k_gram_lds(const double *__restrict__
     if (gate_mode == 3 && !ctrl->gram_full) return;
     if (gate_mode == 4 && ctrl->gram_full) return;
   }
-  extern __shared__ double smem[];  // [mp][GL_LD], then the 64 weights of the chunk
-  constexpr int NT = 64 * NW, CPP = NT / 32;  // columns staged per pass
+  extern __shared__ double smem[];  // [mp][GL_LD], then the weights of the chunk
+  constexpr int GL_LD = GL_RB + 2, TPC = GL_RB / 2;  // padded column stride; threads per column (a row pair each)
+  constexpr int NT = 64 * NW, CPP = NT / TPC;         // columns staged per pass
   const int mp = mt * 16;
   double *wch = smem + (size_t)mp * GL_LD;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ru = tid & 31, cb = tid >> 5;
+  const int ru = tid % TPC, cb = tid / TPC;
   const int slab = blockIdx.x;
   const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
   const int nchunk = (int)((r_end - r_begin + GL_RB - 1) / GL_RB);
-  const double *src[NPASS];
+  // column pointers: kept in registers, except in the largest instance where the accumulators need them (there the
+  // column index is re-read per chunk: one cached load against 64 rows of MFMA work)
+  constexpr bool PTRS = TPW <= 10;
+  const double *src[PTRS ? NPASS : 1];
+  if (PTRS) {
 #pragma unroll
-  for (int i = 0; i < NPASS; i++) {
-    const int col = i * CPP + cb;
-    src[i] = gram_col(X, aux, ld, col < mp ? cols[col] : cols[0]) + 2 * ru;
+    for (int i = 0; i < NPASS; i++) {
+      const int col = i * CPP + cb;
+      src[i] = gram_col(X, aux, ld, col < mp ? cols[col] : cols[0]) + 2 * ru;
+    }
   }
   d2 st[NPASS], wst = d2{0.0, 0.0};
   auto load = [&](long r0) {
@@ -791,9 +796,12 @@ __global__ void __launch_bounds__(64 * NW) k_gram_lds(const double *__restrict__
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
       st[i] = d2{0.0, 0.0};
-      if (in && i * CPP + cb < mp) st[i] = *reinterpret_cast<const d2 *>(src[i] + r0);
+      if (in && i * CPP + cb < mp) {
+        const double *q_ = PTRS ? src[i] : gram_col(X, aux, ld, cols[i * CPP + cb]) + 2 * ru;
+        st[i] = *reinterpret_cast<const d2 *>(q_ + r0);
+      }
     }
-    if (WEIGHTED && tid < 32) wst = in ? *reinterpret_cast<const d2 *>(w + r0 + 2 * ru) : d2{0.0, 0.0};
+    if (WEIGHTED && tid < TPC) wst = in ? *reinterpret_cast<const d2 *>(w + r0 + 2 * ru) : d2{0.0, 0.0};
   };
   auto store = [&]() {
 #pragma unroll
@@ -801,7 +809,7 @@ __global__ void __launch_bounds__(64 * NW) k_gram_lds(const double *__restrict__
       const int col = i * CPP + cb;
       if (col < mp) *reinterpret_cast<d2 *>(smem + (size_t)col * GL_LD + 2 * ru) = st[i];
     }
-    if (WEIGHTED && tid < 32) *reinterpret_cast<d2 *>(wch + 2 * ru) = wst;
+    if (WEIGHTED && tid < TPC) *reinterpret_cast<d2 *>(wch + 2 * ru) = wst;
   };
   int tI[TPW], tJ[TPW];
   d4 acc[TPW];
@@ -4415,21 +4423,23 @@ bool topk_supported(int len, int k) {
 
 static int g_gram_variant = 1;  // 1 = LDS-staged kernel where it applies (default), 0 = k_gram throughout
 void gram_set_variant(int v) { g_gram_variant = v; }
-// the LDS-staged kernel forms whole lower triangles of at most 12 tile rows (the callers size the slabs for it:
+// the LDS-staged kernel forms whole lower triangles of at most 16 tile rows (the callers size the slabs for it:
 // gram_lds_slabs())
 bool gram_lds_applies(int ntiles, int tile_base) {
-  return g_gram_variant == 1 && tile_base == 0 && ntiles <= 12 * 13 / 2;
+  return g_gram_variant == 1 && tile_base == 0 && ntiles <= 16 * 17 / 2;
 }
 hipError_t gram_lds_prepare() {
   // dynamic LDS beyond 64 KB has to be requested once per kernel instance
   hipError_t e = hipSuccess;
-  const int big = (12 * 16 * GL_LD + GL_RB) * (int)sizeof(double);
+  const int big = (12 * 16 * 66 + 64) * (int)sizeof(double);
 #define GL_ATTR(K) \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
-  GL_ATTR((k_gram_lds<4, 9, 16, true>));
-  GL_ATTR((k_gram_lds<4, 9, 16, false>));
-  GL_ATTR((k_gram_lds<8, 10, 12, true>));
-  GL_ATTR((k_gram_lds<8, 10, 12, false>));
+  GL_ATTR((k_gram_lds<4, 9, 16, 64, true>));
+  GL_ATTR((k_gram_lds<4, 9, 16, 64, false>));
+  GL_ATTR((k_gram_lds<8, 10, 12, 64, true>));
+  GL_ATTR((k_gram_lds<8, 10, 12, 64, false>));
+  GL_ATTR((k_gram_lds<8, 17, 8, 32, true>));
+  GL_ATTR((k_gram_lds<8, 17, 8, 32, false>));
 #undef GL_ATTR
   return e;
 }
@@ -4437,23 +4447,27 @@ hipError_t gram_lds_prepare() {
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
                        double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st, int tile_base) {
-  if (gram_lds_applies(ntiles, tile_base)) {
+  // (gate modes 3 / 4 are the cached LM Gram: a whole-triangle launch that nearly always falls through its gate next to
+  // an incremental one -- the fall-through of a large-LDS block costs more than it could ever save there)
+  if (gram_lds_applies(ntiles, tile_base) && gate_mode != 3 && gate_mode != 4) {
     int mt = 1;
     while (mt * (mt + 1) / 2 < ntiles) mt++;
-    const size_t lds = ((size_t)mt * 16 * GL_LD + GL_RB) * sizeof(double);
-#define GL_GO(NW_, TPW_, NP_)                                                                                       \
+#define GL_GO(NW_, TPW_, NP_, RB_)                                                                                  \
   do {                                                                                                              \
+    const size_t lds = ((size_t)mt * 16 * (RB_ + 2) + RB_) * sizeof(double);                                        \
     if (w)                                                                                                          \
-      hipLaunchKernelGGL((k_gram_lds<NW_, TPW_, NP_, true>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld, cols, \
-                         w, rows_per_slab, nslab, mt, part, ntiles, ctrl, slot, gate_mode);                         \
+      hipLaunchKernelGGL((k_gram_lds<NW_, TPW_, NP_, RB_, true>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld, \
+                         cols, w, rows_per_slab, nslab, mt, part, ntiles, ctrl, slot, gate_mode);                   \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_gram_lds<NW_, TPW_, NP_, false>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld,      \
+      hipLaunchKernelGGL((k_gram_lds<NW_, TPW_, NP_, RB_, false>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld, \
                          cols, w, rows_per_slab, nslab, mt, part, ntiles, ctrl, slot, gate_mode);                   \
   } while (0)
     if (mt <= 8)
-      GL_GO(4, 9, 16);
+      GL_GO(4, 9, 16, 64);
+    else if (mt <= 12)
+      GL_GO(8, 10, 12, 64);
     else
-      GL_GO(8, 10, 12);
+      GL_GO(8, 17, 8, 32);  // 32-row chunks: the accumulators leave no room for a 64-row prefetch
 #undef GL_GO
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 15) / 16), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
