@@ -2,8 +2,8 @@
 -O2 -DNDEBUG -std=c++11, single thread by construction) on this host, on a bounded sample of BASELINE configs[1]:
 the first candidates of the same path on the same full-size data.  Test/measurement infrastructure only.
 
-  python tools/ref_cpu_timing.py [kmax [n p]]
-  BESS_REF_LIB=oracle/_ref/libbess_ref_fast.so OMP_NUM_THREADS=32 python tools/ref_cpu_timing.py 3
+  python oracle/ref_cpu_timing.py [kmax [n p]]
+  BESS_REF_LIB=oracle/_ref/libbess_ref_fast.so OMP_NUM_THREADS=32 python oracle/ref_cpu_timing.py 3
       the "optimistic" build of the same sources (-O3 -march=x86-64-v3 -fopenmp; oracle/Makefile ref_fast)"""
 import json
 import os

@@ -1,3 +1,7 @@
+"""Development aid: time per phase of the conjugate-gradient solve kernels (k_cg / k_cgr), accumulated by the kernels
+themselves (100 MHz wall clock).  Needs a library built with -DBESSX_CG_PROFILE:
+  make -C bess_amd/csrc HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBESSX_CG_PROFILE" -B all
+  python tools/cgprof.py"""
 import sys, ctypes, numpy as np
 sys.path.insert(0,'.')
 from bess_amd import capi, synth
