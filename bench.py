@@ -201,6 +201,10 @@ def main():
             "roofline": roof,
             "passes_over_X_per_candidate": roof["passes_over_X_timed"] / float(len(seq) * args.steps),
             "pdas_iterations_per_candidate": pdas_iters / float(len(seq) * args.steps),
+            # I_k of SURVEY 8d: PDAS iterations Algorithm::fit took per candidate (identical to the reference's,
+            # tests/test_fullsize_gpu.py), as a histogram {iterations: candidates}
+            "pdas_iterations_histogram": {str(int(k)): int(v) for k, v in
+                                          zip(*np.unique(out["cand_iters"], return_counts=True))},
             "upload_and_normalise_seconds": upload_s,
             "selected_k": int(out["best_T0"]), "selected_ic": float(out["ic"]),
         }
