@@ -88,9 +88,13 @@ __device__ __forceinline__ void publish_body(const PubArgs &pa) {
   const volatile int *d4 = reinterpret_cast<const volatile int *>(pa.dev + pa.off_a);
   int *h4 = reinterpret_cast<int *>(pa.host + pa.off_a);
   for (int i = tid; i < pa.kcopy; i += nt) h4[i] = d4[i];
+  // release: every thread's system-scope fence, the barrier, then the flag.  The flag store itself can be relaxed --
+  // a release fence followed by a relaxed atomic store is a release operation on it (and a second system-scope
+  // release by thread 0 would be one more round trip to host memory)
+  // (the full fence is needed: with only s_waitcnt vmcnt(0) per wave the host saw stale blocks at once, tools/soak.py)
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(pa.seq_host, pa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) __hip_atomic_store(pa.seq_host, pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Block-wide sum for 256-thread blocks, fixed order; result valid in thread 0.
