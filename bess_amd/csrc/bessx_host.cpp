@@ -148,6 +148,7 @@ struct bessx_session {
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
+  int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
   bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
   bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
@@ -670,7 +671,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
       e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, s->ctrl, parked,
                             s->st);
     if (e == hipSuccess && !s->cov_bg)  // entries between cached columns, by slot: what the solve gathers from
-      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, COV_CS, s->ctrl, parked, s->st);
+      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, s->ctrl, parked, s->st);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
   }
   return 0;
@@ -752,7 +753,7 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     // parks the fit (cov_stall = 2) and the Cholesky kernel is issued for the slot (force_chol).
     CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
                    s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
-                   s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, COV_CS, PubArgs{}};
+                   s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, s->cov_cs, PubArgs{}};
     // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
     if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
       fz.pub = *sf->pub;
@@ -2796,6 +2797,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
         if (const char *ev = std::getenv("BESSX_FUSE")) s->fuse = std::string(ev) != "0";
         if (const char *ev = std::getenv("BESSX_CG_LAYOUT")) s->cg_by_rows = std::string(ev) != "tiles";
+        if (const char *ev = std::getenv("BESSX_COV_CS")) s->cov_cs = std::min(COV_CS, std::max(1, std::atoi(ev)));
         if (const char *ev = std::getenv("BESSX_CG_TOL")) {
           const double v = std::atof(ev);
           if (v >= 1e-15 && v <= 1e-6) s->cg_tol = v;
