@@ -1741,6 +1741,14 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
     v += __shfl_xor(v, 32);
     return v;
   };
+  // reciprocal to full precision for the step lengths: hardware estimate + two Newton steps (a division costs more,
+  // and alpha / beta only steer the iteration)
+  auto frcp = [](double v) -> double {
+    double y = __builtin_amdgcn_rcp(v);
+    y = fma(fma(-v, y, 1.0), y, y);
+    y = fma(fma(-v, y, 1.0), y, y);
+    return y;
+  };
   auto dot = [&](const double (&a)[RPT], const double (&b)[RPT]) -> double {
     double t = 0.0;
 #pragma unroll
@@ -1816,15 +1824,18 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
       matvec(p_t, ap);
 #pragma unroll
       for (int r = 0; r < RPT; r++) ap[r] = fma(ridge, p_t[r], ap[r]);
-      const double alpha = rs / dot(p_t, ap);
+      const double alpha = rs * frcp(dot(p_t, ap));
       if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < RPT; r++) xs[lane + 64 * r] = fma(alpha, p_t[r], xs[lane + 64 * r]);
       }
 #pragma unroll
       for (int r = 0; r < RPT; r++) r_t[r] = fma(-alpha, ap[r], r_t[r]);
+      // (|r|^2 by the update formula |r|^2 - 2 alpha r.Ap + alpha^2 |Ap|^2, which would fold the step's sums into one
+      // reduction, was tried: its rounding error is amplified by |r_old|^2 / |r_new|^2 ~ 300 at every step and the
+      // recurrence is useless after five steps)
       const double rs_new = dot(r_t, r_t);
-      const double bt = rs_new / rs;
+      const double bt = rs_new * frcp(rs);
 #pragma unroll
       for (int r = 0; r < RPT; r++) p_t[r] = fma(bt, p_t[r], r_t[r]);
       rs = rs_new;
