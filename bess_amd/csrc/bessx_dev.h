@@ -69,7 +69,10 @@ struct PubArgs {
   unsigned long long *seq_host;
   unsigned long long seq;
   const int *count_ptr;
-  int on;
+  int on;               // 1: publish now (copy dev -> host, release the sequence number);  2: only take a snapshot of
+                        // the block into `snap` (device) -- the publication follows from there, off the critical path
+  unsigned char *snap;  // device staging block (same offsets as dev; the cache's column count at snap_count_off)
+  size_t snap_count_off;
 };
 // k_topk2 can end with the work of k_cov_need (covariance form of the LM fit) when the scores fit one chunk
 struct TopkNeed {
@@ -85,6 +88,10 @@ struct TopkNeed {
   const unsigned char *inA;  // membership flags of the current active set
   int inc1;                  // the scores are those on which the previous fit (one size smaller) ended: arg-max path
   int bmm_fresh;             // ... and bmm (block maxima + their columns) comes from the k_cov_d that made them
+  // deferred publication of the PARENT fit's result block (pub.on = 1, pub.dev = its snapshot): done by a second
+  // workgroup of this launch, concurrently with the selection -- the two system-scope round trips of a publication
+  // are then not part of the chain's critical path
+  PubArgs pub;
   // fused k_fit_continue(chained): this launch opens a fit chained behind fit `cont_parent` (cont_on = 1)
   int cont_on, cont_serial, cont_parent;
   // fused commit of a repeated active set (the record-and-stop branch of k_commit): commit_on = 1

@@ -151,6 +151,7 @@ struct bessx_session {
   int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
   bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
+  bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (BESSX_DEFER_PUBLISH=0: in the tail)
   bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
   // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
   // kernel could have the rest of the GPU.  Measured on configs[1] it does not pay: the panel blocks delay the
@@ -200,6 +201,12 @@ struct bessx_session {
   bool publish = true;               // results handed over by k_publish (else: asynchronous copy + synchronise)
   unsigned long long *pub_flag = nullptr, pub_seq = 0;  // pinned sequence numbers k_publish releases (one per buffer)
   unsigned char *res_buf[2] = {nullptr, nullptr};       // the two pinned result blocks; res_h points at the current one
+  // Deferred publication (chained fits): the last kernel of a chained batch leaves a device snapshot of the result
+  // block in snap[buf]; `pend` is the publication that has to follow it -- attached to the first kernel of the next
+  // chained fit (second workgroup) or issued as a k_publish launch before the host waits for it.
+  unsigned char *snap[2] = {nullptr, nullptr};
+  bool pend_on = false;
+  PubArgs pend = {};
   // Chained warm-start fits (covariance mode): the path function announces the fit that will follow (hint); the
   // first batch of that fit is queued behind the current one before the host waits for the current result.
   struct Hint {
@@ -346,6 +353,8 @@ static void session_free(bessx_session *s) {
   for (auto q : s->res_buf)
     if (q) (void)hipHostFree(q);
   if (s->pub_flag) (void)hipHostFree(s->pub_flag);
+  for (auto q : s->snap)
+    if (q) (void)hipFree(q);
   if (s->stage_h) (void)hipHostFree(s->stage_h);
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->st) (void)hipStreamDestroy(s->st);
@@ -443,6 +452,7 @@ static int reset_path_caches(bessx_session *s) {
     s->ahead.armed = false;
     HIPX(hipStreamSynchronize(s->st));
   }
+  s->pend_on = false;  // a deferred publication of a fit nobody will ask for
   s->hint.on = false;
   if (s->st2) {
     HIPX(hipStreamSynchronize(s->st2));
@@ -729,6 +739,9 @@ static int cov_bg_fence_main(bessx_session *s) {
 struct SlotFuse {
   const PubArgs *pub = nullptr;
   bool pub_fused = false;
+  bool pub_snapshot = false;           // the tail only snapshots the block (chained batch): publication deferred
+  const PubArgs *attach = nullptr;     // deferred publication of the parent fit, for the first selection kernel
+  bool attached = false;
   int cont_serial = 0, cont_parent = 0;
   bool cont = false, cont_fused = false;
 };
@@ -757,6 +770,7 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
     if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
       fz.pub = *sf->pub;
+      if (sf->pub_snapshot) fz.pub.on = 2;
       sf->pub_fused = true;
     }
     if (s->cov_cg && !force_chol)
@@ -819,6 +833,10 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
       nd.cont_serial = sf->cont_serial;
       nd.cont_parent = sf->cont_parent;
       sf->cont_fused = true;
+      if (sf->attach) {  // ... and its second workgroup publishes the parent's snapshot meanwhile
+        nd.pub = *sf->attach;
+        sf->attached = true;
+      }
     }
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
   } else if (e == hipSuccess) {
@@ -1046,8 +1064,29 @@ static PubArgs publish_args(bessx_session *s, int kcopy, int buf, unsigned long 
                 s->pub_flag + 8 * buf,
                 *seq,
                 s->cov_mode ? s->cov[0].meta : nullptr,
-                1};
+                1,
+                s->snap[buf],
+                s->res_bytes};
   return pa;
+}
+
+// the publication that follows a snapshot: same target and sequence number, source = the snapshot
+static PubArgs publish_from_snapshot(const PubArgs &tail) {
+  PubArgs pa = tail;
+  pa.on = 1;
+  pa.dev = tail.snap;
+  pa.count_ptr = reinterpret_cast<const int *>(tail.snap + tail.snap_count_off);
+  return pa;
+}
+
+// a deferred publication nobody has attached to a launch: issue it as a launch of its own
+static int publish_flush(bessx_session *s) {
+  if (!s->pend_on) return 0;
+  s->pend_on = false;
+  const PubArgs &pa = s->pend;
+  HIPX(launch_publish(pa.dev, pa.host, pa.ctrl_bytes, pa.off_sse, pa.n_sse, pa.off_b, pa.off_a, pa.kcopy, pa.seq_host,
+                      pa.seq, s->st, pa.count_ptr));
+  return 0;
 }
 
 static int publish_launch(bessx_session *s, const PubArgs &pa) {
@@ -1335,23 +1374,44 @@ static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, in
   ah.buf = buf;
   // the first selection can open the fit itself when no kernel precedes it in slot 1 (same lambda: the scores stand)
   const bool cont_fusable = s->fuse && hint.lambda == parent_lambda && topk_can_fuse_need(s->p);
+  // a deferred publication of the parent: rides on this fit's first kernel if that kernel opens the fit itself,
+  // otherwise it goes out now
+  PubArgs parent_pub = {};
+  const bool have_parent_pub = s->pend_on && cont_fusable && s->defer_pub;
+  if (have_parent_pub) {
+    parent_pub = s->pend;
+    s->pend_on = false;
+  } else if (int rc = publish_flush(s)) {
+    return rc;
+  }
   if (!cont_fusable) HIPX(launch_fit_continue(s->ctrl, Tn, s->hist, s->st, ah.serial, 1, parent));
   const PubArgs pa = publish_args(s, Tn, buf, &ah.seq);
-  bool published = false;
+  bool published = false, snapshotted = false;
   for (int b = 0, sl = 1; b < batch && sl <= s->max_iter; b++, sl++) {
     SlotFuse sf;
     const bool last = b + 1 == batch || sl == s->max_iter;
-    if (last) sf.pub = &pa;
+    if (last) {
+      sf.pub = &pa;
+      sf.pub_snapshot = s->defer_pub;  // this batch's own result: snapshot now, publish with the next launch
+    }
     if (sl == 1 && cont_fusable) {
       sf.cont = true;
       sf.cont_serial = ah.serial;
       sf.cont_parent = parent;
+      if (have_parent_pub) sf.attach = &parent_pub;
     }
     if (int rc = enqueue_lm_slot_cov(s, sl, Tn, hint.lambda, rs, sl == 1, hint.lambda == parent_lambda,
                                      hint.lambda == parent_lambda && Tn == parent_T0 + 1, &sf))
       return rc;
     if (sl == 1 && cont_fusable && !sf.cont_fused) return fail(BESSX_ERR_HIP, "internal: chained fit was not opened");
+    if (sl == 1 && have_parent_pub && !sf.attached) return fail(BESSX_ERR_HIP, "internal: deferred publication lost");
     published = published || sf.pub_fused;
+    snapshotted = snapshotted || (sf.pub_fused && sf.pub_snapshot);
+  }
+  if (snapshotted) {  // the publication of this batch is pending: the next chained launch or publish_flush() issues it
+    s->pend = publish_from_snapshot(pa);
+    s->pend_on = true;
+    return 0;
   }
   return published ? 0 : publish_launch(s, pa);
 }
@@ -1397,16 +1457,23 @@ static int algorithm_fit(bessx_session *s) {
         !s->trace.on) {
       // keep the chain going: the fit after this one goes in before this one's result is awaited
       if (int rc = enqueue_chained(s, hint, rs, mine.serial, mine.buf ^ 1, 2, lambda, T0)) return rc;
+      // this fit's result may still be a snapshot waiting for a launch to carry it (nothing was chained behind it)
+      if (!s->ahead.armed)
+        if (int rc = publish_flush(s)) return rc;
       if (int rc = publish_wait(s, mine.buf, mine.seq)) return rc;
       // serial mismatch: the device did not start this fit (its gate failed); the state is still the previous
       // fit's, the fit chained behind it cannot have started either
       ahead_hit = reinterpret_cast<const FitCtrl *>(s->res_h)->serial == mine.serial;
-      if (!ahead_hit) s->ahead.armed = false;
+      if (!ahead_hit) {
+        s->ahead.armed = false;
+        s->pend_on = false;  // (the fit queued behind it cannot start: its snapshot is never asked for)
+      }
       (ahead_hit ? s->chain_hits : s->chain_dead)++;
       my_buf = mine.buf;
       ahead_serial = mine.serial;
     } else {
       HIPX(hipStreamSynchronize(s->st));
+      s->pend_on = false;
       s->dev_state_rs = -1;
       use_cache = false;
       s->chain_mismatch++;
@@ -1510,7 +1577,10 @@ static int algorithm_fit(bessx_session *s) {
     }
     if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
     // the chained fit only starts if this one ended here with fresh score sums
-    if (s->ahead.armed && !(hc->done && hc->d_fresh && !hc->info)) s->ahead.armed = false;
+    if (s->ahead.armed && !(hc->done && hc->d_fresh && !hc->info)) {
+      s->ahead.armed = false;
+      s->pend_on = false;
+    }
     if (hc->cov_stall) {
       if (int rc = cov_unpark(s, hc, T0, lambda, rs, &slot)) return rc;
       continue;
@@ -2603,6 +2673,10 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       std::memset(s->res_buf[b], 0, off);
     }
     s->res_h = s->res_buf[0];
+    for (int b = 0; b < 2; b++) {
+      HIPT(hipMalloc(reinterpret_cast<void **>(&s->snap[b]), off + 64));
+      HIPT(hipMemset(s->snap[b], 0, off + 64));
+    }
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->pub_flag), 128));
     s->pub_flag[0] = 0ull;
     s->pub_flag[8] = 0ull;  // second buffer's flag, its own cache line
@@ -2796,6 +2870,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         }
         if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
         if (const char *ev = std::getenv("BESSX_FUSE")) s->fuse = std::string(ev) != "0";
+        if (const char *ev = std::getenv("BESSX_DEFER_PUBLISH")) s->defer_pub = std::string(ev) != "0";
+        if (!s->fuse) s->defer_pub = false;
         if (const char *ev = std::getenv("BESSX_CG_LAYOUT")) s->cg_by_rows = std::string(ev) != "tiles";
         if (const char *ev = std::getenv("BESSX_COV_CS")) s->cov_cs = std::min(COV_CS, std::max(1, std::atoi(ev)));
         if (const char *ev = std::getenv("BESSX_CG_TOL")) {

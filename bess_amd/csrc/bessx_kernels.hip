@@ -97,6 +97,21 @@ __device__ __forceinline__ void publish_body(const PubArgs &pa) {
   if (tid == 0) __hip_atomic_store(pa.seq_host, pa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Tail of the last kernel of a chained batch: only a device-side snapshot of what a publication would copy; the
+// publication itself rides on the next launch of the chain (second workgroup of k_topk) or a k_publish launch.
+__device__ __forceinline__ void snapshot_body(const PubArgs &pa) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const volatile unsigned long long *d8 = reinterpret_cast<const volatile unsigned long long *>(pa.dev);
+  unsigned long long *h8 = reinterpret_cast<unsigned long long *>(pa.snap);
+  for (int i = tid; i < pa.ctrl_bytes / 8; i += nt) h8[i] = d8[i];
+  for (int i = tid; i < pa.n_sse; i += nt) h8[pa.off_sse / 8 + i] = d8[pa.off_sse / 8 + i];
+  for (int i = tid; i < pa.kcopy; i += nt) h8[pa.off_b / 8 + i] = d8[pa.off_b / 8 + i];
+  const volatile int *d4 = reinterpret_cast<const volatile int *>(pa.dev + pa.off_a);
+  int *h4 = reinterpret_cast<int *>(pa.snap + pa.off_a);
+  for (int i = tid; i < pa.kcopy; i += nt) h4[i] = d4[i];
+  if (tid == 0) *reinterpret_cast<int *>(pa.snap + pa.snap_count_off) = pa.count_ptr != nullptr ? pa.count_ptr[0] : 0;
+}
+
 // Block-wide sum for 256-thread blocks, fixed order; result valid in thread 0.
 __device__ __forceinline__ double block_sum_256(double v, double *sm /*>=4*/) {
   v = wave_sum(v);
@@ -366,6 +381,10 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
                                                int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
                                                int slot, const int *__restrict__ run_flag, const TopkNeed nd) {
   KT(1);
+  if (nd.pub.on && blockIdx.x == 1) {  // second workgroup: publishes the parent fit's snapshot, nothing else
+    publish_body(nd.pub);
+    return;
+  }
   if (nd.cont_on) {
     // k_fit_continue(chained) as the prologue of the first kernel of the chained fit: it only starts if the fit
     // before it (serial cont_parent) ended here on a repeated set with fresh score sums
@@ -398,7 +417,8 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
   }
   if (run_flag != nullptr && *run_flag == 0) return;
   __shared__ int wcnt[2][16];
-  if (nd.slot_of != nullptr && nd.inc1 && nd.ctrl->l == 0 && nd.ctrl->k_cur + 1 == k && gridDim.x == 1) {
+  if (nd.slot_of != nullptr && nd.inc1 && nd.ctrl->l == 0 && nd.ctrl->k_cur + 1 == k &&
+      (gridDim.x == 1 || nd.pub.on)) {
     // First iteration of a fit chained behind a fit of size k-1 whose last iteration confirmed A_cur = max_k(bd, k-1)
     // on exactly these scores: max_k(bd, k) is A_cur plus the best score outside it (ties -> lower index, the same
     // total order).  An arg-max instead of a selection.
@@ -1649,9 +1669,12 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
                                             const double tol) {
   KT(3);
   cg_body<CH_SLOTS, NW>(m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
-  if (fz.pub.on) {  // last kernel of a batch of slots: publish the result block, whatever the body did
+  if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
     __syncthreads();
-    publish_body(fz.pub);
+    if (fz.pub.on == 2)
+      snapshot_body(fz.pub);
+    else
+      publish_body(fz.pub);
   }
 }
 
@@ -1910,9 +1933,12 @@ __global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const 
                                              const double tol) {
   KT(2);
   cgr_body<RPT, NCW>(m, nc, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
-  if (fz.pub.on) {  // last kernel of a batch of slots: publish the result block, whatever the body did
+  if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
     __syncthreads();
-    publish_body(fz.pub);
+    if (fz.pub.on == 2)
+      snapshot_body(fz.pub);
+    else
+      publish_body(fz.pub);
   }
 }
 
@@ -4382,6 +4408,10 @@ static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_
                                   const int *run_flag = nullptr, const TopkNeed *need = nullptr) {
   TopkNeed nd = {};
   if (need) nd = *need;
+  if (nd.pub.on) {
+    if (nblk != 1) return hipErrorInvalidValue;  // the publisher rides on single-chunk selections only
+    nblk = 2;
+  }
   const int per = (std::min(len, chunk) + 1023) / 1024;
 #define TOPK_GO(EB)                                                                                              \
   hipLaunchKernelGGL(k_topk<EB>, dim3(nblk), dim3(1024), 0, st, score, idx_in, len, chunk, k, out, (int *)nullptr, \
