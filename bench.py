@@ -75,8 +75,8 @@ def cpu_baseline(X, y, budget_s=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--p", type=int, default=10000)
     ap.add_argument("--kmax", type=int, default=200)
