@@ -111,6 +111,12 @@ void topk_set_variant(int v);  // test / benchmark hook: 0 = bit-by-bit search, 
 void gram_set_variant(int v);  // 1 = LDS-staged Gram kernel where it applies (default), 0 = k_gram throughout
 bool gram_lds_applies(int ntiles, int tile_base);
 hipError_t gram_lds_prepare();
+hipError_t launch_gram_irls(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
+                            const double *y, const double *w, const double *mask, int rows_per_slab, int nslab, int mt,
+                            double *part, int ntiles, const FitCtrl *ctrl, int slot, int t, int T0,
+                            const double *bcur, double *llpart, hipStream_t st);
+hipError_t launch_gram_reduce(const double *part, int nslab, int ntiles, double *Gt, const FitCtrl *ctrl, int slot,
+                              int gate_mode, hipStream_t st);
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
                        int rows_per_slab, const GramTask *tasks, int ntask, int nslab, double *part, int ntiles,
                        double *Gt, const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st, int tile_base = 0);

@@ -151,6 +151,11 @@ struct bessx_session {
   int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
   bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
+  // GLM IRLS step with the working response formed inside the Gram kernel (k_gram_irls: one read of the active
+  // columns per step instead of two).  Measured on configs[2]: 0.180 s against 0.175 s unfused -- the 64 rows' exp /
+  // log work and two more barriers per chunk serialise inside a block that has its CU to itself -- so it is OFF
+  // unless BESSX_IRLS_FUSE=1.
+  bool irls_fuse = false;
   bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (BESSX_DEFER_PUBLISH=0: in the tail)
   bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
   // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
@@ -933,6 +938,20 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
   int mt, mp, ntask, ntiles, rps, nslab;
   if (int rc = glm_geometry(s, T0, &mt, &mp, &ntask, &ntiles, &rps, &nslab)) return rc;
   double *z = s->aux + 2 * s->ld;
+  if (s->irls_fuse && mt <= 16 && gram_lds_applies(ntiles, 0)) {
+    // one pass over the active columns per step: linear predictor, weights and working response are formed inside
+    // the Gram kernel from its LDS tile (k_gram_irls); then the convergence test, the reduction and the solve
+    hipError_t e = launch_gram_irls(fam, s->X, s->aux, s->ld, s->n, s->gcols, s->y, s->w, s->mask[rs], rps, nslab, mt,
+                                    s->gpart, ntiles, s->ctrl, slot, t, T0, s->bcur, s->llpart, s->st);
+    if (e == hipSuccess)
+      e = launch_glm_irls_check(s->ctrl, slot, t, fam, s->llpart, nslab, T0 + 1, s->bcur, s->bprev, s->st);
+    if (e == hipSuccess) e = launch_gram_reduce(s->gpart, nslab, ntiles, s->Gt, s->ctrl, slot, 1, s->st);
+    if (e == hipSuccess)
+      e = launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot, 1,
+                      s->st);
+    if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_irls_step: ") + hipGetErrorString(e));
+    return 0;
+  }
   hipError_t e = launch_glm_irls_prep(fam, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, slot, t, s->A_new, T0,
                                       s->bcur, s->Wv, z, s->llpart, s->st);
   if (e == hipSuccess)
@@ -2449,6 +2468,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
     HIPT(gram_lds_prepare());
+    if (const char *ev = std::getenv("BESSX_IRLS_FUSE")) s->irls_fuse = std::string(ev) == "1";
     if (const char *ev = std::getenv("BESSX_GRAM")) gram_set_variant(std::string(ev) == "direct" ? 0 : 1);
   }
   const int n = pb->n;
@@ -2748,7 +2768,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   s->h_rs.push_back(q);
   HIPT(dmalloc(&s->Wv, (size_t)ld));
   HIPT(hipMemset(s->Wv, 0, (size_t)ld * sizeof(double)));
-  HIPT(dmalloc(&s->llpart, (size_t)s->n_sse_blk));
+  HIPT(dmalloc(&s->llpart, (size_t)std::max(s->n_sse_blk, 1024)));  // (also one entry per row slab of k_gram_irls)
   HIPT(dmalloc(&s->bcur, (size_t)capA + 16));
   HIPT(dmalloc(&s->bprev, (size_t)capA + 16));
   HIPT(dmalloc(&s->logfact, (size_t)ld));

@@ -892,6 +892,193 @@ __global__ void __launch_bounds__(64 * NW) k_gram_lds(const double *__restrict__
     if (tI[ts] >= 0) *reinterpret_cast<d4 *>(out + (size_t)(wv + NW * ts) * 256 + lane * 4) = acc[ts];
 }
 
+__device__ __forceinline__ double clampv(double v, double c);
+// IRLS step of the GLM fits with k_glm_irls_prep folded into the Gram: the block that has staged 64 rows of every
+// active column in LDS also forms their linear predictor, weight and working response there (same arithmetic, same
+// order), so the step reads the active columns once instead of twice and W, z never go to memory.  The convergence
+// test (k_glm_irls_check) follows; the reduction of the slab partials and the solve stay gated by it.
+template <int NW, int TPW, int NPASS, int GL_RB, int FAM>
+__global__ void __launch_bounds__(64 * NW) k_gram_irls(const double *__restrict__ X, const double *__restrict__ aux,
+                                                       long ld, int n, const int *__restrict__ cols,
+                                                       const double *__restrict__ y, const double *__restrict__ w,
+                                                       const double *__restrict__ mask, int rows_per_slab, int nslab,
+                                                       int mt, double *__restrict__ part, int ntiles,
+                                                       const FitCtrl *__restrict__ ctrl, int slot, int t, int T0,
+                                                       const double *__restrict__ bcur,
+                                                       double *__restrict__ llpart) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
+  constexpr bool WEIGHTED = true;
+  extern __shared__ double smem[];  // [mp][GL_LD], then the weights of the chunk
+  constexpr int GL_LD = GL_RB + 2, TPC = GL_RB / 2;  // padded column stride; threads per column (a row pair each)
+  constexpr int NT = 64 * NW, CPP = NT / TPC;         // columns staged per pass
+  const int mp = mt * 16;
+  double *wch = smem + (size_t)mp * GL_LD;  // IRLS weight of the chunk's rows (W w mask)
+  double *ych = wch + GL_RB, *owch = ych + GL_RB, *mkch = owch + GL_RB;  // y, observation weight, row mask
+  double *etap = mkch + GL_RB;                                            // [4][GL_RB] partial linear predictors
+  double *bet = etap + 4 * GL_RB;                                         // the iterate: intercept, T0 coefficients
+  for (int i = threadIdx.x; i <= T0; i += 64 * NW) bet[i] = bcur[i];
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ru = tid % TPC, cb = tid / TPC;
+  const int slab = blockIdx.x;
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + GL_RB - 1) / GL_RB);
+  // column pointers: kept in registers, except in the largest instance where the accumulators need them (there the
+  // column index is re-read per chunk: one cached load against 64 rows of MFMA work)
+  constexpr bool PTRS = TPW <= 10;
+  const double *src[PTRS ? NPASS : 1];
+  if (PTRS) {
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int col = i * CPP + cb;
+      src[i] = gram_col(X, aux, ld, col < mp ? cols[col] : cols[0]) + 2 * ru;
+    }
+  }
+  d2 st[NPASS], wst = d2{0.0, 0.0}, yst = d2{0.0, 0.0}, mst = d2{0.0, 0.0};
+  auto load = [&](long r0) {
+    const bool in = r0 + 2 * ru < r_end;  // slabs end on multiples of 16 rows: a row pair is in or out as a whole
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      st[i] = d2{0.0, 0.0};
+      if (in && i * CPP + cb < mp) {
+        const double *q_ = PTRS ? src[i] : gram_col(X, aux, ld, cols[i * CPP + cb]) + 2 * ru;
+        st[i] = *reinterpret_cast<const d2 *>(q_ + r0);
+      }
+    }
+    if (tid < TPC) {
+      yst = in ? *reinterpret_cast<const d2 *>(y + r0 + 2 * ru) : d2{0.0, 0.0};
+      wst = in ? *reinterpret_cast<const d2 *>(w + r0 + 2 * ru) : d2{0.0, 0.0};
+      mst = (in && mask != nullptr) ? *reinterpret_cast<const d2 *>(mask + r0 + 2 * ru) : d2{in ? 1.0 : 0.0, in ? 1.0 : 0.0};
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int col = i * CPP + cb;
+      if (col < mp) *reinterpret_cast<d2 *>(smem + (size_t)col * GL_LD + 2 * ru) = st[i];
+    }
+    if (tid < TPC) {
+      *reinterpret_cast<d2 *>(ych + 2 * ru) = yst;
+      *reinterpret_cast<d2 *>(owch + 2 * ru) = wst;
+      *reinterpret_cast<d2 *>(mkch + 2 * ru) = mst;
+    }
+  };
+  int tI[TPW], tJ[TPW];
+  d4 acc[TPW];
+#pragma unroll
+  for (int ts = 0; ts < TPW; ts++) {
+    const int t = wv + NW * ts;
+    int I = -1, J = -1;
+    if (t < ntiles) tile_of(t, I, J);
+    tI[ts] = __builtin_amdgcn_readfirstlane(I);
+    tJ[ts] = __builtin_amdgcn_readfirstlane(J);
+    acc[ts] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+  // k_glm_irls_prep on the rows of the staged chunk: linear predictor from the LDS tile with the same four
+  // interleaved accumulators and the same order as lin_pred2 (bit-identical eta), then the family's weight and
+  // working response; z goes into its column of the tile, W w mask into wch
+  double ll = 0.0;
+  auto prep = [&](long r0) {
+    const int row = tid % GL_RB, pt = tid / GL_RB;
+    if (pt < 4) {
+      double acc = 0.0;
+      const int k4 = T0 & ~3;
+      for (int a = pt; a < k4; a += 4) acc = fma(smem[(size_t)(a + 1) * GL_LD + row], bet[a + 1], acc);
+      if (pt == 0)
+        for (int a = k4; a < T0; a++) acc = fma(smem[(size_t)(a + 1) * GL_LD + row], bet[a + 1], acc);
+      etap[pt * GL_RB + row] = acc;
+    }
+    __syncthreads();
+    if (tid < GL_RB) {
+      const bool in = r0 + row < (long)n;
+      double eta = ((etap[row] + etap[GL_RB + row]) + (etap[2 * GL_RB + row] + etap[3 * GL_RB + row])) + bet[0];
+      const double yy = ych[row], ww = owch[row], mm = mkch[row];
+      double Wt = 0.0, zt = 0.0;
+      if (in) {
+        if (FAM == 2) {
+          const double e = exp(clampv(eta, 30.0)), Pi = e / (1.0 + e);
+          ll += (yy * log(Pi) + (1.0 - yy) * log(1.0 - Pi)) * ww * mm;
+          double W = Pi * (1.0 - Pi);
+          if (t > 0 && W < 0.001) W = 0.001;
+          zt = eta + (yy - Pi) / W;
+          Wt = W * ww * mm;
+        } else {
+          double e;
+          if (t == 0) {
+            e = exp(eta);
+          } else {
+            eta = clampv(eta, 30.0);
+            e = exp(eta);
+            if (e < 0.001) e = 0.001;
+            ll += (yy * eta - e) * ww * mm;
+          }
+          zt = eta + (yy - e) / e;
+          Wt = e * ww * mm;
+        }
+      }
+      smem[(size_t)(mp - 1) * GL_LD + row] = zt;  // the working response is the last column (k_gram_cols)
+      wch[row] = Wt;
+    }
+    __syncthreads();
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int ts = 0; ts < TPW; ts++) {
+      if (tI[ts] >= 0) {  // wave-uniform
+        const double *pa = smem + (size_t)(tI[ts] * 16 + c) * GL_LD + 4 * q;
+        const double *pb = smem + (size_t)(tJ[ts] * 16 + c) * GL_LD + 4 * q;
+#pragma unroll
+        for (int sx = 0; sx < GL_RB / 16; sx++) {
+          const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * sx), a1 = *reinterpret_cast<const d2 *>(pa + 16 * sx + 2);
+          const d2 b0 = *reinterpret_cast<const d2 *>(pb + 16 * sx), b1 = *reinterpret_cast<const d2 *>(pb + 16 * sx + 2);
+          double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
+          if (WEIGHTED) {
+            const d2 w0 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q);
+            const d2 w1 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q + 2);
+            ax *= w0.x;
+            ay *= w0.y;
+            az *= w1.x;
+            aw *= w1.y;
+          }
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0.x, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b0.y, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b1.x, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b1.y, acc[ts], 0, 0, 0);
+        }
+      }
+    }
+  };
+  if (nchunk > 0) {
+    load(r_begin);
+    store();
+    if (nchunk > 1) load(r_begin + GL_RB);
+    __syncthreads();
+    for (int k = 0; k < nchunk; k++) {
+      prep(r_begin + (long)k * GL_RB);
+      compute();
+      __syncthreads();
+      if (k + 1 < nchunk) store();
+      __syncthreads();
+      if (k + 2 < nchunk) load(r_begin + (long)(k + 2) * GL_RB);
+    }
+  }
+  {  // log-likelihood terms of this slab (k_glm_irls_check adds the slabs up)
+    __shared__ double llw[NW];
+    ll = wave_sum(ll);
+    if ((tid & 63) == 0) llw[tid >> 6] = ll;
+    __syncthreads();
+    if (tid == 0) {
+      double tl = 0.0;
+      for (int q = 0; q < NW; q++) tl += llw[q];
+      llpart[slab] = tl;
+    }
+  }
+  double *out = part + (size_t)slab * ntiles * 256;
+#pragma unroll
+  for (int ts = 0; ts < TPW; ts++)
+    if (tI[ts] >= 0) *reinterpret_cast<d4 *>(out + (size_t)(wv + NW * ts) * 256 + lane * 4) = acc[ts];
+}
+
 __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ part, int nslab, int ntiles,
                                                      double *__restrict__ Gt, const FitCtrl *__restrict__ ctrl,
                                                      int slot, int gate_mode) {
@@ -4476,7 +4663,7 @@ bool gram_lds_applies(int ntiles, int tile_base) {
 hipError_t gram_lds_prepare() {
   // dynamic LDS beyond 64 KB has to be requested once per kernel instance
   hipError_t e = hipSuccess;
-  const int big = (12 * 16 * 66 + 64) * (int)sizeof(double);
+  const int big = (12 * 16 * 66 + 8 * 64 + 12 * 16) * (int)sizeof(double);
 #define GL_ATTR(K) \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
   GL_ATTR((k_gram_lds<4, 9, 16, 64, true>));
@@ -4485,8 +4672,53 @@ hipError_t gram_lds_prepare() {
   GL_ATTR((k_gram_lds<8, 10, 12, 64, false>));
   GL_ATTR((k_gram_lds<8, 17, 8, 32, true>));
   GL_ATTR((k_gram_lds<8, 17, 8, 32, false>));
+  GL_ATTR((k_gram_irls<4, 9, 16, 64, 2>));
+  GL_ATTR((k_gram_irls<4, 9, 16, 64, 3>));
+  GL_ATTR((k_gram_irls<8, 10, 12, 64, 2>));
+  GL_ATTR((k_gram_irls<8, 10, 12, 64, 3>));
+  GL_ATTR((k_gram_irls<8, 17, 8, 32, 2>));
+  GL_ATTR((k_gram_irls<8, 17, 8, 32, 3>));
 #undef GL_ATTR
   return e;
+}
+
+// fused IRLS step (k_gram_irls): slab partials of the weighted Gram + the slabs' log-likelihood terms.  The caller
+// runs k_glm_irls_check next, then launch_gram_reduce() and the solve (both gated by the check's verdict).
+hipError_t launch_gram_irls(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
+                            const double *y, const double *w, const double *mask, int rows_per_slab, int nslab, int mt,
+                            double *part, int ntiles, const FitCtrl *ctrl, int slot, int t, int T0,
+                            const double *bcur, double *llpart, hipStream_t st) {
+  if (mt < 1 || mt > 16 || T0 + 2 > mt * 16) return hipErrorInvalidValue;  // intercept, T0 columns, ..., z last
+#define GI_GO(NW_, TPW_, NP_, RB_, FAM_)                                                                             \
+  do {                                                                                                               \
+    const size_t lds = ((size_t)mt * 16 * (RB_ + 2) + 8 * RB_ + (size_t)mt * 16) * sizeof(double);                   \
+    hipLaunchKernelGGL((k_gram_irls<NW_, TPW_, NP_, RB_, FAM_>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld, n, \
+                       cols, y, w, mask, rows_per_slab, nslab, mt, part, ntiles, ctrl, slot, t, T0, bcur, llpart);   \
+  } while (0)
+#define GI_FAM(NW_, TPW_, NP_, RB_) \
+  if (fam == 2)                     \
+    GI_GO(NW_, TPW_, NP_, RB_, 2);  \
+  else                              \
+    GI_GO(NW_, TPW_, NP_, RB_, 3)
+  if (mt <= 8) {
+    GI_FAM(4, 9, 16, 64);
+  } else if (mt <= 12) {
+    GI_FAM(8, 10, 12, 64);
+  } else {
+    GI_FAM(8, 17, 8, 32);
+  }
+#undef GI_FAM
+#undef GI_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_gram_reduce(const double *part, int nslab, int ntiles, double *Gt, const FitCtrl *ctrl, int slot,
+                              int gate_mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_gram_reduce, dim3((ntiles * 256 + 15) / 16), dim3(256), 0, st, part, nslab, ntiles, Gt, ctrl,
+                     slot, gate_mode);
+  LAUNCH_CHECK();
+  return hipSuccess;
 }
 
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,

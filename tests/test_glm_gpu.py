@@ -75,3 +75,23 @@ def test_poisson_cv(gpu):
     X, y = _poisson_data()
     check(gpu, X, y, dict(POIS, is_cv=True, K=5, cv_fold_id=synth.make_cv_folds(800, 5), sequence=np.arange(1, 9)),
           "poisson cv")
+
+
+def test_fused_irls_step_gives_the_same_fits(gpu, monkeypatch):
+    """BESSX_IRLS_FUSE=1 (working response formed inside the Gram kernel, off by default: measured no faster) runs
+    the same arithmetic in the same order: identical supports, iteration counts and coefficients."""
+    X, y, _, _ = synth.make_logistic(1500, 300, 8, seed=6)
+    Xp, yp = X[:, :120], np.random.default_rng(5).poisson(np.exp(np.clip(0.3 * X[:, 0] - 0.2 * X[:, 3], -3, 3))).astype(float)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BESSX_IRLS_FUSE", flag)
+        with gpu.Session(X, y, data_type=2, model_type=2) as s:
+            a = s.sequential_path(np.arange(1, 25), ic_type=3)
+        with gpu.Session(Xp, yp, data_type=2, model_type=3) as s:
+            b = s.sequential_path(np.arange(1, 9), ic_type=3)
+        outs.append((a, b))
+    for u, v in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(u["cand_support"], v["cand_support"])
+        np.testing.assert_array_equal(u["cand_iters"], v["cand_iters"])
+        np.testing.assert_allclose(u["cand_beta"], v["cand_beta"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(u["cand_ic"], v["cand_ic"], rtol=1e-10)
