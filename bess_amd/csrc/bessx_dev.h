@@ -39,7 +39,9 @@ struct FitCtrl {
   int sse_valid;   // sse_dot / sse_nrm belong to the current coefficients (set by the fused k_chol)
   double sse_dot;  // beta . X^T(m y) of the last solve
   double sse_nrm;  // |beta|^2 of the last solve
+  unsigned long long snap_seq;  // sequence number of the last device snapshot of this block (deferred publication)
 };
+static_assert(sizeof(FitCtrl) <= 128, "the published control block is 128 bytes");
 
 constexpr int GRAM_JC = 8;  // most tiles of one tile row handled by one wave of k_gram (runs of 8/4/2/1)
 struct GramTask {
@@ -92,6 +94,9 @@ struct TopkNeed {
   // workgroup of this launch, concurrently with the selection -- the two system-scope round trips of a publication
   // are then not part of the chain's critical path
   PubArgs pub;
+  // ... and this batch's own snapshot (snap.on = 2), taken right where a repeated active set is recorded, so that the
+  // solve kernel behind this launch has nothing left to do
+  PubArgs snap;
   // fused k_fit_continue(chained): this launch opens a fit chained behind fit `cont_parent` (cont_on = 1)
   int cont_on, cont_serial, cont_parent;
   // fused commit of a repeated active set (the record-and-stop branch of k_commit): commit_on = 1

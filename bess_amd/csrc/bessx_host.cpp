@@ -843,6 +843,10 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
         sf->attached = true;
       }
     }
+    if (sf && sf->pub && sf->pub_snapshot && s->fuse && nd.commit_on && s->cov_cg && rs == 0) {
+      nd.snap = *sf->pub;  // last slot of a chained batch: a repeated set is recorded AND snapshotted here
+      nd.snap.on = 2;
+    }
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
   } else if (e == hipSuccess) {
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);

@@ -553,6 +553,11 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
         __syncthreads();
         commit_body(nd.ctrl, slot, k, out, nullptr, 0, 0, nd.cm_A_cur, nd.cm_b_cur, nd.cm_beta_dense, nd.cm_hist,
                     nd.cm_hist_beta, nd.cm_hist_coef0, nd.cm_hist_stride, &same_any_sh, nd.cm_inA);
+        if (nd.snap.on == 2) {  // the fit has ended: its snapshot for the deferred publication, here and now
+          if (threadIdx.x == 0) nd.ctrl->snap_seq = nd.snap.seq;
+          __syncthreads();
+          snapshot_body(nd.snap);
+        }
       }
       return;
     }
@@ -1858,10 +1863,11 @@ __global__ void __launch_bounds__(64 * NW) k_cg(int m, int mt, double ridge, con
   cg_body<CH_SLOTS, NW>(m, mt, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
   if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
     __syncthreads();
-    if (fz.pub.on == 2)
-      snapshot_body(fz.pub);
-    else
+    if (fz.pub.on == 2) {
+      if (fz.ctrl->snap_seq != fz.pub.seq) snapshot_body(fz.pub);  // (else the selection kernel has taken it already)
+    } else {
       publish_body(fz.pub);
+    }
   }
 }
 
@@ -2122,10 +2128,11 @@ __global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const 
   cgr_body<RPT, NCW>(m, nc, ridge, rhs, A_new, sol, ctrl, slot, fz, maxit, tol);
   if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
     __syncthreads();
-    if (fz.pub.on == 2)
-      snapshot_body(fz.pub);
-    else
+    if (fz.pub.on == 2) {
+      if (fz.ctrl->snap_seq != fz.pub.seq) snapshot_body(fz.pub);  // (else the selection kernel has taken it already)
+    } else {
       publish_body(fz.pub);
+    }
   }
 }
 
