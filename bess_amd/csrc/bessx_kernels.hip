@@ -74,20 +74,42 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// The work of k_publish as the tail of another single-block kernel: every thread of the block calls it after a
-// barrier that follows the last write to the result block.  Plain (volatile) reads: the block was written by this
-// very kernel.
-__device__ __forceinline__ void publish_body(const PubArgs &pa) {
+// Copy of the result block (control words, loss sums, the first kcopy coefficients and indices) from `src` to `dst`
+// by the whole workgroup.  The block was (partly) written by this very kernel, so the reads go to L2 (relaxed
+// agent-scope atomic loads), but -- unlike volatile accesses, which the compiler keeps in program order and waits
+// for one by one -- they are all in flight before the first store.
+__device__ __forceinline__ void copy_result_block(const PubArgs &pa, const unsigned char *src, unsigned char *dst) {
   const int tid = threadIdx.x, nt = blockDim.x;
+  const unsigned long long *d8 = reinterpret_cast<const unsigned long long *>(src);
+  unsigned long long *h8 = reinterpret_cast<unsigned long long *>(dst);
+  const int *d4 = reinterpret_cast<const int *>(src + pa.off_a);
+  int *h4 = reinterpret_cast<int *>(dst + pa.off_a);
+  auto ld8 = [](const unsigned long long *q) {
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto ld4 = [](const int *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // one element of every region per thread and round (the regions are a few hundred elements at most)
+  const int nc = pa.ctrl_bytes / 8;
+  const int rounds = (max(max(nc, pa.n_sse), pa.kcopy) + nt - 1) / nt;
+  for (int r = 0; r < rounds; r++) {
+    const int i = r * nt + tid;
+    const bool c = i < nc, e = i < pa.n_sse, k = i < pa.kcopy;
+    const unsigned long long vc = c ? ld8(d8 + i) : 0ull, ve = e ? ld8(d8 + pa.off_sse / 8 + i) : 0ull;
+    const unsigned long long vb = k ? ld8(d8 + pa.off_b / 8 + i) : 0ull;
+    const int va = k ? ld4(d4 + i) : 0;
+    if (c) h8[i] = vc;
+    if (e) h8[pa.off_sse / 8 + i] = ve;
+    if (k) h8[pa.off_b / 8 + i] = vb;
+    if (k) h4[i] = va;
+  }
+}
+
+// The work of k_publish as the tail of another single-block kernel: every thread of the block calls it after a
+// barrier that follows the last write to the result block.
+__device__ __forceinline__ void publish_body(const PubArgs &pa) {
+  const int tid = threadIdx.x;
   if (tid == 0 && pa.count_ptr != nullptr) pa.seq_host[1] = (unsigned long long)pa.count_ptr[0];
-  const volatile unsigned long long *d8 = reinterpret_cast<const volatile unsigned long long *>(pa.dev);
-  unsigned long long *h8 = reinterpret_cast<unsigned long long *>(pa.host);
-  for (int i = tid; i < pa.ctrl_bytes / 8; i += nt) h8[i] = d8[i];
-  for (int i = tid; i < pa.n_sse; i += nt) h8[pa.off_sse / 8 + i] = d8[pa.off_sse / 8 + i];
-  for (int i = tid; i < pa.kcopy; i += nt) h8[pa.off_b / 8 + i] = d8[pa.off_b / 8 + i];
-  const volatile int *d4 = reinterpret_cast<const volatile int *>(pa.dev + pa.off_a);
-  int *h4 = reinterpret_cast<int *>(pa.host + pa.off_a);
-  for (int i = tid; i < pa.kcopy; i += nt) h4[i] = d4[i];
+  copy_result_block(pa, pa.dev, pa.host);
   // release: every thread's system-scope fence, the barrier, then the flag.  The flag store itself can be relaxed --
   // a release fence followed by a relaxed atomic store is a release operation on it (and a second system-scope
   // release by thread 0 would be one more round trip to host memory)
@@ -100,16 +122,9 @@ __device__ __forceinline__ void publish_body(const PubArgs &pa) {
 // Tail of the last kernel of a chained batch: only a device-side snapshot of what a publication would copy; the
 // publication itself rides on the next launch of the chain (second workgroup of k_topk) or a k_publish launch.
 __device__ __forceinline__ void snapshot_body(const PubArgs &pa) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const volatile unsigned long long *d8 = reinterpret_cast<const volatile unsigned long long *>(pa.dev);
-  unsigned long long *h8 = reinterpret_cast<unsigned long long *>(pa.snap);
-  for (int i = tid; i < pa.ctrl_bytes / 8; i += nt) h8[i] = d8[i];
-  for (int i = tid; i < pa.n_sse; i += nt) h8[pa.off_sse / 8 + i] = d8[pa.off_sse / 8 + i];
-  for (int i = tid; i < pa.kcopy; i += nt) h8[pa.off_b / 8 + i] = d8[pa.off_b / 8 + i];
-  const volatile int *d4 = reinterpret_cast<const volatile int *>(pa.dev + pa.off_a);
-  int *h4 = reinterpret_cast<int *>(pa.snap + pa.off_a);
-  for (int i = tid; i < pa.kcopy; i += nt) h4[i] = d4[i];
-  if (tid == 0) *reinterpret_cast<int *>(pa.snap + pa.snap_count_off) = pa.count_ptr != nullptr ? pa.count_ptr[0] : 0;
+  copy_result_block(pa, pa.dev, pa.snap);
+  if (threadIdx.x == 0)
+    *reinterpret_cast<int *>(pa.snap + pa.snap_count_off) = pa.count_ptr != nullptr ? pa.count_ptr[0] : 0;
 }
 
 // Block-wide sum for 256-thread blocks, fixed order; result valid in thread 0.
