@@ -195,6 +195,7 @@ struct CoxBufs {
   double *C1, *CU, *CV, *C2;                           // one-pass score: prefix sums of ew/S0, u, ew - u, ew/S0^2
   int one_pass;                                        // score pass reads X once (k_cox_score1p)
   int need_uv;                                         // CU / CV wanted although the score is not one-pass (groups)
+  double *ldl_work;                                    // 256 x 256: dense copy for the LDL^T fallback of the Newton solve
 };
 size_t cox_scan_scratch_doubles(long ld, int kmax);
 hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,

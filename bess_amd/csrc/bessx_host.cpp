@@ -2923,6 +2923,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     for (auto v : vecs) HIPT(V(v, (size_t)ld));
     double **vecs1[] = {&c.C1, &c.CU, &c.CV, &c.C2};
     for (auto v : vecs1) HIPT(V(v, (size_t)ld));
+    HIPT(V(&c.ldl_work, (size_t)256 * 256));
     // k-sized work space: for sparsity levels up to 254 now, grown by cox_reserve() when a larger one is asked for
     s->cox_M_cols = 256;
     HIPT(V(&c.M, (size_t)ld * s->cox_M_cols));

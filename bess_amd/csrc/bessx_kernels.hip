@@ -3483,6 +3483,76 @@ __global__ void __launch_bounds__(256) k_tile_sub(double *__restrict__ a, const 
   if (i < n) a[i] = a[i] - b[i];
 }
 
+// Fallback of the Newton solve: the system (G1 - G2 - 2 lambda I) u = g is positive definite unless the ridge term,
+// whose sign the reference has as written (src/Algorithm.h:1429, 1471), outweighs the information matrix -- then
+// the Cholesky kernel reports a non-positive pivot (info = 1).  The reference solves with LDL^T and does not care;
+// this kernel does the same (un-pivoted LDL^T on a dense copy, one workgroup, global memory: rare and small), only
+// when info says the Cholesky kernel gave up, and clears info when it succeeds.
+__global__ void __launch_bounds__(256) k_ldlt_fallback(const double *__restrict__ Gt, int m, double ridge,
+                                                       const double *__restrict__ rhs, double *__restrict__ sol,
+                                                       int *__restrict__ info, const FitCtrl *__restrict__ ctrl,
+                                                       int slot, int t, double *__restrict__ work) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  if (*info == 0) return;
+  __shared__ double col[256], zz[256];
+  __shared__ double dj_sh;
+  __shared__ int bad_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double *A = work;              // m x m, column-major, lower triangle used
+  if (tid == 0) bad_sh = 0;
+  for (int idx = tid; idx < m * m; idx += 256) {
+    const int i = idx % m, j = idx / m;
+    if (i >= j) {
+      double v = Gt[tile_id(i >> 4, j >> 4) * 256 + tile_elem(i & 15, j & 15)];
+      if (i == j) v += ridge;
+      A[idx] = v;
+    }
+  }
+  for (int i = tid; i < m; i += 256) zz[i] = rhs[i];
+  __syncthreads();
+  for (int j = 0; j < m; j++) {
+    if (tid == 0) {
+      const double d = A[(size_t)j * m + j];
+      dj_sh = d;
+      if (!(fabs(d) > 0.0) || !isfinite(d)) bad_sh = 1;
+    }
+    __syncthreads();
+    const double dj = dj_sh;
+    if (bad_sh) break;  // uniform
+    for (int i = j + 1 + tid; i < m; i += 256) {
+      const double a = A[(size_t)j * m + i];
+      col[i] = a;                       // a_ij = l_ij d_j
+      A[(size_t)j * m + i] = a / dj;    // l_ij
+    }
+    __syncthreads();
+    // trailing update of the lower triangle: a_il -= l_ij d_j l_lj = a_ij * (a_lj / d_j)
+    for (int l = j + 1 + wave; l < m; l += 4) {
+      const double f = col[l] / dj;
+      for (int i = l + lane; i < m; i += 64) A[(size_t)l * m + i] -= col[i] * f;
+    }
+    __syncthreads();
+  }
+  if (bad_sh) return;  // info stays 1: the host reports BESSX_ERR_NUMERIC
+  // forward substitution L z = g, then z / d, then L^T u = z
+  for (int j = 0; j < m; j++) {
+    const double zj = zz[j];
+    for (int i = j + 1 + tid; i < m; i += 256) zz[i] -= A[(size_t)j * m + i] * zj;
+    __syncthreads();
+  }
+  for (int i = tid; i < m; i += 256) zz[i] /= A[(size_t)i * m + i];
+  __syncthreads();
+  for (int j = m - 1; j >= 0; j--) {
+    // u_j = z_j - sum_{i > j} l_ij u_i
+    double part = 0.0;
+    for (int i = j + 1 + tid; i < m; i += 256) part += A[(size_t)j * m + i] * zz[i];
+    part = block_sum_256(part, col);
+    if (tid == 0) zz[j] -= part;
+    __syncthreads();
+  }
+  for (int i = tid; i < m; i += 256) sol[i] = zz[i];
+  if (tid == 0) *info = 0;
+}
+
 // UD = X_A u  (direction of the linear predictor; beta1 = beta0 + 0.5^m u with u = -h^{-1} g, :1473-1474)
 __global__ void __launch_bounds__(128) k_cox_dir(const double *__restrict__ X, long ld,
                                                  const FitCtrl *__restrict__ ctrl, int slot, int t,
@@ -5168,6 +5238,11 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                   : launch_chol_big(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, rdiag, zbig, ctrl, slot,
                                     2, st);
   if (e != hipSuccess) return e;
+  if (mt <= CH_MT && lambda != 0.0 && cb.ldl_work != nullptr) {  // (k_chol leaves Gt untouched: it works in registers)
+    hipLaunchKernelGGL(k_ldlt_fallback, dim3(1), dim3(256), 0, st, (const double *)Gt, k, -2.0 * lambda,
+                       (const double *)cb.g, cb.u, &ctrl->info, (const FitCtrl *)ctrl, slot, t, cb.ldl_work);
+    LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_cox_dir, dim3(nb2), dim3(128), 0, st, X, ld, (const FitCtrl *)ctrl, slot, t, A_new, k,
                      (const double *)cb.u, cb.UD);
   LAUNCH_CHECK();

@@ -102,3 +102,26 @@ def test_cox_groups_need_the_group_algorithm(gpu):
     with pytest.raises(gpu.BessxError) as e:
         gpu.Session(X, status, data_type=3, model_type=4, algorithm_type=1, g_index=gi)
     assert e.value.code == 3
+
+
+def test_cox_newton_system_that_is_not_positive_definite(gpu):
+    """A ridge term that outweighs the information matrix (small n, lambda > 0.1; the reference adds 2 lambda with the
+    sign that subtracts, src/Algorithm.h:1471) makes the Newton system indefinite: the Cholesky kernel gives up and
+    the LDL^T fallback kernel solves it, as the reference's LDLT does.  Found by tools/fuzz_parity.py (seed 1, case
+    59).  Supports are compared exactly; the coefficients of such a system only to 1e-5."""
+    X, _, status, _, _ = synth.make_cox(97, 272, 9, seed=222610918)
+    kw = dict(COX, max_iter=3, sequence=np.arange(3, 15), lambda_seq=[0.12957971161634982, 0.15912213204776818,
+                                                                     0.17984158281889373],
+              always_select=[21, 233], ic_type=3)
+    from oracle import port_ctypes as P
+    from test_lm_gpu import run_gpu
+    want, got = P.trace(X, status, **kw), run_gpu(gpu, X, status, kw)
+    assert len(got["trace"]["fits"]) == len(want["fits"]) == 36
+    for a, b in zip(got["trace"]["fits"], want["fits"]):
+        assert len(a["iters"]) == len(b["iters"])
+        for u, v in zip(a["iters"], b["iters"]):
+            assert np.array_equal(u, v)
+        for u, v in zip(a["betas"], b["betas"]):
+            assert np.max(np.abs(u - v)) <= 1e-5 * max(np.max(np.abs(v)), 1e-300)
+    np.testing.assert_allclose(got["trace"]["ic_calls"], want["ic_calls"], rtol=1e-6)
+    assert np.array_equal(np.nonzero(got["beta"])[0], np.nonzero(want["beta"])[0])

@@ -1,0 +1,92 @@
+"""Randomised differential test: GPU paths against the plain-C oracle (test infrastructure) on many small random
+problems and option combinations -- families, weights, always_select, lambda grids, CV, golden section, groups,
+both LM score-pass forms.  Every PDAS iteration's active set must match; coefficients to 1e-6.
+  python tools/fuzz_parity.py [cases] [seed]
+(lives in tools/ but is a test: it imports the oracle exactly like tests/ do)"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from bess_amd import capi, synth  # noqa: E402
+from helpers import assert_same_trace  # noqa: E402
+from oracle import port_ctypes as P  # noqa: E402
+from test_lm_gpu import run_gpu  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+fails = 0
+for c in range(cases):
+    fam = rng.choice(["lm", "lm", "lm", "logit", "poisson", "cox"])
+    n = int(rng.integers(80, 1500))
+    p = int(rng.integers(8, 400))
+    kt = int(min(max(2, p // 6), rng.integers(2, 12)))
+    seed = int(rng.integers(1, 1 << 30))
+    kw = {}
+    if fam == "lm":
+        X, y, _, _ = synth.make_lm(n, p, kt, seed=seed)
+        kw["score_mode"] = int(rng.integers(1, 3))
+    elif fam == "logit":
+        X, y, _, _ = synth.make_logistic(n, p, kt, seed=seed)
+        kw.update(data_type=2, model_type=2)
+    elif fam == "poisson":
+        X = np.random.default_rng(seed).standard_normal((n, p))
+        b = np.zeros(p)
+        b[:kt] = np.random.default_rng(seed + 1).uniform(-0.4, 0.4, kt)
+        y = np.random.default_rng(seed + 2).poisson(np.exp(np.clip(X @ b, -4, 3))).astype(float)
+        kw.update(data_type=2, model_type=3)
+    else:
+        X, _, y, _, _ = synth.make_cox(n, p, kt, seed=seed)
+        kw.update(data_type=3, model_type=4)
+    kmax = int(min(p, n // 4, rng.integers(3, 25)))
+    if rng.random() < 0.25:
+        kw["weight"] = rng.uniform(0.5, 2.0, n)
+    if rng.random() < 0.2:
+        kw["is_warm_start"] = False
+    if rng.random() < 0.15:
+        kw["max_iter"] = int(rng.integers(2, 6))
+    if rng.random() < 0.2 and fam != "cox":
+        kw["is_normal"] = bool(rng.random() < 0.5)
+    mode = rng.choice(["seq", "seq", "gs", "lam", "cv", "grp"])
+    if mode == "gs":
+        kw.update(path_type=2, s_min=1, s_max=kmax)
+    elif mode == "lam":
+        kw.update(sequence=np.arange(1, max(3, kmax // 2)), lambda_seq=sorted(rng.uniform(0, 0.2, int(rng.integers(2, 4)))))
+    elif mode == "cv":
+        K = int(rng.integers(2, 6))
+        kw.update(is_cv=True, K=K, cv_fold_id=synth.make_cv_folds(n, K, seed=seed), sequence=np.arange(1, max(3, kmax // 2)))
+    elif mode == "grp" and p >= 12:
+        cuts = np.sort(rng.choice(np.arange(1, p), min(p - 1, int(rng.integers(3, max(4, p // 3)))), replace=False))
+        gi = np.concatenate([[0], cuts]).astype(np.int32)
+        if np.max(np.diff(np.append(gi, p))) > 16:
+            gi = np.arange(0, p, 3).astype(np.int32)
+        kw.update(algorithm_type=2, g_index=gi, sequence=np.arange(1, min(len(gi), 6)))
+        kw.pop("score_mode", None)
+    else:
+        kw["sequence"] = np.arange(1, kmax + 1)
+    if mode != "grp" and rng.random() < 0.2 and kmax >= 3:
+        al = sorted(rng.choice(p, 2, replace=False).tolist())
+        kw["always_select"] = al
+        if "sequence" in kw:
+            kw["sequence"] = np.arange(3, max(4, kmax))
+        else:
+            kw["s_min"] = 3
+            kw["s_max"] = max(4, kmax)
+    kw["ic_type"] = int(rng.integers(1, 5))
+    okw = {k: v for k, v in kw.items() if k != "score_mode"}
+    try:
+        want = P.trace(X, y, **okw)
+        got = run_gpu(capi, X, y, kw)
+        # LM information criteria are n log(loss) + ...: a loss that agrees to 1e-10 relative moves them by 1e-10 n
+        assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="case %d" % c, ic_atol=1e-9 * n)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print("CASE %d FAILED: fam=%s n=%d p=%d seed=%d mode=%s kw=%r\n  %s" % (
+            c, fam, n, p, seed, mode, {k: (v if np.size(v) < 8 else "...") for k, v in kw.items()}, str(e)[:300]), flush=True)
+    if c % 25 == 24:
+        print("%d cases, %d failures, %.0f s" % (c + 1, fails, time.time() - t0), flush=True)
+print("fuzz done: %d cases, %d failures" % (cases, fails))
+sys.exit(1 if fails else 0)
