@@ -25,7 +25,9 @@ def assert_same_trace(got, want, beta_rtol=1e-6, what="", ic_atol=1e-9):
             scale = max(np.max(np.abs(y)), 1e-300)
             assert np.max(np.abs(x - y)) <= beta_rtol * scale, "%s: fit %d iteration %d beta differs by %g" % (
                 what, fi, it + 1, np.max(np.abs(x - y)) / scale)
-        np.testing.assert_allclose(a["coef0s"], b["coef0s"], rtol=beta_rtol, atol=beta_rtol * 1e-3)
+        # intercepts: relative to their own size or to the size of the fit's coefficients, whichever is larger
+        bscale = max([float(np.max(np.abs(v))) for v in b["betas"] if len(v)] + [1e-3])
+        np.testing.assert_allclose(a["coef0s"], b["coef0s"], rtol=beta_rtol, atol=beta_rtol * bscale)
     np.testing.assert_allclose(got["ic_calls"], want["ic_calls"], rtol=1e-9, atol=ic_atol, err_msg=what + " ic values")
     np.testing.assert_allclose(got["loss_calls"], want["loss_calls"], rtol=1e-9, atol=1e-12, err_msg=what + " loss values")
 
