@@ -1,0 +1,139 @@
+"""Randomised differential test: GPU paths against the plain-C oracle (test infrastructure) on many small random
+problems and option combinations -- families, weights, always_select, lambda grids, CV, golden section, groups,
+both LM score-pass forms.  Every PDAS iteration's active set must match; coefficients to 1e-6.
+  python tests/fuzz_parity.py [cases] [seed]        (FUZZ_SCALE=medium: n up to 30 000, p up to 4 000)
+tests/test_fuzz_gpu.py runs a fixed slice of it in the GPU suite."""
+import sys
+import time
+
+import numpy as np
+
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bess_amd import capi, synth  # noqa: E402
+from helpers import assert_same_trace  # noqa: E402
+from oracle import port_ctypes as P  # noqa: E402
+from test_lm_gpu import run_gpu  # noqa: E402
+
+
+
+def run(cases=100, seed=1, medium=False, verbose=True):
+    """Returns the number of failing cases."""
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    fails = 0
+    for c in range(cases):
+        fam = rng.choice(["lm", "lm", "lm", "logit", "poisson", "cox"])
+        if medium:  # FUZZ_SCALE=medium: shapes that take the multi-block / multi-slab / two-level paths
+            n = int(rng.integers(3000, 30000))
+            p = int(rng.integers(300, 4000))
+        else:
+            n = int(rng.integers(80, 1500))
+            p = int(rng.integers(8, 400))
+        kt = int(min(max(2, p // 6), rng.integers(2, 12)))
+        seed = int(rng.integers(1, 1 << 30))
+        kw = {}
+        if fam == "lm":
+            X, y, _, _ = synth.make_lm(n, p, kt, seed=seed)
+            kw["score_mode"] = int(rng.integers(1, 3))
+        elif fam == "logit":
+            X, y, _, _ = synth.make_logistic(n, p, kt, seed=seed)
+            kw.update(data_type=2, model_type=2)
+        elif fam == "poisson":
+            X = np.random.default_rng(seed).standard_normal((n, p))
+            b = np.zeros(p)
+            b[:kt] = np.random.default_rng(seed + 1).uniform(-0.4, 0.4, kt)
+            y = np.random.default_rng(seed + 2).poisson(np.exp(np.clip(X @ b, -4, 3))).astype(float)
+            kw.update(data_type=2, model_type=3)
+        else:
+            X, _, y, _, _ = synth.make_cox(n, p, kt, seed=seed)
+            kw.update(data_type=3, model_type=4)
+        kmax = int(min(p, n // 4, rng.integers(3, 60 if medium else 25)))
+        if rng.random() < 0.25:
+            kw["weight"] = rng.uniform(0.5, 2.0, n)
+        if rng.random() < 0.2:
+            kw["is_warm_start"] = False
+        if rng.random() < 0.15:
+            kw["max_iter"] = int(rng.integers(2, 6))
+        if rng.random() < 0.2 and fam != "cox":
+            kw["is_normal"] = bool(rng.random() < 0.5)
+        mode = rng.choice(["seq", "seq", "gs", "lam", "cv", "grp", "powell", "scr"])
+        if mode == "scr" and fam == "poisson":
+            mode = "seq"  # (Poisson screening is refused: undefined behaviour in the reference)
+        if mode == "gs":
+            kw.update(path_type=2, s_min=1, s_max=kmax)
+        elif mode == "lam":
+            kw.update(sequence=np.arange(1, max(3, kmax // 2)), lambda_seq=sorted(rng.uniform(0, 0.2, int(rng.integers(2, 4)))))
+        elif mode == "cv":
+            K = int(rng.integers(2, 6))
+            kw.update(is_cv=True, K=K, cv_fold_id=synth.make_cv_folds(n, K, seed=seed), sequence=np.arange(1, max(3, kmax // 2)))
+        elif mode == "grp" and p >= 12 and not (medium and fam == "cox"):  # (the oracle's Cox group branch is O(n^2))
+            cuts = np.sort(rng.choice(np.arange(1, p), min(p - 1, int(rng.integers(3, max(4, p // 3)))), replace=False))
+            gi = np.concatenate([[0], cuts]).astype(np.int32)
+            if np.max(np.diff(np.append(gi, p))) > 16:
+                gi = np.arange(0, p, 3).astype(np.int32)
+            kw.update(algorithm_type=2, g_index=gi, sequence=np.arange(1, min(len(gi), 6)))
+            kw.pop("score_mode", None)
+        elif mode == "powell":
+            kw.update(algorithm_type=5, path_type=3, s_min=1, s_max=max(2, kmax), lambda_min=0.001,
+                      lambda_max=float(rng.uniform(0.05, 0.5)), nlambda=int(rng.integers(4, 10)),
+                      powell_path=int(rng.integers(1, 3)))
+            kw.pop("is_normal", None)
+        elif mode == "scr" and p >= 20 and max(kmax + 2, 8) < p:
+            kw["screening_size"] = int(rng.integers(max(kmax + 2, 8), p))
+            kw["sequence"] = np.arange(1, kmax + 1)
+            kw.pop("is_normal", None)
+        else:
+            kw["sequence"] = np.arange(1, kmax + 1)
+        if mode not in ("grp", "powell", "scr") and rng.random() < 0.2 and kmax >= 3:
+            al = sorted(rng.choice(p, 2, replace=False).tolist())
+            kw["always_select"] = al
+            if "sequence" in kw:
+                kw["sequence"] = np.arange(3, max(4, kmax))
+            else:
+                kw["s_min"] = 3
+                kw["s_max"] = max(4, kmax)
+        kw["ic_type"] = int(rng.integers(1, 5))
+        okw = {k: v for k, v in kw.items() if k != "score_mode"}
+        if medium:
+            print("case %d: %s n=%d p=%d mode=%s kmax=%d ..." % (c, fam, n, p, mode, kmax), flush=True)
+        try:
+            if "screening_size" in kw:
+                okw.pop("screening_size")
+                want = P.trace_screened(X, y, kw["screening_size"], **okw)
+                want["beta"] = want["beta_screened"]  # the traces are in the screened numbering on both sides
+            else:
+                want = P.trace(X, y, **okw)
+            got = run_gpu(capi, X, y, kw)
+            if "screening_size" in kw:
+                assert np.array_equal(got["screening_A"], want["screening_A"]), "kept columns differ"
+            # LM information criteria are n log(loss) + ...: a loss that agrees to 1e-10 relative moves them by 1e-10 n
+            # (Cox with a ridge that can outweigh the information matrix: an indefinite Newton system, coefficients to 1e-4)
+            loose = fam == "cox" and mode in ("lam", "powell")
+            if loose:
+                assert len(got["trace"]["fits"]) == len(want["fits"])
+                for a, b in zip(got["trace"]["fits"], want["fits"]):
+                    assert len(a["iters"]) == len(b["iters"]) and all(np.array_equal(u, v) for u, v in zip(a["iters"], b["iters"]))
+                    for u, v in zip(a["betas"], b["betas"]):
+                        assert np.max(np.abs(u - v)) <= 1e-4 * max(np.max(np.abs(v)), 1e-300)
+            else:
+                assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="case %d" % c, ic_atol=1e-9 * n)
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print("CASE %d FAILED: fam=%s n=%d p=%d seed=%d mode=%s kw=%r\n  %s" % (
+                c, fam, n, p, seed, mode, {k: (v if np.size(v) < 8 else "...") for k, v in kw.items()}, str(e)[:300]), flush=True)
+        if c % (5 if medium else 25) == (4 if medium else 24):
+            print("%d cases, %d failures, %.0f s" % (c + 1, fails, time.time() - t0), flush=True)
+
+    if verbose:
+        print("fuzz done: %d cases, %d failures" % (cases, fails))
+    return fails
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    sys.exit(1 if run(n_cases, sd, os.environ.get("FUZZ_SCALE") == "medium") else 0)

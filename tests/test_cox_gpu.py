@@ -107,7 +107,7 @@ def test_cox_groups_need_the_group_algorithm(gpu):
 def test_cox_newton_system_that_is_not_positive_definite(gpu):
     """A ridge term that outweighs the information matrix (small n, lambda > 0.1; the reference adds 2 lambda with the
     sign that subtracts, src/Algorithm.h:1471) makes the Newton system indefinite: the Cholesky kernel gives up and
-    the LDL^T fallback kernel solves it, as the reference's LDLT does.  Found by tools/fuzz_parity.py (seed 1, case
+    the LDL^T fallback kernel solves it, as the reference's LDLT does.  Found by tests/fuzz_parity.py (seed 1, case
     59).  Supports are compared exactly; the coefficients of such a system only to 1e-5."""
     X, _, status, _, _ = synth.make_cox(97, 272, 9, seed=222610918)
     kw = dict(COX, max_iter=3, sequence=np.arange(3, 15), lambda_seq=[0.12957971161634982, 0.15912213204776818,
