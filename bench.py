@@ -188,6 +188,10 @@ def main():
         n_cand = args.kmax * args.steps * (1 if kpath else world)
         value = n_cand / dt
         roof = roofline_of(k1, covariance)
+        try:  # the spec peak next to a ceiling measured on this very device (read + write of a D2D copy)
+            roof["measured_stream_copy_GBps"] = capi.op_stream_copy_gbps(1 << 30, 10)
+        except Exception:
+            roof["measured_stream_copy_GBps"] = None
         line = {
             "metric": "candidate subsets solved/sec (n=50k,p=10k,k<=200 LM)", "value": value,
             "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
