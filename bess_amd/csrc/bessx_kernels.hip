@@ -4148,7 +4148,10 @@ __global__ void __launch_bounds__(256) k_cov_panel(const double *__restrict__ X,
 // streamed tile w with both right-hand-side tiles.  Loads of chunk k+1 are in flight while chunk k is multiplied;
 // one barrier per chunk.
 constexpr int CP_RB = 64;            // rows per chunk
-constexpr int CP_LD = CP_RB + 2;     // padded row stride of a column in LDS (doubles)
+#ifndef CP_PAD
+#define CP_PAD 2
+#endif
+constexpr int CP_LD = CP_RB + CP_PAD;  // padded row stride of a column in LDS (doubles)
 constexpr int CP_COLS = 64 + COV_R;  // columns staged per chunk
 template <bool MASKED, bool DB>
 __global__ void __launch_bounds__(256) k_cov_panel_lds(const double *__restrict__ X, const double *__restrict__ aux,
