@@ -2,25 +2,38 @@
 """bench.py -- candidate subsets solved per second on BASELINE configs[1]:
 LM sequential path, synthetic Gaussian n=50000, p=10000, s.list = 1..200, GIC, warm start, max_iter 20.
 
-A "step" is one pass of the hot path over one batch: the full 200-candidate warm-start chain
-(Algorithm::fit to PDAS convergence + train_loss + ic per candidate) on data that is already
-resident in HBM (upload + normalisation are untimed and reported separately).
+A "step" is one pass of the hot path over one batch: the full 200-candidate path (Algorithm::fit to PDAS
+convergence + train_loss + ic per candidate) on data that is already resident in HBM (upload + normalisation are
+untimed and reported separately; the one pass over X for X^T y / diag(X^T X), which the reference does inside
+sequential_path (src/path.cpp:37), happens at session creation here: ~0.6 ms, `group_XTX_ms_outside_step`).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n N --p P --kmax KMAX] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lm-seq|lm-cv-gs] [--shard kpath|replica]
+                  [--n N --p P --kmax KMAX] [--no-cpu-baseline]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  The units that shard are
-independent candidate chains: every rank holds a replica of X and solves the same 200-candidate
-path for its OWN response vector (same X beta, rank-specific noise seed), i.e. N independent
-best-subset problems per step.  There is no data-path collective; the per-candidate IC curves are
-all-gathered over RCCL at the end of each step (8 B per candidate), as north_star prescribes.
---shard kpath switches to strong scaling instead: ONE problem, s.list cut into N contiguous warm-start
-chains (bess_amd/dist.py partition), IC curve all-gathered, best k picked on every rank.
+--gpus N > 1 without a launcher (WORLD_SIZE unset): this process starts N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU)
+BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the launcher's code.  Under a launcher,
+WORLD_SIZE must equal --gpus.
+
+N > 1, default (--shard kpath): STRONG scaling of the ONE configs[1] problem.  X is replicated; s.list = 1..200 is
+cut into N contiguous chunks, each chunk one warm-start chain (bess_amd/dist.py partition); no data-path collective;
+the IC curve (8 B per candidate) is all-gathered over RCCL each step and every rank picks the best k.  A chunk's
+first candidate starts cold, so its chain can differ from the single chain's: after the timed
+region rank 0 runs the single chain and the line reports for how many k the supports agree.
+--shard replica: WEAK scaling, N independent problems (rank-specific response on the same design).
+--workload lm-cv-gs: BASELINE configs[3] (gs_path on [1, kmax] under 5-fold CV), the K fold chains + the full-data
+chain and, in the final sweep, (fold x s) pairs dealt to the ranks (bess_amd.dist.FoldShardedCV).
+
+BESSX_BENCH_ONE_DEVICE=1 rehearses the N-rank path on a box with ONE GPU (ranks share device 0, collectives over
+gloo) -- never what the driver runs.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,47 +45,13 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)
+# the one full-path run of the compiled reference that exists (it produced tests/golden/fullsize_lm.npz)
+RECORDED_FULL_PATH = {"seconds": 10038.0, "candidates": 200, "value": 200 / 10038.0, "unit": "candidates/s",
+                      "cores": 1, "host": "build container (8 vCPU), not the GPU box",
+                      "source": "tests/golden/fullsize_lm.npz: ref_wall_seconds (tests/golden/make_fullsize_ref.py lm)"}
 
 
-def make_problem(n, p, k_true, rank):
-    """configs[1] inputs (bess_amd/synth.py).  rank 0 is exactly the BASELINE problem; other ranks
-    replace the noise vector by a rank-seeded one (an independent problem on the same design)."""
-    from bess_amd import synth
-    X, y, support, beta = synth.make_lm(n, p, k_true)
-    if rank > 0:
-        rng = np.random.Generator(np.random.PCG64(synth.SEED_LM + 1000 * rank))
-        y = X[:, support] @ beta[support] + rng.standard_normal(n)
-    return X, y
-
-
-def cpu_baseline(X, y, budget_s=30.0):
-    """Time the CPU path on this host, one thread, on a bounded sample of the same workload: the first
-    candidates (k = 1, 2, 3) of the same warm-start chain on the same full-size data.
-    Preferred: the reference's own Eigen build (oracle/_ref/libbess_ref.so, compiled from the reference sources
-    with the package flags -O2 -DNDEBUG -std=c++11; single-threaded by construction) -> kind "reference".
-    Fallback when that library did not travel: the plain-C oracle -> kind "port".
-    value = steady-state candidates/s = (kmax - 1) / (t[k=1..kmax] - t[k=1]), i.e. without the one-time copy /
-    normalisation the GPU number also excludes."""
-    from oracle import ref_ctypes as R
-    from oracle import port_ctypes as P
-    use_ref = R.available()
-    run = (lambda seq: R.trace(X, y, ic_type=3, sequence=seq)) if use_ref else \
-          (lambda seq: P.trace(X, y, ic_type=3, sequence=seq))
-    t0 = time.time()
-    run([1])
-    t1 = time.time() - t0
-    kmax = 3 if 3.5 * t1 < budget_s else 2
-    t0 = time.time()
-    run(list(range(1, kmax + 1)))
-    tk = time.time() - t0
-    per = max((tk - t1) / (kmax - 1), 1e-9)
-    return {"value": 1.0 / per, "unit": "candidates/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": "k=1..%d of the same sequential path on the full n=%d p=%d data: %.1f s (k=1 alone, incl. one-time "
-                      "copy+normalise: %.1f s); value = steady-state rate, incl. set-up it is %.3f candidates/s; host has "
-                      "%d cores, 1 used" % (kmax, X.shape[0], X.shape[1], tk, t1, kmax / tk, os.cpu_count())}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -81,29 +60,150 @@ def main():
     ap.add_argument("--p", type=int, default=10000)
     ap.add_argument("--kmax", type=int, default=200)
     ap.add_argument("--k-true", type=int, default=100)
+    ap.add_argument("--workload", choices=["lm-seq", "lm-cv-gs"], default="lm-seq")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard", choices=["replica", "kpath"], default="replica")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per timed segment")
+    ap.add_argument("--shard", choices=["auto", "replica", "kpath"], default="auto",
+                    help="N > 1: kpath (default) = strong scaling of one problem; replica = weak scaling")
     ap.add_argument("--score-mode", choices=["auto", "streaming", "covariance"], default="auto",
                     help="evaluation of the LM score pass (include/bessx.h, bessx_problem.score_mode)")
     ap.add_argument("--no-streaming-leg", action="store_true",
                     help="skip the extra (untimed-by-contract) measurement of the streaming score pass at N=1")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """--gpus N > 1 and no launcher: start N fresh ranks.  Nothing in this process has touched the GPU
+    (torch.cuda.device_count() does not initialise it), and it never exec()s: the ranks are children."""
+    one_dev = os.environ.get("BESSX_BENCH_ONE_DEVICE") == "1"
+    if not one_dev:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print("bench.py: --gpus %d but %d visible (BESSX_BENCH_ONE_DEVICE=1 rehearses on one device)"
+                  % (args.gpus, have), file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    # the ranks read their arguments from the environment: torchrun's own parser trips over script options that
+    # are prefixes of its own (--n / --nnodes); --gpus is repeated on the command line for readability only
+    env["BESSX_BENCH_ARGV"] = json.dumps(sys.argv[1:])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus)]
+    return subprocess.call(cmd, env=env)
+
+
+def make_problem(n, p, k_true, rank):
+    """configs[1] inputs (bess_amd/synth.py).  rank 0 is exactly the BASELINE problem; in the weak-scaling mode the
+    other ranks replace the noise vector by a rank-seeded one (an independent problem on the same design)."""
+    from bess_amd import synth
+    X, y, support, beta = synth.make_lm(n, p, k_true)
+    if rank > 0:
+        rng = np.random.Generator(np.random.PCG64(synth.SEED_LM + 1000 * rank))
+        y = X[:, support] @ beta[support] + rng.standard_normal(n)
+    return X, y
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(X, y, gpu_out, sess_norm, kmax, budget_s):
+    """The reference's Eigen path (oracle/_ref/libbess_ref.so: the reference sources compiled with the package's own
+    flags -O2 -DNDEBUG -std=c++11, single-threaded by construction) timed on THIS host, pinned to one core, on a
+    bounded sample of the same workload -- two segments of the same warm-start chain on the same full-size data:
+    the head (k = 1, 2, ...) and the far end (k = 181, ... started from the k = 180 model, which is taken from the
+    GPU path: same support, coefficients within 1e-6), each for about `budget_s` seconds.  A candidate = fit +
+    train_loss + ic, as in sequential_path (src/path.cpp:48-74).  value = candidates timed / their seconds over
+    both segments; set-up (copy + normalise) is excluded like the GPU figure excludes upload + normalise.
+    Fallback when the compiled reference did not travel: the plain-C oracle on the head segment -> kind "port"."""
+    from oracle import ref_ctypes as R
+    from oracle import port_ctypes as P
+    n, p = X.shape
+    pinned = None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        pinned = cores[len(cores) // 2]
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        cores = []
+    try:
+        base = {"unit": "candidates/s", "cores": 1, "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+                "pinned_to_core": pinned, "recorded_full_path": RECORDED_FULL_PATH}
+        if not R.available():
+            t0 = time.time()
+            P.trace(X, y, ic_type=3, sequence=[1])
+            t1 = time.time() - t0
+            t0 = time.time()
+            P.trace(X, y, ic_type=3, sequence=[1, 2, 3])
+            t3 = time.time() - t0
+            base.update({"value": 2.0 / max(t3 - t1, 1e-9), "kind": "port",
+                         "sample": "plain-C oracle, k=2..3 of the chain (k=1..3: %.1f s, k=1: %.1f s)" % (t3, t1)})
+            return base
+        head = R.time_chain(X, y, np.arange(1, kmax + 1), budget_s=budget_s)
+        segs = [("k=1..%d" % len(head["seconds"]), head)]
+        k0 = min(180, kmax - 2)
+        if k0 >= 4:
+            xm, xn, ym = sess_norm
+            sup = gpu_out["cand_support"][k0 - 1][:k0]
+            init = gpu_out["cand_beta"][k0 - 1][:k0] * xn[sup] / np.sqrt(float(n))  # back to the normalised scale
+            tail = R.time_chain(X, y, np.arange(k0 + 1, kmax + 1), init_idx=sup, init_val=init, budget_s=budget_s)
+            ok = list(tail["iters"]) == list(gpu_out["cand_iters"][k0:k0 + len(tail["iters"])])
+            segs.append(("k=%d..%d (started from the k=%d model)" % (k0 + 1, k0 + len(tail["seconds"]), k0), tail))
+        else:
+            ok = None
+        cnt = sum(len(s["seconds"]) for _, s in segs)
+        sec = sum(float(np.sum(s["seconds"])) for _, s in segs)
+        base.update({
+            "value": cnt / sec, "kind": "reference",
+            "segments": [{"candidates": name, "seconds_per_candidate": [round(float(v), 3) for v in s["seconds"]],
+                          "pdas_iterations": [int(v) for v in s["iters"]],
+                          "setup_seconds": round(s["setup_seconds"], 2)} for name, s in segs],
+            "tail_iterations_match_gpu": ok,
+            "sample": "%d candidates of the same chain on the full n=%d p=%d data in %.1f s: %s; package build "
+                      "(-O2, 1 thread); an -O3 -march=x86-64-v3 -fopenmp build of the same sources is timed by "
+                      "oracle/ref_cpu_timing.py (profiles/README.md)" % (cnt, n, p, sec, " + ".join(s for s, _ in segs))})
+        return base
+    finally:
+        if cores:
+            os.sched_setaffinity(0, set(cores))
+
+
+def main():
+    inherited = os.environ.pop("BESSX_BENCH_ARGV", None)  # set by launch_ranks() for its children
+    args = parse_args(json.loads(inherited) if inherited else None)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
-    from bess_amd import capi
+    from bess_amd import capi, synth
     from bess_amd import dist as bdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libbessx has no CPU path")
-    # rehearsal of the N-rank path on a box with ONE GPU (never what the driver runs): all ranks share device 0 and
-    # the IC curves travel over gloo -- BESSX_BENCH_ONE_DEVICE=1 BESSX_BENCH_BACKEND=gloo
-    if os.environ.get("BESSX_BENCH_ONE_DEVICE") == "1":
+    one_dev = os.environ.get("BESSX_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
         local_rank = 0
-    backend = os.environ.get("BESSX_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("BESSX_BENCH_BACKEND", "gloo" if one_dev else "nccl")
     comm_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     distributed = world > 1
@@ -119,12 +219,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kpath = args.shard == "kpath" and distributed
-    X, y = make_problem(args.n, args.p, args.k_true, 0 if kpath else rank)
-    seq = np.arange(1, args.kmax + 1)
+    def max_over_ranks(dt):
+        if not distributed:
+            return dt
+        t = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.workload == "lm-cv-gs":
+        return bench_cv(args, world, rank, local_rank, comm_dev, barrier, max_over_ranks)
+
+    shard = args.shard if args.shard != "auto" else "kpath"
+    kpath = shard == "kpath" and distributed
+    X, y = make_problem(args.n, args.p, args.k_true, 0 if (kpath or not distributed) else rank)
+    full_seq = np.arange(1, args.kmax + 1)
+    seq = full_seq
     if kpath:
         lo, hi = bdist.partition(args.kmax, world, rank)
-        seq = seq[lo:hi]
+        seq = full_seq[lo:hi]
     t0 = time.time()
     mode = {"auto": 0, "streaming": 1, "covariance": 2}[args.score_mode]
     sess = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
@@ -150,31 +262,51 @@ def main():
         elif distributed:
             ic_curves = bdist.gather_rows(out["cand_ic"], world, device=comm_dev)
     barrier()
-    dt = time.time() - t0
-    if distributed:
-        tmax = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(time.time() - t0)
     k1 = sess.score_pass_stats()
     sess.enable_kernel_timing(False)
+
+    chunk_report = None
+    if kpath:
+        # compare the chunked chains with the single warm-start chain, after the timed region
+        sup = np.full((args.kmax, args.kmax), -1.0)
+        sup[lo:hi, :out["cand_support"].shape[1]] = out["cand_support"]
+        allsup = bdist.gather_rows(sup.ravel(), world, device=comm_dev)
+        rank_seconds = bdist.gather_rows(np.array([out["device_seconds"]]), world, device=comm_dev).ravel()
+        if rank == 0:
+            chunked = np.full((args.kmax, args.kmax), -1, dtype=np.int64)
+            for r in range(world):
+                a, b = bdist.partition(args.kmax, world, r)
+                chunked[a:b] = allsup[r].reshape(args.kmax, args.kmax)[a:b]
+            single = sess.sequential_path(full_seq, ic_type=3)
+            same = [bool(np.array_equal(chunked[k, :k + 1], single["cand_support"][k, :k + 1])) for k in range(args.kmax)]
+            chunk_report = {
+                "chunks": [list(map(int, (bdist.partition(args.kmax, world, r)[0] + 1,
+                                          bdist.partition(args.kmax, world, r)[1]))) for r in range(world)],
+                "supports_equal_to_single_chain": int(np.sum(same)), "of": args.kmax,
+                "differing_k": [int(k + 1) for k in range(args.kmax) if not same[k]][:40],
+                "best_k_chunked": int(bdist.select_best(ic_curves[0])) + 1, "best_k_single_chain": int(single["best_T0"]),
+                "seconds_per_rank_last_step": [round(float(v), 5) for v in rank_seconds]}
 
     def roofline_of(stats, cov):
         """HBM roofline of the kernel that streams X: algorithmic bytes (8 n p per pass over X) / its HIP-event time."""
         passes = stats["algorithmic_bytes"] / (8.0 * args.n * args.p)
         per_pass = stats["seconds"] / passes if passes else 0.0
         achieved = 8.0 * args.n * args.p / per_pass / 1e9 if passes else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and (args.n, args.p) == (50000, 10000):
             try:
                 traffic = json.load(open(tpath)).get("k_cov_panel_hbm_bytes_per_pass" if cov else
                                                      "k_xtv_hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, " \
+                              "not measured in this run)"
             except Exception:
                 traffic = None
-        kern = ("k_cov_panel_lds (X^T diag(m) X_S on the fp64 matrix cores: 32 new Gram columns per pass over X)"
+        kern = ("k_cov_panel (X^T diag(m) X_S on the fp64 matrix cores: 32 new Gram columns per pass over X)"
                 if cov else "k_xtv<8,16,false> (X^T r score pass)")
         roof = {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": 8.0 * args.n * args.p, "avg_launch_ms": 1e3 * per_pass,
                 "launches_timed": stats["launches"], "passes_over_X_timed": passes}
         if cov and per_pass:
@@ -185,24 +317,40 @@ def main():
         return roof
 
     if rank == 0:
-        n_cand = args.kmax * args.steps * (1 if kpath else world)
+        n_cand = args.kmax * args.steps * (1 if (kpath or not distributed) else world)
         value = n_cand / dt
         roof = roofline_of(k1, covariance)
         try:  # the spec peak next to a ceiling measured on this very device (read + write of a D2D copy)
             roof["measured_stream_copy_GBps"] = capi.op_stream_copy_gbps(1 << 30, 10)
         except Exception:
             roof["measured_stream_copy_GBps"] = None
+        step_s = dt / args.steps
+        x_seconds = k1["seconds"] / args.steps
         line = {
             "metric": "candidate subsets solved/sec (n=50k,p=10k,k<=200 LM)", "value": value,
             "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if kpath else "weak",
+            "ms_per_step": 1e3 * step_s, "higher_is_better": True,
+            "scaling": "strong" if (kpath or not distributed) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: LM sequential path, Gaussian X n=%d p=%d, s.list=1..%d, GIC, "
                                    "warm start, max_iter=20, is_normal" % (args.n, args.p, args.kmax),
-                       "candidates_per_step_per_gpu": args.kmax, "units_sharded": "independent candidate chains "
-                       "(one response vector per rank on a replicated X)", "collective": "all_gather of the IC curve",
+                       "candidates_per_step": args.kmax * (1 if (kpath or not distributed) else world),
+                       "units_sharded": ("contiguous chunks of s.list, one warm-start chain per rank, X replicated"
+                                         if kpath else "independent problems (one response vector per rank on a "
+                                         "replicated X)" if distributed else "none (one GPU)"),
+                       "collective": "all_gather of the IC curve" if distributed else "none",
                        "score_pass": "covariance updates (cached Gram columns)" if covariance else "streaming"},
             "roofline": roof,
+            # the WHOLE step against the HBM roof: bytes the step streams from X / step time, and where the time goes
+            "whole_step": {"bytes_streamed_from_X": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p,
+                           "achieved_GBps": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p / step_s / 1e9,
+                           "frac_of_hbm_peak": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p / step_s
+                           / 1e9 / HBM_PEAK_GBPS,
+                           "time_share": {"kernel_streaming_X": x_seconds / step_s,
+                                          "candidate_chain_and_host (selection, k x k solve, p x k GEMV, publish)":
+                                          1.0 - x_seconds / step_s}},
+            "group_XTX_ms_outside_step": "X^T y and diag(X^T X) (one pass over X, src/path.cpp:37) are formed at "
+                                         "session creation, inside upload_and_normalise_seconds",
             "passes_over_X_per_candidate": roof["passes_over_X_timed"] / float(len(seq) * args.steps),
             "pdas_iterations_per_candidate": pdas_iters / float(len(seq) * args.steps),
             # I_k of SURVEY 8d: PDAS iterations Algorithm::fit took per candidate (identical to the reference's,
@@ -210,8 +358,12 @@ def main():
             "pdas_iterations_histogram": {str(int(k)): int(v) for k, v in
                                           zip(*np.unique(out["cand_iters"], return_counts=True))},
             "upload_and_normalise_seconds": upload_s,
-            "selected_k": int(out["best_T0"]), "selected_ic": float(out["ic"]),
+            "selected_k": int(out["best_T0"]) if not kpath else chunk_report["best_k_chunked"],
+            "selected_ic": float(out["ic"]) if not kpath else float(np.min(ic_curves[0])),
         }
+        if chunk_report:
+            line["kpath_chunks_vs_single_chain"] = chunk_report
+        norm = sess.normalization() if world == 1 else None
         if covariance and world == 1 and not args.no_streaming_leg:
             # the other evaluation of the same path (every PDAS iteration reads X once), for comparison
             sess.close()
@@ -229,21 +381,69 @@ def main():
             s2.close()
             line["streaming_score_pass"] = {
                 "value": len(seq) / d2, "unit": "candidates/s", "steps": 1, "roofline": roofline_of(st2, False),
+                "whole_step_frac_of_hbm_peak": st2["launches"] * 8.0 * args.n * args.p / d2 / 1e9 / HBM_PEAK_GBPS,
                 "passes_over_X_per_candidate": st2["launches"] / float(len(seq)),
                 "same_selection": bool(int(o2["best_T0"]) == int(out["best_T0"]) and
                                        np.array_equal(np.nonzero(o2["beta"])[0], np.nonzero(out["beta"])[0]))}
-        if ic_curves is not None:
+        if ic_curves is not None and not kpath:
             line["ic_curves_gathered"] = int(ic_curves.shape[0])
             line["best_k_per_problem"] = [int(bdist.select_best(c)) + 1 for c in ic_curves]
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(X, y)
+                line["cpu_baseline"] = cpu_baseline(X, y, out, norm, args.kmax, args.cpu_budget)
             except Exception as e:  # the checker is optional for the measurement itself
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": 1, "kind": "port",
                                         "sample": "failed: %r" % (e,)}
         print(json.dumps(line))
+        sys.stdout.flush()
     sess.close()
     if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_cv(args, world, rank, local_rank, comm_dev, barrier, max_over_ranks):
+    """BASELINE configs[3]: gs_path on [1, kmax] with 5-fold CV, fold chains (and, in the final sweep, fold x s
+    pairs) dealt to the ranks; a step = one whole golden-section path.  candidates = distinct (s) evaluated by the
+    path; fits = Algorithm::fit calls (full data + folds)."""
+    import torch
+    import torch.distributed as dist
+    from bess_amd import capi, synth
+    from bess_amd import dist as bdist
+    X, y, _, _ = synth.make_lm(args.n, args.p, args.k_true)
+    t0 = time.time()
+    sess = capi.Session(X, y, data_type=1, model_type=1, device=local_rank)
+    sess.set_cv(5, synth.make_cv_folds(args.n, 5))
+    del X
+    torch.cuda.synchronize()
+    upload_s = time.time() - t0
+    cdev = "cuda" if comm_dev == "cuda" else None
+    out = None
+    for _ in range(args.warmup):
+        out = bdist.FoldShardedCV(sess, 5, world, rank, device=cdev).gs_path(1, args.kmax)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        out = bdist.FoldShardedCV(sess, 5, world, rank, device=cdev).gs_path(1, args.kmax)
+    barrier()
+    dt = max_over_ranks(time.time() - t0)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "candidate subsets solved/sec (n=50k,p=10k, LM gs_path + 5-fold CV)",
+            "value": out["n_candidates"] * args.steps / dt, "unit": "candidates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[3]: LM golden-section path on [1,%d] + 5-fold CV, Gaussian X n=%d p=%d, "
+                                   "fixed folds (synth.make_cv_folds)" % (args.kmax, args.n, args.p),
+                       "units_sharded": "5 fold chains + the full-data chain (unit u on rank u %% N); final sweep: "
+                                        "(fold x s) pairs", "collective": "all_gather of the fit records"},
+            "fits_per_s": out["n_fits"] * args.steps / dt, "fits_per_step": int(out["n_fits"]),
+            "pdas_iterations_per_step": int(out["n_pdas_iters"]), "evaluation_rounds": int(out["evaluations"]),
+            "selected_k": int(out["best_T0"]), "cv_loss": float(out["ic"]), "upload_and_normalise_seconds": upload_s}))
+        sys.stdout.flush()
+    sess.close()
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -30,6 +30,9 @@ SYMBOLS = [
 ]
 
 
+MAX_SPARSITY = 16382  # T0_HARD of bessx_host.cpp: the largest bessx_problem.max_sparsity
+
+
 class BessxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libbessx error %d: %s" % (code, msg))
@@ -41,7 +44,7 @@ class Problem(ctypes.Structure):
                 ("is_normal", _i), ("model_type", _i), ("algorithm_type", _i), ("max_iter", _i),
                 ("is_warm_start", _i), ("always_select", _I), ("always_select_len", _i), ("device", _i),
                 ("group_index", _I), ("group_index_len", _i),
-                ("is_screening", _i), ("screening_size", _i), ("score_mode", _i)]
+                ("is_screening", _i), ("screening_size", _i), ("score_mode", _i), ("max_sparsity", _i)]
 
 
 class PathResult(ctypes.Structure):
@@ -172,7 +175,7 @@ class Session:
 
     def __init__(self, x, y, weight=None, data_type=1, is_normal=True, model_type=1, algorithm_type=1, max_iter=20,
                  is_warm_start=True, always_select=(), x_col_major=False, device=-1, g_index=None,
-                 is_screening=False, screening_size=0, score_mode=0):
+                 is_screening=False, screening_size=0, score_mode=0, max_sparsity=0):
         x = np.asfortranarray(x, dtype=np.float64) if x_col_major else _f64(x)
         self.n, self.p = x.shape
         y = _f64(y).reshape(-1)
@@ -186,7 +189,8 @@ class Session:
             self._gsize_max = int(np.max(np.diff(np.append(gi, self.p))))
         pb = Problem(self.n, self.p, _dp(x), int(x_col_major), _dp(y), _dp(w), data_type, int(is_normal), model_type,
                      algorithm_type, max_iter, int(is_warm_start), _ip(al), al.size, device, _ip(gi),
-                     0 if gi is None else gi.size, int(is_screening), int(screening_size), int(score_mode))
+                     0 if gi is None else gi.size, int(is_screening), int(screening_size), int(score_mode),
+                     int(max_sparsity))
         h = _vp()
         _check(lib().bessx_session_create(ctypes.byref(h), ctypes.byref(pb)))
         self._h = h

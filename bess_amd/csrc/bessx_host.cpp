@@ -66,7 +66,8 @@ struct Trace {
 };
 
 static constexpr int T0_FAST = 254;  // fast path: m + 1 <= 256 lives in the registers of k_chol (with an intercept)
-static constexpr int T0_CAP = 2046;  // blocked global-memory Cholesky beyond that: m + 2 <= 2048
+static constexpr int T0_CAP = 2046;   // default capacity of a session (bessx_problem.max_sparsity = 0): m + 2 <= 2048
+static constexpr int T0_HARD = 16382;  // largest capacity a session can be created with: m + 2 <= 16384
 
 }  // namespace bessx
 
@@ -232,6 +233,7 @@ struct bessx_session {
   // host statistics
   std::vector<double> x_mean_h, x_norm_h;
   double y_mean_h = 0.0;
+  double nullloss = 0.0;  // Data::get_nullloss (src/Data.h:120-130)
   // Algorithm state (reference member names in comments)
   SparseVec beta;                 // Algorithm::beta
   double coef0 = 0.0;             // Algorithm::coef0
@@ -425,11 +427,18 @@ static int cov_collect(bessx_session *s, int nfill) {
 
 static int alloc_gram_cache(bessx_session *s) {
   bessx_session::GramCache c;
-  HIPX(dmalloc(&c.g0, (size_t)256 * 256));
-  HIPX(dmalloc(&c.g1, (size_t)256 * 256));
-  HIPX(dmalloc(&c.A, 256));
-  HIPX(dmalloc(&c.meta, 2));
-  HIPX(hipMemset(c.meta, 0, 2 * sizeof(int)));
+  hipError_t e = dmalloc(&c.g0, (size_t)256 * 256);
+  if (e == hipSuccess) e = dmalloc(&c.g1, (size_t)256 * 256);
+  if (e == hipSuccess) e = dmalloc(&c.A, 256);
+  if (e == hipSuccess) e = dmalloc(&c.meta, 2);
+  if (e == hipSuccess) e = hipMemset(c.meta, 0, 2 * sizeof(int));
+  if (e != hipSuccess) {  // nothing half-built is left behind
+    (void)hipFree(c.g0);
+    (void)hipFree(c.g1);
+    (void)hipFree(c.A);
+    (void)hipFree(c.meta);
+    return fail(BESSX_ERR_HIP, std::string("Gram cache: ") + hipGetErrorString(e));
+  }
   s->gcache.push_back(c);
   return 0;
 }
@@ -440,13 +449,20 @@ static constexpr int COV_CS = 512;         // side of the slot-indexed Gram of t
 
 static int alloc_cov_cache(bessx_session *s) {
   bessx_session::CovCache c;
-  HIPX(dmalloc(&c.G, (size_t)s->p * s->cov_C));
-  HIPX(dmalloc(&c.slot_of, (size_t)s->p));
-  HIPX(dmalloc(&c.meta, 4));
-  HIPX(dmalloc(&c.GS, (size_t)COV_CS * COV_CS));
-  HIPX(hipMemset(c.GS, 0, (size_t)COV_CS * COV_CS * sizeof(double)));
-  HIPX(hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int)));
-  HIPX(hipMemset(c.meta, 0, 4 * sizeof(int)));
+  hipError_t e = dmalloc(&c.G, (size_t)s->p * s->cov_C);
+  if (e == hipSuccess) e = dmalloc(&c.slot_of, (size_t)s->p);
+  if (e == hipSuccess) e = dmalloc(&c.meta, 4);
+  if (e == hipSuccess) e = dmalloc(&c.GS, (size_t)COV_CS * COV_CS);
+  if (e == hipSuccess) e = hipMemset(c.GS, 0, (size_t)COV_CS * COV_CS * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(c.meta, 0, 4 * sizeof(int));
+  if (e != hipSuccess) {
+    (void)hipFree(c.G);
+    (void)hipFree(c.slot_of);
+    (void)hipFree(c.meta);
+    (void)hipFree(c.GS);
+    return fail(BESSX_ERR_HIP, std::string("Gram column cache: ") + hipGetErrorString(e));
+  }
   s->cov.push_back(c);
   return 0;
 }
@@ -1445,8 +1461,9 @@ static int algorithm_fit(bessx_session *s) {
   const int T0 = s->sparsity_level, rs = s->cur_rows;
   const double lambda = s->lambda_level;
   if (T0 < 1 || T0 > s->cap)
-    return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, min(p, " +
-                                   std::to_string(T0_CAP) + ")]");
+    return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, " + std::to_string(s->cap) +
+                                   "]: a session holds work space for min(p, max(2046, bessx_problem.max_sparsity))"
+                                   " active columns, max_sparsity <= " + std::to_string(T0_HARD));
   if (s->model_type == 4)
     if (int rc = cox_reserve(s, T0)) return rc;
   if (!topk_supported(s->p, T0)) return fail(BESSX_ERR_UNSUPPORTED, "top-k selection: p too large for this sparsity level");
@@ -2626,7 +2643,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->part2, (size_t)s->nrb * p));
   HIPT(dmalloc(&s->bd, (size_t)p));
   HIPT(dmalloc(&s->beta_dense, (size_t)p));
-  s->cap = std::min(p, T0_CAP);
+  if (pb->max_sparsity < 0 || pb->max_sparsity > T0_HARD)
+    return bail(fail(BESSX_ERR_ARG, "max_sparsity must be in [0, " + std::to_string(T0_HARD) + "]"));
+  s->cap = std::min(p, std::max(T0_CAP, pb->max_sparsity));
   s->capA = (s->cap + 2 + 15) / 16 * 16;
   s->capA = std::max(s->capA, 256);
   s->hist_stride = s->capA;
@@ -2744,6 +2763,18 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipMemcpy(s->x_mean_h.data(), s->x_mean, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
     HIPT(hipMemcpy(s->x_norm_h.data(), s->x_norm, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
     HIPT(hipMemcpy(&s->y_mean_h, s->y_mean_d, sizeof(double), hipMemcpyDeviceToHost));
+    {
+      // Data::get_nullloss, src/Data.h:120-130, on the response as Data holds it after normalize() (centred by the
+      // weighted mean for data_type 1) and, for the linear model, add_weight() (rows times sqrt(w), src/bess.cpp:97)
+      double acc = 0.0, wsum = 0.0;
+      for (int i = 0; i < n; i++) {
+        const double wi = pb->weight ? pb->weight[i] : 1.0;
+        const double yi = pb->y[i] - (pb->data_type == 1 && pb->is_normal ? s->y_mean_h : 0.0);
+        acc += (pb->model_type == 1 ? wi : 1.0) * yi * yi;
+        wsum += wi;
+      }
+      s->nullloss = pb->data_type == 1 ? acc / (double)n : 2.0 * std::log(2.0) * wsum;
+    }
   }
   // row set 0: all rows
   s->mask.push_back(nullptr);
@@ -2944,6 +2975,41 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
 
 void bessx_session_destroy(bessx_session *s) { session_free(s); }
 
+// Free everything bessx_session_set_cv allocated for the folds (row sets 1..K); every vector is walked by its own
+// length, so this is safe on the partly built state an allocation failure leaves behind.
+static void drop_folds(bessx_session *s) {
+  auto drop = [](std::vector<double *> &v) {
+    for (size_t i = 1; i < v.size(); i++) (void)hipFree(v[i]);
+    if (!v.empty()) v.resize(1);
+  };
+  drop(s->mask);
+  drop(s->xtx);
+  drop(s->xty);
+  drop(s->part_rs);
+  drop(s->r_rs);
+  drop(s->part2_rs);
+  drop(s->h_rs);
+  drop(s->gxtx_rs);
+  for (size_t i = 1; i < s->gcache.size(); i++) {
+    (void)hipFree(s->gcache[i].g0);
+    (void)hipFree(s->gcache[i].g1);
+    (void)hipFree(s->gcache[i].A);
+    (void)hipFree(s->gcache[i].meta);
+  }
+  if (!s->gcache.empty()) s->gcache.resize(1);
+  for (size_t i = 1; i < s->cov.size(); i++) {
+    (void)hipFree(s->cov[i].G);
+    (void)hipFree(s->cov[i].slot_of);
+    (void)hipFree(s->cov[i].meta);
+    (void)hipFree(s->cov[i].GS);
+  }
+  if (!s->cov.empty()) s->cov.resize(1);
+  if (!s->n_train.empty()) s->n_train.resize(1);
+  s->n_test.clear();
+  s->cv_init.clear();
+  s->K = 0;
+}
+
 int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned seed) {
   if (!s || K < 2 || K > s->n) return fail(BESSX_ERR_ARG, "set_cv: bad arguments");
   HIPX(hipSetDevice(s->device));
@@ -2966,37 +3032,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
       for (int i = b; i < e; i++) fold[perm[i]] = k;
     }
   }
-  // drop previous folds
-  for (size_t i = 1; i < s->mask.size(); i++) {
-    (void)hipFree(s->mask[i]);
-    (void)hipFree(s->xtx[i]);
-    (void)hipFree(s->xty[i]);
-    (void)hipFree(s->part_rs[i]);
-    (void)hipFree(s->r_rs[i]);
-    (void)hipFree(s->part2_rs[i]);
-    (void)hipFree(s->h_rs[i]);
-    (void)hipFree(s->gcache[i].g0);
-    (void)hipFree(s->gcache[i].g1);
-    (void)hipFree(s->gcache[i].A);
-    (void)hipFree(s->gcache[i].meta);
-  }
-  s->gcache.resize(1);
-  for (size_t i = 1; i < s->cov.size(); i++) {
-    (void)hipFree(s->cov[i].G);
-    (void)hipFree(s->cov[i].slot_of);
-    (void)hipFree(s->cov[i].meta);
-    (void)hipFree(s->cov[i].GS);
-  }
-  if (!s->cov.empty()) s->cov.resize(1);
-  for (size_t i = 1; i < s->gxtx_rs.size(); i++) (void)hipFree(s->gxtx_rs[i]);
-  if (!s->gxtx_rs.empty()) s->gxtx_rs.resize(1);
-  s->mask.resize(1);
-  s->xtx.resize(1);
-  s->xty.resize(1);
-  s->part_rs.resize(1);
-  s->r_rs.resize(1);
-  s->part2_rs.resize(1);
-  s->h_rs.resize(1);
+  drop_folds(s);
   s->cache.assign(K + 1, bessx_session::RsCache());
   s->n_train.resize(1);
   s->n_test.assign(K, 0);
@@ -3013,36 +3049,49 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
       }
     }
     s->n_test[k] = n - nt;
-    if (nt < 1 || n - nt < 1) return fail(BESSX_ERR_ARG, "set_cv: empty train or test fold");
-    double *dm = nullptr, *q1 = nullptr, *q2 = nullptr, *q3 = nullptr, *q4 = nullptr;
-    HIPX(dmalloc(&dm, (size_t)s->ld));
-    HIPX(hipMemcpy(dm, m.data(), (size_t)s->ld * sizeof(double), hipMemcpyHostToDevice));
-    HIPX(dmalloc(&q1, (size_t)p));
-    HIPX(dmalloc(&q2, (size_t)p));
-    HIPX(dmalloc(&q3, part_elems(s)));
-    HIPX(dmalloc(&q4, (size_t)s->ld));
-    HIPX(hipMemset(q4, 0, (size_t)s->ld * sizeof(double)));
-    s->mask.push_back(dm);
-    s->xtx.push_back(q1);
-    s->xty.push_back(q2);
-    s->part_rs.push_back(q3);
-    s->r_rs.push_back(q4);
-    HIPX(dmalloc(&q3, (size_t)s->nrb * p));
-    HIPX(dmalloc(&q4, (size_t)s->ld));
-    HIPX(hipMemset(q4, 0, (size_t)s->ld * sizeof(double)));
-    s->part2_rs.push_back(q3);
-    s->h_rs.push_back(q4);
-    if (int rc = alloc_gram_cache(s)) return rc;
-    if (s->cov_mode)
-      if (int rc = alloc_cov_cache(s)) return rc;
-    if (s->grouped) {
-      double *qg = nullptr;
-      HIPX(dmalloc(&qg, (size_t)s->goff_h[s->N]));
-      s->gxtx_rs.push_back(qg);
+    if (nt < 1 || n - nt < 1) {
+      drop_folds(s);
+      return fail(BESSX_ERR_ARG, "set_cv: empty train or test fold");
     }
+    // every buffer is handed to its vector as soon as it exists: a failure further down leaves nothing unowned, and
+    // drop_folds() (which walks every vector by its own length) returns the session to the no-CV state
+#define CVX(expr)                                                                            \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      drop_folds(s);                                                                         \
+      return fail(BESSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+    }                                                                                        \
+  } while (0)
+    auto grow = [&](std::vector<double *> &v, size_t count, bool zero) -> hipError_t {
+      double *q = nullptr;
+      hipError_t e = dmalloc(&q, count);
+      if (e != hipSuccess) return e;
+      v.push_back(q);
+      return zero ? hipMemset(q, 0, count * sizeof(double)) : hipSuccess;
+    };
+    CVX(grow(s->mask, (size_t)s->ld, false));
+    CVX(hipMemcpy(s->mask.back(), m.data(), (size_t)s->ld * sizeof(double), hipMemcpyHostToDevice));
+    CVX(grow(s->xtx, (size_t)p, false));
+    CVX(grow(s->xty, (size_t)p, false));
+    CVX(grow(s->part_rs, part_elems(s), false));
+    CVX(grow(s->r_rs, (size_t)s->ld, true));
+    CVX(grow(s->part2_rs, (size_t)s->nrb * p, false));
+    CVX(grow(s->h_rs, (size_t)s->ld, true));
+    int rc = alloc_gram_cache(s);
+    if (rc == 0 && s->cov_mode) rc = alloc_cov_cache(s);
+    if (rc) {
+      drop_folds(s);
+      return rc;
+    }
+    if (s->grouped) CVX(grow(s->gxtx_rs, (size_t)s->goff_h[s->N], false));
     s->n_train.push_back(nt);
     if (s->model_type == 1)
-      if (int rc = prepare_rowset(s, k + 1)) return rc;
+      if (int rc2 = prepare_rowset(s, k + 1)) {
+        drop_folds(s);
+        return rc2;
+      }
+#undef CVX
   }
   HIPX(hipStreamSynchronize(s->st));
   return BESSX_OK;
@@ -3166,6 +3215,9 @@ int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const i
                       double *train_loss, double *test_loss) {
   if (!s) return fail(BESSX_ERR_ARG, "null session");
   if (fold >= s->K) return fail(BESSX_ERR_ARG, "fold index out of range");
+  if (s->grouped)
+    return fail(BESSX_ERR_UNSUPPORTED, "bessx_session_fit: sessions with groups of size > 1 return up to T0 * group "
+                                       "size columns, which support[T0] / beta[T0] cannot hold; use the path calls");
   HIPX(hipSetDevice(s->device));
   s->cur_rows = fold < 0 ? 0 : fold + 1;
   s->sparsity_level = T0;
@@ -3231,6 +3283,16 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
   pb.group_index_len = gindex_len;
   pb.is_screening = is_screening ? 1 : 0;
   pb.screening_size = screening_size;
+  {
+    // the work space is sized for the largest active set the path can ask for (levels count groups)
+    long top = path_type == 1 ? 0 : s_max;
+    if (path_type == 1)
+      for (int i = 0; i < sequence_len; i++) top = std::max<long>(top, sequence ? sequence[i] : 0);
+    long gmax = 1;
+    for (int g = 0; g < gindex_len; g++)
+      gmax = std::max<long>(gmax, (g + 1 < gindex_len ? gindex[g + 1] : x_col) - gindex[g]);
+    pb.max_sparsity = (int)std::min<long>(std::min<long>(top * gmax, x_col), T0_HARD);
+  }
   bessx_session *s = nullptr;
   if (int rc = bessx_session_create(&s, &pb)) return rc;
   int rc = 0;
@@ -3251,7 +3313,7 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
     *coef0_out = res.coef0;
     *train_loss_out = res.train_loss;
     *ic_out = res.ic;
-    if (nullloss_out) *nullloss_out = 0.0;
+    if (nullloss_out) *nullloss_out = s->nullloss;
     if (aic_out && aic_out_len > 0) aic_out[0] = 0.0;
     if (bic_out && bic_out_len > 0) bic_out[0] = 0.0;
     if (gic_out && gic_out_len > 0) gic_out[0] = 0.0;

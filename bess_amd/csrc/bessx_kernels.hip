@@ -3687,8 +3687,11 @@ __global__ void __launch_bounds__(256) k_screen_score_lm(const double *__restric
                                                          double *__restrict__ score) {
   int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= p) return;
-  const double b = sxy[j] / sxx[j];
-  score[j] = (always != nullptr && always[j]) ? DBL_MAX : b * b;
+  // an all-zero column: the reference's colPivHouseholderQr().solve returns 0 for it (src/screening.cpp:44-61), so
+  // it ranks last; 0 / 0 here would hand a NaN key to the selection
+  const double b = sxx[j] > 0.0 ? sxy[j] / sxx[j] : 0.0;
+  const double v = b * b;
+  score[j] = (always != nullptr && always[j]) ? DBL_MAX : ((v <= DBL_MAX) ? v : 0.0);
 }
 
 // state per column: st[0..1] = beta0, st[2..3] = beta1, st[4] = ll0; done[j] != 0 once converged.
@@ -3745,7 +3748,8 @@ __global__ void __launch_bounds__(256) k_screen_score_logit(const double *__rest
   int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= p) return;
   const double b = state[(size_t)j * 5 + 1];
-  score[j] = (always != nullptr && always[j]) ? DBL_MAX : b * b;
+  const double v = b * b;  // a degenerate column (singular 2 x 2 system) must not rank first: non-finite -> 0
+  score[j] = (always != nullptr && always[j]) ? DBL_MAX : ((v <= DBL_MAX) ? v : 0.0);
 }
 
 // Cox marginal fit, cox_fit (src/coxph.cpp:97-172) on one column: the whole damped Newton loop of a column runs in
@@ -3848,7 +3852,10 @@ __global__ void __launch_bounds__(256) k_screen_cox(const double *__restrict__ X
     b0 = b1;
     ll0 = ll1;
   }
-  if (threadIdx.x == 0) score[j] = b0 * b0;
+  if (threadIdx.x == 0) {
+    const double v = b0 * b0;
+    score[j] = (v <= DBL_MAX) ? v : 0.0;  // non-finite (degenerate column) -> ranks last
+  }
 }
 
 // X2[:, q] = X[:, A[q]]   (x_A of src/screening.cpp:82-87)
@@ -4733,9 +4740,11 @@ hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand,
   int nchunk = (len + chunk - 1) / chunk;
   long ncand = (long)nchunk * k;
   if (ncand > chunk || k > chunk) return hipErrorInvalidValue;  // would need a third level
-  // every chunk is full except possibly the last; a short last chunk would leave holes in cand, so it
-  // is only allowed when it still holds >= k scores (checked by the caller via topk_supported()).
-  hipError_t e = launch_topk_one(nchunk, score, nullptr, len, chunk, k, cand, ctrl, slot, st, run_flag);
+  // the chunks are BALANCED (ceil(len / nchunk) scores each, the last at most nchunk - 1 fewer): a chunk shorter
+  // than k would leave holes in cand, and with full 32768-wide chunks whether that happens depended on
+  // len mod 32768 (p = 32769 allowed k = 1 only).  topk_supported() checks the last chunk still holds >= k scores.
+  const int bal = (len + nchunk - 1) / nchunk;
+  hipError_t e = launch_topk_one(nchunk, score, nullptr, len, bal, k, cand, ctrl, slot, st, run_flag);
   if (e != hipSuccess) return e;
   return launch_topk_one(1, score, cand, (int)ncand, chunk, k, out, ctrl, slot, st, run_flag);
 }
@@ -4744,7 +4753,8 @@ bool topk_supported(int len, int k) {
   const int chunk = 1024 * TOPK_E;
   if (len <= chunk) return k <= len;
   int nchunk = (len + chunk - 1) / chunk;
-  int last = len - (nchunk - 1) * chunk;
+  const int bal = (len + nchunk - 1) / nchunk;
+  int last = len - (nchunk - 1) * bal;
   return k <= last && (long)nchunk * k <= chunk;
 }
 

@@ -117,6 +117,13 @@ class bess_base:
                 self.screening_size = max(p, int(n / np.log(n)))
         else:
             self.screening_size = 1
+        # libbessx holds the k x k work space of a session in HBM for at most 16382 active columns
+        # (include/bessx.h: bessx_problem.max_sparsity); the reference has no such bound (any T0 <= p)
+        top = max(self.sequence) if self.path_type_int == 1 else self.s_max
+        gsz = int(np.max(np.diff(list(g_index) + [p])))
+        if min(p, top * gsz) > capi.MAX_SPARSITY:
+            raise ValueError("bess_amd: sparsity levels up to %d active columns are supported, this path asks for %d "
+                             "(shorten `sequence` / lower `s_max`)" % (capi.MAX_SPARSITY, min(p, top * gsz)))
         result = capi.pywrap_bess(X, y, self.data_type, weight, is_normal, self.algorithm_type_int,
                                   self.model_type_int, self.max_iter, self.exchange_num, self.path_type_int,
                                   self.is_warm_start, self.ic_type_int, self.is_cv, self.K, g_index, state,

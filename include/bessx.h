@@ -41,7 +41,8 @@ int bessx_device_info(char *buf, int buf_len);
  *    Identical argument list (bool -> int).  x is row-major x_row * x_col.  Writes
  *    beta_out[0..x_col), *coef0_out, *train_loss_out, *ic_out exactly like the reference
  *    (src/bess.cpp:277-280); additionally fills the slots the reference leaves
- *    uninitialised: *nullloss_out (Data::get_nullloss, src/Data.h:120-130),
+ *    uninitialised: *nullloss_out (Data::get_nullloss, src/Data.h:120-130: |y|^2 / n of the
+ *    normalised response for data_type 1, else 2 log 2 * sum(weight)),
  *    A_out[0..k) = selected support, *l_out = PDAS iterations of the selected candidate;
  *    aic/bic/gic_out are set to 0.
  *    Differences, all documented in INTEGRATION.md: is_cv draws folds from a fixed-seed
@@ -99,6 +100,11 @@ typedef struct {
                          1 = streaming: every PDAS iteration reads X once, 2 = covariance updates: cached Gram
                          columns X^T x_a, X is read only when a new column enters.  Same results either way up to
                          summation order. */
+  int max_sparsity;   /* largest number of active COLUMNS any fit of this session will be asked for (sparsity level x
+                         largest group size); sizes the k x k work space.  0 = default: min(p, 2046).  Up to 16382;
+                         levels beyond 254 use the blocked Cholesky in global memory.  bessx_pywrap_bess derives it
+                         from sequence / s_max, so the reference's default sequence 1..min(p, n / log n)
+                         (python/bess/linear.py:285-287) runs as it is. */
 } bessx_problem;
 
 int bessx_session_create(bessx_session **out, const bessx_problem *prob);

@@ -45,6 +45,9 @@ def lib():
         _lib.bess_ref_trace2.argtypes = (
             [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _I, _i, _D, _i, _i, _i, _d, _d, _i, _i,
              _I, _i, _I, _i] + [_D, _D, _D, _D, _D])
+        _lib.bess_ref_time_chain.restype = _i
+        _lib.bess_ref_time_chain.argtypes = [_D, _i, _i, _D, _D, _i, _i, _i, _i, _i, _i, _I, _i, _I, _D, _i, _d, _d,
+                                             _D, _I, _I, _D]
         _lib.bess_ref_screening.restype = _i
         _lib.bess_ref_screening.argtypes = [_D, _i, _i, _D, _D, _i, _i, _I, _i, _I]
         _lib.bess_ref_trace_size.restype = _i
@@ -125,8 +128,9 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
                            sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max, lambda_min, lambda_max,
                            nlambda, powell_path, _ip(g_index), g_index.size, _ip(always_select), always_select.size,
                            _dp(beta), _dp(coef0), _dp(loss), _dp(ic), _dp(lam_out))
-    if rc != 0:
+    if rc not in (0, 2):
         raise RuntimeError("bess_ref_trace failed")
+    truncated = rc == 2  # BESS_REF_BUDGET_S ran out: whole fits so far, no best model (oracle/ref_harness.cpp)
 
     def geti(which):
         a = np.zeros(max(L.bess_ref_trace_size(which), 1), dtype=np.int32)
@@ -152,7 +156,33 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
         fits[-1]["betas"].append(beta_flat[off:nxt].copy())
         fits[-1]["coef0s"].append(float(coef0_calls[c]))
     return {"beta": beta, "coef0": float(coef0[0]), "train_loss": float(loss[0]), "ic": float(ic[0]),
-            "lambda": float(lam_out[0]), "fits": fits, "loss_calls": getd(4), "ic_calls": getd(5)}
+            "lambda": float(lam_out[0]), "fits": fits, "loss_calls": getd(4), "ic_calls": getd(5),
+            "truncated": truncated}
+
+
+def time_chain(x, y, sequence, init_idx=(), init_val=(), init_coef0=0.0, budget_s=15.0, weight=None, data_type=1,
+               is_normal=True, algorithm_type=1, model_type=1, max_iter=20, ic_type=3):
+    """Wall time per candidate of one warm-start chain of the reference's own Algorithm / Metric objects
+    (oracle/ref_harness.cpp: bess_ref_time_chain), optionally started from a given model (normalised scale) so that
+    candidates from the far end of a path can be timed alone.  Returns {"seconds": [...], "iters": [...],
+    "setup_seconds": s}; stops after the first candidate that ends beyond budget_s."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n, p = x.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    w = np.ones(n) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+    seq = np.ascontiguousarray(sequence, dtype=np.int32)
+    ii = np.ascontiguousarray(init_idx, dtype=np.int32)
+    iv = np.ascontiguousarray(init_val, dtype=np.float64)
+    sec = np.zeros(max(seq.size, 1))
+    its = np.zeros(max(seq.size, 1), dtype=np.int32)
+    done = ctypes.c_int(0)
+    setup = ctypes.c_double(0.0)
+    rc = lib().bess_ref_time_chain(_dp(x), n, p, _dp(y), _dp(w), data_type, int(is_normal), algorithm_type, model_type,
+                                   max_iter, ic_type, _ip(seq), seq.size, _ip(ii), _dp(iv), ii.size, init_coef0,
+                                   budget_s, _dp(sec), _ip(its), ctypes.byref(done), ctypes.byref(setup))
+    if rc != 0:
+        raise RuntimeError("bess_ref_time_chain failed")
+    return {"seconds": sec[:done.value].copy(), "iters": its[:done.value].copy(), "setup_seconds": setup.value}
 
 
 def screening(x, y, weight, model_type, screening_size, always_select=()):

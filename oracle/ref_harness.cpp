@@ -26,6 +26,9 @@
 #include <Eigen/Eigen>
 #include <vector>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
 #include "List.h"
 #include "Data.h"
 #include "Algorithm.h"
@@ -53,6 +56,16 @@ struct Trace {
 
 Trace g_trace;
 
+// Long full-size runs (tests/golden/make_fullsize_ref.py): BESS_REF_PROGRESS=1 prints one line per fit;
+// BESS_REF_BUDGET_S=<seconds> ends the run at the first fit that would START after the budget (thrown from
+// get_A at l == 1, caught in bess_ref_trace2, which then returns 2): the trace holds whole fits only and the
+// caller labels the golden file as a prefix of the path.
+struct BudgetExceeded {};
+std::chrono::steady_clock::time_point g_start;
+double g_budget_s = 0.0;
+int g_progress = 0, g_fit_count = 0;
+double elapsed_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - g_start).count(); }
+
 template <class Base>
 struct TracedAlgorithm : public Base {
   TracedAlgorithm(Data &data, int algorithm_type, unsigned int max_iter) : Base(data, algorithm_type, max_iter) {}
@@ -60,6 +73,14 @@ struct TracedAlgorithm : public Base {
   void get_A(Eigen::MatrixXd X, Eigen::VectorXd y, Eigen::VectorXd beta, double coef0, int T0, Eigen::VectorXd weights,
              Eigen::VectorXi index, Eigen::VectorXi gsize, int N, Eigen::VectorXi &A_out) override {
     int train_n = (int)X.rows();
+    if (this->l == 1) {
+      if (g_budget_s > 0.0 && elapsed_s() > g_budget_s) throw BudgetExceeded();
+      g_fit_count++;
+      if (g_progress) {
+        std::fprintf(stderr, "[ref] fit %d T0=%d train_n=%d t=%.0fs\n", g_fit_count, T0, train_n, elapsed_s());
+        std::fflush(stderr);
+      }
+    }
     Base::get_A(X, y, beta, coef0, T0, weights, index, gsize, N, A_out);
     g_trace.geta_meta.push_back(this->l);
     g_trace.geta_meta.push_back(T0);
@@ -158,6 +179,10 @@ int bess_ref_trace2(const double *x, int n, int p, const double *y, const double
                     const int *always_select, int always_len, double *beta_out, double *coef0_out,
                     double *train_loss_out, double *ic_out, double *lambda_out) {
   g_trace.clear();
+  g_start = std::chrono::steady_clock::now();
+  g_fit_count = 0;
+  g_progress = std::getenv("BESS_REF_PROGRESS") != nullptr;
+  g_budget_s = std::getenv("BESS_REF_BUDGET_S") ? std::atof(std::getenv("BESS_REF_BUDGET_S")) : 0.0;
   Eigen::MatrixXd X(n, p);
   for (int i = 0; i < n; i++)
     for (int j = 0; j < p; j++) X(i, j) = x[(size_t)i * p + j];
@@ -221,6 +246,7 @@ int bess_ref_trace2(const double *x, int n, int p, const double *y, const double
   }
 
   List result;
+  try {
   if (path_type == 1) {
     result = sequential_path(data, algorithm, metric, SEQ, LAM);
   } else if (path_type == 3) {
@@ -235,6 +261,13 @@ int bess_ref_trace2(const double *x, int n, int p, const double *y, const double
   } else {
     result = gs_path(data, algorithm, metric, s_min, s_max, 0, 0.);
   }
+  } catch (const BudgetExceeded &) {
+    // whole fits recorded so far stay readable through bess_ref_trace_size/copy; no best model
+    g_trace.metric_depth = 0;
+    delete algorithm;
+    delete metric;
+    return 2;
+  }
 
   Eigen::VectorXd beta;
   double coef0, train_loss, ic;
@@ -246,6 +279,88 @@ int bess_ref_trace2(const double *x, int n, int p, const double *y, const double
   *coef0_out = coef0;
   *train_loss_out = train_loss;
   *ic_out = ic;
+  delete algorithm;
+  delete metric;
+  return 0;
+}
+
+// CPU-baseline timing (bench.py's cpu_baseline leg): one warm-start chain of the reference's own Algorithm / Metric
+// objects, driven through their public setters in the order sequential_path uses them (src/path.cpp:48-74:
+// update_train_mask, update_sparsity_level, update_lambda_level, update_beta_init, update_coef0_init,
+// update_group_XTX, fit(), then train_loss() and ic()), but STARTING from a caller-supplied model (init_idx /
+// init_val in the normalised scale Algorithm::beta lives in) so that a segment from the far end of a path (k = 181..)
+// can be timed without paying for the 180 candidates before it.  cand_seconds[i] = wall time of candidate i (fit +
+// train_loss + ic); stops after the first candidate that ends beyond budget_s.  Set-up (copy + normalise) is
+// reported separately, like the GPU figure excludes upload + normalise.
+int bess_ref_time_chain(const double *x, int n, int p, const double *y, const double *weight, int data_type,
+                        int is_normal, int algorithm_type, int model_type, int max_iter, int ic_type,
+                        const int *sequence, int sequence_len, const int *init_idx, const double *init_val,
+                        int init_len, double init_coef0, double budget_s, double *cand_seconds, int *cand_iters,
+                        int *n_done, double *setup_seconds) {
+  auto t_setup = std::chrono::steady_clock::now();
+  g_trace.clear();
+  g_budget_s = 0.0;
+  g_progress = 0;
+  Eigen::MatrixXd X(n, p);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < p; j++) X(i, j) = x[(size_t)i * p + j];
+  Eigen::VectorXd Y(n), W(n);
+  for (int i = 0; i < n; i++) {
+    Y(i) = y[i];
+    W(i) = weight[i];
+  }
+  Eigen::VectorXi G(p);
+  for (int j = 0; j < p; j++) G(j) = j;
+  Data data(X, Y, data_type, W, is_normal != 0, G);
+  Algorithm *algorithm = nullptr;
+  Metric *metric = nullptr;
+  if (model_type == 1) {
+    data.add_weight();
+    algorithm = new GroupPdasLm(data, algorithm_type, max_iter);
+    metric = new LmMetric(ic_type, false, 5);
+  } else if (model_type == 2) {
+    algorithm = new GroupPdasLogistic(data, algorithm_type, max_iter);
+    metric = new LogisticMetric(ic_type, false, 5);
+  } else if (model_type == 3) {
+    algorithm = new GroupPdasPoisson(data, algorithm_type, max_iter);
+    metric = new PoissonMetric(ic_type, false, 5);
+  } else {
+    algorithm = new GroupPdasCox(data, algorithm_type, max_iter);
+    metric = new CoxMetric(ic_type, false, 5);
+  }
+  algorithm->set_warm_start(true);
+  algorithm->always_select = Eigen::VectorXi(0);
+  algorithm->tao = 0.;
+  Eigen::VectorXi full_mask(n);
+  for (int i = 0; i < n; i++) full_mask(i) = i;
+  std::vector<Eigen::MatrixXd> full_group_XTX =
+      group_XTX(data.x, data.g_index, data.g_size, data.n, data.p, data.g_num, algorithm->model_type);
+  Eigen::VectorXd beta_init = Eigen::VectorXd::Zero(p);
+  for (int i = 0; i < init_len; i++) beta_init(init_idx[i]) = init_val[i];
+  double coef0_init = init_coef0;
+  *setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_setup).count();
+  auto t0 = std::chrono::steady_clock::now();
+  *n_done = 0;
+  for (int i = 0; i < sequence_len; i++) {
+    auto tc = std::chrono::steady_clock::now();
+    algorithm->update_train_mask(full_mask);
+    algorithm->update_sparsity_level(sequence[i]);
+    algorithm->update_lambda_level(0.0);
+    algorithm->update_beta_init(beta_init);
+    algorithm->update_coef0_init(coef0_init);
+    algorithm->update_group_XTX(full_group_XTX);
+    algorithm->fit();
+    beta_init = algorithm->get_beta();
+    coef0_init = algorithm->get_coef0();
+    volatile double sink = metric->train_loss(algorithm, data);
+    sink = metric->ic(algorithm, data);
+    (void)sink;
+    auto t1 = std::chrono::steady_clock::now();
+    cand_seconds[i] = std::chrono::duration<double>(t1 - tc).count();
+    cand_iters[i] = algorithm->get_l();
+    *n_done = i + 1;
+    if (std::chrono::duration<double>(t1 - t0).count() > budget_s) break;
+  }
   delete algorithm;
   delete metric;
   return 0;

@@ -5,6 +5,12 @@ Run once in the build container (it needs /root/reference to have been compiled 
 
     python tests/golden/make_fullsize_ref.py lm        # BASELINE configs[1], k = 1..200
     python tests/golden/make_fullsize_ref.py logistic  # BASELINE configs[2], k = 1..100
+    python tests/golden/make_fullsize_ref.py lmcv      # BASELINE configs[3], gs_path on [1,200] + 5-fold CV
+    python tests/golden/make_fullsize_ref.py cox 4000  # BASELINE configs[4] recipe at the largest n the
+                                                       # reference's n x n risk-set matrix allows (p=2000, k=1..40)
+
+BESS_REF_PROGRESS=1 prints one line per fit; BESS_REF_BUDGET_S=<s> stops the reference at the first fit that
+would start after the budget: the file then holds a PREFIX of the path (`truncated` = 1, no best model).
 
 Output: tests/golden/fullsize_<name>.npz holding, for every candidate of the warm-start
 chain, the active set of every PDAS iteration, the fitted coefficients, the loss and the
@@ -37,6 +43,7 @@ ref = _load("ref_ctypes", os.path.join(ROOT, "oracle", "ref_ctypes.py"))
 def pack(t, extra):
     fits = t["fits"]
     out = dict(extra)
+    out["truncated"] = int(t.get("truncated", False))
     out["best_beta_idx"] = np.nonzero(t["beta"])[0].astype(np.int32)
     out["best_beta_val"] = t["beta"][np.nonzero(t["beta"])[0]]
     out["best_coef0"] = t["coef0"]
@@ -69,11 +76,39 @@ def main():
         t0 = time.time()
         t = ref.trace(X, y, data_type=2, model_type=2, ic_type=3, sequence=np.arange(1, kmax + 1))
         extra = {"n": X.shape[0], "p": X.shape[1], "seed": synth.SEED_LOGISTIC, "true_support": support, "ic_type": 3}
+    elif which == "lmcv":
+        X, y, support, beta = synth.make_lm(2000, 500, 10) if small else synth.make_lm()
+        fold = synth.make_cv_folds(X.shape[0])
+        smax = kmax or (40 if small else 200)
+        t0 = time.time()
+        t = ref.trace(X, y, data_type=1, model_type=1, ic_type=3, path_type=2, s_min=1, s_max=smax, is_cv=True, K=5,
+                      cv_fold_id=fold)
+        extra = {"n": X.shape[0], "p": X.shape[1], "seed": synth.SEED_LM, "fold_seed": synth.SEED_CV,
+                 "true_support": support, "ic_type": 3, "s_max": smax}
+        kmax = smax
+    elif which == "cox":
+        n = kmax or 4000
+        p, ktrue, kmax = (300, 8, 12) if small else (2000, 20, 40)
+        if small:
+            n = 600
+        X, tm, status, support, beta = synth.make_cox(n, p, ktrue)
+        t0 = time.time()
+        t = ref.trace(X, status, data_type=3, model_type=4, ic_type=3, sequence=np.arange(1, kmax + 1))
+        extra = {"n": n, "p": p, "k_true": ktrue, "seed": synth.SEED_COX, "true_support": support, "ic_type": 3}
+    elif which == "bigk":
+        # sparsity levels beyond the register / LDS resident solvers and beyond the default session capacity (2046)
+        X, y, support, beta = synth.make_lm(300, 120, 5, seed=5) if small else synth.make_lm(8000, 2600, 10, seed=5)
+        seq = [100, 110] if small else [2040, 2100, 2300]
+        kmax = max(seq)
+        t0 = time.time()
+        t = ref.trace(X, y, data_type=1, model_type=1, ic_type=3, sequence=seq)
+        extra = {"n": X.shape[0], "p": X.shape[1], "seed": 5, "sequence": np.array(seq), "ic_type": 3}
     else:
         raise SystemExit("unknown config " + which)
     extra["ref_wall_seconds"] = time.time() - t0
     extra["kmax"] = kmax
-    out = "/tmp/small_%s.npz" % which if small else os.path.join(HERE, "fullsize_%s.npz" % which)
+    name = {"cox": "fullsize_cox_n%d.npz" % extra["n"], "bigk": "ref_bigk.npz"}.get(which, "fullsize_%s.npz" % which)
+    out = "/tmp/small_%s.npz" % which if small else os.path.join(HERE, name)
     np.savez_compressed(out, **pack(t, extra))
     print("done", which, "in", extra["ref_wall_seconds"], "s")
 

@@ -32,3 +32,39 @@ def test_bench_line(gpu):
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0
     assert d["streaming_score_pass"]["same_selection"] is True
     assert sum(d["pdas_iterations_histogram"].values()) == 30
+
+
+def _run_bench(extra, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "3000", "--p", "800", "--kmax", "30",
+                          "--k-true", "10", "--steps", "2", "--warmup", "1"] + extra, cwd=ROOT, capture_output=True,
+                         text=True, timeout=timeout, env=e)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_and_shards_the_k_path(gpu):
+    """`python bench.py --gpus 2` with no launcher starts 2 ranks itself; the default N > 1 mode is the strong-scaling
+    k-path split of ONE problem.  On the one-GPU box the ranks share the device (BESSX_BENCH_ONE_DEVICE=1, gloo)."""
+    d = _run_bench(["--gpus", "2"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert abs(d["value"] - 30 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]  # ONE problem: 30 candidates / step
+    rep = d["kpath_chunks_vs_single_chain"]
+    assert rep["chunks"] == [[1, 15], [16, 30]] and rep["of"] == 30
+    assert rep["supports_equal_to_single_chain"] >= 25 and rep["best_k_chunked"] == rep["best_k_single_chain"]
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_bench_weak_scaling_and_cv_workload_on_two_ranks(gpu):
+    d = _run_bench(["--gpus", "2", "--shard", "replica", "--no-cpu-baseline"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["ic_curves_gathered"] == 2
+    assert abs(d["value"] - 2 * 30 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    one = _run_bench(["--workload", "lm-cv-gs", "--no-cpu-baseline"])
+    two = _run_bench(["--gpus", "2", "--workload", "lm-cv-gs", "--no-cpu-baseline"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    for k in ("selected_k", "fits_per_step", "pdas_iterations_per_step"):
+        assert one[k] == two[k], k
+    assert abs(one["cv_loss"] - two["cv_loss"]) <= 1e-12 * abs(one["cv_loss"])
