@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbessx.so")
+# BESSX_LIB_PATH: development aid (an instrumented build of the same library, e.g. -DBESSX_KTRACE for tools/ktrace.py)
+LIB_PATH = os.environ.get("BESSX_LIB_PATH") or os.path.join(_HERE, "libbessx.so")
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)

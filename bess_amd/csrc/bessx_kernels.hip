@@ -3687,11 +3687,12 @@ __global__ void __launch_bounds__(256) k_screen_score_lm(const double *__restric
                                                          double *__restrict__ score) {
   int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= p) return;
-  // an all-zero column: the reference's colPivHouseholderQr().solve returns 0 for it (src/screening.cpp:44-61), so
-  // it ranks last; 0 / 0 here would hand a NaN key to the selection
-  const double b = sxx[j] > 0.0 ? sxy[j] / sxx[j] : 0.0;
+  // an all-zero column: the reference's colPivHouseholderQr (Eigen 3.3.4) counts its zero pivot as non-zero and
+  // solve() divides by it (src/screening.cpp:44-48): beta = +-inf, the column ranks FIRST (measured on the compiled
+  // reference, tests/test_limits_gpu.py).  0 / 0 here would be a NaN key; +inf states the same rank explicitly.
+  const double b = sxx[j] > 0.0 ? sxy[j] / sxx[j] : HUGE_VAL;
   const double v = b * b;
-  score[j] = (always != nullptr && always[j]) ? DBL_MAX : ((v <= DBL_MAX) ? v : 0.0);
+  score[j] = (always != nullptr && always[j]) ? DBL_MAX : ((v == v) ? v : HUGE_VAL);
 }
 
 // state per column: st[0..1] = beta0, st[2..3] = beta1, st[4] = ll0; done[j] != 0 once converged.

@@ -58,6 +58,13 @@ def select_best(curve):
 # K + 1 chains are the independent units: unit u lives on rank u % world for the whole path, which keeps every
 # chain exactly as the single-process path runs it -- the results do not depend on the number of ranks.  X is
 # replicated; the only communication is one all-gather of the K + 1 small fit records per evaluation.
+#
+# (fold x s) pairs (the final sweep of gs_path, src/path.cpp:301-328): under the default warm start fold k
+# at size s + 1 starts from fold k at size s (cv_initial_model_param.row(k)), so the pairs of one fold ARE a chain and
+# at most K + 1 ranks have work; dealing them out singly would change the starting points and with them, possibly,
+# the supports.  With is_warm_start = False every (candidate, unit) pair is independent: whole batches of candidates
+# -- the sweep of gs_path, every size of sequential_path -- are dealt pair by pair to ALL ranks (_round_cold), with
+# results identical to the single-process path for any number of ranks.
 # ------------------------------------------------------------------------------------------------------------
 class _NoComm:
     """world = 1: the all-gather is the identity."""
@@ -136,6 +143,42 @@ class FoldShardedCV:
         self.n_pdas_iters += sum(r["iters"] for r in recs.values())
         return recs
 
+    # -- is_warm_start = False: every (candidate, unit) pair is independent (Algorithm::fit starts from zero,
+    # Metric::test_loss does not read cv_initial_model_param) -- a batch of candidates is dealt pair by pair to ALL
+    # ranks, so more than K + 1 ranks have work ((fold x s) pairs of the final sweep of gs_path) ----------
+    def _round_cold(self, T0s, lam):
+        pairs = [(i, u) for i in range(len(T0s)) for u in range(self.K + 1)]
+        tmax = max(T0s)
+        reclen = self.HEAD + 1 + 2 * tmax
+        per_rank = -(-len(pairs) // self.world)
+        mine = np.full((per_rank, reclen), np.nan)
+        row = 0
+        empty = (np.zeros(0, np.int32), np.zeros(0))
+        for q, (i, u) in enumerate(pairs):
+            if q % self.world != self.rank:
+                continue
+            T0 = T0s[i]
+            r = self.s.fit(T0, lam, -1 if u == self.K else u, empty[0], empty[1], 0.0)
+            mine[row, :self.HEAD + 1] = (u, r["iters"], r["coef0"], r["train_loss"], r["test_loss"], i)
+            mine[row, self.HEAD + 1:self.HEAD + 1 + T0] = r["support"]
+            mine[row, self.HEAD + 1 + tmax:self.HEAD + 1 + tmax + T0] = r["beta"]
+            row += 1
+        out = [dict() for _ in T0s]
+        for block in self.comm.all_gather(mine, self.world):
+            for rec in block:
+                if np.isnan(rec[0]):
+                    continue
+                i = int(rec[self.HEAD])
+                T0 = T0s[i]
+                out[i][int(rec[0])] = {"iters": int(rec[1]), "coef0": float(rec[2]), "train_loss": float(rec[3]),
+                                       "test_loss": float(rec[4]),
+                                       "support": rec[self.HEAD + 1:self.HEAD + 1 + T0].astype(np.int32),
+                                       "beta": rec[self.HEAD + 1 + tmax:self.HEAD + 1 + tmax + T0].copy()}
+        self.evaluations += 1
+        self.n_fits += len(pairs)
+        self.n_pdas_iters += sum(r["iters"] for recs in out for r in recs.values())
+        return out
+
     @staticmethod
     def _cv_loss(recs, K):
         acc = 0.0
@@ -189,10 +232,15 @@ class FoldShardedCV:
         ns, nl = len(seq), len(lam)
         full_init, coef0_init = (np.zeros(0, np.int32), np.zeros(0)), 0.0
         grid, cands = {}, []
+        cold = {}
+        if not self.warm:  # independent candidates: one batch per lambda, (s x unit) pairs over all ranks
+            for j in range(nl):
+                for i, recs in enumerate(self._round_cold(seq, lam[j])):
+                    cold[(i, j)] = recs
         for i in range(ns):
             order = range(nl) if i % 2 == 0 else range(nl - 1, -1, -1)  # snake order, :50
             for j in order:
-                recs = self._round(seq[i], lam[j], True, True, full_init, coef0_init)
+                recs = cold[(i, j)] if cold else self._round(seq[i], lam[j], True, True, full_init, coef0_init)
                 full = recs[self.K]
                 if self.warm:
                     full_init, coef0_init = (full["support"], full["beta"]), full["coef0"]
@@ -215,6 +263,19 @@ class FoldShardedCV:
         def fit_point(T, twice):
             # the full-data fit and the first ic() are independent: one round; the second ic() (:204+:210,
             # :245+:253, :286+:294) continues the fold chains, a second round without the full-data unit
+            if not self.warm:
+                # cold starts: the second ic() repeats the first one's K fits exactly (same start, same rows); it is
+                # counted (the reference runs it) but not recomputed
+                recs = self._round_cold([T], 0.0)[0]
+                full = recs[self.K]
+                first = self._cv_loss(recs, self.K)
+                cands.append({"T0": T, "lambda": 0.0, "support": full["support"], "beta": full["beta"],
+                              "coef0": full["coef0"], "iters": full["iters"], "loss": full["train_loss"],
+                              "ic": first})
+                if twice:
+                    self.n_fits += self.K
+                    self.n_pdas_iters += sum(recs[k]["iters"] for k in range(self.K))
+                return first, (first if twice else None)
             coef0_prev = st["coef0_init"]
             recs = self._round(T, 0.0, True, True, st["full_init"], coef0_prev)
             full = recs[self.K]
@@ -245,9 +306,11 @@ class FoldShardedCV:
                 ic2, icT2 = fit_point(T2, True)
         best = {"T0": 0, "lambda": 0.0, "support": np.zeros(0, np.int32), "beta": np.zeros(0), "coef0": 0.0,
                 "loss": 0.0, "ic": np.finfo(np.float64).max, "iters": 0}
+        sweep = None if self.warm else self._round_cold(list(range(Tmin, Tmax + 1)), 0.0)  # (fold x s) pairs
         for T in range(Tmin, Tmax + 1):
             coef0_prev = st["coef0_init"]
-            recs = self._round(T, 0.0, True, True, st["full_init"], coef0_prev)
+            recs = sweep[T - Tmin] if sweep is not None else \
+                self._round(T, 0.0, True, True, st["full_init"], coef0_prev)
             full = recs[self.K]
             if self.warm:
                 st["full_init"], st["coef0_init"] = (full["support"], full["beta"]), full["coef0"]

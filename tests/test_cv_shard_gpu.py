@@ -57,3 +57,28 @@ def test_logistic_cv_gs_path_from_the_fit_primitive(gpu):
     np.testing.assert_allclose(out["beta"], ref["beta"], rtol=1e-8)
     np.testing.assert_allclose([out["coef0"], out["train_loss"], out["ic"]],
                                [ref["coef0"], ref["train_loss"], ref["ic"]], rtol=1e-8)
+
+
+@pytest.mark.parametrize("path", ["gs", "seq"])
+def test_cold_start_pairs_from_the_fit_primitive(gpu, path):
+    """is_warm_start = False: every (candidate, fold) pair is an independent fit (FoldShardedCV._round_cold deals them
+    to all ranks); here on one rank, against the library's own cold CV paths and the oracle."""
+    X, y, _, _ = synth.make_lm(1000, 300, 10)
+    fold = synth.make_cv_folds(1000, 5)
+    with gpu.Session(X, y, is_warm_start=False) as s:
+        s.set_cv(5, fold)
+        ref = s.gs_path(1, 30, ic_type=3, is_cv=True) if path == "gs" else \
+            s.sequential_path(np.arange(1, 16), ic_type=3, is_cv=True)
+        cv = bdist.FoldShardedCV(s, 5, is_warm_start=False)
+        out = cv.gs_path(1, 30) if path == "gs" else cv.sequential_path(np.arange(1, 16))
+    assert out["best_T0"] == ref["best_T0"] and out["n_fits"] == ref["n_fits"]
+    assert out["n_pdas_iters"] == ref["n_pdas_iters"]
+    np.testing.assert_array_equal(out["cand_T0"], ref["cand_T0"])
+    np.testing.assert_allclose(out["cand_ic"], ref["cand_ic"], rtol=1e-12)
+    np.testing.assert_allclose(out["beta"], ref["beta"], rtol=1e-10)
+    kw = dict(path_type=2, s_min=1, s_max=30) if path == "gs" else dict(sequence=np.arange(1, 16))
+    want = P.trace(X, y, ic_type=3, is_cv=True, K=5, cv_fold_id=fold, is_warm_start=False, **kw)
+    sup = np.nonzero(want["beta"])[0]
+    assert np.array_equal(np.nonzero(out["beta"])[0], sup)
+    np.testing.assert_allclose(out["beta"][sup], want["beta"][sup], rtol=1e-6)
+    assert out["n_fits"] == len(want["fits"])

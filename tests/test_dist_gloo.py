@@ -71,8 +71,8 @@ def _cv_worker(rank, world, port, path, out_path):
     from helpers import NumpyLmSession
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     X, y, fold = _cv_problem()
-    cv = bdist.FoldShardedCV(NumpyLmSession(X, y, fold, 5), 5, world, rank, is_warm_start=path != "seqcold")
-    if path == "gs":
+    cv = bdist.FoldShardedCV(NumpyLmSession(X, y, fold, 5), 5, world, rank, is_warm_start=not path.endswith("cold"))
+    if path in ("gs", "gscold"):
         out = cv.gs_path(1, 20)
     elif path == "seqlam":  # lambda grid in snake order (src/path.cpp:50)
         out = cv.sequential_path(np.arange(1, 7), [0.0, 0.02, 0.1])
@@ -85,7 +85,8 @@ def _cv_worker(rank, world, port, path, out_path):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("path,world", [("gs", 2), ("seq", 2), ("gs", 3), ("seqlam", 2), ("seqcold", 3)])
+@pytest.mark.parametrize("path,world", [("gs", 2), ("seq", 2), ("gs", 3), ("seqlam", 2), ("seqcold", 3),
+                                        ("gscold", 8), ("seqcold", 8)])
 def test_cv_folds_sharded_over_ranks(tmp_path, path, world):
     """K fold chains + the full-data chain on `world` gloo ranks: every rank ends with the same model, and it is the
     one the pinned oracle's single-process gs_path / sequential_path under CV selects (same folds)."""
@@ -93,12 +94,14 @@ def test_cv_folds_sharded_over_ranks(tmp_path, path, world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import port_ctypes as P
     out = str(tmp_path / "cv")
-    port = 29531 + world + {"gs": 7, "seq": 0, "seqlam": 13, "seqcold": 19}[path]
+    port = 29531 + world + {"gs": 7, "seq": 0, "seqlam": 13, "seqcold": 19, "gscold": 29}[path]
     mp.spawn(_cv_worker, args=(world, port, path, out), nprocs=world, join=True)
     X, y, fold = _cv_problem()
     kw = {"gs": dict(path_type=2, s_min=1, s_max=20), "seq": dict(sequence=np.arange(1, 13)),
           "seqlam": dict(sequence=np.arange(1, 7), lambda_seq=[0.0, 0.02, 0.1]),
-          "seqcold": dict(sequence=np.arange(1, 13), is_warm_start=False)}[path]
+          "seqcold": dict(sequence=np.arange(1, 13), is_warm_start=False),
+          # (fold x s) pairs of the golden-section evaluations and of the final sweep over 8 ranks
+          "gscold": dict(path_type=2, s_min=1, s_max=20, is_warm_start=False)}[path]
     want = P.trace(X, y, is_cv=True, K=5, cv_fold_id=fold, **kw)
     got = [np.load(out + ".%d.npz" % r) for r in range(world)]
     for g in got[1:]:
