@@ -21,7 +21,7 @@ _vp = ctypes.c_void_p
 
 # names every build of libbessx.so must export (checked by tests/test_abi.py against include/bessx.h)
 SYMBOLS = [
-    "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_session_create",
+    "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_bessCpp", "bessx_session_create",
     "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_sequential_path", "bessx_session_gs_path",
     "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
@@ -46,6 +46,12 @@ class Problem(ctypes.Structure):
                 ("is_warm_start", _i), ("always_select", _I), ("always_select_len", _i), ("device", _i),
                 ("group_index", _I), ("group_index_len", _i),
                 ("is_screening", _i), ("screening_size", _i), ("score_mode", _i), ("max_sparsity", _i)]
+
+
+class RResult(ctypes.Structure):
+    _fields_ = [("beta", _D), ("coef0", _d), ("train_loss", _d), ("ic", _d), ("lambda_", _d), ("all_capacity", _i),
+                ("n_all", _i), ("beta_all", _D), ("coef0_all", _D), ("train_loss_all", _D), ("ic_all", _D),
+                ("screening_A", _I)]
 
 
 class PathResult(ctypes.Structure):
@@ -74,6 +80,9 @@ def lib():
             [_D, _i, _i, _D, _i, _i, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _I, _i, _D, _i, _I, _i, _D, _i]
             + [_i, _i, _i, _d, _d, _d, _i, _i, _i, _i, _I, _i, _d]
             + [_D, _i, _D, _i, _D, _i, _D, _i, _D, _D, _i, _D, _i, _D, _i, _I, _i, _I])
+        L.bessx_bessCpp.argtypes = ([_D, _i, _i, _D, _i, _D, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _D, _i, _I, _i, _D,
+                                     _i, _i, _i, _i, _d, _d, _d, _i, _i, _i, _i, _I, _i, _I, _i, _d,
+                                     ctypes.POINTER(RResult)])
         L.bessx_session_create.argtypes = [ctypes.POINTER(_vp), ctypes.POINTER(Problem)]
         L.bessx_session_destroy.argtypes = [_vp]
         L.bessx_session_destroy.restype = None
@@ -169,6 +178,45 @@ def pywrap_bess(x, y, data_type, weight, is_normal, algorithm_type, model_type, 
         loss.size, _dp(ic), ic.size, _dp(nullloss), _dp(aic), aic.size, _dp(bic), bic.size, _dp(gic), gic.size,
         _ip(a_out), a_out.size, _ip(l_out)))
     return beta, coef0, loss, ic, float(nullloss[0]), aic, bic, gic, a_out, int(l_out[0])
+
+
+def bessCpp(x, y, data_type, weight, is_normal, algorithm_type, model_type, max_iter, exchange_num, path_type,
+            is_warm_start, ic_type, is_cv, K, state, sequence, lambda_seq, s_min, s_max, K_max, epsilon, lambda_min,
+            lambda_max, nlambda, is_screening, screening_size, powell_path, g_index, always_select, tao):
+    """The R-facing entry (src/bess.h:20-33) through the C ABI (bessx_bessCpp): same 30 arguments, x handed over
+    column-major like an R matrix; returns the named entries of the list the R build returns."""
+    x = np.asfortranarray(x, dtype=np.float64)
+    n, p = x.shape
+    y, weight, state, lambda_seq = _f64(y).reshape(-1), _f64(weight), _f64(state), _f64(lambda_seq)
+    sequence, g_index, always_select = _i32(sequence), _i32(g_index), _i32(always_select)
+    cap = sequence.size * lambda_seq.size if path_type == 1 else 2 * (s_max - s_min + 1) + 128
+    beta = np.zeros(p)
+    beta_all = np.zeros((p, cap), order="F")
+    coef0_all, loss_all, ic_all = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    scr = np.zeros(max(screening_size, 1), dtype=np.int32)
+    r = RResult()
+    r.beta, r.all_capacity = _dp(beta), cap
+    r.beta_all, r.coef0_all, r.train_loss_all, r.ic_all, r.screening_A = (_dp(beta_all), _dp(coef0_all), _dp(loss_all),
+                                                                         _dp(ic_all), _ip(scr))
+    _check(lib().bessx_bessCpp(_dp(x), n, p, _dp(y), data_type, _dp(weight), int(is_normal), algorithm_type, model_type,
+                               max_iter, exchange_num, path_type, int(is_warm_start), ic_type, int(is_cv), K, _dp(state),
+                               state.size, _ip(sequence), sequence.size, _dp(lambda_seq), lambda_seq.size, s_min, s_max,
+                               K_max, epsilon, lambda_min, lambda_max, nlambda, int(is_screening), screening_size,
+                               powell_path, _ip(g_index), g_index.size, _ip(always_select), always_select.size, tao,
+                               ctypes.byref(r)))
+    k = min(r.n_all, cap)
+    out = {"beta": beta, "coef0": r.coef0, "train_loss": r.train_loss, "ic": r.ic, "lambda": r.lambda_,
+           "beta_all": np.array(beta_all[:, :k]), "coef0_all": coef0_all[:k], "train_loss_all": loss_all[:k],
+           "ic_all": ic_all[:k]}
+    if path_type == 1:  # list over lambda of p x len(sequence); ic_all as the len(sequence) x len(lambda) matrix
+        ns, nl = sequence.size, lambda_seq.size
+        out["beta_all"] = [np.array(beta_all[:, j * ns:(j + 1) * ns]) for j in range(nl)]
+        out["coef0_all"] = [coef0_all[j * ns:(j + 1) * ns] for j in range(nl)]
+        out["train_loss_all"] = [loss_all[j * ns:(j + 1) * ns] for j in range(nl)]
+        out["ic_all"] = ic_all[:ns * nl].reshape(nl, ns).T
+    if is_screening:
+        out["screening_A"] = scr[:screening_size].copy()
+    return out
 
 
 class Session:

@@ -3332,6 +3332,115 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
 }
 
 // ----------------------------------------------------------------------------------------------
+// bessCpp drop-in for the R package (src/bess.h:20-33; R/src/RcppExports.cpp:10-48): see include/bessx.h 1b
+// ----------------------------------------------------------------------------------------------
+int bessx_bessCpp(const double *x, int n, int p, const double *y, int data_type, const double *weight, int is_normal,
+                  int algorithm_type, int model_type, int max_iter, int exchange_num, int path_type,
+                  int is_warm_start, int ic_type, int is_cv, int K, const double *state, int state_len,
+                  const int *sequence, int sequence_len, const double *lambda_seq, int lambda_len, int s_min, int s_max,
+                  int K_max, double epsilon, double lambda_min, double lambda_max, int nlambda, int is_screening,
+                  int screening_size, int powell_path, const int *g_index, int g_index_len, const int *always_select,
+                  int always_select_len, double tao, bessx_r_result *res) {
+  (void)exchange_num; (void)state; (void)state_len; (void)K_max; (void)epsilon; (void)tao;  // dead in the reference too
+  if (!x || !y || !res || !res->beta) return fail(BESSX_ERR_ARG, "bessCpp: null argument");
+  if (!g_index || g_index_len < 1 || g_index_len > p) return fail(BESSX_ERR_ARG, "bessCpp: bad group index");
+  const bool seqp = path_type == 1;
+  const bool powell = !seqp && (algorithm_type == 5 || algorithm_type == 3);  // src/bess.cpp:174-180
+  if (seqp && (!sequence || sequence_len < 1 || !lambda_seq || lambda_len < 1))
+    return fail(BESSX_ERR_ARG, "bessCpp: empty sequence / lambda_seq");
+  bessx_problem pb;
+  std::memset(&pb, 0, sizeof(pb));
+  pb.n = n;
+  pb.p = p;
+  pb.x = x;
+  pb.x_col_major = 1;
+  pb.y = y;
+  pb.weight = weight;
+  pb.data_type = data_type;
+  pb.is_normal = is_normal;
+  pb.model_type = model_type;
+  pb.algorithm_type = algorithm_type;
+  pb.max_iter = max_iter;
+  pb.is_warm_start = is_warm_start;
+  pb.always_select = always_select;
+  pb.always_select_len = always_select_len;
+  pb.device = -1;
+  pb.group_index = g_index;
+  pb.group_index_len = g_index_len;
+  pb.is_screening = is_screening ? 1 : 0;
+  pb.screening_size = screening_size;
+  long gmax = 1, top = seqp ? 0 : s_max;
+  for (int g = 0; g < g_index_len; g++) gmax = std::max<long>(gmax, (g + 1 < g_index_len ? g_index[g + 1] : p) - g_index[g]);
+  if (seqp)
+    for (int i = 0; i < sequence_len; i++) top = std::max<long>(top, sequence[i]);
+  pb.max_sparsity = (int)std::min<long>(std::min<long>(top * gmax, p), T0_HARD);
+  bessx_session *s = nullptr;
+  if (int rc = bessx_session_create(&s, &pb)) return rc;
+  auto done = [&](int rc) {
+    std::string keep = g_err;
+    bessx_session_destroy(s);
+    g_err = keep;
+    return rc;
+  };
+  if (is_cv)
+    if (int rc = bessx_session_set_cv(s, K, nullptr, 123u)) return done(rc);
+  const int cap = seqp ? sequence_len * lambda_len : (powell ? 128 : 2 * (s_max - s_min + 1) + 64);
+  const int maxT = (int)std::max<long>(1, std::min<long>(p, std::max<long>(top, 1) * gmax));
+  std::vector<double> c_ic((size_t)cap), c_loss((size_t)cap), c_c0((size_t)cap), c_beta((size_t)cap * maxT);
+  std::vector<int> c_sup((size_t)cap * maxT, -1), c_T0((size_t)cap);
+  std::vector<double> c_lam((size_t)cap);
+  bessx_path_result r;
+  std::memset(&r, 0, sizeof(r));
+  r.beta = res->beta;
+  r.capacity = cap;
+  r.max_T0 = maxT;
+  r.cand_T0 = c_T0.data();
+  r.cand_lambda = c_lam.data();
+  r.cand_ic = c_ic.data();
+  r.cand_train_loss = c_loss.data();
+  r.cand_coef0 = c_c0.data();
+  r.cand_beta = c_beta.data();
+  r.cand_support = c_sup.data();
+  int rc = seqp     ? bessx_session_sequential_path(s, sequence, sequence_len, lambda_seq, lambda_len, ic_type, is_cv, &r)
+           : powell ? bessx_session_pgs_path(s, s_min, s_max, lambda_min, lambda_max, nlambda, powell_path, ic_type,
+                                             is_cv, &r)
+                    : bessx_session_gs_path(s, s_min, s_max, ic_type, is_cv, &r);
+  if (rc) return done(rc);
+  if (is_screening && res->screening_A) bessx_session_get_screening(s, res->screening_A, screening_size);
+  res->coef0 = r.coef0;
+  res->train_loss = r.train_loss;
+  res->ic = r.ic;
+  res->lambda = r.lambda;
+  const int nc = std::min(r.n_candidates, cap);
+  res->n_all = nc;
+  // candidates arrive in evaluation order; the sequential path's order is the snake of src/path.cpp:50
+  std::vector<int> where((size_t)nc);
+  if (seqp) {
+    int c = 0;
+    for (int i = 0; i < sequence_len; i++) {
+      const int step = (i % 2 == 0) ? 1 : -1;
+      for (int j = (i % 2 == 0) ? 0 : lambda_len - 1; j < lambda_len && j >= 0 && c < nc; j += step)
+        where[c++] = j * sequence_len + i;
+    }
+  } else {
+    for (int c = 0; c < nc; c++) where[c] = c;
+  }
+  const int wr = std::min(nc, res->all_capacity);
+  if (res->beta_all) std::fill(res->beta_all, res->beta_all + (size_t)p * std::max(res->all_capacity, 0), 0.0);
+  for (int c = 0; c < nc; c++) {
+    const int q = where[c];
+    if (q >= wr) continue;
+    if (res->coef0_all) res->coef0_all[q] = c_c0[c];
+    if (res->train_loss_all) res->train_loss_all[q] = c_loss[c];
+    if (res->ic_all) res->ic_all[q] = c_ic[c];
+    if (res->beta_all)
+      for (int t = 0; t < maxT && c_sup[(size_t)c * maxT + t] >= 0; t++)
+        res->beta_all[(size_t)q * p + c_sup[(size_t)c * maxT + t]] = c_beta[(size_t)c * maxT + t];
+  }
+  return done(BESSX_OK);
+}
+
+// ----------------------------------------------------------------------------------------------
 // single-kernel entry points for parity tests
 // ----------------------------------------------------------------------------------------------
 int bessx_op_xtv(const double *x, int n, int p, int ld, const double *v, const double *v2, double *out,

@@ -62,6 +62,37 @@ int bessx_pywrap_bess(double *x, int x_row, int x_col, double *y, int y_len, int
                       double *gic_out, int gic_out_len, int *A_out, int A_out_len, int *l_out);
 
 /* ---------------------------------------------------------------------------------------
+ * 1b. Drop-in for bessCpp (src/bess.h:20-33, src/bess.cpp:37-214), the C++ entry the R package binds
+ *     (R/src/RcppExports.cpp:10-48).  Same 30 arguments with Eigen objects unpacked into pointer + length
+ *     (bool -> int); x is COLUMN-major n x p, as Eigen::MatrixXd and R matrices are.  The outputs are the named
+ *     entries of the list the R build returns (src/path.cpp:116-123 sequential, :376-380 golden section,
+ *     + screening_A, src/bess.cpp:207), flattened:
+ *       sequential_path: candidate q = j * sequence_len + i for lambda j and size i -- beta_all = lambda_len blocks of
+ *         p x sequence_len (column-major), coef0_all / train_loss_all = lambda_len blocks of sequence_len, ic_all =
+ *         sequence_len x lambda_len column-major;  n_all = sequence_len * lambda_len.
+ *       gs_path / pgs_path: candidate q = evaluation order (every new golden-section point, then every improvement
+ *         of the final sweep; Powell: the best point of every line search and the final re-fit); n_all = count.
+ *     All coefficients are de-normalised like the R build's (src/path.cpp:76-110, :330-373).  R/src/bess_amd_shim.cpp
+ *     is the Rcpp wrapper around this function.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  double *beta;            /* p (caller-allocated) */
+  double coef0, train_loss, ic, lambda;
+  int all_capacity;        /* in: candidates the *_all arrays can hold (beta_all: p * all_capacity doubles) */
+  int n_all;               /* out: candidates the path produced (written: min(n_all, all_capacity)) */
+  double *beta_all, *coef0_all, *train_loss_all, *ic_all; /* caller-allocated, any may be NULL */
+  int *screening_A;        /* screening_size entries (0-based original columns) when is_screening, may be NULL */
+} bessx_r_result;
+
+int bessx_bessCpp(const double *x, int n, int p, const double *y, int data_type, const double *weight, int is_normal,
+                  int algorithm_type, int model_type, int max_iter, int exchange_num, int path_type,
+                  int is_warm_start, int ic_type, int is_cv, int K, const double *state, int state_len,
+                  const int *sequence, int sequence_len, const double *lambda_seq, int lambda_len, int s_min, int s_max,
+                  int K_max, double epsilon, double lambda_min, double lambda_max, int nlambda, int is_screening,
+                  int screening_size, int powell_path, const int *g_index, int g_index_len, const int *always_select,
+                  int always_select_len, double tao, bessx_r_result *res);
+
+/* ---------------------------------------------------------------------------------------
  * 2. Session: the state bessCpp builds (src/bess.cpp:61-165), resident in HBM.
  * ------------------------------------------------------------------------------------- */
 typedef struct bessx_session bessx_session;

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "bessx.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(bessx_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(bessx_[A-Za-z_0-9]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
