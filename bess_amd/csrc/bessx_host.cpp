@@ -101,6 +101,7 @@ struct bessx_session {
   int *gidx = nullptr, *gsz = nullptr, *goff = nullptr, *gcols_new = nullptr;
   double *mblk = nullptr, *dcol = nullptr;
   double *mblk2 = nullptr;  // Cox with groups: second term of the per-group blocks
+  double *mwork = nullptr, *zwork = nullptr;  // groups wider than 16 columns: Cholesky work copy of the blocks, 2 p vector
   int *allcols = nullptr;   // 0 .. p-1 (column lists of the panels of the Cox group branch)
   std::vector<double *> gxtx_rs;  // per row set: X_g^T diag(mask) X_g blocks (LM)
   int cox_state_rs = -1;
@@ -302,6 +303,8 @@ static void session_free(bessx_session *s) {
   F(s->mblk);
   F(s->dcol);
   F(s->mblk2);
+  F(s->mwork);
+  F(s->zwork);
   F(s->allcols);
   for (auto q : s->gxtx_rs) F(q);
   for (auto q : s->cox_allocs) F(q);
@@ -1227,7 +1230,8 @@ static int algorithm_fit_grouped(bessx_session *s) {
       e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], nullptr, s->part_rs[rs], nullptr, nullptr, 0, s->st);
       if (e == hipSuccess)
         e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->part_rs[rs], s->nrb, s->p, 1,
-                               (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st);
+                               (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork,
+                               s->zwork);
     } else if (cox) {
       // X_g^T h X_g without the n x n Hessian of src/Algorithm.h:1536-1546 (launch_cox_group_moments)
       e = launch_cox_group_moments(s->X, s->ld, s->n, s->p, s->cox, s->allcols, (int)std::min<size_t>(s->cox_M_cols, 256),
@@ -1235,13 +1239,13 @@ static int algorithm_fit_grouped(bessx_session *s) {
                                    (long)s->goff_h[s->N], s->mblk, s->mblk2, s->dcol, s->st);
       if (e == hipSuccess)
         e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->mblk, s->dcol, nullptr, 0, s->p, 0, 1.0, lambda,
-                               s->beta_dense, s->always, s->bd, s->st);
+                               s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork, s->zwork);
     } else {
       e = launch_group_moments(s->gmax, s->X, s->ld, s->n, s->h_rs[rs], s->r_rs[rs], s->N, s->gidx, s->gsz, s->goff,
                                s->mblk, s->dcol, s->st);
       if (e == hipSuccess)
         e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->mblk, s->dcol, nullptr, 0, s->p, 0, 1.0, lambda,
-                               s->beta_dense, s->always, s->bd, s->st);
+                               s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork, s->zwork);
     }
     if (e == hipSuccess) e = launch_topk(s->bd, s->N, T0, s->A_new, s->cand, nullptr, 0, s->st);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group get_A: ") + hipGetErrorString(e));
@@ -2623,10 +2627,16 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       s->gidx_h[g] = a;
       s->gsz_h[g] = b - a;
       s->gmax = std::max(s->gmax, b - a);
-      s->goff_h[g + 1] = s->goff_h[g] + (b - a) * (b - a);
+      const long long nxt = (long long)s->goff_h[g] + (long long)(b - a) * (b - a);
+      if (nxt > 0x7fffffffLL) return bail(fail(BESSX_ERR_UNSUPPORTED, "group blocks exceed 2^31 entries in total"));
+      s->goff_h[g + 1] = (int)nxt;
     }
     s->grouped = s->gmax > 1;
-    if (s->gmax > 16) return bail(fail(BESSX_ERR_UNSUPPORTED, "group sizes above 16 are not built"));
+    // groups of up to 16 columns: register-resident blocks and a Jacobi square root per thread; wider ones: tiled
+    // moments and a Cholesky form of the same score (k_group_moments_big / k_group_score_big).  Cox forms the
+    // suffix-sum matrix of whole groups in a 256-column panel.
+    if (s->gmax > 256 && s->model_type == 4)
+      return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox: groups wider than 256 columns are not built"));
     if (s->grouped && s->model_type == 4 && !(pb->algorithm_type == 2 || pb->algorithm_type == 3))
       return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox with groups of size > 1 exists only for algorithm_type 2 / 3 (the "
                                               "group branch of GroupPdasCox::get_A, src/Algorithm.h:1497-1568)"));
@@ -2830,6 +2840,10 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(dmalloc(&s->gcols_new, (size_t)s->capA));
     HIPT(dmalloc(&s->mblk, (size_t)s->goff_h[s->N]));
     HIPT(dmalloc(&s->dcol, (size_t)p));
+    if (s->gmax > 16) {
+      HIPT(dmalloc(&s->mwork, (size_t)s->goff_h[s->N]));
+      HIPT(dmalloc(&s->zwork, (size_t)2 * p));
+    }
     if (s->model_type == 4) {
       HIPT(dmalloc(&s->mblk2, (size_t)s->goff_h[s->N]));
       HIPT(dmalloc(&s->allcols, (size_t)p));

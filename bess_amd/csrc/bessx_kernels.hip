@@ -2535,6 +2535,7 @@ __global__ void __launch_bounds__(256) k_group_moments(const double *__restrict_
   // sums of a panel at a time); mblk / dcol stay indexed by the global group / column
   __shared__ double sm[4];
   const int g = blockIdx.x, s = gsz[g], c0 = gidx[g];
+  if (s > S) return;  // (uniform) wider groups: k_group_moments_big
   const int cx = c0 - cshift;
   double acc[S * (S + 1) / 2], dacc[S];
 #pragma unroll
@@ -2585,6 +2586,7 @@ __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict
   const int g = blockIdx.x * 64 + threadIdx.x;
   if (g >= N) return;
   const int s = gsz[g], c0 = gidx[g];
+  if (s > GRP_MAX) return;  // wider groups: k_group_score_big
   double a[GRP_MAX * GRP_MAX], v[GRP_MAX * GRP_MAX], dv[GRP_MAX], bv[GRP_MAX], t[GRP_MAX];
   for (int u = 0; u < s; u++) {
     double d;
@@ -2660,6 +2662,146 @@ __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict
   }
   if (always != nullptr && always[g]) res = DBL_MAX;
   bd[g] = res;
+}
+
+// ---- groups wider than GRP_MAX columns (any width the session's k x k capacity allows) ------------------------
+// Moments: one block per (group, 8 x 8 tile of its s x s block); 64 + 8 register accumulators per thread over the
+// rows, fixed-order block sums.  The tile index t enumerates the lower triangle of the ceil(s / 8)^2 tile grid.
+constexpr int GB_T = 8;
+__global__ void __launch_bounds__(256) k_group_moments_big(const double *__restrict__ X, long ld, int n,
+                                                           const double *__restrict__ w1,
+                                                           const double *__restrict__ w2,
+                                                           const int *__restrict__ gidx, const int *__restrict__ gsz,
+                                                           const int *__restrict__ goff, double *__restrict__ mblk,
+                                                           double *__restrict__ dcol, int cshift) {
+  __shared__ double sm[4];
+  const int g = blockIdx.x, s = gsz[g], c0 = gidx[g];
+  if (s <= GRP_MAX) return;
+  const int nt = (s + GB_T - 1) / GB_T;
+  int tu = 0, t = blockIdx.y;
+  if (t >= nt * (nt + 1) / 2) return;
+  while (t > tu) {  // row tu of the triangle holds tu + 1 tiles
+    t -= tu + 1;
+    tu++;
+  }
+  const int tv = t, u0 = tu * GB_T, v0 = tv * GB_T;
+  const double *xu = X + (size_t)(c0 - cshift + u0) * ld, *xv = X + (size_t)(c0 - cshift + v0) * ld;
+  double acc[GB_T][GB_T], dacc[GB_T];
+#pragma unroll
+  for (int a = 0; a < GB_T; a++) {
+    dacc[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < GB_T; b++) acc[a][b] = 0.0;
+  }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double cu[GB_T], cv[GB_T];
+#pragma unroll
+    for (int a = 0; a < GB_T; a++) {
+      cu[a] = u0 + a < s ? xu[(size_t)a * ld + i] : 0.0;
+      cv[a] = v0 + a < s ? xv[(size_t)a * ld + i] : 0.0;
+    }
+    const double wa = w1 ? w1[i] : 1.0, wb = w2 ? w2[i] : 0.0;
+#pragma unroll
+    for (int a = 0; a < GB_T; a++) {
+      const double ua = cu[a] * wa;
+      dacc[a] = fma(cu[a], wb, dacc[a]);
+#pragma unroll
+      for (int b = 0; b < GB_T; b++) acc[a][b] = fma(ua, cv[b], acc[a][b]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < GB_T; a++) {
+    if (tv == 0 && w2 != nullptr) {  // X_g^T w2 once per tile row (uniform)
+      const double dv = block_sum_256(dacc[a], sm);
+      if (threadIdx.x == 0 && u0 + a < s) dcol[c0 + u0 + a] = dv;
+    }
+#pragma unroll
+    for (int b = 0; b < GB_T; b++) {
+      const double mv = block_sum_256(acc[a][b], sm);
+      if (threadIdx.x == 0 && u0 + a < s && v0 + b < s) {
+        mblk[goff[g] + (v0 + b) * s + (u0 + a)] = mv;
+        mblk[goff[g] + (u0 + a) * s + (v0 + b)] = mv;
+      }
+    }
+  }
+}
+
+// Score of a wide group WITHOUT the matrix square root: with M = Phi^2 = L L^T (Cholesky),
+//   || Phi b + Phi^{-1} d ||^2 = b'Mb + 2 b'd + d'M^{-1}d = || L^T b + L^{-1} d ||^2,
+// a sum of squares again (no cancellation).  One block per group: left-looking column Cholesky in a global work
+// copy W (L2-resident), forward substitution, then the column sums of L against b.
+__global__ void __launch_bounds__(256) k_group_score_big(int N, const int *__restrict__ gidx,
+                                                         const int *__restrict__ gsz, const int *__restrict__ goff,
+                                                         const double *__restrict__ mblk,
+                                                         const double *__restrict__ dcol,
+                                                         const double *__restrict__ part, int nrb, int p, int lm,
+                                                         double n_t, double lambda,
+                                                         const double *__restrict__ beta_dense,
+                                                         const unsigned char *__restrict__ always,
+                                                         double *__restrict__ work, double *__restrict__ zwork,
+                                                         double *__restrict__ bd) {
+  __shared__ double sm[4];
+  __shared__ double piv;
+  const int g = blockIdx.x, s = gsz[g], c0 = gidx[g], tid = threadIdx.x;
+  if (s <= GRP_MAX) return;
+  double *W = work + goff[g];          // s x s, column-major: W[j * s + i] = element (i, j)
+  double *z = zwork + c0, *bv = zwork + p + c0;  // right-hand side / solution and beta of this group
+  for (int u = tid; u < s; u += 256) {
+    double d;
+    if (lm) {
+      double sacc = 0.0;
+      for (int rb = 0; rb < nrb; rb++) sacc += part[(size_t)rb * p + c0 + u];
+      d = sacc / n_t;
+    } else {
+      d = dcol[c0 + u];
+    }
+    const double b = beta_dense[c0 + u];
+    bv[u] = b;
+    z[u] = d - 2.0 * lambda * b;
+  }
+  for (int e = tid; e < s * s; e += 256) {
+    const int i = e % s, j = e / s;
+    double m = mblk[goff[g] + e];
+    if (lm) m = m / n_t;
+    if (i == j) m += 2.0 * lambda;
+    W[e] = m;
+  }
+  __syncthreads();
+  for (int j = 0; j < s; j++) {
+    // column j: W[i][j] -= sum_{k<j} L[i][k] L[j][k] for i >= j (each thread its own rows: no conflicts)
+    for (int i = j + tid; i < s; i += 256) {
+      double v = W[(size_t)j * s + i];
+      for (int k = 0; k < j; k++) v = fma(-W[(size_t)k * s + i], W[(size_t)k * s + j], v);
+      W[(size_t)j * s + i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) piv = sqrt(W[(size_t)j * s + j]);
+    __syncthreads();
+    const double rp = 1.0 / piv;
+    for (int i = j + tid; i < s; i += 256) W[(size_t)j * s + i] = (i == j) ? piv : W[(size_t)j * s + i] * rp;
+    __syncthreads();
+  }
+  // forward substitution z <- L^{-1} z (column oriented)
+  for (int j = 0; j < s; j++) {
+    if (tid == 0) z[j] = z[j] / W[(size_t)j * s + j];
+    __syncthreads();
+    const double zj = z[j];
+    for (int i = j + 1 + tid; i < s; i += 256) z[i] = fma(-W[(size_t)j * s + i], zj, z[i]);
+    __syncthreads();
+  }
+  // t_j = sum_{i>=j} L[i][j] b_i + z_j; result = sum t_j^2 / s
+  double acc = 0.0;
+  for (int j = tid; j < s; j += 256) {
+    double t = z[j];
+    for (int i = j; i < s; i++) t = fma(W[(size_t)j * s + i], bv[i], t);
+    acc = fma(t, t, acc);
+  }
+  acc = block_sum_256(acc, sm);
+  if (tid == 0) {
+    double res = acc / (double)s;
+    if (always != nullptr && always[g]) res = DBL_MAX;
+    bd[g] = res;
+  }
 }
 
 // commit of a group-mode iteration: history on the T0 group ids, coefficients on the K expanded columns
@@ -5292,6 +5434,12 @@ hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const
     GM_GO(16);
 #undef GM_GO
   LAUNCH_CHECK();
+  if (smax > GRP_MAX) {  // the wide groups, tile by tile (blocks of narrow groups / surplus tiles return at once)
+    const int nt = (smax + GB_T - 1) / GB_T;
+    hipLaunchKernelGGL(k_group_moments_big, dim3(N, nt * (nt + 1) / 2), dim3(256), 0, st, X, ld, n, w1, w2, gidx, gsz,
+                       goff, mblk, dcol, cshift);
+    LAUNCH_CHECK();
+  }
   return hipSuccess;
 }
 
@@ -5351,10 +5499,16 @@ hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxB
 hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
                               const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
                               double lambda, const double *beta_dense, const unsigned char *always, double *bd,
-                              hipStream_t st) {
+                              hipStream_t st, int smax, double *work, double *zwork) {
   hipLaunchKernelGGL(k_group_score, dim3((N + 63) / 64), dim3(64), 0, st, N, gidx, gsz, goff, mblk, dcol, part, nrb, p,
                      lm, n_t, lambda, beta_dense, always, bd);
   LAUNCH_CHECK();
+  if (smax > GRP_MAX) {
+    if (work == nullptr || zwork == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_group_score_big, dim3(N), dim3(256), 0, st, N, gidx, gsz, goff, mblk, dcol, part, nrb, p, lm,
+                       n_t, lambda, beta_dense, always, work, zwork, bd);
+    LAUNCH_CHECK();
+  }
   return hipSuccess;
 }
 

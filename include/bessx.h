@@ -26,7 +26,7 @@ enum {
   BESSX_OK = 0,
   BESSX_ERR_ARG = 1,         /* invalid argument (the reference would crash or read out of bounds) */
   BESSX_ERR_HIP = 2,         /* HIP runtime / device failure, or no device */
-  BESSX_ERR_UNSUPPORTED = 3, /* valid for the reference, not built here (groups of size > 1, screening) */
+  BESSX_ERR_UNSUPPORTED = 3, /* valid for the reference, not built here (see bessx_problem: screening with groups / Poisson) */
   BESSX_ERR_NUMERIC = 4      /* non-finite pivot in a k x k solve */
 };
 
@@ -114,7 +114,9 @@ typedef struct {
   int device;        /* HIP device ordinal, or -1 for the current device */
   const int *group_index; /* Data::g_index (src/Data.h:59-67): first column of every group, ascending from 0; NULL or
                              length p = every column its own group.  With groups, sparsity levels and always_select
-                             count / name GROUPS.  Group sizes up to 16; Cox with real groups needs algorithm_type 2 / 3
+                             count / name GROUPS.  Any group width the session's capacity (max_sparsity) holds -- up to 16 columns
+                             a register-resident block per group, wider ones a tiled path; Cox: at most 256 columns per
+                             group.  Cox with real groups needs algorithm_type 2 / 3
                              (the group branch of GroupPdasCox::get_A, src/Algorithm.h:1497-1568). */
   int group_index_len;
   int is_screening;   /* sure independence screening before the path (screening(), src/screening.cpp:26-105; called at

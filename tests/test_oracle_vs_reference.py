@@ -49,3 +49,27 @@ def test_cox_group_branch_random(seed):
                     sequence=np.arange(1, 4))):
         kw = dict(kw, data_type=3, model_type=4)
         assert_same_trace(P.trace(X, st, **kw), R.trace(X, st, **kw), beta_rtol=1e-8, what="cox groups %d" % seed)
+
+
+def _wide_groups(p, seed):
+    """group starts with widths 1..40 mixed (some beyond the 16-column register path of the GPU kernels)"""
+    rng = np.random.default_rng(seed)
+    starts, c = [], 0
+    while c < p:
+        starts.append(c)
+        c += int(rng.choice([1, 2, 5, 16, 17, 24, 40]))
+    return np.array(starts, dtype=np.int32)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_wide_groups_random(seed):
+    """Groups wider than 16 columns: the oracle's Jacobi square root against Eigen's sqrt() / LDLT in the reference
+    (src/utilities.cpp:142-177), LM and logistic."""
+    X, y, _, _ = synth.make_lm(500, 150, 6, seed=seed)
+    gi = _wide_groups(150, seed)
+    kw = dict(algorithm_type=2, g_index=gi, ic_type=3, sequence=np.arange(1, 5))
+    assert_same_trace(P.trace(X, y, **kw), R.trace(X, y, **kw), beta_rtol=1e-8, what="lm wide groups %d" % seed)
+    Xl, yl, _, _ = synth.make_logistic(900, 120, 5, seed=seed)
+    gl = _wide_groups(120, seed + 1)
+    kw = dict(algorithm_type=2, g_index=gl, data_type=2, model_type=2, ic_type=3, sequence=np.arange(1, 4))
+    assert_same_trace(P.trace(Xl, yl, **kw), R.trace(Xl, yl, **kw), beta_rtol=1e-7, what="logit wide groups %d" % seed)
