@@ -252,7 +252,8 @@ class Session:
 
     def counters(self):
         """Diagnostics of the covariance form (bessx_session_counter)."""
-        names = ("chained_fits", "cg_fallbacks", "passes_over_X", "chained_queued", "background_fills")
+        names = ("chained_fits", "cg_fallbacks", "passes_over_X", "chained_queued", "background_fills",
+                 "solves_from_inverse", "inverse_rebuilds")
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in enumerate(names)}
 
     def screening(self):

@@ -156,6 +156,12 @@ hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_
 // row-dealt kernel (k_cgr), otherwise / beyond the tile-dealt one (k_cg)
 hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
                      int slot, const CholFuse *fuse, int maxit, hipStream_t st, double tol = 1e-13, bool by_rows = true);
+// the selection of a covariance-form slot and the solve behind it in one launch (k_sel_cgr)
+bool sel_cgr_applies(int len, int m);
+hipError_t launch_sel_cgr(const double *score, int len, int k, int *A_new, const FitCtrl *ctrl, int slot,
+                          const TopkNeed *need, double ridge, const double *rhs, double *sol, const CholFuse *fuse,
+                          int maxit, hipStream_t st, double tol, double *H = nullptr, int *hact = nullptr,
+                          int *hmeta = nullptr, double *hinfo = nullptr, const int *cmeta = nullptr);
 hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                            const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);

@@ -147,11 +147,20 @@ struct bessx_session {
     double *G = nullptr;
     int *slot_of = nullptr, *meta = nullptr;
     double *GS = nullptr;  // COV_CS x COV_CS: Gram entries between cached columns, indexed by cache slot (L2-sized)
+    // the maintained inverse of the last k x k system solved on this row set (hinv_body of the kernels): COV_CS x COV_CS
+    // slot-indexed, the slots it covers, {valid, cache generation}, {its ridge, the ridge of the last solve}
+    double *H = nullptr;
+    int *hact = nullptr, *hmeta = nullptr;
+    double *hinfo = nullptr;
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
   int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
+  bool fuse_sel = true;    // selection + solve of a slot in one launch, k_sel_cgr (BESSX_FUSE_SEL=0: two launches)
+  bool hinv = false;       // ... with the solve taken from a maintained inverse (bordering updates, hinv_body) where
+                           // possible: BESSX_HINV=1.  Off by default: measured at parity with the conjugate-gradient solve
+                           // (31 vs 30 us per solve launch on configs[1])
   bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
   // GLM IRLS step with the working response formed inside the Gram kernel (k_gram_irls: one read of the active
   // columns per step instead of two).  Measured on configs[2]: 0.180 s against 0.175 s unfused -- the 64 rows' exp /
@@ -336,6 +345,10 @@ static void session_free(bessx_session *s) {
     F(c.slot_of);
     F(c.meta);
     F(c.GS);
+    F(c.H);
+    F(c.hact);
+    F(c.hmeta);
+    F(c.hinfo);
   }
   F(s->cov_part);
   F(s->bd2);
@@ -459,11 +472,22 @@ static int alloc_cov_cache(bessx_session *s) {
   if (e == hipSuccess) e = hipMemset(c.GS, 0, (size_t)COV_CS * COV_CS * sizeof(double));
   if (e == hipSuccess) e = hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int));
   if (e == hipSuccess) e = hipMemset(c.meta, 0, 4 * sizeof(int));
+  if (e == hipSuccess) e = dmalloc(&c.H, (size_t)COV_CS * COV_CS);
+  if (e == hipSuccess) e = dmalloc(&c.hact, (size_t)COV_CS);
+  if (e == hipSuccess) e = dmalloc(&c.hmeta, 4);
+  if (e == hipSuccess) e = dmalloc(&c.hinfo, 2);
+  if (e == hipSuccess) e = hipMemset(c.hact, 0, (size_t)COV_CS * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(c.hmeta, 0, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(c.hinfo, 0xff, 2 * sizeof(double));  // NaN: no ridge seen yet
   if (e != hipSuccess) {
     (void)hipFree(c.G);
     (void)hipFree(c.slot_of);
     (void)hipFree(c.meta);
     (void)hipFree(c.GS);
+    (void)hipFree(c.H);
+    (void)hipFree(c.hact);
+    (void)hipFree(c.hmeta);
+    (void)hipFree(c.hinfo);
     return fail(BESSX_ERR_HIP, std::string("Gram column cache: ") + hipGetErrorString(e));
   }
   s->cov.push_back(c);
@@ -489,6 +513,10 @@ static int reset_path_caches(bessx_session *s) {
   for (auto &c : s->cov) {
     HIPX(hipMemsetAsync(c.slot_of, 0xff, (size_t)s->p * sizeof(int), s->st));
     HIPX(hipMemsetAsync(c.meta, 0, 4 * sizeof(int), s->st));
+    // the maintained inverse belongs to the old slot numbering; a path starts without one (and without a ridge seen)
+    HIPX(hipMemsetAsync(c.hmeta, 0, 4 * sizeof(int), s->st));
+    HIPX(hipMemsetAsync(c.hact, 0, (size_t)COV_CS * sizeof(int), s->st));
+    HIPX(hipMemsetAsync(c.hinfo, 0xff, 2 * sizeof(double), s->st));
   }
   return 0;
 }
@@ -770,6 +798,21 @@ struct SlotFuse {
   bool cont = false, cont_fused = false;
 };
 
+// arguments of the solve of a covariance-form slot (k_cg / k_cgr / k_chol with the gather and the commit fused in)
+static CholFuse cov_fuse_args(bessx_session *s, int rs, int T0, bool force_chol, SlotFuse *sf) {
+  bessx_session::CovCache &cv = s->cov[rs];
+  CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
+                 s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
+                 s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, s->cov_cs, PubArgs{}};
+  // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
+  if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
+    fz.pub = *sf->pub;
+    if (sf->pub_snapshot) fz.pub.on = 2;
+    sf->pub_fused = true;
+  }
+  return fz;
+}
+
 // solve + commit + residual of a slot whose active columns are all cached
 static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, bool force_chol = false,
                             SlotFuse *sf = nullptr) {
@@ -788,15 +831,7 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     // one launch: Gram gathered from the cache while loading, the solve, then the commit.  The solve is conjugate
     // gradients warm-started from the previous coefficients (k_cg); if its true residual does not reach 1e-13 it
     // parks the fit (cov_stall = 2) and the Cholesky kernel is issued for the slot (force_chol).
-    CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
-                   s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
-                   s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, s->cov_cs, PubArgs{}};
-    // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
-    if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
-      fz.pub = *sf->pub;
-      if (sf->pub_snapshot) fz.pub.on = 2;
-      sf->pub_fused = true;
-    }
+    CholFuse fz = cov_fuse_args(s, rs, T0, force_chol, sf);
     if (s->cov_cg && !force_chol)
       e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st, s->cg_tol,
                     s->cg_by_rows);
@@ -865,6 +900,18 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
     if (sf && sf->pub && sf->pub_snapshot && s->fuse && nd.commit_on && s->cov_cg && rs == 0) {
       nd.snap = *sf->pub;  // last slot of a chained batch: a repeated set is recorded AND snapshotted here
       nd.snap.on = 2;
+    }
+    if (s->fuse_sel && s->fuse && s->cov_cg && sel_cgr_applies(s->p, T0)) {
+      // selection and solve of this slot in ONE launch (k_sel_cgr): same phases, same control-block protocol
+      CholFuse fz = cov_fuse_args(s, rs, T0, false, sf);
+      const bool hv = s->hinv && fz.GS != nullptr;
+      e = launch_sel_cgr(s->bd, s->p, T0, s->A_new, s->ctrl, slot, &nd, lambda, s->xty[rs], s->sol, &fz, 64, s->st,
+                         s->cg_tol, hv ? cv.H : nullptr, cv.hact, cv.hmeta, cv.hinfo, cv.meta);
+      if (e == hipSuccess && rs != 0)  // CV row sets: sums of squares over the test rows for the final coefficients
+        e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
+                            s->sse, s->st, 1);
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot_cov (fused): ") + hipGetErrorString(e));
+      return 0;
     }
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
   } else if (e == hipSuccess) {
@@ -2939,6 +2986,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         }
         if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
         if (const char *ev = std::getenv("BESSX_FUSE")) s->fuse = std::string(ev) != "0";
+        if (const char *ev = std::getenv("BESSX_FUSE_SEL")) s->fuse_sel = std::string(ev) != "0";
+        if (const char *ev = std::getenv("BESSX_HINV")) s->hinv = std::string(ev) == "1";
         if (const char *ev = std::getenv("BESSX_DEFER_PUBLISH")) s->defer_pub = std::string(ev) != "0";
         if (!s->fuse) s->defer_pub = false;
         if (const char *ev = std::getenv("BESSX_CG_LAYOUT")) s->cg_by_rows = std::string(ev) != "tiles";
@@ -3016,6 +3065,10 @@ static void drop_folds(bessx_session *s) {
     (void)hipFree(s->cov[i].slot_of);
     (void)hipFree(s->cov[i].meta);
     (void)hipFree(s->cov[i].GS);
+    (void)hipFree(s->cov[i].H);
+    (void)hipFree(s->cov[i].hact);
+    (void)hipFree(s->cov[i].hmeta);
+    (void)hipFree(s->cov[i].hinfo);
   }
   if (!s->cov.empty()) s->cov.resize(1);
   if (!s->n_train.empty()) s->n_train.resize(1);
@@ -3207,6 +3260,15 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 2: return s->cov_panel_groups;
     case 3: return s->chain_queued;
     case 4: return s->cov_bg_fills;
+    case 5:
+    case 6: {  // maintained inverse, all-rows row set, since the last path started: solves taken from it / rebuilds
+      if (s->cov.empty() || s->cov[0].hmeta == nullptr) return 0;
+      int h[4] = {0, 0, 0, 0};
+      if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess ||
+          hipMemcpy(h, s->cov[0].hmeta, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+      return h[which == 5 ? 2 : 3];
+    }
     default: return -1;
   }
 }

@@ -390,23 +390,22 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
 
 // nd.slot_of != nullptr (covariance form of the LM fit, single chunk): the kernel ends with the work of k_cov_need on
 // the indices it has just selected -- one launch less per PDAS iteration.
-template <int EB>  // keys per thread this instance can hold (bucket of ceil(len / 1024))
-__global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score, const int *__restrict__ idx_in,
-                                               int len_total, int chunk, int k, int *__restrict__ out,
-                                               int *__restrict__ out_count, const FitCtrl *__restrict__ ctrl,
-                                               int slot, const int *__restrict__ run_flag, const TopkNeed nd) {
-  KT(1);
-  if (nd.pub.on && blockIdx.x == 1) {  // second workgroup: publishes the parent fit's snapshot, nothing else
-    publish_body(nd.pub);
-    return;
-  }
+// The selection as a device function of an NT-thread block (NT threads = 16 waves: k_topk; 8 waves: the first phase
+// of k_sel_cgr, which goes on to solve the selected system in the same launch).  EB = keys per thread this instance
+// can hold (bucket of ceil(len / NT)).
+template <int EB, int NT>
+__device__ __forceinline__ void topk_body(const double *__restrict__ score, const int *__restrict__ idx_in,
+                                          int len_total, int chunk, int k, int *__restrict__ out,
+                                          int *__restrict__ out_count, const FitCtrl *ctrl, int slot,
+                                          const int *__restrict__ run_flag, const TopkNeed &nd) {
+  constexpr int NWV = NT / 64;
   if (nd.cont_on) {
     // k_fit_continue(chained) as the prologue of the first kernel of the chained fit: it only starts if the fit
     // before it (serial cont_parent) ended here on a repeated set with fresh score sums
     FitCtrl *c = nd.ctrl;
     const bool go = c->serial == nd.cont_parent && c->done && c->d_fresh && c->l >= 0 && !c->cov_stall && !c->info;
     if (!go) return;  // uniform
-    for (int i = threadIdx.x; i < k; i += 1024) nd.cm_hist[i] = 0;
+    for (int i = threadIdx.x; i < k; i += NT) nd.cm_hist[i] = 0;
     __syncthreads();  // every thread has read the old block
     if (threadIdx.x == 0) {
       c->done = 0;
@@ -431,21 +430,21 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     return;
   }
   if (run_flag != nullptr && *run_flag == 0) return;
-  __shared__ int wcnt[2][16];
+  __shared__ int wcnt[2][NWV];
   if (nd.slot_of != nullptr && nd.inc1 && nd.ctrl->l == 0 && nd.ctrl->k_cur + 1 == k &&
       (gridDim.x == 1 || nd.pub.on)) {
     // First iteration of a fit chained behind a fit of size k-1 whose last iteration confirmed A_cur = max_k(bd, k-1)
     // on exactly these scores: max_k(bd, k) is A_cur plus the best score outside it (ties -> lower index, the same
     // total order).  An arg-max instead of a selection.
-    __shared__ unsigned long long bk[16];
-    __shared__ int bi[16];
+    __shared__ unsigned long long bk[NWV];
+    __shared__ int bi[NWV];
     PH_BEGIN();
     unsigned long long best = 0ull;
     int besti = 0x7fffffff;
     if (nd.bmm != nullptr && nd.bmm_fresh) {
       // the k_cov_d that produced these scores left, per block of 32 columns, the largest score outside the active
       // set and its column: the arg-max over p scores is the arg-max over p / 32 block maxima (same total order)
-      for (int b = threadIdx.x; b < nd.nbmm; b += 1024) {
+      for (int b = threadIdx.x; b < nd.nbmm; b += NT) {
         const double v = nd.bmm[2 * b + 1];
         if (v >= 0.0) {
           const unsigned long long key = score_key(v);
@@ -462,14 +461,14 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
       unsigned char ia[EB];
 #pragma unroll
       for (int e = 0; e < EB; e++) {
-        const int i = threadIdx.x + e * 1024;
+        const int i = threadIdx.x + e * NT;
         const bool in = i < len_total;
         sc[e] = in ? score[i] : 0.0;
         ia[e] = in ? nd.inA[i] : (unsigned char)1;
       }
 #pragma unroll
       for (int e = 0; e < EB; e++) {
-        const int i = threadIdx.x + e * 1024;
+        const int i = threadIdx.x + e * NT;
         const unsigned long long key = score_key(sc[e]);
         if (!ia[e] && (key > best || (key == best && i < besti))) {
           best = key;
@@ -495,7 +494,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     best = bk[0];
     besti = bi[0];
 #pragma unroll
-    for (int w = 1; w < 16; w++)
+    for (int w = 1; w < NWV; w++)
       if (bk[w] > best || (bk[w] == best && bi[w] < besti)) {
         best = bk[w];
         besti = bi[w];
@@ -505,7 +504,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     // block (a binary search by one thread is a chain of dependent global loads)
     const int *A_old = nd.A_cur;
     int lo = 0;
-    for (int base = 0; base < k - 1; base += 1024) {  // uniform trip count
+    for (int base = 0; base < k - 1; base += NT) {  // uniform trip count
       const int i = base + threadIdx.x;
       int smaller = 0;
       if (i < k - 1) {
@@ -521,7 +520,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     }
     __syncthreads();
     PH(2);
-    cov_need_body<1024>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
+    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
     PH(3);
     PH_COUNT();
     return;
@@ -531,9 +530,9 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     // outside it.  If every inside score beats every outside score (and the set has the wanted size, and this is
     // not the first iteration of the fit) the selection returns the same set, A == A_list.col(l-1): nothing to
     // search, nothing to look up.
-    __shared__ double rmn[16], rmx[16];
+    __shared__ double rmn[NWV], rmx[NWV];
     double mn = DBL_MAX, mx = -1.0;
-    for (int b = threadIdx.x; b < nd.nbmm; b += 1024) {
+    for (int b = threadIdx.x; b < nd.nbmm; b += NT) {
       mn = fmin(mn, nd.bmm[2 * b]);
       mx = fmax(mx, nd.bmm[2 * b + 1]);
     }
@@ -550,7 +549,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     mn = rmn[0];
     mx = rmx[0];
 #pragma unroll
-    for (int w = 1; w < 16; w++) {
+    for (int w = 1; w < NWV; w++) {
       mn = fmin(mn, rmn[w]);
       mx = fmax(mx, rmx[w]);
     }
@@ -577,13 +576,13 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
       return;
     }
   }
-  __shared__ int wsum[16];
-  __shared__ int wsum2[16];
+  __shared__ int wsum[NWV];
+  __shared__ int wsum2[NWV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int base = blockIdx.x * chunk;
   const int len = min(chunk, len_total - base);
   const int kk = min(k, len);
-  const int E = (len + 1023) / 1024;  // <= EB
+  const int E = (len + NT - 1) / NT;  // <= EB
   const int e0 = tid * E;
   unsigned long long key[EB];
 #pragma unroll
@@ -608,7 +607,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     __syncthreads();
     int tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) tot += wcnt[par][w];
+    for (int w = 0; w < NWV; w++) tot += wcnt[par][w];
     if (tot >= kk) T = cand;
     par ^= 1;
     if (tot == kk) break;  // uniform: every thread computed the same tot
@@ -633,7 +632,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
+    for (int w = 0; w < NWV; w++) {
       int sv = ws[w];
       off += (w < wave) ? sv : 0;
       tot += sv;
@@ -667,8 +666,21 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
   if (tid == 0 && out_count != nullptr) out_count[blockIdx.x] = kk;
   if (nd.slot_of != nullptr) {
     __syncthreads();  // the selected indices are visible to the whole block
-    cov_need_body<1024>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
+    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
   }
+}
+
+template <int EB>  // keys per thread this instance can hold (bucket of ceil(len / 1024))
+__global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score, const int *__restrict__ idx_in,
+                                               int len_total, int chunk, int k, int *__restrict__ out,
+                                               int *__restrict__ out_count, const FitCtrl *ctrl, int slot,
+                                               const int *__restrict__ run_flag, const TopkNeed nd) {
+  KT(1);
+  if (nd.pub.on && blockIdx.x == 1) {  // second workgroup: publishes the parent fit's snapshot, nothing else
+    publish_body(nd.pub);
+    return;
+  }
+  topk_body<EB, 1024>(score, idx_in, len_total, chunk, k, out, out_count, ctrl, slot, run_flag, nd);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2145,6 +2157,408 @@ __global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const 
     __syncthreads();
     if (fz.pub.on == 2) {
       if (fz.ctrl->snap_seq != fz.pub.seq) snapshot_body(fz.pub);  // (else the selection kernel has taken it already)
+    } else {
+      publish_body(fz.pub);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7 (d), the k x k solve of a covariance-form slot WITHOUT an iteration: the inverse H = (G_AA + ridge I)^{-1} of
+// the last solve on this row set is kept in memory (slot-indexed like GS, L2-resident) and carried from one active
+// set to the next by the bordering identities
+//   a column j enters:  u = H g,  s = G_jj + ridge - g.u,  H <- [[H + u u^T/s, -u/s], [-u^T/s, 1/s]]   (g = G_Aj)
+//   a column t leaves:  H <- H_{-t,-t} - h_t h_t^T / H_tt                                              (h_t = H_At)
+// -- one pass over k^2 numbers to read and one to update per change, no chain of dependent reductions (the
+// conjugate-gradient solve is ~10 products with 2 barriers each).  A warm-started path changes one column per
+// candidate.  The coefficients are then x = H q and are ACCEPTED ONLY on the recomputed residual
+// |q - (G + ridge I) x| <= tol |q| (one step of iterative refinement x += H r if needed), the same criterion the
+// conjugate-gradient kernel applies; anything else -- H not valid for this cache generation / ridge, more than
+// HV_LIM changes, a slot beyond the slot-indexed Gram, a non-positive Schur complement, the residual test -- returns
+// false and the caller runs cgr_body.  After such a conjugate-gradient solve H is rebuilt for the new set by
+// bordering it up column by column (hinv_rebuild), if the ridge is the one of the previous solve on this row set
+// (a lambda grid changes it at every fit: no point in rebuilding there).
+// Layout: H[a * CS + b], a, b = cache slots; hact[slot] = 1 for the slots H currently covers; hmeta[0] = valid,
+// hmeta[1] = cache generation (cmeta[3]) it belongs to; hinfo[0] = ridge of H, hinfo[1] = ridge of the last solve.
+// ------------------------------------------------------------------------------------------
+constexpr int HV_R = 256;   // most unknowns (cgr_body's limit is 208)
+constexpr int HV_CS = 512;  // slots the inverse can cover (= COV_CS of the host)
+constexpr int HV_LIM = 6;   // most single-column changes taken incrementally
+
+struct HvShared {
+  int sA[HV_R], sS[HV_R];     // columns and cache slots of the wanted set, in the order of A_new
+  int cur[HV_R];              // slots H covers right now
+  int ncur;
+  int lst[2][HV_R];           // leaving / entering slots (ascending)
+  int nl[2];
+  double g[HV_R], u[HV_R], x[HV_R], q[HV_R], r[HV_R];
+  double part[8][HV_R];       // partial sums of hv_matvec
+  double red[8][4];
+};
+
+__device__ __forceinline__ double hv_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// out[i] = sum_j M[idx[j] * CS + idx[i]] * v[j] for i < n (M symmetric: = sum_j M[idx[i]][idx[j]] v[j]).
+// Thread t owns output i = t % np and every `parts`-th term j (parts = 512 / np): for a fixed j neighbouring threads
+// read neighbouring slots of one row of M (coalesced), every thread's loads are independent of one another (many in
+// flight, no cross-lane reduction in the loop); the `parts` partial sums of an output meet in LDS in fixed order.
+// A wave-per-row form with a shuffle reduction per row was ~20 us per product at n = 100: one L2 round trip per row.
+__device__ __forceinline__ void hv_matvec(HvShared &sh, const double *M, int CS, const int *idx, int n,
+                                          const double *v, double *out) {
+  const int tid = threadIdx.x;
+  const int np = n <= 64 ? 64 : (n <= 128 ? 128 : 256), parts = 512 / np;
+  const int i = tid % np, part = tid / np;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (i < n) {
+    const double *col = M + idx[i];
+    // 8 independent loads in flight per thread and round (two accumulators keep the order of summation fixed)
+    int j = part;
+    for (; j + 7 * parts < n; j += 8 * parts) {
+      double mv[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) mv[q] = col[(size_t)idx[j + q * parts] * CS];
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        acc0 = fma(mv[q], v[j + q * parts], acc0);
+        acc1 = fma(mv[q + 1], v[j + (q + 1) * parts], acc1);
+      }
+    }
+    double mv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) mv[q] = j + q * parts < n ? col[(size_t)idx[j + q * parts] * CS] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      acc0 = fma(mv[q], j + q * parts < n ? v[j + q * parts] : 0.0, acc0);
+      acc1 = fma(mv[q + 1], j + (q + 1) * parts < n ? v[j + (q + 1) * parts] : 0.0, acc1);
+    }
+  }
+  sh.part[part][i] = acc0 + acc1;
+  __syncthreads();
+  if (tid < n) {
+    double t = sh.part[0][tid];
+    for (int q = 1; q < parts; q++) t += sh.part[q][tid];
+    out[tid] = t;
+  }
+  __syncthreads();
+}
+
+// block-wide sums of up to 4 values, fixed order; every thread gets the results
+__device__ __forceinline__ void hv_block_sum(HvShared &sh, double (&v)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const double t = hv_wave_sum(v[c]);
+    if (lane == 0) sh.red[wave][c] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    double t = sh.red[0][c];
+#pragma unroll
+    for (int w = 1; w < 8; w++) t += sh.red[w][c];
+    v[c] = t;
+  }
+  __syncthreads();
+}
+
+// H <- bordered by slot j (sh.cur / sh.ncur = the slots covered so far).  Returns false (uniformly) if the Schur
+// complement is not safely positive.
+__device__ __forceinline__ bool hv_add(HvShared &sh, double *H, const double *GS, int CS, int j, double ridge) {
+  const int tid = threadIdx.x, n = sh.ncur;
+  const double gam = GS[(size_t)j * CS + j] + ridge;
+  for (int a = tid; a < n; a += 512) sh.g[a] = GS[(size_t)j * CS + sh.cur[a]];
+  __syncthreads();
+  hv_matvec(sh, H, CS, sh.cur, n, sh.g, sh.u);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int a = tid; a < n; a += 512) acc[0] = fma(sh.g[a], sh.u[a], acc[0]);
+  hv_block_sum(sh, acc);
+  const double sc = gam - acc[0];
+  if (!(sc > 1e-10 * gam)) return false;
+  const double rs = 1.0 / sc;
+  // H += u u^T / s on the covered block: one element per thread and step, neighbouring threads along a row
+  for (int e0 = tid; e0 < n * n; e0 += 4 * 512) {
+    double *ptr[4];
+    double hv4[4], f[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // 4 independent read-modify-writes in flight
+      const int e = min(e0 + q * 512, n * n - 1), a = e / n, b = e - a * n;
+      ptr[q] = H + (size_t)sh.cur[a] * CS + sh.cur[b];
+      f[q] = sh.u[a] * rs * sh.u[b];
+      hv4[q] = *ptr[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (e0 + q * 512 < n * n) *ptr[q] = hv4[q] + f[q];
+  }
+  for (int a = tid; a < n; a += 512) {
+    const double ua = -sh.u[a] * rs;
+    H[(size_t)sh.cur[a] * CS + j] = ua;
+    H[(size_t)j * CS + sh.cur[a]] = ua;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    H[(size_t)j * CS + j] = rs;
+    sh.cur[n] = j;
+    sh.ncur = n + 1;
+  }
+  __syncthreads();
+  return true;
+}
+
+// H <- without slot t
+__device__ __forceinline__ bool hv_drop(HvShared &sh, double *H, int CS, int t) {
+  const int tid = threadIdx.x, n = sh.ncur;
+  const double piv = H[(size_t)t * CS + t];
+  if (!(piv > 0.0)) return false;
+  for (int a = tid; a < n; a += 512) sh.g[a] = H[(size_t)t * CS + sh.cur[a]];
+  __syncthreads();
+  const double rp = 1.0 / piv;
+  for (int e0 = tid; e0 < n * n; e0 += 4 * 512) {
+    double *ptr[4];
+    double hv4[4], f[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int e = min(e0 + q * 512, n * n - 1), a = e / n, b = e - a * n;
+      ptr[q] = H + (size_t)sh.cur[a] * CS + sh.cur[b];
+      f[q] = -sh.g[a] * rp * sh.g[b];
+      hv4[q] = *ptr[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (e0 + q * 512 < n * n) *ptr[q] = hv4[q] + f[q];  // (row / column t itself is dropped from the list below)
+  }
+  __syncthreads();
+  if (tid == 0) {  // remove t from the list (order of the others kept)
+    int w = 0;
+    for (int a = 0; a < n; a++)
+      if (sh.cur[a] != t) sh.cur[w++] = sh.cur[a];
+    sh.ncur = w;
+  }
+  __syncthreads();
+  return true;
+}
+
+struct HinvArgs {
+  double *H;
+  int *hact, *hmeta;
+  double *hinfo;
+  const int *cmeta;  // the column cache's meta block: [3] = generation (bumped when the cache starts over)
+};
+
+// sets sh.sA / sh.sS from A_new; false if a slot is outside the slot-indexed matrices
+__device__ __forceinline__ bool hv_load_set(HvShared &sh, const int *A_new, int m, const int *slot_of, int CS) {
+  int bad = 0;
+  for (int i = threadIdx.x; i < m; i += 512) {
+    const int a = A_new[i], sl = slot_of[a];
+    sh.sA[i] = a;
+    sh.sS[i] = sl;
+    bad |= (sl < 0 || sl >= CS) ? 1 : 0;
+  }
+  return !__syncthreads_or(bad);
+}
+
+// Rebuild H for the set in sh.sA / sh.sS (already loaded) by bordering it up one column at a time.
+__device__ __forceinline__ void hinv_rebuild(HvShared &sh, const HinvArgs &hv, const double *GS, int CS, int m,
+                                             double ridge) {
+  const int tid = threadIdx.x;
+  if (tid == 0) sh.ncur = 0;
+  __syncthreads();
+  bool ok = true;
+  for (int i = 0; i < m && ok; i++) ok = hv_add(sh, hv.H, GS, CS, sh.sS[i], ridge);
+  for (int t = tid; t < CS; t += 512) hv.hact[t] = 0;
+  __syncthreads();
+  if (ok)
+    for (int i = tid; i < m; i += 512) hv.hact[sh.sS[i]] = 1;
+  if (tid == 0) {
+    hv.hmeta[0] = ok ? 1 : 0;
+    hv.hmeta[1] = hv.cmeta[3];
+    hv.hmeta[3] += 1;  // statistics: rebuilds
+    hv.hinfo[0] = ridge;
+  }
+  __syncthreads();
+}
+
+// The solve of slot `slot` from the maintained inverse.  true: the slot has been dealt with (solved + committed, or
+// not this launch's business); false: the caller runs the conjugate-gradient body.
+__device__ __forceinline__ bool hinv_body(HvShared &sh, int m, double ridge, const double *rhs, const int *A_new,
+                                          double *sol, const FitCtrl *ctrl, int slot, const CholFuse &fz,
+                                          const HinvArgs &hv, const double tol, int *same_any_sh) {
+  if (ctrl->done || ctrl->l != slot - 1) return true;
+  if (ctrl->same_prev) return false;  // (cgr_body records the repeated set)
+  const int tid = threadIdx.x, CS = fz.CS;
+  if (fz.GS == nullptr || CS > HV_CS || m > HV_R - 1) return false;
+  const bool valid = hv.hmeta[0] == 1 && hv.hmeta[1] == hv.cmeta[3] && hv.hinfo[0] == ridge;  // uniform
+  if (!valid) return false;
+  PH_BEGIN();
+  if (!hv_load_set(sh, A_new, m, fz.slot_of, CS)) return false;
+  PH(8);
+  // what leaves and what enters, both in ascending slot order (thread t looks at slot t: CS <= 512 threads)
+  {
+    if (tid == 0) sh.nl[0] = sh.nl[1] = sh.ncur = 0;
+    __syncthreads();
+    const int old = tid < CS ? hv.hact[tid] : 0;  // (issued before the flags below are built)
+    sh.lst[0][tid & (HV_R - 1)] = 0;              // lst[0..1] double as the 512 "wanted" flags for a moment
+    sh.lst[1][tid & (HV_R - 1)] = 0;
+    __syncthreads();
+    for (int i = tid; i < m; i += 512) (&sh.lst[0][0])[sh.sS[i]] = 1;
+    __syncthreads();
+    const int nw = (&sh.lst[0][0])[tid];
+    __syncthreads();
+    const int kind = (old && !nw) ? 0 : ((nw && !old) ? 1 : -1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {  // c = 0 leaving, 1 entering, 2 covered now: ordered compaction by ballots
+      const bool f = c == 2 ? old != 0 : kind == c;
+      const unsigned long long bal = __ballot(f);
+      if ((tid & 63) == 0) sh.red[tid >> 6][0] = (double)__popcll(bal);
+      __syncthreads();
+      int off = 0, tot = 0;
+      for (int w = 0; w < 8; w++) {
+        const int cw = (int)sh.red[w][0];
+        off += w < (tid >> 6) ? cw : 0;
+        tot += cw;
+      }
+      const int pos = off + (int)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+      if (f && pos < HV_R) (c == 2 ? sh.cur : sh.lst[c])[pos] = tid;
+      if (tid == 0) (c == 2 ? sh.ncur : sh.nl[c]) = tot;
+      __syncthreads();
+    }
+  }
+  if (sh.nl[0] + sh.nl[1] > HV_LIM || sh.ncur > HV_R - 1) return false;
+  PH(9);
+  bool ok = true;
+  for (int c = 0; c < sh.nl[0] && ok; c++) ok = hv_drop(sh, hv.H, CS, sh.lst[0][c]);
+  for (int c = 0; c < sh.nl[1] && ok; c++) ok = hv_add(sh, hv.H, fz.GS, CS, sh.lst[1][c], ridge);
+  PH(10);
+  if (ok) {
+    // x = H q in the order of A_new, residual against the cached Gram entries, one refinement step if needed
+    for (int i = tid; i < m; i += 512) sh.q[i] = rhs[sh.sA[i]];
+    __syncthreads();
+    hv_matvec(sh, hv.H, CS, sh.sS, m, sh.q, sh.x);
+    double qq;
+    {
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int i = tid; i < m; i += 512) a[0] = fma(sh.q[i], sh.q[i], a[0]);
+      hv_block_sum(sh, a);
+      qq = a[0];
+    }
+    PH(11);
+    for (int round = 0; round < 2; round++) {
+      hv_matvec(sh, fz.GS, CS, sh.sS, m, sh.x, sh.g);  // g = G x
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int i = tid; i < m; i += 512) {
+        const double rv = sh.q[i] - (sh.g[i] + ridge * sh.x[i]);
+        sh.r[i] = rv;
+        a[0] = fma(rv, rv, a[0]);
+      }
+      hv_block_sum(sh, a);
+      ok = a[0] <= tol * tol * qq;  // (NaN fails)
+      if (ok || round == 1) break;
+#ifdef BESSX_KTRACE
+      if (tid == 0) atomicAdd(&g_phase[29], 1ull);  // refinement steps
+#endif
+      hv_matvec(sh, hv.H, CS, sh.sS, m, sh.r, sh.u);  // x += H r
+      for (int i = tid; i < m; i += 512) sh.x[i] += sh.u[i];
+      __syncthreads();
+    }
+  }
+  if (!ok) {  // H may be half-updated: drop it, the conjugate-gradient body takes over (and rebuilds it)
+    if (tid == 0) hv.hmeta[0] = 0;
+    __syncthreads();
+    return false;
+  }
+  PH(12);
+  // H now belongs to the new set
+  for (int t = tid; t < CS; t += 512) hv.hact[t] = 0;
+  __syncthreads();
+  for (int i = tid; i < m; i += 512) {
+    hv.hact[sh.sS[i]] = 1;
+    sol[i] = sh.x[i];
+  }
+  if (tid == 0) {
+    hv.hinfo[1] = ridge;
+    hv.hmeta[2] += 1;  // statistics: solves taken from the maintained inverse
+  }
+  {
+    // loss terms as in cgr_body: |y - X b|^2 = y.y - b.(q + rho) - ridge |b|^2, rho = the residual just recomputed
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    double gd = 0.0;
+    for (int i = tid; i < m; i += 512) {
+      const double x = sh.x[i], qr = sh.q[i] + sh.r[i];
+      a[0] = fma(x, qr, a[0]);
+      a[1] = fma(x, x, a[1]);
+      a[2] = fma(fabs(x), fabs(qr), a[2]);
+      gd = fmax(gd, fz.GS[(size_t)sh.sS[i] * CS + sh.sS[i]]);
+    }
+    hv_block_sum(sh, a);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) gd = fmax(gd, __shfl_xor(gd, o));
+    if ((tid & 63) == 0) sh.red[tid >> 6][0] = gd;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 8; w++) gd = fmax(gd, sh.red[w][0]);
+      const double tr = fz.yy - a[0] - ridge * a[1];
+      fz.ctrl->sse_dot = a[0];
+      fz.ctrl->sse_nrm = a[1];
+      fz.ctrl->sse_valid = (tr > 1e-6 * fz.yy && 4e-16 * (a[2] + (ridge + gd) * a[1] + fz.yy) <= 1e-10 * tr) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  PH(13);
+  commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+              fz.hist_coef0, fz.hist_stride, same_any_sh, fz.inA);
+  PH(14);
+#ifdef BESSX_KTRACE
+  if (tid == 0) atomicAdd(&g_phase[30], 1ull);
+#endif
+  return true;
+}
+
+// One PDAS iteration of the covariance form behind its GEMV in ONE launch: the selection (topk_body on 8 waves: the
+// chained-fit prologue, the arg-max / repeated-set shortcuts or the full search, the cache lookup) and then, in the
+// same workgroup, the gather + conjugate-gradient solve + commit of k_cgr.  The two phases talk through the control
+// block exactly as the two launches did (every gate is re-read from memory after the barrier), so the results are
+// those of k_topk followed by k_cgr -- without the second launch, its fall-through when the selection has already
+// settled the slot, and the boundary between them (tools/ktrace.py: 581 + 581 launches per 200-candidate path).
+// blockIdx.x == 1 (only when nd.pub.on): the deferred publication of the parent fit, as in k_topk.
+template <int EB, int RPT, int NCW>
+__global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ score, int len, int k, int *out,
+                                                 const FitCtrl *ctrl, int slot, const TopkNeed nd, int nc, double ridge,
+                                                 const double *__restrict__ rhs, double *sol, const CholFuse fz,
+                                                 int maxit, const double tol, const HinvArgs hv) {
+  KT(14);
+  if (nd.pub.on && blockIdx.x == 1) {
+    publish_body(nd.pub);
+    return;
+  }
+  topk_body<EB, 512>(score, nullptr, len, len, k, out, nullptr, ctrl, slot, nullptr, nd);
+  __syncthreads();  // the selection's writes (A_new, the control block, a commit) are visible to the whole block
+  __shared__ HvShared hsh;
+  __shared__ int hv_same_any;
+  bool handled = false;
+  if (hv.H != nullptr) handled = hinv_body(hsh, k, ridge, rhs, out, sol, ctrl, slot, fz, hv, tol, &hv_same_any);
+  if (!handled) {
+    const bool was_mine = hv.H != nullptr && !ctrl->done && ctrl->l == slot - 1 && !ctrl->same_prev;  // uniform
+    cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
+    __syncthreads();
+    if (was_mine && ctrl->l == slot) {
+      // the conjugate-gradient body solved and committed this slot: bring the inverse up to the new set if the ridge
+      // is the previous solve's (a path at fixed lambda: the next candidates then go through hinv_body)
+      const bool same_ridge = hv.hinfo[1] == ridge;
+      if (same_ridge && fz.GS != nullptr && fz.CS <= HV_CS && k <= HV_R - 1 &&
+          hv_load_set(hsh, out, k, fz.slot_of, fz.CS))
+        hinv_rebuild(hsh, hv, fz.GS, fz.CS, k, ridge);
+      __syncthreads();
+      if (threadIdx.x == 0) hv.hinfo[1] = ridge;
+    }
+  }
+  if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
+    __syncthreads();
+    if (fz.pub.on == 2) {
+      if (fz.ctrl->snap_seq != fz.pub.seq) snapshot_body(fz.pub);  // (else the selection phase has taken it already)
     } else {
       publish_body(fz.pub);
     }
@@ -4144,7 +4558,10 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
   }
   const bool spec = nm > 0 && bd != nullptr;
   if (tid == 0) {
-    if (restart) meta[0] = 0;  // (otherwise untouched: a background fill may be adding columns concurrently)
+    if (restart) {
+      meta[0] = 0;  // (otherwise untouched: a background fill may be adding columns concurrently)
+      meta[3] += 1;  // cache generation: slot numbers start over (the maintained inverse of hinv_body is void)
+    }
     meta[1] = nm;
     meta[2] = spec ? 1 : 0;
     ctrl->cov_nmiss = nm;
@@ -5131,6 +5548,43 @@ hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *
   else
     CG_GO(17, 8);
 #undef CG_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// selection + solve in one launch (k_sel_cgr): scores in one chunk of at most 32768, systems of at most 208 unknowns
+bool sel_cgr_applies(int len, int m) { return len <= 512 * 64 && m >= 1 && m <= 208; }
+hipError_t launch_sel_cgr(const double *score, int len, int k, int *A_new, const FitCtrl *ctrl, int slot,
+                          const TopkNeed *need, double ridge, const double *rhs, double *sol, const CholFuse *fuse,
+                          int maxit, hipStream_t st, double tol, double *H, int *hact, int *hmeta, double *hinfo,
+                          const int *cmeta) {
+  const HinvArgs hv = {H, hact, hmeta, hinfo, cmeta};
+  if (!sel_cgr_applies(len, k) || need == nullptr || fuse == nullptr) return hipErrorInvalidValue;
+  const TopkNeed nd = *need;
+  const CholFuse fz = *fuse;
+  const int nblk = nd.pub.on ? 2 : 1, nc = (k + 7) / 8, per = (len + 511) / 512;
+#define SC_GO(EB, RP, NW_)                                                                                          \
+  hipLaunchKernelGGL((k_sel_cgr<EB, RP, NW_>), dim3(nblk), dim3(512), 0, st, score, len, k, A_new, ctrl, slot, nd, nc, \
+                     ridge, rhs, sol, fz, maxit, tol, hv)
+#define SC_BY_M(EB)          \
+  do {                       \
+    if (k <= 64)             \
+      SC_GO(EB, 1, 8);       \
+    else if (k <= 128)       \
+      SC_GO(EB, 2, 16);      \
+    else if (k <= 192)       \
+      SC_GO(EB, 3, 24);      \
+    else                     \
+      SC_GO(EB, 4, 26);      \
+  } while (0)
+  if (per <= 8)
+    SC_BY_M(8);
+  else if (per <= 24)
+    SC_BY_M(24);
+  else
+    SC_BY_M(64);
+#undef SC_BY_M
+#undef SC_GO
   LAUNCH_CHECK();
   return hipSuccess;
 }

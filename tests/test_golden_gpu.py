@@ -130,12 +130,11 @@ def test_unsupported_and_invalid_requests_fail_loudly(gpu):
         gpu.pywrap_bess(*bad)
     assert e.value.code == 1
     Xw = np.random.default_rng(0).standard_normal((60, 40))
-    bad = list(_pywrap_args(Xw, Xw[:, 0]))
-    bad[14] = np.array([0, 20])  # a group of 20 columns: larger than the built maximum of 16
-    bad[16] = [1]
-    with pytest.raises(gpu.BessxError) as e:
-        gpu.pywrap_bess(*bad)
-    assert e.value.code == 3
+    wide = list(_pywrap_args(Xw, Xw[:, 0]))
+    wide[14] = np.array([0, 20])  # two groups of 20 columns: wider than the register-resident group path, accepted
+    wide[16] = [1]
+    r = gpu.pywrap_bess(*wide)
+    assert np.count_nonzero(r[0]) == 20 and np.all(r[0][:20] != 0)  # y = first column: the first group is chosen
     bad = list(a)
     bad[16] = [9]  # sparsity level > p
     with pytest.raises(gpu.BessxError) as e:

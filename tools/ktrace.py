@@ -10,7 +10,7 @@ X,y,_,_=synth.make_lm()
 L=capi.lib()
 cap=1<<16
 buf=(ctypes.c_ulonglong*cap)()
-names={1:'topk',2:'cgr',3:'cg',4:'cov_d',5:'panel',6:'reduce',7:'compact',8:'continue',9:'publish',10:'fill_list',11:'resume',12:'need',13:'begin'}
+names={1:'topk',2:'cgr',3:'cg',4:'cov_d',5:'panel',6:'reduce',7:'compact',8:'continue',9:'publish',10:'fill_list',11:'resume',12:'need',13:'begin',14:'sel_cgr'}
 import time
 with capi.Session(X,y) as s:
     s.sequential_path(np.arange(1,201), ic_type=3)
@@ -19,6 +19,8 @@ with capi.Session(X,y) as s:
     t0=time.time(); s.sequential_path(np.arange(1,201), ic_type=3); wall=time.time()-t0
     n=L.bessx_debug_ktrace(buf,cap,1)
     ph=(ctypes.c_ulonglong*32)(); L.bessx_debug_phase(ph,1)
+    print("counters", s.counters())
+    if ph[30]: print("hinv phases (us per solve, %d solves, %d refinements):"%(ph[30],ph[29]), {k:round(ph[i]*0.01/ph[30],2) for i,k in zip(range(8,15),("load","diff","update","x=Hq","resid","finish","commit"))})
     print("phases (us per call, %d calls):"%ph[31], [round(ph[i]*0.01/max(ph[31],1),2) for i in range(8)])
 ev=[(buf[i]&255, (buf[i]>>8)*0.01) for i in range(n)]  # us
 ev.sort(key=lambda e:e[1])
@@ -27,6 +29,13 @@ tot=collections.defaultdict(float); cnt=collections.Counter()
 for (k,t),(k2,t2) in zip(ev,ev[1:]):
     tot[k]+=t2-t; cnt[k]+=1
 for k,v in sorted(tot.items(),key=lambda x:-x[1]): print("%-10s %5d launches  %8.3f ms  avg %6.2f us"%(names.get(k,k),cnt[k],v/1e3,v/cnt[k]))
+# the selection(+solve) launches by what they turned out to do, told by their duration
+for kid in (14, 1, 2):
+    d=np.array([t2-t for (k,t),(k2,t2) in zip(ev,ev[1:]) if k==kid])
+    if d.size:
+        for lo,hi,what in ((0,3,"fell through"),(3,12,"shortcut / commit / snapshot"),(12,1e9,"solve")):
+            m=(d>=lo)&(d<hi)
+            print("%-8s %-30s %4d launches %7.3f ms  median %6.2f us"%(names.get(kid,kid),what,int(m.sum()),d[m].sum()/1e3,np.median(d[m]) if m.any() else 0))
 mid=n//2
 for (k,t),(k2,t2) in list(zip(ev,ev[1:]))[mid:mid+24]: print("%-10s %7.2f us"%(names.get(k,k),t2-t))
 # durations of the launch that follows a repeated-set selection (the publishing solve kernel): 8-9 us = publish only,
