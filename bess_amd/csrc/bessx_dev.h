@@ -245,7 +245,7 @@ hipError_t launch_gather_cols(const double *X, long ld, const int *A, int pnew, 
 hipError_t launch_cov_need(const int *list, int len, const double *bd, double *bd2, int p, int *slot_of, int *meta,
                            int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st);
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                FitCtrl *ctrl, int parked, hipStream_t st);
+                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max = 32);
 hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
 int cov_streamed_tiles_per_wave();
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,

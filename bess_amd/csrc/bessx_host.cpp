@@ -157,6 +157,7 @@ struct bessx_session {
   bool cov_mode = false;
   int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
+  int cov_spec = 32;       // most speculative columns per fill: 64 with the pair panel kernel (variant 4), else 32
   bool fuse_sel = true;    // selection + solve of a slot in one launch, k_sel_cgr (BESSX_FUSE_SEL=0: two launches)
   bool hinv = false;       // ... with the solve taken from a maintained inverse (bordering updates, hinv_body) where
                            // possible: BESSX_HINV=1.  Off by default: measured at parity with the conjugate-gradient solve
@@ -740,6 +741,9 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
 }
 
 static bool cov_speculates(const bessx_session *s);
+// the capacity the device-side lookup (cov_need_body: "count + len + 32 > C -> start the cache over") is told: a fill
+// can add up to cov_spec speculative columns beyond the requested ones
+static int cov_C_dev(const bessx_session *s) { return s->cov_C - (s->cov_spec - COV_R); }
 
 // Background fill for row set 0: the 32 best-scoring uncached columns (scores as they are when the kernels run),
 // their Gram columns, and only then their publication in slot_of.  after_main: wait for everything queued on the
@@ -848,7 +852,7 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
   return 0;
 }
 
-static bool cov_speculates(const bessx_session *s) { return topk_supported(s->p, COV_R) && s->p >= 2 * COV_R; }
+static bool cov_speculates(const bessx_session *s) { return topk_supported(s->p, s->cov_spec) && s->p >= 2 * s->cov_spec; }
 
 // skip_d: d of exactly the starting coefficients is in memory (previous fit of the chain); scores_ok: so are the
 // sacrifice scores (same lambda), nothing to recompute before the selection.
@@ -874,7 +878,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   // top-k, then the repeated-set test + cache lookup (parks the fit when a column of A_new is not cached) -- in the
   // same launch when the scores fit one chunk of the selection kernel
   if (e == hipSuccess && topk_can_fuse_need(s->p)) {
-    TopkNeed nd = {cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, s->cov_C, cv.slot_of, cv.meta, s->cov_fcols,
+    TopkNeed nd = {cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cov_C_dev(s), cv.slot_of, cv.meta, s->cov_fcols,
                    s->ctrl, s->A_cur, s->cov_bmm, (s->p + 31) / 32, s->inA, (slot == 1 && grow1) ? 1 : 0,
                    (slot == 1 && grow1 && s->bmm_owner == rs) ? 1 : 0};
     nd.cm_A_cur = s->A_cur;
@@ -917,7 +921,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
   } else if (e == hipSuccess) {
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
     if (e == hipSuccess)
-      e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C,
+      e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s),
                           s->cov_fcols, s->ctrl, slot, s->A_cur, s->st);
   }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot_cov: ") + hipGetErrorString(e));
@@ -939,16 +943,18 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
   const bool spec = cov_speculates(s);
   if (rs == 0) {
     if (int rc = cov_bg_fence_main(s)) return rc;
-    const int add = spec ? ((nm + 16 + COV_R - 1) / COV_R) * COV_R : (nm + COV_R - 1) / COV_R * COV_R;
+    const int sm = s->cov_spec;  // most speculative columns per fill (k_cov_fill_list: same rounding)
+    const int add = spec ? std::min(((nm + sm / 2 + sm - 1) / sm) * sm, nm + sm) : (nm + COV_R - 1) / COV_R * COV_R;
     s->cov_fg_pending += add;
     s->cov_count_ub += add;
   }
   hipError_t e = hipSuccess;
-  if (spec) e = launch_topk(s->bd2, s->p, COV_R, s->cov_extras, s->cand, nullptr, 0, s->st);
-  if (e == hipSuccess) e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st);
+  if (spec) e = launch_topk(s->bd2, s->p, s->cov_spec, s->cov_extras, s->cand, nullptr, 0, s->st);
+  if (e == hipSuccess)
+    e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st, s->cov_spec);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark: ") + hipGetErrorString(e));
   // upper bound of the list length (the device drops speculative columns that turn out to be cached already)
-  const int room = spec ? std::min(((nm + 16 + COV_R - 1) / COV_R) * COV_R - nm, COV_R) : 0;
+  const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, s->cov_spec) : 0;
   const int ngroups = (nm + room + COV_R - 1) / COV_R;
   if (int rc = enqueue_cov_fill(s, rs, ngroups, 1)) return rc;
   HIPX(launch_cov_resume(s->ctrl, s->st));
@@ -1452,7 +1458,7 @@ static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, in
                            double parent_lambda, int parent_T0) {
   const int Tn = hint.T0;
   if (!(hint.on && s->chain && s->publish && s->warm_start && !s->trace.on && rs == 0 && s->cov_mode && Tn >= 1 &&
-        Tn <= s->cap && Tn + 2 * COV_R <= s->cov_C && topk_supported(s->p, Tn)))
+        Tn <= s->cap && Tn + COV_R + s->cov_spec <= s->cov_C && topk_supported(s->p, Tn)))
     return 0;
   bessx_session::Ahead &ah = s->ahead;
   s->chain_queued++;
@@ -1529,7 +1535,7 @@ static int algorithm_fit(bessx_session *s) {
   bessx_session::RsCache &cc = s->cache[rs];
   // (Cox keeps its state vectors once per session, not per row set, so it only reuses within one row set.)
   // covariance-update form of the score pass for this fit (LM; the cache must be able to hold the active set)
-  const bool cov = s->cov_mode && !glm && T0 + 2 * COV_R <= s->cov_C && k_init + 2 * COV_R <= s->cov_C;
+  const bool cov = s->cov_mode && !glm && T0 + COV_R + s->cov_spec <= s->cov_C && k_init + COV_R + s->cov_spec <= s->cov_C;
   bool use_cache = cc.valid && cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx &&
                    cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs) && (glm || cc.cov_layout == cov);
   if (cox) s->cox_state_rs = rs;
@@ -1615,10 +1621,10 @@ static int algorithm_fit(bessx_session *s) {
       s->cov_fg_pending += k_init;
       s->cov_count_ub += k_init;
     }
-    e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, s->cov_C, s->cov_fcols, s->ctrl, 0,
+    e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s), s->cov_fcols, s->ctrl, 0,
                         s->A_cur, s->st);
     if (e == hipSuccess)
-      e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 0, s->st);
+      e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 0, s->st, s->cov_spec);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov begin: ") + hipGetErrorString(e));
     if (int rc = enqueue_cov_fill(s, rs, (k_init + COV_R - 1) / COV_R, 0)) return rc;
   }
@@ -2912,22 +2918,24 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       return bail(fail(BESSX_ERR_ARG, "covariance score mode exists for LM with singleton groups only"));
     if (eligible && mode != 1) {
       // capacity: every column if p is small, else a few active sets' worth, within 1 GiB per row set
-      long C = std::min<long>(((long)p + 31) / 32 * 32 + 2 * COV_R, 2560);
+      if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(4, std::atoi(ev)));
+      // the pair kernel (variant 4) forms two 32-column groups per pass over X: fills then speculate up to 64 columns
+      s->cov_spec = (s->cov_variant == 4 && p >= 4 * COV_R && topk_supported(p, 2 * COV_R)) ? 2 * COV_R : COV_R;
+      long C = std::min<long>(((long)p + 31) / 32 * 32 + COV_R + s->cov_spec, 2560);
       const long budget = ((long)1 << 30) / ((long)p * 8);
       C = std::min(C, budget / 32 * 32);
       if (const char *ev = std::getenv("BESSX_COV_CAP"))  // test hook: a small cache exercises the restart path
         C = std::min<long>(C, std::max(0, std::atoi(ev)) / 32 * 32);
-      if (C >= 3 * COV_R) {
+      if (C >= 2 * COV_R + s->cov_spec) {
         s->cov_mode = true;
         s->cov_C = (int)C;
         const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
         // row slabs: the staged panel kernel runs one 256-thread block per CU at a time (100 KB of LDS), so pick
         // the slab count whose block count wastes the least of the last round of 256 blocks
         long ns = 1, rps = ld;
-        if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(3, std::atoi(ev)));
         {
           // blocks resident at a time: 256 CUs x (1 for the double-buffered tile, 3 for the single one)
-          const long conc = s->cov_variant == 1 ? 256 : (s->cov_variant == 3 ? 512 : 768);
+          const long conc = s->cov_variant == 1 ? 256 : (s->cov_variant >= 3 ? 512 : 768);
           double best = 1e300;
           const long ns_max = std::max<long>(1, std::min<long>(64, ld / 256));
           for (long t = 1; t <= ns_max; t++) {
@@ -2949,7 +2957,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         HIPT(hipMemset(s->inA, 0, (size_t)p));
         HIPT(dmalloc(&s->cov_bmm, (size_t)3 * ((p + 31) / 32)));
         HIPT(dmalloc(&s->cov_fcols, (size_t)s->capA + 4 * COV_R));
-        HIPT(dmalloc(&s->cov_extras, (size_t)COV_R));
+        HIPT(dmalloc(&s->cov_extras, (size_t)2 * COV_R));
         TRY(alloc_cov_cache(s));
         HIPT(cov_panel_prepare());
         if (const char *ev = std::getenv("BESSX_COV_BG")) s->cov_bg = std::atoi(ev) != 0;

@@ -4593,7 +4593,7 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
 __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, const int *__restrict__ extras,
                                                        const double *__restrict__ bd2, int *__restrict__ slot_of,
                                                        int *__restrict__ meta, FitCtrl *__restrict__ ctrl,
-                                                       int parked) {
+                                                       int parked, int spec_max) {
   KT(10);
   if (parked ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int nm = meta[1];
@@ -4603,10 +4603,12 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
     return;
   }
   const int count = meta[0], spec = meta[2];
-  const int room = spec ? min(((nm + 16 + COV_R - 1) / COV_R) * COV_R - nm, COV_R) : 0;
+  // spec_max = 32: the list is rounded up to the next multiple of 32 that leaves room for >= 16 speculative columns;
+  // spec_max = 64 (pair panel kernel: two groups per pass over X): to the next multiple of 64 with room for >= 32
+  const int room = spec ? min(((nm + spec_max / 2 + spec_max - 1) / spec_max) * spec_max - nm, spec_max) : 0;
   __shared__ int s_ne;
   if (tid < 64) {
-    const bool valid = spec && tid < COV_R && bd2[extras[tid]] >= 0.0;  // a genuine uncached column
+    const bool valid = spec && tid < spec_max && bd2[extras[tid]] >= 0.0;  // a genuine uncached column
     const unsigned long long bal = __ballot(valid);
     const int rank = __popcll(bal & ((1ull << tid) - 1ull));
     if (valid && rank < room) fcols[nm + rank] = extras[tid];
@@ -4906,6 +4908,144 @@ __global__ void __launch_bounds__(256) k_cov_panel_lds2(const double *__restrict
   double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
   *reinterpret_cast<d4 *>(out + lane * 4) = acc0;
   *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
+}
+
+// The panel kernel for a PAIR of 32-column groups: 64 right-hand-side columns against the same 64 streamed columns,
+// X read ONCE for both groups.  At 32 right-hand-side columns the kernel sits between its two roofs (8 flop per
+// streamed byte: 0.65 of HBM, 0.54 of the fp64 matrix cores, neither saturated because the per-chunk overheads --
+// barriers, staging stores, operand reads -- are paid per 32 KB of X); at 64 the same overheads buy twice the matrix
+// work, the kernel is bound by the fp64 MFMA rate (16 flop per streamed byte) and a path needs about half the passes
+// over X.  Same staging scheme as k_cov_panel_lds2 (coalesced 16-byte loads two chunks ahead, one LDS tile
+// [column][row + pad]); wave w multiplies streamed tile w with the four right-hand-side tiles.  If the second group
+// is beyond the fill list (decided on the device) the block does the work of the 32-column kernel.
+constexpr int CP2_COLS = 64 + 2 * COV_R;  // columns staged per chunk
+// TWO: both groups of the pair are in the fill list (decided on the device, one branch at kernel entry -- inside the
+// loop it would split the matrix-core instruction stream).  The operand reads of row step s + 1 are issued before the
+// MFMAs of step s (two operand register sets): left to the compiler, every step started with its LDS reads and a
+// full wait, exposing the LDS latency eight times per chunk.
+template <bool MASKED, bool TWO>
+__device__ __forceinline__ void cov_pair_body(const double *__restrict__ X, const double *__restrict__ aux, long ld,
+                                              int p, const double *__restrict__ mask, const int *__restrict__ fcols,
+                                              int g0, int rows_per_slab, int nslab, int njg,
+                                              double *__restrict__ part, double *smem) {
+  constexpr int NT = TWO ? 4 : 2;   // right-hand-side tiles
+  constexpr int NL = TWO ? 16 : 12;  // staged columns / 8 = loads per thread and chunk
+  const int slab = blockIdx.x / njg, jg = blockIdx.x - slab * njg;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
+  const int ru = tid & 31, cbase = tid >> 5;
+  // streamed columns jg * 64 + cbase + 8 i: one pointer and a uniform stride (a column beyond p re-reads the last
+  // existing one of its thread: its products land in rows >= p, which the reduce kernel never stores); right-hand-side
+  // columns: one pointer each
+  const int jc = min(jg * 64 + cbase, p - 1);
+  const double *sx = X + (size_t)jc * ld + 2 * ru;
+  const long sstride = 8 * ld;
+  const int ilim = jg * 64 + cbase < p ? (p - 1 - (jg * 64 + cbase)) / 8 : 0;  // last i whose column exists
+  const double *src[NL - 8];
+#pragma unroll
+  for (int i = 0; i < NL - 8; i++) src[i] = gram_col(X, aux, ld, fcols[g0 * COV_R + i * 8 + cbase]) + 2 * ru;
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + CP_RB - 1) / CP_RB);
+  d2 st[NL], ms;
+  auto load_chunk = [&](long r) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      st[i] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(sx + min(i, ilim) * sstride + r));
+#pragma unroll
+    for (int i = 8; i < NL; i++) st[i] = *reinterpret_cast<const d2 *>(src[i - 8] + r);
+    if (MASKED) ms = *reinterpret_cast<const d2 *>(mask + r + 2 * ru);
+  };
+  auto store_chunk = [&]() {
+    double *dst = smem + 2 * ru;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      d2 v = st[i];
+      if (MASKED && i >= 8) v = v * ms;
+      *reinterpret_cast<d2 *>(dst + (size_t)(i * 8 + cbase) * CP_LD) = v;
+    }
+  };
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+  const double *pa = smem + (size_t)(wv * 16 + c) * CP_LD + 4 * q;
+  const double *pb = smem + (size_t)(64 + c) * CP_LD + 4 * q;  // right-hand-side tile t at pb + t * 16 * CP_LD
+  struct Ops {
+    d2 a0, a1, b0[NT], b1[NT];
+  };
+  auto read_ops = [&](int s, Ops &o) {
+    o.a0 = *reinterpret_cast<const d2 *>(pa + 16 * s);
+    o.a1 = *reinterpret_cast<const d2 *>(pa + 16 * s + 2);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      o.b0[t] = *reinterpret_cast<const d2 *>(pb + (size_t)t * 16 * CP_LD + 16 * s);
+      o.b1[t] = *reinterpret_cast<const d2 *>(pb + (size_t)t * 16 * CP_LD + 16 * s + 2);
+    }
+  };
+  auto mfma_ops = [&](const Ops &o) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.x, o.b0[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.y, o.b0[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.x, o.b1[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.y, o.b1[t].y, acc[t], 0, 0, 0);
+  };
+  auto compute = [&]() {
+    Ops oa, ob;
+    read_ops(0, oa);
+#pragma unroll
+    for (int s = 0; s < CP_RB / 16; s += 2) {
+      read_ops(s + 1, ob);
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads back in front of their use)
+      mfma_ops(oa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < CP_RB / 16) read_ops(s + 2, oa);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ops(ob);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // LDS = chunk k; the registers hold chunk k + 1, loaded while chunk k is multiplied (one stage: the matrix work of
+  // a chunk is twice that of the 32-column kernel, and two 240-register waves per SIMD would not fit)
+  load_chunk(r_begin);
+  store_chunk();
+  if (nchunk > 1) load_chunk(r_begin + CP_RB);
+  __syncthreads();
+  for (int k = 0; k < nchunk; k++) {
+    compute();
+    __syncthreads();
+    if (k + 1 < nchunk) store_chunk();
+    __syncthreads();
+    if (k + 2 < nchunk) load_chunk(r_begin + (long)(k + 2) * CP_RB);
+  }
+  // the partial-sum layout of the 32-column kernels: [group][slab][tile pair] -- the reduce kernel is unchanged
+  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
+  double *out = part + ((size_t)slab * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
+  *reinterpret_cast<d4 *>(out + lane * 4) = acc[0];
+  *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc[1];
+  if (TWO) {
+    double *out2 = out + (size_t)nslab * tiles_per_slab * 256;
+    *reinterpret_cast<d4 *>(out2 + lane * 4) = acc[NT - 2];
+    *reinterpret_cast<d4 *>(out2 + 256 + lane * 4) = acc[NT - 1];
+  }
+}
+
+template <bool MASKED>
+__global__ void __launch_bounds__(256) k_cov_panel_pair(const double *__restrict__ X, const double *__restrict__ aux,
+                                                        long ld, int p, const double *__restrict__ mask,
+                                                        const int *__restrict__ fcols, int g0, int rows_per_slab,
+                                                        int nslab, int njg, double *__restrict__ part,
+                                                        const FitCtrl *__restrict__ ctrl, int big,
+                                                        const int *__restrict__ bgm) {
+  KT(5);
+  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
+  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
+  if (g0 * COV_R >= nfill) return;
+  extern __shared__ double smem[];  // [CP2_COLS][CP_LD]
+  if ((g0 + 1) * COV_R < nfill)     // uniform
+    cov_pair_body<MASKED, true>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
+  else
+    cov_pair_body<MASKED, false>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
 }
 
 // G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
@@ -6046,8 +6186,9 @@ hipError_t launch_cov_need(const int *list, int len, const double *bd, double *b
 }
 
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                FitCtrl *ctrl, int parked, hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_fill_list, dim3(1), dim3(256), 0, st, fcols, extras, bd2, slot_of, meta, ctrl, parked);
+                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max) {
+  hipLaunchKernelGGL(k_cov_fill_list, dim3(1), dim3(256), 0, st, fcols, extras, bd2, slot_of, meta, ctrl, parked,
+                     spec_max);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -6072,7 +6213,20 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
 #define PANEL_GO(M, D)                                                                                              \
   hipLaunchKernelGGL((k_cov_panel_lds<M, D>), dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0, \
                      ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm)
-    if (variant == 3) {
+    if (variant == 4 && ngroups <= 2) {
+      // one block per (slab, 64-column group) for BOTH groups of the launch: X streamed once
+      const size_t lds2 = (size_t)CP2_COLS * CP_LD * sizeof(double);
+      const long nb2 = (long)nslab * njg;
+      if (mask)
+        hipLaunchKernelGGL(k_cov_panel_pair<true>, dim3((unsigned)nb2), dim3(256), lds2, st, X, aux, ld, p, mask, fcols,
+                           g0, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
+      else
+        hipLaunchKernelGGL(k_cov_panel_pair<false>, dim3((unsigned)nb2), dim3(256), lds2, st, X, aux, ld, p, mask, fcols,
+                           g0, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
+      LAUNCH_CHECK();
+      return hipSuccess;
+    }
+    if (variant >= 3) {
       if (mask)
         hipLaunchKernelGGL(k_cov_panel_lds2<true>, dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0,
                            ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
@@ -6112,8 +6266,15 @@ hipError_t cov_panel_prepare() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<true, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<false, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<false, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  const int lds2 = (int)((size_t)CP2_COLS * CP_LD * sizeof(double));
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_pair<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_pair<false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
 }
 
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
