@@ -7,12 +7,13 @@
       BESSX_BENCH_BACKEND=gloo BESSX_BENCH_ONE_DEVICE=1 rehearses the N-rank path on ONE GPU (<= 6 ranks).
 Prints one JSON line: candidates/s, PDAS iterations, score-pass timing (HIP events inside the library)."""
 import json
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bess_amd import capi, synth  # noqa: E402
 
 
