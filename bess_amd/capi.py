@@ -22,7 +22,7 @@ _vp = ctypes.c_void_p
 # names every build of libbessx.so must export (checked by tests/test_abi.py against include/bessx.h)
 SYMBOLS = [
     "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_bessCpp", "bessx_session_create",
-    "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_sequential_path", "bessx_session_gs_path",
+    "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_get_cv_folds", "bessx_session_sequential_path", "bessx_session_gs_path",
     "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
@@ -93,6 +93,7 @@ def lib():
         L.bessx_session_get_screening.argtypes = [_vp, _I, _i]
         L.bessx_session_get_screening.restype = _i
         L.bessx_session_set_cv.argtypes = [_vp, _i, _I, ctypes.c_uint]
+        L.bessx_session_get_cv_folds.argtypes = [_vp, _I]
         L.bessx_session_sequential_path.argtypes = [_vp, _I, _i, _D, _i, _i, _i, ctypes.POINTER(PathResult)]
         L.bessx_session_gs_path.argtypes = [_vp, _i, _i, _i, _i, ctypes.POINTER(PathResult)]
         L.bessx_session_pgs_path.argtypes = [_vp, _i, _i, _d, _d, _i, _i, _i, _i, ctypes.POINTER(PathResult)]
@@ -283,6 +284,12 @@ class Session:
         f = None if fold_id is None else _i32(fold_id)
         _check(lib().bessx_session_set_cv(self._h, K, _ip(f), seed))
         self.K = K
+
+    def cv_folds(self):
+        """Test fold of every row as set_cv fixed it (given, or drawn from the seed)."""
+        f = np.zeros(self.n, dtype=np.int32)
+        _check(lib().bessx_session_get_cv_folds(self._h, _ip(f)))
+        return f
 
     def trace_enable(self, on=True):
         _check(lib().bessx_session_trace_enable(self._h, int(on)))

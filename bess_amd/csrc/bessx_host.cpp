@@ -243,6 +243,7 @@ struct bessx_session {
   unsigned char *stage_h = nullptr;  // pinned staging for init vectors
   // host statistics
   std::vector<double> x_mean_h, x_norm_h;
+  std::vector<int> cv_fold;  // test fold of every row (bessx_session_get_cv_folds)
   double y_mean_h = 0.0;
   double nullloss = 0.0;  // Data::get_nullloss (src/Data.h:120-130)
   // Algorithm state (reference member names in comments)
@@ -3082,6 +3083,7 @@ static void drop_folds(bessx_session *s) {
   if (!s->n_train.empty()) s->n_train.resize(1);
   s->n_test.clear();
   s->cv_init.clear();
+  s->cv_fold.clear();
   s->K = 0;
 }
 
@@ -3113,6 +3115,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
   s->n_test.assign(K, 0);
   s->K = K;
   s->cv_init.assign(K, SparseVec());
+  s->cv_fold = fold;
   std::vector<double> m((size_t)s->ld);
   for (int k = 0; k < K; k++) {
     std::fill(m.begin(), m.end(), 0.0);
@@ -3169,6 +3172,13 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
 #undef CVX
   }
   HIPX(hipStreamSynchronize(s->st));
+  return BESSX_OK;
+}
+
+int bessx_session_get_cv_folds(const bessx_session *s, int *fold_id) {
+  if (!s || !fold_id) return fail(BESSX_ERR_ARG, "null argument");
+  if (s->K < 2 || (int)s->cv_fold.size() != s->n) return fail(BESSX_ERR_ARG, "no cross-validation folds set");
+  std::copy(s->cv_fold.begin(), s->cv_fold.end(), fold_id);
   return BESSX_OK;
 }
 

@@ -157,6 +157,9 @@ long long bessx_session_counter(const bessx_session *s, int which);
  * gives the test fold of row i; fold_id == NULL draws a permutation from mt19937(seed) and cuts
  * it into K contiguous chunks exactly as src/Metric.h:66-78 does. */
 int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned seed);
+/* The test fold of every row as bessx_session_set_cv fixed it (given or drawn): fold_id[0..n).  Lets a caller hand
+ * the very same folds to another implementation (the tests feed them to the oracle). */
+int bessx_session_get_cv_folds(const bessx_session *s, int *fold_id);
 
 /* Results of a path run.  All pointers are caller-allocated; any of the *_all pointers may be
  * NULL to skip that output.  Candidates are stored in evaluation order. */

@@ -135,6 +135,33 @@ static void data_add_weight(odata *d) {
   }
 }
 
+/* Data::normalize + add_weight on a column-major copy, exported so that the device's normalisation kernels can be
+ * checked against the same restatement the paths use (tests/test_ops_gpu.py).  x: n x p column-major, in place. */
+int bess_oracle_normalize(double *x, int n, int p, double *y, const double *weight, int data_type, int is_normal,
+                          int add_weight, double *x_mean, double *x_norm, double *y_mean) {
+  odata d;
+  int j;
+  if (!x || !y || !weight || n < 1 || p < 1) return 1;
+  memset(&d, 0, sizeof(d));
+  d.n = n;
+  d.p = p;
+  d.x = x;
+  d.y = y;
+  d.w = (double *)weight;
+  d.x_mean = x_mean;
+  d.x_norm = x_norm;
+  d.data_type = data_type;
+  d.is_normal = is_normal;
+  for (j = 0; j < p; j++) {
+    x_mean[j] = 0.0;
+    x_norm[j] = 0.0;
+  }
+  if (is_normal) data_normalize(&d);
+  if (add_weight) data_add_weight(&d);
+  *y_mean = d.y_mean;
+  return 0;
+}
+
 /* ------------------------------------------------------------------ small linear algebra */
 
 int bess_oracle_sym_solve(const double *a, int k, const double *b, double *x) {

@@ -67,6 +67,11 @@ int bess_oracle_screening(const double *x, int n, int p, const double *y, const 
 
 /* Small building blocks exposed so that single HIP kernels can be checked in isolation. */
 
+/* Data::normalize (src/Data.h:79-93, src/normalize.cpp:20-85) and, if add_weight, Data::add_weight (src/Data.h:70-77)
+ * on a column-major n x p copy, in place; statistics as Data keeps them. */
+int bess_oracle_normalize(double *x, int n, int p, double *y, const double *weight, int data_type, int is_normal,
+                          int add_weight, double *x_mean, double *x_norm, double *y_mean);
+
 /* max_k (src/utilities.cpp:179-188): indices of the k largest scores, ascending.
  * Ties are broken towards the lower index (the reference's nth_element leaves ties
  * implementation-defined). */

@@ -179,3 +179,20 @@ def sym_solve(a, b):
     x = np.zeros(max(k, 1))
     lib().bess_oracle_sym_solve(a.ctypes.data_as(_D), k, _dp(b), _dp(x))
     return x[:k]
+
+
+def normalize(x, y, weight, data_type, is_normal=True, add_weight=False):
+    """Data::normalize (+ add_weight) of the oracle on a copy: returns (x, y, x_mean, x_norm, y_mean)."""
+    x = np.array(x, dtype=np.float64, order="F")
+    n, p = x.shape
+    y = np.array(y, dtype=np.float64)
+    w = np.ascontiguousarray(weight, dtype=np.float64)
+    xm, xn, ym = np.zeros(p), np.zeros(p), ctypes.c_double(0.0)
+    L = lib()
+    L.bess_oracle_normalize.argtypes = [_D, ctypes.c_int, ctypes.c_int, _D, _D, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        _D, _D, ctypes.POINTER(ctypes.c_double)]
+    rc = L.bess_oracle_normalize(_dp(x), n, p, _dp(y), _dp(w), data_type, int(is_normal), int(add_weight), _dp(xm),
+                                 _dp(xn), ctypes.byref(ym))
+    if rc:
+        raise RuntimeError("bess_oracle_normalize failed")
+    return x, y, xm, xn, ym.value

@@ -95,3 +95,47 @@ def test_normalize_matches_reference_formulas(gpu, data_type):
         np.testing.assert_allclose(xm, mean, rtol=1e-12, atol=1e-14)
     if data_type == 1:
         assert abs(ym - (y @ w) / n) < 1e-13
+
+
+@pytest.mark.parametrize("data_type,is_normal,add_weight", [(1, True, True), (2, True, False), (3, True, False),
+                                                              (1, False, True), (2, False, False)])
+def test_normalize_matches_the_oracle(gpu, data_type, is_normal, add_weight):
+    """Row a16 against the pinned oracle's own Data::normalize / add_weight (the NumPy restatement above is the
+    builder's; this is the one the paths are checked with)."""
+    rng = np.random.default_rng(10 * data_type + is_normal)
+    n, p = 517, 33
+    x = rng.standard_normal((n, p)) * rng.uniform(0.5, 3, p) + rng.uniform(-2, 2, p)
+    y = rng.standard_normal(n) + 3
+    w = rng.uniform(0.5, 2.0, n)
+    got = gpu.op_normalize(x, y, w, data_type, is_normal, add_weight)
+    want = P.normalize(x, y, w, data_type, is_normal, add_weight)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12, atol=1e-13)
+    if is_normal:
+        np.testing.assert_allclose(got[3], want[3], rtol=1e-13)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-12, atol=1e-14)
+        assert abs(got[4] - want[4]) < 1e-13
+
+
+def test_seed_drawn_cv_partition_has_the_reference_shape_and_drives_the_same_path(gpu):
+    """Row a17: bessx_session_set_cv(fold_id = NULL) draws a permutation and cuts it like Metric::set_cv_train_test_mask
+    (src/Metric.h:66-78): K contiguous chunks of floor(n / K) rows, the last one taking the remainder.  The drawn folds
+    are read back and handed to the ORACLE: the cross-validated path must then be the oracle's, fit by fit."""
+    from bess_amd import synth
+    from helpers import assert_same_trace
+    X, y, _, _ = synth.make_lm(503, 60, 5)
+    with gpu.Session(X, y) as s:
+        s.set_cv(5, None, seed=99)
+        fold = s.cv_folds()
+        s.trace_enable(True)
+        got = s.sequential_path(np.arange(1, 9), ic_type=3, is_cv=True)
+    sizes = np.bincount(fold, minlength=5)
+    assert list(sizes) == [100, 100, 100, 100, 103] and fold.min() == 0 and fold.max() == 4
+    with gpu.Session(X, y) as s2:  # the same seed draws the same folds; another seed does not
+        s2.set_cv(5, None, seed=99)
+        assert np.array_equal(s2.cv_folds(), fold)
+        s2.set_cv(5, None, seed=100)
+        assert not np.array_equal(s2.cv_folds(), fold)
+    want = P.trace(X, y, ic_type=3, is_cv=True, K=5, cv_fold_id=fold, sequence=np.arange(1, 9))
+    assert_same_trace(got["trace"], want, what="seed-drawn folds")
+    np.testing.assert_allclose(got["beta"], want["beta"], rtol=1e-6, atol=1e-12)
