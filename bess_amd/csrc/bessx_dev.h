@@ -254,7 +254,8 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
 hipError_t cov_panel_prepare();
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
                              int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st,
-                             const int *bgm = nullptr);
+                             const int *bgm = nullptr, int ex_lo = 0, int ex_hi = 0);
+hipError_t launch_rows_permute(const double *X, long ld, int p, const int *perm, long ldp, double *Xp, hipStream_t st);
 hipError_t launch_cov_compact(const double *G, int p, const int *slot_of, const int *fcols, int g0, int ngroups,
                               double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st);
 // background (speculative) fill on a second stream

@@ -152,6 +152,7 @@ struct bessx_session {
     double *H = nullptr;
     int *hact = nullptr, *hmeta = nullptr;
     double *hinfo = nullptr;
+    bool shares_map = false;  // slot_of / meta are row set 0's (shared fills: every row set caches the same columns)
   };
   std::vector<CovCache> cov;
   bool cov_mode = false;
@@ -191,6 +192,13 @@ struct bessx_session {
   long long cov_cg_fallbacks = 0;
   int cov_C = 0;              // cache capacity in columns
   int cov_rps = 0, cov_nslab = 0;
+  // shared fills of the CV row sets (LM, covariance form): a fold-major copy Xp of X (rows regrouped by test fold,
+  // every fold padded to whole row slabs) lets ONE unmasked pass of the panel kernel serve all K + 1 row sets -- the
+  // slab partials of every fold but k sum to fold k's training-row Gram columns, all slabs to the full-data ones
+  bool cv_shared = false;
+  double *Xp = nullptr, *zp = nullptr, *cvp_part = nullptr;
+  long ldp = 0;
+  int cvp_rps = 0, cvp_nsl = 0;  // rows per slab, slabs per fold (fold k owns slabs [k * cvp_nsl, (k + 1) * cvp_nsl))
   int cov_variant = 3;        // panel kernel: 3 = LDS tile, loads two chunks ahead (2 blocks per CU); 2 = LDS tile,
                               // one chunk ahead (3 blocks per CU); 1 = double-buffered tile (1 block per CU);
                               // 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
@@ -342,10 +350,15 @@ static void session_free(bessx_session *s) {
     F(c.A);
     F(c.meta);
   }
+  F(s->Xp);
+  F(s->zp);
+  F(s->cvp_part);
   for (auto &c : s->cov) {
     F(c.G);
-    F(c.slot_of);
-    F(c.meta);
+    if (!c.shares_map) {
+      F(c.slot_of);
+      F(c.meta);
+    }
     F(c.GS);
     F(c.H);
     F(c.hact);
@@ -465,15 +478,20 @@ static constexpr int COV_R = 32;        // columns per panel group (matches the 
 static constexpr int COV_SLOT_GROUPS = 2;  // groups an ordinary PDAS slot launches
 static constexpr int COV_CS = 512;         // side of the slot-indexed Gram of the cached columns (2 MiB)
 
-static int alloc_cov_cache(bessx_session *s) {
+static int alloc_cov_cache(bessx_session *s, bool share_map = false) {
   bessx_session::CovCache c;
   hipError_t e = dmalloc(&c.G, (size_t)s->p * s->cov_C);
-  if (e == hipSuccess) e = dmalloc(&c.slot_of, (size_t)s->p);
-  if (e == hipSuccess) e = dmalloc(&c.meta, 4);
+  if (share_map && !s->cov.empty()) {
+    c.slot_of = s->cov[0].slot_of;
+    c.meta = s->cov[0].meta;
+    c.shares_map = true;
+  }
+  if (e == hipSuccess && !c.shares_map) e = dmalloc(&c.slot_of, (size_t)s->p);
+  if (e == hipSuccess && !c.shares_map) e = dmalloc(&c.meta, 4);
   if (e == hipSuccess) e = dmalloc(&c.GS, (size_t)COV_CS * COV_CS);
   if (e == hipSuccess) e = hipMemset(c.GS, 0, (size_t)COV_CS * COV_CS * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(c.meta, 0, 4 * sizeof(int));
+  if (e == hipSuccess && !c.shares_map) e = hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int));
+  if (e == hipSuccess && !c.shares_map) e = hipMemset(c.meta, 0, 4 * sizeof(int));
   if (e == hipSuccess) e = dmalloc(&c.H, (size_t)COV_CS * COV_CS);
   if (e == hipSuccess) e = dmalloc(&c.hact, (size_t)COV_CS);
   if (e == hipSuccess) e = dmalloc(&c.hmeta, 4);
@@ -483,8 +501,10 @@ static int alloc_cov_cache(bessx_session *s) {
   if (e == hipSuccess) e = hipMemset(c.hinfo, 0xff, 2 * sizeof(double));  // NaN: no ridge seen yet
   if (e != hipSuccess) {
     (void)hipFree(c.G);
-    (void)hipFree(c.slot_of);
-    (void)hipFree(c.meta);
+    if (!c.shares_map) {
+      (void)hipFree(c.slot_of);
+      (void)hipFree(c.meta);
+    }
     (void)hipFree(c.GS);
     (void)hipFree(c.H);
     (void)hipFree(c.hact);
@@ -725,8 +745,29 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
     const int ng = std::min(COV_SLOT_GROUPS, ngroups - g0);
     hipEvent_t ea = nullptr, eb = nullptr;
     if (int rc = k1_begin(s, &ea, &eb)) return rc;
-    hipError_t e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, g0, ng, s->cov_rps,
-                                    s->cov_nslab, s->cov_part, s->ctrl, parked, s->st, s->cov_variant);
+    hipError_t e = hipSuccess;
+    if (s->cv_shared) {
+      // one unmasked pass over the fold-major copy serves every row set: the columns enter ALL caches (same slots)
+      const int nsl_all = s->K * s->cvp_nsl;
+      e = launch_cov_panel(s->Xp, s->zp, s->ldp, s->p, nullptr, s->cov_fcols, g0, ng, s->cvp_rps, nsl_all, s->cvp_part,
+                           s->ctrl, parked, s->st, s->cov_variant);
+      if (s->timing && e == hipSuccess) {
+        e = hipEventRecord(eb, s->st);
+        s->cov_timed.push_back({s->ev_used - 2, g0});
+      }
+      for (int r = 0; r <= s->K && e == hipSuccess; r++) {
+        bessx_session::CovCache &cr = s->cov[r];
+        const int lo = r == 0 ? 0 : (r - 1) * s->cvp_nsl, hi = r == 0 ? 0 : r * s->cvp_nsl;  // fold r-1's own rows out
+        e = launch_cov_reduce(s->cvp_part, s->p, s->cov_fcols, cr.slot_of, cr.G, g0, ng, nsl_all, s->ctrl, parked, s->st,
+                              nullptr, lo, hi);
+        if (e == hipSuccess)
+          e = launch_cov_compact(cr.G, s->p, cr.slot_of, s->cov_fcols, g0, ng, cr.GS, s->cov_cs, s->ctrl, parked, s->st);
+      }
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel (shared): ") + hipGetErrorString(e));
+      continue;
+    }
+    e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, g0, ng, s->cov_rps,
+                         s->cov_nslab, s->cov_part, s->ctrl, parked, s->st, s->cov_variant);
     if (s->timing && e == hipSuccess) {
       e = hipEventRecord(eb, s->st);
       s->cov_timed.push_back({s->ev_used - 2, g0});
@@ -3069,10 +3110,17 @@ static void drop_folds(bessx_session *s) {
     (void)hipFree(s->gcache[i].meta);
   }
   if (!s->gcache.empty()) s->gcache.resize(1);
+  (void)hipFree(s->Xp);
+  (void)hipFree(s->zp);
+  (void)hipFree(s->cvp_part);
+  s->Xp = s->zp = s->cvp_part = nullptr;
+  s->cv_shared = false;
   for (size_t i = 1; i < s->cov.size(); i++) {
     (void)hipFree(s->cov[i].G);
-    (void)hipFree(s->cov[i].slot_of);
-    (void)hipFree(s->cov[i].meta);
+    if (!s->cov[i].shares_map) {
+      (void)hipFree(s->cov[i].slot_of);
+      (void)hipFree(s->cov[i].meta);
+    }
     (void)hipFree(s->cov[i].GS);
     (void)hipFree(s->cov[i].H);
     (void)hipFree(s->cov[i].hact);
@@ -3116,6 +3164,9 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
   s->K = K;
   s->cv_init.assign(K, SparseVec());
   s->cv_fold = fold;
+  // shared fills (see bessx_session::cv_shared): LM in the covariance form, no background fills
+  bool share = s->cov_mode && s->model_type == 1 && !s->cov_bg && !s->grouped;
+  if (const char *ev = std::getenv("BESSX_CV_SHARED")) share = share && std::string(ev) != "0";
   std::vector<double> m((size_t)s->ld);
   for (int k = 0; k < K; k++) {
     std::fill(m.begin(), m.end(), 0.0);
@@ -3157,7 +3208,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     CVX(grow(s->part2_rs, (size_t)s->nrb * p, false));
     CVX(grow(s->h_rs, (size_t)s->ld, true));
     int rc = alloc_gram_cache(s);
-    if (rc == 0 && s->cov_mode) rc = alloc_cov_cache(s);
+    if (rc == 0 && s->cov_mode) rc = alloc_cov_cache(s, share);
     if (rc) {
       drop_folds(s);
       return rc;
@@ -3170,6 +3221,38 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
         return rc2;
       }
 #undef CVX
+  }
+  if (share) {
+    // fold-major copy: fold k's test rows (ascending) padded with zero rows to cvp_nsl whole slabs of cvp_rps rows
+    int nmax = 0;
+    for (int k = 0; k < K; k++) nmax = std::max(nmax, s->n_test[k]);
+    const int nsl = std::max(1, (nmax + 1023) / 2048);
+    const int rps = ((nmax + nsl - 1) / nsl + 63) / 64 * 64;
+    const long seg = (long)nsl * rps, ldp = seg * K;
+    std::vector<int> perm((size_t)ldp, -1), fill((size_t)K, 0);
+    for (int i = 0; i < n; i++) perm[(size_t)fold[i] * seg + fill[fold[i]]++] = i;
+    int *dperm = nullptr;
+    const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
+    hipError_t e = dmalloc(&dperm, (size_t)ldp);
+    if (e == hipSuccess) e = hipMemcpy(dperm, perm.data(), (size_t)ldp * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dmalloc(&s->Xp, (size_t)ldp * p);
+    if (e == hipSuccess) e = dmalloc(&s->zp, (size_t)ldp);
+    if (e == hipSuccess) e = hipMemsetAsync(s->zp, 0, (size_t)ldp * sizeof(double), s->st);
+    if (e == hipSuccess)
+      e = dmalloc(&s->cvp_part, (size_t)COV_SLOT_GROUPS * K * nsl * njg * cov_streamed_tiles_per_wave() * 2 * 256);
+    if (e == hipSuccess) e = launch_rows_permute(s->X, s->ld, p, dperm, ldp, s->Xp, s->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+    (void)hipFree(dperm);
+    if (e != hipSuccess) {
+      drop_folds(s);
+      return fail(BESSX_ERR_HIP, std::string("set_cv (fold-major copy): ") + hipGetErrorString(e));
+    }
+    s->ldp = ldp;
+    s->cvp_rps = rps;
+    s->cvp_nsl = nsl;
+    s->cv_shared = true;
+    // every cache now holds the same columns: start them (and the shared slot map) from empty
+    if (int rc = reset_path_caches(s)) return rc;
   }
   HIPX(hipStreamSynchronize(s->st));
   return BESSX_OK;

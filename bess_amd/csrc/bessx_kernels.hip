@@ -5053,7 +5053,7 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
                                                     int njg, int p, const int *__restrict__ fcols,
                                                     const int *__restrict__ slot_of, double *__restrict__ G,
                                                     const FitCtrl *__restrict__ ctrl, int slot, int big,
-                                                    const int *__restrict__ bgm) {
+                                                    const int *__restrict__ bgm, int ex_lo, int ex_hi) {
   KT(6);
   if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
   const int gl = blockIdx.y;
@@ -5061,7 +5061,10 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
   const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
   const int tile = blockIdx.x, e = threadIdx.x;
   double s = 0.0;
-  for (int sl = 0; sl < nslab; sl++) s += part[(((size_t)gl * nslab + sl) * tiles_per_slab + tile) * 256 + e];
+  // slabs [ex_lo, ex_hi) are left out: on the fold-major copy of X (shared fills of the CV row sets) they are the
+  // rows of the fold whose TRAINING rows this cache belongs to
+  for (int sl = 0; sl < nslab; sl++)
+    if (sl < ex_lo || sl >= ex_hi) s += part[(((size_t)gl * nslab + sl) * tiles_per_slab + tile) * 256 + e];
   const int jt = tile >> 1, ni = tile & 1, lane = e >> 2, reg = e & 3;
   const int j = jt * 16 + (lane >> 4) + 4 * reg;
   const int ci = (g0 + gl) * COV_R + ni * 16 + (lane & 15);
@@ -6278,11 +6281,30 @@ hipError_t cov_panel_prepare() {
 }
 
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
-                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st, const int *bgm) {
+                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st, const int *bgm,
+                             int ex_lo, int ex_hi) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
   hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, part, g0, ngroups, nslab, njg, p,
-                     fcols, slot_of, G, ctrl, 0, parked, bgm);
+                     fcols, slot_of, G, ctrl, 0, parked, bgm, ex_lo, ex_hi);
   LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// Xp[j][r] = X[j][perm[r]] (0 where perm[r] < 0): the fold-major copy of X for the shared fills of the CV row sets
+__global__ void __launch_bounds__(256) k_rows_permute(const double *__restrict__ X, long ld, const int *__restrict__ perm,
+                                                      long ldp, double *__restrict__ Xp) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= ldp) return;
+  const int o = perm[r];
+  Xp[(size_t)blockIdx.y * ldp + r] = o >= 0 ? X[(size_t)blockIdx.y * ld + o] : 0.0;
+}
+hipError_t launch_rows_permute(const double *X, long ld, int p, const int *perm, long ldp, double *Xp, hipStream_t st) {
+  for (int j0 = 0; j0 < p; j0 += 32768) {  // grid.y limit
+    const int nj = std::min(32768, p - j0);
+    hipLaunchKernelGGL(k_rows_permute, dim3((unsigned)((ldp + 255) / 256), nj), dim3(256), 0, st, X + (size_t)j0 * ld, ld,
+                       perm, ldp, Xp + (size_t)j0 * ldp);
+    LAUNCH_CHECK();
+  }
   return hipSuccess;
 }
 

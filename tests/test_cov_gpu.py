@@ -164,3 +164,28 @@ def test_maintained_inverse_solve_walks_the_same_path(gpu, monkeypatch):
     got = s.sequential_path(np.arange(1, 61), (0.0,), 3, False)
     s.close()
     assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="hinv, cache restarts")
+
+
+@pytest.mark.parametrize("n,p,K", [(1000, 300, 5), (777, 150, 4)])
+def test_cv_row_sets_share_their_fills(gpu, monkeypatch, n, p, K):
+    """Cross-validation in the covariance form: one unmasked pass over a fold-major copy of X fills the Gram-column
+    caches of ALL K + 1 row sets (the slab partials of every fold but k sum to fold k's training rows).  Same path as with
+    one masked pass per row set (BESSX_CV_SHARED=0), far fewer passes over X, and the oracle's path fit by fit."""
+    X, y, _, _ = synth.make_lm(n, p, 10, seed=n)
+    fold = synth.make_cv_folds(n, K, seed=3)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BESSX_CV_SHARED", mode)
+        with gpu.Session(X, y, score_mode=2) as s:
+            s.set_cv(K, fold)
+            s.trace_enable(True)
+            outs[mode] = (s.gs_path(1, 30, ic_type=3, is_cv=True), s.counters()["passes_over_X"],
+                          s.sequential_path(np.arange(1, 13), [0.0, 0.03], ic_type=3, is_cv=True))
+    a, b = outs["1"], outs["0"]
+    assert a[1] < b[1] / 2, (a[1], b[1])  # far fewer 32-column passes over X
+    for i in (0, 2):
+        assert np.array_equal(a[i]["cand_support"], b[i]["cand_support"]) and a[i]["n_fits"] == b[i]["n_fits"]
+        np.testing.assert_allclose(a[i]["cand_ic"], b[i]["cand_ic"], rtol=1e-10)
+        np.testing.assert_allclose(a[i]["beta"], b[i]["beta"], rtol=1e-9, atol=1e-13)
+    want = P.trace(X, y, ic_type=3, is_cv=True, K=K, cv_fold_id=fold, path_type=2, s_min=1, s_max=30)
+    assert_same_trace(a[0]["trace"], want, what="shared CV fills")
