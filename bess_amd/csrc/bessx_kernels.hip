@@ -5011,12 +5011,15 @@ __device__ __forceinline__ void cov_pair_body(const double *__restrict__ X, cons
   store_chunk();
   if (nchunk > 1) load_chunk(r_begin + CP_RB);
   __syncthreads();
+#ifndef PAIR_DBG
+#define PAIR_DBG 0
+#endif
   for (int k = 0; k < nchunk; k++) {
     compute();
-    __syncthreads();
-    if (k + 1 < nchunk) store_chunk();
-    __syncthreads();
-    if (k + 2 < nchunk) load_chunk(r_begin + (long)(k + 2) * CP_RB);
+    if (PAIR_DBG != 2) __syncthreads();
+    if (PAIR_DBG != 1 && PAIR_DBG != 3 && k + 1 < nchunk) store_chunk();
+    if (PAIR_DBG != 2) __syncthreads();
+    if (PAIR_DBG != 1 && k + 2 < nchunk) load_chunk(r_begin + (long)(k + 2) * CP_RB);
   }
   // the partial-sum layout of the 32-column kernels: [group][slab][tile pair] -- the reduce kernel is unchanged
   const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
