@@ -74,7 +74,12 @@ def run(cases=100, seed=1, medium=False, verbose=True):
         elif mode == "grp" and p >= 12 and not (medium and fam == "cox"):  # (the oracle's Cox group branch is O(n^2))
             cuts = np.sort(rng.choice(np.arange(1, p), min(p - 1, int(rng.integers(3, max(4, p // 3)))), replace=False))
             gi = np.concatenate([[0], cuts]).astype(np.int32)
-            if np.max(np.diff(np.append(gi, p))) > 16:
+            # (groups wider than 16 columns take the tiled moment / Cholesky-score kernels; Cox keeps whole groups in
+            # a 256-column panel)
+            gs_ = np.sort(np.diff(np.append(gi, p)))[::-1]
+            if gs_[0] > (64 if fam == "cox" else 200) or int(np.sum(gs_[:5])) > n // 3:
+                # (also: the widest selectable groups together must stay well below n -- a rank-deficient restricted
+                # fit is BESSX_ERR_NUMERIC here, the reference's pivoted QR returns a basic solution)
                 gi = np.arange(0, p, 3).astype(np.int32)
             kw.update(algorithm_type=2, g_index=gi, sequence=np.arange(1, min(len(gi), 6)))
             kw.pop("score_mode", None)
