@@ -2960,7 +2960,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       return bail(fail(BESSX_ERR_ARG, "covariance score mode exists for LM with singleton groups only"));
     if (eligible && mode != 1) {
       // capacity: every column if p is small, else a few active sets' worth, within 1 GiB per row set
-      if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(4, std::atoi(ev)));
+      if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(6, std::atoi(ev)));
       // the pair kernel (variant 4) forms two 32-column groups per pass over X: fills then speculate up to 64 columns
       s->cov_spec = (s->cov_variant == 4 && p >= 4 * COV_R && topk_supported(p, 2 * COV_R)) ? 2 * COV_R : COV_R;
       long C = std::min<long>(((long)p + 31) / 32 * 32 + COV_R + s->cov_spec, 2560);
@@ -2977,7 +2977,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         long ns = 1, rps = ld;
         {
           // blocks resident at a time: 256 CUs x (1 for the double-buffered tile, 3 for the single one)
-          const long conc = s->cov_variant == 1 ? 256 : (s->cov_variant >= 3 ? 512 : 768);
+          const long conc = (s->cov_variant == 1 || s->cov_variant == 5) ? 256 : (s->cov_variant >= 3 ? 512 : 768);
           double best = 1e300;
           const long ns_max = std::max<long>(1, std::min<long>(64, ld / 256));
           for (long t = 1; t <= ns_max; t++) {

@@ -5051,6 +5051,145 @@ __global__ void __launch_bounds__(256) k_cov_panel_pair(const double *__restrict
     cov_pair_body<MASKED, false>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
 }
 
+// ---- the 32-column panel kernel with LDS-DMA staging (BESSX_PANEL_VARIANT=5, unmasked row sets) ----------------
+// Instrumented builds of the register-staged kernels put 22 % of their time into the ds_write_b128
+// staging stores and 13 % into the two barriers per chunk, while the HBM loads themselves were fully hidden.  Here
+// the columns go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no store pass): one wave
+// instruction moves 64 rows of 2 columns (1 KiB) into an UNPADDED tile [column][64 rows]; the 16-byte unit u of
+// column C lands at position u ^ g(C), g(C) = 2 (C & 7) | ((C >> 3) & 1), by permuting which unit each lane FETCHES
+// (the DMA destination is lane-linear), and the operand reads apply the same involution -- the sixteen lanes of every
+// ds_read_b128 group then hit sixteen different 16-byte bank slots.  Three LDS tiles (144 KB, one 4-wave block per
+// CU): chunk k is multiplied while chunks k + 1 and k + 2 are in flight, ONE barrier per chunk (the tile a DMA
+// overwrites was read two chunks ago), counted vmcnt waits, operand reads of the next row step issued ahead of the
+// MFMAs (one wave per SIMD: nothing else hides the LDS latency).
+constexpr int CG_COLS = 64 + COV_R;  // staged columns
+__device__ __forceinline__ int cg_swz(int C) { return ((C & 7) << 1) | ((C >> 3) & 1); }
+
+// RB = rows per chunk: 64 (three 48 KB tiles, one block per CU) or 32 (three 24 KB tiles, two blocks per CU; one DMA
+// instruction then moves 32 rows of 4 columns)
+template <int RB>
+__device__ __forceinline__ void cov_glds_body(const double *__restrict__ X, const double *__restrict__ aux, long ld,
+                                              int p, const int *__restrict__ fcols, int g0, int ngroups,
+                                              int rows_per_slab, int nslab, int njg, double *__restrict__ part,
+                                              const FitCtrl *__restrict__ ctrl, int big,
+                                              const int *__restrict__ bgm) {
+  constexpr int UPC = RB / 2;            // 16-byte units per column and chunk
+  constexpr int CPI = 64 / UPC;          // columns per DMA instruction
+  constexpr int IPW = CG_COLS / CPI / 4;  // DMA instructions per wave and chunk
+  constexpr int TILE = CG_COLS * RB;      // doubles per LDS tile
+  KT(5);
+  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
+  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
+  const long per_group = (long)nslab * njg;
+  const int gl = (int)(blockIdx.x / per_group);
+  if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
+  const int rem = (int)(blockIdx.x - (long)gl * per_group);
+  const int slab = rem / njg, jg = rem - slab * njg;
+  extern __shared__ double smem[];  // [3][CG_COLS][RB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
+  // DMA side: wave wv moves the column groups wv * IPW + i; lane: column CPI * group + lane / UPC, position lane % UPC
+  const double *src[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; i++) {
+    const int cc = CPI * (wv * IPW + i) + lane / UPC;
+    int col;
+    if (cc < 64)
+      col = min(jg * 64 + cc, p - 1);  // (a column beyond p re-reads the last one: its rows are never stored)
+    else
+      col = fcols[(g0 + gl) * COV_R + cc - 64];
+    const int u = (lane % UPC) ^ cg_swz(cc);  // the unit this lane fetches so that it LANDS at position lane % UPC
+    src[i] = gram_col(X, aux, ld, col) + 2 * u;
+  }
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + RB - 1) / RB);
+  auto dma_chunk = [&](int k) {
+    double *tile = smem + (size_t)(k % 3) * TILE + (size_t)(wv * IPW) * CPI * RB;
+    const long r = r_begin + (long)k * RB;
+#pragma unroll
+    for (int i = 0; i < IPW; i++)
+      __builtin_amdgcn_global_load_lds(src[i] + r, (__attribute__((address_space(3))) void *)(tile + (size_t)i * CPI * RB),
+                                       16, 0, 0);
+  };
+  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+  // operand reads: column C, rows 16 s + 4 q .. + 3 = units 8 s + 2 q, + 1, swizzled
+  const int ca = wv * 16 + c, cb0 = 64 + c, cb1 = 80 + c;
+  const int ga = cg_swz(ca), gb0 = cg_swz(cb0), gb1 = cg_swz(cb1);
+  struct Ops {
+    d2 a0, a1, x0, x1, y0, y1;
+  };
+  auto read_ops = [&](const double *tile, int s, Ops &o) {
+    const int u = 8 * s + 2 * q;
+    const double *pa = tile + (size_t)ca * RB, *pb0 = tile + (size_t)cb0 * RB, *pb1 = tile + (size_t)cb1 * RB;
+    o.a0 = *reinterpret_cast<const d2 *>(pa + 2 * (u ^ ga));
+    o.a1 = *reinterpret_cast<const d2 *>(pa + 2 * ((u + 1) ^ ga));
+    o.x0 = *reinterpret_cast<const d2 *>(pb0 + 2 * (u ^ gb0));
+    o.x1 = *reinterpret_cast<const d2 *>(pb0 + 2 * ((u + 1) ^ gb0));
+    o.y0 = *reinterpret_cast<const d2 *>(pb1 + 2 * (u ^ gb1));
+    o.y1 = *reinterpret_cast<const d2 *>(pb1 + 2 * ((u + 1) ^ gb1));
+  };
+  auto mfma_ops = [&](const Ops &o) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.x, o.x0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.x, o.y0.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.y, o.x0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.y, o.y0.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.x, o.x1.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.x, o.y1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.y, o.x1.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.y, o.y1.y, acc1, 0, 0, 0);
+  };
+  dma_chunk(0);
+  if (nchunk > 1) dma_chunk(1);
+  for (int k = 0; k < nchunk; k++) {
+    // this wave's part of chunk k has landed (the DMAs of chunk k + 1 may still be in flight) ...
+    if (k + 1 < nchunk) {
+      if (IPW == 12)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ... and after the barrier everybody's has, and everybody is done reading the tile of chunk k - 1
+    __builtin_amdgcn_s_barrier();
+    if (k + 2 < nchunk) dma_chunk(k + 2);  // into the tile of chunk k - 1
+    const double *tile = smem + (size_t)(k % 3) * TILE;
+    Ops oa, ob;
+    read_ops(tile, 0, oa);
+#pragma unroll
+    for (int s = 0; s < RB / 16; s += 2) {
+      read_ops(tile, s + 1, ob);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ops(oa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < RB / 16) read_ops(tile, s + 2, oa);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_ops(ob);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
+  double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
+  *reinterpret_cast<d4 *>(out + lane * 4) = acc0;
+  *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
+}
+
+// (two plain kernels around the body: a __global__ TEMPLATE that uses the LDS-DMA builtin is silently not instantiated
+// by the host pass of hipcc 7.2 -- the library then fails to load with an undefined stub)
+__global__ void __launch_bounds__(256) k_cov_panel_glds64(const double *__restrict__ X, const double *__restrict__ aux,
+                                                          long ld, int p, const int *__restrict__ fcols, int g0,
+                                                          int ngroups, int rows_per_slab, int nslab, int njg,
+                                                          double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
+                                                          int big, const int *__restrict__ bgm) {
+  cov_glds_body<64>(X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, big, bgm);
+}
+__global__ void __launch_bounds__(256) k_cov_panel_glds32(const double *__restrict__ X, const double *__restrict__ aux,
+                                                          long ld, int p, const int *__restrict__ fcols, int g0,
+                                                          int ngroups, int rows_per_slab, int nslab, int njg,
+                                                          double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
+                                                          int big, const int *__restrict__ bgm) {
+  cov_glds_body<32>(X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, big, bgm);
+}
+
 // G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
 __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
                                                     int njg, int p, const int *__restrict__ fcols,
@@ -6219,6 +6358,18 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
 #define PANEL_GO(M, D)                                                                                              \
   hipLaunchKernelGGL((k_cov_panel_lds<M, D>), dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0, \
                      ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm)
+    if ((variant == 5 || variant == 6) && mask == nullptr) {
+      // LDS-DMA staging, three tiles: 5 = 64-row chunks, one block per CU; 6 = 32-row chunks, two blocks per CU
+      const long nb5 = (long)ngroups * nslab * njg;
+      if (variant == 5)
+        hipLaunchKernelGGL(k_cov_panel_glds64, dim3((unsigned)nb5), dim3(256), (size_t)3 * CG_COLS * 64 * sizeof(double),
+                           st, X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
+      else
+        hipLaunchKernelGGL(k_cov_panel_glds32, dim3((unsigned)nb5), dim3(256), (size_t)3 * CG_COLS * 32 * sizeof(double),
+                           st, X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
+      LAUNCH_CHECK();
+      return hipSuccess;
+    }
     if (variant == 4 && ngroups <= 2) {
       // one block per (slab, 64-column group) for BOTH groups of the launch: X streamed once
       const size_t lds2 = (size_t)CP2_COLS * CP_LD * sizeof(double);
@@ -6274,6 +6425,12 @@ hipError_t cov_panel_prepare() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<false, true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_glds64),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * CG_COLS * 64 * sizeof(double)));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_glds32),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * CG_COLS * 32 * sizeof(double)));
   if (e != hipSuccess) return e;
   const int lds2 = (int)((size_t)CP2_COLS * CP_LD * sizeof(double));
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_pair<true>),
