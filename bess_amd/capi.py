@@ -23,7 +23,7 @@ _vp = ctypes.c_void_p
 SYMBOLS = [
     "bessx_last_error", "bessx_device_info", "bessx_pywrap_bess", "bessx_bessCpp", "bessx_session_create",
     "bessx_session_destroy", "bessx_session_set_cv", "bessx_session_get_cv_folds", "bessx_session_sequential_path", "bessx_session_gs_path",
-    "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_score_mode", "bessx_session_counter",
+    "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_get_screening_groups", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_session_reset_caches", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
@@ -92,6 +92,8 @@ def lib():
         L.bessx_session_score_mode.restype = _i
         L.bessx_session_get_screening.argtypes = [_vp, _I, _i]
         L.bessx_session_get_screening.restype = _i
+        L.bessx_session_get_screening_groups.argtypes = [_vp, _I, _i]
+        L.bessx_session_get_screening_groups.restype = _i
         L.bessx_session_set_cv.argtypes = [_vp, _i, _I, ctypes.c_uint]
         L.bessx_session_get_cv_folds.argtypes = [_vp, _I]
         L.bessx_session_sequential_path.argtypes = [_vp, _I, _i, _D, _i, _i, _i, ctypes.POINTER(PathResult)]
@@ -262,6 +264,13 @@ class Session:
         a = np.zeros(self.p_kept, dtype=np.int32)
         lib().bessx_session_get_screening(self._h, _ip(a), a.size)
         return a
+
+    def screening_groups(self):
+        """Kept original group numbers after screening with groups of size > 1 (empty otherwise)."""
+        n = lib().bessx_session_get_screening_groups(self._h, None, 0)
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        lib().bessx_session_get_screening_groups(self._h, _ip(a), n)
+        return a[:n]
 
     def close(self):
         if getattr(self, "_h", None):

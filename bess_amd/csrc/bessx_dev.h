@@ -222,6 +222,10 @@ hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const
                                 const int *gidx, const int *gsz, const int *goff, double *mblk, double *dcol,
                                 hipStream_t st, int cshift = 0);
 hipError_t launch_iota(int *a, int n, hipStream_t st);
+// screening with groups, LM: score_g = |argmin_b |y - X_g b||^2 / size(g) from the group moments
+hipError_t launch_group_lsq_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
+                                  const double *dcol, const unsigned char *always, double *work, double *zwork,
+                                  double *score, hipStream_t st);
 hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxBufs cb, const int *allcols, int mcols,
                                     int smax, int N, const int *gidx_h, const int *gsz_h, const int *gidx,
                                     const int *gsz, const int *goff, long mblk_len, double *mblk, double *mblk2,

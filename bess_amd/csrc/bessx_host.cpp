@@ -252,6 +252,7 @@ struct bessx_session {
   // host statistics
   std::vector<double> x_mean_h, x_norm_h;
   std::vector<int> cv_fold;  // test fold of every row (bessx_session_get_cv_folds)
+  std::vector<int> screen_groups, scr_gidx;  // screening with groups: kept original groups; group index of the kept data
   double y_mean_h = 0.0;
   double nullloss = 0.0;  // Data::get_nullloss (src/Data.h:120-130)
   // Algorithm state (reference member names in comments)
@@ -2606,15 +2607,29 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   if (pb->is_screening) {
     // screening(), src/screening.cpp:26-105, before anything else touches the data (src/bess.cpp:57-61)
     const int pf = pb->p, ss = pb->screening_size;
-    if (pb->group_index && pb->group_index_len > 0 && pb->group_index_len != pf)
-      return bail(fail(BESSX_ERR_UNSUPPORTED, "screening with groups of size > 1 is not built"));
+    const bool gscr = pb->group_index && pb->group_index_len > 0 && pb->group_index_len != pf;
+    if (gscr && pb->model_type != 1)
+      return bail(fail(BESSX_ERR_UNSUPPORTED, "screening with groups of size > 1 is built for the linear model only"));
+    if (gscr) {
+      // groups of the original columns (Data::g_index semantics); screening_size and always_select count GROUPS
+      const int Ng = pb->group_index_len;
+      long long tot = 0;
+      for (int g = 0; g < Ng; g++) {
+        const int a = pb->group_index[g], b = g + 1 < Ng ? pb->group_index[g + 1] : pf;
+        if ((g == 0 && a != 0) || b <= a || b > pf)
+          return bail(fail(BESSX_ERR_ARG, "group_index must start at 0 and increase strictly"));
+        tot += (long long)(b - a) * (b - a);
+      }
+      if (tot > 0x7fffffffLL) return bail(fail(BESSX_ERR_UNSUPPORTED, "group blocks exceed 2^31 entries in total"));
+    }
+    const int nunits = gscr ? pb->group_index_len : pf;  // what is ranked: groups or columns
     if (pb->model_type == 3)
       return bail(fail(BESSX_ERR_UNSUPPORTED, "Poisson screening: poisson_fit is undefined behaviour in the reference (src/poisson.cpp:113)"));
-    if (ss < 1 || ss > pf) return bail(fail(BESSX_ERR_ARG, "screening_size must be in 1..p"));
-    if (!topk_supported(pf, ss)) return bail(fail(BESSX_ERR_UNSUPPORTED, "screening_size too large for the top-k kernel"));
+    if (ss < 1 || ss > nunits) return bail(fail(BESSX_ERR_ARG, "screening_size must be in 1..p (1..number of groups)"));
+    if (!topk_supported(nunits, ss)) return bail(fail(BESSX_ERR_UNSUPPORTED, "screening_size too large for the top-k kernel"));
     std::vector<unsigned char> fl((size_t)pf, 0);
     for (int a : always_sel) {
-      if (a < 0 || a >= pf) return bail(fail(BESSX_ERR_ARG, "always_select index out of range"));
+      if (a < 0 || a >= nunits) return bail(fail(BESSX_ERR_ARG, "always_select index out of range"));
       fl[a] = 1;
     }
     double *Xraw = nullptr, *yw = nullptr, *scr = nullptr;
@@ -2663,7 +2678,43 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     }
     double *score = scr, *sxy = scr + pf, *sxx = scr + 2 * (size_t)pf, *work = scr + 3 * (size_t)pf;
     int *done = ibuf, *keep = ibuf + pf, *cand = ibuf + pf + ss;
-    if (pb->model_type == 1) {
+    std::vector<int> g_lo, g_sz;  // grouped screening: first column and width of every original group
+    if (gscr) {
+      // LM marginal fit of a whole group (src/screening.cpp:44-48): moments X_g^T X_g, X_g^T y, then a Cholesky solve
+      const int Ng = nunits;
+      std::vector<int> g_off((size_t)Ng + 1, 0);
+      int gmax = 1;
+      g_lo.resize(Ng);
+      g_sz.resize(Ng);
+      for (int g = 0; g < Ng; g++) {
+        g_lo[g] = pb->group_index[g];
+        g_sz[g] = (g + 1 < Ng ? pb->group_index[g + 1] : pf) - g_lo[g];
+        g_off[g + 1] = g_off[g] + g_sz[g] * g_sz[g];
+        gmax = std::max(gmax, g_sz[g]);
+      }
+      int *gd = nullptr;
+      double *gm = nullptr;
+      auto gdrop = [&]() {
+        (void)hipFree(gd);
+        (void)hipFree(gm);
+      };
+      hipError_t e = dmalloc(&gd, (size_t)3 * Ng + 1);
+      if (e == hipSuccess) e = dmalloc(&gm, (size_t)2 * g_off[Ng] + 3 * (size_t)pf);
+      if (e == hipSuccess) e = hipMemcpy(gd, g_lo.data(), (size_t)Ng * sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(gd + Ng, g_sz.data(), (size_t)Ng * sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(gd + 2 * Ng, g_off.data(), ((size_t)Ng + 1) * sizeof(int), hipMemcpyHostToDevice);
+      double *mblk = gm, *mwork = gm + g_off[Ng], *dcol = gm + 2 * (size_t)g_off[Ng], *zw = dcol + pf;
+      if (e == hipSuccess)
+        e = launch_group_moments(gmax, Xraw, ld, n, nullptr, yw, Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, s->st);
+      if (e == hipSuccess)
+        e = launch_group_lsq_score(Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, fl_d, mwork, zw, score, s->st);
+      if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+      gdrop();
+      if (e != hipSuccess) {
+        drop();
+        return bail(fail(BESSX_ERR_HIP, std::string("group screening: ") + hipGetErrorString(e)));
+      }
+    } else if (pb->model_type == 1) {
       // beta_j = x_j.y / x_j.x_j: the closed form of lm_fit on one column (src/screening.cpp:44-47), one score pass
       HIPS(launch_xtv(Xraw, ld, pf, s->U, yw, yw + 2 * ld, work, work + (size_t)s->nrb * pf, nullptr, 0, s->st));
       HIPS(launch_part_sum(work, s->nrb, pf, sxy, s->st));
@@ -2674,14 +2725,31 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     } else {
       HIPS(launch_screen_cox(Xraw, ld, n, pf, yw, yw + ld, fl_d, score, s->st));
     }
-    HIPS(launch_topk(score, pf, ss, keep, cand, nullptr, 0, s->st));
+    HIPS(launch_topk(score, nunits, ss, keep, cand, nullptr, 0, s->st));
     HIPS(hipStreamSynchronize(s->st));
     s->screen_map.assign((size_t)ss, 0);
     HIPS(hipMemcpy(s->screen_map.data(), keep, (size_t)ss * sizeof(int), hipMemcpyDeviceToHost));
+    int pk = ss;  // columns kept
+    if (gscr) {
+      // kept groups -> their columns (ascending), the group index of the kept data, always_select by kept-group rank
+      s->screen_groups = s->screen_map;
+      s->screen_map.clear();
+      s->scr_gidx.clear();
+      for (int g : s->screen_groups) {
+        s->scr_gidx.push_back((int)s->screen_map.size());
+        for (int u = 0; u < g_sz[g]; u++) s->screen_map.push_back(g_lo[g] + u);
+      }
+      pk = (int)s->screen_map.size();
+      (void)hipFree(ibuf);
+      ibuf = nullptr;
+      HIPS(dmalloc(&ibuf, (size_t)pk));
+      keep = ibuf;
+      HIPS(hipMemcpy(keep, s->screen_map.data(), (size_t)pk * sizeof(int), hipMemcpyHostToDevice));
+    }
     double *X2 = nullptr;
-    HIPS(dmalloc(&X2, (size_t)ld * ss));
+    HIPS(dmalloc(&X2, (size_t)ld * pk));
     {
-      hipError_t e = launch_gather_cols(Xraw, ld, keep, ss, X2, s->st);
+      hipError_t e = launch_gather_cols(Xraw, ld, keep, pk, X2, s->st);
       if (e == hipSuccess) e = hipStreamSynchronize(s->st);
       if (e != hipSuccess) {
         (void)hipFree(X2);
@@ -2692,12 +2760,11 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     drop();
 #undef HIPS
     s->X = X2;
-    s->p = ss;
+    s->p = pk;
     x_ready = true;
-    // always_select re-indexed into the kept columns (src/screening.cpp:90-102)
-    for (int &a : always_sel) {
-      a = (int)(std::lower_bound(s->screen_map.begin(), s->screen_map.end(), a) - s->screen_map.begin());
-    }
+    // always_select re-indexed into the kept columns / groups (src/screening.cpp:90-102)
+    const std::vector<int> &ranked = gscr ? s->screen_groups : s->screen_map;
+    for (int &a : always_sel) a = (int)(std::lower_bound(ranked.begin(), ranked.end(), a) - ranked.begin());
   }
   const int p = s->p;
   s->data_type = pb->data_type;
@@ -2708,16 +2775,19 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   s->warm_start = pb->is_warm_start ? 1 : 0;
   {
     // groups: Data::g_index / g_size / g_num (src/Data.h:59-67)
-    const bool have_groups = pb->group_index && pb->group_index_len > 0 && !pb->is_screening;
-    const int gl = have_groups ? pb->group_index_len : p;
+    // (after screening with groups the session lives on the kept groups: scr_gidx is their group index)
+    const bool kept_groups = pb->is_screening && !s->scr_gidx.empty();
+    const bool have_groups = kept_groups || (pb->group_index && pb->group_index_len > 0 && !pb->is_screening);
+    const int *gsrc = kept_groups ? s->scr_gidx.data() : pb->group_index;
+    const int gl = kept_groups ? (int)s->scr_gidx.size() : (have_groups ? pb->group_index_len : p);
     s->N = gl;
     s->gidx_h.resize(gl);
     s->gsz_h.resize(gl);
     s->goff_h.resize(gl + 1);
     s->goff_h[0] = 0;
     for (int g = 0; g < gl; g++) {
-      const int a = have_groups ? pb->group_index[g] : g;
-      const int b = g + 1 < gl ? (have_groups ? pb->group_index[g + 1] : g + 1) : p;
+      const int a = have_groups ? gsrc[g] : g;
+      const int b = g + 1 < gl ? (have_groups ? gsrc[g + 1] : g + 1) : p;
       if ((g == 0 && a != 0) || b <= a || b > p) return bail(fail(BESSX_ERR_ARG, "group_index must start at 0 and increase strictly"));
       s->gidx_h[g] = a;
       s->gsz_h[g] = b - a;
@@ -3380,6 +3450,13 @@ int bessx_session_get_screening(const bessx_session *s, int *columns, int cap) {
   return s->p;
 }
 
+int bessx_session_get_screening_groups(const bessx_session *s, int *groups, int cap) {
+  if (!s) return 0;
+  const int cnt = (int)s->screen_groups.size();
+  for (int g = 0; g < cnt && g < cap && groups; g++) groups[g] = s->screen_groups[g];
+  return cnt;
+}
+
 int bessx_session_reset_caches(bessx_session *s) {
   if (!s) return fail(BESSX_ERR_ARG, "null session");
   HIPX(hipSetDevice(s->device));
@@ -3583,7 +3660,11 @@ int bessx_bessCpp(const double *x, int n, int p, const double *y, int data_type,
                                              is_cv, &r)
                     : bessx_session_gs_path(s, s_min, s_max, ic_type, is_cv, &r);
   if (rc) return done(rc);
-  if (is_screening && res->screening_A) bessx_session_get_screening(s, res->screening_A, screening_size);
+  if (is_screening && res->screening_A) {
+    // screening_A of src/screening.cpp:68: kept columns, or kept GROUPS when the groups have more than one column
+    if (bessx_session_get_screening_groups(s, res->screening_A, screening_size) == 0)
+      bessx_session_get_screening(s, res->screening_A, screening_size);
+  }
   res->coef0 = r.coef0;
   res->train_loss = r.train_loss;
   res->ic = r.ic;

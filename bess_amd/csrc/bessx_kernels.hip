@@ -3218,6 +3218,65 @@ __global__ void __launch_bounds__(256) k_group_score_big(int N, const int *__res
   }
 }
 
+// Screening with groups, LM (src/screening.cpp:44-48 on a group: beta = argmin |y - X_g b|, no intercept, no weights):
+// with M = X_g^T X_g and d = X_g^T y from the group-moment kernels, beta = M^{-1} d by a Cholesky in a global work copy
+// (left-looking, as k_group_score_big) + forward and backward substitution; score = |beta|^2 / s.  One block per
+// group, any width.  A singular block (an all-zero column) gives a non-finite coefficient like the reference's QR
+// solve, which divides by the zero pivot: ranked first (+inf), never a NaN key.
+__global__ void __launch_bounds__(256) k_group_lsq_score(int N, const int *__restrict__ gidx,
+                                                         const int *__restrict__ gsz, const int *__restrict__ goff,
+                                                         const double *__restrict__ mblk,
+                                                         const double *__restrict__ dcol,
+                                                         const unsigned char *__restrict__ always,
+                                                         double *__restrict__ work, double *__restrict__ zwork,
+                                                         double *__restrict__ score) {
+  __shared__ double sm[4];
+  __shared__ double piv;
+  const int g = blockIdx.x, s = gsz[g], c0 = gidx[g], tid = threadIdx.x;
+  if (always != nullptr && always[g]) {
+    if (tid == 0) score[g] = DBL_MAX;
+    return;
+  }
+  double *W = work + goff[g], *z = zwork + c0;
+  for (int u = tid; u < s; u += 256) z[u] = dcol[c0 + u];
+  for (int e = tid; e < s * s; e += 256) W[e] = mblk[goff[g] + e];
+  __syncthreads();
+  for (int j = 0; j < s; j++) {
+    for (int i = j + tid; i < s; i += 256) {
+      double v = W[(size_t)j * s + i];
+      for (int k = 0; k < j; k++) v = fma(-W[(size_t)k * s + i], W[(size_t)k * s + j], v);
+      W[(size_t)j * s + i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) piv = sqrt(W[(size_t)j * s + j]);
+    __syncthreads();
+    const double rp = 1.0 / piv;
+    for (int i = j + tid; i < s; i += 256) W[(size_t)j * s + i] = (i == j) ? piv : W[(size_t)j * s + i] * rp;
+    __syncthreads();
+  }
+  for (int j = 0; j < s; j++) {  // L y = d
+    if (tid == 0) z[j] = z[j] / W[(size_t)j * s + j];
+    __syncthreads();
+    const double zj = z[j];
+    for (int i = j + 1 + tid; i < s; i += 256) z[i] = fma(-W[(size_t)j * s + i], zj, z[i]);
+    __syncthreads();
+  }
+  for (int j = s - 1; j >= 0; j--) {  // L^T b = y
+    if (tid == 0) z[j] = z[j] / W[(size_t)j * s + j];
+    __syncthreads();
+    const double zj = z[j];
+    for (int i = tid; i < j; i += 256) z[i] = fma(-W[(size_t)i * s + j], zj, z[i]);
+    __syncthreads();
+  }
+  double acc = 0.0;
+  for (int u = tid; u < s; u += 256) acc = fma(z[u], z[u], acc);
+  acc = block_sum_256(acc, sm);
+  if (tid == 0) {
+    const double v = acc / (double)s;
+    score[g] = (v == v) ? v : HUGE_VAL;
+  }
+}
+
 // commit of a group-mode iteration: history on the T0 group ids, coefficients on the K expanded columns
 __global__ void __launch_bounds__(256) k_commit_group(FitCtrl *__restrict__ ctrl, int slot, int T0,
                                                       const int *__restrict__ G_new, int K,
@@ -6179,6 +6238,15 @@ hipError_t launch_group_moments(int smax, const double *X, long ld, int n, const
                        goff, mblk, dcol, cshift);
     LAUNCH_CHECK();
   }
+  return hipSuccess;
+}
+
+hipError_t launch_group_lsq_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
+                                  const double *dcol, const unsigned char *always, double *work, double *zwork,
+                                  double *score, hipStream_t st) {
+  hipLaunchKernelGGL(k_group_lsq_score, dim3(N), dim3(256), 0, st, N, gidx, gsz, goff, mblk, dcol, always, work, zwork,
+                     score);
+  LAUNCH_CHECK();
   return hipSuccess;
 }
 

@@ -50,6 +50,8 @@ def lib():
                                              _D, _I, _I, _D]
         _lib.bess_ref_screening.restype = _i
         _lib.bess_ref_screening.argtypes = [_D, _i, _i, _D, _D, _i, _i, _I, _i, _I]
+        _lib.bess_ref_screening_groups.restype = _i
+        _lib.bess_ref_screening_groups.argtypes = [_D, _i, _i, _D, _D, _i, _i, _I, _i, _I, _i, _I]
         _lib.bess_ref_trace_size.restype = _i
         _lib.bess_ref_trace_size.argtypes = [_i]
         _lib.bess_ref_trace_copy_int.restype = None
@@ -194,4 +196,18 @@ def screening(x, y, weight, model_type, screening_size, always_select=()):
     al = np.ascontiguousarray(always_select, dtype=np.int32)
     out = np.zeros(screening_size, dtype=np.int32)
     lib().bess_ref_screening(_dp(x), n, p, _dp(y), _dp(w), model_type, screening_size, _ip(al), al.size, _ip(out))
+    return out
+
+
+def screening_groups(x, y, weight, model_type, screening_size, g_index, always_select=()):
+    """The reference's screening() with groups of size > 1: kept GROUP numbers (ascending)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n, p = x.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    w = np.ones(n) if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+    gi = np.ascontiguousarray(g_index, dtype=np.int32)
+    al = np.ascontiguousarray(always_select, dtype=np.int32)
+    out = np.zeros(screening_size, dtype=np.int32)
+    lib().bess_ref_screening_groups(_dp(x), n, p, _dp(y), _dp(w), model_type, screening_size, _ip(gi), gi.size, _ip(al),
+                                    al.size, _ip(out))
     return out

@@ -367,8 +367,20 @@ int bess_ref_time_chain(const double *x, int n, int p, const double *y, const do
 }
 
 // The reference's screening() alone (src/screening.cpp:26-105): returns the kept column indices.
+int bess_ref_screening_groups(const double *x, int n, int p, const double *y, const double *weight, int model_type,
+                              int screening_size, const int *g_index, int g_len, const int *always_select,
+                              int always_len, int *screening_A);
+
 int bess_ref_screening(const double *x, int n, int p, const double *y, const double *weight, int model_type,
                        int screening_size, const int *always_select, int always_len, int *screening_A) {
+  return bess_ref_screening_groups(x, n, p, y, weight, model_type, screening_size, nullptr, 0, always_select, always_len,
+                                   screening_A);
+}
+
+// ... with a group index (g_index == NULL: singleton groups): screening_A = kept GROUP numbers
+int bess_ref_screening_groups(const double *x, int n, int p, const double *y, const double *weight, int model_type,
+                              int screening_size, const int *g_index, int g_len, const int *always_select,
+                              int always_len, int *screening_A) {
   Eigen::MatrixXd X(n, p);
   for (int i = 0; i < n; i++)
     for (int j = 0; j < p; j++) X(i, j) = x[(size_t)i * p + j];
@@ -377,8 +389,9 @@ int bess_ref_screening(const double *x, int n, int p, const double *y, const dou
     Y(i) = y[i];
     W(i) = weight[i];
   }
-  Eigen::VectorXi G(p), AS(always_len);
-  for (int j = 0; j < p; j++) G(j) = j;
+  const int gl = g_index ? g_len : p;
+  Eigen::VectorXi G(gl), AS(always_len);
+  for (int j = 0; j < gl; j++) G(j) = g_index ? g_index[j] : j;
   for (int i = 0; i < always_len; i++) AS(i) = always_select[i];
   Eigen::VectorXi A = screening(X, Y, W, model_type, screening_size, G, AS);
   for (int i = 0; i < A.size(); i++) screening_A[i] = A(i);

@@ -71,6 +71,54 @@ def test_screening_argument_errors(gpu):
     with pytest.raises(gpu.BessxError) as e:  # Poisson: undefined behaviour in the reference, refused here
         gpu.Session(X, np.abs(np.round(y)), data_type=2, model_type=3, is_screening=True, screening_size=10)
     assert e.value.code == 3
-    with pytest.raises(gpu.BessxError) as e:
-        gpu.Session(X, y, is_screening=True, screening_size=10, g_index=[0, 5, 10])
+    with pytest.raises(gpu.BessxError) as e:  # groups of size > 1: linear model only
+        gpu.Session(X, (y > 0).astype(float), data_type=2, model_type=2, algorithm_type=2, is_screening=True,
+                    screening_size=2, g_index=[0, 5, 10])
     assert e.value.code == 3
+
+
+def _group_index(p, seed, wide=False):
+    rng = np.random.default_rng(seed)
+    starts, c = [], 0
+    while c < p:
+        starts.append(c)
+        c += int(rng.choice([1, 2, 3, 5, 20] if wide else [1, 2, 3, 4]))
+    return np.array(starts, dtype=np.int32)
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_lm_screening_with_groups(gpu, wide):
+    """Screening with groups of size > 1 (LM): the kept GROUPS are the compiled reference's screening_A; the path then
+    runs on the kept groups' columns exactly like the oracle run on that sub-matrix with the kept group index; the
+    coefficients come back in the caller's column numbering (the reference misplaces them here, src/bess.cpp:195-198)."""
+    from oracle import ref_ctypes as R
+    n, p = 500, 240
+    X, y, _, _ = synth.make_lm(n, p, 8, seed=17)
+    gi = _group_index(p, 5, wide)
+    N, keep_n = len(gi), len(gi) // 3
+    sizes = np.diff(np.append(gi, p))
+    always = [int(N - 2)]
+    with gpu.Session(X, y, algorithm_type=2, g_index=gi, is_screening=True, screening_size=keep_n,
+                     always_select=always) as s:
+        groups, cols = s.screening_groups(), s.screening()
+        s.trace_enable(True)
+        got = s.sequential_path(np.arange(2, 6), ic_type=3)
+    if R.available():
+        assert np.array_equal(groups, R.screening_groups(X, y, None, 1, keep_n, gi, always))
+    assert len(groups) == keep_n and always[0] in groups
+    want_cols = np.concatenate([np.arange(gi[g], gi[g] + sizes[g]) for g in groups])
+    assert np.array_equal(cols, want_cols)
+    # the oracle on the kept columns with the kept group index and the re-ranked always_select
+    new_gi = np.concatenate([[0], np.cumsum(sizes[groups])[:-1]]).astype(np.int32)
+    al = [int(np.searchsorted(groups, always[0]))]
+    want = P.trace(X[:, cols], y, algorithm_type=2, g_index=new_gi, ic_type=3, sequence=np.arange(2, 6),
+                   always_select=al)
+    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="grouped screening")
+    full = np.zeros(p)
+    full[cols] = want["beta"]
+    np.testing.assert_allclose(got["beta"], full, rtol=1e-6, atol=1e-12)  # the right columns of the ORIGINAL numbering
+    # the R-facing entry reports the kept groups as screening_A
+    r = gpu.bessCpp(X, y, 1, np.ones(n), True, 2, 1, 20, 2, 1, True, 3, False, 5, np.full(10, 2.0), np.arange(2, 6), [0.0],
+                    1, 1, 10, 10.0, 0.0, 0.0, 100, True, keep_n, 1, gi, always, 1.1)
+    assert np.array_equal(r["screening_A"], groups)
+    np.testing.assert_allclose(r["beta"], full, rtol=1e-6, atol=1e-12)
