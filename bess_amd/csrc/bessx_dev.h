@@ -226,6 +226,12 @@ hipError_t launch_iota(int *a, int n, hipStream_t st);
 hipError_t launch_group_lsq_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
                                   const double *dcol, const unsigned char *always, double *work, double *zwork,
                                   double *score, hipStream_t st);
+// screening with groups, logistic: per-group IRLS (groups of at most 8 columns)
+bool screen_logit_group_supported(int gmax);
+size_t screen_logit_group_state_doubles(int N);
+hipError_t launch_screen_logit_group(const double *X, long ld, int n, int N, const int *gidx, const int *gsz,
+                                     const double *y, const double *w, double *state, int *done,
+                                     const unsigned char *always, double *score, hipStream_t st);
 hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxBufs cb, const int *allcols, int mcols,
                                     int smax, int N, const int *gidx_h, const int *gsz_h, const int *gidx,
                                     const int *gsz, const int *goff, long mblk_len, double *mblk, double *mblk2,

@@ -2608,8 +2608,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     // screening(), src/screening.cpp:26-105, before anything else touches the data (src/bess.cpp:57-61)
     const int pf = pb->p, ss = pb->screening_size;
     const bool gscr = pb->group_index && pb->group_index_len > 0 && pb->group_index_len != pf;
-    if (gscr && pb->model_type != 1)
-      return bail(fail(BESSX_ERR_UNSUPPORTED, "screening with groups of size > 1 is built for the linear model only"));
+    if (gscr && pb->model_type != 1 && pb->model_type != 2)
+      return bail(fail(BESSX_ERR_UNSUPPORTED, "screening with groups of size > 1 is built for the linear and the "
+                                              "logistic model (Cox: singleton groups; Poisson: not at all)"));
     if (gscr) {
       // groups of the original columns (Data::g_index semantics); screening_size and always_select count GROUPS
       const int Ng = pb->group_index_len;
@@ -2704,10 +2705,25 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       if (e == hipSuccess) e = hipMemcpy(gd + Ng, g_sz.data(), (size_t)Ng * sizeof(int), hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMemcpy(gd + 2 * Ng, g_off.data(), ((size_t)Ng + 1) * sizeof(int), hipMemcpyHostToDevice);
       double *mblk = gm, *mwork = gm + g_off[Ng], *dcol = gm + 2 * (size_t)g_off[Ng], *zw = dcol + pf;
-      if (e == hipSuccess)
-        e = launch_group_moments(gmax, Xraw, ld, n, nullptr, yw, Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, s->st);
-      if (e == hipSuccess)
-        e = launch_group_lsq_score(Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, fl_d, mwork, zw, score, s->st);
+      if (pb->model_type == 1) {
+        if (e == hipSuccess)
+          e = launch_group_moments(gmax, Xraw, ld, n, nullptr, yw, Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, s->st);
+        if (e == hipSuccess)
+          e = launch_group_lsq_score(Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, fl_d, mwork, zw, score, s->st);
+      } else {
+        // logit_fit on the columns of a group (src/logistic.cpp:60-160)
+        if (!screen_logit_group_supported(gmax)) {
+          gdrop();
+          drop();
+          return bail(fail(BESSX_ERR_UNSUPPORTED, "logistic screening: groups of more than 8 columns are not built"));
+        }
+        double *gstate = nullptr;
+        if (e == hipSuccess) e = dmalloc(&gstate, screen_logit_group_state_doubles(Ng));
+        if (e == hipSuccess)
+          e = launch_screen_logit_group(Xraw, ld, n, Ng, gd, gd + Ng, yw, yw + ld, gstate, done, fl_d, score, s->st);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+        (void)hipFree(gstate);
+      }
       if (e == hipSuccess) e = hipStreamSynchronize(s->st);
       gdrop();
       if (e != hipSuccess) {

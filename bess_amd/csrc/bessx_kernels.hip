@@ -4368,6 +4368,117 @@ __global__ void __launch_bounds__(256) k_screen_score_logit(const double *__rest
   score[j] = (always != nullptr && always[j]) ? DBL_MAX : ((v <= DBL_MAX) ? v : 0.0);
 }
 
+// Screening with groups, logistic (logit_fit, src/logistic.cpp:60-160, on the columns of one group): IRLS on [1, X_g]
+// from zero, no floor on the weights, stop when |ll0 - ll1| / (0.1 + |ll1|) < 1e-6, at most 1 + 30 solves, result =
+// the iterate BEFORE the last solve.  One block per group and IRLS step (like k_screen_logit_pass for single columns):
+// the block forms X^T W X (lower triangle, intercept first), X^T W z and the log-likelihood of the current iterate in
+// registers over the rows, thread 0 applies the stopping rule and solves the (s + 1) x (s + 1) system (LDL^T).
+// Groups of at most SGL_MAX columns.  state per group: beta0[SGL_MAX + 1], beta1[SGL_MAX + 1], ll0.
+constexpr int SGL_MAX = 8;
+constexpr int SGL_ST = 2 * (SGL_MAX + 1) + 1;
+__global__ void __launch_bounds__(256) k_screen_logit_group(const double *__restrict__ X, long ld, int n,
+                                                            const double *__restrict__ y, const double *__restrict__ w,
+                                                            const int *__restrict__ gidx, const int *__restrict__ gsz,
+                                                            int t, double *__restrict__ state, int *__restrict__ done) {
+  constexpr int M = SGL_MAX + 1, NT = M * (M + 1) / 2;
+  const int g = blockIdx.x;
+  if (done[g]) return;
+  __shared__ double sm[4];
+  __shared__ double bsh[M];
+  const int s = gsz[g], m = s + 1;
+  double *st = state + (size_t)g * SGL_ST;
+  const double *x = X + (size_t)gidx[g] * ld;
+  if (threadIdx.x < M) bsh[threadIdx.x] = threadIdx.x < m ? (t == 0 ? st[threadIdx.x] : st[M + threadIdx.x]) : 0.0;
+  __syncthreads();
+  double S[NT], tv[M], ll = 0.0;
+#pragma unroll
+  for (int a = 0; a < NT; a++) S[a] = 0.0;
+#pragma unroll
+  for (int a = 0; a < M; a++) tv[a] = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double v[M];
+    v[0] = 1.0;
+    double eta = bsh[0];
+#pragma unroll
+    for (int u = 1; u < M; u++) {
+      v[u] = u < m ? x[(size_t)(u - 1) * ld + i] : 0.0;
+      eta = fma(v[u], bsh[u], eta);
+    }
+    const double yi = y[i], wi = w[i];
+    const double e = exp(clampv(eta, 30.0)), Pi = e / (1.0 + e);
+    ll += (yi * log(Pi) + (1.0 - yi) * log(1.0 - Pi)) * wi;
+    double W = Pi * (1.0 - Pi);
+    const double z = eta + (yi - Pi) / W;
+    W = W * wi;
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < M; a++) {
+      const double wa = W * v[a];
+      tv[a] = fma(wa, z, tv[a]);
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        S[q] = fma(wa, v[b], S[q]);
+        q++;
+      }
+    }
+  }
+  ll = block_sum_256(ll, sm);
+#pragma unroll
+  for (int a = 0; a < NT; a++) S[a] = block_sum_256(S[a], sm);
+#pragma unroll
+  for (int a = 0; a < M; a++) tv[a] = block_sum_256(tv[a], sm);
+  if (threadIdx.x == 0) {
+    if (t == 0) {
+      st[2 * M] = ll;
+    } else {
+      if (fabs(st[2 * M] - ll) / (0.1 + fabs(ll)) < 1e-6) {
+        done[g] = 1;  // result: beta0, the iterate before the last solve
+        return;
+      }
+      for (int a = 0; a < m; a++) st[a] = st[M + a];
+      st[2 * M] = ll;
+    }
+    // (s + 1) x (s + 1) solve, un-pivoted LDL^T on the lower triangle S[a (a + 1) / 2 + b]
+    double L[M][M], D[M], xs[M];
+    for (int j = 0; j < m; j++) {
+      double dj = S[j * (j + 1) / 2 + j];
+      for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k] * D[k];
+      D[j] = dj;
+      for (int i = j + 1; i < m; i++) {
+        double v = S[i * (i + 1) / 2 + j];
+        for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
+        L[i][j] = v / dj;
+      }
+    }
+    for (int i = 0; i < m; i++) {
+      double v = tv[i];
+      for (int k = 0; k < i; k++) v -= L[i][k] * xs[k];
+      xs[i] = v;
+    }
+    for (int i = 0; i < m; i++) xs[i] = xs[i] / D[i];
+    for (int i = m - 1; i >= 0; i--) {
+      double v = xs[i];
+      for (int k = i + 1; k < m; k++) v -= L[k][i] * xs[k];
+      xs[i] = v;
+    }
+    for (int a = 0; a < m; a++) st[M + a] = xs[a];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_screen_score_logit_group(const double *__restrict__ state, int N,
+                                                                  const int *__restrict__ gsz,
+                                                                  const unsigned char *__restrict__ always,
+                                                                  double *__restrict__ score) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= N) return;
+  const double *st = state + (size_t)g * SGL_ST;
+  const int s = gsz[g];
+  double acc = 0.0;
+  for (int u = 1; u <= s; u++) acc += st[u] * st[u];
+  const double v = acc / (double)s;  // coef_norm, src/screening.cpp:60
+  score[g] = (always != nullptr && always[g]) ? DBL_MAX : ((v <= DBL_MAX) ? v : 0.0);
+}
+
 // Cox marginal fit, cox_fit (src/coxph.cpp:97-172) on one column: the whole damped Newton loop of a column runs in
 // one block; the risk-set sums are block scans over the rows taken from the last (rows are sorted by time).
 __device__ __forceinline__ double wave_scan_incl(double v) {
@@ -6347,6 +6458,24 @@ hipError_t launch_screen_logit(const double *X, long ld, int n, int p, const dou
   }
   hipLaunchKernelGGL(k_screen_score_logit, dim3((p + 255) / 256), dim3(256), 0, st, (const double *)state, p, always,
                      score);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+bool screen_logit_group_supported(int gmax) { return gmax <= SGL_MAX; }
+size_t screen_logit_group_state_doubles(int N) { return (size_t)N * SGL_ST; }
+hipError_t launch_screen_logit_group(const double *X, long ld, int n, int N, const int *gidx, const int *gsz,
+                                     const double *y, const double *w, double *state, int *done,
+                                     const unsigned char *always, double *score, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(state, 0, (size_t)N * SGL_ST * sizeof(double), st);
+  if (e == hipSuccess) e = hipMemsetAsync(done, 0, (size_t)N * sizeof(int), st);
+  if (e != hipSuccess) return e;
+  for (int t = 0; t <= 30; t++) {  // the solve before the loop + 30 loop iterations (src/logistic.cpp:135-155)
+    hipLaunchKernelGGL(k_screen_logit_group, dim3(N), dim3(256), 0, st, X, ld, n, y, w, gidx, gsz, t, state, done);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_screen_score_logit_group, dim3((N + 255) / 256), dim3(256), 0, st, (const double *)state, N, gsz,
+                     always, score);
   LAUNCH_CHECK();
   return hipSuccess;
 }

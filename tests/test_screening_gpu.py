@@ -71,9 +71,10 @@ def test_screening_argument_errors(gpu):
     with pytest.raises(gpu.BessxError) as e:  # Poisson: undefined behaviour in the reference, refused here
         gpu.Session(X, np.abs(np.round(y)), data_type=2, model_type=3, is_screening=True, screening_size=10)
     assert e.value.code == 3
-    with pytest.raises(gpu.BessxError) as e:  # groups of size > 1: linear model only
-        gpu.Session(X, (y > 0).astype(float), data_type=2, model_type=2, algorithm_type=2, is_screening=True,
-                    screening_size=2, g_index=[0, 5, 10])
+    Xc, _, st, _, _ = synth.make_cox(200, 50, 3)
+    with pytest.raises(gpu.BessxError) as e:  # groups of size > 1: linear and logistic model only
+        gpu.Session(Xc, st, data_type=3, model_type=4, algorithm_type=2, is_screening=True, screening_size=2,
+                    g_index=[0, 5, 10])
     assert e.value.code == 3
 
 
@@ -122,3 +123,30 @@ def test_lm_screening_with_groups(gpu, wide):
                     1, 1, 10, 10.0, 0.0, 0.0, 100, True, keep_n, 1, gi, always, 1.1)
     assert np.array_equal(r["screening_A"], groups)
     np.testing.assert_allclose(r["beta"], full, rtol=1e-6, atol=1e-12)
+
+
+def test_logistic_screening_with_groups(gpu):
+    """logit_fit on whole groups (src/logistic.cpp:60-160; groups of at most 8 columns): kept groups = the compiled
+    reference's, then the path on the kept columns like the oracle's on that sub-matrix."""
+    from oracle import ref_ctypes as R
+    n, p = 900, 120
+    X, y, _, _ = synth.make_logistic(n, p, 6, seed=23)
+    gi = _group_index(p, 9)
+    N, keep_n = len(gi), len(gi) // 2
+    sizes = np.diff(np.append(gi, p))
+    kw = dict(data_type=2, model_type=2, algorithm_type=2)
+    with gpu.Session(X, y, g_index=gi, is_screening=True, screening_size=keep_n, **kw) as s:
+        groups, cols = s.screening_groups(), s.screening()
+        s.trace_enable(True)
+        got = s.sequential_path(np.arange(1, 5), ic_type=3)
+    if R.available():
+        assert np.array_equal(groups, R.screening_groups(X, y, None, 2, keep_n, gi))
+    new_gi = np.concatenate([[0], np.cumsum(sizes[groups])[:-1]]).astype(np.int32)
+    want = P.trace(X[:, cols], y, g_index=new_gi, ic_type=3, sequence=np.arange(1, 5), **kw)
+    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="grouped logistic screening")
+    full = np.zeros(p)
+    full[cols] = want["beta"]
+    np.testing.assert_allclose(got["beta"], full, rtol=1e-6, atol=1e-12)
+    with pytest.raises(gpu.BessxError) as e:  # wider groups: refused for the logistic marginal fits
+        gpu.Session(X, y, g_index=[0, 20, 60], is_screening=True, screening_size=2, **kw)
+    assert e.value.code == 3
