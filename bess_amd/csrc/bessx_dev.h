@@ -232,6 +232,11 @@ size_t screen_logit_group_state_doubles(int N);
 hipError_t launch_screen_logit_group(const double *X, long ld, int n, int N, const int *gidx, const int *gsz,
                                      const double *y, const double *w, double *state, int *done,
                                      const unsigned char *always, double *score, hipStream_t st);
+// screening with groups, Cox: per-group damped Newton (groups of at most 4 columns)
+bool screen_cox_group_supported(int gmax);
+hipError_t launch_screen_cox_group(const double *X, long ld, int n, int N, const int *gidx, const int *gsz,
+                                   const double *st_, const double *w, const unsigned char *always, double *score,
+                                   hipStream_t st);
 hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxBufs cb, const int *allcols, int mcols,
                                     int smax, int N, const int *gidx_h, const int *gsz_h, const int *gidx,
                                     const int *gsz, const int *goff, long mblk_len, double *mblk, double *mblk2,

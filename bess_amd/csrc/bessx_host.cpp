@@ -2608,9 +2608,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     // screening(), src/screening.cpp:26-105, before anything else touches the data (src/bess.cpp:57-61)
     const int pf = pb->p, ss = pb->screening_size;
     const bool gscr = pb->group_index && pb->group_index_len > 0 && pb->group_index_len != pf;
-    if (gscr && pb->model_type != 1 && pb->model_type != 2)
-      return bail(fail(BESSX_ERR_UNSUPPORTED, "screening with groups of size > 1 is built for the linear and the "
-                                              "logistic model (Cox: singleton groups; Poisson: not at all)"));
+    // (Poisson is refused below, with or without groups)
     if (gscr) {
       // groups of the original columns (Data::g_index semantics); screening_size and always_select count GROUPS
       const int Ng = pb->group_index_len;
@@ -2710,6 +2708,15 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
           e = launch_group_moments(gmax, Xraw, ld, n, nullptr, yw, Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, s->st);
         if (e == hipSuccess)
           e = launch_group_lsq_score(Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, fl_d, mwork, zw, score, s->st);
+      } else if (pb->model_type == 4) {
+        // cox_fit on the columns of a group (src/coxph.cpp:42-108)
+        if (!screen_cox_group_supported(gmax)) {
+          gdrop();
+          drop();
+          return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox screening: groups of more than 4 columns are not built"));
+        }
+        if (e == hipSuccess)
+          e = launch_screen_cox_group(Xraw, ld, n, Ng, gd, gd + Ng, yw, yw + ld, fl_d, score, s->st);
       } else {
         // logit_fit on the columns of a group (src/logistic.cpp:60-160)
         if (!screen_logit_group_supported(gmax)) {

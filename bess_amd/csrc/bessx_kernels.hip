@@ -4516,6 +4516,179 @@ __device__ double screen_cox_ll(const double *__restrict__ x, const double *__re
   return s;
 }
 
+// Screening with groups, Cox (cox_fit, src/coxph.cpp:42-108, on the columns of one group): the damped Newton loop of
+// k_screen_cox with an s-vector gradient and an s x s information matrix -- one block per group, the risk-set sums
+// S0, S1_u, S2_uv as 1 + s + s (s + 1) / 2 block scans over the rows taken from the last (rows are sorted by time).
+// Groups of at most SCG_MAX columns.
+constexpr int SCG_MAX = 4;
+constexpr int SCG_NS = 1 + SCG_MAX + SCG_MAX * (SCG_MAX + 1) / 2;
+
+__device__ double screen_cox_ll_group(const double *__restrict__ x, long ld, int s, const double *__restrict__ st,
+                                      const double *__restrict__ w, int n, const double *b, double *sm /*>=8*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double carry = 0.0, acc = 0.0;
+  for (int base = 0; base < n; base += 256) {
+    const int r = base + threadIdx.x, i = n - 1 - r;
+    double eta = 0.0;
+#pragma unroll
+    for (int u = 0; u < SCG_MAX; u++)
+      if (u < s && r < n) eta = fma(x[(size_t)u * ld + i], b[u], eta);
+    const double e = r < n ? exp(clampv(eta, 30.0)) : 0.0;
+    double c = wave_scan_incl(e);
+    if (lane == 63) sm[wv] = c;
+    __syncthreads();
+    double pre = carry;
+    for (int q = 0; q < wv; q++) pre += sm[q];
+    carry += ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    c += pre;
+    if (r < n) acc += (log(e / c) * st[i]) * w[i];
+    __syncthreads();
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) sm[4] = acc;
+  __syncthreads();
+  acc = sm[4];
+  __syncthreads();
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) k_screen_cox_group(const double *__restrict__ X, long ld, int n,
+                                                          const double *__restrict__ st, const double *__restrict__ w,
+                                                          const int *__restrict__ gidx, const int *__restrict__ gsz,
+                                                          const unsigned char *__restrict__ always,
+                                                          double *__restrict__ score) {
+  const int g = blockIdx.x;
+  if (always != nullptr && always[g]) {
+    if (threadIdx.x == 0) score[g] = DBL_MAX;
+    return;
+  }
+  __shared__ double sm[4 * SCG_NS + 16];
+  __shared__ double dsh[SCG_MAX];
+  const int s = gsz[g];
+  const double *x = X + (size_t)gidx[g] * ld;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double b0[SCG_MAX], b1[SCG_MAX], ll0 = 1e5;
+#pragma unroll
+  for (int u = 0; u < SCG_MAX; u++) b0[u] = 0.0;
+  for (int l = 1; l <= 30; l++) {
+    double carry[SCG_NS], gr[SCG_MAX], H[SCG_MAX * (SCG_MAX + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < SCG_NS; k++) carry[k] = 0.0;
+#pragma unroll
+    for (int u = 0; u < SCG_MAX; u++) gr[u] = 0.0;
+#pragma unroll
+    for (int k = 0; k < SCG_MAX * (SCG_MAX + 1) / 2; k++) H[k] = 0.0;
+    for (int base = 0; base < n; base += 256) {
+      const int r = base + threadIdx.x, i = n - 1 - r;
+      double xi[SCG_MAX], eta = 0.0;
+#pragma unroll
+      for (int u = 0; u < SCG_MAX; u++) {
+        xi[u] = (u < s && r < n) ? x[(size_t)u * ld + i] : 0.0;
+        eta = fma(xi[u], b0[u], eta);
+      }
+      const double th = r < n ? exp(clampv(eta, 50.0)) : 0.0;
+      double a[SCG_NS];
+      a[0] = th;
+      int q = 1 + SCG_MAX;
+#pragma unroll
+      for (int u = 0; u < SCG_MAX; u++) {
+        a[1 + u] = th * xi[u];
+#pragma unroll
+        for (int v = 0; v <= u; v++) {
+          a[q] = (th * xi[u]) * xi[v];
+          q++;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < SCG_NS; k++) {
+        a[k] = wave_scan_incl(a[k]);
+        if (lane == 63) sm[4 * k + wv] = a[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < SCG_NS; k++) {
+        double pre = carry[k];
+        for (int w4 = 0; w4 < wv; w4++) pre += sm[4 * k + w4];
+        carry[k] += ((sm[4 * k] + sm[4 * k + 1]) + sm[4 * k + 2]) + sm[4 * k + 3];
+        a[k] += pre;
+      }
+      if (r < n) {
+        const double ws = w[i] * st[i], r0 = 1.0 / a[0];
+        double q1[SCG_MAX];
+        int qq = 1 + SCG_MAX, hk = 0;
+#pragma unroll
+        for (int u = 0; u < SCG_MAX; u++) {
+          q1[u] = a[1 + u] * r0;
+          gr[u] += (xi[u] - q1[u]) * ws;
+#pragma unroll
+          for (int v = 0; v <= u; v++) {
+            H[hk] += (a[qq] * r0 - q1[u] * q1[v]) * ws;
+            hk++;
+            qq++;
+          }
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < SCG_MAX; u++) gr[u] = block_sum_256(gr[u], sm);
+#pragma unroll
+    for (int k = 0; k < SCG_MAX * (SCG_MAX + 1) / 2; k++) H[k] = block_sum_256(H[k], sm);
+    if (threadIdx.x == 0) {
+      // d = h^{-1} g with h = -H (src/coxph.cpp:85-91): H x = g by an un-pivoted LDL^T, d = -x
+      double L[SCG_MAX][SCG_MAX], D[SCG_MAX], xs[SCG_MAX];
+      for (int j = 0; j < s; j++) {
+        double dj = H[j * (j + 1) / 2 + j];
+        for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k] * D[k];
+        D[j] = dj;
+        for (int i = j + 1; i < s; i++) {
+          double v = H[i * (i + 1) / 2 + j];
+          for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
+          L[i][j] = v / dj;
+        }
+      }
+      for (int i = 0; i < s; i++) {
+        double v = gr[i];
+        for (int k = 0; k < i; k++) v -= L[i][k] * xs[k];
+        xs[i] = v;
+      }
+      for (int i = 0; i < s; i++) xs[i] = xs[i] / D[i];
+      for (int i = s - 1; i >= 0; i--) {
+        double v = xs[i];
+        for (int k = i + 1; k < s; k++) v -= L[k][i] * xs[k];
+        xs[i] = v;
+      }
+      for (int u = 0; u < SCG_MAX; u++) dsh[u] = u < s ? -xs[u] : 0.0;
+    }
+    __syncthreads();
+    double d[SCG_MAX];
+#pragma unroll
+    for (int u = 0; u < SCG_MAX; u++) d[u] = dsh[u];
+    __syncthreads();
+    int m = 1;
+#pragma unroll
+    for (int u = 0; u < SCG_MAX; u++) b1[u] = b0[u] - 0.5 * d[u];
+    double ll1 = screen_cox_ll_group(x, ld, s, st, w, n, b1, sm);
+    while (ll0 > ll1 && m < 5) {
+      m = m + 1;
+      const double f = pow(0.5, (double)m);
+#pragma unroll
+      for (int u = 0; u < SCG_MAX; u++) b1[u] = b0[u] - f * d[u];
+      ll1 = screen_cox_ll_group(x, ld, s, st, w, n, b1, sm);
+    }
+    if (fabs(ll0 - ll1) / fabs(0.1 + ll0) < 1e-5) break;
+#pragma unroll
+    for (int u = 0; u < SCG_MAX; u++) b0[u] = b1[u];
+    ll0 = ll1;
+  }
+  if (threadIdx.x == 0) {
+    double acc = 0.0;
+    for (int u = 0; u < s; u++) acc += b0[u] * b0[u];
+    const double v = acc / (double)s;
+    score[g] = (v <= DBL_MAX) ? v : 0.0;  // non-finite (degenerate group) -> ranks last
+  }
+}
+
 __global__ void __launch_bounds__(256) k_screen_cox(const double *__restrict__ X, long ld, int n,
                                                     const double *__restrict__ st, const double *__restrict__ w,
                                                     const unsigned char *__restrict__ always,
@@ -6483,6 +6656,15 @@ hipError_t launch_screen_logit_group(const double *X, long ld, int n, int N, con
 hipError_t launch_screen_cox(const double *X, long ld, int n, int p, const double *st_, const double *w,
                              const unsigned char *always, double *score, hipStream_t st) {
   hipLaunchKernelGGL(k_screen_cox, dim3(p), dim3(256), 0, st, X, ld, n, st_, w, always, score);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+bool screen_cox_group_supported(int gmax) { return gmax <= SCG_MAX; }
+hipError_t launch_screen_cox_group(const double *X, long ld, int n, int N, const int *gidx, const int *gsz,
+                                   const double *st_, const double *w, const unsigned char *always, double *score,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(k_screen_cox_group, dim3(N), dim3(256), 0, st, X, ld, n, st_, w, gidx, gsz, always, score);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -121,12 +121,14 @@ typedef struct {
   int group_index_len;
   int is_screening;   /* sure independence screening before the path (screening(), src/screening.cpp:26-105; called at
                          src/bess.cpp:57-61): keep the screening_size columns with the largest squared marginal
-                         coefficient on the raw data plus always_select.  LM, logistic and Cox with singleton
-                         groups; LM also with groups of size > 1 (screening_size and always_select then count / name
-                         GROUPS; the marginal fit is the least-squares fit on the whole group; the coefficients are
-                         written to the columns they belong to -- the reference misplaces them in this case,
-                         src/bess.cpp:195-198).  Poisson is refused (the reference's poisson_fit is undefined behaviour
-                         there, src/poisson.cpp:113), and so are logistic / Cox with groups of size > 1.  The session then lives on the kept columns: sparsity levels, traces,
+                         coefficient on the raw data plus always_select.  LM, logistic and Cox; with groups of
+                         size > 1 (LM any width, logistic at most 8, Cox at most 4 columns per group) screening_size
+                         and always_select count / name GROUPS, the marginal fit is the model's fit on the whole
+                         group, and the coefficients are written to the columns they belong to -- the reference
+                         misplaces them in this case, src/bess.cpp:195-198.  Poisson is refused (the reference's
+                         poisson_fit is undefined behaviour there, src/poisson.cpp:113), and so are wider logistic /
+                         Cox groups.
+                         The session then lives on the kept columns: sparsity levels, traces,
                          bessx_session_fit and bessx_session_get_normalization index them 0..screening_size-1
                          (bessx_session_get_screening gives the map); every bessx_path_result is written in the
                          ORIGINAL column numbering, like src/bess.cpp:186-209. */
@@ -148,7 +150,7 @@ void bessx_session_destroy(bessx_session *s);
 /* screening_A of src/screening.cpp:68: original column of every kept column (ascending).  Returns the number of
  * kept columns (= p when the session was created without screening, map = identity); writes min(count, cap). */
 int bessx_session_get_screening(const bessx_session *s, int *columns, int cap);
-/* Screening with groups of size > 1 (linear model): the kept ORIGINAL group numbers (ascending) = screening_A of the
+/* Screening with groups of size > 1: the kept ORIGINAL group numbers (ascending) = screening_A of the
  * reference for that case; 0 when the session was not screened by groups.  Returns the count, writes min(count, cap). */
 int bessx_session_get_screening_groups(const bessx_session *s, int *groups, int cap);
 /* 1 = streaming score pass, 2 = covariance updates: what bessx_problem.score_mode resolved to for this session. */

@@ -72,7 +72,7 @@ def test_screening_argument_errors(gpu):
         gpu.Session(X, np.abs(np.round(y)), data_type=2, model_type=3, is_screening=True, screening_size=10)
     assert e.value.code == 3
     Xc, _, st, _, _ = synth.make_cox(200, 50, 3)
-    with pytest.raises(gpu.BessxError) as e:  # groups of size > 1: linear and logistic model only
+    with pytest.raises(gpu.BessxError) as e:  # Cox marginal fits: groups of at most 4 columns
         gpu.Session(Xc, st, data_type=3, model_type=4, algorithm_type=2, is_screening=True, screening_size=2,
                     g_index=[0, 5, 10])
     assert e.value.code == 3
@@ -150,3 +150,30 @@ def test_logistic_screening_with_groups(gpu):
     with pytest.raises(gpu.BessxError) as e:  # wider groups: refused for the logistic marginal fits
         gpu.Session(X, y, g_index=[0, 20, 60], is_screening=True, screening_size=2, **kw)
     assert e.value.code == 3
+
+
+def test_cox_screening_with_groups(gpu):
+    """cox_fit on whole groups (src/coxph.cpp:42-108; groups of at most 4 columns): kept groups = the compiled
+    reference's, then the path on the kept columns like the oracle's on that sub-matrix."""
+    from oracle import ref_ctypes as R
+    n, p = 600, 90
+    X, _, st, _, _ = synth.make_cox(n, p, 5, seed=31)
+    gi = _group_index(p, 13)
+    N, keep_n = len(gi), len(gi) // 2
+    sizes = np.diff(np.append(gi, p))
+    always = [int(N - 1)]
+    kw = dict(data_type=3, model_type=4, algorithm_type=2)
+    with gpu.Session(X, st, g_index=gi, is_screening=True, screening_size=keep_n, always_select=always, **kw) as s:
+        groups, cols = s.screening_groups(), s.screening()
+        s.trace_enable(True)
+        got = s.sequential_path(np.arange(2, 5), ic_type=3)
+    if R.available():
+        assert np.array_equal(groups, R.screening_groups(X, st, None, 4, keep_n, gi, always))
+    assert len(groups) == keep_n and always[0] in groups
+    new_gi = np.concatenate([[0], np.cumsum(sizes[groups])[:-1]]).astype(np.int32)
+    al = [int(np.searchsorted(groups, always[0]))]
+    want = P.trace(X[:, cols], st, g_index=new_gi, ic_type=3, sequence=np.arange(2, 5), always_select=al, **kw)
+    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="grouped Cox screening")
+    full = np.zeros(p)
+    full[cols] = want["beta"]
+    np.testing.assert_allclose(got["beta"], full, rtol=1e-6, atol=1e-12)
