@@ -147,6 +147,7 @@ struct CholFuse {
   const double *d;     // X^T (m r) of the current coefficients (start value of entering columns, k_cg)
   const double *GS;    // slot-indexed Gram of the cached columns (CS x CS), or nullptr (k_cgr gathers from it)
   int CS;
+  const double *zero;  // a word that holds 0.0 (what k_cgr reads for matrix columns outside its system)
   PubArgs pub;         // pub.on: this launch closes a batch of slots and publishes the result block (k_cg / k_cgr)
 };
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,

@@ -152,6 +152,7 @@ struct bessx_session {
     double *H = nullptr;
     int *hact = nullptr, *hmeta = nullptr;
     double *hinfo = nullptr;
+    double *zero = nullptr;  // a few words that hold 0.0 (CholFuse::zero)
     bool shares_map = false;  // slot_of / meta are row set 0's (shared fills: every row set caches the same columns)
   };
   std::vector<CovCache> cov;
@@ -365,6 +366,7 @@ static void session_free(bessx_session *s) {
     F(c.hact);
     F(c.hmeta);
     F(c.hinfo);
+    F(c.zero);
   }
   F(s->cov_part);
   F(s->bd2);
@@ -500,6 +502,8 @@ static int alloc_cov_cache(bessx_session *s, bool share_map = false) {
   if (e == hipSuccess) e = hipMemset(c.hact, 0, (size_t)COV_CS * sizeof(int));
   if (e == hipSuccess) e = hipMemset(c.hmeta, 0, 4 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(c.hinfo, 0xff, 2 * sizeof(double));  // NaN: no ridge seen yet
+  if (e == hipSuccess) e = dmalloc(&c.zero, 8);
+  if (e == hipSuccess) e = hipMemset(c.zero, 0, 8 * sizeof(double));
   if (e != hipSuccess) {
     (void)hipFree(c.G);
     if (!c.shares_map) {
@@ -511,6 +515,7 @@ static int alloc_cov_cache(bessx_session *s, bool share_map = false) {
     (void)hipFree(c.hact);
     (void)hipFree(c.hmeta);
     (void)hipFree(c.hinfo);
+    (void)hipFree(c.zero);
     return fail(BESSX_ERR_HIP, std::string("Gram column cache: ") + hipGetErrorString(e));
   }
   s->cov.push_back(c);
@@ -850,7 +855,8 @@ static CholFuse cov_fuse_args(bessx_session *s, int rs, int T0, bool force_chol,
   bessx_session::CovCache &cv = s->cov[rs];
   CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
                  s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
-                 s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, s->cov_cs, PubArgs{}};
+                 s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, s->cov_cs,
+                 cv.zero, PubArgs{}};
   // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
   if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
     fz.pub = *sf->pub;
@@ -3219,6 +3225,7 @@ static void drop_folds(bessx_session *s) {
     (void)hipFree(s->cov[i].hact);
     (void)hipFree(s->cov[i].hmeta);
     (void)hipFree(s->cov[i].hinfo);
+    (void)hipFree(s->cov[i].zero);
   }
   if (!s->cov.empty()) s->cov.resize(1);
   if (!s->n_train.empty()) s->n_train.resize(1);

@@ -1647,8 +1647,26 @@ __device__ unsigned long long g_cg_prof[16];
       tprev_ = now_;                                                   \
     }                                                                  \
   } while (0)
+// inside the loop: accumulated in registers of thread 0 (an atomic per stamp would be waited for by the next one)
+#define CGL_DECL() unsigned long long lacc_[4] = {0ull, 0ull, 0ull, 0ull}
+#define CGL(i)                                        \
+  do {                                                \
+    if (threadIdx.x == 0) {                           \
+      unsigned long long now_ = wall_clock64();       \
+      lacc_[i] += now_ - tprev_;                      \
+      tprev_ = now_;                                  \
+    }                                                 \
+  } while (0)
+#define CGL_FLUSH()                                                        \
+  do {                                                                     \
+    if (threadIdx.x == 0)                                                  \
+      for (int q_ = 0; q_ < 4; q_++) atomicAdd(&g_cg_prof[7 + q_], lacc_[q_]); \
+  } while (0)
 #else
 #define CGP(i)
+#define CGL_DECL()
+#define CGL(i)
+#define CGL_FLUSH()
 #endif
 template <int CH_SLOTS, int NW>
 __device__ __forceinline__ void cg_body(int m, int mt, double ridge, const double *__restrict__ rhs,
@@ -1932,12 +1950,15 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
   __shared__ double part[8][R];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int off_gs = 0;  // a column of this system outside the slot-indexed copy GS?
   for (int i = tid; i < R; i += 512) {
     const int a = i < m ? A_new[i] : 0;
+    const int sl = i < m ? fz.slot_of[a] : 0;
     sA[i] = a;
-    sS[i] = i < m ? fz.slot_of[a] : 0;
+    sS[i] = sl;
+    off_gs |= (sl < 0 || sl >= fz.CS) ? 1 : 0;
   }
-  __syncthreads();
+  const bool all_gs = !__syncthreads_or(off_gs) && fz.GS != nullptr;  // uniform
   CGP(0);
   const int c0 = wave * nc;
   // right-hand side, warm start (previous coefficients of the columns that stay; a column that enters starts from
@@ -1956,33 +1977,68 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
     x0[r] = (own && bv == 0.0 && fz.d != nullptr && sl >= 0) ? dv / (gv + ridge) : bv;
   }
   double g[RPT][NCW];
-#pragma unroll
-  for (int c = 0; c < NCW; c++) {
-    const int col = c0 + c;
-    const bool cok = c < nc && col < m;
-    const int sl = cok ? sS[col] : 0;  // wave-uniform
-    if (cok && sl < 0) fz.ctrl->cov_miss = 1;
-    const double *gcol = fz.G + (size_t)(sl < 0 ? 0 : sl) * fz.p;
-    const bool small = fz.GS != nullptr && sl < fz.CS;  // uniform
+  {
+    // every index this thread needs first (LDS), then all the loads back to back: an index read or a branch between
+    // two loads would put an LDS / branch latency in front of every one of them
+    int srr[RPT], saa[RPT], slv[NCW];
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
       const int row = lane + 64 * r;
-      double v = 0.0;
-      if (cok && sl >= 0 && row < m) {
-        const int sr = sS[row];
-        // both slots inside the slot-indexed copy (L2-resident, neighbouring rows share lines): read it from there
-        v = (small && sr >= 0 && sr < fz.CS) ? fz.GS[(size_t)sl * fz.CS + sr] : gcol[sA[row]];
+      srr[r] = row < m ? sS[row] : -1;
+      saa[r] = row < m ? sA[row] : -1;
+    }
+#pragma unroll
+    for (int c = 0; c < NCW; c++) slv[c] = sS[min(c0 + c, R - 1)];
+    if (all_gs) {
+      // the usual case: every column inside the slot-indexed copy GS.  One base per column, one index per row, and no
+      // zeroing behind the loads (a value that is only needed under a uniform condition gets its load sunk into a
+      // branch, with a wait behind every load -- 13 us of gather instead of 4): columns outside the system read a word
+      // that holds 0.0, rows outside it read some finite Gram entry and are dropped from the products (matvec_pv)
+      int rs_[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; r++) rs_[r] = max(srr[r], 0);
+#pragma unroll
+      for (int c = 0; c < NCW; c++) {
+        const bool cok = c < nc && c0 + c < m;
+        const double *colb = cok ? fz.GS + (size_t)slv[c] * fz.CS : fz.zero;  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < RPT; r++) g[r][c] = colb[cok ? rs_[r] : 0];
       }
-      g[r][c] = v;
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCW; c++) {
+        const int col = c0 + c;
+        const bool cok = c < nc && col < m;
+        // (kept in a vector register: with readfirstlane on these NCW uniform values the kernel had 210 scalar-register
+        // spills and that build produced wrong matrices)
+        const int sl = cok ? slv[c] : 0;  // wave-uniform
+        if (cok && sl < 0) fz.ctrl->cov_miss = 1;
+        const bool cgo = cok && sl >= 0;
+        const double *gcol = fz.G + (size_t)(sl < 0 ? 0 : sl) * fz.p;
+        const bool small = fz.GS != nullptr && sl < fz.CS;  // uniform
+        const double *gsrow = small ? fz.GS + (size_t)(sl < 0 ? 0 : sl) * fz.CS : fz.G;
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+          const bool ok = cgo && saa[r] >= 0;
+          // both slots inside the slot-indexed copy (L2-resident, neighbouring rows share lines): read it from there
+          const bool gs = small && srr[r] >= 0 && srr[r] < fz.CS;
+          const double *src = !ok ? fz.G : (gs ? gsrow + srr[r] : gcol + saa[r]);
+          const double v = *src;  // unconditional (a valid address either way)
+          g[r][c] = ok ? v : 0.0;
+        }
+      }
     }
   }
   CGP(1);
   // wave-local sum over all R rows (every wave holds every row): fixed order, identical in all waves
   auto wsum = [&](double v) -> double {
-    v = row_sum16(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v = row_sum16(v);  // the same value in the 16 lanes of a row
+    // (r0 + r1) + (r2 + r3) like the xor-16 / xor-32 exchange, but through the scalar unit instead of two LDS permutes
+    auto rl = [](double x, int l) -> double {
+      return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                              __builtin_amdgcn_readlane(__double2loint(x), l));
+    };
+    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
   };
   // reciprocal to full precision for the step lengths: hardware estimate + two Newton steps (a division costs more,
   // and alpha / beta only steer the iteration)
@@ -2003,13 +2059,20 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
     double acc[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; r++) acc[r] = 0.0;
+    // the broadcast reads of v_j in groups of 8, all of a group issued before its products; no branch per column (the
+    // matrix entries of columns >= nc are zero, and c0 + c < R because nc <= NCW)
 #pragma unroll
-    for (int c = 0; c < NCW; c++) {
-      if (c < nc) {  // uniform
-        const double vj = pv[min(c0 + c, R - 1)];  // broadcast read
+    for (int cb = 0; cb < NCW; cb += 8) {
+      double vj[8];
 #pragma unroll
-        for (int r = 0; r < RPT; r++) acc[r] = fma(g[r][c], vj, acc[r]);
-      }
+      for (int c = 0; c < 8; c++)
+        if (cb + c < NCW) vj[c] = pv[c0 + cb + c];
+#pragma unroll
+      for (int c = 0; c < 8; c++)
+        if (cb + c < NCW) {
+#pragma unroll
+          for (int r = 0; r < RPT; r++) acc[r] = fma(g[r][cb + c], vj[c], acc[r]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < RPT; r++) part[wave][lane + 64 * r] = acc[r];
@@ -2019,7 +2082,7 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
       double t = part[0][lane + 64 * r];
 #pragma unroll
       for (int w = 1; w < 8; w++) t += part[w][lane + 64 * r];
-      y[r] = t;
+      y[r] = lane + 64 * r < m ? t : 0.0;  // (rows outside the system may hold any finite matrix entries)
     }
   };
   auto matvec = [&](const double (&v)[RPT], double (&y)[RPT]) {
@@ -2062,12 +2125,16 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
   CGP(3);
   bool ok = false;
   int it = 0;
+  CGL_DECL();
   for (int round = 0; round < 3 && !ok; round++) {
     for (; it < maxit && rs > 1e-4 * tol * tol * qq; it++) {  // recurrence residual target: |r| <= tol / 100 |q|
+      CGL(0);
       matvec(p_t, ap);
+      CGL(1);
 #pragma unroll
       for (int r = 0; r < RPT; r++) ap[r] = fma(ridge, p_t[r], ap[r]);
       const double alpha = rs * frcp(dot(p_t, ap));
+      CGL(2);
       if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < RPT; r++) xs[lane + 64 * r] = fma(alpha, p_t[r], xs[lane + 64 * r]);
@@ -2082,6 +2149,7 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
 #pragma unroll
       for (int r = 0; r < RPT; r++) p_t[r] = fma(bt, p_t[r], r_t[r]);
       rs = rs_new;
+      CGL(3);
     }
     // the recurrence drifts: accept only on the recomputed residual |q - (G + ridge I) x| <= tol |q|
     if (wave == 0) {
@@ -2100,6 +2168,7 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
     ok = rs <= tol * tol * qq;  // also catches NaN (singular / indefinite matrix): the comparison fails
     if (it >= maxit) break;
   }
+  CGL_FLUSH();
   CGP(4);
 #ifdef BESSX_CG_PROFILE
   if (threadIdx.x == 0) atomicAdd(&g_cg_prof[14], (unsigned long long)it);
@@ -2524,7 +2593,9 @@ __device__ __forceinline__ bool hinv_body(HvShared &sh, int m, double ridge, con
 // those of k_topk followed by k_cgr -- without the second launch, its fall-through when the selection has already
 // settled the slot, and the boundary between them (tools/ktrace.py: 581 + 581 launches per 200-candidate path).
 // blockIdx.x == 1 (only when nd.pub.on): the deferred publication of the parent fit, as in k_topk.
-template <int EB, int RPT, int NCW>
+// HV: the instance that carries the maintained-inverse solve (BESSX_HINV=1); the default instance has none of its
+// code, registers or shared memory.
+template <int EB, int RPT, int NCW, bool HV>
 __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ score, int len, int k, int *out,
                                                  const FitCtrl *ctrl, int slot, const TopkNeed nd, int nc, double ridge,
                                                  const double *__restrict__ rhs, double *sol, const CholFuse fz,
@@ -2536,24 +2607,28 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
   }
   topk_body<EB, 512>(score, nullptr, len, len, k, out, nullptr, ctrl, slot, nullptr, nd);
   __syncthreads();  // the selection's writes (A_new, the control block, a commit) are visible to the whole block
-  __shared__ HvShared hsh;
-  __shared__ int hv_same_any;
-  bool handled = false;
-  if (hv.H != nullptr) handled = hinv_body(hsh, k, ridge, rhs, out, sol, ctrl, slot, fz, hv, tol, &hv_same_any);
-  if (!handled) {
-    const bool was_mine = hv.H != nullptr && !ctrl->done && ctrl->l == slot - 1 && !ctrl->same_prev;  // uniform
-    cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
-    __syncthreads();
-    if (was_mine && ctrl->l == slot) {
-      // the conjugate-gradient body solved and committed this slot: bring the inverse up to the new set if the ridge
-      // is the previous solve's (a path at fixed lambda: the next candidates then go through hinv_body)
-      const bool same_ridge = hv.hinfo[1] == ridge;
-      if (same_ridge && fz.GS != nullptr && fz.CS <= HV_CS && k <= HV_R - 1 &&
-          hv_load_set(hsh, out, k, fz.slot_of, fz.CS))
-        hinv_rebuild(hsh, hv, fz.GS, fz.CS, k, ridge);
+  if constexpr (HV) {
+    __shared__ HvShared hsh;
+    __shared__ int hv_same_any;
+    bool handled = false;
+    if (hv.H != nullptr) handled = hinv_body(hsh, k, ridge, rhs, out, sol, ctrl, slot, fz, hv, tol, &hv_same_any);
+    if (!handled) {
+      const bool was_mine = hv.H != nullptr && !ctrl->done && ctrl->l == slot - 1 && !ctrl->same_prev;  // uniform
+      cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
       __syncthreads();
-      if (threadIdx.x == 0) hv.hinfo[1] = ridge;
+      if (was_mine && ctrl->l == slot) {
+        // the conjugate-gradient body solved and committed this slot: bring the inverse up to the new set if the ridge
+        // is the previous solve's (a path at fixed lambda: the next candidates then go through hinv_body)
+        const bool same_ridge = hv.hinfo[1] == ridge;
+        if (same_ridge && fz.GS != nullptr && fz.CS <= HV_CS && k <= HV_R - 1 &&
+            hv_load_set(hsh, out, k, fz.slot_of, fz.CS))
+          hinv_rebuild(hsh, hv, fz.GS, fz.CS, k, ridge);
+        __syncthreads();
+        if (threadIdx.x == 0) hv.hinfo[1] = ridge;
+      }
     }
+  } else {
+    cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
   }
   if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
     __syncthreads();
@@ -6191,9 +6266,15 @@ hipError_t launch_sel_cgr(const double *score, int len, int k, int *A_new, const
   const TopkNeed nd = *need;
   const CholFuse fz = *fuse;
   const int nblk = nd.pub.on ? 2 : 1, nc = (k + 7) / 8, per = (len + 511) / 512;
-#define SC_GO(EB, RP, NW_)                                                                                          \
-  hipLaunchKernelGGL((k_sel_cgr<EB, RP, NW_>), dim3(nblk), dim3(512), 0, st, score, len, k, A_new, ctrl, slot, nd, nc, \
-                     ridge, rhs, sol, fz, maxit, tol, hv)
+#define SC_GO(EB, RP, NW_)                                                                                     \
+  do {                                                                                                         \
+    if (H != nullptr)                                                                                          \
+      hipLaunchKernelGGL((k_sel_cgr<EB, RP, NW_, true>), dim3(nblk), dim3(512), 0, st, score, len, k, A_new, ctrl, \
+                         slot, nd, nc, ridge, rhs, sol, fz, maxit, tol, hv);                                   \
+    else                                                                                                       \
+      hipLaunchKernelGGL((k_sel_cgr<EB, RP, NW_, false>), dim3(nblk), dim3(512), 0, st, score, len, k, A_new, ctrl, \
+                         slot, nd, nc, ridge, rhs, sol, fz, maxit, tol, hv);                                   \
+  } while (0)
 #define SC_BY_M(EB)          \
   do {                       \
     if (k <= 64)             \

@@ -1,7 +1,7 @@
 """Development aid: time per phase of the conjugate-gradient solve kernels (k_cg / k_cgr), accumulated by the kernels
 themselves (100 MHz wall clock).  Needs a library built with -DBESSX_CG_PROFILE:
-  make -C bess_amd/csrc HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBESSX_CG_PROFILE" -B all
-  python tools/cgprof.py"""
+  make -C bess_amd/csrc prof DEFS=-DBESSX_CG_PROFILE
+  BESSX_LIB_PATH=bess_amd/csrc/build_prof/libbessx.so python tools/cgprof.py"""
 import sys, ctypes, numpy as np
 sys.path.insert(0,'.')
 from bess_amd import capi, synth
@@ -18,3 +18,6 @@ n=v[15]
 print("solves",n,"iters/solve",v[14]/n)
 names=["idx setup","gather","rhs/x0","init resid","cg loop","final resid+loss","commit"]
 for i,nm in enumerate(names): print("%-18s total %.3f ms  per solve %.2f us"%(nm, v[i]*10e-6, v[i]*0.01/n))
+its=max(v[14],1)
+for i,nm in [(7,"loop: top"),(8,"loop: matvec"),(9,"loop: ridge+dot+alpha"),(10,"loop: updates+dot+beta")]:
+    print("%-26s per step %.3f us"%(nm, v[i]*0.01/its))
