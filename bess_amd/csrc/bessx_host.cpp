@@ -156,6 +156,8 @@ struct bessx_session {
     bool shares_map = false;  // slot_of / meta are row set 0's (shared fills: every row set caches the same columns)
   };
   std::vector<CovCache> cov;
+  long long dbg_waits = 0, dbg_waits_ready = 0;  // BESSX_DEBUG: waits for a published block / already there on arrival
+  double dbg_enq_s = 0.0;                          // ... seconds spent queueing chained fits
   bool cov_mode = false;
   int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
@@ -290,8 +292,10 @@ static void session_free(bessx_session *s) {
   if (!s) return;
   if (std::getenv("BESSX_DEBUG"))
     std::fprintf(stderr, "[bessx] chained fits: queued %lld, used %lld, not started %lld, mismatched %lld; "
-                 "CG solves handed to Cholesky: %lld\n",
-                 s->chain_queued, s->chain_hits, s->chain_dead, s->chain_mismatch, s->cov_cg_fallbacks);
+                 "CG solves handed to Cholesky: %lld; waits for a published block: %lld, of which the block was "
+                 "already there %lld; queueing chained fits took %.3f ms\n",
+                 s->chain_queued, s->chain_hits, s->chain_dead, s->chain_mismatch, s->cov_cg_fallbacks, s->dbg_waits,
+                 s->dbg_waits_ready, s->dbg_enq_s * 1e3);
   (void)hipSetDevice(s->device);
   if (s->st) (void)hipStreamSynchronize(s->st);
   auto F = [](void *q) {
@@ -1246,6 +1250,8 @@ static int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long l
 static int publish_wait(bessx_session *s, int buf, unsigned long long want) {
   volatile unsigned long long *flag = s->pub_flag + 8 * buf;
   s->res_h = s->res_buf[buf];
+  s->dbg_waits++;
+  if (*flag >= want) s->dbg_waits_ready++;  // the result was there already: the device is ahead of the host
   for (unsigned spins = 1;; spins++) {
     if (*flag >= want) break;
     if ((spins & 0x3ff) == 0) {
@@ -1704,8 +1710,11 @@ static int algorithm_fit(bessx_session *s) {
         if (!published)
           if (int rc = publish_launch(s, pa)) return rc;
         // chain the announced next fit of the warm-start path behind this one before waiting for this one
-        if (first_batch)
+        if (first_batch) {
+          const auto tq = std::chrono::steady_clock::now();
           if (int rc = enqueue_chained(s, hint, rs, my_serial, my_buf ^ 1, batch, lambda, T0)) return rc;
+          s->dbg_enq_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count();
+        }
         if (int rc = publish_wait(s, my_buf, seq)) return rc;
       }
     }

@@ -74,6 +74,70 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Wave-wide reductions without LDS permutes: four DPP exchanges inside each row of 16 lanes (mirror, half mirror, the
+// two quad swaps: every lane of a row ends with the row's result), then the four rows through the scalar unit
+// (v_readlane).  A __shfl_xor butterfly costs one LDS round trip per stage and 32-bit word.
+#define BESSX_DPP32(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false)
+__device__ __forceinline__ double dpp_f64(double v, const int stage) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (stage) {
+    case 0: lo = BESSX_DPP32(lo, 0x140); hi = BESSX_DPP32(hi, 0x140); break;  // row_mirror
+    case 1: lo = BESSX_DPP32(lo, 0x141); hi = BESSX_DPP32(hi, 0x141); break;  // row_half_mirror
+    case 2: lo = BESSX_DPP32(lo, 0x4E); hi = BESSX_DPP32(hi, 0x4E); break;    // quad_perm [2,3,0,1]
+    default: lo = BESSX_DPP32(lo, 0xB1); hi = BESSX_DPP32(hi, 0xB1); break;   // quad_perm [1,0,3,2]
+  }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int dpp_i32(int v, const int stage) {
+  switch (stage) {
+    case 0: return BESSX_DPP32(v, 0x140);
+    case 1: return BESSX_DPP32(v, 0x141);
+    case 2: return BESSX_DPP32(v, 0x4E);
+    default: return BESSX_DPP32(v, 0xB1);
+  }
+}
+__device__ __forceinline__ double readlane_f64(double v, const int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// minimum of mn and maximum of mx over the wave, in every lane (min / max are exact: the order does not matter)
+__device__ __forceinline__ void wave_min_max(double &mn, double &mx) {
+#pragma unroll
+  for (int st = 0; st < 4; st++) {
+    mn = fmin(mn, dpp_f64(mn, st));
+    mx = fmax(mx, dpp_f64(mx, st));
+  }
+  mn = fmin(fmin(readlane_f64(mn, 0), readlane_f64(mn, 16)), fmin(readlane_f64(mn, 32), readlane_f64(mn, 48)));
+  mx = fmax(fmax(readlane_f64(mx, 0), readlane_f64(mx, 16)), fmax(readlane_f64(mx, 32), readlane_f64(mx, 48)));
+}
+// arg-max of (key, lower index on ties) over the wave, in every lane: a total order, so the result does not depend on
+// the order of the comparisons
+__device__ __forceinline__ void wave_argmax(unsigned long long &best, int &besti) {
+  auto take = [&](unsigned long long ok, int oi) {
+    if (ok > best || (ok == best && oi < besti)) {
+      best = ok;
+      besti = oi;
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < 4; st++) {
+    const double od = dpp_f64(__longlong_as_double((long long)best), st);
+    const int oi = dpp_i32(besti, st);
+    take((unsigned long long)__double_as_longlong(od), oi);
+  }
+  const double bd_ = __longlong_as_double((long long)best);
+  unsigned long long rk[4];
+  int ri[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    rk[q] = (unsigned long long)__double_as_longlong(readlane_f64(bd_, 16 * q));
+    ri[q] = __builtin_amdgcn_readlane(besti, 16 * q);
+  }
+  best = rk[0];
+  besti = ri[0];
+#pragma unroll
+  for (int q = 1; q < 4; q++) take(rk[q], ri[q]);
+}
+
 // Copy of the result block (control words, loss sums, the first kcopy coefficients and indices) from `src` to `dst`
 // by the whole workgroup.  The block was (partly) written by this very kernel, so the reads go to L2 (relaxed
 // agent-scope atomic loads), but -- unlike volatile accesses, which the compiler keeps in program order and waits
@@ -378,7 +442,7 @@ template <int NT>
 __device__ void cov_need_body(const int *__restrict__ list, int len, const double *__restrict__ bd,
                               double *__restrict__ bd2, int p, int *__restrict__ slot_of, int *__restrict__ meta, int C,
                               int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
-                              const int *__restrict__ A_cur);
+                              const int *__restrict__ A_cur, bool known_diff = false);
 
 __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot, int T0,
                                             const int *__restrict__ A_new, const double *__restrict__ sol,
@@ -477,15 +541,7 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
       }
     }
     PH(0);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      const unsigned long long ok = __shfl_xor(best, o);
-      const int oi = __shfl_xor(besti, o);
-      if (ok > best || (ok == best && oi < besti)) {
-        best = ok;
-        besti = oi;
-      }
-    }
+    wave_argmax(best, besti);
     if ((threadIdx.x & 63) == 0) {
       bk[threadIdx.x >> 6] = best;
       bi[threadIdx.x >> 6] = besti;
@@ -520,12 +576,16 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
     }
     __syncthreads();
     PH(2);
-    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
+    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur, true);
     PH(3);
     PH_COUNT();
     return;
   }
+#ifdef BESSX_KTRACE
+  unsigned long long tph_ = wall_clock64();  // (the repeated-set branch below is stamped too: g_phase[16..20], count [28])
+#endif
   if (nd.slot_of != nullptr && nd.ctrl->fast_same) {
+    PH(16);
     // k_cov_d left, per block of 32 columns, the smallest score inside the current active set and the largest
     // outside it.  If every inside score beats every outside score (and the set has the wanted size, and this is
     // not the first iteration of the fit) the selection returns the same set, A == A_list.col(l-1): nothing to
@@ -536,11 +596,8 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
       mn = fmin(mn, nd.bmm[2 * b]);
       mx = fmax(mx, nd.bmm[2 * b + 1]);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      mn = fmin(mn, __shfl_xor(mn, o));
-      mx = fmax(mx, __shfl_xor(mx, o));
-    }
+    wave_min_max(mn, mx);
+    PH(17);
     if ((threadIdx.x & 63) == 0) {
       rmn[threadIdx.x >> 6] = mn;
       rmx[threadIdx.x >> 6] = mx;
@@ -559,6 +616,7 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
       nd.ctrl->fast_same = 0;
       if (same) nd.ctrl->same_prev = 1;
     }
+    PH(18);
     if (same) {
       if (nd.commit_on) {
         // ... and record the iteration right here (the record-and-stop branch of k_commit): the solve kernel queued
@@ -567,11 +625,16 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
         __syncthreads();
         commit_body(nd.ctrl, slot, k, out, nullptr, 0, 0, nd.cm_A_cur, nd.cm_b_cur, nd.cm_beta_dense, nd.cm_hist,
                     nd.cm_hist_beta, nd.cm_hist_coef0, nd.cm_hist_stride, &same_any_sh, nd.cm_inA);
+        PH(19);
         if (nd.snap.on == 2) {  // the fit has ended: its snapshot for the deferred publication, here and now
           if (threadIdx.x == 0) nd.ctrl->snap_seq = nd.snap.seq;
           __syncthreads();
           snapshot_body(nd.snap);
         }
+        PH(20);
+#ifdef BESSX_KTRACE
+        if (threadIdx.x == 0) atomicAdd(&g_phase[28], 1ull);
+#endif
       }
       return;
     }
@@ -2605,8 +2668,15 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
     publish_body(nd.pub);
     return;
   }
+#ifdef BESSX_KTRACE
+  const unsigned long long kt0_ = wall_clock64();
+#endif
   topk_body<EB, 512>(score, nullptr, len, len, k, out, nullptr, ctrl, slot, nullptr, nd);
   __syncthreads();  // the selection's writes (A_new, the control block, a commit) are visible to the whole block
+#ifdef BESSX_KTRACE
+  const unsigned long long kt1_ = wall_clock64();
+  unsigned long long kt2_ = kt1_;
+#endif
   if constexpr (HV) {
     __shared__ HvShared hsh;
     __shared__ int hv_same_any;
@@ -2629,6 +2699,10 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
     }
   } else {
     cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
+#ifdef BESSX_KTRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    kt2_ = wall_clock64();
+#endif
   }
   if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
     __syncthreads();
@@ -2638,6 +2712,20 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
       publish_body(fz.pub);
     }
   }
+#ifdef BESSX_KTRACE
+  if constexpr (!HV) {  // block 0's time in the selection, the solve body and the tail, by what the launch did
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      const unsigned long long kt3_ = wall_clock64();
+      const int cls = ctrl->same_prev ? 0 : 1;
+      atomicAdd(&g_phase[8 + 3 * cls], kt1_ - kt0_);
+      atomicAdd(&g_phase[9 + 3 * cls], kt2_ - kt1_);
+      atomicAdd(&g_phase[10 + 3 * cls], kt3_ - kt2_);
+      atomicAdd(&g_phase[14 + cls], 1ull);
+    }
+  }
+  KT(15);  // end of block 0: what follows until the next kernel's start stamp is boundary / idle time
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4931,10 +5019,13 @@ template <int NT>
 __device__ void cov_need_body(const int *__restrict__ list, int len, const double *__restrict__ bd,
                               double *__restrict__ bd2, int p, int *__restrict__ slot_of, int *__restrict__ meta, int C,
                               int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
-                              const int *__restrict__ A_cur) {
+                              const int *__restrict__ A_cur, bool known_diff) {
   __shared__ int wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (slot > 0) {
+  if (slot > 0 && known_diff) {
+    // (the caller has just built the list as A_cur plus one column: it differs, no need to compare)
+    if (tid == 0) ctrl->same_prev = 0;
+  } else if (slot > 0) {
     int diff = 1;
     if (ctrl->l >= 1 && ctrl->k_cur == len) {
       diff = 0;
@@ -4952,6 +5043,19 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
     __syncthreads();
   }
   int nm = 0;
+  if (!restart && len <= NT) {
+    // the usual outcome, every column cached: one vote instead of the scan below
+    const int col = tid < len ? list[tid] : -1;
+    const int miss = (col >= 0 && slot_of[col] < 0) ? 1 : 0;
+    if (!__syncthreads_or(miss)) {
+      if (tid == 0) {
+        meta[1] = 0;
+        meta[2] = 0;
+        ctrl->cov_nmiss = 0;
+      }
+      return;
+    }
+  }
   for (int base = 0; base < len; base += NT) {
     const int i = base + tid;
     const int col = i < len ? list[i] : -1;
@@ -5709,6 +5813,14 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
                                                double *__restrict__ bd, const unsigned char *__restrict__ inA,
                                                double *__restrict__ bmm, const FitCtrl *__restrict__ ctrl, int slot) {
   KT(4);
+  // what the epilogue needs of this block's 32 columns does not depend on the control block: these loads are in
+  // flight while the gate below waits for its own (one round trip less on the block's critical path)
+  const int jj = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jj;
+  const bool epi = g == 0 && j < p;
+  const double e_xty = epi ? xty[j] : 0.0, e_b = epi ? beta_dense[j] : 0.0, e_xtx = epi ? xtx[j] : 1.0;
+  const unsigned char e_in = epi ? inA[j] : (unsigned char)0;
+  const unsigned char e_al = (epi && always != nullptr) ? always[j] : (unsigned char)0;
   if (ctrl->done || ctrl->l != slot - 1) return;
   // 32 columns x 8 thread groups per block; group g adds the active columns i = g, g+8, ... (two interleaved
   // accumulators), the 8 partial sums are added in group order: a fixed summation tree.
@@ -5717,8 +5829,6 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
   __shared__ double s_b[CHUNK];
   __shared__ double sm[8][32];
   const int kc = ctrl->k_cur;
-  const int jj = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + jj;
   double acc0 = 0.0, acc1 = 0.0;
   for (int base = 0; base < kc; base += CHUNK) {
     const int cnt = min(CHUNK, kc - base);
@@ -5730,13 +5840,24 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
     }
     __syncthreads();
     if (j < p) {
-      int i = g;
-      for (; i + 8 < cnt; i += 16) {
-        const double g0 = G[(size_t)max(s_sl[i], 0) * p + j], g1 = G[(size_t)max(s_sl[i + 8], 0) * p + j];
-        acc0 = fma(g0, s_b[i], acc0);
-        acc1 = fma(g1, s_b[i + 8], acc1);
+      // 8 cache entries in flight per thread before the first product (a loop of "two loads, wait, two products" pays
+      // the L2 latency once per pair); entries beyond cnt read slot 0 and meet a zero coefficient.  Same summation
+      // order as before: i = g, g + 16, ... into acc0, i = g + 8, g + 24, ... into acc1.
+      for (int i0 = g; i0 < cnt; i0 += 64) {
+        double gv[8], bv[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          const int i = i0 + 8 * t;
+          const bool in = i < cnt;
+          gv[t] = G[(size_t)(in ? max(s_sl[i], 0) : 0) * p + j];
+          bv[t] = in ? s_b[i] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          if (i0 + 8 * t < cnt) acc0 = fma(gv[t], bv[t], acc0);
+          if (i0 + 8 * (t + 1) < cnt) acc1 = fma(gv[t + 1], bv[t + 1], acc1);
+        }
       }
-      if (i < cnt) acc0 = fma(G[(size_t)max(s_sl[i], 0) * p + j], s_b[i], acc0);
     }
     __syncthreads();
   }
@@ -5746,19 +5867,19 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
     double t = sm[0][jj];
 #pragma unroll
     for (int q = 1; q < 8; q++) t += sm[q][jj];
-    const double s1 = xty[j] - t;
+    const double s1 = e_xty - t;
     d_out[j] = s1;
-    const double b = beta_dense[j];
+    const double b = e_b;
     const double d = s1 / n_t - 2.0 * lambda * b;
-    const double phi = sqrt(2.0 * lambda + xtx[j] / n_t);
+    const double phi = sqrt(2.0 * lambda + e_xtx / n_t);
     const double inv = 1.0 / phi;
     const double tt = phi * b + inv * d;
     double v = tt * tt;
-    if (always != nullptr && always[j]) v = DBL_MAX;
+    if (e_al) v = DBL_MAX;
     bd[j] = v;
     // repeated-set shortcut: smallest score inside the current active set, largest outside, per block
-    sm[1][jj] = inA[j] ? v : DBL_MAX;
-    sm[2][jj] = inA[j] ? -1.0 : v;
+    sm[1][jj] = e_in ? v : DBL_MAX;
+    sm[2][jj] = e_in ? -1.0 : v;
   } else if (g == 0) {
     sm[1][jj] = DBL_MAX;
     sm[2][jj] = -1.0;

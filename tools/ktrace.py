@@ -10,7 +10,7 @@ X,y,_,_=synth.make_lm()
 L=capi.lib()
 cap=1<<16
 buf=(ctypes.c_ulonglong*cap)()
-names={1:'topk',2:'cgr',3:'cg',4:'cov_d',5:'panel',6:'reduce',7:'compact',8:'continue',9:'publish',10:'fill_list',11:'resume',12:'need',13:'begin',14:'sel_cgr'}
+names={1:'topk',2:'cgr',3:'cg',4:'cov_d',5:'panel',6:'reduce',7:'compact',8:'continue',9:'publish',10:'fill_list',11:'resume',12:'need',13:'begin',14:'sel_cgr',15:'after sel_cgr (boundary / idle)'}
 import time
 with capi.Session(X,y) as s:
     s.sequential_path(np.arange(1,201), ic_type=3)
@@ -22,6 +22,9 @@ with capi.Session(X,y) as s:
     print("counters", s.counters())
     if ph[30]: print("hinv phases (us per solve, %d solves, %d refinements):"%(ph[30],ph[29]), {k:round(ph[i]*0.01/ph[30],2) for i,k in zip(range(8,15),("load","diff","update","x=Hq","resid","finish","commit"))})
     print("phases (us per call, %d calls):"%ph[31], [round(ph[i]*0.01/max(ph[31],1),2) for i in range(8)])
+    for cls,nm in ((0,"repeated set"),(1,"other (solve / fell through)")):
+        if ph[14+cls] and not ph[30]: print("k_sel_cgr block 0, %s (%d launches): selection, solve body, tail us:"%(nm,ph[14+cls]), [round(ph[8+3*cls+i]*0.01/ph[14+cls],2) for i in range(3)])
+    if ph[28]: print("repeated-set launches (us per call, %d calls): entry, block extremes, decision, commit, snapshot:"%ph[28], [round(ph[i]*0.01/ph[28],2) for i in range(16,21)])
 ev=[(buf[i]&255, (buf[i]>>8)*0.01) for i in range(n)]  # us
 ev.sort(key=lambda e:e[1])
 print("events",n,"wall ms",wall*1e3,"span ms",(ev[-1][1]-ev[0][1])/1e3)
@@ -29,6 +32,14 @@ tot=collections.defaultdict(float); cnt=collections.Counter()
 for (k,t),(k2,t2) in zip(ev,ev[1:]):
     tot[k]+=t2-t; cnt[k]+=1
 for k,v in sorted(tot.items(),key=lambda x:-x[1]): print("%-10s %5d launches  %8.3f ms  avg %6.2f us"%(names.get(k,k),cnt[k],v/1e3,v/cnt[k]))
+# time between the end of a k_sel_cgr block 0 and the next kernel's start, by what that launch was
+gaps=collections.defaultdict(list)
+for i in range(len(ev)-2):
+    if ev[i][0]==14 and ev[i+1][0]==15:
+        body=ev[i+1][1]-ev[i][1]
+        what="fell through" if body<1.5 else ("repeated set" if body<8 else "solve")
+        gaps[(what,names.get(ev[i+2][0],ev[i+2][0]))].append(ev[i+2][1]-ev[i+1][1])
+for k,v in sorted(gaps.items()): print("after sel_cgr %-14s -> %-8s %4d times  median %5.2f us  mean %5.2f us  sum %.3f ms"%(k[0],k[1],len(v),np.median(v),np.mean(v),np.sum(v)/1e3))
 # the selection(+solve) launches by what they turned out to do, told by their duration
 for kid in (14, 1, 2):
     d=np.array([t2-t for (k,t),(k2,t2) in zip(ev,ev[1:]) if k==kid])
