@@ -1254,7 +1254,9 @@ static int publish_wait(bessx_session *s, int buf, unsigned long long want) {
   if (*flag >= want) s->dbg_waits_ready++;  // the result was there already: the device is ahead of the host
   for (unsigned spins = 1;; spins++) {
     if (*flag >= want) break;
-    if ((spins & 0x3ff) == 0) {
+    // (rarely: a hipStreamQuery puts a marker with a system-scope release behind the last queued kernel, and the
+    // kernel after it then starts ~4 us late -- once per fit when the query ran every 1024 spins, tools/ktrace.py)
+    if ((spins & 0xfffff) == 0) {
       hipError_t q = hipStreamQuery(s->st);
       if (q == hipSuccess) {
         if (*flag >= want) break;

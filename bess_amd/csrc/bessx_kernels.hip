@@ -452,6 +452,67 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
                                             double *__restrict__ hist_coef0, int hist_stride, int *same_any_sh,
                                             unsigned char *__restrict__ inA);
 
+// The repeated-set shortcut of the covariance form (the caller has seen ctrl->fast_same): k_cov_d left, per block of 32
+// columns, the smallest score inside the current active set and the largest outside it.  If every inside score beats
+// every outside score (and the set has the wanted size, and this is not the first iteration of the fit) the selection
+// returns the same set, A == A_list.col(l-1): nothing to search, nothing to look up -- the iteration is recorded
+// (the record-and-stop branch of k_commit) and, when this launch ends a chained batch, the result block snapshotted.
+// Returns true when the slot is settled.
+template <int NT>
+__device__ __forceinline__ bool repeated_set_body(const TopkNeed &nd, int k, int *__restrict__ out, int slot) {
+  constexpr int NWV = NT / 64;
+#ifdef BESSX_KTRACE
+  unsigned long long tph_ = wall_clock64();  // (stamps g_phase[16..20], count [28])
+#endif
+  PH(16);
+  __shared__ double rmn[NWV], rmx[NWV];
+  double mn = DBL_MAX, mx = -1.0;
+  for (int b = threadIdx.x; b < nd.nbmm; b += NT) {
+    mn = fmin(mn, nd.bmm[2 * b]);
+    mx = fmax(mx, nd.bmm[2 * b + 1]);
+  }
+  wave_min_max(mn, mx);
+  PH(17);
+  if ((threadIdx.x & 63) == 0) {
+    rmn[threadIdx.x >> 6] = mn;
+    rmx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  mn = rmn[0];
+  mx = rmx[0];
+#pragma unroll
+  for (int w = 1; w < NWV; w++) {
+    mn = fmin(mn, rmn[w]);
+    mx = fmax(mx, rmx[w]);
+  }
+  const bool same = nd.ctrl->l >= 1 && nd.ctrl->k_cur == k && mn > mx;  // uniform
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    nd.ctrl->fast_same = 0;
+    if (same) nd.ctrl->same_prev = 1;
+  }
+  PH(18);
+  if (!same) return false;
+  if (nd.commit_on) {
+    // (otherwise the solve kernel queued behind this one records the iteration)
+    __shared__ int same_any_sh;
+    __syncthreads();
+    commit_body(nd.ctrl, slot, k, out, nullptr, 0, 0, nd.cm_A_cur, nd.cm_b_cur, nd.cm_beta_dense, nd.cm_hist,
+                nd.cm_hist_beta, nd.cm_hist_coef0, nd.cm_hist_stride, &same_any_sh, nd.cm_inA);
+    PH(19);
+    if (nd.snap.on == 2) {  // the fit has ended: its snapshot for the deferred publication, here and now
+      if (threadIdx.x == 0) nd.ctrl->snap_seq = nd.snap.seq;
+      __syncthreads();
+      snapshot_body(nd.snap);
+    }
+    PH(20);
+#ifdef BESSX_KTRACE
+    if (threadIdx.x == 0) atomicAdd(&g_phase[28], 1ull);
+#endif
+  }
+  return true;
+}
+
 // nd.slot_of != nullptr (covariance form of the LM fit, single chunk): the kernel ends with the work of k_cov_need on
 // the indices it has just selected -- one launch less per PDAS iteration.
 // The selection as a device function of an NT-thread block (NT threads = 16 waves: k_topk; 8 waves: the first phase
@@ -581,63 +642,8 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
     PH_COUNT();
     return;
   }
-#ifdef BESSX_KTRACE
-  unsigned long long tph_ = wall_clock64();  // (the repeated-set branch below is stamped too: g_phase[16..20], count [28])
-#endif
   if (nd.slot_of != nullptr && nd.ctrl->fast_same) {
-    PH(16);
-    // k_cov_d left, per block of 32 columns, the smallest score inside the current active set and the largest
-    // outside it.  If every inside score beats every outside score (and the set has the wanted size, and this is
-    // not the first iteration of the fit) the selection returns the same set, A == A_list.col(l-1): nothing to
-    // search, nothing to look up.
-    __shared__ double rmn[NWV], rmx[NWV];
-    double mn = DBL_MAX, mx = -1.0;
-    for (int b = threadIdx.x; b < nd.nbmm; b += NT) {
-      mn = fmin(mn, nd.bmm[2 * b]);
-      mx = fmax(mx, nd.bmm[2 * b + 1]);
-    }
-    wave_min_max(mn, mx);
-    PH(17);
-    if ((threadIdx.x & 63) == 0) {
-      rmn[threadIdx.x >> 6] = mn;
-      rmx[threadIdx.x >> 6] = mx;
-    }
-    __syncthreads();
-    mn = rmn[0];
-    mx = rmx[0];
-#pragma unroll
-    for (int w = 1; w < NWV; w++) {
-      mn = fmin(mn, rmn[w]);
-      mx = fmax(mx, rmx[w]);
-    }
-    const bool same = nd.ctrl->l >= 1 && nd.ctrl->k_cur == k && mn > mx;  // uniform
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      nd.ctrl->fast_same = 0;
-      if (same) nd.ctrl->same_prev = 1;
-    }
-    PH(18);
-    if (same) {
-      if (nd.commit_on) {
-        // ... and record the iteration right here (the record-and-stop branch of k_commit): the solve kernel queued
-        // behind this one then falls through its gate instead of doing a launch's worth of bookkeeping
-        __shared__ int same_any_sh;
-        __syncthreads();
-        commit_body(nd.ctrl, slot, k, out, nullptr, 0, 0, nd.cm_A_cur, nd.cm_b_cur, nd.cm_beta_dense, nd.cm_hist,
-                    nd.cm_hist_beta, nd.cm_hist_coef0, nd.cm_hist_stride, &same_any_sh, nd.cm_inA);
-        PH(19);
-        if (nd.snap.on == 2) {  // the fit has ended: its snapshot for the deferred publication, here and now
-          if (threadIdx.x == 0) nd.ctrl->snap_seq = nd.snap.seq;
-          __syncthreads();
-          snapshot_body(nd.snap);
-        }
-        PH(20);
-#ifdef BESSX_KTRACE
-        if (threadIdx.x == 0) atomicAdd(&g_phase[28], 1ull);
-#endif
-      }
-      return;
-    }
+    if (repeated_set_body<NT>(nd, k, out, slot)) return;
   }
   __shared__ int wsum[NWV];
   __shared__ int wsum2[NWV];
@@ -2671,6 +2677,34 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
 #ifdef BESSX_KTRACE
   const unsigned long long kt0_ = wall_clock64();
 #endif
+  if constexpr (!HV) {
+    // The commonest short launch -- the selection that only confirms the active set and ends the fit -- first and in
+    // one piece: a launch lands on a compute unit whose instruction cache has none of this kernel, and the same steps
+    // spread over the selection, the solve body and the tail were a string of instruction-fetch misses
+    // (block 0: 4.0 -> 3.6 us, tools/ktrace.py).
+    if (!nd.cont_on && nd.commit_on && nd.slot_of != nullptr && !ctrl->done && ctrl->l == slot - 1 && ctrl->l >= 1 &&
+        nd.ctrl->fast_same) {  // uniform
+      if (repeated_set_body<512>(nd, k, out, slot)) {
+        if (fz.pub.on) {  // last kernel of a batch of slots, as at the end of this kernel
+          __syncthreads();
+          if (fz.pub.on == 2) {
+            if (fz.ctrl->snap_seq != fz.pub.seq) snapshot_body(fz.pub);
+          } else {
+            publish_body(fz.pub);
+          }
+        }
+#ifdef BESSX_KTRACE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+          atomicAdd(&g_phase[8], wall_clock64() - kt0_);
+          atomicAdd(&g_phase[14], 1ull);
+        }
+        KT(15);
+#endif
+        return;
+      }
+    }
+  }
   topk_body<EB, 512>(score, nullptr, len, len, k, out, nullptr, ctrl, slot, nullptr, nd);
   __syncthreads();  // the selection's writes (A_new, the control block, a commit) are visible to the whole block
 #ifdef BESSX_KTRACE
