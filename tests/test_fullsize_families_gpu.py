@@ -170,7 +170,9 @@ def test_lm_cv_golden_section_matches_compiled_reference_at_full_size(lmcv_full)
     outs, _, _ = lmcv_full
     for mode in (2, 1):
         nfit = assert_matches_golden(outs[mode]["trace"], g, "configs[3] LM gs_path + 5-fold CV, score_mode %d" % mode)
-        assert nfit >= 12  # at least the two first golden-section points, each evaluated twice (q4)
+        # the committed golden is the complete run (145 fits, 368 PDAS iterations, 8 515 s of the compiled reference); a
+        # regenerated, time-boxed one must still cover the two first golden-section points, each evaluated twice (q4)
+        assert nfit == len(g["fit_T0"]) if not int(g["truncated"]) else nfit >= 12
         assert_best_model(outs[mode], g)
 
 
