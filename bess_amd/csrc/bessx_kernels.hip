@@ -62,6 +62,7 @@ __device__ unsigned long long g_phase[32];
 #define PH_COUNT()
 #endif
 
+constexpr int COV_R = 32;   // right-hand-side columns per panel group (two MFMA tiles)
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -564,6 +565,12 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
     __shared__ unsigned long long bk[NWV];
     __shared__ int bi[NWV];
     PH_BEGIN();
+    // this thread's element of the old active set, its cache slot and the cache's column count: loads that do not
+    // depend on the arg-max, in flight while it runs (used when the old set fits one round of the block)
+    const bool one_round = k - 1 <= NT;
+    const int a_mine = (one_round && (int)threadIdx.x < k - 1) ? nd.A_cur[threadIdx.x] : -1;
+    const int sl_mine = a_mine >= 0 ? nd.slot_of[a_mine] : 0;
+    const int cnt_cache = one_round ? nd.meta[0] : 0;
     unsigned long long best = 0ull;
     int besti = 0x7fffffff;
     if (nd.bmm != nullptr && nd.bmm_fresh) {
@@ -621,6 +628,41 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
     // block (a binary search by one thread is a chain of dependent global loads)
     const int *A_old = nd.A_cur;
     int lo = 0;
+    if (one_round) {
+      // the list goes out and the cache lookup is answered from registers: no re-read of what was just stored
+      const int sl_new = nd.slot_of[besti];
+      int smaller = 0;
+      if (a_mine >= 0) {
+        out[threadIdx.x + (a_mine > besti ? 1 : 0)] = a_mine;
+        smaller = a_mine < besti ? 1 : 0;
+      }
+      lo = __syncthreads_count(smaller);
+      const int miss = ((a_mine >= 0 && sl_mine < 0) || sl_new < 0) ? 1 : 0;
+      const bool any_miss = __syncthreads_or(miss) != 0;
+      if (threadIdx.x == 0) {
+        out[lo] = besti;
+        nd.ctrl->fast_same = 0;
+      }
+      PH(2);
+      if (!any_miss && !(cnt_cache + k + COV_R > nd.C) && slot > 0) {
+        // every column cached, no restart: what cov_need_body would conclude (the set differs from A_cur by construction)
+        if (threadIdx.x == 0) {
+          nd.ctrl->same_prev = 0;
+          nd.meta[1] = 0;
+          nd.meta[2] = 0;
+          nd.ctrl->cov_nmiss = 0;
+        }
+        __syncthreads();
+        PH(3);
+        PH_COUNT();
+        return;
+      }
+      __syncthreads();
+      cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur, true);
+      PH(3);
+      PH_COUNT();
+      return;
+    }
     for (int base = 0; base < k - 1; base += NT) {  // uniform trip count
       const int i = base + threadIdx.x;
       int smaller = 0;
@@ -5034,7 +5076,6 @@ __global__ void __launch_bounds__(256) k_gram_cols(const int *__restrict__ A_new
 //   k_cov_reduce     fixed-order sum over slabs, scatter into G
 //   k_cov_d / k_cov_gram   the GEMV and the Gram gather
 // ------------------------------------------------------------------------------------------
-constexpr int COV_R = 32;   // right-hand-side columns per panel group (two MFMA tiles)
 constexpr int COV_NJ = 4;   // streamed 16-column tiles per wave
 
 __device__ __forceinline__ bool cov_gate(const FitCtrl *ctrl, int slot) {
