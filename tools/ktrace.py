@@ -1,7 +1,7 @@
 """Development aid: start time stamps of the covariance-form kernels in launch order, WITHOUT a profiler (rocprofv3
 serialises every launch to >= 4.6 us and overstates the small ones).  Needs a library built with -DBESSX_KTRACE:
-  make -C bess_amd/csrc HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DBESSX_KTRACE" -B all
-  python tools/ktrace.py
+  make -C bess_amd/csrc ktrace
+  BESSX_LIB_PATH=bess_amd/csrc/build_kt/libbessx.so python tools/ktrace.py
 Prints start-to-start time per kernel for one 200-candidate path of configs[1] and a sample of the sequence."""
 import sys, ctypes, collections, numpy as np
 sys.path.insert(0,'.')
