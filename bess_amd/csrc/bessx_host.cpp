@@ -202,6 +202,7 @@ struct bessx_session {
   double *Xp = nullptr, *zp = nullptr, *cvp_part = nullptr;
   long ldp = 0;
   int cvp_rps = 0, cvp_nsl = 0;  // rows per slab, slabs per fold (fold k owns slabs [k * cvp_nsl, (k + 1) * cvp_nsl))
+  bool cov_pair_auto = true;  // launches of two groups use the pair panel kernel (BESSX_PANEL_PAIR_AUTO=0: never)
   int cov_variant = 3;        // panel kernel: 3 = LDS tile, loads two chunks ahead (2 blocks per CU); 2 = LDS tile,
                               // one chunk ahead (3 blocks per CU); 1 = double-buffered tile (1 block per CU);
                               // 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
@@ -749,6 +750,12 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
 // Form the Gram columns of the fill list, 2 groups of 32 columns per launch pair (the slab partials of a launch
 // share one work space).  parked = 1: for a parked fit, 0: start of a fit.  The panel kernel is the one kernel
 // of this mode that reads X: its launches are timed like the streaming score pass (k1_*).
+// Two groups in one launch (a fill of more than 32 columns: cold starts, the chunks of a sharded path): the pair panel
+// kernel forms both in ONE pass over X (1.36 ms against 2 x 0.76 ms); single groups keep the default.
+static int panel_variant_for(const bessx_session *s, int ng) {
+  return (s->cov_variant == 3 && ng == 2 && s->cov_pair_auto) ? 4 : s->cov_variant;
+}
+
 static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
   bessx_session::CovCache &cv = s->cov[rs];
   for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS) {
@@ -760,7 +767,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
       // one unmasked pass over the fold-major copy serves every row set: the columns enter ALL caches (same slots)
       const int nsl_all = s->K * s->cvp_nsl;
       e = launch_cov_panel(s->Xp, s->zp, s->ldp, s->p, nullptr, s->cov_fcols, g0, ng, s->cvp_rps, nsl_all, s->cvp_part,
-                           s->ctrl, parked, s->st, s->cov_variant);
+                           s->ctrl, parked, s->st, panel_variant_for(s, ng));
       if (s->timing && e == hipSuccess) {
         e = hipEventRecord(eb, s->st);
         s->cov_timed.push_back({s->ev_used - 2, g0});
@@ -777,7 +784,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
       continue;
     }
     e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, g0, ng, s->cov_rps,
-                         s->cov_nslab, s->cov_part, s->ctrl, parked, s->st, s->cov_variant);
+                         s->cov_nslab, s->cov_part, s->ctrl, parked, s->st, panel_variant_for(s, ng));
     if (s->timing && e == hipSuccess) {
       e = hipEventRecord(eb, s->st);
       s->cov_timed.push_back({s->ev_used - 2, g0});
@@ -3071,6 +3078,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     if (eligible && mode != 1) {
       // capacity: every column if p is small, else a few active sets' worth, within 1 GiB per row set
       if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(6, std::atoi(ev)));
+      if (const char *ev = std::getenv("BESSX_PANEL_PAIR_AUTO")) s->cov_pair_auto = std::string(ev) != "0";
       // the pair kernel (variant 4) forms two 32-column groups per pass over X: fills then speculate up to 64 columns
       s->cov_spec = (s->cov_variant == 4 && p >= 4 * COV_R && topk_supported(p, 2 * COV_R)) ? 2 * COV_R : COV_R;
       long C = std::min<long>(((long)p + 31) / 32 * 32 + COV_R + s->cov_spec, 2560);

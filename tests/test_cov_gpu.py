@@ -111,7 +111,7 @@ def test_conjugate_gradients_hand_ill_conditioned_systems_to_cholesky(gpu, monke
 @pytest.mark.parametrize("knob", ["BESSX_CHAIN=0", "BESSX_PUBLISH=0", "BESSX_COV_SOLVER=chol", "BESSX_COV_BG=1",
                                   "BESSX_PANEL_VARIANT=0", "BESSX_PANEL_VARIANT=1", "BESSX_PANEL_VARIANT=2",
                                   "BESSX_CG_LAYOUT=tiles", "BESSX_FUSE=0", "BESSX_CG_TOL=1e-10", "BESSX_COV_CS=24",
-                                  "BESSX_DEFER_PUBLISH=0", "BESSX_FUSE_SEL=0", "BESSX_HINV=1", "BESSX_PANEL_VARIANT=4", "BESSX_PANEL_VARIANT=5",
+                                  "BESSX_DEFER_PUBLISH=0", "BESSX_FUSE_SEL=0", "BESSX_PANEL_PAIR_AUTO=0", "BESSX_HINV=1", "BESSX_PANEL_VARIANT=4", "BESSX_PANEL_VARIANT=5",
                                   "BESSX_PANEL_VARIANT=6"])
 def test_runtime_knobs_do_not_change_results(gpu, monkeypatch, knob):
     """Every optional mechanism of the covariance form can be switched off (or, for the background fills, on): the
