@@ -23,10 +23,10 @@ import sys
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit("no *%s under %s" % (suffix, d))
-    return hits[0]
+    return hits[-1]  # the newest: gpurun_out/ keeps the files of earlier collections next to the new ones
 
 
 def stats(src, dst):
