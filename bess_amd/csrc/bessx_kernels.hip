@@ -2058,7 +2058,12 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
   constexpr int R = 64 * RPT;
   __shared__ int sA[R], sS[R];
   __shared__ double pv[R], qs[R], xs[R], gds[R];
-  __shared__ double part[8][R];
+  // partial products of the 8 waves, two buffers in turn (a step's sums may still be read by a slow wave while a
+  // fast one writes the next step's: one barrier per product is then enough), and one copy of the multiplied vector
+  // per wave (every wave holds it: no barrier between writing and reading one's own copy)
+  __shared__ double part[2][8][R];
+  __shared__ double pvw[8][R];
+  int pbuf = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int off_gs = 0;  // a column of this system outside the slot-indexed copy GS?
@@ -2186,23 +2191,49 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
         }
     }
 #pragma unroll
-    for (int r = 0; r < RPT; r++) part[wave][lane + 64 * r] = acc[r];
+    for (int r = 0; r < RPT; r++) part[pbuf][wave][lane + 64 * r] = acc[r];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-      double t = part[0][lane + 64 * r];
+      double t = part[pbuf][0][lane + 64 * r];
 #pragma unroll
-      for (int w = 1; w < 8; w++) t += part[w][lane + 64 * r];
+      for (int w = 1; w < 8; w++) t += part[pbuf][w][lane + 64 * r];
       y[r] = lane + 64 * r < m ? t : 0.0;  // (rows outside the system may hold any finite matrix entries)
     }
+    pbuf ^= 1;
   };
+  // y = G v for a vector every wave holds in registers (the search direction): through the wave's own LDS copy
   auto matvec = [&](const double (&v)[RPT], double (&y)[RPT]) {
-    if (wave == 0) {
+    double *mine = pvw[wave];
 #pragma unroll
-      for (int r = 0; r < RPT; r++) pv[lane + 64 * r] = v[r];
+    for (int r = 0; r < RPT; r++) mine[lane + 64 * r] = v[r];
+    double acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) acc[r] = 0.0;
+#pragma unroll
+    for (int cb = 0; cb < NCW; cb += 8) {
+      double vj[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++)
+        if (cb + c < NCW) vj[c] = mine[c0 + cb + c];
+#pragma unroll
+      for (int c = 0; c < 8; c++)
+        if (cb + c < NCW) {
+#pragma unroll
+          for (int r = 0; r < RPT; r++) acc[r] = fma(g[r][cb + c], vj[c], acc[r]);
+        }
     }
+#pragma unroll
+    for (int r = 0; r < RPT; r++) part[pbuf][wave][lane + 64 * r] = acc[r];
     __syncthreads();
-    matvec_pv(y);
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      double t = part[pbuf][0][lane + 64 * r];
+#pragma unroll
+      for (int w = 1; w < 8; w++) t += part[pbuf][w][lane + 64 * r];
+      y[r] = lane + 64 * r < m ? t : 0.0;
+    }
+    pbuf ^= 1;
   };
   // q, x and the diagonal live in LDS (x is advanced by wave 0 only): the registers belong to the matrix
   double r_t[RPT], p_t[RPT], ap[RPT];
