@@ -116,10 +116,13 @@ void topk_set_variant(int v);  // test / benchmark hook: 0 = bit-by-bit search, 
 void gram_set_variant(int v);  // 1 = LDS-staged Gram kernel where it applies (default), 0 = k_gram throughout
 bool gram_lds_applies(int ntiles, int tile_base);
 hipError_t gram_lds_prepare();
-hipError_t launch_gram_irls(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
-                            const double *y, const double *w, const double *mask, int rows_per_slab, int nslab, int mt,
-                            double *part, int ntiles, const FitCtrl *ctrl, int slot, int t, int T0,
-                            const double *bcur, double *llpart, hipStream_t st);
+// the IRLS step of the GLM fits in one pass over the active columns (k_irls_gram): up to 8 tile rows
+bool irls_gram_applies(int mt);
+int irls_gram_slab_rows(int mt, long ld);
+hipError_t launch_irls_gram(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
+                            const double *y, const double *w, const double *mask, int nslab, int mt, double *part,
+                            int ntiles, const FitCtrl *ctrl, int slot, int t, int T0, const double *bcur,
+                            double *llpart, hipStream_t st);
 hipError_t launch_gram_reduce(const double *part, int nslab, int ntiles, double *Gt, const FitCtrl *ctrl, int slot,
                               int gate_mode, hipStream_t st);
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
@@ -150,9 +153,18 @@ struct CholFuse {
   const double *zero;  // a word that holds 0.0 (what k_cgr reads for matrix columns outside its system)
   PubArgs pub;         // pub.on: this launch closes a batch of slots and publishes the result block (k_cg / k_cgr)
 };
+// the IRLS convergence test at the head of k_chol (otherwise its own launch, k_glm_irls_check): on = 1
+struct IrlsChk {
+  int on;
+  FitCtrl *ctrl;
+  int t, fam;
+  const double *llpart;  // log-likelihood terms of the iterate the Gram was formed at, nblk of them
+  int nblk, m;           // m = coefficients incl. the intercept
+  double *bcur, *bprev;
+};
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
-                       hipStream_t st, const CholFuse *fuse = nullptr);
+                       hipStream_t st, const CholFuse *fuse = nullptr, const IrlsChk *chk = nullptr);
 // tol: accepted relative residual |q - (G + ridge I) x| <= tol |q|; by_rows: systems of up to 208 unknowns use the
 // row-dealt kernel (k_cgr), otherwise / beyond the tile-dealt one (k_cg)
 hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,

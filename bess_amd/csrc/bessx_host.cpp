@@ -167,11 +167,12 @@ struct bessx_session {
                            // possible: BESSX_HINV=1.  Off by default: measured at parity with the conjugate-gradient solve
                            // (31 vs 30 us per solve launch on configs[1])
   bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
-  // GLM IRLS step with the working response formed inside the Gram kernel (k_gram_irls: one read of the active
-  // columns per step instead of two).  Measured on configs[2]: 0.180 s against 0.175 s unfused -- the 64 rows' exp /
-  // log work and two more barriers per chunk serialise inside a block that has its CU to itself -- so it is OFF
-  // unless BESSX_IRLS_FUSE=1.
-  bool irls_fuse = false;
+  // GLM IRLS step in three launches instead of five: linear predictor, weights, working response and the slab Gram
+  // in ONE pass over the active columns (k_irls_gram), the reduction, then the convergence test at the head of the
+  // solve.  (Round 2's k_gram_irls did the per-row work 64 rows at a time between the barriers of the staging pipeline
+  // and lost, 0.180 s against 0.175 s on configs[2]; it is gone.)
+  bool irls_fuse = true;   // GLM IRLS step as k_irls_gram + k_gram_reduce + k_chol (BESSX_IRLS_FUSE=0: the five-launch step)
+  size_t llpart_cap = 0;
   bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (BESSX_DEFER_PUBLISH=0: in the tail)
   bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
   // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
@@ -1074,19 +1075,22 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
   int mt, mp, ntask, ntiles, rps, nslab;
   if (int rc = glm_geometry(s, T0, &mt, &mp, &ntask, &ntiles, &rps, &nslab)) return rc;
   double *z = s->aux + 2 * s->ld;
-  if (s->irls_fuse && mt <= 16 && gram_lds_applies(ntiles, 0)) {
-    // one pass over the active columns per step: linear predictor, weights and working response are formed inside
-    // the Gram kernel from its LDS tile (k_gram_irls); then the convergence test, the reduction and the solve
-    hipError_t e = launch_gram_irls(fam, s->X, s->aux, s->ld, s->n, s->gcols, s->y, s->w, s->mask[rs], rps, nslab, mt,
-                                    s->gpart, ntiles, s->ctrl, slot, t, T0, s->bcur, s->llpart, s->st);
-    if (e == hipSuccess)
-      e = launch_glm_irls_check(s->ctrl, slot, t, fam, s->llpart, nslab, T0 + 1, s->bcur, s->bprev, s->st);
-    if (e == hipSuccess) e = launch_gram_reduce(s->gpart, nslab, ntiles, s->Gt, s->ctrl, slot, 1, s->st);
-    if (e == hipSuccess)
-      e = launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot, 1,
-                      s->st);
-    if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_irls_step: ") + hipGetErrorString(e));
-    return 0;
+  if (s->irls_fuse && irls_gram_applies(mt)) {
+    // two launches less and one pass over the active columns instead of two: linear predictor, weights and working
+    // response are formed inside the Gram kernel (k_irls_gram), the convergence test at the head of the solve
+    const int rows = irls_gram_slab_rows(mt, s->ld);
+    const int ns = (int)((s->ld + rows - 1) / rows);
+    if ((size_t)ns * ntiles * 256 <= s->gpart_elems && (size_t)ns <= s->llpart_cap) {
+      hipError_t e = launch_irls_gram(fam, s->X, s->aux, s->ld, s->n, s->gcols, s->y, s->w, s->mask[rs], ns, mt,
+                                      s->gpart, ntiles, s->ctrl, slot, t, T0, s->bcur, s->llpart, s->st);
+      if (e == hipSuccess) e = launch_gram_reduce(s->gpart, ns, ntiles, s->Gt, s->ctrl, slot, 1, s->st);
+      const IrlsChk ck = {1, s->ctrl, t, fam, s->llpart, ns, T0 + 1, s->bcur, s->bprev};
+      if (e == hipSuccess)
+        e = launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot, 1,
+                        s->st, nullptr, &ck);
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_irls_step: ") + hipGetErrorString(e));
+      return 0;
+    }
   }
   hipError_t e = launch_glm_irls_prep(fam, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, slot, t, s->A_new, T0,
                                       s->bcur, s->Wv, z, s->llpart, s->st);
@@ -3025,7 +3029,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   s->h_rs.push_back(q);
   HIPT(dmalloc(&s->Wv, (size_t)ld));
   HIPT(hipMemset(s->Wv, 0, (size_t)ld * sizeof(double)));
-  HIPT(dmalloc(&s->llpart, (size_t)std::max(s->n_sse_blk, 1024)));  // (also one entry per row slab of k_gram_irls)
+  s->llpart_cap = (size_t)std::max(s->n_sse_blk, 1024);  // (also one entry per row slab of k_irls_gram)
+  HIPT(dmalloc(&s->llpart, s->llpart_cap));
   HIPT(dmalloc(&s->bcur, (size_t)capA + 16));
   HIPT(dmalloc(&s->bprev, (size_t)capA + 16));
   HIPT(dmalloc(&s->logfact, (size_t)ld));

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -1036,108 +1037,107 @@ __global__ void __launch_bounds__(64 * NW) k_gram_lds(const double *__restrict__
 }
 
 __device__ __forceinline__ double clampv(double v, double c);
-// IRLS step of the GLM fits with k_glm_irls_prep folded into the Gram: the block that has staged 64 rows of every
-// active column in LDS also forms their linear predictor, weight and working response there (same arithmetic, same
-// order), so the step reads the active columns once instead of twice and W, z never go to memory.  The convergence
-// test (k_glm_irls_check) follows; the reduction of the slab partials and the solve stay gated by it.
-template <int NW, int TPW, int NPASS, int GL_RB, int FAM>
-__global__ void __launch_bounds__(64 * NW) k_gram_irls(const double *__restrict__ X, const double *__restrict__ aux,
-                                                       long ld, int n, const int *__restrict__ cols,
-                                                       const double *__restrict__ y, const double *__restrict__ w,
-                                                       const double *__restrict__ mask, int rows_per_slab, int nslab,
-                                                       int mt, double *__restrict__ part, int ntiles,
-                                                       const FitCtrl *__restrict__ ctrl, int slot, int t, int T0,
-                                                       const double *__restrict__ bcur,
-                                                       double *__restrict__ llpart) {
+// IRLS step t of the GLM restricted fits (logistic :1148-1204, Poisson :1273-1322) in ONE pass over the active
+// columns: linear predictor, working weights, working response, log-likelihood terms AND the slab's weighted Gram
+// [1, X_A, z]^T diag(W w mask) [1, X_A, z] -- what k_glm_irls_prep + k_gram_lds did in two launches and two reads of
+// X_A (round 2; an earlier fusion, k_gram_irls, did the per-row work chunk by chunk between the barriers of the
+// staging pipeline and was no faster).  Here one 512-thread block owns a row slab (about one slab per compute unit)
+// and walks it in groups of NCH 64-row chunks; per group it
+//   (A) has ALL the group's loads in flight at once (thread (ru, cb): row pair ru of every chunk, columns cb, cb + 16,
+//       ...; coalesced 16-byte loads, NCH x NPASS per thread) and KEEPS them in registers -- the loads of the next
+//       group are issued chunk by chunk as the registers are emptied into the tile in (C), under the products;
+//   (B) forms the linear predictor from those registers (per-thread partial over its columns, the two column halves
+//       of a wave folded by one cross-lane add, the 8 waves through LDS), then EVERY row of the slab gets its
+//       exp / log / division at once, one row per thread -- not 64 rows at a time between barriers;
+//   (C) stages chunk after chunk from the registers into the LDS tile (no second read of X_A), the working response
+//       as the last column, and multiplies on the fp64 matrix cores exactly like k_gram_lds.
+// Output: the slab partials of all tiles (k_gram_reduce adds them up) and the slab's log-likelihood term (the
+// convergence test at the head of k_chol adds those up).  Same arithmetic per row as k_glm_irls_prep; the linear
+// predictor is summed in a different (fixed) order.
+template <int NPASS, int NCH, int TPW, int FAM>
+__global__ void __launch_bounds__(512) k_irls_gram(const double *__restrict__ X, const double *__restrict__ aux,
+                                                   long ld, int n, const int *__restrict__ cols,
+                                                   const double *__restrict__ y, const double *__restrict__ w,
+                                                   const double *__restrict__ mask, int rows_per_slab, int mt,
+                                                   double *__restrict__ part, int ntiles,
+                                                   const FitCtrl *__restrict__ ctrl, int slot, int t, int T0,
+                                                   const double *__restrict__ bcur, double *__restrict__ llpart) {
   if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
-  constexpr bool WEIGHTED = true;
-  extern __shared__ double smem[];  // [mp][GL_LD], then the weights of the chunk
-  constexpr int GL_LD = GL_RB + 2, TPC = GL_RB / 2;  // padded column stride; threads per column (a row pair each)
-  constexpr int NT = 64 * NW, CPP = NT / TPC;         // columns staged per pass
+  constexpr int RB = 64, GL_LD = RB + 2, TPC = RB / 2, NW = 8, CPP = 64 * NW / TPC, ROWS = NCH * RB;
+  extern __shared__ double smem[];  // [tile: mp x GL_LD | etap: NW x ROWS (phase B only)] Wl[ROWS] zl[ROWS] bet[mp]
   const int mp = mt * 16;
-  double *wch = smem + (size_t)mp * GL_LD;  // IRLS weight of the chunk's rows (W w mask)
-  double *ych = wch + GL_RB, *owch = ych + GL_RB, *mkch = owch + GL_RB;  // y, observation weight, row mask
-  double *etap = mkch + GL_RB;                                            // [4][GL_RB] partial linear predictors
-  double *bet = etap + 4 * GL_RB;                                         // the iterate: intercept, T0 coefficients
-  for (int i = threadIdx.x; i <= T0; i += 64 * NW) bet[i] = bcur[i];
+  const size_t tile_doubles = (size_t)mp * GL_LD > (size_t)NW * ROWS ? (size_t)mp * GL_LD : (size_t)NW * ROWS;
+  double *etap = smem;
+  double *Wl = smem + tile_doubles, *zl = Wl + ROWS, *bet = zl + ROWS;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ru = tid % TPC, cb = tid / TPC;
   const int slab = blockIdx.x;
   const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
-  const int nchunk = (int)((r_end - r_begin + GL_RB - 1) / GL_RB);
-  // column pointers: kept in registers, except in the largest instance where the accumulators need them (there the
-  // column index is re-read per chunk: one cached load against 64 rows of MFMA work)
-  constexpr bool PTRS = TPW <= 10;
-  const double *src[PTRS ? NPASS : 1];
-  if (PTRS) {
+  const int ngroup = (int)((r_end - r_begin + ROWS - 1) / ROWS);  // the slab in groups of NCH chunks
+  for (int i = tid; i < mp; i += 64 * NW) bet[i] = i <= T0 ? bcur[i] : 0.0;
+  // (A) every load of a group in flight at once.  Column mp - 1 is the working response: formed here, never read.
+  int cidx[NPASS];  // column of X (>= 0), auxiliary column (-1, -2), or none (INT_MIN): the pointer is formed per load
 #pragma unroll
-    for (int i = 0; i < NPASS; i++) {
-      const int col = i * CPP + cb;
-      src[i] = gram_col(X, aux, ld, col < mp ? cols[col] : cols[0]) + 2 * ru;
-    }
+  for (int i = 0; i < NPASS; i++) {
+    const int col = i * CPP + cb;
+    cidx[i] = (col < mp - 1) ? cols[col] : INT_MIN;
   }
-  d2 st[NPASS], wst = d2{0.0, 0.0}, yst = d2{0.0, 0.0}, mst = d2{0.0, 0.0};
-  auto load = [&](long r0) {
-    const bool in = r0 + 2 * ru < r_end;  // slabs end on multiples of 16 rows: a row pair is in or out as a whole
+  d2 st[NCH][NPASS];
+  auto load_chunk = [&](int ch, long g_begin) {
+    const long r0 = g_begin + (long)ch * RB + 2 * ru;
+    const bool in = r0 < r_end;  // ld is a multiple of 16: a row pair is in or out as a whole
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
-      st[i] = d2{0.0, 0.0};
-      if (in && i * CPP + cb < mp) {
-        const double *q_ = PTRS ? src[i] : gram_col(X, aux, ld, cols[i * CPP + cb]) + 2 * ru;
-        st[i] = *reinterpret_cast<const d2 *>(q_ + r0);
-      }
-    }
-    if (tid < TPC) {
-      yst = in ? *reinterpret_cast<const d2 *>(y + r0 + 2 * ru) : d2{0.0, 0.0};
-      wst = in ? *reinterpret_cast<const d2 *>(w + r0 + 2 * ru) : d2{0.0, 0.0};
-      mst = (in && mask != nullptr) ? *reinterpret_cast<const d2 *>(mask + r0 + 2 * ru) : d2{in ? 1.0 : 0.0, in ? 1.0 : 0.0};
+      st[ch][i] = d2{0.0, 0.0};
+      if (in && cidx[i] != INT_MIN) st[ch][i] = *reinterpret_cast<const d2 *>(gram_col(X, aux, ld, cidx[i]) + r0);
     }
   };
-  auto store = [&]() {
 #pragma unroll
-    for (int i = 0; i < NPASS; i++) {
-      const int col = i * CPP + cb;
-      if (col < mp) *reinterpret_cast<d2 *>(smem + (size_t)col * GL_LD + 2 * ru) = st[i];
-    }
-    if (tid < TPC) {
-      *reinterpret_cast<d2 *>(ych + 2 * ru) = yst;
-      *reinterpret_cast<d2 *>(owch + 2 * ru) = wst;
-      *reinterpret_cast<d2 *>(mkch + 2 * ru) = mst;
-    }
-  };
+  for (int ch = 0; ch < NCH; ch++) load_chunk(ch, r_begin);
   int tI[TPW], tJ[TPW];
   d4 acc[TPW];
 #pragma unroll
   for (int ts = 0; ts < TPW; ts++) {
-    const int t = wv + NW * ts;
+    const int tt = wv + NW * ts;
     int I = -1, J = -1;
-    if (t < ntiles) tile_of(t, I, J);
+    if (tt < ntiles) tile_of(tt, I, J);
     tI[ts] = __builtin_amdgcn_readfirstlane(I);
     tJ[ts] = __builtin_amdgcn_readfirstlane(J);
     acc[ts] = d4{0.0, 0.0, 0.0, 0.0};
   }
-  // k_glm_irls_prep on the rows of the staged chunk: linear predictor from the LDS tile with the same four
-  // interleaved accumulators and the same order as lin_pred2 (bit-identical eta), then the family's weight and
-  // working response; z goes into its column of the tile, W w mask into wch
   double ll = 0.0;
-  auto prep = [&](long r0) {
-    const int row = tid % GL_RB, pt = tid / GL_RB;
-    if (pt < 4) {
-      double acc = 0.0;
-      const int k4 = T0 & ~3;
-      for (int a = pt; a < k4; a += 4) acc = fma(smem[(size_t)(a + 1) * GL_LD + row], bet[a + 1], acc);
-      if (pt == 0)
-        for (int a = k4; a < T0; a++) acc = fma(smem[(size_t)(a + 1) * GL_LD + row], bet[a + 1], acc);
-      etap[pt * GL_RB + row] = acc;
+  for (int g = 0; g < ngroup; g++) {
+    const long g_begin = r_begin + (long)g * ROWS;
+    const int nch = (int)((min(g_begin + ROWS, r_end) - g_begin + RB - 1) / RB);
+    double yy = 0.0, ww = 0.0, mm = 0.0;
+    const long myrow = g_begin + tid;
+    const bool rin = tid < ROWS && myrow < (long)n && myrow < r_end;  // (a group may reach beyond a short slab)
+    if (rin) {
+      yy = y[myrow];
+      ww = w[myrow];
+      mm = mask != nullptr ? mask[myrow] : 1.0;
+    }
+    __syncthreads();  // bet is there; the previous group's products have let go of the tile
+    // (B) linear predictor of every row of the group
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+      d2 e = d2{0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < NPASS; i++) {
+        const int col = i * CPP + cb;
+        e += st[ch][i] * (col < mp ? bet[col] : 0.0);
+      }
+      e.x += __shfl_xor(e.x, 32);  // the wave holds two column classes (cb even / odd) of the same row pairs
+      e.y += __shfl_xor(e.y, 32);
+      if (lane < 32) *reinterpret_cast<d2 *>(etap + (size_t)wv * ROWS + ch * RB + 2 * ru) = e;
     }
     __syncthreads();
-    if (tid < GL_RB) {
-      const bool in = r0 + row < (long)n;
-      double eta = ((etap[row] + etap[GL_RB + row]) + (etap[2 * GL_RB + row] + etap[3 * GL_RB + row])) + bet[0];
-      const double yy = ych[row], ww = owch[row], mm = mkch[row];
+    if (tid < ROWS) {
+      double eta = ((etap[tid] + etap[ROWS + tid]) + (etap[2 * ROWS + tid] + etap[3 * ROWS + tid])) +
+                   ((etap[4 * ROWS + tid] + etap[5 * ROWS + tid]) + (etap[6 * ROWS + tid] + etap[7 * ROWS + tid]));
       double Wt = 0.0, zt = 0.0;
-      if (in) {
+      if (rin) {
         if (FAM == 2) {
           const double e = exp(clampv(eta, 30.0)), Pi = e / (1.0 + e);
           ll += (yy * log(Pi) + (1.0 - yy) * log(1.0 - Pi)) * ww * mm;
@@ -1159,68 +1159,64 @@ __global__ void __launch_bounds__(64 * NW) k_gram_irls(const double *__restrict_
           Wt = e * ww * mm;
         }
       }
-      smem[(size_t)(mp - 1) * GL_LD + row] = zt;  // the working response is the last column (k_gram_cols)
-      wch[row] = Wt;
+      Wl[tid] = Wt;
+      zl[tid] = zt;
     }
-    __syncthreads();
-  };
-  auto compute = [&]() {
+    __syncthreads();  // (etap is dead from here on: the tile takes its place)
+    // (C) the group's Gram, chunk by chunk from the registers; a chunk's registers are refilled with the same chunk
+    // of the NEXT group as soon as it is in the tile, so those loads fly under the products
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ch++) {
+      if (ch > 0) __syncthreads();
 #pragma unroll
-    for (int ts = 0; ts < TPW; ts++) {
-      if (tI[ts] >= 0) {  // wave-uniform
-        const double *pa = smem + (size_t)(tI[ts] * 16 + c) * GL_LD + 4 * q;
-        const double *pb = smem + (size_t)(tJ[ts] * 16 + c) * GL_LD + 4 * q;
+      for (int c2 = 0; c2 < NCH; c2++) {
+        if (ch == c2) {  // block-uniform: the register array is indexed by a constant
 #pragma unroll
-        for (int sx = 0; sx < GL_RB / 16; sx++) {
-          const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * sx), a1 = *reinterpret_cast<const d2 *>(pa + 16 * sx + 2);
-          const d2 b0 = *reinterpret_cast<const d2 *>(pb + 16 * sx), b1 = *reinterpret_cast<const d2 *>(pb + 16 * sx + 2);
-          double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
-          if (WEIGHTED) {
+          for (int i = 0; i < NPASS; i++) {
+            const int col = i * CPP + cb;
+            if (col < mp - 1) *reinterpret_cast<d2 *>(smem + (size_t)col * GL_LD + 2 * ru) = st[c2][i];
+          }
+          if (g + 1 < ngroup) load_chunk(c2, g_begin + ROWS);
+        }
+      }
+      if (cb == (mp - 1) % CPP)
+        *reinterpret_cast<d2 *>(smem + (size_t)(mp - 1) * GL_LD + 2 * ru) = *reinterpret_cast<const d2 *>(zl + ch * RB + 2 * ru);
+      __syncthreads();
+      const double *wch = Wl + ch * RB;
+#pragma unroll
+      for (int ts = 0; ts < TPW; ts++) {
+        if (tI[ts] >= 0) {  // wave-uniform
+          const double *pa = smem + (size_t)(tI[ts] * 16 + c) * GL_LD + 4 * q;
+          const double *pb = smem + (size_t)(tJ[ts] * 16 + c) * GL_LD + 4 * q;
+#pragma unroll
+          for (int sx = 0; sx < RB / 16; sx++) {
+            const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * sx), a1 = *reinterpret_cast<const d2 *>(pa + 16 * sx + 2);
+            const d2 b0 = *reinterpret_cast<const d2 *>(pb + 16 * sx), b1 = *reinterpret_cast<const d2 *>(pb + 16 * sx + 2);
             const d2 w0 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q);
             const d2 w1 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q + 2);
-            ax *= w0.x;
-            ay *= w0.y;
-            az *= w1.x;
-            aw *= w1.y;
+            acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x * w0.x, b0.x, acc[ts], 0, 0, 0);
+            acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y * w0.y, b0.y, acc[ts], 0, 0, 0);
+            acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x * w1.x, b1.x, acc[ts], 0, 0, 0);
+            acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y * w1.y, b1.y, acc[ts], 0, 0, 0);
           }
-          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0.x, acc[ts], 0, 0, 0);
-          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b0.y, acc[ts], 0, 0, 0);
-          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b1.x, acc[ts], 0, 0, 0);
-          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b1.y, acc[ts], 0, 0, 0);
         }
       }
     }
-  };
-  if (nchunk > 0) {
-    load(r_begin);
-    store();
-    if (nchunk > 1) load(r_begin + GL_RB);
-    __syncthreads();
-    for (int k = 0; k < nchunk; k++) {
-      prep(r_begin + (long)k * GL_RB);
-      compute();
-      __syncthreads();
-      if (k + 1 < nchunk) store();
-      __syncthreads();
-      if (k + 2 < nchunk) load(r_begin + (long)(k + 2) * GL_RB);
-    }
   }
-  {  // log-likelihood terms of this slab (k_glm_irls_check adds the slabs up)
+  {  // log-likelihood terms of this slab (the convergence test adds the slabs up)
     __shared__ double llw[NW];
     ll = wave_sum(ll);
-    if ((tid & 63) == 0) llw[tid >> 6] = ll;
+    if (lane == 0) llw[wv] = ll;
     __syncthreads();
-    if (tid == 0) {
-      double tl = 0.0;
-      for (int q = 0; q < NW; q++) tl += llw[q];
-      llpart[slab] = tl;
-    }
+    if (tid == 0)
+      llpart[slab] = ((llw[0] + llw[1]) + (llw[2] + llw[3])) + ((llw[4] + llw[5]) + (llw[6] + llw[7]));
   }
   double *out = part + (size_t)slab * ntiles * 256;
 #pragma unroll
   for (int ts = 0; ts < TPW; ts++)
     if (tI[ts] >= 0) *reinterpret_cast<d4 *>(out + (size_t)(wv + NW * ts) * 256 + lane * 4) = acc[ts];
 }
+
 
 __global__ void __launch_bounds__(256) k_gram_reduce(const double *__restrict__ part, int nslab, int ntiles,
                                                      double *__restrict__ Gt, const FitCtrl *__restrict__ ctrl,
@@ -1445,12 +1441,17 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
 // fz.G != nullptr (covariance mode of the LM fit): the Gram entries are gathered from the column cache
 // (G[row A_a, column slot_of[A_b]]) instead of read from Gt, and the kernel ends with the work of k_commit -- two
 // launches less per PDAS iteration.
+template <int NT>
+__device__ __forceinline__ bool irls_check_body(FitCtrl *__restrict__ ctrl, int t, int fam,
+                                                const double *__restrict__ llpart, int nblk, int m,
+                                                double *__restrict__ bcur, double *__restrict__ bprev);
+
 template <int CH_SLOTS>  // register tiles per wave: 5 (mt <= 8), 7 (<= 10), 10 (<= 12), 14 (<= 14), 17 (<= 16)
 __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int m, int mt, double ridge,
                                               int ridge_skip0, const double *__restrict__ rhs,
                                               const int *__restrict__ rhs_gather, double *__restrict__ sol,
                                               int *__restrict__ info, const FitCtrl *__restrict__ ctrl, int slot,
-                                              int gate_mode, const CholFuse fz) {
+                                              int gate_mode, const CholFuse fz, const IrlsChk ck) {
   __shared__ int same_any_sh;
   if (ctrl != nullptr) {
     if (ctrl->done || ctrl->l != slot - 1) return;
@@ -1461,6 +1462,12 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
       return;
     }
     if ((gate_mode == 1 || gate_mode == 2) && ctrl->irls_done) return;
+  }
+  if (ck.on) {
+    // IRLS step t, convergence test first (what k_glm_irls_check does as its own launch): the log-likelihood terms
+    // of the iterate this Gram was formed at are in ck.llpart.  Converged (or out of steps): nothing is solved.
+    if (ck.ctrl->irls_steps != ck.t) return;
+    if (irls_check_body<512>(ck.ctrl, ck.t, ck.fam, ck.llpart, ck.nblk, ck.m, ck.bcur, ck.bprev)) return;
   }
   // LDS images are addressed by integer offsets.  The single-wave phases below pass data between
   // lanes through LDS; WAVE_SYNC orders them (LDS executes one wave's DS operations in order; the
@@ -3755,17 +3762,21 @@ __global__ void __launch_bounds__(128) k_glm_irls_prep(const double *__restrict_
 // IRLS step t, convergence test (single block).  Logistic (:1181): |ll0 - ll1| / (0.1 + |ll1|) < 1e-6, result =
 // iterate BEFORE the last solve, at most 30 tests; Poisson (:1315): |ll0 - ll1| / |0.1 + ll0| < 1e-6 with
 // ll0 = 1e5 initially, result = the latest iterate, at most 50 solves.  On exit with irls_done the
-// result sits in bprev (what k_commit reads).
-__global__ void __launch_bounds__(256) k_glm_irls_check(FitCtrl *__restrict__ ctrl, int slot, int t, int fam,
-                                                        const double *__restrict__ llpart, int nblk, int m,
-                                                        double *__restrict__ bcur, double *__restrict__ bprev) {
-  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
-  __shared__ double sm[4];
+// result sits in bprev (what k_commit reads).  Returns (block-uniform) whether the chain has ended.
+template <int NT>
+__device__ __forceinline__ bool irls_check_body(FitCtrl *__restrict__ ctrl, int t, int fam,
+                                                const double *__restrict__ llpart, int nblk, int m,
+                                                double *__restrict__ bcur, double *__restrict__ bprev) {
+  __shared__ double sm[NT / 64];
   __shared__ int fin;
   double s = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 256) s += llpart[b];
-  s = block_sum_256(s, sm);
+  for (int b = threadIdx.x; b < nblk; b += NT) s += llpart[b];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    s = 0.0;
+    for (int q = 0; q < NT / 64; q++) s += sm[q];
     int done = 0;
     if (fam == 2) {
       if (t == 0) {
@@ -3788,12 +3799,20 @@ __global__ void __launch_bounds__(256) k_glm_irls_check(FitCtrl *__restrict__ ct
   __syncthreads();
   const int f = fin;
   if (f != 2)
-    for (int i = threadIdx.x; i < m; i += 256) bprev[i] = bcur[i];
+    for (int i = threadIdx.x; i < m; i += NT) bprev[i] = bcur[i];
   __syncthreads();
   if (threadIdx.x == 0) {
     ctrl->irls_steps = t + 1;
     if (f != 0) ctrl->irls_done = 1;
   }
+  return f != 0;
+}
+
+__global__ void __launch_bounds__(256) k_glm_irls_check(FitCtrl *__restrict__ ctrl, int slot, int t, int fam,
+                                                        const double *__restrict__ llpart, int nblk, int m,
+                                                        double *__restrict__ bcur, double *__restrict__ bprev) {
+  if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
+  irls_check_body<256>(ctrl, t, fam, llpart, nblk, m, bcur, bprev);
 }
 
 // start of the sub-model fit of one PDAS iteration: logistic starts from zero (:1155), Poisson from
@@ -6267,43 +6286,65 @@ hipError_t gram_lds_prepare() {
   GL_ATTR((k_gram_lds<8, 10, 12, 64, false>));
   GL_ATTR((k_gram_lds<8, 17, 8, 32, true>));
   GL_ATTR((k_gram_lds<8, 17, 8, 32, false>));
-  GL_ATTR((k_gram_irls<4, 9, 16, 64, 2>));
-  GL_ATTR((k_gram_irls<4, 9, 16, 64, 3>));
-  GL_ATTR((k_gram_irls<8, 10, 12, 64, 2>));
-  GL_ATTR((k_gram_irls<8, 10, 12, 64, 3>));
-  GL_ATTR((k_gram_irls<8, 17, 8, 32, 2>));
-  GL_ATTR((k_gram_irls<8, 17, 8, 32, 3>));
+  GL_ATTR((k_irls_gram<2, 8, 1, 2>));
+  GL_ATTR((k_irls_gram<2, 8, 1, 3>));
+  GL_ATTR((k_irls_gram<3, 8, 1, 2>));
+  GL_ATTR((k_irls_gram<3, 8, 1, 3>));
+  GL_ATTR((k_irls_gram<4, 6, 2, 2>));
+  GL_ATTR((k_irls_gram<4, 6, 2, 3>));
+  GL_ATTR((k_irls_gram<5, 5, 2, 2>));
+  GL_ATTR((k_irls_gram<5, 5, 2, 3>));
+  GL_ATTR((k_irls_gram<6, 4, 3, 2>));
+  GL_ATTR((k_irls_gram<6, 4, 3, 3>));
+  GL_ATTR((k_irls_gram<7, 3, 4, 2>));
+  GL_ATTR((k_irls_gram<7, 3, 4, 3>));
+  GL_ATTR((k_irls_gram<8, 2, 5, 2>));
+  GL_ATTR((k_irls_gram<8, 2, 5, 3>));
 #undef GL_ATTR
   return e;
 }
 
-// fused IRLS step (k_gram_irls): slab partials of the weighted Gram + the slabs' log-likelihood terms.  The caller
-// runs k_glm_irls_check next, then launch_gram_reduce() and the solve (both gated by the check's verdict).
-hipError_t launch_gram_irls(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
-                            const double *y, const double *w, const double *mask, int rows_per_slab, int nslab, int mt,
-                            double *part, int ntiles, const FitCtrl *ctrl, int slot, int t, int T0,
-                            const double *bcur, double *llpart, hipStream_t st) {
-  if (mt < 1 || mt > 16 || T0 + 2 > mt * 16) return hipErrorInvalidValue;  // intercept, T0 columns, ..., z last
-#define GI_GO(NW_, TPW_, NP_, RB_, FAM_)                                                                             \
-  do {                                                                                                               \
-    const size_t lds = ((size_t)mt * 16 * (RB_ + 2) + 8 * RB_ + (size_t)mt * 16) * sizeof(double);                   \
-    hipLaunchKernelGGL((k_gram_irls<NW_, TPW_, NP_, RB_, FAM_>), dim3(nslab), dim3(64 * NW_), lds, st, X, aux, ld, n, \
-                       cols, y, w, mask, rows_per_slab, nslab, mt, part, ntiles, ctrl, slot, t, T0, bcur, llpart);   \
+// fused IRLS step (k_irls_gram): slab partials of the weighted Gram + the slabs' log-likelihood terms.  The caller
+// follows it with k_gram_reduce and k_chol (whose head is the convergence test).  Slabs are NCH 64-row chunks: 8 chunks
+// up to 4 tile rows, 4 beyond (the registers that hold the slab between the two uses bound NCH x tile rows).
+// rows per slab: about one slab per compute unit (whole 64-row chunks), at least one group of chunks
+// rows per slab: about one slab per compute unit, whole 64-row chunks
+int irls_gram_slab_rows(int mt, long ld) {
+  (void)mt;
+  return (int)(((ld + 255) / 256 + 63) / 64 * 64);
+}
+bool irls_gram_applies(int mt) { return g_gram_variant == 1 && mt >= 1 && mt <= 8; }
+hipError_t launch_irls_gram(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
+                            const double *y, const double *w, const double *mask, int nslab, int mt, double *part,
+                            int ntiles, const FitCtrl *ctrl, int slot, int t, int T0, const double *bcur,
+                            double *llpart, hipStream_t st) {
+  if (!irls_gram_applies(mt) || T0 + 2 > mt * 16) return hipErrorInvalidValue;  // intercept, T0 columns, ..., z last
+  const int rows = irls_gram_slab_rows(mt, ld);
+  if ((long)nslab * rows < ld) return hipErrorInvalidValue;
+#define IG_GO(NP_, NCH_, TPW_, FAM_)                                                                               \
+  do {                                                                                                             \
+    const size_t tile = std::max((size_t)mt * 16 * 66, (size_t)8 * NCH_ * 64);                                     \
+    const size_t lds = (tile + 2 * (size_t)NCH_ * 64 + (size_t)mt * 16) * sizeof(double);                          \
+    hipLaunchKernelGGL((k_irls_gram<NP_, NCH_, TPW_, FAM_>), dim3(nslab), dim3(512), lds, st, X, aux, ld, n, cols, \
+                       y, w, mask, rows, mt, part, ntiles, ctrl, slot, t, T0, bcur, llpart);                       \
   } while (0)
-#define GI_FAM(NW_, TPW_, NP_, RB_) \
-  if (fam == 2)                     \
-    GI_GO(NW_, TPW_, NP_, RB_, 2);  \
-  else                              \
-    GI_GO(NW_, TPW_, NP_, RB_, 3)
-  if (mt <= 8) {
-    GI_FAM(4, 9, 16, 64);
-  } else if (mt <= 12) {
-    GI_FAM(8, 10, 12, 64);
-  } else {
-    GI_FAM(8, 17, 8, 32);
+#define IG_FAM(NP_, NCH_, TPW_) \
+  if (fam == 2)                 \
+    IG_GO(NP_, NCH_, TPW_, 2);  \
+  else                          \
+    IG_GO(NP_, NCH_, TPW_, 3)
+  switch (mt) {
+    case 1:
+    case 2: IG_FAM(2, 8, 1); break;
+    case 3: IG_FAM(3, 8, 1); break;
+    case 4: IG_FAM(4, 6, 2); break;
+    case 5: IG_FAM(5, 5, 2); break;
+    case 6: IG_FAM(6, 4, 3); break;
+    case 7: IG_FAM(7, 3, 4); break;
+    default: IG_FAM(8, 2, 5); break;
   }
-#undef GI_FAM
-#undef GI_GO
+#undef IG_FAM
+#undef IG_GO
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -6389,15 +6430,17 @@ hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, in
 
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
-                       hipStream_t st, const CholFuse *fuse) {
+                       hipStream_t st, const CholFuse *fuse, const IrlsChk *chk) {
   if (mt < 1 || m + 1 > mt * 16) return hipErrorInvalidValue;
   if (mt > CH_MT) return hipErrorInvalidValue;  // callers route larger systems to launch_chol_big
   CholFuse fz = {};
   if (fuse) fz = *fuse;
+  IrlsChk ck = {};
+  if (chk) ck = *chk;
   // register tiles per wave = ceil(mt (mt + 1) / 2 / 8): the smallest instance that fits (fewer live accumulators)
 #define CHOL_GO(S)                                                                                                   \
   hipLaunchKernelGGL(k_chol<S>, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol, info, \
-                     ctrl, slot, gate_mode, fz)
+                     ctrl, slot, gate_mode, fz, ck)
   if (mt <= 8)
     CHOL_GO(5);
   else if (mt <= 10)

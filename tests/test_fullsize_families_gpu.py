@@ -27,8 +27,11 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _gold(name):
+    """The committed golden vectors of the compiled reference.  A missing file is a FAILURE, not a skip: these are
+    the strongest comparisons of the suite and the files are part of the repository."""
     path = os.path.join(GOLDEN, name)
-    return np.load(path) if os.path.exists(path) else None
+    assert os.path.exists(path), "golden file %s is missing (tests/golden/make_fullsize_ref.py regenerates it)" % path
+    return np.load(path)
 
 
 def assert_matches_golden(trace, g, what, beta_rtol=1e-6, metric_rtol=1e-8):
@@ -110,8 +113,6 @@ def test_logistic_config_properties_at_full_size(logistic_full):
 
 def test_logistic_config_matches_compiled_reference_at_full_size(logistic_full):
     g = _gold("fullsize_logistic.npz")
-    if g is None:
-        pytest.skip("tests/golden/fullsize_logistic.npz not generated")
     _, out, _, _ = logistic_full
     nfit = assert_matches_golden(out["trace"], g, "configs[2] logistic n=100000 p=5000", beta_rtol=1e-6)
     assert nfit >= 20
@@ -165,8 +166,6 @@ def test_lm_cv_golden_section_properties_at_full_size(lmcv_full):
 
 def test_lm_cv_golden_section_matches_compiled_reference_at_full_size(lmcv_full):
     g = _gold("fullsize_lmcv.npz")
-    if g is None:
-        pytest.skip("tests/golden/fullsize_lmcv.npz not generated")
     outs, _, _ = lmcv_full
     for mode in (2, 1):
         nfit = assert_matches_golden(outs[mode]["trace"], g, "configs[3] LM gs_path + 5-fold CV, score_mode %d" % mode)
@@ -181,8 +180,6 @@ def test_cox_config_recipe_matches_compiled_reference_at_n4000(gpu):
     """The configs[4] recipe (synth.make_cox, SEED_COX) at the largest n the reference's dense n x n risk-set matrix
     allows: every PDAS iteration of k = 1..40 on n = 4000, p = 2000 against the compiled reference."""
     g = _gold("fullsize_cox_n4000.npz")
-    if g is None:
-        pytest.skip("tests/golden/fullsize_cox_n4000.npz not generated")
     n, p, ktrue, kmax = int(g["n"]), int(g["p"]), int(g["k_true"]), int(g["kmax"])
     X, _, status, support, _ = synth.make_cox(n, p, ktrue)
     for form in ("1pass", "2pass"):

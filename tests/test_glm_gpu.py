@@ -78,8 +78,10 @@ def test_poisson_cv(gpu):
 
 
 def test_fused_irls_step_gives_the_same_fits(gpu, monkeypatch):
-    """BESSX_IRLS_FUSE=1 (working response formed inside the Gram kernel, off by default: measured no faster) runs
-    the same arithmetic in the same order: identical supports, iteration counts and coefficients."""
+    """The three-launch IRLS step (k_irls_gram: linear predictor, weights, working response and Gram in one pass; the
+    convergence test at the head of the solve; the default) against the five-launch step (BESSX_IRLS_FUSE=0): the same
+    arithmetic per row, the linear predictor summed in another order -- identical supports, PDAS iteration counts and
+    IRLS step counts, coefficients to rounding."""
     X, y, _, _ = synth.make_logistic(1500, 300, 8, seed=6)
     Xp, yp = X[:, :120], np.random.default_rng(5).poisson(np.exp(np.clip(0.3 * X[:, 0] - 0.2 * X[:, 3], -3, 3))).astype(float)
     outs = []
