@@ -215,7 +215,14 @@ struct CoxBufs {
   int one_pass;                                        // score pass reads X once (k_cox_score1p)
   int need_uv;                                         // CU / CV wanted although the score is not one-pass (groups)
   double *ldl_work;                                    // 256 x 256: dense copy for the LDL^T fallback of the Newton solve
+  // one-pass Hessian of the Newton step (k_cox_hess): weights of the second Gram, its slab partials, per slab the
+  // column totals of theta x, the slab carries and the vectors q_b
+  int hess_fused;
+  double *CW, *HP2, *HT, *CAR, *HQ;
 };
+int cox_hess_slab_rows(long ld);
+bool cox_hess_applies(int mt);
+hipError_t cox_hess_prepare();
 size_t cox_scan_scratch_doubles(long ld, int kmax);
 hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, const double *w, const double *mask,
                             const FitCtrl *ctrl, int when, const int *A_cur, const double *b_cur, CoxBufs cb,

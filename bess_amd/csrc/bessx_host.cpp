@@ -1174,7 +1174,9 @@ static int enqueue_cox_head(bessx_session *s, int slot, int T0, double lambda, i
     e = launch_cox_score(s->part_rs[rs], s->cox.one_pass ? nullptr : s->part2_rs[rs], s->nrb, s->p, s->beta_dense,
                          lambda, s->always, s->bd, s->ctrl, slot, s->st);
   if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
+  // (one-pass Hessian: the column behind the active ones is the bookkeeping column of k_cox_hess)
+  const int aux_col = (s->cox.hess_fused && cox_hess_applies(mt)) ? 2 : 0;
+  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, aux_col, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
   if (e == hipSuccess) e = launch_cox_newton_begin(s->ctrl, slot, T0, s->cox, s->idcols, s->st);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cox_head: ") + hipGetErrorString(e));
   return 0;
@@ -1412,7 +1414,8 @@ static int algorithm_fit_grouped(bessx_session *s) {
       // GroupPdasCox::primary_model_fit on the expanded columns: the Newton chain of the ungrouped path
       if (int rc = cox_reserve(s, K)) return rc;
       const int mp = (K + 1 + 15) / 16 * 16;
-      e = launch_gram_cols(s->gcols_new, K, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 0, s->st);
+      e = launch_gram_cols(s->gcols_new, K, mp, 0, (s->cox.hess_fused && cox_hess_applies(mp / 16)) ? 2 : 0, s->gcols,
+                           s->ctrl, slot, s->A_cur, 0, s->st);
       if (e == hipSuccess) e = launch_cox_newton_begin(s->ctrl, slot, K, s->cox, s->idcols, s->st);
       if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group cox begin: ") + hipGetErrorString(e));
       const int tmax = 30;
@@ -3200,6 +3203,23 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(V(&c.Gt2, (size_t)136 * 256));
     HIPT(V(&c.llpart, (size_t)(n + 255) / 256 + 1));
     HIPT(V(&c.SCR, cox_scan_scratch_doubles(ld, 256)));
+    // one-pass Hessian of the Newton step (k_cox_hess, up to 10 tile rows; BESSX_COX_HESS=2pass: M = S1 / S0
+    // materialised and two Gram launches, as in round 2)
+    c.hess_fused = 1;
+    if (const char *ev = std::getenv("BESSX_COX_HESS")) c.hess_fused = std::string(ev) != "2pass";
+    if (c.hess_fused) {
+      const size_t hrows = (size_t)cox_hess_slab_rows(ld), hns = ((size_t)ld + hrows - 1) / hrows;
+      if (hns * 55 * 256 > s->gpart_elems) {
+        c.hess_fused = 0;  // (cannot happen with the default workspace: 256 slabs x 55 tiles)
+      } else {
+        HIPT(cox_hess_prepare());
+        HIPT(V(&c.CW, (size_t)ld));
+        HIPT(V(&c.HP2, hns * 55 * 256));
+        HIPT(V(&c.HT, hns * 160));
+        HIPT(V(&c.CAR, hns * 160));
+        HIPT(V(&c.HQ, hns * 160));
+      }
+    }
   }
   if (s->model_type == 1) TRY(prepare_rowset(s, 0));
   HIPT(hipStreamSynchronize(s->st));

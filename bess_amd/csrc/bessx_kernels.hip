@@ -4280,7 +4280,8 @@ __global__ void __launch_bounds__(SC_T) k_cox_cscan_apply(const double *__restri
                                                           const double *__restrict__ THF, double *__restrict__ VG,
                                                           double *__restrict__ WG1, long n, long ld,
                                                           const double *__restrict__ scr,
-                                                          const FitCtrl *__restrict__ ctrl, int slot, int t) {
+                                                          const FitCtrl *__restrict__ ctrl, int slot, int t,
+                                                          double *__restrict__ RC, double *__restrict__ CW) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   __shared__ double sm[4];
   const long r0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
@@ -4300,13 +4301,46 @@ __global__ void __launch_bounds__(SC_T) k_cox_cscan_apply(const double *__restri
     if (i < n) {
       s += x[q];
       const double tc = THF[i] * s;
-      VG[i] = WD[i] - tc;
+      const double vg = WD[i] - tc;
+      VG[i] = vg;
       WG1[i] = tc;
+      if (RC != nullptr) {
+        // one-pass Hessian (k_cox_hess): the gradient rides in the first Gram as the column VG / WG1 (a row with
+        // VG != 0 is an event row or lies behind one, so its theta C is positive); weights of the second Gram
+        RC[i] = tc != 0.0 ? vg / tc : 0.0;
+        CW[i] = x[q] * RS0F[i];
+      }
     } else if (i < ld) {
       VG[i] = 0.0;
       WG1[i] = 0.0;
+      if (RC != nullptr) {
+        RC[i] = 0.0;
+        CW[i] = 0.0;
+      }
     }
   }
+}
+
+// eta0 of Newton step t without a pass over the active columns: step 1 starts from beta0 = 0; afterwards the line search
+// has accepted beta0 + 0.5^m u, whose linear predictor is eta0 + 0.5^m UD (UD = X_A u is in memory from k_cox_dir).
+// theta = exp(clamp eta0) on the training rows, as k_cox_fit_eta.
+__global__ void __launch_bounds__(256) k_cox_eta_upd(long ld, int n, const double *__restrict__ mask,
+                                                     const FitCtrl *__restrict__ ctrl, int slot, int t,
+                                                     const double *__restrict__ UD, double *__restrict__ ETA0,
+                                                     double *__restrict__ THF) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i >= ld) return;
+  d2 e = d2{0.0, 0.0};
+  if (t > 1) {
+    const int m = ctrl->ls_m;
+    const double step = m == 1 ? 0.5 : (m == 2 ? 0.25 : (m == 3 ? 0.125 : (m == 4 ? 0.0625 : 0.03125)));
+    e = *reinterpret_cast<const d2 *>(ETA0 + i) + *reinterpret_cast<const d2 *>(UD + i) * step;
+  }
+  const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
+  *reinterpret_cast<d2 *>(ETA0 + i) = e;
+  *reinterpret_cast<d2 *>(THF + i) =
+      d2{i < n ? exp(clampv(e.x, 30.0)) * mk.x : 0.0, i + 1 < n ? exp(clampv(e.y, 30.0)) * mk.y : 0.0};
 }
 
 // M[:, a] = suffix(theta x_a) / S0 (the n x k matrix S1/S0, :1426-1428) and g_a = x_a . VG + 2 lambda b0_a (:1429).
@@ -4377,6 +4411,223 @@ __global__ void __launch_bounds__(SC_T) k_cox_M_apply(const double *__restrict__
       for (int j = 0; j < nb; j++) gg += scr[(size_t)(k + a) * nb + j];
       g[a] = gg + 2.0 * lambda * b0[a];
     }
+  }
+}
+
+// ---- Newton step, one-pass Hessian ----------------------------------------------------------------------------------
+// -h = X_A^T diag(theta C) X_A - M^T diag(w delta) M with M_i = S1_i / S0_i, S1_i = sum_{l >= i} theta_l x_l (:1458-1470).
+// Round 2 materialised M (two scan launches over the n x k active columns, k_cox_M_tot / k_cox_M_apply), then formed
+// two Grams from two more reads (X_A, M).  Here ONE kernel reads X_A once: with c_i = w_i delta_i / S0_i^2 the second
+// term is sum_i c_i S1_i S1_i^T, and inside a row slab b S1_i = L_i + car_b with L_i the suffix sum over the slab's own
+// rows and car_b the total of the later slabs, so
+//     sum_{i in b} c_i S1_i S1_i^T = L_b^T diag(c) L_b + car_b p1_b^T + p1_b car_b^T + P0_b car_b car_b^T,
+//     p1_b = sum c_i L_i,  P0_b = sum c_i
+// -- no carry has to be known while X is read (the same exchange as the one-pass score, k_cox_score1p).  A block owns a
+// slab and walks its 64-row chunks bottom-up: chunk into the LDS tile, first Gram on the matrix cores (weights theta C),
+// then the tile is turned IN PLACE into the suffix sums (one wave per column, the 64 rows of the chunk in its 64
+// lanes: DPP shifts inside the 16-lane rows, v_readlane across them, the running column sum of the later chunks from
+// LDS), second Gram on the same tile (weights c).  One spare column (index k) carries the bookkeeping through the
+// products: in the first Gram it holds (w delta - theta C) / (theta C), so row k of that Gram is the gradient
+// X_A^T (w delta - theta C) (:1429); in the second it holds ones, so row k is p1_b and its diagonal entry P0_b.
+// k_cox_car then forms the slab carries, k_cox_hess_reduce sums the slabs, applies the three carry terms and writes
+// the tiles k_chol takes plus the gradient.
+__device__ __forceinline__ double dpp_row_shl_f64(double v, const int n) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (n) {  // lane i of a 16-lane row receives lane i + n of the same row, 0.0 beyond the row
+    case 1: lo = BESSX_DPP32(lo, 0x101); hi = BESSX_DPP32(hi, 0x101); break;
+    case 2: lo = BESSX_DPP32(lo, 0x102); hi = BESSX_DPP32(hi, 0x102); break;
+    case 4: lo = BESSX_DPP32(lo, 0x104); hi = BESSX_DPP32(hi, 0x104); break;
+    default: lo = BESSX_DPP32(lo, 0x108); hi = BESSX_DPP32(hi, 0x108); break;
+  }
+  return __hiloint2double(hi, lo);
+}
+// out_l = sum_{l' >= l} v_l' over the 64 lanes of the wave (fixed order)
+__device__ __forceinline__ double wave_suffix_scan(double v, int lane) {
+  v += dpp_row_shl_f64(v, 1);
+  v += dpp_row_shl_f64(v, 2);
+  v += dpp_row_shl_f64(v, 4);
+  v += dpp_row_shl_f64(v, 8);
+  const double t1 = readlane_f64(v, 16), t2 = readlane_f64(v, 32), t3 = readlane_f64(v, 48);
+  const int q = lane >> 4;
+  const double add = q == 0 ? (t1 + (t2 + t3)) : (q == 1 ? (t2 + t3) : (q == 2 ? t3 : 0.0));
+  return v + add;
+}
+
+template <int TPW, int NPASS>
+__global__ void __launch_bounds__(512) k_cox_hess(const double *__restrict__ X, const double *__restrict__ aux, long ld,
+                                                  const int *__restrict__ cols, const double *__restrict__ WG1,
+                                                  const double *__restrict__ CW, const double *__restrict__ THF,
+                                                  int rows_per_slab, int mt, int k, double *__restrict__ part1,
+                                                  double *__restrict__ part2, double *__restrict__ HT, int ntiles,
+                                                  const FitCtrl *__restrict__ ctrl, int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  constexpr int RB = 64, GL_LD = RB + 2, TPC = RB / 2, NW = 8, CPP = 64 * NW / TPC;
+  extern __shared__ double smem[];  // tile [mp][GL_LD], then w1[RB] w2[RB] th[RB] run[mp]
+  const int mp = mt * 16;
+  double *w1 = smem + (size_t)mp * GL_LD, *w2 = w1 + RB, *th = w2 + RB, *run = th + RB;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ru = tid % TPC, cb = tid / TPC;
+  const int slab = blockIdx.x;
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + RB - 1) / RB);
+  for (int i = tid; i < mp; i += 64 * NW) run[i] = 0.0;
+  int cidx[NPASS];
+#pragma unroll
+  for (int i = 0; i < NPASS; i++) {
+    const int col = i * CPP + cb;
+    cidx[i] = col < mp ? cols[col] : INT_MIN;
+  }
+  d2 st[NPASS], v1 = d2{0.0, 0.0}, v2 = d2{0.0, 0.0}, v3 = d2{0.0, 0.0};
+  auto load = [&](int kc) {
+    const long r0 = r_begin + (long)kc * RB + 2 * ru;
+    const bool in = r0 < r_end;  // slabs end on multiples of 16 rows: a row pair is in or out as a whole
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      st[i] = d2{0.0, 0.0};
+      if (in && cidx[i] != INT_MIN) st[i] = *reinterpret_cast<const d2 *>(gram_col(X, aux, ld, cidx[i]) + r0);
+    }
+    if (tid < TPC) {
+      v1 = in ? *reinterpret_cast<const d2 *>(WG1 + r0) : d2{0.0, 0.0};
+      v2 = in ? *reinterpret_cast<const d2 *>(CW + r0) : d2{0.0, 0.0};
+      v3 = in ? *reinterpret_cast<const d2 *>(THF + r0) : d2{0.0, 0.0};
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int col = i * CPP + cb;
+      if (col < mp) *reinterpret_cast<d2 *>(smem + (size_t)col * GL_LD + 2 * ru) = st[i];
+    }
+    if (tid < TPC) {
+      *reinterpret_cast<d2 *>(w1 + 2 * ru) = v1;
+      *reinterpret_cast<d2 *>(w2 + 2 * ru) = v2;
+      *reinterpret_cast<d2 *>(th + 2 * ru) = v3;
+    }
+  };
+  int tI[TPW], tJ[TPW];
+  d4 acc1[TPW], acc2[TPW];
+#pragma unroll
+  for (int ts = 0; ts < TPW; ts++) {
+    const int tt = wv + NW * ts;
+    int I = -1, J = -1;
+    if (tt < ntiles) tile_of(tt, I, J);
+    tI[ts] = __builtin_amdgcn_readfirstlane(I);
+    tJ[ts] = __builtin_amdgcn_readfirstlane(J);
+    acc1[ts] = d4{0.0, 0.0, 0.0, 0.0};
+    acc2[ts] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+  auto products = [&](d4 (&acc)[TPW], const double *wch) {
+#pragma unroll
+    for (int ts = 0; ts < TPW; ts++) {
+      if (tI[ts] >= 0) {  // wave-uniform
+        const double *pa = smem + (size_t)(tI[ts] * 16 + c) * GL_LD + 4 * q;
+        const double *pb = smem + (size_t)(tJ[ts] * 16 + c) * GL_LD + 4 * q;
+#pragma unroll
+        for (int sx = 0; sx < RB / 16; sx++) {
+          const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * sx), a1 = *reinterpret_cast<const d2 *>(pa + 16 * sx + 2);
+          const d2 b0 = *reinterpret_cast<const d2 *>(pb + 16 * sx), b1 = *reinterpret_cast<const d2 *>(pb + 16 * sx + 2);
+          const d2 w0 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q);
+          const d2 wq = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q + 2);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x * w0.x, b0.x, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y * w0.y, b0.y, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x * wq.x, b1.x, acc[ts], 0, 0, 0);
+          acc[ts] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y * wq.y, b1.y, acc[ts], 0, 0, 0);
+        }
+      }
+    }
+  };
+  if (nchunk > 0) load(nchunk - 1);
+  __syncthreads();  // run[] is zero
+  for (int kc = nchunk - 1; kc >= 0; kc--) {  // bottom-up: the suffix sums run from the slab's last row
+    store();
+    if (kc > 0) load(kc - 1);
+    __syncthreads();
+    products(acc1, w1);
+    __syncthreads();
+    for (int col = wv; col < k; col += NW) {
+      double *tc = smem + (size_t)col * GL_LD;
+      const double s = wave_suffix_scan(th[lane] * tc[lane], lane) + run[col];
+      tc[lane] = s;
+      if (lane == 0) run[col] = s;
+    }
+    if (wv == (k & (NW - 1))) smem[(size_t)k * GL_LD + lane] = 1.0;
+    __syncthreads();
+    products(acc2, w2);
+    __syncthreads();
+  }
+  double *o1 = part1 + (size_t)slab * ntiles * 256, *o2 = part2 + (size_t)slab * ntiles * 256;
+#pragma unroll
+  for (int ts = 0; ts < TPW; ts++)
+    if (tI[ts] >= 0) {
+      *reinterpret_cast<d4 *>(o1 + (size_t)(wv + NW * ts) * 256 + lane * 4) = acc1[ts];
+      *reinterpret_cast<d4 *>(o2 + (size_t)(wv + NW * ts) * 256 + lane * 4) = acc2[ts];
+    }
+  for (int i = tid; i < mp; i += 64 * NW) HT[(size_t)slab * mp + i] = i < k ? run[i] : 0.0;
+}
+
+// slab carries car_b = sum_{b' > b} T_b' (T_b = the slab's own column totals of theta x) and q_b = p1_b + P0_b car_b / 2:
+// the three carry terms of a slab are car_b q_b^T + q_b car_b^T.  One thread per column, the slabs last to first.
+__global__ void __launch_bounds__(64) k_cox_car(const double *__restrict__ HT, const double *__restrict__ part2,
+                                                int nslab, int mt, int k, int ntiles, double *__restrict__ CAR,
+                                                double *__restrict__ Q, const FitCtrl *__restrict__ ctrl, int slot,
+                                                int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  const int mp = mt * 16, col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= mp) return;
+  const size_t e1 = tile_id(k >> 4, col >> 4) * 256 + tile_elem(k & 15, col & 15);
+  const size_t e0 = tile_id(k >> 4, k >> 4) * 256 + tile_elem(k & 15, k & 15);
+  double runv = 0.0;
+  for (int b = nslab - 1; b >= 0; b--) {
+    const double *pb = part2 + (size_t)b * ntiles * 256;
+    const double p1 = col < k ? pb[e1] : 0.0, P0 = pb[e0];
+    CAR[(size_t)b * mp + col] = runv;
+    Q[(size_t)b * mp + col] = p1 + 0.5 * P0 * runv;
+    runv += HT[(size_t)b * mp + col];
+  }
+}
+
+// Gt = sum_b [G1_b - P2_b - car_b q_b^T - q_b car_b^T] on the k x k block (fixed order: 16 groups of slabs, then the
+// groups), g = row k of sum_b G1_b + 2 lambda beta0 (:1429; the sign of the ridge terms as the reference has them).
+__global__ void __launch_bounds__(256) k_cox_hess_reduce(const double *__restrict__ part1,
+                                                         const double *__restrict__ part2,
+                                                         const double *__restrict__ CAR, const double *__restrict__ Q,
+                                                         int nslab, int ntiles, int mp, int k, double lambda,
+                                                         const double *__restrict__ b0, double *__restrict__ Gt,
+                                                         double *__restrict__ g, const FitCtrl *__restrict__ ctrl,
+                                                         int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  __shared__ double sm[16][17];
+  const int el = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const size_t tot = (size_t)ntiles * 256;
+  const size_t e = (size_t)blockIdx.x * 16 + el;
+  double s = 0.0;
+  int i = -1, j = -1;
+  if (e < tot) {
+    int I, J;
+    tile_of((int)(e >> 8), I, J);
+    const int ee = (int)(e & 255), ln = ee >> 2, reg = ee & 3;
+    i = 16 * I + (ln >> 4) + 4 * reg;
+    j = 16 * J + (ln & 15);
+    const bool inner = i < k && j < k, grad = i == k;
+    for (int sl = gq; sl < nslab; sl += 16) {
+      double v = part1[(size_t)sl * tot + e];
+      if (!grad) v -= part2[(size_t)sl * tot + e];
+      if (inner) {
+        const double *cr = CAR + (size_t)sl * mp, *qr = Q + (size_t)sl * mp;
+        v -= cr[i] * qr[j] + qr[i] * cr[j];
+      }
+      s += v;
+    }
+  }
+  sm[gq][el] = s;
+  __syncthreads();
+  if (gq == 0 && e < tot) {
+    double tsum = sm[0][el];
+#pragma unroll
+    for (int r = 1; r < 16; r++) tsum += sm[r][el];
+    Gt[e] = tsum;
+    if (i == k && j < k) g[j] = tsum + 2.0 * lambda * b0[j];
   }
 }
 
@@ -5102,7 +5353,8 @@ __global__ void __launch_bounds__(256) k_gram_cols(const int *__restrict__ A_new
     int a = i - intercept;
     if (intercept && i == 0) v = -2;
     else if (a >= 0 && a < T0) v = A_new[a];
-    if (rhs_col && i == mp - 1) v = -3;
+    if (rhs_col == 1 && i == mp - 1) v = -3;
+    if (rhs_col == 2 && a == T0) v = -3;  // (Cox, one-pass Hessian: the bookkeeping column right behind the active ones)
     cols[i] = v;
   }
 }
@@ -6784,14 +7036,36 @@ hipError_t launch_cox_newton_begin(FitCtrl *ctrl, int slot, int k, CoxBufs cb, i
   return hipSuccess;
 }
 
+// slab geometry of the one-pass Hessian kernel: about one slab per compute unit, whole 64-row chunks
+int cox_hess_slab_rows(long ld) { return (int)(((ld + 255) / 256 + 63) / 64 * 64); }
+bool cox_hess_applies(int mt) { return mt >= 1 && mt <= 10; }  // (beyond: two accumulator sets no longer fit the registers)
+hipError_t cox_hess_prepare() {
+  hipError_t e = hipSuccess;
+  const int big = (10 * 16 * 66 + 3 * 64 + 10 * 16) * (int)sizeof(double);
+#define CH_ATTR(K) \
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+  CH_ATTR((k_cox_hess<2, 4>));
+  CH_ATTR((k_cox_hess<5, 8>));
+  CH_ATTR((k_cox_hess<7, 10>));
+#undef CH_ATTR
+  return e;
+}
+
 hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, int n, const double *mask,
                                   FitCtrl *ctrl, int slot, int t, const int *A_new, int k, double lambda,
                                   const int *gcols, const int *idcols, int mt, const GramTask *tasks, int ntask,
                                   int rps, int nslab, double *gpart, int ntiles, double *Gt, CoxBufs cb,
                                   hipStream_t st, double *rdiag, double *zbig) {
   const int nb2 = (int)((ld + 255) / 256);
-  hipLaunchKernelGGL(k_cox_fit_eta, dim3(nb2), dim3(128), 0, st, X, ld, n, mask, (const FitCtrl *)ctrl, slot, t,
-                     A_new, k, (const double *)cb.b0, cb.ETA0, cb.THF);
+  const bool fused = cb.hess_fused && cox_hess_applies(mt);
+  if (fused) {
+    // (the linear predictor of the accepted trial point instead of a pass over the active columns)
+    hipLaunchKernelGGL(k_cox_eta_upd, dim3((int)((ld + 511) / 512)), dim3(256), 0, st, ld, n, mask,
+                       (const FitCtrl *)ctrl, slot, t, (const double *)cb.UD, cb.ETA0, cb.THF);
+  } else {
+    hipLaunchKernelGGL(k_cox_fit_eta, dim3(nb2), dim3(128), 0, st, X, ld, n, mask, (const FitCtrl *)ctrl, slot, t,
+                       A_new, k, (const double *)cb.b0, cb.ETA0, cb.THF);
+  }
   LAUNCH_CHECK();
   {
     hipError_t es = launch_scan3(cb.THF, nullptr, nullptr, cb.S0F, nullptr, nullptr, cb.RS0F, (long)n, 1, 1, cb.SCR,
@@ -6805,24 +7079,53 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_cox_cscan_apply, dim3(nbl), dim3(SC_T), 0, st, (const double *)cb.WD, (const double *)cb.RS0F,
                        (const double *)cb.THF, cb.VG, cb.WG1, (long)n, ld, (const double *)cb.SCR,
-                       (const FitCtrl *)ctrl, slot, t);
+                       (const FitCtrl *)ctrl, slot, t, fused ? const_cast<double *>(aux) + 2 * ld : (double *)nullptr,
+                       fused ? cb.CW : (double *)nullptr);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cox_M_tot, dim3(nbn, k), dim3(SC_T), 0, st, X, ld, (long)n, A_new, (const double *)cb.THF,
-                       (const double *)cb.VG, cb.SCR, (const FitCtrl *)ctrl, slot, t);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cox_M_apply, dim3(nbn, k), dim3(SC_T), 0, st, X, ld, (long)n, A_new, (const double *)cb.THF,
-                       (const double *)cb.RS0F, (const double *)cb.b0, lambda, (const double *)cb.SCR, cb.M, cb.g,
-                       (const FitCtrl *)ctrl, slot, t);
+    if (fused) {
+      const int hrows = cox_hess_slab_rows(ld), hns = (int)((ld + hrows - 1) / hrows), mp = mt * 16;
+      const size_t lds = ((size_t)mp * 66 + 3 * 64 + mp) * sizeof(double);
+      if (mt <= 4)
+        hipLaunchKernelGGL((k_cox_hess<2, 4>), dim3(hns), dim3(512), lds, st, X, aux, ld, gcols, (const double *)cb.WG1,
+                           (const double *)cb.CW, (const double *)cb.THF, hrows, mt, k, gpart, cb.HP2, cb.HT, ntiles,
+                           (const FitCtrl *)ctrl, slot, t);
+      else if (mt <= 8)
+        hipLaunchKernelGGL((k_cox_hess<5, 8>), dim3(hns), dim3(512), lds, st, X, aux, ld, gcols, (const double *)cb.WG1,
+                           (const double *)cb.CW, (const double *)cb.THF, hrows, mt, k, gpart, cb.HP2, cb.HT, ntiles,
+                           (const FitCtrl *)ctrl, slot, t);
+      else
+        hipLaunchKernelGGL((k_cox_hess<7, 10>), dim3(hns), dim3(512), lds, st, X, aux, ld, gcols,
+                           (const double *)cb.WG1, (const double *)cb.CW, (const double *)cb.THF, hrows, mt, k, gpart,
+                           cb.HP2, cb.HT, ntiles, (const FitCtrl *)ctrl, slot, t);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_cox_car, dim3((mp + 63) / 64), dim3(64), 0, st, (const double *)cb.HT,
+                         (const double *)cb.HP2, hns, mt, k, ntiles, cb.CAR, cb.HQ, (const FitCtrl *)ctrl, slot, t);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_cox_hess_reduce, dim3((ntiles * 256 + 15) / 16), dim3(256), 0, st, (const double *)gpart,
+                         (const double *)cb.HP2, (const double *)cb.CAR, (const double *)cb.HQ, hns, ntiles, mp, k,
+                         lambda, (const double *)cb.b0, Gt, cb.g, (const FitCtrl *)ctrl, slot, t);
+      LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(k_cox_M_tot, dim3(nbn, k), dim3(SC_T), 0, st, X, ld, (long)n, A_new, (const double *)cb.THF,
+                         (const double *)cb.VG, cb.SCR, (const FitCtrl *)ctrl, slot, t);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_cox_M_apply, dim3(nbn, k), dim3(SC_T), 0, st, X, ld, (long)n, A_new, (const double *)cb.THF,
+                         (const double *)cb.RS0F, (const double *)cb.b0, lambda, (const double *)cb.SCR, cb.M, cb.g,
+                         (const FitCtrl *)ctrl, slot, t);
+      LAUNCH_CHECK();
+    }
+  }
+  hipError_t e = hipSuccess;
+  if (!fused) {
+    // Hessian: -h = X_A^T diag(theta C) X_A - M^T diag(w delta) M  (from :1458-1470)
+    e = launch_gram(X, aux, ld, gcols, cb.WG1, rps, tasks, ntask, nslab, gpart, ntiles, Gt, ctrl, slot, 2, st, 0);
+    if (e != hipSuccess) return e;
+    e = launch_gram(cb.M, aux, ld, idcols, cb.WD, rps, tasks, ntask, nslab, gpart, ntiles, cb.Gt2, ctrl, slot, 2, st, 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tile_sub, dim3((ntiles * 256 + 255) / 256), dim3(256), 0, st, Gt, (const double *)cb.Gt2,
+                       (long)ntiles * 256, (const FitCtrl *)ctrl, slot, t);
     LAUNCH_CHECK();
   }
-  // Hessian: -h = X_A^T diag(theta C) X_A - M^T diag(w delta) M  (from :1458-1470)
-  hipError_t e = launch_gram(X, aux, ld, gcols, cb.WG1, rps, tasks, ntask, nslab, gpart, ntiles, Gt, ctrl, slot, 2, st, 0);
-  if (e != hipSuccess) return e;
-  e = launch_gram(cb.M, aux, ld, idcols, cb.WD, rps, tasks, ntask, nslab, gpart, ntiles, cb.Gt2, ctrl, slot, 2, st, 0);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_tile_sub, dim3((ntiles * 256 + 255) / 256), dim3(256), 0, st, Gt, (const double *)cb.Gt2,
-                     (long)ntiles * 256, (const FitCtrl *)ctrl, slot, t);
-  LAUNCH_CHECK();
   e = mt <= CH_MT ? launch_chol(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, ctrl, slot, 2, st)
                   : launch_chol_big(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, rdiag, zbig, ctrl, slot,
                                     2, st);
