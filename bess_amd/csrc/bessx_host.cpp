@@ -3205,8 +3205,13 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(V(&c.SCR, cox_scan_scratch_doubles(ld, 256)));
     // one-pass Hessian of the Newton step (k_cox_hess, up to 10 tile rows; BESSX_COX_HESS=2pass: M = S1 / S0
     // materialised and two Gram launches, as in round 2)
-    c.hess_fused = 1;
-    if (const char *ev = std::getenv("BESSX_COX_HESS")) c.hess_fused = std::string(ev) != "2pass";
+    // Small samples keep the two-pass form: it is built like the reference's own formulas (M = S1 / S0, two Grams), so
+    // on the ill-conditioned fits small n produces (near-separated risk sets, a ridge that outweighs the information
+    // matrix) its rounding follows the reference's more closely -- both forms are accurate to rounding there, but a
+    // Newton iteration on such a system amplifies rounding to 1e-4 and beyond (tests/test_cox_gpu.py).
+    // BESSX_COX_HESS=1pass forces the one-pass form at any size.
+    c.hess_fused = n >= 1024 ? 1 : 0;
+    if (const char *ev = std::getenv("BESSX_COX_HESS")) c.hess_fused = std::string(ev) == "2pass" ? 0 : (std::string(ev) == "1pass" ? 1 : c.hess_fused);
     if (c.hess_fused) {
       const size_t hrows = (size_t)cox_hess_slab_rows(ld), hns = ((size_t)ld + hrows - 1) / hrows;
       if (hns * 55 * 256 > s->gpart_elems) {

@@ -4462,9 +4462,9 @@ __global__ void __launch_bounds__(512) k_cox_hess(const double *__restrict__ X, 
                                                   const FitCtrl *__restrict__ ctrl, int slot, int t) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   constexpr int RB = 64, GL_LD = RB + 2, TPC = RB / 2, NW = 8, CPP = 64 * NW / TPC;
-  extern __shared__ double smem[];  // tile [mp][GL_LD], then w1[RB] w2[RB] th[RB] run[mp]
+  extern __shared__ double smem[];  // tile [mp][GL_LD], then w1[RB] w2[RB] th[RB] w2c[RB] run[mp]
   const int mp = mt * 16;
-  double *w1 = smem + (size_t)mp * GL_LD, *w2 = w1 + RB, *th = w2 + RB, *run = th + RB;
+  double *w1 = smem + (size_t)mp * GL_LD, *w2 = w1 + RB, *th = w2 + RB, *w2c = th + RB, *run = w2c + RB;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ru = tid % TPC, cb = tid / TPC;
@@ -4517,7 +4517,7 @@ __global__ void __launch_bounds__(512) k_cox_hess(const double *__restrict__ X, 
     acc1[ts] = d4{0.0, 0.0, 0.0, 0.0};
     acc2[ts] = d4{0.0, 0.0, 0.0, 0.0};
   }
-  auto products = [&](d4 (&acc)[TPW], const double *wch) {
+  auto products = [&](d4 (&acc)[TPW], const double *wch, int nsx) {
 #pragma unroll
     for (int ts = 0; ts < TPW; ts++) {
       if (tI[ts] >= 0) {  // wave-uniform
@@ -4525,6 +4525,7 @@ __global__ void __launch_bounds__(512) k_cox_hess(const double *__restrict__ X, 
         const double *pb = smem + (size_t)(tJ[ts] * 16 + c) * GL_LD + 4 * q;
 #pragma unroll
         for (int sx = 0; sx < RB / 16; sx++) {
+          if (sx >= nsx) break;  // block-uniform
           const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * sx), a1 = *reinterpret_cast<const d2 *>(pa + 16 * sx + 2);
           const d2 b0 = *reinterpret_cast<const d2 *>(pb + 16 * sx), b1 = *reinterpret_cast<const d2 *>(pb + 16 * sx + 2);
           const d2 w0 = *reinterpret_cast<const d2 *>(wch + 16 * sx + 4 * q);
@@ -4543,17 +4544,29 @@ __global__ void __launch_bounds__(512) k_cox_hess(const double *__restrict__ X, 
     store();
     if (kc > 0) load(kc - 1);
     __syncthreads();
-    products(acc1, w1);
+    products(acc1, w1, RB / 16);
     __syncthreads();
+    // the second Gram has non-zero weights on the event rows only (c_i = w_i delta_i / S0_i^2): the suffix sums are
+    // written COMPACTED to the top of the tile, event rows first in their order, and the product walks only the
+    // 16-row steps they fill (about half of them)
+    const double cw = w2[lane];
+    const unsigned long long evm = __ballot(cw != 0.0);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(evm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)evm, 0u));
+    const int nev = __popcll(evm);  // the same in every wave
+    const bool ev = cw != 0.0;
     for (int col = wv; col < k; col += NW) {
       double *tc = smem + (size_t)col * GL_LD;
       const double s = wave_suffix_scan(th[lane] * tc[lane], lane) + run[col];
-      tc[lane] = s;
       if (lane == 0) run[col] = s;
+      if (ev) tc[rank] = s;
     }
-    if (wv == (k & (NW - 1))) smem[(size_t)k * GL_LD + lane] = 1.0;
+    if (wv == (k & (NW - 1))) {
+      smem[(size_t)k * GL_LD + lane] = 1.0;
+      w2c[lane] = 0.0;
+      if (ev) w2c[rank] = cw;  // (one wave: in-order LDS, the zero fill lands first)
+    }
     __syncthreads();
-    products(acc2, w2);
+    products(acc2, w2c, (nev + 15) >> 4);
     __syncthreads();
   }
   double *o1 = part1 + (size_t)slab * ntiles * 256, *o2 = part2 + (size_t)slab * ntiles * 256;
@@ -4567,23 +4580,29 @@ __global__ void __launch_bounds__(512) k_cox_hess(const double *__restrict__ X, 
 }
 
 // slab carries car_b = sum_{b' > b} T_b' (T_b = the slab's own column totals of theta x) and q_b = p1_b + P0_b car_b / 2:
-// the three carry terms of a slab are car_b q_b^T + q_b car_b^T.  One thread per column, the slabs last to first.
-__global__ void __launch_bounds__(64) k_cox_car(const double *__restrict__ HT, const double *__restrict__ part2,
-                                                int nslab, int mt, int k, int ntiles, double *__restrict__ CAR,
-                                                double *__restrict__ Q, const FitCtrl *__restrict__ ctrl, int slot,
-                                                int t) {
+// the three carry terms of a slab are car_b q_b^T + q_b car_b^T.  One block per column, one thread per slab (at most
+// 256 slabs: cox_hess_slab_rows), the slabs scanned last to first in a fixed order.
+__global__ void __launch_bounds__(256) k_cox_car(const double *__restrict__ HT, const double *__restrict__ part2,
+                                                 int nslab, int mt, int k, int ntiles, double *__restrict__ CAR,
+                                                 double *__restrict__ Q, const FitCtrl *__restrict__ ctrl, int slot,
+                                                 int t) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
-  const int mp = mt * 16, col = blockIdx.x * 64 + threadIdx.x;
-  if (col >= mp) return;
+  __shared__ double sm[4];
+  const int mp = mt * 16, col = blockIdx.x;
+  const int b = nslab - 1 - (int)threadIdx.x;  // thread order = scan order: the last slab first
   const size_t e1 = tile_id(k >> 4, col >> 4) * 256 + tile_elem(k & 15, col & 15);
   const size_t e0 = tile_id(k >> 4, k >> 4) * 256 + tile_elem(k & 15, k & 15);
-  double runv = 0.0;
-  for (int b = nslab - 1; b >= 0; b--) {
+  double tb = 0.0, p1 = 0.0, P0 = 0.0;
+  if (b >= 0) {
     const double *pb = part2 + (size_t)b * ntiles * 256;
-    const double p1 = col < k ? pb[e1] : 0.0, P0 = pb[e0];
-    CAR[(size_t)b * mp + col] = runv;
-    Q[(size_t)b * mp + col] = p1 + 0.5 * P0 * runv;
-    runv += HT[(size_t)b * mp + col];
+    tb = HT[(size_t)b * mp + col];
+    p1 = col < k ? pb[e1] : 0.0;
+    P0 = pb[e0];
+  }
+  const double car = block_excl_256(tb, sm, nullptr);
+  if (b >= 0) {
+    CAR[(size_t)b * mp + col] = car;
+    Q[(size_t)b * mp + col] = p1 + 0.5 * P0 * car;
   }
 }
 
@@ -4730,16 +4749,18 @@ __device__ __forceinline__ double cox_trial_theta(double eta0, double ud, double
   return exp(clampv(eta0 + step * ud, 30.0)) * mk;
 }
 
+constexpr int LS_E = 2, LS_B = SC_T * LS_E;  // rows per thread / per block of the line-search scans (n / 512 blocks)
+
 __global__ void __launch_bounds__(SC_T) k_cox_ls5_tot(long n, const double *__restrict__ mask,
                                                       const double *__restrict__ ETA0, const double *__restrict__ UD,
                                                       double *__restrict__ scr, const FitCtrl *__restrict__ ctrl,
                                                       int slot, int t) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   __shared__ double sm[4];
-  const long r0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
+  const long r0 = (long)blockIdx.x * LS_B + (long)threadIdx.x * LS_E;
   double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < SC_E; q++) {
+  for (int q = 0; q < LS_E; q++) {
     const long r = r0 + q;
     if (r < n) {
       const long i = n - 1 - r;
@@ -4763,10 +4784,18 @@ __global__ void __launch_bounds__(SC_T) k_cox_ls5_apply(long n, const double *__
                                                         const FitCtrl *__restrict__ ctrl, int slot, int t) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   __shared__ double sm[4];
-  const long r0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
-  double th[5][SC_E], wd[SC_E];
+  __shared__ double cw[5][4];
+  const int nb = gridDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * LS_B + (long)threadIdx.x * LS_E;
+  // carries: the totals of the blocks before this one, summed by the whole block (fixed order: thread-strided
+  // partial sums, wave butterflies, the four waves in order)
+  double cs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += SC_T)
 #pragma unroll
-  for (int q = 0; q < SC_E; q++) {
+    for (int m = 0; m < 5; m++) cs[m] += scr[(size_t)m * nb + j];
+  double th[5][LS_E], wd[LS_E];
+#pragma unroll
+  for (int q = 0; q < LS_E; q++) {
     const long r = r0 + q;
     wd[q] = 0.0;
 #pragma unroll
@@ -4781,21 +4810,26 @@ __global__ void __launch_bounds__(SC_T) k_cox_ls5_apply(long n, const double *__
   }
 #pragma unroll
   for (int m = 0; m < 5; m++) {
-    double carry = 0.0;
-    for (int j = 0; j < (int)blockIdx.x; j++) carry += scr[(size_t)m * gridDim.x + j];
+    cs[m] = wave_sum(cs[m]);
+    if (lane == 0) cw[m][wave] = cs[m];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    const double carry = ((cw[m][0] + cw[m][1]) + cw[m][2]) + cw[m][3];
     double tt = 0.0;
 #pragma unroll
-    for (int q = 0; q < SC_E; q++) tt += th[m][q];
+    for (int q = 0; q < LS_E; q++) tt += th[m][q];
     double sfx = carry + block_excl_256(tt, sm, nullptr);
     double v = 0.0;
 #pragma unroll
-    for (int q = 0; q < SC_E; q++) {
+    for (int q = 0; q < LS_E; q++) {
       sfx += th[m][q];
       if (wd[q] != 0.0) v += wd[q] * log(th[m][q] / sfx);
     }
     double bt;
     (void)block_excl_256(v, sm, &bt);
-    if (threadIdx.x == 0) llp[(size_t)m * gridDim.x + blockIdx.x] = bt;
+    if (threadIdx.x == 0) llp[(size_t)m * nb + blockIdx.x] = bt;
   }
 }
 
@@ -7041,7 +7075,7 @@ int cox_hess_slab_rows(long ld) { return (int)(((ld + 255) / 256 + 63) / 64 * 64
 bool cox_hess_applies(int mt) { return mt >= 1 && mt <= 10; }  // (beyond: two accumulator sets no longer fit the registers)
 hipError_t cox_hess_prepare() {
   hipError_t e = hipSuccess;
-  const int big = (10 * 16 * 66 + 3 * 64 + 10 * 16) * (int)sizeof(double);
+  const int big = (10 * 16 * 66 + 4 * 64 + 10 * 16) * (int)sizeof(double);
 #define CH_ATTR(K) \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big)
   CH_ATTR((k_cox_hess<2, 4>));
@@ -7084,7 +7118,7 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
     LAUNCH_CHECK();
     if (fused) {
       const int hrows = cox_hess_slab_rows(ld), hns = (int)((ld + hrows - 1) / hrows), mp = mt * 16;
-      const size_t lds = ((size_t)mp * 66 + 3 * 64 + mp) * sizeof(double);
+      const size_t lds = ((size_t)mp * 66 + 4 * 64 + mp) * sizeof(double);
       if (mt <= 4)
         hipLaunchKernelGGL((k_cox_hess<2, 4>), dim3(hns), dim3(512), lds, st, X, aux, ld, gcols, (const double *)cb.WG1,
                            (const double *)cb.CW, (const double *)cb.THF, hrows, mt, k, gpart, cb.HP2, cb.HT, ntiles,
@@ -7098,7 +7132,8 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                            (const double *)cb.WG1, (const double *)cb.CW, (const double *)cb.THF, hrows, mt, k, gpart,
                            cb.HP2, cb.HT, ntiles, (const FitCtrl *)ctrl, slot, t);
       LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_cox_car, dim3((mp + 63) / 64), dim3(64), 0, st, (const double *)cb.HT,
+      if (hns > 256) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(k_cox_car, dim3(mp), dim3(256), 0, st, (const double *)cb.HT,
                          (const double *)cb.HP2, hns, mt, k, ntiles, cb.CAR, cb.HQ, (const FitCtrl *)ctrl, slot, t);
       LAUNCH_CHECK();
       hipLaunchKernelGGL(k_cox_hess_reduce, dim3((ntiles * 256 + 15) / 16), dim3(256), 0, st, (const double *)gpart,
@@ -7139,7 +7174,7 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                      (const double *)cb.u, cb.UD);
   LAUNCH_CHECK();
   {
-    const int nbs = (int)(((long)n + SC_B - 1) / SC_B);
+    const int nbs = (int)(((long)n + LS_B - 1) / LS_B);
     hipLaunchKernelGGL(k_cox_ls5_tot, dim3(nbs), dim3(SC_T), 0, st, (long)n, mask, (const double *)cb.ETA0,
                        (const double *)cb.UD, cb.SCR, (const FitCtrl *)ctrl, slot, t);
     LAUNCH_CHECK();

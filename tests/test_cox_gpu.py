@@ -63,6 +63,41 @@ def test_cox_score_pass_forms_agree(gpu, monkeypatch):
         np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-10)
 
 
+@pytest.mark.parametrize("form", ["1pass", "2pass"])
+def test_cox_hessian_forms_against_the_oracle(gpu, monkeypatch, form):
+    """The Newton step's Hessian in one pass over the active columns (k_cox_hess: both Grams and the gradient from one
+    read, slab-local suffix sums + carry terms; default from n = 1024) and in the two-pass form built like the
+    reference's formulas (M = S1 / S0 materialised; default below), each FORCED on the same problems: plain, weighted,
+    ridge, CV row masks, a slab count that does not divide the rows, sparsity levels across tile boundaries."""
+    monkeypatch.setenv("BESSX_COX_HESS", form)
+    X, _, status, _, _ = synth.make_cox(600, 100, 6)
+    check(gpu, X, status, dict(COX, ic_type=3, sequence=np.arange(1, 13)), "cox seq, hessian " + form)
+    w = np.random.default_rng(1).uniform(0.5, 2, 600)
+    check(gpu, X, status, dict(COX, ic_type=3, sequence=np.arange(1, 9), weight=w), "cox weighted, hessian " + form)
+    check(gpu, X, status, dict(COX, is_cv=True, K=5, cv_fold_id=synth.make_cv_folds(600, 5), sequence=np.arange(1, 9)),
+          "cox cv, hessian " + form)
+    check(gpu, X, status, dict(COX, ic_type=3, sequence=np.arange(1, 7), lambda_seq=[0.0, 0.02]),
+          "cox ridge, hessian " + form)
+    X, _, status, _, _ = synth.make_cox(5000, 130, 8, seed=5000)
+    check(gpu, X, status, dict(COX, ic_type=3, sequence=[3, 15, 16, 17, 31, 32, 33, 40]), "cox 5000x130, hessian " + form)
+
+
+def test_cox_hessian_forms_agree(gpu, monkeypatch):
+    """One-pass and two-pass Hessian on a sample large enough for many row slabs (n = 20 000: 256 slabs, the last one
+    short) and sparsity levels up to 10 tile rows: the same path, coefficients to rounding."""
+    X, _, status, _, _ = synth.make_cox(20000, 400, 20, seed=31)
+    outs = []
+    for form in ("1pass", "2pass"):
+        monkeypatch.setenv("BESSX_COX_HESS", form)
+        with gpu.Session(X, status, data_type=3, model_type=4) as s:
+            outs.append(s.sequential_path(np.array([1, 2, 5, 17, 40, 64, 65, 100, 129, 150]), ic_type=3))
+    a, b = outs
+    np.testing.assert_array_equal(a["cand_support"], b["cand_support"])
+    np.testing.assert_array_equal(a["cand_iters"], b["cand_iters"])
+    np.testing.assert_allclose(a["cand_beta"], b["cand_beta"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-10)
+
+
 # ---- Cox with groups of size > 1: the group branch of GroupPdasCox::get_A (algorithm_type 2 / 3) --------------
 def _cox_groups(seed, n=500, p=64):
     X, _, status, _, _ = synth.make_cox(n, p, 5, seed=seed)
