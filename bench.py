@@ -27,6 +27,11 @@ chain and, in the final sweep, (fold x s) pairs dealt to the ranks (bess_amd.dis
 BESSX_BENCH_ONE_DEVICE=1 rehearses the N-rank path on a box with ONE GPU (ranks share device 0, collectives over
 gloo) -- never what the driver runs.
 
+At N = 1 with the default sizes the line also carries `other_configs`: one timed path each of BASELINE configs[2]
+(logistic n=100k p=5k k<=100), configs[3] (LM gs_path + 5-fold CV) and configs[4] (Cox n=200k p=20k k<=150) with the
+kernel that streams X against the HBM roof and the time per IRLS / Newton step (--no-other-configs skips them; they
+add about two minutes, most of it generating and uploading the 32 GB Cox design).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -69,6 +74,8 @@ def parse_args(argv=None):
                     help="evaluation of the LM score pass (include/bessx.h, bessx_problem.score_mode)")
     ap.add_argument("--no-streaming-leg", action="store_true",
                     help="skip the extra (untimed-by-contract) measurement of the streaming score pass at N=1")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the N=1 measurements of BASELINE configs[2], [3], [4] (other_configs in the line)")
     return ap.parse_args(argv)
 
 
@@ -178,6 +185,86 @@ def cpu_baseline(X, y, gpu_out, sess_norm, kmax, budget_s):
     finally:
         if cores:
             os.sched_setaffinity(0, set(cores))
+
+
+def measure_other_configs(local_rank, X_lm, y_lm):
+    """BASELINE configs[2] (logistic n=100k p=5k k<=100), configs[3] (LM gs_path + 5-fold CV on the configs[1] data)
+    and configs[4] (Cox n=200k p=20k k<=150) on ONE GPU, one path each after one warm-up path (a path call starts from
+    empty caches, so the repeat does the same work).  Per config: candidates/s, the kernel that streams X against the
+    HBM roof (HIP events on the session stream), the whole path against the HBM roof, and where the rest goes (steps
+    of the IRLS / Newton chains, time per step)."""
+    import torch
+    from bess_amd import capi, synth
+
+    def timed(sess, run, n, p):
+        run()  # warm-up (first use of a kernel loads its code object)
+        sess.enable_kernel_timing(True)
+        sess.score_pass_stats(reset=True)
+        sess.submodel_steps(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = run()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        k1 = sess.score_pass_stats()
+        steps = sess.submodel_steps()
+        sess.enable_kernel_timing(False)
+        passes = k1["algorithmic_bytes"] / (8.0 * n * p)
+        per_pass = k1["seconds"] / passes if passes else 0.0
+        gbps = 8.0 * n * p / per_pass / 1e9 if per_pass else 0.0
+        rec = {
+            "candidates": int(out["n_candidates"]), "candidates_per_s": out["n_candidates"] / dt, "ms_per_path": 1e3 * dt,
+            "fits": int(out["n_fits"]), "pdas_iterations": int(out["n_pdas_iters"]),
+            "passes_over_X": passes,
+            "score_kernel": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": gbps / HBM_PEAK_GBPS, "avg_launch_ms": 1e3 * per_pass,
+                             "algorithmic_bytes_per_pass": 8.0 * n * p, "measured_by": "HIP events on the session stream"},
+            "whole_path_frac_of_hbm": passes * 8.0 * n * p / dt / 1e9 / HBM_PEAK_GBPS,
+            "time_share": {"kernel_streaming_X": k1["seconds"] / dt, "rest_of_the_chain_and_host": 1.0 - k1["seconds"] / dt},
+            "selected_k": int(out["best_T0"]), "criterion": float(out["ic"]),
+        }
+        if steps:
+            rec["submodel_steps"] = int(steps)
+            rec["us_per_submodel_step_incl_iteration_overheads"] = 1e6 * (dt - k1["seconds"]) / steps
+        return rec
+
+    res = {}
+    # configs[3] first: it shares the configs[1] data
+    n, p = X_lm.shape
+    t0 = time.time()
+    with capi.Session(X_lm, y_lm, data_type=1, model_type=1, device=local_rank) as sess:
+        sess.set_cv(5, synth.make_cv_folds(n, 5))
+        setup = time.time() - t0
+        rec = timed(sess, lambda: sess.gs_path(1, 200, ic_type=3, is_cv=True), n, p)
+    rec.update({"workload": "configs[3]: LM gs_path on [1,200] + 5-fold CV (fixed folds), n=%d p=%d; a candidate = the "
+                            "full-data fit + 5 fold fits" % (n, p),
+                "fits_per_s": rec["fits"] / (rec["ms_per_path"] / 1e3), "score_kernel_name": "k_cov_panel (32 Gram "
+                "columns of every row set per pass over the fold-major copy of X)", "setup_seconds": setup})
+    res["lmcv"] = rec
+    del X_lm
+    t0 = time.time()
+    X, y, _, _ = synth.make_logistic(100000, 5000, 50)
+    with capi.Session(X, y, data_type=2, model_type=2, device=local_rank) as sess:
+        setup = time.time() - t0
+        del X
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 101), ic_type=3), 100000, 5000)
+    rec.update({"workload": "configs[2]: logistic PDAS + IRLS, sequential path k=1..100, n=100000 p=5000, GIC",
+                "score_kernel_name": "k_xtv<.., two accumulators> (X^T g and X^2^T h in one pass)",
+                "submodel": "IRLS step = k_irls_gram + k_gram_reduce + k_chol (3 launches)", "setup_seconds": setup})
+    res["logistic"] = rec
+    t0 = time.time()
+    X, _, st, _, _ = synth.make_cox(200000, 20000, 75)
+    with capi.Session(X, st, data_type=3, model_type=4, device=local_rank) as sess:
+        setup = time.time() - t0
+        del X
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 151), ic_type=3), 200000, 20000)
+    rec.update({"workload": "configs[4]: Cox PDAS, sequential path k=1..150, n=200000 p=20000 (32 GB X), GIC",
+                "score_kernel_name": "k_cox_score1p (risk-set score, X read once)",
+                "submodel": "Newton step = linear predictor update, 4 scan launches, k_cox_hess (both Grams + gradient in "
+                            "one pass over the active columns), carries, reduction, k_chol, direction, 3 line-search "
+                            "launches", "setup_seconds": setup})
+    res["cox"] = rec
+    return res
 
 
 def main():
@@ -394,6 +481,12 @@ def main():
             except Exception as e:  # the checker is optional for the measurement itself
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": 1, "kind": "port",
                                         "sample": "failed: %r" % (e,)}
+        if world == 1 and not args.no_other_configs and (args.n, args.p, args.kmax) == (50000, 10000, 200):
+            sess.close()
+            try:
+                line["other_configs"] = measure_other_configs(local_rank, X, y)
+            except Exception as e:  # never lose the headline line to a secondary measurement
+                line["other_configs"] = {"error": repr(e)}
         print(json.dumps(line))
         sys.stdout.flush()
     sess.close()

@@ -26,7 +26,7 @@ SYMBOLS = [
     "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_get_screening_groups", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
-    "bessx_session_enable_kernel_timing", "bessx_session_fit", "bessx_session_reset_caches", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
+    "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_reset_caches", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench",
 ]
 
@@ -106,6 +106,7 @@ def lib():
         L.bessx_session_get_normalization.argtypes = [_vp, _D, _D, _D]
         L.bessx_session_score_pass_stats.argtypes = [_vp, _i, _D, ctypes.POINTER(_ll), _D]
         L.bessx_session_enable_kernel_timing.argtypes = [_vp, _i]
+        L.bessx_session_submodel_steps.argtypes = [_vp, _i, ctypes.POINTER(_ll)]
         L.bessx_session_fit.argtypes = [_vp, _i, _d, _i, _I, _D, _i, _d, _I, _D, _D, _I, _D, _D]
         L.bessx_session_reset_caches.argtypes = [_vp]
         L.bessx_op_xtv.argtypes = [_D, _i, _i, _i, _D, _D, _D, _D]
@@ -311,6 +312,12 @@ class Session:
         _check(lib().bessx_session_score_pass_stats(self._h, int(reset), ctypes.byref(sec), ctypes.byref(cnt),
                                                     ctypes.byref(nb)))
         return {"seconds": sec.value, "launches": cnt.value, "algorithmic_bytes": nb.value}
+
+    def submodel_steps(self, reset=False):
+        """IRLS / Newton steps of the restricted fits since the last reset (0 for LM)."""
+        cnt = _ll(0)
+        _check(lib().bessx_session_submodel_steps(self._h, int(reset), ctypes.byref(cnt)))
+        return cnt.value
 
     def normalization(self):
         xm, xn, ym = np.zeros(self.p_kept), np.zeros(self.p_kept), _d(0)

@@ -173,6 +173,7 @@ struct bessx_session {
   // and lost, 0.180 s against 0.175 s on configs[2]; it is gone.)
   bool irls_fuse = true;   // GLM IRLS step as k_irls_gram + k_gram_reduce + k_chol (BESSX_IRLS_FUSE=0: the five-launch step)
   size_t llpart_cap = 0;
+  long long n_submodel_steps = 0;  // IRLS / Newton steps taken since the last reset (bessx_session_submodel_steps)
   bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (BESSX_DEFER_PUBLISH=0: in the tail)
   bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
   // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
@@ -1811,6 +1812,7 @@ static int algorithm_fit(bessx_session *s) {
     if (int rc = k1_collect(s, k1_pairs)) return rc;
     k1_pairs.clear();
     if (steps_used > 0) s->irls_guess = std::min(tmax + 1, steps_used + 1);
+    s->n_submodel_steps += steps_used;
     slot++;
     if (hc->done) break;
   }
@@ -3483,6 +3485,13 @@ int bessx_session_get_normalization(bessx_session *s, double *x_mean, double *x_
 int bessx_session_enable_kernel_timing(bessx_session *s, int on) {
   if (!s) return fail(BESSX_ERR_ARG, "null session");
   s->timing = on != 0;
+  return BESSX_OK;
+}
+
+int bessx_session_submodel_steps(bessx_session *s, int reset, long long *steps) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  if (steps) *steps = s->n_submodel_steps;
+  if (reset) s->n_submodel_steps = 0;
   return BESSX_OK;
 }
 

@@ -221,6 +221,10 @@ int bessx_session_get_normalization(bessx_session *s, double *x_mean, double *x_
 int bessx_session_score_pass_stats(bessx_session *s, int reset, double *seconds, long long *launches,
                                    double *algorithmic_bytes);
 int bessx_session_enable_kernel_timing(bessx_session *s, int on);
+/* Steps of the restricted fits' inner iterations taken since the last reset: IRLS solves of the logistic / Poisson
+ * fits (src/Algorithm.h:1148-1204, 1273-1322), Newton steps of the Cox fit (:1377-1490); 0 for LM.  A statistic for
+ * bench.py (time per step of the chain between two passes over X). */
+int bessx_session_submodel_steps(bessx_session *s, int reset, long long *steps);
 
 /* ---------------------------------------------------------------------------------------
  * 3. One Algorithm::fit (src/Algorithm.h:113-171) on the resident data.
