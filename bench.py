@@ -21,6 +21,10 @@ the IC curve (8 B per candidate) is all-gathered over RCCL each step and every r
 first candidate starts cold, so its chain can differ from the single chain's: after the timed
 region rank 0 runs the single chain and the line reports for how many k the supports agree.
 --shard replica: WEAK scaling, N independent problems (rank-specific response on the same design).
+--workload cox-seq: BASELINE configs[4] (Cox PDAS, n=200000 p=20000 k<=150), the same k-path split: every candidate pays
+its own passes over the 32 GB design, so this is the path whose chunks scale; every rank generates and uploads the
+whole design (32 GB of host memory per rank while it does).
+--chunk-start cold|ladder: how a chunk that begins at k0 > 1 gets there (see --help).
 --workload lm-cv-gs: BASELINE configs[3] (gs_path on [1, kmax] under 5-fold CV), the K fold chains + the full-data
 chain and, in the final sweep, (fold x s) pairs dealt to the ranks (bess_amd.dist.FoldShardedCV).
 
@@ -61,11 +65,18 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=50000)
-    ap.add_argument("--p", type=int, default=10000)
-    ap.add_argument("--kmax", type=int, default=200)
-    ap.add_argument("--k-true", type=int, default=100)
-    ap.add_argument("--workload", choices=["lm-seq", "lm-cv-gs"], default="lm-seq")
+    ap.add_argument("--n", type=int, default=None, help="default: 50000 (lm-*), 200000 (cox-seq)")
+    ap.add_argument("--p", type=int, default=None, help="default: 10000 (lm-*), 20000 (cox-seq)")
+    ap.add_argument("--kmax", type=int, default=None, help="default: 200 (lm-*), 150 (cox-seq)")
+    ap.add_argument("--k-true", type=int, default=None, help="default: 100 (lm-*), 75 (cox-seq)")
+    ap.add_argument("--workload", choices=["lm-seq", "lm-cv-gs", "cox-seq"], default="lm-seq",
+                    help="lm-seq = BASELINE configs[1] (the metric); lm-cv-gs = configs[3]; cox-seq = configs[4]")
+    ap.add_argument("--chunk-start", choices=["auto", "cold", "ladder"], default="auto",
+                    help="N > 1, --shard kpath: how a chunk that does not begin at k = 1 reaches its first sparsity "
+                         "level: cold = Algorithm::fit from the empty model at k0; ladder = a warm-start chain up the "
+                         "levels k0/8, k0/4, k0/2 first (their candidates are discarded); auto = ladder from k0 = 128 "
+                         "(measured on configs[1], tools/coldstart.py: 11.2 vs 12.2 ms at k0 = 176, but 7.9 vs 7.2 ms at "
+                         "k0 = 101)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per timed segment")
     ap.add_argument("--shard", choices=["auto", "replica", "kpath"], default="auto",
@@ -76,7 +87,14 @@ def parse_args(argv=None):
                     help="skip the extra (untimed-by-contract) measurement of the streaming score pass at N=1")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the N=1 measurements of BASELINE configs[2], [3], [4] (other_configs in the line)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.chunk_start_option = args.chunk_start
+    dn, dp, dk, dt = (200000, 20000, 150, 75) if args.workload == "cox-seq" else (50000, 10000, 200, 100)
+    args.n = dn if args.n is None else args.n
+    args.p = dp if args.p is None else args.p
+    args.kmax = dk if args.kmax is None else args.kmax
+    args.k_true = dt if args.k_true is None else args.k_true
+    return args
 
 
 def launch_ranks(args):
@@ -318,16 +336,32 @@ def main():
 
     shard = args.shard if args.shard != "auto" else "kpath"
     kpath = shard == "kpath" and distributed
-    X, y = make_problem(args.n, args.p, args.k_true, 0 if (kpath or not distributed) else rank)
+    cox = args.workload == "cox-seq"
+    if cox:
+        # configs[4]: every rank holds the whole (replicated) design; rows sorted by time, y = status
+        X, _, y, _, _ = synth.make_cox(args.n, args.p, args.k_true)
+    else:
+        X, y = make_problem(args.n, args.p, args.k_true, 0 if (kpath or not distributed) else rank)
     full_seq = np.arange(1, args.kmax + 1)
     seq = full_seq
+    n_lead = 0  # candidates in front of the chunk that only lead up to it (ladder start): run, timed, discarded
     if kpath:
         lo, hi = bdist.partition(args.kmax, world, rank)
         seq = full_seq[lo:hi]
+        k0 = int(seq[0]) if len(seq) else 0
+        if args.chunk_start == "auto":
+            args.chunk_start = "ladder" if k0 >= 128 else "cold"  # (per rank; the line reports rank 0's = "cold")
+        if args.chunk_start == "ladder" and lo > 0:
+            lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
+            n_lead = len(lead)
+            seq = np.concatenate([np.array(lead, dtype=full_seq.dtype), seq])
     t0 = time.time()
     mode = {"auto": 0, "streaming": 1, "covariance": 2}[args.score_mode]
-    sess = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
-                        score_mode=mode, device=local_rank)
+    if cox:
+        sess = capi.Session(X, y, data_type=3, model_type=4, max_iter=20, is_warm_start=True, device=local_rank)
+    else:
+        sess = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
+                            score_mode=mode, device=local_rank)
     covariance = sess.score_mode() == 2
     torch.cuda.synchronize()
     upload_s = time.time() - t0
@@ -344,6 +378,10 @@ def main():
     for _ in range(args.steps):
         out = sess.sequential_path(seq, ic_type=3)
         pdas_iters += out["n_pdas_iters"]
+        if n_lead:  # the ladder's own candidates are not part of the chunk
+            for key in ("cand_ic", "cand_support", "cand_iters", "cand_beta", "cand_train_loss", "cand_T0"):
+                if key in out:
+                    out[key] = out[key][n_lead:]
         if kpath:  # gather the IC curve: the only collective of the path
             ic_curves = bdist.gather_curve(out["cand_ic"], args.kmax, world, rank, device=comm_dev)[None, :]
         elif distributed:
@@ -373,7 +411,10 @@ def main():
                 "supports_equal_to_single_chain": int(np.sum(same)), "of": args.kmax,
                 "differing_k": [int(k + 1) for k in range(args.kmax) if not same[k]][:40],
                 "best_k_chunked": int(bdist.select_best(ic_curves[0])) + 1, "best_k_single_chain": int(single["best_T0"]),
-                "seconds_per_rank_last_step": [round(float(v), 5) for v in rank_seconds]}
+                "seconds_per_rank_last_step": [round(float(v), 5) for v in rank_seconds],
+                "chunk_start": args.chunk_start_option,
+                "chunk_start_meaning": "auto: ladder for chunks beginning at k0 >= 128, else cold; ladder: a chunk beginning at k0 > 1 first climbs the warm-start chain k0/8, k0/4, "
+                                       "k0/2 (timed, candidates discarded); cold: Algorithm::fit from the empty model at k0"}
 
     def roofline_of(stats, cov):
         """HBM roofline of the kernel that streams X: algorithmic bytes (8 n p per pass over X) / its HIP-event time."""
@@ -391,7 +432,8 @@ def main():
             except Exception:
                 traffic = None
         kern = ("k_cov_panel (X^T diag(m) X_S on the fp64 matrix cores: 32 new Gram columns per pass over X)"
-                if cov else "k_xtv<8,16,false> (X^T r score pass)")
+                if cov else ("k_cox_score1p (risk-set score of all p columns, X read once)" if cox else
+                             "k_xtv<8,16,false> (X^T r score pass)"))
         roof = {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": 8.0 * args.n * args.p, "avg_launch_ms": 1e3 * per_pass,
@@ -414,19 +456,25 @@ def main():
         step_s = dt / args.steps
         x_seconds = k1["seconds"] / args.steps
         line = {
-            "metric": "candidate subsets solved/sec (n=50k,p=10k,k<=200 LM)", "value": value,
+            "metric": ("candidate subsets solved/sec (Cox n=%dk,p=%dk,k<=%d)" % (args.n // 1000, args.p // 1000, args.kmax)
+                       if cox else "candidate subsets solved/sec (n=50k,p=10k,k<=200 LM)"), "value": value,
             "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * step_s, "higher_is_better": True,
             "scaling": "strong" if (kpath or not distributed) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: LM sequential path, Gaussian X n=%d p=%d, s.list=1..%d, GIC, "
-                                   "warm start, max_iter=20, is_normal" % (args.n, args.p, args.kmax),
+            "config": {"workload": ("configs[4]: Cox PDAS sequential path, Gaussian X n=%d p=%d (rows sorted by time), "
+                                    "s.list=1..%d, GIC, warm start, max_iter=20" % (args.n, args.p, args.kmax)) if cox else
+                                   ("configs[1]: LM sequential path, Gaussian X n=%d p=%d, s.list=1..%d, GIC, "
+                                    "warm start, max_iter=20, is_normal" % (args.n, args.p, args.kmax)),
                        "candidates_per_step": args.kmax * (1 if (kpath or not distributed) else world),
                        "units_sharded": ("contiguous chunks of s.list, one warm-start chain per rank, X replicated"
                                          if kpath else "independent problems (one response vector per rank on a "
                                          "replicated X)" if distributed else "none (one GPU)"),
                        "collective": "all_gather of the IC curve" if distributed else "none",
-                       "score_pass": "covariance updates (cached Gram columns)" if covariance else "streaming"},
+                       "score_pass": "covariance updates (cached Gram columns)" if covariance else "streaming",
+                       # k-path chunks: every rank owns a chunk of at least one candidate as long as N <= kmax
+                       "ranks_with_work": min(world, args.kmax) if kpath else world,
+                       "chunk_start": (args.chunk_start_option if kpath else None)},
             "roofline": roof,
             # the WHOLE step against the HBM roof: bytes the step streams from X / step time, and where the time goes
             "whole_step": {"bytes_streamed_from_X": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p,
@@ -451,7 +499,7 @@ def main():
         if chunk_report:
             line["kpath_chunks_vs_single_chain"] = chunk_report
         norm = sess.normalization() if world == 1 else None
-        if covariance and world == 1 and not args.no_streaming_leg:
+        if covariance and world == 1 and not args.no_streaming_leg and not cox:
             # the other evaluation of the same path (every PDAS iteration reads X once), for comparison
             sess.close()
             s2 = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
@@ -475,13 +523,13 @@ def main():
         if ic_curves is not None and not kpath:
             line["ic_curves_gathered"] = int(ic_curves.shape[0])
             line["best_k_per_problem"] = [int(bdist.select_best(c)) + 1 for c in ic_curves]
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not cox:
             try:
                 line["cpu_baseline"] = cpu_baseline(X, y, out, norm, args.kmax, args.cpu_budget)
             except Exception as e:  # the checker is optional for the measurement itself
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": 1, "kind": "port",
                                         "sample": "failed: %r" % (e,)}
-        if world == 1 and not args.no_other_configs and (args.n, args.p, args.kmax) == (50000, 10000, 200):
+        if world == 1 and not cox and not args.no_other_configs and (args.n, args.p, args.kmax) == (50000, 10000, 200):
             sess.close()
             try:
                 line["other_configs"] = measure_other_configs(local_rank, X, y)

@@ -68,3 +68,20 @@ def test_bench_weak_scaling_and_cv_workload_on_two_ranks(gpu):
     for k in ("selected_k", "fits_per_step", "pdas_iterations_per_step"):
         assert one[k] == two[k], k
     assert abs(one["cv_loss"] - two["cv_loss"]) <= 1e-12 * abs(one["cv_loss"])
+
+
+def test_bench_cox_k_path_on_two_ranks(gpu):
+    """`bench.py --workload cox-seq --gpus 2` (BASELINE configs[4] at reduced size): the Cox k-path in two contiguous
+    chunks, IC curve all-gathered, chunks compared with the single chain after the timed region; both ways a chunk can
+    reach its first sparsity level."""
+    for start in ("ladder", "cold"):
+        d = _run_bench(["--gpus", "2", "--workload", "cox-seq", "--chunk-start", start], {"BESSX_BENCH_ONE_DEVICE": "1"})
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["metric"].startswith("candidate subsets solved/sec (Cox")
+        assert d["config"]["ranks_with_work"] == 2 and d["config"]["chunk_start"] == start
+        assert abs(d["value"] - 30 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+        rep = d["kpath_chunks_vs_single_chain"]
+        assert rep["chunks"] == [[1, 15], [16, 30]] and rep["of"] == 30 and rep["chunk_start"] == start
+        assert rep["supports_equal_to_single_chain"] >= 25 and rep["best_k_chunked"] == rep["best_k_single_chain"]
+        assert d["roofline"]["kernel"].startswith("k_cox_score1p") and d["roofline"]["achieved"] > 0
+    one = _run_bench(["--workload", "cox-seq"])
+    assert one["n_gpus"] == 1 and one["selected_k"] == d["kpath_chunks_vs_single_chain"]["best_k_single_chain"]
