@@ -97,14 +97,36 @@ def parse_args(argv=None):
     return args
 
 
+def visible_gpus():
+    """GPUs this process could use, found without the HIP / HSA runtime (the launching process stays clear of the GPU):
+    none without /dev/kfd; the *_VISIBLE_DEVICES list if one is set; else the GPU agents in the kernel driver's topology
+    files (an upper bound inside a container that exposes fewer).  None when nothing can be read -- the ranks then fail by
+    themselves on a missing device."""
+    if not os.path.exists("/dev/kfd"):
+        return 0  # no compute driver node: no GPU for this process
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            return len([v for v in os.environ[var].split(",") if v.strip()])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        count = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+        return count
+    except (OSError, ValueError):
+        return None
+
+
 def launch_ranks(args):
-    """--gpus N > 1 and no launcher: start N fresh ranks.  Nothing in this process has touched the GPU
-    (torch.cuda.device_count() does not initialise it), and it never exec()s: the ranks are children."""
+    """--gpus N > 1 and no launcher: start N fresh ranks as CHILD processes (never exec).  The parent does not import
+    torch and makes no HIP call; the device count comes from the driver's topology files."""
     one_dev = os.environ.get("BESSX_BENCH_ONE_DEVICE") == "1"
     if not one_dev:
-        import torch
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        have = visible_gpus()
+        if have is not None and have < args.gpus:
             print("bench.py: --gpus %d but %d visible (BESSX_BENCH_ONE_DEVICE=1 rehearses on one device)"
                   % (args.gpus, have), file=sys.stderr)
             return 2
@@ -350,7 +372,9 @@ def main():
         seq = full_seq[lo:hi]
         k0 = int(seq[0]) if len(seq) else 0
         if args.chunk_start == "auto":
-            args.chunk_start = "ladder" if k0 >= 128 else "cold"  # (per rank; the line reports rank 0's = "cold")
+            # (LM, covariance form: the ladder saves Gram-column passes at large k0; Cox: every rung pays its own passes
+            # over X and the cold start is faster at every k0 -- tools/coldstart.py, tools/coldstart_cox.py)
+            args.chunk_start = "ladder" if (k0 >= 128 and not cox) else "cold"
         if args.chunk_start == "ladder" and lo > 0:
             lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
             n_lead = len(lead)

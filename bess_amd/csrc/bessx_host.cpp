@@ -967,7 +967,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
       nd.snap = *sf->pub;  // last slot of a chained batch: a repeated set is recorded AND snapshotted here
       nd.snap.on = 2;
     }
-    if (s->fuse_sel && s->fuse && s->cov_cg && sel_cgr_applies(s->p, T0)) {
+    if (s->fuse_sel && s->fuse && s->cov_cg && s->cg_by_rows && sel_cgr_applies(s->p, T0)) {  // (k_sel_cgr solves by rows)
       // selection and solve of this slot in ONE launch (k_sel_cgr): same phases, same control-block protocol
       CholFuse fz = cov_fuse_args(s, rs, T0, false, sf);
       const bool hv = s->hinv && fz.GS != nullptr;
@@ -3318,6 +3318,34 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
   // shared fills (see bessx_session::cv_shared): LM in the covariance form, no background fills
   bool share = s->cov_mode && s->model_type == 1 && !s->cov_bg && !s->grouped;
   if (const char *ev = std::getenv("BESSX_CV_SHARED")) share = share && std::string(ev) != "0";
+  // The shared fills need a fold-major second copy of X (every fold padded to whole row slabs).  Whether they are used
+  // is settled HERE, before any cache is created as a sharer of row set 0's slot map: the copy must not be much larger
+  // than X (many small folds pad badly: K <= n is accepted) and its allocations must succeed -- otherwise the masked
+  // per-row-set fills, which need nothing extra, stay in place instead of set_cv failing.
+  int sh_nsl = 0, sh_rps = 0;
+  long sh_ldp = 0;
+  if (share) {
+    std::vector<int> cnt((size_t)K, 0);
+    for (int i = 0; i < n; i++) cnt[fold[i]]++;
+    const int nmax = *std::max_element(cnt.begin(), cnt.end());
+    sh_nsl = std::max(1, (nmax + 1023) / 2048);
+    sh_rps = ((nmax + sh_nsl - 1) / sh_nsl + 63) / 64 * 64;
+    sh_ldp = (long)sh_nsl * sh_rps * K;
+    const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
+    hipError_t e = sh_ldp * 2 > s->ld * 3 ? hipErrorOutOfMemory : hipSuccess;  // more than 1.5 x the rows of X
+    if (e == hipSuccess) e = dmalloc(&s->Xp, (size_t)sh_ldp * p);
+    if (e == hipSuccess) e = dmalloc(&s->zp, (size_t)sh_ldp);
+    if (e == hipSuccess)
+      e = dmalloc(&s->cvp_part, (size_t)COV_SLOT_GROUPS * K * sh_nsl * njg * cov_streamed_tiles_per_wave() * 2 * 256);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();  // (an allocation failure is not an error of this call)
+      (void)hipFree(s->Xp);
+      (void)hipFree(s->zp);
+      (void)hipFree(s->cvp_part);
+      s->Xp = s->zp = s->cvp_part = nullptr;
+      share = false;
+    }
+  }
   std::vector<double> m((size_t)s->ld);
   for (int k = 0; k < K; k++) {
     std::fill(m.begin(), m.end(), 0.0);
@@ -3375,22 +3403,13 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
   }
   if (share) {
     // fold-major copy: fold k's test rows (ascending) padded with zero rows to cvp_nsl whole slabs of cvp_rps rows
-    int nmax = 0;
-    for (int k = 0; k < K; k++) nmax = std::max(nmax, s->n_test[k]);
-    const int nsl = std::max(1, (nmax + 1023) / 2048);
-    const int rps = ((nmax + nsl - 1) / nsl + 63) / 64 * 64;
-    const long seg = (long)nsl * rps, ldp = seg * K;
+    const long seg = (long)sh_nsl * sh_rps, ldp = sh_ldp;
     std::vector<int> perm((size_t)ldp, -1), fill((size_t)K, 0);
     for (int i = 0; i < n; i++) perm[(size_t)fold[i] * seg + fill[fold[i]]++] = i;
     int *dperm = nullptr;
-    const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
     hipError_t e = dmalloc(&dperm, (size_t)ldp);
     if (e == hipSuccess) e = hipMemcpy(dperm, perm.data(), (size_t)ldp * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = dmalloc(&s->Xp, (size_t)ldp * p);
-    if (e == hipSuccess) e = dmalloc(&s->zp, (size_t)ldp);
     if (e == hipSuccess) e = hipMemsetAsync(s->zp, 0, (size_t)ldp * sizeof(double), s->st);
-    if (e == hipSuccess)
-      e = dmalloc(&s->cvp_part, (size_t)COV_SLOT_GROUPS * K * nsl * njg * cov_streamed_tiles_per_wave() * 2 * 256);
     if (e == hipSuccess) e = launch_rows_permute(s->X, s->ld, p, dperm, ldp, s->Xp, s->st);
     if (e == hipSuccess) e = hipStreamSynchronize(s->st);
     (void)hipFree(dperm);
@@ -3399,11 +3418,14 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
       return fail(BESSX_ERR_HIP, std::string("set_cv (fold-major copy): ") + hipGetErrorString(e));
     }
     s->ldp = ldp;
-    s->cvp_rps = rps;
-    s->cvp_nsl = nsl;
+    s->cvp_rps = sh_rps;
+    s->cvp_nsl = sh_nsl;
     s->cv_shared = true;
     // every cache now holds the same columns: start them (and the shared slot map) from empty
-    if (int rc = reset_path_caches(s)) return rc;
+    if (int rc = reset_path_caches(s)) {
+      drop_folds(s);
+      return rc;
+    }
   }
   HIPX(hipStreamSynchronize(s->st));
   return BESSX_OK;
