@@ -122,7 +122,7 @@ int irls_gram_slab_rows(int mt, long ld);
 hipError_t launch_irls_gram(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
                             const double *y, const double *w, const double *mask, int nslab, int mt, double *part,
                             int ntiles, const FitCtrl *ctrl, int slot, int t, int T0, const double *bcur,
-                            double *llpart, hipStream_t st);
+                            double *llpart, hipStream_t st, int wfloor = 1);
 hipError_t launch_gram_reduce(const double *part, int nslab, int ntiles, double *Gt, const FitCtrl *ctrl, int slot,
                               int gate_mode, hipStream_t st);
 hipError_t launch_gram(const double *X, const double *aux, long ld, const int *cols, const double *w,
@@ -198,7 +198,8 @@ hipError_t launch_glm_irls_begin(const FitCtrl *ctrl, int slot, int fam, int m, 
                                  hipStream_t st);
 hipError_t launch_glm_irls_prep(int fam, const double *X, long ld, int n, const double *y, const double *w,
                                 const double *mask, const FitCtrl *ctrl, int slot, int t, const int *A_new, int T0,
-                                const double *bcur, double *Wv, double *z, double *llpart, hipStream_t st);
+                                const double *bcur, double *Wv, double *z, double *llpart, hipStream_t st,
+                                int wfloor = 1);
 hipError_t launch_glm_irls_check(FitCtrl *ctrl, int slot, int t, int fam, const double *llpart, int nblk, int m,
                                  double *bcur, double *bprev, hipStream_t st);
 // Cox (src/Algorithm.h:1370-1650, src/coxph.cpp:16-40)
@@ -219,6 +220,8 @@ struct CoxBufs {
   // column totals of theta x, the slab carries and the vectors q_b
   int hess_fused;
   double *CW, *HP2, *HT, *CAR, *HQ;
+  double fit_clamp;  // clamp of the linear predictor in the Newton step: 30 (src/Algorithm.h:1417-1422); cox_fit of the
+                     // screening uses 50 (src/coxph.cpp:65-71)
 };
 int cox_hess_slab_rows(long ld);
 bool cox_hess_applies(int mt);

@@ -27,6 +27,9 @@
 namespace bessx {
 
 static thread_local std::string g_err;
+// set while a session is created for the marginal fit of one wide group of the screening (screening(),
+// src/screening.cpp:42-63): 1 = logit_fit (no weight floor), 2 = cox_fit (linear predictor clamped at 50)
+static thread_local int g_marginal_fit_variant = 0;
 
 static int fail(int code, const std::string &msg) {
   g_err = msg;
@@ -172,6 +175,8 @@ struct bessx_session {
   // solve.  (Round 2's k_gram_irls did the per-row work 64 rows at a time between the barriers of the staging pipeline
   // and lost, 0.180 s against 0.175 s on configs[2]; it is gone.)
   bool irls_fuse = true;   // GLM IRLS step as k_irls_gram + k_gram_reduce + k_chol (BESSX_IRLS_FUSE=0: the five-launch step)
+  int irls_wfloor = 1;     // floor of the logistic IRLS weight inside the loop (src/Algorithm.h:1188-1192); 0 in the
+                           // sub-sessions that run logit_fit for the screening of wide groups (src/logistic.cpp:60-160)
   size_t llpart_cap = 0;
   long long n_submodel_steps = 0;  // IRLS / Newton steps taken since the last reset (bessx_session_submodel_steps)
   bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (BESSX_DEFER_PUBLISH=0: in the tail)
@@ -1083,7 +1088,7 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
     const int ns = (int)((s->ld + rows - 1) / rows);
     if ((size_t)ns * ntiles * 256 <= s->gpart_elems && (size_t)ns <= s->llpart_cap) {
       hipError_t e = launch_irls_gram(fam, s->X, s->aux, s->ld, s->n, s->gcols, s->y, s->w, s->mask[rs], ns, mt,
-                                      s->gpart, ntiles, s->ctrl, slot, t, T0, s->bcur, s->llpart, s->st);
+                                      s->gpart, ntiles, s->ctrl, slot, t, T0, s->bcur, s->llpart, s->st, s->irls_wfloor);
       if (e == hipSuccess) e = launch_gram_reduce(s->gpart, ns, ntiles, s->Gt, s->ctrl, slot, 1, s->st);
       const IrlsChk ck = {1, s->ctrl, t, fam, s->llpart, ns, T0 + 1, s->bcur, s->bprev};
       if (e == hipSuccess)
@@ -1094,7 +1099,7 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
     }
   }
   hipError_t e = launch_glm_irls_prep(fam, s->X, s->ld, s->n, s->y, s->w, s->mask[rs], s->ctrl, slot, t, s->A_new, T0,
-                                      s->bcur, s->Wv, z, s->llpart, s->st);
+                                      s->bcur, s->Wv, z, s->llpart, s->st, s->irls_wfloor);
   if (e == hipSuccess)
     e = launch_glm_irls_check(s->ctrl, slot, t, fam, s->llpart, s->n_sse_blk, T0 + 1, s->bcur, s->bprev, s->st);
   const GramTask *tk = nullptr;
@@ -2623,6 +2628,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
     HIPT(gram_lds_prepare());
     if (const char *ev = std::getenv("BESSX_IRLS_FUSE")) s->irls_fuse = std::string(ev) == "1";
+    s->irls_wfloor = g_marginal_fit_variant == 1 ? 0 : 1;
     if (const char *ev = std::getenv("BESSX_GRAM")) gram_set_variant(std::string(ev) == "direct" ? 0 : 1);
   }
   const int n = pb->n;
@@ -2742,21 +2748,12 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         if (e == hipSuccess)
           e = launch_group_lsq_score(Ng, gd, gd + Ng, gd + 2 * Ng, mblk, dcol, fl_d, mwork, zw, score, s->st);
       } else if (pb->model_type == 4) {
-        // cox_fit on the columns of a group (src/coxph.cpp:42-108)
-        if (!screen_cox_group_supported(gmax)) {
-          gdrop();
-          drop();
-          return bail(fail(BESSX_ERR_UNSUPPORTED, "Cox screening: groups of more than 4 columns are not built"));
-        }
+        // cox_fit on the columns of a group (src/coxph.cpp:42-108): one block per group up to 4 columns
+        // (k_screen_cox_group leaves wider groups alone; their fit follows below)
         if (e == hipSuccess)
           e = launch_screen_cox_group(Xraw, ld, n, Ng, gd, gd + Ng, yw, yw + ld, fl_d, score, s->st);
       } else {
-        // logit_fit on the columns of a group (src/logistic.cpp:60-160)
-        if (!screen_logit_group_supported(gmax)) {
-          gdrop();
-          drop();
-          return bail(fail(BESSX_ERR_UNSUPPORTED, "logistic screening: groups of more than 8 columns are not built"));
-        }
+        // logit_fit on the columns of a group (src/logistic.cpp:60-160): one block per group up to 8 columns
         double *gstate = nullptr;
         if (e == hipSuccess) e = dmalloc(&gstate, screen_logit_group_state_doubles(Ng));
         if (e == hipSuccess)
@@ -2765,6 +2762,71 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         (void)hipFree(gstate);
       }
       if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+      if (e == hipSuccess && pb->model_type != 1) {
+        // Wider groups: logit_fit / cox_fit ARE the families' restricted fits on the group's columns (cold start,
+        // lambda = 0, the same stopping rules) -- logit_fit without the floor of the IRLS weight, cox_fit with the
+        // linear predictor clamped at 50 instead of 30 in the Newton direction.  Each such group is fitted by the
+        // solver's own chain (IRLS: k_irls_gram + k_chol; Newton: k_cox_hess ...) in a sub-session that holds just its
+        // columns, unnormalised, with every column active.
+        const bool logit = pb->model_type == 2;
+        const int limit = logit ? 8 : 4;
+        for (int g = 0; g < Ng && e == hipSuccess; g++) {
+          const int gs = g_sz[g];
+          if (gs <= limit) continue;
+          double sc = DBL_MAX;
+          if (!fl[g]) {
+            if (logit && n <= gs) {
+              gdrop();
+              drop();
+              return bail(fail(BESSX_ERR_UNSUPPORTED, "logistic screening: a group at least as wide as the sample is "
+                               "undefined behaviour in the reference (logit_fit returns n coefficients, "
+                               "src/logistic.cpp:62-110, of which screening() reads the last g_size, src/screening.cpp:60)"));
+            }
+            std::vector<double> xs((size_t)n * gs);
+            if (pb->x_col_major) {
+              std::memcpy(xs.data(), pb->x + (size_t)g_lo[g] * n, xs.size() * sizeof(double));
+            } else {
+              for (int i = 0; i < n; i++)
+                for (int u = 0; u < gs; u++) xs[(size_t)i * gs + u] = pb->x[(size_t)i * pf + g_lo[g] + u];
+            }
+            bessx_problem q = {};
+            q.n = n;
+            q.p = gs;
+            q.x = xs.data();
+            q.x_col_major = pb->x_col_major;
+            q.y = pb->y;
+            q.weight = pb->weight;
+            q.data_type = logit ? 2 : 3;
+            q.is_normal = 0;
+            q.model_type = pb->model_type;
+            q.algorithm_type = 1;
+            q.max_iter = 2;  // the second PDAS iteration repeats the (complete) active set and ends the fit
+            q.is_warm_start = 1;
+            q.device = s->device;
+            bessx_session *sub = nullptr;
+            g_marginal_fit_variant = logit ? 1 : 2;
+            int rc = bessx_session_create(&sub, &q);
+            g_marginal_fit_variant = 0;
+            std::vector<int> sup((size_t)gs);
+            std::vector<double> bq((size_t)gs);
+            if (rc == 0)
+              rc = bessx_session_fit(sub, gs, 0.0, -1, nullptr, nullptr, 0, 0.0, sup.data(), bq.data(), nullptr, nullptr,
+                                     nullptr, nullptr);
+            if (sub) bessx_session_destroy(sub);
+            (void)hipSetDevice(s->device);
+            if (rc != 0) {
+              gdrop();
+              drop();
+              return bail(rc);
+            }
+            double acc = 0.0;
+            for (int u = 0; u < gs; u++) acc += bq[u] * bq[u];
+            const double v = acc / (double)gs;  // coef_norm, src/screening.cpp:60
+            sc = (v <= DBL_MAX) ? v : 0.0;
+          }
+          e = hipMemcpy(score + g, &sc, sizeof(double), hipMemcpyHostToDevice);
+        }
+      }
       gdrop();
       if (e != hipSuccess) {
         drop();
@@ -3212,6 +3274,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     // matrix) its rounding follows the reference's more closely -- both forms are accurate to rounding there, but a
     // Newton iteration on such a system amplifies rounding to 1e-4 and beyond (tests/test_cox_gpu.py).
     // BESSX_COX_HESS=1pass forces the one-pass form at any size.
+    c.fit_clamp = g_marginal_fit_variant == 2 ? 50.0 : 30.0;
     c.hess_fused = n >= 1024 ? 1 : 0;
     if (const char *ev = std::getenv("BESSX_COX_HESS")) c.hess_fused = std::string(ev) == "2pass" ? 0 : (std::string(ev) == "1pass" ? 1 : c.hess_fused);
     if (c.hess_fused) {

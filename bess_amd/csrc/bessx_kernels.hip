@@ -1061,7 +1061,8 @@ __global__ void __launch_bounds__(512) k_irls_gram(const double *__restrict__ X,
                                                    const double *__restrict__ mask, int rows_per_slab, int mt,
                                                    double *__restrict__ part, int ntiles,
                                                    const FitCtrl *__restrict__ ctrl, int slot, int t, int T0,
-                                                   const double *__restrict__ bcur, double *__restrict__ llpart) {
+                                                   const double *__restrict__ bcur, double *__restrict__ llpart,
+                                                   int wfloor) {
   if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
   constexpr int RB = 64, GL_LD = RB + 2, TPC = RB / 2, NW = 8, CPP = 64 * NW / TPC, ROWS = NCH * RB;
   extern __shared__ double smem[];  // [tile: mp x GL_LD | etap: NW x ROWS (phase B only)] Wl[ROWS] zl[ROWS] bet[mp]
@@ -1142,7 +1143,7 @@ __global__ void __launch_bounds__(512) k_irls_gram(const double *__restrict__ X,
           const double e = exp(clampv(eta, 30.0)), Pi = e / (1.0 + e);
           ll += (yy * log(Pi) + (1.0 - yy) * log(1.0 - Pi)) * ww * mm;
           double W = Pi * (1.0 - Pi);
-          if (t > 0 && W < 0.001) W = 0.001;
+          if (t > 0 && wfloor && W < 0.001) W = 0.001;  // (logit_fit of the screening has no floor, src/logistic.cpp:60-160)
           zt = eta + (yy - Pi) / W;
           Wt = W * ww * mm;
         } else {
@@ -3709,7 +3710,8 @@ __global__ void __launch_bounds__(128) k_glm_irls_prep(const double *__restrict_
                                                        const FitCtrl *__restrict__ ctrl, int slot, int t,
                                                        const int *__restrict__ A_new, int T0,
                                                        const double *__restrict__ bcur, double *__restrict__ Wv,
-                                                       double *__restrict__ z, double *__restrict__ llpart) {
+                                                       double *__restrict__ z, double *__restrict__ llpart,
+                                                       int wfloor) {
   if (ctrl->done || ctrl->l != slot - 1 || ctrl->same_prev || ctrl->irls_done || ctrl->irls_steps != t) return;
   const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
   double ll = 0.0;
@@ -3729,7 +3731,7 @@ __global__ void __launch_bounds__(128) k_glm_irls_prep(const double *__restrict_
           double e = exp(clampv(eta, 30.0)), Pi = e / (1.0 + e);
           ll += (yy * log(Pi) + (1.0 - yy) * log(1.0 - Pi)) * ww * mm;
           double W = Pi * (1.0 - Pi);
-          if (t > 0 && W < 0.001) W = 0.001;
+          if (t > 0 && wfloor && W < 0.001) W = 0.001;
           zt = eta + (yy - Pi) / W;
           Wt = W * ww * mm;
         } else {
@@ -4245,7 +4247,7 @@ __global__ void __launch_bounds__(128) k_cox_fit_eta(const double *__restrict__ 
                                                      const FitCtrl *__restrict__ ctrl, int slot, int t,
                                                      const int *__restrict__ A_new, int k,
                                                      const double *__restrict__ b0, double *__restrict__ ETA0,
-                                                     double *__restrict__ THF) {
+                                                     double *__restrict__ THF, double clampc) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   const long i = ((long)blockIdx.x * 128 + threadIdx.x) * 2;
   if (i >= ld) return;
@@ -4253,7 +4255,7 @@ __global__ void __launch_bounds__(128) k_cox_fit_eta(const double *__restrict__ 
   const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
   *reinterpret_cast<d2 *>(ETA0 + i) = sx;
   *reinterpret_cast<d2 *>(THF + i) =
-      d2{i < n ? exp(clampv(sx.x, 30.0)) * mk.x : 0.0, i + 1 < n ? exp(clampv(sx.y, 30.0)) * mk.y : 0.0};
+      d2{i < n ? exp(clampv(sx.x, clampc)) * mk.x : 0.0, i + 1 < n ? exp(clampv(sx.y, clampc)) * mk.y : 0.0};
 }
 
 // C_i = prefix sum of w delta / S0 ;  VG = w delta - theta C (so that g = X_A^T VG, :1429) ; WG1 = theta C
@@ -4327,7 +4329,7 @@ __global__ void __launch_bounds__(SC_T) k_cox_cscan_apply(const double *__restri
 __global__ void __launch_bounds__(256) k_cox_eta_upd(long ld, int n, const double *__restrict__ mask,
                                                      const FitCtrl *__restrict__ ctrl, int slot, int t,
                                                      const double *__restrict__ UD, double *__restrict__ ETA0,
-                                                     double *__restrict__ THF) {
+                                                     double *__restrict__ THF, double clampc) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
   if (i >= ld) return;
@@ -4340,7 +4342,7 @@ __global__ void __launch_bounds__(256) k_cox_eta_upd(long ld, int n, const doubl
   const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
   *reinterpret_cast<d2 *>(ETA0 + i) = e;
   *reinterpret_cast<d2 *>(THF + i) =
-      d2{i < n ? exp(clampv(e.x, 30.0)) * mk.x : 0.0, i + 1 < n ? exp(clampv(e.y, 30.0)) * mk.y : 0.0};
+      d2{i < n ? exp(clampv(e.x, clampc)) * mk.x : 0.0, i + 1 < n ? exp(clampv(e.y, clampc)) * mk.y : 0.0};
 }
 
 // M[:, a] = suffix(theta x_a) / S0 (the n x k matrix S1/S0, :1426-1428) and g_a = x_a . VG + 2 lambda b0_a (:1429).
@@ -4956,7 +4958,7 @@ __global__ void __launch_bounds__(256) k_screen_logit_group(const double *__rest
                                                             int t, double *__restrict__ state, int *__restrict__ done) {
   constexpr int M = SGL_MAX + 1, NT = M * (M + 1) / 2;
   const int g = blockIdx.x;
-  if (done[g]) return;
+  if (done[g] || gsz[g] > SGL_MAX) return;  // (wider groups: the restricted-fit chain of a sub-session, host side)
   __shared__ double sm[4];
   __shared__ double bsh[M];
   const int s = gsz[g], m = s + 1;
@@ -5047,6 +5049,7 @@ __global__ void __launch_bounds__(256) k_screen_score_logit_group(const double *
   if (g >= N) return;
   const double *st = state + (size_t)g * SGL_ST;
   const int s = gsz[g];
+  if (s > SGL_MAX) return;  // (scored by the host from a sub-session's fit)
   double acc = 0.0;
   for (int u = 1; u <= s; u++) acc += st[u] * st[u];
   const double v = acc / (double)s;  // coef_norm, src/screening.cpp:60
@@ -5132,6 +5135,7 @@ __global__ void __launch_bounds__(256) k_screen_cox_group(const double *__restri
                                                           const unsigned char *__restrict__ always,
                                                           double *__restrict__ score) {
   const int g = blockIdx.x;
+  if (gsz[g] > SCG_MAX) return;  // (wider groups: the Newton chain of a sub-session, host side)
   if (always != nullptr && always[g]) {
     if (threadIdx.x == 0) score[g] = DBL_MAX;
     return;
@@ -6603,7 +6607,7 @@ bool irls_gram_applies(int mt) { return g_gram_variant == 1 && mt >= 1 && mt <= 
 hipError_t launch_irls_gram(int fam, const double *X, const double *aux, long ld, int n, const int *cols,
                             const double *y, const double *w, const double *mask, int nslab, int mt, double *part,
                             int ntiles, const FitCtrl *ctrl, int slot, int t, int T0, const double *bcur,
-                            double *llpart, hipStream_t st) {
+                            double *llpart, hipStream_t st, int wfloor) {
   if (!irls_gram_applies(mt) || T0 + 2 > mt * 16) return hipErrorInvalidValue;  // intercept, T0 columns, ..., z last
   const int rows = irls_gram_slab_rows(mt, ld);
   if ((long)nslab * rows < ld) return hipErrorInvalidValue;
@@ -6612,7 +6616,7 @@ hipError_t launch_irls_gram(int fam, const double *X, const double *aux, long ld
     const size_t tile = std::max((size_t)mt * 16 * 66, (size_t)8 * NCH_ * 64);                                     \
     const size_t lds = (tile + 2 * (size_t)NCH_ * 64 + (size_t)mt * 16) * sizeof(double);                          \
     hipLaunchKernelGGL((k_irls_gram<NP_, NCH_, TPW_, FAM_>), dim3(nslab), dim3(512), lds, st, X, aux, ld, n, cols, \
-                       y, w, mask, rows, mt, part, ntiles, ctrl, slot, t, T0, bcur, llpart);                       \
+                       y, w, mask, rows, mt, part, ntiles, ctrl, slot, t, T0, bcur, llpart, wfloor);               \
   } while (0)
 #define IG_FAM(NP_, NCH_, TPW_) \
   if (fam == 2)                 \
@@ -6947,14 +6951,15 @@ hipError_t launch_glm_irls_begin(const FitCtrl *ctrl, int slot, int fam, int m, 
 
 hipError_t launch_glm_irls_prep(int fam, const double *X, long ld, int n, const double *y, const double *w,
                                 const double *mask, const FitCtrl *ctrl, int slot, int t, const int *A_new, int T0,
-                                const double *bcur, double *Wv, double *z, double *llpart, hipStream_t st) {
+                                const double *bcur, double *Wv, double *z, double *llpart, hipStream_t st,
+                                int wfloor) {
   int nblk = (int)((ld + 255) / 256);
   if (fam == 2)
     hipLaunchKernelGGL(k_glm_irls_prep<2>, dim3(nblk), dim3(128), 0, st, X, ld, n, y, w, mask, ctrl, slot, t, A_new,
-                       T0, bcur, Wv, z, llpart);
+                       T0, bcur, Wv, z, llpart, wfloor);
   else
     hipLaunchKernelGGL(k_glm_irls_prep<3>, dim3(nblk), dim3(128), 0, st, X, ld, n, y, w, mask, ctrl, slot, t, A_new,
-                       T0, bcur, Wv, z, llpart);
+                       T0, bcur, Wv, z, llpart, wfloor);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -7095,10 +7100,10 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
   if (fused) {
     // (the linear predictor of the accepted trial point instead of a pass over the active columns)
     hipLaunchKernelGGL(k_cox_eta_upd, dim3((int)((ld + 511) / 512)), dim3(256), 0, st, ld, n, mask,
-                       (const FitCtrl *)ctrl, slot, t, (const double *)cb.UD, cb.ETA0, cb.THF);
+                       (const FitCtrl *)ctrl, slot, t, (const double *)cb.UD, cb.ETA0, cb.THF, cb.fit_clamp);
   } else {
     hipLaunchKernelGGL(k_cox_fit_eta, dim3(nb2), dim3(128), 0, st, X, ld, n, mask, (const FitCtrl *)ctrl, slot, t,
-                       A_new, k, (const double *)cb.b0, cb.ETA0, cb.THF);
+                       A_new, k, (const double *)cb.b0, cb.ETA0, cb.THF, cb.fit_clamp);
   }
   LAUNCH_CHECK();
   {

@@ -122,12 +122,12 @@ typedef struct {
   int is_screening;   /* sure independence screening before the path (screening(), src/screening.cpp:26-105; called at
                          src/bess.cpp:57-61): keep the screening_size columns with the largest squared marginal
                          coefficient on the raw data plus always_select.  LM, logistic and Cox; with groups of
-                         size > 1 (LM any width, logistic at most 8, Cox at most 4 columns per group) screening_size
-                         and always_select count / name GROUPS, the marginal fit is the model's fit on the whole
-                         group, and the coefficients are written to the columns they belong to -- the reference
-                         misplaces them in this case, src/bess.cpp:195-198.  Poisson is refused (the reference's
-                         poisson_fit is undefined behaviour there, src/poisson.cpp:113), and so are wider logistic /
-                         Cox groups.
+                         size > 1 (any width) screening_size and always_select count / name GROUPS, the marginal fit
+                         is the model's fit on the whole group, and the coefficients are written to the columns they
+                         belong to -- the reference misplaces them in this case, src/bess.cpp:195-198.  Poisson is
+                         refused (the reference's poisson_fit is undefined behaviour there, src/poisson.cpp:113), and so
+                         is a logistic group at least as wide as the sample (logit_fit's n <= p branch returns n
+                         coefficients of which screening() reads the last g_size: out of bounds).
                          The session then lives on the kept columns: sparsity levels, traces,
                          bessx_session_fit and bessx_session_get_normalization index them 0..screening_size-1
                          (bessx_session_get_screening gives the map); every bessx_path_result is written in the
