@@ -109,8 +109,15 @@ struct TopkNeed {
   unsigned char *cm_inA;
 };
 bool topk_can_fuse_need(int len);
+// exact std::nth_element semantics behind a tie at the selection boundary (k_topk_ties): flag = 2 ints (zeroed once:
+// [0] raised by the selection kernels and cleared by k_topk_ties, [1] its heap-select branch was needed), work = 3 len ints
+struct TopkTie {
+  int *flag;
+  int *work;
+};
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
-                       hipStream_t st, const int *run_flag = nullptr, const TopkNeed *need = nullptr);
+                       hipStream_t st, const int *run_flag = nullptr, const TopkNeed *need = nullptr,
+                       const TopkTie *tie = nullptr);
 bool topk_supported(int len, int k);
 void topk_set_variant(int v);  // test / benchmark hook: 0 = bit-by-bit search, 1 = radix search (default)
 void gram_set_variant(int v);  // 1 = LDS-staged Gram kernel where it applies (default), 0 = k_gram throughout

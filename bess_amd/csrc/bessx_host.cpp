@@ -128,6 +128,8 @@ struct bessx_session {
   double *part2 = nullptr, *bd = nullptr, *beta_dense = nullptr, *sol = nullptr;
   double *tmpv = nullptr;
   int *A_new = nullptr, *cand = nullptr, *hist = nullptr, *gcols = nullptr, *info = nullptr;
+  int *tie_buf = nullptr;  // [2 flags | 3 p work ints] of the exact selection behind a score tie (k_topk_ties)
+  TopkTie tie = {nullptr, nullptr};
   double *hist_beta = nullptr, *hist_coef0 = nullptr;
   int cap = 0;          // largest sparsity level this session accepts: min(p, T0_CAP)
   int capA = 0;         // array length for T0-sized buffers: cap + 2 rounded up to a tile multiple
@@ -200,6 +202,7 @@ struct bessx_session {
   long long cov_bg_fills = 0;
   bool cov_cg = true;          // solve by k_cg (falls back to k_chol per slot); BESSX_COV_SOLVER=chol switches it off
   long long cov_cg_fallbacks = 0;
+  long long cov_tie_rescues = 0;  // slots redone with the exact tie rule (cov_stall = 3)
   int cov_C = 0;              // cache capacity in columns
   int cov_rps = 0, cov_nslab = 0;
   // shared fills of the CV row sets (LM, covariance form): a fold-major copy Xp of X (rows regrouped by test fold,
@@ -349,6 +352,7 @@ static void session_free(bessx_session *s) {
   F(s->tmpv);
   F(s->A_new);
   F(s->cand);
+  F(s->tie_buf);
   F(s->hist);
   F(s->gcols);
   F(s->info);
@@ -713,7 +717,7 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
   if (e == hipSuccess)
     e = launch_score(s->part_rs[rs], nullptr, s->nrb, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs],
                      lambda, 0, s->always, s->bd, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
   if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
   if (e == hipSuccess && mt > 16) {
     // beyond the register-resident solver: whole Gram every time, blocked Cholesky in global memory
@@ -986,7 +990,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
     }
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, &nd);
   } else if (e == hipSuccess) {
-    e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+    e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
     if (e == hipSuccess)
       e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s),
                           s->cov_fcols, s->ctrl, slot, s->A_cur, s->st);
@@ -1004,6 +1008,21 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
     s->cov_cg_fallbacks++;
     HIPX(launch_cov_resume(s->ctrl, s->st));
     if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs, true)) return rc;
+    *next_slot = stalled + 1;
+    return 0;
+  }
+  if (hc->cov_stall == 3) {
+    // equal scores at the selection boundary (duplicated columns, 0/1 designs): the fused selection parked the fit; the
+    // slot is redone unfused -- plain selection, the exact tie rule (k_topk_ties: the moves of the reference's
+    // std::nth_element, src/utilities.cpp:179-188), cache lookup, then the solve
+    s->cov_tie_rescues++;
+    HIPX(launch_cov_resume(s->ctrl, s->st));
+    hipError_t e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, stalled, s->st, nullptr, nullptr, &s->tie);
+    if (e == hipSuccess)
+      e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta,
+                          cov_C_dev(s), s->cov_fcols, s->ctrl, stalled, s->A_cur, s->st);
+    if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark (tie): ") + hipGetErrorString(e));
+    if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
     *next_slot = stalled + 1;
     return 0;
   }
@@ -1067,7 +1086,7 @@ static int enqueue_glm_head(bessx_session *s, int slot, int T0, double lambda, i
   if (e == hipSuccess)
     e = launch_score(s->part_rs[rs], s->part2_rs[rs], s->nrb, s->p, s->beta_dense, nullptr, (double)s->n_train[rs],
                      lambda, 1, s->always, s->bd, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
   // a repeated active set reproduces the logistic fit (cold start); Poisson restarts from the new intercept
   if (e == hipSuccess)
     e = launch_gram_cols(s->A_new, T0, mp, 1, 1, s->gcols, s->ctrl, slot, s->A_cur, fam == 2 ? 1 : 0, s->st);
@@ -1179,7 +1198,7 @@ static int enqueue_cox_head(bessx_session *s, int slot, int T0, double lambda, i
   if (e == hipSuccess)
     e = launch_cox_score(s->part_rs[rs], s->cox.one_pass ? nullptr : s->part2_rs[rs], s->nrb, s->p, s->beta_dense,
                          lambda, s->always, s->bd, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st);
+  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
   // (one-pass Hessian: the column behind the active ones is the bookkeeping column of k_cox_hess)
   const int aux_col = (s->cox.hess_fused && cox_hess_applies(mt)) ? 2 : 0;
   if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, aux_col, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
@@ -1376,7 +1395,7 @@ static int algorithm_fit_grouped(bessx_session *s) {
         e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->mblk, s->dcol, nullptr, 0, s->p, 0, 1.0, lambda,
                                s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork, s->zwork);
     }
-    if (e == hipSuccess) e = launch_topk(s->bd, s->N, T0, s->A_new, s->cand, nullptr, 0, s->st);
+    if (e == hipSuccess) e = launch_topk(s->bd, s->N, T0, s->A_new, s->cand, nullptr, 0, s->st, nullptr, nullptr, &s->tie);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group get_A: ") + hipGetErrorString(e));
     HIPX(hipMemcpyAsync(G.data(), s->A_new, (size_t)T0 * sizeof(int), hipMemcpyDeviceToHost, s->st));
     HIPX(hipStreamSynchronize(s->st));
@@ -2702,7 +2721,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     const size_t scr_len = (size_t)pf * 3 + std::max((size_t)2 * s->nrb * pf, (size_t)5 * pf);
     HIPS(dmalloc(&yw, (size_t)ld * 3));
     HIPS(dmalloc(&scr, scr_len));
-    HIPS(dmalloc(&ibuf, (size_t)pf + ss + 32768));
+    HIPS(dmalloc(&ibuf, (size_t)pf + ss + 32768 + 3 * (size_t)pf + 8));
     HIPS(dmalloc(&fl_d, (size_t)pf));
     HIPS(hipMemcpy(fl_d, fl.data(), (size_t)pf, hipMemcpyHostToDevice));
     {
@@ -2843,7 +2862,13 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     } else {
       HIPS(launch_screen_cox(Xraw, ld, n, pf, yw, yw + ld, fl_d, score, s->st));
     }
-    HIPS(launch_topk(score, nunits, ss, keep, cand, nullptr, 0, s->st));
+    {
+      // max_k(coef_norm, screening_size), src/screening.cpp:66: equal marginal scores (duplicated columns) are tied
+      int *tflag = ibuf + pf + ss + 32768;
+      HIPS(hipMemsetAsync(tflag, 0, 8 * sizeof(int), s->st));
+      const TopkTie tie = {tflag, tflag + 8};
+      HIPS(launch_topk(score, nunits, ss, keep, cand, nullptr, 0, s->st, nullptr, nullptr, &tie));
+    }
     HIPS(hipStreamSynchronize(s->st));
     s->screen_map.assign((size_t)ss, 0);
     HIPS(hipMemcpy(s->screen_map.data(), keep, (size_t)ss * sizeof(int), hipMemcpyDeviceToHost));
@@ -2948,6 +2973,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->rdiag, (size_t)capA));
   HIPT(dmalloc(&s->zbig, (size_t)capA));
   HIPT(dmalloc(&s->cand, 32768));
+  HIPT(dmalloc(&s->tie_buf, (size_t)3 * p + 8));
+  HIPT(hipMemset(s->tie_buf, 0, 8 * sizeof(int)));
+  s->tie = TopkTie{s->tie_buf, s->tie_buf + 8};
   HIPT(dmalloc(&s->hist, (size_t)(s->max_iter + 2) * s->hist_stride));
   HIPT(dmalloc(&s->hist_beta, (size_t)(s->max_iter + 2) * s->hist_stride));
   HIPT(dmalloc(&s->hist_coef0, (size_t)(s->max_iter + 2)));
@@ -3910,9 +3938,13 @@ int bessx_op_topk(const double *score, int len, int k, int *out_idx) {
   int *dout, *dcand;
   HIPX(sc.alloc(&ds, (size_t)len));
   HIPX(sc.alloc(&dout, (size_t)k));
+  int *dtie;
   HIPX(sc.alloc(&dcand, (size_t)32768));
+  HIPX(sc.alloc(&dtie, (size_t)3 * len + 8));
+  HIPX(hipMemset(dtie, 0, 8 * sizeof(int)));
   HIPX(hipMemcpy(ds, score, (size_t)len * sizeof(double), hipMemcpyHostToDevice));
-  HIPX(launch_topk(ds, len, k, dout, dcand, nullptr, 0, nullptr));
+  const TopkTie tie = {dtie, dtie + 8};
+  HIPX(launch_topk(ds, len, k, dout, dcand, nullptr, 0, nullptr, nullptr, nullptr, &tie));
   HIPX(hipMemcpy(out_idx, dout, (size_t)k * sizeof(int), hipMemcpyDeviceToHost));
   return BESSX_OK;
 }

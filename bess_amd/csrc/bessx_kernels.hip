@@ -574,19 +574,25 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
     const int cnt_cache = one_round ? nd.meta[0] : 0;
     unsigned long long best = 0ull;
     int besti = 0x7fffffff;
+    bool have = false;
+    int dupl = 0;  // this thread has met its maximum more than once
+    auto feed = [&](unsigned long long key, int i) {
+      if (!have || key > best) {
+        best = key;
+        besti = i;
+        have = true;
+        dupl = 0;
+      } else if (key == best) {
+        dupl = 1;
+        if (i < besti) besti = i;
+      }
+    };
     if (nd.bmm != nullptr && nd.bmm_fresh) {
       // the k_cov_d that produced these scores left, per block of 32 columns, the largest score outside the active
       // set and its column: the arg-max over p scores is the arg-max over p / 32 block maxima (same total order)
       for (int b = threadIdx.x; b < nd.nbmm; b += NT) {
         const double v = nd.bmm[2 * b + 1];
-        if (v >= 0.0) {
-          const unsigned long long key = score_key(v);
-          const int i = (int)nd.bmm[2 * nd.nbmm + b];
-          if (key > best || (key == best && i < besti)) {
-            best = key;
-            besti = i;
-          }
-        }
+        if (v >= 0.0) feed(score_key(v), (int)nd.bmm[2 * nd.nbmm + b]);
       }
     } else {
       // all loads first (independent), then the comparisons: a load behind a branch per element serialises
@@ -602,14 +608,12 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
 #pragma unroll
       for (int e = 0; e < EB; e++) {
         const int i = threadIdx.x + e * NT;
-        const unsigned long long key = score_key(sc[e]);
-        if (!ia[e] && (key > best || (key == best && i < besti))) {
-          best = key;
-          besti = i;
-        }
+        if (!ia[e]) feed(score_key(sc[e]), i);
       }
     }
     PH(0);
+    const unsigned long long mybest = best;  // this thread's own maximum, before the reductions
+    const int mybesti = besti;
     wave_argmax(best, besti);
     if ((threadIdx.x & 63) == 0) {
       bk[threadIdx.x >> 6] = best;
@@ -624,6 +628,19 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
         best = bk[w];
         besti = bi[w];
       }
+    {
+      // Is the maximum outside the set UNIQUE?  If a second column ties with it, the k-th and the (k + 1)-th largest
+      // score are equal and the arg-max (lower index) is not what the reference's nth_element returns: leave the
+      // shortcut, the full search below finds the tie and parks the fit for the exact selection.  A thread holds the
+      // maxima of the entries it looked at: a tie shows as another thread's (or another entry's) equal key; from the
+      // block maxima of k_cov_d only one entry per 32 columns is seen, so the winner's own 32-column block is read too.
+      int dup = (have && mybest == best && (mybesti != besti || dupl)) ? 1 : 0;
+      if (!dup && threadIdx.x < 32) {
+        const int j = (besti & ~31) + (int)threadIdx.x;
+        if (j < len_total && j != besti && !nd.inA[j] && score_key(score[j]) == best) dup = 1;
+      }
+      if (__syncthreads_or(dup)) goto full_search;  // uniform
+    }
     PH(1);
     // ordered insertion of besti into the sorted A_cur; its position = number of smaller elements, counted by the
     // block (a binary search by one thread is a chain of dependent global loads)
@@ -685,6 +702,7 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
     PH_COUNT();
     return;
   }
+full_search:
   if (nd.slot_of != nullptr && nd.ctrl->fast_same) {
     if (repeated_set_body<NT>(nd, k, out, slot)) return;
   }
@@ -757,6 +775,18 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
   (void)block_excl_scan(ngt, wsum, tot_gt);
   const int need_eq = kk - tot_gt;  // how many ties to take, lowest indices first
   int eq_before = block_excl_scan(neq, wsum2, tot_eq);
+  if (nd.slot_of != nullptr && tot_eq > need_eq && kk < len) {
+    // Covariance form (this launch goes on to the cache lookup and, in k_sel_cgr, to the solve): the k-th and the
+    // (k + 1)-th largest score are equal, so the set is the one std::nth_element's moves leave (k_topk_ties), not the
+    // lower indices.  Park the fit (cov_stall = 3: every queued kernel falls through); the host redoes this slot's
+    // selection exactly and issues the rest of the slot.
+    if (tid == 0) {
+      nd.ctrl->cov_stall = 3;
+      nd.ctrl->l = -1 - nd.ctrl->l;
+      nd.ctrl->fast_same = 0;
+    }
+    return;  // uniform
+  }
   int take_eq = min(max(need_eq - eq_before, 0), neq);
   int nsel = ngt + take_eq, tot_sel;
   int pos = block_excl_scan(nsel, wsum, tot_sel);
@@ -775,7 +805,10 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
       pos++;
     }
   }
-  if (tid == 0 && out_count != nullptr) out_count[blockIdx.x] = kk;
+  // more keys equal to the threshold than the selection can take: the k-th and the (k + 1)-th largest score are EQUAL.
+  // The reference's std::nth_element then keeps whichever of the tied indices its partition steps leave in front
+  // (implementation-defined, not the lower index taken above): flag it, k_topk_ties redoes the selection move by move
+  if (tid == 0 && out_count != nullptr && tot_eq > need_eq && kk < len) out_count[0] = 1;
   if (nd.slot_of != nullptr) {
     __syncthreads();  // the selected indices are visible to the whole block
     cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
@@ -793,6 +826,172 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
     return;
   }
   topk_body<EB, 1024>(score, idx_in, len_total, chunk, k, out, out_count, ctrl, slot, run_flag, nd);
+}
+
+// max_k when the k-th and the (k + 1)-th largest score are equal (duplicated columns, 0/1 designs): the reference's
+// std::nth_element (libstdc++, GCC 11: __introselect = median-of-3 pivot to the front, Hoare-style unguarded partition,
+// insertion sort of the last <= 3) decides which tied indices land in the first k positions, so its moves are redone
+// here on the index array 0 .. len-1, comparator comp(i, j) = score[i] > score[j] (src/utilities.cpp:179-188).  One
+// 1024-thread block; the partition of a range, sequential in the library, is done in parallel from its definition:
+// the scan from the left stops at the positions whose element is NOT greater than the pivot (in ascending order
+// L_0 < L_1 < ...), the scan from the right at those whose element is NOT smaller (descending R_0 > R_1 > ...), the
+// t-th exchange swaps positions L_t and R_t while L_t < R_t -- up to there neither scan has met a position written by
+// an earlier exchange, so both lists are read off the unmodified range -- and the partition returns where the left scan
+// stands once the scans have met: min(L_t, R_{t-1}) (the last exchange left a stop at R_{t-1}).  work = 3 len ints (index array, L list / selection flags, R list).  Runs only when the selection kernel
+// has raised flag[0]; clears it.  flag[1] = 1: depth limit of the introselect reached (its heap-select branch, which
+// only adversarial inputs take, is not restated) -- the lower-index selection of k_topk stays.
+__global__ void __launch_bounds__(1024) k_topk_ties(const double *__restrict__ score, int len, int k,
+                                                    int *__restrict__ out, int *__restrict__ flag,
+                                                    int *__restrict__ work, const FitCtrl *ctrl, int slot,
+                                                    const int *__restrict__ run_flag) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  if (run_flag != nullptr && *run_flag == 0) return;
+  if (flag[0] == 0) return;
+  constexpr int NT = 1024, NWV = NT / 64;
+  __shared__ int wsum[NWV];
+  __shared__ int sh_first, sh_last;
+  __shared__ double sh_piv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int *idx = work, *Lp = work + len, *Rp = work + 2 * (size_t)len;
+  for (int i = tid; i < len; i += NT) idx[i] = i;
+  if (tid == 0) {
+    sh_first = 0;
+    sh_last = len;
+  }
+  __syncthreads();
+  // exclusive rank of this thread's flag among the block's flags (thread order), and the block total
+  auto block_rank = [&](bool f, int &total) -> int {
+    const unsigned long long m = __ballot(f);
+    const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) {
+      off += w < wave ? wsum[w] : 0;
+      tot += wsum[w];
+    }
+    total = tot;
+    __syncthreads();
+    return off + before;
+  };
+  int depth = 0;
+  while ((len >> (depth + 1)) > 0) depth++;  // std::__lg(len)
+  depth *= 2;
+  const int nth = k;
+  while (true) {
+    const int first = sh_first, last = sh_last;
+    if (last - first <= 3) break;
+    if (depth == 0) {
+      if (tid == 0) {
+        flag[1] = 1;
+        flag[0] = 0;
+      }
+      return;
+    }
+    depth--;
+    if (tid == 0) {
+      // __move_median_to_first(first, first + 1, mid, last - 1)
+      const int mid = first + (last - first) / 2;
+      int *r = idx + first, *a = idx + first + 1, *b = idx + mid, *c = idx + last - 1;
+      const double sa = score[*a], sb = score[*b], sc = score[*c];
+      int *pick;
+      if (sa > sb) pick = (sb > sc) ? b : ((sa > sc) ? c : a);
+      else pick = (sa > sc) ? a : ((sb > sc) ? c : b);
+      const int t = *r;
+      *r = *pick;
+      *pick = t;
+      sh_piv = score[*r];
+    }
+    __syncthreads();
+    const double sp = sh_piv;
+    const int lo = first + 1, hi = last;  // __unguarded_partition(first + 1, last, pivot = first)
+    int totL = 0, totR = 0;
+    for (int base = lo; base < hi; base += NT) {  // stops of the scan from the left, ascending
+      const int i = base + tid;
+      const bool f = i < hi && !(score[idx[i]] > sp);
+      int tot;
+      const int r = block_rank(f, tot);
+      if (f) Lp[totL + r] = i;
+      totL += tot;
+    }
+    for (int base = hi - 1; base >= lo; base -= NT) {  // stops of the scan from the right, descending
+      const int i = base - tid;
+      const bool f = i >= lo && !(sp > score[idx[i]]);
+      int tot;
+      const int r = block_rank(f, tot);
+      if (f) Rp[totR + r] = i;
+      totR += tot;
+    }
+    __syncthreads();
+    // number of exchanges = number of t with L_t < R_t (the predicate is monotone in t)
+    const int tm = min(totL, totR);
+    int cnt = 0;
+    for (int base = 0; base < tm; base += NT) {
+      const int t = base + tid;
+      int tot;
+      (void)block_rank(t < tm && Lp[t] < Rp[t], tot);
+      cnt += tot;
+    }
+    // where the scan from the left stands when the scans have met: at its next stop of the unmodified range, or at
+    // the position of the last exchange (which now holds an element that is not greater than the pivot), whichever
+    // comes first
+    int cut = cnt < totL ? Lp[cnt] : 0x7fffffff;
+    if (cnt >= 1) cut = min(cut, Rp[cnt - 1]);
+    if (cut == 0x7fffffff) {  // cannot happen: the median-of-3 pivot guards the scan
+      if (tid == 0) {
+        flag[1] = 1;
+        flag[0] = 0;
+      }
+      return;
+    }
+    __syncthreads();
+    for (int t = tid; t < cnt; t += NT) {
+      const int a = Lp[t], b = Rp[t], va = idx[a], vb = idx[b];
+      idx[a] = vb;
+      idx[b] = va;
+    }
+    if (tid == 0) {
+      if (cut <= nth) sh_first = cut;
+      else sh_last = cut;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    // __insertion_sort of the last <= 3 elements
+    const int first = sh_first, last = sh_last;
+    for (int i = first + 1; i < last; i++) {
+      const int val = idx[i];
+      const double sv = score[val];
+      int j = i;
+      if (sv > score[idx[first]]) {
+        for (; j > first; j--) idx[j] = idx[j - 1];
+        idx[first] = val;
+      } else {
+        while (sv > score[idx[j - 1]]) {
+          idx[j] = idx[j - 1];
+          j--;
+        }
+        idx[j] = val;
+      }
+    }
+  }
+  __syncthreads();
+  // std::sort(ind, ind + k): the selected indices ascending -- membership flags, then an ordered compaction
+  for (int i = tid; i < len; i += NT) Lp[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < k; i += NT) Lp[idx[i]] = 1;
+  __syncthreads();
+  int done = 0;
+  for (int base = 0; base < len; base += NT) {
+    const int i = base + tid;
+    const bool f = i < len && Lp[i] != 0;
+    int tot;
+    const int r = block_rank(f, tot);
+    if (f) out[done + r] = i;
+    done += tot;
+  }
+  if (tid == 0) flag[0] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -6493,7 +6692,8 @@ void topk_set_variant(int) {}  // reserved: one selection kernel exists
 
 static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_in, int len, int chunk, int k,
                                   int *out, const FitCtrl *ctrl, int slot, hipStream_t st,
-                                  const int *run_flag = nullptr, const TopkNeed *need = nullptr) {
+                                  const int *run_flag = nullptr, const TopkNeed *need = nullptr,
+                                  int *tie_flag = nullptr) {
   TopkNeed nd = {};
   if (need) nd = *need;
   if (nd.pub.on) {
@@ -6502,7 +6702,7 @@ static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_
   }
   const int per = (std::min(len, chunk) + 1023) / 1024;
 #define TOPK_GO(EB)                                                                                              \
-  hipLaunchKernelGGL(k_topk<EB>, dim3(nblk), dim3(1024), 0, st, score, idx_in, len, chunk, k, out, (int *)nullptr, \
+  hipLaunchKernelGGL(k_topk<EB>, dim3(nblk), dim3(1024), 0, st, score, idx_in, len, chunk, k, out, tie_flag, \
                      ctrl, slot, run_flag, nd)
   if (per <= 2)
     TOPK_GO(2);
@@ -6531,10 +6731,25 @@ static hipError_t launch_topk_one(int nblk, const double *score, const int *idx_
 
 bool topk_can_fuse_need(int len) { return len <= 1024 * TOPK_E; }
 
+// the exact selection behind a tie (k_topk_ties); tie->flag is raised by the selection kernels, tie->work = 3 len ints
+static hipError_t launch_topk_ties(const double *score, int len, int k, int *out, const TopkTie *tie,
+                                   const FitCtrl *ctrl, int slot, hipStream_t st, const int *run_flag) {
+  hipLaunchKernelGGL(k_topk_ties, dim3(1), dim3(1024), 0, st, score, len, k, out, tie->flag, tie->work, ctrl, slot,
+                     run_flag);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
 hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand, const FitCtrl *ctrl, int slot,
-                       hipStream_t st, const int *run_flag, const TopkNeed *need) {
+                       hipStream_t st, const int *run_flag, const TopkNeed *need, const TopkTie *tie) {
   const int chunk = 1024 * TOPK_E;
-  if (len <= chunk) return launch_topk_one(1, score, nullptr, len, chunk, k, out, ctrl, slot, st, run_flag, need);
+  if (need != nullptr && need->slot_of != nullptr) tie = nullptr;  // (fused flavours of the covariance form: see launch_sel_cgr)
+  int *tflag = tie != nullptr ? tie->flag : nullptr;
+  if (len <= chunk) {
+    hipError_t e = launch_topk_one(1, score, nullptr, len, chunk, k, out, ctrl, slot, st, run_flag, need, tflag);
+    if (e == hipSuccess && tie != nullptr) e = launch_topk_ties(score, len, k, out, tie, ctrl, slot, st, run_flag);
+    return e;
+  }
   if (need != nullptr) return hipErrorInvalidValue;  // callers check topk_can_fuse_need()
   int nchunk = (len + chunk - 1) / chunk;
   long ncand = (long)nchunk * k;
@@ -6543,9 +6758,12 @@ hipError_t launch_topk(const double *score, int len, int k, int *out, int *cand,
   // than k would leave holes in cand, and with full 32768-wide chunks whether that happens depended on
   // len mod 32768 (p = 32769 allowed k = 1 only).  topk_supported() checks the last chunk still holds >= k scores.
   const int bal = (len + nchunk - 1) / nchunk;
-  hipError_t e = launch_topk_one(nchunk, score, nullptr, len, bal, k, cand, ctrl, slot, st, run_flag);
+  // (a tie inside one chunk need not be one of the whole selection; redoing the selection exactly is right either way)
+  hipError_t e = launch_topk_one(nchunk, score, nullptr, len, bal, k, cand, ctrl, slot, st, run_flag, nullptr, tflag);
   if (e != hipSuccess) return e;
-  return launch_topk_one(1, score, cand, (int)ncand, chunk, k, out, ctrl, slot, st, run_flag);
+  e = launch_topk_one(1, score, cand, (int)ncand, chunk, k, out, ctrl, slot, st, run_flag, nullptr, tflag);
+  if (e == hipSuccess && tie != nullptr) e = launch_topk_ties(score, len, k, out, tie, ctrl, slot, st, run_flag);
+  return e;
 }
 
 bool topk_supported(int len, int k) {

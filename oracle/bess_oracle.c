@@ -20,6 +20,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -201,33 +202,96 @@ int bess_oracle_sym_solve(const double *a, int k, const double *b, double *x) {
   return rc;
 }
 
-typedef struct {
-  double s;
-  int i;
-} spair;
-static int spair_cmp(const void *a, const void *b) {
-  const spair *x = (const spair *)a, *y = (const spair *)b;
-  if (x->s > y->s) return -1;
-  if (x->s < y->s) return 1;
-  return (x->i > y->i) - (x->i < y->i);
-}
 static int int_cmp(const void *a, const void *b) {
   int x = *(const int *)a, y = *(const int *)b;
   return (x > y) - (x < y);
 }
 
-void bess_oracle_max_k(const double *score, int len, int k, int *out) {
-  /* max_k, src/utilities.cpp:179-188 */
-  int i;
-  spair *s = (spair *)malloc((size_t)len * sizeof(spair));
-  for (i = 0; i < len; i++) {
-    s[i].s = score[i];
-    s[i].i = i;
+/* std::nth_element as libstdc++ (GCC 11, bits/stl_algo.h: __introselect, __unguarded_partition_pivot,
+ * __move_median_to_first, __unguarded_partition, __insertion_sort) runs it on the index array 0..len-1 with the
+ * comparator of max_k, comp(i, j) = vec(i) > vec(j) (src/utilities.cpp:179-188).  With distinct scores any selection
+ * returns the same set; with EQUAL scores at the boundary (duplicated columns, 0/1 designs) which of the tied indices
+ * land in the first k positions is decided by exactly these moves, so they are restated step by step.  The reference's
+ * toolchain is the pinned dependency here: the golden vectors and oracle/_ref are built with g++ 11.4 / libstdc++.
+ * The heap-select branch (depth limit 2 floor(log2 len) exhausted: adversarial inputs only) is not restated: abort. */
+static const double *nth_vec;
+static int nth_comp(int i, int j) { return nth_vec[i] > nth_vec[j]; }
+static void nth_swap(int *a, int *b) {
+  int t = *a;
+  *a = *b;
+  *b = t;
+}
+static void nth_move_median_to_first(int *result, int *a, int *b, int *c) {
+  if (nth_comp(*a, *b)) {
+    if (nth_comp(*b, *c)) nth_swap(result, b);
+    else if (nth_comp(*a, *c)) nth_swap(result, c);
+    else nth_swap(result, a);
+  } else if (nth_comp(*a, *c)) nth_swap(result, a);
+  else if (nth_comp(*b, *c)) nth_swap(result, c);
+  else nth_swap(result, b);
+}
+static int *nth_unguarded_partition(int *first, int *last, int *pivot) {
+  for (;;) {
+    while (nth_comp(*first, *pivot)) ++first;
+    --last;
+    while (nth_comp(*pivot, *last)) --last;
+    if (!(first < last)) return first;
+    nth_swap(first, last);
+    ++first;
   }
-  qsort(s, (size_t)len, sizeof(spair), spair_cmp);
-  for (i = 0; i < k; i++) out[i] = s[i].i;
+}
+static void nth_insertion_sort(int *first, int *last) {
+  int *i;
+  if (first == last) return;
+  for (i = first + 1; i != last; ++i) {
+    int val = *i;
+    if (nth_comp(val, *first)) {
+      memmove(first + 1, first, (size_t)(i - first) * sizeof(int));
+      *first = val;
+    } else {
+      int *cur = i, *next = i - 1;
+      while (nth_comp(val, *next)) {
+        *cur = *next;
+        cur = next;
+        --next;
+      }
+      *cur = val;
+    }
+  }
+}
+static void nth_element_libstdcxx(int *first, int *nth, int *last) {
+  long depth_limit;
+  long len = last - first;
+  int lg = 0;
+  if (first == last || nth == last) return;
+  while ((len >> (lg + 1)) > 0) lg++; /* std::__lg */
+  depth_limit = 2L * lg;
+  while (last - first > 3) {
+    int *mid, *cut;
+    if (depth_limit == 0) {
+      fprintf(stderr, "bess_oracle: nth_element reached its heap-select branch (not restated)\n");
+      abort();
+    }
+    --depth_limit;
+    mid = first + (last - first) / 2;
+    nth_move_median_to_first(first, first + 1, mid, last - 1);
+    cut = nth_unguarded_partition(first + 1, last, first);
+    if (cut <= nth) first = cut;
+    else last = cut;
+  }
+  nth_insertion_sort(first, last);
+}
+
+void bess_oracle_max_k(const double *score, int len, int k, int *out) {
+  /* max_k, src/utilities.cpp:179-188: nth_element(ind, ind + k, ind + len, vec(i) > vec(j)); sort(ind, ind + k) */
+  int i;
+  int *ind = (int *)malloc((size_t)len * sizeof(int));
+  for (i = 0; i < len; i++) ind[i] = i;
+  nth_vec = score;
+  nth_element_libstdcxx(ind, ind + k, ind + len);
+  for (i = 0; i < k; i++) out[i] = ind[i];
   qsort(out, (size_t)k, sizeof(int), int_cmp);
-  free(s);
+  free(ind);
 }
 
 /* ------------------------------------------------------------------ Algorithm */

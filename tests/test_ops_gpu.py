@@ -38,9 +38,27 @@ def test_topk_ties_and_specials(gpu):
     for k in range(1, 11):
         assert np.array_equal(gpu.op_topk(s, k), P.max_k(s, k)), k
     z = np.zeros(5000)
-    assert np.array_equal(gpu.op_topk(z, 7), np.arange(7))
+    assert np.array_equal(gpu.op_topk(z, 7), P.max_k(z, 7))
     s = np.arange(40000, dtype=float) % 97  # many ties across both selection levels
     assert np.array_equal(gpu.op_topk(s, 120), P.max_k(s, 120))
+
+
+@pytest.mark.parametrize("length", [5, 64, 1000, 4097, 10000, 32768, 50000])
+def test_topk_follows_nth_element_under_ties(gpu, length):
+    """Equal scores at the selection boundary: the set is the one libstdc++'s std::nth_element leaves in front (what
+    max_k of the reference returns, src/utilities.cpp:179-188; restated move by move in the oracle and checked against
+    the compiled reference on paths, tests/test_oracle_vs_reference.py) -- k_topk_ties redoes those moves on the device.
+    Quantised scores in several densities, every boundary position from 'all tied' to 'one pair tied'."""
+    rng = np.random.default_rng(length)
+    for levels in (1, 2, 3, 7, 50, 1000):
+        s = rng.integers(0, levels, length).astype(float)
+        if levels == 50:
+            s[rng.choice(length, max(1, length // 10), replace=False)] = np.finfo(float).max  # always_select entries
+        ks = sorted({1, 2, 3, length // 2, length - 1, length} | set(int(v) for v in rng.integers(1, length + 1, 4)))
+        for k in ks:
+            if k > 2046 or k < 1 or (length > 32768 and k > 200):
+                continue
+            assert np.array_equal(gpu.op_topk(s, k), P.max_k(s, k)), (levels, k)
 
 
 @pytest.mark.parametrize("n,p,m", [(97, 8, 3), (500, 40, 16), (1000, 60, 17), (3000, 300, 100), (5000, 400, 200),

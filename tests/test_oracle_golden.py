@@ -61,7 +61,9 @@ def test_oracle_building_blocks():
     want = np.sort(np.argsort(-s, kind="stable")[:k])
     assert np.array_equal(P.max_k(s, k), want)
     s2 = np.array([1.0, 3.0, 3.0, 3.0, 0.5])
-    assert list(P.max_k(s2, 2)) == [1, 2]  # ties -> lower index
+    # ties: whatever libstdc++'s nth_element leaves in the first k positions (restated move by move in the oracle; on
+    # this input its partition keeps the first and the LAST of the three tied indices)
+    assert list(P.max_k(s2, 2)) == [1, 3]
     a = rng.standard_normal((60, 12))
     g = a.T @ a
     b = rng.standard_normal(12)
