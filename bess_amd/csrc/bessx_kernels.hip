@@ -4481,8 +4481,7 @@ __global__ void __launch_bounds__(SC_T) k_cox_cscan_apply(const double *__restri
                                                           const double *__restrict__ THF, double *__restrict__ VG,
                                                           double *__restrict__ WG1, long n, long ld,
                                                           const double *__restrict__ scr,
-                                                          const FitCtrl *__restrict__ ctrl, int slot, int t,
-                                                          double *__restrict__ RC, double *__restrict__ CW) {
+                                                          const FitCtrl *__restrict__ ctrl, int slot, int t) {
   if (COX_NEWTON_GATE(ctrl, slot, t)) return;
   __shared__ double sm[4];
   const long r0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
@@ -4502,46 +4501,13 @@ __global__ void __launch_bounds__(SC_T) k_cox_cscan_apply(const double *__restri
     if (i < n) {
       s += x[q];
       const double tc = THF[i] * s;
-      const double vg = WD[i] - tc;
-      VG[i] = vg;
+      VG[i] = WD[i] - tc;
       WG1[i] = tc;
-      if (RC != nullptr) {
-        // one-pass Hessian (k_cox_hess): the gradient rides in the first Gram as the column VG / WG1 (a row with
-        // VG != 0 is an event row or lies behind one, so its theta C is positive); weights of the second Gram
-        RC[i] = tc != 0.0 ? vg / tc : 0.0;
-        CW[i] = x[q] * RS0F[i];
-      }
     } else if (i < ld) {
       VG[i] = 0.0;
       WG1[i] = 0.0;
-      if (RC != nullptr) {
-        RC[i] = 0.0;
-        CW[i] = 0.0;
-      }
     }
   }
-}
-
-// eta0 of Newton step t without a pass over the active columns: step 1 starts from beta0 = 0; afterwards the line search
-// has accepted beta0 + 0.5^m u, whose linear predictor is eta0 + 0.5^m UD (UD = X_A u is in memory from k_cox_dir).
-// theta = exp(clamp eta0) on the training rows, as k_cox_fit_eta.
-__global__ void __launch_bounds__(256) k_cox_eta_upd(long ld, int n, const double *__restrict__ mask,
-                                                     const FitCtrl *__restrict__ ctrl, int slot, int t,
-                                                     const double *__restrict__ UD, double *__restrict__ ETA0,
-                                                     double *__restrict__ THF, double clampc) {
-  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
-  if (i >= ld) return;
-  d2 e = d2{0.0, 0.0};
-  if (t > 1) {
-    const int m = ctrl->ls_m;
-    const double step = m == 1 ? 0.5 : (m == 2 ? 0.25 : (m == 3 ? 0.125 : (m == 4 ? 0.0625 : 0.03125)));
-    e = *reinterpret_cast<const d2 *>(ETA0 + i) + *reinterpret_cast<const d2 *>(UD + i) * step;
-  }
-  const d2 mk = mask ? *reinterpret_cast<const d2 *>(mask + i) : d2{1.0, 1.0};
-  *reinterpret_cast<d2 *>(ETA0 + i) = e;
-  *reinterpret_cast<d2 *>(THF + i) =
-      d2{i < n ? exp(clampv(e.x, clampc)) * mk.x : 0.0, i + 1 < n ? exp(clampv(e.y, clampc)) * mk.y : 0.0};
 }
 
 // M[:, a] = suffix(theta x_a) / S0 (the n x k matrix S1/S0, :1426-1428) and g_a = x_a . VG + 2 lambda b0_a (:1429).
@@ -4611,6 +4577,135 @@ __global__ void __launch_bounds__(SC_T) k_cox_M_apply(const double *__restrict__
       double gg = 0.0;
       for (int j = 0; j < nb; j++) gg += scr[(size_t)(k + a) * nb + j];
       g[a] = gg + 2.0 * lambda * b0[a];
+    }
+  }
+}
+
+// ---- Newton step, the n-vector work in three launches (one-pass Hessian form) -------------------------------------
+// theta, its suffix sums S0, C = prefix sums of w delta / S0, and the row weights of the two Grams used to take five
+// launches (linear predictor, k_scan3_tot / _apply, k_cox_cscan_tot / _apply).  With ONE partition of the rows into
+// 1024-row blocks for both scans the block totals of one scan are produced by the kernel that applies the previous one:
+//   k_cox_nvecA: eta0 (carried from the line search), theta, block totals of theta
+//   k_cox_nvecB: S0 = suffix sums (carry: the totals of the later blocks), 1 / S0, block totals of w delta / S0
+//   k_cox_nvecC: C = prefix sums (carry: the totals of the earlier blocks), theta C, w delta - theta C, and the
+//                bookkeeping vectors of k_cox_hess
+// Fixed summation order (thread-strided partial sums of the block totals, butterflies, the waves in order; inside a
+// block the scan of block_excl_256), no atomics.
+__device__ __forceinline__ double block_sum_of_totals(const double *__restrict__ tot, int lo, int hi, double *sm4) {
+  double s = 0.0;
+  for (int j = lo + (int)threadIdx.x; j < hi; j += SC_T) s += tot[j];
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const double r = ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(SC_T) k_cox_nvecA(long ld, int n, const double *__restrict__ mask,
+                                                    const FitCtrl *__restrict__ ctrl, int slot, int t,
+                                                    const double *__restrict__ UD, double *__restrict__ ETA0,
+                                                    double *__restrict__ THF, double clampc,
+                                                    double *__restrict__ totA) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  __shared__ double sm[4];
+  const long i0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
+  double step = 0.0;
+  if (t > 1) {
+    const int m = ctrl->ls_m;
+    step = m == 1 ? 0.5 : (m == 2 ? 0.25 : (m == 3 ? 0.125 : (m == 4 ? 0.0625 : 0.03125)));
+  }
+  double tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < SC_E; q++) {
+    const long i = i0 + q;
+    if (i < ld) {
+      const double e = t > 1 ? ETA0[i] + UD[i] * step : 0.0;
+      const double th = i < n ? exp(clampv(e, clampc)) * (mask ? mask[i] : 1.0) : 0.0;
+      ETA0[i] = e;
+      THF[i] = th;
+      tt += th;
+    }
+  }
+  double bt;
+  (void)block_excl_256(tt, sm, &bt);
+  if (threadIdx.x == 0) totA[blockIdx.x] = bt;
+}
+
+__global__ void __launch_bounds__(SC_T) k_cox_nvecB(long ld, int n, const double *__restrict__ THF,
+                                                    const double *__restrict__ WD, const double *__restrict__ totA,
+                                                    double *__restrict__ S0F, double *__restrict__ RS0F,
+                                                    double *__restrict__ totB, const FitCtrl *__restrict__ ctrl,
+                                                    int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  __shared__ double sm[4];
+  const int nb = gridDim.x;
+  const double carry = block_sum_of_totals(totA, (int)blockIdx.x + 1, nb, sm);
+  // thread order = scan order: the block's rows from the last to the first
+  const long top = (long)blockIdx.x * SC_B + SC_B - 1 - (long)threadIdx.x * SC_E;
+  double th[SC_E], tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < SC_E; q++) {
+    const long i = top - q;
+    th[q] = i < n ? THF[i] : 0.0;
+    tt += th[q];
+  }
+  double s = carry + block_excl_256(tt, sm, nullptr);
+  double xs = 0.0;
+#pragma unroll
+  for (int q = 0; q < SC_E; q++) {
+    const long i = top - q;
+    if (i < n) {
+      s += th[q];
+      const double r = s != 0.0 ? 1.0 / s : 0.0;  // (rows behind the last training row of a fold: empty risk set)
+      S0F[i] = s;
+      RS0F[i] = r;
+      const double wd = WD[i];
+      if (wd != 0.0) xs += wd * r;
+    }
+  }
+  double bt;
+  (void)block_excl_256(xs, sm, &bt);
+  if (threadIdx.x == 0) totB[blockIdx.x] = bt;
+}
+
+__global__ void __launch_bounds__(SC_T) k_cox_nvecC(long ld, int n, const double *__restrict__ THF,
+                                                    const double *__restrict__ WD, const double *__restrict__ RS0F,
+                                                    const double *__restrict__ totB, double *__restrict__ VG,
+                                                    double *__restrict__ WG1, double *__restrict__ RC,
+                                                    double *__restrict__ CW, const FitCtrl *__restrict__ ctrl,
+                                                    int slot, int t) {
+  if (COX_NEWTON_GATE(ctrl, slot, t)) return;
+  __shared__ double sm[4];
+  const double carry = block_sum_of_totals(totB, 0, (int)blockIdx.x, sm);
+  const long i0 = (long)blockIdx.x * SC_B + (long)threadIdx.x * SC_E;
+  double x[SC_E], rs[SC_E], tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < SC_E; q++) {
+    const long i = i0 + q;
+    rs[q] = i < n ? RS0F[i] : 0.0;
+    x[q] = (i < n && WD[i] != 0.0) ? WD[i] * rs[q] : 0.0;
+    tt += x[q];
+  }
+  double s = carry + block_excl_256(tt, sm, nullptr);
+#pragma unroll
+  for (int q = 0; q < SC_E; q++) {
+    const long i = i0 + q;
+    if (i < n) {
+      s += x[q];
+      const double tc = THF[i] * s, vg = WD[i] - tc;
+      VG[i] = vg;
+      WG1[i] = tc;
+      // the gradient rides in the first Gram of k_cox_hess as the column VG / WG1 (a row with VG != 0 is an event row or
+      // lies behind one, so its theta C is positive); CW = w delta / S0^2, the row weights of the second Gram
+      RC[i] = tc != 0.0 ? vg / tc : 0.0;
+      CW[i] = x[q] * rs[q];
+    } else if (i < ld) {
+      VG[i] = 0.0;
+      WG1[i] = 0.0;
+      RC[i] = 0.0;
+      CW[i] = 0.0;
     }
   }
 }
@@ -7316,29 +7411,38 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
   const int nb2 = (int)((ld + 255) / 256);
   const bool fused = cb.hess_fused && cox_hess_applies(mt);
   if (fused) {
-    // (the linear predictor of the accepted trial point instead of a pass over the active columns)
-    hipLaunchKernelGGL(k_cox_eta_upd, dim3((int)((ld + 511) / 512)), dim3(256), 0, st, ld, n, mask,
-                       (const FitCtrl *)ctrl, slot, t, (const double *)cb.UD, cb.ETA0, cb.THF, cb.fit_clamp);
+    // the n-vector work in three launches; SCR: block totals of theta, then of w delta / S0
+    const int nbl = (int)((ld + SC_B - 1) / SC_B);
+    double *totA = cb.SCR, *totB = cb.SCR + nbl;
+    hipLaunchKernelGGL(k_cox_nvecA, dim3(nbl), dim3(SC_T), 0, st, ld, n, mask, (const FitCtrl *)ctrl, slot, t,
+                       (const double *)cb.UD, cb.ETA0, cb.THF, cb.fit_clamp, totA);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cox_nvecB, dim3(nbl), dim3(SC_T), 0, st, ld, n, (const double *)cb.THF, (const double *)cb.WD,
+                       (const double *)totA, cb.S0F, cb.RS0F, totB, (const FitCtrl *)ctrl, slot, t);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cox_nvecC, dim3(nbl), dim3(SC_T), 0, st, ld, n, (const double *)cb.THF, (const double *)cb.WD,
+                       (const double *)cb.RS0F, (const double *)totB, cb.VG, cb.WG1, const_cast<double *>(aux) + 2 * ld,
+                       cb.CW, (const FitCtrl *)ctrl, slot, t);
+    LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL(k_cox_fit_eta, dim3(nb2), dim3(128), 0, st, X, ld, n, mask, (const FitCtrl *)ctrl, slot, t,
                        A_new, k, (const double *)cb.b0, cb.ETA0, cb.THF, cb.fit_clamp);
-  }
-  LAUNCH_CHECK();
-  {
+    LAUNCH_CHECK();
     hipError_t es = launch_scan3(cb.THF, nullptr, nullptr, cb.S0F, nullptr, nullptr, cb.RS0F, (long)n, 1, 1, cb.SCR,
                                  (const FitCtrl *)ctrl, 2, slot, t, st);
     if (es != hipSuccess) return es;
   }
   {
     const int nbn = (int)(((long)n + SC_B - 1) / SC_B), nbl = (int)((ld + SC_B - 1) / SC_B);
-    hipLaunchKernelGGL(k_cox_cscan_tot, dim3(nbl), dim3(SC_T), 0, st, (const double *)cb.WD, (const double *)cb.RS0F,
-                       (long)n, cb.SCR, (const FitCtrl *)ctrl, slot, t);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cox_cscan_apply, dim3(nbl), dim3(SC_T), 0, st, (const double *)cb.WD, (const double *)cb.RS0F,
-                       (const double *)cb.THF, cb.VG, cb.WG1, (long)n, ld, (const double *)cb.SCR,
-                       (const FitCtrl *)ctrl, slot, t, fused ? const_cast<double *>(aux) + 2 * ld : (double *)nullptr,
-                       fused ? cb.CW : (double *)nullptr);
-    LAUNCH_CHECK();
+    if (!fused) {
+      hipLaunchKernelGGL(k_cox_cscan_tot, dim3(nbl), dim3(SC_T), 0, st, (const double *)cb.WD, (const double *)cb.RS0F,
+                         (long)n, cb.SCR, (const FitCtrl *)ctrl, slot, t);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_cox_cscan_apply, dim3(nbl), dim3(SC_T), 0, st, (const double *)cb.WD, (const double *)cb.RS0F,
+                         (const double *)cb.THF, cb.VG, cb.WG1, (long)n, ld, (const double *)cb.SCR,
+                         (const FitCtrl *)ctrl, slot, t);
+      LAUNCH_CHECK();
+    }
     if (fused) {
       const int hrows = cox_hess_slab_rows(ld), hns = (int)((ld + hrows - 1) / hrows), mp = mt * 16;
       const size_t lds = ((size_t)mp * 66 + 4 * 64 + mp) * sizeof(double);
