@@ -159,7 +159,10 @@ struct CholFuse {
   int CS;
   const double *zero;  // a word that holds 0.0 (what k_cgr reads for matrix columns outside its system)
   PubArgs pub;         // pub.on: this launch closes a batch of slots and publishes the result block (k_cg / k_cgr)
+  double *fb_work;     // k_chol: work space of the pivoted fallback solve (256 x 256 + 1024 doubles), or nullptr
+  const int *dep;      // k_cg / k_cgr: != 0 when exactly dependent columns are cached for the row set (CovCache meta[4])
 };
+constexpr size_t CHOL_FB_DOUBLES = 256 * 256 + 1024;
 // the IRLS convergence test at the head of k_chol (otherwise its own launch, k_glm_irls_check): on = 1
 struct IrlsChk {
   int on;
@@ -172,6 +175,10 @@ struct IrlsChk {
 hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                        const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot, int gate_mode,
                        hipStream_t st, const CholFuse *fuse = nullptr, const IrlsChk *chk = nullptr);
+// the pivoted solve behind a launch_chol whose kernel gave up (info = 2); fuse->fb_work is required
+hipError_t launch_sym_fallback(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
+                               const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot,
+                               hipStream_t st, const CholFuse *fuse);
 // tol: accepted relative residual |q - (G + ridge I) x| <= tol |q|; by_rows: systems of up to 208 unknowns use the
 // row-dealt kernel (k_cgr), otherwise / beyond the tile-dealt one (k_cg)
 hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *A_new, double *sol, const FitCtrl *ctrl,
@@ -302,7 +309,8 @@ hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const 
                              const int *bgm = nullptr, int ex_lo = 0, int ex_hi = 0);
 hipError_t launch_rows_permute(const double *X, long ld, int p, const int *perm, long ldp, double *Xp, hipStream_t st);
 hipError_t launch_cov_compact(const double *G, int p, const int *slot_of, const int *fcols, int g0, int ngroups,
-                              double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st);
+                              double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st,
+                              const double *xtx = nullptr, int *meta = nullptr);
 // background (speculative) fill on a second stream
 hipError_t launch_cov_bg_select(const double *bd, const int *slot_of, int p, double *bd2, hipStream_t st);
 hipError_t launch_cov_bg_list(const int *extras, const double *bd2, const int *slot_of, const int *meta, int C,

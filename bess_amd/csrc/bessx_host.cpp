@@ -128,6 +128,7 @@ struct bessx_session {
   double *part2 = nullptr, *bd = nullptr, *beta_dense = nullptr, *sol = nullptr;
   double *tmpv = nullptr;
   int *A_new = nullptr, *cand = nullptr, *hist = nullptr, *gcols = nullptr, *info = nullptr;
+  double *fb_work = nullptr;  // dense work space of the pivoted fallback solve inside k_chol (sym_pivoted_solve)
   int *tie_buf = nullptr;  // [2 flags | 3 p work ints] of the exact selection behind a score tie (k_topk_ties)
   TopkTie tie = {nullptr, nullptr};
   double *hist_beta = nullptr, *hist_coef0 = nullptr;
@@ -177,6 +178,8 @@ struct bessx_session {
   // solve.  (Round 2's k_gram_irls did the per-row work 64 rows at a time between the barriers of the staging pipeline
   // and lost, 0.180 s against 0.175 s on configs[2]; it is gone.)
   bool irls_fuse = true;   // GLM IRLS step as k_irls_gram + k_gram_reduce + k_chol (BESSX_IRLS_FUSE=0: the five-launch step)
+  bool glm_fallback = false;  // the IRLS chain carries the pivoted fallback solve behind every k_chol (set, and the
+                              // fit redone, the first time a k_chol of this session meets a rank-deficient system)
   int irls_wfloor = 1;     // floor of the logistic IRLS weight inside the loop (src/Algorithm.h:1188-1192); 0 in the
                            // sub-sessions that run logit_fit for the screening of wide groups (src/logistic.cpp:60-160)
   size_t llpart_cap = 0;
@@ -353,6 +356,7 @@ static void session_free(bessx_session *s) {
   F(s->A_new);
   F(s->cand);
   F(s->tie_buf);
+  F(s->fb_work);
   F(s->hist);
   F(s->gcols);
   F(s->info);
@@ -506,11 +510,11 @@ static int alloc_cov_cache(bessx_session *s, bool share_map = false) {
     c.shares_map = true;
   }
   if (e == hipSuccess && !c.shares_map) e = dmalloc(&c.slot_of, (size_t)s->p);
-  if (e == hipSuccess && !c.shares_map) e = dmalloc(&c.meta, 4);
+  if (e == hipSuccess && !c.shares_map) e = dmalloc(&c.meta, 8);
   if (e == hipSuccess) e = dmalloc(&c.GS, (size_t)COV_CS * COV_CS);
   if (e == hipSuccess) e = hipMemset(c.GS, 0, (size_t)COV_CS * COV_CS * sizeof(double));
   if (e == hipSuccess && !c.shares_map) e = hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int));
-  if (e == hipSuccess && !c.shares_map) e = hipMemset(c.meta, 0, 4 * sizeof(int));
+  if (e == hipSuccess && !c.shares_map) e = hipMemset(c.meta, 0, 8 * sizeof(int));
   if (e == hipSuccess) e = dmalloc(&c.H, (size_t)COV_CS * COV_CS);
   if (e == hipSuccess) e = dmalloc(&c.hact, (size_t)COV_CS);
   if (e == hipSuccess) e = dmalloc(&c.hmeta, 4);
@@ -556,13 +560,20 @@ static int reset_path_caches(bessx_session *s) {
   for (auto &g : s->gcache) HIPX(hipMemsetAsync(g.meta, 0, 2 * sizeof(int), s->st));
   for (auto &c : s->cov) {
     HIPX(hipMemsetAsync(c.slot_of, 0xff, (size_t)s->p * sizeof(int), s->st));
-    HIPX(hipMemsetAsync(c.meta, 0, 4 * sizeof(int), s->st));
+    HIPX(hipMemsetAsync(c.meta, 0, 8 * sizeof(int), s->st));
     // the maintained inverse belongs to the old slot numbering; a path starts without one (and without a ridge seen)
     HIPX(hipMemsetAsync(c.hmeta, 0, 4 * sizeof(int), s->st));
     HIPX(hipMemsetAsync(c.hact, 0, (size_t)COV_CS * sizeof(int), s->st));
     HIPX(hipMemsetAsync(c.hinfo, 0xff, 2 * sizeof(double), s->st));
   }
   return 0;
+}
+
+// k_chol outside the covariance form: only the work space of its pivoted fallback solve rides in the fuse block
+static CholFuse chol_fallback_only(const bessx_session *s) {
+  CholFuse fz = {};
+  fz.fb_work = s->fb_work;
+  return fz;
 }
 
 static void build_gram_tasks(int mt, std::vector<GramTask> &out) {
@@ -735,8 +746,13 @@ static int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, in
                               tasks_full, ntask, rps, nslab, s->gtasks + s->gtask_inc_off[mt],
                               ntask_i, rps_i, nslab_i, s->gpart, s->Gt, s->Rt, s->gsrc, gc.g0, gc.g1, gc.A, gc.meta,
                               s->ctrl, slot, s->st);
+    const CholFuse fbz = chol_fallback_only(s);
     if (e == hipSuccess)
-      e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st);
+      e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
+                      &fbz);
+    if (e == hipSuccess)  // (exactly dependent active columns: the pivoted solve; falls through otherwise)
+      e = launch_sym_fallback(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, s->st,
+                              &fbz);
   }
   if (e == hipSuccess)
     e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
@@ -789,7 +805,8 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
         e = launch_cov_reduce(s->cvp_part, s->p, s->cov_fcols, cr.slot_of, cr.G, g0, ng, nsl_all, s->ctrl, parked, s->st,
                               nullptr, lo, hi);
         if (e == hipSuccess)
-          e = launch_cov_compact(cr.G, s->p, cr.slot_of, s->cov_fcols, g0, ng, cr.GS, s->cov_cs, s->ctrl, parked, s->st);
+          e = launch_cov_compact(cr.G, s->p, cr.slot_of, s->cov_fcols, g0, ng, cr.GS, s->cov_cs, s->ctrl, parked, s->st,
+                                 s->xtx[r], cr.meta);
       }
       if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel (shared): ") + hipGetErrorString(e));
       continue;
@@ -804,7 +821,8 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
       e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, s->ctrl, parked,
                             s->st);
     if (e == hipSuccess && !s->cov_bg)  // entries between cached columns, by slot: what the solve gathers from
-      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, s->ctrl, parked, s->st);
+      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, s->ctrl, parked, s->st, s->xtx[rs],
+                             cv.meta);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
   }
   return 0;
@@ -878,7 +896,7 @@ static CholFuse cov_fuse_args(bessx_session *s, int rs, int T0, bool force_chol,
   CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
                  s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
                  s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, s->cov_cs,
-                 cv.zero, PubArgs{}};
+                 cv.zero, PubArgs{}, s->fb_work, cv.meta + 4};
   // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
   if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
     fz.pub = *sf->pub;
@@ -910,9 +928,13 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
     if (s->cov_cg && !force_chol)
       e = launch_cg(T0, (T0 + 15) / 16, lambda, s->xty[rs], s->A_new, s->sol, s->ctrl, slot, &fz, 64, s->st, s->cg_tol,
                     s->cg_by_rows);
-    else
+    else {
       e = launch_chol(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot, 0, s->st,
                       &fz);
+      if (e == hipSuccess)  // (its pivot test failed: pivoted solve + the commit k_chol skipped)
+        e = launch_sym_fallback(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->ctrl, slot,
+                                s->st, &fz);
+    }
   }
   // CV row sets need the sums of squares over the test rows too: one pass over the active columns for the final
   // coefficients (runs iff the fit ended here).  On all rows the loss comes from the solved system (k_chol).
@@ -1110,9 +1132,13 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
                                       s->gpart, ntiles, s->ctrl, slot, t, T0, s->bcur, s->llpart, s->st, s->irls_wfloor);
       if (e == hipSuccess) e = launch_gram_reduce(s->gpart, ns, ntiles, s->Gt, s->ctrl, slot, 1, s->st);
       const IrlsChk ck = {1, s->ctrl, t, fam, s->llpart, ns, T0 + 1, s->bcur, s->bprev};
+      const CholFuse fbz = chol_fallback_only(s);
       if (e == hipSuccess)
         e = launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot, 1,
-                        s->st, nullptr, &ck);
+                        s->st, &fbz, &ck);
+      if (e == hipSuccess && s->glm_fallback)
+        e = launch_sym_fallback(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot,
+                                s->st, &fbz);
       if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_irls_step: ") + hipGetErrorString(e));
       return 0;
     }
@@ -1127,11 +1153,15 @@ static int enqueue_glm_irls_step(bessx_session *s, int slot, int t, int T0, doub
   if (e == hipSuccess)
     e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->Wv, rps, tk, ntask, nslab, s->gpart, ntiles, s->Gt, s->ctrl,
                     slot, 1, s->st);
+  const CholFuse fbz = chol_fallback_only(s);
   if (e == hipSuccess)
     e = mt <= 16 ? launch_chol(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl,
-                               slot, 1, s->st)
+                               slot, 1, s->st, &fbz)
                  : launch_chol_big(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info,
                                    s->rdiag, s->zbig, s->ctrl, slot, 1, s->st);
+  if (e == hipSuccess && mt <= 16 && s->glm_fallback)
+    e = launch_sym_fallback(s->Gt, T0 + 1, mt, 2.0 * lambda, 1, nullptr, nullptr, s->bcur, &s->ctrl->info, s->ctrl, slot,
+                            s->st, &fbz);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_glm_irls_step: ") + hipGetErrorString(e));
   return 0;
 }
@@ -1418,15 +1448,19 @@ static int algorithm_fit_grouped(bessx_session *s) {
       int ntask = 0, rps, nslab;
       if (int rc = gram_tasks_for(s, mt, &tk, &ntask)) return rc;
       gram_geometry(s, ntask, &rps, &nslab, ntiles);
+      const CholFuse fbz = chol_fallback_only(s);
       e = launch_gram_cols(s->gcols_new, K, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 0, s->st);
       if (e == hipSuccess)
         e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, tk, ntask, nslab, s->gpart, ntiles, s->Gt,
                         s->ctrl, slot, 0, s->st, 0);
       if (e == hipSuccess)
         e = mt <= 16 ? launch_chol(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info, s->ctrl,
-                                   slot, 0, s->st)
+                                   slot, 0, s->st, &fbz)
                      : launch_chol_big(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info,
                                        s->rdiag, s->zbig, s->ctrl, slot, 0, s->st);
+      if (e == hipSuccess && mt <= 16)  // (wide groups on few rows: more columns than independent rows)
+        e = launch_sym_fallback(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info, s->ctrl, slot,
+                                s->st, &fbz);
       if (e == hipSuccess)
         e = launch_commit_group(s->ctrl, slot, T0, s->A_new, K, s->gcols_new, s->sol, 0, 0, s->A_cur, s->b_cur,
                                 s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
@@ -1508,6 +1542,14 @@ static int algorithm_fit_grouped(bessx_session *s) {
       if (hc->irls_last > 0) s->irls_guess = std::min(tmax + 1, hc->irls_last + 1);
     }
     if (hc->done) break;
+  }
+  if (hc->info == 2 && glm && !cox && !s->glm_fallback) {  // (see algorithm_fit)
+    s->glm_fallback = true;
+    HIPX(hipStreamSynchronize(s->st));
+    HIPX(hipMemsetAsync(&s->ctrl->info, 0, sizeof(int), s->st));
+    s->cache[rs].valid = false;
+    s->dev_state_rs = -1;
+    return algorithm_fit_grouped(s);
   }
   if (hc->info) return fail(BESSX_ERR_NUMERIC, "non-finite value in the k x k solve (singular Gram matrix?)");
   const int K = hc->k_cur;
@@ -1839,6 +1881,17 @@ static int algorithm_fit(bessx_session *s) {
     s->n_submodel_steps += steps_used;
     slot++;
     if (hc->done) break;
+  }
+  if (hc->info == 2 && glm && !cox && !s->glm_fallback) {
+    // an IRLS system of this fit was rank-deficient to working precision (exactly dependent active columns) and its
+    // k_chol stood back: from now on the chain carries the pivoted solve behind every k_chol (a fall-through launch
+    // per step that sessions without such data never pay), and this fit is redone with it
+    s->glm_fallback = true;
+    HIPX(hipStreamSynchronize(s->st));
+    HIPX(hipMemsetAsync(&s->ctrl->info, 0, sizeof(int), s->st));
+    s->cache[rs].valid = false;
+    s->dev_state_rs = -1;
+    return algorithm_fit(s);
   }
   if (hc->info) return fail(BESSX_ERR_NUMERIC, "non-finite value in the k x k solve (singular Gram matrix?)");
   // results
@@ -2973,6 +3026,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->rdiag, (size_t)capA));
   HIPT(dmalloc(&s->zbig, (size_t)capA));
   HIPT(dmalloc(&s->cand, 32768));
+  HIPT(dmalloc(&s->fb_work, CHOL_FB_DOUBLES));
   HIPT(dmalloc(&s->tie_buf, (size_t)3 * p + 8));
   HIPT(hipMemset(s->tie_buf, 0, 8 * sizeof(int)));
   s->tie = TopkTie{s->tie_buf, s->tie_buf + 8};
@@ -3285,7 +3339,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     for (auto v : vecs) HIPT(V(v, (size_t)ld));
     double **vecs1[] = {&c.C1, &c.CU, &c.CV, &c.C2};
     for (auto v : vecs1) HIPT(V(v, (size_t)ld));
-    HIPT(V(&c.ldl_work, (size_t)256 * 256));
+    HIPT(V(&c.ldl_work, CHOL_FB_DOUBLES));
     // k-sized work space: for sparsity levels up to 254 now, grown by cox_reserve() when a larger one is asked for
     s->cox_M_cols = 256;
     HIPT(V(&c.M, (size_t)ld * s->cox_M_cols));
@@ -4064,7 +4118,12 @@ int bessx_op_chol_solve(const double *a, int m, const double *b, double *sol) {
   HIPX(hipMemcpy(Gt, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPX(hipMemcpy(drhs, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
   if (mt <= 16) {
-    HIPX(launch_chol(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, 0, nullptr));
+    double *dfb;
+    HIPX(sc.alloc(&dfb, CHOL_FB_DOUBLES));
+    CholFuse fbz = {};
+    fbz.fb_work = dfb;  // (a singular / indefinite matrix goes to the pivoted solve, like in the fits)
+    HIPX(launch_chol(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, 0, nullptr, &fbz));
+    HIPX(launch_sym_fallback(Gt, m, mt, 0.0, 0, drhs, nullptr, dsol, dinfo, nullptr, 0, nullptr, &fbz));
   } else {
     double *rd, *zz;
     HIPX(sc.alloc(&rd, (size_t)mt * 16));

@@ -1641,6 +1641,153 @@ __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot
 // fz.G != nullptr (covariance mode of the LM fit): the Gram entries are gathered from the column cache
 // (G[row A_a, column slot_of[A_b]]) instead of read from Gt, and the kernel ends with the work of k_commit -- two
 // launches less per PDAS iteration.
+// position of entry (row, col) of a 16 x 16 tile in the fp64-MFMA accumulator layout; index of tile (I, J), I >= J
+__device__ __forceinline__ int tile_elem(int row, int col) { return ((((row & 3) << 4) | col) << 2) | (row >> 2); }
+__device__ __forceinline__ size_t tile_id(int I, int J) { return (size_t)I * (I + 1) / 2 + J; }
+
+// Rank-revealing fallback of the k x k solves (k_chol, k_ldlt_fallback's successor).  The reference solves its normal
+// equations with factorizations that survive a singular or indefinite matrix: column-pivoted Householder QR of the LM
+// Gram (src/Algorithm.h:1131-1135), Eigen's LDLT -- diagonal pivoting, a zero pivot gives a zero coefficient -- for the
+// IRLS and Newton systems (:1171, :1199, :1299, :1473).  The fast kernels here (Cholesky in registers, conjugate
+// gradients) assume positive definite; when a pivot collapses (exactly dependent columns: duplicates both in the active
+// set, more columns than independent rows) or turns negative (the Cox Newton matrix under a large ridge, whose sign the
+// reference has as written), the system is solved again by LDL^T WITH DIAGONAL PIVOTING on a dense copy in global
+// memory: at every step the largest remaining |diagonal| (first of equals, like Eigen's maxCoeff) is the pivot; a
+// pivot below 1e-11 of the largest diagonal counts as zero: its unknown is set to 0 and dropped -- the basic solution
+// of the consistent system, the coefficient of a duplicated column going to the copy that is eliminated first.
+// (Eigen's own tests are "exactly zero" / eps^2-relative: on exactly dependent columns whether they fire is decided by
+// rounding, so the reference's numbers there are not reproducible by any other arithmetic; see DESIGN.md.)
+// One workgroup, O(m^3 / NT) global-memory steps: rare and small.  A: m x m, both triangles, leading dimension m;
+// b: right-hand side in, solution out; dv / perm / zf: m entries of scratch each.  Returns nothing; non-finite
+// results are the caller's to flag.
+template <int NT>
+__device__ void sym_pivoted_solve(double *__restrict__ A, int m, double *__restrict__ b, double *__restrict__ dv,
+                                  int *__restrict__ perm, int *__restrict__ zf) {
+  __shared__ double s_v[NT / 64];
+  __shared__ int s_i[NT / 64];
+  __shared__ double s_scal;
+  __shared__ int s_piv;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the largest |diagonal| and, at every step, the first index of the largest remaining one
+  auto arg_absmax_diag = [&](int from) {
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    for (int j = from + tid; j < m; j += NT) {
+      const double v = fabs(A[(size_t)j * m + j]);
+      if (v > bv || (v == bv && j < bi)) {
+        bv = v;
+        bi = j;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      s_v[wave] = bv;
+      s_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_v[0];
+      int i = s_i[0];
+      for (int w = 1; w < NT / 64; w++)
+        if (s_v[w] > v || (s_v[w] == v && s_i[w] < i)) {
+          v = s_v[w];
+          i = s_i[w];
+        }
+      s_scal = v;
+      s_piv = i == 0x7fffffff ? from : i;  // (all NaN: any pivot will do, the result is flagged non-finite)
+    }
+    __syncthreads();
+  };
+  arg_absmax_diag(0);
+  const double tol = 1e-11 * s_scal;
+  for (int k = 0; k < m; k++) {
+    arg_absmax_diag(k);
+    const int piv = s_piv;
+    if (tid == 0) perm[k] = piv;
+    if (piv != k) {  // symmetric exchange of k and piv: rows, then columns
+      for (int c = tid; c < m; c += NT) {
+        const double t0 = A[(size_t)c * m + k];
+        A[(size_t)c * m + k] = A[(size_t)c * m + piv];
+        A[(size_t)c * m + piv] = t0;
+      }
+      __syncthreads();
+      for (int r = tid; r < m; r += NT) {
+        const double t0 = A[(size_t)k * m + r];
+        A[(size_t)k * m + r] = A[(size_t)piv * m + r];
+        A[(size_t)piv * m + r] = t0;
+      }
+      if (tid == 0) {
+        const double t0 = b[k];
+        b[k] = b[piv];
+        b[piv] = t0;
+      }
+      __syncthreads();
+    }
+    const double d = A[(size_t)k * m + k];
+    const bool dead = !(fabs(d) > tol);
+    if (tid == 0) {
+      dv[k] = dead ? 0.0 : d;
+      zf[k] = dead ? 1 : 0;
+    }
+    const int r = m - k - 1;
+    if (dead) {
+      for (int i = k + 1 + tid; i < m; i += NT) A[(size_t)k * m + i] = 0.0;  // no coupling through a dropped unknown
+      __syncthreads();
+      continue;
+    }
+    for (int i = k + 1 + tid; i < m; i += NT) A[(size_t)k * m + i] = A[(size_t)k * m + i] / d;  // column k: l_ik
+    __syncthreads();
+    // trailing block (both triangles): a_ij -= l_ik a_kj, a_kj still unscaled in row k
+    for (long idx = tid; idx < (long)r * r; idx += NT) {
+      const int i = k + 1 + (int)(idx % r), j = k + 1 + (int)(idx / r);
+      A[(size_t)j * m + i] -= A[(size_t)k * m + i] * A[(size_t)j * m + k];
+    }
+    __syncthreads();
+  }
+  // P b -> L^-1 -> D^+ -> L^-T -> P^T
+  for (int k = 0; k < m; k++) {
+    const double bk = b[k];
+    __syncthreads();
+    for (int i = k + 1 + tid; i < m; i += NT) b[i] -= A[(size_t)k * m + i] * bk;
+    __syncthreads();
+  }
+  for (int i = tid; i < m; i += NT) b[i] = zf[i] ? 0.0 : b[i] / dv[i];
+  __syncthreads();
+  for (int k = m - 1; k >= 0; k--) {
+    double part = 0.0;
+    for (int i = k + 1 + tid; i < m; i += NT) part += A[(size_t)k * m + i] * b[i];
+    part = wave_sum(part);
+    __syncthreads();
+    if (lane == 0) s_v[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+      double t0 = 0.0;
+      for (int w = 0; w < NT / 64; w++) t0 += s_v[w];
+      b[k] -= t0;
+    }
+    __syncthreads();
+  }
+  if (tid == 0)
+    for (int k = m - 1; k >= 0; k--) {
+      const int pv = perm[k];
+      if (pv != k) {
+        const double t0 = b[k];
+        b[k] = b[pv];
+        b[pv] = t0;
+      }
+    }
+  __syncthreads();
+}
+
 template <int NT>
 __device__ __forceinline__ bool irls_check_body(FitCtrl *__restrict__ ctrl, int t, int fam,
                                                 const double *__restrict__ llpart, int nblk, int m,
@@ -1677,6 +1824,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
   __shared__ double Lsh[CH_MT * TS];          // factored diagonal blocks
   __shared__ double z[CH_MT * 16];            // right-hand side / solution
   __shared__ double Rsh[CH_MT * 16];          // reciprocals of the diagonal of L
+  __shared__ double dorig[CH_MT * 16];        // the diagonal as loaded (a pivot below 1e-11 of it: rank-deficient system)
 #define WAVE_SYNC()                                          \
   do {                                                       \
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   \
@@ -1757,6 +1905,7 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
           if (row == mp - 1 && col == mp - 1) v = 1.0;
         }
         gv[r] = v;
+        if (row == col) dorig[row] = v;
       }
       acc[s] = d4{gv[0], gv[1], gv[2], gv[3]};
     }
@@ -1931,7 +2080,17 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
     sol[tid] = v;
     bad = !(fabs(v) <= DBL_MAX);
   }
-  if (__syncthreads_or(bad) && tid == 0 && info != nullptr) *info = 1;
+  // rank-deficient to working precision?  1 / L_jj is still in LDS (Rsh) and so is the diagonal as it was loaded: a
+  // pivot below 1e-11 of its own diagonal entry means exactly dependent columns (duplicates both in the active set,
+  // more columns than independent rows) -- the quotient of two rounding errors would follow.  Such a system, and one
+  // whose solution is not finite (negative pivot), is left to the pivoted solve (k_sym_fallback): info = 2.
+  if (tid < m) {
+    const double rinv = Rsh[tid];
+    bad = bad || !(1.0 > 1e-11 * dorig[tid] * rinv * rinv);
+  }
+  const bool failed = __syncthreads_or(bad) != 0;
+  if (failed && tid == 0 && info != nullptr) *info = 2;
+  if (failed) return;  // (nothing is committed: k_sym_fallback solves and commits, or the host reports the error)
   if (fz.G != nullptr) {  // sol is visible to the whole block after the barrier above
     // the loss of this solve comes from a residual pass (k_resid_lm): only k_cg has the true residual of the
     // normal equations at hand that makes the solved-system formula an identity
@@ -1940,6 +2099,64 @@ __global__ void __launch_bounds__(512) k_chol(const double *__restrict__ Gt, int
                 fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
   }
 #undef WAVE_SYNC
+}
+
+// The pivoted solve behind a k_chol launch that gave up (info = 2): same arguments, same gate; the matrix is read again
+// (tiles Gt, or gathered from the Gram column cache like k_chol does), laid out densely in fz.fb_work and solved by
+// sym_pivoted_solve.  Success clears info (and, in the covariance form, does the commit k_chol skipped); a result
+// that is still not finite leaves info = 1 for the host.  One workgroup; falls through in ~2 us when there is nothing
+// to repair.
+__global__ void __launch_bounds__(512) k_sym_fallback(const double *__restrict__ Gt, int m, int mt, double ridge,
+                                                      int ridge_skip0, const double *__restrict__ rhs,
+                                                      const int *__restrict__ rhs_gather, double *__restrict__ sol,
+                                                      int *__restrict__ info, const FitCtrl *__restrict__ ctrl,
+                                                      int slot, const CholFuse fz) {
+  if (info == nullptr || *info != 2) return;
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  __shared__ int same_any_sh;
+  __shared__ int sA[CH_MT * 16], sS[CH_MT * 16];
+  const int tid = threadIdx.x;
+  if (fz.G != nullptr) {
+    for (int i = tid; i < m; i += 512) {
+      const int a = rhs_gather[i];
+      sA[i] = a;
+      sS[i] = max(fz.slot_of[a], 0);
+    }
+    __syncthreads();
+  }
+  double *A = fz.fb_work, *bb = A + 256 * 256, *dvv = bb + 256;
+  int *perm = reinterpret_cast<int *>(dvv + 256), *zf = perm + 256;
+  for (int idx = tid; idx < m * m; idx += 512) {
+    const int i = idx % m, j = idx / m;
+    double v;
+    if (fz.G != nullptr) {
+      v = fz.G[(size_t)sS[j] * fz.p + sA[i]];
+    } else {
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      v = Gt[tile_id(hi >> 4, lo >> 4) * 256 + tile_elem(hi & 15, lo & 15)];
+    }
+    if (i == j && !(ridge_skip0 && i == 0)) v += ridge;
+    A[idx] = v;
+  }
+  for (int i = tid; i < m; i += 512)
+    bb[i] = rhs != nullptr ? rhs[rhs_gather ? rhs_gather[i] : i]
+                           : Gt[tile_id(mt - 1, i >> 4) * 256 + tile_elem(15, i & 15)];  // IRLS: Gram column mp - 1
+  __syncthreads();
+  sym_pivoted_solve<512>(A, m, bb, dvv, perm, zf);
+  bool bad = false;
+  if (tid < m) {
+    const double v = bb[tid];
+    sol[tid] = v;
+    bad = !(fabs(v) <= DBL_MAX);
+  }
+  const bool failed = __syncthreads_or(bad) != 0;
+  if (tid == 0) *info = failed ? 1 : 0;
+  if (failed) return;
+  if (fz.G != nullptr) {
+    if (tid == 0) fz.ctrl->sse_valid = 0;
+    commit_body(fz.ctrl, slot, fz.T0, rhs_gather, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+                fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1996,6 +2213,13 @@ __device__ __forceinline__ void cg_body(int m, int mt, double ridge, const doubl
   if (ctrl->same_prev) {
     commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
                 fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+    return;
+  }
+  if (fz.dep != nullptr && *fz.dep != 0) {  // exactly dependent columns cached: k_chol's pivot test decides (see cgr_body)
+    if (threadIdx.x == 0) {
+      fz.ctrl->cov_stall = 2;
+      fz.ctrl->l = -1 - fz.ctrl->l;
+    }
     return;
   }
 #ifdef BESSX_CG_PROFILE
@@ -2256,6 +2480,16 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
   if (ctrl->same_prev) {
     commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
                 fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
+    return;
+  }
+  if (fz.dep != nullptr && *fz.dep != 0) {
+    // exactly dependent columns are cached for this row set (k_cov_compact): a system that holds such a pair is for
+    // the factorisation with the pivot test (k_chol -> sym_pivoted_solve), not for an iteration that would quietly
+    // return one of its many solutions.  Parked like a solve that missed its residual target.
+    if (threadIdx.x == 0) {
+      fz.ctrl->cov_stall = 2;
+      fz.ctrl->l = -1 - fz.ctrl->l;
+    }
     return;
   }
 #ifdef BESSX_CG_PROFILE
@@ -3047,8 +3281,6 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
 // (it stays L2 resident), one small launch per phase of a block column.  Correct for any size; the in-register
 // kernel above is the fast path for the BASELINE sizes (k <= 254).  Same augmented-row trick for the right-hand side.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_elem(int row, int col) { return ((((row & 3) << 4) | col) << 2) | (row >> 2); }
-__device__ __forceinline__ size_t tile_id(int I, int J) { return (size_t)I * (I + 1) / 2 + J; }
 
 #define BIG_GATE(ctrl, slot, gate_mode)                                              \
   if ((ctrl) != nullptr) {                                                           \
@@ -5792,6 +6024,7 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
     if (restart) {
       meta[0] = 0;  // (otherwise untouched: a background fill may be adding columns concurrently)
       meta[3] += 1;  // cache generation: slot numbers start over (the maintained inverse of hinv_body is void)
+      meta[4] = 0;   // no cached columns, no dependent pairs
     }
     meta[1] = nm;
     meta[2] = spec ? 1 : 0;
@@ -6453,28 +6686,34 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
 __global__ void __launch_bounds__(256) k_cov_compact(const double *__restrict__ G, int p,
                                                      const int *__restrict__ slot_of,
                                                      const int *__restrict__ fcols, int g0, double *__restrict__ GS,
-                                                     int CS, const FitCtrl *__restrict__ ctrl, int big) {
+                                                     int CS, const FitCtrl *__restrict__ ctrl, int big,
+                                                     const double *__restrict__ xtx, int *__restrict__ meta) {
   KT(7);
   if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int gl = blockIdx.y;
   if ((g0 + gl) * COV_R >= ctrl->cov_nfill) return;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int t = j < p ? slot_of[j] : -1;
-  if (t < 0 || t >= CS) return;
+  if (t < 0) return;
+  const double dj = xtx != nullptr ? xtx[j] : 0.0;
   for (int c = 0; c < COV_R; c++) {
     const int col = fcols[(g0 + gl) * COV_R + c];
     if (col < 0) continue;
     const int sc = slot_of[col];
-    if (sc < 0 || sc >= CS) continue;
+    if (sc < 0) continue;
     const double v = G[(size_t)sc * p + j];
-    GS[(size_t)sc * CS + t] = v;
-    GS[(size_t)t * CS + sc] = v;
+    // two cached columns that are exactly dependent (duplicates, mirror images: |x_j . x_col| = |x_j| |x_col|): a system
+    // that holds both is singular but consistent -- conjugate gradients would split the coefficient between them where
+    // the reference's pivoted factorisation gives it to one.  meta[4] tells the solve kernels to leave such row sets
+    // to k_chol, whose pivot test routes them to the pivoted solve (sym_pivoted_solve).
+    if (xtx != nullptr && j != col && v * v >= (1.0 - 2e-11) * dj * xtx[col] && dj > 0.0) meta[4] = 1;
+    if (sc < CS && t < CS) {
+      GS[(size_t)sc * CS + t] = v;
+      GS[(size_t)t * CS + sc] = v;
+    }
   }
 }
 
-// ---- background (speculative) fill, issued on a second stream while the PDAS chain keeps the first one busy with
-// its single-workgroup kernels: scores of the uncached columns -> top 32 -> Gram columns -> publication.
-// bgm: [0] list length (0 or a multiple of 32), [1] first cache slot, [2] columns in the list.
 __global__ void __launch_bounds__(256) k_cov_bg_mask(const double *__restrict__ bd, const int *__restrict__ slot_of,
                                                      int p, double *__restrict__ bd2) {
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -7059,6 +7298,16 @@ hipError_t launch_chol(const double *Gt, int m, int mt, double ridge, int ridge_
   return hipSuccess;
 }
 
+hipError_t launch_sym_fallback(const double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
+                               const int *rhs_gather, double *sol, int *info, const FitCtrl *ctrl, int slot,
+                               hipStream_t st, const CholFuse *fuse) {
+  if (mt < 1 || mt > CH_MT || fuse == nullptr || fuse->fb_work == nullptr || info == nullptr) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_sym_fallback, dim3(1), dim3(512), 0, st, Gt, m, mt, ridge, ridge_skip0, rhs, rhs_gather, sol,
+                     info, ctrl, slot, *fuse);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
 // Conjugate-gradient solve of the covariance form (k_cg); falls back to k_chol through the parked-fit protocol.
 #ifdef BESSX_CG_PROFILE
 extern "C" __attribute__((visibility("default"))) int bessx_debug_cg_profile(unsigned long long *out, int reset) {
@@ -7488,9 +7737,16 @@ hipError_t launch_cox_newton_step(const double *X, const double *aux, long ld, i
                        (long)ntiles * 256, (const FitCtrl *)ctrl, slot, t);
     LAUNCH_CHECK();
   }
-  e = mt <= CH_MT ? launch_chol(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, ctrl, slot, 2, st)
+  // lambda = 0: a collapsed pivot (exactly dependent active columns) goes to the pivoted solve inside k_chol; with a
+  // ridge the matrix G1 - G2 - 2 lambda I can be indefinite and the un-pivoted LDL^T below follows the oracle
+  CholFuse fbz = {};
+  fbz.fb_work = lambda == 0.0 ? cb.ldl_work : nullptr;
+  e = mt <= CH_MT ? launch_chol(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, ctrl, slot, 2, st, &fbz)
                   : launch_chol_big(Gt, k, mt, -2.0 * lambda, 0, cb.g, nullptr, cb.u, &ctrl->info, rdiag, zbig, ctrl, slot,
                                     2, st);
+  if (e != hipSuccess) return e;
+  if (e == hipSuccess && mt <= CH_MT && lambda == 0.0 && cb.ldl_work != nullptr)
+    e = launch_sym_fallback(Gt, k, mt, 0.0, 0, cb.g, nullptr, cb.u, &ctrl->info, ctrl, slot, st, &fbz);
   if (e != hipSuccess) return e;
   if (mt <= CH_MT && lambda != 0.0 && cb.ldl_work != nullptr) {  // (k_chol leaves Gt untouched: it works in registers)
     hipLaunchKernelGGL(k_ldlt_fallback, dim3(1), dim3(256), 0, st, (const double *)Gt, k, -2.0 * lambda,
@@ -7864,9 +8120,10 @@ hipError_t launch_rows_permute(const double *X, long ld, int p, const int *perm,
 }
 
 hipError_t launch_cov_compact(const double *G, int p, const int *slot_of, const int *fcols, int g0, int ngroups,
-                              double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st) {
+                              double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st, const double *xtx,
+                              int *meta) {
   hipLaunchKernelGGL(k_cov_compact, dim3((p + 255) / 256, ngroups), dim3(256), 0, st, G, p, slot_of, fcols, g0, GS, CS,
-                     ctrl, parked);
+                     ctrl, parked, xtx, meta);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -78,8 +78,11 @@ def run(cases=100, seed=1, medium=False, verbose=True):
             # a 256-column panel)
             gs_ = np.sort(np.diff(np.append(gi, p)))[::-1]
             if gs_[0] > (64 if fam == "cox" else 200) or int(np.sum(gs_[:5])) > n // 3:
-                # (also: the widest selectable groups together must stay well below n -- a rank-deficient restricted
-                # fit is BESSX_ERR_NUMERIC here, the reference's pivoted QR returns a basic solution)
+                # (also: the widest selectable groups together must stay well below n.  A restricted fit with more
+                # columns than independent rows has no reproducible reference value -- the reference's pivoted QR and
+                # the oracle's LDL^T both return quotients of rounding errors there -- so a DIFFERENTIAL run cannot use
+                # such draws; the GPU path returns the basic solution of its pivoted solve instead of an error:
+                # tests/test_rank_deficient_gpu.py)
                 gi = np.arange(0, p, 3).astype(np.int32)
             kw.update(algorithm_type=2, g_index=gi, sequence=np.arange(1, min(len(gi), 6)))
             kw.pop("score_mode", None)
