@@ -3957,21 +3957,32 @@ __global__ void __launch_bounds__(256) k_group_lsq_score(int N, const int *__res
       W[(size_t)j * s + i] = v;
     }
     __syncthreads();
-    if (tid == 0) piv = sqrt(W[(size_t)j * s + j]);
+    if (tid == 0) {
+      // a column that depends exactly on the ones before it (a duplicate inside the group, more columns than rows):
+      // its pivot collapses against its own sum of squares.  The reference's column-pivoted QR gives such a column
+      // the coefficient 0 (src/screening.cpp:44-48); here it is dropped the same way: unit pivot, no coupling, and a
+      // zero right-hand side entry below.  (An all-zero column keeps its 0 / 0: the group then ranks first, as the
+      // reference's division by the zero pivot makes it, tests/test_limits_gpu.py.)
+      const double d0 = mblk[goff[g] + (size_t)j * s + j], vj = W[(size_t)j * s + j];
+      const bool dead = d0 > 0.0 && !(vj > 1e-11 * d0);
+      piv = dead ? -1.0 : sqrt(vj);
+    }
     __syncthreads();
-    const double rp = 1.0 / piv;
-    for (int i = j + tid; i < s; i += 256) W[(size_t)j * s + i] = (i == j) ? piv : W[(size_t)j * s + i] * rp;
+    const bool dead = piv < 0.0;
+    const double rp = dead ? 0.0 : 1.0 / piv;
+    // (a dropped column is marked by a negative diagonal entry: its unknown is 0 in both substitutions)
+    for (int i = j + tid; i < s; i += 256) W[(size_t)j * s + i] = (i == j) ? (dead ? -1.0 : piv) : W[(size_t)j * s + i] * rp;
     __syncthreads();
   }
   for (int j = 0; j < s; j++) {  // L y = d
-    if (tid == 0) z[j] = z[j] / W[(size_t)j * s + j];
+    if (tid == 0) z[j] = W[(size_t)j * s + j] < 0.0 ? 0.0 : z[j] / W[(size_t)j * s + j];
     __syncthreads();
     const double zj = z[j];
     for (int i = j + 1 + tid; i < s; i += 256) z[i] = fma(-W[(size_t)j * s + i], zj, z[i]);
     __syncthreads();
   }
   for (int j = s - 1; j >= 0; j--) {  // L^T b = y
-    if (tid == 0) z[j] = z[j] / W[(size_t)j * s + j];
+    if (tid == 0) z[j] = W[(size_t)j * s + j] < 0.0 ? 0.0 : z[j] / W[(size_t)j * s + j];
     __syncthreads();
     const double zj = z[j];
     for (int i = tid; i < j; i += 256) z[i] = fma(-W[(size_t)i * s + j], zj, z[i]);

@@ -219,3 +219,22 @@ def test_cox_screening_with_groups(gpu):
     full = np.zeros(p)
     full[cols] = want["beta"]
     np.testing.assert_allclose(got["beta"], full, rtol=1e-6, atol=1e-12)
+
+
+def test_lm_group_screening_with_dependent_columns_inside_a_group(gpu):
+    """A duplicated and a mirrored column INSIDE groups: the group's marginal least-squares fit is rank-deficient; the
+    reference's column-pivoted QR gives the dependent copy the coefficient 0 (src/screening.cpp:44-48) and so does the
+    group solve here (k_group_lsq_score drops a column whose pivot collapses).  Kept groups = the compiled reference's
+    (recorded with oracle/_ref/libbess_ref.so on exactly these inputs; re-checked against it where it is present)."""
+    from oracle import ref_ctypes as R
+    X, y, _, _ = synth.make_lm(200, 60, 4, seed=11)
+    X = np.array(X)
+    gi = np.arange(0, 60, 5, dtype=np.int32)
+    X[:, 7] = X[:, 5]
+    X[:, 23] = -X[:, 21]
+    want = {4: [1, 2, 8, 9], 6: [1, 2, 5, 8, 9, 11], 9: [0, 1, 2, 4, 5, 6, 8, 9, 11]}
+    for keep, groups in want.items():
+        if R.available():
+            assert list(R.screening_groups(X, y, None, 1, keep, gi)) == groups
+        with gpu.Session(X, y, algorithm_type=2, g_index=gi, is_screening=True, screening_size=keep) as s:
+            assert list(s.screening_groups()) == groups, keep
