@@ -257,7 +257,8 @@ class Session:
     def counters(self):
         """Diagnostics of the covariance form (bessx_session_counter)."""
         names = ("chained_fits", "cg_fallbacks", "passes_over_X", "chained_queued", "background_fills",
-                 "solves_from_inverse", "inverse_rebuilds")
+                 "solves_from_inverse", "inverse_rebuilds", "cv_side_by_side_rounds", "cv_union_fills", "tie_rescues",
+                 "cache_restarts")
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in enumerate(names)}
 
     def screening(self):

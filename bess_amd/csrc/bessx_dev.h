@@ -101,6 +101,7 @@ struct TopkNeed {
   int cont_on, cont_serial, cont_parent;
   // fused commit of a repeated active set (the record-and-stop branch of k_commit): commit_on = 1
   int commit_on;
+  int no_restart;  // fold chains side by side: a full cache parks the fit (cov_stall = 4) instead of starting it over
   int *cm_A_cur;
   double *cm_b_cur, *cm_beta_dense;
   int *cm_hist;
@@ -295,10 +296,21 @@ hipError_t launch_screen_cox(const double *X, long ld, int n, int p, const doubl
 hipError_t launch_gather_cols(const double *X, long ld, const int *A, int pnew, double *X2, hipStream_t st);
 // covariance-update mode (LM)
 hipError_t launch_cov_need(const int *list, int len, const double *bd, double *bd2, int p, int *slot_of, int *meta,
-                           int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st);
+                           int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st,
+                           int no_restart = 0);
+// spec: the lookup formed the masked score copy bd2 and `extras` holds its best columns (0: only the missing columns)
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max = 32);
+                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec);
 hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
+// one fill for several parked fits that share a slot map (k_cov_fill_union)
+struct CovUnion {
+  int nf;
+  const int *list[8];  // the column sets that have to be cached when the fill is done
+  int len[8];
+};
+hipError_t launch_cov_fill_union(const CovUnion &u, int restart, const int *extras, const double *bd2, int spec_max,
+                                 int spec_min, int *slot_of, int *meta, int p, int *fcols, FitCtrl *fill_ctrl,
+                                 hipStream_t st);
 int cov_streamed_tiles_per_wave();
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,

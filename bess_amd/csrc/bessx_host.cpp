@@ -15,10 +15,14 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bessx.h"
@@ -75,6 +79,72 @@ static constexpr int T0_HARD = 16382;  // largest capacity a session can be crea
 }  // namespace bessx
 
 using namespace bessx;
+
+// Host threads that queue the chains' launches: launches that alternate between streams cost the host ~10 us each
+// (measured: 35 launches per round, 12 ms per path of configs[3]); one thread per chain queues its 7 on its own stream
+// while the others do the same.  Workers spin for a job for a short while after the last one, then block.
+struct FoldPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  unsigned ticket = 0;  // (under mu) number of the current job
+  std::atomic<unsigned> ticket_hint{0};  // ... its copy for the spinning phase
+  std::atomic<int> pending{0};
+  bool quit = false;
+  std::function<void(int)> job;
+  int device = 0;
+  void worker(int k) {
+    (void)hipSetDevice(device);
+    unsigned seen = 0;
+    for (;;) {
+      bool got = false;
+      for (int spin = 0; spin < 200000 && !got; spin++) {  // ~ a few hundred microseconds
+        got = ticket_hint.load(std::memory_order_acquire) != seen;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return quit || ticket != seen; });
+        if (quit) return;
+        seen = ticket;
+      }
+      job(k);
+      pending.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void start(int nworkers, int dev) {
+    device = dev;
+    for (int k = 1; k <= nworkers; k++) th.emplace_back([this, k] { worker(k); });
+  }
+  // runs fn(0) on the caller and fn(1..nworkers) on the workers; returns when all are done
+  void run(const std::function<void(int)> &fn) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = fn;
+      pending.store((int)th.size(), std::memory_order_relaxed);
+      ticket++;
+      ticket_hint.store(ticket, std::memory_order_release);
+    }
+    cv.notify_all();
+    fn(0);
+    while (pending.load(std::memory_order_acquire) != 0) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+    th.clear();
+  }
+};
 
 struct bessx_session {
   int p_full = 0;                 // columns of the caller's x (p = columns kept by the screening)
@@ -215,6 +285,25 @@ struct bessx_session {
   double *Xp = nullptr, *zp = nullptr, *cvp_part = nullptr;
   long ldp = 0;
   int cvp_rps = 0, cvp_nsl = 0;  // rows per slab, slabs per fold (fold k owns slabs [k * cvp_nsl, (k + 1) * cvp_nsl))
+  // The K fold chains of a CV evaluation side by side (LM, covariance form, shared fills; Metric::test_loss,
+  // src/Metric.h:150-195, fits the folds one after another, but fold k's fit depends on nothing the others produce):
+  // every fold has a CONTEXT of its own -- a bessx_session that borrows the parent's data, row-set vectors and Gram
+  // column caches and owns what a fit writes (stream, control / result block, scores, selection and solve work space,
+  // host-side warm-start state).  fold_fits_side_by_side() drives them in lock step; whenever chains are parked on
+  // missing columns ONE fill (k_cov_fill_union + a pass over the fold-major copy) serves all of them, issued while
+  // every chain is quiet, so nobody reads the shared slot map while it is rewritten.  BESSX_CV_SIDE_BY_SIDE=0: the
+  // folds are fitted one after another on the parent's own state (round 2's form).
+  bessx_session *parent = nullptr;          // set in a fold context
+  std::vector<bessx_session *> fold_ctx;    // [k]: context of row set k + 1 (empty: folds run on the parent)
+  bool cv_side_by_side = true;
+  bool cov_no_restart = false;              // fold context: a full cache parks the fit (cov_stall = 4), the host restarts it
+  FitCtrl *fill_ctrl = nullptr;             // gate + statistics block of the union fills (device)
+  FitCtrl *fill_ctrl_h = nullptr;           // ... its pinned host copy
+  hipEvent_t ev_fill = nullptr, ev_ctx = nullptr;
+  long long cv_union_fills = 0, cv_rounds = 0;
+  int fill_groups_seen = 0;                 // fill_ctrl->cov_groups already added to cov_panel_groups
+  FoldPool *fold_pool = nullptr;            // host threads that queue the chains' launches (one per chain)
+  double sbs_t[6] = {0, 0, 0, 0, 0, 0};     // BESSX_DEBUG: seconds in start / enqueue / wait / fill / continue / results
   bool cov_pair_auto = true;  // launches of two groups use the pair panel kernel (BESSX_PANEL_PAIR_AUTO=0: never)
   int cov_variant = 3;        // panel kernel: 3 = LDS tile, loads two chunks ahead (2 blocks per CU); 2 = LDS tile,
                               // one chunk ahead (3 blocks per CU); 1 = double-buffered tile (1 block per CU);
@@ -302,8 +391,46 @@ static hipError_t dmalloc(T **ptr, size_t count) {
   return hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(count, 1) * sizeof(T));
 }
 
+// A fold context (bessx_session::fold_ctx) owns only what a fit writes; everything else is the parent's.
+static void fold_ctx_free(bessx_session *c) {
+  if (!c) return;
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  void *dev[] = {c->resblk, c->bd, c->bd2, c->beta_dense, c->inA, c->cov_bmm, c->sol, c->A_new, c->cand, c->tie_buf,
+                 c->fb_work, c->hist, c->hist_beta, c->hist_coef0, c->Gt, c->init_idx_d, c->init_val_d, c->cov_fcols,
+                 c->cov_extras, c->rdiag, c->zbig};
+  for (void *q : dev)
+    if (q) (void)hipFree(q);
+  if (c->res_buf[0]) (void)hipHostFree(c->res_buf[0]);
+  if (c->pub_flag) (void)hipHostFree(c->pub_flag);
+  if (c->stage_h) (void)hipHostFree(c->stage_h);
+  if (c->st) (void)hipStreamDestroy(c->st);
+  delete c;
+}
+
+static void drop_fold_contexts(bessx_session *s) {
+  if (s->fold_pool) {
+    s->fold_pool->stop();
+    delete s->fold_pool;
+    s->fold_pool = nullptr;
+  }
+  for (bessx_session *c : s->fold_ctx) fold_ctx_free(c);
+  s->fold_ctx.clear();
+  if (s->fill_ctrl) (void)hipFree(s->fill_ctrl);
+  if (s->fill_ctrl_h) (void)hipHostFree(s->fill_ctrl_h);
+  if (s->ev_fill) (void)hipEventDestroy(s->ev_fill);
+  if (s->ev_ctx) (void)hipEventDestroy(s->ev_ctx);
+  s->fill_ctrl = s->fill_ctrl_h = nullptr;
+  s->ev_fill = s->ev_ctx = nullptr;
+  s->fill_groups_seen = 0;
+}
+
 static void session_free(bessx_session *s) {
   if (!s) return;
+  if (std::getenv("BESSX_DEBUG") && !s->fold_ctx.empty())
+    std::fprintf(stderr, "[bessx] fold chains side by side: %lld rounds, %lld union fills; ms in start %.2f, enqueue %.2f, "
+                 "wait %.2f, fill %.2f, continue %.2f, results %.2f\n", s->cv_rounds, s->cv_union_fills, s->sbs_t[0] * 1e3,
+                 s->sbs_t[1] * 1e3, s->sbs_t[2] * 1e3, s->sbs_t[3] * 1e3, s->sbs_t[4] * 1e3, s->sbs_t[5] * 1e3);
+  drop_fold_contexts(s);
   if (std::getenv("BESSX_DEBUG"))
     std::fprintf(stderr, "[bessx] chained fits: queued %lld, used %lld, not started %lld, mismatched %lld; "
                  "CG solves handed to Cholesky: %lld; waits for a published block: %lld, of which the block was "
@@ -557,6 +684,11 @@ static int reset_path_caches(bessx_session *s) {
   s->cov_count_ub = s->cov_count_seen = s->cov_fg_pending = s->bg_outstanding = 0;
   for (auto &c : s->cache) c.valid = false;
   s->dev_state_rs = -1;
+  for (bessx_session *c : s->fold_ctx) {
+    HIPX(hipStreamSynchronize(c->st));
+    for (auto &cc : c->cache) cc.valid = false;
+    c->dev_state_rs = -1;
+  }
   for (auto &g : s->gcache) HIPX(hipMemsetAsync(g.meta, 0, 2 * sizeof(int), s->st));
   for (auto &c : s->cov) {
     HIPX(hipMemsetAsync(c.slot_of, 0xff, (size_t)s->p * sizeof(int), s->st));
@@ -783,8 +915,9 @@ static int panel_variant_for(const bessx_session *s, int ng) {
   return (s->cov_variant == 3 && ng == 2 && s->cov_pair_auto) ? 4 : s->cov_variant;
 }
 
-static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
+static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const FitCtrl *gate = nullptr) {
   bessx_session::CovCache &cv = s->cov[rs];
+  const FitCtrl *gc = gate ? gate : s->ctrl;  // whose cov_stall / cov_nfill the launches look at
   for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS) {
     const int ng = std::min(COV_SLOT_GROUPS, ngroups - g0);
     hipEvent_t ea = nullptr, eb = nullptr;
@@ -794,7 +927,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
       // one unmasked pass over the fold-major copy serves every row set: the columns enter ALL caches (same slots)
       const int nsl_all = s->K * s->cvp_nsl;
       e = launch_cov_panel(s->Xp, s->zp, s->ldp, s->p, nullptr, s->cov_fcols, g0, ng, s->cvp_rps, nsl_all, s->cvp_part,
-                           s->ctrl, parked, s->st, panel_variant_for(s, ng));
+                           gc, parked, s->st, panel_variant_for(s, ng));
       if (s->timing && e == hipSuccess) {
         e = hipEventRecord(eb, s->st);
         s->cov_timed.push_back({s->ev_used - 2, g0});
@@ -802,26 +935,26 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked) {
       for (int r = 0; r <= s->K && e == hipSuccess; r++) {
         bessx_session::CovCache &cr = s->cov[r];
         const int lo = r == 0 ? 0 : (r - 1) * s->cvp_nsl, hi = r == 0 ? 0 : r * s->cvp_nsl;  // fold r-1's own rows out
-        e = launch_cov_reduce(s->cvp_part, s->p, s->cov_fcols, cr.slot_of, cr.G, g0, ng, nsl_all, s->ctrl, parked, s->st,
+        e = launch_cov_reduce(s->cvp_part, s->p, s->cov_fcols, cr.slot_of, cr.G, g0, ng, nsl_all, gc, parked, s->st,
                               nullptr, lo, hi);
         if (e == hipSuccess)
-          e = launch_cov_compact(cr.G, s->p, cr.slot_of, s->cov_fcols, g0, ng, cr.GS, s->cov_cs, s->ctrl, parked, s->st,
+          e = launch_cov_compact(cr.G, s->p, cr.slot_of, s->cov_fcols, g0, ng, cr.GS, s->cov_cs, gc, parked, s->st,
                                  s->xtx[r], cr.meta);
       }
       if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel (shared): ") + hipGetErrorString(e));
       continue;
     }
     e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[rs], s->cov_fcols, g0, ng, s->cov_rps,
-                         s->cov_nslab, s->cov_part, s->ctrl, parked, s->st, panel_variant_for(s, ng));
+                         s->cov_nslab, s->cov_part, gc, parked, s->st, panel_variant_for(s, ng));
     if (s->timing && e == hipSuccess) {
       e = hipEventRecord(eb, s->st);
       s->cov_timed.push_back({s->ev_used - 2, g0});
     }
     if (e == hipSuccess)
-      e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, s->ctrl, parked,
+      e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, gc, parked,
                             s->st);
     if (e == hipSuccess && !s->cov_bg)  // entries between cached columns, by slot: what the solve gathers from
-      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, s->ctrl, parked, s->st, s->xtx[rs],
+      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, gc, parked, s->st, s->xtx[rs],
                              cv.meta);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
   }
@@ -983,6 +1116,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
     nd.cm_hist_stride = s->hist_stride;
     nd.cm_inA = s->inA;
     nd.commit_on = (s->fuse && (T0 + 1 + 15) / 16 <= 16) ? 1 : 0;  // (beyond: launch_commit does it, unfused)
+    nd.no_restart = s->cov_no_restart ? 1 : 0;
     if (sf && sf->cont && s->fuse && slot == 1 && skip_d && scores_ok) {
       // nothing runs before the selection in this slot: it opens the chained fit itself
       nd.cont_on = 1;
@@ -1015,7 +1149,7 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
     e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
     if (e == hipSuccess)
       e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s),
-                          s->cov_fcols, s->ctrl, slot, s->A_cur, s->st);
+                          s->cov_fcols, s->ctrl, slot, s->A_cur, s->st, s->cov_no_restart ? 1 : 0);
   }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot_cov: ") + hipGetErrorString(e));
   return enqueue_cov_tail(s, slot, T0, lambda, rs, false, sf);
@@ -1042,7 +1176,7 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
     hipError_t e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, stalled, s->st, nullptr, nullptr, &s->tie);
     if (e == hipSuccess)
       e = launch_cov_need(s->A_new, T0, cov_speculates(s) ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta,
-                          cov_C_dev(s), s->cov_fcols, s->ctrl, stalled, s->A_cur, s->st);
+                          cov_C_dev(s), s->cov_fcols, s->ctrl, stalled, s->A_cur, s->st, s->cov_no_restart ? 1 : 0);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark (tie): ") + hipGetErrorString(e));
     if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
     *next_slot = stalled + 1;
@@ -1059,7 +1193,8 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
   hipError_t e = hipSuccess;
   if (spec) e = launch_topk(s->bd2, s->p, s->cov_spec, s->cov_extras, s->cand, nullptr, 0, s->st);
   if (e == hipSuccess)
-    e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st, s->cov_spec);
+    e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st, s->cov_spec,
+                             spec ? 1 : 0);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark: ") + hipGetErrorString(e));
   // upper bound of the list length (the device drops speculative columns that turn out to be cached already)
   const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, s->cov_spec) : 0;
@@ -1651,10 +1786,13 @@ static int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, in
 }
 
 // One Algorithm::fit with the state set by the update_* style members of the session.
+static void fold_contexts_invalidate(bessx_session *s);
+
 static int algorithm_fit(bessx_session *s) {
   if (s->grouped) return algorithm_fit_grouped(s);
   const int T0 = s->sparsity_level, rs = s->cur_rows;
   const double lambda = s->lambda_level;
+  if (rs != 0 && !s->fold_ctx.empty()) fold_contexts_invalidate(s);  // a fold fitted on the parent's own state
   if (T0 < 1 || T0 > s->cap)
     return fail(BESSX_ERR_ARG, "sparsity level " + std::to_string(T0) + " outside [1, " + std::to_string(s->cap) +
                                    "]: a session holds work space for min(p, max(2046, bessx_problem.max_sparsity))"
@@ -1762,7 +1900,7 @@ static int algorithm_fit(bessx_session *s) {
     e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s), s->cov_fcols, s->ctrl, 0,
                         s->A_cur, s->st);
     if (e == hipSuccess)
-      e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 0, s->st, s->cov_spec);
+      e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 0, s->st, s->cov_spec, 0);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov begin: ") + hipGetErrorString(e));
     if (int rc = enqueue_cov_fill(s, rs, (k_init + COV_R - 1) / COV_R, 0)) return rc;
   }
@@ -1969,6 +2107,350 @@ static int algorithm_fit(bessx_session *s) {
 }
 
 // --------------------------------------------------------------------------------------------
+// The K fold fits of a CV evaluation side by side (Metric::test_loss, src/Metric.h:150-195; see
+// bessx_session::fold_ctx).  Every fold context runs the same slots algorithm_fit() would queue for it -- warm start
+// from the fold's previous coefficients (:177-188), batches of two PDAS iterations, the parked-fit protocol -- on its
+// own stream; the host enqueues a batch for every chain, waits for all of them, and serves every chain that is parked
+// on missing Gram columns with ONE fill while all chains are quiet.
+// --------------------------------------------------------------------------------------------
+static void fold_contexts_invalidate(bessx_session *s) {
+  for (bessx_session *c : s->fold_ctx) {
+    for (auto &cc : c->cache) cc.valid = false;
+    c->dev_state_rs = -1;
+  }
+}
+
+static bool side_by_side_applies(const bessx_session *s, int T0) {
+  if (s->parent || s->K < 1 || s->fold_ctx.size() != (size_t)s->K) return false;
+  if (s->trace.on || s->model_type != 1 || s->grouped || !s->cov_mode || !s->cv_shared) return false;
+  if (T0 < 1 || T0 > s->cap || (T0 + 1 + 15) / 16 > 16) return false;  // (the fused selection + solve launches)
+  if (!topk_supported(s->p, T0) || !topk_can_fuse_need(s->p) || !sel_cgr_applies(s->p, T0)) return false;
+  // every chain's set must fit a cache that has just been started over, and the list of one fill its buffer
+  if ((long)s->K * T0 + s->cov_spec + COV_R > (long)cov_C_dev(s)) return false;
+  if ((long)s->K * T0 + 2 * s->cov_spec + COV_R > (long)s->capA + 4 * COV_R) return false;
+  if (s->warm_start)
+    for (const SparseVec &b : s->cv_init)
+      if ((int)b.idx.size() + COV_R + s->cov_spec > s->cov_C) return false;
+  return true;
+}
+
+static int fold_fits_side_by_side(bessx_session *s, double *out) {
+  const int K = s->K, T0 = s->sparsity_level, p = s->p;
+  const double lambda = s->lambda_level;
+  enum Todo { NONE, START, RESUME, UNPARK };
+  struct Chain {
+    bessx_session *c = nullptr;
+    int rs = 0, slot = 1, k_init = 0, serial = 0;
+    bool use_cache = false, scores_ok = false, grow1 = false, active = true, wait_fill = false;
+    Todo todo = START;
+    unsigned long long seq = 0;
+    const FitCtrl *hc = nullptr;
+    int rc = 0;
+    std::string err;
+  };
+  std::vector<Chain> ch((size_t)K);
+  auto quiet = [&]() {
+    for (bessx_session *c : s->fold_ctx) (void)hipStreamSynchronize(c->st);
+    (void)hipStreamSynchronize(s->st);
+  };
+#define SBS(expr)                  \
+  do {                             \
+    int rc__ = (expr);             \
+    if (rc__) {                    \
+      std::string keep__ = g_err;  \
+      quiet();                     \
+      fold_contexts_invalidate(s); \
+      g_err = keep__;              \
+      return rc__;                 \
+    }                              \
+  } while (0)
+#define SBSH(expr)                                                                                  \
+  do {                                                                                              \
+    hipError_t e__ = (expr);                                                                        \
+    if (e__ != hipSuccess)                                                                          \
+      SBS(fail(BESSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)));                 \
+  } while (0)
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto tick = [&](int which, std::chrono::steady_clock::time_point &t0) {
+    const auto t1 = tnow();
+    s->sbs_t[which] += std::chrono::duration<double>(t1 - t0).count();
+    t0 = t1;
+  };
+  auto tm = tnow();
+  for (int r = 1; r <= K; r++) s->cache[r].valid = false;  // the fold row sets' state now lives in the contexts
+  if (s->dev_state_rs > 0) s->dev_state_rs = -1;
+  // ---- start of the K fits: Algorithm::fit up to its first iteration (src/Algorithm.h:147-160)
+  // the opening of one chain's fit (its own stream): warm start from the device state or from the uploaded support
+  auto open_fit = [&](Chain &q) -> int {
+    bessx_session *c = q.c;
+    if (q.use_cache) {
+      HIPX(launch_fit_continue(c->ctrl, T0, c->hist, c->st, q.serial, 0));
+      return 0;
+    }
+    int *st_idx = reinterpret_cast<int *>(c->stage_h);
+    double *st_val = reinterpret_cast<double *>(c->stage_h + (size_t)c->capA * sizeof(int));
+    for (int i = 0; i < q.k_init; i++) {
+      st_idx[i] = c->beta_init.idx[i];
+      st_val[i] = c->beta_init.val[i];
+    }
+    if (q.k_init) {
+      HIPX(hipMemcpyAsync(c->init_idx_d, st_idx, q.k_init * sizeof(int), hipMemcpyHostToDevice, c->st));
+      HIPX(hipMemcpyAsync(c->init_val_d, st_val, q.k_init * sizeof(double), hipMemcpyHostToDevice, c->st));
+    }
+    HIPX(launch_fit_begin(c->ctrl, T0, q.k_init, c->init_idx_d, c->init_val_d, c->coef0_init, c->A_cur, c->b_cur,
+                          c->beta_dense, p, c->hist, c->st, c->inA));
+    return 0;
+  };
+  for (int k = 0; k < K; k++) {
+    Chain &q = ch[k];
+    bessx_session *c = q.c = s->fold_ctx[k];
+    const int rs = q.rs = k + 1;
+    c->sparsity_level = T0;
+    c->lambda_level = lambda;
+    c->cur_rows = rs;
+    c->beta_init = s->warm_start ? s->cv_init[k] : s->beta_init;  // update_beta_init(cv_initial_model_param.row(k))
+    c->coef0_init = s->coef0_init;
+    q.k_init = (int)c->beta_init.idx.size();
+    if (q.k_init > c->cap) SBS(fail(BESSX_ERR_ARG, "initial support too large"));
+    bessx_session::RsCache &cc = c->cache[rs];
+    q.use_cache = cc.valid && cc.coef0 == c->coef0_init && cc.beta.idx == c->beta_init.idx &&
+                  cc.beta.val == c->beta_init.val && cc.cov_layout && c->dev_state_rs == rs;
+    cc.valid = false;
+    q.serial = ++c->fit_serial;
+    q.scores_ok = q.use_cache && cc.lambda == lambda;
+    q.grow1 = q.scores_ok && cc.T0 + 1 == T0;
+    c->dev_state_rs = rs;
+    if (!q.use_cache && q.k_init > 0) {
+      // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones.  Done
+      // for this chain alone, to the end, before any chain reads the slot map (nothing else is queued yet); a full
+      // cache may start over here.
+      SBS(open_fit(q));
+      q.todo = NONE;
+      bessx_session::CovCache &cv = c->cov[rs];
+      SBSH(launch_cov_need(c->A_cur, q.k_init, nullptr, c->bd2, p, cv.slot_of, cv.meta, cov_C_dev(c), c->cov_fcols, c->ctrl,
+                           0, c->A_cur, c->st, 0));
+      SBSH(launch_cov_fill_list(c->cov_fcols, c->cov_extras, c->bd2, cv.slot_of, cv.meta, c->ctrl, 0, c->st, c->cov_spec, 0));
+      SBS(enqueue_cov_fill(c, rs, (q.k_init + COV_R - 1) / COV_R, 0));
+      SBSH(hipStreamSynchronize(c->st));
+    }
+  }
+  if (!s->fold_pool) {
+    s->fold_pool = new FoldPool();
+    s->fold_pool->start(K - 1, s->device);
+  }
+  tick(0, tm);
+  // ---- lock-step rounds
+  // one chain's share of a round, on its own stream (runs on its own host thread): what the previous read-back asked
+  // for (wake a parked fit up and finish its slot), then the next batch of two PDAS iterations and the publication
+  auto chain_round = [&](int k) {
+    Chain &q = ch[k];
+    if (!q.active) return;
+    bessx_session *c = q.c;
+    auto body = [&]() -> int {
+      if (q.wait_fill) HIPX(hipStreamWaitEvent(c->st, s->ev_fill, 0));  // nobody reads the caches before the fill is in
+      q.wait_fill = false;
+      if (q.todo == START) {
+        if (int rc = open_fit(q)) return rc;
+      } else if (q.todo == RESUME) {
+        const int stalled = -1 - q.hc->l + 1;
+        HIPX(launch_cov_resume(c->ctrl, c->st));
+        if (int rc = enqueue_cov_tail(c, stalled, T0, lambda, q.rs)) return rc;
+        q.slot = stalled + 1;
+      } else if (q.todo == UNPARK) {
+        if (int rc = cov_unpark(c, q.hc, T0, lambda, q.rs, &q.slot)) return rc;  // 2: Cholesky for the slot; 3: the exact tie rule
+      }
+      q.todo = NONE;
+      for (int b = 0; b < 2 && q.slot <= c->max_iter; b++, q.slot++)
+        if (int rc = enqueue_lm_slot_cov(c, q.slot, T0, lambda, q.rs, q.use_cache && q.slot == 1, q.scores_ok, q.grow1, nullptr))
+          return rc;
+      return publish_enqueue(c, T0, 0, &q.seq);  // the result block goes to pinned memory by a kernel of the chain
+    };
+    q.rc = body();
+    if (q.rc) q.err = g_err;  // (the message is thread-local)
+  };
+  int remaining = K;
+  while (remaining > 0) {
+    s->cv_rounds++;
+    s->fold_pool->run(chain_round);
+    for (Chain &q : ch)
+      if (q.active && q.rc) {
+        g_err = q.err;
+        SBS(q.rc);
+      }
+    tick(1, tm);
+    for (Chain &q : ch) {
+      if (!q.active) continue;
+      SBS(publish_wait(q.c, 0, q.seq));
+      q.hc = reinterpret_cast<const FitCtrl *>(q.c->res_h);
+    }
+    tick(2, tm);
+    // chains parked on missing columns (1) or on a full cache (4): one fill for all of them, now that every chain is quiet
+    bool filled = false;
+    {
+      int n_parked = 0, sum_nm = 0;
+      bool any_full = false;
+      Chain *spec_src = nullptr;
+      for (Chain &q : ch) {
+        if (!q.active) continue;
+        const int stl = q.hc->cov_stall;
+        if (stl != 1 && stl != 4) continue;
+        n_parked++;
+        any_full = any_full || stl == 4;
+        if (stl == 1) {
+          sum_nm += q.hc->cov_nmiss;
+          if (!spec_src && cov_speculates(q.c)) spec_src = &q;
+        }
+      }
+      if (n_parked > 0) {
+        int meta_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        SBSH(hipMemcpyAsync(meta_h, s->cov[0].meta, sizeof(meta_h), hipMemcpyDeviceToHost, s->st));
+        SBSH(hipStreamSynchronize(s->st));
+        const bool restart = any_full || meta_h[0] + sum_nm + s->cov_spec + COV_R > cov_C_dev(s);
+        CovUnion u = {};
+        int ub = 0;
+        for (Chain &q : ch) {
+          if (!q.active) continue;
+          const int stl = q.hc->cov_stall;
+          if (stl == 1 || stl == 4 || (restart && stl == 2)) {
+            u.list[u.nf] = q.c->A_new;  // the set this chain's parked slot is about to solve on
+            u.len[u.nf++] = T0;
+            ub += (restart || stl != 1) ? T0 : q.hc->cov_nmiss;
+          } else if (restart && stl == 0 && !q.hc->done && q.slot <= q.c->max_iter) {
+            u.list[u.nf] = q.c->A_cur;  // in the middle of a fit: its next score pass multiplies these columns
+            u.len[u.nf++] = T0;
+            ub += T0;
+          }
+        }
+        static const int spec_min_env = [] {
+          const char *ev = std::getenv("BESSX_CV_SPEC_MIN");
+          return ev ? std::atoi(ev) : -1;
+        }();
+        const int spec_min = spec_min_env >= 0 ? std::min(spec_min_env, s->cov_spec) : s->cov_spec / 2;
+        if (spec_src) {
+          bessx_session *cs = spec_src->c;
+          SBSH(launch_topk(cs->bd2, p, s->cov_spec, cs->cov_extras, cs->cand, nullptr, 0, cs->st));
+          SBSH(hipEventRecord(s->ev_ctx, cs->st));
+          SBSH(hipStreamWaitEvent(s->st, s->ev_ctx, 0));
+        }
+        SBSH(launch_cov_fill_union(u, restart ? 1 : 0, spec_src ? spec_src->c->cov_extras : nullptr,
+                                   spec_src ? spec_src->c->bd2 : nullptr, s->cov_spec, spec_min, s->cov[0].slot_of, s->cov[0].meta, p,
+                                   s->cov_fcols, s->fill_ctrl, s->st));
+        // the list's real length (columns two folds miss are listed once) decides how many groups are formed: the
+        // pair kernel the host would pick for two groups costs 1.8 passes even when the second group is empty
+        SBSH(hipMemcpyAsync(s->fill_ctrl_h, s->fill_ctrl, sizeof(FitCtrl), hipMemcpyDeviceToHost, s->st));
+        SBSH(hipStreamSynchronize(s->st));
+        s->cov_panel_groups += s->fill_ctrl_h->cov_groups - s->fill_groups_seen;
+        s->fill_groups_seen = s->fill_ctrl_h->cov_groups;
+        const int ngroups = s->fill_ctrl_h->cov_nfill / COV_R;
+        if (const char *ev = std::getenv("BESSX_DEBUG"))
+          if (std::atoi(ev) >= 2)
+            std::fprintf(stderr, "[sbs] union fill: %d chains parked, sum of their missing columns %d, list %d columns, "
+                         "%d cached after it%s\n", n_parked, sum_nm, s->fill_ctrl_h->cov_nfill, s->fill_ctrl_h->k_cur,
+                         restart ? " (cache started over)" : "");
+        if (ngroups > (ub + (spec_src ? s->cov_spec : 0) + 2 * COV_R - 1) / COV_R)
+          SBS(fail(BESSX_ERR_NUMERIC, "internal error: union fill list longer than its bound"));
+        SBS(enqueue_cov_fill(s, 0, ngroups, 1, s->fill_ctrl));
+        SBSH(hipEventRecord(s->ev_fill, s->st));
+        s->cv_union_fills++;
+        filled = true;
+        if (s->timing) {
+          SBSH(hipStreamSynchronize(s->st));
+          SBS(cov_collect(s, s->fill_ctrl_h->cov_nfill));
+        }
+      }
+    }
+    tick(3, tm);
+    for (Chain &q : ch) {
+      if (!q.active) continue;
+      const FitCtrl *hc = q.hc;
+      q.wait_fill = filled;
+      if (hc->cov_stall == 1 || hc->cov_stall == 4) {
+        q.todo = RESUME;
+      } else if (hc->cov_stall) {
+        q.todo = UNPARK;
+      } else if (hc->done || q.slot > q.c->max_iter) {
+        q.active = false;
+        remaining--;
+      }
+    }
+    tick(4, tm);
+    static const bool verbose = [] {
+      const char *ev = std::getenv("BESSX_DEBUG");
+      return ev && std::atoi(ev) >= 2;
+    }();
+    if (verbose) {
+      static double last[6] = {0, 0, 0, 0, 0, 0};
+      int act = 0;
+      for (Chain &q : ch) act += q.active ? 1 : 0;
+      std::fprintf(stderr, "[sbs] T0 %d round: enqueue %.0f us, wait %.0f, fill %.0f (%s), still active %d\n", T0,
+                   (s->sbs_t[1] - last[1]) * 1e6, (s->sbs_t[2] - last[2]) * 1e6, (s->sbs_t[3] - last[3]) * 1e6,
+                   filled ? "union fill" : "-", act);
+      for (int i = 0; i < 6; i++) last[i] = s->sbs_t[i];
+    }
+  }
+  // ---- results (the tail of algorithm_fit), in fold order
+  double acc = 0.0;
+  for (int k = 0; k < K; k++) {
+    Chain &q = ch[k];
+    bessx_session *c = q.c;
+    const FitCtrl *hc = q.hc;
+    if (!hc->done) {
+      // out of iterations: the sums of squares of the last coefficients have not been formed yet
+      SBSH(launch_resid_lm(c->X, c->ld, c->n, c->y, c->mask[q.rs], c->ctrl, hc->l, c->A_cur, c->b_cur, c->r_rs[q.rs], c->sse,
+                           c->st, 2));
+      SBS(read_results(c, T0));
+      hc = reinterpret_cast<const FitCtrl *>(c->res_h);
+    }
+    s->cov_panel_groups += hc->cov_groups;
+    if (hc->cov_miss)
+      SBS(fail(BESSX_ERR_NUMERIC, "internal error: an active column was missing from the Gram column cache"));
+    if (hc->info) SBS(fail(BESSX_ERR_NUMERIC, "non-finite value in the k x k solve (singular Gram matrix?)"));
+    const double *sse_h = reinterpret_cast<const double *>(c->res_h + ((unsigned char *)c->sse - c->resblk));
+    const double *b_h = reinterpret_cast<const double *>(c->res_h + ((unsigned char *)c->b_cur - c->resblk));
+    const int *a_h = reinterpret_cast<const int *>(c->res_h + ((unsigned char *)c->A_cur - c->resblk));
+    c->beta.idx.assign(a_h, a_h + T0);
+    c->beta.val.assign(b_h, b_h + T0);
+    c->coef0 = hc->coef0;
+    c->l = hc->done ? hc->l : c->max_iter + 1;
+    double tr = 0.0, te = 0.0;
+    for (int b = 0; b < c->n_sse_blk; b++) {
+      tr += sse_h[2 * b];
+      te += sse_h[2 * b + 1];
+    }
+    c->sse_train = tr;
+    c->sse_test = te;
+    bessx_session::RsCache &cc = c->cache[q.rs];
+    cc.valid = hc->done && hc->d_fresh;
+    cc.cov_layout = true;
+    cc.lambda = lambda;
+    cc.T0 = T0;
+    cc.beta = c->beta;
+    cc.coef0 = c->coef0;
+    s->n_fits += 1;
+    s->n_iters += hc->l;
+    s->cov_cg_fallbacks += c->cov_cg_fallbacks;
+    s->cov_tie_rescues += c->cov_tie_rescues;
+    c->cov_cg_fallbacks = c->cov_tie_rescues = 0;
+    if (s->warm_start) s->cv_init[k] = c->beta;
+    acc += c->sse_test / (double)(2 * s->n_test[k]);  // src/Metric.h:190
+  }
+  // what Algorithm holds after the loop of test_loss: the LAST fold's fit (path.cpp reads it, :314-319)
+  const bessx_session *last = s->fold_ctx[K - 1];
+  s->beta = last->beta;
+  s->coef0 = last->coef0;
+  s->l = last->l;
+  s->sse_train = last->sse_train;
+  s->sse_test = last->sse_test;
+  s->cur_rows = K;
+  if (s->warm_start) s->beta_init = s->cv_init[K - 1];
+  *out = acc / (double)K;
+  tick(5, tm);
+#undef SBS
+#undef SBSH
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------
 // Metric (src/Metric.h).  Values come from sums the residual kernel already produced.
 // --------------------------------------------------------------------------------------------
 static double metric_train_loss_value(const bessx_session *s) {
@@ -1993,6 +2475,7 @@ static int metric_train_loss(bessx_session *s, double *out) {
 
 // test_loss under CV: K fold fits, src/Metric.h:150-195
 static int metric_test_loss(bessx_session *s, double *out) {
+  if (side_by_side_applies(s, s->sparsity_level)) return fold_fits_side_by_side(s, out);
   double acc = 0.0;
   for (int k = 0; k < s->K; k++) {
     if (s->warm_start) s->beta_init = s->cv_init[k];  // update_beta_init(cv_initial_model_param.row(k))
@@ -3386,6 +3869,7 @@ void bessx_session_destroy(bessx_session *s) { session_free(s); }
 // Free everything bessx_session_set_cv allocated for the folds (row sets 1..K); every vector is walked by its own
 // length, so this is safe on the partly built state an allocation failure leaves behind.
 static void drop_folds(bessx_session *s) {
+  drop_fold_contexts(s);
   auto drop = [](std::vector<double *> &v) {
     for (size_t i = 1; i < v.size(); i++) (void)hipFree(v[i]);
     if (!v.empty()) v.resize(1);
@@ -3429,6 +3913,115 @@ static void drop_folds(bessx_session *s) {
   s->cv_init.clear();
   s->cv_fold.clear();
   s->K = 0;
+}
+
+// Context of row set rs for the fold chains that run side by side (see bessx_session::fold_ctx): a copy of the parent
+// that borrows its data and caches and owns the state a fit writes.  Same capacities as the parent, so every enqueue
+// function of the covariance form works on it unchanged.
+static int fold_ctx_create(bessx_session *ps, int rs, bessx_session **out) {
+  bessx_session *c = new bessx_session(*ps);
+  c->parent = ps;
+  c->fold_pool = nullptr;
+  c->fold_ctx.clear();
+  c->fill_ctrl = c->fill_ctrl_h = nullptr;
+  c->ev_fill = c->ev_ctx = nullptr;
+  c->ev_pool.clear();
+  c->ev_used = 0;
+  c->timing = false;
+  c->trace = Trace();
+  c->cov_timed.clear();
+  c->cox_allocs.clear();
+  c->publish = false;  // results by an asynchronous copy of the block: the driver waits for all chains at once
+  c->chain = false;
+  c->defer_pub = false;
+  c->hinv = false;
+  c->cov_bg = false;
+  c->st2 = nullptr;
+  c->ev_main = c->ev_bg = nullptr;
+  c->bg_inflight = false;
+  c->cov_target = 0;
+  c->cov_no_restart = true;
+  c->hint = bessx_session::Hint();
+  c->ahead = bessx_session::Ahead();
+  c->pend_on = false;
+  c->cache.assign(ps->cache.size(), bessx_session::RsCache());
+  c->dev_state_rs = -1;
+  c->bmm_owner = -1;
+  c->fit_serial = 0;
+  c->cur_rows = rs;
+  c->n_fits = c->n_iters = 0;
+  c->cov_cg_fallbacks = c->cov_tie_rescues = c->cov_panel_groups = 0;
+  c->chain_queued = c->chain_hits = c->chain_dead = c->chain_mismatch = 0;
+  c->dbg_waits = c->dbg_waits_ready = 0;
+  c->pub_flag = nullptr;  // (allocated below: the chains hand their result blocks over by k_publish)
+  c->pub_seq = 0;
+  c->snap[0] = c->snap[1] = nullptr;
+  c->res_buf[0] = c->res_buf[1] = nullptr;
+  c->res_h = nullptr;
+  c->stage_h = nullptr;
+  c->st = nullptr;
+  // owned device buffers: cleared first so that a failure half way frees only what this function allocated
+  c->resblk = nullptr;
+  c->bd = c->bd2 = c->beta_dense = c->cov_bmm = c->sol = c->fb_work = c->hist_beta = c->hist_coef0 = c->Gt = nullptr;
+  c->init_val_d = c->rdiag = c->zbig = nullptr;
+  c->inA = nullptr;
+  c->A_new = c->cand = c->tie_buf = c->hist = c->init_idx_d = c->cov_fcols = c->cov_extras = nullptr;
+  const int p = ps->p, capA = ps->capA, mt_max = capA / 16;
+  hipError_t e = hipSuccess;
+  {
+    int lo = 0, hi = 0;
+    e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // (the chains share the parent's priority level: spread over the levels, which have their own pools of hardware
+    // queues, the chains on the lower levels ran 2-8 x slower per kernel and the path no faster)
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, hi);
+  }
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->resblk), ps->res_bytes);
+  if (e == hipSuccess) e = hipMemset(c->resblk, 0, ps->res_bytes);
+  if (e == hipSuccess) {
+    c->ctrl = reinterpret_cast<FitCtrl *>(c->resblk + ((unsigned char *)ps->ctrl - ps->resblk));
+    c->sse = reinterpret_cast<double *>(c->resblk + ((unsigned char *)ps->sse - ps->resblk));
+    c->b_cur = reinterpret_cast<double *>(c->resblk + ((unsigned char *)ps->b_cur - ps->resblk));
+    c->A_cur = reinterpret_cast<int *>(c->resblk + ((unsigned char *)ps->A_cur - ps->resblk));
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->res_buf[0]), ps->res_bytes);
+  }
+  if (e == hipSuccess) {
+    std::memset(c->res_buf[0], 0, ps->res_bytes);
+    c->res_h = c->res_buf[0];
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->stage_h), (size_t)capA * (sizeof(int) + sizeof(double)));
+  }
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->pub_flag), 128);
+  if (e == hipSuccess) c->pub_flag[0] = c->pub_flag[8] = 0ull;
+  if (e == hipSuccess) e = dmalloc(&c->bd, (size_t)p);
+  if (e == hipSuccess) e = dmalloc(&c->bd2, (size_t)p);
+  if (e == hipSuccess) e = dmalloc(&c->beta_dense, (size_t)p);
+  if (e == hipSuccess) e = hipMemset(c->beta_dense, 0, (size_t)p * sizeof(double));
+  if (e == hipSuccess) e = dmalloc(&c->inA, (size_t)p);
+  if (e == hipSuccess) e = hipMemset(c->inA, 0, (size_t)p);
+  if (e == hipSuccess) e = dmalloc(&c->cov_bmm, (size_t)3 * ((p + 31) / 32));
+  if (e == hipSuccess) e = dmalloc(&c->sol, (size_t)capA);
+  if (e == hipSuccess) e = dmalloc(&c->A_new, (size_t)capA);
+  if (e == hipSuccess) e = dmalloc(&c->rdiag, (size_t)capA);
+  if (e == hipSuccess) e = dmalloc(&c->zbig, (size_t)capA);
+  if (e == hipSuccess) e = dmalloc(&c->cand, 32768);
+  if (e == hipSuccess) e = dmalloc(&c->fb_work, CHOL_FB_DOUBLES);
+  if (e == hipSuccess) e = dmalloc(&c->tie_buf, (size_t)3 * p + 8);
+  if (e == hipSuccess) e = hipMemset(c->tie_buf, 0, 8 * sizeof(int));
+  if (e == hipSuccess) c->tie = TopkTie{c->tie_buf, c->tie_buf + 8};
+  if (e == hipSuccess) e = dmalloc(&c->hist, (size_t)(ps->max_iter + 2) * ps->hist_stride);
+  if (e == hipSuccess) e = dmalloc(&c->hist_beta, (size_t)(ps->max_iter + 2) * ps->hist_stride);
+  if (e == hipSuccess) e = dmalloc(&c->hist_coef0, (size_t)(ps->max_iter + 2));
+  if (e == hipSuccess) e = dmalloc(&c->init_idx_d, (size_t)capA);
+  if (e == hipSuccess) e = dmalloc(&c->init_val_d, (size_t)capA);
+  if (e == hipSuccess) e = dmalloc(&c->Gt, (size_t)mt_max * (mt_max + 1) / 2 * 256);
+  if (e == hipSuccess) e = dmalloc(&c->cov_fcols, (size_t)capA + 4 * COV_R);
+  if (e == hipSuccess) e = dmalloc(&c->cov_extras, (size_t)2 * COV_R);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    fold_ctx_free(c);
+    return fail(BESSX_ERR_HIP, std::string("fold context: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return 0;
 }
 
 int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned seed) {
@@ -3571,6 +4164,29 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
       drop_folds(s);
       return rc;
     }
+    // one fit context per fold: the K chains of a CV evaluation run side by side (fold_fits_side_by_side).  A failed
+    // allocation leaves the folds on the parent's own state.
+    bool sbs = s->cv_side_by_side && K <= 8 && s->publish && s->fuse && s->cov_cg && s->cg_by_rows && s->fuse_sel;
+    if (const char *ev = std::getenv("BESSX_CV_SIDE_BY_SIDE")) sbs = sbs && std::string(ev) != "0";
+    if (sbs) {
+      hipError_t e = hipMalloc(reinterpret_cast<void **>(&s->fill_ctrl), sizeof(FitCtrl));
+      if (e == hipSuccess) e = hipMemset(s->fill_ctrl, 0, sizeof(FitCtrl));
+      if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s->fill_ctrl_h), sizeof(FitCtrl));
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fill, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_ctx, hipEventDisableTiming);
+      for (int k = 0; k < K && e == hipSuccess; k++) {
+        bessx_session *c = nullptr;
+        if (fold_ctx_create(s, k + 1, &c) != 0) {
+          e = hipErrorOutOfMemory;
+          break;
+        }
+        s->fold_ctx.push_back(c);
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        drop_fold_contexts(s);
+      }
+    }
   }
   HIPX(hipStreamSynchronize(s->st));
   return BESSX_OK;
@@ -3694,6 +4310,17 @@ long long bessx_session_counter(const bessx_session *s, int which) {
           hipMemcpy(h, s->cov[0].hmeta, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
         return -1;
       return h[which == 5 ? 2 : 3];
+    }
+    case 7: return s->cv_rounds;
+    case 8: return s->cv_union_fills;
+    case 9: return s->cov_tie_rescues;
+    case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
+      if (s->cov.empty()) return 0;
+      int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess ||
+          hipMemcpy(m, s->cov[0].meta, sizeof(m), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+      return m[3];
     }
     default: return -1;
   }

@@ -444,7 +444,7 @@ template <int NT>
 __device__ void cov_need_body(const int *__restrict__ list, int len, const double *__restrict__ bd,
                               double *__restrict__ bd2, int p, int *__restrict__ slot_of, int *__restrict__ meta, int C,
                               int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
-                              const int *__restrict__ A_cur, bool known_diff = false);
+                              const int *__restrict__ A_cur, bool known_diff = false, bool no_restart = false);
 
 __device__ __forceinline__ void commit_body(FitCtrl *__restrict__ ctrl, int slot, int T0,
                                             const int *__restrict__ A_new, const double *__restrict__ sol,
@@ -666,8 +666,6 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
         // every column cached, no restart: what cov_need_body would conclude (the set differs from A_cur by construction)
         if (threadIdx.x == 0) {
           nd.ctrl->same_prev = 0;
-          nd.meta[1] = 0;
-          nd.meta[2] = 0;
           nd.ctrl->cov_nmiss = 0;
         }
         __syncthreads();
@@ -676,7 +674,8 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
         return;
       }
       __syncthreads();
-      cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur, true);
+      cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur, true,
+                      nd.no_restart != 0);
       PH(3);
       PH_COUNT();
       return;
@@ -697,7 +696,8 @@ __device__ __forceinline__ void topk_body(const double *__restrict__ score, cons
     }
     __syncthreads();
     PH(2);
-    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur, true);
+    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur, true,
+                      nd.no_restart != 0);
     PH(3);
     PH_COUNT();
     return;
@@ -811,7 +811,8 @@ full_search:
   if (tid == 0 && out_count != nullptr && tot_eq > need_eq && kk < len) out_count[0] = 1;
   if (nd.slot_of != nullptr) {
     __syncthreads();  // the selected indices are visible to the whole block
-    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur);
+    cov_need_body<NT>(out, k, nd.bd, nd.bd2, nd.p, nd.slot_of, nd.meta, nd.C, nd.fcols, nd.ctrl, slot, nd.A_cur, false,
+                      nd.no_restart != 0);
   }
 }
 
@@ -5961,7 +5962,8 @@ __device__ __forceinline__ bool cov_gate(const FitCtrl *ctrl, int slot) {
   return ctrl->l == slot - 1 && !ctrl->same_prev;
 }
 
-// meta: [0] columns cached, [1] missing columns of this request, [2] speculation wanted for this request.
+// meta: [0] columns cached, [3] cache generation, [4] a dependent pair is cached (the request itself -- how many
+// columns are missing -- lives in the fit's own control block, cov_nmiss: row sets that share their fills share meta).
 // slot > 0: the request is the new active set of a PDAS iteration.  The kernel first does what k_gram_cols does in
 // the streaming form (repeated active set -> same_prev), then looks the columns up.  If some are missing the fit is
 // PARKED (cov_stall = 1, l = -1 - l: every gated kernel of this and the following slots falls through) and the host,
@@ -5971,7 +5973,7 @@ template <int NT>
 __device__ void cov_need_body(const int *__restrict__ list, int len, const double *__restrict__ bd,
                               double *__restrict__ bd2, int p, int *__restrict__ slot_of, int *__restrict__ meta, int C,
                               int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
-                              const int *__restrict__ A_cur, bool known_diff) {
+                              const int *__restrict__ A_cur, bool known_diff, bool no_restart) {
   __shared__ int wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (slot > 0 && known_diff) {
@@ -5989,6 +5991,16 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
   }
   int count = meta[0];
   const bool restart = count + len + COV_R > C;  // no room: start the cache over (uniform branch)
+  if (restart && no_restart && slot > 0) {
+    // fold chains running side by side share the slot map: nobody rewrites it under the others.  Park the fit
+    // (cov_stall = 4); the host starts the cache over when every chain is quiet (k_cov_fill_union)
+    if (tid == 0) {
+      ctrl->cov_nmiss = 0;
+      ctrl->cov_stall = 4;
+      ctrl->l = -1 - ctrl->l;
+    }
+    return;
+  }
   if (restart) {
     for (int j = tid; j < p; j += NT) slot_of[j] = -1;
     count = 0;
@@ -6000,11 +6012,7 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
     const int col = tid < len ? list[tid] : -1;
     const int miss = (col >= 0 && slot_of[col] < 0) ? 1 : 0;
     if (!__syncthreads_or(miss)) {
-      if (tid == 0) {
-        meta[1] = 0;
-        meta[2] = 0;
-        ctrl->cov_nmiss = 0;
-      }
+      if (tid == 0) ctrl->cov_nmiss = 0;
       return;
     }
   }
@@ -6037,9 +6045,7 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
       meta[3] += 1;  // cache generation: slot numbers start over (the maintained inverse of hinv_body is void)
       meta[4] = 0;   // no cached columns, no dependent pairs
     }
-    meta[1] = nm;
-    meta[2] = spec ? 1 : 0;
-    ctrl->cov_nmiss = nm;
+    ctrl->cov_nmiss = nm;  // (the request lives in the fit's own control block: row sets may share meta)
     if (nm > 0 && slot > 0) {
       ctrl->cov_stall = 1;
       ctrl->l = -1 - ctrl->l;
@@ -6056,10 +6062,10 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
                                                   const double *__restrict__ bd, double *__restrict__ bd2, int p,
                                                   int *__restrict__ slot_of, int *__restrict__ meta, int C,
                                                   int *__restrict__ fcols, FitCtrl *__restrict__ ctrl, int slot,
-                                                  const int *__restrict__ A_cur) {
+                                                  const int *__restrict__ A_cur, int no_restart) {
   KT(12);
   if (ctrl->done || (slot == 0 ? ctrl->l != 0 : ctrl->l != slot - 1)) return;
-  cov_need_body<256>(list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot, A_cur);
+  cov_need_body<256>(list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot, A_cur, false, no_restart != 0);
 }
 
 // Final fill list: the missing columns, then speculative ones (the best-scoring uncached columns, `extras`) up to
@@ -6068,16 +6074,17 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
 __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, const int *__restrict__ extras,
                                                        const double *__restrict__ bd2, int *__restrict__ slot_of,
                                                        int *__restrict__ meta, FitCtrl *__restrict__ ctrl,
-                                                       int parked, int spec_max) {
+                                                       int parked, int spec_max, int spec) {
   KT(10);
   if (parked ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
-  const int nm = meta[1];
+  const int nm = ctrl->cov_nmiss;  // left by the lookup of this fit (k_cov_need / cov_need_body)
   const int tid = threadIdx.x;
   if (nm == 0) {
     if (tid == 0) ctrl->cov_nfill = 0;
     return;
   }
-  const int count = meta[0], spec = meta[2];
+  const int count = meta[0];
+  // spec: the lookup left a masked copy of the scores (bd2) and the host ran the selection of `extras` on it.
   // spec_max = 32: the list is rounded up to the next multiple of 32 that leaves room for >= 16 speculative columns;
   // spec_max = 64 (pair panel kernel: two groups per pass over X): to the next multiple of 64 with room for >= 32
   const int room = spec ? min(((nm + spec_max / 2 + spec_max - 1) / spec_max) * spec_max - nm, spec_max) : 0;
@@ -6095,7 +6102,6 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
   for (int i = tid; i < tot; i += 256) slot_of[fcols[i]] = count + i;
   if (tid == 0) {
     meta[0] = count + tot;
-    meta[1] = 0;
     ctrl->cov_nfill = padded;
     ctrl->cov_groups += padded / COV_R;
   }
@@ -6106,6 +6112,81 @@ __global__ void k_cov_resume(FitCtrl *__restrict__ ctrl) {
   if (ctrl->cov_stall) {
     ctrl->cov_stall = 0;
     ctrl->l = -1 - ctrl->l;
+  }
+}
+
+// Fold chains side by side (CV row sets, shared fills; bessx_host.cpp: fold_fits_side_by_side): ONE fill for every chain
+// that is parked on a cache miss (cov_stall = 1) or on a full cache (4).  Runs while every chain is quiet.  The wanted
+// sets (u.list: the new active set of every parked chain; after `restart` -- decided by the host, which knows the
+// column count -- also the current active set of every chain that is in the middle of a fit) are looked up again
+// here against the slot map as it is NOW: a column two folds miss gets one slot, and after a restart every wanted
+// column is missing.  Then the best uncached columns of ONE chain's scores (extras / bd2: the masked copy its lookup left)
+// fill the list up by the rule of k_cov_fill_list.  fill_ctrl gates the panel / reduce / compact launches of the fill
+// (cov_stall = 1, cov_nfill) and carries the column count (k_cur) and the pass count (cov_groups) back to the host.
+__global__ void __launch_bounds__(256) k_cov_fill_union(const CovUnion u, int restart, const int *__restrict__ extras,
+                                                        const double *__restrict__ bd2, int spec_max, int spec_min,
+                                                        int *__restrict__ slot_of, int *__restrict__ meta, int p,
+                                                        int *__restrict__ fcols, FitCtrl *__restrict__ fill_ctrl) {
+  __shared__ int wsum[4];
+  __shared__ int s_ne;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (restart) {
+    for (int j = tid; j < p; j += 256) slot_of[j] = -1;
+    __syncthreads();
+  }
+  const int count = restart ? 0 : meta[0];
+  int nm = 0;
+  for (int f = 0; f < u.nf; f++) {  // uniform
+    const int *__restrict__ list = u.list[f];
+    const int len = u.len[f];
+    for (int base = 0; base < len; base += 256) {
+      const int i = base + tid;
+      const int col = i < len ? list[i] : -1;
+      const int miss = (col >= 0 && slot_of[col] < 0) ? 1 : 0;
+      const unsigned long long bal = __ballot(miss);
+      const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wsum[wave] = __popcll(bal);
+      __syncthreads();
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        off += (w < wave) ? wsum[w] : 0;
+        tot += wsum[w];
+      }
+      if (miss) {
+        fcols[nm + off + rank] = col;
+        slot_of[col] = count + nm + off + rank;
+      }
+      nm += tot;
+      __syncthreads();  // (the slots handed out are visible to the lookups of the next chunk / chain)
+    }
+  }
+  // (spec_min: the list is rounded up to the next multiple of spec_max that leaves room for that many speculative columns)
+  const int room = (extras != nullptr && nm > 0) ? min(((nm + spec_min + spec_max - 1) / spec_max) * spec_max - nm, spec_max) : 0;
+  if (tid == 0) s_ne = 0;
+  __syncthreads();
+  if (tid < 64 && room > 0) {
+    const int col = tid < spec_max ? extras[tid] : -1;
+    const bool valid = col >= 0 && bd2[col] >= 0.0 && slot_of[col] < 0;  // still a genuine uncached column
+    const unsigned long long bal = __ballot(valid);
+    const int rank = __popcll(bal & ((1ull << tid) - 1ull));
+    if (valid && rank < room) fcols[nm + rank] = col;
+    if (tid == 0) s_ne = min((int)__popcll(bal), room);
+  }
+  __syncthreads();
+  const int tot = nm + s_ne, padded = (tot + COV_R - 1) / COV_R * COV_R;
+  for (int i = tot + tid; i < padded; i += 256) fcols[i] = -1;
+  for (int i = nm + tid; i < tot; i += 256) slot_of[fcols[i]] = count + i;
+  if (tid == 0) {
+    meta[0] = count + tot;
+    if (restart) {
+      meta[3] += 1;
+      meta[4] = 0;
+    }
+    fill_ctrl->cov_stall = 1;
+    fill_ctrl->cov_nfill = padded;
+    fill_ctrl->cov_groups += padded / COV_R;
+    fill_ctrl->k_cur = count + tot;
   }
 }
 
@@ -7985,23 +8066,34 @@ hipError_t launch_gram_cols(const int *A_new, int T0, int mp, int intercept, int
 }
 
 hipError_t launch_cov_need(const int *list, int len, const double *bd, double *bd2, int p, int *slot_of, int *meta,
-                           int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st) {
+                           int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st,
+                           int no_restart) {
   hipLaunchKernelGGL(k_cov_need, dim3(1), dim3(256), 0, st, list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot,
-                     A_cur);
+                     A_cur, no_restart);
   LAUNCH_CHECK();
   return hipSuccess;
 }
 
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max) {
+                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec) {
   hipLaunchKernelGGL(k_cov_fill_list, dim3(1), dim3(256), 0, st, fcols, extras, bd2, slot_of, meta, ctrl, parked,
-                     spec_max);
+                     spec_max, spec);
   LAUNCH_CHECK();
   return hipSuccess;
 }
 
 hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st) {
   hipLaunchKernelGGL(k_cov_resume, dim3(1), dim3(1), 0, st, ctrl);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_fill_union(const CovUnion &u, int restart, const int *extras, const double *bd2, int spec_max,
+                                 int spec_min, int *slot_of, int *meta, int p, int *fcols, FitCtrl *fill_ctrl,
+                                 hipStream_t st) {
+  if (u.nf < 1 || u.nf > 8 || spec_max > 64 || spec_min < 0 || spec_min > spec_max) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_cov_fill_union, dim3(1), dim3(256), 0, st, u, restart, extras, bd2, spec_max, spec_min, slot_of, meta, p,
+                     fcols, fill_ctrl);
   LAUNCH_CHECK();
   return hipSuccess;
 }
