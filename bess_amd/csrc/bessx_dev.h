@@ -302,6 +302,16 @@ hipError_t launch_cov_need(const int *list, int len, const double *bd, double *b
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
                                 FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec);
 hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
+// the row sets of a cross-validation that share their fills (one launch reduces / compacts for all of them)
+struct CovRowSets {
+  int nr;
+  double *G[9], *GS[9];
+  const double *xtx[9];
+  int ex_lo[9], ex_hi[9];  // slabs of the fold-major copy this row set leaves out (its own fold's rows)
+};
+hipError_t launch_cov_reduce_compact_sets(const double *part, int p, const int *fcols, const int *slot_of, int *meta,
+                                          const CovRowSets &rs, int g0, int ngroups, int nslab, int CS,
+                                          const FitCtrl *ctrl, int parked, hipStream_t st);
 // one fill for several parked fits that share a slot map (k_cov_fill_union)
 struct CovUnion {
   int nf;

@@ -932,7 +932,21 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, c
         e = hipEventRecord(eb, s->st);
         s->cov_timed.push_back({s->ev_used - 2, g0});
       }
-      for (int r = 0; r <= s->K && e == hipSuccess; r++) {
+      if (s->K + 1 <= 9 && e == hipSuccess) {
+        // every row set in one reduce and one compact launch (they share the slot map and the list)
+        CovRowSets rsets = {};
+        rsets.nr = s->K + 1;
+        for (int r = 0; r <= s->K; r++) {
+          rsets.G[r] = s->cov[r].G;
+          rsets.GS[r] = s->cov[r].GS;
+          rsets.xtx[r] = s->xtx[r];
+          rsets.ex_lo[r] = r == 0 ? 0 : (r - 1) * s->cvp_nsl;  // fold r-1's own rows out
+          rsets.ex_hi[r] = r == 0 ? 0 : r * s->cvp_nsl;
+        }
+        e = launch_cov_reduce_compact_sets(s->cvp_part, s->p, s->cov_fcols, s->cov[0].slot_of, s->cov[0].meta, rsets, g0, ng,
+                                           nsl_all, s->cov_cs, gc, parked, s->st);
+      }
+      for (int r = 0; r <= s->K && e == hipSuccess && s->K + 1 > 9; r++) {
         bessx_session::CovCache &cr = s->cov[r];
         const int lo = r == 0 ? 0 : (r - 1) * s->cvp_nsl, hi = r == 0 ? 0 : r * s->cvp_nsl;  // fold r-1's own rows out
         e = launch_cov_reduce(s->cvp_part, s->p, s->cov_fcols, cr.slot_of, cr.G, g0, ng, nsl_all, gc, parked, s->st,
@@ -2389,6 +2403,7 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
     }
   }
   // ---- results (the tail of algorithm_fit), in fold order
+  if (s->warm_start) s->beta_init = s->cv_init[K - 1];  // (update_beta_init of the last fold: its warm start, not its result)
   double acc = 0.0;
   for (int k = 0; k < K; k++) {
     Chain &q = ch[k];
@@ -2442,7 +2457,6 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
   s->sse_train = last->sse_train;
   s->sse_test = last->sse_test;
   s->cur_rows = K;
-  if (s->warm_start) s->beta_init = s->cv_init[K - 1];
   *out = acc / (double)K;
   tick(5, tm);
 #undef SBS

@@ -6747,12 +6747,11 @@ __global__ void __launch_bounds__(256) k_cov_panel_glds32(const double *__restri
 }
 
 // G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
-__global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
-                                                    int njg, int p, const int *__restrict__ fcols,
-                                                    const int *__restrict__ slot_of, double *__restrict__ G,
-                                                    const FitCtrl *__restrict__ ctrl, int slot, int big,
-                                                    const int *__restrict__ bgm, int ex_lo, int ex_hi) {
-  KT(6);
+__device__ __forceinline__ void cov_reduce_body(const double *__restrict__ part, int g0, int ngroups, int nslab,
+                                                int njg, int p, const int *__restrict__ fcols,
+                                                const int *__restrict__ slot_of, double *__restrict__ G,
+                                                const FitCtrl *__restrict__ ctrl, int big,
+                                                const int *__restrict__ bgm, int ex_lo, int ex_hi) {
   if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
   const int gl = blockIdx.y;
   if (gl >= ngroups || (g0 + gl) * COV_R >= (big == 2 ? bgm[0] : ctrl->cov_nfill)) return;
@@ -6772,15 +6771,34 @@ __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ p
   if (j < p && col >= 0) G[(size_t)(big == 2 ? bgm[1] + ci : slot_of[col]) * p + j] = s;
 }
 
+__global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
+                                                    int njg, int p, const int *__restrict__ fcols,
+                                                    const int *__restrict__ slot_of, double *__restrict__ G,
+                                                    const FitCtrl *__restrict__ ctrl, int slot, int big,
+                                                    const int *__restrict__ bgm, int ex_lo, int ex_hi) {
+  KT(6);
+  cov_reduce_body(part, g0, ngroups, nslab, njg, p, fcols, slot_of, G, ctrl, big, bgm, ex_lo, ex_hi);
+}
+
+// ... for every row set of a cross-validation at once (shared fills: blockIdx.z = row set; all of them cache the same
+// columns under the same slots, each leaves its own fold's slabs out)
+__global__ void __launch_bounds__(256) k_cov_reduce_sets(const double *__restrict__ part, int g0, int ngroups, int nslab,
+                                                         int njg, int p, const int *__restrict__ fcols,
+                                                         const int *__restrict__ slot_of, const CovRowSets rs,
+                                                         const FitCtrl *__restrict__ ctrl, int big) {
+  KT(6);
+  const int r = blockIdx.z;
+  cov_reduce_body(part, g0, ngroups, nslab, njg, p, fcols, slot_of, rs.G[r], ctrl, big, nullptr, rs.ex_lo[r], rs.ex_hi[r]);
+}
+
 // After a fill: the Gram entries between the columns just cached and every cached column, written into the small
 // slot-indexed matrix GS (both triangles) that the row-dealt solve gathers from -- a few hundred KB that stay in L2,
 // instead of k^2 reads scattered over the p x C cache.
-__global__ void __launch_bounds__(256) k_cov_compact(const double *__restrict__ G, int p,
-                                                     const int *__restrict__ slot_of,
-                                                     const int *__restrict__ fcols, int g0, double *__restrict__ GS,
-                                                     int CS, const FitCtrl *__restrict__ ctrl, int big,
-                                                     const double *__restrict__ xtx, int *__restrict__ meta) {
-  KT(7);
+__device__ __forceinline__ void cov_compact_body(const double *__restrict__ G, int p,
+                                                 const int *__restrict__ slot_of,
+                                                 const int *__restrict__ fcols, int g0, double *__restrict__ GS,
+                                                 int CS, const FitCtrl *__restrict__ ctrl, int big,
+                                                 const double *__restrict__ xtx, int *__restrict__ meta) {
   if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int gl = blockIdx.y;
   if ((g0 + gl) * COV_R >= ctrl->cov_nfill) return;
@@ -6804,6 +6822,24 @@ __global__ void __launch_bounds__(256) k_cov_compact(const double *__restrict__ 
       GS[(size_t)t * CS + sc] = v;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) k_cov_compact(const double *__restrict__ G, int p,
+                                                     const int *__restrict__ slot_of,
+                                                     const int *__restrict__ fcols, int g0, double *__restrict__ GS,
+                                                     int CS, const FitCtrl *__restrict__ ctrl, int big,
+                                                     const double *__restrict__ xtx, int *__restrict__ meta) {
+  KT(7);
+  cov_compact_body(G, p, slot_of, fcols, g0, GS, CS, ctrl, big, xtx, meta);
+}
+
+__global__ void __launch_bounds__(256) k_cov_compact_sets(const CovRowSets rs, int p, const int *__restrict__ slot_of,
+                                                          const int *__restrict__ fcols, int g0, int CS,
+                                                          const FitCtrl *__restrict__ ctrl, int big,
+                                                          int *__restrict__ meta) {
+  KT(7);
+  const int r = blockIdx.z;
+  cov_compact_body(rs.G[r], p, slot_of, fcols, g0, rs.GS[r], CS, ctrl, big, rs.xtx[r], meta);
 }
 
 __global__ void __launch_bounds__(256) k_cov_bg_mask(const double *__restrict__ bd, const int *__restrict__ slot_of,
@@ -8200,6 +8236,20 @@ hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const 
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
   hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, part, g0, ngroups, nslab, njg, p,
                      fcols, slot_of, G, ctrl, 0, parked, bgm, ex_lo, ex_hi);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_reduce_compact_sets(const double *part, int p, const int *fcols, const int *slot_of, int *meta,
+                                          const CovRowSets &rs, int g0, int ngroups, int nslab, int CS,
+                                          const FitCtrl *ctrl, int parked, hipStream_t st) {
+  if (rs.nr < 1 || rs.nr > 9) return hipErrorInvalidValue;
+  const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
+  hipLaunchKernelGGL(k_cov_reduce_sets, dim3(njg * COV_NJ * 2, ngroups, rs.nr), dim3(256), 0, st, part, g0, ngroups,
+                     nslab, njg, p, fcols, slot_of, rs, ctrl, parked);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_cov_compact_sets, dim3((p + 255) / 256, ngroups, rs.nr), dim3(256), 0, st, rs, p, slot_of, fcols,
+                     g0, CS, ctrl, parked, meta);
   LAUNCH_CHECK();
   return hipSuccess;
 }
