@@ -256,10 +256,9 @@ class Session:
 
     def counters(self):
         """Diagnostics of the covariance form (bessx_session_counter)."""
-        names = ("chained_fits", "cg_fallbacks", "passes_over_X", "chained_queued", "background_fills",
-                 "solves_from_inverse", "inverse_rebuilds", "cv_side_by_side_rounds", "cv_union_fills", "tie_rescues",
-                 "cache_restarts")
-        return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in enumerate(names)}
+        names = {0: "chained_fits", 1: "cg_fallbacks", 2: "passes_over_X", 3: "chained_queued", 7: "cv_side_by_side_rounds",
+                 8: "cv_union_fills", 9: "tie_rescues", 10: "cache_restarts"}  # (4-6: mechanisms removed in round 3)
+        return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in names.items()}
 
     def screening(self):
         """screening_A: original column of every kept column."""

@@ -188,8 +188,7 @@ hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *
 bool sel_cgr_applies(int len, int m);
 hipError_t launch_sel_cgr(const double *score, int len, int k, int *A_new, const FitCtrl *ctrl, int slot,
                           const TopkNeed *need, double ridge, const double *rhs, double *sol, const CholFuse *fuse,
-                          int maxit, hipStream_t st, double tol, double *H = nullptr, int *hact = nullptr,
-                          int *hmeta = nullptr, double *hinfo = nullptr, const int *cmeta = nullptr);
+                          int maxit, hipStream_t st, double tol);
 hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                            const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);
@@ -324,20 +323,16 @@ hipError_t launch_cov_fill_union(const CovUnion &u, int restart, const int *extr
 int cov_streamed_tiles_per_wave();
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
-                            int parked, hipStream_t st, int variant = 3, const int *bgm = nullptr);
+                            int parked, hipStream_t st, int variant = 3);
 hipError_t cov_panel_prepare();
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
                              int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st,
-                             const int *bgm = nullptr, int ex_lo = 0, int ex_hi = 0);
+                             int ex_lo = 0, int ex_hi = 0);
 hipError_t launch_rows_permute(const double *X, long ld, int p, const int *perm, long ldp, double *Xp, hipStream_t st);
 hipError_t launch_cov_compact(const double *G, int p, const int *slot_of, const int *fcols, int g0, int ngroups,
                               double *GS, int CS, const FitCtrl *ctrl, int parked, hipStream_t st,
                               const double *xtx = nullptr, int *meta = nullptr);
 // background (speculative) fill on a second stream
-hipError_t launch_cov_bg_select(const double *bd, const int *slot_of, int p, double *bd2, hipStream_t st);
-hipError_t launch_cov_bg_list(const int *extras, const double *bd2, const int *slot_of, const int *meta, int C,
-                              int reserve, int *fcols, int *bgm, hipStream_t st);
-hipError_t launch_cov_bg_publish(const int *fcols, const int *bgm, int *slot_of, int *meta, hipStream_t st);
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
                         const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,
                         double lambda, const unsigned char *always, double *bd, const unsigned char *inA, double *bmm,

@@ -223,11 +223,6 @@ struct bessx_session {
     double *G = nullptr;
     int *slot_of = nullptr, *meta = nullptr;
     double *GS = nullptr;  // COV_CS x COV_CS: Gram entries between cached columns, indexed by cache slot (L2-sized)
-    // the maintained inverse of the last k x k system solved on this row set (hinv_body of the kernels): COV_CS x COV_CS
-    // slot-indexed, the slots it covers, {valid, cache generation}, {its ridge, the ridge of the last solve}
-    double *H = nullptr;
-    int *hact = nullptr, *hmeta = nullptr;
-    double *hinfo = nullptr;
     double *zero = nullptr;  // a few words that hold 0.0 (CholFuse::zero)
     bool shares_map = false;  // slot_of / meta are row set 0's (shared fills: every row set caches the same columns)
   };
@@ -239,9 +234,6 @@ struct bessx_session {
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
   int cov_spec = 32;       // most speculative columns per fill: 64 with the pair panel kernel (variant 4), else 32
   bool fuse_sel = true;    // selection + solve of a slot in one launch, k_sel_cgr (BESSX_FUSE_SEL=0: two launches)
-  bool hinv = false;       // ... with the solve taken from a maintained inverse (bordering updates, hinv_body) where
-                           // possible: BESSX_HINV=1.  Off by default: measured at parity with the conjugate-gradient solve
-                           // (31 vs 30 us per solve launch on configs[1])
   bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
   // GLM IRLS step in three launches instead of five: linear predictor, weights, working response and the slab Gram
   // in ONE pass over the active columns (k_irls_gram), the reduction, then the convergence test at the head of the
@@ -256,23 +248,6 @@ struct bessx_session {
   long long n_submodel_steps = 0;  // IRLS / Newton steps taken since the last reset (bessx_session_submodel_steps)
   bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (BESSX_DEFER_PUBLISH=0: in the tail)
   bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
-  // Background (speculative) fills on a second, low-priority stream: the PDAS chain keeps one CU busy, the panel
-  // kernel could have the rest of the GPU.  Measured on configs[1] it does not pay: the panel blocks delay the
-  // chain's small kernels by about what the avoided foreground fills would have cost, and a speculation made more
-  // than ~20 candidates ahead rarely hits.  Kept as an option (BESSX_COV_BG=1), off by default.
-  bool cov_bg = false;
-  hipStream_t st2 = nullptr;
-  hipEvent_t ev_main = nullptr, ev_bg = nullptr;
-  bool bg_inflight = false;
-  double *bd2_bg = nullptr, *part_bg = nullptr;
-  int *extras_bg = nullptr, *fcols_bg = nullptr, *bgm = nullptr, *cand_bg = nullptr;
-  int cov_count_seen = 0;      // row set 0: columns cached according to the last published result block
-  int cov_fg_pending = 0;      // ... plus what foreground fills queued since then can add at most
-  int bg_outstanding = 0;      // ... plus 32 per background fill not yet known to have finished
-  int cov_count_ub = 0;        // = the sum of the three: an upper bound of the cached columns at any time
-  int cov_target = 0;          // cached columns worth having for the path in progress (0 = no background fills)
-  int cov_spare = 96;          // background fills keep this many columns cached beyond the active set (BESSX_COV_SPARE)
-  long long cov_bg_fills = 0;
   bool cov_cg = true;          // solve by k_cg (falls back to k_chol per slot); BESSX_COV_SOLVER=chol switches it off
   long long cov_cg_fallbacks = 0;
   long long cov_tie_rescues = 0;  // slots redone with the exact tie rule (cov_stall = 3)
@@ -305,9 +280,9 @@ struct bessx_session {
   FoldPool *fold_pool = nullptr;            // host threads that queue the chains' launches (one per chain)
   double sbs_t[6] = {0, 0, 0, 0, 0, 0};     // BESSX_DEBUG: seconds in start / enqueue / wait / fill / continue / results
   bool cov_pair_auto = true;  // launches of two groups use the pair panel kernel (BESSX_PANEL_PAIR_AUTO=0: never)
-  int cov_variant = 3;        // panel kernel: 3 = LDS tile, loads two chunks ahead (2 blocks per CU); 2 = LDS tile,
-                              // one chunk ahead (3 blocks per CU); 1 = double-buffered tile (1 block per CU);
-                              // 0 = direct-to-register loads.  BESSX_PANEL_VARIANT overrides.
+  int cov_variant = 3;        // panel kernel: 3 = one 32-column group per block (k_cov_panel_lds2), two-group launches by the
+                              // pair kernel; 4 = the pair kernel whenever it applies, fills speculate up to 64 columns
+                              // (BESSX_PANEL_VARIANT=4; measured at parity on configs[1])
   double *cov_part = nullptr, *bd2 = nullptr;
   unsigned char *inA = nullptr;        // 1 for the columns of the current active set
   double *cov_bmm = nullptr;           // per-block min / max of k_cov_d's repeated-set shortcut (+ arg-max columns)
@@ -509,26 +484,12 @@ static void session_free(bessx_session *s) {
       F(c.meta);
     }
     F(c.GS);
-    F(c.H);
-    F(c.hact);
-    F(c.hmeta);
-    F(c.hinfo);
     F(c.zero);
   }
   F(s->cov_part);
   F(s->bd2);
   F(s->inA);
   F(s->cov_bmm);
-  if (s->st2) (void)hipStreamSynchronize(s->st2);
-  F(s->bd2_bg);
-  F(s->part_bg);
-  F(s->extras_bg);
-  F(s->fcols_bg);
-  F(s->bgm);
-  F(s->cand_bg);
-  if (s->ev_main) (void)hipEventDestroy(s->ev_main);
-  if (s->ev_bg) (void)hipEventDestroy(s->ev_bg);
-  if (s->st2) (void)hipStreamDestroy(s->st2);
   F(s->cov_fcols);
   F(s->cov_extras);
   F(s->Rt);
@@ -642,13 +603,6 @@ static int alloc_cov_cache(bessx_session *s, bool share_map = false) {
   if (e == hipSuccess) e = hipMemset(c.GS, 0, (size_t)COV_CS * COV_CS * sizeof(double));
   if (e == hipSuccess && !c.shares_map) e = hipMemset(c.slot_of, 0xff, (size_t)s->p * sizeof(int));
   if (e == hipSuccess && !c.shares_map) e = hipMemset(c.meta, 0, 8 * sizeof(int));
-  if (e == hipSuccess) e = dmalloc(&c.H, (size_t)COV_CS * COV_CS);
-  if (e == hipSuccess) e = dmalloc(&c.hact, (size_t)COV_CS);
-  if (e == hipSuccess) e = dmalloc(&c.hmeta, 4);
-  if (e == hipSuccess) e = dmalloc(&c.hinfo, 2);
-  if (e == hipSuccess) e = hipMemset(c.hact, 0, (size_t)COV_CS * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(c.hmeta, 0, 4 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(c.hinfo, 0xff, 2 * sizeof(double));  // NaN: no ridge seen yet
   if (e == hipSuccess) e = dmalloc(&c.zero, 8);
   if (e == hipSuccess) e = hipMemset(c.zero, 0, 8 * sizeof(double));
   if (e != hipSuccess) {
@@ -658,10 +612,6 @@ static int alloc_cov_cache(bessx_session *s, bool share_map = false) {
       (void)hipFree(c.meta);
     }
     (void)hipFree(c.GS);
-    (void)hipFree(c.H);
-    (void)hipFree(c.hact);
-    (void)hipFree(c.hmeta);
-    (void)hipFree(c.hinfo);
     (void)hipFree(c.zero);
     return fail(BESSX_ERR_HIP, std::string("Gram column cache: ") + hipGetErrorString(e));
   }
@@ -677,11 +627,6 @@ static int reset_path_caches(bessx_session *s) {
   }
   s->pend_on = false;  // a deferred publication of a fit nobody will ask for
   s->hint.on = false;
-  if (s->st2) {
-    HIPX(hipStreamSynchronize(s->st2));
-    s->bg_inflight = false;
-  }
-  s->cov_count_ub = s->cov_count_seen = s->cov_fg_pending = s->bg_outstanding = 0;
   for (auto &c : s->cache) c.valid = false;
   s->dev_state_rs = -1;
   for (bessx_session *c : s->fold_ctx) {
@@ -693,10 +638,6 @@ static int reset_path_caches(bessx_session *s) {
   for (auto &c : s->cov) {
     HIPX(hipMemsetAsync(c.slot_of, 0xff, (size_t)s->p * sizeof(int), s->st));
     HIPX(hipMemsetAsync(c.meta, 0, 8 * sizeof(int), s->st));
-    // the maintained inverse belongs to the old slot numbering; a path starts without one (and without a ridge seen)
-    HIPX(hipMemsetAsync(c.hmeta, 0, 4 * sizeof(int), s->st));
-    HIPX(hipMemsetAsync(c.hact, 0, (size_t)COV_CS * sizeof(int), s->st));
-    HIPX(hipMemsetAsync(c.hinfo, 0xff, 2 * sizeof(double), s->st));
   }
   return 0;
 }
@@ -950,7 +891,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, c
         bessx_session::CovCache &cr = s->cov[r];
         const int lo = r == 0 ? 0 : (r - 1) * s->cvp_nsl, hi = r == 0 ? 0 : r * s->cvp_nsl;  // fold r-1's own rows out
         e = launch_cov_reduce(s->cvp_part, s->p, s->cov_fcols, cr.slot_of, cr.G, g0, ng, nsl_all, gc, parked, s->st,
-                              nullptr, lo, hi);
+                              lo, hi);
         if (e == hipSuccess)
           e = launch_cov_compact(cr.G, s->p, cr.slot_of, s->cov_fcols, g0, ng, cr.GS, s->cov_cs, gc, parked, s->st,
                                  s->xtx[r], cr.meta);
@@ -967,7 +908,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, c
     if (e == hipSuccess)
       e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, gc, parked,
                             s->st);
-    if (e == hipSuccess && !s->cov_bg)  // entries between cached columns, by slot: what the solve gathers from
+    if (e == hipSuccess)  // entries between cached columns, by slot: what the solve gathers from
       e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, gc, parked, s->st, s->xtx[rs],
                              cv.meta);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
@@ -979,48 +920,6 @@ static bool cov_speculates(const bessx_session *s);
 // the capacity the device-side lookup (cov_need_body: "count + len + 32 > C -> start the cache over") is told: a fill
 // can add up to cov_spec speculative columns beyond the requested ones
 static int cov_C_dev(const bessx_session *s) { return s->cov_C - (s->cov_spec - COV_R); }
-
-// Background fill for row set 0: the 32 best-scoring uncached columns (scores as they are when the kernels run),
-// their Gram columns, and only then their publication in slot_of.  after_main: wait for everything queued on the
-// main stream so far (a foreground fill allocates slots too; the two never overlap).
-static int cov_bg_enqueue(bessx_session *s, int T0, bool after_main) {
-  if (!s->cov_bg || !s->cov_mode || s->cov_target <= 0 || !cov_speculates(s)) return 0;
-  const int reserve = s->cov_target + 2 * COV_R;  // never fill the cache so far that the foreground would restart it
-  if (s->cov_count_ub + COV_R + reserve > s->cov_C || s->cov_count_ub >= s->cov_target + s->cov_spare) return 0;
-  bessx_session::CovCache &cv = s->cov[0];
-  if (s->bg_inflight) HIPX(hipStreamWaitEvent(s->st2, s->ev_bg, 0));  // (same stream: already ordered; harmless)
-  if (after_main) {
-    HIPX(hipEventRecord(s->ev_main, s->st));
-    HIPX(hipStreamWaitEvent(s->st2, s->ev_main, 0));
-  }
-  hipError_t e = launch_cov_bg_select(s->bd, cv.slot_of, s->p, s->bd2_bg, s->st2);
-  if (e == hipSuccess) e = launch_topk(s->bd2_bg, s->p, COV_R, s->extras_bg, s->cand_bg, nullptr, 0, s->st2);
-  if (e == hipSuccess)
-    e = launch_cov_bg_list(s->extras_bg, s->bd2_bg, cv.slot_of, cv.meta, s->cov_C, reserve, s->fcols_bg, s->bgm, s->st2);
-  if (e == hipSuccess)
-    e = launch_cov_panel(s->X, s->aux, s->ld, s->p, s->mask[0], s->fcols_bg, 0, 1, s->cov_rps, s->cov_nslab, s->part_bg,
-                         s->ctrl, 2, s->st2, s->cov_variant, s->bgm);
-  if (e == hipSuccess)
-    e = launch_cov_reduce(s->part_bg, s->p, s->fcols_bg, cv.slot_of, cv.G, 0, 1, s->cov_nslab, s->ctrl, 2, s->st2, s->bgm);
-  if (e == hipSuccess) e = launch_cov_bg_publish(s->fcols_bg, s->bgm, cv.slot_of, cv.meta, s->st2);
-  if (e == hipSuccess) e = hipEventRecord(s->ev_bg, s->st2);
-  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_bg_enqueue: ") + hipGetErrorString(e));
-  s->bg_inflight = true;
-  s->bg_outstanding++;
-  s->cov_count_ub += COV_R;
-  s->cov_bg_fills++;
-  s->cov_panel_groups++;
-  return 0;
-}
-
-// the main stream is about to allocate cache slots (foreground fill): let a background fill in flight finish first
-static int cov_bg_fence_main(bessx_session *s) {
-  if (s->bg_inflight) {
-    HIPX(hipStreamWaitEvent(s->st, s->ev_bg, 0));
-    s->bg_inflight = false;
-  }
-  return 0;
-}
 
 // Fusions of the small kernels around a slot (BESSX_FUSE=0 turns them off):
 //  * pub: the slot closes a batch -- its solve kernel publishes the result block itself (*pub_fused = true) instead
@@ -1042,7 +941,7 @@ static CholFuse cov_fuse_args(bessx_session *s, int rs, int T0, bool force_chol,
   bessx_session::CovCache &cv = s->cov[rs];
   CholFuse fz = {cv.G,          cv.slot_of, s->p,         T0,           s->ctrl,        s->A_cur, s->b_cur,
                  s->beta_dense, s->hist,    s->hist_beta, s->hist_coef0, s->hist_stride, s->inA,   s->yy_h[rs],
-                 s->part_rs[rs], s->cov_bg ? nullptr : cv.GS, s->cov_cs,
+                 s->part_rs[rs], cv.GS, s->cov_cs,
                  cv.zero, PubArgs{}, s->fb_work, cv.meta + 4};
   // the last kernel of the batch publishes: only when nothing follows the solve in this slot (all rows, k_cg)
   if (sf && sf->pub && s->fuse && s->cov_cg && !force_chol && rs == 0) {
@@ -1149,9 +1048,8 @@ static int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda
     if (s->fuse_sel && s->fuse && s->cov_cg && s->cg_by_rows && sel_cgr_applies(s->p, T0)) {  // (k_sel_cgr solves by rows)
       // selection and solve of this slot in ONE launch (k_sel_cgr): same phases, same control-block protocol
       CholFuse fz = cov_fuse_args(s, rs, T0, false, sf);
-      const bool hv = s->hinv && fz.GS != nullptr;
       e = launch_sel_cgr(s->bd, s->p, T0, s->A_new, s->ctrl, slot, &nd, lambda, s->xty[rs], s->sol, &fz, 64, s->st,
-                         s->cg_tol, hv ? cv.H : nullptr, cv.hact, cv.hmeta, cv.hinfo, cv.meta);
+                         s->cg_tol);
       if (e == hipSuccess && rs != 0)  // CV row sets: sums of squares over the test rows for the final coefficients
         e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
                             s->sse, s->st, 1);
@@ -1197,13 +1095,6 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
     return 0;
   }
   const bool spec = cov_speculates(s);
-  if (rs == 0) {
-    if (int rc = cov_bg_fence_main(s)) return rc;
-    const int sm = s->cov_spec;  // most speculative columns per fill (k_cov_fill_list: same rounding)
-    const int add = spec ? std::min(((nm + sm / 2 + sm - 1) / sm) * sm, nm + sm) : (nm + COV_R - 1) / COV_R * COV_R;
-    s->cov_fg_pending += add;
-    s->cov_count_ub += add;
-  }
   hipError_t e = hipSuccess;
   if (spec) e = launch_topk(s->bd2, s->p, s->cov_spec, s->cov_extras, s->cand, nullptr, 0, s->st);
   if (e == hipSuccess)
@@ -1217,11 +1108,6 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
   HIPX(launch_cov_resume(s->ctrl, s->st));
   if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
   *next_slot = stalled + 1;
-  // the chain goes on with single-workgroup kernels: use the idle CUs to form the next likely columns now
-  if (rs == 0) {
-    if (int rc = cov_bg_enqueue(s, T0, true)) return rc;
-    if (int rc = cov_bg_enqueue(s, T0, false)) return rc;
-  }
   return 0;
 }
 
@@ -1906,11 +1792,6 @@ static int algorithm_fit(bessx_session *s) {
   if (cov && !use_cache && k_init > 0) {
     // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones
     bessx_session::CovCache &cv = s->cov[rs];
-    if (rs == 0) {
-      if (int rc = cov_bg_fence_main(s)) return rc;
-      s->cov_fg_pending += k_init;
-      s->cov_count_ub += k_init;
-    }
     e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s), s->cov_fcols, s->ctrl, 0,
                         s->A_cur, s->st);
     if (e == hipSuccess)
@@ -1955,16 +1836,6 @@ static int algorithm_fit(bessx_session *s) {
     }
     have_results = false;
     hc = reinterpret_cast<const FitCtrl *>(s->res_h);
-    if (rs == 0 && s->publish) {
-      // the published block carries the cache's column count; foreground fills queued before it are included
-      if (s->bg_inflight && hipEventQuery(s->ev_bg) == hipSuccess) {
-        s->bg_inflight = false;
-        s->bg_outstanding = 0;
-      }
-      s->cov_count_seen = (int)s->pub_flag[8 * (s->res_h == s->res_buf[1] ? 1 : 0) + 1];
-      s->cov_fg_pending = 0;
-      s->cov_count_ub = s->cov_count_seen + COV_R * s->bg_outstanding;
-    }
     if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
     // the chained fit only starts if this one ended here with fresh score sums
     if (s->ahead.armed && !(hc->done && hc->d_fresh && !hc->info)) {
@@ -1974,10 +1845,6 @@ static int algorithm_fit(bessx_session *s) {
     if (hc->cov_stall) {
       if (int rc = cov_unpark(s, hc, T0, lambda, rs, &slot)) return rc;
       continue;
-    }
-    if (rs == 0 && s->cov_target > 0 && !s->bg_inflight && s->cov_count_ub - T0 < s->cov_spare) {
-      // few spare columns cached beyond the active set: form the next likely ones before they are missed
-      if (int rc = cov_bg_enqueue(s, T0, false)) return rc;
     }
     if (hc->done || slot > s->max_iter) break;
   }
@@ -3071,22 +2938,9 @@ static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const dou
   s->n_iters = 0;
   auto t0 = std::chrono::steady_clock::now();
   if (int rc0 = reset_path_caches(s)) return rc0;  // a path call starts cold, like a bessCpp call
-  // columns worth caching ahead of need: the largest sparsity level of this path (no CV: row set 0 only)
-  s->cov_target = 0;
-  if (s->cov_bg && s->cov_mode && !is_cv && s->warm_start) {
-    int tmax = gs ? s_max : 0;
-    for (int i = 0; i < ns && !gs; i++) tmax = std::max(tmax, seq[i]);
-    s->cov_target = std::min(s->p, std::max(tmax, 1) + 16);
-  }
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
                 : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res);
-  s->cov_target = 0;
-  if (s->st2) {  // background fills still in flight belong to this call
-    hipError_t eb = hipStreamSynchronize(s->st2);
-    s->bg_inflight = false;
-    if (rc == 0 && eb != hipSuccess) rc = fail(BESSX_ERR_HIP, std::string("background fill: ") + hipGetErrorString(eb));
-  }
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
   res->n_fits = s->n_fits;
@@ -3728,7 +3582,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       return bail(fail(BESSX_ERR_ARG, "covariance score mode exists for LM with singleton groups only"));
     if (eligible && mode != 1) {
       // capacity: every column if p is small, else a few active sets' worth, within 1 GiB per row set
-      if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::max(0, std::min(6, std::atoi(ev)));
+      if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::atoi(ev) == 4 ? 4 : 3;
       if (const char *ev = std::getenv("BESSX_PANEL_PAIR_AUTO")) s->cov_pair_auto = std::string(ev) != "0";
       // the pair kernel (variant 4) forms two 32-column groups per pass over X: fills then speculate up to 64 columns
       s->cov_spec = (s->cov_variant == 4 && p >= 4 * COV_R && topk_supported(p, 2 * COV_R)) ? 2 * COV_R : COV_R;
@@ -3741,12 +3595,11 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         s->cov_mode = true;
         s->cov_C = (int)C;
         const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
-        // row slabs: the staged panel kernel runs one 256-thread block per CU at a time (100 KB of LDS), so pick
-        // the slab count whose block count wastes the least of the last round of 256 blocks
+        // row slabs: two 256-thread blocks of the panel kernel share a CU (50 KB of LDS each), so pick the slab count
+        // whose block count wastes the least of the last round of 512 blocks
         long ns = 1, rps = ld;
         {
-          // blocks resident at a time: 256 CUs x (1 for the double-buffered tile, 3 for the single one)
-          const long conc = (s->cov_variant == 1 || s->cov_variant == 5) ? 256 : (s->cov_variant >= 3 ? 512 : 768);
+          const long conc = 512;  // blocks resident at a time
           double best = 1e300;
           const long ns_max = std::max<long>(1, std::min<long>(64, ld / 256));
           for (long t = 1; t <= ns_max; t++) {
@@ -3771,42 +3624,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         HIPT(dmalloc(&s->cov_extras, (size_t)2 * COV_R));
         TRY(alloc_cov_cache(s));
         HIPT(cov_panel_prepare());
-        if (const char *ev = std::getenv("BESSX_COV_BG")) s->cov_bg = std::atoi(ev) != 0;
-        if (const char *ev = std::getenv("BESSX_COV_SPARE")) s->cov_spare = std::max(0, std::atoi(ev));
-        if (s->cov_bg) {
-          const char *mk = std::getenv("BESSX_COV_BG_MASK");
-          int ncu = 0;
-          (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device);
-          if (!(mk && std::atoi(mk) == 0) && ncu >= 64 && ncu % 32 == 0) {
-            // The panel blocks of a background fill must never hold a compute unit the chain's small kernels are
-            // waiting for: the second stream is confined to a subset of the CUs that leaves 4 CUs of every XCD free
-            // under either numbering of the mask bits (bit i = XCD i % 8, CU i / 8, or XCD i / 32, CU i % 32).
-            std::vector<uint32_t> mask((size_t)ncu / 32, 0xffffffffu);
-            int w = 28;  // CUs per group of 32 the fills may use (BESSX_COV_BG_W): fewer = gentler on the chain
-            if (const char *ev = std::getenv("BESSX_COV_BG_W")) w = std::min(28, std::max(1, std::atoi(ev)));
-            for (int i = 0; i < ncu; i++)
-              if (i < 32 || i % 32 < 4 || i % 32 >= 4 + w) mask[i / 32] &= ~(1u << (i % 32));
-            HIPT(hipExtStreamCreateWithCUMask(&s->st2, (uint32_t)mask.size(), mask.data()));
-          } else {
-            // lowest priority: the chain's small kernels on the main stream must never queue behind panel blocks
-            int lo = 0, hi = 0;
-            HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPT(hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, lo));
-          }
-          HIPT(hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
-          HIPT(hipEventCreateWithFlags(&s->ev_bg, hipEventDisableTiming));
-          HIPT(dmalloc(&s->bd2_bg, (size_t)p));
-          HIPT(dmalloc(&s->part_bg, (size_t)ns * njg * cov_streamed_tiles_per_wave() * 2 * 256));
-          HIPT(dmalloc(&s->extras_bg, (size_t)COV_R));
-          HIPT(dmalloc(&s->fcols_bg, (size_t)2 * COV_R));
-          HIPT(dmalloc(&s->bgm, 4));
-          HIPT(hipMemset(s->bgm, 0, 4 * sizeof(int)));
-          HIPT(dmalloc(&s->cand_bg, 32768));
-        }
         if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
         if (const char *ev = std::getenv("BESSX_FUSE")) s->fuse = std::string(ev) != "0";
         if (const char *ev = std::getenv("BESSX_FUSE_SEL")) s->fuse_sel = std::string(ev) != "0";
-        if (const char *ev = std::getenv("BESSX_HINV")) s->hinv = std::string(ev) == "1";
         if (const char *ev = std::getenv("BESSX_DEFER_PUBLISH")) s->defer_pub = std::string(ev) != "0";
         if (!s->fuse) s->defer_pub = false;
         if (const char *ev = std::getenv("BESSX_CG_LAYOUT")) s->cg_by_rows = std::string(ev) != "tiles";
@@ -3915,10 +3735,6 @@ static void drop_folds(bessx_session *s) {
       (void)hipFree(s->cov[i].meta);
     }
     (void)hipFree(s->cov[i].GS);
-    (void)hipFree(s->cov[i].H);
-    (void)hipFree(s->cov[i].hact);
-    (void)hipFree(s->cov[i].hmeta);
-    (void)hipFree(s->cov[i].hinfo);
     (void)hipFree(s->cov[i].zero);
   }
   if (!s->cov.empty()) s->cov.resize(1);
@@ -3948,12 +3764,6 @@ static int fold_ctx_create(bessx_session *ps, int rs, bessx_session **out) {
   c->publish = false;  // results by an asynchronous copy of the block: the driver waits for all chains at once
   c->chain = false;
   c->defer_pub = false;
-  c->hinv = false;
-  c->cov_bg = false;
-  c->st2 = nullptr;
-  c->ev_main = c->ev_bg = nullptr;
-  c->bg_inflight = false;
-  c->cov_target = 0;
   c->cov_no_restart = true;
   c->hint = bessx_session::Hint();
   c->ahead = bessx_session::Ahead();
@@ -4068,7 +3878,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
   s->cv_init.assign(K, SparseVec());
   s->cv_fold = fold;
   // shared fills (see bessx_session::cv_shared): LM in the covariance form, no background fills
-  bool share = s->cov_mode && s->model_type == 1 && !s->cov_bg && !s->grouped;
+  bool share = s->cov_mode && s->model_type == 1 && !s->grouped;
   if (const char *ev = std::getenv("BESSX_CV_SHARED")) share = share && std::string(ev) != "0";
   // The shared fills need a fold-major second copy of X (every fold padded to whole row slabs).  Whether they are used
   // is settled HERE, before any cache is created as a sharer of row set 0's slot map: the copy must not be much larger
@@ -4315,16 +4125,9 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 1: return s->cov_cg_fallbacks;
     case 2: return s->cov_panel_groups;
     case 3: return s->chain_queued;
-    case 4: return s->cov_bg_fills;
+    case 4: return 0;  // (background fills: measured slower in round 2 and removed)
     case 5:
-    case 6: {  // maintained inverse, all-rows row set, since the last path started: solves taken from it / rebuilds
-      if (s->cov.empty() || s->cov[0].hmeta == nullptr) return 0;
-      int h[4] = {0, 0, 0, 0};
-      if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->st) != hipSuccess ||
-          hipMemcpy(h, s->cov[0].hmeta, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
-        return -1;
-      return h[which == 5 ? 2 : 3];
-    }
+    case 6: return 0;  // (solves from a maintained inverse: measured at parity in round 2 and removed)
     case 7: return s->cv_rounds;
     case 8: return s->cv_union_fills;
     case 9: return s->cov_tie_rescues;

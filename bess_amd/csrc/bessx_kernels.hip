@@ -2816,360 +2816,6 @@ __global__ void __launch_bounds__(512) k_cgr(int m, int nc, double ridge, const 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// K7 (d), the k x k solve of a covariance-form slot WITHOUT an iteration: the inverse H = (G_AA + ridge I)^{-1} of
-// the last solve on this row set is kept in memory (slot-indexed like GS, L2-resident) and carried from one active
-// set to the next by the bordering identities
-//   a column j enters:  u = H g,  s = G_jj + ridge - g.u,  H <- [[H + u u^T/s, -u/s], [-u^T/s, 1/s]]   (g = G_Aj)
-//   a column t leaves:  H <- H_{-t,-t} - h_t h_t^T / H_tt                                              (h_t = H_At)
-// -- one pass over k^2 numbers to read and one to update per change, no chain of dependent reductions (the
-// conjugate-gradient solve is ~10 products with 2 barriers each).  A warm-started path changes one column per
-// candidate.  The coefficients are then x = H q and are ACCEPTED ONLY on the recomputed residual
-// |q - (G + ridge I) x| <= tol |q| (one step of iterative refinement x += H r if needed), the same criterion the
-// conjugate-gradient kernel applies; anything else -- H not valid for this cache generation / ridge, more than
-// HV_LIM changes, a slot beyond the slot-indexed Gram, a non-positive Schur complement, the residual test -- returns
-// false and the caller runs cgr_body.  After such a conjugate-gradient solve H is rebuilt for the new set by
-// bordering it up column by column (hinv_rebuild), if the ridge is the one of the previous solve on this row set
-// (a lambda grid changes it at every fit: no point in rebuilding there).
-// Layout: H[a * CS + b], a, b = cache slots; hact[slot] = 1 for the slots H currently covers; hmeta[0] = valid,
-// hmeta[1] = cache generation (cmeta[3]) it belongs to; hinfo[0] = ridge of H, hinfo[1] = ridge of the last solve.
-// ------------------------------------------------------------------------------------------
-constexpr int HV_R = 256;   // most unknowns (cgr_body's limit is 208)
-constexpr int HV_CS = 512;  // slots the inverse can cover (= COV_CS of the host)
-constexpr int HV_LIM = 6;   // most single-column changes taken incrementally
-
-struct HvShared {
-  int sA[HV_R], sS[HV_R];     // columns and cache slots of the wanted set, in the order of A_new
-  int cur[HV_R];              // slots H covers right now
-  int ncur;
-  int lst[2][HV_R];           // leaving / entering slots (ascending)
-  int nl[2];
-  double g[HV_R], u[HV_R], x[HV_R], q[HV_R], r[HV_R];
-  double part[8][HV_R];       // partial sums of hv_matvec
-  double red[8][4];
-};
-
-__device__ __forceinline__ double hv_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// out[i] = sum_j M[idx[j] * CS + idx[i]] * v[j] for i < n (M symmetric: = sum_j M[idx[i]][idx[j]] v[j]).
-// Thread t owns output i = t % np and every `parts`-th term j (parts = 512 / np): for a fixed j neighbouring threads
-// read neighbouring slots of one row of M (coalesced), every thread's loads are independent of one another (many in
-// flight, no cross-lane reduction in the loop); the `parts` partial sums of an output meet in LDS in fixed order.
-// A wave-per-row form with a shuffle reduction per row was ~20 us per product at n = 100: one L2 round trip per row.
-__device__ __forceinline__ void hv_matvec(HvShared &sh, const double *M, int CS, const int *idx, int n,
-                                          const double *v, double *out) {
-  const int tid = threadIdx.x;
-  const int np = n <= 64 ? 64 : (n <= 128 ? 128 : 256), parts = 512 / np;
-  const int i = tid % np, part = tid / np;
-  double acc0 = 0.0, acc1 = 0.0;
-  if (i < n) {
-    const double *col = M + idx[i];
-    // 8 independent loads in flight per thread and round (two accumulators keep the order of summation fixed)
-    int j = part;
-    for (; j + 7 * parts < n; j += 8 * parts) {
-      double mv[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) mv[q] = col[(size_t)idx[j + q * parts] * CS];
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
-        acc0 = fma(mv[q], v[j + q * parts], acc0);
-        acc1 = fma(mv[q + 1], v[j + (q + 1) * parts], acc1);
-      }
-    }
-    double mv[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) mv[q] = j + q * parts < n ? col[(size_t)idx[j + q * parts] * CS] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; q += 2) {
-      acc0 = fma(mv[q], j + q * parts < n ? v[j + q * parts] : 0.0, acc0);
-      acc1 = fma(mv[q + 1], j + (q + 1) * parts < n ? v[j + (q + 1) * parts] : 0.0, acc1);
-    }
-  }
-  sh.part[part][i] = acc0 + acc1;
-  __syncthreads();
-  if (tid < n) {
-    double t = sh.part[0][tid];
-    for (int q = 1; q < parts; q++) t += sh.part[q][tid];
-    out[tid] = t;
-  }
-  __syncthreads();
-}
-
-// block-wide sums of up to 4 values, fixed order; every thread gets the results
-__device__ __forceinline__ void hv_block_sum(HvShared &sh, double (&v)[4]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const double t = hv_wave_sum(v[c]);
-    if (lane == 0) sh.red[wave][c] = t;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    double t = sh.red[0][c];
-#pragma unroll
-    for (int w = 1; w < 8; w++) t += sh.red[w][c];
-    v[c] = t;
-  }
-  __syncthreads();
-}
-
-// H <- bordered by slot j (sh.cur / sh.ncur = the slots covered so far).  Returns false (uniformly) if the Schur
-// complement is not safely positive.
-__device__ __forceinline__ bool hv_add(HvShared &sh, double *H, const double *GS, int CS, int j, double ridge) {
-  const int tid = threadIdx.x, n = sh.ncur;
-  const double gam = GS[(size_t)j * CS + j] + ridge;
-  for (int a = tid; a < n; a += 512) sh.g[a] = GS[(size_t)j * CS + sh.cur[a]];
-  __syncthreads();
-  hv_matvec(sh, H, CS, sh.cur, n, sh.g, sh.u);
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int a = tid; a < n; a += 512) acc[0] = fma(sh.g[a], sh.u[a], acc[0]);
-  hv_block_sum(sh, acc);
-  const double sc = gam - acc[0];
-  if (!(sc > 1e-10 * gam)) return false;
-  const double rs = 1.0 / sc;
-  // H += u u^T / s on the covered block: one element per thread and step, neighbouring threads along a row
-  for (int e0 = tid; e0 < n * n; e0 += 4 * 512) {
-    double *ptr[4];
-    double hv4[4], f[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {  // 4 independent read-modify-writes in flight
-      const int e = min(e0 + q * 512, n * n - 1), a = e / n, b = e - a * n;
-      ptr[q] = H + (size_t)sh.cur[a] * CS + sh.cur[b];
-      f[q] = sh.u[a] * rs * sh.u[b];
-      hv4[q] = *ptr[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (e0 + q * 512 < n * n) *ptr[q] = hv4[q] + f[q];
-  }
-  for (int a = tid; a < n; a += 512) {
-    const double ua = -sh.u[a] * rs;
-    H[(size_t)sh.cur[a] * CS + j] = ua;
-    H[(size_t)j * CS + sh.cur[a]] = ua;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    H[(size_t)j * CS + j] = rs;
-    sh.cur[n] = j;
-    sh.ncur = n + 1;
-  }
-  __syncthreads();
-  return true;
-}
-
-// H <- without slot t
-__device__ __forceinline__ bool hv_drop(HvShared &sh, double *H, int CS, int t) {
-  const int tid = threadIdx.x, n = sh.ncur;
-  const double piv = H[(size_t)t * CS + t];
-  if (!(piv > 0.0)) return false;
-  for (int a = tid; a < n; a += 512) sh.g[a] = H[(size_t)t * CS + sh.cur[a]];
-  __syncthreads();
-  const double rp = 1.0 / piv;
-  for (int e0 = tid; e0 < n * n; e0 += 4 * 512) {
-    double *ptr[4];
-    double hv4[4], f[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int e = min(e0 + q * 512, n * n - 1), a = e / n, b = e - a * n;
-      ptr[q] = H + (size_t)sh.cur[a] * CS + sh.cur[b];
-      f[q] = -sh.g[a] * rp * sh.g[b];
-      hv4[q] = *ptr[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (e0 + q * 512 < n * n) *ptr[q] = hv4[q] + f[q];  // (row / column t itself is dropped from the list below)
-  }
-  __syncthreads();
-  if (tid == 0) {  // remove t from the list (order of the others kept)
-    int w = 0;
-    for (int a = 0; a < n; a++)
-      if (sh.cur[a] != t) sh.cur[w++] = sh.cur[a];
-    sh.ncur = w;
-  }
-  __syncthreads();
-  return true;
-}
-
-struct HinvArgs {
-  double *H;
-  int *hact, *hmeta;
-  double *hinfo;
-  const int *cmeta;  // the column cache's meta block: [3] = generation (bumped when the cache starts over)
-};
-
-// sets sh.sA / sh.sS from A_new; false if a slot is outside the slot-indexed matrices
-__device__ __forceinline__ bool hv_load_set(HvShared &sh, const int *A_new, int m, const int *slot_of, int CS) {
-  int bad = 0;
-  for (int i = threadIdx.x; i < m; i += 512) {
-    const int a = A_new[i], sl = slot_of[a];
-    sh.sA[i] = a;
-    sh.sS[i] = sl;
-    bad |= (sl < 0 || sl >= CS) ? 1 : 0;
-  }
-  return !__syncthreads_or(bad);
-}
-
-// Rebuild H for the set in sh.sA / sh.sS (already loaded) by bordering it up one column at a time.
-__device__ __forceinline__ void hinv_rebuild(HvShared &sh, const HinvArgs &hv, const double *GS, int CS, int m,
-                                             double ridge) {
-  const int tid = threadIdx.x;
-  if (tid == 0) sh.ncur = 0;
-  __syncthreads();
-  bool ok = true;
-  for (int i = 0; i < m && ok; i++) ok = hv_add(sh, hv.H, GS, CS, sh.sS[i], ridge);
-  for (int t = tid; t < CS; t += 512) hv.hact[t] = 0;
-  __syncthreads();
-  if (ok)
-    for (int i = tid; i < m; i += 512) hv.hact[sh.sS[i]] = 1;
-  if (tid == 0) {
-    hv.hmeta[0] = ok ? 1 : 0;
-    hv.hmeta[1] = hv.cmeta[3];
-    hv.hmeta[3] += 1;  // statistics: rebuilds
-    hv.hinfo[0] = ridge;
-  }
-  __syncthreads();
-}
-
-// The solve of slot `slot` from the maintained inverse.  true: the slot has been dealt with (solved + committed, or
-// not this launch's business); false: the caller runs the conjugate-gradient body.
-__device__ __forceinline__ bool hinv_body(HvShared &sh, int m, double ridge, const double *rhs, const int *A_new,
-                                          double *sol, const FitCtrl *ctrl, int slot, const CholFuse &fz,
-                                          const HinvArgs &hv, const double tol, int *same_any_sh) {
-  if (ctrl->done || ctrl->l != slot - 1) return true;
-  if (ctrl->same_prev) return false;  // (cgr_body records the repeated set)
-  const int tid = threadIdx.x, CS = fz.CS;
-  if (fz.GS == nullptr || CS > HV_CS || m > HV_R - 1) return false;
-  const bool valid = hv.hmeta[0] == 1 && hv.hmeta[1] == hv.cmeta[3] && hv.hinfo[0] == ridge;  // uniform
-  if (!valid) return false;
-  PH_BEGIN();
-  if (!hv_load_set(sh, A_new, m, fz.slot_of, CS)) return false;
-  PH(8);
-  // what leaves and what enters, both in ascending slot order (thread t looks at slot t: CS <= 512 threads)
-  {
-    if (tid == 0) sh.nl[0] = sh.nl[1] = sh.ncur = 0;
-    __syncthreads();
-    const int old = tid < CS ? hv.hact[tid] : 0;  // (issued before the flags below are built)
-    sh.lst[0][tid & (HV_R - 1)] = 0;              // lst[0..1] double as the 512 "wanted" flags for a moment
-    sh.lst[1][tid & (HV_R - 1)] = 0;
-    __syncthreads();
-    for (int i = tid; i < m; i += 512) (&sh.lst[0][0])[sh.sS[i]] = 1;
-    __syncthreads();
-    const int nw = (&sh.lst[0][0])[tid];
-    __syncthreads();
-    const int kind = (old && !nw) ? 0 : ((nw && !old) ? 1 : -1);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {  // c = 0 leaving, 1 entering, 2 covered now: ordered compaction by ballots
-      const bool f = c == 2 ? old != 0 : kind == c;
-      const unsigned long long bal = __ballot(f);
-      if ((tid & 63) == 0) sh.red[tid >> 6][0] = (double)__popcll(bal);
-      __syncthreads();
-      int off = 0, tot = 0;
-      for (int w = 0; w < 8; w++) {
-        const int cw = (int)sh.red[w][0];
-        off += w < (tid >> 6) ? cw : 0;
-        tot += cw;
-      }
-      const int pos = off + (int)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
-      if (f && pos < HV_R) (c == 2 ? sh.cur : sh.lst[c])[pos] = tid;
-      if (tid == 0) (c == 2 ? sh.ncur : sh.nl[c]) = tot;
-      __syncthreads();
-    }
-  }
-  if (sh.nl[0] + sh.nl[1] > HV_LIM || sh.ncur > HV_R - 1) return false;
-  PH(9);
-  bool ok = true;
-  for (int c = 0; c < sh.nl[0] && ok; c++) ok = hv_drop(sh, hv.H, CS, sh.lst[0][c]);
-  for (int c = 0; c < sh.nl[1] && ok; c++) ok = hv_add(sh, hv.H, fz.GS, CS, sh.lst[1][c], ridge);
-  PH(10);
-  if (ok) {
-    // x = H q in the order of A_new, residual against the cached Gram entries, one refinement step if needed
-    for (int i = tid; i < m; i += 512) sh.q[i] = rhs[sh.sA[i]];
-    __syncthreads();
-    hv_matvec(sh, hv.H, CS, sh.sS, m, sh.q, sh.x);
-    double qq;
-    {
-      double a[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int i = tid; i < m; i += 512) a[0] = fma(sh.q[i], sh.q[i], a[0]);
-      hv_block_sum(sh, a);
-      qq = a[0];
-    }
-    PH(11);
-    for (int round = 0; round < 2; round++) {
-      hv_matvec(sh, fz.GS, CS, sh.sS, m, sh.x, sh.g);  // g = G x
-      double a[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int i = tid; i < m; i += 512) {
-        const double rv = sh.q[i] - (sh.g[i] + ridge * sh.x[i]);
-        sh.r[i] = rv;
-        a[0] = fma(rv, rv, a[0]);
-      }
-      hv_block_sum(sh, a);
-      ok = a[0] <= tol * tol * qq;  // (NaN fails)
-      if (ok || round == 1) break;
-#ifdef BESSX_KTRACE
-      if (tid == 0) atomicAdd(&g_phase[29], 1ull);  // refinement steps
-#endif
-      hv_matvec(sh, hv.H, CS, sh.sS, m, sh.r, sh.u);  // x += H r
-      for (int i = tid; i < m; i += 512) sh.x[i] += sh.u[i];
-      __syncthreads();
-    }
-  }
-  if (!ok) {  // H may be half-updated: drop it, the conjugate-gradient body takes over (and rebuilds it)
-    if (tid == 0) hv.hmeta[0] = 0;
-    __syncthreads();
-    return false;
-  }
-  PH(12);
-  // H now belongs to the new set
-  for (int t = tid; t < CS; t += 512) hv.hact[t] = 0;
-  __syncthreads();
-  for (int i = tid; i < m; i += 512) {
-    hv.hact[sh.sS[i]] = 1;
-    sol[i] = sh.x[i];
-  }
-  if (tid == 0) {
-    hv.hinfo[1] = ridge;
-    hv.hmeta[2] += 1;  // statistics: solves taken from the maintained inverse
-  }
-  {
-    // loss terms as in cgr_body: |y - X b|^2 = y.y - b.(q + rho) - ridge |b|^2, rho = the residual just recomputed
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    double gd = 0.0;
-    for (int i = tid; i < m; i += 512) {
-      const double x = sh.x[i], qr = sh.q[i] + sh.r[i];
-      a[0] = fma(x, qr, a[0]);
-      a[1] = fma(x, x, a[1]);
-      a[2] = fma(fabs(x), fabs(qr), a[2]);
-      gd = fmax(gd, fz.GS[(size_t)sh.sS[i] * CS + sh.sS[i]]);
-    }
-    hv_block_sum(sh, a);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) gd = fmax(gd, __shfl_xor(gd, o));
-    if ((tid & 63) == 0) sh.red[tid >> 6][0] = gd;
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 8; w++) gd = fmax(gd, sh.red[w][0]);
-      const double tr = fz.yy - a[0] - ridge * a[1];
-      fz.ctrl->sse_dot = a[0];
-      fz.ctrl->sse_nrm = a[1];
-      fz.ctrl->sse_valid = (tr > 1e-6 * fz.yy && 4e-16 * (a[2] + (ridge + gd) * a[1] + fz.yy) <= 1e-10 * tr) ? 1 : 0;
-    }
-  }
-  __syncthreads();
-  PH(13);
-  commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
-              fz.hist_coef0, fz.hist_stride, same_any_sh, fz.inA);
-  PH(14);
-#ifdef BESSX_KTRACE
-  if (tid == 0) atomicAdd(&g_phase[30], 1ull);
-#endif
-  return true;
-}
-
 // One PDAS iteration of the covariance form behind its GEMV in ONE launch: the selection (topk_body on 8 waves: the
 // chained-fit prologue, the arg-max / repeated-set shortcuts or the full search, the cache lookup) and then, in the
 // same workgroup, the gather + conjugate-gradient solve + commit of k_cgr.  The two phases talk through the control
@@ -3177,13 +2823,13 @@ __device__ __forceinline__ bool hinv_body(HvShared &sh, int m, double ridge, con
 // those of k_topk followed by k_cgr -- without the second launch, its fall-through when the selection has already
 // settled the slot, and the boundary between them (tools/ktrace.py: 581 + 581 launches per 200-candidate path).
 // blockIdx.x == 1 (only when nd.pub.on): the deferred publication of the parent fit, as in k_topk.
-// HV: the instance that carries the maintained-inverse solve (BESSX_HINV=1); the default instance has none of its
-// code, registers or shared memory.
-template <int EB, int RPT, int NCW, bool HV>
+// (Round 2 also built a solve from a maintained inverse carried between active sets by bordering updates: correct,
+// 31 us per solve against 30 -- DESIGN.md 3a -- and removed in round 3.)
+template <int EB, int RPT, int NCW>
 __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ score, int len, int k, int *out,
                                                  const FitCtrl *ctrl, int slot, const TopkNeed nd, int nc, double ridge,
                                                  const double *__restrict__ rhs, double *sol, const CholFuse fz,
-                                                 int maxit, const double tol, const HinvArgs hv) {
+                                                 int maxit, const double tol) {
   KT(14);
   if (nd.pub.on && blockIdx.x == 1) {
     publish_body(nd.pub);
@@ -3192,7 +2838,7 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
 #ifdef BESSX_KTRACE
   const unsigned long long kt0_ = wall_clock64();
 #endif
-  if constexpr (!HV) {
+  {
     // The commonest short launch -- the selection that only confirms the active set and ends the fit -- first and in
     // one piece: a launch lands on a compute unit whose instruction cache has none of this kernel, and the same steps
     // spread over the selection, the solve body and the tail were a string of instruction-fetch misses
@@ -3226,33 +2872,11 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
   const unsigned long long kt1_ = wall_clock64();
   unsigned long long kt2_ = kt1_;
 #endif
-  if constexpr (HV) {
-    __shared__ HvShared hsh;
-    __shared__ int hv_same_any;
-    bool handled = false;
-    if (hv.H != nullptr) handled = hinv_body(hsh, k, ridge, rhs, out, sol, ctrl, slot, fz, hv, tol, &hv_same_any);
-    if (!handled) {
-      const bool was_mine = hv.H != nullptr && !ctrl->done && ctrl->l == slot - 1 && !ctrl->same_prev;  // uniform
-      cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
-      __syncthreads();
-      if (was_mine && ctrl->l == slot) {
-        // the conjugate-gradient body solved and committed this slot: bring the inverse up to the new set if the ridge
-        // is the previous solve's (a path at fixed lambda: the next candidates then go through hinv_body)
-        const bool same_ridge = hv.hinfo[1] == ridge;
-        if (same_ridge && fz.GS != nullptr && fz.CS <= HV_CS && k <= HV_R - 1 &&
-            hv_load_set(hsh, out, k, fz.slot_of, fz.CS))
-          hinv_rebuild(hsh, hv, fz.GS, fz.CS, k, ridge);
-        __syncthreads();
-        if (threadIdx.x == 0) hv.hinfo[1] = ridge;
-      }
-    }
-  } else {
-    cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
+  cgr_body<RPT, NCW>(k, nc, ridge, rhs, out, sol, ctrl, slot, fz, maxit, tol);
 #ifdef BESSX_KTRACE
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    kt2_ = wall_clock64();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  kt2_ = wall_clock64();
 #endif
-  }
   if (fz.pub.on) {  // last kernel of a batch of slots: publish (or snapshot) the result block, whatever the body did
     __syncthreads();
     if (fz.pub.on == 2) {
@@ -3262,7 +2886,7 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
     }
   }
 #ifdef BESSX_KTRACE
-  if constexpr (!HV) {  // block 0's time in the selection, the solve body and the tail, by what the launch did
+  {  // block 0's time in the selection, the solve body and the tail, by what the launch did
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
       const unsigned long long kt3_ = wall_clock64();
@@ -6042,7 +5666,7 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
   if (tid == 0) {
     if (restart) {
       meta[0] = 0;  // (otherwise untouched: a background fill may be adding columns concurrently)
-      meta[3] += 1;  // cache generation: slot numbers start over (the maintained inverse of hinv_body is void)
+      meta[3] += 1;  // cache generation: slot numbers start over
       meta[4] = 0;   // no cached columns, no dependent pairs
     }
     ctrl->cov_nmiss = nm;  // (the request lives in the fit's own control block: row sets may share meta)
@@ -6190,193 +5814,32 @@ __global__ void __launch_bounds__(256) k_cov_fill_union(const CovUnion u, int re
   }
 }
 
-// One wave: COV_NJ streamed tiles x 2 right-hand-side tiles on one row slab.  big = 1: issued by the host for a
-// parked fit (no slot gate), covers groups g0 .. g0+ngroups-1.
-template <bool MASKED>
-__global__ void __launch_bounds__(256) k_cov_panel(const double *__restrict__ X, const double *__restrict__ aux,
-                                                   long ld, int p, const double *__restrict__ mask,
-                                                   const int *__restrict__ fcols, int g0, int ngroups,
-                                                   int rows_per_slab, int nslab, int njg,
-                                                   double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
-                                                   int slot, int big, const int *__restrict__ bgm) {
-  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
-  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
-  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long per_group = (long)nslab * njg;
-  const int gl = (int)(wid / per_group);
-  if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
-  const int rem = (int)(wid - (long)gl * per_group);
-  const int slab = rem / njg, jg = rem - slab * njg;
-  const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-  const double *pb[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ni++) pb[ni] = gram_col(X, aux, ld, fcols[(g0 + gl) * COV_R + ni * 16 + c]) + 4 * q;
-  const double *pa[COV_NJ];
-#pragma unroll
-  for (int t = 0; t < COV_NJ; t++) {
-    const int j = (jg * COV_NJ + t) * 16 + c;
-    pa[t] = gram_col(X, aux, ld, j < p ? j : -1) + 4 * q;
-  }
-  d4 acc[COV_NJ][2];
-#pragma unroll
-  for (int t = 0; t < COV_NJ; t++) {
-    acc[t][0] = d4{0.0, 0.0, 0.0, 0.0};
-    acc[t][1] = d4{0.0, 0.0, 0.0, 0.0};
-  }
-  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
-  for (long r = r_begin; r < r_end; r += 16) {
-    double b[2][4];
-#pragma unroll
-    for (int ni = 0; ni < 2; ni++) {
-      const d2 b0 = *reinterpret_cast<const d2 *>(pb[ni] + r), b1 = *reinterpret_cast<const d2 *>(pb[ni] + r + 2);
-      b[ni][0] = b0.x;
-      b[ni][1] = b0.y;
-      b[ni][2] = b1.x;
-      b[ni][3] = b1.y;
-    }
-    if (MASKED) {
-      const d2 m0 = *reinterpret_cast<const d2 *>(mask + r + 4 * q), m1 = *reinterpret_cast<const d2 *>(mask + r + 4 * q + 2);
-#pragma unroll
-      for (int ni = 0; ni < 2; ni++) {
-        b[ni][0] *= m0.x;
-        b[ni][1] *= m0.y;
-        b[ni][2] *= m1.x;
-        b[ni][3] *= m1.y;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < COV_NJ; t++) {
-      const d2 a0 = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pa[t] + r));
-      const d2 a1 = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pa[t] + r + 2));
-      const double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
-#pragma unroll
-      for (int ni = 0; ni < 2; ni++) {
-        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b[ni][0], acc[t][ni], 0, 0, 0);
-        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b[ni][1], acc[t][ni], 0, 0, 0);
-        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b[ni][2], acc[t][ni], 0, 0, 0);
-        acc[t][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b[ni][3], acc[t][ni], 0, 0, 0);
-      }
-    }
-  }
-  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
-  double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)jg * COV_NJ * 2) * 256;
-#pragma unroll
-  for (int t = 0; t < COV_NJ; t++)
-#pragma unroll
-    for (int ni = 0; ni < 2; ni++) *reinterpret_cast<d4 *>(out + (size_t)(t * 2 + ni) * 256 + lane * 4) = acc[t][ni];
-}
-
-// LDS-staged variant: one BLOCK (4 waves) = 64 streamed columns x 32 right-hand-side columns on one row slab.
+// The panel kernel: one BLOCK (4 waves) = 64 streamed columns x 32 right-hand-side columns on one row slab; big = 1:
+// issued by the host for a parked fit (no slot gate), covers groups g0 .. g0+ngroups-1.
 // Global loads are coalesced the way the streaming score pass does it -- a wave instruction reads 512 contiguous
-// bytes of each of two columns (64 rows) -- into registers, then to a double-buffered LDS tile [column][row]
-// (row stride padded to 66 doubles: conflict-free 16-byte reads in the MFMA operand layout).  Wave w multiplies
-// streamed tile w with both right-hand-side tiles.  Loads of chunk k+1 are in flight while chunk k is multiplied;
-// one barrier per chunk.
+// bytes of each of two columns (64 rows) -- into registers, then to an LDS tile [column][row] (row stride padded to
+// 66 doubles: conflict-free 16-byte reads in the MFMA operand layout).  Wave w multiplies streamed tile w with both
+// right-hand-side tiles.  (Round 2 measured this design against direct-to-register loads, a double-buffered tile, LDS-DMA
+// staging with 64- and 32-row chunks and a copy of X in the MFMA operand layout: DESIGN.md 3a; only the two kernels
+// that won are kept -- this one, and the pair kernel for launches of two groups.)
 constexpr int CP_RB = 64;            // rows per chunk
 #ifndef CP_PAD
 #define CP_PAD 2
 #endif
 constexpr int CP_LD = CP_RB + CP_PAD;  // padded row stride of a column in LDS (doubles)
 constexpr int CP_COLS = 64 + COV_R;  // columns staged per chunk
-template <bool MASKED, bool DB>
-__global__ void __launch_bounds__(256) k_cov_panel_lds(const double *__restrict__ X, const double *__restrict__ aux,
-                                                       long ld, int p, const double *__restrict__ mask,
-                                                       const int *__restrict__ fcols, int g0, int ngroups,
-                                                       int rows_per_slab, int nslab, int njg,
-                                                       double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
-                                                       int big, const int *__restrict__ bgm) {
-  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
-  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
-  const long per_group = (long)nslab * njg;
-  const int gl = (int)(blockIdx.x / per_group);
-  if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
-  const int rem = (int)(blockIdx.x - (long)gl * per_group);
-  const int slab = rem / njg, jg = rem - slab * njg;
-  extern __shared__ double smem[];  // [2][CP_COLS][CP_LD]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
-  // this thread's 12 loads per chunk: unit u = i*256 + tid -> column u/32 of the staged set, rows 2*(u%32)..+1
-  const int ru = tid & 31, cbase = tid >> 5;
-  const double *src[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
-    const int cc = i * 8 + cbase;
-    int col;
-    if (cc < 64) {
-      const int j = jg * 64 + cc;
-      col = j < p ? j : -1;
-    } else {
-      col = fcols[(g0 + gl) * COV_R + cc - 64];
-    }
-    src[i] = gram_col(X, aux, ld, col) + 2 * ru;
-  }
-  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
-  const int nchunk = (int)((r_end - r_begin + CP_RB - 1) / CP_RB);
-  d2 stage[12], mstage;
-  auto load_chunk = [&](long r) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) stage[i] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src[i] + r));
-#pragma unroll
-    for (int i = 8; i < 12; i++) stage[i] = *reinterpret_cast<const d2 *>(src[i] + r);
-    if (MASKED) mstage = *reinterpret_cast<const d2 *>(mask + r + 2 * ru);
-  };
-  auto store_chunk = [&](int buf) {
-    double *dst = smem + (size_t)buf * CP_COLS * CP_LD + 2 * ru;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-      d2 v = stage[i];
-      if (MASKED && i >= 8) v = v * mstage;
-      *reinterpret_cast<d2 *>(dst + (size_t)(i * 8 + cbase) * CP_LD) = v;
-    }
-  };
-  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-  load_chunk(r_begin);
-  store_chunk(0);
-  __syncthreads();
-  for (int k = 0; k < nchunk; k++) {
-    const bool more = k + 1 < nchunk;
-    if (more) load_chunk(r_begin + (long)(k + 1) * CP_RB);
-    const double *buf = smem + (DB ? (size_t)(k & 1) * CP_COLS * CP_LD : 0);
-    const double *pa = buf + (size_t)(wv * 16 + c) * CP_LD + 4 * q;
-    const double *pb0 = buf + (size_t)(64 + c) * CP_LD + 4 * q, *pb1 = buf + (size_t)(80 + c) * CP_LD + 4 * q;
-#pragma unroll
-    for (int s = 0; s < CP_RB / 16; s++) {
-      const d2 a0 = *reinterpret_cast<const d2 *>(pa + 16 * s), a1 = *reinterpret_cast<const d2 *>(pa + 16 * s + 2);
-      const d2 x0 = *reinterpret_cast<const d2 *>(pb0 + 16 * s), x1 = *reinterpret_cast<const d2 *>(pb0 + 16 * s + 2);
-      const d2 y0 = *reinterpret_cast<const d2 *>(pb1 + 16 * s), y1 = *reinterpret_cast<const d2 *>(pb1 + 16 * s + 2);
-      const double ax = a0.x, ay = a0.y, az = a1.x, aw = a1.y;
-      const double b0x = x0.x, b0y = x0.y, b0z = x1.x, b0w = x1.y;
-      const double b1x = y0.x, b1y = y0.y, b1z = y1.x, b1w = y1.y;
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b1x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b0y, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b1y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b0z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(az, b1z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b0w, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, b1w, acc1, 0, 0, 0);
-    }
-    if (!DB) __syncthreads();  // single buffer: everybody has finished reading before it is overwritten
-    if (more) store_chunk(DB ? ((k + 1) & 1) : 0);
-    __syncthreads();
-  }
-  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
-  double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
-  *reinterpret_cast<d4 *>(out + lane * 4) = acc0;
-  *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
-}
-
-// Same kernel with the loads running TWO chunks ahead (two register stages, one LDS tile): more bytes in flight
-// per CU at the same LDS footprint (3 blocks per CU).
+// The loads run TWO chunks ahead (two register stages, one LDS tile, two barriers per chunk): more bytes in flight per
+// CU at the LDS footprint of one tile (2-3 blocks per CU).
 template <bool MASKED>
 __global__ void __launch_bounds__(256) k_cov_panel_lds2(const double *__restrict__ X, const double *__restrict__ aux,
                                                         long ld, int p, const double *__restrict__ mask,
                                                         const int *__restrict__ fcols, int g0, int ngroups,
                                                         int rows_per_slab, int nslab, int njg,
                                                         double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
-                                                        int big, const int *__restrict__ bgm) {
+                                                        int big) {
   KT(5);
-  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
-  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
+  const int nfill = ctrl->cov_nfill;
   const long per_group = (long)nslab * njg;
   const int gl = (int)(blockIdx.x / per_group);
   if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
@@ -6594,11 +6057,10 @@ __global__ void __launch_bounds__(256) k_cov_panel_pair(const double *__restrict
                                                         long ld, int p, const double *__restrict__ mask,
                                                         const int *__restrict__ fcols, int g0, int rows_per_slab,
                                                         int nslab, int njg, double *__restrict__ part,
-                                                        const FitCtrl *__restrict__ ctrl, int big,
-                                                        const int *__restrict__ bgm) {
+                                                        const FitCtrl *__restrict__ ctrl, int big) {
   KT(5);
-  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
-  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
+  const int nfill = ctrl->cov_nfill;
   if (g0 * COV_R >= nfill) return;
   extern __shared__ double smem[];  // [CP2_COLS][CP_LD]
   if ((g0 + 1) * COV_R < nfill)     // uniform
@@ -6607,154 +6069,15 @@ __global__ void __launch_bounds__(256) k_cov_panel_pair(const double *__restrict
     cov_pair_body<MASKED, false>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
 }
 
-// ---- the 32-column panel kernel with LDS-DMA staging (BESSX_PANEL_VARIANT=5, unmasked row sets) ----------------
-// Instrumented builds of the register-staged kernels put 22 % of their time into the ds_write_b128
-// staging stores and 13 % into the two barriers per chunk, while the HBM loads themselves were fully hidden.  Here
-// the columns go global -> LDS directly (global_load_lds_dwordx4: no VGPR staging, no store pass): one wave
-// instruction moves 64 rows of 2 columns (1 KiB) into an UNPADDED tile [column][64 rows]; the 16-byte unit u of
-// column C lands at position u ^ g(C), g(C) = 2 (C & 7) | ((C >> 3) & 1), by permuting which unit each lane FETCHES
-// (the DMA destination is lane-linear), and the operand reads apply the same involution -- the sixteen lanes of every
-// ds_read_b128 group then hit sixteen different 16-byte bank slots.  Three LDS tiles (144 KB, one 4-wave block per
-// CU): chunk k is multiplied while chunks k + 1 and k + 2 are in flight, ONE barrier per chunk (the tile a DMA
-// overwrites was read two chunks ago), counted vmcnt waits, operand reads of the next row step issued ahead of the
-// MFMAs (one wave per SIMD: nothing else hides the LDS latency).
-constexpr int CG_COLS = 64 + COV_R;  // staged columns
-__device__ __forceinline__ int cg_swz(int C) { return ((C & 7) << 1) | ((C >> 3) & 1); }
-
-// RB = rows per chunk: 64 (three 48 KB tiles, one block per CU) or 32 (three 24 KB tiles, two blocks per CU; one DMA
-// instruction then moves 32 rows of 4 columns)
-template <int RB>
-__device__ __forceinline__ void cov_glds_body(const double *__restrict__ X, const double *__restrict__ aux, long ld,
-                                              int p, const int *__restrict__ fcols, int g0, int ngroups,
-                                              int rows_per_slab, int nslab, int njg, double *__restrict__ part,
-                                              const FitCtrl *__restrict__ ctrl, int big,
-                                              const int *__restrict__ bgm) {
-  constexpr int UPC = RB / 2;            // 16-byte units per column and chunk
-  constexpr int CPI = 64 / UPC;          // columns per DMA instruction
-  constexpr int IPW = CG_COLS / CPI / 4;  // DMA instructions per wave and chunk
-  constexpr int TILE = CG_COLS * RB;      // doubles per LDS tile
-  KT(5);
-  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
-  const int nfill = big == 2 ? bgm[0] : ctrl->cov_nfill;
-  const long per_group = (long)nslab * njg;
-  const int gl = (int)(blockIdx.x / per_group);
-  if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
-  const int rem = (int)(blockIdx.x - (long)gl * per_group);
-  const int slab = rem / njg, jg = rem - slab * njg;
-  extern __shared__ double smem[];  // [3][CG_COLS][RB]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
-  // DMA side: wave wv moves the column groups wv * IPW + i; lane: column CPI * group + lane / UPC, position lane % UPC
-  const double *src[IPW];
-#pragma unroll
-  for (int i = 0; i < IPW; i++) {
-    const int cc = CPI * (wv * IPW + i) + lane / UPC;
-    int col;
-    if (cc < 64)
-      col = min(jg * 64 + cc, p - 1);  // (a column beyond p re-reads the last one: its rows are never stored)
-    else
-      col = fcols[(g0 + gl) * COV_R + cc - 64];
-    const int u = (lane % UPC) ^ cg_swz(cc);  // the unit this lane fetches so that it LANDS at position lane % UPC
-    src[i] = gram_col(X, aux, ld, col) + 2 * u;
-  }
-  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
-  const int nchunk = (int)((r_end - r_begin + RB - 1) / RB);
-  auto dma_chunk = [&](int k) {
-    double *tile = smem + (size_t)(k % 3) * TILE + (size_t)(wv * IPW) * CPI * RB;
-    const long r = r_begin + (long)k * RB;
-#pragma unroll
-    for (int i = 0; i < IPW; i++)
-      __builtin_amdgcn_global_load_lds(src[i] + r, (__attribute__((address_space(3))) void *)(tile + (size_t)i * CPI * RB),
-                                       16, 0, 0);
-  };
-  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-  // operand reads: column C, rows 16 s + 4 q .. + 3 = units 8 s + 2 q, + 1, swizzled
-  const int ca = wv * 16 + c, cb0 = 64 + c, cb1 = 80 + c;
-  const int ga = cg_swz(ca), gb0 = cg_swz(cb0), gb1 = cg_swz(cb1);
-  struct Ops {
-    d2 a0, a1, x0, x1, y0, y1;
-  };
-  auto read_ops = [&](const double *tile, int s, Ops &o) {
-    const int u = 8 * s + 2 * q;
-    const double *pa = tile + (size_t)ca * RB, *pb0 = tile + (size_t)cb0 * RB, *pb1 = tile + (size_t)cb1 * RB;
-    o.a0 = *reinterpret_cast<const d2 *>(pa + 2 * (u ^ ga));
-    o.a1 = *reinterpret_cast<const d2 *>(pa + 2 * ((u + 1) ^ ga));
-    o.x0 = *reinterpret_cast<const d2 *>(pb0 + 2 * (u ^ gb0));
-    o.x1 = *reinterpret_cast<const d2 *>(pb0 + 2 * ((u + 1) ^ gb0));
-    o.y0 = *reinterpret_cast<const d2 *>(pb1 + 2 * (u ^ gb1));
-    o.y1 = *reinterpret_cast<const d2 *>(pb1 + 2 * ((u + 1) ^ gb1));
-  };
-  auto mfma_ops = [&](const Ops &o) {
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.x, o.x0.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.x, o.y0.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.y, o.x0.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0.y, o.y0.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.x, o.x1.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.x, o.y1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.y, o.x1.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1.y, o.y1.y, acc1, 0, 0, 0);
-  };
-  dma_chunk(0);
-  if (nchunk > 1) dma_chunk(1);
-  for (int k = 0; k < nchunk; k++) {
-    // this wave's part of chunk k has landed (the DMAs of chunk k + 1 may still be in flight) ...
-    if (k + 1 < nchunk) {
-      if (IPW == 12)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // ... and after the barrier everybody's has, and everybody is done reading the tile of chunk k - 1
-    __builtin_amdgcn_s_barrier();
-    if (k + 2 < nchunk) dma_chunk(k + 2);  // into the tile of chunk k - 1
-    const double *tile = smem + (size_t)(k % 3) * TILE;
-    Ops oa, ob;
-    read_ops(tile, 0, oa);
-#pragma unroll
-    for (int s = 0; s < RB / 16; s += 2) {
-      read_ops(tile, s + 1, ob);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ops(oa);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < RB / 16) read_ops(tile, s + 2, oa);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_ops(ob);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
-  double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
-  *reinterpret_cast<d4 *>(out + lane * 4) = acc0;
-  *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
-}
-
-// (two plain kernels around the body: a __global__ TEMPLATE that uses the LDS-DMA builtin is silently not instantiated
-// by the host pass of hipcc 7.2 -- the library then fails to load with an undefined stub)
-__global__ void __launch_bounds__(256) k_cov_panel_glds64(const double *__restrict__ X, const double *__restrict__ aux,
-                                                          long ld, int p, const int *__restrict__ fcols, int g0,
-                                                          int ngroups, int rows_per_slab, int nslab, int njg,
-                                                          double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
-                                                          int big, const int *__restrict__ bgm) {
-  cov_glds_body<64>(X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, big, bgm);
-}
-__global__ void __launch_bounds__(256) k_cov_panel_glds32(const double *__restrict__ X, const double *__restrict__ aux,
-                                                          long ld, int p, const int *__restrict__ fcols, int g0,
-                                                          int ngroups, int rows_per_slab, int nslab, int njg,
-                                                          double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
-                                                          int big, const int *__restrict__ bgm) {
-  cov_glds_body<32>(X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, big, bgm);
-}
-
 // G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
 __device__ __forceinline__ void cov_reduce_body(const double *__restrict__ part, int g0, int ngroups, int nslab,
                                                 int njg, int p, const int *__restrict__ fcols,
                                                 const int *__restrict__ slot_of, double *__restrict__ G,
                                                 const FitCtrl *__restrict__ ctrl, int big,
-                                                const int *__restrict__ bgm, int ex_lo, int ex_hi) {
-  if (big == 2 ? false : (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0))) return;
+                                                int ex_lo, int ex_hi) {
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int gl = blockIdx.y;
-  if (gl >= ngroups || (g0 + gl) * COV_R >= (big == 2 ? bgm[0] : ctrl->cov_nfill)) return;
+  if (gl >= ngroups || (g0 + gl) * COV_R >= ctrl->cov_nfill) return;
   const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
   const int tile = blockIdx.x, e = threadIdx.x;
   double s = 0.0;
@@ -6766,18 +6089,16 @@ __device__ __forceinline__ void cov_reduce_body(const double *__restrict__ part,
   const int j = jt * 16 + (lane >> 4) + 4 * reg;
   const int ci = (g0 + gl) * COV_R + ni * 16 + (lane & 15);
   const int col = fcols[ci];
-  // background fill: the columns are not visible in slot_of yet (k_cov_bg_publish does that last); their cache
-  // slots are bgm[1] + position in the list
-  if (j < p && col >= 0) G[(size_t)(big == 2 ? bgm[1] + ci : slot_of[col]) * p + j] = s;
+  if (j < p && col >= 0) G[(size_t)slot_of[col] * p + j] = s;
 }
 
 __global__ void __launch_bounds__(256) k_cov_reduce(const double *__restrict__ part, int g0, int ngroups, int nslab,
                                                     int njg, int p, const int *__restrict__ fcols,
                                                     const int *__restrict__ slot_of, double *__restrict__ G,
                                                     const FitCtrl *__restrict__ ctrl, int slot, int big,
-                                                    const int *__restrict__ bgm, int ex_lo, int ex_hi) {
+                                                    int ex_lo, int ex_hi) {
   KT(6);
-  cov_reduce_body(part, g0, ngroups, nslab, njg, p, fcols, slot_of, G, ctrl, big, bgm, ex_lo, ex_hi);
+  cov_reduce_body(part, g0, ngroups, nslab, njg, p, fcols, slot_of, G, ctrl, big, ex_lo, ex_hi);
 }
 
 // ... for every row set of a cross-validation at once (shared fills: blockIdx.z = row set; all of them cache the same
@@ -6788,7 +6109,7 @@ __global__ void __launch_bounds__(256) k_cov_reduce_sets(const double *__restric
                                                          const FitCtrl *__restrict__ ctrl, int big) {
   KT(6);
   const int r = blockIdx.z;
-  cov_reduce_body(part, g0, ngroups, nslab, njg, p, fcols, slot_of, rs.G[r], ctrl, big, nullptr, rs.ex_lo[r], rs.ex_hi[r]);
+  cov_reduce_body(part, g0, ngroups, nslab, njg, p, fcols, slot_of, rs.G[r], ctrl, big, rs.ex_lo[r], rs.ex_hi[r]);
 }
 
 // After a fill: the Gram entries between the columns just cached and every cached column, written into the small
@@ -6842,41 +6163,6 @@ __global__ void __launch_bounds__(256) k_cov_compact_sets(const CovRowSets rs, i
   cov_compact_body(rs.G[r], p, slot_of, fcols, g0, rs.GS[r], CS, ctrl, big, rs.xtx[r], meta);
 }
 
-__global__ void __launch_bounds__(256) k_cov_bg_mask(const double *__restrict__ bd, const int *__restrict__ slot_of,
-                                                     int p, double *__restrict__ bd2) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < p) bd2[j] = slot_of[j] >= 0 ? -1.0 : bd[j];  // (bd may be mid-update: the choice is only a guess)
-}
-
-__global__ void __launch_bounds__(64) k_cov_bg_list(const int *__restrict__ extras, const double *__restrict__ bd2,
-                                                    const int *__restrict__ slot_of, const int *__restrict__ meta,
-                                                    int C, int reserve, int *__restrict__ fcols,
-                                                    int *__restrict__ bgm) {
-  const int tid = threadIdx.x;
-  const int count = meta[0];
-  const bool valid = tid < COV_R && bd2[extras[tid]] >= 0.0 && slot_of[extras[tid]] < 0;
-  const unsigned long long bal = __ballot(valid);
-  const int rank = __popcll(bal & ((1ull << tid) - 1ull)), tot = (int)__popcll(bal);
-  const bool room = count + COV_R + reserve <= C;  // never so full that the foreground would restart the cache
-  if (tid < COV_R) fcols[tid] = -1;
-  __syncthreads();
-  if (room && valid) fcols[rank] = extras[tid];
-  if (tid == 0) {
-    bgm[0] = (room && tot > 0) ? COV_R : 0;
-    bgm[1] = count;
-    bgm[2] = room ? tot : 0;
-  }
-}
-
-__global__ void __launch_bounds__(64) k_cov_bg_publish(const int *__restrict__ fcols, const int *__restrict__ bgm,
-                                                       int *__restrict__ slot_of, int *__restrict__ meta) {
-  const int tid = threadIdx.x, tot = bgm[2], base = bgm[1];
-  if (bgm[0] == 0 || meta[0] != base) return;  // nothing filled, or the foreground allocated in between
-  if (tid < tot) slot_of[fcols[tid]] = base + tid;
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) meta[0] = base + tot;
-}
 
 // d_j = (X^T m y)_j - sum_i G[j, slot(A_i)] b_i ; 64 columns per block, the sum over i cut in 4 interleaved parts.
 // The sacrifice score of k_score (LM branch) is formed in the same kernel: bd_j = (phi b_j + d_j / phi)^2 with
@@ -7509,22 +6795,14 @@ hipError_t launch_cg(int m, int mt, double ridge, const double *rhs, const int *
 bool sel_cgr_applies(int len, int m) { return len <= 512 * 64 && m >= 1 && m <= 208; }
 hipError_t launch_sel_cgr(const double *score, int len, int k, int *A_new, const FitCtrl *ctrl, int slot,
                           const TopkNeed *need, double ridge, const double *rhs, double *sol, const CholFuse *fuse,
-                          int maxit, hipStream_t st, double tol, double *H, int *hact, int *hmeta, double *hinfo,
-                          const int *cmeta) {
-  const HinvArgs hv = {H, hact, hmeta, hinfo, cmeta};
+                          int maxit, hipStream_t st, double tol) {
   if (!sel_cgr_applies(len, k) || need == nullptr || fuse == nullptr) return hipErrorInvalidValue;
   const TopkNeed nd = *need;
   const CholFuse fz = *fuse;
   const int nblk = nd.pub.on ? 2 : 1, nc = (k + 7) / 8, per = (len + 511) / 512;
-#define SC_GO(EB, RP, NW_)                                                                                     \
-  do {                                                                                                         \
-    if (H != nullptr)                                                                                          \
-      hipLaunchKernelGGL((k_sel_cgr<EB, RP, NW_, true>), dim3(nblk), dim3(512), 0, st, score, len, k, A_new, ctrl, \
-                         slot, nd, nc, ridge, rhs, sol, fz, maxit, tol, hv);                                   \
-    else                                                                                                       \
-      hipLaunchKernelGGL((k_sel_cgr<EB, RP, NW_, false>), dim3(nblk), dim3(512), 0, st, score, len, k, A_new, ctrl, \
-                         slot, nd, nc, ridge, rhs, sol, fz, maxit, tol, hv);                                   \
-  } while (0)
+#define SC_GO(EB, RP, NW_)                                                                                      \
+  hipLaunchKernelGGL((k_sel_cgr<EB, RP, NW_>), dim3(nblk), dim3(512), 0, st, score, len, k, A_new, ctrl, slot, nd, nc, \
+                     ridge, rhs, sol, fz, maxit, tol)
 #define SC_BY_M(EB)          \
   do {                       \
     if (k <= 64)             \
@@ -8138,90 +7416,37 @@ int cov_streamed_tiles_per_wave() { return COV_NJ; }
 
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
-                            int parked, hipStream_t st, int variant, const int *bgm) {
+                            int parked, hipStream_t st, int variant) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
-  if (variant >= 1) {
-    // LDS-staged: one block per (group, slab, 64-column group); 1 = double-buffered LDS tile, 2 = single buffer
-    // (half the LDS: three blocks share a CU and hide each other's barriers)
-    const size_t lds = (size_t)(variant == 1 ? 2 : 1) * CP_COLS * CP_LD * sizeof(double);
-    const long nblk = (long)ngroups * nslab * njg;
-#define PANEL_GO(M, D)                                                                                              \
-  hipLaunchKernelGGL((k_cov_panel_lds<M, D>), dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0, \
-                     ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm)
-    if ((variant == 5 || variant == 6) && mask == nullptr) {
-      // LDS-DMA staging, three tiles: 5 = 64-row chunks, one block per CU; 6 = 32-row chunks, two blocks per CU
-      const long nb5 = (long)ngroups * nslab * njg;
-      if (variant == 5)
-        hipLaunchKernelGGL(k_cov_panel_glds64, dim3((unsigned)nb5), dim3(256), (size_t)3 * CG_COLS * 64 * sizeof(double),
-                           st, X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
-      else
-        hipLaunchKernelGGL(k_cov_panel_glds32, dim3((unsigned)nb5), dim3(256), (size_t)3 * CG_COLS * 32 * sizeof(double),
-                           st, X, aux, ld, p, fcols, g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
-      LAUNCH_CHECK();
-      return hipSuccess;
-    }
-    if (variant == 4 && ngroups <= 2) {
-      // one block per (slab, 64-column group) for BOTH groups of the launch: X streamed once
-      const size_t lds2 = (size_t)CP2_COLS * CP_LD * sizeof(double);
-      const long nb2 = (long)nslab * njg;
-      if (mask)
-        hipLaunchKernelGGL(k_cov_panel_pair<true>, dim3((unsigned)nb2), dim3(256), lds2, st, X, aux, ld, p, mask, fcols,
-                           g0, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
-      else
-        hipLaunchKernelGGL(k_cov_panel_pair<false>, dim3((unsigned)nb2), dim3(256), lds2, st, X, aux, ld, p, mask, fcols,
-                           g0, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
-      LAUNCH_CHECK();
-      return hipSuccess;
-    }
-    if (variant >= 3) {
-      if (mask)
-        hipLaunchKernelGGL(k_cov_panel_lds2<true>, dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0,
-                           ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
-      else
-        hipLaunchKernelGGL(k_cov_panel_lds2<false>, dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols,
-                           g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, parked, bgm);
-      LAUNCH_CHECK();
-      return hipSuccess;
-    }
-    if (mask && variant == 1)
-      PANEL_GO(true, true);
-    else if (mask)
-      PANEL_GO(true, false);
-    else if (variant == 1)
-      PANEL_GO(false, true);
+  if (variant == 4 && ngroups <= 2) {
+    // one block per (slab, 64-column group) for BOTH groups of the launch: X streamed once
+    const size_t lds2 = (size_t)CP2_COLS * CP_LD * sizeof(double);
+    const long nb2 = (long)nslab * njg;
+    if (mask)
+      hipLaunchKernelGGL(k_cov_panel_pair<true>, dim3((unsigned)nb2), dim3(256), lds2, st, X, aux, ld, p, mask, fcols,
+                         g0, rows_per_slab, nslab, njg, part, ctrl, parked);
     else
-      PANEL_GO(false, false);
-#undef PANEL_GO
+      hipLaunchKernelGGL(k_cov_panel_pair<false>, dim3((unsigned)nb2), dim3(256), lds2, st, X, aux, ld, p, mask, fcols,
+                         g0, rows_per_slab, nslab, njg, part, ctrl, parked);
     LAUNCH_CHECK();
     return hipSuccess;
   }
-  const long nwaves = (long)ngroups * nslab * njg;
-  const int nblk = (int)((nwaves + 3) / 4);
+  // one block per (group, slab, 64-column group)
+  const size_t lds = (size_t)CP_COLS * CP_LD * sizeof(double);
+  const long nblk = (long)ngroups * nslab * njg;
   if (mask)
-    hipLaunchKernelGGL(k_cov_panel<true>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
-                       rows_per_slab, nslab, njg, part, ctrl, 0, parked, bgm);
+    hipLaunchKernelGGL(k_cov_panel_lds2<true>, dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols, g0,
+                       ngroups, rows_per_slab, nslab, njg, part, ctrl, parked);
   else
-    hipLaunchKernelGGL(k_cov_panel<false>, dim3(nblk), dim3(256), 0, st, X, aux, ld, p, mask, fcols, g0, ngroups,
-                       rows_per_slab, nslab, njg, part, ctrl, 0, parked, bgm);
+    hipLaunchKernelGGL(k_cov_panel_lds2<false>, dim3((unsigned)nblk), dim3(256), lds, st, X, aux, ld, p, mask, fcols,
+                       g0, ngroups, rows_per_slab, nslab, njg, part, ctrl, parked);
   LAUNCH_CHECK();
   return hipSuccess;
 }
 
 // one-time opt-in to more than 64 KB of dynamic LDS for the staged panel kernel
 hipError_t cov_panel_prepare() {
-  const int lds = (int)((size_t)2 * CP_COLS * CP_LD * sizeof(double));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<true, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_lds<false, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_glds64),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * CG_COLS * 64 * sizeof(double)));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_glds32),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)3 * CG_COLS * 32 * sizeof(double)));
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
   const int lds2 = (int)((size_t)CP2_COLS * CP_LD * sizeof(double));
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_pair<true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
@@ -8231,11 +7456,11 @@ hipError_t cov_panel_prepare() {
 }
 
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,
-                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st, const int *bgm,
-                             int ex_lo, int ex_hi) {
+                             int ngroups, int nslab, const FitCtrl *ctrl, int parked, hipStream_t st, int ex_lo,
+                             int ex_hi) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
   hipLaunchKernelGGL(k_cov_reduce, dim3(njg * COV_NJ * 2, ngroups), dim3(256), 0, st, part, g0, ngroups, nslab, njg, p,
-                     fcols, slot_of, G, ctrl, 0, parked, bgm, ex_lo, ex_hi);
+                     fcols, slot_of, G, ctrl, 0, parked, ex_lo, ex_hi);
   LAUNCH_CHECK();
   return hipSuccess;
 }
@@ -8281,24 +7506,6 @@ hipError_t launch_cov_compact(const double *G, int p, const int *slot_of, const 
   return hipSuccess;
 }
 
-hipError_t launch_cov_bg_select(const double *bd, const int *slot_of, int p, double *bd2, hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_bg_mask, dim3((p + 255) / 256), dim3(256), 0, st, bd, slot_of, p, bd2);
-  LAUNCH_CHECK();
-  return hipSuccess;
-}
-
-hipError_t launch_cov_bg_list(const int *extras, const double *bd2, const int *slot_of, const int *meta, int C,
-                              int reserve, int *fcols, int *bgm, hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_bg_list, dim3(1), dim3(64), 0, st, extras, bd2, slot_of, meta, C, reserve, fcols, bgm);
-  LAUNCH_CHECK();
-  return hipSuccess;
-}
-
-hipError_t launch_cov_bg_publish(const int *fcols, const int *bgm, int *slot_of, int *meta, hipStream_t st) {
-  hipLaunchKernelGGL(k_cov_bg_publish, dim3(1), dim3(64), 0, st, fcols, bgm, slot_of, meta);
-  LAUNCH_CHECK();
-  return hipSuccess;
-}
 
 hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double *xty, const int *A_cur,
                         const double *b_cur, double *d_out, const double *beta_dense, const double *xtx, double n_t,

@@ -157,11 +157,10 @@ int bessx_session_get_screening_groups(const bessx_session *s, int *groups, int 
 int bessx_session_score_mode(const bessx_session *s);
 /* Diagnostics of the covariance form since the session was created: which = 0 fits that ran chained behind their
  * predecessor, 1 conjugate-gradient solves handed to the Cholesky kernel, 2 passes over X (32-column panel groups),
- * 3 chained fits queued, 4 background (speculative) fills issued; since the last path call started, on the all-rows
- * row set: 5 k x k solves taken from the maintained inverse, 6 rebuilds of that inverse; 7 rounds in which the fold
- * fits of cross-validation ran side by side (one fit context per fold), 8 fills that served several parked folds at
- * once, 9 PDAS iterations redone with the exact tie rule, 10 times the Gram column cache was started over since the last
- * path call started.  -1 for an unknown id. */
+ * 3 chained fits queued; 4-6 always 0 (background fills and the maintained inverse of round 2: measured, removed);
+ * 7 rounds in which the fold fits of cross-validation ran side by side (one fit context per fold), 8 fills that served
+ * several parked folds at once, 9 PDAS iterations redone with the exact tie rule, 10 times the Gram column cache was
+ * started over since the last path call started.  -1 for an unknown id. */
 long long bessx_session_counter(const bessx_session *s, int which);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)

@@ -108,14 +108,13 @@ def test_conjugate_gradients_hand_ill_conditioned_systems_to_cholesky(gpu, monke
     assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="collinear chol")
 
 
-@pytest.mark.parametrize("knob", ["BESSX_CHAIN=0", "BESSX_PUBLISH=0", "BESSX_COV_SOLVER=chol", "BESSX_COV_BG=1",
-                                  "BESSX_PANEL_VARIANT=0", "BESSX_PANEL_VARIANT=1", "BESSX_PANEL_VARIANT=2",
+@pytest.mark.parametrize("knob", ["BESSX_CHAIN=0", "BESSX_PUBLISH=0", "BESSX_COV_SOLVER=chol",
                                   "BESSX_CG_LAYOUT=tiles", "BESSX_FUSE=0", "BESSX_CG_TOL=1e-10", "BESSX_COV_CS=24",
-                                  "BESSX_DEFER_PUBLISH=0", "BESSX_FUSE_SEL=0", "BESSX_PANEL_PAIR_AUTO=0", "BESSX_HINV=1", "BESSX_PANEL_VARIANT=4", "BESSX_PANEL_VARIANT=5",
-                                  "BESSX_PANEL_VARIANT=6"])
+                                  "BESSX_DEFER_PUBLISH=0", "BESSX_FUSE_SEL=0", "BESSX_PANEL_PAIR_AUTO=0", "BESSX_PANEL_VARIANT=4",
+                                  "BESSX_CV_SIDE_BY_SIDE=0"])
 def test_runtime_knobs_do_not_change_results(gpu, monkeypatch, knob):
-    """Every optional mechanism of the covariance form can be switched off (or, for the background fills, on): the
-    candidates, their supports and their ICs stay the same."""
+    """Every optional mechanism of the covariance form can be switched off: the candidates, their supports and their ICs
+    stay the same."""
     X, y, _, _ = synth.make_lm(1500, 2500, 15)
     seq = np.arange(1, 41)
     with gpu.Session(X, y, score_mode=2) as s:
@@ -139,32 +138,6 @@ def test_score_mode_argument(gpu):
     with pytest.raises(gpu.BessxError) as e:
         gpu.Session(X, y, score_mode=7)
     assert e.value.code == 1
-
-
-def test_maintained_inverse_solve_walks_the_same_path(gpu, monkeypatch):
-    """BESSX_HINV=1: the k x k systems of a fixed-lambda path are solved from an inverse carried from one active set to
-    the next by bordering updates (accepted on the same residual test as the conjugate-gradient solve).  Every PDAS
-    iteration against the oracle, with ridge, with swaps (cold start) and across a cache restart; and it is really used."""
-    monkeypatch.setenv("BESSX_HINV", "1")
-    X, y, _, _ = synth.make_lm(2000, 900, 12, seed=21)
-    for kw in (dict(ic_type=3, sequence=np.arange(1, 61)),
-               dict(ic_type=3, sequence=np.arange(1, 31), lambda_seq=[0.05]),
-               dict(ic_type=3, sequence=[5, 9, 30, 31, 32, 20, 21])):
-        want = P.trace(X, y, **kw)
-        s = gpu.Session(X, y, score_mode=2)
-        s.trace_enable(True)
-        got = s.sequential_path(kw["sequence"], kw.get("lambda_seq", (0.0,)), 3, False)
-        used = s.counters()["solves_from_inverse"]
-        s.close()
-        assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="hinv %r" % (kw,))
-        assert used >= len(kw["sequence"]) // 2, used
-    monkeypatch.setenv("BESSX_COV_CAP", "128")  # the cache starts over several times: the inverse is dropped with it
-    want = P.trace(X, y, ic_type=3, sequence=np.arange(1, 61))
-    s = gpu.Session(X, y, score_mode=2)
-    s.trace_enable(True)
-    got = s.sequential_path(np.arange(1, 61), (0.0,), 3, False)
-    s.close()
-    assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="hinv, cache restarts")
 
 
 @pytest.mark.parametrize("n,p,K", [(1000, 300, 5), (777, 150, 4)])
