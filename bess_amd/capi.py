@@ -26,7 +26,7 @@ SYMBOLS = [
     "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_get_screening_groups", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
-    "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_reset_caches", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
+    "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_fit_width", "bessx_session_reset_caches", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench",
 ]
 
@@ -369,13 +369,22 @@ class Session:
 
     def fit(self, T0, lam=0.0, fold=-1, init_idx=(), init_val=(), init_coef0=0.0):
         ii, iv = _i32(init_idx), _f64(init_val)
-        sup, b = np.zeros(T0, dtype=np.int32), np.zeros(T0)
+        w = self.fit_width(T0)  # T0 columns, or the columns of the T0 widest groups (groups of size > 1)
+        sup, b = np.zeros(w, dtype=np.int32), np.zeros(w)
         c0, tr, te, it = _d(0), _d(0), _d(0), _i(0)
         _check(lib().bessx_session_fit(self._h, T0, lam, fold, _ip(ii), _dp(iv), ii.size, init_coef0, _ip(sup),
                                        _dp(b), ctypes.byref(c0), ctypes.byref(it), ctypes.byref(tr),
                                        ctypes.byref(te)))
-        return {"support": sup, "beta": b, "coef0": c0.value, "iters": it.value, "train_loss": tr.value,
+        keep = sup >= 0  # (with groups the selected columns may be fewer than the width)
+        return {"support": sup[keep], "beta": b[keep], "coef0": c0.value, "iters": it.value, "train_loss": tr.value,
                 "test_loss": te.value}
+
+    def fit_width(self, T0):
+        """Most columns a fit of sparsity level T0 returns (bessx_session_fit_width)."""
+        w = int(lib().bessx_session_fit_width(self._h, int(T0)))
+        if w < 0:
+            raise BessxError(1, "sparsity level outside [1, number of groups]")
+        return w
 
     def reset_caches(self):
         """Start cold, like a path call does (bessx_session_reset_caches)."""

@@ -4163,14 +4163,23 @@ int bessx_session_reset_caches(bessx_session *s) {
   return reset_path_caches(s);
 }
 
+int bessx_session_fit_width(const bessx_session *s, int T0) {
+  if (!s || T0 < 1 || T0 > s->N) return -1;
+  if (!s->grouped) return T0;
+  std::vector<int> sz(s->gsz_h);
+  std::partial_sort(sz.begin(), sz.begin() + T0, sz.end(), std::greater<int>());
+  long w = 0;
+  for (int i = 0; i < T0; i++) w += sz[i];
+  return (int)std::min<long>(w, s->p);
+}
+
 int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx, const double *init_val,
                       int init_len, double init_coef0, int *support, double *beta, double *coef0, int *iters,
                       double *train_loss, double *test_loss) {
   if (!s) return fail(BESSX_ERR_ARG, "null session");
   if (fold >= s->K) return fail(BESSX_ERR_ARG, "fold index out of range");
-  if (s->grouped)
-    return fail(BESSX_ERR_UNSUPPORTED, "bessx_session_fit: sessions with groups of size > 1 return up to T0 * group "
-                                       "size columns, which support[T0] / beta[T0] cannot hold; use the path calls");
+  const int width = bessx_session_fit_width(s, T0);
+  if (width < 0) return fail(BESSX_ERR_ARG, "sparsity level outside [1, number of groups]");
   HIPX(hipSetDevice(s->device));
   s->cur_rows = fold < 0 ? 0 : fold + 1;
   s->sparsity_level = T0;
@@ -4183,9 +4192,12 @@ int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const i
   }
   s->coef0_init = init_coef0;
   if (int rc = algorithm_fit(s)) return rc;
-  for (int i = 0; i < T0; i++) {
-    if (support) support[i] = s->beta.idx[i];
-    if (beta) beta[i] = s->beta.val[i];
+  // (groups of size > 1: T0 counts groups, the fit returns the columns of the selected groups -- at most `width`)
+  const int got = (int)s->beta.idx.size();
+  if (got > width) return fail(BESSX_ERR_NUMERIC, "internal error: more columns selected than bessx_session_fit_width allows");
+  for (int i = 0; i < width; i++) {
+    if (support) support[i] = i < got ? s->beta.idx[i] : -1;
+    if (beta) beta[i] = i < got ? s->beta.val[i] : 0.0;
   }
   if (coef0) *coef0 = s->coef0;
   if (iters) *iters = s->l;

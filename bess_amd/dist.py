@@ -110,8 +110,20 @@ class FoldShardedCV:
             session.reset_caches()  # a path starts cold, like a bessCpp call
 
     # -- one evaluation round: the units of this rank, then the all-gather of the records ------------------
+    def _width(self, T0):
+        """Columns a record reserves for a fit of sparsity level T0: T0, or -- sessions with groups of size > 1, where T0
+        counts groups -- the columns of the T0 widest groups (unused entries: support -1)."""
+        return int(self.s.fit_width(T0)) if hasattr(self.s, "fit_width") else int(T0)
+
+    @staticmethod
+    def _unpack(sup, beta):
+        sup = np.asarray(sup)
+        keep = sup >= 0
+        return sup[keep].astype(np.int32), np.asarray(beta)[keep].copy()
+
     def _round(self, T0, lam, want_full, want_folds, full_init, coef0_init):
-        reclen = self.HEAD + 2 * T0
+        W = self._width(T0)
+        reclen = self.HEAD + 2 * W
         mine = np.full((self.per_rank, reclen), np.nan)
         row = 0
         for u in self.units:
@@ -127,17 +139,19 @@ class FoldShardedCV:
                 if self.warm:
                     self.cv_init[u] = (r["support"].copy(), r["beta"].copy())
             mine[row, :self.HEAD] = (u, r["iters"], r["coef0"], r["train_loss"], r["test_loss"])
-            mine[row, self.HEAD:self.HEAD + T0] = r["support"]
-            mine[row, self.HEAD + T0:] = r["beta"]
+            k = len(r["support"])
+            mine[row, self.HEAD:self.HEAD + W] = -1
+            mine[row, self.HEAD + W:] = 0.0
+            mine[row, self.HEAD:self.HEAD + k] = r["support"]
+            mine[row, self.HEAD + W:self.HEAD + W + k] = r["beta"]
             row += 1
         recs = {}
         for block in self.comm.all_gather(mine, self.world):
             for rec in block:
                 if not np.isnan(rec[0]):
+                    sup, beta = self._unpack(rec[self.HEAD:self.HEAD + W], rec[self.HEAD + W:])
                     recs[int(rec[0])] = {"iters": int(rec[1]), "coef0": float(rec[2]), "train_loss": float(rec[3]),
-                                         "test_loss": float(rec[4]),
-                                         "support": rec[self.HEAD:self.HEAD + T0].astype(np.int32),
-                                         "beta": rec[self.HEAD + T0:].copy()}
+                                         "test_loss": float(rec[4]), "support": sup, "beta": beta}
         self.evaluations += 1
         self.n_fits += len(recs)
         self.n_pdas_iters += sum(r["iters"] for r in recs.values())
@@ -148,7 +162,7 @@ class FoldShardedCV:
     # ranks, so more than K + 1 ranks have work ((fold x s) pairs of the final sweep of gs_path) ----------
     def _round_cold(self, T0s, lam):
         pairs = [(i, u) for i in range(len(T0s)) for u in range(self.K + 1)]
-        tmax = max(T0s)
+        tmax = max(self._width(T0) for T0 in T0s)
         reclen = self.HEAD + 1 + 2 * tmax
         per_rank = -(-len(pairs) // self.world)
         mine = np.full((per_rank, reclen), np.nan)
@@ -160,8 +174,11 @@ class FoldShardedCV:
             T0 = T0s[i]
             r = self.s.fit(T0, lam, -1 if u == self.K else u, empty[0], empty[1], 0.0)
             mine[row, :self.HEAD + 1] = (u, r["iters"], r["coef0"], r["train_loss"], r["test_loss"], i)
-            mine[row, self.HEAD + 1:self.HEAD + 1 + T0] = r["support"]
-            mine[row, self.HEAD + 1 + tmax:self.HEAD + 1 + tmax + T0] = r["beta"]
+            k = len(r["support"])
+            mine[row, self.HEAD + 1:self.HEAD + 1 + tmax] = -1
+            mine[row, self.HEAD + 1 + tmax:] = 0.0
+            mine[row, self.HEAD + 1:self.HEAD + 1 + k] = r["support"]
+            mine[row, self.HEAD + 1 + tmax:self.HEAD + 1 + tmax + k] = r["beta"]
             row += 1
         out = [dict() for _ in T0s]
         for block in self.comm.all_gather(mine, self.world):
@@ -169,11 +186,9 @@ class FoldShardedCV:
                 if np.isnan(rec[0]):
                     continue
                 i = int(rec[self.HEAD])
-                T0 = T0s[i]
+                sup, beta = self._unpack(rec[self.HEAD + 1:self.HEAD + 1 + tmax], rec[self.HEAD + 1 + tmax:])
                 out[i][int(rec[0])] = {"iters": int(rec[1]), "coef0": float(rec[2]), "train_loss": float(rec[3]),
-                                       "test_loss": float(rec[4]),
-                                       "support": rec[self.HEAD + 1:self.HEAD + 1 + T0].astype(np.int32),
-                                       "beta": rec[self.HEAD + 1 + tmax:self.HEAD + 1 + tmax + T0].copy()}
+                                       "test_loss": float(rec[4]), "support": sup, "beta": beta}
         self.evaluations += 1
         self.n_fits += len(pairs)
         self.n_pdas_iters += sum(r["iters"] for recs in out for r in recs.values())

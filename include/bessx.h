@@ -232,7 +232,10 @@ int bessx_session_submodel_steps(bessx_session *s, int reset, long long *steps);
  * 3. One Algorithm::fit (src/Algorithm.h:113-171) on the resident data.
  *    fold = -1: all rows; else the training rows of that CV fold (update_train_mask +
  *    update_group_XTX, src/Metric.h:182-183).  init_* is the warm start (update_beta_init /
- *    update_coef0_init) as a sparse vector.  Outputs: support[T0] ascending, beta[T0], coef0,
+ *    update_coef0_init) as a sparse vector of COLUMNS.  Outputs: support[W] ascending, beta[W] with
+ *    W = bessx_session_fit_width(s, T0): T0 for singleton groups; with groups of size > 1 (T0 counts groups,
+ *    Algorithm::fit returns the columns of the selected groups) the widest T0 groups' column count -- entries beyond
+ *    the selected columns are -1 / 0.  coef0,
  *    iters (Algorithm::l), train_loss = the family's train_loss on ALL rows (src/Metric.h:145,266,
  *    426,565), test_loss = the family's CV test loss on the fold's test rows (0 when fold < 0).
  * ------------------------------------------------------------------------------------- */
@@ -240,6 +243,7 @@ int bessx_session_submodel_steps(bessx_session *s, int reset, long long *steps);
  * warm starts): the state a path call starts from (a bessCpp call starts from nothing).  A caller that builds its own
  * path out of bessx_session_fit (bess_amd/dist.py) calls this first, so that a repeated path does not reuse work. */
 int bessx_session_reset_caches(bessx_session *s);
+int bessx_session_fit_width(const bessx_session *s, int T0); /* -1: T0 outside [1, number of groups] */
 int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx,
                       const double *init_val, int init_len, double init_coef0, int *support, double *beta,
                       double *coef0, int *iters, double *train_loss, double *test_loss);

@@ -82,3 +82,41 @@ def test_cold_start_pairs_from_the_fit_primitive(gpu, path):
     assert np.array_equal(np.nonzero(out["beta"])[0], sup)
     np.testing.assert_allclose(out["beta"][sup], want["beta"][sup], rtol=1e-6)
     assert out["n_fits"] == len(want["fits"])
+
+
+@pytest.mark.parametrize("fam", ["lm", "logistic"])
+def test_grouped_cv_paths_from_the_fit_primitive(gpu, fam):
+    """Groups of size > 1: T0 counts groups and a fit returns the columns of the selected groups (ragged widths);
+    bessx_session_fit hands them over padded to bessx_session_fit_width, the records carry them between ranks, and
+    the fold-sharded paths reproduce the library's own grouped CV paths and the oracle's."""
+    n, p = 900, 120
+    g_index = np.concatenate([np.arange(0, 60, 3), np.arange(60, 100, 2), np.arange(100, 120, 5)]).astype(np.int32)
+    if fam == "lm":
+        X, y, _, _ = synth.make_lm(n, p, 9, seed=12)
+        skw = dict(algorithm_type=2)
+    else:
+        X, y, _, _ = synth.make_logistic(n, p, 6, seed=12)
+        skw = dict(algorithm_type=2, data_type=2, model_type=2)
+    fold = synth.make_cv_folds(n, 4, seed=5)
+    G = len(g_index)
+    with gpu.Session(X, y, g_index=g_index, **skw) as s:
+        assert s.fit_width(3) == 15 and s.fit_width(5) == 23 and s.fit_width(G) == p  # the widest groups: 4 of 5 columns
+        s.set_cv(4, fold)
+        ref = (s.gs_path(1, 12, ic_type=3, is_cv=True), s.sequential_path(np.arange(1, 9), ic_type=3, is_cv=True))
+        one = s.fit(4, 0.0, fold=1)
+        assert 4 <= len(one["support"]) <= s.fit_width(4) and np.all(np.diff(one["support"]) > 0)
+    with gpu.Session(X, y, g_index=g_index, **skw) as s:
+        s.set_cv(4, fold)
+        out = (bdist.FoldShardedCV(s, 4, data_type=skw.get("data_type", 1)).gs_path(1, 12),
+               bdist.FoldShardedCV(s, 4, data_type=skw.get("data_type", 1)).sequential_path(np.arange(1, 9)))
+    for o, r in zip(out, ref):
+        assert o["best_T0"] == r["best_T0"] and o["n_fits"] == r["n_fits"] and o["n_pdas_iters"] == r["n_pdas_iters"]
+        np.testing.assert_allclose(o["cand_ic"], r["cand_ic"], rtol=1e-9)
+        np.testing.assert_array_equal(np.nonzero(o["beta"])[0], np.nonzero(r["beta"])[0])
+        np.testing.assert_allclose(o["beta"], r["beta"], rtol=1e-8)
+        np.testing.assert_allclose([o["coef0"], o["train_loss"], o["ic"]], [r["coef0"], r["train_loss"], r["ic"]], rtol=1e-8)
+    want = P.trace(X, y, ic_type=3, is_cv=True, K=4, cv_fold_id=fold, path_type=2, s_min=1, s_max=12, g_index=g_index,
+                   **skw)
+    sup = np.nonzero(want["beta"])[0]
+    assert np.array_equal(np.nonzero(out[0]["beta"])[0], sup)
+    np.testing.assert_allclose(out[0]["beta"][sup], want["beta"][sup], rtol=1e-5)
