@@ -4690,6 +4690,42 @@ int bessx_op_xtv_bench(int n, int p, int variant, int repeats, double *gbps, dou
   return BESSX_OK;
 }
 
+int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms) {
+  if (int rc = need_device()) return rc;
+  if (n < 1 || p < 1 || repeats < 1 || !gbps) return fail(BESSX_ERR_ARG, "op_cox_score_bench: bad arguments");
+  Scratch sc;
+  const long ld = ((long)n + 1023) / 1024 * 1024;
+  const int nrb = (int)(ld / 1024);
+  double *dX, *vec, *out;
+  HIPX(sc.alloc(&dX, (size_t)ld * p));
+  HIPX(sc.alloc(&vec, (size_t)ld * 4));
+  HIPX(sc.alloc(&out, (size_t)5 * nrb * p + nrb));
+  HIPX(launch_fill(dX, ld * (long)p, 1.0, nullptr));
+  HIPX(launch_fill(vec, ld * 4, 0.5, nullptr));
+  hipEvent_t e0, e1;
+  HIPX(hipEventCreate(&e0));
+  HIPX(hipEventCreate(&e1));
+  if (variant != 0) return fail(BESSX_ERR_ARG, "op_cox_score_bench: only variant 0 (the kernel the solver runs) exists");
+  CoxBufs cb = {};
+  cb.one_pass = 1;
+  cb.TH = vec;
+  cb.CU = vec + ld;
+  cb.CV = vec + 2 * ld;
+  cb.C2 = vec + 3 * ld;
+  HIPX(launch_cox_score_pass(dX, ld, p, 8, nrb, cb, out, nullptr, nullptr, 0, nullptr));
+  HIPX(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < repeats; i++) HIPX(launch_cox_score_pass(dX, ld, p, 8, nrb, cb, out, nullptr, nullptr, 0, nullptr));
+  HIPX(hipEventRecord(e1, nullptr));
+  HIPX(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPX(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbps = 8.0 * (double)n * (double)p * repeats / ((double)ms * 1e-3) / 1e9;
+  if (avg_ms) *avg_ms = ms / repeats;
+  return BESSX_OK;
+}
+
 int bessx_op_stream_copy_gbps(long long bytes, int repeats, double *gbps) {
   if (int rc = need_device()) return rc;
   if (bytes < (1 << 20) || repeats < 1 || !gbps) return fail(BESSX_ERR_ARG, "op_stream_copy: bad arguments");
