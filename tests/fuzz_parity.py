@@ -70,7 +70,11 @@ def run(cases=100, seed=1, medium=False, verbose=True):
                       lambda_seq=sorted(rng.uniform(0, 0.1 if fam == "cox" else 0.2, int(rng.integers(2, 4)))))
         elif mode == "cv":
             K = int(rng.integers(2, 6))
-            kw.update(is_cv=True, K=K, cv_fold_id=synth.make_cv_folds(n, K, seed=seed), sequence=np.arange(1, max(3, kmax // 2)))
+            kw.update(is_cv=True, K=K, cv_fold_id=synth.make_cv_folds(n, K, seed=seed))
+            if rng.random() < 0.5:
+                kw["sequence"] = np.arange(1, max(3, kmax // 2))
+            else:
+                kw.update(path_type=2, s_min=1, s_max=max(3, kmax))
         elif mode == "grp" and p >= 12 and not (medium and fam == "cox"):  # (the oracle's Cox group branch is O(n^2))
             cuts = np.sort(rng.choice(np.arange(1, p), min(p - 1, int(rng.integers(3, max(4, p // 3)))), replace=False))
             gi = np.concatenate([[0], cuts]).astype(np.int32)
@@ -143,6 +147,16 @@ def run(cases=100, seed=1, medium=False, verbose=True):
                     np.testing.assert_allclose(got["ic"], want["ic"], rtol=1e-6)
             else:
                 assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="case %d" % c, ic_atol=1e-9 * n)
+            if not (mode == "powell" and fam != "lm"):
+                # the same call without the trace: the fast paths (fits chained on the device, fused selection + solve
+                # launches, the fold fits of a CV evaluation side by side) must walk the path the traced run walked
+                fast = run_gpu(capi, X, y, kw, trace=False)
+                assert fast["n_fits"] == got["n_fits"] and fast["n_pdas_iters"] == got["n_pdas_iters"], "untraced: fit counts"
+                assert np.array_equal(fast["cand_support"], got["cand_support"]), "untraced: supports"
+                assert np.array_equal(fast["cand_iters"], got["cand_iters"]), "untraced: iterations"
+                tol = 1e-4 if loose else 1e-8
+                np.testing.assert_allclose(fast["cand_ic"], got["cand_ic"], rtol=tol, atol=1e-9 * n)
+                np.testing.assert_allclose(fast["beta"], got["beta"], rtol=max(tol, 1e-7), atol=1e-12)
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("CASE %d FAILED: fam=%s n=%d p=%d seed=%d mode=%s kw=%r\n  %s" % (

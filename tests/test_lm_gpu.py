@@ -10,7 +10,7 @@ from helpers import assert_same_trace
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(capi, X, y, kw):
+def run_gpu(capi, X, y, kw, trace=True):
     s = capi.Session(X, y, weight=kw.get("weight"), data_type=kw.get("data_type", 1),
                      is_normal=kw.get("is_normal", True), model_type=kw.get("model_type", 1),
                      algorithm_type=kw.get("algorithm_type", 1),
@@ -18,7 +18,7 @@ def run_gpu(capi, X, y, kw):
                      always_select=kw.get("always_select", ()), g_index=kw.get("g_index"),
                      is_screening=kw.get("screening_size", 0) > 0, screening_size=kw.get("screening_size", 0),
                      score_mode=kw.get("score_mode", 0))
-    s.trace_enable(True)
+    s.trace_enable(bool(trace))  # (trace=False: the fast paths -- chained fits, fused launches, fold fits side by side)
     kept = s.screening()
     if kw.get("is_cv"):
         s.set_cv(kw["K"], kw["cv_fold_id"])
