@@ -82,7 +82,8 @@ using namespace bessx;
 
 // Host threads that queue the chains' launches: launches that alternate between streams cost the host ~10 us each
 // (measured: 35 launches per round, 12 ms per path of configs[3]); one thread per chain queues its 7 on its own stream
-// while the others do the same.  Workers spin for a job for a short while after the last one, then block.
+// while the others do the same.  Workers spin for a job for a few milliseconds after the last one, then block on a
+// condition variable (an idle session holds no core).
 struct FoldPool {
   std::vector<std::thread> th;
   std::mutex mu;
@@ -98,7 +99,9 @@ struct FoldPool {
     unsigned seen = 0;
     for (;;) {
       bool got = false;
-      for (int spin = 0; spin < 200000 && !got; spin++) {  // ~ a few hundred microseconds
+      // ~ 4 ms of spinning (a pause is ~ 40-50 cycles): longer than the longest gap inside a path -- a union fill of
+      // three groups is 2.5 ms; with 1 ms the workers slept through the fills and configs[3] took 32.9 instead of 29.4 ms
+      for (int spin = 0; spin < 200000 && !got; spin++) {
         got = ticket_hint.load(std::memory_order_acquire) != seen;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
