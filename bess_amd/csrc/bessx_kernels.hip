@@ -4244,23 +4244,52 @@ __global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(256) k_cox_score_1p(const double *__restrict__ part, int nrb, int p,
+// Folds the row blocks of k_cox_score1p's sums (carry in block order).  A block = 64 columns x 8 chunks of row blocks
+// (one wave per chunk; a thread walks ITS chunk of ITS column from the bottom); inside a chunk the carry is
+// car = off + lc with off = the total of the later chunks, so a chunk leaves A = sum [P2 + lc (2 P1 + lc P0)],
+// B = sum [2 P1 + 2 lc P0], C = sum P0 and its total T, and Q = sum over chunks (last to first) A + off (B + off C)
+// -- fixed order, same for every launch.  (One thread per column over all nrb blocks kept 79 of 256 CUs busy with a
+// 196-step loop: 81 us per PDAS iteration at p = 20 000; this form: ~10 us.)
+__global__ void __launch_bounds__(512) k_cox_score_1p(const double *__restrict__ part, int nrb, int p,
                                                       const double *__restrict__ beta_dense, double lambda,
                                                       const unsigned char *__restrict__ always,
                                                       double *__restrict__ bd, const FitCtrl *__restrict__ ctrl,
                                                       int slot) {
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
-  int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= p) return;
+  __shared__ double sh[8][6][64];
+  const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
   const size_t plane = (size_t)nrb * p;
-  double car = 0.0, q = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int rb = nrb - 1; rb >= 0; rb--) {
-    const size_t o = (size_t)rb * p + j;
-    const double p0 = part[5 * plane + rb];
-    q += part[2 * plane + o] + car * (2.0 * part[plane + o] + car * p0);
-    car += part[o];
-    s1 += part[3 * plane + o];
-    s2 += part[4 * plane + o];
+  const int per = (nrb + 7) / 8, lo = min(nrb, c * per), hi = min(nrb, lo + per);
+  double lc = 0.0, A = 0.0, B = 0.0, C = 0.0, s1 = 0.0, s2 = 0.0;
+  if (j < p) {
+    for (int rb = hi - 1; rb >= lo; rb--) {
+      const size_t o = (size_t)rb * p + j;
+      const double p0 = part[5 * plane + rb], t = part[o], p1 = part[plane + o], p2 = part[2 * plane + o];
+      A += p2 + lc * (2.0 * p1 + lc * p0);
+      B += 2.0 * (p1 + lc * p0);
+      C += p0;
+      lc += t;
+      s1 += part[3 * plane + o];
+      s2 += part[4 * plane + o];
+    }
+  }
+  sh[c][0][lane] = A;
+  sh[c][1][lane] = B;
+  sh[c][2][lane] = C;
+  sh[c][3][lane] = lc;
+  sh[c][4][lane] = s1;
+  sh[c][5][lane] = s2;
+  __syncthreads();
+  if (c != 0 || j >= p) return;
+  double off = 0.0, q = 0.0;
+  s1 = 0.0;
+  s2 = 0.0;
+  for (int w = 7; w >= 0; w--) {
+    q += sh[w][0][lane] + off * (sh[w][1][lane] + off * sh[w][2][lane]);
+    off += sh[w][3][lane];
+    s1 += sh[w][4][lane];
+    s2 += sh[w][5][lane];
   }
   s2 -= q;
   const double b = beta_dense[j];
@@ -7027,7 +7056,7 @@ hipError_t launch_cox_score(const double *part, const double *part2, int nrb, in
                             double lambda, const unsigned char *always, double *bd, const FitCtrl *ctrl, int slot,
                             hipStream_t st) {
   if (part2 == nullptr)  // one-pass layout (k_cox_score1p)
-    hipLaunchKernelGGL(k_cox_score_1p, dim3((p + 255) / 256), dim3(256), 0, st, part, nrb, p, beta_dense, lambda,
+    hipLaunchKernelGGL(k_cox_score_1p, dim3((p + 63) / 64), dim3(512), 0, st, part, nrb, p, beta_dense, lambda,
                        always, bd, ctrl, slot);
   else
     hipLaunchKernelGGL(k_cox_score, dim3((p + 255) / 256), dim3(256), 0, st, part, part2, nrb, p, beta_dense, lambda,
