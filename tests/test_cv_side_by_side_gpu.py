@@ -106,3 +106,18 @@ def test_ties_and_collinear_columns_inside_the_chains(gpu, monkeypatch):
     fold = synth.make_cv_folds(n, 4, seed=2)
     a, ca, cb = _both(gpu, monkeypatch, X, y, 4, fold, 20)
     assert ca["cg_fallbacks"] > 0
+
+
+def test_more_folds_than_contexts_fall_back_to_one_fit_at_a_time(gpu):
+    """K = 10 > 8: no fold contexts are created; the folds are fitted one after another on the session's own state."""
+    X, y, _, _ = synth.make_lm(1200, 200, 8, seed=9)
+    fold = synth.make_cv_folds(1200, 10, seed=2)
+    with gpu.Session(X, y, score_mode=2) as s:
+        s.set_cv(10, fold)
+        out = s.gs_path(1, 20, ic_type=3, is_cv=True)
+        assert s.counters()["cv_side_by_side_rounds"] == 0
+    want = P.trace(X, y, ic_type=3, is_cv=True, K=10, cv_fold_id=fold, path_type=2, s_min=1, s_max=20)
+    sup = np.nonzero(want["beta"])[0]
+    assert np.array_equal(np.nonzero(out["beta"])[0], sup) and out["n_fits"] == len(want["fits"])
+    np.testing.assert_allclose(out["beta"][sup], want["beta"][sup], rtol=1e-6)
+    np.testing.assert_allclose(out["ic"], want["ic"], rtol=1e-7)
