@@ -839,8 +839,7 @@ __global__ void __launch_bounds__(1024) k_topk(const double *__restrict__ score,
 // t-th exchange swaps positions L_t and R_t while L_t < R_t -- up to there neither scan has met a position written by
 // an earlier exchange, so both lists are read off the unmodified range -- and the partition returns where the left scan
 // stands once the scans have met: min(L_t, R_{t-1}) (the last exchange left a stop at R_{t-1}).  work = 3 len ints (index array, L list / selection flags, R list).  Runs only when the selection kernel
-// has raised flag[0]; clears it.  flag[1] = 1: depth limit of the introselect reached (its heap-select branch, which
-// only adversarial inputs take, is not restated) -- the lower-index selection of k_topk stays.
+// has raised flag[0]; clears it.  The heap-select branch of the introselect (depth limit reached) is done by one thread.
 __global__ void __launch_bounds__(1024) k_topk_ties(const double *__restrict__ score, int len, int k,
                                                     int *__restrict__ out, int *__restrict__ flag,
                                                     int *__restrict__ work, const FitCtrl *ctrl, int slot,
@@ -884,11 +883,51 @@ __global__ void __launch_bounds__(1024) k_topk_ties(const double *__restrict__ s
     const int first = sh_first, last = sh_last;
     if (last - first <= 3) break;
     if (depth == 0) {
+      // depth limit exhausted: std::__heap_select(first, nth + 1, last) and iter_swap(first, nth), move by move (one
+      // thread: rare, and the range is what 2 floor(log2 len) partitions have left)
       if (tid == 0) {
-        flag[1] = 1;
-        flag[0] = 0;
+        int *f = idx + first;
+        const long hl = (long)nth + 1 - first;
+        auto adjust = [&](long hole, int value) {  // std::__adjust_heap incl. __push_heap
+          const long top = hole;
+          long child = hole;
+          while (child < (hl - 1) / 2) {
+            child = 2 * (child + 1);
+            if (score[f[child]] > score[f[child - 1]]) child--;
+            f[hole] = f[child];
+            hole = child;
+          }
+          if ((hl & 1) == 0 && child == (hl - 2) / 2) {
+            child = 2 * (child + 1);
+            f[hole] = f[child - 1];
+            hole = child - 1;
+          }
+          long parent = (hole - 1) / 2;
+          while (hole > top && score[f[parent]] > score[value]) {
+            f[hole] = f[parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+          }
+          f[hole] = value;
+        };
+        if (hl >= 2)
+          for (long parent = (hl - 2) / 2;; parent--) {  // std::__make_heap
+            adjust(parent, f[parent]);
+            if (parent == 0) break;
+          }
+        for (int i = nth + 1; i < last; i++)
+          if (score[idx[i]] > score[f[0]]) {  // std::__pop_heap(first, middle, i)
+            const int value = idx[i];
+            idx[i] = f[0];
+            adjust(0, value);
+          }
+        const int t = idx[first];
+        idx[first] = idx[nth];
+        idx[nth] = t;
+        sh_first = sh_last = first;  // (nothing left for the insertion sort)
       }
-      return;
+      __syncthreads();
+      break;
     }
     depth--;
     if (tid == 0) {

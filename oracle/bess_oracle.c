@@ -213,7 +213,7 @@ static int int_cmp(const void *a, const void *b) {
  * returns the same set; with EQUAL scores at the boundary (duplicated columns, 0/1 designs) which of the tied indices
  * land in the first k positions is decided by exactly these moves, so they are restated step by step.  The reference's
  * toolchain is the pinned dependency here: the golden vectors and oracle/_ref are built with g++ 11.4 / libstdc++.
- * The heap-select branch (depth limit 2 floor(log2 len) exhausted: adversarial inputs only) is not restated: abort. */
+ * The heap-select branch (depth limit 2 floor(log2 len) exhausted) is restated too: small ranges reach it. */
 static const double *nth_vec;
 static int nth_comp(int i, int j) { return nth_vec[i] > nth_vec[j]; }
 static void nth_swap(int *a, int *b) {
@@ -259,6 +259,51 @@ static void nth_insertion_sort(int *first, int *last) {
     }
   }
 }
+/* std::__adjust_heap / __push_heap / __make_heap / __pop_heap / __heap_select of libstdc++ (bits/stl_heap.h,
+ * bits/stl_algo.h), on the index array with the same comparator: the branch introselect takes when its depth limit is
+ * exhausted (small ranges with unlucky pivots reach it: 2 floor(log2 len) partitions may shrink a range by one each). */
+static void nth_adjust_heap(int *first, long hole, long len, int value) {
+  const long top = hole;
+  long child = hole, parent;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (nth_comp(first[child], first[child - 1])) child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  parent = (hole - 1) / 2; /* __push_heap */
+  while (hole > top && nth_comp(first[parent], value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+static void nth_heap_select(int *first, int *middle, int *last) {
+  const long len = middle - first;
+  int *i;
+  if (len >= 2) { /* __make_heap */
+    long parent = (len - 2) / 2;
+    for (;;) {
+      nth_adjust_heap(first, parent, len, first[parent]);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  for (i = middle; i < last; ++i)
+    if (nth_comp(*i, *first)) { /* __pop_heap(first, middle, i) */
+      const int value = *i;
+      *i = *first;
+      nth_adjust_heap(first, 0, len, value);
+    }
+}
+static long nth_heap_selects = 0; /* how often the branch was taken (tests want to know that they reached it) */
+long bess_oracle_nth_heap_selects(void) { return nth_heap_selects; }
 static void nth_element_libstdcxx(int *first, int *nth, int *last) {
   long depth_limit;
   long len = last - first;
@@ -269,8 +314,10 @@ static void nth_element_libstdcxx(int *first, int *nth, int *last) {
   while (last - first > 3) {
     int *mid, *cut;
     if (depth_limit == 0) {
-      fprintf(stderr, "bess_oracle: nth_element reached its heap-select branch (not restated)\n");
-      abort();
+      nth_heap_selects++;
+      nth_heap_select(first, nth + 1, last);
+      nth_swap(first, nth); /* "place the nth largest element in its final position" */
+      return;
     }
     --depth_limit;
     mid = first + (last - first) / 2;
@@ -282,13 +329,29 @@ static void nth_element_libstdcxx(int *first, int *nth, int *last) {
   nth_insertion_sort(first, last);
 }
 
+/* test hook: the score vector (and k) of the last max_k call that took the heap-select branch */
+static double nth_last_hs_scores[4096];
+static int nth_last_hs_len = 0, nth_last_hs_k = 0;
+int bess_oracle_last_heap_select(double *scores, int cap, int *k) {
+  int i;
+  for (i = 0; i < nth_last_hs_len && i < cap; i++) scores[i] = nth_last_hs_scores[i];
+  *k = nth_last_hs_k;
+  return nth_last_hs_len;
+}
+
 void bess_oracle_max_k(const double *score, int len, int k, int *out) {
   /* max_k, src/utilities.cpp:179-188: nth_element(ind, ind + k, ind + len, vec(i) > vec(j)); sort(ind, ind + k) */
   int i;
   int *ind = (int *)malloc((size_t)len * sizeof(int));
+  const long hs_before = nth_heap_selects;
   for (i = 0; i < len; i++) ind[i] = i;
   nth_vec = score;
   nth_element_libstdcxx(ind, ind + k, ind + len);
+  if (nth_heap_selects != hs_before && len <= 4096) {
+    memcpy(nth_last_hs_scores, score, (size_t)len * sizeof(double));
+    nth_last_hs_len = len;
+    nth_last_hs_k = k;
+  }
   for (i = 0; i < k; i++) out[i] = ind[i];
   qsort(out, (size_t)k, sizeof(int), int_cmp);
   free(ind);

@@ -76,6 +76,8 @@ int bess_oracle_normalize(double *x, int n, int p, double *y, const double *weig
  * Ties are broken towards the lower index (the reference's nth_element leaves ties
  * implementation-defined). */
 void bess_oracle_max_k(const double *score, int len, int k, int *out);
+long bess_oracle_nth_heap_selects(void); /* times max_k took the heap-select branch of std::nth_element */
+int bess_oracle_last_heap_select(double *scores, int cap, int *k); /* ... and the input of the last such call */
 
 /* Solve the symmetric system A x = b (A is k x k, column-major, only the lower triangle
  * is read) by an un-pivoted LDL^T.  Returns 0, or 1 if a pivot is exactly zero. */

@@ -164,6 +164,13 @@ def trace_screened(x, y, screening_size, **kw):
     return t
 
 
+def nth_heap_selects():
+    """How often max_k has taken the heap-select branch of the restated std::nth_element in this process."""
+    f = lib().bess_oracle_nth_heap_selects
+    f.restype = ctypes.c_long
+    return int(f())
+
+
 def max_k(score, k):
     score = np.ascontiguousarray(score, dtype=np.float64)
     out = np.zeros(max(k, 1), dtype=np.int32)

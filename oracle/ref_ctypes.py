@@ -53,6 +53,8 @@ def lib():
         _lib.bess_ref_screening_groups.restype = _i
         _lib.bess_ref_screening_groups.argtypes = [_D, _i, _i, _D, _D, _i, _i, _I, _i, _I, _i, _I]
         _lib.bess_ref_trace_size.restype = _i
+        _lib.bess_ref_max_k.restype = None
+        _lib.bess_ref_max_k.argtypes = [_D, _i, _i, _I]
         _lib.bess_ref_trace_size.argtypes = [_i]
         _lib.bess_ref_trace_copy_int.restype = None
         _lib.bess_ref_trace_copy_int.argtypes = [_i, _I]
@@ -160,6 +162,14 @@ def trace(x, y, weight=None, data_type=1, is_normal=True, algorithm_type=1, mode
     return {"beta": beta, "coef0": float(coef0[0]), "train_loss": float(loss[0]), "ic": float(ic[0]),
             "lambda": float(lam_out[0]), "fits": fits, "loss_calls": getd(4), "ic_calls": getd(5),
             "truncated": truncated}
+
+
+def max_k(score, k):
+    """The reference's max_k (src/utilities.cpp:179-188) on a score vector: the k selected indices, ascending."""
+    score = np.ascontiguousarray(score, dtype=np.float64)
+    out = np.zeros(max(k, 1), dtype=np.int32)
+    lib().bess_ref_max_k(_dp(score), score.size, k, _ip(out))
+    return out[:k]
 
 
 def time_chain(x, y, sequence, init_idx=(), init_val=(), init_coef0=0.0, budget_s=15.0, weight=None, data_type=1,

@@ -400,6 +400,14 @@ int bess_ref_screening_groups(const double *x, int n, int p, const double *y, co
 
 // Trace read-out.  which: 0 geta_meta(int) 1 a_flat(int) 2 beta_flat(double) 3 coef0_calls(double)
 //                         4 loss_calls(double) 5 ic_calls(double)
+// the reference's max_k itself (src/utilities.cpp:179-188): std::nth_element + sort on the index vector
+void bess_ref_max_k(const double *score, int len, int k, int *out) {
+  Eigen::VectorXd v = Eigen::Map<const Eigen::VectorXd>(score, len);
+  Eigen::VectorXi r;
+  max_k(v, k, r);
+  for (int i = 0; i < k; i++) out[i] = r(i);
+}
+
 int bess_ref_trace_size(int which) {
   switch (which) {
     case 0: return (int)g_trace.geta_meta.size();

@@ -61,6 +61,24 @@ def test_topk_follows_nth_element_under_ties(gpu, length):
             assert np.array_equal(gpu.op_topk(s, k), P.max_k(s, k)), (levels, k)
 
 
+def test_topk_heap_select_branch_under_ties(gpu):
+    """Score vectors on which std::nth_element exhausts its depth limit and finishes with __heap_select (a PDAS iteration
+    produced the first; tests/golden/make_heap_select.py), with equal scores at the selection boundary: k_topk_ties takes
+    the same branch (one thread, move by move) -- selections of the compiled reference."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "heap_select_ties.npz"))
+    for sc, k, want in zip(g["scores"], g["k"], g["selected"]):
+        assert np.array_equal(gpu.op_topk(sc, int(k)), want[:k]), int(k)
+    base = g["scores"][0]
+    order = np.argsort(-base)
+    for k in range(2, 40):  # every tie group across every boundary: whichever branch the moves take, as the oracle
+        for lo in range(0, k + 1, 2):
+            for hi in (k + 1, k + 3):
+                sc = base.copy()
+                sc[order[lo:hi]] = base[order[lo]]
+                assert np.array_equal(gpu.op_topk(sc, k), P.max_k(sc, k)), (k, lo, hi)
+
+
 @pytest.mark.parametrize("n,p,m", [(97, 8, 3), (500, 40, 16), (1000, 60, 17), (3000, 300, 100), (5000, 400, 200),
                                    (4096, 300, 255), (3000, 700, 600)])
 def test_gram_matches_numpy(gpu, n, p, m):

@@ -76,3 +76,14 @@ def test_oracle_rejects_bad_arguments():
         P.trace(X, y, sequence=[X.shape[1] + 1])
     with pytest.raises(ValueError):
         P.trace(X, y, is_cv=True, K=5, cv_fold_id=None, sequence=[1])
+
+
+def test_max_k_heap_select_branch_matches_the_reference_golden():
+    """std::nth_element runs out of its depth limit on score vectors a PDAS iteration really produces (63 distinct values,
+    k = 10) and falls to __heap_select; with EQUAL scores at the boundary the selected set is what its heap moves leave
+    in front.  Golden selections: the compiled reference's max_k (tests/golden/make_heap_select.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "heap_select_ties.npz"))
+    before = P.nth_heap_selects()
+    for sc, k, want in zip(g["scores"], g["k"], g["selected"]):
+        assert np.array_equal(P.max_k(sc, int(k)), want[:k]), int(k)
+    assert P.nth_heap_selects() - before == len(g["k"])  # every vector takes the branch

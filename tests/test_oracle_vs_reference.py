@@ -102,3 +102,27 @@ def test_score_ties_follow_the_reference_selection():
             for u, v in zip(fa["iters"], fb["iters"]):
                 assert np.array_equal(u, v)
         assert np.array_equal(np.nonzero(a["beta"])[0], np.nonzero(b["beta"])[0])
+
+
+def test_max_k_against_the_reference_incl_its_heap_select_branch():
+    """max_k itself (src/utilities.cpp:179-188), oracle against the compiled reference: random quantised scores (ties at
+    every boundary position), and the vectors that exhaust the depth limit of std::nth_element (its __heap_select branch,
+    tests/golden/heap_select_ties.npz) with fresh perturbations of their tie groups."""
+    import os
+    rng = np.random.default_rng(5)
+    for _ in range(3000):
+        L = int(rng.integers(2, 200))
+        k = int(rng.integers(1, L + 1))
+        sc = rng.integers(0, int(rng.integers(1, 8)), L).astype(float)
+        assert np.array_equal(P.max_k(sc, k), R.max_k(sc, k))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "heap_select_ties.npz"))
+    base = g["scores"][0]
+    order = np.argsort(-base)
+    hits = P.nth_heap_selects()
+    for k in range(2, 40):
+        for lo in range(0, k + 1):
+            for hi in range(k + 1, min(63, k + 6)):
+                sc = base.copy()
+                sc[order[lo:hi]] = base[order[lo]]
+                assert np.array_equal(P.max_k(sc, k), R.max_k(sc, k)), (k, lo, hi)
+    assert P.nth_heap_selects() > hits
