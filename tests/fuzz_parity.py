@@ -112,7 +112,7 @@ def run(cases=100, seed=1, medium=False, verbose=True):
             else:
                 kw["s_min"] = 3
                 kw["s_max"] = max(4, kmax)
-        if mode in ("seq", "gs", "lam", "grp", "powell") and rng.random() < 0.2:
+        if mode in ("seq", "gs", "lam", "grp", "powell", "scr") and rng.random() < 0.2:
             # cross-validation on top of any path type (folds of a random size; the fold fits of LM covariance-form
             # sessions run side by side when untraced)
             K = int(rng.integers(2, 7))
