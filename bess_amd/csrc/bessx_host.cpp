@@ -4012,6 +4012,28 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
       if (e != hipSuccess) {
         (void)hipGetLastError();
         drop_fold_contexts(s);
+      } else {
+        // The host threads, the hardware queues of the chains' streams and (5.5 ms per stream, one after another:
+        // measured) whatever the runtime sets up at a stream's first launch of the slot kernels come into being at their
+        // first use -- 30-40 ms on the first evaluation of a path.  Use them once here, where the data is set up anyway:
+        // one PDAS slot and a publication per chain, all falling through their gates (slot 5 of a fit that has not begun).
+        s->fold_pool = new FoldPool();
+        s->fold_pool->start(K - 1, s->device);
+        std::vector<hipError_t> we((size_t)K, hipSuccess);
+        s->fold_pool->run([&](int k) {
+          bessx_session *c = s->fold_ctx[k];
+          unsigned long long seq = 0;
+          if (enqueue_lm_slot_cov(c, 5, std::min(77, s->cap), 0.0, k + 1, false, false, false, nullptr) != 0 ||
+              publish_enqueue(c, 1, 0, &seq) != 0)
+            we[k] = hipErrorUnknown;
+          if (we[k] == hipSuccess) we[k] = hipStreamSynchronize(c->st);
+        });
+        for (hipError_t w : we)
+          if (w != hipSuccess) {
+            (void)hipGetLastError();
+            drop_fold_contexts(s);
+            break;
+          }
       }
     }
   }
