@@ -121,3 +121,26 @@ def test_more_folds_than_contexts_fall_back_to_one_fit_at_a_time(gpu):
     assert np.array_equal(np.nonzero(out["beta"])[0], sup) and out["n_fits"] == len(want["fits"])
     np.testing.assert_allclose(out["beta"][sup], want["beta"][sup], rtol=1e-6)
     np.testing.assert_allclose(out["ic"], want["ic"], rtol=1e-7)
+
+
+def test_fold_contexts_are_rebuilt_and_torn_down(gpu):
+    """set_cv twice (other K, other folds): contexts, streams and host threads of the first call are dropped and rebuilt;
+    a session that never runs a CV path, or runs plain paths between CV paths, tears them down cleanly."""
+    X, y, _, _ = synth.make_lm(900, 180, 7, seed=3)
+    with gpu.Session(X, y, score_mode=2) as s:
+        s.set_cv(4, synth.make_cv_folds(900, 4, seed=1))
+    with gpu.Session(X, y, score_mode=2) as s:
+        s.set_cv(3, synth.make_cv_folds(900, 3, seed=1))
+        a = s.gs_path(1, 15, ic_type=3, is_cv=True)
+        fold = synth.make_cv_folds(900, 6, seed=2)
+        s.set_cv(6, fold)
+        plain = s.sequential_path(np.arange(1, 10), ic_type=3)
+        b = s.gs_path(1, 15, ic_type=3, is_cv=True)
+        one = s.fit(5, 0.0, fold=2)  # a fold fitted on the session's own state: the contexts start over afterwards
+        c = s.gs_path(1, 15, ic_type=3, is_cv=True)
+        assert s.counters()["cv_side_by_side_rounds"] > 0
+    assert a["n_fits"] > 0 and len(one["support"]) == 5 and plain["n_candidates"] == 9
+    assert np.array_equal(b["cand_support"], c["cand_support"]) and np.array_equal(b["cand_ic"], c["cand_ic"])
+    want = P.trace(X, y, ic_type=3, is_cv=True, K=6, cv_fold_id=fold, path_type=2, s_min=1, s_max=15)
+    np.testing.assert_allclose(b["ic"], want["ic"], rtol=1e-7)
+    assert np.array_equal(np.nonzero(b["beta"])[0], np.nonzero(want["beta"])[0])
