@@ -366,7 +366,7 @@ def main():
         X, y = make_problem(args.n, args.p, args.k_true, 0 if (kpath or not distributed) else rank)
     full_seq = np.arange(1, args.kmax + 1)
     seq = full_seq
-    n_lead = 0  # candidates in front of the chunk that only lead up to it (ladder start): run, timed, discarded
+    lead = []  # sparsity levels in front of the chunk that only lead up to it (ladder start): run, timed, discarded
     if kpath:
         lo, hi = bdist.partition(args.kmax, world, rank)
         seq = full_seq[lo:hi]
@@ -377,8 +377,6 @@ def main():
             args.chunk_start = "ladder" if (k0 >= 128 and not cox) else "cold"
         if args.chunk_start == "ladder" and lo > 0:
             lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
-            n_lead = len(lead)
-            seq = np.concatenate([np.array(lead, dtype=full_seq.dtype), seq])
     t0 = time.time()
     mode = {"auto": 0, "streaming": 1, "covariance": 2}[args.score_mode]
     if cox:
@@ -392,23 +390,26 @@ def main():
 
     ic_curves = None
     out = None
+    stitch = None
+    # N > 1, k-path: the chunks are stitched into the single warm-start chain every step (bess_amd.dist.StitchedKPath)
+    stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev) if kpath else None
     for _ in range(args.warmup):
-        out = sess.sequential_path(seq, ic_type=3)
+        out = stitched.step() if kpath else sess.sequential_path(seq, ic_type=3)
     sess.enable_kernel_timing(True)
     sess.score_pass_stats(reset=True)
     barrier()
     t0 = time.time()
     pdas_iters = 0
     for _ in range(args.steps):
+        if kpath:
+            stitch = stitched.step()  # chunk, stitch rounds, all-gather of the IC curve: the whole step of this rank
+            out = stitch["chunk"] if stitch["chunk"] is not None else {"cand_iters": np.zeros(0, np.int32)}
+            pdas_iters += int(np.sum(out["cand_iters"]))
+            ic_curves = stitch["ic_curve"][None, :]
+            continue
         out = sess.sequential_path(seq, ic_type=3)
         pdas_iters += out["n_pdas_iters"]
-        if n_lead:  # the ladder's own candidates are not part of the chunk
-            for key in ("cand_ic", "cand_support", "cand_iters", "cand_beta", "cand_train_loss", "cand_T0"):
-                if key in out:
-                    out[key] = out[key][n_lead:]
-        if kpath:  # gather the IC curve: the only collective of the path
-            ic_curves = bdist.gather_curve(out["cand_ic"], args.kmax, world, rank, device=comm_dev)[None, :]
-        elif distributed:
+        if distributed:
             ic_curves = bdist.gather_rows(out["cand_ic"], world, device=comm_dev)
     barrier()
     dt = max_over_ranks(time.time() - t0)
@@ -419,9 +420,9 @@ def main():
     if kpath:
         # compare the chunked chains with the single warm-start chain, after the timed region
         sup = np.full((args.kmax, args.kmax), -1.0)
-        sup[lo:hi, :out["cand_support"].shape[1]] = out["cand_support"]
+        if hi > lo:
+            sup[lo:hi, :out["cand_support"].shape[1]] = out["cand_support"]
         allsup = bdist.gather_rows(sup.ravel(), world, device=comm_dev)
-        rank_seconds = bdist.gather_rows(np.array([out["device_seconds"]]), world, device=comm_dev).ravel()
         if rank == 0:
             chunked = np.full((args.kmax, args.kmax), -1, dtype=np.int64)
             for r in range(world):
@@ -434,8 +435,17 @@ def main():
                                           bdist.partition(args.kmax, world, r)[1]))) for r in range(world)],
                 "supports_equal_to_single_chain": int(np.sum(same)), "of": args.kmax,
                 "differing_k": [int(k + 1) for k in range(args.kmax) if not same[k]][:40],
-                "best_k_chunked": int(bdist.select_best(ic_curves[0])) + 1, "best_k_single_chain": int(single["best_T0"]),
-                "seconds_per_rank_last_step": [round(float(v), 5) for v in rank_seconds],
+                "ic_curve_max_rel_diff_to_single_chain": float(np.max(np.abs(ic_curves[0] - single["cand_ic"]) /
+                                                                      np.maximum(np.abs(single["cand_ic"]), 1e-300))),
+                "best_k_chunked": int(stitch["best_k"]), "best_k_single_chain": int(single["best_T0"]),
+                # last timed step: what every rank spent in its chunk (the parallel part) and in the stitch rounds
+                "chunk_seconds_per_rank": [round(v, 5) for v in stitch["chunk_seconds_per_rank"]],
+                "stitch_seconds_per_rank": [round(v, 5) for v in stitch["stitch_seconds_per_rank"]],
+                "stitch_refits": stitch["stitch_refits"], "stitch_refits_per_rank": stitch["stitch_refits_per_rank"],
+                "stitch_rounds": stitch["stitch_rounds"],
+                "stitching": "after its chunk rank r re-fits its first candidates warm from rank r-1's last model until "
+                             "a candidate coincides with its chunk's (same support, coefficients to 1e-9); the "
+                             "candidates before that point are replaced: the gathered path IS the single chain's",
                 "chunk_start": args.chunk_start_option,
                 "chunk_start_meaning": "auto: ladder for chunks beginning at k0 >= 128, else cold; ladder: a chunk beginning at k0 > 1 first climbs the warm-start chain k0/8, k0/4, "
                                        "k0/2 (timed, candidates discarded); cold: Algorithm::fit from the empty model at k0"}
@@ -510,8 +520,8 @@ def main():
                                           1.0 - x_seconds / step_s}},
             "group_XTX_ms_outside_step": "X^T y and diag(X^T X) (one pass over X, src/path.cpp:37) are formed at "
                                          "session creation, inside upload_and_normalise_seconds",
-            "passes_over_X_per_candidate": roof["passes_over_X_timed"] / float(len(seq) * args.steps),
-            "pdas_iterations_per_candidate": pdas_iters / float(len(seq) * args.steps),
+            "passes_over_X_per_candidate": roof["passes_over_X_timed"] / float(max(len(seq), 1) * args.steps),
+            "pdas_iterations_per_candidate": pdas_iters / float(max(len(seq), 1) * args.steps),
             # I_k of SURVEY 8d: PDAS iterations Algorithm::fit took per candidate (identical to the reference's,
             # tests/test_fullsize_gpu.py), as a histogram {iterations: candidates}
             "pdas_iterations_histogram": {str(int(k)): int(v) for k, v in

@@ -26,7 +26,8 @@ SYMBOLS = [
     "bessx_session_pgs_path", "bessx_session_get_screening", "bessx_session_get_screening_groups", "bessx_session_score_mode", "bessx_session_counter",
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
-    "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_fit_width", "bessx_session_reset_caches", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
+    "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_fit_width", "bessx_session_reset_caches",
+    "bessx_session_sequential_path_chain", "bessx_session_cv_eval", "bessx_session_debug_block_stream", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench", "bessx_op_cox_score_bench",
 ]
 
@@ -60,6 +61,13 @@ class PathResult(ctypes.Structure):
                 ("cand_iters", _I), ("cand_train_loss", _D), ("cand_ic", _D), ("cand_coef0", _D),
                 ("cand_support", _I), ("cand_beta", _D), ("max_T0", _i), ("device_seconds", _d), ("n_fits", _ll),
                 ("n_pdas_iters", _ll)]
+
+
+class PathChain(ctypes.Structure):
+    _fields_ = [("init_idx", _I), ("init_val", _D), ("init_len", _i), ("init_coef0", _d), ("keep_caches", _i),
+                ("stop_support", _I), ("stop_beta", _D), ("stop_rows", _i), ("stop_row_len", _i), ("stop_rtol", _d),
+                ("stopped_at", _i), ("last_idx", _I), ("last_val", _D), ("last_cap", _i), ("last_len", _i),
+                ("last_coef0", _d)]
 
 
 _lib = None
@@ -109,6 +117,10 @@ def lib():
         L.bessx_session_submodel_steps.argtypes = [_vp, _i, ctypes.POINTER(_ll)]
         L.bessx_session_fit.argtypes = [_vp, _i, _d, _i, _I, _D, _i, _d, _I, _D, _D, _I, _D, _D]
         L.bessx_session_reset_caches.argtypes = [_vp]
+        L.bessx_session_sequential_path_chain.argtypes = [_vp, _I, _i, _D, _i, _i, _i, ctypes.POINTER(PathChain),
+                                                          ctypes.POINTER(PathResult)]
+        L.bessx_session_cv_eval.argtypes = [_vp, _i, _d, _i, _I, _D, _i, _d, _I, _i, _I, _D, _D, _I, _D, _D]
+        L.bessx_session_debug_block_stream.argtypes = [_vp, _i]
         L.bessx_op_xtv.argtypes = [_D, _i, _i, _i, _D, _D, _D, _D]
         L.bessx_op_topk.argtypes = [_D, _i, _i, _I]
         L.bessx_op_gram.argtypes = [_D, _i, _i, _i, _I, _i, _D, _D]
@@ -248,6 +260,7 @@ class Session:
         _check(lib().bessx_session_create(ctypes.byref(h), ctypes.byref(pb)))
         self._h = h
         self.K = 0
+        self.is_warm_start = bool(is_warm_start)
         self.p_kept = lib().bessx_session_get_screening(h, None, 0)  # columns the session works on
 
     def score_mode(self):
@@ -257,7 +270,8 @@ class Session:
     def counters(self):
         """Diagnostics of the covariance form (bessx_session_counter)."""
         names = {0: "chained_fits", 1: "cg_fallbacks", 2: "passes_over_X", 3: "chained_queued", 7: "cv_side_by_side_rounds",
-                 8: "cv_union_fills", 9: "tie_rescues", 10: "cache_restarts"}  # (4-6: mechanisms removed in round 3)
+                 8: "cv_union_fills", 9: "tie_rescues", 10: "cache_restarts", 11: "cv_contexts_dropped",
+                 12: "cv_fold_contexts"}  # (4-6: mechanisms removed in round 3)
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in names.items()}
 
     def screening(self):
@@ -355,6 +369,64 @@ class Session:
         return self._run(lambda r: L.bessx_session_sequential_path(self._h, _ip(seq), seq.size, _dp(lam), lam.size,
                                                                    ic_type, int(is_cv), r),
                          seq.size * lam.size, min(self.p, (int(seq.max()) if seq.size else 1) * self._gsize_max))
+
+    def sequential_path_chain(self, sequence, lambda_seq=(0.0,), ic_type=4, is_cv=False, init_idx=(), init_val=(),
+                              init_coef0=0.0, keep_caches=False, stop_support=None, stop_beta=None, stop_rtol=1e-9):
+        """sequential_path as one link of a longer warm-start chain (bessx_session_sequential_path_chain): starts from
+        the given (normalised) model, optionally on the caches of the previous call, and stops after the first
+        candidate that equals the caller's own row of stop_support / stop_beta.  Adds to the path result: stopped_at,
+        last_idx / last_val / last_coef0 (the model the next candidate of the chain starts from)."""
+        seq, lam = _i32(sequence), _f64(lambda_seq)
+        ii, iv = _i32(init_idx), _f64(init_val)
+        max_T0 = min(self.p, (int(seq.max()) if seq.size else 1) * self._gsize_max)
+        ch = PathChain()
+        ch.init_idx, ch.init_val, ch.init_len, ch.init_coef0 = _ip(ii), _dp(iv), ii.size, float(init_coef0)
+        ch.keep_caches = int(bool(keep_caches))
+        ss = sb = None
+        if stop_support is not None:
+            ss = np.full((len(stop_support), max_T0), -1, dtype=np.int32)
+            sb = np.zeros((len(stop_support), max_T0))
+            for r, row in enumerate(stop_support):
+                row = np.asarray(row)
+                row = row[row >= 0]
+                ss[r, :row.size] = row
+                if stop_beta is not None:
+                    sb[r, :row.size] = np.asarray(stop_beta[r])[:row.size]
+            ch.stop_support, ch.stop_rows, ch.stop_row_len, ch.stop_rtol = _ip(ss), ss.shape[0], max_T0, float(stop_rtol)
+            ch.stop_beta = _dp(sb) if stop_beta is not None else None
+        li, lv = np.zeros(max_T0, dtype=np.int32), np.zeros(max_T0)
+        ch.last_idx, ch.last_val, ch.last_cap = _ip(li), _dp(lv), max_T0
+        L = lib()
+        out = self._run(lambda r: L.bessx_session_sequential_path_chain(self._h, _ip(seq), seq.size, _dp(lam), lam.size,
+                                                                        ic_type, int(is_cv), ctypes.byref(ch), r),
+                        seq.size * lam.size, max_T0)
+        n_last = min(ch.last_len, max_T0)
+        out.update({"stopped_at": int(ch.stopped_at), "last_idx": li[:n_last].copy(), "last_val": lv[:n_last].copy(),
+                    "last_coef0": float(ch.last_coef0)})
+        return out
+
+    def cv_eval(self, T0, lam=0.0, want_full=True, init_idx=(), init_val=(), init_coef0=0.0, folds=()):
+        """One cross-validated candidate restricted to `folds` (ascending), the full-data fit in front when want_full
+        (bessx_session_cv_eval).  Returns the list of fit records [full,] fold..., each like fit()'s."""
+        ii, iv, fo = _i32(init_idx), _f64(init_val), _i32(folds)
+        w = self.fit_width(T0)
+        nrec = int(bool(want_full)) + fo.size
+        sup, b = np.zeros((max(nrec, 1), w), dtype=np.int32), np.zeros((max(nrec, 1), w))
+        c0, tr, te = np.zeros(max(nrec, 1)), np.zeros(max(nrec, 1)), np.zeros(max(nrec, 1))
+        it = np.zeros(max(nrec, 1), dtype=np.int32)
+        _check(lib().bessx_session_cv_eval(self._h, int(T0), float(lam), int(bool(want_full)), _ip(ii), _dp(iv), ii.size,
+                                           float(init_coef0), _ip(fo), fo.size, _ip(sup), _dp(b), _dp(c0), _ip(it),
+                                           _dp(tr), _dp(te)))
+        recs = []
+        for r in range(nrec):
+            keep = sup[r] >= 0
+            recs.append({"support": sup[r][keep], "beta": b[r][keep], "coef0": float(c0[r]), "iters": int(it[r]),
+                         "train_loss": float(tr[r]), "test_loss": float(te[r])})
+        return recs
+
+    def debug_block_stream(self, milliseconds):
+        """Test hook: everything queued on the session's stream waits behind a host function that sleeps."""
+        _check(lib().bessx_session_debug_block_stream(self._h, int(milliseconds)))
 
     def gs_path(self, s_min, s_max, ic_type=4, is_cv=False):
         L = lib()

@@ -82,47 +82,61 @@ using namespace bessx;
 
 // Host threads that queue the chains' launches: launches that alternate between streams cost the host ~10 us each
 // (measured: 35 launches per round, 12 ms per path of configs[3]); one thread per chain queues its 7 on its own stream
-// while the others do the same.  Workers spin for a job for a few milliseconds after the last one, then block on a
-// condition variable (an idle session holds no core).
+// while the others do the same.  Workers spin for a job for a while after the last one, then block on a condition
+// variable (an idle session holds no core).  The spin is ~4 ms where the host has cores to spare (longer than the
+// longest gap inside a path -- a union fill of three groups is 2.5 ms; with 1 ms the workers slept through the fills and
+// configs[3] took 32.9 instead of 29.4 ms) and ~0.2 ms where K spinning threads per session would oversubscribe it
+// (fewer than 4 hardware threads per chain: several ranks or sessions per host); BESSX_POOL_SPIN_US overrides.
+// The caller's wait for its workers is bounded: spin, then sleep on a condition variable, and give up at the
+// session's deadline (a worker stuck inside a HIP call) -- the pool is then marked broken and never joined.
 struct FoldPool {
   std::vector<std::thread> th;
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv, cv_done;
   unsigned ticket = 0;  // (under mu) number of the current job
   std::atomic<unsigned> ticket_hint{0};  // ... its copy for the spinning phase
   std::atomic<int> pending{0};
-  bool quit = false;
+  bool quit = false, broken = false;
   std::function<void(int)> job;
   int device = 0;
+  int spin_iters = 200000;  // pauses of ~40-50 cycles
   void worker(int k) {
     (void)hipSetDevice(device);
     unsigned seen = 0;
     for (;;) {
       bool got = false;
-      // ~ 4 ms of spinning (a pause is ~ 40-50 cycles): longer than the longest gap inside a path -- a union fill of
-      // three groups is 2.5 ms; with 1 ms the workers slept through the fills and configs[3] took 32.9 instead of 29.4 ms
-      for (int spin = 0; spin < 200000 && !got; spin++) {
+      for (int spin = 0; spin < spin_iters && !got; spin++) {
         got = ticket_hint.load(std::memory_order_acquire) != seen;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
       }
+      std::function<void(int)> mine;
       {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return quit || ticket != seen; });
         if (quit) return;
         seen = ticket;
+        mine = job;
       }
-      job(k);
-      pending.fetch_sub(1, std::memory_order_release);
+      mine(k);
+      if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        std::lock_guard<std::mutex> lk(mu);  // (the caller may be asleep on cv_done)
+        cv_done.notify_all();
+      }
     }
   }
   void start(int nworkers, int dev) {
     device = dev;
+    const unsigned hw = std::thread::hardware_concurrency();
+    spin_iters = (hw >= 4u * (unsigned)(nworkers + 1)) ? 200000 : 10000;
+    if (const char *ev = std::getenv("BESSX_POOL_SPIN_US")) spin_iters = std::max(0, std::atoi(ev)) * 50;
     for (int k = 1; k <= nworkers; k++) th.emplace_back([this, k] { worker(k); });
   }
-  // runs fn(0) on the caller and fn(1..nworkers) on the workers; returns when all are done
-  void run(const std::function<void(int)> &fn) {
+  // runs fn(0) on the caller and fn(1..nworkers) on the workers; true when all are done, false when the workers did
+  // not finish within deadline_s (the pool is then broken: its threads may still be inside fn)
+  bool run(const std::function<void(int)> &fn, double deadline_s) {
+    if (broken) return false;
     {
       std::lock_guard<std::mutex> lk(mu);
       job = fn;
@@ -132,11 +146,17 @@ struct FoldPool {
     }
     cv.notify_all();
     fn(0);
-    while (pending.load(std::memory_order_acquire) != 0) {
+    for (int spin = 0; spin < 400000; spin++) {  // ~8 ms: the workers queue a handful of launches each
+      if (pending.load(std::memory_order_acquire) == 0) return true;
 #if defined(__x86_64__)
       __builtin_ia32_pause();
 #endif
     }
+    std::unique_lock<std::mutex> lk(mu);
+    const bool ok = cv_done.wait_for(lk, std::chrono::duration<double>(deadline_s),
+                                     [&] { return pending.load(std::memory_order_acquire) == 0; });
+    if (!ok) broken = true;
+    return ok;
   }
   void stop() {
     {
@@ -144,7 +164,12 @@ struct FoldPool {
       quit = true;
     }
     cv.notify_all();
-    for (auto &t : th) t.join();
+    for (auto &t : th) {
+      if (broken)
+        t.detach();  // a worker that never came back from a HIP call cannot be joined
+      else
+        t.join();
+    }
     th.clear();
   }
 };
@@ -279,8 +304,14 @@ struct bessx_session {
   FitCtrl *fill_ctrl_h = nullptr;           // ... its pinned host copy
   hipEvent_t ev_fill = nullptr, ev_ctx = nullptr;
   long long cv_union_fills = 0, cv_rounds = 0;
+  long long cv_ctx_dropped = 0;             // times the fold contexts were given up (allocation / launch failure at set_cv)
   int fill_groups_seen = 0;                 // fill_ctrl->cov_groups already added to cov_panel_groups
   FoldPool *fold_pool = nullptr;            // host threads that queue the chains' launches (one per chain)
+  // Every wait of the host on the device (the spin on a published result block, the wait for the chains' host threads)
+  // gives up after this many seconds of wall clock and returns BESSX_ERR_HIP with the stream's status: a wedged kernel
+  // must not hang the caller at 100 % of a core.  BESSX_WAIT_TIMEOUT_S (read at session creation) overrides; a session
+  // that timed out still has work queued on the device and can only be destroyed.
+  double wait_deadline_s = 30.0;
   double sbs_t[6] = {0, 0, 0, 0, 0, 0};     // BESSX_DEBUG: seconds in start / enqueue / wait / fill / continue / results
   bool cov_pair_auto = true;  // launches of two groups use the pair panel kernel (BESSX_PANEL_PAIR_AUTO=0: never)
   int cov_variant = 3;        // panel kernel: 3 = one 32-column group per block (k_cov_panel_lds2), two-group launches by the
@@ -388,7 +419,7 @@ static void fold_ctx_free(bessx_session *c) {
 static void drop_fold_contexts(bessx_session *s) {
   if (s->fold_pool) {
     s->fold_pool->stop();
-    delete s->fold_pool;
+    if (!s->fold_pool->broken) delete s->fold_pool;  // (a broken pool's threads may still touch it: leaked on purpose)
     s->fold_pool = nullptr;
   }
   for (bessx_session *c : s->fold_ctx) fold_ctx_free(c);
@@ -1358,8 +1389,24 @@ static int publish_wait(bessx_session *s, int buf, unsigned long long want) {
   s->res_h = s->res_buf[buf];
   s->dbg_waits++;
   if (*flag >= want) s->dbg_waits_ready++;  // the result was there already: the device is ahead of the host
+  std::chrono::steady_clock::time_point t0;
+  bool timed = false;
   for (unsigned spins = 1;; spins++) {
     if (*flag >= want) break;
+    // the wall clock every 2^14 spins (~0.5 ms; reading it is ~20 ns and touches nothing the device sees)
+    if ((spins & 0x3fff) == 0) {
+      const auto now = std::chrono::steady_clock::now();
+      if (!timed) {
+        t0 = now;
+        timed = true;
+      } else if (std::chrono::duration<double>(now - t0).count() > s->wait_deadline_s) {
+        const hipError_t q = hipStreamQuery(s->st);
+        if (q == hipSuccess && *flag >= want) break;
+        return fail(BESSX_ERR_HIP, "no result block from the device within " + std::to_string(s->wait_deadline_s) +
+                                       " s (BESSX_WAIT_TIMEOUT_S); stream status: " + hipGetErrorString(q) +
+                                       " -- the session can only be destroyed now");
+      }
+    }
     // (rarely: a hipStreamQuery puts a marker with a system-scope release behind the last queued kernel, and the
     // kernel after it then starts ~4 us late -- once per fit when the query ran every 1024 spins, tools/ktrace.py)
     if ((spins & 0xfffff) == 0) {
@@ -2009,22 +2056,27 @@ static bool side_by_side_applies(const bessx_session *s, int T0) {
   if (s->trace.on || s->model_type != 1 || s->grouped || !s->cov_mode || !s->cv_shared) return false;
   if (T0 < 1 || T0 > s->cap || (T0 + 1 + 15) / 16 > 16) return false;  // (the fused selection + solve launches)
   if (!topk_supported(s->p, T0) || !topk_can_fuse_need(s->p) || !sel_cgr_applies(s->p, T0)) return false;
-  // every chain's set must fit a cache that has just been started over, and the list of one fill its buffer
-  if ((long)s->K * T0 + s->cov_spec + COV_R > (long)cov_C_dev(s)) return false;
-  if ((long)s->K * T0 + 2 * s->cov_spec + COV_R > (long)s->capA + 4 * COV_R) return false;
-  if (s->warm_start)
-    for (const SparseVec &b : s->cv_init)
-      if ((int)b.idx.size() + COV_R + s->cov_spec > s->cov_C) return false;
+  // every chain's sets -- the support it starts from AND the one it is heading for -- must fit a cache that has just
+  // been started over, together, and the list of one fill its buffer
+  long need = 0;
+  for (int k = 0; k < s->K; k++)
+    need += std::max(T0, s->warm_start ? (int)s->cv_init[k].idx.size() : (int)s->beta_init.idx.size());
+  if (need + s->cov_spec + COV_R > (long)cov_C_dev(s)) return false;
+  if (need + 2 * s->cov_spec + COV_R > (long)s->capA + 4 * COV_R) return false;
   return true;
 }
 
-static int fold_fits_side_by_side(bessx_session *s, double *out) {
+// `only`: the folds to fit (ascending; nullptr = all K) -- a rank of a fold-sharded CV path fits its own folds
+// (bessx_session_cv_eval); `per_fold`: test loss of every fitted fold, in the order of `only`.  *out = their mean.
+static int fold_fits_side_by_side(bessx_session *s, double *out, const std::vector<int> *only = nullptr,
+                                  double *per_fold = nullptr) {
   const int K = s->K, T0 = s->sparsity_level, p = s->p;
   const double lambda = s->lambda_level;
   enum Todo { NONE, START, RESUME, UNPARK };
   struct Chain {
     bessx_session *c = nullptr;
     int rs = 0, slot = 1, k_init = 0, serial = 0;
+    int prev_T0 = 0;  // sparsity level of the fit whose state the chain's device buffers hold (use_cache)
     bool use_cache = false, scores_ok = false, grow1 = false, active = true, wait_fill = false;
     Todo todo = START;
     unsigned long long seq = 0;
@@ -2033,6 +2085,11 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
     std::string err;
   };
   std::vector<Chain> ch((size_t)K);
+  std::vector<char> sel((size_t)K, only ? 0 : 1);
+  if (only)
+    for (int k : *only) sel[(size_t)k] = 1;
+  int nsel = 0;
+  for (char v : sel) nsel += v;
   auto quiet = [&]() {
     for (bessx_session *c : s->fold_ctx) (void)hipStreamSynchronize(c->st);
     (void)hipStreamSynchronize(s->st);
@@ -2085,10 +2142,15 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
                           c->beta_dense, p, c->hist, c->st, c->inA));
     return 0;
   };
+  std::vector<int> openers;
   for (int k = 0; k < K; k++) {
     Chain &q = ch[k];
     bessx_session *c = q.c = s->fold_ctx[k];
     const int rs = q.rs = k + 1;
+    if (!sel[k]) {
+      q.active = false;
+      continue;
+    }
     c->sparsity_level = T0;
     c->lambda_level = lambda;
     c->cur_rows = rs;
@@ -2100,22 +2162,60 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
     q.use_cache = cc.valid && cc.coef0 == c->coef0_init && cc.beta.idx == c->beta_init.idx &&
                   cc.beta.val == c->beta_init.val && cc.cov_layout && c->dev_state_rs == rs;
     cc.valid = false;
+    q.prev_T0 = cc.T0;
     q.serial = ++c->fit_serial;
     q.scores_ok = q.use_cache && cc.lambda == lambda;
     q.grow1 = q.scores_ok && cc.T0 + 1 == T0;
     c->dev_state_rs = rs;
     if (!q.use_cache && q.k_init > 0) {
-      // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones.  Done
-      // for this chain alone, to the end, before any chain reads the slot map (nothing else is queued yet); a full
-      // cache may start over here.
-      SBS(open_fit(q));
+      SBS(open_fit(q));  // (fit_begin leaves the initial support in A_cur)
       q.todo = NONE;
-      bessx_session::CovCache &cv = c->cov[rs];
-      SBSH(launch_cov_need(c->A_cur, q.k_init, nullptr, c->bd2, p, cv.slot_of, cv.meta, cov_C_dev(c), c->cov_fcols, c->ctrl,
-                           0, c->A_cur, c->st, 0));
-      SBSH(launch_cov_fill_list(c->cov_fcols, c->cov_extras, c->bd2, cv.slot_of, cv.meta, c->ctrl, 0, c->st, c->cov_spec, 0));
-      SBS(enqueue_cov_fill(c, rs, (q.k_init + COV_R - 1) / COV_R, 0));
-      SBSH(hipStreamSynchronize(c->st));
+      openers.push_back(k);
+    }
+  }
+  if (!openers.empty()) {
+    // The first score pass of a chain that starts from an uploaded support multiplies the cached Gram columns of that
+    // support: form the missing ones -- for ALL such chains in ONE fill on the shared slot map, before any chain reads
+    // it.  Whether the cache has to be started over is decided here, once, from its occupancy and the sum of the
+    // supports; when it is, the chains that continue from their device state get their current columns back in the
+    // same fill (their next selection only looks the ENTERING columns up).  (Until round 3 every chain ran its own
+    // slot-0 lookup one after another, and a later chain's restart could evict what an earlier one had just filled.)
+    for (int k : openers) SBSH(hipStreamSynchronize(ch[k].c->st));
+    int meta_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    SBSH(hipMemcpyAsync(meta_h, s->cov[0].meta, sizeof(meta_h), hipMemcpyDeviceToHost, s->st));
+    SBSH(hipStreamSynchronize(s->st));
+    long want = 0;
+    for (int k : openers) want += ch[k].k_init;
+    const bool restart = meta_h[0] + want + COV_R > (long)cov_C_dev(s);
+    CovUnion u = {};
+    long ub = 0;
+    for (int k = 0; k < K; k++) {
+      Chain &q = ch[k];
+      if (!q.active) continue;
+      const bool opener = !q.use_cache && q.k_init > 0;
+      if (opener || (restart && q.use_cache && q.prev_T0 > 0)) {
+        u.list[u.nf] = q.c->A_cur;
+        u.len[u.nf++] = opener ? q.k_init : q.prev_T0;
+        ub += opener ? q.k_init : q.prev_T0;
+      }
+    }
+    SBSH(launch_cov_fill_union(u, restart ? 1 : 0, nullptr, nullptr, s->cov_spec, 0, s->cov[0].slot_of, s->cov[0].meta, p,
+                               s->cov_fcols, s->fill_ctrl, s->st));
+    SBSH(hipMemcpyAsync(s->fill_ctrl_h, s->fill_ctrl, sizeof(FitCtrl), hipMemcpyDeviceToHost, s->st));
+    SBSH(hipStreamSynchronize(s->st));
+    s->cov_panel_groups += s->fill_ctrl_h->cov_groups - s->fill_groups_seen;
+    s->fill_groups_seen = s->fill_ctrl_h->cov_groups;
+    const int ngroups = s->fill_ctrl_h->cov_nfill / COV_R;
+    if (ngroups > (ub + COV_R - 1) / COV_R) SBS(fail(BESSX_ERR_NUMERIC, "internal error: opening fill list longer than its bound"));
+    if (ngroups > 0) {
+      SBS(enqueue_cov_fill(s, 0, ngroups, 1, s->fill_ctrl));
+      SBSH(hipEventRecord(s->ev_fill, s->st));
+      s->cv_union_fills++;
+      for (Chain &q : ch) q.wait_fill = q.active;
+      if (s->timing) {
+        SBSH(hipStreamSynchronize(s->st));
+        SBS(cov_collect(s, s->fill_ctrl_h->cov_nfill));
+      }
     }
   }
   if (!s->fold_pool) {
@@ -2152,10 +2252,13 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
     q.rc = body();
     if (q.rc) q.err = g_err;  // (the message is thread-local)
   };
-  int remaining = K;
+  int remaining = nsel;
   while (remaining > 0) {
     s->cv_rounds++;
-    s->fold_pool->run(chain_round);
+    if (!s->fold_pool->run(chain_round, s->wait_deadline_s))
+      SBS(fail(BESSX_ERR_HIP, "the host threads of the fold chains did not return from queueing their launches within " +
+                                  std::to_string(s->wait_deadline_s) + " s (BESSX_WAIT_TIMEOUT_S) -- the session can only "
+                                  "be destroyed now"));
     for (Chain &q : ch)
       if (q.active && q.rc) {
         g_err = q.err;
@@ -2273,9 +2376,13 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
     }
   }
   // ---- results (the tail of algorithm_fit), in fold order
-  if (s->warm_start) s->beta_init = s->cv_init[K - 1];  // (update_beta_init of the last fold: its warm start, not its result)
+  int k_last = K - 1;
+  while (k_last > 0 && !sel[k_last]) k_last--;
+  if (s->warm_start) s->beta_init = s->cv_init[k_last];  // (update_beta_init of the last fold: its warm start, not its result)
   double acc = 0.0;
+  int n_out = 0;
   for (int k = 0; k < K; k++) {
+    if (!sel[k]) continue;
     Chain &q = ch[k];
     bessx_session *c = q.c;
     const FitCtrl *hc = q.hc;
@@ -2317,17 +2424,20 @@ static int fold_fits_side_by_side(bessx_session *s, double *out) {
     s->cov_tie_rescues += c->cov_tie_rescues;
     c->cov_cg_fallbacks = c->cov_tie_rescues = 0;
     if (s->warm_start) s->cv_init[k] = c->beta;
-    acc += c->sse_test / (double)(2 * s->n_test[k]);  // src/Metric.h:190
+    const double tl = c->sse_test / (double)(2 * s->n_test[k]);  // src/Metric.h:190
+    if (per_fold) per_fold[n_out] = tl;
+    n_out++;
+    acc += tl;
   }
   // what Algorithm holds after the loop of test_loss: the LAST fold's fit (path.cpp reads it, :314-319)
-  const bessx_session *last = s->fold_ctx[K - 1];
+  const bessx_session *last = s->fold_ctx[k_last];
   s->beta = last->beta;
   s->coef0 = last->coef0;
   s->l = last->l;
   s->sse_train = last->sse_train;
   s->sse_test = last->sse_test;
-  s->cur_rows = K;
-  *out = acc / (double)K;
+  s->cur_rows = k_last + 1;
+  *out = acc / (double)nsel;
   tick(5, tm);
 #undef SBS
 #undef SBSH
@@ -2467,15 +2577,50 @@ static void store_best(bessx_session *s, bessx_path_result *res, const Candidate
   res->best_iters = c.iters;
 }
 
+// does candidate c equal row `row` of the chain's stop table (supports in the caller's numbering, -1 padded;
+// coefficients de-normalised like cand_beta, compared to stop_rtol when given)?
+static bool chain_row_matches(const bessx_session *s, const bessx_path_chain *ch, int row, const Candidate &c) {
+  if (!ch->stop_support || row >= ch->stop_rows) return false;
+  const int *want = ch->stop_support + (size_t)row * ch->stop_row_len;
+  const int k = (int)c.beta.idx.size();
+  if (k > ch->stop_row_len) return false;
+  for (int j = 0; j < ch->stop_row_len; j++)
+    if (want[j] != (j < k ? caller_col(s, c.beta.idx[j]) : -1)) return false;
+  if (ch->stop_beta) {
+    SparseVec b = c.beta;
+    double c0 = c.coef0;
+    denormalize(s, b, c0, false);
+    const double *wb = ch->stop_beta + (size_t)row * ch->stop_row_len;
+    for (int j = 0; j < k; j++)
+      if (!(std::fabs(b.val[j] - wb[j]) <= ch->stop_rtol * std::max(std::fabs(b.val[j]), std::fabs(wb[j])))) return false;
+  }
+  return true;
+}
+
 static int sequential_path(bessx_session *s, const int *seq, int ns, const double *lam, int nl, int ic_type,
-                           int is_cv, bessx_path_result *res) {
+                           int is_cv, bessx_path_result *res, bessx_path_chain *chain = nullptr) {
   // src/path.cpp:25-132
   SparseVec beta_init;
   double coef0_init = 0.0;
+  if (chain) {
+    // the warm-start chain of :60-64 continued from a model another process holds (update_beta_init /
+    // update_coef0_init, src/Algorithm.h:85-93, before the first candidate)
+    for (int i = 0; i < chain->init_len; i++) {
+      if (chain->init_idx[i] < 0 || chain->init_idx[i] >= s->p) return fail(BESSX_ERR_ARG, "chain: init index out of range");
+      beta_init.idx.push_back(chain->init_idx[i]);
+      beta_init.val.push_back(chain->init_val[i]);
+    }
+    coef0_init = chain->init_coef0;
+    chain->stopped_at = -1;
+    chain->last_len = 0;
+    chain->last_coef0 = 0.0;
+  }
   std::vector<Candidate> grid((size_t)ns * nl);
-  for (int i = 0; i < ns; i++) {
+  std::vector<char> have((size_t)ns * nl, 0);
+  bool stop = false;
+  for (int i = 0; i < ns && !stop; i++) {
     int step = (i % 2 == 0) ? 1 : -1;
-    for (int j = (i % 2 == 0) ? 0 : nl - 1; j < nl && j >= 0; j += step) {
+    for (int j = (i % 2 == 0) ? 0 : nl - 1; j < nl && j >= 0 && !stop; j += step) {
       {
         // announce the fit that follows in the snake order (src/path.cpp:36-50): it can be chained on the device
         int jn = j + step, in = i;
@@ -2495,6 +2640,7 @@ static int sequential_path(bessx_session *s, const int *seq, int ns, const doubl
         coef0_init = s->coef0;
       }
       Candidate &c = grid[(size_t)j * ns + i];
+      have[(size_t)j * ns + i] = 1;
       c.T0 = seq[i];
       c.lambda = lam[j];
       c.beta = s->beta;
@@ -2503,12 +2649,27 @@ static int sequential_path(bessx_session *s, const int *seq, int ns, const doubl
       if (int rc = metric_train_loss(s, &c.loss)) return rc;
       if (int rc = metric_ic(s, ic_type, is_cv, &c.ic)) return rc;
       store_candidate(s, res, c, false);
+      if (chain && chain_row_matches(s, chain, res->n_candidates - 1, c)) {
+        // from here on the chain the caller already holds IS this chain: same model, same successor
+        chain->stopped_at = res->n_candidates - 1;
+        stop = true;
+      }
     }
   }
   size_t best = 0;  // minCoeff over the column-major (ns x nl) matrix: first minimum in storage order
-  for (size_t q = 0; q < grid.size(); q++)
-    if (grid[q].ic < grid[best].ic) best = q;
+  while (best < grid.size() && !have[best]) best++;
+  for (size_t q = best; q < grid.size(); q++)
+    if (have[q] && grid[q].ic < grid[best].ic) best = q;
   store_best(s, res, grid[best], false);
+  if (chain) {
+    // Algorithm::beta / coef0 as the path would hand them to the next candidate (normalised scale)
+    chain->last_len = (int)beta_init.idx.size();
+    chain->last_coef0 = coef0_init;
+    for (int i = 0; i < chain->last_len && i < chain->last_cap; i++) {
+      if (chain->last_idx) chain->last_idx[i] = beta_init.idx[i];
+      if (chain->last_val) chain->last_val[i] = beta_init.val[i];
+    }
+  }
   return 0;
 }
 
@@ -2928,8 +3089,20 @@ struct PgsArgs {
   int powell_path, nlambda;
 };
 
+// the part of reset_path_caches() a path needs that continues on the caches of the previous call
+static int settle_device_chain(bessx_session *s) {
+  if (s->ahead.armed) {
+    s->ahead.armed = false;
+    HIPX(hipStreamSynchronize(s->st));
+  }
+  s->pend_on = false;
+  s->hint.on = false;
+  return 0;
+}
+
 static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *lam, int nl, int s_min,
-                    int s_max, int ic_type, int is_cv, bessx_path_result *res, const PgsArgs *pgs = nullptr) {
+                    int s_max, int ic_type, int is_cv, bessx_path_result *res, const PgsArgs *pgs = nullptr,
+                    bessx_path_chain *chain = nullptr) {
   if (!s || !res) return fail(BESSX_ERR_ARG, "null session or result");
   if (is_cv && s->K < 2) return fail(BESSX_ERR_ARG, "is_cv needs bessx_session_set_cv first");
   HIPX(hipSetDevice(s->device));
@@ -2940,10 +3113,12 @@ static int run_path(bessx_session *s, bool gs, const int *seq, int ns, const dou
   s->n_fits = 0;
   s->n_iters = 0;
   auto t0 = std::chrono::steady_clock::now();
-  if (int rc0 = reset_path_caches(s)) return rc0;  // a path call starts cold, like a bessCpp call
+  // a path call starts cold, like a bessCpp call -- unless it continues the job of the previous call (chain->keep_caches:
+  // the Gram columns and score sums in memory depend on the data only and stay valid)
+  if (int rc0 = (chain && chain->keep_caches) ? settle_device_chain(s) : reset_path_caches(s)) return rc0;
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
-                : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res);
+                : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res, chain);
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
   res->n_fits = s->n_fits;
@@ -3453,6 +3628,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     s->pub_flag[0] = 0ull;
     s->pub_flag[8] = 0ull;  // second buffer's flag, its own cache line
     if (const char *ev = std::getenv("BESSX_PUBLISH")) s->publish = std::atoi(ev) != 0;
+    if (const char *ev = std::getenv("BESSX_WAIT_TIMEOUT_S")) s->wait_deadline_s = std::max(0.001, std::atof(ev));
     if (const char *ev = std::getenv("BESSX_CHAIN")) s->chain = std::atoi(ev) != 0;
     if (!s->publish) s->chain = false;
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), (size_t)capA * (sizeof(int) + sizeof(double))));
@@ -4012,6 +4188,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
       if (e != hipSuccess) {
         (void)hipGetLastError();
         drop_fold_contexts(s);
+        s->cv_ctx_dropped++;
       } else {
         // The host threads, the hardware queues of the chains' streams and (5.5 ms per stream, one after another:
         // measured) whatever the runtime sets up at a stream's first launch of the slot kernels come into being at their
@@ -4020,18 +4197,25 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
         s->fold_pool = new FoldPool();
         s->fold_pool->start(K - 1, s->device);
         std::vector<hipError_t> we((size_t)K, hipSuccess);
-        s->fold_pool->run([&](int k) {
+        // (a sparsity level the side-by-side driver would really run on this session: the largest one <= 77 that
+        // side_by_side_applies() accepts -- launch geometry and LDS sizes follow from it; none: no warm-up)
+        int warm_T0 = 0;
+        for (int t = std::min(77, s->cap); t >= 1 && !warm_T0; t--)
+          if (side_by_side_applies(s, t)) warm_T0 = t;
+        const bool ran = warm_T0 == 0 || s->fold_pool->run([&](int k) {
           bessx_session *c = s->fold_ctx[k];
           unsigned long long seq = 0;
-          if (enqueue_lm_slot_cov(c, 5, std::min(77, s->cap), 0.0, k + 1, false, false, false, nullptr) != 0 ||
+          if (enqueue_lm_slot_cov(c, 5, warm_T0, 0.0, k + 1, false, false, false, nullptr) != 0 ||
               publish_enqueue(c, 1, 0, &seq) != 0)
             we[k] = hipErrorUnknown;
           if (we[k] == hipSuccess) we[k] = hipStreamSynchronize(c->st);
-        });
+        }, s->wait_deadline_s);
+        if (!ran) we[0] = hipErrorUnknown;
         for (hipError_t w : we)
           if (w != hipSuccess) {
             (void)hipGetLastError();
             drop_fold_contexts(s);
+            s->cv_ctx_dropped++;  // (visible through bessx_session_counter(s, 11): the folds then run one after another)
             break;
           }
       }
@@ -4053,6 +4237,21 @@ int bessx_session_sequential_path(bessx_session *s, const int *sequence, int seq
   if (!sequence || sequence_len < 1 || !lambda_seq || lambda_len < 1)
     return fail(BESSX_ERR_ARG, "sequential_path: empty sequence");
   return run_path(s, false, sequence, sequence_len, lambda_seq, lambda_len, 0, 0, ic_type, is_cv, res);
+}
+
+int bessx_session_sequential_path_chain(bessx_session *s, const int *sequence, int sequence_len,
+                                        const double *lambda_seq, int lambda_len, int ic_type, int is_cv,
+                                        bessx_path_chain *chain, bessx_path_result *res) {
+  if (!sequence || sequence_len < 1 || !lambda_seq || lambda_len < 1)
+    return fail(BESSX_ERR_ARG, "sequential_path: empty sequence");
+  if (!chain) return fail(BESSX_ERR_ARG, "sequential_path_chain: null chain");
+  if (chain->init_len < 0 || (chain->init_len > 0 && (!chain->init_idx || !chain->init_val)))
+    return fail(BESSX_ERR_ARG, "sequential_path_chain: bad initial model");
+  if (is_cv && chain->init_len > 0)
+    return fail(BESSX_ERR_UNSUPPORTED, "sequential_path_chain: under CV a chain would need the folds' models as well");
+  if (chain->stop_support && (chain->stop_rows < 0 || chain->stop_row_len < 1))
+    return fail(BESSX_ERR_ARG, "sequential_path_chain: bad stop table");
+  return run_path(s, false, sequence, sequence_len, lambda_seq, lambda_len, 0, 0, ic_type, is_cv, res, nullptr, chain);
 }
 
 int bessx_session_gs_path(bessx_session *s, int s_min, int s_max, int ic_type, int is_cv, bessx_path_result *res) {
@@ -4156,6 +4355,8 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 7: return s->cv_rounds;
     case 8: return s->cv_union_fills;
     case 9: return s->cov_tie_rescues;
+    case 11: return s->cv_ctx_dropped;
+    case 12: return (long long)s->fold_ctx.size();
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -4228,6 +4429,90 @@ int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const i
   if (iters) *iters = s->l;
   if (train_loss) *train_loss = metric_train_loss_value(s);
   if (test_loss) *test_loss = fold < 0 ? 0.0 : metric_fold_test_loss(s, fold);
+  return BESSX_OK;
+}
+
+// One evaluation of a cross-validated candidate for a SUBSET of the folds (and, optionally, the full-data fit in front
+// of them): what a rank of a fold-sharded path owns (bess_amd/dist.py).  The fold fits take the library's own route --
+// the chains side by side with union fills where that applies, one after another on the session's state otherwise --
+// and the session's own per-fold warm starts (Metric::cv_initial_model_param).
+int bessx_session_cv_eval(bessx_session *s, int T0, double lambda, int want_full, const int *init_idx,
+                          const double *init_val, int init_len, double init_coef0, const int *folds, int n_folds,
+                          int *support, double *beta, double *coef0, int *iters, double *train_loss, double *test_loss) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  if (n_folds < 0 || (n_folds > 0 && !folds)) return fail(BESSX_ERR_ARG, "cv_eval: bad fold list");
+  if (n_folds > 0 && s->K < 2) return fail(BESSX_ERR_ARG, "cv_eval needs bessx_session_set_cv first");
+  for (int i = 0; i < n_folds; i++)
+    if (folds[i] < 0 || folds[i] >= s->K || (i > 0 && folds[i] <= folds[i - 1]))
+      return fail(BESSX_ERR_ARG, "cv_eval: folds must be ascending indices in [0, K)");
+  const int width = bessx_session_fit_width(s, T0);
+  if (width < 0) return fail(BESSX_ERR_ARG, "sparsity level outside [1, number of groups]");
+  HIPX(hipSetDevice(s->device));
+  s->sparsity_level = T0;
+  s->lambda_level = lambda;
+  s->beta_init.clear();
+  for (int i = 0; i < init_len; i++) {
+    if (init_idx[i] < 0 || init_idx[i] >= s->p) return fail(BESSX_ERR_ARG, "init index out of range");
+    s->beta_init.idx.push_back(init_idx[i]);
+    s->beta_init.val.push_back(init_val[i]);
+  }
+  s->coef0_init = init_coef0;
+  int rec = 0;
+  auto put = [&](const SparseVec &b, double c0, int l, double tr, double te) -> int {
+    const int got = (int)b.idx.size();
+    if (got > width) return fail(BESSX_ERR_NUMERIC, "internal error: more columns selected than bessx_session_fit_width allows");
+    for (int i = 0; i < width; i++) {
+      if (support) support[(size_t)rec * width + i] = i < got ? b.idx[i] : -1;
+      if (beta) beta[(size_t)rec * width + i] = i < got ? b.val[i] : 0.0;
+    }
+    if (coef0) coef0[rec] = c0;
+    if (iters) iters[rec] = l;
+    if (train_loss) train_loss[rec] = tr;
+    if (test_loss) test_loss[rec] = te;
+    rec++;
+    return 0;
+  };
+  if (want_full) {
+    s->cur_rows = 0;
+    if (int rc = algorithm_fit(s)) return rc;
+    if (int rc = put(s->beta, s->coef0, s->l, metric_train_loss_value(s), 0.0)) return rc;
+  }
+  if (n_folds == 0) return BESSX_OK;
+  const std::vector<int> only(folds, folds + n_folds);
+  s->metric_depth++;
+  int rc = 0;
+  if (side_by_side_applies(s, T0)) {
+    std::vector<double> tl((size_t)n_folds);
+    double mean = 0.0;
+    rc = fold_fits_side_by_side(s, &mean, &only, tl.data());
+    for (int i = 0; i < n_folds && rc == 0; i++) {
+      const bessx_session *c = s->fold_ctx[(size_t)only[i]];
+      rc = put(c->beta, c->coef0, c->l, metric_train_loss_value(c), tl[i]);
+    }
+  } else {
+    const SparseVec keep = s->beta_init;
+    for (int i = 0; i < n_folds && rc == 0; i++) {
+      const int k = only[i];
+      s->beta_init = s->warm_start ? s->cv_init[k] : keep;  // update_beta_init(cv_initial_model_param.row(k))
+      s->cur_rows = k + 1;                                  // update_train_mask + update_group_XTX
+      rc = algorithm_fit(s);
+      if (rc) break;
+      if (s->warm_start) s->cv_init[k] = s->beta;
+      rc = put(s->beta, s->coef0, s->l, metric_train_loss_value(s), metric_fold_test_loss(s, k));
+    }
+  }
+  s->metric_depth--;
+  return rc;
+}
+
+static void debug_sleep_cb(void *ms) {
+  std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)ms));
+}
+
+int bessx_session_debug_block_stream(bessx_session *s, int milliseconds) {
+  if (!s || milliseconds < 0) return fail(BESSX_ERR_ARG, "bad argument");
+  HIPX(hipSetDevice(s->device));
+  HIPX(hipLaunchHostFunc(s->st, debug_sleep_cb, reinterpret_cast<void *>((intptr_t)milliseconds)));
   return BESSX_OK;
 }
 

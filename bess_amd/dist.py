@@ -48,24 +48,6 @@ def select_best(curve):
     return int(np.argmin(curve))
 
 
-# ------------------------------------------------------------------------------------------------------------
-# Cross-validated paths with the fold fits dealt to ranks (BASELINE configs[3]).
-#
-# Under CV one candidate (s, lambda) = the full-data Algorithm::fit + K fold fits (Metric::test_loss,
-# src/Metric.h:150-195).  Every fold is its own warm-start chain (cv_initial_model_param.row(k), :177-188) and the
-# full-data fits are another one (src/path.cpp:60-64, :173-177); a fold fit reads nothing of the full-data fit of
-# the same candidate (its coef0_init is the one the path handed to that fit, i.e. the PREVIOUS candidate's).  So the
-# K + 1 chains are the independent units: unit u lives on rank u % world for the whole path, which keeps every
-# chain exactly as the single-process path runs it -- the results do not depend on the number of ranks.  X is
-# replicated; the only communication is one all-gather of the K + 1 small fit records per evaluation.
-#
-# (fold x s) pairs (the final sweep of gs_path, src/path.cpp:301-328): under the default warm start fold k
-# at size s + 1 starts from fold k at size s (cv_initial_model_param.row(k)), so the pairs of one fold ARE a chain and
-# at most K + 1 ranks have work; dealing them out singly would change the starting points and with them, possibly,
-# the supports.  With is_warm_start = False every (candidate, unit) pair is independent: whole batches of candidates
-# -- the sweep of gs_path, every size of sequential_path -- are dealt pair by pair to ALL ranks (_round_cold), with
-# results identical to the single-process path for any number of ranks.
-# ------------------------------------------------------------------------------------------------------------
 class _NoComm:
     """world = 1: the all-gather is the identity."""
 
@@ -86,6 +68,131 @@ class _TorchComm:
         return [o.cpu().numpy() for o in out]
 
 
+# ------------------------------------------------------------------------------------------------------------
+# The k-path in contiguous chunks whose gathered candidates EQUAL the single warm-start chain's for every k
+# (option (c) carried through; reference chain: src/path.cpp:60-64).
+#
+# Candidate k of sequential_path starts from candidate k-1's model.  Rank r walks its chunk [lo_r, hi_r) as a chain
+# of its own, whose first candidate has no predecessor (cold or ladder start): that chain may differ from the single
+# chain's for a few candidates (PDAS is a local fixed-point iteration).  After the chunks -- they are the parallel
+# part -- the chains are STITCHED: rank r takes rank r-1's last model (normalised coefficients, bit for bit), re-fits
+# its first candidate warm from it and keeps walking warm until a candidate coincides with its own chunk's (same
+# support, coefficients to the solver's tolerance); from there on the two chains are the same chain, and the
+# candidates in front of that point are replaced.  Rank r-1's last model is only final once ITS stitch has ended
+# without touching its last candidate, so the stitching runs in rounds until no last model changed (one round
+# unless a whole chunk had to be replaced; at most world-1).  X stays replicated; per step: the chunk, then per
+# round one all-gather of (flag, last model) -- a few KB -- and the all-gather of the IC curve.
+# ------------------------------------------------------------------------------------------------------------
+class StitchedKPath:
+    """`session` needs sequential_path_chain(sequence, ic_type=, init_idx=, init_val=, init_coef0=, keep_caches=,
+    stop_support=, stop_beta=, stop_rtol=) -> path result + stopped_at, last_idx, last_val, last_coef0
+    (bess_amd.capi.Session).  step() returns this rank's chunk of the single chain plus the gathered IC curve."""
+
+    def __init__(self, session, sequence, world=1, rank=0, ic_type=3, lead=(), device=None, stop_rtol=1e-9, comm=None):
+        self.s, self.world, self.rank = session, int(world), int(rank)
+        self.full_seq = np.asarray(sequence, dtype=np.int32)
+        self.kmax = int(self.full_seq.size)
+        self.ic_type = ic_type
+        self.lo, self.hi = partition(self.kmax, self.world, self.rank)
+        self.seq = self.full_seq[self.lo:self.hi]
+        self.lead = np.asarray([k for k in lead if self.lo > 0 and 1 <= k < (self.seq[0] if self.seq.size else 0)],
+                               dtype=np.int32)  # ladder start: sparsity levels walked in front of the chunk, discarded
+        self.comm = comm if comm is not None else (_TorchComm(device) if world > 1 else _NoComm())
+        self.stop_rtol = stop_rtol
+        self.width = int(self.full_seq.max()) if self.kmax else 1  # longest support of the path (singleton groups)
+
+    KEYS = ("cand_T0", "cand_iters", "cand_train_loss", "cand_ic", "cand_coef0", "cand_support", "cand_beta")
+
+    def _model_record(self, changed, idx, val, coef0):
+        rec = np.zeros(3 + 2 * self.width)
+        rec[0], rec[1], rec[2] = float(changed), len(idx), coef0
+        rec[3:3 + len(idx)] = idx
+        rec[3 + self.width:3 + self.width + len(idx)] = val
+        return rec
+
+    def _model_of(self, rec):
+        k = int(rec[1])
+        return rec[3:3 + k].astype(np.int32), rec[3 + self.width:3 + self.width + k].copy(), float(rec[2])
+
+    def step(self):
+        import time
+        t0 = time.time()
+        nl = int(self.lead.size)
+        mine = None
+        last = (np.zeros(0, np.int32), np.zeros(0), 0.0)
+        if self.seq.size:
+            out = self.s.sequential_path_chain(np.concatenate([self.lead, self.seq]), ic_type=self.ic_type)
+            mine = {k: np.array(out[k][nl:]) for k in self.KEYS}
+            last = (out["last_idx"], out["last_val"], out["last_coef0"])
+        t_chunk = time.time() - t0
+        refits, rounds = 0, 0
+        models = self.comm.all_gather(self._model_record(True, *last), self.world)
+        need = self.rank >= 1 and self.seq.size > 0  # round 1: every chunk but the first has a predecessor to meet
+        while True:
+            rounds += 1
+            changed = False
+            if need:
+                pi, pv, pc = self._model_of(models[self.rank - 1])
+                res = self.s.sequential_path_chain(self.seq, ic_type=self.ic_type, init_idx=pi, init_val=pv,
+                                                   init_coef0=pc, keep_caches=True, stop_support=mine["cand_support"],
+                                                   stop_beta=mine["cand_beta"], stop_rtol=self.stop_rtol)
+                m = int(res["n_candidates"])
+                for k in self.KEYS:
+                    a, b = mine[k], res[k]
+                    if a.ndim == 2:
+                        a[:m, :] = -1 if a.dtype.kind == "i" else 0.0
+                        a[:m, :b.shape[1]] = b[:m]
+                    else:
+                        a[:m] = b[:m]
+                refits += m
+                if res["stopped_at"] < 0:  # the whole chunk was replaced: its last model is a new one
+                    changed = True
+                    last = (res["last_idx"], res["last_val"], res["last_coef0"])
+            models = self.comm.all_gather(self._model_record(changed, *last), self.world)
+            flags = [bool(m[0]) for m in models]
+            if not any(flags):
+                break
+            need = self.rank >= 1 and self.seq.size > 0 and flags[self.rank - 1]
+            if rounds > self.world:
+                raise RuntimeError("stitching did not settle in world rounds")
+        t_stitch = time.time() - t0 - t_chunk
+        # the one result collective: the IC curve (and, for the report, this step's stitch statistics)
+        longest = -(-self.kmax // self.world)
+        buf = np.full(longest + 3, np.nan)
+        if mine is not None:
+            buf[:self.seq.size] = mine["cand_ic"]
+        buf[longest:] = (refits, t_chunk, t_stitch)
+        curve = np.empty(self.kmax)
+        stats = []
+        for r, b in enumerate(self.comm.all_gather(buf, self.world)):
+            lo, hi = partition(self.kmax, self.world, r)
+            curve[lo:hi] = b[:hi - lo]
+            stats.append(b[longest:])
+        stats = np.asarray(stats)
+        return {"chunk": mine, "ic_curve": curve, "best_k": int(self.full_seq[select_best(curve)]),
+                "stitch_refits": int(stats[:, 0].sum()), "stitch_refits_per_rank": [int(v) for v in stats[:, 0]],
+                "stitch_rounds": rounds, "chunk_seconds_per_rank": [float(v) for v in stats[:, 1]],
+                "stitch_seconds_per_rank": [float(v) for v in stats[:, 2]]}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Cross-validated paths with the fold fits dealt to ranks (SURVEY.md 8e, BASELINE configs[3]).
+#
+# Under CV one candidate (s, lambda) = the full-data Algorithm::fit + K fold fits (Metric::test_loss,
+# src/Metric.h:150-195).  Every fold is its own warm-start chain (cv_initial_model_param.row(k), :177-188) and the
+# full-data fits are another one (src/path.cpp:60-64, :173-177); a fold fit reads nothing of the full-data fit of
+# the same candidate (its coef0_init is the one the path handed to that fit, i.e. the PREVIOUS candidate's).  So the
+# K + 1 chains are the independent units: unit u lives on rank u % world for the whole path, which keeps every
+# chain exactly as the single-process path runs it -- the results do not depend on the number of ranks.  X is
+# replicated; the only communication is one all-gather of the K + 1 small fit records per evaluation.
+#
+# (fold x s) pairs (SURVEY 8e, the final sweep of gs_path, src/path.cpp:301-328): under the default warm start fold k
+# at size s + 1 starts from fold k at size s (cv_initial_model_param.row(k)), so the pairs of one fold ARE a chain and
+# at most K + 1 ranks have work; dealing them out singly would change the starting points and with them, possibly,
+# the supports.  With is_warm_start = False every (candidate, unit) pair is independent: whole batches of candidates
+# -- the sweep of gs_path, every size of sequential_path -- are dealt pair by pair to ALL ranks (_round_cold), with
+# results identical to the single-process path for any number of ranks.
+# ------------------------------------------------------------------------------------------------------------
 class FoldShardedCV:
     """sequential_path / gs_path under cross-validation (src/path.cpp:25-389 with Metric::is_cv) over `world`
     ranks.  `session` is this rank's solver on the replicated data with the folds already set
@@ -95,11 +202,12 @@ class FoldShardedCV:
 
     HEAD = 5  # record = [T0, iters, coef0, train_loss, test_loss, support[T0 ...], beta[T0 ...]]
 
-    def __init__(self, session, K, world=1, rank=0, is_warm_start=True, data_type=1, is_normal=True, device=None):
+    def __init__(self, session, K, world=1, rank=0, is_warm_start=True, data_type=1, is_normal=True, device=None,
+                 comm=None):
         self.s, self.K, self.world, self.rank = session, int(K), int(world), int(rank)
         self.warm = bool(is_warm_start)
         self.data_type, self.is_normal = data_type, is_normal
-        self.comm = _TorchComm(device) if world > 1 else _NoComm()
+        self.comm = comm if comm is not None else (_TorchComm(device) if world > 1 else _NoComm())
         self.units = [u for u in range(self.K + 1) if u % self.world == self.rank]  # unit K = the full-data chain
         self.per_rank = -(-(self.K + 1) // self.world)
         self.cv_init = {k: (np.zeros(0, np.int32), np.zeros(0)) for k in range(self.K)}  # cv_initial_model_param
@@ -126,6 +234,23 @@ class FoldShardedCV:
         reclen = self.HEAD + 2 * W
         mine = np.full((self.per_rank, reclen), np.nan)
         row = 0
+        if self.warm and getattr(self.s, "is_warm_start", False) and hasattr(self.s, "cv_eval"):
+            # the library evaluates this rank's share of the candidate in ONE call: the full-data fit (if this rank owns
+            # that chain) and its folds' fits -- side by side on their own streams with union fills where that applies,
+            # from the session's own per-fold warm starts (bessx_session_cv_eval)
+            own_full = bool(want_full) and self.K in self.units
+            folds = [u for u in self.units if u != self.K] if want_folds else []
+            init = full_init if full_init is not None else (np.zeros(0, np.int32), np.zeros(0))
+            got = self.s.cv_eval(T0, lam, own_full, init[0], init[1], coef0_init, folds) if (own_full or folds) else []
+            for u, r in zip(([self.K] if own_full else []) + folds, got):
+                mine[row, :self.HEAD] = (u, r["iters"], r["coef0"], r["train_loss"], r["test_loss"])
+                k = len(r["support"])
+                mine[row, self.HEAD:self.HEAD + W] = -1
+                mine[row, self.HEAD + W:] = 0.0
+                mine[row, self.HEAD:self.HEAD + k] = r["support"]
+                mine[row, self.HEAD + W:self.HEAD + W + k] = r["beta"]
+                row += 1
+            return self._gather_round(mine, W)
         for u in self.units:
             if u == self.K:
                 if not want_full:
@@ -145,6 +270,9 @@ class FoldShardedCV:
             mine[row, self.HEAD:self.HEAD + k] = r["support"]
             mine[row, self.HEAD + W:self.HEAD + W + k] = r["beta"]
             row += 1
+        return self._gather_round(mine, W)
+
+    def _gather_round(self, mine, W):
         recs = {}
         for block in self.comm.all_gather(mine, self.world):
             for rec in block:

@@ -14,6 +14,7 @@ SEED_LM = 20200308       # configs[1] and configs[3]
 SEED_LOGISTIC = 20200309  # configs[2]
 SEED_CV = 20200310       # configs[3] fold permutation
 SEED_COX = 20200311      # configs[4]
+SEED_POISSON = 20200312  # the Poisson family at the logistic shape
 
 
 def _design(rng, n, p):
@@ -47,6 +48,19 @@ def make_logistic(n=100000, p=5000, k_true=50, seed=SEED_LOGISTIC):
     eta = np.clip(X[:, support] @ beta[support], -30.0, 30.0)
     pr = np.exp(eta) / (1.0 + np.exp(eta))
     y = (rng.uniform(0.0, 1.0, n) < pr).astype(np.float64)
+    return X, y, support, beta
+
+
+def make_poisson(n=100000, p=5000, k_true=50, seed=SEED_POISSON):
+    """Poisson at the shape of configs[2]: y ~ Poisson(exp(clip(X beta / 16, -30, 30))) -- the reference's
+    generator scales the design by 1/16 for this family (python/bess/gen_data.py:60-73); here the design stays
+    N(0,1) and the scale sits in the linear predictor, which is the same model after column normalisation."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = _design(rng, n, p)
+    support, beta = _coef(rng, n, p, k_true, 2.0, 10.0)
+    beta = beta / 16.0
+    eta = np.clip(X[:, support] @ beta[support], -30.0, 30.0)
+    y = rng.poisson(np.exp(eta)).astype(np.float64)
     return X, y, support, beta
 
 

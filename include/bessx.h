@@ -160,7 +160,9 @@ int bessx_session_score_mode(const bessx_session *s);
  * 3 chained fits queued; 4-6 always 0 (background fills and the maintained inverse of round 2: measured, removed);
  * 7 rounds in which the fold fits of cross-validation ran side by side (one fit context per fold), 8 fills that served
  * several parked folds at once, 9 PDAS iterations redone with the exact tie rule, 10 times the Gram column cache was
- * started over since the last path call started.  -1 for an unknown id. */
+ * started over since the last path call started, 11 times bessx_session_set_cv had to give the per-fold fit contexts up
+ * (allocation or launch failure: the fold fits then run one after another -- slower, same results), 12 fold contexts
+ * alive now (K when the fold fits of a CV evaluation run side by side, else 0).  -1 for an unknown id. */
 long long bessx_session_counter(const bessx_session *s, int which);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)
@@ -195,6 +197,42 @@ typedef struct {
 int bessx_session_sequential_path(bessx_session *s, const int *sequence, int sequence_len,
                                   const double *lambda_seq, int lambda_len, int ic_type, int is_cv,
                                   bessx_path_result *res);
+/* sequential_path as ONE LINK of a longer warm-start chain (src/path.cpp:60-64: candidate i starts from candidate
+ * i-1's model) that several processes walk in pieces -- the k-path chunks of a multi-GPU run (bess_amd/dist.py,
+ * StitchedKPath).  in: the model the first candidate starts from = Algorithm::update_beta_init / update_coef0_init
+ * (src/Algorithm.h:85-93) with the predecessor's Algorithm::get_beta / get_coef0 (:97-111), NORMALISED scale, column
+ * indices of the session; keep_caches != 0: the call continues the job of the previous path call on this session (the
+ * cached Gram columns and score sums depend on the data only and stay), 0: it starts cold like every path call.
+ * stop_support / stop_beta (optional): candidates the caller already holds for this very sequence, laid out like
+ * cand_support / cand_beta of a bessx_path_result (row i = candidate i in evaluation order, stop_row_len entries, -1 / 0
+ * padded, caller's column numbering, de-normalised coefficients).  The path stops after the first candidate i whose
+ * support equals row i (and whose coefficients agree within stop_rtol when stop_beta is given): from there on the
+ * chain the caller holds IS this chain -- same model, hence the same successors.  That candidate is stored;
+ * stopped_at = i, or -1 when the whole sequence was walked.  The best model of the result is the best of the
+ * candidates evaluated.  out: last_* = the model the NEXT candidate of the chain would start from (normalised;
+ * last_len entries, min(last_len, last_cap) written).  Not offered under CV with an initial model (the folds' chains
+ * would have to be handed over as well). */
+typedef struct {
+  const int *init_idx;
+  const double *init_val;
+  int init_len;
+  double init_coef0;
+  int keep_caches;
+  const int *stop_support;
+  const double *stop_beta; /* may be NULL: supports only */
+  int stop_rows, stop_row_len;
+  double stop_rtol;
+  int stopped_at;          /* out */
+  int *last_idx;           /* caller-allocated, last_cap entries; may be NULL */
+  double *last_val;
+  int last_cap;
+  int last_len;            /* out */
+  double last_coef0;       /* out */
+} bessx_path_chain;
+int bessx_session_sequential_path_chain(bessx_session *s, const int *sequence, int sequence_len,
+                                        const double *lambda_seq, int lambda_len, int ic_type, int is_cv,
+                                        bessx_path_chain *chain, bessx_path_result *res);
+
 /* gs_path (src/path.cpp:134-389): integer golden section on [s_min, s_max] then exhaustive sweep. */
 int bessx_session_gs_path(bessx_session *s, int s_min, int s_max, int ic_type, int is_cv, bessx_path_result *res);
 
@@ -247,6 +285,26 @@ int bessx_session_fit_width(const bessx_session *s, int T0); /* -1: T0 outside [
 int bessx_session_fit(bessx_session *s, int T0, double lambda, int fold, const int *init_idx,
                       const double *init_val, int init_len, double init_coef0, int *support, double *beta,
                       double *coef0, int *iters, double *train_loss, double *test_loss);
+
+/* One evaluation of a cross-validated candidate restricted to SOME folds: Metric::test_loss (src/Metric.h:150-195) for
+ * the folds listed (ascending), preceded -- want_full != 0 -- by the full-data Algorithm::fit the path runs before it
+ * (src/path.cpp:58, :171).  What one rank of a fold-sharded CV path owns (bess_amd.dist.FoldShardedCV): the fold fits
+ * take the library's own route (LM covariance form: the chains side by side on their own streams, one fill of the
+ * shared Gram column caches for all parked folds), and start from the session's own per-fold warm starts
+ * (cv_initial_model_param.row(k), :177-188; cleared by every path call and by bessx_session_reset_caches).  init_* /
+ * init_coef0 = update_beta_init / update_coef0_init as the path sets them before the candidate (the full-data chain's
+ * previous model; the fold fits read coef0_init, and beta_init when the session was created without warm start).
+ * Outputs: want_full + n_folds records in the order [full,] folds[0], folds[1], ...; record r = support / beta
+ * [r * W .. (r+1) * W) with W = bessx_session_fit_width(s, T0), coef0[r], iters[r], train_loss[r], test_loss[r]
+ * (0 for the full-data fit) -- the fields of bessx_session_fit. */
+int bessx_session_cv_eval(bessx_session *s, int T0, double lambda, int want_full, const int *init_idx,
+                          const double *init_val, int init_len, double init_coef0, const int *folds, int n_folds,
+                          int *support, double *beta, double *coef0, int *iters, double *train_loss, double *test_loss);
+
+/* Test hook: queue a host function on the session's stream that sleeps for `milliseconds` -- everything queued behind
+ * it waits, as behind a wedged kernel (tests/test_deadline_gpu.py: the waits of the host give up at
+ * BESSX_WAIT_TIMEOUT_S instead of spinning for ever). */
+int bessx_session_debug_block_stream(bessx_session *s, int milliseconds);
 
 /* ---------------------------------------------------------------------------------------
  * 4. Single-kernel entry points (host buffers in, host buffers out; each call uploads,

@@ -5,6 +5,7 @@ Run once in the build container (it needs /root/reference to have been compiled 
 
     python tests/golden/make_fullsize_ref.py lm        # BASELINE configs[1], k = 1..200
     python tests/golden/make_fullsize_ref.py logistic  # BASELINE configs[2], k = 1..100
+    python tests/golden/make_fullsize_ref.py poisson   # the Poisson family at the configs[2] shape, k = 1..100
     python tests/golden/make_fullsize_ref.py lmcv      # BASELINE configs[3], gs_path on [1,200] + 5-fold CV
     python tests/golden/make_fullsize_ref.py cox 4000  # BASELINE configs[4] recipe at the largest n the
                                                        # reference's n x n risk-set matrix allows (p=2000, k=1..40)
@@ -76,6 +77,12 @@ def main():
         t0 = time.time()
         t = ref.trace(X, y, data_type=2, model_type=2, ic_type=3, sequence=np.arange(1, kmax + 1))
         extra = {"n": X.shape[0], "p": X.shape[1], "seed": synth.SEED_LOGISTIC, "true_support": support, "ic_type": 3}
+    elif which == "poisson":
+        kmax = kmax or 100
+        X, y, support, beta = synth.make_poisson(2000, 500, 10) if small else synth.make_poisson()
+        t0 = time.time()
+        t = ref.trace(X, y, data_type=2, model_type=3, ic_type=3, sequence=np.arange(1, kmax + 1))
+        extra = {"n": X.shape[0], "p": X.shape[1], "seed": synth.SEED_POISSON, "true_support": support, "ic_type": 3}
     elif which == "lmcv":
         X, y, support, beta = synth.make_lm(2000, 500, 10) if small else synth.make_lm()
         fold = synth.make_cv_folds(X.shape[0])

@@ -77,3 +77,87 @@ class NumpyLmSession:
         return {"support": A.astype(np.int32), "beta": bA, "coef0": float(init_coef0), "iters": l,
                 "train_loss": float(res @ res) / self.n,
                 "test_loss": float(res[test] @ res[test]) / (2 * max(int(test.sum()), 1)) if fold >= 0 else 0.0}
+
+    def sequential_path_chain(self, sequence, ic_type=3, init_idx=(), init_val=(), init_coef0=0.0, keep_caches=False,
+                              stop_support=None, stop_beta=None, stop_rtol=1e-9):
+        """Stand-in for capi.Session.sequential_path_chain (one link of a warm-start chain, src/path.cpp:60-64), GIC."""
+        seq = [int(v) for v in sequence]
+        W = max(seq)
+        bi, bv = np.asarray(init_idx, dtype=np.int32), np.asarray(init_val, dtype=np.float64)
+        out = {"cand_T0": [], "cand_iters": [], "cand_train_loss": [], "cand_ic": [], "cand_coef0": [],
+               "cand_support": [], "cand_beta": []}
+        stopped = -1
+        for i, T0 in enumerate(seq):
+            r = self.fit(T0, 0.0, -1, bi, bv, init_coef0)
+            bi, bv = r["support"], r["beta"]
+            sup = np.full(W, -1, dtype=np.int32)
+            sup[:T0] = r["support"]
+            b = np.zeros(W)
+            b[:T0] = np.sqrt(self.n) * r["beta"] / self.x_norm[r["support"]]
+            out["cand_T0"].append(T0)
+            out["cand_iters"].append(r["iters"])
+            out["cand_train_loss"].append(r["train_loss"])
+            out["cand_ic"].append(self.n * np.log(r["train_loss"]) + np.log(self.p) * np.log(np.log(self.n)) * T0)
+            out["cand_coef0"].append(self.y_mean - float(b[:T0] @ self.x_mean[r["support"]]))
+            out["cand_support"].append(sup)
+            out["cand_beta"].append(b)
+            if stop_support is not None and i < len(stop_support):
+                want = np.asarray(stop_support[i])
+                want = want[want >= 0]
+                if np.array_equal(want, r["support"]) and (stop_beta is None or np.allclose(
+                        np.asarray(stop_beta[i])[:T0], b[:T0], rtol=stop_rtol, atol=0)):
+                    stopped = i
+                    break
+        res = {k: np.asarray(v) for k, v in out.items()}
+        res.update({"n_candidates": len(out["cand_T0"]), "stopped_at": stopped, "last_idx": bi.copy(),
+                    "last_val": bv.copy(), "last_coef0": float(init_coef0)})
+        return res
+
+
+class ThreadComm:
+    """In-process stand-in for torch.distributed in tests that run N 'ranks' as N threads of one process (each with a
+    session of its own on the one GPU; ctypes releases the GIL inside the library): all_gather over a barrier."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.slots = [None] * world
+        self.barrier = threading.Barrier(world)
+
+    def view(self, rank):
+        parent = self
+
+        class _View:
+            def all_gather(self, mine, world):
+                parent.slots[rank] = np.array(mine, dtype=np.float64, copy=True)
+                parent.barrier.wait()
+                got = [parent.slots[r].copy() for r in range(parent.world)]
+                parent.barrier.wait()
+                return got
+        return _View()
+
+
+def run_ranks(world, fn):
+    """fn(rank, comm) on `world` threads; returns the list of results, re-raises the first exception."""
+    import threading
+    tc = ThreadComm(world)
+    res, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            res[r] = fn(r, tc.view(r))
+        except BaseException as e:  # noqa: BLE001 (a failed rank must not leave the others in the barrier for ever)
+            err[r] = e
+            tc.barrier.abort()
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, __import__("threading").BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    return res

@@ -54,8 +54,14 @@ def test_bench_gpus_2_starts_two_ranks_and_shards_the_k_path(gpu):
     assert abs(d["value"] - 30 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]  # ONE problem: 30 candidates / step
     rep = d["kpath_chunks_vs_single_chain"]
     assert rep["chunks"] == [[1, 15], [16, 30]] and rep["of"] == 30
-    assert rep["supports_equal_to_single_chain"] >= 25 and rep["best_k_chunked"] == rep["best_k_single_chain"]
+    # the chunks are stitched into the single warm-start chain: EVERY candidate's support equals the single chain's
+    assert rep["supports_equal_to_single_chain"] == rep["of"] and rep["differing_k"] == []
+    assert rep["best_k_chunked"] == rep["best_k_single_chain"] and rep["ic_curve_max_rel_diff_to_single_chain"] < 1e-10
+    assert rep["stitch_refits"] >= 1 and rep["stitch_rounds"] >= 1 and len(rep["stitch_seconds_per_rank"]) == 2
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    lad = _run_bench(["--gpus", "2", "--chunk-start", "ladder"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    rep = lad["kpath_chunks_vs_single_chain"]
+    assert rep["supports_equal_to_single_chain"] == rep["of"] and rep["chunk_start"] == "ladder"
 
 
 def test_bench_weak_scaling_and_cv_workload_on_two_ranks(gpu):
@@ -81,7 +87,8 @@ def test_bench_cox_k_path_on_two_ranks(gpu):
         assert abs(d["value"] - 30 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
         rep = d["kpath_chunks_vs_single_chain"]
         assert rep["chunks"] == [[1, 15], [16, 30]] and rep["of"] == 30 and rep["chunk_start"] == start
-        assert rep["supports_equal_to_single_chain"] >= 25 and rep["best_k_chunked"] == rep["best_k_single_chain"]
+        assert rep["supports_equal_to_single_chain"] == rep["of"] and rep["best_k_chunked"] == rep["best_k_single_chain"]
+        assert rep["ic_curve_max_rel_diff_to_single_chain"] < 1e-10 and rep["stitch_refits"] >= 1
         assert d["roofline"]["kernel"].startswith("k_cox_score1p") and d["roofline"]["achieved"] > 0
     one = _run_bench(["--workload", "cox-seq"])
     assert one["n_gpus"] == 1 and one["selected_k"] == d["kpath_chunks_vs_single_chain"]["best_k_single_chain"]

@@ -120,3 +120,62 @@ def test_grouped_cv_paths_from_the_fit_primitive(gpu, fam):
     sup = np.nonzero(want["beta"])[0]
     assert np.array_equal(np.nonzero(out[0]["beta"])[0], sup)
     np.testing.assert_allclose(out[0]["beta"][sup], want["beta"][sup], rtol=1e-5)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("path", ["gs", "seq"])
+def test_fold_subsets_through_the_library(gpu, world, path):
+    """bessx_session_cv_eval: every rank evaluates ITS folds of a candidate in one library call -- the chains side by
+    side, union fills -- and the full-data fit if it owns that chain.  Ranks = threads with a session each; every rank
+    ends with the library's own single-process CV path."""
+    from helpers import run_ranks
+    X, y, _, _ = synth.make_lm(1000, 300, 10)
+    fold = synth.make_cv_folds(1000, 5)
+    with gpu.Session(X, y, score_mode=2) as s:
+        s.set_cv(5, fold)
+        ref = s.gs_path(1, 30, ic_type=3, is_cv=True) if path == "gs" else \
+            s.sequential_path(np.arange(1, 16), ic_type=3, is_cv=True)
+
+    def rank_fn(rank, comm):
+        with gpu.Session(X, y, score_mode=2) as sr:
+            sr.set_cv(5, fold)
+            cv = bdist.FoldShardedCV(sr, 5, world, rank, comm=comm)
+            out = cv.gs_path(1, 30) if path == "gs" else cv.sequential_path(np.arange(1, 16))
+            return out, sr.counters(), len([u for u in cv.units if u != 5])
+
+    for out, cnt, nfolds in run_ranks(world, rank_fn):
+        assert out["best_T0"] == ref["best_T0"] and out["n_fits"] == ref["n_fits"]
+        assert out["n_pdas_iters"] == ref["n_pdas_iters"]
+        np.testing.assert_array_equal(out["cand_T0"], ref["cand_T0"])
+        np.testing.assert_allclose(out["cand_ic"], ref["cand_ic"], rtol=1e-12)
+        np.testing.assert_allclose(out["beta"], ref["beta"], rtol=1e-10)
+        np.testing.assert_allclose([out["coef0"], out["train_loss"], out["ic"]],
+                                   [ref["coef0"], ref["train_loss"], ref["ic"]], rtol=1e-10)
+        assert cnt["cv_fold_contexts"] == 5
+        assert (cnt["cv_side_by_side_rounds"] > 0) == (nfolds > 0)  # the folds took the chains' route, not fit by fit
+
+
+def test_cv_eval_records(gpu):
+    """The records of one call: [full,] folds in order, each what bessx_session_fit returns for that unit."""
+    X, y, _, _ = synth.make_lm(800, 200, 8, seed=2)
+    fold = synth.make_cv_folds(800, 4, seed=1)
+    with gpu.Session(X, y, score_mode=2) as a, gpu.Session(X, y, score_mode=2) as b:
+        a.set_cv(4, fold)
+        b.set_cv(4, fold)
+        recs = a.cv_eval(6, 0.0, True, folds=[1, 3])
+        assert len(recs) == 3
+        want = [b.fit(6, 0.0, -1), b.fit(6, 0.0, 1), b.fit(6, 0.0, 3)]
+        for r, w in zip(recs, want):
+            np.testing.assert_array_equal(r["support"], w["support"])
+            np.testing.assert_allclose(r["beta"], w["beta"], rtol=1e-9)
+            assert r["iters"] == w["iters"]
+            np.testing.assert_allclose([r["train_loss"], r["test_loss"]], [w["train_loss"], w["test_loss"]], rtol=1e-10)
+        # the next candidate continues the folds' own chains (cv_initial_model_param) inside the library
+        nxt = a.cv_eval(7, 0.0, False, init_idx=recs[0]["support"], init_val=recs[0]["beta"], folds=[1, 3])
+        w1 = b.fit(7, 0.0, 1, want[1]["support"], want[1]["beta"])
+        np.testing.assert_array_equal(nxt[0]["support"], w1["support"])
+        assert nxt[0]["iters"] == w1["iters"]
+        with pytest.raises(gpu.BessxError):
+            a.cv_eval(6, 0.0, False, folds=[3, 1])
+        with pytest.raises(gpu.BessxError):
+            a.cv_eval(6, 0.0, False, folds=[4])

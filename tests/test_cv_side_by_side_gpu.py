@@ -144,3 +144,45 @@ def test_fold_contexts_are_rebuilt_and_torn_down(gpu):
     want = P.trace(X, y, ic_type=3, is_cv=True, K=6, cv_fold_id=fold, path_type=2, s_min=1, s_max=15)
     np.testing.assert_allclose(b["ic"], want["ic"], rtol=1e-7)
     assert np.array_equal(np.nonzero(b["beta"])[0], np.nonzero(want["beta"])[0])
+
+
+def test_chains_opened_from_uploaded_supports_share_one_fill(gpu, monkeypatch):
+    """All K chains start from uploaded supports (their device state was lost to a fold fitted on the session's own
+    state) into a nearly full cache: the Gram columns of the K initial supports are formed by ONE fill whose restart is
+    decided once -- until round 3 every chain ran its own slot-0 lookup, and a later chain's restart evicted what an
+    earlier chain had just filled (BESSX_ERR_NUMERIC 'an active column was missing from the Gram column cache')."""
+    monkeypatch.setenv("BESSX_COV_CAP", "160")
+    X, y, _, _ = synth.make_lm(900, 2500, 20, seed=4)
+    fold = synth.make_cv_folds(900, 3, seed=1)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BESSX_CV_SIDE_BY_SIDE", mode)
+        with gpu.Session(X, y, score_mode=2) as s:
+            s.set_cv(3, fold)
+            recs, init = [], (np.zeros(0, np.int32), np.zeros(0))
+            for T0 in (26, 28, 30):
+                r = s.cv_eval(T0, 0.0, True, init[0], init[1], 0.0, [0, 1, 2])
+                init = (r[0]["support"], r[0]["beta"])
+                recs.append(r)
+            s.fit(6, 0.0, fold=1)  # a fold on the session's own state: the contexts lose their device state
+            recs.append(s.cv_eval(31, 0.0, True, init[0], init[1], 0.0, [0, 1, 2]))
+            recs.append(s.cv_eval(32, 0.0, False, init[0], init[1], 0.0, [0, 2]))
+            outs[mode] = (recs, s.counters())
+    (a, ca), (b, cb) = outs["1"], outs["0"]
+    assert ca["cv_side_by_side_rounds"] > 0 and cb["cv_side_by_side_rounds"] == 0
+    assert ca["cache_restarts"] > 0
+    for ra, rb in zip(a, b):
+        assert len(ra) == len(rb)
+        for x, z in zip(ra, rb):
+            np.testing.assert_array_equal(x["support"], z["support"])
+            assert x["iters"] == z["iters"]
+            np.testing.assert_allclose(x["beta"], z["beta"], rtol=1e-9, atol=1e-13)
+            np.testing.assert_allclose([x["train_loss"], x["test_loss"]], [z["train_loss"], z["test_loss"]], rtol=1e-10)
+
+
+def test_dropped_contexts_are_visible(gpu):
+    X, y, _, _ = synth.make_lm(600, 100, 5)
+    with gpu.Session(X, y, score_mode=2) as s:
+        s.set_cv(4, synth.make_cv_folds(600, 4))
+        c = s.counters()
+        assert c["cv_fold_contexts"] == 4 and c["cv_contexts_dropped"] == 0

@@ -127,3 +127,63 @@ def test_cv_sharding_is_independent_of_world_size():
     assert np.array_equal(np.nonzero(out["beta"])[0], np.nonzero(want["beta"])[0])
     np.testing.assert_allclose([out["coef0"], out["train_loss"], out["ic"]],
                                [want["coef0"], want["train_loss"], want["ic"]], rtol=1e-9)
+
+
+# ---- k-path chunks stitched into the single warm-start chain (bess_amd.dist.StitchedKPath) -------------------
+def _hard_lm(n=300, p=80, seed=3):
+    """Correlated columns and a weak signal: a chunk started cold lands in other local fixed points than the warm
+    chain, so the stitching has real work (half of the candidates of the cold chunks differ from the single chain)."""
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((n, p))
+    X = Z.copy()
+    for j in range(1, p):
+        X[:, j] = 0.8 * X[:, j - 1] + 0.6 * Z[:, j]
+    beta = np.zeros(p)
+    beta[rng.choice(p, 12, replace=False)] = rng.uniform(0.3, 1.0, 12) * rng.choice([-1.0, 1.0], 12)
+    return X, X @ beta + rng.standard_normal(n)
+
+
+def _stitch_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from bess_amd import dist as bdist
+    from helpers import NumpyLmSession
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    X, y = _hard_lm()
+    seq = np.arange(1, 25)
+    rep = bdist.StitchedKPath(NumpyLmSession(X, y, np.zeros(len(y), int), 1), seq, world, rank).step()
+    sup = np.full((len(seq), 24), -1)
+    lo, hi = bdist.partition(len(seq), world, rank)
+    sup[lo:hi, :rep["chunk"]["cand_support"].shape[1]] = rep["chunk"]["cand_support"]
+    np.savez(out_path + ".%d.npz" % rank, sup=sup, lo=lo, hi=hi, curve=rep["ic_curve"], best=rep["best_k"],
+             refits=rep["stitch_refits_per_rank"], rounds=rep["stitch_rounds"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_stitched_kpath_equals_the_single_chain(tmp_path, world):
+    """Chunks of the k-path on `world` gloo ranks, stitched: every candidate's support equals the single warm-start
+    chain's (the pinned oracle's sequential_path), although the cold chunks alone differ from it."""
+    sys.path.insert(0, ROOT)
+    from bess_amd import dist as bdist
+    from oracle import port_ctypes as P
+    out = str(tmp_path / "st")
+    mp.spawn(_stitch_worker, args=(world, 29600 + world, out), nprocs=world, join=True)
+    X, y = _hard_lm()
+    seq = np.arange(1, 25)
+    want = P.trace(X, y, ic_type=3, sequence=seq)
+    got = [np.load(out + ".%d.npz" % r) for r in range(world)]
+    for k, f in enumerate(want["fits"]):
+        r = [i for i in range(world) if got[i]["lo"] <= k < got[i]["hi"]][0]
+        assert np.array_equal(got[r]["sup"][k, :k + 1], f["iters"][-1]), k + 1
+    for g in got:
+        np.testing.assert_allclose(g["curve"], want["ic_calls"], rtol=1e-9)
+        assert int(g["best"]) == int(seq[int(np.argmin(want["ic_calls"]))])
+    # the cold chunks alone would NOT have been the single chain (the stitch replaced candidates)
+    assert int(np.sum(got[0]["refits"])) > world - 1
+    cold = P.trace(X, y, ic_type=3, sequence=seq[bdist.partition(len(seq), world, world - 1)[0]:])
+    assert any(not np.array_equal(c["iters"][-1], w["iters"][-1])
+               for c, w in zip(cold["fits"], want["fits"][bdist.partition(len(seq), world, world - 1)[0]:]))

@@ -1,0 +1,120 @@
+"""The k-path as links of ONE warm-start chain (bessx_session_sequential_path_chain, src/path.cpp:60-64) and the
+stitched chunks of a multi-rank run (bess_amd.dist.StitchedKPath): the gathered candidates equal the single chain's for
+every k -- the same supports, criteria and coefficients -- for LM (both score forms), logistic and Cox, cold and ladder
+starts.  The ranks are threads of this process, each with a session of its own on the one GPU."""
+import numpy as np
+import pytest
+
+from bess_amd import dist as bdist
+from bess_amd import synth
+from helpers import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def _hard(fam, n, p, seed=3):
+    """Correlated columns, weak signal: a chunk started cold settles in other local fixed points than the warm chain."""
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((n, p))
+    X = Z.copy()
+    for j in range(1, p):
+        X[:, j] = 0.8 * X[:, j - 1] + 0.6 * Z[:, j]
+    beta = np.zeros(p)
+    beta[rng.choice(p, 12, replace=False)] = rng.uniform(0.3, 1.0, 12) * rng.choice([-1.0, 1.0], 12)
+    eta = X @ beta
+    if fam == "lm":
+        return X, eta + rng.standard_normal(n), dict(data_type=1, model_type=1)
+    if fam == "logistic":
+        return X, (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(float), dict(data_type=2, model_type=2)
+    t = (-np.log(rng.uniform(size=n)) / np.exp(0.5 * eta)) ** 0.5
+    c = np.quantile(t, 0.8) * rng.uniform(size=n) * 2
+    st = (t < c).astype(float)
+    order = np.argsort(np.minimum(t, c), kind="stable")
+    return np.ascontiguousarray(X[order]), st[order], dict(data_type=3, model_type=4)
+
+
+CASES = [("lm", dict(score_mode=2)), ("lm", dict(score_mode=1)), ("logistic", {}), ("cox", {})]
+
+
+@pytest.mark.parametrize("fam,extra", CASES)
+def test_chain_links_equal_the_single_chain(gpu, fam, extra):
+    X, y, kw = _hard(fam, 1200, 150)
+    kw.update(extra)
+    seq = np.arange(1, 31)
+    with gpu.Session(X, y, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        for keep in (True, False):
+            head = s.sequential_path_chain(seq[:13], ic_type=3)
+            assert head["stopped_at"] == -1 and len(head["last_idx"]) == 13
+            tail = s.sequential_path_chain(seq[13:], ic_type=3, init_idx=head["last_idx"], init_val=head["last_val"],
+                                           init_coef0=head["last_coef0"], keep_caches=keep)
+            np.testing.assert_array_equal(head["cand_support"], single["cand_support"][:13, :13])
+            np.testing.assert_array_equal(tail["cand_support"], single["cand_support"][13:])
+            np.testing.assert_array_equal(tail["cand_iters"], single["cand_iters"][13:])
+            np.testing.assert_allclose(tail["cand_ic"], single["cand_ic"][13:], rtol=1e-11)
+            np.testing.assert_allclose(tail["cand_beta"], single["cand_beta"][13:], rtol=1e-8, atol=1e-12)
+        # stop at the first candidate that equals the caller's: here the very first one
+        again = s.sequential_path_chain(seq[13:], ic_type=3, init_idx=head["last_idx"], init_val=head["last_val"],
+                                        init_coef0=head["last_coef0"], keep_caches=True,
+                                        stop_support=single["cand_support"][13:], stop_beta=single["cand_beta"][13:])
+        assert again["stopped_at"] == 0 and again["n_candidates"] == 1
+        # ... and never, against a table of other supports
+        wrong = single["cand_support"][13:].copy()
+        wrong[:, 0] = (wrong[:, 0] + 1) % 150
+        walk = s.sequential_path_chain(seq[13:], ic_type=3, init_idx=head["last_idx"], init_val=head["last_val"],
+                                       init_coef0=head["last_coef0"], keep_caches=True, stop_support=wrong)
+        assert walk["stopped_at"] == -1 and walk["n_candidates"] == 17
+        np.testing.assert_array_equal(walk["cand_support"], single["cand_support"][13:])
+
+
+@pytest.mark.parametrize("fam,extra", CASES)
+@pytest.mark.parametrize("world,ladder", [(2, False), (3, True), (4, False)])
+def test_stitched_chunks_equal_the_single_chain(gpu, fam, extra, world, ladder):
+    X, y, kw = _hard(fam, 1200, 150)
+    kw.update(extra)
+    seq = np.arange(1, 33)
+    with gpu.Session(X, y, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        # what the chunks alone would have returned (no stitching): they do differ from the single chain on this design
+        lo = bdist.partition(len(seq), world, world - 1)[0]
+        cold = s.sequential_path(seq[lo:], ic_type=3)
+    differs = not np.array_equal(cold["cand_support"], single["cand_support"][lo:])
+
+    def rank_fn(rank, comm):
+        a, b = bdist.partition(len(seq), world, rank)
+        k0 = int(seq[a])
+        lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0}) if (ladder and a > 0) else []
+        with gpu.Session(X, y, **kw) as sr:
+            sk = bdist.StitchedKPath(sr, seq, world, rank, ic_type=3, lead=lead, comm=comm)
+            first = sk.step()
+            second = sk.step()  # a step starts cold again: same work, same result
+        np.testing.assert_array_equal(first["chunk"]["cand_support"], second["chunk"]["cand_support"])
+        assert first["stitch_refits_per_rank"] == second["stitch_refits_per_rank"]
+        return second
+
+    res = run_ranks(world, rank_fn)
+    W = single["cand_support"].shape[1]
+    for r, rep in enumerate(res):
+        a, b = bdist.partition(len(seq), world, r)
+        c = rep["chunk"]
+        sup = np.full((b - a, W), -1, dtype=np.int32)
+        sup[:, :c["cand_support"].shape[1]] = c["cand_support"]
+        np.testing.assert_array_equal(sup, single["cand_support"][a:b])
+        np.testing.assert_array_equal(c["cand_iters"], single["cand_iters"][a:b])
+        np.testing.assert_allclose(c["cand_ic"], single["cand_ic"][a:b], rtol=1e-11)
+        np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-11)
+        assert rep["best_k"] == single["best_T0"]
+    assert sum(res[0]["stitch_refits_per_rank"]) >= world - 1
+    if differs and not ladder:
+        assert sum(res[0]["stitch_refits_per_rank"]) > world - 1  # candidates were really replaced
+
+
+def test_chain_refuses_what_it_cannot_continue(gpu):
+    X, y, _, _ = synth.make_lm(600, 100, 5)
+    with gpu.Session(X, y) as s:
+        s.set_cv(4, synth.make_cv_folds(600, 4))
+        with pytest.raises(gpu.BessxError) as e:
+            s.sequential_path_chain([3, 4], ic_type=3, is_cv=True, init_idx=[1, 2], init_val=[0.5, 0.5])
+        assert e.value.code == 3
+        with pytest.raises(gpu.BessxError):
+            s.sequential_path_chain([3, 4], ic_type=3, init_idx=[1, 100], init_val=[0.5, 0.5])
