@@ -316,10 +316,13 @@ struct CovUnion {
   int nf;
   const int *list[8];  // the column sets that have to be cached when the fill is done
   int len[8];
+  int on_restart[8];   // 1: this set is already cached -- it is listed only if the cache is started over
 };
+// restart: 0 keep the cache, 1 start it over, 2 decide on the device -- start over iff the columns the due lists miss
+// (counted per list: an upper bound) do not fit the C-column cache; fill_ctrl->cov_nmiss tells which it was
 hipError_t launch_cov_fill_union(const CovUnion &u, int restart, const int *extras, const double *bd2, int spec_max,
                                  int spec_min, int *slot_of, int *meta, int p, int *fcols, FitCtrl *fill_ctrl,
-                                 hipStream_t st);
+                                 hipStream_t st, int C = 0);
 int cov_streamed_tiles_per_wave();
 hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, const double *mask, const int *fcols,
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,

@@ -2176,31 +2176,27 @@ static int fold_fits_side_by_side(bessx_session *s, double *out, const std::vect
   if (!openers.empty()) {
     // The first score pass of a chain that starts from an uploaded support multiplies the cached Gram columns of that
     // support: form the missing ones -- for ALL such chains in ONE fill on the shared slot map, before any chain reads
-    // it.  Whether the cache has to be started over is decided here, once, from its occupancy and the sum of the
-    // supports; when it is, the chains that continue from their device state get their current columns back in the
-    // same fill (their next selection only looks the ENTERING columns up).  (Until round 3 every chain ran its own
+    // it.  Whether the cache has to be started over is decided once, by the fill's own list kernel, from the cache's
+    // occupancy and the columns these supports miss; when it is, the chains that continue from their device state get
+    // their current columns back in the same fill (their next selection only looks the ENTERING columns up).  (Until round 3 every chain ran its own
     // slot-0 lookup one after another, and a later chain's restart could evict what an earlier one had just filled.)
     for (int k : openers) SBSH(hipStreamSynchronize(ch[k].c->st));
-    int meta_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    SBSH(hipMemcpyAsync(meta_h, s->cov[0].meta, sizeof(meta_h), hipMemcpyDeviceToHost, s->st));
-    SBSH(hipStreamSynchronize(s->st));
-    long want = 0;
-    for (int k : openers) want += ch[k].k_init;
-    const bool restart = meta_h[0] + want + COV_R > (long)cov_C_dev(s);
     CovUnion u = {};
     long ub = 0;
     for (int k = 0; k < K; k++) {
       Chain &q = ch[k];
       if (!q.active) continue;
       const bool opener = !q.use_cache && q.k_init > 0;
-      if (opener || (restart && q.use_cache && q.prev_T0 > 0)) {
+      if (opener || (q.use_cache && q.prev_T0 > 0)) {
         u.list[u.nf] = q.c->A_cur;
-        u.len[u.nf++] = opener ? q.k_init : q.prev_T0;
+        u.len[u.nf] = opener ? q.k_init : q.prev_T0;
+        u.on_restart[u.nf++] = opener ? 0 : 1;  // (a chain that continues from its device state: cached unless started over)
         ub += opener ? q.k_init : q.prev_T0;
       }
     }
-    SBSH(launch_cov_fill_union(u, restart ? 1 : 0, nullptr, nullptr, s->cov_spec, 0, s->cov[0].slot_of, s->cov[0].meta, p,
-                               s->cov_fcols, s->fill_ctrl, s->st));
+    // (restart = 2: the kernel starts the cache over iff the openers' missing columns do not fit what is left)
+    SBSH(launch_cov_fill_union(u, 2, nullptr, nullptr, s->cov_spec, 0, s->cov[0].slot_of, s->cov[0].meta, p, s->cov_fcols,
+                               s->fill_ctrl, s->st, cov_C_dev(s)));
     SBSH(hipMemcpyAsync(s->fill_ctrl_h, s->fill_ctrl, sizeof(FitCtrl), hipMemcpyDeviceToHost, s->st));
     SBSH(hipStreamSynchronize(s->st));
     s->cov_panel_groups += s->fill_ctrl_h->cov_groups - s->fill_groups_seen;

@@ -5818,10 +5818,26 @@ __global__ void k_cov_resume(FitCtrl *__restrict__ ctrl) {
 __global__ void __launch_bounds__(256) k_cov_fill_union(const CovUnion u, int restart, const int *__restrict__ extras,
                                                         const double *__restrict__ bd2, int spec_max, int spec_min,
                                                         int *__restrict__ slot_of, int *__restrict__ meta, int p,
-                                                        int *__restrict__ fcols, FitCtrl *__restrict__ fill_ctrl) {
+                                                        int *__restrict__ fcols, FitCtrl *__restrict__ fill_ctrl, int C) {
   __shared__ int wsum[4];
   __shared__ int s_ne;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (restart == 2) {
+    // decided here: the due lists' missing columns (a column two lists miss counts twice: an upper bound) against
+    // the room that is left
+    int ub = 0;
+    for (int f = 0; f < u.nf; f++) {
+      if (u.on_restart[f]) continue;
+      const int *__restrict__ list = u.list[f];
+      for (int base = 0; base < u.len[f]; base += 256) {
+        const int i = base + tid;
+        const int col = i < u.len[f] ? list[i] : -1;
+        ub += __syncthreads_count(col >= 0 && slot_of[col] < 0);
+      }
+    }
+    restart = (meta[0] + ub + COV_R > C) ? 1 : 0;
+    __syncthreads();
+  }
   if (restart) {
     for (int j = tid; j < p; j += 256) slot_of[j] = -1;
     __syncthreads();
@@ -5829,6 +5845,7 @@ __global__ void __launch_bounds__(256) k_cov_fill_union(const CovUnion u, int re
   const int count = restart ? 0 : meta[0];
   int nm = 0;
   for (int f = 0; f < u.nf; f++) {  // uniform
+    if (u.on_restart[f] && !restart) continue;
     const int *__restrict__ list = u.list[f];
     const int len = u.len[f];
     for (int base = 0; base < len; base += 256) {
@@ -5879,6 +5896,7 @@ __global__ void __launch_bounds__(256) k_cov_fill_union(const CovUnion u, int re
     fill_ctrl->cov_nfill = padded;
     fill_ctrl->cov_groups += padded / COV_R;
     fill_ctrl->k_cur = count + tot;
+    fill_ctrl->cov_nmiss = restart;  // (1: the cache was started over by this fill)
   }
 }
 
@@ -7472,10 +7490,10 @@ hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st) {
 
 hipError_t launch_cov_fill_union(const CovUnion &u, int restart, const int *extras, const double *bd2, int spec_max,
                                  int spec_min, int *slot_of, int *meta, int p, int *fcols, FitCtrl *fill_ctrl,
-                                 hipStream_t st) {
+                                 hipStream_t st, int C) {
   if (u.nf < 1 || u.nf > 8 || spec_max > 64 || spec_min < 0 || spec_min > spec_max) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_cov_fill_union, dim3(1), dim3(256), 0, st, u, restart, extras, bd2, spec_max, spec_min, slot_of, meta, p,
-                     fcols, fill_ctrl);
+                     fcols, fill_ctrl, C);
   LAUNCH_CHECK();
   return hipSuccess;
 }
