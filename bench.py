@@ -227,7 +227,114 @@ def cpu_baseline(X, y, gpu_out, sess_norm, kmax, budget_s):
             os.sched_setaffinity(0, set(cores))
 
 
-def measure_other_configs(local_rank, X_lm, y_lm):
+def _pin_one_core():
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        pinned = cores[len(cores) // 2]
+        os.sched_setaffinity(0, {pinned})
+        return cores, pinned
+    except (AttributeError, OSError):
+        return [], None
+
+
+def _mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return float(ln.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline_logistic(X, y, gpu_out, sess_norm, kmax, budget_s):
+    """configs[2] beside its GPU figure: the compiled reference (GroupPdasLogistic + LogisticMetric, src/Algorithm.h:
+    1148-1263, src/Metric.h:259-417) on the full n x p data, one core, two segments of the same warm-start chain -- the
+    head (k = 1, ...) and the far end (k = kmax-1, ... started from the GPU path's k = kmax-2 model: same support) --
+    each until the first candidate that ends beyond budget_s.  BASELINE.md section 3."""
+    from oracle import ref_ctypes as R
+    n, p = X.shape
+    base = {"unit": "candidates/s", "cores": 1, "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+    if not R.available():
+        return dict(base, value=None, kind="reference", sample="oracle/_ref/libbess_ref.so did not travel")
+    cores, pinned = _pin_one_core()
+    try:
+        head = R.time_chain(X, y, np.arange(1, 4), budget_s=budget_s, data_type=2, model_type=2)
+        segs = [("k=1..%d" % len(head["seconds"]), head)]
+        k0 = kmax - 2
+        xm, xn, _ = sess_norm
+        sup = gpu_out["cand_support"][k0 - 1][:k0]
+        bden = gpu_out["cand_beta"][k0 - 1][:k0]
+        init = bden * xn[sup] / np.sqrt(float(n))                 # back to the normalised scale
+        c0 = float(gpu_out["cand_coef0"][k0 - 1]) + float(np.dot(bden, xm[sup]))  # src/path.cpp:99-101 undone
+        tail = R.time_chain(X, y, np.arange(k0 + 1, kmax + 1), init_idx=sup, init_val=init, init_coef0=c0,
+                            budget_s=budget_s, data_type=2, model_type=2)
+        segs.append(("k=%d..%d (started from the GPU path's k=%d model)" % (k0 + 1, k0 + len(tail["seconds"]), k0), tail))
+        ok = list(tail["iters"]) == list(gpu_out["cand_iters"][k0:k0 + len(tail["iters"])])
+        cnt = sum(len(sg["seconds"]) for _, sg in segs)
+        sec = sum(float(np.sum(sg["seconds"])) for _, sg in segs)
+        return dict(base, value=cnt / sec, kind="reference", pinned_to_core=pinned, tail_iterations_match_gpu=ok,
+                    segments=[{"candidates": nm, "seconds_per_candidate": [round(float(v), 3) for v in sg["seconds"]],
+                               "pdas_iterations": [int(v) for v in sg["iters"]],
+                               "setup_seconds": round(sg["setup_seconds"], 2)} for nm, sg in segs],
+                    sample="%d candidates of the same chain on the full n=%d p=%d data in %.1f s (%s); package build "
+                           "(-O2, 1 thread)" % (cnt, n, p, sec, " + ".join(nm for nm, _ in segs)),
+                    recorded_full_path={"seconds": 4038.0, "candidates": 100, "value": 100 / 4038.0,
+                                        "host": "build container (8 vCPU), not the GPU box",
+                                        "source": "tests/golden/fullsize_logistic.npz: ref_wall_seconds"})
+    finally:
+        if cores:
+            os.sched_setaffinity(0, set(cores))
+
+
+def cpu_baseline_cox(X_full, status_full, budget_s):
+    """configs[4] beside its GPU figure.  The reference cannot run it (dense n x n risk-set matrix, src/Algorithm.h:1386:
+    320 GB at n = 200000), so: (a) the compiled reference at n = 1000 / 2000 / 4000 (p = 400, k = 1..8, the recipe of
+    configs[4]) -- documents its O(n^2); (b) the plain-C oracle (the build's own O(n k^2) restatement, kind "port") on
+    the FULL n = 200000, p = 20000 data for the first candidates of the chain, when the host has the memory for its
+    column-major copy of X (32 GB more)."""
+    from bess_amd import synth
+    from oracle import ref_ctypes as R
+    from oracle import port_ctypes as P
+    base = {"unit": "candidates/s", "cores": 1, "cpu_model": cpu_model(), "host_cores": os.cpu_count()}
+    cores, pinned = _pin_one_core()
+    try:
+        out = dict(base, pinned_to_core=pinned)
+        if R.available():
+            rows = []
+            for n in (1000, 2000, 4000):
+                Xs, _, st, _, _ = synth.make_cox(n, 400, 8)
+                tc = R.time_chain(Xs, st, np.arange(1, 9), budget_s=budget_s, data_type=3, model_type=4)
+                rows.append({"n": n, "p": 400, "candidates": int(len(tc["seconds"])),
+                             "seconds": round(float(np.sum(tc["seconds"])), 3),
+                             "candidates_per_s": float(len(tc["seconds"]) / max(np.sum(tc["seconds"]), 1e-9))})
+            out["reference_small_n"] = {"kind": "reference", "rows": rows,
+                                        "note": "compiled reference, k = 1..8 (or as many as fit %.0f s), p = 400: seconds grow "
+                                                "~ n^2 (the n x n matrix of src/Algorithm.h:1386); n = 200000 would need "
+                                                "320 GB" % budget_s}
+        n, p = X_full.shape
+        need = 8.0 * n * p / 1e9 + 8.0
+        if _mem_available_gb() > need:
+            t0 = time.time()
+            P.trace(X_full, status_full, data_type=3, model_type=4, ic_type=3, sequence=[1])
+            t1 = time.time() - t0
+            setup_s, path_s = P.last_timing()
+            out.update({"value": 1.0 / path_s, "kind": "port", "setup_seconds": round(setup_s, 1),
+                        "sample": "plain-C oracle (oracle/bess_oracle.c, the O(n k^2) restatement, 1 thread) on the full "
+                                  "n=%d p=%d data: candidate k = 1 of the chain in %.1f s (its column-major copy + "
+                                  "normalisation of X, %.1f s, excluded like the GPU figure excludes upload + normalise; "
+                                  "call %.1f s in all)" % (n, p, path_s, setup_s, t1)})
+        else:
+            out.update({"value": None, "kind": "port",
+                        "sample": "skipped: the oracle's own copy of X needs %.0f GB of host memory, %.0f available"
+                                  % (need, _mem_available_gb())})
+        return out
+    finally:
+        if cores:
+            os.sched_setaffinity(0, set(cores))
+
+
+def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
     """BASELINE configs[2] (logistic n=100k p=5k k<=100), configs[3] (LM gs_path + 5-fold CV on the configs[1] data)
     and configs[4] (Cox n=200k p=20k k<=150) on ONE GPU, one path each after one warm-up path (a path call starts from
     empty caches, so the repeat does the same work).  Per config: candidates/s, the kernel that streams X against the
@@ -286,8 +393,16 @@ def measure_other_configs(local_rank, X_lm, y_lm):
     X, y, _, _ = synth.make_logistic(100000, 5000, 50)
     with capi.Session(X, y, data_type=2, model_type=2, device=local_rank) as sess:
         setup = time.time() - t0
-        del X
-        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 101), ic_type=3), 100000, 5000)
+        keep = {}
+        rec = timed(sess, lambda: keep.setdefault("out", sess.sequential_path(np.arange(1, 101), ic_type=3)), 100000, 5000)
+        norm = sess.normalization()
+    if cpu_budget:
+        try:
+            rec["cpu_baseline"] = cpu_baseline_logistic(X, y, keep["out"], norm, 100, cpu_budget)
+        except Exception as e:
+            rec["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": 1, "kind": "reference",
+                                   "sample": "failed: %r" % (e,)}
+    del X, keep
     rec.update({"workload": "configs[2]: logistic PDAS + IRLS, sequential path k=1..100, n=100000 p=5000, GIC",
                 "score_kernel_name": "k_xtv<.., two accumulators> (X^T g and X^2^T h in one pass)",
                 "submodel": "IRLS step = k_irls_gram + k_gram_reduce + k_chol (3 launches)", "setup_seconds": setup})
@@ -296,8 +411,16 @@ def measure_other_configs(local_rank, X_lm, y_lm):
     X, _, st, _, _ = synth.make_cox(200000, 20000, 75)
     with capi.Session(X, st, data_type=3, model_type=4, device=local_rank) as sess:
         setup = time.time() - t0
-        del X
+        if not cpu_budget:
+            del X
         rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 151), ic_type=3), 200000, 20000)
+    if cpu_budget:
+        try:
+            rec["cpu_baseline"] = cpu_baseline_cox(X, st, cpu_budget)
+        except Exception as e:
+            rec["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": 1, "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+        del X
     rec.update({"workload": "configs[4]: Cox PDAS, sequential path k=1..150, n=200000 p=20000 (32 GB X), GIC",
                 "score_kernel_name": "k_cox_score1p (risk-set score, X read once)",
                 "submodel": "Newton step = linear predictor update, 4 scan launches, k_cox_hess (both Grams + gradient in "
@@ -566,7 +689,8 @@ def main():
         if world == 1 and not cox and not args.no_other_configs and (args.n, args.p, args.kmax) == (50000, 10000, 200):
             sess.close()
             try:
-                line["other_configs"] = measure_other_configs(local_rank, X, y)
+                line["other_configs"] = measure_other_configs(local_rank, X, y,
+                                                              None if args.no_cpu_baseline else args.cpu_budget)
             except Exception as e:  # never lose the headline line to a secondary measurement
                 line["other_configs"] = {"error": repr(e)}
         print(json.dumps(line))

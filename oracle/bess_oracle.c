@@ -16,6 +16,7 @@
  * section).  Group sizes > 1, screening and the Powell path are out of scope
  * (SURVEY.md section 8f).
  */
+#define _POSIX_C_SOURCE 199309L /* clock_gettime */
 #include "bess_oracle.h"
 
 #include <float.h>
@@ -23,6 +24,20 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+/* wall time of the last bess_oracle_run*: set-up (copy, normalise, group_XTX) and the path itself -- for bench.py's
+ * cpu_baseline leg (kind "port"), which reports them apart like the GPU figure excludes upload + normalise */
+static double g_last_setup_s = 0.0, g_last_path_s = 0.0;
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void bess_oracle_last_timing(double *setup_s, double *path_s) {
+  if (setup_s) *setup_s = g_last_setup_s;
+  if (path_s) *path_s = g_last_path_s;
+}
 
 /* ------------------------------------------------------------------ trace */
 
@@ -214,7 +229,9 @@ static int int_cmp(const void *a, const void *b) {
  * land in the first k positions is decided by exactly these moves, so they are restated step by step.  The reference's
  * toolchain is the pinned dependency here: the golden vectors and oracle/_ref are built with g++ 11.4 / libstdc++.
  * The heap-select branch (depth limit 2 floor(log2 len) exhausted) is restated too: small ranges reach it. */
-static const double *nth_vec;
+/* (per thread: bess_oracle_max_k alone may be called from several threads; the path functions may not -- their trace
+ * buffers are file-scope) */
+static __thread const double *nth_vec;
 static int nth_comp(int i, int j) { return nth_vec[i] > nth_vec[j]; }
 static void nth_swap(int *a, int *b) {
   int t = *a;
@@ -1835,6 +1852,8 @@ int bess_oracle_run3(const double *x, int n, int p, const double *y, const doubl
   opoint best;
   double *xtx;
   int i, j, k;
+  const double t_enter = now_s();
+  double t_path;
   if (n < 1 || p < 1 || model_type < 1 || model_type > 4) return 1;
   if (is_cv && (cv_fold_id == NULL || K < 2)) return 2;
   if (g_index == NULL) g_len = p;
@@ -1875,8 +1894,17 @@ int bess_oracle_run3(const double *x, int n, int p, const double *y, const doubl
     if (d.gsz[gq] > d.gmax) d.gmax = d.gsz[gq];
     d.goff[gq + 1] = d.goff[gq] + d.gsz[gq] * d.gsz[gq];
   }
+  /* row-major -> column-major in 64 x 64 blocks (the plain double loop crawls at BASELINE sizes: 32 GB for configs[4]) */
+  for (i = 0; i < n; i += 64) {
+    const int ie = i + 64 < n ? i + 64 : n;
+    for (j = 0; j < p; j += 64) {
+      const int je = j + 64 < p ? j + 64 : p;
+      int ii, jj;
+      for (jj = j; jj < je; jj++)
+        for (ii = i; ii < ie; ii++) d.x[(size_t)jj * n + ii] = x[(size_t)ii * p + jj];
+    }
+  }
   for (i = 0; i < n; i++) {
-    for (j = 0; j < p; j++) d.x[(size_t)j * n + i] = x[(size_t)i * p + j];
     d.y[i] = y[i];
     d.w[i] = weight[i];
   }
@@ -1929,6 +1957,8 @@ int bess_oracle_run3(const double *x, int n, int p, const double *y, const doubl
 
   best.beta = (double *)calloc((size_t)p, sizeof(double));
   best.coef0 = best.loss = best.ic = 0.0;
+  t_path = now_s();
+  g_last_setup_s = t_path - t_enter;
   if (path_type == 1) {
     seq_path(&a, &m, xtx, sequence, sequence_len, lambda_seq, lambda_len, &best);
   } else if (path_type == 3) {
@@ -1940,6 +1970,7 @@ int bess_oracle_run3(const double *x, int n, int p, const double *y, const doubl
     gs_path(&a, &m, xtx, s_min, s_max, &best);
   }
 
+  g_last_path_s = now_s() - t_path;
   memcpy(beta_out, best.beta, (size_t)p * sizeof(double));
   *coef0_out = best.coef0;
   *train_loss_out = best.loss;

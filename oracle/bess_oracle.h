@@ -83,6 +83,9 @@ int bess_oracle_last_heap_select(double *scores, int cap, int *k); /* ... and th
  * is read) by an un-pivoted LDL^T.  Returns 0, or 1 if a pivot is exactly zero. */
 int bess_oracle_sym_solve(const double *a, int k, const double *b, double *x);
 
+/* wall seconds of the last bess_oracle_run*: set-up (copy, normalise, group_XTX) and the path itself */
+void bess_oracle_last_timing(double *setup_s, double *path_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,15 @@ def trace_screened(x, y, screening_size, **kw):
     return t
 
 
+def last_timing():
+    """(set-up seconds, path seconds) of the last trace() call: copy + normalise + group_XTX, and the path itself."""
+    f = lib().bess_oracle_last_timing
+    f.restype = None
+    a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    f(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
 def nth_heap_selects():
     """How often max_k has taken the heap-select branch of the restated std::nth_element in this process."""
     f = lib().bess_oracle_nth_heap_selects
