@@ -77,6 +77,11 @@ def parse_args(argv=None):
                          "levels k0/8, k0/4, k0/2 first (their candidates are discarded); auto = ladder from k0 = 128 "
                          "(measured on configs[1], tools/coldstart.py: 11.2 vs 12.2 ms at k0 = 176, but 7.9 vs 7.2 ms at "
                          "k0 = 101)")
+    ap.add_argument("--prefill", default="auto",
+                    help="N > 1, --shard kpath, LM covariance form: columns of the cooperative prefill of the Gram column "
+                         "caches in front of the chunks (bess_amd.dist.cooperative_prefill: the ranks share the passes "
+                         "over X their cold starts would repeat; ONE data-path all-gather of p x 32 blocks).  0 = "
+                         "replicas only, as north_star partitions the path; auto = 320 for lm-seq, 0 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per timed segment")
     ap.add_argument("--shard", choices=["auto", "replica", "kpath"], default="auto",
@@ -515,7 +520,12 @@ def main():
     out = None
     stitch = None
     # N > 1, k-path: the chunks are stitched into the single warm-start chain every step (bess_amd.dist.StitchedKPath)
-    stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev) if kpath else None
+    prefill = 0
+    if kpath and covariance and not cox:
+        prefill = 320 if args.prefill == "auto" else int(args.prefill)
+        prefill = max(0, min(prefill, (args.p // 32) * 32, 1024)) // 32 * 32
+    stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev,
+                                   prefill=prefill) if kpath else None
     for _ in range(args.warmup):
         out = stitched.step() if kpath else sess.sequential_path(seq, ic_type=3)
     sess.enable_kernel_timing(True)
@@ -566,6 +576,11 @@ def main():
                 "stitch_seconds_per_rank": [round(v, 5) for v in stitch["stitch_seconds_per_rank"]],
                 "stitch_refits": stitch["stitch_refits"], "stitch_refits_per_rank": stitch["stitch_refits_per_rank"],
                 "stitch_rounds": stitch["stitch_rounds"],
+                "prefill_columns": prefill, "prefill_seconds_per_rank": [round(v, 5) for v in stitch["prefill_seconds_per_rank"]],
+                "prefill": ("cooperative prefill: the %d columns with the largest marginal scores are formed once, their "
+                            "32-column groups dealt to the ranks, the p x 32 blocks all-gathered (%d bytes per rank: a "
+                            "data-path collective north_star's partitioning does not have; --prefill 0 = replicas only)"
+                            % (prefill, prefill * args.p * 8)) if prefill else "none (replicas only)",
                 "stitching": "after its chunk rank r re-fits its first candidates warm from rank r-1's last model until "
                              "a candidate coincides with its chunk's (same support, coefficients to 1e-9); the "
                              "candidates before that point are replaced: the gathered path IS the single chain's",
@@ -627,7 +642,10 @@ def main():
                        "units_sharded": ("contiguous chunks of s.list, one warm-start chain per rank, X replicated"
                                          if kpath else "independent problems (one response vector per rank on a "
                                          "replicated X)" if distributed else "none (one GPU)"),
-                       "collective": "all_gather of the IC curve" if distributed else "none",
+                       "collective": ("all_gather of the IC curve + per stitch round one all_gather of the chunks' last "
+                                      "models" + (" + one all_gather of Gram column blocks (cooperative prefill)"
+                                                  if (kpath and prefill) else "")) if kpath else
+                                     ("all_gather of the IC curve" if distributed else "none"),
                        "score_pass": "covariance updates (cached Gram columns)" if covariance else "streaming",
                        # k-path chunks: every rank owns a chunk of at least one candidate as long as N <= kmax
                        "ranks_with_work": min(world, args.kmax) if kpath else world,

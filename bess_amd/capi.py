@@ -27,7 +27,9 @@ SYMBOLS = [
     "bessx_session_trace_enable", "bessx_session_trace_size", "bessx_session_trace_copy_int",
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_fit_width", "bessx_session_reset_caches",
-    "bessx_session_sequential_path_chain", "bessx_session_cv_eval", "bessx_session_debug_block_stream", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
+    "bessx_session_sequential_path_chain", "bessx_session_cv_eval", "bessx_session_debug_block_stream",
+    "bessx_session_marginal_scores", "bessx_session_cov_prefill_begin", "bessx_session_cov_prefill_compute",
+    "bessx_session_cov_prefill_export", "bessx_session_cov_prefill_import", "bessx_session_cov_prefill_end", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench", "bessx_op_cox_score_bench",
 ]
 
@@ -121,6 +123,12 @@ def lib():
                                                           ctypes.POINTER(PathResult)]
         L.bessx_session_cv_eval.argtypes = [_vp, _i, _d, _i, _I, _D, _i, _d, _I, _i, _I, _D, _D, _I, _D, _D]
         L.bessx_session_debug_block_stream.argtypes = [_vp, _i]
+        L.bessx_session_marginal_scores.argtypes = [_vp, _D]
+        L.bessx_session_cov_prefill_begin.argtypes = [_vp, _I, _i]
+        L.bessx_session_cov_prefill_compute.argtypes = [_vp, _i, _i]
+        L.bessx_session_cov_prefill_export.argtypes = [_vp, _i, _i, _vp, _i]
+        L.bessx_session_cov_prefill_import.argtypes = [_vp, _i, _i, _vp, _i]
+        L.bessx_session_cov_prefill_end.argtypes = [_vp]
         L.bessx_op_xtv.argtypes = [_D, _i, _i, _i, _D, _D, _D, _D]
         L.bessx_op_topk.argtypes = [_D, _i, _i, _I]
         L.bessx_op_gram.argtypes = [_D, _i, _i, _i, _I, _i, _D, _D]
@@ -423,6 +431,39 @@ class Session:
             recs.append({"support": sup[r][keep], "beta": b[r][keep], "coef0": float(c0[r]), "iters": int(it[r]),
                          "train_loss": float(tr[r]), "test_loss": float(te[r])})
         return recs
+
+    # ---- cooperative prefill of the Gram column cache (bessx_session_cov_prefill_*) ----
+    def marginal_scores(self):
+        bd = np.zeros(self.p_kept)
+        _check(lib().bessx_session_marginal_scores(self._h, _dp(bd)))
+        return bd
+
+    def cov_prefill_begin(self, cols):
+        c = _i32(cols)
+        _check(lib().bessx_session_cov_prefill_begin(self._h, _ip(c), c.size))
+
+    def cov_prefill_compute(self, g0, ngroups):
+        _check(lib().bessx_session_cov_prefill_compute(self._h, int(g0), int(ngroups)))
+
+    def cov_prefill_export(self, g0, ngroups, device_ptr=None):
+        """The p x 32 blocks of groups g0 .. g0+ngroups-1: into device memory at device_ptr, or returned as an array."""
+        if device_ptr is not None:
+            _check(lib().bessx_session_cov_prefill_export(self._h, int(g0), int(ngroups), _vp(int(device_ptr)), 1))
+            return None
+        out = np.empty(int(ngroups) * 32 * self.p_kept)
+        _check(lib().bessx_session_cov_prefill_export(self._h, int(g0), int(ngroups), out.ctypes.data_as(_vp), 0))
+        return out
+
+    def cov_prefill_import(self, g0, ngroups, blocks=None, device_ptr=None):
+        if device_ptr is not None:
+            _check(lib().bessx_session_cov_prefill_import(self._h, int(g0), int(ngroups), _vp(int(device_ptr)), 1))
+            return
+        b = _f64(blocks)
+        assert b.size == int(ngroups) * 32 * self.p_kept
+        _check(lib().bessx_session_cov_prefill_import(self._h, int(g0), int(ngroups), b.ctypes.data_as(_vp), 0))
+
+    def cov_prefill_end(self):
+        _check(lib().bessx_session_cov_prefill_end(self._h))
 
     def debug_block_stream(self, milliseconds):
         """Test hook: everything queued on the session's stream waits behind a host function that sleeps."""

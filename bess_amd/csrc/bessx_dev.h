@@ -281,7 +281,11 @@ hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxB
 hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
                               const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
                               double lambda, const double *beta_dense, const unsigned char *always, double *bd,
-                              hipStream_t st, int smax = 1, double *work = nullptr, double *zwork = nullptr);
+                              hipStream_t st, int smax = 1, double *work = nullptr, double *zwork = nullptr,
+                              const FitCtrl *ctrl = nullptr, int slot = 0);
+// find_ind on the device for groups of one width (k_group_expand)
+hipError_t launch_group_expand(const int *G_sel, int T0, int gs, const int *gidx, int *cols, const FitCtrl *ctrl,
+                               int slot, hipStream_t st);
 hipError_t launch_commit_group(FitCtrl *ctrl, int slot, int T0, const int *G_new, int K, const int *cols,
                                const double *sol, int has_intercept, int wait_chain, int *A_cur, double *b_cur,
                                double *beta_dense, int *hist, double *hist_beta, double *hist_coef0, int hist_stride,

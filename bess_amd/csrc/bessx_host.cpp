@@ -198,6 +198,7 @@ struct bessx_session {
   // groups (Data::g_index / g_size, src/Data.h:59-67); grouped == some group has more than one column
   bool grouped = false;
   int N = 0, gmax = 1;
+  int g_uniform = 0;  // width of every group when they all have the same one (> 1), else 0: find_ind on the device
   std::vector<int> gidx_h, gsz_h, goff_h;
   int *gidx = nullptr, *gsz = nullptr, *goff = nullptr, *gcols_new = nullptr;
   double *mblk = nullptr, *dcol = nullptr;
@@ -323,6 +324,7 @@ struct bessx_session {
   int bmm_owner = -1;                  // row set of the k_cov_d launch that wrote cov_bmm last
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
+  int prefill_cols = 0;            // columns listed by bessx_session_cov_prefill_begin (0: no prefill in progress)
   std::vector<std::pair<size_t, int>> cov_timed;  // (event index, first group) of the timed panel launches
   double *Rt = nullptr;
   int *gsrc = nullptr;
@@ -890,11 +892,14 @@ static int panel_variant_for(const bessx_session *s, int ng) {
   return (s->cov_variant == 3 && ng == 2 && s->cov_pair_auto) ? 4 : s->cov_variant;
 }
 
-static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const FitCtrl *gate = nullptr) {
+// gfirst / compact: a cooperative prefill (bessx_session_cov_prefill_*) forms only SOME groups of the list here and
+// fills the slot-indexed Gram GS once every group is in (its own and the ones imported from the other ranks)
+static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const FitCtrl *gate = nullptr,
+                            int gfirst = 0, bool compact = true) {
   bessx_session::CovCache &cv = s->cov[rs];
   const FitCtrl *gc = gate ? gate : s->ctrl;  // whose cov_stall / cov_nfill the launches look at
-  for (int g0 = 0; g0 < ngroups; g0 += COV_SLOT_GROUPS) {
-    const int ng = std::min(COV_SLOT_GROUPS, ngroups - g0);
+  for (int g0 = gfirst; g0 < gfirst + ngroups; g0 += COV_SLOT_GROUPS) {
+    const int ng = std::min(COV_SLOT_GROUPS, gfirst + ngroups - g0);
     hipEvent_t ea = nullptr, eb = nullptr;
     if (int rc = k1_begin(s, &ea, &eb)) return rc;
     hipError_t e = hipSuccess;
@@ -942,7 +947,7 @@ static int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, c
     if (e == hipSuccess)
       e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, gc, parked,
                             s->st);
-    if (e == hipSuccess)  // entries between cached columns, by slot: what the solve gathers from
+    if (e == hipSuccess && compact)  // entries between cached columns, by slot: what the solve gathers from
       e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, gc, parked, s->st, s->xtx[rs],
                              cv.meta);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
@@ -1487,6 +1492,66 @@ static int algorithm_fit_grouped(bessx_session *s) {
   std::vector<int> G(T0), cols;
   std::vector<std::vector<int>> cols_hist;
   int slot = 1;
+  // LM, every group of the same width: the selected groups are expanded to columns ON THE DEVICE (k_group_expand), so
+  // the number of active columns is known up front, the PDAS iterations are queued two at a time as gated slots like
+  // the ungrouped fit's, and the host reads ONE result block per batch -- one round trip for a warm-started fit that
+  // ends within two iterations (round 3: two synchronisations per iteration).  Ragged groups, the traced path and the
+  // other families keep the host-side expansion below.
+  if (!glm && s->g_uniform > 0 && !s->trace.on && (long)T0 * s->g_uniform + 2 <= (long)s->capA) {
+    const int gs = s->g_uniform, K = T0 * gs;
+    const int mt = (K + 1 + 15) / 16, mp = mt * 16, ntiles = mt * (mt + 1) / 2;
+    const GramTask *tk = nullptr;
+    int ntask = 0, rps, nslab;
+    if (int rc = gram_tasks_for(s, mt, &tk, &ntask)) return rc;
+    gram_geometry(s, ntask, &rps, &nslab, ntiles);
+    if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
+    const CholFuse fbz = chol_fallback_only(s);
+    std::vector<std::pair<size_t, bool>> k1_pairs;
+    while (slot <= s->max_iter) {
+      const int first = slot;
+      for (int b = 0; b < 2 && slot <= s->max_iter; b++, slot++) {
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (int rc = k1_begin(s, &ea, &eb)) return rc;
+        e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], nullptr, s->part_rs[rs], nullptr, s->ctrl, slot, s->st);
+        if (s->timing && e == hipSuccess) {
+          e = hipEventRecord(eb, s->st);
+          k1_pairs.push_back({s->ev_used - 2, false});
+        }
+        if (e == hipSuccess)
+          e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->part_rs[rs], s->nrb, s->p, 1,
+                                 (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork,
+                                 s->zwork, s->ctrl, slot);
+        if (e == hipSuccess)
+          e = launch_topk(s->bd, s->N, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
+        if (e == hipSuccess) e = launch_group_expand(s->A_new, T0, gs, s->gidx, s->gcols_new, s->ctrl, slot, s->st);
+        if (e == hipSuccess) e = launch_gram_cols(s->gcols_new, K, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 0, s->st);
+        if (e == hipSuccess)
+          e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, tk, ntask, nslab, s->gpart, ntiles, s->Gt,
+                          s->ctrl, slot, 0, s->st, 0);
+        if (e == hipSuccess)
+          e = mt <= 16 ? launch_chol(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info, s->ctrl,
+                                     slot, 0, s->st, &fbz)
+                       : launch_chol_big(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info,
+                                         s->rdiag, s->zbig, s->ctrl, slot, 0, s->st);
+        if (e == hipSuccess && mt <= 16)
+          e = launch_sym_fallback(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info, s->ctrl, slot,
+                                  s->st, &fbz);
+        if (e == hipSuccess)
+          e = launch_commit_group(s->ctrl, slot, T0, s->A_new, K, s->gcols_new, s->sol, 0, 0, s->A_cur, s->b_cur,
+                                  s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+        if (e == hipSuccess)
+          e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
+                              s->sse, s->st);
+        if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit (device expansion): ") + hipGetErrorString(e));
+      }
+      if (int rc = read_results(s)) return rc;
+      for (size_t i = 0; i < k1_pairs.size(); i++) k1_pairs[i].second = (first + (int)i) <= hc->l;
+      if (int rc = k1_collect(s, k1_pairs)) return rc;
+      k1_pairs.clear();
+      if (hc->done) break;
+    }
+    slot = s->max_iter + 1;  // (skip the host-side loop below)
+  }
   for (; slot <= s->max_iter; slot++) {
     // ---- get_A: per-group sacrifices and top-k over the groups
     if (!glm) {
@@ -3518,6 +3583,13 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       s->goff_h[g + 1] = (int)nxt;
     }
     s->grouped = s->gmax > 1;
+    s->g_uniform = 0;
+    if (s->grouped) {
+      bool same = true;
+      for (int g = 0; g < gl; g++) same = same && s->gsz_h[g] == s->gmax;
+      if (same) s->g_uniform = s->gmax;
+      if (std::getenv("BESSX_GROUP_EXPAND") && std::string(std::getenv("BESSX_GROUP_EXPAND")) == "host") s->g_uniform = 0;
+    }
     // groups of up to 16 columns: register-resident blocks and a Jacobi square root per thread; wider ones: tiled
     // moments and a Cholesky form of the same score (k_group_moments_big / k_group_score_big).  Cox forms the
     // suffix-sum matrix of whole groups in a 256-column panel.
@@ -3761,9 +3833,12 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       if (const char *ev = std::getenv("BESSX_PANEL_PAIR_AUTO")) s->cov_pair_auto = std::string(ev) != "0";
       // the pair kernel (variant 4) forms two 32-column groups per pass over X: fills then speculate up to 64 columns
       s->cov_spec = (s->cov_variant == 4 && p >= 4 * COV_R && topk_supported(p, 2 * COV_R)) ? 2 * COV_R : COV_R;
-      long C = std::min<long>(((long)p + 31) / 32 * 32 + COV_R + s->cov_spec, 2560);
-      const long budget = ((long)1 << 30) / ((long)p * 8);
-      C = std::min(C, budget / 32 * 32);
+      // capacity: EVERY column when that fits 2 GiB per row set (p <= ~16000: a path then forms a column at most once and
+      // the cache is never started over -- at 2560 columns the reference's default sequence 1..min(p, n / log n) at
+      // n = 25000, p = 3000 restarted it 1237 times and streamed X 73 000 times, round 4); else 2560 columns within 2 GiB
+      const long all = ((long)p + 31) / 32 * 32 + COV_R + s->cov_spec;
+      const long budget = (((long)2 << 30) / ((long)p * 8)) / 32 * 32;
+      long C = all <= budget ? all : std::min<long>(2560, budget);
       if (const char *ev = std::getenv("BESSX_COV_CAP"))  // test hook: a small cache exercises the restart path
         C = std::min<long>(C, std::max(0, std::atoi(ev)) / 32 * 32);
       if (C >= 2 * COV_R + s->cov_spec) {
@@ -4499,6 +4574,111 @@ int bessx_session_cv_eval(bessx_session *s, int T0, double lambda, int want_full
   }
   s->metric_depth--;
   return rc;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Cooperative prefill of the Gram column cache (LM, covariance form, all rows): the ranks of a k-path run share the
+// passes over X that every chunk's cold start would otherwise repeat (bess_amd/dist.py, cooperative_prefill).  All ranks
+// list the same columns -- slots are handed out in list order on a cache started over, so slot numbers agree across
+// ranks -- each forms its share of the 32-column groups, the p x 32 blocks travel (RCCL all-gather), every rank
+// imports the others' and fills the slot-indexed Gram once.  Cache contents only: no result depends on it.
+// ----------------------------------------------------------------------------------------------
+static int prefill_ready(bessx_session *s) {
+  if (!s) return fail(BESSX_ERR_ARG, "null session");
+  if (!s->cov_mode || s->model_type != 1 || s->grouped)
+    return fail(BESSX_ERR_UNSUPPORTED, "cov_prefill: the session does not run the covariance form of the LM score pass");
+  if (s->cv_shared) return fail(BESSX_ERR_UNSUPPORTED, "cov_prefill: not offered on sessions with cross-validation folds");
+  HIPX(hipSetDevice(s->device));
+  if (!s->fill_ctrl) {
+    HIPX(hipMalloc(reinterpret_cast<void **>(&s->fill_ctrl), sizeof(FitCtrl)));
+    HIPX(hipMemset(s->fill_ctrl, 0, sizeof(FitCtrl)));
+    HIPX(hipHostMalloc(reinterpret_cast<void **>(&s->fill_ctrl_h), sizeof(FitCtrl)));
+  }
+  return 0;
+}
+
+int bessx_session_marginal_scores(bessx_session *s, double *bd) {
+  if (!s || !bd) return fail(BESSX_ERR_ARG, "null argument");
+  if (s->model_type != 1 || s->grouped) return fail(BESSX_ERR_UNSUPPORTED, "marginal_scores: LM with singleton groups");
+  HIPX(hipSetDevice(s->device));
+  // get_A at beta = 0, lambda = 0 (src/Algorithm.h:1109-1123): d_j = x_j . y / n, bd_j = (d_j / phi_j)^2, phi_j^2 = x_j . x_j / n
+  std::vector<double> xty((size_t)s->p), xtx((size_t)s->p);
+  HIPX(hipStreamSynchronize(s->st));
+  HIPX(hipMemcpy(xty.data(), s->xty[0], xty.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPX(hipMemcpy(xtx.data(), s->xtx[0], xtx.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const double n = (double)s->n_train[0];
+  for (int j = 0; j < s->p; j++) {
+    const double phi = std::sqrt(xtx[j] / n), d = xty[j] / n;
+    const double t = d * (1.0 / phi);
+    bd[j] = t * t;
+  }
+  return BESSX_OK;
+}
+
+int bessx_session_cov_prefill_begin(bessx_session *s, const int *cols, int ncols) {
+  if (int rc = prefill_ready(s)) return rc;
+  if (!cols || ncols < 1 || ncols % COV_R != 0) return fail(BESSX_ERR_ARG, "cov_prefill: need a multiple of 32 columns");
+  if (ncols + s->cov_spec + COV_R > cov_C_dev(s) || ncols > s->capA)
+    return fail(BESSX_ERR_ARG, "cov_prefill: the list does not fit the Gram column cache");
+  std::vector<char> seen((size_t)s->p, 0);
+  for (int i = 0; i < ncols; i++) {
+    if (cols[i] < 0 || cols[i] >= s->p || seen[(size_t)cols[i]]) return fail(BESSX_ERR_ARG, "cov_prefill: bad column list");
+    seen[(size_t)cols[i]] = 1;
+  }
+  if (int rc = reset_path_caches(s)) return rc;
+  int *st_idx = reinterpret_cast<int *>(s->stage_h);
+  std::copy(cols, cols + ncols, st_idx);
+  HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, (size_t)ncols * sizeof(int), hipMemcpyHostToDevice, s->st));
+  CovUnion u = {};
+  u.nf = 1;
+  u.list[0] = s->init_idx_d;
+  u.len[0] = ncols;
+  HIPX(launch_cov_fill_union(u, 1, nullptr, nullptr, s->cov_spec, 0, s->cov[0].slot_of, s->cov[0].meta, s->p, s->cov_fcols,
+                             s->fill_ctrl, s->st));
+  HIPX(hipStreamSynchronize(s->st));  // (the staging buffer is free again)
+  s->prefill_cols = ncols;
+  return BESSX_OK;
+}
+
+int bessx_session_cov_prefill_compute(bessx_session *s, int g0, int ngroups) {
+  if (int rc = prefill_ready(s)) return rc;
+  if (g0 < 0 || ngroups < 0 || (g0 + ngroups) * COV_R > s->prefill_cols) return fail(BESSX_ERR_ARG, "cov_prefill: group range");
+  if (ngroups == 0) return BESSX_OK;
+  if (int rc = enqueue_cov_fill(s, 0, ngroups, 1, s->fill_ctrl, g0, false)) return rc;
+  s->cov_panel_groups += ngroups;
+  HIPX(hipStreamSynchronize(s->st));
+  return cov_collect(s, s->prefill_cols);
+}
+
+int bessx_session_cov_prefill_export(bessx_session *s, int g0, int ngroups, double *dst, int dst_on_device) {
+  if (int rc = prefill_ready(s)) return rc;
+  if (!dst || g0 < 0 || ngroups < 0 || (g0 + ngroups) * COV_R > s->prefill_cols) return fail(BESSX_ERR_ARG, "cov_prefill: group range");
+  const size_t cnt = (size_t)ngroups * COV_R * s->p;
+  HIPX(hipMemcpyAsync(dst, s->cov[0].G + (size_t)g0 * COV_R * s->p, cnt * sizeof(double),
+                      dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->st));
+  HIPX(hipStreamSynchronize(s->st));
+  return BESSX_OK;
+}
+
+int bessx_session_cov_prefill_import(bessx_session *s, int g0, int ngroups, const double *src, int src_on_device) {
+  if (int rc = prefill_ready(s)) return rc;
+  if (!src || g0 < 0 || ngroups < 0 || (g0 + ngroups) * COV_R > s->prefill_cols) return fail(BESSX_ERR_ARG, "cov_prefill: group range");
+  const size_t cnt = (size_t)ngroups * COV_R * s->p;
+  HIPX(hipMemcpyAsync(s->cov[0].G + (size_t)g0 * COV_R * s->p, src, cnt * sizeof(double),
+                      src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st));
+  HIPX(hipStreamSynchronize(s->st));  // (the caller's buffer is free again when the call returns)
+  return BESSX_OK;
+}
+
+int bessx_session_cov_prefill_end(bessx_session *s) {
+  if (int rc = prefill_ready(s)) return rc;
+  if (s->prefill_cols < COV_R) return fail(BESSX_ERR_ARG, "cov_prefill_end without cov_prefill_begin");
+  bessx_session::CovCache &cv = s->cov[0];
+  HIPX(launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, 0, s->prefill_cols / COV_R, cv.GS, s->cov_cs, s->fill_ctrl, 1,
+                          s->st, s->xtx[0], cv.meta));
+  HIPX(hipStreamSynchronize(s->st));
+  s->prefill_cols = 0;
+  return BESSX_OK;
 }
 
 static void debug_sleep_cb(void *ms) {

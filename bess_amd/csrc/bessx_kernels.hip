@@ -3369,7 +3369,9 @@ __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict
                                                     int nrb, int p, int lm, double n_t, double lambda,
                                                     const double *__restrict__ beta_dense,
                                                     const unsigned char *__restrict__ always,
-                                                    double *__restrict__ bd) {
+                                                    double *__restrict__ bd, const FitCtrl *__restrict__ ctrl,
+                                                    int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;  // (a speculative slot of a fit that has ended)
   const int g = blockIdx.x * 64 + threadIdx.x;
   if (g >= N) return;
   const int s = gsz[g], c0 = gidx[g];
@@ -3526,9 +3528,11 @@ __global__ void __launch_bounds__(256) k_group_score_big(int N, const int *__res
                                                          const double *__restrict__ beta_dense,
                                                          const unsigned char *__restrict__ always,
                                                          double *__restrict__ work, double *__restrict__ zwork,
-                                                         double *__restrict__ bd) {
+                                                         double *__restrict__ bd, const FitCtrl *__restrict__ ctrl,
+                                                         int slot) {
   __shared__ double sm[4];
   __shared__ double piv;
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
   const int g = blockIdx.x, s = gsz[g], c0 = gidx[g], tid = threadIdx.x;
   if (s <= GRP_MAX) return;
   double *W = work + goff[g];          // s x s, column-major: W[j * s + i] = element (i, j)
@@ -7354,16 +7358,35 @@ hipError_t launch_cox_group_moments(const double *X, long ld, int n, int p, CoxB
 hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
                               const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
                               double lambda, const double *beta_dense, const unsigned char *always, double *bd,
-                              hipStream_t st, int smax, double *work, double *zwork) {
+                              hipStream_t st, int smax, double *work, double *zwork, const FitCtrl *ctrl, int slot) {
   hipLaunchKernelGGL(k_group_score, dim3((N + 63) / 64), dim3(64), 0, st, N, gidx, gsz, goff, mblk, dcol, part, nrb, p,
-                     lm, n_t, lambda, beta_dense, always, bd);
+                     lm, n_t, lambda, beta_dense, always, bd, ctrl, slot);
   LAUNCH_CHECK();
   if (smax > GRP_MAX) {
     if (work == nullptr || zwork == nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_group_score_big, dim3(N), dim3(256), 0, st, N, gidx, gsz, goff, mblk, dcol, part, nrb, p, lm,
-                       n_t, lambda, beta_dense, always, work, zwork, bd);
+                       n_t, lambda, beta_dense, always, work, zwork, bd, ctrl, slot);
     LAUNCH_CHECK();
   }
+  return hipSuccess;
+}
+
+// find_ind (src/utilities.cpp:113-130) on the device for groups of ONE width gs: the T0 selected groups (ascending) ->
+// their T0 * gs columns, in order (all p columns when every group is selected: the same formula).  Gated like the
+// kernels around it, so that a PDAS iteration of a grouped fit needs no host round trip between selection and fit.
+__global__ void __launch_bounds__(256) k_group_expand(const int *__restrict__ G_sel, int T0, int gs,
+                                                      const int *__restrict__ gidx, int *__restrict__ cols,
+                                                      const FitCtrl *__restrict__ ctrl, int slot) {
+  if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= T0 * gs) return;
+  cols[i] = gidx[G_sel[i / gs]] + i % gs;
+}
+
+hipError_t launch_group_expand(const int *G_sel, int T0, int gs, const int *gidx, int *cols, const FitCtrl *ctrl,
+                               int slot, hipStream_t st) {
+  hipLaunchKernelGGL(k_group_expand, dim3((T0 * gs + 255) / 256), dim3(256), 0, st, G_sel, T0, gs, gidx, cols, ctrl, slot);
+  LAUNCH_CHECK();
   return hipSuccess;
 }
 

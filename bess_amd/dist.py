@@ -67,6 +67,70 @@ class _TorchComm:
         dist.all_gather(out, t)
         return [o.cpu().numpy() for o in out]
 
+    def exchange_blocks(self, session, world, rank, ng):
+        """The data-path collective of the cooperative prefill: every rank's p x 32 Gram column blocks to every rank.
+        Backend nccl (= RCCL over xGMI): the blocks never leave device memory -- the library copies them out of and into
+        its cache through the tensors' device pointers.  gloo (CPU tests, one-device rehearsal): through host arrays."""
+        import torch
+        import torch.distributed as dist
+        p = session.p_kept
+        longest = -(-ng // world)
+        lo, hi = partition(ng, world, rank)
+        on_dev = self.device is not None and str(self.device).startswith("cuda")
+        if on_dev:
+            buf = torch.zeros(longest * 32 * p, dtype=torch.float64, device=self.device)
+            if hi > lo:
+                session.cov_prefill_export(lo, hi - lo, device_ptr=buf.data_ptr())
+            out = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(out, buf)
+            torch.cuda.synchronize()
+            for r in range(world):
+                a, b = partition(ng, world, r)
+                if r != rank and b > a:
+                    session.cov_prefill_import(a, b - a, device_ptr=out[r].data_ptr())
+            return
+        mine = np.zeros(longest * 32 * p)
+        if hi > lo:
+            mine[:(hi - lo) * 32 * p] = session.cov_prefill_export(lo, hi - lo)
+        for r, blk in enumerate(self.all_gather(mine, world)):
+            a, b = partition(ng, world, r)
+            if r != rank and b > a:
+                session.cov_prefill_import(a, b - a, blk[:(b - a) * 32 * p])
+
+
+def cooperative_prefill(session, world, rank, comm, n_cols):
+    """Before the chunks of a k-path start cold: the ranks share the passes over X their cold starts would all repeat.
+    The list is the same on every rank -- the n_cols columns with the largest sacrifice scores at beta = 0, what the
+    first PDAS iteration of any cold fit ranks (src/Algorithm.h:1109-1128) --; rank r forms the Gram columns of its
+    contiguous share of the 32-column groups (one pass over X per group, two groups per pass with the pair kernel),
+    the p x 32 blocks are all-gathered (2.4 MB each at p = 10000: the ONE data-path collective of this mode, which
+    north_star's replicas-only partitioning does not have -- keep n_cols = 0 for that), and every rank's cache then
+    holds all of them under the same slots.  Columns a chunk needs beyond the list are formed by the rank itself, as
+    without the prefill.  Cache contents only: every result is what it is without it."""
+    ng = int(n_cols) // 32
+    if ng < 1:
+        return 0
+    scores = session.marginal_scores()
+    cols = np.argsort(-scores, kind="stable")[:ng * 32].astype(np.int32)
+    session.cov_prefill_begin(cols)
+    lo, hi = partition(ng, world, rank)
+    session.cov_prefill_compute(lo, hi - lo)
+    if world > 1:
+        if hasattr(comm, "exchange_blocks"):
+            comm.exchange_blocks(session, world, rank, ng)
+        else:
+            p = session.p_kept
+            longest = -(-ng // world)
+            mine = np.zeros(longest * 32 * p)
+            if hi > lo:
+                mine[:(hi - lo) * 32 * p] = session.cov_prefill_export(lo, hi - lo)
+            for r, blk in enumerate(comm.all_gather(mine, world)):
+                a, b = partition(ng, world, r)
+                if r != rank and b > a:
+                    session.cov_prefill_import(a, b - a, blk[:(b - a) * 32 * p])
+    session.cov_prefill_end()
+    return hi - lo
+
 
 # ------------------------------------------------------------------------------------------------------------
 # The k-path in contiguous chunks whose gathered candidates EQUAL the single warm-start chain's for every k
@@ -88,7 +152,8 @@ class StitchedKPath:
     stop_support=, stop_beta=, stop_rtol=) -> path result + stopped_at, last_idx, last_val, last_coef0
     (bess_amd.capi.Session).  step() returns this rank's chunk of the single chain plus the gathered IC curve."""
 
-    def __init__(self, session, sequence, world=1, rank=0, ic_type=3, lead=(), device=None, stop_rtol=1e-9, comm=None):
+    def __init__(self, session, sequence, world=1, rank=0, ic_type=3, lead=(), device=None, stop_rtol=1e-9, comm=None,
+                 prefill=0):
         self.s, self.world, self.rank = session, int(world), int(rank)
         self.full_seq = np.asarray(sequence, dtype=np.int32)
         self.kmax = int(self.full_seq.size)
@@ -99,6 +164,7 @@ class StitchedKPath:
                                dtype=np.int32)  # ladder start: sparsity levels walked in front of the chunk, discarded
         self.comm = comm if comm is not None else (_TorchComm(device) if world > 1 else _NoComm())
         self.stop_rtol = stop_rtol
+        self.prefill = int(prefill)  # columns of the cooperative prefill in front of the chunks (0: replicas only)
         self.width = int(self.full_seq.max()) if self.kmax else 1  # longest support of the path (singleton groups)
 
     KEYS = ("cand_T0", "cand_iters", "cand_train_loss", "cand_ic", "cand_coef0", "cand_support", "cand_beta")
@@ -120,8 +186,13 @@ class StitchedKPath:
         nl = int(self.lead.size)
         mine = None
         last = (np.zeros(0, np.int32), np.zeros(0), 0.0)
+        t_pre = 0.0
+        if self.prefill >= 32 and self.world > 1:
+            cooperative_prefill(self.s, self.world, self.rank, self.comm, self.prefill)
+            t_pre = time.time() - t0
         if self.seq.size:
-            out = self.s.sequential_path_chain(np.concatenate([self.lead, self.seq]), ic_type=self.ic_type)
+            out = self.s.sequential_path_chain(np.concatenate([self.lead, self.seq]), ic_type=self.ic_type,
+                                               keep_caches=t_pre > 0.0)
             mine = {k: np.array(out[k][nl:]) for k in self.KEYS}
             last = (out["last_idx"], out["last_val"], out["last_coef0"])
         t_chunk = time.time() - t0
@@ -158,10 +229,10 @@ class StitchedKPath:
         t_stitch = time.time() - t0 - t_chunk
         # the one result collective: the IC curve (and, for the report, this step's stitch statistics)
         longest = -(-self.kmax // self.world)
-        buf = np.full(longest + 3, np.nan)
+        buf = np.full(longest + 4, np.nan)
         if mine is not None:
             buf[:self.seq.size] = mine["cand_ic"]
-        buf[longest:] = (refits, t_chunk, t_stitch)
+        buf[longest:] = (refits, t_chunk - t_pre, t_stitch, t_pre)
         curve = np.empty(self.kmax)
         stats = []
         for r, b in enumerate(self.comm.all_gather(buf, self.world)):
@@ -172,7 +243,8 @@ class StitchedKPath:
         return {"chunk": mine, "ic_curve": curve, "best_k": int(self.full_seq[select_best(curve)]),
                 "stitch_refits": int(stats[:, 0].sum()), "stitch_refits_per_rank": [int(v) for v in stats[:, 0]],
                 "stitch_rounds": rounds, "chunk_seconds_per_rank": [float(v) for v in stats[:, 1]],
-                "stitch_seconds_per_rank": [float(v) for v in stats[:, 2]]}
+                "stitch_seconds_per_rank": [float(v) for v in stats[:, 2]],
+                "prefill_seconds_per_rank": [float(v) for v in stats[:, 3]]}
 
 
 # ------------------------------------------------------------------------------------------------------------

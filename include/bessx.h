@@ -301,6 +301,23 @@ int bessx_session_cv_eval(bessx_session *s, int T0, double lambda, int want_full
                           const double *init_val, int init_len, double init_coef0, const int *folds, int n_folds,
                           int *support, double *beta, double *coef0, int *iters, double *train_loss, double *test_loss);
 
+/* Cooperative prefill of the Gram column cache (LM, covariance form of the score pass, all rows; not on sessions with
+ * CV folds): several sessions that hold the SAME data -- the ranks of a multi-GPU k-path -- share the passes over X that
+ * each of their cold starts would repeat.  Every rank lists the same columns (begin: the cache is started over and slot
+ * i goes to cols[i], so slot numbers agree across ranks), forms the Gram columns X^T x_c of ITS groups of 32 (compute),
+ * hands the p x 32 blocks out (export; group g = 32 * p doubles, column after column) and takes the others' in (import),
+ * then fills the slot-indexed Gram between cached columns once (end).  A path call that follows with
+ * bessx_path_chain.keep_caches finds the columns cached.  Cache contents only -- no result depends on it; the blocks
+ * are bit-identical to what the rank would have formed itself.  bessx_session_marginal_scores: the sacrifice scores of
+ * get_A at beta = 0 (src/Algorithm.h:1109-1123), what the first PDAS iteration of a cold fit ranks -- the list is
+ * their top M.  *_on_device: the buffer is device memory of this session's device (else host memory). */
+int bessx_session_marginal_scores(bessx_session *s, double *bd /* p */);
+int bessx_session_cov_prefill_begin(bessx_session *s, const int *cols, int ncols /* multiple of 32, distinct */);
+int bessx_session_cov_prefill_compute(bessx_session *s, int g0, int ngroups);
+int bessx_session_cov_prefill_export(bessx_session *s, int g0, int ngroups, double *dst, int dst_on_device);
+int bessx_session_cov_prefill_import(bessx_session *s, int g0, int ngroups, const double *src, int src_on_device);
+int bessx_session_cov_prefill_end(bessx_session *s);
+
 /* Test hook: queue a host function on the session's stream that sleeps for `milliseconds` -- everything queued behind
  * it waits, as behind a wedged kernel (tests/test_deadline_gpu.py: the waits of the host give up at
  * BESSX_WAIT_TIMEOUT_S instead of spinning for ever). */

@@ -1,0 +1,62 @@
+"""Group selection with groups of one width: the selected groups are expanded to columns on the device
+(k_group_expand; find_ind, src/utilities.cpp:113-130) and the PDAS iterations of a fit are queued as gated slots, one
+host round trip per batch.  Same fits as the host-side expansion (BESSX_GROUP_EXPAND=host: two synchronisations per
+iteration, round 3's form) and as the oracle: every candidate's groups, iteration counts, coefficients, criteria."""
+import numpy as np
+import pytest
+
+from bess_amd import synth
+from oracle import port_ctypes as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _grouped_lm(n, G, gs, k_true, seed):
+    rng = np.random.default_rng(seed)
+    p = G * gs
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    for g in rng.choice(G, k_true, replace=False):
+        beta[g * gs:(g + 1) * gs] = rng.uniform(0.3, 1.5, gs) * rng.choice([-1.0, 1.0], gs)
+    y = X @ beta + rng.standard_normal(n)
+    return X, y, np.arange(0, p, gs).astype(np.int32)
+
+
+@pytest.mark.parametrize("gs,G,T", [(5, 120, 14), (2, 200, 30), (20, 40, 6), (5, 150, 60), (3, 40, 40)])
+def test_uniform_groups_expand_on_the_device(gpu, monkeypatch, gs, G, T):
+    X, y, g_index = _grouped_lm(1500, G, gs, 6, seed=gs + G)
+    outs = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("BESSX_GROUP_EXPAND", mode)
+        with gpu.Session(X, y, g_index=g_index, algorithm_type=2) as s:
+            outs[mode] = (s.sequential_path(np.arange(1, T + 1), ic_type=3), s.gs_path(1, min(T, 20), ic_type=3))
+    for a, b in zip(outs["device"], outs["host"]):
+        np.testing.assert_array_equal(a["cand_support"], b["cand_support"])
+        np.testing.assert_array_equal(a["cand_iters"], b["cand_iters"])
+        np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-12)
+        np.testing.assert_allclose(a["cand_beta"], b["cand_beta"], rtol=1e-10, atol=1e-14)
+        assert a["best_T0"] == b["best_T0"] and a["n_pdas_iters"] == b["n_pdas_iters"]
+    if G * gs <= 600 and T <= 30:
+        want = P.trace(X, y, ic_type=3, sequence=np.arange(1, T + 1), g_index=g_index, algorithm_type=2)
+        got = outs["device"][0]
+        sup = np.nonzero(want["beta"])[0]
+        assert np.array_equal(np.nonzero(got["beta"])[0], sup)
+        np.testing.assert_allclose(got["beta"][sup], want["beta"][sup], rtol=1e-6)
+        np.testing.assert_allclose(got["cand_ic"], want["ic_calls"], rtol=1e-8)
+        assert list(got["cand_iters"]) == [len(f["iters"]) for f in want["fits"]]
+
+
+def test_grouped_cv_and_ridge_paths_on_the_device_path(gpu, monkeypatch):
+    X, y, g_index = _grouped_lm(1200, 80, 4, 5, seed=11)
+    fold = synth.make_cv_folds(1200, 4, seed=2)
+    outs = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("BESSX_GROUP_EXPAND", mode)
+        with gpu.Session(X, y, g_index=g_index, algorithm_type=3) as s:
+            s.set_cv(4, fold)
+            outs[mode] = (s.sequential_path(np.arange(1, 11), [0.0, 0.05], ic_type=3, is_cv=True),
+                          s.gs_path(1, 12, ic_type=3, is_cv=True))
+    for a, b in zip(outs["device"], outs["host"]):
+        np.testing.assert_array_equal(a["cand_support"], b["cand_support"])
+        np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-12)
+        assert a["n_fits"] == b["n_fits"] and a["n_pdas_iters"] == b["n_pdas_iters"]

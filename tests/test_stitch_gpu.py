@@ -118,3 +118,83 @@ def test_chain_refuses_what_it_cannot_continue(gpu):
         assert e.value.code == 3
         with pytest.raises(gpu.BessxError):
             s.sequential_path_chain([3, 4], ic_type=3, init_idx=[1, 100], init_val=[0.5, 0.5])
+
+
+def test_cooperative_prefill_fills_the_same_cache(gpu):
+    """bessx_session_cov_prefill_*: three ranks (threads, a session each) form one group of 32 Gram columns each, exchange
+    the p x 32 blocks and end with the cache one rank alone would have built -- bit for bit --, which is X^T x_c of the
+    normalised design; a path that continues on it (keep_caches) returns what it returns without it, with fewer passes."""
+    X, y, _, _ = synth.make_lm(1500, 400, 10)
+    seq = np.arange(1, 41)
+    with gpu.Session(X, y, score_mode=2) as s:
+        plain = s.sequential_path(seq, ic_type=3)
+        passes_plain = s.counters()["passes_over_X"]
+        scores = s.marginal_scores()
+        cols = np.argsort(-scores, kind="stable")[:96].astype(np.int32)
+        s.cov_prefill_begin(cols)
+        s.cov_prefill_compute(0, 3)
+        full = s.cov_prefill_export(0, 3)
+        s.cov_prefill_end()
+        before = s.counters()["passes_over_X"]
+        kept = s.sequential_path_chain(seq, ic_type=3, keep_caches=True)
+        passes_kept = s.counters()["passes_over_X"] - before
+        xm, xn, ym = s.normalization()
+    np.testing.assert_array_equal(kept["cand_support"], plain["cand_support"])
+    np.testing.assert_allclose(kept["cand_ic"], plain["cand_ic"], rtol=1e-11)
+    assert passes_kept < passes_plain
+    Xn = np.sqrt(1500.0) * (X - xm) / xn
+    want = (Xn.T @ Xn[:, cols]).T.ravel()  # column after column, p entries each
+    np.testing.assert_allclose(full, want, rtol=1e-10, atol=1e-7)
+    # the first PDAS iteration of a cold fit ranks exactly these scores
+    d = Xn.T @ (y - ym) / 1500.0
+    np.testing.assert_allclose(scores, d * d, rtol=1e-9, atol=1e-12)
+
+    # every rank ends with the same blocks: read them back before anything restarts the cache
+    def rank_blocks(rank, comm):
+        with gpu.Session(X, y, score_mode=2) as sr:
+            sc = sr.marginal_scores()
+            cl = np.argsort(-sc, kind="stable")[:96].astype(np.int32)
+            sr.cov_prefill_begin(cl)
+            lo, hi = bdist.partition(3, 3, rank)
+            sr.cov_prefill_compute(lo, hi - lo)
+            mine = sr.cov_prefill_export(lo, hi - lo)
+            for r, blk in enumerate(comm.all_gather(mine, 3)):
+                if r != rank:
+                    sr.cov_prefill_import(r, 1, blk)
+            got = sr.cov_prefill_export(0, 3)
+            sr.cov_prefill_end()
+            out = sr.sequential_path_chain(seq, ic_type=3, keep_caches=True)
+            return got, out["cand_support"]
+
+    for got, sup in run_ranks(3, rank_blocks):
+        np.testing.assert_array_equal(got, full)
+        np.testing.assert_array_equal(sup, plain["cand_support"])
+    with gpu.Session(X, y, score_mode=1) as s1:
+        with pytest.raises(gpu.BessxError) as e:
+            s1.cov_prefill_begin(cols)
+        assert e.value.code == 3
+    with gpu.Session(X, y, score_mode=2) as s2:
+        with pytest.raises(gpu.BessxError):
+            s2.cov_prefill_begin(cols[:40])  # not a multiple of 32
+        with pytest.raises(gpu.BessxError):
+            s2.cov_prefill_begin(np.concatenate([cols[:31], cols[:1]]))  # a column twice
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_stitched_chunks_with_the_cooperative_prefill(gpu, world):
+    X, y, kw = _hard("lm", 1200, 400)
+    seq = np.arange(1, 33)
+    with gpu.Session(X, y, score_mode=2, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+
+    def rank_fn(rank, comm):
+        with gpu.Session(X, y, score_mode=2, **kw) as sr:
+            return bdist.StitchedKPath(sr, seq, world, rank, ic_type=3, comm=comm, prefill=128).step()
+
+    res = run_ranks(world, rank_fn)
+    for r, rep in enumerate(res):
+        a, b = bdist.partition(len(seq), world, r)
+        c = rep["chunk"]["cand_support"]
+        np.testing.assert_array_equal(c, single["cand_support"][a:b, :c.shape[1]])
+        np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-11)
+        assert min(rep["prefill_seconds_per_rank"]) > 0.0
