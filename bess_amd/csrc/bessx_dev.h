@@ -315,6 +315,23 @@ struct CovRowSets {
 hipError_t launch_cov_reduce_compact_sets(const double *part, int p, const int *fcols, const int *slot_of, int *meta,
                                           const CovRowSets &rs, int g0, int ngroups, int nslab, int CS,
                                           const FitCtrl *ctrl, int parked, hipStream_t st);
+// Conjugate gradients for the LM systems of the covariance form beyond the register-resident solvers (bessx_cgbig.hip):
+// one launch per step, every workgroup multiplies its 8 rows of the dense k x k copy of the cached Gram entries.
+constexpr int CGB_MAX_K = 4096;  // the search direction lives in LDS (32 KB), 16 vector elements per thread in registers
+struct CgbState {
+  double rr[2];   // |r|^2 of the last two steps (by step parity)
+  double qq;      // |q|^2
+  int done_step;  // step at which the recurrence residual reached its target (0x7fffffff: not yet)
+  int steps;      // steps taken
+};
+struct CgbWork {
+  double *x, *q, *r[2], *p[2], *ap[2], *part_pq[2], *part_qq;
+  CgbState *st;
+};
+size_t cgb_work_doubles(int kcap);  // work space (the dense matrix first) for systems of up to kcap unknowns
+hipError_t launch_cg_big(const double *G, int p, const int *slot_of, const int *meta, const int *A_new, int k,
+                         double ridge, const double *xty, const double *beta_dense, double *work, int kcap, double *sol,
+                         FitCtrl *ctrl, int slot, int nsteps, double tol, hipStream_t st);
 // one fill for several parked fits that share a slot map (k_cov_fill_union)
 struct CovUnion {
   int nf;

@@ -325,6 +325,8 @@ struct bessx_session {
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
   int prefill_cols = 0;            // columns listed by bessx_session_cov_prefill_begin (0: no prefill in progress)
+  double *cgb_work = nullptr;      // large-system conjugate gradients (bessx_cgbig.hip): dense matrix + vectors, on first use
+  int cgb_cap = 0, cgb_guess = 40; // ... unknowns it holds; step launches queued per solve (adapted to the steps the last took)
   std::vector<std::pair<size_t, int>> cov_timed;  // (event index, first group) of the timed panel launches
   double *Rt = nullptr;
   int *gsrc = nullptr;
@@ -523,6 +525,7 @@ static void session_free(bessx_session *s) {
     F(c.zero);
   }
   F(s->cov_part);
+  F(s->cgb_work);
   F(s->bd2);
   F(s->inA);
   F(s->cov_bmm);
@@ -991,13 +994,39 @@ static CholFuse cov_fuse_args(bessx_session *s, int rs, int T0, bool force_chol,
   return fz;
 }
 
+// work space of the large-system conjugate gradients (bessx_cgbig.hip), on first use: 134 MB at 4096 unknowns
+static int cgb_reserve(bessx_session *s) {
+  bessx_session *owner = s->parent ? s->parent : s;
+  if (!owner->cgb_work) {
+    const int kcap = std::min(owner->cap, CGB_MAX_K);
+    if (dmalloc(&owner->cgb_work, cgb_work_doubles(kcap)) != hipSuccess) {
+      (void)hipGetLastError();
+      owner->cgb_work = nullptr;
+      return 1;  // (no memory: the blocked Cholesky does it)
+    }
+    owner->cgb_cap = kcap;
+  }
+  s->cgb_work = owner->cgb_work;
+  s->cgb_cap = owner->cgb_cap;
+  return 0;
+}
+
 // solve + commit + residual of a slot whose active columns are all cached
 static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, bool force_chol = false,
                             SlotFuse *sf = nullptr) {
   const int mt = (T0 + 1 + 15) / 16;
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
-  if (mt > 16) {
+  if (mt > 16 && s->cov_cg && !force_chol && T0 <= CGB_MAX_K && cgb_reserve(s) == 0) {
+    // beyond the register-resident solvers: conjugate gradients over the whole chip, one launch per step
+    // (bessx_cgbig.hip); an iterate whose true residual misses the target parks the fit (cov_stall = 2) and the
+    // blocked Cholesky below finishes the slot (force_chol)
+    e = launch_cg_big(cv.G, s->p, cv.slot_of, cv.meta, s->A_new, T0, lambda, s->xty[rs], s->beta_dense, s->cgb_work,
+                      s->cgb_cap, s->sol, s->ctrl, slot, s->cgb_guess, s->cg_tol, s->st);
+    if (e == hipSuccess)
+      e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+                        s->hist_beta, s->hist_coef0, s->hist_stride, s->st, s->inA);
+  } else if (mt > 16) {
     e = launch_cov_gram(cv.G, s->p, cv.slot_of, s->A_new, T0, mt, s->Gt, cv.meta, s->ctrl, slot, s->st);
     if (e == hipSuccess)
       e = launch_chol_big(s->Gt, T0, mt, lambda, 0, s->xty[rs], s->A_new, s->sol, &s->ctrl->info, s->rdiag, s->zbig,
@@ -1113,6 +1142,7 @@ static int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda
   if (hc->cov_stall == 2) {
     // the conjugate-gradient solve did not reach its residual target: Cholesky for this slot
     s->cov_cg_fallbacks++;
+    if ((T0 + 1 + 15) / 16 > 16) s->cgb_guess = 64;  // (large system: perhaps only short of step launches)
     HIPX(launch_cov_resume(s->ctrl, s->st));
     if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs, true)) return rc;
     *next_slot = stalled + 1;
@@ -1973,6 +2003,8 @@ static int algorithm_fit(bessx_session *s) {
   if (cov) {
     s->cov_panel_groups += hc->cov_groups;
     if (hc->cov_miss) return fail(BESSX_ERR_NUMERIC, "internal error: an active column was missing from the Gram column cache");
+    // large systems: as many conjugate-gradient step launches per solve as the last solve took, and a few
+    if ((T0 + 1 + 15) / 16 > 16 && hc->irls_last > 0) s->cgb_guess = std::max(12, std::min(64, hc->irls_last + 8));
   }
   while (!glm && !cov) {
     int first = slot;

@@ -5686,7 +5686,18 @@ __device__ void cov_need_body(const int *__restrict__ list, int len, const doubl
     if (!diff) return;  // A == A_list.col(l-1): nothing to solve, nothing to look up
   }
   int count = meta[0];
-  const bool restart = count + len + COV_R > C;  // no room: start the cache over (uniform branch)
+  bool restart = count + len + COV_R > C;  // no room: start the cache over (uniform branch)
+  if (restart) {
+    // (that test counts the columns of the set that ARE cached as well; before the cache is given up, count the ones
+    // really missing -- with a cache that holds every column of the design the answer is always "there is room")
+    int missing = 0;
+    for (int base = 0; base < len; base += NT) {
+      const int i = base + tid;
+      const int col = i < len ? list[i] : -1;
+      missing += __syncthreads_count(col >= 0 && slot_of[col] < 0);
+    }
+    restart = count + missing + COV_R > C;
+  }
   if (restart && no_restart && slot > 0) {
     // fold chains running side by side share the slot map: nobody rewrites it under the others.  Park the fit
     // (cov_stall = 4); the host starts the cache over when every chain is quiet (k_cov_fill_union)
