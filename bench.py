@@ -393,7 +393,50 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
                 "fits_per_s": rec["fits"] / (rec["ms_per_path"] / 1e3), "score_kernel_name": "k_cov_panel (32 Gram "
                 "columns of every row set per pass over the fold-major copy of X)", "setup_seconds": setup})
     res["lmcv"] = rec
+    # SURVEY 8f rank 3, group selection: the configs[1] design as 2000 groups of 5 columns, 1..40 groups
+    t0 = time.time()
+    with capi.Session(X_lm, y_lm, data_type=1, model_type=1, algorithm_type=2, g_index=np.arange(0, p, 5, dtype=np.int32),
+                      device=local_rank) as sess:
+        setup = time.time() - t0
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 41), ic_type=3), n, p)
+    rec.update({"workload": "SURVEY 8f: grouped LM (algorithm_type 2), the configs[1] data as %d groups of 5 columns, "
+                            "sequential path over 1..40 groups, GIC" % (p // 5),
+                "score_kernel_name": "k_xtv (X^T r, one pass over X per PDAS iteration; the per-group sacrifices "
+                                     "follow in k_group_score)",
+                "host_round_trips": "one per batch of two PDAS iterations (the selected groups are expanded to columns on "
+                                    "the device, k_group_expand)", "setup_seconds": setup})
+    res["grouped_lm"] = rec
     del X_lm
+    # the reference's DEFAULT call: sequence = 1..min(p, n / log n) (python/bess/linear.py:285-287) at n = 25000, p = 3000
+    nd, pd = 25000, 3000
+    kd = min(pd, int(nd / np.log(nd)))
+    Xd, yd, sup_d, _ = synth.make_lm(nd, pd, 12, seed=9)
+    t0 = time.time()
+    with capi.Session(Xd, yd, data_type=1, model_type=1, max_sparsity=kd, device=local_rank) as sess:
+        setup = time.time() - t0
+        del Xd
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, kd + 1), ic_type=4), nd, pd)
+        cnt = sess.counters()
+    rec.update({"workload": "the reference's default sequence 1..min(p, n / log n) = 1..%d (python/bess/linear.py:285-287), "
+                            "LM n=%d p=%d, EBIC: sparsity levels far beyond the register-resident solvers" % (kd, nd, pd),
+                "score_kernel_name": "k_cov_panel (32 Gram columns per pass over X; every column of the design is formed "
+                                     "once: the cache holds all p columns)",
+                "submodel": "k > 254: conjugate gradients on the dense copy of the cached Gram entries, one launch per "
+                            "step over the whole chip (bessx_cgbig.hip); Cholesky hand-overs: %d" % cnt["cg_fallbacks"],
+                "round_3_seconds": 24.0, "setup_seconds": setup})
+    res["default_sequence"] = rec
+    # SURVEY 8f rank 1, Poisson at the shape of configs[2]
+    t0 = time.time()
+    X, y, _, _ = synth.make_poisson(100000, 5000, 50)
+    with capi.Session(X, y, data_type=2, model_type=3, device=local_rank) as sess:
+        setup = time.time() - t0
+        del X
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 101), ic_type=3), 100000, 5000)
+    rec.update({"workload": "SURVEY 8f: Poisson PDAS + IRLS (warm-started), sequential path k=1..100, n=100000 p=5000, GIC; "
+                            "pinned by tests/golden/fullsize_poisson.npz (compiled reference)",
+                "score_kernel_name": "k_xtv<.., two accumulators> (X^T g and X^2^T h in one pass)",
+                "submodel": "IRLS step = k_irls_gram + k_gram_reduce + k_chol (3 launches)", "setup_seconds": setup})
+    res["poisson"] = rec
     t0 = time.time()
     X, y, _, _ = synth.make_logistic(100000, 5000, 50)
     with capi.Session(X, y, data_type=2, model_type=2, device=local_rank) as sess:
@@ -499,12 +542,6 @@ def main():
         lo, hi = bdist.partition(args.kmax, world, rank)
         seq = full_seq[lo:hi]
         k0 = int(seq[0]) if len(seq) else 0
-        if args.chunk_start == "auto":
-            # (LM, covariance form: the ladder saves Gram-column passes at large k0; Cox: every rung pays its own passes
-            # over X and the cold start is faster at every k0 -- tools/coldstart.py, tools/coldstart_cox.py)
-            args.chunk_start = "ladder" if (k0 >= 128 and not cox) else "cold"
-        if args.chunk_start == "ladder" and lo > 0:
-            lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
     t0 = time.time()
     mode = {"auto": 0, "streaming": 1, "covariance": 2}[args.score_mode]
     if cox:
@@ -524,6 +561,15 @@ def main():
     if kpath and covariance and not cox:
         prefill = 320 if args.prefill == "auto" else int(args.prefill)
         prefill = max(0, min(prefill, (args.p // 32) * 32, 1024)) // 32 * 32
+    if kpath:
+        if args.chunk_start == "auto":
+            # measured on configs[1], 8 chunks on one GPU (tools/coldstart.py, tools/coop_prefill.py, profiles/r04_*):
+            # without the prefill the ladder saves Gram-column passes at large k0 (11.5 vs 12.5 ms for the slowest chunk),
+            # on the prefilled cache the cold start is faster (9.5 vs 10.1 ms); Cox: every rung pays its own passes over
+            # X and the cold start is faster at every k0 (tools/coldstart_cox.py)
+            args.chunk_start = "ladder" if (k0 >= 128 and not cox and not prefill) else "cold"
+        if args.chunk_start == "ladder" and lo > 0:
+            lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
     stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev,
                                    prefill=prefill) if kpath else None
     for _ in range(args.warmup):

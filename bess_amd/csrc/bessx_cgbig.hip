@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) k_cgb_init(const double *__restrict__ A, 
     if (wg == 0) {
       w.st->done_step = 0x7fffffff;
       w.st->steps = 0;
+      ctrl->sse_valid = 0;  // (the loss terms of an earlier solve do not belong to this slot's coefficients)
       w.st->rr[0] = w.st->rr[1] = 1.0;
       // two exactly dependent columns are cached: a singular but consistent system must go to the pivoted route
       // (k_cov_compact's flag, see cov_compact_body) -- park the fit, the host issues the Cholesky for the slot
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(256) k_cgb_resid(const double *__restrict__ A,
       const int row = row0 + 2 * wave + h;
       if (row < k) {
         const double rho = w.q[row] - (ax[h] + ridge * ps[row]);
+        w.r[0][row] = rho;  // (the step buffers are free now: k_cgb_accept forms the loss terms from it)
         ss = fma(rho, rho, ss);
       }
     }
@@ -240,7 +242,8 @@ __global__ void __launch_bounds__(256) k_cgb_resid(const double *__restrict__ A,
   if (tid == 0) w.part_pq[0][wg] = ((sm[0] + sm[1]) + sm[2]) + sm[3];  // (the step buffers are free now)
 }
 
-__global__ void __launch_bounds__(256) k_cgb_accept(int k, int nwg, double tol, CgbWork w, double *__restrict__ sol,
+__global__ void __launch_bounds__(256) k_cgb_accept(const double *__restrict__ A, int lda, int k, int nwg, double tol,
+                                                    double ridge, double yy, CgbWork w, double *__restrict__ sol,
                                                     FitCtrl *__restrict__ ctrl, int slot) {
   if (!cgb_gate(ctrl, slot)) return;
   __shared__ double sm[8];
@@ -256,9 +259,32 @@ __global__ void __launch_bounds__(256) k_cgb_accept(int k, int nwg, double tol, 
     }
     return;
   }
-  for (int i = tid; i < k; i += 256) sol[i] = w.x[i];
-  if (tid == 0) ctrl->irls_steps = w.st->steps;  // (the commit moves it to irls_last: the host sizes its next batch of
-                                                 // step launches from it)
+  // the solution, and the loss without a pass over X (as in the small systems' solve, cgr_body):
+  // |y - X b|^2 = y.y - b.(q + rho) - ridge |b|^2 with rho the residual of the normal equations just recomputed
+  double t1 = 0.0, t2 = 0.0, t3 = 0.0, gd = 0.0;
+  for (int i = tid; i < k; i += 256) {
+    const double x = w.x[i], qr = w.q[i] + w.r[0][i];
+    sol[i] = x;
+    t1 = fma(x, qr, t1);
+    t2 = fma(x, x, t2);
+    t3 = fma(fabs(x), fabs(qr), t3);
+    gd = fmax(gd, A[(size_t)i * lda + i]);
+  }
+  const double a1 = bsum256(t1, sm), a2 = bsum256(t2, sm), a3 = bsum256(t3, sm);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) gd = fmax(gd, __shfl_xor(gd, o));
+  __syncthreads();
+  if ((tid & 63) == 0) sm[tid >> 6] = gd;
+  __syncthreads();
+  gd = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+  if (tid == 0) {
+    const double tr = yy - a1 - ridge * a2;
+    ctrl->sse_dot = a1;
+    ctrl->sse_nrm = a2;
+    ctrl->sse_valid = (tr > 1e-6 * yy && 4e-16 * (a3 + (ridge + gd) * a2 + yy) <= 1e-10 * tr) ? 1 : 0;
+    ctrl->irls_steps = w.st->steps;  // (the commit moves it to irls_last: the host sizes its next batch of step launches
+                                     // from it)
+  }
 }
 
 }  // namespace
@@ -297,7 +323,7 @@ CgbWork cgb_carve(double *base, int kcap) {
 // One solve: gather, start, `nsteps` step launches (those beyond convergence fall through), true residual, verdict.
 hipError_t launch_cg_big(const double *G, int p, const int *slot_of, const int *meta, const int *A_new, int k,
                          double ridge, const double *xty, const double *beta_dense, double *work, int kcap, double *sol,
-                         FitCtrl *ctrl, int slot, int nsteps, double tol, hipStream_t st) {
+                         FitCtrl *ctrl, int slot, int nsteps, double tol, double yy, hipStream_t st) {
   if (k < 1 || k > kcap || kcap > CGB_MAX_K || nsteps < 1) return hipErrorInvalidValue;
   const int lda = (kcap + 15) / 16 * 16;
   const int nwg = (k + CGB_ROWS - 1) / CGB_ROWS;
@@ -316,7 +342,8 @@ hipError_t launch_cg_big(const double *G, int p, const int *slot_of, const int *
   hipLaunchKernelGGL(k_cgb_resid, dim3(nwg), dim3(256), 0, st, (const double *)A, lda, k, ridge, w, (const FitCtrl *)ctrl,
                      slot);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_cgb_accept, dim3(1), dim3(256), 0, st, k, nwg, tol, w, sol, ctrl, slot);
+  hipLaunchKernelGGL(k_cgb_accept, dim3(1), dim3(256), 0, st, (const double *)A, lda, k, nwg, tol, ridge, yy, w, sol, ctrl,
+                     slot);
   LAUNCH_CHECK();
   return hipSuccess;
 }

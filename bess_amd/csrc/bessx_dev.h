@@ -331,7 +331,7 @@ struct CgbWork {
 size_t cgb_work_doubles(int kcap);  // work space (the dense matrix first) for systems of up to kcap unknowns
 hipError_t launch_cg_big(const double *G, int p, const int *slot_of, const int *meta, const int *A_new, int k,
                          double ridge, const double *xty, const double *beta_dense, double *work, int kcap, double *sol,
-                         FitCtrl *ctrl, int slot, int nsteps, double tol, hipStream_t st);
+                         FitCtrl *ctrl, int slot, int nsteps, double tol, double yy, hipStream_t st);
 // one fill for several parked fits that share a slot map (k_cov_fill_union)
 struct CovUnion {
   int nf;

@@ -1017,12 +1017,14 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
   const int mt = (T0 + 1 + 15) / 16;
   bessx_session::CovCache &cv = s->cov[rs];
   hipError_t e = hipSuccess;
+  bool used_cgb = false;
   if (mt > 16 && s->cov_cg && !force_chol && T0 <= CGB_MAX_K && cgb_reserve(s) == 0) {
     // beyond the register-resident solvers: conjugate gradients over the whole chip, one launch per step
     // (bessx_cgbig.hip); an iterate whose true residual misses the target parks the fit (cov_stall = 2) and the
     // blocked Cholesky below finishes the slot (force_chol)
     e = launch_cg_big(cv.G, s->p, cv.slot_of, cv.meta, s->A_new, T0, lambda, s->xty[rs], s->beta_dense, s->cgb_work,
-                      s->cgb_cap, s->sol, s->ctrl, slot, s->cgb_guess, s->cg_tol, s->st);
+                      s->cgb_cap, s->sol, s->ctrl, slot, s->cgb_guess, s->cg_tol, s->yy_h[rs], s->st);
+    used_cgb = e == hipSuccess;
     if (e == hipSuccess)
       e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 0, s->A_cur, s->b_cur, s->beta_dense, s->hist,
                         s->hist_beta, s->hist_coef0, s->hist_stride, s->st, s->inA);
@@ -1052,7 +1054,8 @@ static int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, i
   }
   // CV row sets need the sums of squares over the test rows too: one pass over the active columns for the final
   // coefficients (runs iff the fit ended here).  On all rows the loss comes from the solved system (k_chol).
-  if (e == hipSuccess && (rs != 0 || mt > 16 || !s->cov_cg))
+  // (the large-system conjugate gradients hand the loss terms over like the small systems' solve)
+  if (e == hipSuccess && (rs != 0 || (mt > 16 && !used_cgb) || !s->cov_cg))
     e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, slot, s->A_cur, s->b_cur, s->r_rs[rs],
                         s->sse, s->st, 1);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_cov_tail: ") + hipGetErrorString(e));
@@ -1993,7 +1996,8 @@ static int algorithm_fit(bessx_session *s) {
     }
     if (hc->done || slot > s->max_iter) break;
   }
-  if (cov && !hc->done && (rs != 0 || (T0 + 1 + 15) / 16 > 16 || !s->cov_cg)) {
+  const bool cgb_fit = cov && (T0 + 1 + 15) / 16 > 16 && s->cov_cg && T0 <= CGB_MAX_K && s->cgb_work != nullptr;
+  if (cov && !hc->done && (rs != 0 || ((T0 + 1 + 15) / 16 > 16 && !cgb_fit) || !s->cov_cg)) {
     // out of iterations: the sums of squares of the last coefficients have not been formed yet
     HIPX(launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, hc->l, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                          s->st, 2));
@@ -2070,7 +2074,7 @@ static int algorithm_fit(bessx_session *s) {
   s->l = hc->done ? hc->l : s->max_iter + 1;
   double tr = 0.0, te = 0.0;
   const int mt_fit = (T0 + 1 + 15) / 16;
-  if (cov && rs == 0 && mt_fit <= 16 && s->cov_cg) {
+  if (cov && rs == 0 && (mt_fit <= 16 || cgb_fit) && s->cov_cg) {
     // all rows, covariance form, solve by k_cg: no residual was formed.  |y - X beta|^2 = y.y - beta.(q + rho) -
     // lambda |beta|^2 with rho the residual of the normal equations (k_cg hands over both dot products, and clears
     // sse_valid when the cancellation is not harmless).  If the last solve came from the Cholesky fallback, or the

@@ -3362,6 +3362,114 @@ __global__ void __launch_bounds__(256) k_group_moments(const double *__restrict_
   }
 }
 
+// The sacrifice of one group from its s x s moment block: Phi = sqrtm(block), score = |Phi beta + Phi^-1 d|^2 / s
+// (src/Algorithm.h:1112-1123, :1238-1257; Phi / invPhi, src/utilities.cpp:142-177) by a cyclic Jacobi diagonalisation.
+// SC = compile-time width (the loops unroll and the s x s arrays live in registers: 25 + 25 doubles at 5 columns) or 0
+// = any width up to GRP_MAX with run-time loops (the arrays then sit in scratch memory: 1.9 ms per launch for 2000
+// groups of 5 in round 3, 70 % of a grouped LM path).
+template <int SC>
+__device__ __forceinline__ double group_sacrifice(int s_rt, double *__restrict__ a, double *__restrict__ v,
+                                                  const double *__restrict__ bv, const double *__restrict__ dv) {
+  const int s = SC > 0 ? SC : s_rt;
+  constexpr int UF = SC > 0 ? SC : 1;  // (run-time widths: no unrolling)
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, dg = 0.0;
+#pragma unroll UF
+    for (int i = 0; i < s; i++)
+#pragma unroll UF
+      for (int j = 0; j < s; j++) {
+        double e = a[j * s + i];
+        if (i != j) off += e * e;
+        else dg += e * e;
+      }
+    if (off <= 1e-32 * dg || off == 0.0) break;
+#pragma unroll UF
+    for (int i = 0; i < s - 1; i++)
+#pragma unroll UF
+      for (int j = i + 1; j < s; j++) {
+        const double apq = a[j * s + i];
+        if (apq == 0.0) continue;
+        const double theta = (a[j * s + j] - a[i * s + i]) / (2.0 * apq);
+        const double tq = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tq * tq + 1.0), sn = tq * c;
+#pragma unroll UF
+        for (int k = 0; k < s; k++) {
+          const double akp = a[i * s + k], akq = a[j * s + k];
+          a[i * s + k] = c * akp - sn * akq;
+          a[j * s + k] = sn * akp + c * akq;
+        }
+#pragma unroll UF
+        for (int k = 0; k < s; k++) {
+          const double apk = a[k * s + i], aqk = a[k * s + j];
+          a[k * s + i] = c * apk - sn * aqk;
+          a[k * s + j] = sn * apk + c * aqk;
+        }
+#pragma unroll UF
+        for (int k = 0; k < s; k++) {
+          const double vkp = v[i * s + k], vkq = v[j * s + k];
+          v[i * s + k] = c * vkp - sn * vkq;
+          v[j * s + k] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  double t[SC > 0 ? SC : GRP_MAX];
+#pragma unroll UF
+  for (int i = 0; i < s; i++) t[i] = 0.0;
+#pragma unroll UF
+  for (int k = 0; k < s; k++) {
+    double pb = 0.0, pd = 0.0;
+#pragma unroll UF
+    for (int j = 0; j < s; j++) {
+      pb += v[k * s + j] * bv[j];
+      pd += v[k * s + j] * dv[j];
+    }
+    const double sq = sqrt(a[k * s + k]), coef = sq * pb + pd / sq;
+#pragma unroll UF
+    for (int i = 0; i < s; i++) t[i] += v[k * s + i] * coef;
+  }
+  double ss = 0.0;
+#pragma unroll UF
+  for (int i = 0; i < s; i++) ss += t[i] * t[i];
+  return ss / (double)s;
+}
+
+template <int SC>
+__device__ __forceinline__ double group_score_one(int g, int s_rt, int c0, const int *__restrict__ goff,
+                                                  const double *__restrict__ mblk, const double *__restrict__ dcol,
+                                                  const double *__restrict__ part, int nrb, int p, int lm, double n_t,
+                                                  double lambda, const double *__restrict__ beta_dense) {
+  constexpr int SM = SC > 0 ? SC : GRP_MAX;
+  constexpr int UF = SC > 0 ? SC : 1;
+  const int s = SC > 0 ? SC : s_rt;
+  double a[SM * SM], v[SM * SM], dv[SM], bv[SM];
+#pragma unroll UF
+  for (int u = 0; u < s; u++) {
+    double d;
+    if (lm) {
+      double sacc = 0.0;
+      for (int rb = 0; rb < nrb; rb++) sacc += part[(size_t)rb * p + c0 + u];
+      d = sacc / n_t;
+    } else {
+      d = dcol[c0 + u];
+    }
+    bv[u] = beta_dense[c0 + u];
+    dv[u] = d - 2.0 * lambda * bv[u];
+#pragma unroll UF
+    for (int w = 0; w < s; w++) {
+      double m = mblk[goff[g] + w * s + u];
+      if (lm) m = m / n_t;
+      if (u == w) m += 2.0 * lambda;
+      a[w * s + u] = m;
+      v[w * s + u] = (u == w) ? 1.0 : 0.0;
+    }
+  }
+  if (s == 1) {
+    const double phi = sqrt(a[0]), inv = 1.0 / phi, tt = phi * bv[0] + inv * dv[0];
+    return tt * tt;
+  }
+  return group_sacrifice<SC>(s, a, v, bv, dv);
+}
+
 // lm != 0: dcol is taken from the score-pass partials (sum over row blocks / n_t); else dcol holds X^T g already.
 __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict__ gidx, const int *__restrict__ gsz,
                                                     const int *__restrict__ goff, const double *__restrict__ mblk,
@@ -3376,79 +3484,21 @@ __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict
   if (g >= N) return;
   const int s = gsz[g], c0 = gidx[g];
   if (s > GRP_MAX) return;  // wider groups: k_group_score_big
-  double a[GRP_MAX * GRP_MAX], v[GRP_MAX * GRP_MAX], dv[GRP_MAX], bv[GRP_MAX], t[GRP_MAX];
-  for (int u = 0; u < s; u++) {
-    double d;
-    if (lm) {
-      double sacc = 0.0;
-      for (int rb = 0; rb < nrb; rb++) sacc += part[(size_t)rb * p + c0 + u];
-      d = sacc / n_t;
-    } else {
-      d = dcol[c0 + u];
-    }
-    bv[u] = beta_dense[c0 + u];
-    dv[u] = d - 2.0 * lambda * bv[u];
-    t[u] = 0.0;
-    for (int w = 0; w < s; w++) {
-      double m = mblk[goff[g] + w * s + u];
-      if (lm) m = m / n_t;
-      if (u == w) m += 2.0 * lambda;
-      a[w * s + u] = m;
-      v[w * s + u] = (u == w) ? 1.0 : 0.0;
-    }
-  }
   double res;
-  if (s == 1) {
-    const double phi = sqrt(a[0]), inv = 1.0 / phi, tt = phi * bv[0] + inv * dv[0];
-    res = tt * tt;
-  } else {
-    // cyclic Jacobi on the symmetric s x s block
-    for (int sweep = 0; sweep < 60; sweep++) {
-      double off = 0.0, dg = 0.0;
-      for (int i = 0; i < s; i++)
-        for (int j = 0; j < s; j++) {
-          double e = a[j * s + i];
-          if (i != j) off += e * e;
-          else dg += e * e;
-        }
-      if (off <= 1e-32 * dg || off == 0.0) break;
-      for (int i = 0; i < s - 1; i++)
-        for (int j = i + 1; j < s; j++) {
-          const double apq = a[j * s + i];
-          if (apq == 0.0) continue;
-          const double theta = (a[j * s + j] - a[i * s + i]) / (2.0 * apq);
-          const double tq = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-          const double c = 1.0 / sqrt(tq * tq + 1.0), sn = tq * c;
-          for (int k = 0; k < s; k++) {
-            const double akp = a[i * s + k], akq = a[j * s + k];
-            a[i * s + k] = c * akp - sn * akq;
-            a[j * s + k] = sn * akp + c * akq;
-          }
-          for (int k = 0; k < s; k++) {
-            const double apk = a[k * s + i], aqk = a[k * s + j];
-            a[k * s + i] = c * apk - sn * aqk;
-            a[k * s + j] = sn * apk + c * aqk;
-          }
-          for (int k = 0; k < s; k++) {
-            const double vkp = v[i * s + k], vkq = v[j * s + k];
-            v[i * s + k] = c * vkp - sn * vkq;
-            v[j * s + k] = sn * vkp + c * vkq;
-          }
-        }
-    }
-    for (int k = 0; k < s; k++) {
-      double pb = 0.0, pd = 0.0;
-      for (int j = 0; j < s; j++) {
-        pb += v[k * s + j] * bv[j];
-        pd += v[k * s + j] * dv[j];
-      }
-      const double sq = sqrt(a[k * s + k]), coef = sq * pb + pd / sq;
-      for (int i = 0; i < s; i++) t[i] += v[k * s + i] * coef;
-    }
-    double ss = 0.0;
-    for (int i = 0; i < s; i++) ss += t[i] * t[i];
-    res = ss / (double)s;
+#define GS_CASE(S) \
+  case S: res = group_score_one<S>(g, s, c0, goff, mblk, dcol, part, nrb, p, lm, n_t, lambda, beta_dense); break
+  switch (s) {
+    GS_CASE(1);
+    GS_CASE(2);
+    GS_CASE(3);
+    GS_CASE(4);
+    GS_CASE(5);
+    GS_CASE(6);
+    GS_CASE(7);
+    GS_CASE(8);
+    default: res = group_score_one<0>(g, s, c0, goff, mblk, dcol, part, nrb, p, lm, n_t, lambda, beta_dense);
   }
+#undef GS_CASE
   if (always != nullptr && always[g]) res = DBL_MAX;
   bd[g] = res;
 }

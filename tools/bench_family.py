@@ -2,6 +2,8 @@
   python tools/bench_family.py logistic [n p kmax]     configs[2]  default 100000 5000 100
   python tools/bench_family.py cox [n p kmax]          configs[4]  default 200000 20000 150
   python tools/bench_family.py lmcv [n p smax]         configs[3]  default 50000 10000 200  (gs_path + 5-fold CV)
+  python tools/bench_family.py poisson [n p kmax]      SURVEY 8f   default 100000 5000 100
+  python tools/bench_family.py grouped [n p kmax]      SURVEY 8f   default 50000 10000 40   (p / 5 groups of 5 columns)
   python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_family.py lmcv-sharded [n p smax]
       configs[3] with the 5 fold chains + the full-data chain dealt to N ranks (bess_amd.dist.FoldShardedCV);
       BESSX_BENCH_BACKEND=gloo BESSX_BENCH_ONE_DEVICE=1 rehearses the N-rank path on ONE GPU (<= 6 ranks).
@@ -37,6 +39,16 @@ def main():
         sess = capi.Session(X, y, data_type=1, model_type=1)
         sess.set_cv(5, synth.make_cv_folds(n, 5))
         run = lambda: sess.gs_path(1, kmax, ic_type=3, is_cv=True)  # noqa: E731
+    elif fam == "poisson":  # SURVEY 8f rank 1 at the configs[2] shape
+        n, p, kmax = (a + [100000, 5000, 100][len(a):])[:3]
+        X, y, _, _ = synth.make_poisson(n, p, 50)
+        sess = capi.Session(X, y, data_type=2, model_type=3)
+        run = lambda: sess.sequential_path(np.arange(1, kmax + 1), ic_type=3)  # noqa: E731
+    elif fam == "grouped":  # the configs[1] data as p / 5 groups of 5 columns
+        n, p, kmax = (a + [50000, 10000, 40][len(a):])[:3]
+        X, y, _, _ = synth.make_lm(n, p, 100)
+        sess = capi.Session(X, y, data_type=1, model_type=1, algorithm_type=2, g_index=np.arange(0, p, 5, dtype=np.int32))
+        run = lambda: sess.sequential_path(np.arange(1, kmax + 1), ic_type=3)  # noqa: E731
     elif fam == "lmcv-sharded":
         return sharded_cv(a)
     else:
