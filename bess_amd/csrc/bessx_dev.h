@@ -237,6 +237,7 @@ struct CoxBufs {
   double fit_clamp;  // clamp of the linear predictor in the Newton step: 30 (src/Algorithm.h:1417-1422); cox_fit of the
                      // screening uses 50 (src/coxph.cpp:65-71)
 };
+void cox_score_set_variant(int v);  // bench hook: the wave -> (column group, row block) map of k_cox_score1p (1 = default)
 int cox_hess_slab_rows(long ld);
 bool cox_hess_applies(int mt);
 hipError_t cox_hess_prepare();

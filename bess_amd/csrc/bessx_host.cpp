@@ -5227,7 +5227,10 @@ int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbp
   hipEvent_t e0, e1;
   HIPX(hipEventCreate(&e0));
   HIPX(hipEventCreate(&e1));
-  if (variant != 0) return fail(BESSX_ERR_ARG, "op_cox_score_bench: only variant 0 (the kernel the solver runs) exists");
+  // variant 1 (what the solver runs): consecutive waves take consecutive column groups of one row block; 0 (round 3):
+  // the row blocks of one column group
+  if (variant < 0 || variant > 1) return fail(BESSX_ERR_ARG, "op_cox_score_bench: variant 0 or 1");
+  cox_score_set_variant(variant);
   CoxBufs cb = {};
   cb.one_pass = 1;
   cb.TH = vec;
@@ -5245,6 +5248,7 @@ int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbp
   (void)hipEventDestroy(e1);
   *gbps = 8.0 * (double)n * (double)p * repeats / ((double)ms * 1e-3) / 1e9;
   if (avg_ms) *avg_ms = ms / repeats;
+  cox_score_set_variant(1);
   return BESSX_OK;
 }
 

@@ -4267,7 +4267,14 @@ __global__ void __launch_bounds__(256) k_cox_uv(long ld, const double *__restric
 }
 
 // out: 5 arrays of nrb x p (T, P1, P2, sum x v, sum u x^2) followed by P0[nrb]
-template <int U>
+// MAP: which (column group, row block) a wave takes.  0: consecutive waves walk the row blocks of one column group;
+// 1: consecutive waves take consecutive column groups of ONE row block -- the four n-vectors of that row block (32 KB)
+// are then shared by everything in flight at a time instead of being fetched again by every column group.
+// Round 4, full size (tools/cox_score_bench.py, rocprofv3 --pmc FETCH_SIZE): MAP = 1 fetches 31.5 GB per 32 GB pass
+// where MAP = 0 fetches 35.2 GB (the re-read n-vectors), at the SAME 5.1-5.3 ms per pass (0.75-0.79 of 8 TB/s) -- the
+// re-reads were wasted traffic, not what holds the kernel; the four vectors interleaved per row (one 32-byte scalar load
+// instead of four) measured 0.73-0.78 and were dropped.  MAP = 1 is what the solver runs.
+template <int U, int MAP>
 __global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ X, long ld, int p, int nrb,
                                                      const double *__restrict__ TH, const double *__restrict__ CU,
                                                      const double *__restrict__ CV, const double *__restrict__ C2,
@@ -4278,9 +4285,9 @@ __global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ 
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long wid = (long)blockIdx.x * 4 + wv;
   const int ncg = (p + 63) / 64;
-  const long cg = wid / nrb;
-  const int rb = (int)(wid - cg * nrb);
-  if (cg >= ncg) return;
+  const long cg = MAP == 0 ? wid / nrb : wid % ncg;
+  const int rb = MAP == 0 ? (int)(wid - cg * nrb) : (int)(wid / ncg);
+  if (cg >= ncg || rb >= nrb) return;
   const int j0 = (int)cg * 64;
   double loc = 0.0, g1 = 0.0, g2 = 0.0, p1 = 0.0, p2 = 0.0, p0 = 0.0;
   constexpr int NSUB = 128 * U / CS_ROWS;
@@ -7136,14 +7143,22 @@ hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, co
   return hipSuccess;
 }
 
+static int g_cox_score_variant = 1;  // the wave -> (column group, row block) map (tools/cox_score_bench.py measures both)
+void cox_score_set_variant(int v) { g_cox_score_variant = v & 1; }
+
 hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb, CoxBufs cb, double *part,
                                  double *part2, const FitCtrl *ctrl, int slot, hipStream_t st) {
   if (cb.one_pass) {
     long nw = (long)nrb * ((p + 63) / 64);
     int nb = (int)((nw + 3) / 4);
-#define CS1_GO(UU)                                                                                            \
-  hipLaunchKernelGGL(k_cox_score1p<UU>, dim3(nb), dim3(256), 0, st, X, ld, p, nrb, (const double *)cb.TH,     \
+#define CS1_GO3(UU, MM)                                                                                        \
+  hipLaunchKernelGGL((k_cox_score1p<UU, MM>), dim3(nb), dim3(256), 0, st, X, ld, p, nrb, (const double *)cb.TH, \
                      (const double *)cb.CU, (const double *)cb.CV, (const double *)cb.C2, part, ctrl, slot)
+#define CS1_GO(UU)               \
+  if (g_cox_score_variant)       \
+    CS1_GO3(UU, 1);              \
+  else                           \
+    CS1_GO3(UU, 0)
     switch (U) {
       case 8: CS1_GO(8); break;
       case 4: CS1_GO(4); break;
@@ -7151,6 +7166,7 @@ hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb
       default: CS1_GO(1); break;
     }
 #undef CS1_GO
+#undef CS1_GO3
     LAUNCH_CHECK();
     return hipSuccess;
   }

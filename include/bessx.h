@@ -350,7 +350,7 @@ int bessx_op_normalize(double *x, int n, int p, double *y, const double *weight,
 /* Tuning aid for K1: run geometry variant `variant` of the score pass `repeats` times on an n x p matrix
  * generated on the device and report algorithmic GB/s (8*n*p bytes per launch) and the mean launch time. */
 int bessx_op_xtv_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms);
-/* The same for the one-pass Cox score kernel (k_cox_score1p, 8*n*p bytes per launch); variant 0 = the one the solver runs. */
+/* The same for the one-pass Cox score kernel (k_cox_score1p, 8*n*p bytes per launch); variant 1 = the one the solver runs (wave map of round 4), 0 = round 3. */
 int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms);
 /* Device-to-device streaming copy rate in GB/s (read+write bytes / time): the measured HBM ceiling
  * quoted next to the spec peak in bench.py. */

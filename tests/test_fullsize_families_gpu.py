@@ -119,6 +119,48 @@ def test_logistic_config_matches_compiled_reference_at_full_size(logistic_full):
     assert_best_model(out, g)
 
 
+# ------------------------------------------------------------------------------------ Poisson
+@pytest.fixture(scope="module")
+def poisson_full(gpu):
+    """The Poisson family at the shape of configs[2] (north_star names poisson.cpp; no BASELINE config of its own):
+    n = 100000, p = 5000, k = 1..100, warm-started IRLS (src/Algorithm.h:1273-1322), no clamp in get_A (:1338-1339)."""
+    n, p = 100000, 5000
+    X, y, support, beta = synth.make_poisson()
+    s = gpu.Session(X, y, data_type=2, model_type=3)
+    del X
+    s.trace_enable(True)
+    out = s.sequential_path(np.arange(1, 101), ic_type=3)
+    yield s, out, support, (n, p)
+    s.close()
+
+
+def test_poisson_properties_at_full_size(poisson_full):
+    s, out, support, (n, p) = poisson_full
+    again = s.sequential_path(np.arange(1, 101), ic_type=3)
+    for k in ("cand_support", "cand_beta", "cand_ic", "cand_iters", "cand_coef0"):
+        assert np.array_equal(out[k], again[k]), k  # bitwise reproducible
+    fits = out["trace"]["fits"]
+    assert len(fits) == 100 and [f["T0"] for f in fits] == list(range(1, 101))
+    assert_fits_stop_on_a_repeat(fits)
+    # PoissonMetric::ic, src/Metric.h:504-553: loss + log(p) log(log n) T0
+    c = np.log(p) * np.log(np.log(n))
+    np.testing.assert_allclose(out["cand_ic"], out["cand_train_loss"] + c * np.arange(1, 101), rtol=1e-12)
+    chosen = np.nonzero(out["beta"])[0]
+    assert 30 <= out["best_T0"] <= 50 and np.all(np.isin(chosen, support)), (out["best_T0"], chosen)
+    s.trace_enable(False)
+    fast = s.sequential_path(np.arange(1, 101), ic_type=3)  # untraced: the IRLS chains batched by the last step count
+    assert np.array_equal(fast["cand_support"], out["cand_support"])
+    np.testing.assert_allclose(fast["cand_ic"], out["cand_ic"], rtol=1e-12)
+
+
+def test_poisson_matches_compiled_reference_at_full_size(poisson_full):
+    g = _gold("fullsize_poisson.npz")
+    _, out, _, _ = poisson_full
+    nfit = assert_matches_golden(out["trace"], g, "Poisson n=100000 p=5000", beta_rtol=1e-6)
+    assert nfit >= 20
+    assert_best_model(out, g)
+
+
 # ------------------------------------------------------------------------------------------------ configs[3]
 @pytest.fixture(scope="module")
 def lmcv_full(gpu):

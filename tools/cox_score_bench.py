@@ -6,12 +6,12 @@ pattern of k_xtv): 0.53.   python tools/cox_score_bench.py [n p repeats]"""
 import ctypes
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from bess_amd import capi  # noqa: E402
 
 a = [int(v) for v in sys.argv[1:]]
 n, p, rep = (a + [200000, 20000, 5][len(a):])[:3]
-variants = a[3:] or [0]
+variants = a[3:] or [1, 0]
 L = capi.lib()
 for v in variants:
     g, ms = ctypes.c_double(0), ctypes.c_double(0)
