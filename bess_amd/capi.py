@@ -34,7 +34,7 @@ SYMBOLS = [
 ]
 
 
-MAX_SPARSITY = 16382  # T0_HARD of bessx_host.cpp: the largest bessx_problem.max_sparsity
+MAX_SPARSITY = 16382  # T0_HARD of bessx_host.h: the largest bessx_problem.max_sparsity
 
 
 class BessxError(RuntimeError):

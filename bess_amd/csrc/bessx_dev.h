@@ -1,5 +1,5 @@
 // bessx_dev.h -- internal interface between the HIP kernels (bessx_kernels.hip) and the host-side
-// solver (bessx_host.cpp).  Not part of the C ABI (that is include/bessx.h).
+// solver (bessx_session.cpp, bessx_fit.cpp, bessx_cv.cpp, bessx_paths.cpp, bessx_abi.cpp).  Not part of the C ABI (that is include/bessx.h).
 #ifndef BESSX_DEV_H
 #define BESSX_DEV_H
 

@@ -5879,7 +5879,7 @@ __global__ void k_cov_resume(FitCtrl *__restrict__ ctrl) {
   }
 }
 
-// Fold chains side by side (CV row sets, shared fills; bessx_host.cpp: fold_fits_side_by_side): ONE fill for every chain
+// Fold chains side by side (CV row sets, shared fills; bessx_cv.cpp: fold_fits_side_by_side): ONE fill for every chain
 // that is parked on a cache miss (cov_stall = 1) or on a full cache (4).  Runs while every chain is quiet.  The wanted
 // sets (u.list: the new active set of every parked chain; after `restart` -- decided by the host, which knows the
 // column count -- also the current active set of every chain that is in the middle of a fit) are looked up again
