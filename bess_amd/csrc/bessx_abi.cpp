@@ -301,7 +301,6 @@ int bessx_op_gram(const double *x, int n, int p, int ld, const int *cols, int m,
   Scratch sc;
   const int U = 1;
   HIPX(gram_lds_prepare());
-  if (const char *ev = std::getenv("BESSX_GRAM")) gram_set_variant(std::string(ev) == "direct" ? 0 : 1);
   double *dX, *dw = nullptr, *daux, *gpart, *Gt;
   long ldd;
   if (int rc = upload_padded(sc, x, n, p, ld, U, &dX, &ldd)) return rc;

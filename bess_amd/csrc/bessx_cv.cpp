@@ -270,11 +270,7 @@ int fold_fits_side_by_side(bessx_session *s, double *out, const std::vector<int>
             ub += T0;
           }
         }
-        static const int spec_min_env = [] {
-          const char *ev = std::getenv("BESSX_CV_SPEC_MIN");
-          return ev ? std::atoi(ev) : -1;
-        }();
-        const int spec_min = spec_min_env >= 0 ? std::min(spec_min_env, s->cov_spec) : s->cov_spec / 2;
+        const int spec_min = s->cov_spec / 2;
         if (spec_src) {
           bessx_session *cs = spec_src->c;
           SBSH(launch_topk(cs->bd2, p, s->cov_spec, cs->cov_extras, cs->cand, nullptr, 0, cs->st));

@@ -85,7 +85,8 @@ int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, b
 // Two groups in one launch (a fill of more than 32 columns: cold starts, the chunks of a sharded path): the pair panel
 // kernel forms both in ONE pass over X (1.36 ms against 2 x 0.76 ms); single groups keep the default.
 int panel_variant_for(const bessx_session *s, int ng) {
-  return (s->cov_variant == 3 && ng == 2 && s->cov_pair_auto) ? 4 : s->cov_variant;
+  (void)s;
+  return ng == 2 ? 4 : 3;  // 3 = k_cov_panel_lds2 (one 32-column group per block), 4 = k_cov_panel_pair (two groups per pass)
 }
 
 // gfirst / compact: a cooperative prefill (bessx_session_cov_prefill_*) forms only SOME groups of the list here and
@@ -155,7 +156,7 @@ int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const Fi
 // can add up to cov_spec speculative columns beyond the requested ones
 int cov_C_dev(const bessx_session *s) { return s->cov_C - (s->cov_spec - COV_R); }
 
-// Fusions of the small kernels around a slot (BESSX_FUSE=0 turns them off):
+// Fusions of the small kernels around a slot (test hook fuse=0 turns them off):
 //  * pub: the slot closes a batch -- its solve kernel publishes the result block itself (*pub_fused = true) instead
 //    of a k_publish launch behind it;
 //  * the selection kernel records a repeated active set itself (TopkNeed.commit_on) and opens a chained fit
@@ -564,7 +565,7 @@ int enqueue_cox_tail(bessx_session *s, int slot, int T0, int rs) {
 
 // Results of the kernels queued so far.  kcopy >= 0: only the first kcopy coefficients / indices are wanted and
 // the block is published by a kernel into pinned memory (k_publish) while the host spins on its sequence number --
-// no copy engine, no interrupt.  kcopy < 0 (or BESSX_PUBLISH=0): plain asynchronous copy + stream synchronisation.
+// no copy engine, no interrupt.  kcopy < 0 (or test hook publish=0): plain asynchronous copy + stream synchronisation.
 // what a publication of the result block into pinned buffer `buf` copies; takes the next sequence number
 PubArgs publish_args(bessx_session *s, int kcopy, int buf, unsigned long long *seq) {
   *seq = ++s->pub_seq;

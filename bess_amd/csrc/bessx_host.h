@@ -38,6 +38,29 @@ extern thread_local std::string g_err;  // (defined in bessx_session.cpp)
 // src/screening.cpp:42-63): 1 = logit_fit (no weight floor), 2 = cox_fit (linear predictor clamped at 50)
 extern thread_local int g_marginal_fit_variant;
 
+// Test hooks.  ONE environment variable, BESSX_TEST_HOOKS = "name=value,name=value,...", read when a session is created:
+// the tests use it to force the fallback paths the library keeps anyway (an unfused launch sequence, the Cholesky behind
+// the conjugate gradients, the two-pass Cox forms, a small Gram column cache, ...) so that they are compared with the
+// defaults.  Not product configuration -- those are BESSX_SCORE_MODE, BESSX_WAIT_TIMEOUT_S, BESSX_POOL_SPIN_US and
+// BESSX_DEBUG.  Returns the value of `name`, or nullptr.
+inline const char *test_hook(const char *name) {
+  static thread_local std::string val;
+  const char *ev = std::getenv("BESSX_TEST_HOOKS");
+  if (!ev) return nullptr;
+  const std::string all(ev), key = std::string(name) + "=";
+  size_t pos = 0;
+  while (pos < all.size()) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    if (all.compare(pos, key.size(), key) == 0) {
+      val = all.substr(pos + key.size(), end - pos - key.size());
+      return val.c_str();
+    }
+    pos = end + 1;
+  }
+  return nullptr;
+}
+
 inline int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
@@ -265,22 +288,22 @@ struct bessx_session {
   int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
   int cov_spec = 32;       // most speculative columns per fill: 64 with the pair panel kernel (variant 4), else 32
-  bool fuse_sel = true;    // selection + solve of a slot in one launch, k_sel_cgr (BESSX_FUSE_SEL=0: two launches)
-  bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (BESSX_CG_LAYOUT=tiles: k_cg)
+  bool fuse_sel = true;    // selection + solve of a slot in one launch, k_sel_cgr (test hook fuse_sel=0: two launches)
+  bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (test hook cg_layout=tiles: k_cg)
   // GLM IRLS step in three launches instead of five: linear predictor, weights, working response and the slab Gram
   // in ONE pass over the active columns (k_irls_gram), the reduction, then the convergence test at the head of the
   // solve.  (Round 2's k_gram_irls did the per-row work 64 rows at a time between the barriers of the staging pipeline
   // and lost, 0.180 s against 0.175 s on configs[2]; it is gone.)
-  bool irls_fuse = true;   // GLM IRLS step as k_irls_gram + k_gram_reduce + k_chol (BESSX_IRLS_FUSE=0: the five-launch step)
+  bool irls_fuse = true;   // GLM IRLS step as k_irls_gram + k_gram_reduce + k_chol (test hook irls_fuse=0: the five-launch step)
   bool glm_fallback = false;  // the IRLS chain carries the pivoted fallback solve behind every k_chol (set, and the
                               // fit redone, the first time a k_chol of this session meets a rank-deficient system)
   int irls_wfloor = 1;     // floor of the logistic IRLS weight inside the loop (src/Algorithm.h:1188-1192); 0 in the
                            // sub-sessions that run logit_fit for the screening of wide groups (src/logistic.cpp:60-160)
   size_t llpart_cap = 0;
   long long n_submodel_steps = 0;  // IRLS / Newton steps taken since the last reset (bessx_session_submodel_steps)
-  bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (BESSX_DEFER_PUBLISH=0: in the tail)
-  bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); BESSX_FUSE=0 turns them off
-  bool cov_cg = true;          // solve by k_cg (falls back to k_chol per slot); BESSX_COV_SOLVER=chol switches it off
+  bool defer_pub = true;   // chained fits publish through a snapshot + the next launch (test hook defer_publish=0: in the tail)
+  bool fuse = true;  // small-kernel fusions of the covariance form (SlotFuse); test hook fuse=0 turns them off
+  bool cov_cg = true;          // solve by k_cg (falls back to k_chol per slot); test hook cov_solver=chol switches it off
   long long cov_cg_fallbacks = 0;
   long long cov_tie_rescues = 0;  // slots redone with the exact tie rule (cov_stall = 3)
   int cov_C = 0;              // cache capacity in columns
@@ -298,7 +321,7 @@ struct bessx_session {
   // column caches and owns what a fit writes (stream, control / result block, scores, selection and solve work space,
   // host-side warm-start state).  fold_fits_side_by_side() drives them in lock step; whenever chains are parked on
   // missing columns ONE fill (k_cov_fill_union + a pass over the fold-major copy) serves all of them, issued while
-  // every chain is quiet, so nobody reads the shared slot map while it is rewritten.  BESSX_CV_SIDE_BY_SIDE=0: the
+  // every chain is quiet, so nobody reads the shared slot map while it is rewritten.  test hook cv_side_by_side=0: the
   // folds are fitted one after another on the parent's own state (round 2's form).
   bessx_session *parent = nullptr;          // set in a fold context
   std::vector<bessx_session *> fold_ctx;    // [k]: context of row set k + 1 (empty: folds run on the parent)
@@ -317,10 +340,6 @@ struct bessx_session {
   // that timed out still has work queued on the device and can only be destroyed.
   double wait_deadline_s = 30.0;
   double sbs_t[6] = {0, 0, 0, 0, 0, 0};     // BESSX_DEBUG: seconds in start / enqueue / wait / fill / continue / results
-  bool cov_pair_auto = true;  // launches of two groups use the pair panel kernel (BESSX_PANEL_PAIR_AUTO=0: never)
-  int cov_variant = 3;        // panel kernel: 3 = one 32-column group per block (k_cov_panel_lds2), two-group launches by the
-                              // pair kernel; 4 = the pair kernel whenever it applies, fills speculate up to 64 columns
-                              // (BESSX_PANEL_VARIANT=4; measured at parity on configs[1])
   double *cov_part = nullptr, *bd2 = nullptr;
   unsigned char *inA = nullptr;        // 1 for the columns of the current active set
   double *cov_bmm = nullptr;           // per-block min / max of k_cov_d's repeated-set shortcut (+ arg-max columns)
@@ -367,7 +386,7 @@ struct bessx_session {
     double lambda = 0.0;
     unsigned long long seq = 0;
   } ahead;
-  bool chain = true;   // BESSX_CHAIN=0 switches the chaining off
+  bool chain = true;   // test hook chain=0 switches the chaining off
   long long chain_queued = 0, chain_hits = 0, chain_dead = 0, chain_mismatch = 0;
   int fit_serial = 0;
   unsigned char *stage_h = nullptr;  // pinned staging for init vectors

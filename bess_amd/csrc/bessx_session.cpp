@@ -333,11 +333,7 @@ void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *n
     // LDS-staged kernel: one block per slab computes every tile; slabs are whole 64-row chunks, about one block
     // (4 or 8 waves) per CU
     // (4-wave instance, up to 8 tile rows: two blocks fit a CU; measured 512 >= 256 > 128 slabs on configs[2])
-    static const long want = [] {
-      const char *ev = std::getenv("BESSX_GRAM_SLABS");
-      return ev ? std::max(1L, std::atol(ev)) : 0L;
-    }();
-    long ns = std::min<long>(want > 0 ? want : (ntiles <= 36 ? 512 : 256), s->ld / 64);
+    long ns = std::min<long>(ntiles <= 36 ? 512 : 256, s->ld / 64);
     if (s->gpart_elems > 0) ns = std::max<long>(1, std::min<long>(ns, (long)(s->gpart_elems / ((size_t)ntiles * 256))));
     long rps = ((s->ld + ns - 1) / ns + 63) / 64 * 64;
     *rows_per_slab = (int)rps;
@@ -500,9 +496,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
     HIPT(gram_lds_prepare());
-    if (const char *ev = std::getenv("BESSX_IRLS_FUSE")) s->irls_fuse = std::string(ev) == "1";
+    if (const char *ev = test_hook("irls_fuse")) s->irls_fuse = std::string(ev) == "1";
     s->irls_wfloor = g_marginal_fit_variant == 1 ? 0 : 1;
-    if (const char *ev = std::getenv("BESSX_GRAM")) gram_set_variant(std::string(ev) == "direct" ? 0 : 1);
   }
   const int n = pb->n;
   s->n = n;
@@ -799,7 +794,8 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       bool same = true;
       for (int g = 0; g < gl; g++) same = same && s->gsz_h[g] == s->gmax;
       if (same) s->g_uniform = s->gmax;
-      if (std::getenv("BESSX_GROUP_EXPAND") && std::string(std::getenv("BESSX_GROUP_EXPAND")) == "host") s->g_uniform = 0;
+      if (const char *ev = test_hook("group_expand"))
+        if (std::string(ev) == "host") s->g_uniform = 0;
     }
     // groups of up to 16 columns: register-resident blocks and a Jacobi square root per thread; wider ones: tiled
     // moments and a Cholesky form of the same score (k_group_moments_big / k_group_score_big).  Cox forms the
@@ -906,9 +902,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->pub_flag), 128));
     s->pub_flag[0] = 0ull;
     s->pub_flag[8] = 0ull;  // second buffer's flag, its own cache line
-    if (const char *ev = std::getenv("BESSX_PUBLISH")) s->publish = std::atoi(ev) != 0;
+    if (const char *ev = test_hook("publish")) s->publish = std::atoi(ev) != 0;
     if (const char *ev = std::getenv("BESSX_WAIT_TIMEOUT_S")) s->wait_deadline_s = std::max(0.001, std::atof(ev));
-    if (const char *ev = std::getenv("BESSX_CHAIN")) s->chain = std::atoi(ev) != 0;
+    if (const char *ev = test_hook("chain")) s->chain = std::atoi(ev) != 0;
     if (!s->publish) s->chain = false;
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), (size_t)capA * (sizeof(int) + sizeof(double))));
   }
@@ -969,9 +965,9 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&q, (size_t)p));
   s->xty.push_back(q);
   // Cox: the score pass reads X once and leaves five partial sums per (row block, column) + one per block
-  // (k_cox_score1p); BESSX_COX_SCORE=2pass keeps the totals / carry / rescan form (two reads of X)
+  // (k_cox_score1p); the test hook cox_score=2pass keeps the totals / carry / rescan form (two reads of X)
   if (s->model_type == 4) {
-    const char *ev = std::getenv("BESSX_COX_SCORE");
+    const char *ev = test_hook("cox_score");
     s->cox.one_pass = !(ev && std::string(ev) == "2pass");
     s->cox.need_uv = s->grouped ? 1 : 0;
   }
@@ -1040,17 +1036,16 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       return bail(fail(BESSX_ERR_ARG, "covariance score mode exists for LM with singleton groups only"));
     if (eligible && mode != 1) {
       // capacity: every column if p is small, else a few active sets' worth, within 1 GiB per row set
-      if (const char *ev = std::getenv("BESSX_PANEL_VARIANT")) s->cov_variant = std::atoi(ev) == 4 ? 4 : 3;
-      if (const char *ev = std::getenv("BESSX_PANEL_PAIR_AUTO")) s->cov_pair_auto = std::string(ev) != "0";
-      // the pair kernel (variant 4) forms two 32-column groups per pass over X: fills then speculate up to 64 columns
-      s->cov_spec = (s->cov_variant == 4 && p >= 4 * COV_R && topk_supported(p, 2 * COV_R)) ? 2 * COV_R : COV_R;
+      // (fills of exactly two groups take the pair panel kernel, one pass for 64 columns; the switches that made every
+      // fill speculate 64 columns, or never paired, measured at parity in rounds 2-3 and are gone)
+      s->cov_spec = COV_R;
       // capacity: EVERY column when that fits 2 GiB per row set (p <= ~16000: a path then forms a column at most once and
       // the cache is never started over -- at 2560 columns the reference's default sequence 1..min(p, n / log n) at
       // n = 25000, p = 3000 restarted it 1237 times and streamed X 73 000 times, round 4); else 2560 columns within 2 GiB
       const long all = ((long)p + 31) / 32 * 32 + COV_R + s->cov_spec;
       const long budget = (((long)2 << 30) / ((long)p * 8)) / 32 * 32;
       long C = all <= budget ? all : std::min<long>(2560, budget);
-      if (const char *ev = std::getenv("BESSX_COV_CAP"))  // test hook: a small cache exercises the restart path
+      if (const char *ev = test_hook("cov_cap"))  // a small cache exercises the restart path
         C = std::min<long>(C, std::max(0, std::atoi(ev)) / 32 * 32);
       if (C >= 2 * COV_R + s->cov_spec) {
         s->cov_mode = true;
@@ -1085,17 +1080,13 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         HIPT(dmalloc(&s->cov_extras, (size_t)2 * COV_R));
         TRY(alloc_cov_cache(s));
         HIPT(cov_panel_prepare());
-        if (const char *ev = std::getenv("BESSX_COV_SOLVER")) s->cov_cg = std::string(ev) != "chol";
-        if (const char *ev = std::getenv("BESSX_FUSE")) s->fuse = std::string(ev) != "0";
-        if (const char *ev = std::getenv("BESSX_FUSE_SEL")) s->fuse_sel = std::string(ev) != "0";
-        if (const char *ev = std::getenv("BESSX_DEFER_PUBLISH")) s->defer_pub = std::string(ev) != "0";
+        if (const char *ev = test_hook("cov_solver")) s->cov_cg = std::string(ev) != "chol";
+        if (const char *ev = test_hook("fuse")) s->fuse = std::string(ev) != "0";
+        if (const char *ev = test_hook("fuse_sel")) s->fuse_sel = std::string(ev) != "0";
+        if (const char *ev = test_hook("defer_publish")) s->defer_pub = std::string(ev) != "0";
         if (!s->fuse) s->defer_pub = false;
-        if (const char *ev = std::getenv("BESSX_CG_LAYOUT")) s->cg_by_rows = std::string(ev) != "tiles";
-        if (const char *ev = std::getenv("BESSX_COV_CS")) s->cov_cs = std::min(COV_CS, std::max(1, std::atoi(ev)));
-        if (const char *ev = std::getenv("BESSX_CG_TOL")) {
-          const double v = std::atof(ev);
-          if (v >= 1e-15 && v <= 1e-6) s->cg_tol = v;
-        }
+        if (const char *ev = test_hook("cg_layout")) s->cg_by_rows = std::string(ev) != "tiles";
+        if (const char *ev = test_hook("cov_cs")) s->cov_cs = std::min(COV_CS, std::max(1, std::atoi(ev)));
       } else if (mode == 2) {
         return bail(fail(BESSX_ERR_ARG, "covariance score mode: p too large for the Gram column cache"));
       }
@@ -1127,16 +1118,16 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     HIPT(V(&c.Gt2, (size_t)136 * 256));
     HIPT(V(&c.llpart, (size_t)(n + 255) / 256 + 1));
     HIPT(V(&c.SCR, cox_scan_scratch_doubles(ld, 256)));
-    // one-pass Hessian of the Newton step (k_cox_hess, up to 10 tile rows; BESSX_COX_HESS=2pass: M = S1 / S0
+    // one-pass Hessian of the Newton step (k_cox_hess, up to 10 tile rows; test hook cox_hess=2pass: M = S1 / S0
     // materialised and two Gram launches, as in round 2)
     // Small samples keep the two-pass form: it is built like the reference's own formulas (M = S1 / S0, two Grams), so
     // on the ill-conditioned fits small n produces (near-separated risk sets, a ridge that outweighs the information
     // matrix) its rounding follows the reference's more closely -- both forms are accurate to rounding there, but a
     // Newton iteration on such a system amplifies rounding to 1e-4 and beyond (tests/test_cox_gpu.py).
-    // BESSX_COX_HESS=1pass forces the one-pass form at any size.
+    // test hook cox_hess=1pass forces the one-pass form at any size.
     c.fit_clamp = g_marginal_fit_variant == 2 ? 50.0 : 30.0;
     c.hess_fused = n >= 1024 ? 1 : 0;
-    if (const char *ev = std::getenv("BESSX_COX_HESS")) c.hess_fused = std::string(ev) == "2pass" ? 0 : (std::string(ev) == "1pass" ? 1 : c.hess_fused);
+    if (const char *ev = test_hook("cox_hess")) c.hess_fused = std::string(ev) == "2pass" ? 0 : (std::string(ev) == "1pass" ? 1 : c.hess_fused);
     if (c.hess_fused) {
       const size_t hrows = (size_t)cox_hess_slab_rows(ld), hns = ((size_t)ld + hrows - 1) / hrows;
       if (hns * 55 * 256 > s->gpart_elems) {
@@ -1340,7 +1331,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
   s->cv_fold = fold;
   // shared fills (see bessx_session::cv_shared): LM in the covariance form, no background fills
   bool share = s->cov_mode && s->model_type == 1 && !s->grouped;
-  if (const char *ev = std::getenv("BESSX_CV_SHARED")) share = share && std::string(ev) != "0";
+  if (const char *ev = test_hook("cv_shared")) share = share && std::string(ev) != "0";
   // The shared fills need a fold-major second copy of X (every fold padded to whole row slabs).  Whether they are used
   // is settled HERE, before any cache is created as a sharer of row set 0's slot map: the copy must not be much larger
   // than X (many small folds pad badly: K <= n is accepted) and its allocations must succeed -- otherwise the masked
@@ -1452,7 +1443,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     // one fit context per fold: the K chains of a CV evaluation run side by side (fold_fits_side_by_side).  A failed
     // allocation leaves the folds on the parent's own state.
     bool sbs = s->cv_side_by_side && K <= 8 && s->publish && s->fuse && s->cov_cg && s->cg_by_rows && s->fuse_sel;
-    if (const char *ev = std::getenv("BESSX_CV_SIDE_BY_SIDE")) sbs = sbs && std::string(ev) != "0";
+    if (const char *ev = test_hook("cv_side_by_side")) sbs = sbs && std::string(ev) != "0";
     if (sbs) {
       hipError_t e = hipMalloc(reinterpret_cast<void **>(&s->fill_ctrl), sizeof(FitCtrl));
       if (e == hipSuccess) e = hipMemset(s->fill_ctrl, 0, sizeof(FitCtrl));

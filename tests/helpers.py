@@ -2,6 +2,15 @@
 import numpy as np
 
 
+def hooks(monkeypatch, **kw):
+    """Add test hooks of libbessx (BESSX_TEST_HOOKS = "name=value,..."; read when a session is created): they force the
+    fallback paths the library keeps anyway, so that a test can compare them with the defaults."""
+    import os
+    cur = dict(kv.split("=", 1) for kv in os.environ.get("BESSX_TEST_HOOKS", "").split(",") if "=" in kv)
+    cur.update({k: str(v) for k, v in kw.items()})
+    monkeypatch.setenv("BESSX_TEST_HOOKS", ",".join("%s=%s" % kv for kv in cur.items()))
+
+
 def rel_err(u, v):
     u, v = np.asarray(u, dtype=float), np.asarray(v, dtype=float)
     assert u.shape == v.shape, (u.shape, v.shape)

@@ -10,7 +10,7 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import cases  # noqa: E402
-from helpers import assert_same_trace  # noqa: E402
+from helpers import assert_same_trace, hooks  # noqa: E402
 from test_lm_gpu import run_gpu  # noqa: E402
 from oracle import port_ctypes as P  # noqa: E402
 from bess_amd import synth  # noqa: E402
@@ -51,7 +51,7 @@ def test_small_cache_is_restarted(gpu, monkeypatch):
     X, y, _, _ = synth.make_lm(1200, 3000, 25)
     kw = dict(ic_type=3, sequence=np.arange(1, 61))
     want = P.trace(X, y, **kw)
-    monkeypatch.setenv("BESSX_COV_CAP", "160")
+    hooks(monkeypatch, cov_cap="160")
     got = run_gpu(gpu, X, y, dict(kw, score_mode=2))
     assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="small cache")
     kw = dict(is_cv=True, K=3, cv_fold_id=synth.make_cv_folds(1200, 3), path_type=2, s_min=1, s_max=60)
@@ -84,7 +84,7 @@ def test_chained_fits_on_a_lambda_grid_and_short_paths(gpu):
 
 def test_conjugate_gradients_hand_ill_conditioned_systems_to_cholesky(gpu, monkeypatch):
     """Nearly collinear columns: the CG solve cannot reach its residual target and parks the fit; the Cholesky
-    kernel finishes the slot.  Same active sets as the oracle either way; BESSX_COV_SOLVER=chol never uses CG."""
+    kernel finishes the slot.  Same active sets as the oracle either way; the test hook cov_solver=chol never uses CG."""
     rng = np.random.default_rng(11)
     n, p = 1500, 300
     z = rng.standard_normal((n, 6))
@@ -99,7 +99,7 @@ def test_conjugate_gradients_hand_ill_conditioned_systems_to_cholesky(gpu, monke
     s.close()
     assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="collinear cg")
     assert fell_back > 0
-    monkeypatch.setenv("BESSX_COV_SOLVER", "chol")
+    hooks(monkeypatch, cov_solver="chol")
     s = gpu.Session(X, y, score_mode=2)
     s.trace_enable(True)
     got = s.sequential_path(kw["sequence"], (0.0,), 3, False)
@@ -108,19 +108,18 @@ def test_conjugate_gradients_hand_ill_conditioned_systems_to_cholesky(gpu, monke
     assert_same_trace(got["trace"], want, beta_rtol=1e-6, what="collinear chol")
 
 
-@pytest.mark.parametrize("knob", ["BESSX_CHAIN=0", "BESSX_PUBLISH=0", "BESSX_COV_SOLVER=chol",
-                                  "BESSX_CG_LAYOUT=tiles", "BESSX_FUSE=0", "BESSX_CG_TOL=1e-10", "BESSX_COV_CS=24",
-                                  "BESSX_DEFER_PUBLISH=0", "BESSX_FUSE_SEL=0", "BESSX_PANEL_PAIR_AUTO=0", "BESSX_PANEL_VARIANT=4",
-                                  "BESSX_CV_SIDE_BY_SIDE=0"])
+@pytest.mark.parametrize("knob", ["chain=0", "publish=0", "cov_solver=chol", "cg_layout=tiles", "fuse=0", "cov_cs=24",
+                                  "defer_publish=0", "fuse_sel=0", "cv_side_by_side=0"])
 def test_runtime_knobs_do_not_change_results(gpu, monkeypatch, knob):
-    """Every optional mechanism of the covariance form can be switched off: the candidates, their supports and their ICs
-    stay the same."""
+    """Every optional mechanism of the covariance form has a fallback the library keeps (the unfused launch sequence, the
+    Cholesky behind the conjugate gradients, ...); forced through its test hook, the candidates, their supports and their
+    ICs stay the same."""
     X, y, _, _ = synth.make_lm(1500, 2500, 15)
     seq = np.arange(1, 41)
     with gpu.Session(X, y, score_mode=2) as s:
         base = s.sequential_path(seq, ic_type=3)
     name, val = knob.split("=")
-    monkeypatch.setenv(name, val)
+    hooks(monkeypatch, **{name: val})
     with gpu.Session(X, y, score_mode=2) as s:
         alt = s.sequential_path(seq, ic_type=3)
         again = s.sequential_path(seq, ic_type=3)
@@ -144,12 +143,12 @@ def test_score_mode_argument(gpu):
 def test_cv_row_sets_share_their_fills(gpu, monkeypatch, n, p, K):
     """Cross-validation in the covariance form: one unmasked pass over a fold-major copy of X fills the Gram-column
     caches of ALL K + 1 row sets (the slab partials of every fold but k sum to fold k's training rows).  Same path as with
-    one masked pass per row set (BESSX_CV_SHARED=0), far fewer passes over X, and the oracle's path fit by fit."""
+    one masked pass per row set (test hook cv_shared=0), far fewer passes over X, and the oracle's path fit by fit."""
     X, y, _, _ = synth.make_lm(n, p, 10, seed=n)
     fold = synth.make_cv_folds(n, K, seed=3)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("BESSX_CV_SHARED", mode)
+        hooks(monkeypatch, cv_shared=mode)
         with gpu.Session(X, y, score_mode=2) as s:
             s.set_cv(K, fold)
             s.trace_enable(True)

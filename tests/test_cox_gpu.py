@@ -7,6 +7,8 @@ import pytest
 from bess_amd import synth
 from test_glm_gpu import check
 
+from helpers import hooks  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 COX = dict(data_type=3, model_type=4)
 
@@ -43,13 +45,13 @@ def test_cox_sparsity_levels_above_254(gpu):
 
 
 def test_cox_score_pass_forms_agree(gpu, monkeypatch):
-    """BESSX_COX_SCORE=2pass (block totals, carry, rescan: X read twice) and the default one-pass form (summation
+    """test hook cox_score=2pass (block totals, carry, rescan: X read twice) and the default one-pass form (summation
     order exchanged, X read once) give the same path: supports at every iteration, coefficients, IC values."""
     X, _, status, _, _ = synth.make_cox(3000, 260, 8, seed=12)
     fold = synth.make_cv_folds(3000, 5)
     outs = []
     for form in ("1pass", "2pass"):
-        monkeypatch.setenv("BESSX_COX_SCORE", form)
+        hooks(monkeypatch, cox_score=form)
         with gpu.Session(X, status, data_type=3, model_type=4) as s:
             s.set_cv(5, fold)
             s.trace_enable(True)
@@ -69,7 +71,7 @@ def test_cox_hessian_forms_against_the_oracle(gpu, monkeypatch, form):
     read, slab-local suffix sums + carry terms; default from n = 1024) and in the two-pass form built like the
     reference's formulas (M = S1 / S0 materialised; default below), each FORCED on the same problems: plain, weighted,
     ridge, CV row masks, a slab count that does not divide the rows, sparsity levels across tile boundaries."""
-    monkeypatch.setenv("BESSX_COX_HESS", form)
+    hooks(monkeypatch, cox_hess=form)
     X, _, status, _, _ = synth.make_cox(600, 100, 6)
     check(gpu, X, status, dict(COX, ic_type=3, sequence=np.arange(1, 13)), "cox seq, hessian " + form)
     w = np.random.default_rng(1).uniform(0.5, 2, 600)
@@ -88,7 +90,7 @@ def test_cox_hessian_forms_agree(gpu, monkeypatch):
     X, _, status, _, _ = synth.make_cox(20000, 400, 20, seed=31)
     outs = []
     for form in ("1pass", "2pass"):
-        monkeypatch.setenv("BESSX_COX_HESS", form)
+        hooks(monkeypatch, cox_hess=form)
         with gpu.Session(X, status, data_type=3, model_type=4) as s:
             outs.append(s.sequential_path(np.array([1, 2, 5, 17, 40, 64, 65, 100, 129, 150]), ic_type=3))
     a, b = outs

@@ -1,6 +1,6 @@
 """GPU: the K fold fits of a cross-validation evaluation (Metric::test_loss, src/Metric.h:150-195) run SIDE BY SIDE --
 one fit context per fold on its own stream, one fill of the shared Gram-column caches for every fold that is parked
-on missing columns -- and walk exactly the path they walk one after another (BESSX_CV_SIDE_BY_SIDE=0) and the
+on missing columns -- and walk exactly the path they walk one after another (test hook cv_side_by_side=0) and the
 oracle's: golden-section, sequential (two ridge values: the score-only restart of a fit) and Powell paths, a cache
 small enough to be started over while chains are in the middle of their fits, tied scores (the exact tie rule inside
 a chain) and nearly collinear columns (a chain's conjugate-gradient solve handed to Cholesky)."""
@@ -9,6 +9,8 @@ import pytest
 
 from bess_amd import synth
 from oracle import port_ctypes as P
+
+from helpers import hooks  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +24,7 @@ def _paths(s, kmax):
 def _both(gpu, monkeypatch, X, y, K, fold, kmax, **kw):
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("BESSX_CV_SIDE_BY_SIDE", mode)
+        hooks(monkeypatch, cv_side_by_side=mode)
         with gpu.Session(X, y, score_mode=2, **kw) as s:
             s.set_cv(K, fold)
             outs[mode] = (_paths(s, kmax), s.counters())
@@ -57,12 +59,12 @@ def test_cache_started_over_under_the_chains(gpu, monkeypatch):
     """A cache of 160 columns for 3 chains of up to 24 columns: it fills up along the path, a chain that finds it full is
     parked (cov_stall = 4) and the host starts it over for all chains at once -- also for the chains that are in the
     middle of a fit, whose current columns are formed again by the same fill."""
-    monkeypatch.setenv("BESSX_COV_CAP", "160")
+    hooks(monkeypatch, cov_cap="160")
     X, y, _, _ = synth.make_lm(900, 2500, 20, seed=4)
     fold = synth.make_cv_folds(900, 3, seed=1)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("BESSX_CV_SIDE_BY_SIDE", mode)
+        hooks(monkeypatch, cv_side_by_side=mode)
         with gpu.Session(X, y, score_mode=2) as s:
             s.set_cv(3, fold)
             outs[mode] = (s.gs_path(1, 24, ic_type=3, is_cv=True), s.counters())
@@ -89,7 +91,7 @@ def test_ties_and_collinear_columns_inside_the_chains(gpu, monkeypatch):
     fold = synth.make_cv_folds(300, 5)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("BESSX_CV_SIDE_BY_SIDE", mode)
+        hooks(monkeypatch, cv_side_by_side=mode)
         with gpu.Session(X, y, score_mode=2) as s:
             s.set_cv(5, fold)
             outs[mode] = (s.sequential_path(np.arange(1, 7), ic_type=3, is_cv=True), s.counters())
@@ -151,12 +153,12 @@ def test_chains_opened_from_uploaded_supports_share_one_fill(gpu, monkeypatch):
     state) into a nearly full cache: the Gram columns of the K initial supports are formed by ONE fill whose restart is
     decided once -- until round 3 every chain ran its own slot-0 lookup, and a later chain's restart evicted what an
     earlier chain had just filled (BESSX_ERR_NUMERIC 'an active column was missing from the Gram column cache')."""
-    monkeypatch.setenv("BESSX_COV_CAP", "160")
+    hooks(monkeypatch, cov_cap="160")
     X, y, _, _ = synth.make_lm(900, 2500, 20, seed=4)
     fold = synth.make_cv_folds(900, 3, seed=1)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("BESSX_CV_SIDE_BY_SIDE", mode)
+        hooks(monkeypatch, cv_side_by_side=mode)
         with gpu.Session(X, y, score_mode=2) as s:
             s.set_cv(3, fold)
             recs, init = [], (np.zeros(0, np.int32), np.zeros(0))

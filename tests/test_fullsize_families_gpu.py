@@ -22,6 +22,8 @@ import pytest
 from bess_amd import synth
 from bess_amd import dist as bdist
 
+from helpers import hooks  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -225,13 +227,13 @@ def test_cox_config_recipe_matches_compiled_reference_at_n4000(gpu):
     n, p, ktrue, kmax = int(g["n"]), int(g["p"]), int(g["k_true"]), int(g["kmax"])
     X, _, status, support, _ = synth.make_cox(n, p, ktrue)
     for form in ("1pass", "2pass"):
-        os.environ["BESSX_COX_SCORE"] = form
+        os.environ["BESSX_TEST_HOOKS"] = "cox_score=" + form
         try:
             with gpu.Session(X, status, data_type=3, model_type=4) as s:
                 s.trace_enable(True)
                 out = s.sequential_path(np.arange(1, kmax + 1), ic_type=3)
         finally:
-            os.environ.pop("BESSX_COX_SCORE", None)
+            os.environ.pop("BESSX_TEST_HOOKS", None)
         assert_matches_golden(out["trace"], g, "configs[4] recipe at n=%d p=%d, %s score" % (n, p, form),
                               beta_rtol=1e-5, metric_rtol=1e-7)
         assert_best_model(out, g, rtol=1e-5)
@@ -265,7 +267,7 @@ def test_cox_config_properties_at_full_size(gpu, cox_full, monkeypatch):
     again = s.sequential_path(np.arange(1, kmax + 1), ic_type=3)
     for k in ("cand_support", "cand_beta", "cand_ic", "cand_iters"):
         assert np.array_equal(out[k], again[k]), k
-    monkeypatch.setenv("BESSX_COX_SCORE", "2pass")  # read when a session is created
+    hooks(monkeypatch, cox_score="2pass")  # read when a session is created
     with gpu.Session(X, status, data_type=3, model_type=4) as s2:
         two = s2.sequential_path(np.arange(1, 41), ic_type=3)
     assert np.array_equal(two["cand_support"], out["cand_support"][:40, :40])

@@ -6,7 +6,7 @@ import pytest
 
 from bess_amd import synth
 from oracle import port_ctypes as P
-from helpers import assert_same_trace
+from helpers import assert_same_trace, hooks
 from test_lm_gpu import run_gpu
 
 pytestmark = pytest.mark.gpu
@@ -79,14 +79,14 @@ def test_poisson_cv(gpu):
 
 def test_fused_irls_step_gives_the_same_fits(gpu, monkeypatch):
     """The three-launch IRLS step (k_irls_gram: linear predictor, weights, working response and Gram in one pass; the
-    convergence test at the head of the solve; the default) against the five-launch step (BESSX_IRLS_FUSE=0): the same
+    convergence test at the head of the solve; the default) against the five-launch step (test hook irls_fuse=0): the same
     arithmetic per row, the linear predictor summed in another order -- identical supports, PDAS iteration counts and
     IRLS step counts, coefficients to rounding."""
     X, y, _, _ = synth.make_logistic(1500, 300, 8, seed=6)
     Xp, yp = X[:, :120], np.random.default_rng(5).poisson(np.exp(np.clip(0.3 * X[:, 0] - 0.2 * X[:, 3], -3, 3))).astype(float)
     outs = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("BESSX_IRLS_FUSE", flag)
+        hooks(monkeypatch, irls_fuse=flag)
         with gpu.Session(X, y, data_type=2, model_type=2) as s:
             a = s.sequential_path(np.arange(1, 25), ic_type=3)
         with gpu.Session(Xp, yp, data_type=2, model_type=3) as s:

@@ -1,12 +1,14 @@
 """Group selection with groups of one width: the selected groups are expanded to columns on the device
 (k_group_expand; find_ind, src/utilities.cpp:113-130) and the PDAS iterations of a fit are queued as gated slots, one
-host round trip per batch.  Same fits as the host-side expansion (BESSX_GROUP_EXPAND=host: two synchronisations per
+host round trip per batch.  Same fits as the host-side expansion (test hook group_expand=host: two synchronisations per
 iteration, round 3's form) and as the oracle: every candidate's groups, iteration counts, coefficients, criteria."""
 import numpy as np
 import pytest
 
 from bess_amd import synth
 from oracle import port_ctypes as P
+
+from helpers import hooks  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +29,7 @@ def test_uniform_groups_expand_on_the_device(gpu, monkeypatch, gs, G, T):
     X, y, g_index = _grouped_lm(1500, G, gs, 6, seed=gs + G)
     outs = {}
     for mode in ("device", "host"):
-        monkeypatch.setenv("BESSX_GROUP_EXPAND", mode)
+        hooks(monkeypatch, group_expand=mode)
         with gpu.Session(X, y, g_index=g_index, algorithm_type=2) as s:
             outs[mode] = (s.sequential_path(np.arange(1, T + 1), ic_type=3), s.gs_path(1, min(T, 20), ic_type=3))
     for a, b in zip(outs["device"], outs["host"]):
@@ -51,7 +53,7 @@ def test_grouped_cv_and_ridge_paths_on_the_device_path(gpu, monkeypatch):
     fold = synth.make_cv_folds(1200, 4, seed=2)
     outs = {}
     for mode in ("device", "host"):
-        monkeypatch.setenv("BESSX_GROUP_EXPAND", mode)
+        hooks(monkeypatch, group_expand=mode)
         with gpu.Session(X, y, g_index=g_index, algorithm_type=3) as s:
             s.set_cv(4, fold)
             outs[mode] = (s.sequential_path(np.arange(1, 11), [0.0, 0.05], ic_type=3, is_cv=True),
