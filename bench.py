@@ -388,10 +388,25 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
         sess.set_cv(5, synth.make_cv_folds(n, 5))
         setup = time.time() - t0
         rec = timed(sess, lambda: sess.gs_path(1, 200, ic_type=3, is_cv=True), n, p)
+        # the fold-sharded driver (bess_amd.dist.FoldShardedCV on bessx_session_cv_eval) at ONE rank, same session: what a
+        # rank of `--workload lm-cv-gs --gpus N` runs, beside the in-library path it must not be slower than
+        from bess_amd import dist as bdist
+        bdist.FoldShardedCV(sess, 5).gs_path(1, 200)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        sh = bdist.FoldShardedCV(sess, 5).gs_path(1, 200)
+        torch.cuda.synchronize()
+        sharded = {"ms_per_path": 1e3 * (time.time() - t1), "fits": int(sh["n_fits"]),
+                   "pdas_iterations": int(sh["n_pdas_iters"]), "selected_k": int(sh["best_T0"]),
+                   "criterion": float(sh["ic"]), "evaluation_rounds": int(sh["evaluations"])}
     rec.update({"workload": "configs[3]: LM gs_path on [1,200] + 5-fold CV (fixed folds), n=%d p=%d; a candidate = the "
                             "full-data fit + 5 fold fits" % (n, p),
                 "fits_per_s": rec["fits"] / (rec["ms_per_path"] / 1e3), "score_kernel_name": "k_cov_panel (32 Gram "
                 "columns of every row set per pass over the fold-major copy of X)", "setup_seconds": setup})
+    sharded["ratio_to_the_in_library_path"] = sharded["ms_per_path"] / rec["ms_per_path"]
+    sharded["same_result"] = bool(sharded["selected_k"] == rec["selected_k"] and
+                                  abs(sharded["criterion"] - rec["criterion"]) <= 1e-12 * abs(rec["criterion"]))
+    rec["lmcv_sharded_world1"] = sharded
     res["lmcv"] = rec
     # SURVEY 8f rank 3, group selection: the configs[1] design as 2000 groups of 5 columns, 1..40 groups
     t0 = time.time()
