@@ -314,6 +314,12 @@ class FoldShardedCV:
             folds = [u for u in self.units if u != self.K] if want_folds else []
             init = full_init if full_init is not None else (np.zeros(0, np.int32), np.zeros(0))
             got = self.s.cv_eval(T0, lam, own_full, init[0], init[1], coef0_init, folds) if (own_full or folds) else []
+            if self.world == 1:  # nothing to exchange: the records are the result
+                recs = dict(zip(([self.K] if own_full else []) + folds, got))
+                self.evaluations += 1
+                self.n_fits += len(recs)
+                self.n_pdas_iters += sum(r["iters"] for r in recs.values())
+                return recs
             for u, r in zip(([self.K] if own_full else []) + folds, got):
                 mine[row, :self.HEAD] = (u, r["iters"], r["coef0"], r["train_loss"], r["test_loss"])
                 k = len(r["support"])
