@@ -421,6 +421,25 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
                 "host_round_trips": "one per batch of two PDAS iterations (the selected groups are expanded to columns on "
                                     "the device, k_group_expand)", "setup_seconds": setup})
     res["grouped_lm"] = rec
+    # L0L2 / bsrr -- the Powell path over (s, log lambda) with golden-section line searches
+    with capi.Session(X_lm, y_lm, data_type=1, model_type=1, algorithm_type=5, device=local_rank) as sess:
+        rec = timed(sess, lambda: sess.pgs_path(1, 200, 0.01, 100.0, n_lambda=100, powell_path=1, ic_type=3), n, p)
+    rec.update({"workload": "SURVEY 8f: L0L2 (algorithm_type 5) Powell path pgs_path on s in [1,200] x lambda in [0.01,100], "
+                            "golden-section line searches, configs[1] data, GIC; candidates = line searches + the final fit",
+                "score_kernel_name": "k_cov_panel (covariance form)"})
+    res["powell_l0l2"] = rec
+    # sure independence screening in front of the path (10000 -> 2000 columns), then k = 1..100
+    t0 = time.time()
+    with capi.Session(X_lm, y_lm, data_type=1, model_type=1, is_screening=True, screening_size=2000,
+                      device=local_rank) as sess:
+        setup = time.time() - t0
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 101), ic_type=3), n, 2000)
+    rec.update({"workload": "SURVEY 8f: screening (SIS, src/screening.cpp:26-105) of the configs[1] design to its 2000 best "
+                            "columns, then the sequential path k=1..100 on them; the screening itself is one two-accumulator "
+                            "pass over the raw X at session creation",
+                "session_creation_seconds_incl_upload_and_screening": setup,
+                "score_kernel_name": "k_cov_panel on the 2000 kept columns (0.8 GB per pass)"})
+    res["screened_lm"] = rec
     del X_lm
     # the reference's DEFAULT call: sequence = 1..min(p, n / log n) (python/bess/linear.py:285-287) at n = 25000, p = 3000
     nd, pd = 25000, 3000
