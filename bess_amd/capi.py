@@ -29,7 +29,8 @@ SYMBOLS = [
     "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_fit_width", "bessx_session_reset_caches",
     "bessx_session_sequential_path_chain", "bessx_session_cv_eval", "bessx_session_debug_block_stream",
     "bessx_session_marginal_scores", "bessx_session_cov_prefill_begin", "bessx_session_cov_prefill_compute",
-    "bessx_session_cov_prefill_export", "bessx_session_cov_prefill_import", "bessx_session_cov_prefill_end", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
+    "bessx_session_cov_prefill_export", "bessx_session_cov_prefill_import", "bessx_session_cov_prefill_end",
+    "bessx_session_cov_prefill_extend", "bessx_session_cov_state", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench", "bessx_op_cox_score_bench",
 ]
 
@@ -125,6 +126,8 @@ def lib():
         L.bessx_session_debug_block_stream.argtypes = [_vp, _i]
         L.bessx_session_marginal_scores.argtypes = [_vp, _D]
         L.bessx_session_cov_prefill_begin.argtypes = [_vp, _I, _i]
+        L.bessx_session_cov_prefill_extend.argtypes = [_vp, _I, _i]
+        L.bessx_session_cov_state.argtypes = [_vp, _D, _I]
         L.bessx_session_cov_prefill_compute.argtypes = [_vp, _i, _i]
         L.bessx_session_cov_prefill_export.argtypes = [_vp, _i, _i, _vp, _i]
         L.bessx_session_cov_prefill_import.argtypes = [_vp, _i, _i, _vp, _i]
@@ -441,6 +444,16 @@ class Session:
     def cov_prefill_begin(self, cols):
         c = _i32(cols)
         _check(lib().bessx_session_cov_prefill_begin(self._h, _ip(c), c.size))
+
+    def cov_prefill_extend(self, cols):
+        c = _i32(cols)
+        _check(lib().bessx_session_cov_prefill_extend(self._h, _ip(c), c.size))
+
+    def cov_state(self):
+        """(scores of the last fit's last PDAS iteration, cache slot of every column or -1)."""
+        bd, so = np.zeros(self.p_kept), np.zeros(self.p_kept, dtype=np.int32)
+        _check(lib().bessx_session_cov_state(self._h, _dp(bd), _ip(so)))
+        return bd, so
 
     def cov_prefill_compute(self, g0, ngroups):
         _check(lib().bessx_session_cov_prefill_compute(self._h, int(g0), int(ngroups)))

@@ -347,6 +347,7 @@ struct bessx_session {
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
   int prefill_cols = 0;            // columns listed by bessx_session_cov_prefill_begin (0: no prefill in progress)
+  int prefill_base = 0;            // ... first cache slot of that list (0, or the occupancy cov_prefill_extend found)
   double *cgb_work = nullptr;      // large-system conjugate gradients (bessx_cgbig.hip): dense matrix + vectors, on first use
   int cgb_cap = 0, cgb_guess = 40; // ... unknowns it holds; step launches queued per solve (adapted to the steps the last took)
   std::vector<std::pair<size_t, int>> cov_timed;  // (event index, first group) of the timed panel launches

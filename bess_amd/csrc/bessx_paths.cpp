@@ -809,17 +809,30 @@ int bessx_session_marginal_scores(bessx_session *s, double *bd) {
   return BESSX_OK;
 }
 
-int bessx_session_cov_prefill_begin(bessx_session *s, const int *cols, int ncols) {
+// append = 0: the cache is started over and slot i goes to cols[i]; 1: the columns (all of them uncached) take the next
+// free slots of the cache as it is -- the same slots on every rank whose session has done the same work so far
+static int prefill_begin(bessx_session *s, const int *cols, int ncols, int append) {
   if (int rc = prefill_ready(s)) return rc;
   if (!cols || ncols < 1 || ncols % COV_R != 0) return fail(BESSX_ERR_ARG, "cov_prefill: need a multiple of 32 columns");
-  if (ncols + s->cov_spec + COV_R > cov_C_dev(s) || ncols > s->capA)
-    return fail(BESSX_ERR_ARG, "cov_prefill: the list does not fit the Gram column cache");
   std::vector<char> seen((size_t)s->p, 0);
   for (int i = 0; i < ncols; i++) {
     if (cols[i] < 0 || cols[i] >= s->p || seen[(size_t)cols[i]]) return fail(BESSX_ERR_ARG, "cov_prefill: bad column list");
     seen[(size_t)cols[i]] = 1;
   }
-  if (int rc = reset_path_caches(s)) return rc;
+  int base = 0;
+  if (append) {
+    if (int rc = settle_device_chain(s)) return rc;
+    int meta_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPX(hipMemcpyAsync(meta_h, s->cov[0].meta, sizeof(meta_h), hipMemcpyDeviceToHost, s->st));
+    HIPX(hipStreamSynchronize(s->st));
+    base = meta_h[0];
+    for (auto &c : s->cache) c.valid = false;  // (a fit that follows starts from uploaded coefficients)
+    s->dev_state_rs = -1;
+  } else if (int rc = reset_path_caches(s)) {
+    return rc;
+  }
+  if (base + ncols + s->cov_spec + COV_R > cov_C_dev(s) || ncols > s->capA)
+    return fail(BESSX_ERR_ARG, "cov_prefill: the list does not fit the Gram column cache");
   int *st_idx = reinterpret_cast<int *>(s->stage_h);
   std::copy(cols, cols + ncols, st_idx);
   HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, (size_t)ncols * sizeof(int), hipMemcpyHostToDevice, s->st));
@@ -827,10 +840,27 @@ int bessx_session_cov_prefill_begin(bessx_session *s, const int *cols, int ncols
   u.nf = 1;
   u.list[0] = s->init_idx_d;
   u.len[0] = ncols;
-  HIPX(launch_cov_fill_union(u, 1, nullptr, nullptr, s->cov_spec, 0, s->cov[0].slot_of, s->cov[0].meta, s->p, s->cov_fcols,
-                             s->fill_ctrl, s->st));
+  HIPX(launch_cov_fill_union(u, append ? 0 : 1, nullptr, nullptr, s->cov_spec, 0, s->cov[0].slot_of, s->cov[0].meta, s->p,
+                             s->cov_fcols, s->fill_ctrl, s->st));
+  HIPX(hipMemcpyAsync(s->fill_ctrl_h, s->fill_ctrl, sizeof(FitCtrl), hipMemcpyDeviceToHost, s->st));
   HIPX(hipStreamSynchronize(s->st));  // (the staging buffer is free again)
+  if (s->fill_ctrl_h->cov_nfill != ncols)
+    return fail(BESSX_ERR_ARG, "cov_prefill_extend: a listed column is cached already (the slots would not line up across ranks)");
   s->prefill_cols = ncols;
+  s->prefill_base = base;
+  return BESSX_OK;
+}
+
+int bessx_session_cov_prefill_begin(bessx_session *s, const int *cols, int ncols) { return prefill_begin(s, cols, ncols, 0); }
+int bessx_session_cov_prefill_extend(bessx_session *s, const int *cols, int ncols) { return prefill_begin(s, cols, ncols, 1); }
+
+// The sacrifice scores of the last PDAS iteration of the last fit (bd) and the slot of every column in the Gram column
+// cache of the all-rows row set (-1: not cached): what a caller needs to pick the next columns worth caching.
+int bessx_session_cov_state(bessx_session *s, double *bd, int *slot_of) {
+  if (int rc = prefill_ready(s)) return rc;
+  HIPX(hipStreamSynchronize(s->st));
+  if (bd) HIPX(hipMemcpy(bd, s->bd, (size_t)s->p * sizeof(double), hipMemcpyDeviceToHost));
+  if (slot_of) HIPX(hipMemcpy(slot_of, s->cov[0].slot_of, (size_t)s->p * sizeof(int), hipMemcpyDeviceToHost));
   return BESSX_OK;
 }
 
@@ -848,7 +878,7 @@ int bessx_session_cov_prefill_export(bessx_session *s, int g0, int ngroups, doub
   if (int rc = prefill_ready(s)) return rc;
   if (!dst || g0 < 0 || ngroups < 0 || (g0 + ngroups) * COV_R > s->prefill_cols) return fail(BESSX_ERR_ARG, "cov_prefill: group range");
   const size_t cnt = (size_t)ngroups * COV_R * s->p;
-  HIPX(hipMemcpyAsync(dst, s->cov[0].G + (size_t)g0 * COV_R * s->p, cnt * sizeof(double),
+  HIPX(hipMemcpyAsync(dst, s->cov[0].G + ((size_t)s->prefill_base + (size_t)g0 * COV_R) * s->p, cnt * sizeof(double),
                       dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->st));
   HIPX(hipStreamSynchronize(s->st));
   return BESSX_OK;
@@ -858,7 +888,7 @@ int bessx_session_cov_prefill_import(bessx_session *s, int g0, int ngroups, cons
   if (int rc = prefill_ready(s)) return rc;
   if (!src || g0 < 0 || ngroups < 0 || (g0 + ngroups) * COV_R > s->prefill_cols) return fail(BESSX_ERR_ARG, "cov_prefill: group range");
   const size_t cnt = (size_t)ngroups * COV_R * s->p;
-  HIPX(hipMemcpyAsync(s->cov[0].G + (size_t)g0 * COV_R * s->p, src, cnt * sizeof(double),
+  HIPX(hipMemcpyAsync(s->cov[0].G + ((size_t)s->prefill_base + (size_t)g0 * COV_R) * s->p, src, cnt * sizeof(double),
                       src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st));
   HIPX(hipStreamSynchronize(s->st));  // (the caller's buffer is free again when the call returns)
   return BESSX_OK;

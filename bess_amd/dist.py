@@ -98,21 +98,9 @@ class _TorchComm:
                 session.cov_prefill_import(a, b - a, blk[:(b - a) * 32 * p])
 
 
-def cooperative_prefill(session, world, rank, comm, n_cols):
-    """Before the chunks of a k-path start cold: the ranks share the passes over X their cold starts would all repeat.
-    The list is the same on every rank -- the n_cols columns with the largest sacrifice scores at beta = 0, what the
-    first PDAS iteration of any cold fit ranks (src/Algorithm.h:1109-1128) --; rank r forms the Gram columns of its
-    contiguous share of the 32-column groups (one pass over X per group, two groups per pass with the pair kernel),
-    the p x 32 blocks are all-gathered (2.4 MB each at p = 10000: the ONE data-path collective of this mode, which
-    north_star's replicas-only partitioning does not have -- keep n_cols = 0 for that), and every rank's cache then
-    holds all of them under the same slots.  Columns a chunk needs beyond the list are formed by the rank itself, as
-    without the prefill.  Cache contents only: every result is what it is without it."""
-    ng = int(n_cols) // 32
-    if ng < 1:
-        return 0
-    scores = session.marginal_scores()
-    cols = np.argsort(-scores, kind="stable")[:ng * 32].astype(np.int32)
-    session.cov_prefill_begin(cols)
+def _share_and_exchange(session, world, rank, comm, ng):
+    """This rank's contiguous share of the ng listed 32-column groups (one pass over X per group, two groups per pass with
+    the pair kernel), then everybody's blocks to everybody."""
     lo, hi = partition(ng, world, rank)
     session.cov_prefill_compute(lo, hi - lo)
     if world > 1:
@@ -130,6 +118,47 @@ def cooperative_prefill(session, world, rank, comm, n_cols):
                     session.cov_prefill_import(a, b - a, blk[:(b - a) * 32 * p])
     session.cov_prefill_end()
     return hi - lo
+
+
+def cooperative_prefill(session, world, rank, comm, n_cols):
+    """Before the chunks of a k-path start cold: the ranks share the passes over X their cold starts would all repeat.
+    The list is the same on every rank -- the n_cols columns with the largest sacrifice scores at beta = 0, what the
+    first PDAS iteration of any cold fit ranks (src/Algorithm.h:1109-1128) --; rank r forms the Gram columns of its
+    contiguous share of the 32-column groups, the p x 32 blocks are all-gathered (2.56 MB each at p = 10000: the ONE
+    data-path collective of this mode, which north_star's replicas-only partitioning does not have -- keep n_cols = 0
+    for that), and every rank's cache then holds all of them under the same slots.  Columns a chunk needs beyond the
+    list are formed by the rank itself, as without the prefill.  Cache contents only: every result is what it is
+    without it."""
+    ng = int(n_cols) // 32
+    if ng < 1:
+        return 0
+    scores = session.marginal_scores()
+    cols = np.argsort(-scores, kind="stable")[:ng * 32].astype(np.int32)
+    session.cov_prefill_begin(cols)
+    return _share_and_exchange(session, world, rank, comm, ng)
+
+
+def pilot_prefill(session, world, rank, comm, n_first, k_pilot, n_second, ic_type=3):
+    """Two shared fills around a PILOT fit every rank runs identically.  The marginal list of cooperative_prefill covers
+    the first PDAS iteration of a cold fit only: the iterations after it rank the noise columns by the residual of the
+    FITTED model, which the marginal ranking does not predict (tools/coop_prefill.py: the slowest of 8 chunks still spent
+    8.5 of its 9.5 ms on ~9 private fills).  So: (1) the n_first columns with the largest marginal scores, shared;
+    (2) the same fit of sparsity level k_pilot on every rank (same data, same cache, deterministic kernels: bit-identical
+    results and cache states, no communication); (3) the n_second uncached columns the pilot's final scores rank highest
+    -- the columns the chain is about to visit -- appended to the cache in the same slots everywhere, again one share
+    per rank.  Returns the pilot's model (normalised scale): the chunks beyond k_pilot start warm from it instead of cold.
+    Two data-path all-gathers of p x 32 blocks; cache contents and starting points only -- the stitching makes the
+    gathered path the single chain's whatever the chunks started from."""
+    cooperative_prefill(session, world, rank, comm, n_first)
+    pilot = session.sequential_path_chain([int(k_pilot)], ic_type=ic_type, keep_caches=True)
+    bd, slot = session.cov_state()
+    score = np.where(slot >= 0, -np.inf, bd)
+    ng = min(int(n_second) // 32, int(np.sum(slot < 0)) // 32)
+    if ng >= 1:
+        cols = np.argsort(-score, kind="stable")[:ng * 32].astype(np.int32)
+        session.cov_prefill_extend(cols)
+        _share_and_exchange(session, world, rank, comm, ng)
+    return pilot["last_idx"], pilot["last_val"], pilot["last_coef0"]
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -153,7 +182,7 @@ class StitchedKPath:
     (bess_amd.capi.Session).  step() returns this rank's chunk of the single chain plus the gathered IC curve."""
 
     def __init__(self, session, sequence, world=1, rank=0, ic_type=3, lead=(), device=None, stop_rtol=1e-9, comm=None,
-                 prefill=0):
+                 prefill=0, pilot=None):
         self.s, self.world, self.rank = session, int(world), int(rank)
         self.full_seq = np.asarray(sequence, dtype=np.int32)
         self.kmax = int(self.full_seq.size)
@@ -165,6 +194,7 @@ class StitchedKPath:
         self.comm = comm if comm is not None else (_TorchComm(device) if world > 1 else _NoComm())
         self.stop_rtol = stop_rtol
         self.prefill = int(prefill)  # columns of the cooperative prefill in front of the chunks (0: replicas only)
+        self.pilot = pilot           # (k_pilot, n_second) of pilot_prefill, or None: the marginal list alone
         self.width = int(self.full_seq.max()) if self.kmax else 1  # longest support of the path (singleton groups)
 
     KEYS = ("cand_T0", "cand_iters", "cand_train_loss", "cand_ic", "cand_coef0", "cand_support", "cand_beta")
@@ -187,10 +217,21 @@ class StitchedKPath:
         mine = None
         last = (np.zeros(0, np.int32), np.zeros(0), 0.0)
         t_pre = 0.0
+        init = None
         if self.prefill >= 32 and self.world > 1:
-            cooperative_prefill(self.s, self.world, self.rank, self.comm, self.prefill)
+            if self.pilot:
+                model = pilot_prefill(self.s, self.world, self.rank, self.comm, self.prefill, self.pilot[0], self.pilot[1],
+                                      ic_type=self.ic_type)
+                if self.seq.size and int(self.seq[0]) > int(self.pilot[0]):
+                    init = model  # (chunks at or below the pilot's level start cold: cheap there)
+            else:
+                cooperative_prefill(self.s, self.world, self.rank, self.comm, self.prefill)
             t_pre = time.time() - t0
-        if self.seq.size:
+        if self.seq.size and init is not None:
+            nl = 0
+            out = self.s.sequential_path_chain(self.seq, ic_type=self.ic_type, keep_caches=True, init_idx=init[0],
+                                               init_val=init[1], init_coef0=init[2])
+        elif self.seq.size:
             out = self.s.sequential_path_chain(np.concatenate([self.lead, self.seq]), ic_type=self.ic_type,
                                                keep_caches=t_pre > 0.0)
             mine = {k: np.array(out[k][nl:]) for k in self.KEYS}

@@ -313,6 +313,12 @@ int bessx_session_cv_eval(bessx_session *s, int T0, double lambda, int want_full
  * their top M.  *_on_device: the buffer is device memory of this session's device (else host memory). */
 int bessx_session_marginal_scores(bessx_session *s, double *bd /* p */);
 int bessx_session_cov_prefill_begin(bessx_session *s, const int *cols, int ncols /* multiple of 32, distinct */);
+/* A second list on top of the cache as it is (after a prefill, after fits): the columns -- none of them cached yet --
+ * take the next free slots in list order; identical on every rank whose session has done identical work so far. */
+int bessx_session_cov_prefill_extend(bessx_session *s, const int *cols, int ncols);
+/* bd[p]: the sacrifice scores the last fit's last PDAS iteration ranked; slot_of[p]: cache slot of every column, -1 =
+ * not cached.  Either may be NULL.  What a caller needs to choose the next columns worth caching. */
+int bessx_session_cov_state(bessx_session *s, double *bd, int *slot_of);
 int bessx_session_cov_prefill_compute(bessx_session *s, int g0, int ngroups);
 int bessx_session_cov_prefill_export(bessx_session *s, int g0, int ngroups, double *dst, int dst_on_device);
 int bessx_session_cov_prefill_import(bessx_session *s, int g0, int ngroups, const double *src, int src_on_device);

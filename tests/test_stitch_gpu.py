@@ -198,3 +198,31 @@ def test_stitched_chunks_with_the_cooperative_prefill(gpu, world):
         np.testing.assert_array_equal(c, single["cand_support"][a:b, :c.shape[1]])
         np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-11)
         assert min(rep["prefill_seconds_per_rank"]) > 0.0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_stitched_chunks_with_the_pilot_prefill(gpu, world):
+    """pilot_prefill: marginal list, the same pilot fit on every rank, a second shared list from the pilot's scores
+    (appended to the cache in the same slots everywhere), chunks beyond the pilot's level started warm from its model.
+    Starting points and cache contents only: the stitched path is the single chain's."""
+    X, y, kw = _hard("lm", 1200, 400)
+    seq = np.arange(1, 33)
+    with gpu.Session(X, y, score_mode=2, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+
+    def rank_fn(rank, comm):
+        with gpu.Session(X, y, score_mode=2, **kw) as sr:
+            sk = bdist.StitchedKPath(sr, seq, world, rank, ic_type=3, comm=comm, prefill=64, pilot=(12, 96))
+            first = sk.step()
+            again = sk.step()
+            bd, slot = sr.cov_state()
+        np.testing.assert_array_equal(first["chunk"]["cand_support"], again["chunk"]["cand_support"])
+        return again, slot
+
+    res = run_ranks(world, rank_fn)
+    for r, (rep, slot) in enumerate(res):
+        a, b = bdist.partition(len(seq), world, r)
+        c = rep["chunk"]["cand_support"]
+        np.testing.assert_array_equal(c, single["cand_support"][a:b, :c.shape[1]])
+        np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-11)
+        assert int(np.sum(slot >= 0)) >= 64 + 96  # both shared lists are in every rank's cache
