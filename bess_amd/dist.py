@@ -234,6 +234,7 @@ class StitchedKPath:
         elif self.seq.size:
             out = self.s.sequential_path_chain(np.concatenate([self.lead, self.seq]), ic_type=self.ic_type,
                                                keep_caches=t_pre > 0.0)
+        if self.seq.size:
             mine = {k: np.array(out[k][nl:]) for k in self.KEYS}
             last = (out["last_idx"], out["last_val"], out["last_coef0"])
         t_chunk = time.time() - t0
