@@ -82,6 +82,12 @@ def parse_args(argv=None):
                          "caches in front of the chunks (bess_amd.dist.cooperative_prefill: the ranks share the passes "
                          "over X their cold starts would repeat; ONE data-path all-gather of p x 32 blocks).  0 = "
                          "replicas only, as north_star partitions the path; auto = 320 for lm-seq, 0 otherwise")
+    ap.add_argument("--pilot", default="auto",
+                    help="with the prefill: 'K,M2' = every rank runs the same pilot fit of sparsity level K on the prefilled "
+                         "cache, the M2 uncached columns its scores rank highest are shared as a second list and the chunks "
+                         "beyond K start warm from the pilot's model (bess_amd.dist.pilot_prefill); 'none'; auto = from 4 "
+                         "ranks: K = 0.64 kmax rounded to 32, prefill K + 32, M2 = 256 (tools/coop_prefill.py: slowest of 8 "
+                         "ranks 7.5 ms against 9.5 ms with the marginal list alone and 12.8 ms without a prefill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per timed segment")
     ap.add_argument("--shard", choices=["auto", "replica", "kpath"], default="auto",
@@ -591,10 +597,24 @@ def main():
     out = None
     stitch = None
     # N > 1, k-path: the chunks are stitched into the single warm-start chain every step (bess_amd.dist.StitchedKPath)
-    prefill = 0
+    prefill, pilot = 0, None
     if kpath and covariance and not cox:
-        prefill = 320 if args.prefill == "auto" else int(args.prefill)
-        prefill = max(0, min(prefill, (args.p // 32) * 32, 1024)) // 32 * 32
+        # measured on configs[1] (tools/coop_prefill.py, profiles/r04_lm_kpath_*_one_gpu.jsonl): 2 ranks lose with any
+        # prefill (15.0 ms without, 16.1 with 320 columns); 4 ranks: pilot 10.0 ms, marginal list 11.8, none 13.4;
+        # 8 ranks: pilot 7.5 ms, marginal list 9.5, none 11.6
+        kp = int(round(0.64 * args.kmax / 32.0)) * 32
+        if args.pilot not in ("auto", "none"):
+            kp, m2 = (int(v) for v in args.pilot.split(","))
+            pilot = (kp, m2 // 32 * 32)
+        elif args.pilot == "auto" and world >= 4 and 32 <= kp <= args.kmax - 8 and args.p >= 4 * (kp + 32 + 256):
+            pilot = (kp, 256)
+        if args.prefill == "auto":
+            prefill = (pilot[0] + 32) if pilot else (320 if world >= 3 else 0)
+        else:
+            prefill = int(args.prefill)
+        prefill = max(0, min(prefill, (args.p // 64) * 32, 1024)) // 32 * 32
+        if not prefill:
+            pilot = None
     if kpath:
         if args.chunk_start == "auto":
             # measured on configs[1], 8 chunks on one GPU (tools/coldstart.py, tools/coop_prefill.py, profiles/r04_*):
@@ -605,7 +625,7 @@ def main():
         if args.chunk_start == "ladder" and lo > 0:
             lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
     stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev,
-                                   prefill=prefill) if kpath else None
+                                   prefill=prefill, pilot=pilot) if kpath else None
     for _ in range(args.warmup):
         out = stitched.step() if kpath else sess.sequential_path(seq, ic_type=3)
     sess.enable_kernel_timing(True)
@@ -656,11 +676,13 @@ def main():
                 "stitch_seconds_per_rank": [round(v, 5) for v in stitch["stitch_seconds_per_rank"]],
                 "stitch_refits": stitch["stitch_refits"], "stitch_refits_per_rank": stitch["stitch_refits_per_rank"],
                 "stitch_rounds": stitch["stitch_rounds"],
-                "prefill_columns": prefill, "prefill_seconds_per_rank": [round(v, 5) for v in stitch["prefill_seconds_per_rank"]],
+                "prefill_columns": prefill, "pilot": list(pilot) if pilot else None, "prefill_seconds_per_rank": [round(v, 5) for v in stitch["prefill_seconds_per_rank"]],
                 "prefill": ("cooperative prefill: the %d columns with the largest marginal scores are formed once, their "
                             "32-column groups dealt to the ranks, the p x 32 blocks all-gathered (%d bytes per rank: a "
                             "data-path collective north_star's partitioning does not have; --prefill 0 = replicas only)"
-                            % (prefill, prefill * args.p * 8)) if prefill else "none (replicas only)",
+                            % (prefill, prefill * args.p * 8) + ("; then a pilot fit of level %d on every rank, the %d columns its "
+                            "scores rank highest shared the same way, chunks beyond it started warm from its model"
+                            % (pilot[0], pilot[1]) if pilot else "")) if prefill else "none (replicas only)",
                 "stitching": "after its chunk rank r re-fits its first candidates warm from rank r-1's last model until "
                              "a candidate coincides with its chunk's (same support, coefficients to 1e-9); the "
                              "candidates before that point are replaced: the gathered path IS the single chain's",

@@ -64,6 +64,17 @@ def test_bench_gpus_2_starts_two_ranks_and_shards_the_k_path(gpu):
     assert rep["supports_equal_to_single_chain"] == rep["of"] and rep["chunk_start"] == "ladder"
 
 
+def test_bench_three_ranks_with_the_pilot_prefill(gpu):
+    """--gpus 3 on the one-GPU box with the cooperative prefill and the pilot fit in front of the chunks: two data-path
+    all-gathers of Gram column blocks (gloo here), and still every candidate of the single chain."""
+    d = _run_bench(["--gpus", "3", "--prefill", "64", "--pilot", "12,64", "--no-cpu-baseline"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    rep = d["kpath_chunks_vs_single_chain"]
+    assert d["n_gpus"] == 3 and rep["chunks"] == [[1, 10], [11, 20], [21, 30]]
+    assert rep["supports_equal_to_single_chain"] == rep["of"] == 30 and rep["differing_k"] == []
+    assert rep["prefill_columns"] == 64 and rep["pilot"] == [12, 64] and min(rep["prefill_seconds_per_rank"]) > 0
+    assert "cooperative prefill" in d["config"]["collective"]
+
+
 def test_bench_weak_scaling_and_cv_workload_on_two_ranks(gpu):
     d = _run_bench(["--gpus", "2", "--shard", "replica", "--no-cpu-baseline"], {"BESSX_BENCH_ONE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["ic_curves_gathered"] == 2
