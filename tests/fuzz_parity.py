@@ -88,6 +88,12 @@ def run(cases=100, seed=1, medium=False, verbose=True):
                 # such draws; the GPU path returns the basic solution of its pivoted solve instead of an error:
                 # tests/test_rank_deficient_gpu.py)
                 gi = np.arange(0, p, 3).astype(np.int32)
+            if rng.random() < 0.4:
+                # groups of ONE width: untraced LM fits then expand the selected groups on the device (k_group_expand)
+                gs_u = int(rng.integers(2, 6))
+                p = (p // gs_u) * gs_u
+                X = np.ascontiguousarray(X[:, :p])
+                gi = np.arange(0, p, gs_u).astype(np.int32)
             kw.update(algorithm_type=2, g_index=gi, sequence=np.arange(1, min(len(gi), 6)))
             kw.pop("score_mode", None)
         elif mode == "powell":
@@ -172,6 +178,25 @@ def run(cases=100, seed=1, medium=False, verbose=True):
                 tol = 1e-4 if loose else 1e-8
                 np.testing.assert_allclose(fast["cand_ic"], got["cand_ic"], rtol=tol, atol=1e-9 * n)
                 np.testing.assert_allclose(fast["beta"], got["beta"], rtol=max(tol, 1e-7), atol=1e-12)
+            if mode == "seq" and not kw.get("is_cv") and "always_select" not in kw and len(kw["sequence"]) >= 4:
+                # the same path as two LINKS of one warm-start chain (bessx_session_sequential_path_chain): the second
+                # link starts from the model the first hands over, on its caches or cold
+                cut = int(rng.integers(1, len(kw["sequence"]) - 1))
+                with capi.Session(X, y, weight=kw.get("weight"), data_type=kw.get("data_type", 1),
+                                  is_normal=kw.get("is_normal", True), model_type=kw.get("model_type", 1),
+                                  max_iter=kw.get("max_iter", 20), is_warm_start=kw.get("is_warm_start", True),
+                                  score_mode=kw.get("score_mode", 0)) as sc:
+                    head = sc.sequential_path_chain(kw["sequence"][:cut], ic_type=kw["ic_type"])
+                    tail = sc.sequential_path_chain(kw["sequence"][cut:], ic_type=kw["ic_type"], init_idx=head["last_idx"],
+                                                    init_val=head["last_val"], init_coef0=head["last_coef0"],
+                                                    keep_caches=bool(rng.random() < 0.5))
+                w = fast["cand_support"].shape[1]
+                both = np.full((len(kw["sequence"]), w), -1, dtype=np.int32)
+                both[:cut, :head["cand_support"].shape[1]] = head["cand_support"]
+                both[cut:, :tail["cand_support"].shape[1]] = tail["cand_support"]
+                assert np.array_equal(both, fast["cand_support"]), "chain links: supports"
+                np.testing.assert_allclose(np.concatenate([head["cand_ic"], tail["cand_ic"]]), fast["cand_ic"],
+                                           rtol=1e-4 if loose else 1e-8, atol=1e-9 * n, err_msg="chain links: criteria")
         except Exception as e:  # noqa: BLE001
             fails += 1
             print("CASE %d FAILED: fam=%s n=%d p=%d seed=%d mode=%s kw=%r\n  %s" % (
