@@ -354,7 +354,7 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
     import torch
     from bess_amd import capi, synth
 
-    def timed(sess, run, n, p):
+    def timed(sess, run, n, p, traffic_key=None):
         run()  # warm-up (first use of a kernel loads its code object)
         sess.enable_kernel_timing(True)
         sess.score_pass_stats(reset=True)
@@ -370,13 +370,23 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
         passes = k1["algorithmic_bytes"] / (8.0 * n * p)
         per_pass = k1["seconds"] / passes if passes else 0.0
         gbps = 8.0 * n * p / per_pass / 1e9 if per_pass else 0.0
+        traffic = None
+        if traffic_key:  # HBM bytes per pass from the counter passes of an earlier run of the same kernel at this size
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(traffic_key)
+            except Exception:
+                traffic = None
         rec = {
             "candidates": int(out["n_candidates"]), "candidates_per_s": out["n_candidates"] / dt, "ms_per_path": 1e3 * dt,
             "fits": int(out["n_fits"]), "pdas_iterations": int(out["n_pdas_iters"]),
             "passes_over_X": passes,
             "score_kernel": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": gbps / HBM_PEAK_GBPS, "avg_launch_ms": 1e3 * per_pass,
-                             "algorithmic_bytes_per_pass": 8.0 * n * p, "measured_by": "HIP events on the session stream"},
+                             "algorithmic_bytes_per_pass": 8.0 * n * p, "measured_by": "HIP events on the session stream",
+                             "traffic": traffic,
+                             "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                "an earlier run of this kernel at this size, not measured in this run)"
+                                                if traffic else None)},
             "whole_path_frac_of_hbm": passes * 8.0 * n * p / dt / 1e9 / HBM_PEAK_GBPS,
             "time_share": {"kernel_streaming_X": k1["seconds"] / dt, "rest_of_the_chain_and_host": 1.0 - k1["seconds"] / dt},
             "selected_k": int(out["best_T0"]), "criterion": float(out["ic"]),
@@ -471,7 +481,8 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
     with capi.Session(X, y, data_type=2, model_type=3, device=local_rank) as sess:
         setup = time.time() - t0
         del X
-        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 101), ic_type=3), 100000, 5000)
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 101), ic_type=3), 100000, 5000,
+                    "k_xtv_two_accumulators_hbm_bytes_per_pass")
     rec.update({"workload": "SURVEY 8f: Poisson PDAS + IRLS (warm-started), sequential path k=1..100, n=100000 p=5000, GIC; "
                             "pinned by tests/golden/fullsize_poisson.npz (compiled reference)",
                 "score_kernel_name": "k_xtv<.., two accumulators> (X^T g and X^2^T h in one pass)",
@@ -482,7 +493,8 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
     with capi.Session(X, y, data_type=2, model_type=2, device=local_rank) as sess:
         setup = time.time() - t0
         keep = {}
-        rec = timed(sess, lambda: keep.setdefault("out", sess.sequential_path(np.arange(1, 101), ic_type=3)), 100000, 5000)
+        rec = timed(sess, lambda: keep.setdefault("out", sess.sequential_path(np.arange(1, 101), ic_type=3)), 100000, 5000,
+                    "k_xtv_two_accumulators_hbm_bytes_per_pass")
         norm = sess.normalization()
     if cpu_budget:
         try:
@@ -501,7 +513,8 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
         setup = time.time() - t0
         if not cpu_budget:
             del X
-        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 151), ic_type=3), 200000, 20000)
+        rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 151), ic_type=3), 200000, 20000,
+                    "k_cox_score1p_hbm_bytes_per_pass")
     if cpu_budget:
         try:
             rec["cpu_baseline"] = cpu_baseline_cox(X, st, cpu_budget)
