@@ -288,50 +288,53 @@ __global__ void __launch_bounds__(256) k_cox_uv(long ld, const double *__restric
 // where MAP = 0 fetches 35.2 GB (the re-read n-vectors), at the SAME 5.1-5.3 ms per pass (0.75-0.79 of 8 TB/s) -- the
 // re-reads were wasted traffic, not what holds the kernel; the four vectors interleaved per row (one 32-byte scalar load
 // instead of four) measured 0.73-0.78 and were dropped.  MAP = 1 is what the solver runs.
-template <int U, int MAP>
+// RW: rows per sub-tile (32, or 16: half the LDS per wave -- four waves per SIMD instead of two -- and 128-byte instead of
+// 256-byte runs per column and load instruction).
+template <int U, int MAP, int RW, int COLS>
 __global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ X, long ld, int p, int nrb,
                                                      const double *__restrict__ TH, const double *__restrict__ CU,
                                                      const double *__restrict__ CV, const double *__restrict__ C2,
                                                      double *__restrict__ out, const FitCtrl *__restrict__ ctrl,
                                                      int slot) {
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;
-  __shared__ double tile[4][64 * CS_RS];
+  constexpr int RS = RW + 1, NSEG = RW / 2, CPI = 64 / NSEG, NIT = COLS / CPI;
+  __shared__ double tile[4][COLS * RS];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long wid = (long)blockIdx.x * 4 + wv;
-  const int ncg = (p + 63) / 64;
+  const int ncg = (p + COLS - 1) / COLS;
   const long cg = MAP == 0 ? wid / nrb : wid % ncg;
   const int rb = MAP == 0 ? (int)(wid - cg * nrb) : (int)(wid / ncg);
   if (cg >= ncg || rb >= nrb) return;
-  const int j0 = (int)cg * 64;
+  const int j0 = (int)cg * COLS;
   double loc = 0.0, g1 = 0.0, g2 = 0.0, p1 = 0.0, p2 = 0.0, p0 = 0.0;
-  constexpr int NSUB = 128 * U / CS_ROWS;
+  constexpr int NSUB = 128 * U / RW;
   const long rbase = (long)rb * (128 * U);
-  const int c4 = lane >> 4, seg = lane & 15;
-  d2 nxt[16];
+  const int c4 = lane / NSEG, seg = lane % NSEG;
+  d2 nxt[NIT];
   auto load_sub = [&](int sub) {
-    const long r0 = rbase + (long)sub * CS_ROWS + 2 * seg;
+    const long r0 = rbase + (long)sub * RW + 2 * seg;
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-      int j = min(j0 + 4 * it + c4, p - 1);
+    for (int it = 0; it < NIT; it++) {
+      int j = min(j0 + CPI * it + c4, p - 1);
       nxt[it] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(X + (size_t)j * ld + r0));
     }
   };
   load_sub(NSUB - 1);
   for (int sub = NSUB - 1; sub >= 0; sub--) {
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int o = (4 * it + c4) * CS_RS + 2 * seg;
+    for (int it = 0; it < NIT; it++) {
+      const int o = (CPI * it + c4) * RS + 2 * seg;
       tile[wv][o] = nxt[it].x;
       tile[wv][o + 1] = nxt[it].y;
     }
     if (sub > 0) load_sub(sub - 1);  // next tile's loads fly while this one is scanned
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const long r0 = rbase + (long)sub * CS_ROWS;
-    for (int r = CS_ROWS - 1; r >= 0; r--) {
+    const long r0 = rbase + (long)sub * RW;
+    for (int r = RW - 1; r >= 0; r--) {
       // wave-uniform (scalar loads; staging them through LDS measured the same)
       const double th = TH[r0 + r], u = CU[r0 + r], v = CV[r0 + r], c2 = C2[r0 + r];
-      const double x = tile[wv][lane * CS_RS + r];
+      const double x = tile[wv][(COLS == 64 ? lane : (lane & (COLS - 1))) * RS + r];
       loc = fma(th, x, loc);
       g1 = fma(x, v, g1);
       g2 = fma(u * x, x, g2);
@@ -343,7 +346,7 @@ __global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ 
     __builtin_amdgcn_wave_barrier();
   }
   const size_t plane = (size_t)nrb * p;
-  if (j0 + lane < p) {
+  if (lane < COLS && j0 + lane < p) {
     const size_t o = (size_t)rb * p + j0 + lane;
     out[o] = loc;
     out[plane + o] = p1;
@@ -1219,7 +1222,7 @@ hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, co
   return hipSuccess;
 }
 
-static int g_cox_score_variant = 1;  // the wave -> (column group, row block) map (tools/cox_score_bench.py measures both)
+static int g_cox_score_variant = 1;  // the wave -> (column group, row block) map (1 = round 4, 0 = round 3)
 void cox_score_set_variant(int v) { g_cox_score_variant = v & 1; }
 
 hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb, CoxBufs cb, double *part,
@@ -1227,13 +1230,16 @@ hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb
   if (cb.one_pass) {
     long nw = (long)nrb * ((p + 63) / 64);
     int nb = (int)((nw + 3) / 4);
-#define CS1_GO3(UU, MM)                                                                                        \
-  hipLaunchKernelGGL((k_cox_score1p<UU, MM>), dim3(nb), dim3(256), 0, st, X, ld, p, nrb, (const double *)cb.TH, \
+    // (RW = 16 -- half the LDS per wave, four waves per SIMD -- and COLS = 32 with RW = 64 -- 512-byte runs per column
+    // and load instruction, half the lanes idle in the walk -- were measured in round 4 at 0.77-0.79 of 8 TB/s like this
+    // geometry: neither occupancy nor run length is what holds the pass at 6.2-6.4 TB/s; only <.., 32, 64> is instantiated)
+#define CS1_GO3(UU, MM)                                                                                                \
+  hipLaunchKernelGGL((k_cox_score1p<UU, MM, 32, 64>), dim3(nb), dim3(256), 0, st, X, ld, p, nrb, (const double *)cb.TH, \
                      (const double *)cb.CU, (const double *)cb.CV, (const double *)cb.C2, part, ctrl, slot)
-#define CS1_GO(UU)               \
-  if (g_cox_score_variant)       \
-    CS1_GO3(UU, 1);              \
-  else                           \
+#define CS1_GO(UU)         \
+  if (g_cox_score_variant) \
+    CS1_GO3(UU, 1);        \
+  else                     \
     CS1_GO3(UU, 0)
     switch (U) {
       case 8: CS1_GO(8); break;
