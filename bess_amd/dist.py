@@ -328,6 +328,7 @@ class FoldShardedCV:
         self.n_fits = 0
         self.n_pdas_iters = 0
         self.evaluations = 0
+        self._norm = None
         if hasattr(session, "reset_caches"):
             session.reset_caches()  # a path starts cold, like a bessCpp call
 
@@ -454,7 +455,9 @@ class FoldShardedCV:
         beta = np.array(beta, dtype=np.float64)
         if not self.is_normal:
             return beta, coef0
-        xm, xn, ym = self.s.normalization()
+        if self._norm is None:
+            self._norm = self.s.normalization()  # (p-vectors: fetched once per driver, not per candidate)
+        xm, xn, ym = self._norm
         beta = np.sqrt(float(self.s.n)) * beta / xn[sup]
         dot = float(np.dot(beta, xm[sup]))
         if self.data_type == 1:
