@@ -283,7 +283,9 @@ hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int 
                               const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
                               double lambda, const double *beta_dense, const unsigned char *always, double *bd,
                               hipStream_t st, int smax = 1, double *work = nullptr, double *zwork = nullptr,
-                              const FitCtrl *ctrl = nullptr, int slot = 0);
+                              const FitCtrl *ctrl = nullptr, int slot = 0, int eig_mode = 0, double *eig_v = nullptr,
+                              double *eig_l = nullptr);
+constexpr int GRP_EIG_MAX = 16;  // widest group of the register-resident score kernel (GRP_MAX of bessx_kdev.hpp)
 // find_ind on the device for groups of one width (k_group_expand)
 hipError_t launch_group_expand(const int *G_sel, int T0, int gs, const int *gidx, int *cols, const FitCtrl *ctrl,
                                int slot, hipStream_t st);

@@ -673,6 +673,33 @@ int read_results(bessx_session *s, int kcopy) {
 // selected group ids back after the top-k to expand them into columns (find_ind, src/utilities.cpp:113-130), so
 // this loop synchronises twice per PDAS iteration and uses none of the speculative / cached fast paths.
 // --------------------------------------------------------------------------------------------
+// LM with groups: the diagonalisation of every group's block for (row set, lambda), formed on first use by one ungated
+// launch of the score kernel in its store mode (the scores it writes are overwritten by the first real launch)
+static int group_eig_ensure(bessx_session *s, int rs, double lambda) {
+  if (!s->geig_on || s->gmax > GRP_EIG_MAX) return 1;  // (wider groups take the Cholesky-form score kernel: nothing to keep)
+  if ((int)s->geig_v_rs.size() <= rs) {
+    s->geig_v_rs.resize((size_t)rs + 1, nullptr);
+    s->geig_l_rs.resize((size_t)rs + 1, nullptr);
+    s->geig_lambda.resize((size_t)rs + 1, 0.0);
+    s->geig_valid.resize((size_t)rs + 1, 0);
+  }
+  if (!s->geig_v_rs[rs]) {
+    if (dmalloc(&s->geig_v_rs[rs], (size_t)s->goff_h[s->N]) != hipSuccess ||
+        dmalloc(&s->geig_l_rs[rs], (size_t)s->p) != hipSuccess) {
+      (void)hipGetLastError();
+      return 1;  // (no memory: diagonalise at every iteration as before)
+    }
+  }
+  if (s->geig_valid[rs] && s->geig_lambda[rs] == lambda) return 0;
+  // (part = xty of the row set, one "row block": any finite d does -- only the stored decomposition is kept)
+  HIPX(launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->xty[rs], 1, s->p, 1,
+                          (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork, s->zwork,
+                          nullptr, 0, 1, s->geig_v_rs[rs], s->geig_l_rs[rs]));
+  s->geig_valid[rs] = 1;
+  s->geig_lambda[rs] = lambda;
+  return 0;
+}
+
 int algorithm_fit_grouped(bessx_session *s) {
   const int T0 = s->sparsity_level, rs = s->cur_rows, fam = s->model_type;
   const double lambda = s->lambda_level;
@@ -732,6 +759,7 @@ int algorithm_fit_grouped(bessx_session *s) {
     if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
     const CholFuse fbz = chol_fallback_only(s);
     std::vector<std::pair<size_t, bool>> k1_pairs;
+    const bool eig = group_eig_ensure(s, rs, lambda) == 0;
     while (slot <= s->max_iter) {
       const int first = slot;
       for (int b = 0; b < 2 && slot <= s->max_iter; b++, slot++) {
@@ -748,7 +776,8 @@ int algorithm_fit_grouped(bessx_session *s) {
         if (e == hipSuccess)
           e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->dcol, 1, s->p, 1,
                                  (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork,
-                                 s->zwork, s->ctrl, slot);
+                                 s->zwork, s->ctrl, slot, eig ? 2 : 0, eig ? s->geig_v_rs[rs] : nullptr,
+                                 eig ? s->geig_l_rs[rs] : nullptr);
         if (e == hipSuccess)
           e = launch_topk(s->bd, s->N, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
         if (e == hipSuccess) e = launch_group_expand(s->A_new, T0, gs, s->gidx, s->gcols_new, s->ctrl, slot, s->st);
@@ -785,10 +814,12 @@ int algorithm_fit_grouped(bessx_session *s) {
     if (!glm) {
       e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], nullptr, s->part_rs[rs], nullptr, nullptr, 0, s->st);
       if (e == hipSuccess) e = launch_part_sum(s->part_rs[rs], s->nrb, s->p, s->dcol, s->st);
+      const bool eig = e == hipSuccess && group_eig_ensure(s, rs, lambda) == 0;
       if (e == hipSuccess)
         e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->dcol, 1, s->p, 1,
                                (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork,
-                               s->zwork);
+                               s->zwork, nullptr, 0, eig ? 2 : 0, eig ? s->geig_v_rs[rs] : nullptr,
+                               eig ? s->geig_l_rs[rs] : nullptr);
     } else if (cox) {
       // X_g^T h X_g without the n x n Hessian of src/Algorithm.h:1536-1546 (launch_cox_group_moments)
       e = launch_cox_group_moments(s->X, s->ld, s->n, s->p, s->cox, s->allcols, (int)std::min<size_t>(s->cox_M_cols, 256),

@@ -232,6 +232,12 @@ struct bessx_session {
   double *mwork = nullptr, *zwork = nullptr;  // groups wider than 16 columns: Cholesky work copy of the blocks, 2 p vector
   int *allcols = nullptr;   // 0 .. p-1 (column lists of the panels of the Cox group branch)
   std::vector<double *> gxtx_rs;  // per row set: X_g^T diag(mask) X_g blocks (LM)
+  // LM: the diagonalisation of every group's block 2 lambda I + X_g^T X_g / n (k_group_score's Jacobi sweeps) depends on
+  // the row set and lambda only: kept per row set (eigenvectors, eigenvalues) with the lambda it was formed for
+  std::vector<double *> geig_v_rs, geig_l_rs;
+  std::vector<double> geig_lambda;
+  std::vector<char> geig_valid;
+  bool geig_on = true;  // (test hook group_eig=0: diagonalise at every iteration, round 3's form)
   int cox_state_rs = -1;
   int dev_state_rs = -1;                // row set of the fit whose final coefficients sit in A_cur/b_cur/beta_dense
   CoxBufs cox = {};                     // Cox work space (model_type 4 only)

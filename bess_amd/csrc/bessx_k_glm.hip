@@ -67,12 +67,26 @@ __global__ void __launch_bounds__(256) k_group_moments(const double *__restrict_
 // SC = compile-time width (the loops unroll and the s x s arrays live in registers: 25 + 25 doubles at 5 columns) or 0
 // = any width up to GRP_MAX with run-time loops (the arrays then sit in scratch memory: 1.9 ms per launch for 2000
 // groups of 5 in round 3, 70 % of a grouped LM path).
+// eig_mode: 0 = diagonalise and use; 1 = diagonalise, STORE eigenvectors and eigenvalues (ev / el) and use; 2 = LOAD them
+// instead of diagonalising.  For LM the block depends on the row set and lambda only, not on the coefficients: the
+// Jacobi sweeps -- 270 us per launch for 2000 groups of 5, one group per thread -- run once per (row set, lambda) and
+// every PDAS iteration after it loads 30 numbers per group.  Same arithmetic, stored: bit-identical scores.
 template <int SC>
 __device__ __forceinline__ double group_sacrifice(int s_rt, double *__restrict__ a, double *__restrict__ v,
-                                                  const double *__restrict__ bv, const double *__restrict__ dv) {
+                                                  const double *__restrict__ bv, const double *__restrict__ dv,
+                                                  int eig_mode = 0, double *__restrict__ ev = nullptr,
+                                                  double *__restrict__ el = nullptr) {
   const int s = SC > 0 ? SC : s_rt;
   constexpr int UF = SC > 0 ? SC : 1;  // (run-time widths: no unrolling)
-  for (int sweep = 0; sweep < 60; sweep++) {
+  if (eig_mode == 2) {
+#pragma unroll UF
+    for (int k = 0; k < s; k++) {
+      a[k * s + k] = el[k];
+#pragma unroll UF
+      for (int j = 0; j < s; j++) v[k * s + j] = ev[k * s + j];
+    }
+  }
+  for (int sweep = 0; sweep < (eig_mode == 2 ? 0 : 60); sweep++) {
     double off = 0.0, dg = 0.0;
 #pragma unroll UF
     for (int i = 0; i < s; i++)
@@ -112,6 +126,14 @@ __device__ __forceinline__ double group_sacrifice(int s_rt, double *__restrict__
         }
       }
   }
+  if (eig_mode == 1) {
+#pragma unroll UF
+    for (int k = 0; k < s; k++) {
+      el[k] = a[k * s + k];
+#pragma unroll UF
+      for (int j = 0; j < s; j++) ev[k * s + j] = v[k * s + j];
+    }
+  }
   double t[SC > 0 ? SC : GRP_MAX];
 #pragma unroll UF
   for (int i = 0; i < s; i++) t[i] = 0.0;
@@ -137,7 +159,8 @@ template <int SC>
 __device__ __forceinline__ double group_score_one(int g, int s_rt, int c0, const int *__restrict__ goff,
                                                   const double *__restrict__ mblk, const double *__restrict__ dcol,
                                                   const double *__restrict__ part, int nrb, int p, int lm, double n_t,
-                                                  double lambda, const double *__restrict__ beta_dense) {
+                                                  double lambda, const double *__restrict__ beta_dense, int eig_mode,
+                                                  double *__restrict__ eig_v, double *__restrict__ eig_l) {
   constexpr int SM = SC > 0 ? SC : GRP_MAX;
   constexpr int UF = SC > 0 ? SC : 1;
   const int s = SC > 0 ? SC : s_rt;
@@ -167,7 +190,7 @@ __device__ __forceinline__ double group_score_one(int g, int s_rt, int c0, const
     const double phi = sqrt(a[0]), inv = 1.0 / phi, tt = phi * bv[0] + inv * dv[0];
     return tt * tt;
   }
-  return group_sacrifice<SC>(s, a, v, bv, dv);
+  return group_sacrifice<SC>(s, a, v, bv, dv, eig_mode, eig_v ? eig_v + goff[g] : nullptr, eig_l ? eig_l + c0 : nullptr);
 }
 
 // lm != 0: dcol is taken from the score-pass partials (sum over row blocks / n_t); else dcol holds X^T g already.
@@ -178,7 +201,8 @@ __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict
                                                     const double *__restrict__ beta_dense,
                                                     const unsigned char *__restrict__ always,
                                                     double *__restrict__ bd, const FitCtrl *__restrict__ ctrl,
-                                                    int slot) {
+                                                    int slot, int eig_mode, double *__restrict__ eig_v,
+                                                    double *__restrict__ eig_l) {
   if (ctrl != nullptr && (ctrl->done || ctrl->l != slot - 1)) return;  // (a speculative slot of a fit that has ended)
   const int g = blockIdx.x * 64 + threadIdx.x;
   if (g >= N) return;
@@ -186,7 +210,8 @@ __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict
   if (s > GRP_MAX) return;  // wider groups: k_group_score_big
   double res;
 #define GS_CASE(S) \
-  case S: res = group_score_one<S>(g, s, c0, goff, mblk, dcol, part, nrb, p, lm, n_t, lambda, beta_dense); break
+  case S: res = group_score_one<S>(g, s, c0, goff, mblk, dcol, part, nrb, p, lm, n_t, lambda, beta_dense, eig_mode, eig_v, \
+                                   eig_l); break
   switch (s) {
     GS_CASE(1);
     GS_CASE(2);
@@ -196,7 +221,8 @@ __global__ void __launch_bounds__(64) k_group_score(int N, const int *__restrict
     GS_CASE(6);
     GS_CASE(7);
     GS_CASE(8);
-    default: res = group_score_one<0>(g, s, c0, goff, mblk, dcol, part, nrb, p, lm, n_t, lambda, beta_dense);
+    default: res = group_score_one<0>(g, s, c0, goff, mblk, dcol, part, nrb, p, lm, n_t, lambda, beta_dense, eig_mode, eig_v,
+                                      eig_l);
   }
 #undef GS_CASE
   if (always != nullptr && always[g]) res = DBL_MAX;
@@ -1234,9 +1260,10 @@ hipError_t launch_iota(int *a, int n, hipStream_t st) {
 hipError_t launch_group_score(int N, const int *gidx, const int *gsz, const int *goff, const double *mblk,
                               const double *dcol, const double *part, int nrb, int p, int lm, double n_t,
                               double lambda, const double *beta_dense, const unsigned char *always, double *bd,
-                              hipStream_t st, int smax, double *work, double *zwork, const FitCtrl *ctrl, int slot) {
+                              hipStream_t st, int smax, double *work, double *zwork, const FitCtrl *ctrl, int slot,
+                              int eig_mode, double *eig_v, double *eig_l) {
   hipLaunchKernelGGL(k_group_score, dim3((N + 63) / 64), dim3(64), 0, st, N, gidx, gsz, goff, mblk, dcol, part, nrb, p,
-                     lm, n_t, lambda, beta_dense, always, bd, ctrl, slot);
+                     lm, n_t, lambda, beta_dense, always, bd, ctrl, slot, eig_mode, eig_v, eig_l);
   LAUNCH_CHECK();
   if (smax > GRP_MAX) {
     if (work == nullptr || zwork == nullptr) return hipErrorInvalidValue;

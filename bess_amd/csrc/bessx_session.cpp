@@ -91,6 +91,8 @@ void session_free(bessx_session *s) {
   F(s->zwork);
   F(s->allcols);
   for (auto q : s->gxtx_rs) F(q);
+  for (auto q : s->geig_v_rs) F(q);
+  for (auto q : s->geig_l_rs) F(q);
   for (auto q : s->cox_allocs) F(q);
   F(s->idcols);
   F(s->part2);
@@ -405,6 +407,7 @@ int prepare_rowset(bessx_session *s, int rs) {
   if (e == hipSuccess && s->grouped)  // group_XTX blocks, src/utilities.cpp:153-165
     e = launch_group_moments(s->gmax, s->X, s->ld, s->n, m, nullptr, s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs],
                              nullptr, s->st);
+  if ((size_t)rs < s->geig_valid.size()) s->geig_valid[(size_t)rs] = 0;  // (the blocks changed: diagonalise them again)
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("prepare_rowset: ") + hipGetErrorString(e));
   return 0;
 }
@@ -796,6 +799,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       if (same) s->g_uniform = s->gmax;
       if (const char *ev = test_hook("group_expand"))
         if (std::string(ev) == "host") s->g_uniform = 0;
+      if (const char *ev = test_hook("group_eig")) s->geig_on = std::string(ev) != "0";
     }
     // groups of up to 16 columns: register-resident blocks and a Jacobi square root per thread; wider ones: tiled
     // moments and a Cholesky form of the same score (k_group_moments_big / k_group_score_big).  Cox forms the
@@ -1168,6 +1172,10 @@ static void drop_folds(bessx_session *s) {
   drop(s->part2_rs);
   drop(s->h_rs);
   drop(s->gxtx_rs);
+  drop(s->geig_v_rs);
+  drop(s->geig_l_rs);
+  if (s->geig_valid.size() > 1) s->geig_valid.resize(1);
+  if (s->geig_lambda.size() > 1) s->geig_lambda.resize(1);
   for (size_t i = 1; i < s->gcache.size(); i++) {
     (void)hipFree(s->gcache[i].g0);
     (void)hipFree(s->gcache[i].g1);

@@ -62,3 +62,33 @@ def test_grouped_cv_and_ridge_paths_on_the_device_path(gpu, monkeypatch):
         np.testing.assert_array_equal(a["cand_support"], b["cand_support"])
         np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-12)
         assert a["n_fits"] == b["n_fits"] and a["n_pdas_iters"] == b["n_pdas_iters"]
+
+
+@pytest.mark.parametrize("gs,ragged", [(4, False), (3, True)])
+def test_group_blocks_diagonalised_once_per_row_set_and_lambda(gpu, monkeypatch, gs, ragged):
+    """The eigenvectors of every group's block are kept per (row set, lambda) and reused by every iteration, every
+    candidate and every fold fit; a new lambda or new folds form them again.  Same fits as forming them every time."""
+    X, y, g_index = _grouped_lm(900, 60, gs, 5, seed=31 + gs)
+    if ragged:  # (merge two groups: ragged widths take the host-side expansion, the same cached blocks)
+        g_index = np.delete(g_index, 7)
+    outs = {}
+    for mode in ("1", "0"):
+        hooks(monkeypatch, group_eig=mode)
+        with gpu.Session(X, y, g_index=g_index, algorithm_type=3) as s:
+            o = [s.sequential_path(np.arange(1, 9), [0.0, 0.3, 0.0], ic_type=3)]
+            for seed in (2, 5):
+                s.set_cv(3, synth.make_cv_folds(900, 3, seed=seed))
+                o.append(s.sequential_path(np.arange(1, 7), [0.1, 0.0], ic_type=3, is_cv=True))
+            o.append(s.fit(4, lam=0.3))
+            o.append(s.fit(4, lam=0.0))
+            outs[mode] = o
+    for a, b in zip(outs["1"], outs["0"]):
+        for key in ("cand_support", "cand_iters", "support", "iters"):
+            if key in a:
+                np.testing.assert_array_equal(a[key], b[key])
+        for key in ("cand_ic", "cand_beta", "beta"):
+            if key in a:
+                np.testing.assert_allclose(a[key], b[key], rtol=1e-12, atol=1e-14)
+    want = P.trace(X, y, ic_type=3, sequence=np.arange(1, 9), lambda_seq=[0.0, 0.3, 0.0], g_index=g_index,
+                   algorithm_type=3)
+    np.testing.assert_allclose(outs["1"][0]["cand_ic"], want["ic_calls"], rtol=1e-8)
