@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--p", type=int, default=None, help="default: 10000 (lm-*), 20000 (cox-seq)")
     ap.add_argument("--kmax", type=int, default=None, help="default: 200 (lm-*), 150 (cox-seq)")
     ap.add_argument("--k-true", type=int, default=None, help="default: 100 (lm-*), 75 (cox-seq)")
+    ap.add_argument("--no-shared-design", action="store_true",
+                    help="cox-seq with N > 1: every rank draws its own (identical, seeded) copy of the design instead of "
+                         "mapping the one rank 0 leaves in /dev/shm")
     ap.add_argument("--workload", choices=["lm-seq", "lm-cv-gs", "cox-seq"], default="lm-seq",
                     help="lm-seq = BASELINE configs[1] (the metric); lm-cv-gs = configs[3]; cox-seq = configs[4]")
     ap.add_argument("--chunk-start", choices=["auto", "cold", "ladder"], default="auto",
@@ -83,11 +86,17 @@ def parse_args(argv=None):
                          "over X their cold starts would repeat; ONE data-path all-gather of p x 32 blocks).  0 = "
                          "replicas only, as north_star partitions the path; auto = 320 for lm-seq, 0 otherwise")
     ap.add_argument("--pilot", default="auto",
-                    help="with the prefill: 'K,M2' = every rank runs the same pilot fit of sparsity level K on the prefilled "
-                         "cache, the M2 uncached columns its scores rank highest are shared as a second list and the chunks "
-                         "beyond K start warm from the pilot's model (bess_amd.dist.pilot_prefill); 'none'; auto = from 4 "
-                         "ranks: K = 0.64 kmax rounded to 32, prefill K + 32, M2 = 256 (tools/coop_prefill.py: slowest of 8 "
-                         "ranks 7.5 ms against 9.5 ms with the marginal list alone and 12.8 ms without a prefill)")
+                    help="with the prefill: 'K,M2[,W]' = every rank runs the same pilot fit of sparsity level K on the "
+                         "prefilled cache -- with W its own fills are shared too (W columns per fill: the missing ones and "
+                         "the best uncached ones by that iteration's scores, one 32-column group per rank; "
+                         "bessx_session_set_fill_hook) --, the M2 uncached columns its final scores rank highest are shared "
+                         "as a second list and the chunks beyond K start warm from the pilot's model "
+                         "(bess_amd.dist.pilot_prefill); 'none'; auto = K = 0.64 kmax rounded to 32, prefill K, M2 = 0, "
+                         "W = 32 per rank (tools/coop_prefill.py, 8 ranks: slowest 5.2-5.6 ms against 7.5 ms without the "
+                         "shared fills in the pilot, 9.5 ms with the marginal list alone, 12.8 ms without a prefill)")
+    ap.add_argument("--rebalance", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1, k-path: after every step the chunk boundaries move towards equal time per rank "
+                         "(bess_amd.dist.rebalance_bounds); auto = on up to 4 ranks (2 ranks: 13.7 -> 11.9 ms; no gain at 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per timed segment")
     ap.add_argument("--shard", choices=["auto", "replica", "kpath"], default="auto",
@@ -583,8 +592,25 @@ def main():
     shard = args.shard if args.shard != "auto" else "kpath"
     kpath = shard == "kpath" and distributed
     cox = args.workload == "cox-seq"
-    if cox:
-        # configs[4]: every rank holds the whole (replicated) design; rows sorted by time, y = status
+    shared_files = []
+    if cox and distributed and not args.no_shared_design:
+        # configs[4], N ranks of one node: ONE host copy of the (replicated) 32 GB design.  Local rank 0 draws it and
+        # leaves it in shared memory, the others map it read-only and upload from there (round 3: every rank drew
+        # its own copy, 8 x 32 GB of host memory and 8 x the generator's time on the same cores)
+        tag = "/dev/shm/bessx_cox_%s_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), args.n, args.p, args.k_true)
+        shared_files = [tag + "_X.npy", tag + "_y.npy"]
+        if rank == 0:
+            import atexit
+            atexit.register(lambda: [os.unlink(f) for f in shared_files if os.path.exists(f)])
+            X, _, y, _, _ = synth.make_cox(args.n, args.p, args.k_true)
+            np.save(shared_files[0], X)
+            np.save(shared_files[1], y)
+        dist.barrier()
+        if rank != 0:
+            X = np.load(shared_files[0], mmap_mode="r")
+            y = np.load(shared_files[1])
+    elif cox:
+        # configs[4]: the whole (replicated) design; rows sorted by time, y = status
         X, _, y, _, _ = synth.make_cox(args.n, args.p, args.k_true)
     else:
         X, y = make_problem(args.n, args.p, args.k_true, 0 if (kpath or not distributed) else rank)
@@ -605,6 +631,12 @@ def main():
     covariance = sess.score_mode() == 2
     torch.cuda.synchronize()
     upload_s = time.time() - t0
+    if shared_files:  # every rank has uploaded: the shared host copy goes
+        dist.barrier()
+        if rank == 0:
+            for f in shared_files:
+                if os.path.exists(f):
+                    os.unlink(f)
 
     ic_curves = None
     out = None
@@ -616,17 +648,18 @@ def main():
         # prefill (15.0 ms without, 16.1 with 320 columns); 4 ranks: pilot 10.0 ms, marginal list 11.8, none 13.4;
         # 8 ranks: pilot 7.5 ms, marginal list 9.5, none 11.6
         kp = int(round(0.64 * args.kmax / 32.0)) * 32
+        wide = 32 * world
         if args.pilot not in ("auto", "none"):
-            kp, m2 = (int(v) for v in args.pilot.split(","))
-            pilot = (kp, m2 // 32 * 32)
-        elif args.pilot == "auto" and world >= 4 and 32 <= kp <= args.kmax - 8 and args.p >= 4 * (kp + 32 + 256):
-            pilot = (kp, 256)
+            v = [int(q) for q in args.pilot.split(",")]
+            pilot = (v[0], v[1] // 32 * 32) + ((v[2] // 32 * 32,) if len(v) > 2 else ())
+        elif args.pilot == "auto" and 32 <= kp <= args.kmax - 8 and args.p >= 4 * (kp + 32 + 2 * wide):
+            pilot = (kp, 0, wide)
         if args.prefill == "auto":
-            prefill = (pilot[0] + 32) if pilot else (320 if world >= 3 else 0)
+            prefill = pilot[0] if pilot else (320 if world >= 3 else 0)
         else:
             prefill = int(args.prefill)
         prefill = max(0, min(prefill, (args.p // 64) * 32, 1024)) // 32 * 32
-        if not prefill:
+        if not prefill and not (pilot and len(pilot) > 2):
             pilot = None
     if kpath:
         if args.chunk_start == "auto":
@@ -637,8 +670,9 @@ def main():
             args.chunk_start = "ladder" if (k0 >= 128 and not cox and not prefill) else "cold"
         if args.chunk_start == "ladder" and lo > 0:
             lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
+    rebalance = kpath and not lead and (args.rebalance == "on" or (args.rebalance == "auto" and world <= 4 and not cox))
     stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev,
-                                   prefill=prefill, pilot=pilot) if kpath else None
+                                   prefill=prefill, pilot=pilot, rebalance=rebalance) if kpath else None
     for _ in range(args.warmup):
         out = stitched.step() if kpath else sess.sequential_path(seq, ic_type=3)
     sess.enable_kernel_timing(True)
@@ -665,6 +699,8 @@ def main():
     chunk_report = None
     if kpath:
         # compare the chunked chains with the single warm-start chain, after the timed region
+        bounds = stitch["bounds"]  # (of the last timed step: the boundaries move when --rebalance is on)
+        lo, hi = bounds[rank], bounds[rank + 1]
         sup = np.full((args.kmax, args.kmax), -1.0)
         if hi > lo:
             sup[lo:hi, :out["cand_support"].shape[1]] = out["cand_support"]
@@ -672,13 +708,13 @@ def main():
         if rank == 0:
             chunked = np.full((args.kmax, args.kmax), -1, dtype=np.int64)
             for r in range(world):
-                a, b = bdist.partition(args.kmax, world, r)
+                a, b = bounds[r], bounds[r + 1]
                 chunked[a:b] = allsup[r].reshape(args.kmax, args.kmax)[a:b]
             single = sess.sequential_path(full_seq, ic_type=3)
             same = [bool(np.array_equal(chunked[k, :k + 1], single["cand_support"][k, :k + 1])) for k in range(args.kmax)]
             chunk_report = {
-                "chunks": [list(map(int, (bdist.partition(args.kmax, world, r)[0] + 1,
-                                          bdist.partition(args.kmax, world, r)[1]))) for r in range(world)],
+                "chunks": [[int(bounds[r]) + 1, int(bounds[r + 1])] for r in range(world)],
+                "rebalance": bool(rebalance),
                 "supports_equal_to_single_chain": int(np.sum(same)), "of": args.kmax,
                 "differing_k": [int(k + 1) for k in range(args.kmax) if not same[k]][:40],
                 "ic_curve_max_rel_diff_to_single_chain": float(np.max(np.abs(ic_curves[0] - single["cand_ic"]) /
@@ -695,7 +731,9 @@ def main():
                             "data-path collective north_star's partitioning does not have; --prefill 0 = replicas only)"
                             % (prefill, prefill * args.p * 8) + ("; then a pilot fit of level %d on every rank, the %d columns its "
                             "scores rank highest shared the same way, chunks beyond it started warm from its model"
-                            % (pilot[0], pilot[1]) if pilot else "")) if prefill else "none (replicas only)",
+                            % (pilot[0], pilot[1]) if pilot else "") + ("; the pilot fit's own fills shared too, %d columns "
+                            "per fill (the missing ones + the best uncached ones by that iteration's scores), one group per rank"
+                            % pilot[2] if (pilot and len(pilot) > 2) else "")) if (prefill or pilot) else "none (replicas only)",
                 "stitching": "after its chunk rank r re-fits its first candidates warm from rank r-1's last model until "
                              "a candidate coincides with its chunk's (same support, coefficients to 1e-9); the "
                              "candidates before that point are replaced: the gathered path IS the single chain's",

@@ -28,6 +28,7 @@ SYMBOLS = [
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_fit_width", "bessx_session_reset_caches",
     "bessx_session_sequential_path_chain", "bessx_session_cv_eval", "bessx_session_debug_block_stream",
+    "bessx_session_set_fill_hook",
     "bessx_session_marginal_scores", "bessx_session_cov_prefill_begin", "bessx_session_cov_prefill_compute",
     "bessx_session_cov_prefill_export", "bessx_session_cov_prefill_import", "bessx_session_cov_prefill_end",
     "bessx_session_cov_prefill_extend", "bessx_session_cov_state", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
@@ -282,7 +283,7 @@ class Session:
         """Diagnostics of the covariance form (bessx_session_counter)."""
         names = {0: "chained_fits", 1: "cg_fallbacks", 2: "passes_over_X", 3: "chained_queued", 7: "cv_side_by_side_rounds",
                  8: "cv_union_fills", 9: "tie_rescues", 10: "cache_restarts", 11: "cv_contexts_dropped",
-                 12: "cv_fold_contexts"}  # (4-6: mechanisms removed in round 3)
+                 12: "cv_fold_contexts", 13: "shared_wide_fills"}  # (4-6: mechanisms removed in round 3)
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in names.items()}
 
     def screening(self):
@@ -477,6 +478,31 @@ class Session:
 
     def cov_prefill_end(self):
         _check(lib().bessx_session_cov_prefill_end(self._h))
+
+    _FILL_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
+
+    def set_fill_hook(self, fn, width=0):
+        """Shared wide fills inside a fit (bessx_session_set_fill_hook): while set, a parked fit of the all-rows row set
+        lists `width` columns -- the missing ones, then the best uncached ones by the current scores -- and calls
+        fn(n_groups), which forms its share, exchanges the blocks and closes the list (cov_prefill_compute / export /
+        import / end).  fn = None: private fills again.  An exception in fn fails the fit and is re-raised by it."""
+        self._hook_error = None
+        if fn is None:
+            _check(lib().bessx_session_set_fill_hook(self._h, ctypes.cast(None, self._FILL_HOOK), None, 0))
+            self._hook_ref = None
+            return
+
+        def tramp(_user, ng):
+            try:
+                fn(int(ng))
+                return 0
+            except BaseException as e:  # (an exception must not cross the C frames)
+                self._hook_error = e
+                return 1
+
+        ref = self._FILL_HOOK(tramp)
+        _check(lib().bessx_session_set_fill_hook(self._h, ref, None, int(width)))
+        self._hook_ref = ref  # (kept alive as long as the library may call it)
 
     def debug_block_stream(self, milliseconds):
         """Test hook: everything queued on the session's stream waits behind a host function that sleeps."""

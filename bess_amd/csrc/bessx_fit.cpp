@@ -361,6 +361,41 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
   }
   const bool spec = cov_speculates(s);
   hipError_t e = hipSuccess;
+  if (s->fill_hook && rs == 0 && !s->parent && spec) {
+    // shared wide fill (bessx_session_set_fill_hook): the missing columns, then the uncached columns the scores of this
+    // iteration rank highest (bd2: cached and missing ones already at -1), fill_hook_width columns in all
+    const int p = s->p;
+    std::vector<int> miss((size_t)nm), slot_h((size_t)p);
+    std::vector<double> sc((size_t)p);
+    HIPX(hipMemcpyAsync(miss.data(), s->cov_fcols, (size_t)nm * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    HIPX(hipMemcpyAsync(sc.data(), s->bd2, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, s->st));
+    HIPX(hipMemcpyAsync(slot_h.data(), cv.slot_of, (size_t)p * sizeof(int), hipMemcpyDeviceToHost, s->st));
+    HIPX(hipStreamSynchronize(s->st));
+    std::vector<int> order;
+    order.reserve((size_t)p);
+    for (int j = 0; j < p; j++)
+      if (slot_h[j] < 0 && sc[j] >= 0.0) order.push_back(j);
+    int total = std::max(s->fill_hook_width, (nm + COV_R - 1) / COV_R * COV_R);
+    if (nm + (int)order.size() < total) total = (nm + (int)order.size()) / COV_R * COV_R;
+    if (total >= nm && total >= COV_R && total <= s->capA) {
+      const int extra = total - nm;
+      std::partial_sort(order.begin(), order.begin() + extra, order.end(), [&](int a, int b) {
+        return sc[a] > sc[b] || (sc[a] == sc[b] && a < b);  // (ties by column: the same list on every rank)
+      });
+      std::vector<int> list(miss);
+      list.insert(list.end(), order.begin(), order.begin() + extra);
+      if (int rc = prefill_begin(s, list.data(), total, 2)) return rc;
+      if (s->fill_hook(s->fill_hook_user, total / COV_R) != 0)
+        return fail(BESSX_ERR_ARG, "the fill hook reported a failure");
+      if (s->prefill_cols != 0) return fail(BESSX_ERR_ARG, "the fill hook returned without bessx_session_cov_prefill_end");
+      s->shared_wide_fills++;
+      HIPX(launch_cov_resume(s->ctrl, s->st));
+      if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
+      *next_slot = stalled + 1;
+      return 0;
+    }
+    // (fewer uncached columns than one group: the private fill below)
+  }
   if (spec) e = launch_topk(s->bd2, s->p, s->cov_spec, s->cov_extras, s->cand, nullptr, 0, s->st);
   if (e == hipSuccess)
     e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st, s->cov_spec,

@@ -352,6 +352,10 @@ struct bessx_session {
   int bmm_owner = -1;                  // row set of the k_cov_d launch that wrote cov_bmm last
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
+  bessx_fill_hook fill_hook = nullptr;  // shared wide fills of a parked fit (bessx_session_set_fill_hook)
+  void *fill_hook_user = nullptr;
+  int fill_hook_width = 0;
+  long long shared_wide_fills = 0;
   int prefill_cols = 0;            // columns listed by bessx_session_cov_prefill_begin (0: no prefill in progress)
   int prefill_base = 0;            // ... first cache slot of that list (0, or the occupancy cov_prefill_extend found)
   double *cgb_work = nullptr;      // large-system conjugate gradients (bessx_cgbig.hip): dense matrix + vectors, on first use
@@ -488,6 +492,7 @@ int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, 
 int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d,
                                bool scores_ok = false, bool grow1 = false, SlotFuse *sf = nullptr);
 int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int rs, int *next_slot);
+int prefill_begin(bessx_session *s, const int *cols, int ncols, int append);  // bessx_paths.cpp
 int glm_geometry(bessx_session *s, int T0, int *mt, int *mp, int *ntask, int *ntiles, int *rps, int *nslab);
 int enqueue_glm_head(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
                             std::vector<std::pair<size_t, bool>> &k1_pairs);

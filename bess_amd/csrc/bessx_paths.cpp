@@ -809,9 +809,12 @@ int bessx_session_marginal_scores(bessx_session *s, double *bd) {
   return BESSX_OK;
 }
 
+}  // extern "C"
+namespace bessx {
 // append = 0: the cache is started over and slot i goes to cols[i]; 1: the columns (all of them uncached) take the next
 // free slots of the cache as it is -- the same slots on every rank whose session has done the same work so far
-static int prefill_begin(bessx_session *s, const int *cols, int ncols, int append) {
+// 2: like 1 from inside a parked fit (the shared wide fills): the fit's host-side state stays as it is
+int prefill_begin(bessx_session *s, const int *cols, int ncols, int append) {
   if (int rc = prefill_ready(s)) return rc;
   if (!cols || ncols < 1 || ncols % COV_R != 0) return fail(BESSX_ERR_ARG, "cov_prefill: need a multiple of 32 columns");
   std::vector<char> seen((size_t)s->p, 0);
@@ -821,13 +824,16 @@ static int prefill_begin(bessx_session *s, const int *cols, int ncols, int appen
   }
   int base = 0;
   if (append) {
-    if (int rc = settle_device_chain(s)) return rc;
+    if (append == 1)
+      if (int rc = settle_device_chain(s)) return rc;
     int meta_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPX(hipMemcpyAsync(meta_h, s->cov[0].meta, sizeof(meta_h), hipMemcpyDeviceToHost, s->st));
     HIPX(hipStreamSynchronize(s->st));
     base = meta_h[0];
-    for (auto &c : s->cache) c.valid = false;  // (a fit that follows starts from uploaded coefficients)
-    s->dev_state_rs = -1;
+    if (append == 1) {
+      for (auto &c : s->cache) c.valid = false;  // (a fit that follows starts from uploaded coefficients)
+      s->dev_state_rs = -1;
+    }
   } else if (int rc = reset_path_caches(s)) {
     return rc;
   }
@@ -850,6 +856,8 @@ static int prefill_begin(bessx_session *s, const int *cols, int ncols, int appen
   s->prefill_base = base;
   return BESSX_OK;
 }
+}  // namespace bessx
+extern "C" {
 
 int bessx_session_cov_prefill_begin(bessx_session *s, const int *cols, int ncols) { return prefill_begin(s, cols, ncols, 0); }
 int bessx_session_cov_prefill_extend(bessx_session *s, const int *cols, int ncols) { return prefill_begin(s, cols, ncols, 1); }
@@ -902,6 +910,16 @@ int bessx_session_cov_prefill_end(bessx_session *s) {
                           s->st, s->xtx[0], cv.meta));
   HIPX(hipStreamSynchronize(s->st));
   s->prefill_cols = 0;
+  return BESSX_OK;
+}
+
+int bessx_session_set_fill_hook(bessx_session *s, bessx_fill_hook hook, void *user, int width) {
+  if (int rc = prefill_ready(s)) return rc;
+  if (hook && (width < COV_R || width % COV_R != 0 || width > s->capA))
+    return fail(BESSX_ERR_ARG, "set_fill_hook: width must be a multiple of 32 within the session's sparsity capacity");
+  s->fill_hook = hook;
+  s->fill_hook_user = user;
+  s->fill_hook_width = hook ? width : 0;
   return BESSX_OK;
 }
 

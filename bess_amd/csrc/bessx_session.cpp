@@ -1601,6 +1601,7 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 9: return s->cov_tie_rescues;
     case 11: return s->cv_ctx_dropped;
     case 12: return (long long)s->fold_ctx.size();
+    case 13: return s->shared_wide_fills;
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

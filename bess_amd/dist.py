@@ -14,6 +14,40 @@ def partition(n_units, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def rebalance_bounds(bounds, seconds, damping=0.5, fixed_seconds=0.0, deadband=0.12):
+    """Chunk boundaries of a k-path (bounds[r] .. bounds[r+1] = rank r's candidates) moved towards equal TIME per rank:
+    the candidates of a chunk are priced at its measured seconds / its length (candidates at large sparsity levels
+    cost more: larger solves, more Gram columns still to form), the ideal boundaries cut the cumulated price into
+    equal parts, and every boundary moves `damping` of the way there (the fills are lumpy: no jumping after one
+    measurement).  Every chunk keeps at least one candidate; the same input gives the same output on every rank.
+    A time above three times the median is taken for an outlier (a kernel instance loaded at its first launch costs
+    tens of ms once) and clipped; nothing moves while the ranks' step times -- `seconds` plus the part every rank spends
+    alike, `fixed_seconds` -- are within `deadband` of each other."""
+    b = [int(v) for v in bounds]
+    world = len(b) - 1
+    n = b[-1]
+    if world < 2 or n < world or len(seconds) != world:
+        return b
+    seconds = np.minimum(np.asarray(seconds, dtype=np.float64), 3.0 * float(np.median(seconds)))
+    tot = seconds + float(fixed_seconds)
+    if not float(np.mean(tot)) > 0.0 or (float(np.max(tot)) - float(np.min(tot))) <= deadband * float(np.mean(tot)):
+        return b
+    price = np.zeros(n)
+    for r in range(world):
+        if b[r + 1] > b[r]:
+            price[b[r]:b[r + 1]] = max(float(seconds[r]), 0.0) / (b[r + 1] - b[r])
+    cum = np.concatenate([[0.0], np.cumsum(price)])
+    if not cum[-1] > 0.0:
+        return b
+    new = [0]
+    for r in range(1, world):
+        ideal = int(np.searchsorted(cum, cum[-1] * r / world, side="left"))
+        v = int(round(b[r] + damping * (ideal - b[r])))
+        new.append(min(max(v, new[-1] + 1), n - (world - r)))
+    new.append(n)
+    return new
+
+
 def gather_curve(local_values, n_units, world, rank, device=None):
     """All-gather the per-unit scalars of every rank into one curve of length n_units (rank order = unit
     order under partition()).  Works for unequal chunk lengths by padding to the longest chunk."""
@@ -138,7 +172,7 @@ def cooperative_prefill(session, world, rank, comm, n_cols):
     return _share_and_exchange(session, world, rank, comm, ng)
 
 
-def pilot_prefill(session, world, rank, comm, n_first, k_pilot, n_second, ic_type=3):
+def pilot_prefill(session, world, rank, comm, n_first, k_pilot, n_second, ic_type=3, wide=0):
     """Two shared fills around a PILOT fit every rank runs identically.  The marginal list of cooperative_prefill covers
     the first PDAS iteration of a cold fit only: the iterations after it rank the noise columns by the residual of the
     FITTED model, which the marginal ranking does not predict (tools/coop_prefill.py: the slowest of 8 chunks still spent
@@ -150,7 +184,21 @@ def pilot_prefill(session, world, rank, comm, n_first, k_pilot, n_second, ic_typ
     Two data-path all-gathers of p x 32 blocks; cache contents and starting points only -- the stitching makes the
     gathered path the single chain's whatever the chunks started from."""
     cooperative_prefill(session, world, rank, comm, n_first)
-    pilot = session.sequential_path_chain([int(k_pilot)], ic_type=ic_type, keep_caches=True)
+    if wide >= 32 and world > 1:
+        # (2'): the pilot fit's OWN fills shared as well.  Every rank's pilot parks at the same iteration on the same
+        # missing columns; instead of each forming them privately (a pass over X per 32-64 columns, repeated on every
+        # rank) the library lists `wide` columns -- the missing ones, then the best uncached ones by the scores of that
+        # very iteration -- and the ranks form one group each (bessx_session_set_fill_hook)
+        session.set_fill_hook(lambda ng: _share_and_exchange(session, world, rank, comm, ng), int(wide))
+    try:
+        pilot = session.sequential_path_chain([int(k_pilot)], ic_type=ic_type, keep_caches=n_first >= 32)
+    except Exception:
+        if getattr(session, "_hook_error", None) is not None:
+            raise session._hook_error
+        raise
+    finally:
+        if wide >= 32 and world > 1:
+            session.set_fill_hook(None)
     bd, slot = session.cov_state()
     score = np.where(slot >= 0, -np.inf, bd)
     ng = min(int(n_second) // 32, int(np.sum(slot < 0)) // 32)
@@ -182,19 +230,24 @@ class StitchedKPath:
     (bess_amd.capi.Session).  step() returns this rank's chunk of the single chain plus the gathered IC curve."""
 
     def __init__(self, session, sequence, world=1, rank=0, ic_type=3, lead=(), device=None, stop_rtol=1e-9, comm=None,
-                 prefill=0, pilot=None):
+                 prefill=0, pilot=None, rebalance=False):
         self.s, self.world, self.rank = session, int(world), int(rank)
         self.full_seq = np.asarray(sequence, dtype=np.int32)
         self.kmax = int(self.full_seq.size)
         self.ic_type = ic_type
-        self.lo, self.hi = partition(self.kmax, self.world, self.rank)
+        self.bounds = [partition(self.kmax, self.world, r)[0] for r in range(self.world)] + [self.kmax]
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.seq = self.full_seq[self.lo:self.hi]
         self.lead = np.asarray([k for k in lead if self.lo > 0 and 1 <= k < (self.seq[0] if self.seq.size else 0)],
                                dtype=np.int32)  # ladder start: sparsity levels walked in front of the chunk, discarded
+        # rebalance: after every step the chunk boundaries move towards equal chunk + stitch time per rank
+        # (rebalance_bounds on the all-gathered times of that step: the same new boundaries on every rank).  Where a
+        # chunk starts changes nothing in the stitched path.  Not with a ladder start (its rungs are tied to k0).
+        self.rebalance = bool(rebalance) and self.lead.size == 0 and self.world > 1
         self.comm = comm if comm is not None else (_TorchComm(device) if world > 1 else _NoComm())
         self.stop_rtol = stop_rtol
         self.prefill = int(prefill)  # columns of the cooperative prefill in front of the chunks (0: replicas only)
-        self.pilot = pilot           # (k_pilot, n_second) of pilot_prefill, or None: the marginal list alone
+        self.pilot = pilot           # (k_pilot, n_second[, wide]) of pilot_prefill, or None: the marginal list alone
         self.width = int(self.full_seq.max()) if self.kmax else 1  # longest support of the path (singleton groups)
 
     KEYS = ("cand_T0", "cand_iters", "cand_train_loss", "cand_ic", "cand_coef0", "cand_support", "cand_beta")
@@ -218,10 +271,10 @@ class StitchedKPath:
         last = (np.zeros(0, np.int32), np.zeros(0), 0.0)
         t_pre = 0.0
         init = None
-        if self.prefill >= 32 and self.world > 1:
+        if (self.prefill >= 32 or (self.pilot and len(self.pilot) > 2 and self.pilot[2] >= 32)) and self.world > 1:
             if self.pilot:
                 model = pilot_prefill(self.s, self.world, self.rank, self.comm, self.prefill, self.pilot[0], self.pilot[1],
-                                      ic_type=self.ic_type)
+                                      ic_type=self.ic_type, wide=self.pilot[2] if len(self.pilot) > 2 else 0)
                 if self.seq.size and int(self.seq[0]) > int(self.pilot[0]):
                     init = model  # (chunks at or below the pilot's level start cold: cheap there)
             else:
@@ -270,7 +323,7 @@ class StitchedKPath:
                 raise RuntimeError("stitching did not settle in world rounds")
         t_stitch = time.time() - t0 - t_chunk
         # the one result collective: the IC curve (and, for the report, this step's stitch statistics)
-        longest = -(-self.kmax // self.world)
+        longest = max(self.bounds[r + 1] - self.bounds[r] for r in range(self.world))
         buf = np.full(longest + 4, np.nan)
         if mine is not None:
             buf[:self.seq.size] = mine["cand_ic"]
@@ -278,11 +331,16 @@ class StitchedKPath:
         curve = np.empty(self.kmax)
         stats = []
         for r, b in enumerate(self.comm.all_gather(buf, self.world)):
-            lo, hi = partition(self.kmax, self.world, r)
+            lo, hi = self.bounds[r], self.bounds[r + 1]
             curve[lo:hi] = b[:hi - lo]
             stats.append(b[longest:])
         stats = np.asarray(stats)
-        return {"chunk": mine, "ic_curve": curve, "best_k": int(self.full_seq[select_best(curve)]),
+        used = list(self.bounds)
+        if self.rebalance:
+            self.bounds = rebalance_bounds(used, stats[:, 1] + stats[:, 2], fixed_seconds=float(np.median(stats[:, 3])))
+            self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+            self.seq = self.full_seq[self.lo:self.hi]
+        return {"chunk": mine, "ic_curve": curve, "best_k": int(self.full_seq[select_best(curve)]), "bounds": used,
                 "stitch_refits": int(stats[:, 0].sum()), "stitch_refits_per_rank": [int(v) for v in stats[:, 0]],
                 "stitch_rounds": rounds, "chunk_seconds_per_rank": [float(v) for v in stats[:, 1]],
                 "stitch_seconds_per_rank": [float(v) for v in stats[:, 2]],

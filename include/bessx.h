@@ -162,7 +162,8 @@ int bessx_session_score_mode(const bessx_session *s);
  * several parked folds at once, 9 PDAS iterations redone with the exact tie rule, 10 times the Gram column cache was
  * started over since the last path call started, 11 times bessx_session_set_cv had to give the per-fold fit contexts up
  * (allocation or launch failure: the fold fits then run one after another -- slower, same results), 12 fold contexts
- * alive now (K when the fold fits of a CV evaluation run side by side, else 0).  -1 for an unknown id. */
+ * alive now (K when the fold fits of a CV evaluation run side by side, else 0), 13 fills of a parked fit that went
+ * through the fill hook (bessx_session_set_fill_hook).  -1 for an unknown id. */
 long long bessx_session_counter(const bessx_session *s, int which);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)
@@ -323,6 +324,17 @@ int bessx_session_cov_prefill_compute(bessx_session *s, int g0, int ngroups);
 int bessx_session_cov_prefill_export(bessx_session *s, int g0, int ngroups, double *dst, int dst_on_device);
 int bessx_session_cov_prefill_import(bessx_session *s, int g0, int ngroups, const double *src, int src_on_device);
 int bessx_session_cov_prefill_end(bessx_session *s);
+
+/* Shared WIDE fills inside a fit that several sessions run identically (the pilot fit of a multi-GPU k-path: same data,
+ * same cache, deterministic kernels -- every rank's fit parks at the same PDAS iteration on the same missing columns).
+ * With a hook set, a fit of the all-rows row set that parks on missing Gram columns does not form them privately (one
+ * pass over X for 32-64 columns, repeated on every rank): the library lists the missing columns followed by the
+ * uncached columns the CURRENT sacrifice scores rank highest, `width` columns in all (a multiple of 32; the same list on
+ * every rank), hands them slots as bessx_session_cov_prefill_extend does, and calls hook(user, n_groups) -- the caller
+ * forms its share of the groups, exchanges the blocks and closes the list (cov_prefill_compute / export / import /
+ * end); the fit then goes on.  A non-zero return fails the fit with BESSX_ERR_ARG.  hook = NULL: private fills. */
+typedef int (*bessx_fill_hook)(void *user, int n_groups);
+int bessx_session_set_fill_hook(bessx_session *s, bessx_fill_hook hook, void *user, int width);
 
 /* Test hook: queue a host function on the session's stream that sleeps for `milliseconds` -- everything queued behind
  * it waits, as behind a wedged kernel (tests/test_deadline_gpu.py: the waits of the host give up at

@@ -49,7 +49,7 @@ def _run_bench(extra, env=None, timeout=900):
 def test_bench_gpus_2_starts_two_ranks_and_shards_the_k_path(gpu):
     """`python bench.py --gpus 2` with no launcher starts 2 ranks itself; the default N > 1 mode is the strong-scaling
     k-path split of ONE problem.  On the one-GPU box the ranks share the device (BESSX_BENCH_ONE_DEVICE=1, gloo)."""
-    d = _run_bench(["--gpus", "2"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    d = _run_bench(["--gpus", "2", "--rebalance", "off"], {"BESSX_BENCH_ONE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert abs(d["value"] - 30 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]  # ONE problem: 30 candidates / step
     rep = d["kpath_chunks_vs_single_chain"]
@@ -67,12 +67,28 @@ def test_bench_gpus_2_starts_two_ranks_and_shards_the_k_path(gpu):
 def test_bench_three_ranks_with_the_pilot_prefill(gpu):
     """--gpus 3 on the one-GPU box with the cooperative prefill and the pilot fit in front of the chunks: two data-path
     all-gathers of Gram column blocks (gloo here), and still every candidate of the single chain."""
-    d = _run_bench(["--gpus", "3", "--prefill", "64", "--pilot", "12,64", "--no-cpu-baseline"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    d = _run_bench(["--gpus", "3", "--prefill", "64", "--pilot", "12,64", "--no-cpu-baseline", "--rebalance", "off"],
+                   {"BESSX_BENCH_ONE_DEVICE": "1"})
     rep = d["kpath_chunks_vs_single_chain"]
     assert d["n_gpus"] == 3 and rep["chunks"] == [[1, 10], [11, 20], [21, 30]]
     assert rep["supports_equal_to_single_chain"] == rep["of"] == 30 and rep["differing_k"] == []
     assert rep["prefill_columns"] == 64 and rep["pilot"] == [12, 64] and min(rep["prefill_seconds_per_rank"]) > 0
     assert "cooperative prefill" in d["config"]["collective"]
+
+
+def test_bench_three_ranks_with_shared_fills_in_the_pilot_and_moving_chunk_boundaries(gpu):
+    """The pilot fit's own fills shared between the ranks (one 32-column group each per fill) and chunk boundaries that
+    move after every step towards equal time per rank: cache contents and starting points only -- every candidate of
+    the single chain, whatever the boundaries of the last step were."""
+    d = _run_bench(["--gpus", "3", "--prefill", "32", "--pilot", "12,0,96", "--no-cpu-baseline", "--rebalance", "on",
+                    "--steps", "3"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    rep = d["kpath_chunks_vs_single_chain"]
+    assert d["n_gpus"] == 3 and rep["rebalance"] is True and rep["pilot"] == [12, 0, 96]
+    ch = rep["chunks"]
+    assert ch[0][0] == 1 and ch[-1][1] == 30 and all(a[1] + 1 == b[0] for a, b in zip(ch, ch[1:]))
+    assert all(b >= a for a, b in ch)
+    assert rep["supports_equal_to_single_chain"] == rep["of"] == 30 and rep["differing_k"] == []
+    assert rep["best_k_chunked"] == rep["best_k_single_chain"]
 
 
 def test_bench_weak_scaling_and_cv_workload_on_two_ranks(gpu):

@@ -152,12 +152,22 @@ def _stitch_worker(rank, world, port, out_path):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     X, y = _hard_lm()
     seq = np.arange(1, 25)
-    rep = bdist.StitchedKPath(NumpyLmSession(X, y, np.zeros(len(y), int), 1), seq, world, rank).step()
+    sk = bdist.StitchedKPath(NumpyLmSession(X, y, np.zeros(len(y), int), 1), seq, world, rank, rebalance=True)
+    rep = sk.step()
     sup = np.full((len(seq), 24), -1)
     lo, hi = bdist.partition(len(seq), world, rank)
+    assert rep["bounds"][rank] == lo and rep["bounds"][rank + 1] == hi  # the first step runs the equal split
     sup[lo:hi, :rep["chunk"]["cand_support"].shape[1]] = rep["chunk"]["cand_support"]
+    # a second step on boundaries moved by hand to a very uneven split (what rebalancing may arrive at): same path
+    sk.bounds = [0] + [len(seq) - world + r for r in range(1, world)] + [len(seq)]
+    sk.lo, sk.hi = sk.bounds[rank], sk.bounds[rank + 1]
+    sk.seq = sk.full_seq[sk.lo:sk.hi]
+    rep2 = sk.step()
+    sup2 = np.full((len(seq), 24), -1)
+    sup2[rep2["bounds"][rank]:rep2["bounds"][rank + 1], :rep2["chunk"]["cand_support"].shape[1]] = rep2["chunk"]["cand_support"]
     np.savez(out_path + ".%d.npz" % rank, sup=sup, lo=lo, hi=hi, curve=rep["ic_curve"], best=rep["best_k"],
-             refits=rep["stitch_refits_per_rank"], rounds=rep["stitch_rounds"])
+             refits=rep["stitch_refits_per_rank"], rounds=rep["stitch_rounds"], sup2=sup2, curve2=rep2["ic_curve"],
+             bounds2=np.asarray(rep2["bounds"]), bounds3=np.asarray(sk.bounds))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -182,8 +192,35 @@ def test_stitched_kpath_equals_the_single_chain(tmp_path, world):
     for g in got:
         np.testing.assert_allclose(g["curve"], want["ic_calls"], rtol=1e-9)
         assert int(g["best"]) == int(seq[int(np.argmin(want["ic_calls"]))])
+        np.testing.assert_allclose(g["curve2"], want["ic_calls"], rtol=1e-9)
+        assert np.array_equal(g["bounds2"], got[0]["bounds2"]) and np.array_equal(g["bounds3"], got[0]["bounds3"])
+    b2 = got[0]["bounds2"]
+    for k, f in enumerate(want["fits"]):  # the uneven split of the second step: the same single chain
+        r = [i for i in range(world) if b2[i] <= k < b2[i + 1]][0]
+        assert np.array_equal(got[r]["sup2"][k, :k + 1], f["iters"][-1]), k + 1
     # the cold chunks alone would NOT have been the single chain (the stitch replaced candidates)
     assert int(np.sum(got[0]["refits"])) > world - 1
     cold = P.trace(X, y, ic_type=3, sequence=seq[bdist.partition(len(seq), world, world - 1)[0]:])
     assert any(not np.array_equal(c["iters"][-1], w["iters"][-1])
                for c, w in zip(cold["fits"], want["fits"][bdist.partition(len(seq), world, world - 1)[0]:]))
+
+
+def test_rebalance_bounds():
+    """Chunk boundaries move towards equal time per rank, half way per step; outliers are clipped, small imbalances and
+    degenerate inputs leave the boundaries alone, every chunk keeps a candidate."""
+    sys.path.insert(0, ROOT)
+    from bess_amd.dist import rebalance_bounds
+    assert rebalance_bounds([0, 100, 200], [4.5, 9.3], damping=1.0) == [0, 126, 200]
+    assert rebalance_bounds([0, 100, 200], [4.5, 9.3]) == [0, 113, 200]
+    assert rebalance_bounds([0, 100, 200], [4.5, 4.8]) == [0, 100, 200]                    # inside the dead band
+    assert rebalance_bounds([0, 100, 200], [4.5, 9.3], fixed_seconds=100.0) == [0, 100, 200]
+    b = rebalance_bounds([0, 50, 100, 150, 200], [2.8, 460.0, 3.6, 4.1])                    # one rank hit a 0.4 s stall
+    assert b[0] == 0 and b[-1] == 200 and all(y > x for x, y in zip(b, b[1:])) and abs(b[2] - 100) <= 15
+    assert rebalance_bounds([0, 1, 2, 3], [1.0, 50.0, 1.0], damping=1.0) == [0, 1, 2, 3]   # nothing left to give
+    assert rebalance_bounds([0, 7], [3.0]) == [0, 7]
+    assert rebalance_bounds([0, 3, 6], [0.0, 0.0]) == [0, 3, 6]
+    b = [0, 50, 100]
+    for _ in range(12):  # candidates of the upper half cost three times as much: converges to equal time and stays
+        cost = [1.0 * (b[1] - b[0]), 3.0 * (b[2] - b[1])]
+        b = rebalance_bounds(b, cost)
+    assert b == [0, 72, 100] or b == [0, 73, 100] or b == [0, 74, 100]

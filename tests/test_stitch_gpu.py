@@ -228,6 +228,56 @@ def test_stitched_chunks_with_the_pilot_prefill(gpu, world):
         assert int(np.sum(slot >= 0)) >= 64 + 96  # both shared lists are in every rank's cache
 
 
+@pytest.mark.parametrize("world,n_first", [(2, 64), (4, 0), (3, 32)])
+def test_pilot_fit_with_shared_wide_fills(gpu, world, n_first):
+    """bessx_session_set_fill_hook: the pilot fit every rank runs identically parks on missing Gram columns; the ranks
+    then form ONE 32-column group each of a list `wide` long (the missing columns + the best uncached ones by that
+    iteration's scores) instead of every rank forming the same columns privately.  Same pilot model as with private
+    fills, same stitched path as the single chain, fewer passes over X per rank."""
+    X, y, kw = _hard("lm", 1200, 400)
+    seq = np.arange(1, 33)
+    with gpu.Session(X, y, score_mode=2, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        s.sequential_path_chain([1], ic_type=3)  # (cold caches)
+        alone = s.sequential_path_chain([14], ic_type=3, keep_caches=True)
+
+    def rank_fn(rank, comm):
+        with gpu.Session(X, y, score_mode=2, **kw) as sr:
+            calls = []
+            orig = bdist._share_and_exchange
+
+            def counted(session, w, r, c, ng):
+                calls.append(ng)
+                return orig(session, w, r, c, ng)
+
+            model = None
+            if rank == 0:  # (the pilot model itself, once: equal to the fit with private fills)
+                with gpu.Session(X, y, score_mode=2, **kw) as s1:
+                    s1.set_fill_hook(lambda ng: (s1.cov_prefill_compute(0, ng), s1.cov_prefill_end()), 32 * world)
+                    model = s1.sequential_path_chain([14], ic_type=3)
+                    s1.set_fill_hook(None)
+                    assert s1.counters()["shared_wide_fills"] >= 1
+            sk = bdist.StitchedKPath(sr, seq, world, rank, ic_type=3, comm=comm, prefill=n_first, pilot=(14, 64, 32 * world))
+            first = sk.step()
+            again = sk.step()
+            wide_fills = sr.counters()["shared_wide_fills"]
+            passes = sr.counters()["passes_over_X"]
+        np.testing.assert_array_equal(first["chunk"]["cand_support"], again["chunk"]["cand_support"])
+        return again, wide_fills, passes, model
+
+    res = run_ranks(world, rank_fn)
+    for r, (rep, wide_fills, passes, model) in enumerate(res):
+        a, b = bdist.partition(len(seq), world, r)
+        c = rep["chunk"]["cand_support"]
+        np.testing.assert_array_equal(c, single["cand_support"][a:b, :c.shape[1]])
+        np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-11)
+        assert wide_fills >= 2  # (two steps, at least one wide fill in each pilot fit)
+    assert len({q[1] for q in res}) == 1  # every rank parked equally often
+    model = res[0][3]
+    np.testing.assert_array_equal(model["cand_support"], alone["cand_support"])
+    np.testing.assert_allclose(model["cand_beta"], alone["cand_beta"], rtol=1e-9, atol=1e-13)
+
+
 def test_rccl_collectives_of_the_sharded_paths_at_world_one(gpu):
     """The nccl (= RCCL) code path of bess_amd.dist on the one GPU there is: a process group of ONE rank with backend
     "nccl" -- the all-gather of host records through device tensors, and the device-to-device exchange of Gram column
