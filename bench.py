@@ -441,10 +441,21 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
         rec = timed(sess, lambda: sess.sequential_path(np.arange(1, 41), ic_type=3), n, p)
     rec.update({"workload": "SURVEY 8f: grouped LM (algorithm_type 2), the configs[1] data as %d groups of 5 columns, "
                             "sequential path over 1..40 groups, GIC" % (p // 5),
-                "score_kernel_name": "k_xtv (X^T r, one pass over X per PDAS iteration; the per-group sacrifices "
-                                     "follow in k_group_score)",
+                "score_kernel_name": "k_cov_panel (covariance form: d = X^T y - G_A beta_A from cached Gram columns, no "
+                                     "pass over X per PDAS iteration; a parked fit fills 64 columns -- the missing ones and "
+                                     "whole groups by this iteration's sacrifices -- in one pass; the per-group sacrifices "
+                                     "follow in k_group_score, the blocks' diagonalisation cached per lambda)",
                 "host_round_trips": "one per batch of two PDAS iterations (the selected groups are expanded to columns on "
-                                    "the device, k_group_expand)", "setup_seconds": setup})
+                                    "the device, k_group_expand) + one per fill", "setup_seconds": setup})
+    # the streaming form of the same path (score_mode = 1: X^T r by k_xtv, one pass over X per PDAS iteration; round 4's
+    # figure before the covariance form reached the grouped fits)
+    with capi.Session(X_lm, y_lm, data_type=1, model_type=1, algorithm_type=2, g_index=np.arange(0, p, 5, dtype=np.int32),
+                      device=local_rank, score_mode=1) as sess:
+        st = timed(sess, lambda: sess.sequential_path(np.arange(1, 41), ic_type=3), n, p)
+    rec["streaming_form"] = {"candidates_per_s": st["candidates_per_s"], "ms_per_path": st["ms_per_path"],
+                             "passes_over_X": st["passes_over_X"], "score_kernel": st["score_kernel"],
+                             "same_selection": bool(st["selected_k"] == rec["selected_k"] and
+                                                    abs(st["criterion"] - rec["criterion"]) <= 1e-9 * abs(rec["criterion"]))}
     res["grouped_lm"] = rec
     # L0L2 / bsrr -- the Powell path over (s, log lambda) with golden-section line searches
     with capi.Session(X_lm, y_lm, data_type=1, model_type=1, algorithm_type=5, device=local_rank) as sess:

@@ -735,6 +735,63 @@ static int group_eig_ensure(bessx_session *s, int rs, double lambda) {
   return 0;
 }
 
+// Grouped LM in the covariance form: a fit parked on missing Gram columns (cov_stall = 1).  The fill list is built on the
+// host -- the missing columns, then the uncached columns of the groups this iteration's sacrifices rank highest, whole
+// groups first (a group enters the active set with all its columns), 64 columns in all: one pass of the pair kernel --
+// and takes the next free slots of the cache (prefill_begin, in-fit form).  Then the wake-up; the caller queues the rest
+// of the stalled slot.
+static int grouped_cov_fill(bessx_session *s, const FitCtrl *hc, int T0) {
+  (void)T0;
+  bessx_session::CovCache &cv = s->cov[0];
+  const int p = s->p, N = s->N, nm = hc->cov_nmiss;
+  if (nm < 1 || nm > s->capA) return fail(BESSX_ERR_NUMERIC, "internal error: parked grouped fit without a request");
+  std::vector<int> list((size_t)nm), slot_h((size_t)p);
+  std::vector<double> sc((size_t)N);
+  HIPX(hipMemcpyAsync(list.data(), s->cov_fcols, (size_t)nm * sizeof(int), hipMemcpyDeviceToHost, s->st));
+  HIPX(hipMemcpyAsync(sc.data(), s->bd, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, s->st));
+  HIPX(hipMemcpyAsync(slot_h.data(), cv.slot_of, (size_t)p * sizeof(int), hipMemcpyDeviceToHost, s->st));
+  HIPX(hipStreamSynchronize(s->st));
+  for (int c : list) slot_h[(size_t)c] = 0;  // (listed: not a candidate for the rest of the list)
+  std::vector<int> cand;  // groups with uncached columns, best sacrifice first (ties by group number)
+  for (int g = 0; g < N; g++) {
+    bool open = false;
+    for (int j = 0; j < s->gsz_h[g] && !open; j++) open = slot_h[(size_t)s->gidx_h[g] + j] < 0;
+    if (open) cand.push_back(g);
+  }
+  const int want = std::max(2 * COV_R, (nm + COV_R - 1) / COV_R * COV_R);
+  std::sort(cand.begin(), cand.end(), [&](int a, int b) { return sc[a] > sc[b] || (sc[a] == sc[b] && a < b); });
+  for (size_t q = 0; q < cand.size() && (int)list.size() < want; q++) {
+    const int g = cand[q];
+    for (int j = 0; j < s->gsz_h[g] && (int)list.size() < want; j++)
+      if (slot_h[(size_t)s->gidx_h[g] + j] < 0) list.push_back(s->gidx_h[g] + j);
+  }
+  const int total = (int)list.size() / COV_R * COV_R;
+  if (total < nm || total > s->capA) {
+    // hardly an uncached column left to round the list up to whole 32-column groups (or an over-long request): the
+    // missing columns alone, listed on the device as the ungrouped fit's private fill does (last group partly filled)
+    HIPX(launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st, s->cov_spec, 0));
+    if (int rc = enqueue_cov_fill(s, 0, (nm + COV_R - 1) / COV_R, 1)) return rc;
+    if (s->timing) {
+      HIPX(hipStreamSynchronize(s->st));
+      if (int rc = cov_collect(s, nm)) return rc;
+    }
+    HIPX(launch_cov_resume(s->ctrl, s->st));
+    return 0;
+  }
+  if (int rc = prefill_begin(s, list.data(), total, 2)) return rc;
+  if (int rc = enqueue_cov_fill(s, 0, total / COV_R, 1, s->fill_ctrl, 0, false)) return rc;
+  s->cov_panel_groups += total / COV_R;
+  HIPX(launch_cov_compact(cv.G, p, cv.slot_of, s->cov_fcols, 0, total / COV_R, cv.GS, s->cov_cs, s->fill_ctrl, 1, s->st,
+                          s->xtx[0], cv.meta));
+  s->prefill_cols = 0;
+  if (s->timing) {  // (the panel launches' event pairs belong to THIS list)
+    HIPX(hipStreamSynchronize(s->st));
+    if (int rc = cov_collect(s, total)) return rc;
+  }
+  HIPX(launch_cov_resume(s->ctrl, s->st));
+  return 0;
+}
+
 int algorithm_fit_grouped(bessx_session *s) {
   const int T0 = s->sparsity_level, rs = s->cur_rows, fam = s->model_type;
   const double lambda = s->lambda_level;
@@ -760,7 +817,22 @@ int algorithm_fit_grouped(bessx_session *s) {
   }
   hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur, s->b_cur,
                                   s->beta_dense, s->p, s->hist, s->st);
-  if (e == hipSuccess) {
+  // LM, groups of one width, all rows, covariance form (bessx_session_create decides): no residual, no pass over X
+  // per PDAS iteration -- d = X^T y - G_A beta_A from the cached Gram columns of the active groups' columns
+  const bool gcov = !glm && s->cov_mode && rs == 0 && s->g_uniform > 0 && !s->trace.on &&
+                    (long)T0 * s->g_uniform + 2 <= (long)s->capA && k_init <= s->capA;
+  if (e == hipSuccess && gcov) {
+    if (k_init > 0) {
+      // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones
+      bessx_session::CovCache &cv = s->cov[0];
+      e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s), s->cov_fcols,
+                          s->ctrl, 0, s->A_cur, s->st);
+      if (e == hipSuccess)
+        e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 0, s->st, s->cov_spec, 0);
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group cov begin: ") + hipGetErrorString(e));
+      if (int rc = enqueue_cov_fill(s, 0, (k_init + COV_R - 1) / COV_R, 0)) return rc;
+    }
+  } else if (e == hipSuccess) {
     if (!glm)
       e = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, 0, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
                           s->st);
@@ -795,7 +867,73 @@ int algorithm_fit_grouped(bessx_session *s) {
     const CholFuse fbz = chol_fallback_only(s);
     std::vector<std::pair<size_t, bool>> k1_pairs;
     const bool eig = group_eig_ensure(s, rs, lambda) == 0;
-    while (slot <= s->max_iter) {
+    // solve + commit of a slot whose columns are all cached (covariance form), and the sums of squares if the fit ends
+    auto cov_rest = [&](int sl) -> hipError_t {
+      bessx_session::CovCache &cv = s->cov[0];
+      hipError_t q = launch_cov_gram(cv.G, s->p, cv.slot_of, s->gcols_new, K, mt, s->Gt, cv.meta, s->ctrl, sl, s->st);
+      if (q == hipSuccess)
+        q = mt <= 16 ? launch_chol(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info, s->ctrl, sl,
+                                   0, s->st, &fbz)
+                     : launch_chol_big(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info,
+                                       s->rdiag, s->zbig, s->ctrl, sl, 0, s->st);
+      if (q == hipSuccess && mt <= 16)
+        q = launch_sym_fallback(s->Gt, K, mt, lambda, 0, s->xty[rs], s->gcols_new, s->sol, &s->ctrl->info, s->ctrl, sl,
+                                s->st, &fbz);
+      if (q == hipSuccess)
+        q = launch_commit_group(s->ctrl, sl, T0, s->A_new, K, s->gcols_new, s->sol, 0, 0, s->A_cur, s->b_cur,
+                                s->beta_dense, s->hist, s->hist_beta, s->hist_coef0, s->hist_stride, s->st);
+      if (q == hipSuccess)
+        q = launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, sl, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
+                            s->st, 1);
+      return q;
+    };
+    while (gcov && slot <= s->max_iter) {
+      bessx_session::CovCache &cv = s->cov[0];
+      for (int b = 0; b < 2 && slot <= s->max_iter; b++, slot++) {
+        // d (and, unused here, the singleton scores: into bd2) from the cache; the group sacrifices from d
+        e = launch_cov_d(cv.G, s->p, cv.slot_of, s->xty[rs], s->A_cur, s->b_cur, s->dcol, s->beta_dense, s->xtx[rs],
+                         (double)s->n_train[rs], lambda, s->always, s->bd2, s->inA, s->cov_bmm, s->ctrl, slot, s->st);
+        if (e == hipSuccess)
+          e = launch_group_score(s->N, s->gidx, s->gsz, s->goff, s->gxtx_rs[rs], nullptr, s->dcol, 1, s->p, 1,
+                                 (double)s->n_train[rs], lambda, s->beta_dense, s->always, s->bd, s->st, s->gmax, s->mwork,
+                                 s->zwork, s->ctrl, slot, eig ? 2 : 0, eig ? s->geig_v_rs[rs] : nullptr,
+                                 eig ? s->geig_l_rs[rs] : nullptr);
+        if (e == hipSuccess)
+          e = launch_topk(s->bd, s->N, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
+        if (e == hipSuccess) e = launch_group_expand(s->A_new, T0, gs, s->gidx, s->gcols_new, s->ctrl, slot, s->st);
+        // repeated set (same_prev) + cache lookup of the expanded columns: parks the fit when one is missing
+        if (e == hipSuccess)
+          e = launch_cov_need(s->gcols_new, K, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s), s->cov_fcols,
+                              s->ctrl, slot, s->A_cur, s->st, 1);
+        if (e == hipSuccess) e = cov_rest(slot);
+        if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit (covariance form): ") + hipGetErrorString(e));
+      }
+      if (int rc = read_results(s)) return rc;
+      if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
+      if (hc->cov_miss) return fail(BESSX_ERR_NUMERIC, "internal error: an active column was missing from the Gram column cache");
+      if (hc->cov_stall == 1) {
+        const int stalled = -1 - hc->l + 1;
+        if (int rc = grouped_cov_fill(s, hc, T0)) return rc;
+        e = cov_rest(stalled);
+        if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit (after the fill): ") + hipGetErrorString(e));
+        slot = stalled + 1;
+        if (slot > s->max_iter) {  // (the stalled slot was the last one: its result)
+          if (int rc = read_results(s)) return rc;
+          if (int rc = cov_collect(s, hc->cov_nfill)) return rc;
+        }
+        continue;
+      }
+      if (hc->cov_stall) return fail(BESSX_ERR_NUMERIC, "internal error: unexpected stall of a grouped fit");
+      if (hc->done) break;
+    }
+    if (gcov) s->cov_panel_groups += hc->cov_groups;  // (fills gated on the fit's own control block: initial support, fallback)
+    if (gcov && !hc->done) {
+      // out of iterations: the sums of squares of the last coefficients have not been formed yet
+      HIPX(launch_resid_lm(s->X, s->ld, s->n, s->y, s->mask[rs], s->ctrl, hc->l, s->A_cur, s->b_cur, s->r_rs[rs], s->sse,
+                           s->st, 2));
+      if (int rc = read_results(s)) return rc;
+    }
+    while (!gcov && slot <= s->max_iter) {
       const int first = slot;
       for (int b = 0; b < 2 && slot <= s->max_iter; b++, slot++) {
         hipEvent_t ea = nullptr, eb = nullptr;

@@ -779,7 +779,7 @@ int bessx_session_cv_eval(bessx_session *s, int T0, double lambda, int want_full
 // ----------------------------------------------------------------------------------------------
 static int prefill_ready(bessx_session *s) {
   if (!s) return fail(BESSX_ERR_ARG, "null session");
-  if (!s->cov_mode || s->model_type != 1 || s->grouped)
+  if (!s->cov_mode || s->model_type != 1)
     return fail(BESSX_ERR_UNSUPPORTED, "cov_prefill: the session does not run the covariance form of the LM score pass");
   if (s->cv_shared) return fail(BESSX_ERR_UNSUPPORTED, "cov_prefill: not offered on sessions with cross-validation folds");
   HIPX(hipSetDevice(s->device));

@@ -1035,9 +1035,12 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     if (mode == 0)
       if (const char *ev = std::getenv("BESSX_SCORE_MODE")) mode = std::atoi(ev);
     if (mode < 0 || mode > 2) return bail(fail(BESSX_ERR_ARG, "score_mode must be 0 (auto), 1 (streaming) or 2 (covariance)"));
-    const bool eligible = s->model_type == 1 && !s->grouped;
+    // (groups: every group of one width <= 16 columns -- the fits whose selected groups are expanded to columns on the
+    // device --, all rows, and only with a cache that holds every column of the design)
+    const bool eligible = s->model_type == 1 && (!s->grouped || (s->g_uniform > 0 && s->gmax <= GRP_EIG_MAX));
     if (mode == 2 && !eligible)
-      return bail(fail(BESSX_ERR_ARG, "covariance score mode exists for LM with singleton groups only"));
+      return bail(fail(BESSX_ERR_ARG, "covariance score mode exists for LM with singleton groups or groups of one width "
+                                      "(at most 16 columns) only"));
     if (eligible && mode != 1) {
       // capacity: every column if p is small, else a few active sets' worth, within 1 GiB per row set
       // (fills of exactly two groups take the pair panel kernel, one pass for 64 columns; the switches that made every
@@ -1051,6 +1054,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       long C = all <= budget ? all : std::min<long>(2560, budget);
       if (const char *ev = test_hook("cov_cap"))  // a small cache exercises the restart path
         C = std::min<long>(C, std::max(0, std::atoi(ev)) / 32 * 32);
+      if (s->grouped && C < all) C = 0;  // (grouped fits never start the cache over)
       if (C >= 2 * COV_R + s->cov_spec) {
         s->cov_mode = true;
         s->cov_C = (int)C;
@@ -1409,7 +1413,7 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
     CVX(grow(s->part2_rs, (size_t)s->nrb * p, false));
     CVX(grow(s->h_rs, (size_t)s->ld, true));
     int rc = alloc_gram_cache(s);
-    if (rc == 0 && s->cov_mode) rc = alloc_cov_cache(s, share);
+    if (rc == 0 && s->cov_mode && !s->grouped) rc = alloc_cov_cache(s, share);  // (grouped: the all-rows fits only)
     if (rc) {
       drop_folds(s);
       return rc;

@@ -92,3 +92,45 @@ def test_group_blocks_diagonalised_once_per_row_set_and_lambda(gpu, monkeypatch,
     want = P.trace(X, y, ic_type=3, sequence=np.arange(1, 9), lambda_seq=[0.0, 0.3, 0.0], g_index=g_index,
                    algorithm_type=3)
     np.testing.assert_allclose(outs["1"][0]["cand_ic"], want["ic_calls"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("gs,G,T,lam", [(5, 120, 20, 0.0), (2, 300, 40, 0.2), (8, 60, 12, 0.0), (3, 40, 40, 0.0)])
+def test_grouped_lm_in_the_covariance_form(gpu, gs, G, T, lam):
+    """Groups of one width, all rows: d = X^T y - G_A beta_A from cached Gram columns (no pass over X per PDAS
+    iteration), the selected groups' columns looked up in the cache, fills of whole groups listed by the host when a fit
+    parks.  Same candidates as the streaming form (score_mode = 1) and the oracle; a handful of passes over X per path."""
+    X, y, g_index = _grouped_lm(1500, G, gs, 6, seed=3 * gs + G)
+    seq, lams = np.arange(1, T + 1), [lam]
+    outs, passes = {}, {}
+    for mode in (2, 1):
+        with gpu.Session(X, y, g_index=g_index, algorithm_type=3 if lam else 2, score_mode=mode) as s:
+            assert s.score_mode() == mode
+            outs[mode] = [s.sequential_path(seq, lams, ic_type=3)]
+            passes[mode] = s.counters()["passes_over_X"]
+            outs[mode] += [s.gs_path(1, min(T, 20), ic_type=3), s.fit(min(T, 7), lam=lam),
+                           s.fit(min(T, 7), lam=lam, init_idx=np.arange(2 * gs), init_val=np.ones(2 * gs))]
+            s.set_cv(3, synth.make_cv_folds(1500, 3, seed=1))  # fold fits stay in the streaming form
+            outs[mode].append(s.sequential_path(np.arange(1, 6), lams, ic_type=3, is_cv=True))
+    for a, b in zip(outs[2], outs[1]):
+        for key in ("cand_support", "cand_iters", "support", "iters"):
+            if key in a:
+                np.testing.assert_array_equal(a[key], b[key])
+        for key in ("cand_ic", "cand_beta", "beta", "train_loss"):
+            if key in a:
+                np.testing.assert_allclose(a[key], b[key], rtol=1e-9, atol=1e-12)
+    # every column is formed at most once per path; only when fewer than 32 uncached columns are left do the last groups
+    # come in a few columns per pass (the p = 120 case here)
+    assert passes[2] <= gs * G // 32 + 10
+    if G * gs <= 600 and T <= 30 and lam == 0.0:
+        want = P.trace(X, y, ic_type=3, sequence=seq, g_index=g_index, algorithm_type=2)
+        np.testing.assert_allclose(outs[2][0]["cand_ic"], want["ic_calls"], rtol=1e-8)
+        assert list(outs[2][0]["cand_iters"]) == [len(f["iters"]) for f in want["fits"]]
+
+
+def test_covariance_form_insisted_on_where_it_does_not_exist(gpu):
+    X, y, g_index = _grouped_lm(600, 30, 4, 3, seed=5)
+    ragged = np.delete(g_index, 3)
+    with pytest.raises(Exception):
+        gpu.Session(X, y, g_index=ragged, algorithm_type=2, score_mode=2)
+    with gpu.Session(X, y, g_index=ragged, algorithm_type=2) as s:
+        assert s.score_mode() == 1
