@@ -805,23 +805,35 @@ int algorithm_fit_grouped(bessx_session *s) {
   // beta <- beta_init
   const int k_init = (int)s->beta_init.idx.size();
   if (k_init > s->cap) return fail(BESSX_ERR_ARG, "initial support too large");
-  int *st_idx = reinterpret_cast<int *>(s->stage_h);
-  double *st_val = reinterpret_cast<double *>(s->stage_h + (size_t)s->capA * sizeof(int));
-  for (int i = 0; i < k_init; i++) {
-    st_idx[i] = s->beta_init.idx[i];
-    st_val[i] = s->beta_init.val[i];
-  }
-  if (k_init) {
-    HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, s->st));
-    HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
-  }
-  hipError_t e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur, s->b_cur,
-                                  s->beta_dense, s->p, s->hist, s->st);
   // LM, groups of one width, all rows, covariance form (bessx_session_create decides): no residual, no pass over X
   // per PDAS iteration -- d = X^T y - G_A beta_A from the cached Gram columns of the active groups' columns
   const bool gcov = !glm && s->cov_mode && rs == 0 && s->g_uniform > 0 && !s->trace.on &&
                     (long)T0 * s->g_uniform + 2 <= (long)s->capA && k_init <= s->capA;
-  if (e == hipSuccess && gcov) {
+  // ... and a fit that starts from exactly the model the previous fit of this row set left on the device (the next
+  // candidate of a warm-start path) needs no upload and no look-up of its initial support: those columns were the
+  // active set a moment ago
+  bessx_session::RsCache &cc = s->cache[rs];
+  const bool cont = gcov && cc.valid && cc.cov_layout && s->dev_state_rs == rs && cc.coef0 == s->coef0_init &&
+                    cc.beta.idx == s->beta_init.idx && cc.beta.val == s->beta_init.val;
+  cc.valid = false;
+  if (!cont) {
+    int *st_idx = reinterpret_cast<int *>(s->stage_h);
+    double *st_val = reinterpret_cast<double *>(s->stage_h + (size_t)s->capA * sizeof(int));
+    for (int i = 0; i < k_init; i++) {
+      st_idx[i] = s->beta_init.idx[i];
+      st_val[i] = s->beta_init.val[i];
+    }
+    if (k_init) {
+      HIPX(hipMemcpyAsync(s->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, s->st));
+      HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
+    }
+  }
+  hipError_t e = cont ? launch_fit_continue(s->ctrl, T0, s->hist, s->st, ++s->fit_serial, 0, 0)
+                      : launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur,
+                                         s->b_cur, s->beta_dense, s->p, s->hist, s->st);
+  if (e == hipSuccess && cont) {
+    // nothing else to set up
+  } else if (e == hipSuccess && gcov) {
     if (k_init > 0) {
       // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones
       bessx_session::CovCache &cv = s->cov[0];
@@ -846,7 +858,6 @@ int algorithm_fit_grouped(bessx_session *s) {
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("group fit begin: ") + hipGetErrorString(e));
   if (cox) s->cox_state_rs = -1;  // the ungrouped path's per-row-set reuse does not apply here
   s->dev_state_rs = -1;
-  s->cache[rs].valid = false;
   const FitCtrl *hc = reinterpret_cast<const FitCtrl *>(s->res_h);
   std::vector<int> G(T0), cols;
   std::vector<std::vector<int>> cols_hist;
@@ -1152,6 +1163,15 @@ int algorithm_fit_grouped(bessx_session *s) {
   s->sse_test = te;
   s->n_fits += 1;
   s->n_iters += hc->l;
+  if (gcov && hc->done) {  // the device holds exactly this model: a fit that starts from it continues (see `cont`)
+    cc.valid = true;
+    cc.cov_layout = true;
+    cc.lambda = lambda;
+    cc.T0 = T0;
+    cc.beta = s->beta;
+    cc.coef0 = s->coef0;
+    s->dev_state_rs = rs;
+  }
   if (s->trace.on) {
     const int L = hc->l;
     std::vector<double> hb((size_t)(L + 1) * s->hist_stride), hc0(L + 1);
