@@ -51,6 +51,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# chunk chains of the k-path run on a HIP stream each: 8 hardware queues instead of the runtime's default 4, set before
+# anything starts the runtime (bess_amd/__init__.py does the same at import; children inherit it)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)

@@ -361,6 +361,28 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
   }
   const bool spec = cov_speculates(s);
   hipError_t e = hipSuccess;
+  // a chunk chain (bessx_kchunks.cpp) fills the shared cache only while every other chain stands still; if another chain
+  // filled meanwhile the look-up is simply redone (its columns may be there now)
+  struct FillGuard {
+    bessx_session *c = nullptr;
+    ~FillGuard() {
+      if (c) kchains_fill_end(c);
+    }
+  } guard;
+  if (s->kch_owner) {
+    const int waited = kchains_fill_begin(s);
+    if (waited < 0) return fail(BESSX_ERR_HIP, "chunk chains: the fill rendezvous was abandoned");
+    guard.c = s;
+    if (waited > 0) {
+      HIPX(launch_cov_resume(s->ctrl, s->st));
+      e = launch_cov_need(s->A_new, T0, spec ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s),
+                          s->cov_fcols, s->ctrl, stalled, s->A_cur, s->st, 1);
+      if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark (chunk chain): ") + hipGetErrorString(e));
+      if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
+      *next_slot = stalled + 1;
+      return 0;
+    }
+  }
   if (s->fill_hook && rs == 0 && !s->parent && spec) {
     // shared wide fill (bessx_session_set_fill_hook): the missing columns, then the uncached columns the scores of this
     // iteration rank highest (bd2: cached and missing ones already at -1), fill_hook_width columns in all
@@ -405,6 +427,10 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
   const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, s->cov_spec) : 0;
   const int ngroups = (nm + room + COV_R - 1) / COV_R;
   if (int rc = enqueue_cov_fill(s, rs, ngroups, 1)) return rc;
+  if (s->kch_owner) {
+    HIPX(hipStreamSynchronize(s->st));  // the new columns are in memory before any other chain moves again
+    s->kch_owner->kch_chunk_fills++;    // (under the rendezvous: one writer)
+  }
   HIPX(launch_cov_resume(s->ctrl, s->st));
   if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
   *next_slot = stalled + 1;

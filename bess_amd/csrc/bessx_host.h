@@ -200,6 +200,10 @@ struct FoldPool {
   }
 };
 
+namespace bessx {
+struct KChains;
+}
+
 struct bessx_session {
   int p_full = 0;                 // columns of the caller's x (p = columns kept by the screening)
   std::vector<int> screen_map;    // kept column -> original column; empty without screening
@@ -352,6 +356,16 @@ struct bessx_session {
   int bmm_owner = -1;                  // row set of the k_cov_d launch that wrote cov_bmm last
   int *cov_fcols = nullptr, *cov_extras = nullptr;
   long long cov_panel_groups = 0;  // 32-column panel passes over X really executed (host statistics)
+  // The sequential path of ONE problem as several chunk chains at once (bessx_kchunks.cpp): the stitched k-path of the
+  // multi-GPU run inside one device.  A coarse warm-start chain over the chunk boundaries fills the Gram column cache
+  // and hands every chunk its starting model; the chunks then run side by side, each on a fit context of its own
+  // (stream, control block, scores, solve work space) that READS the one cache of the all-rows row set; a chain that
+  // needs a column the cache lacks fills it while every other chain stands still (KChains: safe points between
+  // candidates); the chunks are stitched into the single chain exactly as bess_amd.dist.StitchedKPath does it.
+  bessx::KChains *kch = nullptr;        // parent: contexts, host threads, the fill rendezvous (created at first use)
+  bessx_session *kch_owner = nullptr;   // chain context: the session whose cache it reads
+  int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
+  long long kch_paths = 0, kch_refits = 0, kch_chunk_fills = 0;  // paths run chunked, stitch refits, fills in the chunk phase
   bessx_fill_hook fill_hook = nullptr;  // shared wide fills of a parked fit (bessx_session_set_fill_hook)
   void *fill_hook_user = nullptr;
   int fill_hook_width = 0;
@@ -492,6 +506,15 @@ int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, 
 int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_d,
                                bool scores_ok = false, bool grow1 = false, SlotFuse *sf = nullptr);
 int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int rs, int *next_slot);
+// bessx_kchunks.cpp
+bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int is_cv, const bessx_path_chain *chain);
+int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type, bessx_path_result *res);
+void kchains_safe_point(bessx_session *c);   // chain context, between candidates: stand still while another chain fills
+int kchains_fill_begin(bessx_session *c);    // chain context parked on missing columns: wait until it alone runs
+void kchains_fill_end(bessx_session *c);
+void kchains_free(bessx_session *s);
+int chain_ctx_create(bessx_session *ps, bessx_session **out);  // bessx_session.cpp
+void chain_ctx_free(bessx_session *c);
 int prefill_begin(bessx_session *s, const int *cols, int ncols, int append);  // bessx_paths.cpp
 int glm_geometry(bessx_session *s, int T0, int *mt, int *mp, int *ntask, int *ntiles, int *rps, int *nslab);
 int enqueue_glm_head(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,

@@ -1,0 +1,454 @@
+// bessx_kchunks.cpp -- sequential_path (src/path.cpp:25-132) of ONE LM problem as several chunk chains at once.
+//
+// Candidate k of the path starts from candidate k-1's model (src/path.cpp:60-64): one chain of dependent fits whose
+// kernels are single workgroups -- one compute unit of 256 busy between the passes over X that bring new Gram columns.
+// The multi-GPU run cuts the chain into chunks and STITCHES them back into the single chain
+// (bess_amd.dist.StitchedKPath); here the same is done inside one device, on ONE Gram column cache:
+//   1. a coarse warm-start chain over the sparsity levels in front of the chunks (C - 1 fits): it fills the cache with
+//      nearly every column the path will ask for (its fills speculate 64 columns wide) and leaves every chunk the model
+//      it starts from;
+//   2. the C chunks side by side, each on a fit context of its own (stream, host thread, control block, scores, solve
+//      work space) that reads the shared cache.  A chunk that needs a column the cache lacks fills it while every
+//      other chain stands still between two candidates (the rendezvous below): nobody reads the slot map while it is
+//      rewritten;
+//   3. the stitch: chunk r re-fits its first candidates warm from chunk r-1's last model until one coincides with its
+//      own (same support, coefficients to 1e-9) -- from there on the two chains are the same chain -- and replaces what
+//      was walked before; in rounds, until no chunk's last model changed.
+// The candidates returned are the single chain's: same supports, iteration counts and criteria
+// (tests/test_kchunks_gpu.py; at full size tests/test_fullsize_gpu.py).
+#include "bessx_host.h"
+
+namespace bessx {
+
+struct KChains {
+  std::vector<bessx_session *> ctx;
+  FoldPool pool;
+  bool pool_started = false;
+  // the fill rendezvous
+  std::mutex mu;
+  std::condition_variable cv;
+  int running = 0;            // chains that may have kernels in flight
+  bool fill_pending = false;  // a chain holds (or waits for) the right to fill
+  bool abandoned = false;     // a chain failed: nobody waits any longer
+  double deadline_s = 30.0;
+};
+
+// between two candidates of a chunk chain: if another chain waits to fill, drain this chain's stream and stand still
+void kchains_safe_point(bessx_session *c) {
+  KChains *k = c->kch_owner ? c->kch_owner->kch : nullptr;
+  if (!k) return;
+  std::unique_lock<std::mutex> lk(k->mu);
+  if (!k->fill_pending || k->abandoned) return;
+  lk.unlock();
+  (void)hipStreamSynchronize(c->st);  // (the candidate chained ahead runs to its end or parks)
+  lk.lock();
+  k->running--;
+  k->cv.notify_all();
+  k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s), [&] { return !k->fill_pending || k->abandoned; });
+  k->running++;
+}
+
+// a parked chain asks for the cache: returns 0 when it may fill (every other chain stands still), 1 when another chain
+// filled while this one waited (the right is held all the same: look the columns up again), -1 when the run was abandoned
+int kchains_fill_begin(bessx_session *c) {
+  KChains *k = c->kch_owner->kch;
+  std::unique_lock<std::mutex> lk(k->mu);
+  int waited = 0;
+  while (k->fill_pending && !k->abandoned) {  // another chain is filling: this one is quiet (parked, its stream drained)
+    waited = 1;
+    lk.unlock();
+    (void)hipStreamSynchronize(c->st);
+    lk.lock();
+    if (!k->fill_pending) break;
+    k->running--;
+    k->cv.notify_all();
+    k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s), [&] { return !k->fill_pending || k->abandoned; });
+    k->running++;
+  }
+  if (k->abandoned) return -1;
+  k->fill_pending = true;
+  k->running--;
+  const bool ok = k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s),
+                                 [&] { return k->running == 0 || k->abandoned; });
+  k->running++;
+  if (!ok || k->abandoned) {
+    k->abandoned = true;
+    k->fill_pending = false;
+    k->cv.notify_all();
+    return -1;
+  }
+  return waited;
+}
+
+void kchains_fill_end(bessx_session *c) {
+  KChains *k = c->kch_owner->kch;
+  std::lock_guard<std::mutex> lk(k->mu);
+  k->fill_pending = false;
+  k->cv.notify_all();
+}
+
+// (the caller of a round sets `running` to the number of chains the round starts BEFORE any of them runs: a chain that
+// parks at once must not take the others for finished)
+static void kchains_round(KChains *k, int chains) {
+  std::lock_guard<std::mutex> lk(k->mu);
+  k->running = chains;
+  k->fill_pending = false;
+  k->abandoned = false;
+}
+
+static void kchains_leave(KChains *k, bool failed) {
+  std::lock_guard<std::mutex> lk(k->mu);
+  k->running--;
+  if (failed) {
+    k->abandoned = true;
+    k->fill_pending = false;
+  }
+  k->cv.notify_all();
+}
+
+void kchains_free(bessx_session *s) {
+  if (!s || !s->kch) return;
+  KChains *k = s->kch;
+  if (k->pool_started) k->pool.stop();
+  for (bessx_session *c : k->ctx) chain_ctx_free(c);
+  if (!k->pool.broken) delete k;  // (a broken pool's threads may still touch it: leaked on purpose)
+  s->kch = nullptr;
+}
+
+// how many chunk chains for this path (1 = the single chain)
+static int chains_for(const bessx_session *s, int ns) {
+  int C = s->kpath_chains;
+  if (C == 0) {
+    // automatic: long paths on wide designs.  How many chains pay depends on how many hardware queues the HIP runtime
+    // gives the process' streams (GPU_MAX_HW_QUEUES, default 4; read when the runtime starts): configs[1], 18.6 ms as
+    // one chain -- 4 queues: 2 chains 16.2 ms, 3 and more lose (21.2 / 19.5 ms: streams share queues and wait for each
+    // other); 8 queues: 3 chains 14.9 ms, 4 chains 12.7 ms, 6 chains 16.8 ms (tools/kchunks_bench.py)
+    const char *q = std::getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q ? std::atoi(q) : 4;
+    C = (ns >= 96 && s->p >= 2048) ? (queues >= 8 ? 4 : 2) : 1;
+  }
+  return std::max(1, std::min(std::min(C, 8), ns / 8));
+}
+
+bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int is_cv, const bessx_path_chain *chain) {
+  if (!s || s->kch_owner || s->parent || chain || is_cv || nl != 1) return false;
+  if (s->model_type != 1 || !s->cov_mode || s->grouped || !s->warm_start || s->trace.on || s->cv_shared) return false;
+  if (!s->publish || !s->chain || s->fill_hook) return false;
+  if (s->cov_C < (s->p + 31) / 32 * 32 + COV_R) return false;  // the cache must hold every column: it is never started over
+  if (chains_for(s, ns) < 2) return false;
+  int top = 0;
+  for (int i = 0; i < ns; i++) {
+    if (seq[i] < 1 || (i && seq[i] <= seq[i - 1])) return false;  // ascending levels: every chunk continues its predecessor
+    top = std::max(top, seq[i]);
+  }
+  return top <= 254 && top <= s->cap && top + COV_R + s->cov_spec <= s->cov_C;  // (the register-resident solvers)
+}
+
+namespace {
+
+struct ChunkRun {  // one chunk's candidates, as sequential_path stores them
+  int lo = 0, hi = 0, width = 0;
+  std::vector<int> T0, iters, support;
+  std::vector<double> lam, loss, ic, coef0, beta, best_beta;
+  bessx_path_result res = {};
+  bessx_path_chain chain = {};
+  std::vector<int> init_idx, last_idx;
+  std::vector<double> init_val, last_val;
+  double init_coef0 = 0.0, last_coef0 = 0.0;
+  int last_len = 0;
+  int rc = 0;
+  std::string err;  // (the message of a failure on a host thread: bessx_last_error is per thread)
+  long long fits = 0;
+
+  void shape(int lo_, int hi_, int width_, int p_full) {
+    lo = lo_;
+    hi = hi_;
+    width = width_;
+    const size_t m = (size_t)std::max(1, hi - lo);
+    T0.assign(m, 0);
+    iters.assign(m, 0);
+    lam.assign(m, 0.0);
+    loss.assign(m, 0.0);
+    ic.assign(m, 0.0);
+    coef0.assign(m, 0.0);
+    support.assign(m * width, -1);
+    beta.assign(m * width, 0.0);
+    best_beta.assign((size_t)p_full, 0.0);
+    last_idx.assign((size_t)width, 0);
+    last_val.assign((size_t)width, 0.0);
+  }
+  void bind(bessx_path_result *r) {
+    *r = bessx_path_result();
+    r->beta = best_beta.data();
+    r->capacity = hi - lo;
+    r->cand_T0 = T0.data();
+    r->cand_lambda = lam.data();
+    r->cand_iters = iters.data();
+    r->cand_train_loss = loss.data();
+    r->cand_ic = ic.data();
+    r->cand_coef0 = coef0.data();
+    r->cand_support = support.data();
+    r->cand_beta = beta.data();
+    r->max_T0 = width;
+  }
+};
+
+// the context's own state starts over (the shared cache stays as it is)
+int context_begin(bessx_session *c) {
+  if (int rc = settle_device_chain(c)) return rc;
+  for (auto &q : c->cache) q.valid = false;
+  c->dev_state_rs = -1;
+  c->trace.clear();
+  c->metric_depth = 0;
+  c->n_fits = 0;
+  c->n_iters = 0;
+  return 0;
+}
+
+}  // namespace
+
+int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type,
+                            bessx_path_result *res) {
+  const int C = chains_for(s, ns);
+  HIPX(hipSetDevice(s->device));
+  if (!s->kch) s->kch = new KChains();
+  KChains *k = s->kch;
+  k->deadline_s = s->wait_deadline_s;
+  while ((int)k->ctx.size() < C) {
+    bessx_session *c = nullptr;
+    if (int rc = chain_ctx_create(s, &c)) return rc;
+    k->ctx.push_back(c);
+  }
+  if (!k->pool_started) {
+    k->pool.start(7, s->device);  // (up to 8 chains: the caller is one of them)
+    k->pool_started = true;
+  }
+  if (k->pool.broken) return fail(BESSX_ERR_HIP, "chunk chains: the host threads did not come back from an earlier call");
+  // chunk r = candidates [bounds[r], bounds[r + 1]); later chunks are shorter: a candidate costs more the larger its
+  // level (larger solves), and the last chunk also runs the longest stitch
+  std::vector<int> bounds((size_t)C + 1, 0);
+  {
+    double tot = 0.0;
+    std::vector<double> cum((size_t)ns + 1, 0.0);
+    for (int i = 0; i < ns; i++) {
+      tot += 1.0 + (double)seq[i] / 160.0;
+      cum[(size_t)i + 1] = tot;
+    }
+    for (int r = 1; r < C; r++) {
+      int b = (int)(std::lower_bound(cum.begin(), cum.end(), tot * r / C) - cum.begin());
+      bounds[r] = std::min(std::max(b, bounds[r - 1] + 1), ns - (C - r));
+    }
+    bounds[C] = ns;
+  }
+  const int width = res->max_T0 > 0 ? res->max_T0 : seq[ns - 1];
+  // ---- 1. the coarse chain on the session's own state (the caller has just started the caches over)
+  std::vector<ChunkRun> run((size_t)C);
+  {
+    SparseVec init;
+    double c0 = 0.0;
+    s->hint.on = false;
+    for (int r = 1; r < C; r++) {
+      if (int rc = run_fit(s, seq[bounds[r] - 1], lambda, init, c0)) return rc;
+      init = s->beta;
+      c0 = s->coef0;
+      run[r].init_idx = init.idx;
+      run[r].init_val = init.val;
+      run[r].init_coef0 = c0;
+    }
+    if (int rc = settle_device_chain(s)) return rc;
+    HIPX(hipStreamSynchronize(s->st));  // the cache is complete before any chunk chain reads it
+  }
+  const long long coarse_fits = s->n_fits;
+  // ---- 2. the chunks side by side
+  kchains_round(k, C);
+  for (int r = 0; r < C; r++) run[r].shape(bounds[r], bounds[r + 1], width, s->p_full);
+  auto chunk_job = [&](int r) {
+    if (r >= C) return;
+    bessx_session *c = k->ctx[r];
+    ChunkRun &q = run[r];
+    q.rc = hipSetDevice(s->device) == hipSuccess ? context_begin(c) : fail(BESSX_ERR_HIP, "hipSetDevice");
+    c->timing = s->timing;  // (its fills count in the session's score-pass statistics)
+    if (q.rc == 0) {
+      q.bind(&q.res);
+      q.chain = bessx_path_chain();
+      q.chain.init_idx = q.init_idx.data();
+      q.chain.init_val = q.init_val.data();
+      q.chain.init_len = (int)q.init_idx.size();
+      q.chain.init_coef0 = q.init_coef0;
+      q.chain.keep_caches = 1;
+      q.chain.last_idx = q.last_idx.data();
+      q.chain.last_val = q.last_val.data();
+      q.chain.last_cap = width;
+      q.rc = sequential_path(c, seq + q.lo, q.hi - q.lo, &lambda, 1, ic_type, 0, &q.res, &q.chain);
+      q.last_len = q.chain.last_len;
+      q.last_coef0 = q.chain.last_coef0;
+      q.fits += c->n_fits;
+    }
+    if (q.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) q.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
+    if (q.rc) q.err = g_err;
+    kchains_leave(k, q.rc != 0);
+  };
+  if (!k->pool.run(chunk_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
+  for (int r = 0; r < C; r++)
+    if (run[r].rc) return fail(run[r].rc, "chunk chain: " + run[r].err);
+  // ---- 3. the stitch, in rounds until no chunk's last model changed (bess_amd.dist.StitchedKPath.step)
+  std::vector<char> need((size_t)C, 1), changed((size_t)C, 0);
+  need[0] = 0;
+  long long refits = 0;
+  for (int round = 1;; round++) {
+    std::vector<ChunkRun> st((size_t)C);
+    std::vector<std::vector<int>> pred_idx((size_t)C);
+    std::vector<std::vector<double>> pred_val((size_t)C);
+    std::vector<double> pred_c0((size_t)C, 0.0);
+    for (int r = 1; r < C; r++)
+      if (need[r]) {  // the predecessor's last model as it stands before this round
+        pred_idx[r].assign(run[r - 1].last_idx.begin(), run[r - 1].last_idx.begin() + run[r - 1].last_len);
+        pred_val[r].assign(run[r - 1].last_val.begin(), run[r - 1].last_val.begin() + run[r - 1].last_len);
+        pred_c0[r] = run[r - 1].last_coef0;
+      }
+    auto stitch_job = [&](int r) {
+      if (r >= C || !need[r]) return;
+      bessx_session *c = k->ctx[r];
+      ChunkRun &q = run[r], &t = st[r];
+      t.shape(q.lo, q.hi, width, s->p_full);
+      t.bind(&t.res);
+      t.chain = bessx_path_chain();
+      t.chain.init_idx = pred_idx[r].data();
+      t.chain.init_val = pred_val[r].data();
+      t.chain.init_len = (int)pred_idx[r].size();
+      t.chain.init_coef0 = pred_c0[r];
+      t.chain.keep_caches = 1;
+      t.chain.stop_support = q.support.data();
+      t.chain.stop_beta = q.beta.data();
+      t.chain.stop_rows = q.hi - q.lo;
+      t.chain.stop_row_len = width;
+      t.chain.stop_rtol = 1e-9;
+      t.chain.last_idx = t.last_idx.data();
+      t.chain.last_val = t.last_val.data();
+      t.chain.last_cap = width;
+      t.rc = hipSetDevice(s->device) == hipSuccess ? context_begin(c) : fail(BESSX_ERR_HIP, "hipSetDevice");
+      c->timing = s->timing;
+      if (t.rc == 0) t.rc = sequential_path(c, seq + q.lo, q.hi - q.lo, &lambda, 1, ic_type, 0, &t.res, &t.chain);
+      if (t.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) t.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
+      if (t.rc) t.err = g_err;
+      t.fits = c->n_fits;
+      kchains_leave(k, t.rc != 0);
+    };
+    {
+      int active = 0;
+      for (int r = 1; r < C; r++) active += need[r] ? 1 : 0;
+      kchains_round(k, active);
+    }
+    if (!k->pool.run(stitch_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
+    bool any = false;
+    for (int r = 1; r < C; r++) {
+      changed[r] = 0;
+      if (!need[r]) continue;
+      ChunkRun &q = run[r], &t = st[r];
+      if (t.rc) return fail(t.rc, "chunk chain (stitch): " + t.err);
+      const int m = std::min(t.res.n_candidates, q.hi - q.lo);
+      for (int i = 0; i < m; i++) {  // what was walked before the merge point is replaced
+        q.T0[i] = t.T0[i];
+        q.iters[i] = t.iters[i];
+        q.lam[i] = t.lam[i];
+        q.loss[i] = t.loss[i];
+        q.ic[i] = t.ic[i];
+        q.coef0[i] = t.coef0[i];
+        std::copy(t.support.begin() + (size_t)i * width, t.support.begin() + (size_t)(i + 1) * width,
+                  q.support.begin() + (size_t)i * width);
+        std::copy(t.beta.begin() + (size_t)i * width, t.beta.begin() + (size_t)(i + 1) * width,
+                  q.beta.begin() + (size_t)i * width);
+      }
+      refits += m;
+      q.fits += t.fits;
+      if (t.chain.stopped_at < 0) {  // the whole chunk was replaced: its last model is a new one
+        changed[r] = 1;
+        any = true;
+        q.last_idx = t.last_idx;
+        q.last_val = t.last_val;
+        q.last_len = t.chain.last_len;
+        q.last_coef0 = t.chain.last_coef0;
+      }
+    }
+    if (!any) break;
+    if (round > C) return fail(BESSX_ERR_NUMERIC, "chunk chains: the stitching did not settle");
+    for (int r = 1; r < C; r++) need[r] = changed[r - 1];
+  }
+  // ---- the path's result: the candidates in order, the best of them by the criterion (first minimum, :113)
+  res->n_candidates = 0;
+  int best_r = 0, best_i = 0;
+  long long iters_path = 0, fits_all = coarse_fits;
+  for (int r = 0; r < C; r++) {
+    const ChunkRun &q = run[r];
+    fits_all += q.fits;
+    for (int i = 0; i < q.hi - q.lo; i++) {
+      const int g = res->n_candidates++;
+      iters_path += q.iters[i];
+      if (q.ic[i] < run[best_r].ic[best_i]) {
+        best_r = r;
+        best_i = i;
+      }
+      if (g >= res->capacity) continue;
+      if (res->cand_T0) res->cand_T0[g] = q.T0[i];
+      if (res->cand_lambda) res->cand_lambda[g] = q.lam[i];
+      if (res->cand_iters) res->cand_iters[g] = q.iters[i];
+      if (res->cand_train_loss) res->cand_train_loss[g] = q.loss[i];
+      if (res->cand_ic) res->cand_ic[g] = q.ic[i];
+      if (res->cand_coef0) res->cand_coef0[g] = q.coef0[i];
+      for (int j = 0; j < res->max_T0; j++) {
+        if (res->cand_support) res->cand_support[(size_t)g * res->max_T0 + j] = j < width ? q.support[(size_t)i * width + j] : -1;
+        if (res->cand_beta) res->cand_beta[(size_t)g * res->max_T0 + j] = j < width ? q.beta[(size_t)i * width + j] : 0.0;
+      }
+    }
+  }
+  {
+    const ChunkRun &q = run[best_r];
+    if (res->beta) {
+      std::fill(res->beta, res->beta + s->p_full, 0.0);
+      for (int j = 0; j < width; j++) {
+        const int col = q.support[(size_t)best_i * width + j];
+        if (col >= 0) res->beta[col] = q.beta[(size_t)best_i * width + j];
+      }
+    }
+    res->coef0 = q.coef0[best_i];
+    res->train_loss = q.loss[best_i];
+    res->ic = q.ic[best_i];
+    res->lambda = q.lam[best_i];
+    res->best_T0 = q.T0[best_i];
+    res->best_iters = q.iters[best_i];
+  }
+  for (bessx_session *c : k->ctx) {  // statistics of the contexts belong to the session
+    s->cov_panel_groups += c->cov_panel_groups;
+    s->cov_cg_fallbacks += c->cov_cg_fallbacks;
+    s->cov_tie_rescues += c->cov_tie_rescues;
+    s->chain_queued += c->chain_queued;
+    s->chain_hits += c->chain_hits;
+    c->cov_panel_groups = c->cov_cg_fallbacks = c->cov_tie_rescues = 0;
+    c->chain_queued = c->chain_hits = 0;
+    s->k1_seconds += c->k1_seconds;
+    s->k1_bytes += c->k1_bytes;
+    s->k1_launches += c->k1_launches;
+    c->k1_seconds = c->k1_bytes = 0.0;
+    c->k1_launches = 0;
+  }
+  // fits and get_A calls as the single chain counts them; the work really done (coarse chain, replaced candidates) is in
+  // bessx_session_counter 14-16
+  (void)fits_all;
+  s->n_fits = ns;
+  s->n_iters = iters_path;
+  s->kch_paths++;
+  s->kch_refits += refits;
+  // the session's own device state is the coarse chain's last fit, not the path's last candidate
+  for (auto &q : s->cache) q.valid = false;
+  s->dev_state_rs = -1;
+  // Algorithm state as the path leaves it: the last candidate's model (normalised scale)
+  {
+    const ChunkRun &q = run[C - 1];
+    s->beta.idx.assign(q.last_idx.begin(), q.last_idx.begin() + q.last_len);
+    s->beta.val.assign(q.last_val.begin(), q.last_val.begin() + q.last_len);
+    s->coef0 = q.last_coef0;
+  }
+  return 0;
+}
+
+}  // namespace bessx

@@ -145,6 +145,7 @@ int sequential_path(bessx_session *s, const int *seq, int ns, const double *lam,
       if (int rc = metric_train_loss(s, &c.loss)) return rc;
       if (int rc = metric_ic(s, ic_type, is_cv, &c.ic)) return rc;
       store_candidate(s, res, c, false);
+      if (s->kch_owner) kchains_safe_point(s);
       if (chain && chain_row_matches(s, chain, res->n_candidates - 1, c)) {
         // from here on the chain the caller already holds IS this chain: same model, same successor
         chain->stopped_at = res->n_candidates - 1;
@@ -614,7 +615,8 @@ int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *la
   if (int rc0 = (chain && chain->keep_caches) ? settle_device_chain(s) : reset_path_caches(s)) return rc0;
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
-                : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res, chain);
+           : kchunks_apply(s, seq, ns, nl, is_cv, chain) ? sequential_path_chunked(s, seq, ns, lam[0], ic_type, res)
+                                                         : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res, chain);
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
   res->n_fits = s->n_fits;

@@ -49,6 +49,7 @@ void session_free(bessx_session *s) {
                  "wait %.2f, fill %.2f, continue %.2f, results %.2f\n", s->cv_rounds, s->cv_union_fills, s->sbs_t[0] * 1e3,
                  s->sbs_t[1] * 1e3, s->sbs_t[2] * 1e3, s->sbs_t[3] * 1e3, s->sbs_t[4] * 1e3, s->sbs_t[5] * 1e3);
   drop_fold_contexts(s);
+  kchains_free(s);
   if (std::getenv("BESSX_DEBUG"))
     std::fprintf(stderr, "[bessx] chained fits: queued %lld, used %lld, not started %lld, mismatched %lld; "
                  "CG solves handed to Cholesky: %lld; waits for a published block: %lld, of which the block was "
@@ -909,6 +910,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     if (const char *ev = test_hook("publish")) s->publish = std::atoi(ev) != 0;
     if (const char *ev = std::getenv("BESSX_WAIT_TIMEOUT_S")) s->wait_deadline_s = std::max(0.001, std::atof(ev));
     if (const char *ev = test_hook("chain")) s->chain = std::atoi(ev) != 0;
+    if (const char *ev = std::getenv("BESSX_KPATH_CHAINS")) s->kpath_chains = std::max(0, std::atoi(ev));
     if (!s->publish) s->chain = false;
     HIPT(hipHostMalloc(reinterpret_cast<void **>(&s->stage_h), (size_t)capA * (sizeof(int) + sizeof(double))));
   }
@@ -1312,6 +1314,59 @@ static int fold_ctx_create(bessx_session *ps, int rs, bessx_session **out) {
   return 0;
 }
 
+// A chunk chain's fit context (bessx_session::kch): a fold context of the ALL-ROWS row set that runs the parent's whole
+// fast path -- results handed over by k_publish, the next candidate chained on the device -- on the parent's cache.
+// Beyond a fold context it owns the second result buffer, the snapshots of the deferred publication and the per-row-set
+// vectors a fit of row set 0 writes (d, the residual, the work vector of the loss fallback).
+}  // extern "C"
+namespace bessx {
+int chain_ctx_create(bessx_session *ps, bessx_session **out) {
+  bessx_session *c = nullptr;
+  if (int rc = fold_ctx_create(ps, 0, &c)) return rc;
+  c->kch_owner = ps;
+  c->kch = nullptr;
+  c->publish = ps->publish;
+  c->chain = ps->chain;
+  c->defer_pub = ps->defer_pub;
+  c->cov_no_restart = true;  // (the cache holds every column: never needed; and nobody rewrites the map under the others)
+  c->fill_hook = nullptr;
+  c->tmpv = nullptr;
+  c->part_rs[0] = nullptr;
+  c->r_rs[0] = nullptr;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&c->res_buf[1]), ps->res_bytes);
+  if (e == hipSuccess) std::memset(c->res_buf[1], 0, ps->res_bytes);
+  for (int b = 0; b < 2 && e == hipSuccess; b++) {
+    e = hipMalloc(reinterpret_cast<void **>(&c->snap[b]), ps->res_bytes + 64);
+    if (e == hipSuccess) e = hipMemset(c->snap[b], 0, ps->res_bytes + 64);
+  }
+  if (e == hipSuccess) e = dmalloc(&c->tmpv, (size_t)ps->ld);
+  if (e == hipSuccess) e = dmalloc(&c->part_rs[0], part_elems(ps));
+  if (e == hipSuccess) e = dmalloc(&c->r_rs[0], (size_t)ps->ld);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    chain_ctx_free(c);
+    return fail(BESSX_ERR_HIP, std::string("chunk chain context: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return 0;
+}
+
+void chain_ctx_free(bessx_session *c) {
+  if (!c) return;
+  if (c->st) (void)hipStreamSynchronize(c->st);
+  if (c->res_buf[1]) (void)hipHostFree(c->res_buf[1]);
+  for (int b = 0; b < 2; b++)
+    if (c->snap[b]) (void)hipFree(c->snap[b]);
+  if (c->tmpv) (void)hipFree(c->tmpv);
+  if (c->part_rs[0]) (void)hipFree(c->part_rs[0]);
+  if (c->r_rs[0]) (void)hipFree(c->r_rs[0]);
+  c->res_buf[1] = nullptr;
+  c->snap[0] = c->snap[1] = nullptr;
+  fold_ctx_free(c);
+}
+}  // namespace bessx
+extern "C" {
+
 int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned seed) {
   if (!s || K < 2 || K > s->n) return fail(BESSX_ERR_ARG, "set_cv: bad arguments");
   HIPX(hipSetDevice(s->device));
@@ -1606,6 +1661,9 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 11: return s->cv_ctx_dropped;
     case 12: return (long long)s->fold_ctx.size();
     case 13: return s->shared_wide_fills;
+    case 14: return s->kch_paths;
+    case 15: return s->kch_refits;
+    case 16: return s->kch_chunk_fills;
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -1,0 +1,125 @@
+"""sequential_path of one LM problem as several chunk chains side by side on ONE Gram column cache
+(bess_amd/csrc/bessx_kchunks.cpp; BESSX_KPATH_CHAINS): a coarse chain over the chunk boundaries, the chunks on fit
+contexts of their own, fills of the shared cache while every other chain stands still, the stitch of
+bess_amd.dist.StitchedKPath inside the library.  The path returned is the single warm-start chain's (src/path.cpp:60-64):
+every candidate's support, iteration count, criterion and coefficients."""
+import numpy as np
+import pytest
+
+from bess_amd import synth
+from oracle import port_ctypes as P
+from test_stitch_gpu import _hard
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_path(a, b, beta_rtol=1e-8):
+    np.testing.assert_array_equal(a["cand_support"], b["cand_support"])
+    np.testing.assert_array_equal(a["cand_iters"], b["cand_iters"])
+    np.testing.assert_array_equal(a["cand_T0"], b["cand_T0"])
+    # (the loss of a near-perfect fit is a difference of large numbers, |y|^2 - beta.(X^T y): 1e-9 of the criterion)
+    np.testing.assert_allclose(a["cand_ic"], b["cand_ic"], rtol=1e-9)
+    np.testing.assert_allclose(a["cand_train_loss"], b["cand_train_loss"], rtol=1e-7)
+    np.testing.assert_allclose(a["cand_beta"], b["cand_beta"], rtol=beta_rtol, atol=1e-12)
+    np.testing.assert_allclose(a["cand_coef0"], b["cand_coef0"], rtol=1e-9, atol=1e-12)
+    assert a["best_T0"] == b["best_T0"] and a["n_candidates"] == b["n_candidates"]
+    assert a["n_fits"] == b["n_fits"] and a["n_pdas_iters"] == b["n_pdas_iters"]
+    np.testing.assert_allclose(a["beta"], b["beta"], rtol=beta_rtol, atol=1e-12)
+    np.testing.assert_allclose([a["coef0"], a["ic"], a["train_loss"]], [b["coef0"], b["ic"], b["train_loss"]], rtol=1e-7)
+
+
+@pytest.mark.parametrize("chains", [2, 3, 4, 8])
+def test_chunk_chains_return_the_single_chain(gpu, monkeypatch, chains):
+    X, y, _, _ = synth.make_lm(2500, 700, 20, seed=11)
+    seq = np.arange(1, 65)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        assert s.counters()["kpath_chunked_paths"] == 0
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+    with gpu.Session(X, y) as s:
+        first = s.sequential_path(seq, ic_type=3)
+        cnt = s.counters()
+        assert cnt["kpath_chunked_paths"] == 1 and cnt["kpath_stitch_refits"] >= chains - 1
+        again = s.sequential_path(seq, ic_type=3)          # the contexts and host threads are kept
+        odd = s.sequential_path(seq[::2], ic_type=2)       # levels that are not consecutive
+        lam = s.sequential_path(seq, [0.0, 0.1], ic_type=3)  # two lambdas: the snake order, not chunked
+        gs = s.gs_path(1, 40, ic_type=3)
+        assert s.counters()["kpath_chunked_paths"] == 3
+    _same_path(first, single)
+    _same_path(again, single)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y) as s:
+        _same_path(odd, s.sequential_path(seq[::2], ic_type=2))
+        _same_path(lam, s.sequential_path(seq, [0.0, 0.1], ic_type=3))
+        want_gs = s.gs_path(1, 40, ic_type=3)
+    np.testing.assert_array_equal(gs["cand_support"], want_gs["cand_support"])
+    want = P.trace(X, y, ic_type=3, sequence=seq)
+    np.testing.assert_allclose(first["cand_ic"], want["ic_calls"], rtol=1e-8)
+    assert list(first["cand_iters"]) == [len(f["iters"]) for f in want["fits"]]
+
+
+def test_chunk_chains_on_a_design_where_cold_chunks_go_astray(gpu, monkeypatch):
+    """Correlated columns, weak signal: chunks started from the coarse chain's models land in other local fixed points
+    than the warm chain -- the stitch replaces whole runs of candidates, in more than one round."""
+    X, y, kw = _hard("lm", 1200, 400)
+    seq = np.arange(1, 49)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y, score_mode=2, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+    for chains in (3, 6):
+        monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+        with gpu.Session(X, y, score_mode=2, **kw) as s:
+            got = s.sequential_path(seq, ic_type=3)
+            assert s.counters()["kpath_chunked_paths"] == 1
+            refits = s.counters()["kpath_stitch_refits"]
+        np.testing.assert_array_equal(got["cand_support"], single["cand_support"])
+        np.testing.assert_allclose(got["cand_ic"], single["cand_ic"], rtol=1e-10)
+        assert got["best_T0"] == single["best_T0"]
+        assert refits >= chains - 1
+
+
+def test_chunk_chains_fill_the_shared_cache_one_at_a_time(gpu, monkeypatch):
+    """Many chunks on a design whose coarse chain leaves columns uncached: chunk chains park, wait for the others to
+    stand still, fill, and the path is still the single chain's.  Also after a CV path and single fits on the session."""
+    X, y, _, _ = synth.make_lm(3000, 1500, 60, seed=5)
+    seq = np.arange(1, 129)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y) as s:
+        single = s.sequential_path(seq, ic_type=3)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "8")
+    with gpu.Session(X, y) as s:
+        s.set_cv(3, synth.make_cv_folds(3000, 3, seed=4))
+        cv = s.sequential_path(np.arange(1, 9), ic_type=3, is_cv=True)   # (CV paths are not chunked)
+        one = s.fit(17)
+        for _ in range(3):
+            got = s.sequential_path(seq, ic_type=3)
+            _same_path(got, single)
+        cnt = s.counters()
+    assert len(one["support"]) == 17 and cv["n_candidates"] == 8
+    # (a session with CV folds shares its fills with the folds' caches: no chunk chains there)
+    assert cnt["kpath_chunked_paths"] == 0
+    with gpu.Session(X, y) as s:
+        for _ in range(3):
+            _same_path(s.sequential_path(seq, ic_type=3), single)
+        cnt = s.counters()
+    assert cnt["kpath_chunked_paths"] == 3
+    assert cnt["kpath_chunk_fills"] >= 0
+
+
+def test_no_chunk_chains_where_they_do_not_apply(gpu, monkeypatch):
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "4")
+    X, y, _, _ = synth.make_lm(1500, 300, 10, seed=2)
+    seq = np.arange(1, 41)
+    with gpu.Session(X, y, score_mode=1) as s:  # streaming form
+        s.sequential_path(seq, ic_type=3)
+        assert s.counters()["kpath_chunked_paths"] == 0
+    with gpu.Session(X, y, is_warm_start=False) as s:
+        s.sequential_path(seq, ic_type=3)
+        assert s.counters()["kpath_chunked_paths"] == 0
+    with gpu.Session(X, y) as s:
+        s.sequential_path(seq[::-1].copy(), ic_type=3)  # descending levels
+        s.sequential_path(seq[:12], ic_type=3)          # too short for 4 chunks of 8
+        assert s.counters()["kpath_chunked_paths"] == 0
+        s.sequential_path(seq, ic_type=3)
+        assert s.counters()["kpath_chunked_paths"] == 1
