@@ -841,6 +841,36 @@ def main():
         if chunk_report:
             line["kpath_chunks_vs_single_chain"] = chunk_report
         norm = sess.normalization() if world == 1 else None
+        cnt = sess.counters() if world == 1 else {}
+        if world == 1 and cnt.get("kpath_chunked_paths", 0) > 0:
+            # the path ran as chunk chains side by side on one Gram column cache, stitched into the single warm-start chain
+            # (bessx_kchunks.cpp); the same path as ONE chain on a second session, timed the same way, beside it
+            runs = float(cnt["kpath_chunked_paths"])
+            os.environ["BESSX_KPATH_CHAINS"] = "1"
+            s1 = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
+                              score_mode=mode, device=local_rank)
+            del os.environ["BESSX_KPATH_CHAINS"]
+            for _ in range(2):
+                s1.sequential_path(seq, ic_type=3)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for _ in range(5):
+                o1 = s1.sequential_path(seq, ic_type=3)
+            torch.cuda.synchronize()
+            d1 = (time.time() - t1) / 5
+            s1.close()
+            line["chunk_chains"] = {
+                "chains": cnt["kpath_chains_last_path"], "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "stitch_refits_per_path": cnt["kpath_stitch_refits"] / runs,
+                "fills_in_the_chunk_phase_per_path": cnt["kpath_chunk_fills"] / runs,
+                "single_chain": {"value": len(seq) / d1, "unit": "candidates/s", "ms_per_path": 1e3 * d1},
+                "same_candidates_as_the_single_chain": bool(
+                    np.array_equal(o1["cand_support"], out["cand_support"]) and
+                    np.array_equal(o1["cand_iters"], out["cand_iters"]) and
+                    np.allclose(o1["cand_ic"], out["cand_ic"], rtol=1e-9, atol=0.0)),
+                "what": "a coarse warm-start chain over the chunk boundaries fills the cache and starts every chunk; the "
+                        "chunks run side by side on fit contexts of their own (a stream and a host thread each), fills "
+                        "of the shared cache while every other chain stands still; stitched like the multi-GPU k-path"}
         if covariance and world == 1 and not args.no_streaming_leg and not cox:
             # the other evaluation of the same path (every PDAS iteration reads X once), for comparison
             sess.close()

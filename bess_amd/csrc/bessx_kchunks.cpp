@@ -241,6 +241,11 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     bounds[C] = ns;
   }
   const int width = res->max_T0 > 0 ? res->max_T0 : seq[ns - 1];
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
+  const auto t_begin = now();
   // ---- 1. the coarse chain on the session's own state (the caller has just started the caches over)
   std::vector<ChunkRun> run((size_t)C);
   {
@@ -259,6 +264,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     HIPX(hipStreamSynchronize(s->st));  // the cache is complete before any chunk chain reads it
   }
   const long long coarse_fits = s->n_fits;
+  const auto t_coarse = now();
   // ---- 2. the chunks side by side
   kchains_round(k, C);
   for (int r = 0; r < C; r++) run[r].shape(bounds[r], bounds[r + 1], width, s->p_full);
@@ -291,6 +297,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   if (!k->pool.run(chunk_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
   for (int r = 0; r < C; r++)
     if (run[r].rc) return fail(run[r].rc, "chunk chain: " + run[r].err);
+  const auto t_chunks = now();
   // ---- 3. the stitch, in rounds until no chunk's last model changed (bess_amd.dist.StitchedKPath.step)
   std::vector<char> need((size_t)C, 1), changed((size_t)C, 0);
   need[0] = 0;
@@ -374,6 +381,9 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     if (round > C) return fail(BESSX_ERR_NUMERIC, "chunk chains: the stitching did not settle");
     for (int r = 1; r < C; r++) need[r] = changed[r - 1];
   }
+  s->kch_t[0] += secs(t_begin, t_coarse);
+  s->kch_t[1] += secs(t_coarse, t_chunks);
+  s->kch_t[2] += secs(t_chunks, now());
   // ---- the path's result: the candidates in order, the best of them by the criterion (first minimum, :113)
   res->n_candidates = 0;
   int best_r = 0, best_i = 0;
@@ -437,6 +447,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   s->n_fits = ns;
   s->n_iters = iters_path;
   s->kch_paths++;
+  s->kch_last_chains = C;
   s->kch_refits += refits;
   // the session's own device state is the coarse chain's last fit, not the path's last candidate
   for (auto &q : s->cache) q.valid = false;

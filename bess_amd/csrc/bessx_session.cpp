@@ -49,6 +49,10 @@ void session_free(bessx_session *s) {
                  "wait %.2f, fill %.2f, continue %.2f, results %.2f\n", s->cv_rounds, s->cv_union_fills, s->sbs_t[0] * 1e3,
                  s->sbs_t[1] * 1e3, s->sbs_t[2] * 1e3, s->sbs_t[3] * 1e3, s->sbs_t[4] * 1e3, s->sbs_t[5] * 1e3);
   drop_fold_contexts(s);
+  if (std::getenv("BESSX_DEBUG") && s->kch_paths)
+    std::fprintf(stderr, "[bessx] chunk chains: %lld paths, %lld stitch refits, %lld fills in the chunk phase; ms per path in "
+                 "the coarse chain %.2f, the chunks %.2f, the stitch %.2f\n", s->kch_paths, s->kch_refits, s->kch_chunk_fills,
+                 1e3 * s->kch_t[0] / s->kch_paths, 1e3 * s->kch_t[1] / s->kch_paths, 1e3 * s->kch_t[2] / s->kch_paths);
   kchains_free(s);
   if (std::getenv("BESSX_DEBUG"))
     std::fprintf(stderr, "[bessx] chained fits: queued %lld, used %lld, not started %lld, mismatched %lld; "
@@ -1664,6 +1668,7 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 14: return s->kch_paths;
     case 15: return s->kch_refits;
     case 16: return s->kch_chunk_fills;
+    case 17: return s->kch_last_chains;
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
