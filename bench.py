@@ -675,7 +675,11 @@ def main():
         prefill = max(0, min(prefill, (args.p // 64) * 32, 1024)) // 32 * 32
         if not prefill and not (pilot and len(pilot) > 2):
             pilot = None
+    any_ladder = False
     if kpath:
+        k0_last = int(full_seq[bdist.partition(args.kmax, world, world - 1)[0]]) if args.kmax >= world else 0
+        any_ladder = args.chunk_start == "ladder" or (args.chunk_start == "auto" and k0_last >= 128 and not cox
+                                                      and not prefill)
         if args.chunk_start == "auto":
             # measured on configs[1], 8 chunks on one GPU (tools/coldstart.py, tools/coop_prefill.py, profiles/r04_*):
             # without the prefill the ladder saves Gram-column passes at large k0 (11.5 vs 12.5 ms for the slowest chunk),
@@ -684,7 +688,9 @@ def main():
             args.chunk_start = "ladder" if (k0 >= 128 and not cox and not prefill) else "cold"
         if args.chunk_start == "ladder" and lo > 0:
             lead = sorted({k for k in (k0 // 8, k0 // 4, k0 // 2) if 1 <= k < k0})
-    rebalance = kpath and not lead and (args.rebalance == "on" or (args.rebalance == "auto" and world <= 4 and not cox))
+    # (the same decision on every rank: a ladder start anywhere rules the moving boundaries out)
+    rebalance = kpath and not any_ladder and (args.rebalance == "on" or
+                                              (args.rebalance == "auto" and world <= 4 and not cox))
     stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev,
                                    prefill=prefill, pilot=pilot, rebalance=rebalance) if kpath else None
     for _ in range(args.warmup):

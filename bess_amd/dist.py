@@ -243,7 +243,10 @@ class StitchedKPath:
         # rebalance: after every step the chunk boundaries move towards equal chunk + stitch time per rank
         # (rebalance_bounds on the all-gathered times of that step: the same new boundaries on every rank).  Where a
         # chunk starts changes nothing in the stitched path.  Not with a ladder start (its rungs are tied to k0).
-        self.rebalance = bool(rebalance) and self.lead.size == 0 and self.world > 1
+        # (every rank must decide alike: the flag is the caller's; a ladder on ANY rank rules it out)
+        if rebalance and len(lead):
+            raise ValueError("StitchedKPath: rebalance moves the chunk boundaries, a ladder start is tied to them")
+        self.rebalance = bool(rebalance) and self.world > 1
         self.comm = comm if comm is not None else (_TorchComm(device) if world > 1 else _NoComm())
         self.stop_rtol = stop_rtol
         self.prefill = int(prefill)  # columns of the cooperative prefill in front of the chunks (0: replicas only)
