@@ -362,6 +362,7 @@ struct bessx_session {
   // (stream, control block, scores, solve work space) that READS the one cache of the all-rows row set; a chain that
   // needs a column the cache lacks fills it while every other chain stands still (KChains: safe points between
   // candidates); the chunks are stitched into the single chain exactly as bess_amd.dist.StitchedKPath does it.
+  std::vector<void *> ctx_allocs;       // chain context: device buffers it owns beyond a fold context's
   bessx::KChains *kch = nullptr;        // parent: contexts, host threads, the fill rendezvous (created at first use)
   bessx_session *kch_owner = nullptr;   // chain context: the session whose cache it reads
   int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
@@ -515,6 +516,7 @@ void kchains_safe_point(bessx_session *c);   // chain context, between candidate
 int kchains_fill_begin(bessx_session *c);    // chain context parked on missing columns: wait until it alone runs
 void kchains_fill_end(bessx_session *c);
 void kchains_free(bessx_session *s);
+hipError_t cox_alloc(bessx_session *s);                        // bessx_session.cpp
 int chain_ctx_create(bessx_session *ps, bessx_session **out);  // bessx_session.cpp
 void chain_ctx_free(bessx_session *c);
 int prefill_begin(bessx_session *s, const int *cols, int ncols, int append);  // bessx_paths.cpp

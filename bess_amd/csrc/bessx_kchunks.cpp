@@ -125,23 +125,33 @@ static int chains_for(const bessx_session *s, int ns) {
     // other); 8 queues: 3 chains 14.9 ms, 4 chains 12.7 ms, 6 chains 16.8 ms (tools/kchunks_bench.py)
     const char *q = std::getenv("GPU_MAX_HW_QUEUES");
     const int queues = q ? std::atoi(q) : 4;
-    C = (ns >= 96 && s->p >= 2048) ? (queues >= 8 ? 4 : 2) : 1;
+    if (s->model_type == 1)
+      C = (ns >= 96 && s->p >= 2048) ? (queues >= 8 ? 4 : 2) : 1;
+    else
+      // logistic / Poisson / Cox: one chain's IRLS or Newton steps (small kernels) run beside another's pass over X
+      // (tools/glm_two_chains_probe.py: logistic at full size 155 -> 120 ms with 3 chains, Cox 1.86 -> 1.60 s)
+      C = (ns >= 48 && (double)s->n * s->p >= 1e8) ? (queues >= 8 ? 3 : 2) : 1;
   }
   return std::max(1, std::min(std::min(C, 8), ns / 8));
 }
 
 bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int is_cv, const bessx_path_chain *chain) {
   if (!s || s->kch_owner || s->parent || chain || is_cv || nl != 1) return false;
-  if (s->model_type != 1 || !s->cov_mode || s->grouped || !s->warm_start || s->trace.on || s->cv_shared) return false;
-  if (!s->publish || !s->chain || s->fill_hook) return false;
-  if (s->cov_C < (s->p + 31) / 32 * 32 + COV_R) return false;  // the cache must hold every column: it is never started over
+  if (s->grouped || !s->warm_start || s->trace.on || s->cv_shared || !s->publish || s->fill_hook) return false;
+  if (s->model_type == 1) {
+    if (!s->cov_mode || !s->chain) return false;
+    if (s->cov_C < (s->p + 31) / 32 * 32 + COV_R) return false;  // the cache must hold every column: it is never started over
+  } else if (s->K > 0) {
+    return false;  // (sessions with CV folds keep per-row-set state the chain contexts do not own)
+  }
   if (chains_for(s, ns) < 2) return false;
   int top = 0;
   for (int i = 0; i < ns; i++) {
     if (seq[i] < 1 || (i && seq[i] <= seq[i - 1])) return false;  // ascending levels: every chunk continues its predecessor
     top = std::max(top, seq[i]);
   }
-  return top <= 254 && top <= s->cap && top + COV_R + s->cov_spec <= s->cov_C;  // (the register-resident solvers)
+  if (top > 254 || top > s->cap) return false;  // (the register-resident solvers)
+  return s->model_type != 1 || top + COV_R + s->cov_spec <= s->cov_C;
 }
 
 namespace {
@@ -252,7 +262,9 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     SparseVec init;
     double c0 = 0.0;
     s->hint.on = false;
-    for (int r = 1; r < C; r++) {
+    // (LM only: the coarse chain is what fills the shared cache.  The other families keep no cache: their chunks start
+    // cold, side by side -- a restricted fit is cold-started anyway, only the active set is warm -- and are stitched)
+    for (int r = 1; r < C && s->model_type == 1; r++) {
       if (int rc = run_fit(s, seq[bounds[r] - 1], lambda, init, c0)) return rc;
       init = s->beta;
       c0 = s->coef0;
@@ -435,6 +447,8 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     s->chain_hits += c->chain_hits;
     c->cov_panel_groups = c->cov_cg_fallbacks = c->cov_tie_rescues = 0;
     c->chain_queued = c->chain_hits = 0;
+    s->n_submodel_steps += c->n_submodel_steps;
+    c->n_submodel_steps = 0;
     s->k1_seconds += c->k1_seconds;
     s->k1_bytes += c->k1_bytes;
     s->k1_launches += c->k1_launches;

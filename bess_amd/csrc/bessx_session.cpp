@@ -446,6 +446,69 @@ int upload_vec_padded(Scratch &sc, const double *v, int n, long ld, double **dv)
   return 0;
 }
 
+// Cox work space (the vectors of the state pass and of the Newton step, the k-sized blocks): the session's, and once
+// more for every chunk-chain context of a Cox session (chain_ctx_create)
+#define CX(call)                       \
+  do {                                 \
+    hipError_t e__ = (call);           \
+    if (e__ != hipSuccess) return e__; \
+  } while (0)
+hipError_t cox_alloc(bessx_session *s) {
+  const long ld = s->ld;
+  const int n = s->n, capA = s->capA;
+  {
+    auto V = [&](double **dst, size_t count) -> hipError_t {
+      hipError_t e = dmalloc(dst, count);
+      if (e == hipSuccess) {
+        s->cox_allocs.push_back(*dst);
+        e = hipMemset(*dst, 0, count * sizeof(double));
+      }
+      return e;
+    };
+    CoxBufs &c = s->cox;
+    double **vecs[] = {&c.E, &c.TH, &c.ET, &c.S0, &c.RS0, &c.SALL, &c.STEST, &c.EW, &c.WD, &c.ETA0, &c.THF, &c.S0F,
+                       &c.RS0F, &c.VG, &c.WG1, &c.UD, &c.TH1, &c.S1};
+    for (auto v : vecs) CX(V(v, (size_t)ld));
+    double **vecs1[] = {&c.C1, &c.CU, &c.CV, &c.C2};
+    for (auto v : vecs1) CX(V(v, (size_t)ld));
+    CX(V(&c.ldl_work, CHOL_FB_DOUBLES));
+    // k-sized work space: for sparsity levels up to 254 now, grown by cox_reserve() when a larger one is asked for
+    s->cox_M_cols = 256;
+    CX(V(&c.M, (size_t)ld * s->cox_M_cols));
+    CX(V(&c.g, (size_t)capA));
+    CX(V(&c.u, (size_t)capA));
+    CX(V(&c.b0, (size_t)capA));
+    CX(V(&c.Gt2, (size_t)136 * 256));
+    CX(V(&c.llpart, (size_t)(n + 255) / 256 + 1));
+    CX(V(&c.SCR, cox_scan_scratch_doubles(ld, 256)));
+    // one-pass Hessian of the Newton step (k_cox_hess, up to 10 tile rows; test hook cox_hess=2pass: M = S1 / S0
+    // materialised and two Gram launches, as in round 2)
+    // Small samples keep the two-pass form: it is built like the reference's own formulas (M = S1 / S0, two Grams), so
+    // on the ill-conditioned fits small n produces (near-separated risk sets, a ridge that outweighs the information
+    // matrix) its rounding follows the reference's more closely -- both forms are accurate to rounding there, but a
+    // Newton iteration on such a system amplifies rounding to 1e-4 and beyond (tests/test_cox_gpu.py).
+    // test hook cox_hess=1pass forces the one-pass form at any size.
+    c.fit_clamp = g_marginal_fit_variant == 2 ? 50.0 : 30.0;
+    c.hess_fused = n >= 1024 ? 1 : 0;
+    if (const char *ev = test_hook("cox_hess")) c.hess_fused = std::string(ev) == "2pass" ? 0 : (std::string(ev) == "1pass" ? 1 : c.hess_fused);
+    if (c.hess_fused) {
+      const size_t hrows = (size_t)cox_hess_slab_rows(ld), hns = ((size_t)ld + hrows - 1) / hrows;
+      if (hns * 55 * 256 > s->gpart_elems) {
+        c.hess_fused = 0;  // (cannot happen with the default workspace: 256 slabs x 55 tiles)
+      } else {
+        CX(cox_hess_prepare());
+        CX(V(&c.CW, (size_t)ld));
+        CX(V(&c.HP2, hns * 55 * 256));
+        CX(V(&c.HT, hns * 160));
+        CX(V(&c.CAR, hns * 160));
+        CX(V(&c.HQ, hns * 160));
+      }
+    }
+  }
+  return hipSuccess;
+}
+#undef CX
+
 }  // namespace bessx
 
 extern "C" {
@@ -1107,55 +1170,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     }
   }
   HIPT(dmalloc(&s->idcols, (size_t)capA + 16));
-  if (s->model_type == 4) {
-    auto V = [&](double **dst, size_t count) -> hipError_t {
-      hipError_t e = dmalloc(dst, count);
-      if (e == hipSuccess) {
-        s->cox_allocs.push_back(*dst);
-        e = hipMemset(*dst, 0, count * sizeof(double));
-      }
-      return e;
-    };
-    CoxBufs &c = s->cox;
-    double **vecs[] = {&c.E, &c.TH, &c.ET, &c.S0, &c.RS0, &c.SALL, &c.STEST, &c.EW, &c.WD, &c.ETA0, &c.THF, &c.S0F,
-                       &c.RS0F, &c.VG, &c.WG1, &c.UD, &c.TH1, &c.S1};
-    for (auto v : vecs) HIPT(V(v, (size_t)ld));
-    double **vecs1[] = {&c.C1, &c.CU, &c.CV, &c.C2};
-    for (auto v : vecs1) HIPT(V(v, (size_t)ld));
-    HIPT(V(&c.ldl_work, CHOL_FB_DOUBLES));
-    // k-sized work space: for sparsity levels up to 254 now, grown by cox_reserve() when a larger one is asked for
-    s->cox_M_cols = 256;
-    HIPT(V(&c.M, (size_t)ld * s->cox_M_cols));
-    HIPT(V(&c.g, (size_t)capA));
-    HIPT(V(&c.u, (size_t)capA));
-    HIPT(V(&c.b0, (size_t)capA));
-    HIPT(V(&c.Gt2, (size_t)136 * 256));
-    HIPT(V(&c.llpart, (size_t)(n + 255) / 256 + 1));
-    HIPT(V(&c.SCR, cox_scan_scratch_doubles(ld, 256)));
-    // one-pass Hessian of the Newton step (k_cox_hess, up to 10 tile rows; test hook cox_hess=2pass: M = S1 / S0
-    // materialised and two Gram launches, as in round 2)
-    // Small samples keep the two-pass form: it is built like the reference's own formulas (M = S1 / S0, two Grams), so
-    // on the ill-conditioned fits small n produces (near-separated risk sets, a ridge that outweighs the information
-    // matrix) its rounding follows the reference's more closely -- both forms are accurate to rounding there, but a
-    // Newton iteration on such a system amplifies rounding to 1e-4 and beyond (tests/test_cox_gpu.py).
-    // test hook cox_hess=1pass forces the one-pass form at any size.
-    c.fit_clamp = g_marginal_fit_variant == 2 ? 50.0 : 30.0;
-    c.hess_fused = n >= 1024 ? 1 : 0;
-    if (const char *ev = test_hook("cox_hess")) c.hess_fused = std::string(ev) == "2pass" ? 0 : (std::string(ev) == "1pass" ? 1 : c.hess_fused);
-    if (c.hess_fused) {
-      const size_t hrows = (size_t)cox_hess_slab_rows(ld), hns = ((size_t)ld + hrows - 1) / hrows;
-      if (hns * 55 * 256 > s->gpart_elems) {
-        c.hess_fused = 0;  // (cannot happen with the default workspace: 256 slabs x 55 tiles)
-      } else {
-        HIPT(cox_hess_prepare());
-        HIPT(V(&c.CW, (size_t)ld));
-        HIPT(V(&c.HP2, hns * 55 * 256));
-        HIPT(V(&c.HT, hns * 160));
-        HIPT(V(&c.CAR, hns * 160));
-        HIPT(V(&c.HQ, hns * 160));
-      }
-    }
-  }
+  if (s->model_type == 4) HIPT(cox_alloc(s));
   if (s->model_type == 1) TRY(prepare_rowset(s, 0));
   HIPT(hipStreamSynchronize(s->st));
 #undef TRY
@@ -1346,6 +1361,51 @@ int chain_ctx_create(bessx_session *ps, bessx_session **out) {
   if (e == hipSuccess) e = dmalloc(&c->tmpv, (size_t)ps->ld);
   if (e == hipSuccess) e = dmalloc(&c->part_rs[0], part_elems(ps));
   if (e == hipSuccess) e = dmalloc(&c->r_rs[0], (size_t)ps->ld);
+  if (e == hipSuccess) e = hipMemset(c->r_rs[0], 0, (size_t)ps->ld * sizeof(double));
+  if (e == hipSuccess && ps->model_type != 1) {
+    // the IRLS / Newton families: what their fits write besides -- curvature sums and weights, the IRLS vectors, the
+    // auxiliary columns (column 2 is the working response), the slab partials and column lists of the Gram kernels
+    c->ctx_allocs.clear();
+    auto own = [&](double **dst, size_t count, const double *copy_of) -> hipError_t {
+      *dst = nullptr;
+      hipError_t q = dmalloc(dst, count);
+      if (q != hipSuccess) return q;
+      c->ctx_allocs.push_back(*dst);
+      return copy_of ? hipMemcpy(*dst, copy_of, count * sizeof(double), hipMemcpyDeviceToDevice)
+                     : hipMemset(*dst, 0, count * sizeof(double));
+    };
+    auto own_i = [&](int **dst, size_t count) -> hipError_t {
+      *dst = nullptr;
+      hipError_t q = dmalloc(dst, count);
+      if (q != hipSuccess) return q;
+      c->ctx_allocs.push_back(*dst);
+      return hipMemset(*dst, 0, count * sizeof(int));
+    };
+    const size_t ld = (size_t)ps->ld;
+    e = own(&c->part2_rs[0], (size_t)ps->nrb * ps->p, nullptr);
+    if (e == hipSuccess) e = own(&c->h_rs[0], ld, nullptr);
+    if (e == hipSuccess) e = own(&c->Wv, ld, nullptr);
+    if (e == hipSuccess) e = own(&c->llpart, ps->llpart_cap, nullptr);
+    if (e == hipSuccess) e = own(&c->bcur, (size_t)ps->capA + 16, nullptr);
+    if (e == hipSuccess) e = own(&c->bprev, (size_t)ps->capA + 16, nullptr);
+    if (e == hipSuccess) e = own(&c->aux, 3 * ld, ps->aux);
+    if (e == hipSuccess) e = own(&c->gpart, ps->gpart_elems, nullptr);
+    if (e == hipSuccess) e = own_i(&c->gcols, (size_t)ps->capA + 16);
+    if (e == hipSuccess) e = own_i(&c->idcols, (size_t)ps->capA + 16);
+    if (e == hipSuccess && ps->idcols)
+      e = hipMemcpy(c->idcols, ps->idcols, ((size_t)ps->capA + 16) * sizeof(int), hipMemcpyDeviceToDevice);
+    if (e == hipSuccess && ps->model_type == 4) {
+      CoxBufs keep = ps->cox;
+      c->cox = CoxBufs();
+      c->cox.one_pass = keep.one_pass;
+      c->cox.need_uv = keep.need_uv;
+      c->cox_allocs.clear();
+      e = cox_alloc(c);  // (sets hess_fused / fit_clamp as the session's creation did)
+      c->cox.hess_fused = c->cox.hess_fused && keep.hess_fused;
+      c->cox.fit_clamp = keep.fit_clamp;
+      c->cox_state_rs = -1;
+    }
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     chain_ctx_free(c);
@@ -1364,6 +1424,10 @@ void chain_ctx_free(bessx_session *c) {
   if (c->tmpv) (void)hipFree(c->tmpv);
   if (c->part_rs[0]) (void)hipFree(c->part_rs[0]);
   if (c->r_rs[0]) (void)hipFree(c->r_rs[0]);
+  for (void *q : c->ctx_allocs) (void)hipFree(q);
+  for (void *q : c->cox_allocs) (void)hipFree(q);
+  c->ctx_allocs.clear();
+  c->cox_allocs.clear();
   c->res_buf[1] = nullptr;
   c->snap[0] = c->snap[1] = nullptr;
   fold_ctx_free(c);

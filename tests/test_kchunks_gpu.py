@@ -123,3 +123,40 @@ def test_no_chunk_chains_where_they_do_not_apply(gpu, monkeypatch):
         assert s.counters()["kpath_chunked_paths"] == 0
         s.sequential_path(seq, ic_type=3)
         assert s.counters()["kpath_chunked_paths"] == 1
+
+
+def _glm_case(fam):
+    if fam == "poisson":
+        X, y, _, _ = synth.make_poisson(3000, 300, 12, seed=8)
+        return X, y, dict(data_type=2, model_type=3)
+    X, y, kw = _hard(fam, 2500 if fam == "cox" else 2000, 200)
+    return X, y, kw
+
+
+@pytest.mark.parametrize("fam", ["logistic", "poisson", "cox"])
+@pytest.mark.parametrize("chains", [2, 3])
+def test_chunk_chains_of_the_irls_and_newton_families(gpu, monkeypatch, fam, chains):
+    """Logistic, Poisson, Cox: no Gram column cache to share -- the chunks start cold, side by side (one chain's IRLS /
+    Newton steps beside another's pass over X), each on a context that owns everything a fit of the family writes, and
+    are stitched.  Same candidates as the single chain: supports, iteration counts, criteria, coefficients."""
+    X, y, kw = _glm_case(fam)
+    seq = np.arange(1, 33)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        steps1 = s.submodel_steps() if hasattr(s, "submodel_steps") else None
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+    with gpu.Session(X, y, **kw) as s:
+        got = s.sequential_path(seq, ic_type=3)
+        again = s.sequential_path(seq, ic_type=3)
+        one = s.fit(9)                               # the session's own state is still good for single fits
+        cnt = s.counters()
+    assert cnt["kpath_chunked_paths"] == 2 and cnt["kpath_stitch_refits"] >= 2 * (chains - 1)
+    for out in (got, again):
+        np.testing.assert_array_equal(out["cand_support"], single["cand_support"])
+        np.testing.assert_array_equal(out["cand_iters"], single["cand_iters"])
+        np.testing.assert_allclose(out["cand_ic"], single["cand_ic"], rtol=1e-10)
+        np.testing.assert_allclose(out["cand_beta"], single["cand_beta"], rtol=1e-7, atol=1e-10)
+        assert out["best_T0"] == single["best_T0"] and out["n_pdas_iters"] == single["n_pdas_iters"]
+    assert len(one["support"]) == 9
+    del steps1
