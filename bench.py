@@ -406,6 +406,35 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
         if steps:
             rec["submodel_steps"] = int(steps)
             rec["us_per_submodel_step_incl_iteration_overheads"] = 1e6 * (dt - k1["seconds"]) / steps
+        cnt = sess.counters()
+        if cnt.get("kpath_chunked_paths", 0) > 0:
+            # the path ran as chunk chains side by side (bessx_kchunks.cpp): the same path as ONE chain on the same session
+            # beside it (the kernel statistics above are the chunked run's: passes of several chains share the device)
+            sess.set_kpath_chains(1)
+            run()
+            sess.enable_kernel_timing(True)
+            sess.score_pass_stats(reset=True)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            o1 = run()
+            torch.cuda.synchronize()
+            d1 = time.time() - t1
+            k11 = sess.score_pass_stats()
+            sess.enable_kernel_timing(False)
+            sess.set_kpath_chains(0)
+            p1 = k11["algorithmic_bytes"] / (8.0 * n * p)
+            rec["chunk_chains"] = {
+                "chains": cnt["kpath_chains_last_path"],
+                "stitch_refits_per_path": cnt["kpath_stitch_refits"] / float(cnt["kpath_chunked_paths"]),
+                "single_chain": {"candidates_per_s": o1["n_candidates"] / d1, "ms_per_path": 1e3 * d1, "passes_over_X": p1,
+                                 # the score kernel with the device to itself (beside other chains' kernels a pass takes
+                                 # longer: score_kernel.frac above is the chunked run's)
+                                 "score_kernel_frac_of_hbm": (8.0 * n * p * p1 / k11["seconds"] / 1e9 / HBM_PEAK_GBPS)
+                                 if k11["seconds"] else None},
+                "same_candidates_as_the_single_chain": bool(
+                    np.array_equal(o1["cand_support"], out["cand_support"]) and
+                    np.array_equal(o1["cand_iters"], out["cand_iters"]) and
+                    np.allclose(o1["cand_ic"], out["cand_ic"], rtol=1e-9, atol=0.0))}
         return rec
 
     res = {}
@@ -850,21 +879,18 @@ def main():
         cnt = sess.counters() if world == 1 else {}
         if world == 1 and cnt.get("kpath_chunked_paths", 0) > 0:
             # the path ran as chunk chains side by side on one Gram column cache, stitched into the single warm-start chain
-            # (bessx_kchunks.cpp); the same path as ONE chain on a second session, timed the same way, beside it
+            # (bessx_kchunks.cpp); the same path as ONE chain on the same session, timed the same way, beside it
             runs = float(cnt["kpath_chunked_paths"])
-            os.environ["BESSX_KPATH_CHAINS"] = "1"
-            s1 = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
-                              score_mode=mode, device=local_rank)
-            del os.environ["BESSX_KPATH_CHAINS"]
+            sess.set_kpath_chains(1)
             for _ in range(2):
-                s1.sequential_path(seq, ic_type=3)
+                sess.sequential_path(seq, ic_type=3)
             torch.cuda.synchronize()
             t1 = time.time()
             for _ in range(5):
-                o1 = s1.sequential_path(seq, ic_type=3)
+                o1 = sess.sequential_path(seq, ic_type=3)
             torch.cuda.synchronize()
             d1 = (time.time() - t1) / 5
-            s1.close()
+            sess.set_kpath_chains(0)
             line["chunk_chains"] = {
                 "chains": cnt["kpath_chains_last_path"], "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "stitch_refits_per_path": cnt["kpath_stitch_refits"] / runs,

@@ -28,7 +28,7 @@ SYMBOLS = [
     "bessx_session_trace_copy_double", "bessx_session_get_normalization", "bessx_session_score_pass_stats",
     "bessx_session_enable_kernel_timing", "bessx_session_submodel_steps", "bessx_session_fit", "bessx_session_fit_width", "bessx_session_reset_caches",
     "bessx_session_sequential_path_chain", "bessx_session_cv_eval", "bessx_session_debug_block_stream",
-    "bessx_session_set_fill_hook",
+    "bessx_session_set_fill_hook", "bessx_session_set_kpath_chains",
     "bessx_session_marginal_scores", "bessx_session_cov_prefill_begin", "bessx_session_cov_prefill_compute",
     "bessx_session_cov_prefill_export", "bessx_session_cov_prefill_import", "bessx_session_cov_prefill_end",
     "bessx_session_cov_prefill_extend", "bessx_session_cov_state", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
@@ -479,6 +479,10 @@ class Session:
 
     def cov_prefill_end(self):
         _check(lib().bessx_session_cov_prefill_end(self._h))
+
+    def set_kpath_chains(self, chains):
+        """Chunk chains of sequential_path (bessx_session_set_kpath_chains): 0 automatic, 1 one chain, 2..8."""
+        _check(lib().bessx_session_set_kpath_chains(self._h, int(chains)))
 
     _FILL_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
 

@@ -915,6 +915,12 @@ int bessx_session_cov_prefill_end(bessx_session *s) {
   return BESSX_OK;
 }
 
+int bessx_session_set_kpath_chains(bessx_session *s, int chains) {
+  if (!s || chains < 0 || chains > 8) return fail(BESSX_ERR_ARG, "set_kpath_chains: 0 (automatic) .. 8");
+  s->kpath_chains = chains;
+  return BESSX_OK;
+}
+
 int bessx_session_set_fill_hook(bessx_session *s, bessx_fill_hook hook, void *user, int width) {
   if (int rc = prefill_ready(s)) return rc;
   if (hook && (width < COV_R || width % COV_R != 0 || width > s->capA))

@@ -327,6 +327,11 @@ int bessx_session_cov_prefill_export(bessx_session *s, int g0, int ngroups, doub
 int bessx_session_cov_prefill_import(bessx_session *s, int g0, int ngroups, const double *src, int src_on_device);
 int bessx_session_cov_prefill_end(bessx_session *s);
 
+/* How many chunk chains bessx_session_sequential_path may run side by side (bessx_kchunks.cpp):
+ * 0 = automatic, 1 = one chain, 2..8 = that many where the path qualifies.  The initial value is BESSX_KPATH_CHAINS (else
+ * 0).  The candidates returned are the same for every setting. */
+int bessx_session_set_kpath_chains(bessx_session *s, int chains);
+
 /* Shared WIDE fills inside a fit that several sessions run identically (the pilot fit of a multi-GPU k-path: same data,
  * same cache, deterministic kernels -- every rank's fit parks at the same PDAS iteration on the same missing columns).
  * With a hook set, a fit of the all-rows row set that parks on missing Gram columns does not form them privately (one
