@@ -160,3 +160,32 @@ def test_chunk_chains_of_the_irls_and_newton_families(gpu, monkeypatch, fam, cha
         assert out["best_T0"] == single["best_T0"] and out["n_pdas_iters"] == single["n_pdas_iters"]
     assert len(one["support"]) == 9
     del steps1
+
+
+def test_chunk_chains_with_weights_always_select_screening_and_the_drop_in_entry(gpu, monkeypatch):
+    """Sessions with observation weights, always-selected columns and screening run chunked too (results in the
+    caller's column numbering); the pywrap_bess drop-in creates a session per call: contexts and host threads come and
+    go with it."""
+    rng = np.random.default_rng(4)
+    X, y, _, _ = synth.make_lm(2500, 900, 15, seed=21)
+    w = rng.uniform(0.5, 2.0, 2500)
+    seq = np.arange(1, 57)
+    variants = [dict(weight=w), dict(always_select=[3, 700]), dict(is_screening=True, screening_size=500),
+                dict(weight=w, always_select=[10], is_screening=True, screening_size=600, algorithm_type=5)]
+    for kw in variants:
+        outs = {}
+        for chains in (1, 3):
+            monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+            with gpu.Session(X, y, **kw) as s:
+                outs[chains] = s.sequential_path(seq, [0.05] if kw.get("algorithm_type") == 5 else [0.0], ic_type=3)
+                assert (s.counters()["kpath_chunked_paths"] > 0) == (chains == 3)
+        _same_path(outs[3], outs[1])
+    res = {}
+    for chains in (1, 3):
+        monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+        res[chains] = [gpu.pywrap_bess(X, y, 1, np.ones(2500), True, 1, 1, 20, 5, 1, True, 3, False, 5, np.arange(900), [0.0],
+                                       seq, [0.0], 1, 20, 10, 1e-4, 0.01, 10.0, 10, False, 0, 1, [], 0.0, 900)
+                       for _ in range(2)]
+    for a, b in zip(res[3], res[1]):
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(np.asarray(u, dtype=float), np.asarray(v, dtype=float), rtol=1e-8, atol=1e-12)
