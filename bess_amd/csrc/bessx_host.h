@@ -511,7 +511,8 @@ int enqueue_lm_slot_cov(bessx_session *s, int slot, int T0, double lambda, int r
 int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int rs, int *next_slot);
 // bessx_kchunks.cpp
 bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int is_cv, const bessx_path_chain *chain);
-int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type, bessx_path_result *res);
+int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type, bessx_path_result *res,
+                            bessx_path_chain *chain = nullptr);
 void kchains_safe_point(bessx_session *c);   // chain context, between candidates: stand still while another chain fills
 int kchains_fill_begin(bessx_session *c);    // chain context parked on missing columns: wait until it alone runs
 void kchains_fill_end(bessx_session *c);

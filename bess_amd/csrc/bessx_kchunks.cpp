@@ -116,9 +116,12 @@ void kchains_free(bessx_session *s) {
 }
 
 // how many chunk chains for this path (1 = the single chain)
-static int chains_for(const bessx_session *s, int ns) {
+static int chains_for(const bessx_session *s, int ns, bool link = false) {
   int C = s->kpath_chains;
-  if (C == 0) {
+  if (C == 0 && link && s->model_type == 1 && ns < 96) {
+    // a link of a longer chain (a rank's chunk of a multi-GPU k-path): shorter, so fewer chains
+    C = (ns >= 40 && s->p >= 2048) ? 2 : 1;
+  } else if (C == 0) {
     // automatic: long paths on wide designs.  How many chains pay depends on how many hardware queues the HIP runtime
     // gives the process' streams (GPU_MAX_HW_QUEUES, default 4; read when the runtime starts): configs[1], 18.6 ms as
     // one chain -- 4 queues: 2 chains 16.2 ms, 3 and more lose (21.2 / 19.5 ms: streams share queues and wait for each
@@ -136,7 +139,10 @@ static int chains_for(const bessx_session *s, int ns) {
 }
 
 bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int is_cv, const bessx_path_chain *chain) {
-  if (!s || s->kch_owner || s->parent || chain || is_cv || nl != 1) return false;
+  if (!s || s->kch_owner || s->parent || is_cv || nl != 1) return false;
+  // a link of a longer chain (bessx_session_sequential_path_chain) qualifies when it only starts from a given model
+  // -- the stitch refits, which stop at the first candidate equal to the caller's, are short and stay one chain
+  if (chain && (chain->stop_support || chain->init_len > s->cap)) return false;
   if (s->grouped || !s->warm_start || s->trace.on || s->cv_shared || !s->publish || s->fill_hook) return false;
   if (s->model_type == 1) {
     if (!s->cov_mode || !s->chain) return false;
@@ -144,7 +150,7 @@ bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int i
   } else if (s->K > 0) {
     return false;  // (sessions with CV folds keep per-row-set state the chain contexts do not own)
   }
-  if (chains_for(s, ns) < 2) return false;
+  if (chains_for(s, ns, chain != nullptr) < 2) return false;
   int top = 0;
   for (int i = 0; i < ns; i++) {
     if (seq[i] < 1 || (i && seq[i] <= seq[i - 1])) return false;  // ascending levels: every chunk continues its predecessor
@@ -218,8 +224,8 @@ int context_begin(bessx_session *c) {
 }  // namespace
 
 int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type,
-                            bessx_path_result *res) {
-  const int C = chains_for(s, ns);
+                            bessx_path_result *res, bessx_path_chain *link) {
+  const int C = chains_for(s, ns, link != nullptr);
   HIPX(hipSetDevice(s->device));
   if (!s->kch) s->kch = new KChains();
   KChains *k = s->kch;
@@ -261,6 +267,18 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   {
     SparseVec init;
     double c0 = 0.0;
+    if (link) {  // the model the whole link starts from: chunk 0's start, and the coarse chain's
+      for (int i = 0; i < link->init_len; i++) {
+        if (link->init_idx[i] < 0 || link->init_idx[i] >= s->p) return fail(BESSX_ERR_ARG, "chain: init index out of range");
+        init.idx.push_back(link->init_idx[i]);
+        init.val.push_back(link->init_val[i]);
+      }
+      c0 = link->init_coef0;
+      run[0].init_idx = init.idx;
+      run[0].init_val = init.val;
+      run[0].init_coef0 = c0;
+      link->stopped_at = -1;
+    }
     s->hint.on = false;
     // (LM only: the coarse chain is what fills the shared cache.  The other families keep no cache: their chunks start
     // cold, side by side -- a restricted fit is cold-started anyway, only the active set is warm -- and are stitched)
@@ -466,6 +484,15 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   // the session's own device state is the coarse chain's last fit, not the path's last candidate
   for (auto &q : s->cache) q.valid = false;
   s->dev_state_rs = -1;
+  if (link) {  // the model the link's successor starts from
+    const ChunkRun &q = run[C - 1];
+    link->last_len = q.last_len;
+    link->last_coef0 = q.last_coef0;
+    for (int i = 0; i < q.last_len && i < link->last_cap; i++) {
+      if (link->last_idx) link->last_idx[i] = q.last_idx[i];
+      if (link->last_val) link->last_val[i] = q.last_val[i];
+    }
+  }
   // Algorithm state as the path leaves it: the last candidate's model (normalised scale)
   {
     const ChunkRun &q = run[C - 1];

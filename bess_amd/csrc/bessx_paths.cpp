@@ -615,7 +615,7 @@ int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *la
   if (int rc0 = (chain && chain->keep_caches) ? settle_device_chain(s) : reset_path_caches(s)) return rc0;
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
-           : kchunks_apply(s, seq, ns, nl, is_cv, chain) ? sequential_path_chunked(s, seq, ns, lam[0], ic_type, res)
+           : kchunks_apply(s, seq, ns, nl, is_cv, chain) ? sequential_path_chunked(s, seq, ns, lam[0], ic_type, res, chain)
                                                          : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res, chain);
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();

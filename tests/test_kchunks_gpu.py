@@ -189,3 +189,55 @@ def test_chunk_chains_with_weights_always_select_screening_and_the_drop_in_entry
     for a, b in zip(res[3], res[1]):
         for u, v in zip(a, b):
             np.testing.assert_allclose(np.asarray(u, dtype=float), np.asarray(v, dtype=float), rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("fam", ["lm", "logistic"])
+def test_links_of_a_longer_chain_run_as_chunk_chains_too(gpu, monkeypatch, fam):
+    """bessx_session_sequential_path_chain -- a rank's chunk of a multi-GPU k-path -- qualifies when it only starts from a
+    given model (no stop table): same link as one chain, same hand-over model; and the stitched 2-rank path built from
+    such links is the single chain's."""
+    from bess_amd import dist as bdist
+    from helpers import run_ranks
+    if fam == "lm":
+        X, y, _, _ = synth.make_lm(2500, 700, 20, seed=11)
+        kw = {}
+    else:
+        X, y, kw = _hard("logistic", 2000, 200)
+    seq = np.arange(1, 65)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        head = s.sequential_path_chain(seq[:20], ic_type=3)
+        tail1 = s.sequential_path_chain(seq[20:], ic_type=3, init_idx=head["last_idx"], init_val=head["last_val"],
+                                        init_coef0=head["last_coef0"], keep_caches=True)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "3")
+    with gpu.Session(X, y, **kw) as s:
+        for keep in (True, False):
+            h3 = s.sequential_path_chain(seq[:20], ic_type=3)
+            t3 = s.sequential_path_chain(seq[20:], ic_type=3, init_idx=h3["last_idx"], init_val=h3["last_val"],
+                                         init_coef0=h3["last_coef0"], keep_caches=keep)
+            assert t3["stopped_at"] == -1
+            np.testing.assert_array_equal(t3["cand_support"], tail1["cand_support"])
+            np.testing.assert_array_equal(t3["cand_iters"], tail1["cand_iters"])
+            np.testing.assert_allclose(t3["cand_ic"], tail1["cand_ic"], rtol=1e-9)
+            np.testing.assert_array_equal(t3["last_idx"], tail1["last_idx"])
+            np.testing.assert_allclose(t3["last_val"], tail1["last_val"], rtol=1e-8, atol=1e-12)
+        assert s.counters()["kpath_chunked_paths"] >= 2
+        # a refit with a stop table stays one chain
+        before = s.counters()["kpath_chunked_paths"]
+        r = s.sequential_path_chain(seq[20:], ic_type=3, init_idx=h3["last_idx"], init_val=h3["last_val"],
+                                    init_coef0=h3["last_coef0"], keep_caches=True, stop_support=tail1["cand_support"],
+                                    stop_beta=tail1["cand_beta"])
+        assert r["stopped_at"] == 0 and s.counters()["kpath_chunked_paths"] == before
+
+    def rank_fn(rank, comm):
+        with gpu.Session(X, y, **kw) as sr:
+            rep = bdist.StitchedKPath(sr, seq, 2, rank, ic_type=3, comm=comm).step()
+            return rep, sr.counters()["kpath_chunked_paths"]
+
+    for r, (rep, chunked) in enumerate(run_ranks(2, rank_fn)):
+        a, b = bdist.partition(len(seq), 2, r)
+        c = rep["chunk"]["cand_support"]
+        np.testing.assert_array_equal(c, single["cand_support"][a:b, :c.shape[1]])
+        np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-9)
+        assert chunked >= 1
