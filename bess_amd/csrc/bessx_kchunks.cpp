@@ -235,11 +235,16 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     if (int rc = chain_ctx_create(s, &c)) return rc;
     k->ctx.push_back(c);
   }
-  if (!k->pool_started) {
-    k->pool.start(7, s->device);  // (up to 8 chains: the caller is one of them)
+  if (k->pool.broken) return fail(BESSX_ERR_HIP, "chunk chains: the host threads did not come back from an earlier call");
+  if (!k->pool_started || (int)k->pool.th.size() < C - 1) {  // one host thread per chain; the caller is one of them
+    if (k->pool_started) k->pool.stop();
+    k->pool.quit = false;  // (a pool started again: no job of the previous threads' numbering is left to run)
+    k->pool.ticket = 0;
+    k->pool.ticket_hint.store(0);
+    k->pool.job = nullptr;
+    k->pool.start(C - 1, s->device);
     k->pool_started = true;
   }
-  if (k->pool.broken) return fail(BESSX_ERR_HIP, "chunk chains: the host threads did not come back from an earlier call");
   // chunk r = candidates [bounds[r], bounds[r + 1]); later chunks are shorter: a candidate costs more the larger its
   // level (larger solves), and the last chunk also runs the longest stitch
   std::vector<int> bounds((size_t)C + 1, 0);

@@ -241,3 +241,21 @@ def test_links_of_a_longer_chain_run_as_chunk_chains_too(gpu, monkeypatch, fam):
         np.testing.assert_array_equal(c, single["cand_support"][a:b, :c.shape[1]])
         np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-9)
         assert chunked >= 1
+
+
+def test_the_number_of_chains_can_change_between_paths(gpu, monkeypatch):
+    """bessx_session_set_kpath_chains between paths of one session: more chains than before start more host threads
+    (the pool is started again), fewer leave the extra ones idle; always the single chain's candidates."""
+    monkeypatch.delenv("BESSX_KPATH_CHAINS", raising=False)
+    X, y, _, _ = synth.make_lm(2500, 700, 20, seed=11)
+    seq = np.arange(1, 65)
+    with gpu.Session(X, y) as s:
+        s.set_kpath_chains(1)
+        single = s.sequential_path(seq, ic_type=3)
+        for chains in (2, 5, 3, 8, 2, 1, 4):
+            s.set_kpath_chains(chains)
+            _same_path(s.sequential_path(seq, ic_type=3), single)
+            if chains > 1:
+                assert s.counters()["kpath_chains_last_path"] == chains
+        with pytest.raises(Exception):
+            s.set_kpath_chains(9)
