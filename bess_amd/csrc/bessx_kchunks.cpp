@@ -428,7 +428,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     fits_all += q.fits;
     for (int i = 0; i < q.hi - q.lo; i++) {
       const int g = res->n_candidates++;
-      iters_path += q.iters[i];
+      iters_path += std::min(q.iters[i], s->max_iter);  // (a fit that ran out of iterations reports max_iter + 1)
       if (q.ic[i] < run[best_r].ic[best_i]) {
         best_r = r;
         best_i = i;

@@ -8,3 +8,12 @@ pytestmark = pytest.mark.gpu
 def test_random_problems_match_the_oracle(gpu):
     import fuzz_parity
     assert fuzz_parity.run(cases=150, seed=20260101, verbose=False) == 0
+
+
+def test_random_problems_with_chunk_chains_forced(gpu, monkeypatch):
+    """The same differential test with every qualifying sequential path run as chunk chains side by side
+    (BESSX_KPATH_CHAINS: paths of >= 16 candidates of all four families, weights, warm start, truncated fits): the
+    untraced call must walk the path the traced -- single-chain -- call and the oracle walked."""
+    import fuzz_parity
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "3")
+    assert fuzz_parity.run(cases=120, seed=5, verbose=False) == 0
