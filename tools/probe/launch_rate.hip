@@ -17,11 +17,17 @@ __global__ void k_spin(unsigned long long *out, int ticks) {
 
 int main(int argc, char **argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 1000, W = argc > 2 ? atoi(argv[2]) : 5;
+  const int split = argc > 3 ? atoi(argv[3]) : 0;  // 1: every second stream at the lowest priority, the others at the highest
+  int plo = 0, phi = 0;
+  hipDeviceGetStreamPriorityRange(&plo, &phi);
   for (int T : {1, 2, 4, 8}) {
     std::vector<hipStream_t> st(T);
     std::vector<unsigned long long *> buf(T);
     for (int t = 0; t < T; t++) {
-      hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking);
+      if (split)
+        hipStreamCreateWithPriority(&st[t], hipStreamNonBlocking, (t & 1) ? plo : phi);
+      else
+        hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking);
       hipMalloc((void **)&buf[t], 64);
       hipMemset(buf[t], 0, 64);
       for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st[t], buf[t], 10);
