@@ -245,10 +245,15 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     k->pool.start(C - 1, s->device);
     k->pool_started = true;
   }
-  // chunk r = candidates [bounds[r], bounds[r + 1]); later chunks are shorter: a candidate costs more the larger its
-  // level (larger solves), and the last chunk also runs the longest stitch
+  // chunk r = candidates [bounds[r], bounds[r + 1]): equal lengths.  (Lengths weighted by the level -- a candidate costs
+  // more the larger its solve -- were measured on configs[1]: 1 + k / 40 ... 1 + k / 400 gave 15.0 ... 12.5 ms per path
+  // against 12.1 for equal chunks; where the boundaries fall relative to the fills matters more than the balance.)
+  // The IRLS / Newton families: the later chunks are shorter (their sub-model systems grow with the level: logistic
+  // 123 ms with lengths weighted 1 + k / 160, 129 ms with equal ones).
   std::vector<int> bounds((size_t)C + 1, 0);
-  {
+  if (s->model_type == 1) {
+    for (int r = 1; r <= C; r++) bounds[r] = (int)((long)ns * r / C);
+  } else {
     double tot = 0.0;
     std::vector<double> cum((size_t)ns + 1, 0.0);
     for (int i = 0; i < ns; i++) {
@@ -256,7 +261,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
       cum[(size_t)i + 1] = tot;
     }
     for (int r = 1; r < C; r++) {
-      int b = (int)(std::lower_bound(cum.begin(), cum.end(), tot * r / C) - cum.begin());
+      const int b = (int)(std::lower_bound(cum.begin(), cum.end(), tot * r / C) - cum.begin());
       bounds[r] = std::min(std::max(b, bounds[r - 1] + 1), ns - (C - r));
     }
     bounds[C] = ns;
