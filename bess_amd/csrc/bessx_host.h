@@ -517,6 +517,8 @@ void kchains_safe_point(bessx_session *c);   // chain context, between candidate
 int kchains_fill_begin(bessx_session *c);    // chain context parked on missing columns: wait until it alone runs
 void kchains_fill_end(bessx_session *c);
 void kchains_free(bessx_session *s);
+void kchains_quiesce(bessx_session *s);
+int kchunks_prepare(bessx_session *s, int ns, bool link);
 hipError_t cox_alloc(bessx_session *s);                        // bessx_session.cpp
 int chain_ctx_create(bessx_session *ps, bessx_session **out);  // bessx_session.cpp
 void chain_ctx_free(bessx_session *c);

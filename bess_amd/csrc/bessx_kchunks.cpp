@@ -44,7 +44,10 @@ void kchains_safe_point(bessx_session *c) {
   lk.lock();
   k->running--;
   k->cv.notify_all();
-  k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s), [&] { return !k->fill_pending || k->abandoned; });
+  if (!k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s), [&] { return !k->fill_pending || k->abandoned; })) {
+    k->abandoned = true;  // (a fill that never ended: nobody waits any longer, every chain fails at its next look)
+    k->cv.notify_all();
+  }
   k->running++;
 }
 
@@ -223,19 +226,29 @@ int context_begin(bessx_session *c) {
 
 }  // namespace
 
-int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type,
-                            bessx_path_result *res, bessx_path_chain *link) {
-  const int C = chains_for(s, ns, link != nullptr);
-  HIPX(hipSetDevice(s->device));
+// every chain context's stream idle (after a failed run a context may still have launches queued)
+void kchains_quiesce(bessx_session *s) {
+  if (!s || !s->kch) return;
+  for (bessx_session *c : s->kch->ctx) (void)hipStreamSynchronize(c->st);
+}
+
+// Contexts and host threads for the path's chains.  Non-zero when they cannot be had (no memory for the contexts, host
+// threads lost in an earlier call): the caller then runs the path as one chain -- slower, same result.
+int kchunks_prepare(bessx_session *s, int ns, bool link) {
+  const int C = chains_for(s, ns, link);
+  if (hipSetDevice(s->device) != hipSuccess) return 1;
   if (!s->kch) s->kch = new KChains();
   KChains *k = s->kch;
+  if (k->pool.broken) return 1;
   k->deadline_s = s->wait_deadline_s;
   while ((int)k->ctx.size() < C) {
     bessx_session *c = nullptr;
-    if (int rc = chain_ctx_create(s, &c)) return rc;
+    if (chain_ctx_create(s, &c) != 0) {
+      (void)hipGetLastError();
+      return 1;
+    }
     k->ctx.push_back(c);
   }
-  if (k->pool.broken) return fail(BESSX_ERR_HIP, "chunk chains: the host threads did not come back from an earlier call");
   if (!k->pool_started || (int)k->pool.th.size() < C - 1) {  // one host thread per chain; the caller is one of them
     if (k->pool_started) k->pool.stop();
     k->pool.quit = false;  // (a pool started again: no job of the previous threads' numbering is left to run)
@@ -245,6 +258,16 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     k->pool.start(C - 1, s->device);
     k->pool_started = true;
   }
+  return 0;
+}
+
+int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type,
+                            bessx_path_result *res, bessx_path_chain *link) {
+  const int C = chains_for(s, ns, link != nullptr);
+  HIPX(hipSetDevice(s->device));
+  KChains *k = s->kch;
+  if (!k || (int)k->ctx.size() < C || k->pool.broken)
+    return fail(BESSX_ERR_HIP, "chunk chains: not prepared (kchunks_prepare)");
   // chunk r = candidates [bounds[r], bounds[r + 1]): equal lengths.  (Lengths weighted by the level -- a candidate costs
   // more the larger its solve -- were measured on configs[1]: 1 + k / 40 ... 1 + k / 400 gave 15.0 ... 12.5 ms per path
   // against 12.1 for equal chunks; where the boundaries fall relative to the fills matters more than the balance.)

@@ -588,6 +588,7 @@ struct PgsArgs {
 
 // the part of reset_path_caches() a path needs that continues on the caches of the previous call
 int settle_device_chain(bessx_session *s) {
+  kchains_quiesce(s);
   if (s->ahead.armed) {
     s->ahead.armed = false;
     HIPX(hipStreamSynchronize(s->st));
@@ -613,10 +614,12 @@ int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *la
   // a path call starts cold, like a bessCpp call -- unless it continues the job of the previous call (chain->keep_caches:
   // the Gram columns and score sums in memory depend on the data only and stay valid)
   if (int rc0 = (chain && chain->keep_caches) ? settle_device_chain(s) : reset_path_caches(s)) return rc0;
+  // (chunk chains where the path qualifies and their contexts can be had, else the one chain: same candidates)
+  const bool chunked = !pgs && !gs && kchunks_apply(s, seq, ns, nl, is_cv, chain) && kchunks_prepare(s, ns, chain != nullptr) == 0;
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
-           : kchunks_apply(s, seq, ns, nl, is_cv, chain) ? sequential_path_chunked(s, seq, ns, lam[0], ic_type, res, chain)
-                                                         : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res, chain);
+           : chunked ? sequential_path_chunked(s, seq, ns, lam[0], ic_type, res, chain)
+                     : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res, chain);
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
   res->n_fits = s->n_fits;

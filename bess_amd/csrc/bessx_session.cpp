@@ -269,6 +269,7 @@ int alloc_cov_cache(bessx_session *s, bool share_map) {
 
 // forget every cached quantity that outlives a fit: a path call starts from nothing, like bessCpp
 int reset_path_caches(bessx_session *s) {
+  kchains_quiesce(s);  // (chunk-chain contexts read the caches that are about to be cleared)
   if (s->ahead.armed) {
     s->ahead.armed = false;
     HIPX(hipStreamSynchronize(s->st));
