@@ -284,7 +284,8 @@ class Session:
         names = {0: "chained_fits", 1: "cg_fallbacks", 2: "passes_over_X", 3: "chained_queued", 7: "cv_side_by_side_rounds",
                  8: "cv_union_fills", 9: "tie_rescues", 10: "cache_restarts", 11: "cv_contexts_dropped",
                  12: "cv_fold_contexts", 13: "shared_wide_fills", 14: "kpath_chunked_paths", 15: "kpath_stitch_refits",
-                 16: "kpath_chunk_fills", 17: "kpath_chains_last_path"}  # (4-6: mechanisms removed in round 3)
+                 16: "kpath_chunk_fills", 17: "kpath_chains_last_path",
+                 18: "kpath_stitch_giveups"}  # (4-6: mechanisms removed in round 3)
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in names.items()}
 
     def screening(self):

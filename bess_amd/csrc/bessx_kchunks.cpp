@@ -121,6 +121,7 @@ void kchains_free(bessx_session *s) {
 // how many chunk chains for this path (1 = the single chain)
 static int chains_for(const bessx_session *s, int ns, bool link = false) {
   int C = s->kpath_chains;
+  if (C == 0 && s->kch_auto_off) return 1;  // (this session's chunks do not merge: see the stitch's budget)
   if (C == 0 && link && s->model_type == 1 && ns < 96) {
     // a link of a longer chain (a rank's chunk of a multi-GPU k-path): shorter, so fewer chains
     C = (ns >= 40 && s->p >= 2048) ? 2 : 1;
@@ -362,9 +363,16 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     if (run[r].rc) return fail(run[r].rc, "chunk chain: " + run[r].err);
   const auto t_chunks = now();
   // ---- 3. the stitch, in rounds until no chunk's last model changed (bess_amd.dist.StitchedKPath.step)
+  // A chunk whose refit has not met its own chain after `budget` candidates is on another trajectory than the warm
+  // chain (designs with many near-equivalent supports: correlated columns, weak signal) -- re-walking it, and then its
+  // successors round by round, would cost more than the one chain.  The stitch then gives up: everything from the first
+  // unsettled chunk on is walked as ONE chain from its predecessor's last model, and the session's automatic choice
+  // becomes one chain.
   std::vector<char> need((size_t)C, 1), changed((size_t)C, 0);
   need[0] = 0;
   long long refits = 0;
+  int give_up_from = -1;
+  auto budget_of = [&](int r) { return std::max(8, (run[r].hi - run[r].lo) / 6); };
   for (int round = 1;; round++) {
     std::vector<ChunkRun> st((size_t)C);
     std::vector<std::vector<int>> pred_idx((size_t)C);
@@ -398,7 +406,8 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
       t.chain.last_cap = width;
       t.rc = hipSetDevice(s->device) == hipSuccess ? context_begin(c) : fail(BESSX_ERR_HIP, "hipSetDevice");
       c->timing = s->timing;
-      if (t.rc == 0) t.rc = sequential_path(c, seq + q.lo, q.hi - q.lo, &lambda, 1, ic_type, 0, &t.res, &t.chain);
+      if (t.rc == 0)
+        t.rc = sequential_path(c, seq + q.lo, std::min(q.hi - q.lo, budget_of(r)), &lambda, 1, ic_type, 0, &t.res, &t.chain);
       if (t.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) t.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
       if (t.rc) t.err = g_err;
       t.fits = c->n_fits;
@@ -431,7 +440,10 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
       }
       refits += m;
       q.fits += t.fits;
-      if (t.chain.stopped_at < 0) {  // the whole chunk was replaced: its last model is a new one
+      if (t.chain.stopped_at < 0 && m < q.hi - q.lo) {
+        // out of budget without meeting the chunk's own chain
+        if (give_up_from < 0 || r < give_up_from) give_up_from = r;
+      } else if (t.chain.stopped_at < 0) {  // the whole (short) chunk was replaced: its last model is a new one
         changed[r] = 1;
         any = true;
         q.last_idx = t.last_idx;
@@ -440,10 +452,46 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
         q.last_coef0 = t.chain.last_coef0;
       }
     }
+    if (give_up_from >= 0) {
+      // a chunk behind one whose last model changed in this round was refitted from the old model: unsettled too
+      for (int r = 1; r < give_up_from; r++)
+        if (changed[r] && r + 1 < give_up_from) give_up_from = r + 1;
+      break;
+    }
     if (!any) break;
     if (round > C) return fail(BESSX_ERR_NUMERIC, "chunk chains: the stitching did not settle");
     for (int r = 1; r < C; r++) need[r] = changed[r - 1];
   }
+  if (give_up_from >= 1) {
+    // the rest as ONE chain on the session's own state, from the last settled chunk's last model, on the warm cache
+    const int f = give_up_from;
+    ChunkRun tail;
+    tail.shape(bounds[f], ns, width, s->p_full);
+    tail.bind(&tail.res);
+    tail.chain = bessx_path_chain();
+    tail.chain.init_idx = run[f - 1].last_idx.data();
+    tail.chain.init_val = run[f - 1].last_val.data();
+    tail.chain.init_len = run[f - 1].last_len;
+    tail.chain.init_coef0 = run[f - 1].last_coef0;
+    tail.chain.keep_caches = 1;
+    tail.chain.last_idx = tail.last_idx.data();
+    tail.chain.last_val = tail.last_val.data();
+    tail.chain.last_cap = width;
+    kchains_quiesce(s);
+    if (int rc = settle_device_chain(s)) return rc;
+    for (auto &q : s->cache) q.valid = false;
+    s->dev_state_rs = -1;
+    const long long fits_before = s->n_fits;
+    if (int rc = sequential_path(s, seq + bounds[f], ns - bounds[f], &lambda, 1, ic_type, 0, &tail.res, &tail.chain)) return rc;
+    tail.last_len = tail.chain.last_len;
+    tail.last_coef0 = tail.chain.last_coef0;
+    tail.fits = s->n_fits - fits_before;
+    run.resize((size_t)f);
+    run.push_back(std::move(tail));
+    s->kch_giveups++;
+    if (s->kpath_chains == 0) s->kch_auto_off = true;
+  }
+  const int R = (int)run.size();  // chunks of the result (fewer than C after a give-up)
   s->kch_t[0] += secs(t_begin, t_coarse);
   s->kch_t[1] += secs(t_coarse, t_chunks);
   s->kch_t[2] += secs(t_chunks, now());
@@ -451,7 +499,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   res->n_candidates = 0;
   int best_r = 0, best_i = 0;
   long long iters_path = 0, fits_all = coarse_fits;
-  for (int r = 0; r < C; r++) {
+  for (int r = 0; r < R; r++) {
     const ChunkRun &q = run[r];
     fits_all += q.fits;
     for (int i = 0; i < q.hi - q.lo; i++) {
@@ -518,7 +566,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   for (auto &q : s->cache) q.valid = false;
   s->dev_state_rs = -1;
   if (link) {  // the model the link's successor starts from
-    const ChunkRun &q = run[C - 1];
+    const ChunkRun &q = run[R - 1];
     link->last_len = q.last_len;
     link->last_coef0 = q.last_coef0;
     for (int i = 0; i < q.last_len && i < link->last_cap; i++) {
@@ -528,7 +576,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   }
   // Algorithm state as the path leaves it: the last candidate's model (normalised scale)
   {
-    const ChunkRun &q = run[C - 1];
+    const ChunkRun &q = run[R - 1];
     s->beta.idx.assign(q.last_idx.begin(), q.last_idx.begin() + q.last_len);
     s->beta.val.assign(q.last_val.begin(), q.last_val.begin() + q.last_len);
     s->coef0 = q.last_coef0;

@@ -921,6 +921,7 @@ int bessx_session_cov_prefill_end(bessx_session *s) {
 int bessx_session_set_kpath_chains(bessx_session *s, int chains) {
   if (!s || chains < 0 || chains > 8) return fail(BESSX_ERR_ARG, "set_kpath_chains: 0 (automatic) .. 8");
   s->kpath_chains = chains;
+  s->kch_auto_off = false;  // (an explicit choice, 0 included, is tried afresh)
   return BESSX_OK;
 }
 

@@ -1734,6 +1734,7 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 15: return s->kch_refits;
     case 16: return s->kch_chunk_fills;
     case 17: return s->kch_last_chains;
+    case 18: return s->kch_giveups;
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

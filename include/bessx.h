@@ -165,7 +165,9 @@ int bessx_session_score_mode(const bessx_session *s);
  * alive now (K when the fold fits of a CV evaluation run side by side, else 0), 13 fills of a parked fit that went
  * through the fill hook (bessx_session_set_fill_hook), 14 sequential paths run as chunk chains side by side
  * (BESSX_KPATH_CHAINS), 15 candidates re-fitted by their stitching, 16 fills of the shared cache
- * during the chunk phase, 17 chains of the last such path.  -1 for an unknown id. */
+ * during the chunk phase, 17 chains of the last such path, 18 paths whose stitch gave up (a chunk's refit did not meet its
+ * own chain within its budget: the rest of the path was walked as one chain, and the automatic choice of this session is
+ * one chain from then on).  -1 for an unknown id. */
 long long bessx_session_counter(const bessx_session *s, int which);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)

@@ -259,3 +259,37 @@ def test_the_number_of_chains_can_change_between_paths(gpu, monkeypatch):
                 assert s.counters()["kpath_chains_last_path"] == chains
         with pytest.raises(Exception):
             s.set_kpath_chains(9)
+
+
+def test_the_stitch_gives_up_where_the_chunks_do_not_merge(gpu, monkeypatch):
+    """Correlated columns, weak signal, a long path: the chunks' own chains run on other trajectories than the warm chain.
+    A refit that has not met its chunk within its budget ends the stitch -- the rest of the path is walked as one chain
+    from the last settled model (still the single chain's candidates) -- and the session's automatic choice becomes one
+    chain; an explicit bessx_session_set_kpath_chains tries again."""
+    monkeypatch.delenv("BESSX_KPATH_CHAINS", raising=False)
+    rng = np.random.default_rng(3)
+    n, p = 4000, 2400
+    Z = rng.standard_normal((n, p))
+    X = Z.copy()
+    for j in range(1, p):
+        X[:, j] = 0.6 * X[:, j - 1] + 0.8 * Z[:, j]
+    beta = np.zeros(p)
+    beta[rng.choice(p, 60, replace=False)] = rng.uniform(0.2, 1.0, 60) * rng.choice([-1.0, 1.0], 60)
+    y = X @ beta + 2.0 * rng.standard_normal(n)
+    seq = np.arange(1, 161)
+    with gpu.Session(X, y) as s:
+        s.set_kpath_chains(1)
+        single = s.sequential_path(seq, ic_type=3)
+        s.set_kpath_chains(0)                      # automatic: chunk chains are tried ...
+        first = s.sequential_path(seq, ic_type=3)
+        c1 = s.counters()
+        assert c1["kpath_chunked_paths"] == 1 and c1["kpath_stitch_giveups"] == 1
+        second = s.sequential_path(seq, ic_type=3)  # ... once
+        c2 = s.counters()
+        assert c2["kpath_chunked_paths"] == 1
+        s.set_kpath_chains(4)                      # an explicit choice is honoured (and gives up again, per path)
+        third = s.sequential_path(seq, ic_type=3)
+        c3 = s.counters()
+        assert c3["kpath_chunked_paths"] == 2 and c3["kpath_stitch_giveups"] == 2
+    for out in (first, second, third):
+        _same_path(out, single)
