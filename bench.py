@@ -83,18 +83,23 @@ def parse_args(argv=None):
                          "levels k0/8, k0/4, k0/2 first (their candidates are discarded); auto = ladder from k0 = 128 "
                          "(measured on configs[1], tools/coldstart.py: 11.2 vs 12.2 ms at k0 = 176, but 7.9 vs 7.2 ms at "
                          "k0 = 101)")
-    ap.add_argument("--prefill", default="auto",
+    ap.add_argument("--prefill", default="0",
                     help="N > 1, --shard kpath, LM covariance form: columns of the cooperative prefill of the Gram column "
                          "caches in front of the chunks (bess_amd.dist.cooperative_prefill: the ranks share the passes "
-                         "over X their cold starts would repeat; ONE data-path all-gather of p x 32 blocks).  0 = "
-                         "replicas only, as north_star partitions the path; auto = 320 for lm-seq, 0 otherwise")
-    ap.add_argument("--pilot", default="auto",
+                         "over X their cold starts would repeat; ONE data-path all-gather of p x 32 blocks).  0 (default) "
+                         "= replicas only, as north_star partitions the path: the collectives carry the IC curve and the "
+                         "chunks' last models, nothing else; auto = the measured policy (320 columns from 3 ranks on)")
+    ap.add_argument("--coop-variant", action="store_true",
+                    help="N > 1, lm-seq: after the timed region of the default partition, time the SAME steps once more "
+                         "with --prefill auto --pilot auto (Gram column blocks all-gathered between the ranks) and report "
+                         "it as a second figure, `cooperative_prefill_variant`, in the same line")
+    ap.add_argument("--pilot", default="none",
                     help="with the prefill: 'K,M2[,W]' = every rank runs the same pilot fit of sparsity level K on the "
                          "prefilled cache -- with W its own fills are shared too (W columns per fill: the missing ones and "
                          "the best uncached ones by that iteration's scores, one 32-column group per rank; "
                          "bessx_session_set_fill_hook) --, the M2 uncached columns its final scores rank highest are shared "
                          "as a second list and the chunks beyond K start warm from the pilot's model "
-                         "(bess_amd.dist.pilot_prefill); 'none'; auto = K = 0.64 kmax rounded to 32, prefill K, M2 = 0, "
+                         "(bess_amd.dist.pilot_prefill); 'none' (default); auto = K = 0.64 kmax rounded to 32, prefill K, M2 = 0, "
                          "W = 32 per rank (tools/coop_prefill.py, 8 ranks: slowest 5.2-5.6 ms against 7.5 ms without the "
                          "shared fills in the pilot, 9.5 ms with the marginal list alone, 12.8 ms without a prefill)")
     ap.add_argument("--rebalance", choices=["auto", "on", "off"], default="auto",
@@ -400,13 +405,22 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
                                                 "an earlier run of this kernel at this size, not measured in this run)"
                                                 if traffic else None)},
             "whole_path_frac_of_hbm": passes * 8.0 * n * p / dt / 1e9 / HBM_PEAK_GBPS,
-            "time_share": {"kernel_streaming_X": k1["seconds"] / dt, "rest_of_the_chain_and_host": 1.0 - k1["seconds"] / dt},
+            # kernels of different chains overlap: the SUM of the score kernel's launch durations can exceed the wall time
+            # of the path (round 4 printed 1 - sum / wall as a "share" and got negative time).  Reported as what was
+            # measured: the wall time, the summed kernel time, their ratio; a share only where nothing overlaps.
+            "time": dict({"wall_ms": 1e3 * dt, "summed_score_kernel_ms": 1e3 * k1["seconds"],
+                          "summed_score_kernel_over_wall": k1["seconds"] / dt}),
             "selected_k": int(out["best_T0"]), "criterion": float(out["ic"]),
         }
+        cnt = sess.counters()
+        overlapped = cnt.get("kpath_chunked_paths", 0) > 0 or cnt.get("cv_side_by_side_rounds", 0) > 0
+        rec["time"]["chains_side_by_side"] = bool(overlapped)
+        if not overlapped:
+            rec["time"]["rest_of_the_chain_and_host_share"] = max(0.0, 1.0 - k1["seconds"] / dt)
         if steps:
             rec["submodel_steps"] = int(steps)
-            rec["us_per_submodel_step_incl_iteration_overheads"] = 1e6 * (dt - k1["seconds"]) / steps
-        cnt = sess.counters()
+            if not overlapped:
+                rec["us_per_submodel_step_incl_iteration_overheads"] = 1e6 * max(0.0, dt - k1["seconds"]) / steps
         if cnt.get("kpath_chunked_paths", 0) > 0:
             # the path ran as chunk chains side by side (bessx_kchunks.cpp): the same path as ONE chain on the same session
             # beside it (the kernel statistics above are the chunked run's: passes of several chains share the device)
@@ -414,15 +428,20 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
             run()
             sess.enable_kernel_timing(True)
             sess.score_pass_stats(reset=True)
+            sess.submodel_steps(reset=True)
             torch.cuda.synchronize()
             t1 = time.time()
             o1 = run()
             torch.cuda.synchronize()
             d1 = time.time() - t1
             k11 = sess.score_pass_stats()
+            steps1 = sess.submodel_steps()
             sess.enable_kernel_timing(False)
             sess.set_kpath_chains(0)
             p1 = k11["algorithmic_bytes"] / (8.0 * n * p)
+            if steps1:  # one chain: nothing overlaps, the remainder of the wall time is the sub-model chain + host
+                rec["us_per_submodel_step_incl_iteration_overheads"] = 1e6 * max(0.0, d1 - k11["seconds"]) / steps1
+                rec["us_per_submodel_step_measured_on"] = "the single chain (%d steps)" % steps1
             rec["chunk_chains"] = {
                 "chains": cnt["kpath_chains_last_path"],
                 "stitch_refits_per_path": cnt["kpath_stitch_refits"] / float(cnt["kpath_chunked_paths"]),
@@ -685,25 +704,32 @@ def main():
     out = None
     stitch = None
     # N > 1, k-path: the chunks are stitched into the single warm-start chain every step (bess_amd.dist.StitchedKPath)
-    prefill, pilot = 0, None
-    if kpath and covariance and not cox:
-        # measured on configs[1] (tools/coop_prefill.py, profiles/r04_lm_kpath_*_one_gpu.jsonl): 2 ranks lose with any
-        # prefill (15.0 ms without, 16.1 with 320 columns); 4 ranks: pilot 10.0 ms, marginal list 11.8, none 13.4;
-        # 8 ranks: pilot 7.5 ms, marginal list 9.5, none 11.6
+    def prefill_policy(opt_prefill, opt_pilot):
+        """(prefill columns, pilot) of the k-path's optional cooperative prefill.  The DEFAULT (--prefill 0 --pilot none)
+        is north_star's partition: replicas only.  "auto" = the policy measured on configs[1] (tools/coop_prefill.py,
+        profiles/r04_lm_kpath_*_one_gpu.jsonl; one-device rehearsals, never on N devices): 2 ranks lose with any prefill
+        (15.0 ms without, 16.1 with 320 columns); 4 ranks: pilot 10.0 ms, marginal list 11.8, none 13.4; 8 ranks: pilot
+        7.5 ms, marginal list 9.5, none 11.6."""
+        pf, pl = 0, None
+        if not (kpath and covariance and not cox):
+            return pf, pl
         kp = int(round(0.64 * args.kmax / 32.0)) * 32
         wide = 32 * world
-        if args.pilot not in ("auto", "none"):
-            v = [int(q) for q in args.pilot.split(",")]
-            pilot = (v[0], v[1] // 32 * 32) + ((v[2] // 32 * 32,) if len(v) > 2 else ())
-        elif args.pilot == "auto" and 32 <= kp <= args.kmax - 8 and args.p >= 4 * (kp + 32 + 2 * wide):
-            pilot = (kp, 0, wide)
-        if args.prefill == "auto":
-            prefill = pilot[0] if pilot else (320 if world >= 3 else 0)
+        if opt_pilot not in ("auto", "none"):
+            v = [int(q) for q in opt_pilot.split(",")]
+            pl = (v[0], v[1] // 32 * 32) + ((v[2] // 32 * 32,) if len(v) > 2 else ())
+        elif opt_pilot == "auto" and world >= 4 and 32 <= kp <= args.kmax - 8 and args.p >= 4 * (kp + 32 + 2 * wide):
+            pl = (kp, 0, wide)
+        if opt_prefill == "auto":
+            pf = pl[0] if pl else (320 if world >= 3 else 0)
         else:
-            prefill = int(args.prefill)
-        prefill = max(0, min(prefill, (args.p // 64) * 32, 1024)) // 32 * 32
-        if not prefill and not (pilot and len(pilot) > 2):
-            pilot = None
+            pf = int(opt_prefill)
+        pf = max(0, min(pf, (args.p // 64) * 32, 1024)) // 32 * 32
+        if not pf and not (pl and len(pl) > 2):
+            pl = None
+        return pf, pl
+
+    prefill, pilot = prefill_policy(args.prefill, args.pilot)
     any_ladder = False
     if kpath:
         k0_last = int(full_seq[bdist.partition(args.kmax, world, world - 1)[0]]) if args.kmax >= world else 0
@@ -744,6 +770,32 @@ def main():
     dt = max_over_ranks(time.time() - t0)
     k1 = sess.score_pass_stats()
     sess.enable_kernel_timing(False)
+
+    coop_variant = None
+    if kpath and args.coop_variant and covariance and not cox:
+        # opt-in second figure: the same steps with the cooperative prefill / pilot policy ("auto"), i.e. WITH the
+        # data-path all-gathers of Gram column blocks north_star's partition does not have
+        pf2, pl2 = prefill_policy("auto", "auto")
+        if pf2 or pl2:
+            st2 = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=[], device=comm_dev, prefill=pf2,
+                                      pilot=pl2, rebalance=False)
+            for _ in range(args.warmup):
+                st2.step()
+            barrier()
+            t2 = time.time()
+            for _ in range(args.steps):
+                r2 = st2.step()
+            barrier()
+            dt2 = max_over_ranks(time.time() - t2)
+            coop_variant = {"value": args.kmax * args.steps / dt2, "unit": "candidates/s",
+                            "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps, "prefill_columns": pf2,
+                            "pilot": list(pl2) if pl2 else None,
+                            "ic_curve_equal_to_default_partition": bool(np.allclose(r2["ic_curve"], ic_curves[0],
+                                                                                    rtol=1e-10, atol=0.0)),
+                            "collective": "as the default + all_gathers of p x 32 Gram column blocks (%d bytes per rank "
+                                          "and list)" % (max(pf2, 32) * args.p * 8)}
+        else:
+            coop_variant = {"value": None, "what": "the measured policy asks for no prefill at this N / size"}
 
     chunk_report = None
     if kpath:
@@ -875,6 +927,8 @@ def main():
         }
         if chunk_report:
             line["kpath_chunks_vs_single_chain"] = chunk_report
+        if coop_variant:
+            line["cooperative_prefill_variant"] = coop_variant
         norm = sess.normalization() if world == 1 else None
         cnt = sess.counters() if world == 1 else {}
         if world == 1 and cnt.get("kpath_chunked_paths", 0) > 0:
@@ -993,5 +1047,36 @@ def bench_cv(args, world, rank, local_rank, comm_dev, barrier, max_over_ranks):
         dist.destroy_process_group()
 
 
+def _report_rank_failure(exc):
+    """A rank that dies says so itself: `[rank r] <exception> | bessx_last_error` on stdout, stderr and in a per-rank
+    file (BESSX_BENCH_ERRDIR, default gpurun_out/bench_errors under the repo) -- the launcher's epilogue and the other
+    ranks' secondary "connection closed by peer" tracebacks bury the one message that matters."""
+    import traceback
+    rank = os.environ.get("RANK", "0")
+    last = ""
+    try:
+        from bess_amd import capi
+        last = capi.last_error()
+    except Exception as e2:  # (the library itself may be what failed)
+        last = "<bessx_last_error unavailable: %r>" % (e2,)
+    head = "[rank %s] %s: %s | bessx_last_error: %s" % (rank, type(exc).__name__, exc, last)
+    text = head + "\n" + "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))
+    print(head, flush=True)
+    print(text, file=sys.stderr, flush=True)
+    try:
+        d = os.environ.get("BESSX_BENCH_ERRDIR") or os.path.join(ROOT, "gpurun_out", "bench_errors")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "rank%s_pid%d.err" % (rank, os.getpid())), "w") as f:
+            f.write("argv: %s\n%s" % (json.dumps(sys.argv), text))
+    except OSError:
+        pass
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:  # noqa: BLE001 -- reported, then the rank exits non-zero
+        _report_rank_failure(exc)
+        sys.exit(1)

@@ -146,6 +146,11 @@ def lib():
     return _lib
 
 
+def last_error():
+    """Text of the calling thread's last library error (bessx_last_error)."""
+    return lib().bessx_last_error().decode("utf-8", "replace")
+
+
 def _check(rc):
     if rc != 0:
         raise BessxError(rc, lib().bessx_last_error().decode("utf-8", "replace"))
@@ -285,7 +290,7 @@ class Session:
                  8: "cv_union_fills", 9: "tie_rescues", 10: "cache_restarts", 11: "cv_contexts_dropped",
                  12: "cv_fold_contexts", 13: "shared_wide_fills", 14: "kpath_chunked_paths", 15: "kpath_stitch_refits",
                  16: "kpath_chunk_fills", 17: "kpath_chains_last_path",
-                 18: "kpath_stitch_giveups"}  # (4-6: mechanisms removed in round 3)
+                 18: "kpath_stitch_giveups", 19: "group_XTX_ns"}  # (4-6: mechanisms removed in round 3)
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in names.items()}
 
     def screening(self):

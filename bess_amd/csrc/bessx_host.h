@@ -369,6 +369,7 @@ struct bessx_session {
   long long kch_paths = 0, kch_refits = 0, kch_chunk_fills = 0;  // paths run chunked, stitch refits, fills in the chunk phase
   int kch_last_chains = 0;              // chains of the last chunked path
   bool kch_auto_off = false;            // the chunks of a path did not merge with the chain: the automatic choice is one chain
+  long long group_xtx_ns = 0;           // device time of the all-rows group_XTX pass at session creation (LM)
   long long kch_giveups = 0;            // paths whose stitch ran out of budget (the rest was walked as one chain)
   double kch_t[3] = {0, 0, 0};          // BESSX_DEBUG: seconds in the coarse chain / the chunks / the stitch
   bessx_fill_hook fill_hook = nullptr;  // shared wide fills of a parked fit (bessx_session_set_fill_hook)

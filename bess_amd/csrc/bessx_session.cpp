@@ -288,6 +288,14 @@ int reset_path_caches(bessx_session *s) {
     HIPX(hipMemsetAsync(c.slot_of, 0xff, (size_t)s->p * sizeof(int), s->st));
     HIPX(hipMemsetAsync(c.meta, 0, 8 * sizeof(int), s->st));
   }
+  // The maps are shared with the fold and chunk-chain contexts, which run on streams of their own: the clearing must be
+  // COMPLETE before any of them looks a column up.  (Round 4 left it queued on s->st.  A path whose first work on this
+  // session is a set of fold fits -- a rank of a fold-sharded CV path that owns no full-data fit,
+  // bessx_session_cv_eval(want_full = 0) -- then read the previous path's map while the memset was still waiting in
+  // its queue, kept solving on slots that were handed out anew, and failed with "an active column was missing from
+  // the Gram column cache": once in ~130 two-rank rehearsals on a loaded box, GPUTEST_r04.  Regression test:
+  // tests/test_cv_shard_gpu.py::test_cache_reset_is_complete_before_the_fold_chains_read_the_map.)
+  HIPX(hipStreamSynchronize(s->st));
   return 0;
 }
 
@@ -1172,7 +1180,21 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   }
   HIPT(dmalloc(&s->idcols, (size_t)capA + 16));
   if (s->model_type == 4) HIPT(cox_alloc(s));
-  if (s->model_type == 1) TRY(prepare_rowset(s, 0));
+  if (s->model_type == 1) {
+    // group_XTX of the all-rows set (X^T y, diag(X^T X): one pass over X, src/path.cpp:37 -- the reference pays it
+    // inside every path call, here once per session): its device time is kept for the bench line (counter 19)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (timed) (void)hipEventRecord(e0, s->st);
+    const int rc_xtx = prepare_rowset(s, 0);
+    if (timed && rc_xtx == 0 && hipEventRecord(e1, s->st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) s->group_xtx_ns = (long long)(1e6 * (double)ms);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    TRY(rc_xtx);
+  }
   HIPT(hipStreamSynchronize(s->st));
 #undef TRY
 #undef HIPT
@@ -1735,6 +1757,7 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 16: return s->kch_chunk_fills;
     case 17: return s->kch_last_chains;
     case 18: return s->kch_giveups;
+    case 19: return s->group_xtx_ns;
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

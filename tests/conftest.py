@@ -12,6 +12,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the `-m gpu` suite (the driver runs it with `-x`): single kernels against the oracle first, then the
+# golden fixtures, the full-size configurations, the families, the covariance / CV / chunk-chain / stitch machinery,
+# the single-process bench contract -- and every file that starts OTHER processes on the device last.  (Round 4: a
+# flaky 2-rank rehearsal sorted second alphabetically and hid 383 parity tests.)  Files not named here keep their
+# alphabetical place between the two lists.
+_ORDER_FIRST = [
+    "test_ops_gpu.py", "test_lm_gpu.py", "test_golden_gpu.py", "test_fullsize_gpu.py", "test_fullsize_families_gpu.py",
+    "test_glm_gpu.py", "test_cox_gpu.py", "test_ties_gpu.py", "test_rank_deficient_gpu.py", "test_group_expand_gpu.py",
+    "test_wide_groups_gpu.py", "test_screening_gpu.py", "test_edge_gpu.py", "test_limits_gpu.py", "test_cov_gpu.py",
+    "test_cv_side_by_side_gpu.py", "test_cv_shard_gpu.py", "test_kchunks_gpu.py", "test_stitch_gpu.py",
+    "test_r_boundary_gpu.py", "test_c_caller_gpu.py", "test_fuzz_gpu.py",
+]
+_ORDER_LAST = ["test_bench_contract_gpu.py", "test_deadline_gpu.py", "test_nccl_ranks_gpu.py", "test_zz_bench_ranks_gpu.py"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = os.path.basename(str(item.fspath))
+        if name in _ORDER_FIRST:
+            return (0, _ORDER_FIRST.index(name))
+        if name in _ORDER_LAST:
+            return (2, _ORDER_LAST.index(name))
+        return (1, 0)
+    items.sort(key=key)  # (stable: the order inside a file, and of unnamed files, is pytest's own)
+
+
 def _gpu_available():
     try:
         import torch

@@ -41,6 +41,60 @@ def assert_same_trace(got, want, beta_rtol=1e-6, what="", ic_atol=1e-9):
     np.testing.assert_allclose(got["loss_calls"], want["loss_calls"], rtol=1e-9, atol=1e-12, err_msg=what + " loss values")
 
 
+def golden_final_models(g):
+    """Per fit of a golden file of tests/golden/make_fullsize_ref.py: (support, coefficients, intercept) of its LAST
+    PDAS iteration -- the candidate's model, in the reference's internal (normalised) scale."""
+    out, off, it_off = [], 0, 0
+    for it, t in zip(g["fit_iters"], g["fit_T0"]):
+        last = off + (int(it) - 1) * int(t)
+        out.append((g["A_flat"][last:last + t], g["beta_flat"][last:last + t], float(g["coef0_flat"][it_off + int(it) - 1])))
+        off += int(it) * int(t)
+        it_off += int(it)
+    return out
+
+
+def assert_untraced_path_matches_golden(out, g, X, data_type, what, beta_rtol=1e-6, metric_rtol=1e-9):
+    """An UNTRACED path (what the bench times: chained fits, chunk chains, fused launches -- tracing switches those off)
+    against the compiled reference's golden: every candidate's final support bit-exact, its PDAS iteration count,
+    coefficients to beta_rtol, loss / criterion to metric_rtol, and the selected model.  The golden's coefficients are
+    the reference's internal ones; the path returns them de-normalised (src/path.cpp:76-110), so the golden is brought
+    to the caller's scale with a NumPy restatement of Normalize (src/normalize.cpp:20-85) on the columns involved."""
+    models = golden_final_models(g)
+    nfit = len(models)
+    truncated = int(g["truncated"]) if "truncated" in g.files else 0
+    label = "%s (%s%d candidates of the compiled reference)" % (what, "first " if truncated else "", nfit)
+    assert out["n_candidates"] >= nfit, label
+    assert list(out["cand_T0"][:nfit]) == list(g["fit_T0"]), label + ": order of sparsity levels"
+    assert list(out["cand_iters"][:nfit]) == list(g["fit_iters"]), label + ": PDAS iterations per candidate"
+    n = X.shape[0]
+    cols = np.unique(np.concatenate([m[0] for m in models]))
+    Xc = np.asarray(X[:, cols], dtype=np.float64)
+    mean = Xc.mean(axis=0) if data_type in (1, 2) else np.zeros(cols.size)
+    Xc = Xc - mean
+    norm = np.sqrt((Xc * Xc).sum(axis=0))
+    pos = {int(c): i for i, c in enumerate(cols)}
+    bscale = max(float(np.max(np.abs(m[1]))) for m in models)
+    for i, (A, b, c0) in enumerate(models):
+        t = len(A)
+        assert np.array_equal(out["cand_support"][i][:t], A), "%s: candidate %d (T0=%d) support" % (label, i, t)
+        assert np.all(out["cand_support"][i][t:] == -1)
+        ix = np.array([pos[int(c)] for c in A])
+        got_internal = out["cand_beta"][i][:t] * norm[ix] / np.sqrt(n)
+        np.testing.assert_allclose(got_internal, b, rtol=beta_rtol, atol=beta_rtol * bscale,
+                                   err_msg="%s: candidate %d coefficients" % (label, i))
+        if data_type == 2:  # coef0 - beta . x_mean
+            want_c0 = c0 - float(np.dot(out["cand_beta"][i][:t], mean[ix]))
+            np.testing.assert_allclose(out["cand_coef0"][i], want_c0, rtol=beta_rtol, atol=beta_rtol * max(bscale, 1.0),
+                                       err_msg="%s: candidate %d intercept" % (label, i))
+    np.testing.assert_allclose(out["cand_ic"][:nfit], g["ic_calls"][:nfit], rtol=metric_rtol, err_msg=label + " ic")
+    np.testing.assert_allclose(out["cand_train_loss"][:nfit], g["loss_calls"][:nfit], rtol=metric_rtol,
+                               err_msg=label + " loss")
+    if not truncated:
+        assert np.array_equal(np.nonzero(out["beta"])[0], g["best_beta_idx"]), label + ": selected model"
+        np.testing.assert_allclose(out["beta"][g["best_beta_idx"]], g["best_beta_val"], rtol=beta_rtol)
+    return nfit
+
+
 class NumpyLmSession:
     """CPU stand-in for bess_amd.capi.Session in the multi-rank HOST-LOGIC tests (gloo): the LM fit primitive
     (Algorithm::fit with GroupPdasLm::get_A / primary_model_fit, src/Algorithm.h:113-171, :1097-1135, singleton

@@ -179,3 +179,37 @@ def test_cv_eval_records(gpu):
             a.cv_eval(6, 0.0, False, folds=[3, 1])
         with pytest.raises(gpu.BessxError):
             a.cv_eval(6, 0.0, False, folds=[4])
+
+
+def test_cache_reset_is_complete_before_the_fold_chains_read_the_map(gpu):
+    """Round 4's one red driver run (GPUTEST_r04: rank 0 of `bench.py --gpus 2 --workload lm-cv-gs`, "an active column was
+    missing from the Gram column cache").  bessx_session_reset_caches cleared the shared slot map with memsets queued on
+    the session's stream; a rank that owns no full-data fit starts its next path with fold chains on streams of their
+    own, which could read the previous path's map before the memsets ran.  Here the window is held open: the session's
+    stream is blocked for 300 ms (test hook), the caches are reset, and fold-only evaluations follow at once -- the
+    records must be those of a session that was never blocked."""
+    import time
+    X, y, _, _ = synth.make_lm(3000, 800, 10)
+    fold = synth.make_cv_folds(3000, 5)
+    folds = [0, 2, 4]
+    first = [12, 19, 8, 5, 6, 7, 8, 9, 10, 11]  # the golden-section points and the start of the sweep of bench's rehearsal
+    with gpu.Session(X, y, score_mode=2) as a, gpu.Session(X, y, score_mode=2) as b:
+        for s in (a, b):
+            s.set_cv(5, fold)
+            for T0 in first:  # a first path leaves its columns in the cache and its map behind
+                s.cv_eval(T0, 0.0, False, folds=folds)
+        a.debug_block_stream(300)
+        a.reset_caches()
+        t0, seq, got = time.time(), [], []
+        while time.time() - t0 < 0.6 or len(seq) < 2 * len(first):
+            T0 = first[len(seq) % len(first)]
+            seq.append(T0)
+            got.append(a.cv_eval(T0, 0.0, False, folds=folds))
+        b.reset_caches()
+        for T0, recs in zip(seq, got):
+            want = b.cv_eval(T0, 0.0, False, folds=folds)
+            for r, w in zip(recs, want):
+                np.testing.assert_array_equal(r["support"], w["support"])
+                assert r["iters"] == w["iters"]
+                np.testing.assert_allclose(r["beta"], w["beta"], rtol=1e-9)
+                np.testing.assert_allclose([r["train_loss"], r["test_loss"]], [w["train_loss"], w["test_loss"]], rtol=1e-10)

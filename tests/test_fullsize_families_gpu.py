@@ -22,7 +22,7 @@ import pytest
 from bess_amd import synth
 from bess_amd import dist as bdist
 
-from helpers import hooks  # noqa: E402
+from helpers import assert_untraced_path_matches_golden, hooks  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -121,6 +121,26 @@ def test_logistic_config_matches_compiled_reference_at_full_size(logistic_full):
     assert_best_model(out, g)
 
 
+def test_logistic_benchmarked_path_matches_compiled_reference_at_full_size(gpu, logistic_full):
+    """The UNTRACED path bench.py times (tracing switches the chunk chains off): chain count automatic, one chain and
+    three chains forced -- every candidate's final support, iteration count, coefficients, intercept, loss and criterion
+    against the compiled reference's golden."""
+    g = _gold("fullsize_logistic.npz")
+    s = logistic_full[0]
+    X, y, _, _ = synth.make_logistic()
+    s.trace_enable(False)
+    try:
+        for chains in (0, 1, 3):
+            s.set_kpath_chains(chains)
+            out = s.sequential_path(np.arange(1, 101), ic_type=3)
+            assert_untraced_path_matches_golden(out, g, X, 2, "configs[2] untraced, chains=%d" % chains, metric_rtol=1e-8)
+            if chains == 3:
+                assert s.counters()["kpath_chains_last_path"] == 3
+    finally:
+        s.set_kpath_chains(0)
+        s.trace_enable(True)
+
+
 # ------------------------------------------------------------------------------------ Poisson (SURVEY 8f rank 1)
 @pytest.fixture(scope="module")
 def poisson_full(gpu):
@@ -161,6 +181,21 @@ def test_poisson_matches_compiled_reference_at_full_size(poisson_full):
     nfit = assert_matches_golden(out["trace"], g, "Poisson n=100000 p=5000", beta_rtol=1e-6)
     assert nfit >= 20
     assert_best_model(out, g)
+
+
+def test_poisson_benchmarked_path_matches_compiled_reference_at_full_size(gpu, poisson_full):
+    g = _gold("fullsize_poisson.npz")
+    s = poisson_full[0]
+    X, y, _, _ = synth.make_poisson()
+    s.trace_enable(False)
+    try:
+        for chains in (0, 1, 3):
+            s.set_kpath_chains(chains)
+            out = s.sequential_path(np.arange(1, 101), ic_type=3)
+            assert_untraced_path_matches_golden(out, g, X, 2, "Poisson untraced, chains=%d" % chains, metric_rtol=1e-8)
+    finally:
+        s.set_kpath_chains(0)
+        s.trace_enable(True)
 
 
 # ------------------------------------------------------------------------------------------------ configs[3]
@@ -237,6 +272,21 @@ def test_cox_config_recipe_matches_compiled_reference_at_n4000(gpu):
         assert_matches_golden(out["trace"], g, "configs[4] recipe at n=%d p=%d, %s score" % (n, p, form),
                               beta_rtol=1e-5, metric_rtol=1e-7)
         assert_best_model(out, g, rtol=1e-5)
+
+
+def test_cox_benchmarked_path_matches_compiled_reference_at_n4000(gpu):
+    """The same golden against the UNTRACED Cox path: one chain, and chunk chains forced (2, 3)."""
+    g = _gold("fullsize_cox_n4000.npz")
+    n, p, ktrue, kmax = int(g["n"]), int(g["p"]), int(g["k_true"]), int(g["kmax"])
+    X, _, status, support, _ = synth.make_cox(n, p, ktrue)
+    with gpu.Session(X, status, data_type=3, model_type=4) as s:
+        for chains in (1, 2, 3, 0):
+            s.set_kpath_chains(chains)
+            out = s.sequential_path(np.arange(1, kmax + 1), ic_type=3)
+            assert_untraced_path_matches_golden(out, g, X, 3, "configs[4] recipe n=%d untraced, chains=%d" % (n, chains),
+                                                beta_rtol=1e-5, metric_rtol=1e-7)
+            if chains in (2, 3):
+                assert s.counters()["kpath_chains_last_path"] == chains
 
 
 @pytest.fixture(scope="module")

@@ -16,6 +16,8 @@ import pytest
 
 from bess_amd import synth
 
+from helpers import assert_untraced_path_matches_golden  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "fullsize_lm.npz")
 
@@ -69,3 +71,33 @@ def test_matches_compiled_reference_at_full_size(full):
     np.testing.assert_allclose(out["trace"]["loss_calls"][:kmax], g["loss_calls"], rtol=1e-9)
     assert np.array_equal(np.nonzero(out["beta"])[0], g["best_beta_idx"])
     np.testing.assert_allclose(out["beta"][g["best_beta_idx"]], g["best_beta_val"], rtol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def untraced(gpu):
+    """The shipped configurations of configs[1], as bench.py runs them: no trace."""
+    X, y, _, _ = synth.make_lm()
+    outs = {}
+    with gpu.Session(X, y, score_mode=2) as s:
+        for chains in (0, 1, 4, 2):
+            s.set_kpath_chains(chains)
+            outs["covariance, chains=%s" % ("auto" if chains == 0 else chains)] = (
+                s.sequential_path(np.arange(1, 201), ic_type=3), s.counters())
+    with gpu.Session(X, y, score_mode=1) as s:
+        outs["streaming"] = (s.sequential_path(np.arange(1, 201), ic_type=3), s.counters())
+    return X, outs
+
+
+@pytest.mark.parametrize("which", ["covariance, chains=auto", "covariance, chains=1", "covariance, chains=4",
+                                   "covariance, chains=2", "streaming"])
+def test_benchmarked_path_matches_compiled_reference_at_full_size(untraced, which):
+    X, outs = untraced
+    out, counters = outs[which]
+    assert out["trace"] is None or len(out["trace"]["fits"]) == 0  # untraced: nothing was recorded
+    g = np.load(GOLD)
+    n = assert_untraced_path_matches_golden(out, g, X, 1, "configs[1] untraced, " + which)
+    assert n == 200 and out["n_fits"] == 200 and out["n_pdas_iters"] == int(np.sum(g["fit_iters"]))
+    if which == "covariance, chains=1":
+        assert counters["kpath_chains_last_path"] <= 1
+    if which in ("covariance, chains=4", "covariance, chains=2"):
+        assert counters["kpath_chains_last_path"] == int(which[-1]) and counters["kpath_chunked_paths"] >= 1

@@ -276,50 +276,3 @@ def test_pilot_fit_with_shared_wide_fills(gpu, world, n_first):
     model = res[0][3]
     np.testing.assert_array_equal(model["cand_support"], alone["cand_support"])
     np.testing.assert_allclose(model["cand_beta"], alone["cand_beta"], rtol=1e-9, atol=1e-13)
-
-
-def test_rccl_collectives_of_the_sharded_paths_at_world_one(gpu):
-    """The nccl (= RCCL) code path of bess_amd.dist on the one GPU there is: a process group of ONE rank with backend
-    "nccl" -- the all-gather of host records through device tensors, and the device-to-device exchange of Gram column
-    blocks (exported from / imported into the library's cache through the tensors' device pointers).  More ranks need
-    more devices; this pins the calls, dtypes and pointer plumbing the N-rank run uses."""
-    import os
-    import subprocess
-    import sys
-    code = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, %r)
-import torch, torch.distributed as dist
-from bess_amd import capi, synth, dist as bdist
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29713")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-comm = bdist._TorchComm("cuda")
-got = comm.all_gather(np.arange(7.0), 1)
-assert len(got) == 1 and np.array_equal(got[0], np.arange(7.0))
-X, y, _, _ = synth.make_lm(1500, 400, 10)
-seq = np.arange(1, 25)
-with capi.Session(X, y, score_mode=2) as s:
-    plain = s.sequential_path(seq, ic_type=3)
-    cols = np.argsort(-s.marginal_scores(), kind="stable")[:96].astype(np.int32)
-    s.cov_prefill_begin(cols)
-    s.cov_prefill_compute(0, 3)
-    want = s.cov_prefill_export(0, 3)
-    comm.exchange_blocks(s, 1, 0, 3)            # device path: export into a cuda tensor, nccl all_gather
-    buf = torch.empty(3 * 32 * 400, dtype=torch.float64, device="cuda")
-    s.cov_prefill_export(0, 3, device_ptr=buf.data_ptr())
-    assert np.array_equal(buf.cpu().numpy(), want)
-    s.cov_prefill_import(1, 1, device_ptr=buf.data_ptr() + 32 * 400 * 8)   # a block back in through its device pointer
-    assert np.array_equal(s.cov_prefill_export(0, 3), want)
-    s.cov_prefill_end()
-    rep = bdist.StitchedKPath(s, seq, 1, 0, ic_type=3, comm=comm).step()
-assert np.array_equal(rep["chunk"]["cand_support"], plain["cand_support"])
-np.testing.assert_allclose(rep["ic_curve"], plain["cand_ic"], rtol=1e-12)
-dist.destroy_process_group()
-print("NCCL-OK")
-"""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-c", code % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))],
-                         capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0 and "NCCL-OK" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
