@@ -5,7 +5,13 @@ LM sequential path, synthetic Gaussian n=50000, p=10000, s.list = 1..200, GIC, w
 A "step" is one pass of the hot path over one batch: the full 200-candidate path (Algorithm::fit to PDAS
 convergence + train_loss + ic per candidate) on data that is already resident in HBM (upload + normalisation are
 untimed and reported separately; the one pass over X for X^T y / diag(X^T X), which the reference does inside
-sequential_path (src/path.cpp:37), happens at session creation here: ~0.6 ms, `group_XTX_ms_outside_step`).
+sequential_path (src/path.cpp:37), happens at session creation here: its device time is `group_XTX_ms_outside_step`
+and `ms_per_step_incl_group_XTX` / `value_incl_group_XTX` add it back to every step).
+
+Two evaluations of the score pass are timed with the same --steps / --warmup at N = 1: the headline is the covariance
+form (cached Gram columns; `config.headline_mode`), and the STREAMING formulation north_star prescribes -- every PDAS
+iteration reads X once -- is in `roofline.streaming_*` (candidates/s, ms per step, k_xtv against the HBM roof, the whole
+step against the HBM roof) and, in full, in `streaming_score_pass`.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lm-seq|lm-cv-gs] [--shard kpath|replica]
                   [--n N --p P --kmax KMAX] [--no-cpu-baseline]
@@ -15,11 +21,14 @@ sequential_path (src/path.cpp:37), happens at session creation here: ~0.6 ms, `g
 BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the launcher's code.  Under a launcher,
 WORLD_SIZE must equal --gpus.
 
-N > 1, default (--shard kpath): STRONG scaling of the ONE configs[1] problem.  X is replicated; s.list = 1..200 is
-cut into N contiguous chunks, each chunk one warm-start chain (bess_amd/dist.py partition); no data-path collective;
-the IC curve (8 B per candidate) is all-gathered over RCCL each step and every rank picks the best k.  A chunk's
-first candidate starts cold, so its chain can differ from the single chain's: after the timed
-region rank 0 runs the single chain and the line reports for how many k the supports agree.
+N > 1, default (--shard kpath): STRONG scaling of the ONE configs[1] problem, partitioned as north_star says.  X is
+replicated; s.list = 1..200 is cut into N contiguous chunks, each chunk one warm-start chain (bess_amd/dist.py
+partition), stitched into the single chain (dist.StitchedKPath); NO data-path collective: RCCL carries the IC curve
+(8 B per candidate) and the chunks' last models (a few KB per stitch round).  After the timed region rank 0 runs the
+single chain and the line reports for how many k the supports agree (all of them, by construction of the stitch).
+--coop-variant (opt-in): the same steps once more with the cooperative prefill / pilot policy (Gram column blocks
+all-gathered between the ranks -- a data-path collective north_star does not have), as a second figure
+`cooperative_prefill_variant` in the same line; --prefill / --pilot make that variant the timed one.
 --shard replica: WEAK scaling, N independent problems (rank-specific response on the same design).
 --workload cox-seq: BASELINE configs[4] (Cox PDAS, n=200000 p=20000 k<=150), the same k-path split: every candidate pays
 its own passes over the 32 GB design, so this is the path whose chunks scale; every rank generates and uploads the
@@ -869,6 +878,7 @@ def main():
             tf = 2.0 * args.n * args.p * 32 / per_pass / 1e12
             roof["mfma_fp64"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": tf / FP64_MFMA_PEAK_TFLOPS, "flop_per_pass": 2.0 * args.n * args.p * 32}
+            roof["mfma_fp64_frac"] = tf / FP64_MFMA_PEAK_TFLOPS
         return roof
 
     if rank == 0:
@@ -901,6 +911,10 @@ def main():
                                                   if (kpath and prefill) else "")) if kpath else
                                      ("all_gather of the IC curve" if distributed else "none"),
                        "score_pass": "covariance updates (cached Gram columns)" if covariance else "streaming",
+                       "headline_mode": ("covariance form (Gram-cached: an exact re-formulation of the score pass, same "
+                                         "candidates; NOT the streaming formulation SURVEY 8d's algorithmic bytes are "
+                                         "written for -- that one is in roofline.streaming_*)") if covariance else
+                                        ("streaming (every PDAS iteration reads X once)" if not cox else "Cox score pass"),
                        # k-path chunks: every rank owns a chunk of at least one candidate as long as N <= kmax
                        "ranks_with_work": min(world, args.kmax) if kpath else world,
                        "chunk_start": (args.chunk_start_option if kpath else None)},
@@ -910,11 +924,12 @@ def main():
                            "achieved_GBps": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p / step_s / 1e9,
                            "frac_of_hbm_peak": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p / step_s
                            / 1e9 / HBM_PEAK_GBPS,
-                           "time_share": {"kernel_streaming_X": x_seconds / step_s,
-                                          "candidate_chain_and_host (selection, k x k solve, p x k GEMV, publish)":
-                                          1.0 - x_seconds / step_s}},
-            "group_XTX_ms_outside_step": "X^T y and diag(X^T X) (one pass over X, src/path.cpp:37) are formed at "
-                                         "session creation, inside upload_and_normalise_seconds",
+                           # (the kernel that streams X never overlaps another pass over X -- fills run while every
+                           # chain stands still -- so its summed launch time is a true share of the step)
+                           "time": {"wall_ms": 1e3 * step_s, "summed_kernel_ms_streaming_X": 1e3 * x_seconds,
+                                    "kernel_streaming_X_share": min(1.0, x_seconds / step_s),
+                                    "candidate_chain_and_host_share (selection, k x k solve, p x k GEMV, publish)":
+                                    max(0.0, 1.0 - x_seconds / step_s)}},
             "passes_over_X_per_candidate": roof["passes_over_X_timed"] / float(max(len(seq), 1) * args.steps),
             "pdas_iterations_per_candidate": pdas_iters / float(max(len(seq), 1) * args.steps),
             # I_k of SURVEY 8d: PDAS iterations Algorithm::fit took per candidate (identical to the reference's,
@@ -931,6 +946,14 @@ def main():
             line["cooperative_prefill_variant"] = coop_variant
         norm = sess.normalization() if world == 1 else None
         cnt = sess.counters() if world == 1 else {}
+        if not cox:
+            # the reference forms X^T y / diag(X^T X) inside every sequential_path call (group_XTX, src/path.cpp:37); here
+            # that pass over X runs once per session, outside the step.  Its device time (HIP events at session creation)
+            # and the step with it added back, so that both accountings are in the line:
+            gx_ms = sess.counters().get("group_XTX_ns", 0) / 1e6
+            line["group_XTX_ms_outside_step"] = gx_ms
+            line["ms_per_step_incl_group_XTX"] = 1e3 * step_s + gx_ms
+            line["value_incl_group_XTX"] = (n_cand / args.steps) / (step_s + gx_ms / 1e3)
         if world == 1 and cnt.get("kpath_chunked_paths", 0) > 0:
             # the path ran as chunk chains side by side on one Gram column cache, stitched into the single warm-start chain
             # (bessx_kchunks.cpp); the same path as ONE chain on the same session, timed the same way, beside it
@@ -962,22 +985,44 @@ def main():
             sess.close()
             s2 = capi.Session(X, y, data_type=1, is_normal=True, model_type=1, max_iter=20, is_warm_start=True,
                               score_mode=1, device=local_rank)
-            s2.sequential_path(seq, ic_type=3)
+            # ... timed exactly like the headline: the same --warmup and --steps, wall clock around the steps, HIP events
+            # on every launch of the kernel that streams X.  This is the formulation north_star prescribes (SURVEY 7/8d:
+            # every PDAS iteration reads X once, src/Algorithm.h:1109); the headline's covariance form is a separate mode.
+            for _ in range(args.warmup):
+                s2.sequential_path(seq, ic_type=3)
             s2.enable_kernel_timing(True)
             s2.score_pass_stats(reset=True)
             torch.cuda.synchronize()
             t1 = time.time()
-            o2 = s2.sequential_path(seq, ic_type=3)
+            for _ in range(args.steps):
+                o2 = s2.sequential_path(seq, ic_type=3)
             torch.cuda.synchronize()
-            d2 = time.time() - t1
+            d2 = (time.time() - t1) / args.steps
             st2 = s2.score_pass_stats()
+            gx2 = s2.counters().get("group_XTX_ns", 0) / 1e6
             s2.close()
+            roof2 = roofline_of(st2, False)
+            whole2 = st2["launches"] / float(args.steps) * 8.0 * args.n * args.p / d2 / 1e9 / HBM_PEAK_GBPS
             line["streaming_score_pass"] = {
-                "value": len(seq) / d2, "unit": "candidates/s", "steps": 1, "roofline": roofline_of(st2, False),
-                "whole_step_frac_of_hbm_peak": st2["launches"] * 8.0 * args.n * args.p / d2 / 1e9 / HBM_PEAK_GBPS,
-                "passes_over_X_per_candidate": st2["launches"] / float(len(seq)),
+                "value": len(seq) / d2, "unit": "candidates/s", "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * d2, "ms_per_step_incl_group_XTX": 1e3 * d2 + gx2, "roofline": roof2,
+                "whole_step_frac_of_hbm_peak": whole2,
+                "passes_over_X_per_candidate": st2["launches"] / float(len(seq) * args.steps),
                 "same_selection": bool(int(o2["best_T0"]) == int(out["best_T0"]) and
-                                       np.array_equal(np.nonzero(o2["beta"])[0], np.nonzero(out["beta"])[0]))}
+                                       np.array_equal(np.nonzero(o2["beta"])[0], np.nonzero(out["beta"])[0])),
+                "same_candidates": bool(np.array_equal(o2["cand_support"], out["cand_support"]) and
+                                        np.array_equal(o2["cand_iters"], out["cand_iters"]))}
+            # flat keys inside the dictionaries every consumer of the line keeps (the nested leg above is easy to drop)
+            roof["streaming_candidates_per_s"] = len(seq) / d2
+            roof["streaming_ms_per_step"] = 1e3 * d2
+            roof["streaming_steps"] = args.steps
+            roof["streaming_kernel"] = "k_xtv<8,16,false> (X^T r, one pass over X per PDAS iteration)"
+            roof["streaming_kernel_frac"] = roof2["frac"]
+            roof["streaming_kernel_avg_launch_ms"] = roof2["avg_launch_ms"]
+            roof["streaming_whole_step_frac"] = whole2
+            roof["streaming_passes_over_X_per_candidate"] = st2["launches"] / float(len(seq) * args.steps)
+            line["config"]["streaming_mode"] = ("roofline.streaming_*: the same path with score_mode = streaming (every "
+                                                "PDAS iteration reads X once), same --steps / --warmup")
         if ic_curves is not None and not kpath:
             line["ic_curves_gathered"] = int(ic_curves.shape[0])
             line["best_k_per_problem"] = [int(bdist.select_best(c)) + 1 for c in ic_curves]

@@ -182,7 +182,10 @@ int fold_fits_side_by_side(bessx_session *s, double *out, const std::vector<int>
   }
   if (!s->fold_pool) {
     s->fold_pool = new FoldPool();
-    s->fold_pool->start(K - 1, s->device);
+    {
+      const int dev = s->device;
+      s->fold_pool->start(K - 1, [dev] { (void)hipSetDevice(dev); });
+    }
   }
   tick(0, tm);
   // ---- lock-step rounds

@@ -30,6 +30,7 @@
 
 #include "../../include/bessx.h"
 #include "bessx_dev.h"
+#include "bessx_sync.h"
 
 namespace bessx {
 
@@ -105,100 +106,6 @@ static constexpr int T0_HARD = 16382;  // largest capacity a session can be crea
 }  // namespace bessx
 
 using namespace bessx;
-
-// Host threads that queue the chains' launches: launches that alternate between streams cost the host ~10 us each
-// (measured: 35 launches per round, 12 ms per path of configs[3]); one thread per chain queues its 7 on its own stream
-// while the others do the same.  Workers spin for a job for a while after the last one, then block on a condition
-// variable (an idle session holds no core).  The spin is ~4 ms where the host has cores to spare (longer than the
-// longest gap inside a path -- a union fill of three groups is 2.5 ms; with 1 ms the workers slept through the fills and
-// configs[3] took 32.9 instead of 29.4 ms) and ~0.2 ms where K spinning threads per session would oversubscribe it
-// (fewer than 4 hardware threads per chain: several ranks or sessions per host); BESSX_POOL_SPIN_US overrides.
-// The caller's wait for its workers is bounded: spin, then sleep on a condition variable, and give up at the
-// session's deadline (a worker stuck inside a HIP call) -- the pool is then marked broken and never joined.
-struct FoldPool {
-  std::vector<std::thread> th;
-  std::mutex mu;
-  std::condition_variable cv, cv_done;
-  unsigned ticket = 0;  // (under mu) number of the current job
-  std::atomic<unsigned> ticket_hint{0};  // ... its copy for the spinning phase
-  std::atomic<int> pending{0};
-  bool quit = false, broken = false;
-  std::function<void(int)> job;
-  int device = 0;
-  int spin_iters = 200000;  // pauses of ~40-50 cycles
-  void worker(int k) {
-    (void)hipSetDevice(device);
-    unsigned seen = 0;
-    for (;;) {
-      bool got = false;
-      for (int spin = 0; spin < spin_iters && !got; spin++) {
-        got = ticket_hint.load(std::memory_order_acquire) != seen;
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-      }
-      std::function<void(int)> mine;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return quit || ticket != seen; });
-        if (quit) return;
-        seen = ticket;
-        mine = job;
-      }
-      mine(k);
-      if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-        std::lock_guard<std::mutex> lk(mu);  // (the caller may be asleep on cv_done)
-        cv_done.notify_all();
-      }
-    }
-  }
-  void start(int nworkers, int dev) {
-    device = dev;
-    const unsigned hw = std::thread::hardware_concurrency();
-    spin_iters = (hw >= 4u * (unsigned)(nworkers + 1)) ? 200000 : 10000;
-    if (const char *ev = std::getenv("BESSX_POOL_SPIN_US")) spin_iters = std::max(0, std::atoi(ev)) * 50;
-    for (int k = 1; k <= nworkers; k++) th.emplace_back([this, k] { worker(k); });
-  }
-  // runs fn(0) on the caller and fn(1..nworkers) on the workers; true when all are done, false when the workers did
-  // not finish within deadline_s (the pool is then broken: its threads may still be inside fn)
-  bool run(const std::function<void(int)> &fn, double deadline_s) {
-    if (broken) return false;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      job = fn;
-      pending.store((int)th.size(), std::memory_order_relaxed);
-      ticket++;
-      ticket_hint.store(ticket, std::memory_order_release);
-    }
-    cv.notify_all();
-    fn(0);
-    for (int spin = 0; spin < 400000; spin++) {  // ~8 ms: the workers queue a handful of launches each
-      if (pending.load(std::memory_order_acquire) == 0) return true;
-#if defined(__x86_64__)
-      __builtin_ia32_pause();
-#endif
-    }
-    std::unique_lock<std::mutex> lk(mu);
-    const bool ok = cv_done.wait_for(lk, std::chrono::duration<double>(deadline_s),
-                                     [&] { return pending.load(std::memory_order_acquire) == 0; });
-    if (!ok) broken = true;
-    return ok;
-  }
-  void stop() {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      quit = true;
-    }
-    cv.notify_all();
-    for (auto &t : th) {
-      if (broken)
-        t.detach();  // a worker that never came back from a HIP call cannot be joined
-      else
-        t.join();
-    }
-    th.clear();
-  }
-};
 
 namespace bessx {
 struct KChains;
@@ -542,6 +449,7 @@ int publish_flush(bessx_session *s);
 int publish_launch(bessx_session *s, const PubArgs &pa);
 int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq);
 int publish_wait(bessx_session *s, int buf, unsigned long long want);
+int stream_wait_bounded(bessx_session *s, hipStream_t st, const char *what);  // hipStreamSynchronize with the deadline
 int read_results(bessx_session *s, int kcopy = -1);
 int algorithm_fit_grouped(bessx_session *s);
 int enqueue_chained(bessx_session *s, const bessx_session::Hint &hint, int rs, int parent, int buf, int batch,

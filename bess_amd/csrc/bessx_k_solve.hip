@@ -1813,14 +1813,9 @@ __global__ void __launch_bounds__(256) k_bc_prepare(double *__restrict__ Gt, int
   Gt[(size_t)t * 256 + threadIdx.x] = v;
 }
 
-// block column b: every wave factors tile (b,b) redundantly in registers, wave I-b then substitutes its panel tile
-// (I,b) (16 rows, one lane each); the wave of I == b stores the factor and the reciprocal diagonal.
-__global__ void __launch_bounds__(64) k_bc_panel(double *__restrict__ Gt, double *__restrict__ rdiag, int mt, int b,
-                                                 const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
-  BIG_GATE(ctrl, slot, gate_mode);
-  const int lane = threadIdx.x, rr = lane & 15, I = b + blockIdx.x;
-  const double *D = Gt + tile_id(b, b) * 256;
-  double Lr[16], rinv[16];
+// Cholesky of the 16 x 16 diagonal tile D in the registers of one wave: lane (any of the four with lane & 15 == rr) ends
+// with row rr of L in Lr and the reciprocal diagonal in rinv.
+__device__ __forceinline__ void bc_factor_diag(const double *__restrict__ D, int rr, double (&Lr)[16], double (&rinv)[16]) {
 #pragma unroll
   for (int c = 0; c < 16; c++) Lr[c] = D[tile_elem(rr, c)];
 #pragma unroll
@@ -1831,16 +1826,22 @@ __global__ void __launch_bounds__(64) k_bc_panel(double *__restrict__ Gt, double
     Lr[j] = lij;
 #pragma unroll
     for (int c = j + 1; c < 16; c++) Lr[c] = fma(-lij, bcast_lane(lij, c), Lr[c]);
-    if (I == b && lane == j) rdiag[b * 16 + j] = rinv[j];
   }
+}
+
+// block column b, the tiles BELOW the diagonal: every wave factors tile (b,b) redundantly in registers and substitutes
+// its panel tile (I,b), I = b + 1 + blockIdx.x (16 rows, one lane each).  Tile (b,b) is only READ here: its factor is
+// stored by the extra block of k_bc_update, the next launch.  (Until round 5 the wave of I == b stored the factor in
+// place in THIS launch while the other waves were still reading the unfactored tile -- a race between workgroups that
+// showed up as a logistic fit at k = 260 whose first IRLS solves were off: coefficients 6e-5 away on one fresh box in two,
+// tests/test_lm_gpu.py::test_logistic_beyond_register_solver.)
+__global__ void __launch_bounds__(64) k_bc_panel(double *__restrict__ Gt, int mt, int b,
+                                                 const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+  BIG_GATE(ctrl, slot, gate_mode);
+  const int lane = threadIdx.x, rr = lane & 15, I = b + 1 + blockIdx.x;
+  double Lr[16], rinv[16];
+  bc_factor_diag(Gt + tile_id(b, b) * 256, rr, Lr, rinv);
   double *T = Gt + tile_id(I, b) * 256;
-  if (I == b) {
-    if (lane < 16) {
-#pragma unroll
-      for (int c = 0; c < 16; c++) T[tile_elem(rr, c)] = Lr[c];
-    }
-    return;
-  }
   double x[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) x[j] = T[tile_elem(rr, j)];
@@ -1857,11 +1858,27 @@ __global__ void __launch_bounds__(64) k_bc_panel(double *__restrict__ Gt, double
   }
 }
 
-// trailing update of step b: tile (I,J) -= L(I,b) L(J,b)^T for b < J <= I, one wave per tile, 4 fp64 MFMAs
-__global__ void __launch_bounds__(64) k_bc_update(double *__restrict__ Gt, int mt, int b,
-                                                  const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
+// trailing update of step b: tile (I,J) -= L(I,b) L(J,b)^T for b < J <= I, one wave per tile, 4 fp64 MFMAs.
+// The LAST block (blockIdx.x == number of trailing tiles) stores the factor of the diagonal tile (b,b) and its
+// reciprocal diagonal: nothing in this launch reads that tile, and every reader of the unfactored one (k_bc_panel of
+// step b) has finished.
+__global__ void __launch_bounds__(64) k_bc_update(double *__restrict__ Gt, double *__restrict__ rdiag, int mt, int b,
+                                                  int ntrail, const FitCtrl *__restrict__ ctrl, int slot, int gate_mode) {
   BIG_GATE(ctrl, slot, gate_mode);
   const int lane = threadIdx.x, lc = lane & 15, lq = lane >> 4;
+  if ((int)blockIdx.x == ntrail) {
+    double Lr[16], rinv[16];
+    double *D = Gt + tile_id(b, b) * 256;
+    bc_factor_diag(D, lc, Lr, rinv);
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) D[tile_elem(lc, c)] = Lr[c];
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        if (lane == j) rdiag[b * 16 + j] = rinv[j];  // (rinv is uniform over the lanes)
+    }
+    return;
+  }
   int Ir, Jr;
   tile_of(blockIdx.x, Ir, Jr);  // enumerate the lower triangle of the trailing (mt-b-1) x (mt-b-1) tile grid
   const int I = b + 1 + Ir, J = b + 1 + Jr;
@@ -2171,13 +2188,14 @@ hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_sk
                      ctrl, slot, gate_mode);
   LAUNCH_CHECK();
   for (int b = 0; b < mt; b++) {
-    hipLaunchKernelGGL(k_bc_panel, dim3(mt - b), dim3(64), 0, st, Gt, rdiag, mt, b, ctrl, slot, gate_mode);
-    LAUNCH_CHECK();
-    const int nt = (mt - b - 1) * (mt - b) / 2;
-    if (nt > 0) {
-      hipLaunchKernelGGL(k_bc_update, dim3(nt), dim3(64), 0, st, Gt, mt, b, ctrl, slot, gate_mode);
+    if (mt - b - 1 > 0) {
+      hipLaunchKernelGGL(k_bc_panel, dim3(mt - b - 1), dim3(64), 0, st, Gt, mt, b, ctrl, slot, gate_mode);
       LAUNCH_CHECK();
     }
+    // the trailing tiles + one block that stores the factor of tile (b,b)
+    const int nt = (mt - b - 1) * (mt - b) / 2;
+    hipLaunchKernelGGL(k_bc_update, dim3(nt + 1), dim3(64), 0, st, Gt, rdiag, mt, b, nt, ctrl, slot, gate_mode);
+    LAUNCH_CHECK();
   }
   for (int b = mt - 1; b >= 0; b--) {
     hipLaunchKernelGGL(k_bc_back, dim3(1), dim3(512), 0, st, (const double *)Gt, (const double *)rdiag, z, mt, b, m,

@@ -24,90 +24,27 @@ struct KChains {
   std::vector<bessx_session *> ctx;
   FoldPool pool;
   bool pool_started = false;
-  // the fill rendezvous
-  std::mutex mu;
-  std::condition_variable cv;
-  int running = 0;            // chains that may have kernels in flight
-  bool fill_pending = false;  // a chain holds (or waits for) the right to fill
-  bool abandoned = false;     // a chain failed: nobody waits any longer
-  double deadline_s = 30.0;
+  FillRendezvous rdv;  // the fill rendezvous (bessx_sync.h: built and hammered under ThreadSanitizer, tools/tsan)
 };
 
 // between two candidates of a chunk chain: if another chain waits to fill, drain this chain's stream and stand still
 void kchains_safe_point(bessx_session *c) {
   KChains *k = c->kch_owner ? c->kch_owner->kch : nullptr;
   if (!k) return;
-  std::unique_lock<std::mutex> lk(k->mu);
-  if (!k->fill_pending || k->abandoned) return;
-  lk.unlock();
-  (void)hipStreamSynchronize(c->st);  // (the candidate chained ahead runs to its end or parks)
-  lk.lock();
-  k->running--;
-  k->cv.notify_all();
-  if (!k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s), [&] { return !k->fill_pending || k->abandoned; })) {
-    k->abandoned = true;  // (a fill that never ended: nobody waits any longer, every chain fails at its next look)
-    k->cv.notify_all();
-  }
-  k->running++;
+  k->rdv.safe_point([c] { (void)hipStreamSynchronize(c->st); });
 }
 
 // a parked chain asks for the cache: returns 0 when it may fill (every other chain stands still), 1 when another chain
 // filled while this one waited (the right is held all the same: look the columns up again), -1 when the run was abandoned
 int kchains_fill_begin(bessx_session *c) {
-  KChains *k = c->kch_owner->kch;
-  std::unique_lock<std::mutex> lk(k->mu);
-  int waited = 0;
-  while (k->fill_pending && !k->abandoned) {  // another chain is filling: this one is quiet (parked, its stream drained)
-    waited = 1;
-    lk.unlock();
-    (void)hipStreamSynchronize(c->st);
-    lk.lock();
-    if (!k->fill_pending) break;
-    k->running--;
-    k->cv.notify_all();
-    k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s), [&] { return !k->fill_pending || k->abandoned; });
-    k->running++;
-  }
-  if (k->abandoned) return -1;
-  k->fill_pending = true;
-  k->running--;
-  const bool ok = k->cv.wait_for(lk, std::chrono::duration<double>(k->deadline_s),
-                                 [&] { return k->running == 0 || k->abandoned; });
-  k->running++;
-  if (!ok || k->abandoned) {
-    k->abandoned = true;
-    k->fill_pending = false;
-    k->cv.notify_all();
-    return -1;
-  }
-  return waited;
+  return c->kch_owner->kch->rdv.fill_begin([c] { (void)hipStreamSynchronize(c->st); });
 }
 
-void kchains_fill_end(bessx_session *c) {
-  KChains *k = c->kch_owner->kch;
-  std::lock_guard<std::mutex> lk(k->mu);
-  k->fill_pending = false;
-  k->cv.notify_all();
-}
+void kchains_fill_end(bessx_session *c) { c->kch_owner->kch->rdv.fill_end(); }
 
-// (the caller of a round sets `running` to the number of chains the round starts BEFORE any of them runs: a chain that
-// parks at once must not take the others for finished)
-static void kchains_round(KChains *k, int chains) {
-  std::lock_guard<std::mutex> lk(k->mu);
-  k->running = chains;
-  k->fill_pending = false;
-  k->abandoned = false;
-}
+static void kchains_round(KChains *k, int chains) { k->rdv.round(chains); }
 
-static void kchains_leave(KChains *k, bool failed) {
-  std::lock_guard<std::mutex> lk(k->mu);
-  k->running--;
-  if (failed) {
-    k->abandoned = true;
-    k->fill_pending = false;
-  }
-  k->cv.notify_all();
-}
+static void kchains_leave(KChains *k, bool failed) { k->rdv.leave(failed); }
 
 void kchains_free(bessx_session *s) {
   if (!s || !s->kch) return;
@@ -241,7 +178,7 @@ int kchunks_prepare(bessx_session *s, int ns, bool link) {
   if (!s->kch) s->kch = new KChains();
   KChains *k = s->kch;
   if (k->pool.broken) return 1;
-  k->deadline_s = s->wait_deadline_s;
+  k->rdv.deadline_s = s->wait_deadline_s;
   while ((int)k->ctx.size() < C) {
     bessx_session *c = nullptr;
     if (chain_ctx_create(s, &c) != 0) {
@@ -256,7 +193,10 @@ int kchunks_prepare(bessx_session *s, int ns, bool link) {
     k->pool.ticket = 0;
     k->pool.ticket_hint.store(0);
     k->pool.job = nullptr;
-    k->pool.start(C - 1, s->device);
+    {
+      const int dev = s->device;
+      k->pool.start(C - 1, [dev] { (void)hipSetDevice(dev); });
+    }
     k->pool_started = true;
   }
   return 0;

@@ -935,14 +935,16 @@ int bessx_session_set_fill_hook(bessx_session *s, bessx_fill_hook hook, void *us
   return BESSX_OK;
 }
 
-static void debug_sleep_cb(void *ms) {
-  std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)ms));
+static void debug_sleep_cb(void *us) {
+  std::this_thread::sleep_for(std::chrono::microseconds((long)(intptr_t)us));
 }
 
+// (milliseconds < 0: -milliseconds MICROseconds -- windows of the length of a fit, tests/test_cv_shard_gpu.py)
 int bessx_session_debug_block_stream(bessx_session *s, int milliseconds) {
-  if (!s || milliseconds < 0) return fail(BESSX_ERR_ARG, "bad argument");
+  if (!s || milliseconds < -1000000) return fail(BESSX_ERR_ARG, "bad argument");
   HIPX(hipSetDevice(s->device));
-  HIPX(hipLaunchHostFunc(s->st, debug_sleep_cb, reinterpret_cast<void *>((intptr_t)milliseconds)));
+  const long us = milliseconds >= 0 ? 1000L * milliseconds : -(long)milliseconds;
+  HIPX(hipLaunchHostFunc(s->st, debug_sleep_cb, reinterpret_cast<void *>((intptr_t)us)));
   return BESSX_OK;
 }
 

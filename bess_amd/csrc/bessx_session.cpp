@@ -268,6 +268,21 @@ int alloc_cov_cache(bessx_session *s, bool share_map) {
 }
 
 // forget every cached quantity that outlives a fit: a path call starts from nothing, like bessCpp
+// hipStreamSynchronize with the session's deadline (BESSX_WAIT_TIMEOUT_S): polls the stream, yields between polls
+int stream_wait_bounded(bessx_session *s, hipStream_t st, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return fail(BESSX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(q));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s->wait_deadline_s)
+      return fail(BESSX_ERR_HIP, std::string(what) + ": the stream did not drain within " +
+                                     std::to_string(s->wait_deadline_s) + " s (BESSX_WAIT_TIMEOUT_S) -- the session can "
+                                     "only be destroyed now");
+    if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 int reset_path_caches(bessx_session *s) {
   kchains_quiesce(s);  // (chunk-chain contexts read the caches that are about to be cleared)
   if (s->ahead.armed) {
@@ -295,8 +310,9 @@ int reset_path_caches(bessx_session *s) {
   // its queue, kept solving on slots that were handed out anew, and failed with "an active column was missing from
   // the Gram column cache": once in ~130 two-rank rehearsals on a loaded box, GPUTEST_r04.  Regression test:
   // tests/test_cv_shard_gpu.py::test_cache_reset_is_complete_before_the_fold_chains_read_the_map.)
-  HIPX(hipStreamSynchronize(s->st));
-  return 0;
+  // (bounded like every wait of the host on the device: a stream that never comes back fails the call at the session's
+  // deadline instead of hanging it, tests/test_deadline_gpu.py)
+  return stream_wait_bounded(s, s->st, "clearing the path caches");
 }
 
 // k_chol outside the covariance form: only the work space of its pivoted fallback solve rides in the fuse block
@@ -1626,7 +1642,10 @@ int bessx_session_set_cv(bessx_session *s, int K, const int *fold_id, unsigned s
         // first use -- 30-40 ms on the first evaluation of a path.  Use them once here, where the data is set up anyway:
         // one PDAS slot and a publication per chain, all falling through their gates (slot 5 of a fit that has not begun).
         s->fold_pool = new FoldPool();
-        s->fold_pool->start(K - 1, s->device);
+        {
+      const int dev = s->device;
+      s->fold_pool->start(K - 1, [dev] { (void)hipSetDevice(dev); });
+    }
         std::vector<hipError_t> we((size_t)K, hipSuccess);
         // (a sparsity level the side-by-side driver would really run on this session: the largest one <= 77 that
         // side_by_side_applies() accepts -- launch geometry and LDS sizes follow from it; none: no warm-up)

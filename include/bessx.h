@@ -345,8 +345,8 @@ int bessx_session_set_kpath_chains(bessx_session *s, int chains);
 typedef int (*bessx_fill_hook)(void *user, int n_groups);
 int bessx_session_set_fill_hook(bessx_session *s, bessx_fill_hook hook, void *user, int width);
 
-/* Test hook: queue a host function on the session's stream that sleeps for `milliseconds` -- everything queued behind
- * it waits, as behind a wedged kernel (tests/test_deadline_gpu.py: the waits of the host give up at
+/* Test hook: queue a host function on the session's stream that sleeps for `milliseconds` (negative: that many
+ * MICROseconds) -- everything queued behind it waits, as behind a wedged kernel (tests/test_deadline_gpu.py: the waits of the host give up at
  * BESSX_WAIT_TIMEOUT_S instead of spinning for ever). */
 int bessx_session_debug_block_stream(bessx_session *s, int milliseconds);
 

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PORT_LIB = os.path.join(_HERE, "libbess_oracle.so")
+# BESS_ORACLE_LIB: another build of the same restatement (`make -C oracle asan`: address + undefined-behaviour sanitizers)
+PORT_LIB = os.environ.get("BESS_ORACLE_LIB") or os.path.join(_HERE, "libbess_oracle.so")
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)

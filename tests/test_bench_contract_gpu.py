@@ -30,5 +30,17 @@ def test_bench_line(gpu):
     assert abs(r["algorithmic_bytes_per_launch"] - 8.0 * 3000 * 800) < 1
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0
-    assert d["streaming_score_pass"]["same_selection"] is True
+    assert d["streaming_score_pass"]["same_selection"] is True and d["streaming_score_pass"]["same_candidates"] is True
+    # the streaming formulation is a first-class leg: same steps / warm-up, flat keys inside `roofline` and `config`
+    assert d["streaming_score_pass"]["steps"] == 2 and d["streaming_score_pass"]["warmup"] == 1
+    for k in ("streaming_candidates_per_s", "streaming_ms_per_step", "streaming_kernel_frac", "streaming_whole_step_frac",
+              "mfma_fp64_frac"):
+        assert r[k] > 0, k
+    assert abs(r["streaming_candidates_per_s"] - 30 / (r["streaming_ms_per_step"] * 1e-3)) < 1e-6 * r["streaming_candidates_per_s"]
+    assert "covariance" in d["config"]["headline_mode"]
+    assert d["group_XTX_ms_outside_step"] > 0
+    assert abs(d["ms_per_step_incl_group_XTX"] - d["ms_per_step"] - d["group_XTX_ms_outside_step"]) < 1e-9
+    t = d["whole_step"]["time"]
+    assert 0.0 <= t["kernel_streaming_X_share"] <= 1.0
+    assert all(v >= 0 for v in t.values())
     assert sum(d["pdas_iterations_histogram"].values()) == 30

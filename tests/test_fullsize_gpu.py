@@ -81,10 +81,13 @@ def untraced(gpu):
     with gpu.Session(X, y, score_mode=2) as s:
         for chains in (0, 1, 4, 2):
             s.set_kpath_chains(chains)
-            outs["covariance, chains=%s" % ("auto" if chains == 0 else chains)] = (
-                s.sequential_path(np.arange(1, 201), ic_type=3), s.counters())
+            before = s.counters()["kpath_chunked_paths"]
+            out = s.sequential_path(np.arange(1, 201), ic_type=3)
+            cnt = s.counters()
+            cnt["chunked"] = cnt["kpath_chunked_paths"] - before  # did THIS path run as chunk chains?
+            outs["covariance, chains=%s" % ("auto" if chains == 0 else chains)] = (out, cnt)
     with gpu.Session(X, y, score_mode=1) as s:
-        outs["streaming"] = (s.sequential_path(np.arange(1, 201), ic_type=3), s.counters())
+        outs["streaming"] = (s.sequential_path(np.arange(1, 201), ic_type=3), dict(s.counters(), chunked=0))
     return X, outs
 
 
@@ -97,7 +100,7 @@ def test_benchmarked_path_matches_compiled_reference_at_full_size(untraced, whic
     g = np.load(GOLD)
     n = assert_untraced_path_matches_golden(out, g, X, 1, "configs[1] untraced, " + which)
     assert n == 200 and out["n_fits"] == 200 and out["n_pdas_iters"] == int(np.sum(g["fit_iters"]))
-    if which == "covariance, chains=1":
-        assert counters["kpath_chains_last_path"] <= 1
+    if which in ("covariance, chains=1", "streaming"):
+        assert counters["chunked"] == 0
     if which in ("covariance, chains=4", "covariance, chains=2"):
-        assert counters["kpath_chains_last_path"] == int(which[-1]) and counters["kpath_chunked_paths"] >= 1
+        assert counters["kpath_chains_last_path"] == int(which[-1]) and counters["chunked"] == 1

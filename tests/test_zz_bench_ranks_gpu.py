@@ -55,6 +55,9 @@ def test_bench_gpus_2_starts_two_ranks_and_shards_the_k_path(gpu):
     assert rep["best_k_chunked"] == rep["best_k_single_chain"] and rep["ic_curve_max_rel_diff_to_single_chain"] < 1e-10
     assert rep["stitch_refits"] >= 1 and rep["stitch_rounds"] >= 1 and len(rep["stitch_seconds_per_rank"]) == 2
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    # the default partition is north_star's: replicas only, no Gram blocks between the ranks
+    assert rep["prefill_columns"] == 0 and rep["pilot"] is None and rep["prefill"].startswith("none")
+    assert "Gram column blocks" not in d["config"]["collective"] and "cooperative_prefill_variant" not in d
     lad = _run_bench(["--gpus", "2", "--chunk-start", "ladder"], {"BESSX_BENCH_ONE_DEVICE": "1"})
     rep = lad["kpath_chunks_vs_single_chain"]
     assert rep["supports_equal_to_single_chain"] == rep["of"] and rep["chunk_start"] == "ladder"
@@ -70,6 +73,11 @@ def test_bench_three_ranks_with_the_pilot_prefill(gpu):
     assert rep["supports_equal_to_single_chain"] == rep["of"] == 30 and rep["differing_k"] == []
     assert rep["prefill_columns"] == 64 and rep["pilot"] == [12, 64] and min(rep["prefill_seconds_per_rank"]) > 0
     assert "cooperative prefill" in d["config"]["collective"]
+    # opt-in second figure beside the default partition: same steps, the measured prefill policy (320 columns at 3 ranks)
+    d = _run_bench(["--gpus", "3", "--coop-variant", "--no-cpu-baseline", "--rebalance", "off"], {"BESSX_BENCH_ONE_DEVICE": "1"})
+    rep, var = d["kpath_chunks_vs_single_chain"], d["cooperative_prefill_variant"]
+    assert rep["prefill_columns"] == 0 and rep["supports_equal_to_single_chain"] == rep["of"] == 30
+    assert var["prefill_columns"] == 320 and var["value"] > 0 and var["ic_curve_equal_to_default_partition"] is True
 
 
 def test_bench_three_ranks_with_shared_fills_in_the_pilot_and_moving_chunk_boundaries(gpu):

@@ -1,0 +1,128 @@
+// sync_harness.cpp -- the host-side concurrency primitives of libbessx.so (bess_amd/csrc/bessx_sync.h: FoldPool, the
+// fill rendezvous of the chunk chains) on the CPU, under ThreadSanitizer.  No HIP: a chain's "stream" is a counter of
+// work in flight that the drain function waits out, the "Gram column cache" a plain array that a filling chain rewrites
+// and every running chain reads -- exactly the accesses the rendezvous has to keep apart, so a hole in the protocol is a
+// data race TSan reports (and the checks below fail on torn reads).  Random chain lengths, random parking, random
+// failures (abandon), pools stopped and started again with more workers, as bessx_kchunks.cpp does.
+//   make -C tools/tsan          (g++ -fsanitize=thread; log in profiles/r05_tsan_sync_harness.log)
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "../../bess_amd/csrc/bessx_sync.h"
+
+namespace {
+
+struct Cache {
+  static constexpr int N = 256;
+  long slot_of[N];  // what a fill rewrites and the chains' "kernels" read -- NOT atomic on purpose
+  long version = 0;
+};
+
+struct Chain {
+  std::atomic<int> in_flight{0};  // "kernels" queued on the chain's stream
+  long reads = 0, torn = 0;
+};
+
+// a kernel of a running chain: reads the whole map; all entries must carry one version
+void kernel_reads(const Cache &c, Chain &q) {
+  const long v = c.slot_of[0];
+  for (int i = 1; i < Cache::N; i++)
+    if (c.slot_of[i] != v) q.torn++;
+  q.reads++;
+}
+
+int run_rounds(int C, int rounds, unsigned seed, bool with_failures) {
+  FoldPool pool;
+  pool.spin_iters = 2000;
+  pool.start(C - 1);
+  FillRendezvous rdv;
+  rdv.deadline_s = 20.0;
+  Cache cache;
+  std::memset(cache.slot_of, 0, sizeof(cache.slot_of));
+  std::vector<Chain> ch((size_t)C);
+  long fills = 0, abandons = 0;
+  std::mutex fills_mu;
+  int bad = 0;
+  for (int r = 0; r < rounds; r++) {
+    rdv.round(C);
+    std::atomic<int> failed_chain{-1};
+    auto job = [&](int k) {
+      std::mt19937 rng(seed * 7919u + (unsigned)r * 131u + (unsigned)k);
+      Chain &q = ch[(size_t)k];
+      const int candidates = 3 + (int)(rng() % 12);
+      bool failed = false;
+      auto drain = [&q] {
+        while (q.in_flight.load(std::memory_order_acquire) > 0) q.in_flight.fetch_sub(1, std::memory_order_acq_rel);
+      };
+      for (int cand = 0; cand < candidates && !failed; cand++) {
+        // the fit of a candidate: a few kernels that read the map (the stream has work in flight while they "run")
+        const int kernels = 1 + (int)(rng() % 4);
+        for (int i = 0; i < kernels; i++) {
+          q.in_flight.fetch_add(1, std::memory_order_acq_rel);
+          kernel_reads(cache, q);
+        }
+        if (rng() % 5 == 0) {  // parked on a missing column: ask for the cache, fill, hand it back
+          drain();             // (a parked fit's stream is idle: the host has just read its result block)
+          const int w = rdv.fill_begin(drain);
+          if (w < 0) {
+            failed = true;  // abandoned by another chain's failure
+            break;
+          }
+          if (w == 0 || rng() % 2) {  // (w == 1: another chain filled meanwhile; the columns may still be missing)
+            const long v = ++cache.version;
+            for (int i = 0; i < Cache::N; i++) cache.slot_of[i] = v;  // the rewrite nobody may observe half-way
+            std::lock_guard<std::mutex> lk(fills_mu);
+            fills++;
+          }
+          rdv.fill_end();
+        }
+        if (with_failures && rng() % 97 == 0) {
+          failed = true;
+          failed_chain.store(k);
+          break;
+        }
+        drain();              // publish_wait: the candidate's results are back
+        rdv.safe_point(drain);  // between two candidates
+      }
+      drain();
+      rdv.leave(failed);
+    };
+    if (!pool.run(job, 20.0)) {
+      std::fprintf(stderr, "round %d: the pool did not come back\n", r);
+      return 1;
+    }
+    if (failed_chain.load() >= 0) abandons++;
+    if (r % 7 == 6 && C < 8) {  // the pool grows when a later path asks for more chains (bessx_kchunks.cpp)
+      pool.stop();
+      pool.quit = false;
+      pool.broken = false;
+      pool.ticket = 0;
+      pool.ticket_hint.store(0);
+      pool.start(C - 1);
+    }
+  }
+  pool.stop();
+  long reads = 0, torn = 0;
+  for (Chain &q : ch) {
+    reads += q.reads;
+    torn += q.torn;
+  }
+  std::printf("chains %d, rounds %d: %ld map reads, %ld fills, %ld rounds with a failed chain, torn reads %ld\n", C, rounds,
+              reads, fills, abandons, torn);
+  if (torn) bad = 1;
+  return bad;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  const int rounds = argc > 1 ? std::atoi(argv[1]) : 300;
+  int bad = 0;
+  for (int C : {2, 3, 4, 6, 8}) {
+    bad |= run_rounds(C, rounds, 1234u + (unsigned)C, false);
+    bad |= run_rounds(C, rounds, 4321u + (unsigned)C, true);
+  }
+  std::printf(bad ? "FAILED\n" : "sync harness OK\n");
+  return bad;
+}
