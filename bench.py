@@ -60,9 +60,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# chunk chains of the k-path run on a HIP stream each: 8 hardware queues instead of the runtime's default 4, set before
-# anything starts the runtime (bess_amd/__init__.py does the same at import; children inherit it)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # dense fp64 matrix peak (same guide)
@@ -1117,7 +1114,26 @@ def _report_rank_failure(exc):
         pass
 
 
+def _arm_watchdog():
+    """BESSX_BENCH_WATCHDOG_S=<seconds>: a rank that is still running after that long dumps the Python stack of every
+    thread into its per-rank file (and stderr) and exits -- a hang then says where it sits (tools/soak_bench_ranks.py)."""
+    secs = float(os.environ.get("BESSX_BENCH_WATCHDOG_S", "0") or 0)
+    if secs <= 0:
+        return
+    if os.environ.get("WORLD_SIZE") is None and parse_args(None).gpus > 1:
+        return  # (the launching parent of an N-rank run only waits for its children: they carry the watchdog)
+    import faulthandler
+    d = os.environ.get("BESSX_BENCH_ERRDIR") or os.path.join(ROOT, "gpurun_out", "bench_errors")
+    os.makedirs(d, exist_ok=True)
+    f = open(os.path.join(d, "rank%s_pid%d.watchdog" % (os.environ.get("RANK", "0"), os.getpid())), "w")
+    f.write("watchdog armed: %s s, argv %s\n" % (secs, json.dumps(sys.argv)))
+    f.flush()
+    faulthandler.dump_traceback_later(secs, exit=True, file=f)
+    globals()["_watchdog_file"] = f  # (kept open for the dump)
+
+
 if __name__ == "__main__":
+    _arm_watchdog()
     try:
         main()
     except SystemExit:

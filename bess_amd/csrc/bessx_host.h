@@ -276,6 +276,7 @@ struct bessx_session {
   long long kch_paths = 0, kch_refits = 0, kch_chunk_fills = 0;  // paths run chunked, stitch refits, fills in the chunk phase
   int kch_last_chains = 0;              // chains of the last chunked path
   bool kch_auto_off = false;            // the chunks of a path did not merge with the chain: the automatic choice is one chain
+  bool own_hw_queue = false;            // (fit contexts) the context's stream has a hardware queue outside the runtime's pool
   long long group_xtx_ns = 0;           // device time of the all-rows group_XTX pass at session creation (LM)
   long long kch_giveups = 0;            // paths whose stitch ran out of budget (the rest was walked as one chain)
   double kch_t[3] = {0, 0, 0};          // BESSX_DEBUG: seconds in the coarse chain / the chunks / the stitch
@@ -449,6 +450,8 @@ int publish_flush(bessx_session *s);
 int publish_launch(bessx_session *s, const PubArgs &pa);
 int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq);
 int publish_wait(bessx_session *s, int buf, unsigned long long want);
+bool ctx_stream_create(int device, hipStream_t *st);  // a stream with a hardware queue outside the runtime's pool
+bool ctx_streams_own_queue(int device);              // ... does that work on this device (asked once per process)
 int stream_wait_bounded(bessx_session *s, hipStream_t st, const char *what);  // hipStreamSynchronize with the deadline
 int read_results(bessx_session *s, int kcopy = -1);
 int algorithm_fit_grouped(bessx_session *s);

@@ -67,8 +67,11 @@ static int chains_for(const bessx_session *s, int ns, bool link = false) {
     // gives the process' streams (GPU_MAX_HW_QUEUES, default 4; read when the runtime starts): configs[1], 18.6 ms as
     // one chain -- 4 queues: 2 chains 16.2 ms, 3 and more lose (21.2 / 19.5 ms: streams share queues and wait for each
     // other); 8 queues: 3 chains 14.9 ms, 4 chains 12.7 ms, 6 chains 16.8 ms (tools/kchunks_bench.py)
+    // Round 5: the chains' streams are created with a hardware queue of their own, outside that pool
+    // (ctx_stream_create), so the count no longer depends on the variable; where such streams cannot be had the old
+    // rule stands.
     const char *q = std::getenv("GPU_MAX_HW_QUEUES");
-    const int queues = q ? std::atoi(q) : 4;
+    const int queues = ctx_streams_own_queue(s->device) ? 8 : (q ? std::atoi(q) : 4);
     if (s->model_type == 1)
       C = (ns >= 96 && s->p >= 2048) ? (queues >= 8 ? 4 : 2) : 1;
     else

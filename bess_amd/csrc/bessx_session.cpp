@@ -268,6 +268,39 @@ int alloc_cov_cache(bessx_session *s, bool share_map) {
 }
 
 // forget every cached quantity that outlives a fit: a path call starts from nothing, like bessCpp
+// A stream with a hardware queue of its own (see fold_ctx_create): created with a compute-unit mask that names every
+// compute unit of the device.  false: not available (or switched off by the test hook) -- the caller makes an ordinary one.
+bool ctx_stream_create(int device, hipStream_t *st) {
+  const char *hook = test_hook("ctx_streams");
+  if (hook && std::string(hook) == "pool") return false;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) return false;
+  std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+  if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+  if (hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    *st = nullptr;
+    return false;
+  }
+  return true;
+}
+
+// ... asked once per process and device whether that works here (the automatic chain count depends on it)
+bool ctx_streams_own_queue(int device) {
+  static std::mutex mu;
+  static std::vector<int> known;  // device -> -1 unknown / 0 / 1
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0) return false;
+  if ((int)known.size() <= device) known.resize((size_t)device + 1, -1);
+  if (known[(size_t)device] < 0) {
+    hipStream_t st = nullptr;
+    const bool ok = ctx_stream_create(device, &st);
+    if (ok) (void)hipStreamDestroy(st);
+    known[(size_t)device] = ok ? 1 : 0;
+  }
+  return known[(size_t)device] == 1;
+}
+
 // hipStreamSynchronize with the session's deadline (BESSX_WAIT_TIMEOUT_S): polls the stream, yields between polls
 int stream_wait_bounded(bessx_session *s, hipStream_t st, const char *what) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -1317,11 +1350,20 @@ static int fold_ctx_create(bessx_session *ps, int rs, bessx_session **out) {
   const int p = ps->p, capA = ps->capA, mt_max = capA / 16;
   hipError_t e = hipSuccess;
   {
-    int lo = 0, hi = 0;
-    e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // (the chains share the parent's priority level: spread over the levels, which have their own pools of hardware
-    // queues, the chains on the lower levels ran 2-8 x slower per kernel and the path no faster)
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, hi);
+    // A stream with a hardware queue OF ITS OWN, whatever the process' queue budget: the HIP runtime multiplexes ordinary
+    // streams onto a pool of GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level -- chains that share a
+    // queue wait for each other, which is why round 4 asked for 8 through the environment at import -- but a stream
+    // created with a compute-unit mask is given a queue outside that pool.  The mask names every compute unit of the
+    // device, so it restricts nothing.  BESSX_TEST_HOOKS=ctx_streams=pool: ordinary streams, round 4's form.
+    // (The chains share one priority level: spread over the levels, which have their own pools of hardware queues,
+    // the chains on the lower levels ran 2-8 x slower per kernel and the path no faster.)
+    const bool own_queue = ctx_stream_create(ps->device, &c->st);
+    if (!own_queue) {
+      int lo = 0, hi = 0;
+      e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, hi);
+    }
+    c->own_hw_queue = own_queue;
   }
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->resblk), ps->res_bytes);
   if (e == hipSuccess) e = hipMemset(c->resblk, 0, ps->res_bytes);

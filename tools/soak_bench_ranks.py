@@ -28,6 +28,7 @@ os.makedirs(outdir, exist_ok=True)
 env = dict(os.environ)
 env["BESSX_BENCH_ONE_DEVICE"] = "1"
 env["BESSX_BENCH_ERRDIR"] = os.path.join(outdir, "errors")
+env.setdefault("BESSX_BENCH_WATCHDOG_S", "60")  # a rank still alive after a minute dumps its Python stacks and exits
 shutil.rmtree(env["BESSX_BENCH_ERRDIR"], ignore_errors=True)
 stress = []
 if int(os.environ.get("SOAK_STRESS", "0")) > 0:
@@ -44,8 +45,19 @@ t0 = time.time()
 import atexit
 atexit.register(lambda: [q.kill() for q in stress])
 for r in range(reps):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + bench_args, cwd=ROOT, env=env,
-                         capture_output=True, text=True, timeout=600)
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + bench_args, cwd=ROOT, env=env,
+                             capture_output=True, text=True, timeout=float(os.environ.get("SOAK_REP_TIMEOUT_S", "120")))
+    except subprocess.TimeoutExpired as e:
+        with open(os.path.join(outdir, "hang_rep%d.txt" % r), "w") as f:
+            f.write("==== stdout\n%s\n==== stderr\n%s\n" % (e.stdout, e.stderr))
+        print("HANG at repetition %d after %.0f s; per-rank watchdog dumps in %s" % (r, time.time() - t0, env["BESSX_BENCH_ERRDIR"]), flush=True)
+        for fn in sorted(os.listdir(env["BESSX_BENCH_ERRDIR"])) if os.path.isdir(env["BESSX_BENCH_ERRDIR"]) else []:
+            txt = open(os.path.join(env["BESSX_BENCH_ERRDIR"], fn)).read()
+            if "Thread" in txt or "Traceback" in txt:
+                print("----", fn)
+                print(txt[-3000:], flush=True)
+        sys.exit(1)
     js = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     if out.returncode != 0 or len(js) != 1:
         with open(os.path.join(outdir, "failure_rep%d.txt" % r), "w") as f:
