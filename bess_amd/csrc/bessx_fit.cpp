@@ -85,8 +85,10 @@ int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, b
 // Two groups in one launch (a fill of more than 32 columns: cold starts, the chunks of a sharded path): the pair panel
 // kernel forms both in ONE pass over X (1.36 ms against 2 x 0.76 ms); single groups keep the default.
 int panel_variant_for(const bessx_session *s, int ng) {
-  (void)s;
-  return ng == 2 ? 4 : 3;  // 3 = k_cov_panel_lds2 (one 32-column group per block), 4 = k_cov_panel_pair (two groups per pass)
+  // 3 = k_cov_panel_lds2 (one 32-column group per block), 4 = k_cov_panel_pair (two groups per pass),
+  // 5 = k_cov_panel_dp (round 5: one workgroup per compute unit, two LDS tiles, software-pipelined; one or two groups)
+  if (s->panel_variant == 5) return 5;
+  return ng == 2 ? 4 : 3;
 }
 
 // gfirst / compact: a cooperative prefill (bessx_session_cov_prefill_*) forms only SOME groups of the list here and

@@ -24,6 +24,27 @@ namespace bessx {
 // ------------------------------------------------------------------------------------------
 constexpr int COV_NJ = 4;   // streamed 16-column tiles per wave
 
+// Diagnostic build only (make prof DEFS=-DBESSX_PANEL_CLOCK, tools/panel_bench.py): the shader clock the panel kernels
+// really run at = delta s_memtime (shader cycles) / delta s_memrealtime (100 MHz), block 0 of every launch prints it.
+// MI355X_MICROARCH.md, "DVFS give-back": MFMA-dense loops are held well under 2.4 GHz.
+#ifdef BESSX_PANEL_CLOCK
+#define PCLK_BEGIN()                                                  \
+  const unsigned long long pclk_t0_ = __builtin_amdgcn_s_memtime();   \
+  const unsigned long long pclk_r0_ = __builtin_amdgcn_s_memrealtime()
+#define PCLK_END(tag)                                                                                           \
+  do {                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                 \
+    if (blockIdx.x == 7 && threadIdx.x == 0) {                                                                  \
+      const unsigned long long dt_ = __builtin_amdgcn_s_memtime() - pclk_t0_;                                   \
+      const unsigned long long dr_ = __builtin_amdgcn_s_memrealtime() - pclk_r0_;                               \
+      printf("PCLK %s cycles %llu ticks100MHz %llu MHz %.0f\n", tag, dt_, dr_, dr_ ? 100.0 * (double)dt_ / (double)dr_ : 0.0); \
+    }                                                                                                           \
+  } while (0)
+#else
+#define PCLK_BEGIN()
+#define PCLK_END(tag)
+#endif
+
 __device__ __forceinline__ bool cov_gate(const FitCtrl *ctrl, int slot) {
   if (ctrl->done) return false;
   if (slot == 0) return ctrl->l == 0;  // start of a fit
@@ -212,6 +233,7 @@ __global__ void __launch_bounds__(256) k_cov_panel_lds2(const double *__restrict
   if (gl >= ngroups || (g0 + gl) * COV_R >= nfill) return;
   const int rem = (int)(blockIdx.x - (long)gl * per_group);
   const int slab = rem / njg, jg = rem - slab * njg;
+  PCLK_BEGIN();
   extern __shared__ double smem[];  // [CP_COLS][CP_LD]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
   const int ru = tid & 31, cbase = tid >> 5;
@@ -294,6 +316,7 @@ __global__ void __launch_bounds__(256) k_cov_panel_lds2(const double *__restrict
   double *out = part + (((size_t)gl * nslab + slab) * tiles_per_slab + (size_t)(jg * COV_NJ + wv) * 2) * 256;
   *reinterpret_cast<d4 *>(out + lane * 4) = acc0;
   *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc1;
+  PCLK_END("lds2");
 }
 
 // The panel kernel for a PAIR of 32-column groups: 64 right-hand-side columns against the same 64 streamed columns,
@@ -430,10 +453,197 @@ __global__ void __launch_bounds__(256) k_cov_panel_pair(const double *__restrict
   const int nfill = ctrl->cov_nfill;
   if (g0 * COV_R >= nfill) return;
   extern __shared__ double smem[];  // [CP2_COLS][CP_LD]
+  PCLK_BEGIN();
   if ((g0 + 1) * COV_R < nfill)     // uniform
     cov_pair_body<MASKED, true>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
   else
     cov_pair_body<MASKED, false>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
+  PCLK_END("pair");
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 5: the panel pass as ONE 8-wave workgroup per compute unit over 128 streamed columns, two LDS tiles, one barrier
+// per chunk (k_cov_panel_dp).
+//
+// What the counters and the in-kernel clock said about the two kernels above (profiles/r05_panel_*, README): HBM
+// traffic is the algorithmic 1.03 x, the LDS is 35 % busy, the waves wait to issue 70-76 % of their time -- and the
+// matrix pipe is busy 0.77 / 0.81 of the cycles that REALLY pass: the chip holds its clock at 1.5-2.1 GHz under these
+// kernels (s_memtime against s_memrealtime; the 32-column kernel, which moves more bytes per flop, clocks LOWER than
+// the pair kernel), which is where the distance to the 2.4 GHz peaks comes from.  What a kernel can still change is the
+// data it moves per flop -- every 64-column block stages its own copy of the right-hand-side columns from L2 (half as
+// many bytes again as X itself at 32 columns, as many again at 64) -- and the phases a workgroup stands still in.  Here:
+//   * 128 streamed columns per workgroup: half the right-hand-side traffic (L2 -> LDS) per byte of X;
+//   * 8 waves, wave w multiplies streamed tile w with every right-hand-side tile: two waves per SIMD, as before;
+//   * 32-row chunks, TWO LDS tiles: while chunk k is multiplied out of one, chunk k + 1 is written into the other --
+//     the stores sit between the matrix instructions of the chunk's first row step, the global loads of chunk k + 3
+//     between those of the second -- and ONE barrier per chunk (the kernels above: multiply | barrier | stage | barrier);
+//   * operands of the next row step are read while the current one multiplies; loads run two to three chunks ahead in
+//     two register stages; every staging operation is unconditional (a branch around one costs the compiler its count
+//     of the loads in flight).
+// NT = 2: one 32-column group per pass, NT = 4: a pair.  Same partial-sum layout as the kernels above (k_cov_reduce is
+// unchanged).  104 KB of LDS at NT = 4, 87 KB at NT = 2.
+// ------------------------------------------------------------------------------------------
+constexpr int DP_RB = 32;            // rows per chunk
+constexpr int DP_LD = DP_RB + CP_PAD;  // padded row stride of a column in LDS (doubles)
+constexpr int DP_SC = 128;           // streamed columns per workgroup
+template <bool MASKED, int NT>
+__device__ __forceinline__ void cov_dp_body(const double *__restrict__ X, const double *__restrict__ aux, long ld,
+                                            int p, const double *__restrict__ mask, const int *__restrict__ fcols,
+                                            int g0, int rows_per_slab, int nslab, int njg,
+                                            double *__restrict__ part, double *smem) {
+  constexpr int NS = DP_SC / 32;                // loads of streamed columns per thread and chunk
+  constexpr int NL = NS + NT / 2;               // ... and of right-hand-side columns behind them
+  constexpr int COLS = DP_SC + 16 * NT;         // columns staged per chunk
+  constexpr size_t BUF = (size_t)COLS * DP_LD;  // doubles per LDS tile
+  const int njg2 = (njg + 1) / 2;               // workgroups per slab (128 streamed columns each)
+  const int slab = blockIdx.x / njg2, jb = blockIdx.x - slab * njg2;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
+  const int ru = tid & 15, cbase = tid >> 4;    // 16 threads x 2 rows cover a chunk of one column; 32 columns per load
+  // streamed columns jb * 128 + cbase + 32 i (a column beyond p re-reads the last existing one of its thread: its
+  // products land in rows >= p, which the reduce kernel never stores)
+  const int jc = min(jb * DP_SC + cbase, p - 1);
+  const double *sx = X + (size_t)jc * ld + 2 * ru;
+  const long sstride = 32 * ld;
+  const int ilim = jb * DP_SC + cbase < p ? (p - 1 - (jb * DP_SC + cbase)) / 32 : 0;  // last i whose column exists
+  const double *src[NT / 2];
+#pragma unroll
+  for (int i = 0; i < NT / 2; i++) src[i] = gram_col(X, aux, ld, fcols[g0 * COV_R + i * 32 + cbase]) + 2 * ru;
+  const long r_begin = (long)slab * rows_per_slab, r_end = min(r_begin + rows_per_slab, ld);
+  const int nchunk = (int)((r_end - r_begin + DP_RB - 1) / DP_RB);
+  d2 stA[NL], stB[NL], mA = d2{1.0, 1.0}, mB = d2{1.0, 1.0};
+#define DP_LOAD1(st, ms, r, i)                                                                                  \
+  do {                                                                                                          \
+    if ((i) < NS)                                                                                               \
+      st[i] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(sx + min((i), ilim) * sstride + (r)));    \
+    else                                                                                                        \
+      st[i] = *reinterpret_cast<const d2 *>(src[(i) >= NS ? (i)-NS : 0] + (r));                                 \
+    if (MASKED && (i) == NL - 1) ms = *reinterpret_cast<const d2 *>(mask + (r) + 2 * ru);                       \
+  } while (0)
+#define DP_STORE1(buf, st, ms, i)                                                                               \
+  do {                                                                                                          \
+    d2 v__ = st[i];                                                                                             \
+    if (MASKED && (i) >= NS) v__ = v__ * ms;                                                                    \
+    *reinterpret_cast<d2 *>((buf) + 2 * ru + (size_t)((i)*32 + cbase) * DP_LD) = v__;                           \
+  } while (0)
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+  const size_t offa = (size_t)(wv * 16 + c) * DP_LD + 4 * q, offb = (size_t)(DP_SC + c) * DP_LD + 4 * q;
+  struct Ops {
+    d2 a0, a1, b0[NT], b1[NT];
+  };
+  auto read_ops = [&](const double *buf, int st, Ops &o) {
+    o.a0 = *reinterpret_cast<const d2 *>(buf + offa + 16 * st);
+    o.a1 = *reinterpret_cast<const d2 *>(buf + offa + 16 * st + 2);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      o.b0[t] = *reinterpret_cast<const d2 *>(buf + offb + (size_t)t * 16 * DP_LD + 16 * st);
+      o.b1[t] = *reinterpret_cast<const d2 *>(buf + offb + (size_t)t * 16 * DP_LD + 16 * st + 2);
+    }
+  };
+  // One chunk: DP_RB / 16 row steps of 4 x NT matrix instructions; staging operation n (0 .. 2 NL - 1: the NL stores of
+  // the next chunk into the other tile, then the NL loads of the chunk three ahead into the stage just stored) goes
+  // behind the matrix instructions, spread evenly.
+#define DP_CHUNK(cur, nxt, st, ms, rload)                                                                       \
+  do {                                                                                                          \
+    Ops oa__, ob__;                                                                                             \
+    read_ops(cur, 0, oa__);                                                                                     \
+    int n__ = 0;                                                                                                \
+    _Pragma("unroll") for (int s__ = 0; s__ < DP_RB / 16; s__++) {                                            \
+      Ops &o__ = (s__ & 1) ? ob__ : oa__;                                                                       \
+      if (s__ + 1 < DP_RB / 16) read_ops(cur, s__ + 1, (s__ & 1) ? oa__ : ob__);                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      _Pragma("unroll") for (int j__ = 0; j__ < 4; j__++) {                                                   \
+        const double a__ = j__ == 0 ? o__.a0.x : (j__ == 1 ? o__.a0.y : (j__ == 2 ? o__.a1.x : o__.a1.y));       \
+        _Pragma("unroll") for (int t__ = 0; t__ < NT; t__++) {                                                \
+          const double b__ = j__ == 0 ? o__.b0[t__].x : (j__ == 1 ? o__.b0[t__].y : (j__ == 2 ? o__.b1[t__].x : o__.b1[t__].y)); \
+          acc[t__] = __builtin_amdgcn_mfma_f64_16x16x4f64(a__, b__, acc[t__], 0, 0, 0);                         \
+        }                                                                                                       \
+        /* staging operations due after this group of NT matrix instructions */                                 \
+        const int due__ = (2 * NL * (s__ * 4 + j__ + 1)) / (4 * (DP_RB / 16));                                  \
+        _Pragma("unroll") for (int k__ = 0; k__ < 2 * NL; k__++) {                                            \
+          if (k__ >= n__ && k__ < due__) {                                                                      \
+            if (k__ < NL)                                                                                       \
+              DP_STORE1(nxt, st, ms, k__);                                                                      \
+            else                                                                                                \
+              DP_LOAD1(st, ms, rload, k__ - NL);                                                                \
+          }                                                                                                     \
+        }                                                                                                       \
+        n__ = due__;                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+  double *buf0 = smem, *buf1 = smem + BUF;
+  // a load beyond the slab's last chunk re-reads that last chunk (cache hits); the tile it is stored into is never multiplied
+  const long r_last = r_begin + (long)(nchunk - 1) * DP_RB;
+  // prologue: chunk 0 -> stage A -> tile 0; chunk 1 -> stage B; chunk 2 -> stage A
+#pragma unroll
+  for (int i = 0; i < NL; i++) DP_LOAD1(stA, mA, r_begin, i);
+#pragma unroll
+  for (int i = 0; i < NL; i++) DP_STORE1(buf0, stA, mA, i);
+  {
+    const long r1 = min(r_begin + DP_RB, r_last), r2 = min(r_begin + 2 * DP_RB, r_last);
+#pragma unroll
+    for (int i = 0; i < NL; i++) DP_LOAD1(stB, mB, r1, i);
+#pragma unroll
+    for (int i = 0; i < NL; i++) DP_LOAD1(stA, mA, r2, i);
+  }
+  __syncthreads();
+  // chunk k is in tile k & 1; chunk k + 1 waits in a register stage (odd chunks in B, even ones in A); during chunk k
+  // that stage is stored into the other tile and reloaded with chunk k + 3
+  for (int k = 0; k < nchunk; k += 2) {
+    {
+      const long rl = min(r_begin + (long)(k + 3) * DP_RB, r_last);
+      DP_CHUNK(buf0, buf1, stB, mB, rl);
+    }
+    __syncthreads();
+    if (k + 1 >= nchunk) break;
+    {
+      const long rl = min(r_begin + (long)(k + 4) * DP_RB, r_last);
+      DP_CHUNK(buf1, buf0, stA, mA, rl);
+    }
+    __syncthreads();
+  }
+#undef DP_CHUNK
+#undef DP_LOAD1
+#undef DP_STORE1
+  // streamed tile wv of this workgroup = tile wv & 3 of the 64-column group 2 jb + (wv >> 2) in the layout of the
+  // kernels above; the last workgroup's second half may lie beyond the last group
+  const int jg = 2 * jb + (wv >> 2);
+  if (jg < njg) {
+    const size_t tiles_per_slab = (size_t)njg * COV_NJ * 2;
+    double *out = part + ((size_t)slab * tiles_per_slab + (size_t)(jg * COV_NJ + (wv & 3)) * 2) * 256;
+    *reinterpret_cast<d4 *>(out + lane * 4) = acc[0];
+    *reinterpret_cast<d4 *>(out + 256 + lane * 4) = acc[1];
+    if (NT == 4) {
+      double *out2 = out + (size_t)nslab * tiles_per_slab * 256;
+      *reinterpret_cast<d4 *>(out2 + lane * 4) = acc[NT - 2];
+      *reinterpret_cast<d4 *>(out2 + 256 + lane * 4) = acc[NT - 1];
+    }
+  }
+}
+
+// grid: one 512-thread block per (slab, 128 streamed columns); ngroups = 1: group g0 only (NT = 2), 2: the pair g0,
+// g0 + 1 -- or group g0 alone if the second one is beyond the fill list (decided on the device)
+template <bool MASKED>
+__global__ void __launch_bounds__(512, 1) k_cov_panel_dp(const double *__restrict__ X, const double *__restrict__ aux,
+                                                         long ld, int p, const double *__restrict__ mask,
+                                                         const int *__restrict__ fcols, int g0, int ngroups,
+                                                         int rows_per_slab, int nslab, int njg,
+                                                         double *__restrict__ part, const FitCtrl *__restrict__ ctrl,
+                                                         int big) {
+  KT(5);
+  if (big ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
+  const int nfill = ctrl->cov_nfill;
+  if (g0 * COV_R >= nfill) return;
+  extern __shared__ double smem[];
+  PCLK_BEGIN();
+  if (ngroups >= 2 && (g0 + 1) * COV_R < nfill)  // uniform
+    cov_dp_body<MASKED, 4>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
+  else
+    cov_dp_body<MASKED, 2>(X, aux, ld, p, mask, fcols, g0, rows_per_slab, nslab, njg, part, smem);
+  PCLK_END("dp");
 }
 
 // G[j, slot_of[col]] = sum over slabs (fixed order); grid (tiles of one group, groups)
@@ -699,6 +909,19 @@ hipError_t launch_cov_panel(const double *X, const double *aux, long ld, int p, 
                             int g0, int ngroups, int rows_per_slab, int nslab, double *part, const FitCtrl *ctrl,
                             int parked, hipStream_t st, int variant) {
   const int pt = (p + 15) / 16, njg = (pt + COV_NJ - 1) / COV_NJ;
+  if (variant == 5 && ngroups <= 2) {
+    // one 8-wave block per (slab, 128-column group): k_cov_panel_dp (one or both groups in one pass over X)
+    const size_t ldsd = (size_t)2 * (DP_SC + 64) * DP_LD * sizeof(double);
+    const long nbd = (long)nslab * ((njg + 1) / 2);
+    if (mask)
+      hipLaunchKernelGGL(k_cov_panel_dp<true>, dim3((unsigned)nbd), dim3(512), ldsd, st, X, aux, ld, p, mask, fcols, g0,
+                         ngroups, rows_per_slab, nslab, njg, part, ctrl, parked);
+    else
+      hipLaunchKernelGGL(k_cov_panel_dp<false>, dim3((unsigned)nbd), dim3(512), ldsd, st, X, aux, ld, p, mask, fcols, g0,
+                         ngroups, rows_per_slab, nslab, njg, part, ctrl, parked);
+    LAUNCH_CHECK();
+    return hipSuccess;
+  }
   if (variant == 4 && ngroups <= 2) {
     // one block per (slab, 64-column group) for BOTH groups of the launch: X streamed once
     const size_t lds2 = (size_t)CP2_COLS * CP_LD * sizeof(double);
@@ -732,8 +955,15 @@ hipError_t cov_panel_prepare() {
   e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_pair<true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_pair<false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_pair<false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+  if (e != hipSuccess) return e;
+  const int ldsd = (int)((size_t)2 * (DP_SC + 64) * DP_LD * sizeof(double));
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_dp<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsd);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_panel_dp<false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, ldsd);
 }
 
 hipError_t launch_cov_reduce(const double *part, int p, const int *fcols, const int *slot_of, double *G, int g0,

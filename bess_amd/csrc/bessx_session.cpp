@@ -1188,14 +1188,17 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
         // row slabs: two 256-thread blocks of the panel kernel share a CU (50 KB of LDS each), so pick the slab count
         // whose block count wastes the least of the last round of 512 blocks
+        if (const char *ev = test_hook("panel")) s->panel_variant = std::string(ev) == "dp" ? 5 : 0;
         long ns = 1, rps = ld;
         {
-          const long conc = 512;  // blocks resident at a time
+          // (k_cov_panel_dp: one 8-wave block per compute unit, 128 streamed columns per block)
+          const bool dp = s->panel_variant == 5;
+          const long conc = dp ? 256 : 512;  // blocks resident at a time
           double best = 1e300;
           const long ns_max = std::max<long>(1, std::min<long>(64, ld / 256));
           for (long t = 1; t <= ns_max; t++) {
             const long r = ((ld + t - 1) / t + 63) / 64 * 64, used = (ld + r - 1) / r;
-            const long blocks = (long)njg * used;
+            const long blocks = (long)(dp ? (njg + 1) / 2 : njg) * used;
             const double cost = (double)((blocks + conc - 1) / conc) * (double)r * (blocks < conc ? 2.0 : 1.0);
             if (cost < best) {
               best = cost;

@@ -162,3 +162,37 @@ def test_cv_row_sets_share_their_fills(gpu, monkeypatch, n, p, K):
         np.testing.assert_allclose(a[i]["beta"], b[i]["beta"], rtol=1e-9, atol=1e-13)
     want = P.trace(X, y, ic_type=3, is_cv=True, K=K, cv_fold_id=fold, path_type=2, s_min=1, s_max=30)
     assert_same_trace(a[0]["trace"], want, what="shared CV fills")
+
+
+def test_panel_kernel_dp_against_numpy_and_the_default_kernels(gpu, monkeypatch):
+    """k_cov_panel_dp (round 5: one 8-wave workgroup per compute unit over 128 streamed columns, two LDS tiles, one
+    barrier per chunk; test hook panel=dp): its Gram columns against NumPy X^T X_S -- one group and a pair per pass, a
+    column count that is no multiple of 128, a fold mask -- and a path run with it against the default kernels' path."""
+    X, y, _, _ = synth.make_lm(3000, 1100, 12, seed=5)  # 1100 columns: the last workgroup's second half is partly empty
+    n, p = X.shape
+    Xc = X - X.mean(axis=0)
+    Xn = np.sqrt(float(n)) * Xc / np.sqrt((Xc * Xc).sum(axis=0))
+    cols = ((np.arange(128) * 29 + 7) % p).astype(np.int32)
+    want = Xn.T @ Xn[:, cols]
+    seq = np.arange(1, 41)
+    with gpu.Session(X, y, score_mode=2) as s0:
+        ref = s0.sequential_path(seq, ic_type=3)
+        fold = synth.make_cv_folds(n, 4)
+        s0.set_cv(4, fold)
+        ref_cv = s0.gs_path(1, 30, ic_type=3, is_cv=True)
+    hooks(monkeypatch, panel="dp")
+    with gpu.Session(X, y, score_mode=2) as s:
+        s.cov_prefill_begin(cols)
+        s.cov_prefill_compute(0, 1)
+        s.cov_prefill_compute(1, 1)
+        s.cov_prefill_compute(2, 2)
+        got = s.cov_prefill_export(0, 4).reshape(128, p).T
+        s.cov_prefill_end()
+        assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+        out = s.sequential_path(seq, ic_type=3)
+        assert np.array_equal(out["cand_support"], ref["cand_support"]) and np.array_equal(out["cand_iters"], ref["cand_iters"])
+        np.testing.assert_allclose(out["cand_ic"], ref["cand_ic"], rtol=1e-10)
+        s.set_cv(4, fold)  # the fold-major copy: masked / multi-row-set fills through the same kernel
+        cv = s.gs_path(1, 30, ic_type=3, is_cv=True)
+        assert cv["best_T0"] == ref_cv["best_T0"] and np.array_equal(cv["cand_T0"], ref_cv["cand_T0"])
+        np.testing.assert_allclose(cv["cand_ic"], ref_cv["cand_ic"], rtol=1e-10)
