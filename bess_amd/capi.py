@@ -290,7 +290,9 @@ class Session:
                  8: "cv_union_fills", 9: "tie_rescues", 10: "cache_restarts", 11: "cv_contexts_dropped",
                  12: "cv_fold_contexts", 13: "shared_wide_fills", 14: "kpath_chunked_paths", 15: "kpath_stitch_refits",
                  16: "kpath_chunk_fills", 17: "kpath_chains_last_path",
-                 18: "kpath_stitch_giveups", 19: "group_XTX_ns"}  # (4-6: mechanisms removed in round 3)
+                 18: "kpath_stitch_giveups", 19: "group_XTX_ns",
+                 20: "kpath_merged_chunk_phases", 21: "kpath_chains_taken_over", 22: "kpath_coarse_us",
+                 23: "kpath_chunks_us", 24: "kpath_stitch_us"}  # (4-6: mechanisms removed in round 3)
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in names.items()}
 
     def screening(self):

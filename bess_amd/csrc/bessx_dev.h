@@ -189,6 +189,73 @@ bool sel_cgr_applies(int len, int m);
 hipError_t launch_sel_cgr(const double *score, int len, int k, int *A_new, const FitCtrl *ctrl, int slot,
                           const TopkNeed *need, double ridge, const double *rhs, double *sol, const CholFuse *fuse,
                           int maxit, hipStream_t st, double tol);
+// ---------------------------------------------------------------------------------------------------------------
+// Merged launches over the chunk chains of one sequential path (round 5, bessx_kchunks.cpp: mc_run_chunks).  The C chains
+// of the chunk phase used to run on a stream and a host thread each; the device runs about 2.5 single-workgroup kernels
+// of different streams at a time (tools/probe/launch_rate.hip), so four chains got 2.4 x one chain's rate.  Here every
+// chain is a workgroup (or a slice of the grid) of the SAME launch on ONE stream, and the sequencing the host did per
+// chain -- which candidate, which PDAS iteration, is the fit over, open the next one -- lives in device memory:
+//   k_mc_cov_d    (grid: column blocks x chains)  d and the sacrifice scores of every chain whose coefficients changed
+//   k_mc_sel_cgr  (grid: chains)                  per chain: [record the finished candidate, open the next one,] the
+//                                                 selection (repeated set / arg-max / full search + cache lookup), the
+//                                                 solve, the commit -- the bodies of k_sel_cgr, gate by gate
+// One pair of launches = one PDAS iteration WITH a solve for every chain; the confirming iteration of a candidate and the
+// first selection of the next one ride in the same k_mc_sel_cgr.  The host queues pairs ahead, reads all chains' states
+// back in one block (k_mc_status), serves parked chains with ONE union fill, and takes a chain over (the proven per-
+// context path) where anything unusual turns up: a tie at the selection boundary, a solve that missed its target, a
+// fit out of iterations, a loss that has to be recomputed.
+// ---------------------------------------------------------------------------------------------------------------
+struct McState {   // per chain, device memory: written by k_mc_sel_cgr / k_mc_resume only
+  int cand;        // index within the chunk of the candidate being fitted
+  int ncand;       // candidates of the chunk
+  int need_d;      // the coefficients changed since the last score pass: k_mc_cov_d has work for this chain
+  int finished;    // 1: every candidate recorded; 2: stopped, the host takes the chain over from candidate `cand`
+  int parked;      // cov_stall of a parked fit (1 missing columns, 2 solve, 3 tie, 4 full cache); 0: running
+  int resume;      // set with the wake-up after a fill: this slot's solve is still to run
+  int prev_fresh;  // the previous candidate ended on a repeated set with fresh scores (arg-max start of the next one)
+  int prev_T0;
+  int solves;      // statistics: solves committed
+  int why;         // finished == 2: 1 out of iterations, 2 info / cov_miss, 3 parked with a code the host does not serve
+  int pad_[6];
+};
+static_assert(sizeof(McState) == 64, "McState is copied to the host in 64-byte records");
+constexpr int MC_REC_I = 4;  // per candidate: T0, PDAS iterations, sse_valid, done
+constexpr int MC_REC_D = 4;  // per candidate: coef0, sse_dot, sse_nrm, (unused)
+struct McChain {   // one chain of a merged run: device memory, constant while the run lasts
+  McState *state;
+  const int *seq;  // the chunk's sparsity levels (device), state->ncand of them
+  int width;       // row length of rec_A / rec_b (largest level of the path)
+  int max_iter, p;
+  // score pass from the cached Gram columns (the arguments of k_cov_d)
+  const double *G, *xty, *xtx;
+  double n_t, lambda;
+  const unsigned char *always;
+  double *d_out, *bd, *bmm;
+  // selection and solve (the arguments of k_sel_cgr as enqueue_lm_slot_cov fills them; per candidate only the level and
+  // the arg-max flags change)
+  TopkNeed nd, nd1;  // nd1: the same with inc1 = bmm_fresh = 1 (arg-max start of a candidate one level up)
+  CholFuse fz;       // (its T0 is not read: k_cgr's body takes the level from the size of the system)
+  int *A_new;
+  double *sol;
+  double tol;
+  int maxit;
+  // per-candidate records
+  int *rec_i;
+  double *rec_d;
+  int *rec_A;
+  double *rec_b;
+};
+bool mc_applies(int p, int kmax);
+hipError_t launch_mc_cov_d(const McChain *chains, int nchains, int p, hipStream_t st);
+hipError_t launch_mc_sel_cgr(const McChain *chains, int nchains, int p, hipStream_t st);
+// every chain's state and control block into pinned memory (192 bytes per chain), then the sequence number
+hipError_t launch_mc_status(const McChain *chains, int nchains, unsigned char *host, unsigned long long *seq_host,
+                            unsigned long long seq, hipStream_t st);
+// after the fill that served it: wake the parked fit up (k_cov_resume) and mark its solve as due
+hipError_t launch_mc_resume(const McChain *chains, int chain, hipStream_t st);
+// stop a chain where it stands (the host takes it over)
+hipError_t launch_mc_stop(const McChain *chains, int chain, hipStream_t st);
+
 hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_skip0, const double *rhs,
                            const int *rhs_gather, double *sol, int *info, double *rdiag, double *z,
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);

@@ -273,6 +273,7 @@ struct bessx_session {
   bessx::KChains *kch = nullptr;        // parent: contexts, host threads, the fill rendezvous (created at first use)
   bessx_session *kch_owner = nullptr;   // chain context: the session whose cache it reads
   int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
+  long long kch_merged = 0, kch_takeovers = 0;  // chunk phases run as merged launches; chains the host had to finish
   long long kch_paths = 0, kch_refits = 0, kch_chunk_fills = 0;  // paths run chunked, stitch refits, fills in the chunk phase
   int kch_last_chains = 0;              // chains of the last chunked path
   bool kch_auto_off = false;            // the chunks of a path did not merge with the chain: the automatic choice is one chain
@@ -386,7 +387,13 @@ struct Scratch {
 inline int caller_col(const bessx_session *s, int j) { return s->screen_map.empty() ? j : s->screen_map[j]; }
 
 struct SlotFuse;
-struct Candidate;
+struct Candidate {  // one (s, lambda) of a path: the full-data fit's model (normalised scale) and its criteria
+  int T0 = 0;
+  double lambda = 0.0;
+  SparseVec beta;
+  double coef0 = 0.0, loss = 0.0, ic = 0.0;
+  int iters = 0;
+};
 struct PgsArgs;
 
 // ---- bessx_session.cpp / bessx_fit.cpp / bessx_cv.cpp / bessx_paths.cpp: what they call across files

@@ -744,14 +744,14 @@ __global__ void __launch_bounds__(256) k_cov_compact_sets(const CovRowSets rs, i
 // d_j = (X^T m y)_j - sum_i G[j, slot(A_i)] b_i ; 64 columns per block, the sum over i cut in 4 interleaved parts.
 // The sacrifice score of k_score (LM branch) is formed in the same kernel: bd_j = (phi b_j + d_j / phi)^2 with
 // d_j / n_t - 2 lambda b_j and phi = sqrt(2 lambda + x_j.x_j / n_t).
-__global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int p, const int *__restrict__ slot_of,
-                                               const double *__restrict__ xty, const int *__restrict__ A_cur,
-                                               const double *__restrict__ b_cur, double *__restrict__ d_out,
-                                               const double *__restrict__ beta_dense, const double *__restrict__ xtx,
-                                               double n_t, double lambda, const unsigned char *__restrict__ always,
-                                               double *__restrict__ bd, const unsigned char *__restrict__ inA,
-                                               double *__restrict__ bmm, const FitCtrl *__restrict__ ctrl, int slot) {
-  KT(4);
+// (slot < 0: the caller has checked the gate itself -- the merged launches over chunk chains, k_mc_cov_d)
+__device__ __forceinline__ void cov_d_body(const double *__restrict__ G, int p, const int *__restrict__ slot_of,
+                                           const double *__restrict__ xty, const int *__restrict__ A_cur,
+                                           const double *__restrict__ b_cur, double *__restrict__ d_out,
+                                           const double *__restrict__ beta_dense, const double *__restrict__ xtx,
+                                           double n_t, double lambda, const unsigned char *__restrict__ always,
+                                           double *__restrict__ bd, const unsigned char *__restrict__ inA,
+                                           double *__restrict__ bmm, const FitCtrl *__restrict__ ctrl, int slot) {
   // what the epilogue needs of this block's 32 columns does not depend on the control block: these loads are in
   // flight while the gate below waits for its own (one round trip less on the block's critical path)
   const int jj = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
   const double e_xty = epi ? xty[j] : 0.0, e_b = epi ? beta_dense[j] : 0.0, e_xtx = epi ? xtx[j] : 1.0;
   const unsigned char e_in = epi ? inA[j] : (unsigned char)0;
   const unsigned char e_al = (epi && always != nullptr) ? always[j] : (unsigned char)0;
-  if (ctrl->done || ctrl->l != slot - 1) return;
+  if (slot >= 0 && (ctrl->done || ctrl->l != slot - 1)) return;
   // 32 columns x 8 thread groups per block; group g adds the active columns i = g, g+8, ... (two interleaved
   // accumulators), the 8 partial sums are added in group order: a fixed summation tree.
   constexpr int CHUNK = 512;  // active columns staged per round: cache slots and coefficients go through LDS
@@ -844,6 +844,30 @@ __global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int
     bmm[2 * gridDim.x + blockIdx.x] = (double)mi;
     if (blockIdx.x == 0) const_cast<FitCtrl *>(ctrl)->fast_same = 1;
   }
+}
+
+__global__ void __launch_bounds__(256) k_cov_d(const double *__restrict__ G, int p, const int *__restrict__ slot_of,
+                                               const double *__restrict__ xty, const int *__restrict__ A_cur,
+                                               const double *__restrict__ b_cur, double *__restrict__ d_out,
+                                               const double *__restrict__ beta_dense, const double *__restrict__ xtx,
+                                               double n_t, double lambda, const unsigned char *__restrict__ always,
+                                               double *__restrict__ bd, const unsigned char *__restrict__ inA,
+                                               double *__restrict__ bmm, const FitCtrl *__restrict__ ctrl, int slot) {
+  KT(4);
+  cov_d_body(G, p, slot_of, xty, A_cur, b_cur, d_out, beta_dense, xtx, n_t, lambda, always, bd, inA, bmm, ctrl, slot);
+}
+
+// The score pass of every chunk chain whose coefficients changed since its last one, in ONE launch (bessx_dev.h, McChain):
+// blockIdx.y = chain, blockIdx.x = its block of 32 columns.  Chains that are finished, parked or whose scores are still
+// those of their coefficients fall through.
+__global__ void __launch_bounds__(256) k_mc_cov_d(const McChain *__restrict__ chains) {
+  const McChain &ch = chains[blockIdx.y];
+  const McState *st = ch.state;
+  if (st->finished || st->parked || !st->need_d) return;
+  const FitCtrl *ctrl = ch.nd.ctrl;
+  if (ctrl->done || ctrl->l < 0) return;
+  cov_d_body(ch.G, ch.p, ch.nd.slot_of, ch.xty, ch.nd.A_cur, ch.fz.b_cur, ch.d_out, ch.fz.beta_dense, ch.xtx, ch.n_t,
+             ch.lambda, ch.always, ch.bd, ch.nd.inA, ch.bmm, ctrl, -1);
 }
 
 // Gram tiles of the new active set in the layout k_chol / k_bc_* read (see k_gram_assemble)
@@ -1024,6 +1048,12 @@ hipError_t launch_cov_d(const double *G, int p, const int *slot_of, const double
                         const FitCtrl *ctrl, int slot, hipStream_t st) {
   hipLaunchKernelGGL(k_cov_d, dim3((p + 31) / 32), dim3(256), 0, st, G, p, slot_of, xty, A_cur, b_cur, d_out,
                      beta_dense, xtx, n_t, lambda, always, bd, inA, bmm, ctrl, slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_mc_cov_d(const McChain *chains, int nchains, int p, hipStream_t st) {
+  hipLaunchKernelGGL(k_mc_cov_d, dim3((p + 31) / 32, nchains), dim3(256), 0, st, chains);
   LAUNCH_CHECK();
   return hipSuccess;
 }

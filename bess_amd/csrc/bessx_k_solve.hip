@@ -1355,8 +1355,10 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
                                          const double tol) {
   __shared__ int same_any_sh;
   if (ctrl->done || ctrl->l != slot - 1) return;
+  // (m, the size of the system, is the sparsity level fz.T0 of the fit: the merged launches over chunk chains hand one
+  // CholFuse per chain over for all its candidates and the level with m)
   if (ctrl->same_prev) {
-    commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+    commit_body(fz.ctrl, slot, m, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
                 fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
     return;
   }
@@ -1671,7 +1673,7 @@ __device__ __forceinline__ void cgr_body(int m, int nc, double ridge, const doub
   }
   __syncthreads();
   CGP(5);
-  commit_body(fz.ctrl, slot, fz.T0, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
+  commit_body(fz.ctrl, slot, m, A_new, sol, 0, 0, fz.A_cur, fz.b_cur, fz.beta_dense, fz.hist, fz.hist_beta,
               fz.hist_coef0, fz.hist_stride, &same_any_sh, fz.inA);
   CGP(6);
 }
@@ -1776,6 +1778,203 @@ __global__ void __launch_bounds__(512) k_sel_cgr(const double *__restrict__ scor
   }
   KT(15);  // end of block 0: what follows until the next kernel's start stamp is boundary / idle time
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// Merged launches over chunk chains (bessx_dev.h, McChain): one workgroup per chain does what the host's slot protocol
+// and k_sel_cgr did for it -- record a finished candidate, open the next one (k_fit_continue), select, look the columns
+// up, solve, commit -- with the very bodies of k_sel_cgr (topk_body, cgr_body: same instances per level, same gates
+// through the control block), so a chain's arithmetic is the single chain's, operation by operation.
+// ------------------------------------------------------------------------------------------
+// (the selection and the four instances of the solve as functions of their own: inlined into one kernel they shared one
+// register allocation and spilled 0.7-1.2 KB per thread)
+template <int EB>
+__device__ __noinline__ void mc_topk_call(const double *score, int p, int k, int *out, const FitCtrl *ctrl, int slot,
+                                          const TopkNeed *nd) {
+  topk_body<EB, 512>(score, nullptr, p, p, k, out, nullptr, ctrl, slot, nullptr, *nd);
+}
+template <int RPT, int NCW>
+__device__ __noinline__ void mc_cgr_call(int m, int nc, double ridge, const double *rhs, const int *A_new, double *sol,
+                                         const FitCtrl *ctrl, int slot, const CholFuse *fz, int maxit, double tol) {
+  cgr_body<RPT, NCW>(m, nc, ridge, rhs, A_new, sol, ctrl, slot, *fz, maxit, tol);
+}
+
+template <int EB>
+__global__ void __launch_bounds__(512) k_mc_sel_cgr(const McChain *__restrict__ chains) {
+  // (grid = (1, chains): the selection body takes blockIdx.x for the chunk of the scores it works on -- always 0 here)
+  const McChain &ch = chains[blockIdx.y];
+  McState *st = ch.state;
+  const int tid = threadIdx.x;
+  if (st->finished || st->parked) return;  // uniform
+  // (nd / nd1 and fz are read where they lie -- uniform addresses, scalar loads; thread-private copies of the two
+  // structures went to scratch memory and every field read became a private-memory load: 59 us per launch)
+  const TopkNeed &nd = ch.nd;
+  const CholFuse &fz = ch.fz;
+  FitCtrl *ctrl = nd.ctrl;
+  {
+    // the score pass of this round has run for this chain (k_mc_cov_d, the launch before): the scores are fresh
+    const int nd_ = st->need_d;
+    __syncthreads();
+    if (nd_ && ctrl->done == 0 && tid == 0) st->need_d = 0;
+    __syncthreads();
+    if (nd_ && ctrl->done) {
+      // (a fit that ended on a cycle right after a solve: its scores were never asked for; fall into the loop below)
+    }
+  }
+  for (int pass = 0; pass < 4; pass++) {
+    __syncthreads();
+    const int resume = st->resume;  // uniform
+    if (!resume) {
+      if (ctrl->done) {
+        // ---- the candidate is finished: its record, then the next one (k_fit_continue on the device state)
+        const int cand = st->cand, T0 = ctrl->T0, W = ch.width;
+        for (int i = tid; i < W; i += 512) {
+          ch.rec_A[(size_t)cand * W + i] = i < T0 ? fz.A_cur[i] : -1;
+          ch.rec_b[(size_t)cand * W + i] = i < T0 ? fz.b_cur[i] : 0.0;
+        }
+        const int fresh = (ctrl->d_fresh && !ctrl->info && !ctrl->cov_miss) ? 1 : 0;
+        const int bad = (ctrl->info || ctrl->cov_miss) ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) {
+          ch.rec_i[cand * MC_REC_I + 0] = T0;
+          ch.rec_i[cand * MC_REC_I + 1] = ctrl->l;
+          ch.rec_i[cand * MC_REC_I + 2] = ctrl->sse_valid;
+          ch.rec_i[cand * MC_REC_I + 3] = 1;
+          ch.rec_d[cand * MC_REC_D + 0] = ctrl->coef0;
+          ch.rec_d[cand * MC_REC_D + 1] = ctrl->sse_dot;
+          ch.rec_d[cand * MC_REC_D + 2] = ctrl->sse_nrm;
+        }
+        if (bad) {  // (the record is not to be trusted: the host redoes this candidate)
+          if (tid == 0) {
+            ch.rec_i[cand * MC_REC_I + 3] = 0;
+            st->finished = 2;
+            st->why = 2;
+          }
+          return;
+        }
+        if (cand + 1 >= st->ncand) {
+          if (tid == 0) {
+            st->cand = cand + 1;
+            st->finished = 1;
+          }
+          return;
+        }
+        const int Tn = ch.seq[cand + 1];
+        for (int i = tid; i < Tn; i += 512) nd.cm_hist[i] = 0;
+        __syncthreads();
+        if (tid == 0) {
+          st->cand = cand + 1;
+          st->prev_fresh = fresh;
+          st->prev_T0 = T0;
+          ctrl->done = 0;
+          ctrl->l = 0;
+          ctrl->T0 = Tn;
+          ctrl->irls_done = 0;
+          ctrl->irls_steps = 0;
+          ctrl->info = 0;
+          ctrl->same_prev = 0;
+          ctrl->d_fresh = 0;
+          ctrl->cov_nfill = 0;
+          ctrl->cov_stall = 0;
+          ctrl->cov_groups = 0;
+          ctrl->cov_miss = 0;
+          ctrl->cov_nmiss = 0;
+          ctrl->sse_valid = 0;
+          ctrl->fast_same = 0;
+          ctrl->serial = ctrl->serial + 1;
+          if (!fresh) st->need_d = 1;
+        }
+        __syncthreads();
+        if (!fresh) return;  // the coefficients are newer than the scores: the next score pass first
+      } else if (st->need_d) {
+        return;  // (nothing to select on: the score pass of the next round comes first)
+      }
+      const int T0 = ctrl->T0;
+      const int slot = ctrl->l + 1;
+      if (slot > ch.max_iter || ctrl->l < 0) {  // out of iterations (or a state this kernel does not know): the host's
+        if (tid == 0) {
+          st->finished = 2;
+          st->why = 1;
+        }
+        return;
+      }
+      // ---- the selection of this slot: k_topk's body with the cache lookup (repeated set, arg-max start, full search)
+      // (nd1 = nd with the arg-max flags set: the first selection of a candidate one level above a predecessor that
+      // ended on a repeated set -- the scores are those its last iteration confirmed A_cur on)
+      const bool first = slot == 1 && st->prev_fresh && T0 == st->prev_T0 + 1;  // uniform
+      mc_topk_call<EB>(ch.bd, ch.p, T0, ch.A_new, ctrl, slot, first ? &ch.nd1 : &ch.nd);
+      __syncthreads();
+      if (ctrl->l < 0) {  // parked: missing columns (1), a tie at the selection boundary (3), a full cache (4)
+        if (tid == 0) st->parked = ctrl->cov_stall;
+        return;
+      }
+    } else {
+      __syncthreads();
+      if (tid == 0) st->resume = 0;
+    }
+    // ---- the solve (or the record-and-stop of a repeated set) and the commit: k_cgr's body, the instance k_sel_cgr
+    // launches for this level
+    {
+      const int T0 = ctrl->T0, slot = ctrl->l + 1, nc = (T0 + 7) / 8;
+      if (T0 <= 64)
+        mc_cgr_call<1, 8>(T0, nc, ch.lambda, ch.xty, ch.A_new, ch.sol, ctrl, slot, &ch.fz, ch.maxit, ch.tol);
+      else if (T0 <= 128)
+        mc_cgr_call<2, 16>(T0, nc, ch.lambda, ch.xty, ch.A_new, ch.sol, ctrl, slot, &ch.fz, ch.maxit, ch.tol);
+      else if (T0 <= 192)
+        mc_cgr_call<3, 24>(T0, nc, ch.lambda, ch.xty, ch.A_new, ch.sol, ctrl, slot, &ch.fz, ch.maxit, ch.tol);
+      else
+        mc_cgr_call<4, 26>(T0, nc, ch.lambda, ch.xty, ch.A_new, ch.sol, ctrl, slot, &ch.fz, ch.maxit, ch.tol);
+    }
+    __syncthreads();
+    if (ctrl->l < 0) {  // the solve parked the fit (2: residual target missed / dependent columns): the host's Cholesky
+      if (tid == 0) st->parked = ctrl->cov_stall;
+      return;
+    }
+    if (!ctrl->done) {  // a solve was committed and the fit goes on: the next score pass
+      if (tid == 0) {
+        st->need_d = 1;
+        st->solves += 1;
+      }
+      return;
+    }
+    // the fit has ended (a repeated set: the scores stand; or a cycle after a solve): next pass records it
+  }
+}
+
+// all chains' states and control blocks into pinned memory: [McState (64 B) | FitCtrl (128 B)] per chain, then the
+// sequence number (system-scope release, as k_publish)
+__global__ void __launch_bounds__(64) k_mc_status(const McChain *__restrict__ chains, int nchains, unsigned char *host,
+                                                  unsigned long long *seq_host, unsigned long long seq) {
+  const int tid = threadIdx.x;
+  for (int c = 0; c < nchains; c++) {
+    const unsigned long long *s8 = reinterpret_cast<const unsigned long long *>(chains[c].state);
+    const unsigned long long *c8 = reinterpret_cast<const unsigned long long *>(chains[c].nd.ctrl);
+    unsigned long long *h8 = reinterpret_cast<unsigned long long *>(host + (size_t)c * 192);
+    if (tid < 8) h8[tid] = s8[tid];
+    if (tid >= 8 && tid < 24) h8[tid] = c8[tid - 8];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_mc_resume(const McChain *__restrict__ chains, int chain) {
+  McState *st = chains[chain].state;
+  FitCtrl *ctrl = chains[chain].nd.ctrl;
+  if (ctrl->cov_stall) {
+    ctrl->cov_stall = 0;
+    ctrl->l = -1 - ctrl->l;
+  }
+  st->parked = 0;
+  st->resume = 1;
+}
+
+__global__ void k_mc_stop(const McChain *__restrict__ chains, int chain) {
+  McState *st = chains[chain].state;
+  if (!st->finished) {
+    st->finished = 2;
+    st->why = 3;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2174,6 +2373,36 @@ hipError_t launch_sel_cgr(const double *score, int len, int k, int *A_new, const
     SC_BY_M(64);
 #undef SC_BY_M
 #undef SC_GO
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// merged launches over chunk chains: scores in one chunk of at most 32768, levels within k_sel_cgr's range
+bool mc_applies(int p, int kmax) { return sel_cgr_applies(p, kmax) && topk_can_fuse_need(p); }
+hipError_t launch_mc_sel_cgr(const McChain *chains, int nchains, int p, hipStream_t st) {
+  const int per = (p + 511) / 512;
+  if (per <= 8)
+    hipLaunchKernelGGL((k_mc_sel_cgr<8>), dim3(1, nchains), dim3(512), 0, st, chains);
+  else if (per <= 24)
+    hipLaunchKernelGGL((k_mc_sel_cgr<24>), dim3(1, nchains), dim3(512), 0, st, chains);
+  else
+    hipLaunchKernelGGL((k_mc_sel_cgr<64>), dim3(1, nchains), dim3(512), 0, st, chains);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_mc_status(const McChain *chains, int nchains, unsigned char *host, unsigned long long *seq_host,
+                            unsigned long long seq, hipStream_t st) {
+  hipLaunchKernelGGL(k_mc_status, dim3(1), dim3(64), 0, st, chains, nchains, host, seq_host, seq);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_mc_resume(const McChain *chains, int chain, hipStream_t st) {
+  hipLaunchKernelGGL(k_mc_resume, dim3(1), dim3(1), 0, st, chains, chain);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_mc_stop(const McChain *chains, int chain, hipStream_t st) {
+  hipLaunchKernelGGL(k_mc_stop, dim3(1), dim3(1), 0, st, chains, chain);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -25,7 +25,35 @@ struct KChains {
   FoldPool pool;
   bool pool_started = false;
   FillRendezvous rdv;  // the fill rendezvous (bessx_sync.h: built and hammered under ThreadSanitizer, tools/tsan)
+  // merged launches over the chains (mc_run_chunks): device copies of the chains' descriptions and states, the chunk's
+  // levels, the per-candidate records; pinned status block and its sequence number
+  McChain *mc_chains = nullptr;
+  McState *mc_states = nullptr;
+  int *mc_seq = nullptr, *mc_rec_i = nullptr, *mc_rec_A = nullptr;
+  double *mc_rec_d = nullptr, *mc_rec_b = nullptr;
+  size_t mc_cap_cand = 0, mc_cap_cells = 0;
+  unsigned char *mc_status_h = nullptr;
+  unsigned long long *mc_flag = nullptr, mc_seq_no = 0;
 };
+
+static void mc_free(KChains *k) {
+  if (k->mc_chains) (void)hipFree(k->mc_chains);
+  if (k->mc_states) (void)hipFree(k->mc_states);
+  if (k->mc_seq) (void)hipFree(k->mc_seq);
+  if (k->mc_rec_i) (void)hipFree(k->mc_rec_i);
+  if (k->mc_rec_A) (void)hipFree(k->mc_rec_A);
+  if (k->mc_rec_d) (void)hipFree(k->mc_rec_d);
+  if (k->mc_rec_b) (void)hipFree(k->mc_rec_b);
+  if (k->mc_status_h) (void)hipHostFree(k->mc_status_h);
+  if (k->mc_flag) (void)hipHostFree(k->mc_flag);
+  k->mc_chains = nullptr;
+  k->mc_states = nullptr;
+  k->mc_seq = k->mc_rec_i = k->mc_rec_A = nullptr;
+  k->mc_rec_d = k->mc_rec_b = nullptr;
+  k->mc_status_h = nullptr;
+  k->mc_flag = nullptr;
+  k->mc_cap_cand = k->mc_cap_cells = 0;
+}
 
 // between two candidates of a chunk chain: if another chain waits to fill, drain this chain's stream and stand still
 void kchains_safe_point(bessx_session *c) {
@@ -50,6 +78,7 @@ void kchains_free(bessx_session *s) {
   if (!s || !s->kch) return;
   KChains *k = s->kch;
   if (k->pool_started) k->pool.stop();
+  mc_free(k);
   for (bessx_session *c : k->ctx) chain_ctx_free(c);
   if (!k->pool.broken) delete k;  // (a broken pool's threads may still touch it: leaked on purpose)
   s->kch = nullptr;
@@ -205,6 +234,368 @@ int kchunks_prepare(bessx_session *s, int ns, bool link) {
   return 0;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// The chunk phase as merged launches on ONE stream (bessx_dev.h: McChain).  The chains' own streams and host threads are
+// not used here; the stitch that follows runs as before.  Returns 0 with every chunk's candidates in run[r] (a chain the
+// device could not finish by itself is finished through sequential_path on its context: same candidates), > 0 on a
+// failure, < 0 when the engine does not apply to this path (the caller then runs the chunks on their own streams).
+// ----------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct McHostStatus {
+  McState st;
+  FitCtrl ctrl;
+};
+static_assert(sizeof(McHostStatus) == 192, "192 bytes per chain in the pinned status block");
+
+int mc_wait(bessx_session *s, KChains *k, unsigned long long want) {
+  volatile unsigned long long *flag = k->mc_flag;
+  std::chrono::steady_clock::time_point t0;
+  bool timed = false;
+  for (unsigned spins = 1;; spins++) {
+    if (*flag >= want) break;
+    if ((spins & 0x3fff) == 0) {
+      const auto now = std::chrono::steady_clock::now();
+      if (!timed) {
+        t0 = now;
+        timed = true;
+      } else if (std::chrono::duration<double>(now - t0).count() > s->wait_deadline_s) {
+        return fail(BESSX_ERR_HIP, "chunk chains (merged launches): no status block from the device within " +
+                                       std::to_string(s->wait_deadline_s) + " s (BESSX_WAIT_TIMEOUT_S)");
+      }
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
+// |y - X beta|^2 of a model by one pass over its columns (what algorithm_fit does when the solve's loss terms cancel)
+int mc_sse_by_residual(bessx_session *c, hipStream_t st, const int *idx, const double *val, int T0, double coef0, double *out) {
+  int *st_idx = reinterpret_cast<int *>(c->stage_h);
+  double *st_val = reinterpret_cast<double *>(c->stage_h + (size_t)c->capA * sizeof(int));
+  for (int i = 0; i < T0; i++) {
+    st_idx[i] = idx[i];
+    st_val[i] = val[i];
+  }
+  HIPX(hipMemcpyAsync(c->init_idx_d, st_idx, T0 * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPX(hipMemcpyAsync(c->init_val_d, st_val, T0 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPX(launch_resid_lm(c->X, c->ld, c->n, c->y, c->mask[0], c->ctrl, 0, c->init_idx_d, c->init_val_d, c->tmpv, c->sse, st, 3,
+                       T0, coef0));
+  std::vector<double> part((size_t)2 * c->n_sse_blk);
+  HIPX(hipMemcpyAsync(part.data(), c->sse, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPX(hipStreamSynchronize(st));
+  double tr = 0.0;
+  for (int b = 0; b < c->n_sse_blk; b++) tr += part[2 * b];
+  *out = tr;
+  return 0;
+}
+
+int mc_run_chunks(bessx_session *s, KChains *k, const int *seq, int ns, int C, const std::vector<int> &bounds,
+                  std::vector<ChunkRun> &run, double lambda, int ic_type, int width) {
+  if (s->model_type != 1 || !s->cov_mode || !s->fuse || !s->fuse_sel || !s->cov_cg || !s->cg_by_rows || C > 8) return -1;
+  if (!mc_applies(s->p, seq[ns - 1])) return -1;
+  // Measured on configs[1] (tools/kchunks_bench.py, profiles/README.md, round 5): NOT faster than the chains on streams
+  // of their own -- 12.4-12.6 ms per path against 12.0 with 4 chains, 12.7 with 8 -- because the merged launches run the
+  // chains in lock-step: every step costs what the chain with the largest systems needs (48 us for selection, record,
+  // selection and a 200-unknown solve) and the chunk phase is (candidates per chain) x that.  Kept behind the test hook
+  // kchunks_merged=1, exercised by tests/test_kchunks_gpu.py; the default is the stream per chain.
+  const char *mc_on = test_hook("kchunks_merged");
+  if (!(mc_on && std::string(mc_on) == "1")) return -1;
+  const int p = s->p;
+  hipStream_t st = s->st;
+  // ---- buffers
+  if (!k->mc_chains) {
+    HIPX(hipMalloc(reinterpret_cast<void **>(&k->mc_chains), 8 * sizeof(McChain)));
+    HIPX(hipMalloc(reinterpret_cast<void **>(&k->mc_states), 8 * sizeof(McState)));
+    HIPX(hipHostMalloc(reinterpret_cast<void **>(&k->mc_status_h), 8 * sizeof(McHostStatus)));
+    HIPX(hipHostMalloc(reinterpret_cast<void **>(&k->mc_flag), 128));
+    k->mc_flag[0] = 0ull;
+    k->mc_seq_no = 0;
+  }
+  if ((size_t)ns > k->mc_cap_cand || (size_t)ns * width > k->mc_cap_cells) {
+    if (k->mc_seq) (void)hipFree(k->mc_seq);
+    if (k->mc_rec_i) (void)hipFree(k->mc_rec_i);
+    if (k->mc_rec_d) (void)hipFree(k->mc_rec_d);
+    if (k->mc_rec_A) (void)hipFree(k->mc_rec_A);
+    if (k->mc_rec_b) (void)hipFree(k->mc_rec_b);
+    k->mc_seq = k->mc_rec_i = k->mc_rec_A = nullptr;
+    k->mc_rec_d = k->mc_rec_b = nullptr;
+    k->mc_cap_cand = k->mc_cap_cells = 0;
+    HIPX(dmalloc(&k->mc_seq, (size_t)ns));
+    HIPX(dmalloc(&k->mc_rec_i, (size_t)ns * MC_REC_I));
+    HIPX(dmalloc(&k->mc_rec_d, (size_t)ns * MC_REC_D));
+    HIPX(dmalloc(&k->mc_rec_A, (size_t)ns * width));
+    HIPX(dmalloc(&k->mc_rec_b, (size_t)ns * width));
+    k->mc_cap_cand = (size_t)ns;
+    k->mc_cap_cells = (size_t)ns * width;
+  }
+  if (!s->fill_ctrl) {
+    HIPX(hipMalloc(reinterpret_cast<void **>(&s->fill_ctrl), sizeof(FitCtrl)));
+    HIPX(hipMemset(s->fill_ctrl, 0, sizeof(FitCtrl)));
+    HIPX(hipHostMalloc(reinterpret_cast<void **>(&s->fill_ctrl_h), sizeof(FitCtrl)));
+  }
+  HIPX(hipMemcpyAsync(k->mc_seq, seq, (size_t)ns * sizeof(int), hipMemcpyHostToDevice, st));
+  HIPX(hipMemsetAsync(k->mc_rec_i, 0, (size_t)ns * MC_REC_I * sizeof(int), st));
+  // ---- the chains: their contexts' buffers, the start of their first fit
+  std::vector<McChain> hc((size_t)C);
+  std::vector<McState> hs((size_t)C);
+  for (int r = 0; r < C; r++) {
+    bessx_session *c = k->ctx[r];
+    ChunkRun &q = run[r];
+    if (int rc = context_begin(c)) return rc;
+    c->timing = s->timing;
+    const int lo = q.lo, ncand = q.hi - q.lo, k_init = (int)q.init_idx.size();
+    if (ncand < 1 || k_init > c->cap) return fail(BESSX_ERR_ARG, "chunk chains: bad chunk");
+    bessx_session::CovCache &cv = c->cov[0];
+    int *st_idx = reinterpret_cast<int *>(c->stage_h);
+    double *st_val = reinterpret_cast<double *>(c->stage_h + (size_t)c->capA * sizeof(int));
+    for (int i = 0; i < k_init; i++) {
+      st_idx[i] = q.init_idx[i];
+      st_val[i] = q.init_val[i];
+    }
+    if (k_init) {
+      HIPX(hipMemcpyAsync(c->init_idx_d, st_idx, k_init * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPX(hipMemcpyAsync(c->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    HIPX(launch_fit_begin(c->ctrl, seq[lo], k_init, c->init_idx_d, c->init_val_d, q.init_coef0, c->A_cur, c->b_cur,
+                          c->beta_dense, p, c->hist, st, c->inA));
+    McChain &m = hc[(size_t)r];
+    m = McChain();
+    m.state = k->mc_states + r;
+    m.seq = k->mc_seq + lo;
+    m.width = width;
+    m.max_iter = c->max_iter;
+    m.p = p;
+    m.G = cv.G;
+    m.xty = c->xty[0];
+    m.xtx = c->xtx[0];
+    m.n_t = (double)c->n_train[0];
+    m.lambda = lambda;
+    m.always = c->always;
+    m.d_out = c->part_rs[0];
+    m.bd = c->bd;
+    m.bmm = c->cov_bmm;
+    TopkNeed nd = {cov_speculates(c) ? c->bd : nullptr, c->bd2, p, cov_C_dev(c), cv.slot_of, cv.meta, c->cov_fcols,
+                   c->ctrl, c->A_cur, c->cov_bmm, (p + 31) / 32, c->inA, 0, 0};
+    nd.cm_A_cur = c->A_cur;
+    nd.cm_b_cur = c->b_cur;
+    nd.cm_beta_dense = c->beta_dense;
+    nd.cm_hist = c->hist;
+    nd.cm_hist_beta = c->hist_beta;
+    nd.cm_hist_coef0 = c->hist_coef0;
+    nd.cm_hist_stride = c->hist_stride;
+    nd.cm_inA = c->inA;
+    nd.commit_on = 1;
+    nd.no_restart = 1;
+    m.nd = nd;
+    m.nd1 = nd;
+    m.nd1.inc1 = 1;
+    m.nd1.bmm_fresh = 1;
+    m.fz = cov_fuse_args(c, 0, seq[lo], false, nullptr);
+    m.A_new = c->A_new;
+    m.sol = c->sol;
+    m.tol = c->cg_tol;
+    m.maxit = 64;
+    m.rec_i = k->mc_rec_i + (size_t)lo * MC_REC_I;
+    m.rec_d = k->mc_rec_d + (size_t)lo * MC_REC_D;
+    m.rec_A = k->mc_rec_A + (size_t)lo * width;
+    m.rec_b = k->mc_rec_b + (size_t)lo * width;
+    McState &z = hs[(size_t)r];
+    z = McState();
+    z.ncand = ncand;
+    z.need_d = 1;
+    c->dev_state_rs = -1;
+  }
+  HIPX(hipMemcpyAsync(k->mc_chains, hc.data(), (size_t)C * sizeof(McChain), hipMemcpyHostToDevice, st));
+  HIPX(hipMemcpyAsync(k->mc_states, hs.data(), (size_t)C * sizeof(McState), hipMemcpyHostToDevice, st));
+  HIPX(hipStreamSynchronize(st));  // (hc / hs / the staging buffers are the host's again)
+  // ---- rounds: a batch of (score pass, selection + solve) pairs, then every chain's state
+  int longest = 0;
+  for (int r = 0; r < C; r++) longest = std::max(longest, run[r].hi - run[r].lo);
+  // Batches of 8 pairs: a chain that parks on a missing column waits for the end of its batch before the host sees it
+  // (queueing the whole chunk ahead -- about one pair per candidate -- left a parked chain idle for up to 2.6 ms on
+  // configs[1]); the read-back between two batches costs the device ~25 us of 500.
+  int batch = 8;
+  const McHostStatus *hstat = reinterpret_cast<const McHostStatus *>(k->mc_status_h);
+  std::vector<int> takeover((size_t)C, 0);
+  for (int round = 0;; round++) {
+    if (round > 64 + longest) return fail(BESSX_ERR_NUMERIC, "chunk chains (merged launches): the chains do not end");
+    for (int b = 0; b < batch; b++) {
+      HIPX(launch_mc_cov_d(k->mc_chains, C, p, st));
+      HIPX(launch_mc_sel_cgr(k->mc_chains, C, p, st));
+    }
+    const unsigned long long want = ++k->mc_seq_no;
+    HIPX(launch_mc_status(k->mc_chains, C, k->mc_status_h, k->mc_flag, want, st));
+    if (int rc = mc_wait(s, k, want)) return rc;
+    bool all = true;
+    std::vector<int> parked;
+    for (int r = 0; r < C; r++) {
+      const McHostStatus &h = hstat[r];
+      if (h.st.finished == 1) continue;
+      if (h.st.finished == 2) {
+        takeover[(size_t)r] = 1;
+        continue;
+      }
+      if (h.st.parked == 1) {
+        parked.push_back(r);
+        all = false;
+      } else if (h.st.parked) {  // a tie, a solve for the Cholesky kernel, a full cache: the proven path finishes this chain
+        HIPX(launch_mc_stop(k->mc_chains, r, st));
+        takeover[(size_t)r] = 1;
+      } else {
+        all = false;
+      }
+    }
+    if (!parked.empty()) {
+      // ONE fill for every chain parked on missing columns; nobody else runs (one stream): fold_fits_side_by_side's rule
+      CovUnion u = {};
+      bessx_session *spec_src = nullptr;
+      int ub = 0;
+      for (int r : parked) {
+        bessx_session *c = k->ctx[r];
+        u.list[u.nf] = c->A_new;
+        u.len[u.nf++] = hstat[r].ctrl.T0;
+        ub += hstat[r].ctrl.cov_nmiss;
+        if (!spec_src && cov_speculates(c)) spec_src = c;
+      }
+      if (spec_src)
+        HIPX(launch_topk(spec_src->bd2, p, s->cov_spec, spec_src->cov_extras, spec_src->cand, nullptr, 0, st));
+      HIPX(launch_cov_fill_union(u, 0, spec_src ? spec_src->cov_extras : nullptr, spec_src ? spec_src->bd2 : nullptr,
+                                 s->cov_spec, s->cov_spec / 2, s->cov[0].slot_of, s->cov[0].meta, p, s->cov_fcols,
+                                 s->fill_ctrl, st));
+      HIPX(hipMemcpyAsync(s->fill_ctrl_h, s->fill_ctrl, sizeof(FitCtrl), hipMemcpyDeviceToHost, st));
+      HIPX(hipStreamSynchronize(st));
+      s->cov_panel_groups += s->fill_ctrl_h->cov_groups - s->fill_groups_seen;
+      s->fill_groups_seen = s->fill_ctrl_h->cov_groups;
+      const int ngroups = s->fill_ctrl_h->cov_nfill / COV_R;
+      if (ngroups > (ub + s->cov_spec + 2 * COV_R - 1) / COV_R)
+        return fail(BESSX_ERR_NUMERIC, "internal error: union fill list longer than its bound (chunk chains)");
+      if (int rc = enqueue_cov_fill(s, 0, ngroups, 1, s->fill_ctrl)) return rc;
+      if (s->timing) {
+        HIPX(hipStreamSynchronize(st));
+        if (int rc = cov_collect(s, s->fill_ctrl_h->cov_nfill)) return rc;
+      }
+      for (int r : parked) HIPX(launch_mc_resume(k->mc_chains, r, st));
+      s->kch_chunk_fills++;
+    }
+    if (all) break;
+  }
+  // ---- the records
+  std::vector<int> rec_i((size_t)ns * MC_REC_I), rec_A((size_t)ns * width);
+  std::vector<double> rec_d((size_t)ns * MC_REC_D), rec_b((size_t)ns * width);
+  HIPX(hipMemcpyAsync(rec_i.data(), k->mc_rec_i, rec_i.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPX(hipMemcpyAsync(rec_d.data(), k->mc_rec_d, rec_d.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPX(hipMemcpyAsync(rec_A.data(), k->mc_rec_A, rec_A.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPX(hipMemcpyAsync(rec_b.data(), k->mc_rec_b, rec_b.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPX(hipStreamSynchronize(st));
+  for (int r = 0; r < C; r++) {
+    bessx_session *c = k->ctx[r];
+    ChunkRun &q = run[r];
+    q.bind(&q.res);
+    const int ncand = q.hi - q.lo;
+    int good = 0;
+    SparseVec last;
+    double last_c0 = q.init_coef0;
+    last.idx = q.init_idx;
+    last.val = q.init_val;
+    for (int i = 0; i < ncand; i++) {
+      const int g = q.lo + i;
+      if (!rec_i[(size_t)g * MC_REC_I + 3]) break;
+      const int T0 = rec_i[(size_t)g * MC_REC_I + 0];
+      if (T0 != seq[g]) return fail(BESSX_ERR_NUMERIC, "internal error: chunk chain record out of order");
+      Candidate cand;
+      cand.T0 = T0;
+      cand.lambda = lambda;
+      cand.beta.idx.assign(rec_A.begin() + (size_t)g * width, rec_A.begin() + (size_t)g * width + T0);
+      cand.beta.val.assign(rec_b.begin() + (size_t)g * width, rec_b.begin() + (size_t)g * width + T0);
+      cand.coef0 = rec_d[(size_t)g * MC_REC_D + 0];
+      cand.iters = rec_i[(size_t)g * MC_REC_I + 1];
+      // the loss from the solved system (algorithm_fit, all rows, covariance form), by a pass over the active columns
+      // where those terms cancel
+      const double yy = c->yy_h[0];
+      double tr = yy - rec_d[(size_t)g * MC_REC_D + 1] - lambda * rec_d[(size_t)g * MC_REC_D + 2];
+      if (!rec_i[(size_t)g * MC_REC_I + 2] || !(tr > 1e-6 * yy))
+        if (int rc = mc_sse_by_residual(c, st, cand.beta.idx.data(), cand.beta.val.data(), T0, cand.coef0, &tr)) return rc;
+      c->sparsity_level = T0;
+      c->lambda_level = lambda;
+      c->beta = cand.beta;
+      c->coef0 = cand.coef0;
+      c->l = cand.iters;
+      c->sse_train = tr;
+      c->sse_test = 0.0;
+      if (int rc = metric_train_loss(c, &cand.loss)) return rc;
+      if (int rc = metric_ic(c, ic_type, 0, &cand.ic)) return rc;
+      store_candidate(c, &q.res, cand, false);
+      last = cand.beta;
+      last_c0 = cand.coef0;
+      good++;
+    }
+    q.fits += good;
+    if (good < ncand) {
+      // the device stopped in this chunk (takeover): the rest through sequential_path on the context, warm from the last
+      // recorded model -- the same chain, by the proven code
+      if (!takeover[(size_t)r] && hstat[r].st.finished != 2)
+        return fail(BESSX_ERR_NUMERIC, "internal error: chunk chain ended short of its candidates");
+      s->kch_takeovers++;
+      ChunkRun rest;
+      rest.shape(q.lo + good, q.hi, width, s->p_full);
+      rest.bind(&rest.res);
+      rest.chain = bessx_path_chain();
+      rest.chain.init_idx = last.idx.data();
+      rest.chain.init_val = last.val.data();
+      rest.chain.init_len = (int)last.idx.size();
+      rest.chain.init_coef0 = last_c0;
+      rest.chain.keep_caches = 1;
+      rest.chain.last_idx = rest.last_idx.data();
+      rest.chain.last_val = rest.last_val.data();
+      rest.chain.last_cap = width;
+      if (int rc = context_begin(c)) return rc;
+      KChains *own = c->kch_owner ? c->kch_owner->kch : nullptr;
+      (void)own;
+      kchains_round(k, 1);  // (one chain runs: a fill of its own finds everybody else standing still)
+      int rc = sequential_path(c, seq + q.lo + good, ncand - good, &lambda, 1, ic_type, 0, &rest.res, &rest.chain);
+      if (rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
+      kchains_leave(k, rc != 0);
+      if (rc) return rc;
+      for (int i = 0; i < ncand - good; i++) {
+        const int gi = good + i;  // (copied field by field into the chunk's arrays: they are already de-normalised)
+        q.T0[gi] = rest.T0[i];
+        q.iters[gi] = rest.iters[i];
+        q.lam[gi] = rest.lam[i];
+        q.loss[gi] = rest.loss[i];
+        q.ic[gi] = rest.ic[i];
+        q.coef0[gi] = rest.coef0[i];
+        std::copy(rest.support.begin() + (size_t)i * width, rest.support.begin() + (size_t)(i + 1) * width,
+                  q.support.begin() + (size_t)gi * width);
+        std::copy(rest.beta.begin() + (size_t)i * width, rest.beta.begin() + (size_t)(i + 1) * width,
+                  q.beta.begin() + (size_t)gi * width);
+      }
+      q.res.n_candidates = ncand;
+      q.fits += c->n_fits;
+      q.last_idx = rest.last_idx;
+      q.last_val = rest.last_val;
+      q.last_len = rest.chain.last_len;
+      q.last_coef0 = rest.chain.last_coef0;
+    } else {
+      q.last_len = (int)last.idx.size();
+      for (int i = 0; i < q.last_len && i < width; i++) {
+        q.last_idx[(size_t)i] = last.idx[(size_t)i];
+        q.last_val[(size_t)i] = last.val[(size_t)i];
+      }
+      q.last_coef0 = last_c0;
+    }
+    for (auto &cc : c->cache) cc.valid = false;  // (the device state of the context is the engine's, not a fit's of its own)
+    c->dev_state_rs = -1;
+  }
+  s->kch_merged++;
+  return 0;
+}
+
+}  // namespace
+
 int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type,
                             bessx_path_result *res, bessx_path_chain *link) {
   const int C = chains_for(s, ns, link != nullptr);
@@ -259,22 +650,38 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     s->hint.on = false;
     // (LM only: the coarse chain is what fills the shared cache.  The other families keep no cache: their chunks start
     // cold, side by side -- a restricted fit is cold-started anyway, only the active set is warm -- and are stitched)
-    for (int r = 1; r < C && s->model_type == 1; r++) {
+    // At most COARSE_MAX coarse fits, at chunk boundaries spread evenly over the path: with more chunks than that a
+    // chunk starts from the nearest coarse model below it (or cold, in front of the first one) -- its own first fits
+    // bridge the gap side by side with the other chunks, where a coarse fit per chunk (7 for 8 chunks: + 1.2 ms on
+    // configs[1]) would run before any of them.  Starting points only: the stitch makes the path the single chain's.
+    constexpr int COARSE_MAX = 3;
+    int M = s->model_type == 1 ? std::min(C - 1, COARSE_MAX) : 0;
+    if (const char *ev = test_hook("kchunks_coarse")) M = std::max(0, std::min(M, std::atoi(ev)));  // (0: every chunk starts cold)
+    int done_r = 0;
+    for (int j = 1; j <= M; j++) {
+      const int r = std::max(done_r + 1, (int)((long)C * j / (M + 1)));
+      if (r >= C) break;
       if (int rc = run_fit(s, seq[bounds[r] - 1], lambda, init, c0)) return rc;
       init = s->beta;
       c0 = s->coef0;
-      run[r].init_idx = init.idx;
-      run[r].init_val = init.val;
-      run[r].init_coef0 = c0;
+      for (int q = r; q < C; q++) {  // (every chunk from here on, until a later coarse fit replaces it)
+        run[q].init_idx = init.idx;
+        run[q].init_val = init.val;
+        run[q].init_coef0 = c0;
+      }
+      done_r = r;
     }
     if (int rc = settle_device_chain(s)) return rc;
     HIPX(hipStreamSynchronize(s->st));  // the cache is complete before any chunk chain reads it
   }
   const long long coarse_fits = s->n_fits;
   const auto t_coarse = now();
-  // ---- 2. the chunks side by side
-  kchains_round(k, C);
+  // ---- 2. the chunks side by side: as merged launches on the session's stream where that applies (LM, the fused
+  // selection + solve kernels' range), else on a stream and a host thread each
   for (int r = 0; r < C; r++) run[r].shape(bounds[r], bounds[r + 1], width, s->p_full);
+  const int merged = mc_run_chunks(s, k, seq, ns, C, bounds, run, lambda, ic_type, width);
+  if (merged > 0) return merged;
+  kchains_round(k, C);
   auto chunk_job = [&](int r) {
     if (r >= C) return;
     bessx_session *c = k->ctx[r];
@@ -301,9 +708,11 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     if (q.rc) q.err = g_err;
     kchains_leave(k, q.rc != 0);
   };
-  if (!k->pool.run(chunk_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
-  for (int r = 0; r < C; r++)
-    if (run[r].rc) return fail(run[r].rc, "chunk chain: " + run[r].err);
+  if (merged < 0) {
+    if (!k->pool.run(chunk_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
+    for (int r = 0; r < C; r++)
+      if (run[r].rc) return fail(run[r].rc, "chunk chain: " + run[r].err);
+  }
   const auto t_chunks = now();
   // ---- 3. the stitch, in rounds until no chunk's last model changed (bess_amd.dist.StitchedKPath.step)
   // A chunk whose refit has not met its own chain after `budget` candidates is on another trajectory than the warm

@@ -6,13 +6,6 @@ namespace bessx {
 // --------------------------------------------------------------------------------------------
 // paths (src/path.cpp)
 // --------------------------------------------------------------------------------------------
-struct Candidate {
-  int T0;
-  double lambda;
-  SparseVec beta;
-  double coef0, loss, ic;
-  int iters;
-};
 
 void denormalize(const bessx_session *s, SparseVec &b, double &coef0, bool gs_variant) {
   // src/path.cpp:76-110 (sequential) and :330-342 (golden section: data_type 3 also takes the "else")

@@ -1822,6 +1822,11 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 17: return s->kch_last_chains;
     case 18: return s->kch_giveups;
     case 19: return s->group_xtx_ns;
+    case 20: return s->kch_merged;
+    case 21: return s->kch_takeovers;
+    case 22: return (long long)(1e6 * s->kch_t[0]);
+    case 23: return (long long)(1e6 * s->kch_t[1]);
+    case 24: return (long long)(1e6 * s->kch_t[2]);
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

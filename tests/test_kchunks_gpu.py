@@ -293,3 +293,43 @@ def test_the_stitch_gives_up_where_the_chunks_do_not_merge(gpu, monkeypatch):
         assert c3["kpath_chunked_paths"] == 2 and c3["kpath_stitch_giveups"] == 2
     for out in (first, second, third):
         _same_path(out, single)
+
+
+@pytest.mark.parametrize("chains", [2, 4, 8])
+def test_merged_launches_over_the_chunk_chains_return_the_single_chain(gpu, monkeypatch, chains):
+    """Round 5 (bessx_dev.h, McChain; test hook kchunks_merged=1): the chunk phase as merged launches on ONE stream -- every
+    chain a workgroup of the same launch, the candidate / iteration sequencing in device memory, parked chains served by
+    one union fill -- gives the single chain's candidates like the stream-per-chain form does: consecutive levels, a
+    path with gaps between the levels (no arg-max start), and a design whose chunks need fills of their own."""
+    from helpers import hooks
+    X, y, _, _ = synth.make_lm(2500, 700, 20, seed=11)
+    seq = np.arange(1, 65)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        single_odd = s.sequential_path(seq[::2], ic_type=2)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+    hooks(monkeypatch, kchunks_merged=1)
+    with gpu.Session(X, y) as s:
+        first = s.sequential_path(seq, ic_type=3)
+        cnt = s.counters()
+        assert cnt["kpath_chunked_paths"] == 1 and cnt["kpath_merged_chunk_phases"] == 1
+        again = s.sequential_path(seq, ic_type=3)
+        odd = s.sequential_path(seq[::2], ic_type=2)
+        assert s.counters()["kpath_merged_chunk_phases"] == 3
+    _same_path(first, single)
+    _same_path(again, single)
+    _same_path(odd, single_odd)
+    # a small cache-speculation width and many chunks: the chunks park for fills of their own (union fills)
+    X2, y2, _, _ = synth.make_lm(3000, 2600, 60, seed=3)
+    seq2 = np.arange(1, 161)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    hooks(monkeypatch, kchunks_merged=0)
+    with gpu.Session(X2, y2) as s:
+        want = s.sequential_path(seq2, ic_type=3)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+    hooks(monkeypatch, kchunks_merged=1)
+    with gpu.Session(X2, y2) as s:
+        got = s.sequential_path(seq2, ic_type=3)
+        assert s.counters()["kpath_merged_chunk_phases"] == 1
+    _same_path(got, want)

@@ -20,11 +20,12 @@ for C in [1] + [int(v) for v in sys.argv[1:]]:
         for _ in range(3):
             out = s.sequential_path(seq, ic_type=3)
         ts = []
+        c0 = s.counters()  # (the phase timers and fill counts below are those of the ten timed paths only)
         for _ in range(10):
             t0 = time.time()
             out = s.sequential_path(seq, ic_type=3)
             ts.append(time.time() - t0)
-        cnt = s.counters()
+        cnt = {k: v - c0[k] if k not in ("kpath_chains_last_path",) else v for k, v in s.counters().items()}
     if single is None:
         single = out
     rec = {"chains": C, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "ms_per_path_min": round(1e3 * min(ts), 2),
@@ -33,6 +34,9 @@ for C in [1] + [int(v) for v in sys.argv[1:]]:
            "iterations_equal": int(np.sum(out["cand_iters"] == single["cand_iters"])), "of": kmax,
            "max_rel_ic_diff": float(np.max(np.abs(out["cand_ic"] - single["cand_ic"]) / np.abs(single["cand_ic"]))),
            "pdas_iterations": int(out["n_pdas_iters"]), "best_k": int(out["best_T0"]),
-           "passes_over_X_per_path": cnt["passes_over_X"] / 13.0, "stitch_refits_per_path": cnt["kpath_stitch_refits"] / 13.0,
-           "chunk_fills_per_path": cnt["kpath_chunk_fills"] / 13.0}
+           "passes_over_X_per_path": cnt["passes_over_X"] / 10.0, "stitch_refits_per_path": cnt["kpath_stitch_refits"] / 10.0,
+           "chunk_fills_per_path": cnt["kpath_chunk_fills"] / 10.0,
+           "phase_ms_per_path": {"coarse": round(cnt["kpath_coarse_us"] / 10e3, 2), "chunks": round(cnt["kpath_chunks_us"] / 10e3, 2),
+                                 "stitch": round(cnt["kpath_stitch_us"] / 10e3, 2)},
+           "merged_chunk_phases": cnt["kpath_merged_chunk_phases"], "chains_taken_over": cnt["kpath_chains_taken_over"]}
     print(json.dumps(rec), flush=True)
