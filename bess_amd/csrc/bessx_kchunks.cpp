@@ -101,8 +101,13 @@ static int chains_for(const bessx_session *s, int ns, bool link = false) {
     // rule stands.
     const char *q = std::getenv("GPU_MAX_HW_QUEUES");
     const int queues = ctx_streams_own_queue(s->device) ? 8 : (q ? std::atoi(q) : 4);
-    if (s->model_type == 1)
+    if (s->model_type == 1 && s->cov_mode)
       C = (ns >= 96 && s->p >= 2048) ? (queues >= 8 ? 4 : 2) : 1;
+    else if (s->model_type == 1)
+      // round 5: the STREAMING form of the LM score pass as chunk chains, like the IRLS / Newton families -- every PDAS
+      // iteration is a pass over X, and one chain's selection, Gram panel, solve and residual run beside another's pass
+      // (tools/streaming_chains_bench.py, configs[1]: 190.1 ms as one chain, 168.7 / 173.5 / 162.3 ms with 2 / 3 / 4)
+      C = (ns >= 48 && (double)s->n * s->p >= 1e8) ? (queues >= 8 ? 4 : 2) : 1;
     else
       // logistic / Poisson / Cox: one chain's IRLS or Newton steps (small kernels) run beside another's pass over X
       // (tools/glm_two_chains_probe.py: logistic at full size 155 -> 120 ms with 3 chains, Cox 1.86 -> 1.60 s)
@@ -117,8 +122,8 @@ bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int i
   // -- the stitch refits, which stop at the first candidate equal to the caller's, are short and stay one chain
   if (chain && (chain->stop_support || chain->init_len > s->cap)) return false;
   if (s->grouped || !s->warm_start || s->trace.on || s->cv_shared || !s->publish || s->fill_hook) return false;
-  if (s->model_type == 1) {
-    if (!s->cov_mode || !s->chain) return false;
+  if (s->model_type == 1 && s->cov_mode) {
+    if (!s->chain) return false;
     if (s->cov_C < (s->p + 31) / 32 * 32 + COV_R) return false;  // the cache must hold every column: it is never started over
   } else if (s->K > 0) {
     return false;  // (sessions with CV folds keep per-row-set state the chain contexts do not own)
@@ -130,7 +135,7 @@ bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int i
     top = std::max(top, seq[i]);
   }
   if (top > 254 || top > s->cap) return false;  // (the register-resident solvers)
-  return s->model_type != 1 || top + COV_R + s->cov_spec <= s->cov_C;
+  return !(s->model_type == 1 && s->cov_mode) || top + COV_R + s->cov_spec <= s->cov_C;
 }
 
 namespace {
@@ -655,7 +660,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     // bridge the gap side by side with the other chunks, where a coarse fit per chunk (7 for 8 chunks: + 1.2 ms on
     // configs[1]) would run before any of them.  Starting points only: the stitch makes the path the single chain's.
     constexpr int COARSE_MAX = 3;
-    int M = s->model_type == 1 ? std::min(C - 1, COARSE_MAX) : 0;
+    int M = (s->model_type == 1 && s->cov_mode) ? std::min(C - 1, COARSE_MAX) : 0;  // (no cache to fill otherwise)
     if (const char *ev = test_hook("kchunks_coarse")) M = std::max(0, std::min(M, std::atoi(ev)));  // (0: every chunk starts cold)
     int done_r = 0;
     for (int j = 1; j <= M; j++) {

@@ -1446,6 +1446,38 @@ int chain_ctx_create(bessx_session *ps, bessx_session **out) {
   if (e == hipSuccess) e = dmalloc(&c->part_rs[0], part_elems(ps));
   if (e == hipSuccess) e = dmalloc(&c->r_rs[0], (size_t)ps->ld);
   if (e == hipSuccess) e = hipMemset(c->r_rs[0], 0, (size_t)ps->ld * sizeof(double));
+  if (e == hipSuccess && ps->model_type == 1 && !ps->cov_mode) {
+    // LM in the streaming form of the score pass (round 5): what enqueue_lm_slot writes besides -- the column list and
+    // the slab partials of the Gram kernels, the incremental Gram's row buffer and source map, and the Gram cache of
+    // the all-rows row set (two 256 x 256 buffers, the cached column list, its meta words)
+    c->ctx_allocs.clear();
+    auto own_d = [&](double **dst, size_t count) -> hipError_t {
+      *dst = nullptr;
+      hipError_t q = dmalloc(dst, count);
+      if (q != hipSuccess) return q;
+      c->ctx_allocs.push_back(*dst);
+      return hipMemset(*dst, 0, count * sizeof(double));
+    };
+    auto own_n = [&](int **dst, size_t count) -> hipError_t {
+      *dst = nullptr;
+      hipError_t q = dmalloc(dst, count);
+      if (q != hipSuccess) return q;
+      c->ctx_allocs.push_back(*dst);
+      return hipMemset(*dst, 0, count * sizeof(int));
+    };
+    e = own_d(&c->gpart, ps->gpart_elems);
+    if (e == hipSuccess) e = own_n(&c->gcols, (size_t)ps->capA + 16);
+    if (e == hipSuccess) e = own_d(&c->Rt, (size_t)16 * 256);
+    if (e == hipSuccess) e = own_n(&c->gsrc, 256);
+    if (e == hipSuccess && !c->gcache.empty()) {
+      bessx_session::GramCache g;
+      e = own_d(&g.g0, (size_t)256 * 256);
+      if (e == hipSuccess) e = own_d(&g.g1, (size_t)256 * 256);
+      if (e == hipSuccess) e = own_n(&g.A, 256);
+      if (e == hipSuccess) e = own_n(&g.meta, 2);
+      if (e == hipSuccess) c->gcache[0] = g;
+    }
+  }
   if (e == hipSuccess && ps->model_type != 1) {
     // the IRLS / Newton families: what their fits write besides -- curvature sums and weights, the IRLS vectors, the
     // auxiliary columns (column 2 is the working response), the slab partials and column lists of the Gram kernels

@@ -333,3 +333,29 @@ def test_merged_launches_over_the_chunk_chains_return_the_single_chain(gpu, monk
         got = s.sequential_path(seq2, ic_type=3)
         assert s.counters()["kpath_merged_chunk_phases"] == 1
     _same_path(got, want)
+
+
+@pytest.mark.parametrize("chains", [2, 3])
+def test_chunk_chains_of_the_streaming_lm_path(gpu, monkeypatch, chains):
+    """Round 5: the STREAMING form of the LM score pass (score_mode = 1: every PDAS iteration reads X once -- the
+    formulation north_star prescribes) as chunk chains, like the IRLS / Newton families: the chunks start cold side by
+    side on contexts that own what enqueue_lm_slot writes (score sums, residual, column list, slab partials, the
+    incremental Gram and its cache) and are stitched into the single chain."""
+    X, y, _, _ = synth.make_lm(2500, 700, 20, seed=11)
+    seq = np.arange(1, 65)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y, score_mode=1) as s:
+        single = s.sequential_path(seq, ic_type=3)
+        assert s.counters()["kpath_chunked_paths"] == 0
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+    with gpu.Session(X, y, score_mode=1) as s:
+        first = s.sequential_path(seq, ic_type=3)
+        cnt = s.counters()
+        assert cnt["kpath_chunked_paths"] == 1 and cnt["kpath_chains_last_path"] == chains
+        again = s.sequential_path(seq, ic_type=3)
+        w = s.sequential_path(seq[:40], ic_type=2)
+    _same_path(first, single)
+    _same_path(again, single)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y, score_mode=1) as s:
+        _same_path(w, s.sequential_path(seq[:40], ic_type=2))
