@@ -859,8 +859,9 @@ def main():
             try:
                 traffic = json.load(open(tpath)).get("k_cov_panel_hbm_bytes_per_pass" if cov else
                                                      "k_xtv_hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, " \
-                              "not measured in this run)"
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this kernel on " \
+                              "the round-5 library, tools/collect_profiles_r05.sh; counter passes are their own runs, " \
+                              "not part of this one)"
             except Exception:
                 traffic = None
         kern = ("k_cov_panel (X^T diag(m) X_S on the fp64 matrix cores: 32 new Gram columns per pass over X)"
@@ -996,7 +997,32 @@ def main():
             torch.cuda.synchronize()
             d2 = (time.time() - t1) / args.steps
             st2 = s2.score_pass_stats()
-            gx2 = s2.counters().get("group_XTX_ns", 0) / 1e6
+            cnt2 = s2.counters()
+            gx2 = cnt2.get("group_XTX_ns", 0) / 1e6
+            single2 = None
+            if cnt2.get("kpath_chunked_paths", 0) > 0:
+                # the streaming path ran as chunk chains (round 5: one chain's selection, Gram panel, solve and residual
+                # beside another's pass over X -- the passes of several chains share the device, so a launch of the kernel
+                # that streams X takes longer than alone).  The same path as ONE chain on the same session beside it: the
+                # kernel with the device to itself.
+                s2.set_kpath_chains(1)
+                s2.sequential_path(seq, ic_type=3)
+                s2.score_pass_stats(reset=True)
+                torch.cuda.synchronize()
+                t1 = time.time()
+                n1 = min(args.steps, 3)
+                for _ in range(n1):
+                    o1 = s2.sequential_path(seq, ic_type=3)
+                torch.cuda.synchronize()
+                d1 = (time.time() - t1) / n1
+                st1 = s2.score_pass_stats()
+                single2 = {"value": len(seq) / d1, "unit": "candidates/s", "ms_per_step": 1e3 * d1, "steps": n1,
+                           "roofline": roofline_of(st1, False),
+                           "whole_step_frac_of_hbm_peak": st1["launches"] / float(n1) * 8.0 * args.n * args.p / d1 / 1e9
+                           / HBM_PEAK_GBPS,
+                           "same_candidates_as_the_chunk_chains": bool(
+                               np.array_equal(o1["cand_support"], o2["cand_support"]) and
+                               np.array_equal(o1["cand_iters"], o2["cand_iters"]))}
             s2.close()
             roof2 = roofline_of(st2, False)
             whole2 = st2["launches"] / float(args.steps) * 8.0 * args.n * args.p / d2 / 1e9 / HBM_PEAK_GBPS
@@ -1014,8 +1040,17 @@ def main():
             roof["streaming_ms_per_step"] = 1e3 * d2
             roof["streaming_steps"] = args.steps
             roof["streaming_kernel"] = "k_xtv<8,16,false> (X^T r, one pass over X per PDAS iteration)"
-            roof["streaming_kernel_frac"] = roof2["frac"]
-            roof["streaming_kernel_avg_launch_ms"] = roof2["avg_launch_ms"]
+            # the kernel against the HBM roof: with the device to itself (single chain) where the leg ran as chunk chains
+            ksrc = single2["roofline"] if single2 else roof2
+            roof["streaming_kernel_frac"] = ksrc["frac"]
+            roof["streaming_kernel_avg_launch_ms"] = ksrc["avg_launch_ms"]
+            if single2:
+                line["streaming_score_pass"]["chunk_chains"] = {"chains": cnt2.get("kpath_chains_last_path"),
+                                                                 "single_chain": single2}
+                roof["streaming_chains"] = cnt2.get("kpath_chains_last_path")
+                roof["streaming_kernel_frac_beside_other_chains"] = roof2["frac"]
+                roof["streaming_single_chain_candidates_per_s"] = single2["value"]
+                roof["streaming_single_chain_whole_step_frac"] = single2["whole_step_frac_of_hbm_peak"]
             roof["streaming_whole_step_frac"] = whole2
             roof["streaming_passes_over_X_per_candidate"] = st2["launches"] / float(len(seq) * args.steps)
             line["config"]["streaming_mode"] = ("roofline.streaming_*: the same path with score_mode = streaming (every "

@@ -87,12 +87,18 @@ def untraced(gpu):
             cnt["chunked"] = cnt["kpath_chunked_paths"] - before  # did THIS path run as chunk chains?
             outs["covariance, chains=%s" % ("auto" if chains == 0 else chains)] = (out, cnt)
     with gpu.Session(X, y, score_mode=1) as s:
-        outs["streaming"] = (s.sequential_path(np.arange(1, 201), ic_type=3), dict(s.counters(), chunked=0))
+        for chains in (0, 1):  # automatic (round 5: the streaming form runs as chunk chains too), one chain
+            s.set_kpath_chains(chains)
+            before = s.counters()["kpath_chunked_paths"]
+            out = s.sequential_path(np.arange(1, 201), ic_type=3)
+            cnt = s.counters()
+            cnt["chunked"] = cnt["kpath_chunked_paths"] - before
+            outs["streaming, chains=%s" % ("auto" if chains == 0 else chains)] = (out, cnt)
     return X, outs
 
 
 @pytest.mark.parametrize("which", ["covariance, chains=auto", "covariance, chains=1", "covariance, chains=4",
-                                   "covariance, chains=2", "streaming"])
+                                   "covariance, chains=2", "streaming, chains=auto", "streaming, chains=1"])
 def test_benchmarked_path_matches_compiled_reference_at_full_size(untraced, which):
     X, outs = untraced
     out, counters = outs[which]
@@ -100,7 +106,9 @@ def test_benchmarked_path_matches_compiled_reference_at_full_size(untraced, whic
     g = np.load(GOLD)
     n = assert_untraced_path_matches_golden(out, g, X, 1, "configs[1] untraced, " + which)
     assert n == 200 and out["n_fits"] == 200 and out["n_pdas_iters"] == int(np.sum(g["fit_iters"]))
-    if which in ("covariance, chains=1", "streaming"):
+    if which in ("covariance, chains=1", "streaming, chains=1"):
         assert counters["chunked"] == 0
+    if which in ("covariance, chains=auto", "streaming, chains=auto"):
+        assert counters["chunked"] == 1 and counters["kpath_chains_last_path"] == 4
     if which in ("covariance, chains=4", "covariance, chains=2"):
         assert counters["kpath_chains_last_path"] == int(which[-1]) and counters["chunked"] == 1

@@ -111,9 +111,12 @@ def test_no_chunk_chains_where_they_do_not_apply(gpu, monkeypatch):
     monkeypatch.setenv("BESSX_KPATH_CHAINS", "4")
     X, y, _, _ = synth.make_lm(1500, 300, 10, seed=2)
     seq = np.arange(1, 41)
-    with gpu.Session(X, y, score_mode=1) as s:  # streaming form
+    with gpu.Session(X, y, score_mode=1) as s:  # streaming form: chunked since round 5, but not below the automatic size
         s.sequential_path(seq, ic_type=3)
-        assert s.counters()["kpath_chunked_paths"] == 0
+        assert s.counters()["kpath_chunked_paths"] == 1
+        s.set_kpath_chains(0)  # automatic: 40 levels on 1500 x 300 are below the threshold (48 levels, n p >= 1e8)
+        s.sequential_path(seq, ic_type=3)
+        assert s.counters()["kpath_chunked_paths"] == 1
     with gpu.Session(X, y, is_warm_start=False) as s:
         s.sequential_path(seq, ic_type=3)
         assert s.counters()["kpath_chunked_paths"] == 0
