@@ -366,9 +366,23 @@ static constexpr int COV_R = 32;        // columns per panel group (matches the 
 static constexpr int COV_SLOT_GROUPS = 2;  // groups an ordinary PDAS slot launches
 static constexpr int COV_CS = 512;         // side of the slot-indexed Gram of the cached columns (2 MiB)
 
+// Device memory comes back with whatever it last held: on a fresh box mostly zeros, in a long-lived process the bytes of
+// earlier sessions.  BESSX_TEST_HOOKS=poison=1 fills every allocation with 0xFF bytes (a NaN for a double, -1 for an int),
+// so that a kernel that reads a buffer nobody wrote shows up in the tests instead of on somebody's machine.
+inline bool poison_allocations() {
+  static const bool on = [] {
+    const char *v = test_hook("poison");
+    return v && std::string(v) == "1";
+  }();
+  return on;
+}
+
 template <class T>
 hipError_t dmalloc(T **ptr, size_t count) {
-  return hipMalloc(reinterpret_cast<void **>(ptr), std::max<size_t>(count, 1) * sizeof(T));
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(ptr), bytes);
+  if (e == hipSuccess && poison_allocations()) e = hipMemset(*ptr, 0xff, bytes);
+  return e;
 }
 
 struct Scratch {
@@ -379,6 +393,7 @@ struct Scratch {
   template <class T>
   hipError_t alloc(T **out, size_t count) {
     hipError_t e = hipMalloc(reinterpret_cast<void **>(out), std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess && poison_allocations()) e = hipMemset(*out, 0xff, std::max<size_t>(count, 1) * sizeof(T));
     if (e == hipSuccess) ptrs.push_back(*out);
     return e;
   }
