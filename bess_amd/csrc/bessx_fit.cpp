@@ -420,13 +420,17 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
     }
     // (fewer uncached columns than one group: the private fill below)
   }
-  if (spec) e = launch_topk(s->bd2, s->p, s->cov_spec, s->cov_extras, s->cand, nullptr, 0, s->st);
+  // a cache that holds every column is never started over: the extras are taken from the 64 best uncached columns, so
+  // that the list is full up to its multiple of 32 (k_cov_fill_list, spec = 2)
+  const bool wide = spec && s->cov_C >= (s->p + 31) / 32 * 32 + COV_R && topk_supported(s->p, 2 * COV_R) && s->p >= 4 * COV_R;
+  const int pool = wide ? 2 * COV_R : s->cov_spec;
+  if (spec) e = launch_topk(s->bd2, s->p, pool, s->cov_extras, s->cand, nullptr, 0, s->st);
   if (e == hipSuccess)
     e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st, s->cov_spec,
-                             spec ? 1 : 0);
+                             spec ? (wide ? 2 : 1) : 0);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark: ") + hipGetErrorString(e));
   // upper bound of the list length (the device drops speculative columns that turn out to be cached already)
-  const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, s->cov_spec) : 0;
+  const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, pool) : 0;
   const int ngroups = (nm + room + COV_R - 1) / COV_R;
   if (int rc = enqueue_cov_fill(s, rs, ngroups, 1)) return rc;
   if (s->kch_owner) {

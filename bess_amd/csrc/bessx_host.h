@@ -369,12 +369,9 @@ static constexpr int COV_CS = 512;         // side of the slot-indexed Gram of t
 // Device memory comes back with whatever it last held: on a fresh box mostly zeros, in a long-lived process the bytes of
 // earlier sessions.  BESSX_TEST_HOOKS=poison=1 fills every allocation with 0xFF bytes (a NaN for a double, -1 for an int),
 // so that a kernel that reads a buffer nobody wrote shows up in the tests instead of on somebody's machine.
-inline bool poison_allocations() {
-  static const bool on = [] {
-    const char *v = test_hook("poison");
-    return v && std::string(v) == "1";
-  }();
-  return on;
+inline bool poison_allocations() {  // (read at every allocation: allocations are rare, and a test switches it per session)
+  const char *v = test_hook("poison");
+  return v && std::string(v) == "1";
 }
 
 template <class T>

@@ -81,13 +81,31 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
   // spec: the lookup left a masked copy of the scores (bd2) and the host ran the selection of `extras` on it.
   // spec_max = 32: the list is rounded up to the next multiple of 32 that leaves room for >= 16 speculative columns;
   // spec_max = 64 (pair panel kernel: two groups per pass over X): to the next multiple of 64 with room for >= 32
-  const int room = spec ? min(((nm + spec_max / 2 + spec_max - 1) / spec_max) * spec_max - nm, spec_max) : 0;
+  // spec = 2 (round 5; caches that are never started over): the host selected 64 extras, so that the list is FULL up to
+  // its multiple of 32 whatever nm is (with 32 extras a list of 50 missing columns was rounded to 96 with 14 empty
+  // places -- columns of a pass over X that computed nothing)
+  const int pool = spec == 2 ? 2 * COV_R : spec_max;
+  const int room = spec ? min(((nm + spec_max / 2 + spec_max - 1) / spec_max) * spec_max - nm, pool) : 0;
   __shared__ int s_ne;
   if (tid < 64) {
-    const bool valid = spec && tid < spec_max && bd2[extras[tid]] >= 0.0;  // a genuine uncached column
+    const int col = (spec && tid < pool) ? extras[tid] : -1;
+    const double sc = col >= 0 ? bd2[col] : -1.0;
+    const bool valid = col >= 0 && sc >= 0.0;  // a genuine uncached column
     const unsigned long long bal = __ballot(valid);
-    const int rank = __popcll(bal & ((1ull << tid) - 1ull));
-    if (valid && rank < room) fcols[nm + rank] = extras[tid];
+    // `extras` comes from the selection kernel in ascending COLUMN order; of a pool larger than the room the best by
+    // SCORE are wanted (ties: lower column): rank of this lane's column among the valid ones
+    int rank = 0;
+    if (pool > spec_max) {
+      for (int u = 0; u < 64; u++) {
+        const double su = __shfl(sc, u);
+        const int cu = __shfl(col, u);
+        const bool vu = (bal >> u) & 1ull;
+        if (vu && (su > sc || (su == sc && cu < col))) rank++;
+      }
+    } else {
+      rank = __popcll(bal & ((1ull << tid) - 1ull));
+    }
+    if (valid && rank < room) fcols[nm + rank] = col;
     if (tid == 0) s_ne = min((int)__popcll(bal), room);
   }
   __syncthreads();
