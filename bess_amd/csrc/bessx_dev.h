@@ -372,6 +372,7 @@ hipError_t launch_cov_need(const int *list, int len, const double *bd, double *b
                            int C, int *fcols, FitCtrl *ctrl, int slot, const int *A_cur, hipStream_t st,
                            int no_restart = 0);
 // spec: the lookup formed the masked score copy bd2 and `extras` holds its best columns (0: only the missing columns)
+hipError_t launch_cov_publish_slots(const int *fcols, const int *slot_w, int *slot_of, const FitCtrl *ctrl, hipStream_t st);
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
                                 FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec);
 hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);

@@ -93,10 +93,13 @@ int panel_variant_for(const bessx_session *s, int ng) {
 
 // gfirst / compact: a cooperative prefill (bessx_session_cov_prefill_*) forms only SOME groups of the list here and
 // fills the slot-indexed Gram GS once every group is in (its own and the ones imported from the other ranks)
+// slot_map: the map the reduction and the compaction place the new columns by (staged fills of chunk chains: the
+// writer's map; else the cache's own)
 int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const FitCtrl *gate,
-                            int gfirst, bool compact) {
+                            int gfirst, bool compact, const int *slot_map) {
   bessx_session::CovCache &cv = s->cov[rs];
   const FitCtrl *gc = gate ? gate : s->ctrl;  // whose cov_stall / cov_nfill the launches look at
+  const int *smap = slot_map ? slot_map : cv.slot_of;
   for (int g0 = gfirst; g0 < gfirst + ngroups; g0 += COV_SLOT_GROUPS) {
     const int ng = std::min(COV_SLOT_GROUPS, gfirst + ngroups - g0);
     hipEvent_t ea = nullptr, eb = nullptr;
@@ -144,10 +147,10 @@ int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const Fi
       s->cov_timed.push_back({s->ev_used - 2, g0});
     }
     if (e == hipSuccess)
-      e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, cv.slot_of, cv.G, g0, ng, s->cov_nslab, gc, parked,
+      e = launch_cov_reduce(s->cov_part, s->p, s->cov_fcols, smap, cv.G, g0, ng, s->cov_nslab, gc, parked,
                             s->st);
     if (e == hipSuccess && compact)  // entries between cached columns, by slot: what the solve gathers from
-      e = launch_cov_compact(cv.G, s->p, cv.slot_of, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, gc, parked, s->st, s->xtx[rs],
+      e = launch_cov_compact(cv.G, s->p, smap, s->cov_fcols, g0, ng, cv.GS, s->cov_cs, gc, parked, s->st, s->xtx[rs],
                              cv.meta);
     if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov panel: ") + hipGetErrorString(e));
   }
@@ -367,14 +370,21 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
   // filled meanwhile the look-up is simply redone (its columns may be there now)
   struct FillGuard {
     bessx_session *c = nullptr;
+    bool filled = false;
     ~FillGuard() {
-      if (c) kchains_fill_end(c);
+      if (c) kchains_fill_end(c, filled);
     }
   } guard;
+  // staged fills (the chains of this round do not stand still for each other): the launches of the fill work on the
+  // writer's slot map, the readers' map gets the entries with the last launch
+  const bool staged = s->kch_owner && kchains_staged(s) && cv.slot_w != nullptr;
+  int *smap = staged ? cv.slot_w : cv.slot_of;
   if (s->kch_owner) {
+    kchains_log(s, "parked: asks for the cache", T0, nm);
     const int waited = kchains_fill_begin(s);
     if (waited < 0) return fail(BESSX_ERR_HIP, "chunk chains: the fill rendezvous was abandoned");
     guard.c = s;
+    kchains_log(s, waited ? "has the cache: looks again" : "has the cache: fills", T0, nm);
     if (waited > 0) {
       HIPX(launch_cov_resume(s->ctrl, s->st));
       e = launch_cov_need(s->A_new, T0, spec ? s->bd : nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s),
@@ -426,16 +436,37 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
   const int pool = wide ? 2 * COV_R : s->cov_spec;
   if (spec) e = launch_topk(s->bd2, s->p, pool, s->cov_extras, s->cand, nullptr, 0, s->st);
   if (e == hipSuccess)
-    e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, cv.slot_of, cv.meta, s->ctrl, 1, s->st, s->cov_spec,
+    e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, smap, cv.meta, s->ctrl, 1, s->st, s->cov_spec,
                              spec ? (wide ? 2 : 1) : 0);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark: ") + hipGetErrorString(e));
   // upper bound of the list length (the device drops speculative columns that turn out to be cached already)
   const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, pool) : 0;
   const int ngroups = (nm + room + COV_R - 1) / COV_R;
-  if (int rc = enqueue_cov_fill(s, rs, ngroups, 1)) return rc;
+  // staged fills run on the owner's fill stream where there is one (it leaves some compute units to the other chains'
+  // kernels): the list first, on this chain's stream
+  hipStream_t own_st = s->st;
+  hipStream_t fill_st = staged ? s->kch_owner->kch_fill_st : nullptr;
+  if (fill_st && !s->kch_ev && hipEventCreateWithFlags(&s->kch_ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    s->kch_ev = nullptr;
+    fill_st = nullptr;
+  }
+  if (fill_st) {
+    HIPX(hipEventRecord(s->kch_ev, own_st));
+    HIPX(hipStreamWaitEvent(fill_st, s->kch_ev, 0));
+    s->st = fill_st;
+  }
+  int frc = enqueue_cov_fill(s, rs, ngroups, 1, nullptr, 0, true, smap);
+  hipError_t fe = hipSuccess;
+  if (frc == 0 && staged) fe = launch_cov_publish_slots(s->cov_fcols, cv.slot_w, cv.slot_of, s->ctrl, s->st);
+  s->st = own_st;
+  if (frc) return frc;
+  HIPX(fe);
   if (s->kch_owner) {
-    HIPX(hipStreamSynchronize(s->st));  // the new columns are in memory before any other chain moves again
+    HIPX(hipStreamSynchronize(fill_st ? fill_st : s->st));  // the new columns are in memory before any other chain moves again
     s->kch_owner->kch_chunk_fills++;    // (under the rendezvous: one writer)
+    guard.filled = true;
+    kchains_log(s, "fill done", ngroups, nm);
   }
   HIPX(launch_cov_resume(s->ctrl, s->st));
   if (int rc = enqueue_cov_tail(s, stalled, T0, lambda, rs)) return rc;
@@ -1411,6 +1442,7 @@ int algorithm_fit(bessx_session *s) {
       PubArgs pa = {};
       if (s->publish) pa = publish_args(s, T0, my_buf, &seq);
       bool published = false;
+      if (s->kch_owner && kchains_staged(s)) s->kch_gen_seen = kchains_generation(s);  // (the look-ups queued below run after these fills)
       for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++) {
         SlotFuse sf;
         if (s->publish && (b + 1 == batch || slot == s->max_iter)) sf.pub = &pa;

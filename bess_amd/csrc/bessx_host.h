@@ -194,6 +194,7 @@ struct bessx_session {
   struct CovCache {
     double *G = nullptr;
     int *slot_of = nullptr, *meta = nullptr;
+    int *slot_w = nullptr;  // chunk chains with staged fills: the WRITER's slot map (slot_of is what the readers see)
     double *GS = nullptr;  // COV_CS x COV_CS: Gram entries between cached columns, indexed by cache slot (L2-sized)
     double *zero = nullptr;  // a few words that hold 0.0 (CholFuse::zero)
     bool shares_map = false;  // slot_of / meta are row set 0's (shared fills: every row set caches the same columns)
@@ -273,6 +274,10 @@ struct bessx_session {
   bessx::KChains *kch = nullptr;        // parent: contexts, host threads, the fill rendezvous (created at first use)
   bessx_session *kch_owner = nullptr;   // chain context: the session whose cache it reads
   int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
+  unsigned long long kch_gen_seen = 0;  // (chain context) completed fills when this chain last queued a look-up
+  int *kch_slot_w = nullptr;            // (owner) the writer's slot map of staged fills, p ints
+  hipStream_t kch_fill_st = nullptr;    // (owner) the stream the chains' staged fills run on (some compute units left out)
+  hipEvent_t kch_ev = nullptr;          // (chain context) orders its fill list in front of the fill on kch_fill_st
   long long kch_merged = 0, kch_takeovers = 0;  // chunk phases run as merged launches; chains the host had to finish
   long long kch_paths = 0, kch_refits = 0, kch_chunk_fills = 0;  // paths run chunked, stitch refits, fills in the chunk phase
   int kch_last_chains = 0;              // chains of the last chunked path
@@ -432,7 +437,7 @@ int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, b
                            std::vector<std::pair<size_t, bool>> &k1_pairs);
 int panel_variant_for(const bessx_session *s, int ng);
 int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const FitCtrl *gate = nullptr,
-                            int gfirst = 0, bool compact = true);
+                            int gfirst = 0, bool compact = true, const int *slot_map = nullptr);
 CholFuse cov_fuse_args(bessx_session *s, int rs, int T0, bool force_chol, SlotFuse *sf);
 int cgb_reserve(bessx_session *s);
 int enqueue_cov_tail(bessx_session *s, int slot, int T0, double lambda, int rs, bool force_chol = false,
@@ -446,7 +451,10 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
                             bessx_path_chain *chain = nullptr);
 void kchains_safe_point(bessx_session *c);   // chain context, between candidates: stand still while another chain fills
 int kchains_fill_begin(bessx_session *c);    // chain context parked on missing columns: wait until it alone runs
-void kchains_fill_end(bessx_session *c);
+void kchains_fill_end(bessx_session *c, bool filled = true);
+void kchains_log(bessx_session *c, const char *what, int a, int b);  // (test hook kchunks_log=1)
+bool kchains_staged(const bessx_session *c);               // this round's fills are staged (nobody stands still)
+unsigned long long kchains_generation(bessx_session *c);   // completed fills of the owner's chains so far
 void kchains_free(bessx_session *s);
 void kchains_quiesce(bessx_session *s);
 int kchunks_prepare(bessx_session *s, int ns, bool link);
@@ -470,7 +478,7 @@ int publish_flush(bessx_session *s);
 int publish_launch(bessx_session *s, const PubArgs &pa);
 int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq);
 int publish_wait(bessx_session *s, int buf, unsigned long long want);
-bool ctx_stream_create(int device, hipStream_t *st);  // a stream with a hardware queue outside the runtime's pool
+bool ctx_stream_create(int device, hipStream_t *st, int leave_out = 0, int stride = 1);  // a stream with a hardware queue outside the runtime's pool
 bool ctx_streams_own_queue(int device);              // ... does that work on this device (asked once per process)
 int stream_wait_bounded(bessx_session *s, hipStream_t st, const char *what);  // hipStreamSynchronize with the deadline
 int read_results(bessx_session *s, int kcopy = -1);

@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
   if (tid < 64) {
     const int col = (spec && tid < pool) ? extras[tid] : -1;
     const double sc = col >= 0 ? bd2[col] : -1.0;
-    const bool valid = col >= 0 && sc >= 0.0;  // a genuine uncached column
+    // a genuine uncached column (slot_of here is the WRITER's map: with staged fills -- chunk chains side by side --
+    // a column another chain cached after this chain's look-up is dropped as well)
+    const bool valid = col >= 0 && sc >= 0.0 && slot_of[col] < 0;
     const unsigned long long bal = __ballot(valid);
     // `extras` comes from the selection kernel in ascending COLUMN order; of a pool larger than the room the best by
     // SCORE are wanted (ties: lower column): rank of this lane's column among the valid ones
@@ -116,6 +118,18 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
     meta[0] = count + tot;
     ctrl->cov_nfill = padded;
     ctrl->cov_groups += padded / COV_R;
+  }
+}
+
+// Staged fills (chunk chains side by side, bessx_sync.h: FillRendezvous, concurrent rounds): the launches of a fill work
+// on the writer's slot map; the readers' map gets the new entries here, behind the last launch that writes the columns.
+__global__ void __launch_bounds__(256) k_cov_publish_slots(const int *__restrict__ fcols, const int *__restrict__ slot_w,
+                                                           int *__restrict__ slot_of, const FitCtrl *__restrict__ ctrl) {
+  if (!ctrl->cov_stall) return;
+  const int nf = ctrl->cov_nfill;
+  for (int i = threadIdx.x; i < nf; i += 256) {
+    const int col = fcols[i];
+    if (col >= 0) slot_of[col] = slot_w[col];
   }
 }
 
@@ -917,6 +931,12 @@ hipError_t launch_cov_need(const int *list, int len, const double *bd, double *b
                            int no_restart) {
   hipLaunchKernelGGL(k_cov_need, dim3(1), dim3(256), 0, st, list, len, bd, bd2, p, slot_of, meta, C, fcols, ctrl, slot,
                      A_cur, no_restart);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cov_publish_slots(const int *fcols, const int *slot_w, int *slot_of, const FitCtrl *ctrl, hipStream_t st) {
+  hipLaunchKernelGGL(k_cov_publish_slots, dim3(1), dim3(256), 0, st, fcols, slot_w, slot_of, ctrl);
   LAUNCH_CHECK();
   return hipSuccess;
 }

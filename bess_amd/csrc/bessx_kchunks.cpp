@@ -25,6 +25,17 @@ struct KChains {
   FoldPool pool;
   bool pool_started = false;
   FillRendezvous rdv;  // the fill rendezvous (bessx_sync.h: built and hammered under ThreadSanitizer, tools/tsan)
+  // test hook kchunks_log=1: what every chain did when (to stderr at the end of the path)
+  bool log_on = false;
+  std::mutex log_mu;
+  std::chrono::steady_clock::time_point log_t0;
+  struct LogRow {
+    double ms;
+    int chain;
+    const char *what;
+    int a, b;
+  };
+  std::vector<LogRow> log;
   // merged launches over the chains (mc_run_chunks): device copies of the chains' descriptions and states, the chunk's
   // levels, the per-candidate records; pinned status block and its sequence number
   McChain *mc_chains = nullptr;
@@ -65,12 +76,33 @@ void kchains_safe_point(bessx_session *c) {
 // a parked chain asks for the cache: returns 0 when it may fill (every other chain stands still), 1 when another chain
 // filled while this one waited (the right is held all the same: look the columns up again), -1 when the run was abandoned
 int kchains_fill_begin(bessx_session *c) {
-  return c->kch_owner->kch->rdv.fill_begin([c] { (void)hipStreamSynchronize(c->st); });
+  FillRendezvous &rdv = c->kch_owner->kch->rdv;
+  const int waited = rdv.fill_begin([c] { (void)hipStreamSynchronize(c->st); }, c->kch_gen_seen);
+  if (waited >= 0) c->kch_gen_seen = rdv.generation();  // (the right is held: no fill ends before this chain's does)
+  return waited;
 }
 
-void kchains_fill_end(bessx_session *c) { c->kch_owner->kch->rdv.fill_end(); }
+void kchains_fill_end(bessx_session *c, bool filled) { c->kch_owner->kch->rdv.fill_end(filled); }
 
-static void kchains_round(KChains *k, int chains) { k->rdv.round(chains); }
+void kchains_log(bessx_session *c, const char *what, int a, int b) {
+  bessx_session *o = c->kch_owner ? c->kch_owner : c;
+  KChains *k = o->kch;
+  if (!k || !k->log_on) return;
+  int id = -1;
+  for (size_t i = 0; i < k->ctx.size(); i++)
+    if (k->ctx[i] == c) id = (int)i;
+  const double ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - k->log_t0).count() * 1e3;
+  std::lock_guard<std::mutex> lk(k->log_mu);
+  k->log.push_back({ms, id, what, a, b});
+}
+
+bool kchains_staged(const bessx_session *c) {
+  return c->kch_owner && c->kch_owner->kch && c->kch_owner->kch->rdv.concurrent;  // (set before the round's chains start)
+}
+
+unsigned long long kchains_generation(bessx_session *c) { return c->kch_owner->kch->rdv.generation(); }
+
+static void kchains_round(KChains *k, int chains, bool staged = false) { k->rdv.round(chains, staged); }
 
 static void kchains_leave(KChains *k, bool failed) { k->rdv.leave(failed); }
 
@@ -79,6 +111,10 @@ void kchains_free(bessx_session *s) {
   KChains *k = s->kch;
   if (k->pool_started) k->pool.stop();
   mc_free(k);
+  if (s->kch_slot_w) (void)hipFree(s->kch_slot_w);
+  s->kch_slot_w = nullptr;
+  if (s->kch_fill_st) (void)hipStreamDestroy(s->kch_fill_st);
+  s->kch_fill_st = nullptr;
   for (bessx_session *c : k->ctx) chain_ctx_free(c);
   if (!k->pool.broken) delete k;  // (a broken pool's threads may still touch it: leaked on purpose)
   s->kch = nullptr;
@@ -216,7 +252,9 @@ int kchunks_prepare(bessx_session *s, int ns, bool link) {
   KChains *k = s->kch;
   if (k->pool.broken) return 1;
   k->rdv.deadline_s = s->wait_deadline_s;
-  while ((int)k->ctx.size() < C) {
+  // (LM, covariance form: one more context and host thread -- the coarse chain runs beside the chunks, see below)
+  const int extra = (s->model_type == 1 && s->cov_mode) ? 1 : 0;
+  while ((int)k->ctx.size() < C + extra) {
     bessx_session *c = nullptr;
     if (chain_ctx_create(s, &c) != 0) {
       (void)hipGetLastError();
@@ -224,7 +262,7 @@ int kchunks_prepare(bessx_session *s, int ns, bool link) {
     }
     k->ctx.push_back(c);
   }
-  if (!k->pool_started || (int)k->pool.th.size() < C - 1) {  // one host thread per chain; the caller is one of them
+  if (!k->pool_started || (int)k->pool.th.size() < C - 1 + extra) {  // one host thread per chain; the caller is one of them
     if (k->pool_started) k->pool.stop();
     k->pool.quit = false;  // (a pool started again: no job of the previous threads' numbering is left to run)
     k->pool.ticket = 0;
@@ -232,7 +270,7 @@ int kchunks_prepare(bessx_session *s, int ns, bool link) {
     k->pool.job = nullptr;
     {
       const int dev = s->device;
-      k->pool.start(C - 1, [dev] { (void)hipSetDevice(dev); });
+      k->pool.start(C - 1 + extra, [dev] { (void)hipSetDevice(dev); });
     }
     k->pool_started = true;
   }
@@ -634,65 +672,212 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();
   };
-  const auto t_begin = now();
-  // ---- 1. the coarse chain on the session's own state (the caller has just started the caches over)
-  std::vector<ChunkRun> run((size_t)C);
-  {
-    SparseVec init;
-    double c0 = 0.0;
-    if (link) {  // the model the whole link starts from: chunk 0's start, and the coarse chain's
-      for (int i = 0; i < link->init_len; i++) {
-        if (link->init_idx[i] < 0 || link->init_idx[i] >= s->p) return fail(BESSX_ERR_ARG, "chain: init index out of range");
-        init.idx.push_back(link->init_idx[i]);
-        init.val.push_back(link->init_val[i]);
-      }
-      c0 = link->init_coef0;
-      run[0].init_idx = init.idx;
-      run[0].init_val = init.val;
-      run[0].init_coef0 = c0;
-      link->stopped_at = -1;
+  const bool lm_cov = s->model_type == 1 && s->cov_mode;
+  // Staged fills (bessx_sync.h: FillRendezvous, concurrent rounds; test hook kchunks_staged=0/1): a chain's fill writes
+  // slots no other chain can see until its last launch publishes them, so nobody stands still for a fill.
+  // The pipeline (test hook kchunks_pipeline=0/1; needs staged fills and the extra context): the coarse chain runs on a
+  // context of its own BESIDE the chunks -- chunk 0 starts with it, chunk r as soon as the coarse fit at its lower
+  // boundary is done -- instead of in front of them.
+  bool staged = false, pipeline = false;
+  if (lm_cov) {
+    const char *ev = test_hook("kchunks_staged");
+    staged = !ev || std::atoi(ev) != 0;  // (default; 0: round 4's rendezvous -- every chain stands still for a fill)
+    const char *ep = test_hook("kchunks_pipeline");
+    pipeline = ep && std::atoi(ep) != 0 && (int)k->ctx.size() > C && (int)k->pool.th.size() >= C;
+    if (pipeline) staged = true;
+  }
+  if (staged && !s->kch_slot_w && dmalloc(&s->kch_slot_w, (size_t)s->p) != hipSuccess) {
+    (void)hipGetLastError();
+    s->kch_slot_w = nullptr;
+    staged = pipeline = false;
+  }
+  if (staged && !s->kch_fill_st) {
+    // the fills' stream: every compute unit but a few (test hook kchunks_reserve=count[:stride of the mask bits]; 0: the
+    // fills run on the filling chain's own stream)
+    int leave = 16, stride = 1;
+    if (const char *er = test_hook("kchunks_reserve")) {
+      leave = std::max(0, std::atoi(er));
+      if (const char *c2 = std::strchr(er, ':')) stride = std::max(1, std::atoi(c2 + 1));
     }
-    s->hint.on = false;
-    // (LM only: the coarse chain is what fills the shared cache.  The other families keep no cache: their chunks start
-    // cold, side by side -- a restricted fit is cold-started anyway, only the active set is warm -- and are stitched)
-    // At most COARSE_MAX coarse fits, at chunk boundaries spread evenly over the path: with more chunks than that a
-    // chunk starts from the nearest coarse model below it (or cold, in front of the first one) -- its own first fits
-    // bridge the gap side by side with the other chunks, where a coarse fit per chunk (7 for 8 chunks: + 1.2 ms on
-    // configs[1]) would run before any of them.  Starting points only: the stitch makes the path the single chain's.
-    constexpr int COARSE_MAX = 3;
-    int M = (s->model_type == 1 && s->cov_mode) ? std::min(C - 1, COARSE_MAX) : 0;  // (no cache to fill otherwise)
-    if (const char *ev = test_hook("kchunks_coarse")) M = std::max(0, std::min(M, std::atoi(ev)));  // (0: every chunk starts cold)
+    if (leave > 0 && !ctx_stream_create(s->device, &s->kch_fill_st, leave, stride)) s->kch_fill_st = nullptr;
+  }
+  if (pipeline && s->model_type == 1) {
+    // chunk r starts when coarse fit r is done: the later a chunk starts the shorter it is (weights by test hook
+    // kchunks_weights=w0:w1:...; default: falling linearly to a third)
+    std::vector<double> w((size_t)C, 1.0);
+    for (int r = 0; r < C; r++) w[(size_t)r] = 1.0 - (2.0 / 3.0) * r / std::max(1, C - 1);
+    if (const char *ew = test_hook("kchunks_weights")) {
+      int r = 0;
+      for (const char *q = ew; *q && r < C; r++) {
+        w[(size_t)r] = std::max(0.05, std::atof(q));
+        while (*q && *q != ':') q++;
+        if (*q == ':') q++;
+      }
+    }
+    double tot = 0.0, acc = 0.0;
+    for (double v : w) tot += v;
+    for (int r = 1; r < C; r++) {
+      acc += w[(size_t)r - 1];
+      bounds[(size_t)r] = std::min(std::max((int)std::lround(ns * acc / tot), bounds[(size_t)r - 1] + 1), ns - (C - r));
+    }
+    bounds[(size_t)C] = ns;
+  }
+  const auto t_begin = now();
+  {
+    const char *el = test_hook("kchunks_log");
+    k->log_on = el && std::atoi(el) != 0;
+    k->log_t0 = t_begin;
+    k->log.clear();
+  }
+  std::vector<ChunkRun> run((size_t)C);
+  SparseVec link_init;
+  double link_c0 = 0.0;
+  if (link) {  // the model the whole link starts from: chunk 0's start, and the coarse chain's
+    for (int i = 0; i < link->init_len; i++) {
+      if (link->init_idx[i] < 0 || link->init_idx[i] >= s->p) return fail(BESSX_ERR_ARG, "chain: init index out of range");
+      link_init.idx.push_back(link->init_idx[i]);
+      link_init.val.push_back(link->init_val[i]);
+    }
+    link_c0 = link->init_coef0;
+    run[0].init_idx = link_init.idx;
+    run[0].init_val = link_init.val;
+    run[0].init_coef0 = link_c0;
+    link->stopped_at = -1;
+  }
+  s->hint.on = false;
+  // The coarse chain.  (LM only: it is what fills the shared cache.  The other families keep no cache: their chunks start
+  // cold, side by side -- a restricted fit is cold-started anyway, only the active set is warm -- and are stitched)
+  // In front of the chunks: at most COARSE_MAX coarse fits, at chunk boundaries spread evenly over the path: with more
+  // chunks than that a chunk starts from the nearest coarse model below it (or cold, in front of the first one) -- its
+  // own first fits bridge the gap side by side with the other chunks, where a coarse fit per chunk (7 for 8 chunks:
+  // + 1.2 ms on configs[1]) would run before any of them.  Beside the chunks (pipeline): one per boundary.
+  // Starting points only: the stitch makes the path the single chain's.
+  constexpr int COARSE_MAX = 3;
+  int M = lm_cov ? (pipeline ? C - 1 : std::min(C - 1, COARSE_MAX)) : 0;  // (no cache to fill otherwise)
+  if (const char *ev = test_hook("kchunks_coarse")) M = std::max(0, std::min(M, std::atoi(ev)));  // (0: every chunk starts cold)
+  std::vector<int> coarse_at;  // coarse fit m (1-based) ends at the lower boundary of chunk coarse_at[m - 1]
+  {
     int done_r = 0;
     for (int j = 1; j <= M; j++) {
       const int r = std::max(done_r + 1, (int)((long)C * j / (M + 1)));
       if (r >= C) break;
-      if (int rc = run_fit(s, seq[bounds[r] - 1], lambda, init, c0)) return rc;
+      coarse_at.push_back(r);
+      done_r = r;
+    }
+  }
+  std::vector<int> start_of((size_t)C, 0);  // chunk r starts from coarse fit start_of[r] (0: cold, or the link's model)
+  for (size_t m = 0; m < coarse_at.size(); m++)
+    for (int q = coarse_at[m]; q < C; q++) start_of[(size_t)q] = (int)m + 1;
+  struct CoarseModel {
+    std::vector<int> idx;
+    std::vector<double> val;
+    double c0 = 0.0;
+  };
+  std::vector<CoarseModel> coarse_model(coarse_at.size() + 1);
+  long long coarse_fits = 0;
+  auto t_coarse = t_begin;
+  if (!pipeline) {
+    // ---- 1. the coarse chain on the session's own state (the caller has just started the caches over)
+    SparseVec init = link_init;
+    double c0 = link_c0;
+    for (size_t m = 0; m < coarse_at.size(); m++) {
+      if (int rc = run_fit(s, seq[bounds[(size_t)coarse_at[m]] - 1], lambda, init, c0)) return rc;
       init = s->beta;
       c0 = s->coef0;
-      for (int q = r; q < C; q++) {  // (every chunk from here on, until a later coarse fit replaces it)
-        run[q].init_idx = init.idx;
-        run[q].init_val = init.val;
-        run[q].init_coef0 = c0;
-      }
-      done_r = r;
+      coarse_model[m + 1] = {init.idx, init.val, c0};
     }
     if (int rc = settle_device_chain(s)) return rc;
     HIPX(hipStreamSynchronize(s->st));  // the cache is complete before any chunk chain reads it
+    coarse_fits = s->n_fits;
+    t_coarse = now();
+    for (int r = 0; r < C; r++)
+      if (start_of[(size_t)r] > 0) {
+        const CoarseModel &cm = coarse_model[(size_t)start_of[(size_t)r]];
+        run[(size_t)r].init_idx = cm.idx;
+        run[(size_t)r].init_val = cm.val;
+        run[(size_t)r].init_coef0 = cm.c0;
+      }
   }
-  const long long coarse_fits = s->n_fits;
-  const auto t_coarse = now();
+  if (staged) {  // the writer's slot map starts as a copy of the readers'
+    HIPX(hipMemcpyAsync(s->kch_slot_w, s->cov[0].slot_of, (size_t)s->p * sizeof(int), hipMemcpyDeviceToDevice, s->st));
+    HIPX(hipStreamSynchronize(s->st));
+  }
+  if (lm_cov)
+    for (bessx_session *c : k->ctx) c->cov[0].slot_w = staged ? s->kch_slot_w : nullptr;
   // ---- 2. the chunks side by side: as merged launches on the session's stream where that applies (LM, the fused
   // selection + solve kernels' range), else on a stream and a host thread each
   for (int r = 0; r < C; r++) run[r].shape(bounds[r], bounds[r + 1], width, s->p_full);
-  const int merged = mc_run_chunks(s, k, seq, ns, C, bounds, run, lambda, ic_type, width);
+  const int merged = pipeline ? -1 : mc_run_chunks(s, k, seq, ns, C, bounds, run, lambda, ic_type, width);
   if (merged > 0) return merged;
-  kchains_round(k, C);
+  kchains_round(k, C + (pipeline ? 1 : 0), staged);
+  struct Starts {  // (pipeline) which coarse fits are done
+    std::mutex mu;
+    std::condition_variable cv;
+    int done = 0;
+    bool failed = false;
+  } starts;
+  int coarse_rc = 0;
+  std::string coarse_err;
+  auto coarse_job = [&] {
+    bessx_session *w = k->ctx[(size_t)C];
+    int rc = hipSetDevice(s->device) == hipSuccess ? context_begin(w) : fail(BESSX_ERR_HIP, "hipSetDevice");
+    w->timing = s->timing;
+    w->hint.on = false;
+    SparseVec init = link_init;
+    double c0 = link_c0;
+    for (size_t m = 0; m < coarse_at.size() && rc == 0; m++) {
+      rc = run_fit(w, seq[bounds[(size_t)coarse_at[m]] - 1], lambda, init, c0);
+      if (rc) break;
+      init = w->beta;
+      c0 = w->coef0;
+      {
+        std::lock_guard<std::mutex> lk(starts.mu);
+        coarse_model[m + 1] = {init.idx, init.val, c0};
+        starts.done = (int)m + 1;
+      }
+      kchains_log(w, "coarse fit done", seq[bounds[(size_t)coarse_at[m]] - 1], w->l);
+      starts.cv.notify_all();
+    }
+    if (rc == 0) rc = settle_device_chain(w);
+    if (rc == 0 && hipStreamSynchronize(w->st) != hipSuccess) rc = fail(BESSX_ERR_HIP, "coarse chain: stream");
+    if (rc) {
+      coarse_err = g_err;
+      {
+        std::lock_guard<std::mutex> lk(starts.mu);
+        starts.failed = true;
+      }
+      starts.cv.notify_all();
+    }
+    coarse_rc = rc;
+    coarse_fits = w->n_fits;
+    t_coarse = now();
+    kchains_leave(k, rc != 0);
+  };
   auto chunk_job = [&](int r) {
+    if (pipeline && r == C) {
+      coarse_job();
+      return;
+    }
     if (r >= C) return;
     bessx_session *c = k->ctx[r];
     ChunkRun &q = run[r];
-    q.rc = hipSetDevice(s->device) == hipSuccess ? context_begin(c) : fail(BESSX_ERR_HIP, "hipSetDevice");
+    q.rc = 0;
+    if (pipeline && start_of[(size_t)r] > 0) {  // its starting model: the coarse fit at its lower boundary
+      std::unique_lock<std::mutex> lk(starts.mu);
+      const bool ok = bessx_timed_wait(starts.cv, lk, s->wait_deadline_s,
+                                       [&] { return starts.done >= start_of[(size_t)r] || starts.failed; });
+      if (!ok || starts.failed) {
+        q.rc = fail(BESSX_ERR_HIP, "chunk chain: the coarse chain did not deliver its starting model");
+      } else {
+        const CoarseModel &cm = coarse_model[(size_t)start_of[(size_t)r]];
+        q.init_idx = cm.idx;
+        q.init_val = cm.val;
+        q.init_coef0 = cm.c0;
+      }
+    }
+    if (q.rc == 0) q.rc = hipSetDevice(s->device) == hipSuccess ? context_begin(c) : fail(BESSX_ERR_HIP, "hipSetDevice");
     c->timing = s->timing;  // (its fills count in the session's score-pass statistics)
+    kchains_log(c, "chunk starts", q.lo, q.hi);
     if (q.rc == 0) {
       q.bind(&q.res);
       q.chain = bessx_path_chain();
@@ -711,10 +896,12 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     }
     if (q.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) q.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
     if (q.rc) q.err = g_err;
+    kchains_log(c, "chunk ends", q.lo, q.hi);
     kchains_leave(k, q.rc != 0);
   };
   if (merged < 0) {
     if (!k->pool.run(chunk_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
+    if (pipeline && coarse_rc) return fail(coarse_rc, "coarse chain: " + coarse_err);
     for (int r = 0; r < C; r++)
       if (run[r].rc) return fail(run[r].rc, "chunk chain: " + run[r].err);
   }
@@ -773,7 +960,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     {
       int active = 0;
       for (int r = 1; r < C; r++) active += need[r] ? 1 : 0;
-      kchains_round(k, active);
+      kchains_round(k, active, staged);
     }
     if (!k->pool.run(stitch_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
     bool any = false;
@@ -849,6 +1036,10 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     if (s->kpath_chains == 0) s->kch_auto_off = true;
   }
   const int R = (int)run.size();  // chunks of the result (fewer than C after a give-up)
+  if (k->log_on) {
+    kchains_log(s, "path ends", 0, 0);
+    for (const auto &r : k->log) std::fprintf(stderr, "kchunks %8.3f ms  chain %2d  %-28s %d %d\n", r.ms, r.chain, r.what, r.a, r.b);
+  }
   s->kch_t[0] += secs(t_begin, t_coarse);
   s->kch_t[1] += secs(t_coarse, t_chunks);
   s->kch_t[2] += secs(t_chunks, now());

@@ -270,13 +270,20 @@ int alloc_cov_cache(bessx_session *s, bool share_map) {
 // forget every cached quantity that outlives a fit: a path call starts from nothing, like bessCpp
 // A stream with a hardware queue of its own (see fold_ctx_create): created with a compute-unit mask that names every
 // compute unit of the device.  false: not available (or switched off by the test hook) -- the caller makes an ordinary one.
-bool ctx_stream_create(int device, hipStream_t *st) {
+// leave_out > 0: a stream that may NOT use `leave_out` of the compute units (mask bits 0, stride, 2 stride, ...): the
+// stream the chunk chains' fills run on -- the chains' own small kernels find those units free while a panel pass
+// occupies every other one (bessx_kchunks.cpp).
+bool ctx_stream_create(int device, hipStream_t *st, int leave_out, int stride) {
   const char *hook = test_hook("ctx_streams");
   if (hook && std::string(hook) == "pool") return false;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) return false;
   std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
   if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+  for (int i = 0; i < leave_out; i++) {
+    const int bit = (int)(((long)i * std::max(1, stride)) % prop.multiProcessorCount);
+    mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+  }
   if (hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
     (void)hipGetLastError();
     *st = nullptr;
@@ -1435,6 +1442,10 @@ int chain_ctx_create(bessx_session *ps, bessx_session **out) {
   if (int rc = fold_ctx_create(ps, 0, &c)) return rc;
   c->kch_owner = ps;
   c->kch = nullptr;
+  c->kch_ev = nullptr;
+  c->kch_fill_st = nullptr;
+  c->kch_slot_w = nullptr;
+  c->kch_gen_seen = 0;
   c->publish = ps->publish;
   c->chain = ps->chain;
   c->defer_pub = ps->defer_pub;
@@ -1541,6 +1552,8 @@ int chain_ctx_create(bessx_session *ps, bessx_session **out) {
 void chain_ctx_free(bessx_session *c) {
   if (!c) return;
   if (c->st) (void)hipStreamSynchronize(c->st);
+  if (c->kch_ev) (void)hipEventDestroy(c->kch_ev);
+  c->kch_ev = nullptr;
   if (c->res_buf[1]) (void)hipHostFree(c->res_buf[1]);
   for (int b = 0; b < 2; b++)
     if (c->snap[b]) (void)hipFree(c->snap[b]);

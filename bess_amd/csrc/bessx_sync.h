@@ -134,21 +134,33 @@ struct FoldPool {
 //   abandoned     a chain failed, or a wait ran into the deadline: nobody waits any longer
 // `drain` = what makes the calling chain quiet (the library: hipStreamSynchronize of its stream); it is called with the
 // mutex released.
+// Round 5, `concurrent` rounds: the fills are STAGED -- the filling chain writes Gram columns into slots no reader can
+// see yet and publishes the slot map entries with the last launch of its fill (k_cov_publish_slots) -- so nobody has to
+// stand still: the rendezvous shrinks to the right to fill (one fill at a time) and a count of completed fills, by
+// which a chain tells that the look-up it parked on is out of date (another chain's fill ended since: look up again).
 struct FillRendezvous {
   std::mutex mu;
   std::condition_variable cv;
   int running = 0;
   bool fill_pending = false;
   bool abandoned = false;
+  bool concurrent = false;
+  unsigned long long fills_done = 0;
   double deadline_s = 30.0;
 
   // the caller of a round sets `running` to the number of chains the round starts BEFORE any of them runs: a chain
   // that parks at once must not take the others for finished
-  void round(int chains) {
+  void round(int chains, bool concurrent_fills = false) {
     std::lock_guard<std::mutex> lk(mu);
     running = chains;
     fill_pending = false;
     abandoned = false;
+    concurrent = concurrent_fills;
+  }
+
+  unsigned long long generation() {
+    std::lock_guard<std::mutex> lk(mu);
+    return fills_done;
   }
 
   // a chain has run to the end of its share of the round (failed: nobody waits any longer)
@@ -166,7 +178,7 @@ struct FillRendezvous {
   template <class Drain>
   void safe_point(Drain &&drain) {
     std::unique_lock<std::mutex> lk(mu);
-    if (!fill_pending || abandoned) return;
+    if (!fill_pending || abandoned || concurrent) return;
     lk.unlock();
     drain();  // (the candidate chained ahead runs to its end or parks)
     lk.lock();
@@ -181,9 +193,21 @@ struct FillRendezvous {
 
   // a parked chain asks for the cache: 0 = it may fill (every other chain stands still), 1 = another chain filled
   // while this one waited (the right is held all the same: look the columns up again), -1 = the run was abandoned
+  // (concurrent rounds: `seen` = the count of completed fills the caller's look-up is known to have run after; 1 is
+  // returned whenever a fill has ended since)
   template <class Drain>
-  int fill_begin(Drain &&drain) {
+  int fill_begin(Drain &&drain, unsigned long long seen = 0) {
     std::unique_lock<std::mutex> lk(mu);
+    if (concurrent) {
+      const bool ok = bessx_timed_wait(cv, lk, deadline_s, [&] { return !fill_pending || abandoned; });
+      if (!ok || abandoned) {
+        abandoned = true;
+        cv.notify_all();
+        return -1;
+      }
+      fill_pending = true;
+      return fills_done != seen ? 1 : 0;
+    }
     int waited = 0;
     while (fill_pending && !abandoned) {  // another chain is filling: this one is quiet (parked, its stream drained)
       waited = 1;
@@ -210,9 +234,10 @@ struct FillRendezvous {
     return waited;
   }
 
-  void fill_end() {
+  void fill_end(bool filled = true) {
     std::lock_guard<std::mutex> lk(mu);
     fill_pending = false;
+    if (filled) fills_done++;
     cv.notify_all();
   }
 };

@@ -114,6 +114,106 @@ int run_rounds(int C, int rounds, unsigned seed, bool with_failures) {
   return bad;
 }
 
+// Concurrent rounds (round 5, staged fills): nobody stands still.  The cache is two maps -- slot_w, the writer's (plain
+// ints, touched only under the right to fill), and slot_of, what the chains' "kernels" look up (atomics: a kernel may
+// read an entry while the publishing launch writes it) -- and the column data, plain longs written by the filling chain
+// BEFORE it publishes the entries.  A reader that finds a published entry must find its data complete; two fills must
+// never overlap (they would hand out the same slots: a data race on slot_w / data that TSan reports); and a chain whose
+// look-up is older than the last completed fill must be told to look again (fill_begin returns 1) -- otherwise it
+// would give a column that is cached by now a second slot (counted below as `dup`).
+struct StagedCache {
+  static constexpr int P = 192;
+  int slot_w[P];
+  std::atomic<int> slot_of[P];
+  long data[P];
+  int count = 0;  // (under the right)
+};
+
+int run_staged_rounds(int C, int rounds, unsigned seed) {
+  FoldPool pool;
+  pool.spin_iters = 2000;
+  pool.start(C - 1);
+  FillRendezvous rdv;
+  rdv.deadline_s = 20.0;
+  long fills = 0, relooks = 0, dup = 0, incomplete = 0, lookups = 0;
+  std::mutex stat_mu;
+  for (int r = 0; r < rounds; r++) {
+    StagedCache cache;
+    for (int i = 0; i < StagedCache::P; i++) {
+      cache.slot_w[i] = -1;
+      cache.slot_of[i].store(-1, std::memory_order_relaxed);
+      cache.data[i] = 0;
+    }
+    rdv.round(C, true);
+    auto job = [&](int k) {
+      std::mt19937 rng(seed * 104729u + (unsigned)r * 131u + (unsigned)k);
+      long my_fills = 0, my_relooks = 0, my_dup = 0, my_incomplete = 0, my_lookups = 0;
+      auto drain = [] {};
+      const int candidates = 6 + (int)(rng() % 20);
+      for (int cand = 0; cand < candidates; cand++) {
+        const unsigned long long seen = rdv.generation();  // (the library: read when the batch of launches is queued)
+        int want[4], nw = 1 + (int)(rng() % 4);
+        for (int i = 0; i < nw; i++) want[i] = (int)(rng() % StagedCache::P);
+        // the look-up "kernel"
+        bool missing = false;
+        for (int i = 0; i < nw; i++) {
+          const int sl = cache.slot_of[want[i]].load(std::memory_order_acquire);
+          my_lookups++;
+          if (sl < 0)
+            missing = true;
+          else if (cache.data[sl] != 1000 + want[i])
+            my_incomplete++;  // a published entry whose column is not there
+        }
+        while (missing) {
+          const int w = rdv.fill_begin(drain, seen);
+          if (w < 0) break;
+          if (w == 1) {  // a fill ended since the look-up: look again (the right is held meanwhile)
+            my_relooks++;
+            missing = false;
+            for (int i = 0; i < nw; i++) missing = missing || cache.slot_of[want[i]].load(std::memory_order_acquire) < 0;
+            if (!missing) {
+              rdv.fill_end(false);
+              break;
+            }
+          }
+          // the fill: slots from the writer's map, the columns, then the entries the readers see
+          int newc[4], nn = 0;
+          for (int i = 0; i < nw; i++) {
+            if (cache.slot_of[want[i]].load(std::memory_order_acquire) >= 0) continue;
+            bool listed = false;
+            for (int j = 0; j < nn; j++) listed = listed || newc[j] == want[i];
+            if (listed) continue;
+            if (cache.slot_w[want[i]] >= 0) my_dup++;  // cached by a fill this chain was not told about
+            cache.slot_w[want[i]] = cache.count++;
+            newc[nn++] = want[i];
+          }
+          for (int j = 0; j < nn; j++) cache.data[cache.slot_w[newc[j]]] = 1000 + newc[j];
+          for (int j = 0; j < nn; j++) cache.slot_of[newc[j]].store(cache.slot_w[newc[j]], std::memory_order_release);
+          my_fills++;
+          rdv.fill_end(true);
+          missing = false;
+        }
+        rdv.safe_point(drain);
+      }
+      rdv.leave(false);
+      std::lock_guard<std::mutex> lk(stat_mu);
+      fills += my_fills;
+      relooks += my_relooks;
+      dup += my_dup;
+      incomplete += my_incomplete;
+      lookups += my_lookups;
+    };
+    if (!pool.run(job, 20.0)) {
+      std::fprintf(stderr, "staged round %d: the pool did not come back\n", r);
+      return 1;
+    }
+  }
+  pool.stop();
+  std::printf("staged fills, chains %d, rounds %d: %ld look-ups, %ld fills, %ld second looks, columns cached twice %ld, "
+              "published entries without their column %ld\n", C, rounds, lookups, fills, relooks, dup, incomplete);
+  return (dup || incomplete) ? 1 : 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -122,6 +222,7 @@ int main(int argc, char **argv) {
   for (int C : {2, 3, 4, 6, 8}) {
     bad |= run_rounds(C, rounds, 1234u + (unsigned)C, false);
     bad |= run_rounds(C, rounds, 4321u + (unsigned)C, true);
+    bad |= run_staged_rounds(C + 1, rounds, 777u + (unsigned)C);
   }
   std::printf(bad ? "FAILED\n" : "sync harness OK\n");
   return bad;
