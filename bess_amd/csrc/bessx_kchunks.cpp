@@ -701,11 +701,11 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     }
     if (leave > 0 && !ctx_stream_create(s->device, &s->kch_fill_st, leave, stride)) s->kch_fill_st = nullptr;
   }
-  if (pipeline && s->model_type == 1) {
-    // chunk r starts when coarse fit r is done: the later a chunk starts the shorter it is (weights by test hook
-    // kchunks_weights=w0:w1:...; default: falling linearly to a third)
+  if (lm_cov && (pipeline || test_hook("kchunks_weights"))) {
+    // chunk lengths by weight (test hook kchunks_weights=w0:w1:...).  Pipeline: chunk r starts when coarse fit r is
+    // done -- the later a chunk starts the shorter it is (default: falling linearly to a third)
     std::vector<double> w((size_t)C, 1.0);
-    for (int r = 0; r < C; r++) w[(size_t)r] = 1.0 - (2.0 / 3.0) * r / std::max(1, C - 1);
+    for (int r = 0; r < C && pipeline; r++) w[(size_t)r] = 1.0 - (2.0 / 3.0) * r / std::max(1, C - 1);
     if (const char *ew = test_hook("kchunks_weights")) {
       int r = 0;
       for (const char *q = ew; *q && r < C; r++) {
@@ -1090,6 +1090,11 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     s->cov_panel_groups += c->cov_panel_groups;
     s->cov_cg_fallbacks += c->cov_cg_fallbacks;
     s->cov_tie_rescues += c->cov_tie_rescues;
+    s->dbg_waits += c->dbg_waits;
+    s->dbg_waits_ready += c->dbg_waits_ready;
+    s->dbg_enq_s += c->dbg_enq_s;
+    c->dbg_waits = c->dbg_waits_ready = 0;
+    c->dbg_enq_s = 0.0;
     s->chain_queued += c->chain_queued;
     s->chain_hits += c->chain_hits;
     c->cov_panel_groups = c->cov_cg_fallbacks = c->cov_tie_rescues = 0;

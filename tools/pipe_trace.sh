@@ -42,6 +42,18 @@ for s, e, n, q in seg:
 print("%-30s %22s %22s" % ("kernel (us)", "alone: n median", "beside a panel pass: n median"))
 for n, (a, b) in sorted(names.items(), key=lambda kv: -(sum(kv[1][0]) + sum(kv[1][1])))[:14]:
     print("%-30s %8d %10.1f %12d %10.1f" % (n, len(a), statistics.median(a) if a else 0, len(b), statistics.median(b) if b else 0))
+# what one chain's queue runs (the busiest queue that ran no panel pass)
+cq = max((q for q in byq if not any("k_cov_panel" in r[2] and r[1] - r[0] > 100_000 for r in byq[q])), key=lambda q: len(byq[q]))
+cnt = collections.Counter(r[2] for r in byq[cq])
+dur = collections.defaultdict(list)
+for s_, e_, n_, _ in byq[cq]:
+    dur[n_].append((e_ - s_) / 1e3)
+print("queue %s by kernel:" % cq)
+for n_, c_ in cnt.most_common():
+    d_ = sorted(dur[n_])
+    print("   %-30s n=%4d  median %.1f us  p10 %.1f  p90 %.1f  total %.2f ms" % (n_, c_, statistics.median(d_), d_[len(d_) // 10], d_[(9 * len(d_)) // 10], sum(d_) / 1e3))
+seq_ = [r[2][7:22] for r in byq[cq][60:100]]
+print("   a stretch of it:", seq_)
 # per queue: gaps between consecutive kernels that overlap a panel pass vs not
 for q, rs in sorted(byq.items()):
     ga, gb = [], []
