@@ -442,6 +442,7 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
   // upper bound of the list length (the device drops speculative columns that turn out to be cached already)
   const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, pool) : 0;
   const int ngroups = (nm + room + COV_R - 1) / COV_R;
+  if (test_hook("panel_log")) std::fprintf(stderr, "[bessx] fill: level %d, %d missing, list of up to %d -> %d group(s)%s\n", T0, nm, nm + room, ngroups, s->kch_owner ? " (chunk chain)" : "");
   // staged fills run on the owner's fill stream where there is one (it leaves some compute units to the other chains'
   // kernels): the list first, on this chain's stream
   hipStream_t own_st = s->st;

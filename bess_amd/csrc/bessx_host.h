@@ -282,7 +282,8 @@ struct bessx_session {
   long long kch_paths = 0, kch_refits = 0, kch_chunk_fills = 0;  // paths run chunked, stitch refits, fills in the chunk phase
   int kch_last_chains = 0;              // chains of the last chunked path
   bool kch_auto_off = false;            // the chunks of a path did not merge with the chain: the automatic choice is one chain
-  int panel_variant = 0;                // 5: k_cov_panel_dp for the fills (test hook panel=dp / panel=old)
+  int panel_variant = 0;                // 5: k_cov_panel_dp for the fills (default; test hook panel=lds: 0, the round-2 kernels)
+  int cov_panel_blocks = 0;             // workgroups of one panel pass with the slab count chosen at creation
   bool own_hw_queue = false;            // (fit contexts) the context's stream has a hardware queue outside the runtime's pool
   long long group_xtx_ns = 0;           // device time of the all-rows group_XTX pass at session creation (LM)
   long long kch_giveups = 0;            // paths whose stitch ran out of budget (the rest was walked as one chain)

@@ -695,6 +695,15 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     // the fills' stream: every compute unit but a few (test hook kchunks_reserve=count[:stride of the mask bits]; 0: the
     // fills run on the filling chain's own stream)
     int leave = 16, stride = 1;
+    if (s->panel_variant == 5) {
+      // k_cov_panel_dp runs ONE workgroup per compute unit: the units left out must be ones its last round of
+      // workgroups leaves idle anyway (configs[1]: 237 workgroups), or a pass on the fill stream would take a round more
+      hipDeviceProp_t prop;
+      const int cus = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? prop.multiProcessorCount : 0;
+      const int last = cus > 0 ? s->cov_panel_blocks % cus : 0;
+      const int idle = (cus > 0 && last > 0) ? cus - last : 0;
+      leave = idle >= 4 ? std::min(16, idle) : 0;
+    }
     if (const char *er = test_hook("kchunks_reserve")) {
       leave = std::max(0, std::atoi(er));
       if (const char *c2 = std::strchr(er, ':')) stride = std::max(1, std::atoi(c2 + 1));

@@ -212,6 +212,7 @@ int cov_collect(bessx_session *s, int nfill) {
     s->k1_seconds += (double)ms * 1e-3;
     s->k1_launches += 1;
     s->k1_bytes += 8.0 * (double)s->n * (double)s->p * real;
+    if (test_hook("panel_log")) std::fprintf(stderr, "[bessx] panel pass: %d group(s) %.3f ms%s\n", real, ms, s->kch_owner ? " (chunk chain)" : "");
   }
   s->cov_timed.clear();
   s->ev_used = 0;
@@ -1195,8 +1196,12 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
         const int pt = (p + 15) / 16, njg = (pt + cov_streamed_tiles_per_wave() - 1) / cov_streamed_tiles_per_wave();
         // row slabs: two 256-thread blocks of the panel kernel share a CU (50 KB of LDS each), so pick the slab count
         // whose block count wastes the least of the last round of 512 blocks
+        // the fills' kernel: k_cov_panel_dp (round 5; the default since the chunk chains' coarse phase became a dense
+        // run of passes, where it is 3-4 % faster per pass: DESIGN.md 13); test hook panel=lds: k_cov_panel_lds2 / _pair
+        s->panel_variant = 5;
         if (const char *ev = test_hook("panel")) s->panel_variant = std::string(ev) == "dp" ? 5 : 0;
         long ns = 1, rps = ld;
+        long panel_blocks = 0;
         {
           // (k_cov_panel_dp: one 8-wave block per compute unit, 128 streamed columns per block)
           const bool dp = s->panel_variant == 5;
@@ -1211,9 +1216,11 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
               best = cost;
               ns = used;
               rps = r;
+              panel_blocks = blocks;
             }
           }
         }
+        s->cov_panel_blocks = (int)std::min<long>(panel_blocks, 1 << 30);
         s->cov_rps = (int)rps;
         s->cov_nslab = (int)ns;
         HIPT(dmalloc(&s->cov_part, (size_t)COV_SLOT_GROUPS * ns * njg * cov_streamed_tiles_per_wave() * 2 * 256));

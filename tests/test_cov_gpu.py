@@ -166,7 +166,7 @@ def test_cv_row_sets_share_their_fills(gpu, monkeypatch, n, p, K):
 
 def test_panel_kernel_dp_against_numpy_and_the_default_kernels(gpu, monkeypatch):
     """k_cov_panel_dp (round 5: one 8-wave workgroup per compute unit over 128 streamed columns, two LDS tiles, one
-    barrier per chunk; test hook panel=dp): its Gram columns against NumPy X^T X_S -- one group and a pair per pass, a
+    barrier per chunk; the default, test hook panel=lds selects k_cov_panel_lds2 / _pair): its Gram columns against NumPy X^T X_S -- one group and a pair per pass, a
     column count that is no multiple of 128, a fold mask -- and a path run with it against the default kernels' path."""
     X, y, _, _ = synth.make_lm(3000, 1100, 12, seed=5)  # 1100 columns: the last workgroup's second half is partly empty
     n, p = X.shape
@@ -175,6 +175,7 @@ def test_panel_kernel_dp_against_numpy_and_the_default_kernels(gpu, monkeypatch)
     cols = ((np.arange(128) * 29 + 7) % p).astype(np.int32)
     want = Xn.T @ Xn[:, cols]
     seq = np.arange(1, 41)
+    hooks(monkeypatch, panel="lds")  # (the kernels of rounds 2-4; k_cov_panel_dp is the default since round 5)
     with gpu.Session(X, y, score_mode=2) as s0:
         ref = s0.sequential_path(seq, ic_type=3)
         fold = synth.make_cv_folds(n, 4)

@@ -19,10 +19,12 @@ def test_random_problems_with_chunk_chains_forced(gpu, monkeypatch):
     assert fuzz_parity.run(cases=120, seed=5, verbose=False) == 0
 
 
-@pytest.mark.parametrize("hooks_", ["kchunks_merged=1", "panel=dp", "kchunks_merged=1,panel=dp"])
+@pytest.mark.parametrize("hooks_", ["kchunks_merged=1", "panel=lds", "kchunks_merged=1,panel=lds", "kchunks_staged=0"])
 def test_random_problems_with_the_round_5_variants_forced(gpu, monkeypatch, hooks_):
     """The differential test with round 5's selectable variants switched on for every session: the chunk phase as merged
-    launches on one stream (LM, covariance form) and / or the k_cov_panel_dp fills -- chunk chains forced as above."""
+    launches on one stream (LM, covariance form), the fills by the panel kernels of rounds 2-4 (k_cov_panel_lds2 / _pair
+    instead of k_cov_panel_dp, the default), round 4's fill rendezvous instead of staged fills -- chunk chains forced as
+    above."""
     import fuzz_parity
     monkeypatch.setenv("BESSX_KPATH_CHAINS", "3")
     monkeypatch.setenv("BESSX_TEST_HOOKS", hooks_)
