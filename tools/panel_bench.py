@@ -1,4 +1,5 @@
-"""The panel kernels of the covariance form alone (k_cov_panel_lds2: 32 Gram columns per pass over X; k_cov_panel_pair:
+"""The panel kernels of the covariance form alone (k_cov_panel_dp, one or two 32-column groups per pass over X; with
+BESSX_TEST_HOOKS=panel=lds the kernels of rounds 2-4: k_cov_panel_lds2, 32 Gram columns per pass, and k_cov_panel_pair,
 64 per pass): timed with HIP events through the cooperative-prefill entry points (bessx_session_cov_prefill_*), which
 run exactly the fill a parked fit runs -- list, panel, reduce -- on columns of the caller's choice.
   python tools/panel_bench.py [n p] [repeats] [--check]
@@ -43,7 +44,9 @@ with capi.Session(X, y, score_mode=2) as s:
     ngroups = 8
     cols = (np.arange(ngroups * 32, dtype=np.int32) * 37 + 11) % p
     s.cov_prefill_begin(cols)
-    for name, per_launch in (("k_cov_panel_lds2 (32 columns per pass)", 1), ("k_cov_panel_pair (64 columns per pass)", 2)):
+    lds = "panel=lds" in os.environ.get("BESSX_TEST_HOOKS", "")  # (round 5: k_cov_panel_dp is the default)
+    for name, per_launch in (((("k_cov_panel_lds2" if lds else "k_cov_panel_dp") + " (32 columns per pass)"), 1),
+                             ((("k_cov_panel_pair" if lds else "k_cov_panel_dp") + " (64 columns per pass)"), 2)):
         for g in range(0, ngroups, per_launch):  # warm-up: code objects, clocks
             s.cov_prefill_compute(g, per_launch)
         s.enable_kernel_timing(True)
