@@ -696,12 +696,14 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     // fills run on the filling chain's own stream)
     int leave = 16, stride = 1;
     if (s->panel_variant == 5) {
-      // k_cov_panel_dp runs ONE workgroup per compute unit: the units left out must be ones its last round of
-      // workgroups leaves idle anyway (configs[1]: 237 workgroups), or a pass on the fill stream would take a round more
+      // k_cov_panel_dp runs ONE workgroup per compute unit: the units left out must be ones its rounds of workgroups
+      // leave idle anyway (configs[1]: 237 workgroups, one round), or a pass on the fill stream would take a round more
       hipDeviceProp_t prop;
       const int cus = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? prop.multiProcessorCount : 0;
-      const int last = cus > 0 ? s->cov_panel_blocks % cus : 0;
-      const int idle = (cus > 0 && last > 0) ? cus - last : 0;
+      // (the most units that can go without a round more: rounds = ceil(blocks / units) must stay what it is)
+      const int blocks = s->cov_panel_blocks;
+      const int rounds = (cus > 0 && blocks > 0) ? (blocks + cus - 1) / cus : 0;
+      const int idle = rounds > 0 ? cus - (blocks + rounds - 1) / rounds : 0;
       leave = idle >= 4 ? std::min(16, idle) : 0;
     }
     if (const char *er = test_hook("kchunks_reserve")) {
