@@ -683,7 +683,9 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     const char *ev = test_hook("kchunks_staged");
     staged = !ev || std::atoi(ev) != 0;  // (default; 0: round 4's rendezvous -- every chain stands still for a fill)
     const char *ep = test_hook("kchunks_pipeline");
-    pipeline = ep && std::atoi(ep) != 0 && (int)k->ctx.size() > C && (int)k->pool.th.size() >= C;
+    // (not for a link of a longer chain: the columns of the model it starts from are formed by the coarse chain's
+    // first fit, which must then be over before chunk 0 looks them up)
+    pipeline = ep && std::atoi(ep) != 0 && (int)k->ctx.size() > C && (int)k->pool.th.size() >= C && link == nullptr;
     if (pipeline) staged = true;
   }
   if (staged && !s->kch_slot_w && dmalloc(&s->kch_slot_w, (size_t)s->p) != hipSuccess) {
@@ -809,10 +811,15 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
         run[(size_t)r].init_coef0 = cm.c0;
       }
   }
-  if (staged) {  // the writer's slot map starts as a copy of the readers'
+  // The writer's slot map is a copy of the readers' whenever a round of chains starts (no fill is in flight between two
+  // rounds; what ran in between -- the coarse chain, a chunk phase as merged launches -- filled through the readers' map)
+  auto writer_map_in_step = [&]() -> int {
+    if (!staged) return 0;
     HIPX(hipMemcpyAsync(s->kch_slot_w, s->cov[0].slot_of, (size_t)s->p * sizeof(int), hipMemcpyDeviceToDevice, s->st));
     HIPX(hipStreamSynchronize(s->st));
-  }
+    return 0;
+  };
+  if (int rc = writer_map_in_step()) return rc;
   if (lm_cov)
     for (bessx_session *c : k->ctx) c->cov[0].slot_w = staged ? s->kch_slot_w : nullptr;
   // ---- 2. the chunks side by side: as merged launches on the session's stream where that applies (LM, the fused
@@ -971,6 +978,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     {
       int active = 0;
       for (int r = 1; r < C; r++) active += need[r] ? 1 : 0;
+      if (int rc = writer_map_in_step()) return rc;
       kchains_round(k, active, staged);
     }
     if (!k->pool.run(stitch_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
