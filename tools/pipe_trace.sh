@@ -5,7 +5,7 @@
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=/tmp/pipetrace; rm -rf $out; mkdir -p $out $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 $root/tools/pipe_profile_run.py ${1:-4} > $root/gpurun_out/pipe_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 $root/tools/${PIPE_TRACE_RUNNER:-pipe_profile_run.py} ${1:-4} > $root/gpurun_out/pipe_trace.log 2>&1
 python3 - $out > $root/gpurun_out/pipe_trace_summary.txt <<'PY'
 import csv, glob, sys, collections, statistics
 rows = []
