@@ -1,10 +1,11 @@
 """configs[1]: the Gram column cache after a path, 32-slot group by group (= pass over X by pass): how many of a
 group's columns were ever active, and at which level each is first needed"""
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bess_amd import capi, synth  # noqa: E402
 
 X, y, _, _ = synth.make_lm(50000, 10000, 100)

@@ -1,9 +1,10 @@
 """configs[1]: how many PDAS iterations the candidates take, and what the chained fits did (BESSX_DEBUG counters)"""
+import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bess_amd import capi, synth  # noqa: E402
 
 X, y, _, _ = synth.make_lm(50000, 10000, 100)

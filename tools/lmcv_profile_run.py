@@ -1,10 +1,11 @@
 """configs[3] paths (LM gs_path + 5-fold CV) with pauses between them, for tools/pipe_trace.sh (PIPE_TRACE_RUNNER)"""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bess_amd import capi, synth  # noqa: E402
 
 n, p = 50000, 10000

@@ -1,5 +1,6 @@
+import os
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bess_amd import capi, synth
 X, y, _, _ = synth.make_lm(50000, 10000, 100)
 seq = np.arange(1, 201)

@@ -1,10 +1,11 @@
 """one logged configs[1] path (BESSX_TEST_HOOKS=...,kchunks_log=1): what every chain did when"""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bess_amd import capi, synth  # noqa: E402
 
 X, y, _, _ = synth.make_lm(50000, 10000, 100)
