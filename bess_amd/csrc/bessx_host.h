@@ -274,6 +274,7 @@ struct bessx_session {
   bessx::KChains *kch = nullptr;        // parent: contexts, host threads, the fill rendezvous (created at first use)
   bessx_session *kch_owner = nullptr;   // chain context: the session whose cache it reads
   int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
+  int kch_index = -1;                   // (chain context) its place among the owner's contexts
   unsigned long long kch_gen_seen = 0;  // (chain context) completed fills when this chain last queued a look-up
   int *kch_slot_w = nullptr;            // (owner) the writer's slot map of staged fills, p ints
   hipStream_t kch_fill_st = nullptr;    // (owner) the stream the chains' staged fills run on (some compute units left out)
@@ -454,6 +455,7 @@ void kchains_safe_point(bessx_session *c);   // chain context, between candidate
 int kchains_fill_begin(bessx_session *c);    // chain context parked on missing columns: wait until it alone runs
 void kchains_fill_end(bessx_session *c, bool filled = true);
 void kchains_log(bessx_session *c, const char *what, int a, int b);  // (test hook kchunks_log=1)
+void kchains_progress(bessx_session *c, int n);  // chain context: n candidates of its chunk are stored
 bool kchains_staged(const bessx_session *c);               // this round's fills are staged (nobody stands still)
 unsigned long long kchains_generation(bessx_session *c);   // completed fills of the owner's chains so far
 void kchains_free(bessx_session *s);

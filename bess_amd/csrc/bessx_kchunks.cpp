@@ -25,6 +25,9 @@ struct KChains {
   FoldPool pool;
   bool pool_started = false;
   FillRendezvous rdv;  // the fill rendezvous (bessx_sync.h: built and hammered under ThreadSanitizer, tools/tsan)
+  // candidates a chunk chain has stored so far / whether it has ended (read by its predecessor's early stitch)
+  std::atomic<int> progress[10];
+  std::atomic<int> ended[10];  // 0 running, 1 ended, 2 failed
   // test hook kchunks_log=1: what every chain did when (to stderr at the end of the path)
   bool log_on = false;
   std::mutex log_mu;
@@ -94,6 +97,14 @@ void kchains_log(bessx_session *c, const char *what, int a, int b) {
   const double ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - k->log_t0).count() * 1e3;
   std::lock_guard<std::mutex> lk(k->log_mu);
   k->log.push_back({ms, id, what, a, b});
+}
+
+// a chain context has stored its n-th candidate (rows < n of its result arrays are final)
+void kchains_progress(bessx_session *c, int n) {
+  KChains *k = c->kch_owner ? c->kch_owner->kch : nullptr;
+  if (!k || c->kch_index < 0 || c->kch_index >= 10) return;
+  if (k->ended[c->kch_index].load(std::memory_order_acquire) != 0) return;  // (a refit on the context of an ended chunk)
+  k->progress[c->kch_index].store(n, std::memory_order_release);
 }
 
 bool kchains_staged(const bessx_session *c) {
@@ -260,6 +271,7 @@ int kchunks_prepare(bessx_session *s, int ns, bool link) {
       (void)hipGetLastError();
       return 1;
     }
+    c->kch_index = (int)k->ctx.size();
     k->ctx.push_back(c);
   }
   if (!k->pool_started || (int)k->pool.th.size() < C - 1 + extra) {  // one host thread per chain; the caller is one of them
@@ -836,6 +848,64 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   } starts;
   int coarse_rc = 0;
   std::string coarse_err;
+  // The stitch's first round, early (test hook kchunks_early_stitch=0 switches it off): the thread of chunk r - 1, when its
+  // chunk is walked, re-fits the first candidates of chunk r from its own last model on its own (now idle) context while
+  // the later chunks are still running -- what round 1 of the stitch below would do after ALL chunks have ended.  It
+  // compares with the rows chunk r has stored by then (kchains_progress); a refit that could not see `budget` rows is
+  // thrown away and done again in round 1.
+  bool early_on = !pipeline && C <= 9;
+  if (const char *ee = test_hook("kchunks_early_stitch")) early_on = early_on && std::atoi(ee) != 0;
+  std::vector<ChunkRun> early_st((size_t)C);
+  std::vector<char> early_ok((size_t)C, 0);
+  for (int r = 0; r < 10; r++) {
+    k->progress[r].store(0, std::memory_order_relaxed);
+    k->ended[r].store(0, std::memory_order_relaxed);
+  }
+  auto budget_of = [&](int r) { return std::max(8, (run[r].hi - run[r].lo) / 6); };
+  auto early_stitch = [&](int r) {  // on the thread and the context of chunk r - 1, which has just ended without error
+    bessx_session *c = k->ctx[(size_t)r - 1];
+    ChunkRun &q = run[(size_t)r], &t = early_st[(size_t)r];
+    const int want = std::min(q.hi - q.lo, budget_of(r));
+    const auto t0 = std::chrono::steady_clock::now();
+    while (k->progress[r].load(std::memory_order_acquire) < want && k->ended[r].load(std::memory_order_acquire) == 0) {
+      kchains_safe_point(c);  // (a chain that waits for every other chain to stand still must not wait for this one)
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s->wait_deadline_s) return;
+    }
+    if (k->ended[r].load(std::memory_order_acquire) == 2) return;
+    const int rows = k->progress[r].load(std::memory_order_acquire);
+    if (rows < want) return;
+    const ChunkRun &pr = run[(size_t)r - 1];
+    std::vector<int> pidx(pr.last_idx.begin(), pr.last_idx.begin() + pr.last_len);
+    std::vector<double> pval(pr.last_val.begin(), pr.last_val.begin() + pr.last_len);
+    t.shape(q.lo, q.hi, width, s->p_full);
+    t.bind(&t.res);
+    t.chain = bessx_path_chain();
+    t.chain.init_idx = pidx.data();
+    t.chain.init_val = pval.data();
+    t.chain.init_len = (int)pidx.size();
+    t.chain.init_coef0 = pr.last_coef0;
+    t.chain.keep_caches = 1;
+    t.chain.stop_support = q.support.data();
+    t.chain.stop_beta = q.beta.data();
+    t.chain.stop_rows = rows;  // (the rows chunk r has stored so far: final, it only appends)
+    t.chain.stop_row_len = width;
+    t.chain.stop_rtol = 1e-9;
+    t.chain.last_idx = t.last_idx.data();
+    t.chain.last_val = t.last_val.data();
+    t.chain.last_cap = width;
+    kchains_log(c, "early stitch of the next chunk", q.lo, rows);
+    t.rc = context_begin(c);
+    if (t.rc == 0) t.rc = sequential_path(c, seq + q.lo, want, &lambda, 1, ic_type, 0, &t.res, &t.chain);
+    if (t.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) t.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
+    t.fits = c->n_fits;
+    t.chain.init_idx = nullptr;  // (locals of this function)
+    t.chain.init_val = nullptr;
+    // a failure here is not the path's: round 1 of the stitch does this refit again
+    if (t.rc == 0) early_ok[(size_t)r] = 1;
+    else (void)hipGetLastError();
+    kchains_log(c, "early stitch done", t.res.n_candidates, t.chain.stopped_at);
+  };
   auto coarse_job = [&] {
     bessx_session *w = k->ctx[(size_t)C];
     int rc = hipSetDevice(s->device) == hipSuccess ? context_begin(w) : fail(BESSX_ERR_HIP, "hipSetDevice");
@@ -915,6 +985,8 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     if (q.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) q.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
     if (q.rc) q.err = g_err;
     kchains_log(c, "chunk ends", q.lo, q.hi);
+    if (r < 10) k->ended[r].store(q.rc ? 2 : 1, std::memory_order_release);
+    if (early_on && q.rc == 0 && r + 1 < C) early_stitch(r + 1);
     kchains_leave(k, q.rc != 0);
   };
   if (merged < 0) {
@@ -934,9 +1006,15 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   need[0] = 0;
   long long refits = 0;
   int give_up_from = -1;
-  auto budget_of = [&](int r) { return std::max(8, (run[r].hi - run[r].lo) / 6); };
   for (int round = 1;; round++) {
     std::vector<ChunkRun> st((size_t)C);
+    std::vector<char> have((size_t)C, 0);  // refits of this round that are there already (the early stitch)
+    if (round == 1 && merged < 0)
+      for (int r = 1; r < C; r++)
+        if (early_ok[(size_t)r]) {
+          st[(size_t)r] = std::move(early_st[(size_t)r]);
+          have[(size_t)r] = 1;
+        }
     std::vector<std::vector<int>> pred_idx((size_t)C);
     std::vector<std::vector<double>> pred_val((size_t)C);
     std::vector<double> pred_c0((size_t)C, 0.0);
@@ -947,7 +1025,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
         pred_c0[r] = run[r - 1].last_coef0;
       }
     auto stitch_job = [&](int r) {
-      if (r >= C || !need[r]) return;
+      if (r >= C || !need[r] || have[(size_t)r]) return;
       bessx_session *c = k->ctx[r];
       ChunkRun &q = run[r], &t = st[r];
       t.shape(q.lo, q.hi, width, s->p_full);
@@ -975,13 +1053,13 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
       t.fits = c->n_fits;
       kchains_leave(k, t.rc != 0);
     };
-    {
-      int active = 0;
-      for (int r = 1; r < C; r++) active += need[r] ? 1 : 0;
+    int active = 0;
+    for (int r = 1; r < C; r++) active += (need[r] && !have[(size_t)r]) ? 1 : 0;
+    if (active > 0) {
       if (int rc = writer_map_in_step()) return rc;
       kchains_round(k, active, staged);
+      if (!k->pool.run(stitch_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
     }
-    if (!k->pool.run(stitch_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
     bool any = false;
     for (int r = 1; r < C; r++) {
       changed[r] = 0;

@@ -138,7 +138,10 @@ int sequential_path(bessx_session *s, const int *seq, int ns, const double *lam,
       if (int rc = metric_train_loss(s, &c.loss)) return rc;
       if (int rc = metric_ic(s, ic_type, is_cv, &c.ic)) return rc;
       store_candidate(s, res, c, false);
-      if (s->kch_owner) kchains_safe_point(s);
+      if (s->kch_owner) {
+        kchains_progress(s, res->n_candidates);
+        kchains_safe_point(s);
+      }
       if (chain && chain_row_matches(s, chain, res->n_candidates - 1, c)) {
         // from here on the chain the caller already holds IS this chain: same model, same successor
         chain->stopped_at = res->n_candidates - 1;

@@ -1449,6 +1449,7 @@ int chain_ctx_create(bessx_session *ps, bessx_session **out) {
   if (int rc = fold_ctx_create(ps, 0, &c)) return rc;
   c->kch_owner = ps;
   c->kch = nullptr;
+  c->kch_index = -1;
   c->kch_ev = nullptr;
   c->kch_fill_st = nullptr;
   c->kch_slot_w = nullptr;

@@ -364,23 +364,26 @@ def test_chunk_chains_of_the_streaming_lm_path(gpu, monkeypatch, chains):
         _same_path(w, s.sequential_path(seq[:40], ic_type=2))
 
 
-@pytest.mark.parametrize("variant", ["rendezvous", "staged_own_stream", "staged_fill_stream", "pipeline"])
+@pytest.mark.parametrize("variant", ["rendezvous", "staged_own_stream", "staged_fill_stream", "pipeline", "late_stitch",
+                                     "rendezvous_late_stitch"])
 def test_fill_disciplines_of_the_chunk_chains_return_the_single_chain(gpu, monkeypatch, variant):
     """How a chunk chain's fill of the shared Gram column cache is kept from the other chains (bessx_sync.h:
     FillRendezvous): round 4's rendezvous -- every other chain stands still (kchunks_staged=0) -- and round 5's STAGED
     fills (default): the fill writes slots nobody can look up until its last launch publishes them (k_cov_publish_slots),
     on the filling chain's own stream (kchunks_reserve=0) or on the session's fill stream that leaves some compute units
     to the other chains' kernels; and the coarse chain BESIDE the chunks instead of in front of them (kchunks_pipeline=1:
-    measured slower, kept selectable).  Designs whose chunks need many fills of their own; the same candidates each way,
-    path after path on one session."""
+    measured slower, kept selectable).  And when the first round of the stitch runs: early, on the thread of the chunk in
+    front as soon as that chunk is walked (default), or after all chunks (kchunks_early_stitch=0).  Designs whose chunks need
+    many fills of their own; the same candidates each way, path after path on one session."""
     from helpers import hooks
     hk = {"rendezvous": dict(kchunks_staged=0), "staged_own_stream": dict(kchunks_staged=1, kchunks_reserve=0),
-          "staged_fill_stream": dict(kchunks_staged=1, kchunks_reserve=24), "pipeline": dict(kchunks_pipeline=1)}[variant]
+          "staged_fill_stream": dict(kchunks_staged=1, kchunks_reserve=24), "pipeline": dict(kchunks_pipeline=1),
+          "late_stitch": dict(kchunks_early_stitch=0), "rendezvous_late_stitch": dict(kchunks_staged=0, kchunks_early_stitch=0)}[variant]
     for (n, p, k, seed, top, chains) in ((3000, 2600, 60, 3, 160, 8), (2500, 700, 20, 11, 64, 4), (3000, 1500, 60, 5, 128, 3)):
         X, y, _, _ = synth.make_lm(n, p, k, seed=seed)
         seq = np.arange(1, top + 1)
         monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
-        hooks(monkeypatch, kchunks_staged=1, kchunks_pipeline=0)
+        hooks(monkeypatch, kchunks_staged=1, kchunks_pipeline=0, kchunks_early_stitch=1)
         with gpu.Session(X, y) as s:
             want = s.sequential_path(seq, ic_type=3)
         monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
