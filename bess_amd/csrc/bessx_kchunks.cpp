@@ -234,11 +234,14 @@ struct ChunkRun {  // one chunk's candidates, as sequential_path stores them
   }
 };
 
-// the context's own state starts over (the shared cache stays as it is)
-int context_begin(bessx_session *c) {
+// the context's own state starts over (the shared cache stays as it is); keep_model: except the model its last fit left
+// on the device -- the early stitch continues from exactly that model, without uploading it again
+int context_begin(bessx_session *c, bool keep_model = false) {
   if (int rc = settle_device_chain(c)) return rc;
-  for (auto &q : c->cache) q.valid = false;
-  c->dev_state_rs = -1;
+  if (!keep_model) {
+    for (auto &q : c->cache) q.valid = false;
+    c->dev_state_rs = -1;
+  }
   c->trace.clear();
   c->metric_depth = 0;
   c->n_fits = 0;
@@ -895,7 +898,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     t.chain.last_val = t.last_val.data();
     t.chain.last_cap = width;
     kchains_log(c, "early stitch of the next chunk", q.lo, rows);
-    t.rc = context_begin(c);
+    t.rc = context_begin(c, true);  // (its last fit's model IS the model the refit starts from)
     if (t.rc == 0) t.rc = sequential_path(c, seq + q.lo, want, &lambda, 1, ic_type, 0, &t.res, &t.chain);
     if (t.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) t.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
     t.fits = c->n_fits;
