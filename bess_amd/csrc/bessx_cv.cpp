@@ -12,7 +12,7 @@ namespace bessx {
 // --------------------------------------------------------------------------------------------
 void fold_contexts_invalidate(bessx_session *s) {
   for (bessx_session *c : s->fold_ctx) {
-    for (auto &cc : c->cache) cc.valid = false;
+    for (auto &cc : c->cache) cc.valid = cc.model_only = false;
     c->dev_state_rs = -1;
   }
 }
@@ -84,7 +84,7 @@ int fold_fits_side_by_side(bessx_session *s, double *out, const std::vector<int>
     t0 = t1;
   };
   auto tm = tnow();
-  for (int r = 1; r <= K; r++) s->cache[r].valid = false;  // the fold row sets' state now lives in the contexts
+  for (int r = 1; r <= K; r++) s->cache[r].valid = s->cache[r].model_only = false;  // the fold row sets' state now lives in the contexts
   if (s->dev_state_rs > 0) s->dev_state_rs = -1;
   // ---- start of the K fits: Algorithm::fit up to its first iteration (src/Algorithm.h:147-160)
   // the opening of one chain's fit (its own stream): warm start from the device state or from the uploaded support
@@ -127,7 +127,7 @@ int fold_fits_side_by_side(bessx_session *s, double *out, const std::vector<int>
     bessx_session::RsCache &cc = c->cache[rs];
     q.use_cache = cc.valid && cc.coef0 == c->coef0_init && cc.beta.idx == c->beta_init.idx &&
                   cc.beta.val == c->beta_init.val && cc.cov_layout && c->dev_state_rs == rs;
-    cc.valid = false;
+    cc.valid = cc.model_only = false;
     q.prev_T0 = cc.T0;
     q.serial = ++c->fit_serial;
     q.scores_ok = q.use_cache && cc.lambda == lambda;

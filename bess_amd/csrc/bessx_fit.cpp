@@ -879,7 +879,7 @@ int algorithm_fit_grouped(bessx_session *s) {
   bessx_session::RsCache &cc = s->cache[rs];
   const bool cont = gcov && cc.valid && cc.cov_layout && s->dev_state_rs == rs && cc.coef0 == s->coef0_init &&
                     cc.beta.idx == s->beta_init.idx && cc.beta.val == s->beta_init.val;
-  cc.valid = false;
+  cc.valid = cc.model_only = false;
   if (!cont) {
     int *st_idx = reinterpret_cast<int *>(s->stage_h);
     double *st_val = reinterpret_cast<double *>(s->stage_h + (size_t)s->capA * sizeof(int));
@@ -1205,7 +1205,7 @@ int algorithm_fit_grouped(bessx_session *s) {
     s->glm_fallback = true;
     HIPX(hipStreamSynchronize(s->st));
     HIPX(hipMemsetAsync(&s->ctrl->info, 0, sizeof(int), s->st));
-    s->cache[rs].valid = false;
+    s->cache[rs].valid = s->cache[rs].model_only = false;
     s->dev_state_rs = -1;
     return algorithm_fit_grouped(s);
   }
@@ -1346,7 +1346,15 @@ int algorithm_fit(bessx_session *s) {
   bool use_cache = cc.valid && cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx &&
                    cc.beta.val == s->beta_init.val && (!cox || s->cox_state_rs == rs) && (glm || cc.cov_layout == cov);
   if (cox) s->cox_state_rs = rs;
-  cc.valid = false;
+  // Covariance form: the previous fit of the chain ended on a cycle of active sets (src/Algorithm.h: A equal to an EARLIER
+  // column of A_list) -- its last solve changed the coefficients after the last score pass.  The device still holds
+  // exactly the model this fit starts from: no upload, no look-up of its columns, only the scores are formed again
+  // (round 5; before, such a fit was set up from the host's copy: two copies, k_fit_begin and the six launches of a
+  // slot-0 fill that finds nothing missing -- 19 times per configs[1] path).
+  const bool model_kept = cov && !use_cache && cc.model_only && cc.cov_layout && s->dev_state_rs == rs &&
+                          cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx && cc.beta.val == s->beta_init.val &&
+                          !s->trace.on && test_hook("model_kept") == nullptr;
+  cc.valid = cc.model_only = false;
   // A chained fit may already be queued (or finished) behind the previous one: it is this fit if the path function
   // asked for exactly what it announced; otherwise the device state can no longer be trusted to be the previous
   // fit's result and everything is set up again from the host's copy.
@@ -1390,7 +1398,7 @@ int algorithm_fit(bessx_session *s) {
   hipError_t e = hipSuccess;
   if (ahead_hit) {
     // nothing to queue: the first batch of this fit is running or done
-  } else if (use_cache && s->dev_state_rs == rs) {
+  } else if ((use_cache && s->dev_state_rs == rs) || model_kept) {
     // the device still holds exactly these coefficients (previous fit of the chain): no upload, no re-initialisation
     e = launch_fit_continue(s->ctrl, T0, s->hist, s->st, my_serial, 0);
   } else {
@@ -1420,7 +1428,7 @@ int algorithm_fit(bessx_session *s) {
                             s->A_cur, s->b_cur, s->r_rs[rs], s->h_rs[rs], s->sse, s->st);
   }
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("fit begin: ") + hipGetErrorString(e));
-  if (cov && !use_cache && k_init > 0) {
+  if (cov && !use_cache && !model_kept && k_init > 0) {
     // the first score pass multiplies the cached Gram columns of the initial support: form the missing ones
     bessx_session::CovCache &cv = s->cov[rs];
     e = launch_cov_need(s->A_cur, k_init, nullptr, s->bd2, s->p, cv.slot_of, cv.meta, cov_C_dev(s), s->cov_fcols, s->ctrl, 0,
@@ -1543,7 +1551,7 @@ int algorithm_fit(bessx_session *s) {
     s->glm_fallback = true;
     HIPX(hipStreamSynchronize(s->st));
     HIPX(hipMemsetAsync(&s->ctrl->info, 0, sizeof(int), s->st));
-    s->cache[rs].valid = false;
+    s->cache[rs].valid = s->cache[rs].model_only = false;
     s->dev_state_rs = -1;
     return algorithm_fit(s);
   }
@@ -1592,7 +1600,12 @@ int algorithm_fit(bessx_session *s) {
   }
   s->sse_train = tr;
   s->sse_test = te;
+  if (cov && test_hook("fit_log"))
+    std::fprintf(stderr, "[bessx] fit: level %d, %d iterations, started %s, scores kept %d, ended done=%d d_fresh=%d info=%d, slots queued %d\n", T0,
+                 hc->l, ahead_hit ? "chained on the device" : (use_cache && s->dev_state_rs == rs ? "by k_fit_continue" : (model_kept ? "by k_fit_continue, scores formed again" : "from the host's copy")),
+                 scores_ok ? 1 : 0, hc->done, hc->d_fresh, hc->info, slot - 1);
   cc.valid = hc->done && hc->d_fresh;
+  cc.model_only = cov && hc->done && !hc->d_fresh && !hc->info && !hc->cov_miss;
   cc.cov_layout = cov;
   cc.lambda = lambda;
   cc.T0 = T0;

@@ -156,6 +156,8 @@ struct bessx_session {
   int *idcols = nullptr;
   struct RsCache {
     bool valid = false;  // part_rs / r_rs belong to exactly (beta, coef0) below
+    bool model_only = false;  // (covariance form) the device holds (beta, coef0) below, but the score sums are those of
+                              // the coefficients BEFORE the last solve: a fit that ended on a cycle of active sets
     bool cov_layout = false;  // part_rs holds d itself (covariance mode), not row-block partial sums
     double lambda = 0.0;      // covariance mode: the scores in bd were formed with this lambda
     int T0 = 0;               // ... by a fit of this sparsity level

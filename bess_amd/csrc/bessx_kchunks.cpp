@@ -239,7 +239,7 @@ struct ChunkRun {  // one chunk's candidates, as sequential_path stores them
 int context_begin(bessx_session *c, bool keep_model = false) {
   if (int rc = settle_device_chain(c)) return rc;
   if (!keep_model) {
-    for (auto &q : c->cache) q.valid = false;
+    for (auto &q : c->cache) q.valid = q.model_only = false;
     c->dev_state_rs = -1;
   }
   c->trace.clear();
@@ -645,7 +645,7 @@ int mc_run_chunks(bessx_session *s, KChains *k, const int *seq, int ns, int C, c
       }
       q.last_coef0 = last_c0;
     }
-    for (auto &cc : c->cache) cc.valid = false;  // (the device state of the context is the engine's, not a fit's of its own)
+    for (auto &cc : c->cache) cc.valid = cc.model_only = false;  // (the device state of the context is the engine's, not a fit's of its own)
     c->dev_state_rs = -1;
   }
   s->kch_merged++;
@@ -1123,7 +1123,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     tail.chain.last_cap = width;
     kchains_quiesce(s);
     if (int rc = settle_device_chain(s)) return rc;
-    for (auto &q : s->cache) q.valid = false;
+    for (auto &q : s->cache) q.valid = q.model_only = false;
     s->dev_state_rs = -1;
     const long long fits_before = s->n_fits;
     if (int rc = sequential_path(s, seq + bounds[f], ns - bounds[f], &lambda, 1, ic_type, 0, &tail.res, &tail.chain)) return rc;
@@ -1216,7 +1216,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   s->kch_last_chains = C;
   s->kch_refits += refits;
   // the session's own device state is the coarse chain's last fit, not the path's last candidate
-  for (auto &q : s->cache) q.valid = false;
+  for (auto &q : s->cache) q.valid = q.model_only = false;
   s->dev_state_rs = -1;
   if (link) {  // the model the link's successor starts from
     const ChunkRun &q = run[R - 1];

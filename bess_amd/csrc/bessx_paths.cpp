@@ -832,7 +832,7 @@ int prefill_begin(bessx_session *s, const int *cols, int ncols, int append) {
     HIPX(hipStreamSynchronize(s->st));
     base = meta_h[0];
     if (append == 1) {
-      for (auto &c : s->cache) c.valid = false;  // (a fit that follows starts from uploaded coefficients)
+      for (auto &c : s->cache) c.valid = c.model_only = false;  // (a fit that follows starts from uploaded coefficients)
       s->dev_state_rs = -1;
     }
   } else if (int rc = reset_path_caches(s)) {

@@ -332,11 +332,11 @@ int reset_path_caches(bessx_session *s) {
   }
   s->pend_on = false;  // a deferred publication of a fit nobody will ask for
   s->hint.on = false;
-  for (auto &c : s->cache) c.valid = false;
+  for (auto &c : s->cache) c.valid = c.model_only = false;
   s->dev_state_rs = -1;
   for (bessx_session *c : s->fold_ctx) {
     HIPX(hipStreamSynchronize(c->st));
-    for (auto &cc : c->cache) cc.valid = false;
+    for (auto &cc : c->cache) cc.valid = cc.model_only = false;
     c->dev_state_rs = -1;
   }
   for (auto &g : s->gcache) HIPX(hipMemsetAsync(g.meta, 0, 2 * sizeof(int), s->st));
