@@ -261,7 +261,7 @@ hipError_t launch_chol_big(double *Gt, int m, int mt, double ridge, int ridge_sk
                            const FitCtrl *ctrl, int slot, int gate_mode, hipStream_t st);
 hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
-                            hipStream_t st, unsigned char *inA = nullptr);
+                            hipStream_t st, unsigned char *inA = nullptr, int serial = 0);
 hipError_t launch_fit_continue(FitCtrl *ctrl, int T0, int *hist, hipStream_t st, int serial = 0, int chained = 0,
                                int parent = 0);
 hipError_t launch_commit(FitCtrl *ctrl, int slot, int T0, const int *A_new, const double *sol, int has_intercept,

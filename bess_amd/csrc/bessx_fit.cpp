@@ -1413,7 +1413,7 @@ int algorithm_fit(bessx_session *s) {
       HIPX(hipMemcpyAsync(s->init_val_d, st_val, k_init * sizeof(double), hipMemcpyHostToDevice, s->st));
     }
     e = launch_fit_begin(s->ctrl, T0, k_init, s->init_idx_d, s->init_val_d, s->coef0_init, s->A_cur, s->b_cur,
-                         s->beta_dense, s->p, s->hist, s->st, s->inA);
+                         s->beta_dense, s->p, s->hist, s->st, s->inA, my_serial);
   }
   s->dev_state_rs = rs;
   if (e == hipSuccess && !use_cache && !cov) {

@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
                                                    const double *__restrict__ init_val, double coef0_init,
                                                    int *__restrict__ A_cur, double *__restrict__ b_cur,
                                                    double *__restrict__ beta_dense, int *__restrict__ hist,
-                                                   unsigned char *__restrict__ inA) {
+                                                   unsigned char *__restrict__ inA, int serial) {
   KT(13);
   // beta_dense (and inA) were zeroed by memset nodes just before this launch
   for (int i = threadIdx.x; i < k_init; i += 256) {
@@ -795,6 +795,9 @@ __global__ void __launch_bounds__(256) k_fit_begin(FitCtrl *__restrict__ ctrl, i
     ctrl->cov_nmiss = 0;
     ctrl->sse_valid = 0;
     ctrl->fast_same = 0;
+    // (the fit chained behind this one recognises its parent by this number, like behind a fit opened by
+    // k_fit_continue: without it the first fit of a chain was never followed on the device)
+    if (serial > 0) ctrl->serial = serial;
   }
 }
 
@@ -1203,12 +1206,12 @@ hipError_t launch_gram_lm_cached(const double *X, const double *aux, long ld, in
 
 hipError_t launch_fit_begin(FitCtrl *ctrl, int T0, int k_init, const int *init_idx, const double *init_val,
                             double coef0_init, int *A_cur, double *b_cur, double *beta_dense, int p, int *hist,
-                            hipStream_t st, unsigned char *inA) {
+                            hipStream_t st, unsigned char *inA, int serial) {
   hipError_t e = hipMemsetAsync(beta_dense, 0, (size_t)p * sizeof(double), st);
   if (e == hipSuccess && inA != nullptr) e = hipMemsetAsync(inA, 0, (size_t)p, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fit_begin, dim3(1), dim3(256), 0, st, ctrl, T0, k_init, init_idx, init_val, coef0_init, A_cur,
-                     b_cur, beta_dense, hist, inA);
+                     b_cur, beta_dense, hist, inA, serial);
   LAUNCH_CHECK();
   return hipSuccess;
 }
