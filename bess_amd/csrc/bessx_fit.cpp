@@ -1600,7 +1600,7 @@ int algorithm_fit(bessx_session *s) {
   }
   s->sse_train = tr;
   s->sse_test = te;
-  if (cov && test_hook("fit_log"))
+  if (test_hook("fit_log"))
     std::fprintf(stderr, "[bessx] fit: level %d, %d iterations, started %s, scores kept %d, ended done=%d d_fresh=%d info=%d, slots queued %d\n", T0,
                  hc->l, ahead_hit ? "chained on the device" : (use_cache && s->dev_state_rs == rs ? "by k_fit_continue" : (model_kept ? "by k_fit_continue, scores formed again" : "from the host's copy")),
                  scores_ok ? 1 : 0, hc->done, hc->d_fresh, hc->info, slot - 1);
