@@ -374,7 +374,7 @@ hipError_t launch_cov_need(const int *list, int len, const double *bd, double *b
 // spec: the lookup formed the masked score copy bd2 and `extras` holds its best columns (0: only the missing columns)
 hipError_t launch_cov_publish_slots(const int *fcols, const int *slot_w, int *slot_of, const FitCtrl *ctrl, hipStream_t st);
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec);
+                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec, int spec_min = 0);
 hipError_t launch_cov_resume(FitCtrl *ctrl, hipStream_t st);
 // the row sets of a cross-validation that share their fills (one launch reduces / compacts for all of them)
 struct CovRowSets {

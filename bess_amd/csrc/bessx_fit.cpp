@@ -437,10 +437,10 @@ int cov_unpark(bessx_session *s, const FitCtrl *hc, int T0, double lambda, int r
   if (spec) e = launch_topk(s->bd2, s->p, pool, s->cov_extras, s->cand, nullptr, 0, s->st);
   if (e == hipSuccess)
     e = launch_cov_fill_list(s->cov_fcols, s->cov_extras, s->bd2, smap, cv.meta, s->ctrl, 1, s->st, s->cov_spec,
-                             spec ? (wide ? 2 : 1) : 0);
+                             spec ? (wide ? 2 : 1) : 0, s->cov_spec_min);
   if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("cov_unpark: ") + hipGetErrorString(e));
   // upper bound of the list length (the device drops speculative columns that turn out to be cached already)
-  const int room = spec ? std::min(((nm + s->cov_spec / 2 + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, pool) : 0;
+  const int room = spec ? std::min(((nm + s->cov_spec_min + s->cov_spec - 1) / s->cov_spec) * s->cov_spec - nm, pool) : 0;
   const int ngroups = (nm + room + COV_R - 1) / COV_R;
   if (test_hook("panel_log")) std::fprintf(stderr, "[bessx] fill: level %d, %d missing, list of up to %d -> %d group(s)%s\n", T0, nm, nm + room, ngroups, s->kch_owner ? " (chunk chain)" : "");
   // staged fills run on the owner's fill stream where there is one (it leaves some compute units to the other chains'

@@ -208,6 +208,7 @@ struct bessx_session {
   int cov_cs = 512;        // slots covered by the slot-indexed Gram GS (BESSX_COV_CS <= 512: test hook for the mixed gather)
   double cg_tol = 1e-13;   // accepted relative residual of the conjugate-gradient solve (BESSX_CG_TOL)
   int cov_spec = 32;       // most speculative columns per fill: 64 with the pair panel kernel (variant 4), else 32
+  int cov_spec_min = 8;    // a private fill's list is rounded up to the multiple of 32 that leaves room for this many (test hook cov_spec_min)
   bool fuse_sel = true;    // selection + solve of a slot in one launch, k_sel_cgr (test hook fuse_sel=0: two launches)
   bool cg_by_rows = true;  // row-dealt kernel k_cgr for systems of up to 208 unknowns (test hook cg_layout=tiles: k_cg)
   // GLM IRLS step in three launches instead of five: linear predictor, weights, working response and the slab Gram

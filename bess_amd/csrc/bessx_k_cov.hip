@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_cov_need(const int *__restrict__ list, 
 __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, const int *__restrict__ extras,
                                                        const double *__restrict__ bd2, int *__restrict__ slot_of,
                                                        int *__restrict__ meta, FitCtrl *__restrict__ ctrl,
-                                                       int parked, int spec_max, int spec) {
+                                                       int parked, int spec_max, int spec, int spec_min) {
   KT(10);
   if (parked ? !ctrl->cov_stall : (ctrl->done || ctrl->l != 0)) return;
   const int nm = ctrl->cov_nmiss;  // left by the lookup of this fit (k_cov_need / cov_need_body)
@@ -79,13 +79,15 @@ __global__ void __launch_bounds__(256) k_cov_fill_list(int *__restrict__ fcols, 
   }
   const int count = meta[0];
   // spec: the lookup left a masked copy of the scores (bd2) and the host ran the selection of `extras` on it.
-  // spec_max = 32: the list is rounded up to the next multiple of 32 that leaves room for >= 16 speculative columns;
-  // spec_max = 64 (pair panel kernel: two groups per pass over X): to the next multiple of 64 with room for >= 32
+  // spec_max = 32: the list is rounded up to the next multiple of 32 that leaves room for >= spec_min speculative columns
+  // (round 5: 8, before 16 -- the second group of a two-group launch costs 0.46 ms where a launch of its own costs 0.78,
+  // so 50 missing columns are better served by 64 now and 64 at the next miss than by 96 + 32 + 32: DESIGN.md 3a);
+  // spec_max = 64 (pair panel kernel: two groups per pass over X): to the next multiple of 64
   // spec = 2 (round 5; caches that are never started over): the host selected 64 extras, so that the list is FULL up to
   // its multiple of 32 whatever nm is (with 32 extras a list of 50 missing columns was rounded to 96 with 14 empty
   // places -- columns of a pass over X that computed nothing)
   const int pool = spec == 2 ? 2 * COV_R : spec_max;
-  const int room = spec ? min(((nm + spec_max / 2 + spec_max - 1) / spec_max) * spec_max - nm, pool) : 0;
+  const int room = spec ? min(((nm + spec_min + spec_max - 1) / spec_max) * spec_max - nm, pool) : 0;
   __shared__ int s_ne;
   if (tid < 64) {
     const int col = (spec && tid < pool) ? extras[tid] : -1;
@@ -942,9 +944,10 @@ hipError_t launch_cov_publish_slots(const int *fcols, const int *slot_w, int *sl
 }
 
 hipError_t launch_cov_fill_list(int *fcols, const int *extras, const double *bd2, int *slot_of, int *meta,
-                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec) {
+                                FitCtrl *ctrl, int parked, hipStream_t st, int spec_max, int spec, int spec_min) {
+  if (spec_min <= 0) spec_min = spec_max / 2;
   hipLaunchKernelGGL(k_cov_fill_list, dim3(1), dim3(256), 0, st, fcols, extras, bd2, slot_of, meta, ctrl, parked,
-                     spec_max, spec);
+                     spec_max, spec, spec_min);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -1181,6 +1181,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
       // (fills of exactly two groups take the pair panel kernel, one pass for 64 columns; the switches that made every
       // fill speculate 64 columns, or never paired, measured at parity in rounds 2-3 and are gone)
       s->cov_spec = COV_R;
+      if (const char *ev = test_hook("cov_spec_min")) s->cov_spec_min = std::max(1, std::min(COV_R - 1, std::atoi(ev)));  // (16: rounds 2-4)
       // capacity: EVERY column when that fits 2 GiB per row set (p <= ~16000: a path then forms a column at most once and
       // the cache is never started over -- at 2560 columns the reference's default sequence 1..min(p, n / log n) at
       // n = 25000, p = 3000 restarted it 1237 times and streamed X 73 000 times, round 4); else 2560 columns within 2 GiB
