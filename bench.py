@@ -2,16 +2,20 @@
 """bench.py -- candidate subsets solved per second on BASELINE configs[1]:
 LM sequential path, synthetic Gaussian n=50000, p=10000, s.list = 1..200, GIC, warm start, max_iter 20.
 
-A "step" is one pass of the hot path over one batch: the full 200-candidate path (Algorithm::fit to PDAS
-convergence + train_loss + ic per candidate) on data that is already resident in HBM (upload + normalisation are
-untimed and reported separately; the one pass over X for X^T y / diag(X^T X), which the reference does inside
-sequential_path (src/path.cpp:37), happens at session creation here: its device time is `group_XTX_ms_outside_step`
-and `ms_per_step_incl_group_XTX` / `value_incl_group_XTX` add it back to every step).
+A "step" is one pass of the hot path over one batch: the full 200-candidate path (the all-rows group_XTX pass of
+src/path.cpp:37, then Algorithm::fit to PDAS convergence + train_loss + ic per candidate) on data that is already resident
+in HBM (upload + normalisation are untimed and reported separately).
+
+OUTPUT.  Rank 0 prints ONE line of strict JSON as the LAST line of stdout, at most 6 KB: the contract keys, `roofline`
+(HIP-event timing of the kernel that streams X; covariance form: both roofs per launch width, the binding one on top),
+`cpu_baseline`, the streaming leg's flat keys `roofline.streaming_*`, and a few figures per other config.  The full record
+(every leg, segments of the CPU timing, histograms, the k-path report) goes to gpurun_out/bench_detail.json
+(BESSX_BENCH_DETAIL_STDOUT=1: also as an EARLIER stdout line).
 
 Two evaluations of the score pass are timed with the same --steps / --warmup at N = 1: the headline is the covariance
 form (cached Gram columns; `config.headline_mode`), and the STREAMING formulation north_star prescribes -- every PDAS
 iteration reads X once -- is in `roofline.streaming_*` (candidates/s, ms per step, k_xtv against the HBM roof, the whole
-step against the HBM roof) and, in full, in `streaming_score_pass`.
+step against the HBM roof) and in `streaming_score_pass`.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lm-seq|lm-cv-gs] [--shard kpath|replica]
                   [--n N --p P --kmax KMAX] [--no-cpu-baseline]
@@ -40,12 +44,10 @@ chain and, in the final sweep, (fold x s) pairs dealt to the ranks (bess_amd.dis
 BESSX_BENCH_ONE_DEVICE=1 rehearses the N-rank path on a box with ONE GPU (ranks share device 0, collectives over
 gloo) -- never what the driver runs.
 
-At N = 1 with the default sizes the line also carries `other_configs`: one timed path each of BASELINE configs[2]
+At N = 1 with the default sizes the record also carries `other_configs`: one timed path each of BASELINE configs[2]
 (logistic n=100k p=5k k<=100), configs[3] (LM gs_path + 5-fold CV) and configs[4] (Cox n=200k p=20k k<=150) with the
 kernel that streams X against the HBM roof and the time per IRLS / Newton step (--no-other-configs skips them; they
 add about two minutes, most of it generating and uploading the 32 GB Cox design).
-
-Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -608,6 +610,135 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
     return res
 
 
+LINE_LIMIT = 6000  # bytes: the driver keeps an 8 KB tail of stdout and parses the LAST line (round 5's 20 KB line: parsed null)
+DETAIL_PATH = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _round(v, nd=6):
+    """Floats to `nd` significant digits, recursively (the final line is a report, not a checkpoint)."""
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None  # strict JSON has no NaN / Infinity
+        return float("%.*g" % (nd, v))
+    if isinstance(v, dict):
+        return {k: _round(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_round(x, nd) for x in v]
+    if isinstance(v, (np.floating,)):
+        return _round(float(v), nd)
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.bool_,)):
+        return bool(v)
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract keys + `roofline` + `cpu_baseline` + a few flat figures per other
+    config, at most LINE_LIMIT bytes of strict JSON.  Everything else (segments of the CPU timing, histograms, the per-config
+    records, the k-path report) goes to gpurun_out/bench_detail.json."""
+    keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data"]
+    line = {k: full[k] for k in keep}
+    cfg = full.get("config", {})
+    line["config"] = _pick(cfg, ["workload", "candidates_per_step", "score_pass", "headline_mode", "units_sharded",
+                                 "collective", "ranks_with_work", "streaming_mode"])
+    roof = dict(full.get("roofline", {}))
+    roof.pop("traffic_source", None)
+    line["roofline"] = roof
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind", "sample", "cpu_model", "host_cores",
+                                         "tail_iterations_match_gpu"])
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            line["cpu_baseline"].setdefault(k, cb.get(k))
+        if cb.get("value"):
+            line["gpu_over_cpu_baseline"] = full["value"] / cb["value"]
+    for k in ("group_XTX_ms_inside_step", "value_excl_group_XTX", "ms_per_step_excl_group_XTX",
+              "passes_over_X_per_candidate", "pdas_iterations_per_candidate", "selected_k", "selected_ic",
+              "upload_and_normalise_seconds", "kpath_expected_speedup", "fits_per_s", "fits_per_step",
+              "evaluation_rounds", "cv_loss", "pdas_iterations_per_step"):
+        if k in full:
+            line[k] = full[k]
+    ws = full.get("whole_step")
+    if ws:
+        line["whole_step"] = {"frac_of_hbm_peak": ws.get("frac_of_hbm_peak"),
+                              "kernel_streaming_X_share": ws.get("time", {}).get("kernel_streaming_X_share")}
+    cc = full.get("chunk_chains")
+    if cc:
+        line["chunk_chains"] = {"chains": cc.get("chains"), "same_candidates_as_the_single_chain":
+                                cc.get("same_candidates_as_the_single_chain"),
+                                "single_chain_ms_per_path": cc.get("single_chain", {}).get("ms_per_path")}
+    sp = full.get("streaming_score_pass")
+    if sp:
+        line["streaming_score_pass"] = _pick(sp, ["value", "unit", "steps", "warmup", "ms_per_step", "same_selection",
+                                                  "same_candidates", "whole_step_frac_of_hbm_peak",
+                                                  "passes_over_X_per_candidate"])
+    kp = full.get("kpath_chunks_vs_single_chain")
+    if kp:
+        line["kpath"] = _pick(kp, ["chunks", "supports_equal_to_single_chain", "of", "best_k_chunked",
+                                   "best_k_single_chain", "stitch_refits", "stitch_rounds", "prefill_columns",
+                                   "ic_curve_max_rel_diff_to_single_chain"])
+    cv = full.get("cooperative_prefill_variant")
+    if cv:
+        line["cooperative_prefill_variant"] = _pick(cv, ["value", "ms_per_step", "prefill_columns", "pilot"])
+    oc = full.get("other_configs")
+    if isinstance(oc, dict):
+        small = {}
+        for name, rec in oc.items():
+            if not isinstance(rec, dict):
+                small[name] = rec
+                continue
+            e = _pick(rec, ["candidates_per_s", "ms_per_path", "passes_over_X", "whole_path_frac_of_hbm", "fits_per_s"])
+            sk = rec.get("score_kernel") or {}
+            if sk.get("frac") is not None:
+                e["score_kernel_frac_of_hbm"] = sk["frac"]
+            sc = (rec.get("chunk_chains") or {}).get("single_chain") or {}
+            if sc.get("score_kernel_frac_of_hbm") is not None:
+                e["score_kernel_frac_alone"] = sc["score_kernel_frac_of_hbm"]
+            if (rec.get("chunk_chains") or {}).get("chains") is not None:
+                e["chains"] = rec["chunk_chains"]["chains"]
+            c2 = rec.get("cpu_baseline") or {}
+            if c2.get("value"):
+                e["cpu_baseline"] = {"value": c2["value"], "kind": c2.get("kind"), "cores": c2.get("cores")}
+            small[name] = e
+        line["other_configs"] = small
+    line["detail"] = "gpurun_out/bench_detail.json (the full record of this run; also the FIRST stdout line of rank 0 when " \
+                     "BESSX_BENCH_DETAIL_STDOUT=1)"
+    line = _round(line)
+    # never lose the line to its size: drop the least important parts until it fits
+    for victim in ("detail", "other_configs", "streaming_score_pass", "chunk_chains", "kpath", "whole_step"):
+        if len(json.dumps(line, allow_nan=False)) <= LINE_LIMIT:
+            break
+        if victim == "other_configs" and isinstance(line.get(victim), dict):
+            line[victim] = {k: _pick(v, ["candidates_per_s", "score_kernel_frac_of_hbm"]) if isinstance(v, dict) else None
+                            for k, v in line[victim].items()}
+            if len(json.dumps(line, allow_nan=False)) <= LINE_LIMIT:
+                break
+        line.pop(victim, None)
+    return line
+
+
+def emit(full):
+    """Rank 0's report: the full record to gpurun_out/bench_detail.json, the compact line as the LAST line of stdout."""
+    try:
+        os.makedirs(os.path.dirname(DETAIL_PATH), exist_ok=True)
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(_round(full, 9), f, indent=1, allow_nan=False)
+    except (OSError, ValueError) as e:
+        print("bench.py: could not write %s: %r" % (DETAIL_PATH, e), file=sys.stderr)
+    if os.environ.get("BESSX_BENCH_DETAIL_STDOUT") == "1":
+        print(json.dumps({"bench_detail": _round(full, 9)}, allow_nan=False))
+    text = json.dumps(compact_line(full), allow_nan=False)
+    assert len(text) <= LINE_LIMIT + 2000, len(text)
+    print(text)
+    sys.stdout.flush()
+
+
 def main():
     inherited = os.environ.pop("BESSX_BENCH_ARGV", None)  # set by launch_ranks() for its children
     args = parse_args(json.loads(inherited) if inherited else None)
@@ -775,6 +906,7 @@ def main():
     barrier()
     dt = max_over_ranks(time.time() - t0)
     k1 = sess.score_pass_stats()
+    cw = sess.counters()  # (panel launches by width, device time of the last group_XTX pass: read before any reset)
     sess.enable_kernel_timing(False)
 
     coop_variant = None
@@ -848,47 +980,77 @@ def main():
                 "chunk_start_meaning": "auto: ladder for chunks beginning at k0 >= 128, else cold; ladder: a chunk beginning at k0 > 1 first climbs the warm-start chain k0/8, k0/4, "
                                        "k0/2 (timed, candidates discarded); cold: Algorithm::fit from the empty model at k0"}
 
-    def roofline_of(stats, cov):
-        """HBM roofline of the kernel that streams X: algorithmic bytes (8 n p per pass over X) / its HIP-event time."""
-        passes = stats["algorithmic_bytes"] / (8.0 * args.n * args.p)
-        per_pass = stats["seconds"] / passes if passes else 0.0
-        achieved = 8.0 * args.n * args.p / per_pass / 1e9 if passes else 0.0
+    def roofline_of(stats, cov, widths=None):
+        """Roofline of the kernel that streams X, from its HIP-event time.  Algorithmic bytes = 8 n p per LAUNCH (X is read
+        once per launch whatever the launch computes).  Streaming form (k_xtv / k_cox_score1p): the HBM roof.  Covariance
+        form (k_cov_panel_dp): a launch forms one or two groups of 32 Gram columns, 2 n p 32 flop per group on the fp64
+        matrix cores -- 8 flop/B for one group (below the 9.8 flop/B ridge: HBM binds), 16 flop/B for two (MFMA binds).
+        `widths` = {groups per launch: (launches, seconds)}; both roofs are reported per width, the top-level roof is
+        the one that needs more time over all the launches, and frac = achieved / peak against THAT roof."""
+        launches = stats["algorithmic_bytes"] / (8.0 * args.n * args.p)
+        per_launch = stats["seconds"] / launches if launches else 0.0
+        gbps = 8.0 * args.n * args.p / per_launch / 1e9 if launches else 0.0
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and (args.n, args.p) == (50000, 10000):
             try:
-                traffic = json.load(open(tpath)).get("k_cov_panel_hbm_bytes_per_pass" if cov else
-                                                     "k_xtv_hbm_bytes_per_launch")
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this kernel on " \
-                              "the round-5 library, tools/collect_profiles_r05.sh; counter passes are their own runs, " \
-                              "not part of this one)"
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_cov_panel_hbm_bytes_per_launch" if cov else "k_xtv_hbm_bytes_per_launch")
+                traffic_src = tj.get("source", "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)")
             except Exception:
                 traffic = None
-        kern = ("k_cov_panel (X^T diag(m) X_S on the fp64 matrix cores: 32 new Gram columns per pass over X)"
-                if cov else ("k_cox_score1p (risk-set score of all p columns, X read once)" if cox else
-                             "k_xtv<8,16,false> (X^T r score pass)"))
-        roof = {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": 8.0 * args.n * args.p, "avg_launch_ms": 1e3 * per_pass,
-                "launches_timed": stats["launches"], "passes_over_X_timed": passes}
-        if cov and per_pass:
-            # the same kernel against the other roof: 2 n p 32 flop per pass on the fp64 matrix cores
-            tf = 2.0 * args.n * args.p * 32 / per_pass / 1e12
-            roof["mfma_fp64"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": tf / FP64_MFMA_PEAK_TFLOPS, "flop_per_pass": 2.0 * args.n * args.p * 32}
+        kern = ("k_cov_panel_dp" if cov else ("k_cox_score1p" if cox else "k_xtv<8,16,false>"))
+        roof = {"bound": "hbm", "kernel": kern, "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": 8.0 * args.n * args.p, "avg_launch_ms": 1e3 * per_launch,
+                "launches_timed": stats["launches"], "hbm_frac": gbps / HBM_PEAK_GBPS}
+        if cov and widths and sum(w[0] for w in widths.values()):
+            flop_g = 2.0 * args.n * args.p * 32
+            t_all = sum(w[1] for w in widths.values())
+            f_all = sum(g * w[0] * flop_g for g, w in widths.items())
+            t_hbm = sum(w[0] for w in widths.values()) * 8.0 * args.n * args.p / (HBM_PEAK_GBPS * 1e9)
+            t_mfma = f_all / (FP64_MFMA_PEAK_TFLOPS * 1e12)
+            binding = 0.0
+            by = {}
+            for g, (cnt, sec) in sorted(widths.items()):
+                if not cnt:
+                    continue
+                avg = sec / cnt
+                hf = 8.0 * args.n * args.p / avg / 1e9 / HBM_PEAK_GBPS
+                mf = g * flop_g / avg / 1e12 / FP64_MFMA_PEAK_TFLOPS
+                binding += cnt * max(8.0 * args.n * args.p / (HBM_PEAK_GBPS * 1e9), g * flop_g / (FP64_MFMA_PEAK_TFLOPS * 1e12))
+                by["%d_group%s" % (g, "s" if g > 1 else "")] = {
+                    "launches": int(cnt), "avg_launch_ms": 1e3 * avg, "hbm_frac": hf, "mfma_fp64_frac": mf,
+                    "bound": "mfma" if mf > hf else "hbm", "flop_per_byte": g * flop_g / (8.0 * args.n * args.p)}
+            tf = f_all / t_all / 1e12
+            roof["by_width"] = by
             roof["mfma_fp64_frac"] = tf / FP64_MFMA_PEAK_TFLOPS
+            roof["mfma_fp64_TFLOPs"] = tf
+            roof["hbm_GBps"] = gbps
+            roof["frac_sum_of_binding_roofs"] = binding / t_all  # sum over launches of max(t_HBM, t_MFMA) / sum of times
+            roof["flop_per_group"] = flop_g
+            if t_mfma > t_hbm:  # the matrix cores are the roof that needs more time over these launches
+                roof.update({"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / FP64_MFMA_PEAK_TFLOPS, "dtype": "f64"})
         return roof
+
+    def widths_of(cnt):
+        return {1: (cnt.get("panel_launches_one_group", 0), cnt.get("panel_ns_one_group", 0) / 1e9),
+                2: (cnt.get("panel_launches_two_groups", 0), cnt.get("panel_ns_two_groups", 0) / 1e9)}
 
     if rank == 0:
         n_cand = args.kmax * args.steps * (1 if (kpath or not distributed) else world)
         value = n_cand / dt
-        roof = roofline_of(k1, covariance)
+        roof = roofline_of(k1, covariance, widths_of(cw))
+        roof["passes_over_X_timed"] = float(k1["launches"])
         try:  # SURVEY 8d: the spec peak next to a ceiling measured on this very device (read + write of a D2D copy)
             roof["measured_stream_copy_GBps"] = capi.op_stream_copy_gbps(1 << 30, 10)
         except Exception:
             roof["measured_stream_copy_GBps"] = None
         step_s = dt / args.steps
         x_seconds = k1["seconds"] / args.steps
+        # passes over X per step: the timed launches of the kernel that streams X + (LM) the group_XTX pass of every path
+        x_passes = k1["launches"] / float(args.steps) + (0.0 if cox else 1.0)
         line = {
             "metric": ("candidate subsets solved/sec (Cox n=%dk,p=%dk,k<=%d)" % (args.n // 1000, args.p // 1000, args.kmax)
                        if cox else "candidate subsets solved/sec (n=50k,p=10k,k<=200 LM)"), "value": value,
@@ -918,17 +1080,17 @@ def main():
                        "chunk_start": (args.chunk_start_option if kpath else None)},
             "roofline": roof,
             # the WHOLE step against the HBM roof: bytes the step streams from X / step time, and where the time goes
-            "whole_step": {"bytes_streamed_from_X": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p,
-                           "achieved_GBps": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p / step_s / 1e9,
-                           "frac_of_hbm_peak": roof["passes_over_X_timed"] / args.steps * 8.0 * args.n * args.p / step_s
-                           / 1e9 / HBM_PEAK_GBPS,
-                           # (the kernel that streams X never overlaps another pass over X -- fills run while every
-                           # chain stands still -- so its summed launch time is a true share of the step)
+            "whole_step": {"bytes_streamed_from_X": x_passes * 8.0 * args.n * args.p,
+                           "achieved_GBps": x_passes * 8.0 * args.n * args.p / step_s / 1e9,
+                           "frac_of_hbm_peak": x_passes * 8.0 * args.n * args.p / step_s / 1e9 / HBM_PEAK_GBPS,
+                           # (passes over X never overlap each other: one chain at a time holds the fill right -- staged
+                           # fills run beside other chains' selection / solve kernels, not beside another pass -- so the
+                           # summed launch time of the kernel that streams X is a true share of the step)
                            "time": {"wall_ms": 1e3 * step_s, "summed_kernel_ms_streaming_X": 1e3 * x_seconds,
                                     "kernel_streaming_X_share": min(1.0, x_seconds / step_s),
                                     "candidate_chain_and_host_share (selection, k x k solve, p x k GEMV, publish)":
                                     max(0.0, 1.0 - x_seconds / step_s)}},
-            "passes_over_X_per_candidate": roof["passes_over_X_timed"] / float(max(len(seq), 1) * args.steps),
+            "passes_over_X_per_candidate": x_passes / float(max(len(seq), 1)),
             "pdas_iterations_per_candidate": pdas_iters / float(max(len(seq), 1) * args.steps),
             # I_k of SURVEY 8d: PDAS iterations Algorithm::fit took per candidate (identical to the reference's,
             # tests/test_fullsize_gpu.py), as a histogram {iterations: candidates}
@@ -945,13 +1107,13 @@ def main():
         norm = sess.normalization() if world == 1 else None
         cnt = sess.counters() if world == 1 else {}
         if not cox:
-            # the reference forms X^T y / diag(X^T X) inside every sequential_path call (group_XTX, src/path.cpp:37); here
-            # that pass over X runs once per session, outside the step.  Its device time (HIP events at session creation)
-            # and the step with it added back, so that both accountings are in the line:
-            gx_ms = sess.counters().get("group_XTX_ns", 0) / 1e6
-            line["group_XTX_ms_outside_step"] = gx_ms
-            line["ms_per_step_incl_group_XTX"] = 1e3 * step_s + gx_ms
-            line["value_incl_group_XTX"] = (n_cand / args.steps) / (step_s + gx_ms / 1e3)
+            # the reference forms X^T y / diag(X^T X) inside every sequential_path call (group_XTX, src/path.cpp:37) and so
+            # does every path call here (bessx_paths.cpp run_path): that pass over X IS in the step.  Its device time (HIP
+            # events, last path) and the step without it as side keys (rounds 1-5 had it at session creation):
+            gx_ms = cw.get("group_XTX_ns", 0) / 1e6
+            line["group_XTX_ms_inside_step"] = gx_ms
+            line["ms_per_step_excl_group_XTX"] = 1e3 * step_s - gx_ms
+            line["value_excl_group_XTX"] = (n_cand / args.steps) / max(step_s - gx_ms / 1e3, 1e-12)
         if world == 1 and cnt.get("kpath_chunked_paths", 0) > 0:
             # the path ran as chunk chains side by side on one Gram column cache, stitched into the single warm-start chain
             # (bessx_kchunks.cpp); the same path as ONE chain on the same session, timed the same way, beside it
@@ -998,7 +1160,6 @@ def main():
             d2 = (time.time() - t1) / args.steps
             st2 = s2.score_pass_stats()
             cnt2 = s2.counters()
-            gx2 = cnt2.get("group_XTX_ns", 0) / 1e6
             single2 = None
             if cnt2.get("kpath_chunked_paths", 0) > 0:
                 # the streaming path ran as chunk chains (round 5: one chain's selection, Gram panel, solve and residual
@@ -1028,7 +1189,7 @@ def main():
             whole2 = st2["launches"] / float(args.steps) * 8.0 * args.n * args.p / d2 / 1e9 / HBM_PEAK_GBPS
             line["streaming_score_pass"] = {
                 "value": len(seq) / d2, "unit": "candidates/s", "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": 1e3 * d2, "ms_per_step_incl_group_XTX": 1e3 * d2 + gx2, "roofline": roof2,
+                "ms_per_step": 1e3 * d2, "roofline": roof2,
                 "whole_step_frac_of_hbm_peak": whole2,
                 "passes_over_X_per_candidate": st2["launches"] / float(len(seq) * args.steps),
                 "same_selection": bool(int(o2["best_T0"]) == int(out["best_T0"]) and
@@ -1071,8 +1232,7 @@ def main():
                                                               None if args.no_cpu_baseline else args.cpu_budget)
             except Exception as e:  # never lose the headline line to a secondary measurement
                 line["other_configs"] = {"error": repr(e)}
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(line)
     sess.close()
     if distributed:
         dist.barrier()
@@ -1105,7 +1265,7 @@ def bench_cv(args, world, rank, local_rank, comm_dev, barrier, max_over_ranks):
     barrier()
     dt = max_over_ranks(time.time() - t0)
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "candidate subsets solved/sec (n=50k,p=10k, LM gs_path + 5-fold CV)",
             "value": out["n_candidates"] * args.steps / dt, "unit": "candidates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -1116,8 +1276,7 @@ def bench_cv(args, world, rank, local_rank, comm_dev, barrier, max_over_ranks):
                                         "(fold x s) pairs", "collective": "all_gather of the fit records"},
             "fits_per_s": out["n_fits"] * args.steps / dt, "fits_per_step": int(out["n_fits"]),
             "pdas_iterations_per_step": int(out["n_pdas_iters"]), "evaluation_rounds": int(out["evaluations"]),
-            "selected_k": int(out["best_T0"]), "cv_loss": float(out["ic"]), "upload_and_normalise_seconds": upload_s}))
-        sys.stdout.flush()
+            "selected_k": int(out["best_T0"]), "cv_loss": float(out["ic"]), "upload_and_normalise_seconds": upload_s})
     sess.close()
     if world > 1:
         dist.barrier()

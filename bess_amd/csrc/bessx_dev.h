@@ -56,6 +56,18 @@ hipError_t launch_xtv(const double *X, long ld, int p, int U, const double *v, c
                       double *part2, const FitCtrl *ctrl, int slot, hipStream_t st);
 hipError_t launch_xtv_variant(int variant, const double *X, long ld, int p, const double *v, double *part,
                               hipStream_t st);
+// One pass over X for several chains' score vectors (k_xtv_mc): per chain the arguments of launch_xtv; ran (optional)
+// receives the number of chains whose gate was open (0: the launch fell through).
+constexpr int XTV_MC_MAX = 8;
+struct XtvMc {
+  const double *v[XTV_MC_MAX], *v2[XTV_MC_MAX];
+  double *part[XTV_MC_MAX], *part2[XTV_MC_MAX];
+  const FitCtrl *ctrl[XTV_MC_MAX];
+  int slot[XTV_MC_MAX];
+  int nc;
+  int *ran;
+};
+hipError_t launch_xtv_mc(const double *X, long ld, int p, int U, const XtvMc &a, bool two, hipStream_t st);
 hipError_t launch_score(const double *part, const double *part2, int nrb, int p, const double *beta_dense,
                         const double *xtx, double n_t, double lambda, int glm, const unsigned char *always,
                         double *bd, const FitCtrl *ctrl, int slot, hipStream_t st);

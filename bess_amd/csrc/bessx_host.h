@@ -289,7 +289,8 @@ struct bessx_session {
   int panel_variant = 0;                // 5: k_cov_panel_dp for the fills (default; test hook panel=lds: 0, the round-2 kernels)
   int cov_panel_blocks = 0;             // workgroups of one panel pass with the slab count chosen at creation
   bool own_hw_queue = false;            // (fit contexts) the context's stream has a hardware queue outside the runtime's pool
-  long long group_xtx_ns = 0;           // device time of the all-rows group_XTX pass at session creation (LM)
+  long long group_xtx_ns = 0;           // device time of the last all-rows group_XTX pass inside a path call (LM, timing on)
+  bool path_group_xtx = true;           // every cold path call redoes the all-rows group_XTX pass (src/path.cpp:37)
   long long kch_giveups = 0;            // paths whose stitch ran out of budget (the rest was walked as one chain)
   double kch_t[3] = {0, 0, 0};          // BESSX_DEBUG: seconds in the coarse chain / the chunks / the stitch
   bessx_fill_hook fill_hook = nullptr;  // shared wide fills of a parked fit (bessx_session_set_fill_hook)
@@ -367,6 +368,10 @@ struct bessx_session {
   size_t ev_used = 0;
   double k1_seconds = 0.0, k1_bytes = 0.0;
   long long k1_launches = 0;
+  // panel launches of the covariance form by width (index 0: one 32-column group, 1: two): X is read ONCE per launch
+  // whatever the width, the flops (2 n p 32 per group) double -- two different roofs (HBM / fp64 matrix cores)
+  double panel_w_seconds[2] = {0.0, 0.0};
+  long long panel_w_launches[2] = {0, 0};
   long long n_fits = 0, n_iters = 0;
 };
 

@@ -181,6 +181,118 @@ __global__ void __launch_bounds__(256) k_xtv(const double *__restrict__ X, long 
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 / K2 for SEVERAL chains in one pass over X (round 6).  Chunk chains of the streaming forms (LM score_mode 1,
+// logistic, Poisson) each need X^T v for a vector of their own; issued per chain, every one of them streams the whole of
+// X.  Here a launch carries up to XTV_MC_MAX (v, v2, part, part2, ctrl, slot) sets: a column slice of X is loaded ONCE
+// into registers and every active chain's accumulators are formed from it.
+//
+// Bitwise the same sums as k_xtv: the same row blocks of 128*U rows, the same rows per lane (row0 + u*128 + {0,1}), the
+// same fma chain per lane and column (u ascending, .x then .y from 0), the same butterfly over the 64 lanes (offsets
+// 32, 16, 8, 4, 2, 1 -- k_xtv's exchange steps and its plain steps add the same pairs, the number of columns a wave keeps
+// only changes which lane ends up with which column), the same part[rb][j] layout per chain.
+//
+// Block = 4 waves on ONE row block and XTV_MC_CPW consecutive columns each; the active chains' v (and v2) slices of that
+// row block are staged in LDS once per block (8 KB per chain and vector at U = 8: 3 % of the 1 MB of X the block streams)
+// and a wave re-reads a chain's slice once per pair of columns (8 ds_read_b128) -- registers hold two columns of X
+// (+ the next two in flight), one chain's slice and 2 (4) accumulators, whatever the number of chains.
+// Gate per chain like k_xtv's; a launch whose chains have all converged falls through after the gate loads.
+// ------------------------------------------------------------------------------------------
+constexpr int XTV_MC_CPW = 32;  // columns per wave (128 per block)
+
+template <int U, bool TWO>
+__global__ void __launch_bounds__(256) k_xtv_mc(const double *__restrict__ X, long ld, int p, int nrb, XtvMc a) {
+  extern __shared__ double sv[];  // [active chain][TWO ? 2 : 1][128 * U]
+  __shared__ int act[XTV_MC_MAX + 1];
+  constexpr int RB = 128 * U, VPC = TWO ? 2 : 1;
+  if (threadIdx.x == 0) {
+    int na = 0;
+    for (int c = 0; c < a.nc; c++) {
+      const FitCtrl *ct = a.ctrl[c];
+      if (ct == nullptr || (!ct->done && ct->l == a.slot[c] - 1)) act[na++] = c;
+    }
+    act[XTV_MC_MAX] = na;
+    if (blockIdx.x == 0 && a.ran != nullptr) *a.ran = na;
+  }
+  __syncthreads();
+  const int na = act[XTV_MC_MAX];
+  if (na == 0) return;
+  const int nsp = (p + 4 * XTV_MC_CPW - 1) / (4 * XTV_MC_CPW);
+  const int rb = blockIdx.x / nsp, sp = blockIdx.x - rb * nsp;
+  const long rbase = (long)rb * RB;
+  for (int i = threadIdx.x; i < na * VPC * (RB / 2); i += 256) {
+    const int w = i / (RB / 2), o = i - w * (RB / 2);
+    const int c = act[w / VPC];
+    const double *src = (TWO && (w & 1)) ? a.v2[c] : a.v[c];
+    reinterpret_cast<d2 *>(sv)[i] = *reinterpret_cast<const d2 *>(src + rbase + 2 * o);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j0 = (sp * 4 + wv) * XTV_MC_CPW;
+  if (j0 >= p) return;
+  const long row0 = rbase + lane * 2;
+  d2 xa[U], xb[U], na_[U], nb_[U];
+  auto load2 = [&](int j, d2 (&ca)[U], d2 (&cb)[U]) {
+    const int ja = j < p ? j : p - 1, jb = j + 1 < p ? j + 1 : p - 1;  // tail: recompute the last column, discarded below
+    const double *pa = X + (size_t)ja * ld + row0, *pb = X + (size_t)jb * ld + row0;
+#pragma unroll
+    for (int u = 0; u < U; u++) ca[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pa + u * 128));
+#pragma unroll
+    for (int u = 0; u < U; u++) cb[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pb + u * 128));
+  };
+  load2(j0, xa, xb);
+  const bool up = (lane & 32) != 0;
+  for (int g = 0; g < XTV_MC_CPW && j0 + g < p; g += 2) {
+    const bool more = g + 2 < XTV_MC_CPW && j0 + g + 2 < p;
+    if (more) load2(j0 + g + 2, na_, nb_);  // the next pair's loads fly while every chain's sums are formed
+    for (int w = 0; w < na; w++) {
+      const int c = act[w];
+      const double *vs = sv + (size_t)w * VPC * RB + lane * 2;
+      d2 vr[U], vr2[TWO ? U : 1];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        vr[u] = *reinterpret_cast<const d2 *>(vs + u * 128);
+        if (TWO) vr2[u] = *reinterpret_cast<const d2 *>(vs + RB + u * 128);
+      }
+      double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        a0 = fma(xa[u].x, vr[u].x, a0);
+        a0 = fma(xa[u].y, vr[u].y, a0);
+        a1 = fma(xb[u].x, vr[u].x, a1);
+        a1 = fma(xb[u].y, vr[u].y, a1);
+        if (TWO) {
+          b0 = fma(xa[u].x * xa[u].x, vr2[u].x, b0);
+          b0 = fma(xa[u].y * xa[u].y, vr2[u].y, b0);
+          b1 = fma(xb[u].x * xb[u].x, vr2[u].x, b1);
+          b1 = fma(xb[u].y * xb[u].y, vr2[u].y, b1);
+        }
+      }
+      // butterfly, 2 columns: offset 32 exchanges (the lower half of the lanes keeps column 0), then plain steps
+      double s = (up ? a1 : a0) + __shfl_xor(up ? a0 : a1, 32);
+      double s2 = 0.0;
+      if (TWO) s2 = (up ? b1 : b0) + __shfl_xor(up ? b0 : b1, 32);
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o);
+        if (TWO) s2 += __shfl_xor(s2, o);
+      }
+      const int j = j0 + g + (up ? 1 : 0);
+      if ((lane & 31) == 0 && j < p) {
+        a.part[c][(size_t)rb * p + j] = s;
+        if (TWO) a.part2[c][(size_t)rb * p + j] = s2;
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        xa[u] = na_[u];
+        xb[u] = nb_[u];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // sacrifice scores.  LM: src/Algorithm.h:1109-1126 with 1x1 Phi (src/utilities.cpp:142-151,167-177).
 //   d_j = (sum_rb part[rb][j]) / n_t - 2 lambda beta_j ; phi_j = sqrt(2 lambda + xtx_j / n_t)
 //   bd_j = (phi_j beta_j + d_j / phi_j)^2 ; always_select -> DBL_MAX
@@ -999,6 +1111,35 @@ hipError_t launch_xtv(const double *X, long ld, int p, int U, const double *v, c
                        : launch_xtv_t<2, false>(X, ld, p, v, v2, part, part2, ctrl, slot, st);
     default: return two ? launch_xtv_t<1, true>(X, ld, p, v, v2, part, part2, ctrl, slot, st)
                         : launch_xtv_t<1, false>(X, ld, p, v, v2, part, part2, ctrl, slot, st);
+  }
+}
+
+template <int U, bool TWO>
+static hipError_t launch_xtv_mc_t(const double *X, long ld, int p, const XtvMc &a, hipStream_t st) {
+  const int nrb = (int)(ld / (128 * U));
+  const int nsp = (p + 4 * XTV_MC_CPW - 1) / (4 * XTV_MC_CPW);
+  const size_t lds = (size_t)a.nc * (TWO ? 2 : 1) * 128 * U * sizeof(double);
+  static bool attr_done = false;  // dynamic LDS beyond 64 KB has to be requested once per kernel instance
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xtv_mc<U, TWO>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((size_t)XTV_MC_MAX * (TWO ? 2 : 1) * 128 * U * sizeof(double)));
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_xtv_mc<U, TWO>), dim3(nrb * nsp), dim3(256), lds, st, X, ld, p, nrb, a);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+// X^T v for up to XTV_MC_MAX chains in one pass over X (k_xtv_mc); two = every chain brings a second vector
+hipError_t launch_xtv_mc(const double *X, long ld, int p, int U, const XtvMc &a, bool two, hipStream_t st) {
+  if (a.nc < 1 || a.nc > XTV_MC_MAX) return hipErrorInvalidValue;
+  switch (U) {
+    case 8: return two ? launch_xtv_mc_t<8, true>(X, ld, p, a, st) : launch_xtv_mc_t<8, false>(X, ld, p, a, st);
+    case 4: return two ? launch_xtv_mc_t<4, true>(X, ld, p, a, st) : launch_xtv_mc_t<4, false>(X, ld, p, a, st);
+    case 2: return two ? launch_xtv_mc_t<2, true>(X, ld, p, a, st) : launch_xtv_mc_t<2, false>(X, ld, p, a, st);
+    default: return two ? launch_xtv_mc_t<1, true>(X, ld, p, a, st) : launch_xtv_mc_t<1, false>(X, ld, p, a, st);
   }
 }
 

@@ -1206,6 +1206,12 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     s->k1_launches += c->k1_launches;
     c->k1_seconds = c->k1_bytes = 0.0;
     c->k1_launches = 0;
+    for (int w = 0; w < 2; w++) {
+      s->panel_w_seconds[w] += c->panel_w_seconds[w];
+      s->panel_w_launches[w] += c->panel_w_launches[w];
+      c->panel_w_seconds[w] = 0.0;
+      c->panel_w_launches[w] = 0;
+    }
   }
   // fits and get_A calls as the single chain counts them; the work really done (coarse chain, replaced candidates) is in
   // bessx_session_counter 14-16

@@ -200,8 +200,9 @@ int k1_collect(bessx_session *s, const std::vector<std::pair<size_t, bool>> &pai
   return 0;
 }
 
-// the same for the panel launches of the covariance mode: a launch covers up to 2 groups of 32 columns, each group
-// is one pass over X; nfill = length of the fill list the launches worked on
+// the same for the panel launches of the covariance mode: a launch covers up to 2 groups of 32 columns and reads X
+// ONCE whatever its width (8 n p algorithmic bytes per launch; 2 n p 32 flops per group: the launches are also
+// counted by width, bessx_session_counter 25-28); nfill = length of the fill list the launches worked on
 int cov_collect(bessx_session *s, int nfill) {
   if (!s->timing) return 0;
   for (auto &pr : s->cov_timed) {
@@ -211,7 +212,9 @@ int cov_collect(bessx_session *s, int nfill) {
     HIPX(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.first + 1]));
     s->k1_seconds += (double)ms * 1e-3;
     s->k1_launches += 1;
-    s->k1_bytes += 8.0 * (double)s->n * (double)s->p * real;
+    s->k1_bytes += 8.0 * (double)s->n * (double)s->p;
+    s->panel_w_seconds[real - 1] += (double)ms * 1e-3;
+    s->panel_w_launches[real - 1] += 1;
     if (test_hook("panel_log")) std::fprintf(stderr, "[bessx] panel pass: %d group(s) %.3f ms%s\n", real, ms, s->kch_owner ? " (chunk chain)" : "");
   }
   s->cov_timed.clear();
@@ -1248,26 +1251,10 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   HIPT(dmalloc(&s->idcols, (size_t)capA + 16));
   if (s->model_type == 4) HIPT(cox_alloc(s));
   if (s->model_type == 1) {
-    // group_XTX of the all-rows set (X^T y, diag(X^T X): one pass over X, src/path.cpp:37 -- the reference pays it
-    // inside every path call, here once per session): its device time is kept for the bench line (counter 19)
-    // (timed on its SECOND run: the first one loads the code objects of its kernels, which a session pays once and a
-    // path call never -- 1.6 ms against 0.7 on configs[1])
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-    if (int rc_first = prepare_rowset(s, 0)) {
-      if (e0) (void)hipEventDestroy(e0);
-      if (e1) (void)hipEventDestroy(e1);
-      TRY(rc_first);
-    }
-    if (timed) (void)hipEventRecord(e0, s->st);
-    const int rc_xtx = prepare_rowset(s, 0);
-    if (timed && rc_xtx == 0 && hipEventRecord(e1, s->st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) s->group_xtx_ns = (long long)(1e6 * (double)ms);
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    TRY(rc_xtx);
+    // group_XTX of the all-rows set (X^T y, diag(X^T X): one pass over X, src/path.cpp:37).  The session needs it for
+    // bessx_session_fit callers; every cold path call redoes it inside the call like the reference (run_path)
+    TRY(prepare_rowset(s, 0));
+    if (const char *ev = test_hook("path_group_xtx")) s->path_group_xtx = std::string(ev) != "0";
   }
   HIPT(hipStreamSynchronize(s->st));
 #undef TRY
@@ -1855,6 +1842,8 @@ int bessx_session_score_pass_stats(bessx_session *s, int reset, double *seconds,
     s->k1_seconds = 0.0;
     s->k1_launches = 0;
     s->k1_bytes = 0.0;
+    s->panel_w_seconds[0] = s->panel_w_seconds[1] = 0.0;
+    s->panel_w_launches[0] = s->panel_w_launches[1] = 0;
   }
   return BESSX_OK;
 }
@@ -1888,6 +1877,10 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 22: return (long long)(1e6 * s->kch_t[0]);
     case 23: return (long long)(1e6 * s->kch_t[1]);
     case 24: return (long long)(1e6 * s->kch_t[2]);
+    case 25: return s->panel_w_launches[0];
+    case 26: return (long long)(1e9 * s->panel_w_seconds[0]);
+    case 27: return s->panel_w_launches[1];
+    case 28: return (long long)(1e9 * s->panel_w_seconds[1]);
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

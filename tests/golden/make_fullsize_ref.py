@@ -9,6 +9,13 @@ Run once in the build container (it needs /root/reference to have been compiled 
     python tests/golden/make_fullsize_ref.py lmcv      # BASELINE configs[3], gs_path on [1,200] + 5-fold CV
     python tests/golden/make_fullsize_ref.py cox 4000  # BASELINE configs[4] recipe at the largest n the
                                                        # reference's n x n risk-set matrix allows (p=2000, k=1..40)
+    python tests/golden/make_fullsize_ref.py cox-port 20  # BASELINE configs[4] at FULL size (n=200000, p=20000), k = 1..20,
+                                                       # by the plain-C oracle (oracle/bess_oracle.c, kind "port": the
+                                                       # reference needs a 320 GB n x n matrix there, src/Algorithm.h:1386;
+                                                       # the port is pinned against the compiled reference by
+                                                       # tests/test_oracle_vs_reference.py).  Needs ~100 GB of host memory
+                                                       # (X, its sorted copy, the oracle's column-major copy): run on the
+                                                       # GPU box's host, ~10 minutes of one core
 
 BESS_REF_PROGRESS=1 prints one line per fit; BESS_REF_BUDGET_S=<s> stops the reference at the first fit that
 would start after the budget: the file then holds a PREFIX of the path (`truncated` = 1, no best model).
@@ -102,6 +109,20 @@ def main():
         t0 = time.time()
         t = ref.trace(X, status, data_type=3, model_type=4, ic_type=3, sequence=np.arange(1, kmax + 1))
         extra = {"n": n, "p": p, "k_true": ktrue, "seed": synth.SEED_COX, "true_support": support, "ic_type": 3}
+    elif which == "cox-port":
+        port = _load("port_ctypes", os.path.join(ROOT, "oracle", "port_ctypes.py"))
+        kmax = kmax or 20
+        n, p, ktrue = (600, 300, 8) if small else (200000, 20000, 75)
+        X, tm, status, support, beta = synth.make_cox(n, p, ktrue)
+        print("cox-port: data drawn (n=%d p=%d), oracle starts" % (n, p), flush=True)
+        t0 = time.time()
+        t = port.trace(X, status, data_type=3, model_type=4, ic_type=3, sequence=np.arange(1, kmax + 1))
+        setup_s, path_s = port.last_timing()
+        # fingerprints of the inputs the vectors belong to (the test regenerates them from bess_amd/synth.py)
+        extra = {"n": n, "p": p, "k_true": ktrue, "seed": synth.SEED_COX, "true_support": support, "ic_type": 3,
+                 "kind": "port", "oracle_setup_seconds": setup_s, "oracle_path_seconds": path_s,
+                 "status_sum": float(np.sum(status)), "x_probe": np.array([X[0, 0], X[n // 2, p // 2], X[n - 1, p - 1]]),
+                 "time_probe": np.array([tm[0], tm[n // 2], tm[n - 1]])}
     elif which == "bigk":
         # sparsity levels beyond the register / LDS resident solvers and beyond the default session capacity (2046)
         X, y, support, beta = synth.make_lm(300, 120, 5, seed=5) if small else synth.make_lm(8000, 2600, 10, seed=5)
@@ -114,8 +135,9 @@ def main():
         raise SystemExit("unknown config " + which)
     extra["ref_wall_seconds"] = time.time() - t0
     extra["kmax"] = kmax
-    name = {"cox": "fullsize_cox_n%d.npz" % extra["n"], "bigk": "ref_bigk.npz"}.get(which, "fullsize_%s.npz" % which)
-    out = "/tmp/small_%s.npz" % which if small else os.path.join(HERE, name)
+    name = {"cox": "fullsize_cox_n%d.npz" % extra["n"], "bigk": "ref_bigk.npz",
+            "cox-port": "fullsize_cox_port_prefix.npz"}.get(which, "fullsize_%s.npz" % which)
+    out = "/tmp/small_%s.npz" % which if small else os.path.join(os.environ.get("BESS_GOLDEN_OUT", HERE), name)
     np.savez_compressed(out, **pack(t, extra))
     print("done", which, "in", extra["ref_wall_seconds"], "s")
 
