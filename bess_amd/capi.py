@@ -33,6 +33,7 @@ SYMBOLS = [
     "bessx_session_cov_prefill_export", "bessx_session_cov_prefill_import", "bessx_session_cov_prefill_end",
     "bessx_session_cov_prefill_extend", "bessx_session_cov_state", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench", "bessx_op_cox_score_bench",
+    "bessx_op_xtv_multi", "bessx_op_xtv_multi_bench",
 ]
 
 
@@ -140,6 +141,8 @@ def lib():
         L.bessx_op_normalize.argtypes = [_D, _i, _i, _D, _D, _i, _i, _i, _D, _D, _D]
         L.bessx_op_stream_copy_gbps.argtypes = [_ll, _i, _D]
         L.bessx_op_xtv_bench.argtypes = [_i, _i, _i, _i, _D, _D]
+        L.bessx_op_xtv_multi.argtypes = [_D, _i, _i, _i, _D, _D, _i, _D, _D]
+        L.bessx_op_xtv_multi_bench.argtypes = [_i, _i, _i, _i, _i, _D, _D]
         L.bessx_op_topk_bench.argtypes = [_i, _i, _i, _i, _D]
         L.bessx_op_chol_bench.argtypes = [_i, _i, _D]
         _lib = L
@@ -597,6 +600,18 @@ def op_xtv(x, v, v2=None):
     return (out, out2) if v2 is not None else out
 
 
+def op_xtv_multi(x, vs, v2s=None):
+    """X^T v for the rows of vs (nc x n) in one pass over X; with v2s also X^2^T v2."""
+    x = np.asfortranarray(x, dtype=np.float64)
+    n, p = x.shape
+    vs = np.ascontiguousarray(vs, dtype=np.float64)
+    nc = vs.shape[0]
+    out, out2 = np.zeros((nc, p)), np.zeros((nc, p))
+    v2a = None if v2s is None else np.ascontiguousarray(v2s, dtype=np.float64)
+    _check(lib().bessx_op_xtv_multi(_dp(x), n, p, n, _dp(vs), _dp(v2a), nc, _dp(out), _dp(out2)))
+    return (out, out2) if v2s is not None else out
+
+
 def op_topk(score, k):
     score = _f64(score)
     out = np.zeros(max(k, 1), dtype=np.int32)
@@ -649,6 +664,12 @@ def op_topk_bench(length, k, variant=1, repeats=200):
     us = _d(0)
     _check(lib().bessx_op_topk_bench(length, k, variant, repeats, ctypes.byref(us)))
     return us.value
+
+
+def op_xtv_multi_bench(n, p, nc, two=False, repeats=20):
+    g, ms = _d(0), _d(0)
+    _check(lib().bessx_op_xtv_multi_bench(n, p, nc, int(two), repeats, ctypes.byref(g), ctypes.byref(ms)))
+    return g.value, ms.value
 
 
 def op_xtv_bench(n, p, variant, repeats=20):

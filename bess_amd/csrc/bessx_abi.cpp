@@ -235,6 +235,48 @@ int bessx_op_xtv(const double *x, int n, int p, int ld, const double *v, const d
   return BESSX_OK;
 }
 
+// the same sums for nc vectors at once by the multi-chain kernel (k_xtv_mc: one pass over X): row c of v / v2 / out / out2
+// belongs to chain c.  Bitwise the results of nc calls of bessx_op_xtv (tests/test_ops_gpu.py).
+int bessx_op_xtv_multi(const double *x, int n, int p, int ld, const double *v, const double *v2, int nc, double *out,
+                       double *out2) {
+  if (int rc = need_device()) return rc;
+  if (!x || !v || !out || n < 1 || p < 1 || ld < n || nc < 1 || nc > XTV_MC_MAX || (v2 && !out2))
+    return fail(BESSX_ERR_ARG, "op_xtv_multi: bad arguments");
+  Scratch sc;
+  const int U = n >= 4096 ? 8 : (n >= 2048 ? 4 : (n >= 1024 ? 2 : 1));
+  double *dX, *dout;
+  long ldd;
+  if (int rc = upload_padded(sc, x, n, p, ld, U, &dX, &ldd)) return rc;
+  const int nrb = (int)(ldd / (128L * U));
+  XtvMc a = {};
+  a.nc = nc;
+  for (int c = 0; c < nc; c++) {
+    double *dv, *dv2 = nullptr, *part, *part2 = nullptr;
+    if (int rc = upload_vec_padded(sc, v + (size_t)c * n, n, ldd, &dv)) return rc;
+    if (v2)
+      if (int rc = upload_vec_padded(sc, v2 + (size_t)c * n, n, ldd, &dv2)) return rc;
+    HIPX(sc.alloc(&part, (size_t)nrb * p));
+    HIPX(sc.alloc(&part2, (size_t)nrb * p));
+    a.v[c] = dv;
+    a.v2[c] = dv2;
+    a.part[c] = part;
+    a.part2[c] = part2;
+    a.ctrl[c] = nullptr;
+    a.slot[c] = 0;
+  }
+  HIPX(sc.alloc(&dout, (size_t)p));
+  HIPX(launch_xtv_mc(dX, ldd, p, U, a, v2 != nullptr, nullptr));
+  for (int c = 0; c < nc; c++) {
+    HIPX(launch_part_sum(a.part[c], nrb, p, dout, nullptr));
+    HIPX(hipMemcpy(out + (size_t)c * p, dout, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+    if (v2) {
+      HIPX(launch_part_sum(a.part2[c], nrb, p, dout, nullptr));
+      HIPX(hipMemcpy(out2 + (size_t)c * p, dout, (size_t)p * sizeof(double), hipMemcpyDeviceToHost));
+    }
+  }
+  return BESSX_OK;
+}
+
 int bessx_op_topk(const double *score, int len, int k, int *out_idx) {
   if (int rc = need_device()) return rc;
   if (!score || !out_idx || len < 1 || k < 0 || k > len) return fail(BESSX_ERR_ARG, "op_topk: bad arguments");
@@ -475,6 +517,42 @@ int bessx_op_xtv_bench(int n, int p, int variant, int repeats, double *gbps, dou
   HIPX(launch_xtv_variant(variant, dX, ld, p, dv, part, nullptr));
   HIPX(hipEventRecord(e0, nullptr));
   for (int i = 0; i < repeats; i++) HIPX(launch_xtv_variant(variant, dX, ld, p, dv, part, nullptr));
+  HIPX(hipEventRecord(e1, nullptr));
+  HIPX(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPX(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbps = 8.0 * (double)n * (double)p * repeats / ((double)ms * 1e-3) / 1e9;
+  if (avg_ms) *avg_ms = ms / repeats;
+  return BESSX_OK;
+}
+
+int bessx_op_xtv_multi_bench(int n, int p, int nc, int two, int repeats, double *gbps, double *avg_ms) {
+  if (int rc = need_device()) return rc;
+  if (n < 1 || p < 1 || repeats < 1 || !gbps || nc < 1 || nc > XTV_MC_MAX) return fail(BESSX_ERR_ARG, "op_xtv_multi_bench: bad arguments");
+  Scratch sc;
+  const long ld = ((long)n + 1023) / 1024 * 1024;
+  double *dX, *dv, *part;
+  HIPX(sc.alloc(&dX, (size_t)ld * p));
+  HIPX(sc.alloc(&dv, (size_t)ld * 2 * nc));
+  HIPX(sc.alloc(&part, (size_t)(ld / 1024) * p * 2 * nc));
+  HIPX(launch_fill(dX, ld * (long)p, 1.0, nullptr));
+  HIPX(launch_fill(dv, ld * 2 * nc, 0.5, nullptr));
+  XtvMc a = {};
+  a.nc = nc;
+  for (int c = 0; c < nc; c++) {
+    a.v[c] = dv + (size_t)(2 * c) * ld;
+    a.v2[c] = two ? dv + (size_t)(2 * c + 1) * ld : nullptr;
+    a.part[c] = part + (size_t)(2 * c) * (ld / 1024) * p;
+    a.part2[c] = part + (size_t)(2 * c + 1) * (ld / 1024) * p;
+  }
+  hipEvent_t e0, e1;
+  HIPX(hipEventCreate(&e0));
+  HIPX(hipEventCreate(&e1));
+  HIPX(launch_xtv_mc(dX, ld, p, 8, a, two != 0, nullptr));
+  HIPX(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < repeats; i++) HIPX(launch_xtv_mc(dX, ld, p, 8, a, two != 0, nullptr));
   HIPX(hipEventRecord(e1, nullptr));
   HIPX(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -191,19 +191,24 @@ __global__ void __launch_bounds__(256) k_xtv(const double *__restrict__ X, long 
 // 32, 16, 8, 4, 2, 1 -- k_xtv's exchange steps and its plain steps add the same pairs, the number of columns a wave keeps
 // only changes which lane ends up with which column), the same part[rb][j] layout per chain.
 //
-// Block = 4 waves on ONE row block and XTV_MC_CPW consecutive columns each; the active chains' v (and v2) slices of that
-// row block are staged in LDS once per block (8 KB per chain and vector at U = 8: 3 % of the 1 MB of X the block streams)
-// and a wave re-reads a chain's slice once per pair of columns (8 ds_read_b128) -- registers hold two columns of X
-// (+ the next two in flight), one chain's slice and 2 (4) accumulators, whatever the number of chains.
+// Block = 16 waves on ONE row block, XTV_MC_CPW consecutive columns each; the active chains' v (and v2) slices of that
+// row block are staged in LDS once per block (8 KB per chain and vector at U = 8, against the 4 MB of X the block streams)
+// and a wave re-reads a chain's slice once per PAIR of columns (8 ds_read_b128): registers hold two columns of X, the
+// slices of the chain(s) being summed and their accumulators -- whatever the number of chains.  1024 threads per block
+// cap the kernel at 128 registers: four waves per SIMD hide the load latency (no software prefetch -- the first version
+// kept the next pair in flight in 64 more registers, two waves per SIMD, and the compiler's vmcnt(0) in front of the chain
+// loop made every pair wait for its own loads: 0.25 ms per chain and pass on configs[1], nothing shared).  Without the
+// second accumulator two chains are summed at a time: their dependent shuffle chains (6 ds_bpermute steps each) overlap.
 // Gate per chain like k_xtv's; a launch whose chains have all converged falls through after the gate loads.
 // ------------------------------------------------------------------------------------------
-constexpr int XTV_MC_CPW = 32;  // columns per wave (128 per block)
+constexpr int XTV_MC_CPW = 32;    // columns per wave
+constexpr int XTV_MC_WAVES = 16;  // waves per block (512 columns)
 
 template <int U, bool TWO>
-__global__ void __launch_bounds__(256) k_xtv_mc(const double *__restrict__ X, long ld, int p, int nrb, XtvMc a) {
+__global__ void __launch_bounds__(64 * XTV_MC_WAVES) k_xtv_mc(const double *__restrict__ X, long ld, int p, int nrb, XtvMc a) {
   extern __shared__ double sv[];  // [active chain][TWO ? 2 : 1][128 * U]
-  __shared__ int act[XTV_MC_MAX + 1];
-  constexpr int RB = 128 * U, VPC = TWO ? 2 : 1;
+  __shared__ int act[XTV_MC_MAX + 2];
+  constexpr int RB = 128 * U, VPC = TWO ? 2 : 1, NT = 64 * XTV_MC_WAVES;
   if (threadIdx.x == 0) {
     int na = 0;
     for (int c = 0; c < a.nc; c++) {
@@ -216,10 +221,10 @@ __global__ void __launch_bounds__(256) k_xtv_mc(const double *__restrict__ X, lo
   __syncthreads();
   const int na = act[XTV_MC_MAX];
   if (na == 0) return;
-  const int nsp = (p + 4 * XTV_MC_CPW - 1) / (4 * XTV_MC_CPW);
+  const int nsp = (p + XTV_MC_WAVES * XTV_MC_CPW - 1) / (XTV_MC_WAVES * XTV_MC_CPW);
   const int rb = blockIdx.x / nsp, sp = blockIdx.x - rb * nsp;
   const long rbase = (long)rb * RB;
-  for (int i = threadIdx.x; i < na * VPC * (RB / 2); i += 256) {
+  for (int i = threadIdx.x; i < na * VPC * (RB / 2); i += NT) {
     const int w = i / (RB / 2), o = i - w * (RB / 2);
     const int c = act[w / VPC];
     const double *src = (TWO && (w & 1)) ? a.v2[c] : a.v[c];
@@ -227,66 +232,75 @@ __global__ void __launch_bounds__(256) k_xtv_mc(const double *__restrict__ X, lo
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j0 = (sp * 4 + wv) * XTV_MC_CPW;
+  const int j0 = (sp * XTV_MC_WAVES + wv) * XTV_MC_CPW;
   if (j0 >= p) return;
   const long row0 = rbase + lane * 2;
-  d2 xa[U], xb[U], na_[U], nb_[U];
-  auto load2 = [&](int j, d2 (&ca)[U], d2 (&cb)[U]) {
-    const int ja = j < p ? j : p - 1, jb = j + 1 < p ? j + 1 : p - 1;  // tail: recompute the last column, discarded below
-    const double *pa = X + (size_t)ja * ld + row0, *pb = X + (size_t)jb * ld + row0;
-#pragma unroll
-    for (int u = 0; u < U; u++) ca[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pa + u * 128));
-#pragma unroll
-    for (int u = 0; u < U; u++) cb[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pb + u * 128));
-  };
-  load2(j0, xa, xb);
   const bool up = (lane & 32) != 0;
+  const bool writer = (lane & 31) == 0;
+  // sums of one chain's slice against the two columns in registers, folded over the lanes: column 0 ends in the lower
+  // half of the wave, column 1 in the upper half
+  auto fold = [&](double c0, double c1) {
+    double s = (up ? c1 : c0) + __shfl_xor(up ? c0 : c1, 32);
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+  };
   for (int g = 0; g < XTV_MC_CPW && j0 + g < p; g += 2) {
-    const bool more = g + 2 < XTV_MC_CPW && j0 + g + 2 < p;
-    if (more) load2(j0 + g + 2, na_, nb_);  // the next pair's loads fly while every chain's sums are formed
-    for (int w = 0; w < na; w++) {
-      const int c = act[w];
-      const double *vs = sv + (size_t)w * VPC * RB + lane * 2;
-      d2 vr[U], vr2[TWO ? U : 1];
+    const int ja = j0 + g, jb = ja + 1 < p ? ja + 1 : p - 1;  // tail: the last column again, discarded below
+    const double *pa = X + (size_t)ja * ld + row0, *pb = X + (size_t)jb * ld + row0;
+    d2 xa[U], xb[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        vr[u] = *reinterpret_cast<const d2 *>(vs + u * 128);
-        if (TWO) vr2[u] = *reinterpret_cast<const d2 *>(vs + RB + u * 128);
-      }
-      double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    for (int u = 0; u < U; u++) xa[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pa + u * 128));
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        a0 = fma(xa[u].x, vr[u].x, a0);
-        a0 = fma(xa[u].y, vr[u].y, a0);
-        a1 = fma(xb[u].x, vr[u].x, a1);
-        a1 = fma(xb[u].y, vr[u].y, a1);
-        if (TWO) {
-          b0 = fma(xa[u].x * xa[u].x, vr2[u].x, b0);
-          b0 = fma(xa[u].y * xa[u].y, vr2[u].y, b0);
-          b1 = fma(xb[u].x * xb[u].x, vr2[u].x, b1);
-          b1 = fma(xb[u].y * xb[u].y, vr2[u].y, b1);
+    for (int u = 0; u < U; u++) xb[u] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(pb + u * 128));
+    const int j = ja + (up ? 1 : 0);
+    const bool wr = writer && j < p;
+    if (TWO) {
+      for (int w = 0; w < na; w++) {
+        const double *vs = sv + (size_t)w * 2 * RB + lane * 2;
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const d2 vr = *reinterpret_cast<const d2 *>(vs + u * 128), vr2 = *reinterpret_cast<const d2 *>(vs + RB + u * 128);
+          a0 = fma(xa[u].x, vr.x, a0);
+          a0 = fma(xa[u].y, vr.y, a0);
+          a1 = fma(xb[u].x, vr.x, a1);
+          a1 = fma(xb[u].y, vr.y, a1);
+          b0 = fma(xa[u].x * xa[u].x, vr2.x, b0);
+          b0 = fma(xa[u].y * xa[u].y, vr2.y, b0);
+          b1 = fma(xb[u].x * xb[u].x, vr2.x, b1);
+          b1 = fma(xb[u].y * xb[u].y, vr2.y, b1);
+        }
+        const double s = fold(a0, a1), s2 = fold(b0, b1);
+        if (wr) {
+          const int c = act[w];
+          a.part[c][(size_t)rb * p + j] = s;
+          a.part2[c][(size_t)rb * p + j] = s2;
         }
       }
-      // butterfly, 2 columns: offset 32 exchanges (the lower half of the lanes keeps column 0), then plain steps
-      double s = (up ? a1 : a0) + __shfl_xor(up ? a0 : a1, 32);
-      double s2 = 0.0;
-      if (TWO) s2 = (up ? b1 : b0) + __shfl_xor(up ? b0 : b1, 32);
+    } else {
+      for (int w = 0; w < na; w += 2) {
+        const bool second = w + 1 < na;
+        const double *vs = sv + (size_t)w * RB + lane * 2;
+        const double *vt = second ? vs + RB : vs;  // (odd count: the last chain twice, the copy discarded)
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
 #pragma unroll
-      for (int o = 16; o >= 1; o >>= 1) {
-        s += __shfl_xor(s, o);
-        if (TWO) s2 += __shfl_xor(s2, o);
-      }
-      const int j = j0 + g + (up ? 1 : 0);
-      if ((lane & 31) == 0 && j < p) {
-        a.part[c][(size_t)rb * p + j] = s;
-        if (TWO) a.part2[c][(size_t)rb * p + j] = s2;
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        xa[u] = na_[u];
-        xb[u] = nb_[u];
+        for (int u = 0; u < U; u++) {
+          const d2 vr = *reinterpret_cast<const d2 *>(vs + u * 128), wr2 = *reinterpret_cast<const d2 *>(vt + u * 128);
+          a0 = fma(xa[u].x, vr.x, a0);
+          a0 = fma(xa[u].y, vr.y, a0);
+          a1 = fma(xb[u].x, vr.x, a1);
+          a1 = fma(xb[u].y, vr.y, a1);
+          b0 = fma(xa[u].x, wr2.x, b0);
+          b0 = fma(xa[u].y, wr2.y, b0);
+          b1 = fma(xb[u].x, wr2.x, b1);
+          b1 = fma(xb[u].y, wr2.y, b1);
+        }
+        const double s = fold(a0, a1), t = fold(b0, b1);
+        if (wr) {
+          a.part[act[w]][(size_t)rb * p + j] = s;
+          if (second) a.part[act[w + 1]][(size_t)rb * p + j] = t;
+        }
       }
     }
   }
@@ -1117,7 +1131,7 @@ hipError_t launch_xtv(const double *X, long ld, int p, int U, const double *v, c
 template <int U, bool TWO>
 static hipError_t launch_xtv_mc_t(const double *X, long ld, int p, const XtvMc &a, hipStream_t st) {
   const int nrb = (int)(ld / (128 * U));
-  const int nsp = (p + 4 * XTV_MC_CPW - 1) / (4 * XTV_MC_CPW);
+  const int nsp = (p + XTV_MC_WAVES * XTV_MC_CPW - 1) / (XTV_MC_WAVES * XTV_MC_CPW);
   const size_t lds = (size_t)a.nc * (TWO ? 2 : 1) * 128 * U * sizeof(double);
   static bool attr_done = false;  // dynamic LDS beyond 64 KB has to be requested once per kernel instance
   if (!attr_done) {
@@ -1127,7 +1141,7 @@ static hipError_t launch_xtv_mc_t(const double *X, long ld, int p, const XtvMc &
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_xtv_mc<U, TWO>), dim3(nrb * nsp), dim3(256), lds, st, X, ld, p, nrb, a);
+  hipLaunchKernelGGL((k_xtv_mc<U, TWO>), dim3(nrb * nsp), dim3(64 * XTV_MC_WAVES), lds, st, X, ld, p, nrb, a);
   LAUNCH_CHECK();
   return hipSuccess;
 }

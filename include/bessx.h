@@ -361,6 +361,10 @@ int bessx_session_debug_block_stream(bessx_session *s, int milliseconds);
  * If v2 != NULL also out2[j] = sum_i x[i,j]^2 * v2[i] (K2; src/Algorithm.h:1240-1246). */
 int bessx_op_xtv(const double *x, int n, int p, int ld, const double *v, const double *v2, double *out,
                  double *out2);
+/* K1 / K2 for nc <= 8 vectors in ONE pass over X (the multi-chain score pass of chunk chains, k_xtv_mc): v, v2 are
+ * nc x n (row c = chain c), out, out2 nc x p.  Bitwise the sums of nc bessx_op_xtv calls. */
+int bessx_op_xtv_multi(const double *x, int n, int p, int ld, const double *v, const double *v2, int nc, double *out,
+                       double *out2);
 /* K4: max_k (src/utilities.cpp:179-188): the k largest scores, indices ascending, ties -> lower index. */
 int bessx_op_topk(const double *score, int len, int k, int *out_idx);
 /* timing of the top-k kernel (k_topk) on synthetic chi-square scores; `variant` is reserved (one kernel exists) */
@@ -380,6 +384,9 @@ int bessx_op_normalize(double *x, int n, int p, double *y, const double *weight,
 /* Tuning aid for K1: run geometry variant `variant` of the score pass `repeats` times on an n x p matrix
  * generated on the device and report algorithmic GB/s (8*n*p bytes per launch) and the mean launch time. */
 int bessx_op_xtv_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms);
+/* ... and the multi-chain score pass: nc vector sets per launch (two != 0: with the second accumulator); GB/s counts the
+ * 8*n*p bytes of X once per launch. */
+int bessx_op_xtv_multi_bench(int n, int p, int nc, int two, int repeats, double *gbps, double *avg_ms);
 /* The same for the one-pass Cox score kernel (k_cox_score1p, 8*n*p bytes per launch); variant 1 = the one the solver runs (wave map of round 4), 0 = round 3. */
 int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms);
 /* Device-to-device streaming copy rate in GB/s (read+write bytes / time): the measured HBM ceiling

@@ -300,6 +300,49 @@ def cox_full(gpu):
     s.close()
 
 
+class _Prefix:
+    """A golden of k = 1..K read as a PREFIX of a longer warm-start chain (candidate k starts from candidate k - 1's model,
+    src/path.cpp:60-64: the first K candidates of 1..150 are the candidates of 1..K)."""
+
+    def __init__(self, g):
+        self._g = g
+        self.files = list(g.files)
+
+    def __getitem__(self, k):
+        return np.int64(1) if k == "truncated" else self._g[k]
+
+
+def test_cox_config_matches_the_pinned_oracle_at_full_size(gpu, cox_full, monkeypatch):
+    """configs[4] at the BENCHMARKED size, n = 200 000, p = 20 000: every PDAS iteration of k = 1..20 against the plain-C
+    oracle (oracle/bess_oracle.c, kind "port" -- the reference itself needs a 320 GB n x n matrix here,
+    src/Algorithm.h:1386; the port is pinned against the compiled reference in tests/test_oracle_vs_reference.py and at
+    n = 4000 above).  tests/golden/make_fullsize_ref.py cox-port 20 (574 s of one host core of the GPU box).  Traced
+    (1-pass and 2-pass score) and untraced (one chain, chunk chains forced), src/Algorithm.h:1377-1649."""
+    g = _gold("fullsize_cox_port_prefix.npz")
+    assert str(g["kind"]) == "port" and int(g["n"]) == 200000 and int(g["p"]) == 20000
+    s, out, support, (X, status), (n, p, kmax) = cox_full
+    # the vectors belong to exactly these inputs
+    assert float(np.sum(status)) == float(g["status_sum"])
+    assert np.array_equal(np.array([X[0, 0], X[n // 2, p // 2], X[n - 1, p - 1]]), g["x_probe"])
+    pre = _Prefix(g)
+    nfit = assert_matches_golden(out["trace"], pre, "configs[4] at full size, 1-pass score", beta_rtol=1e-5, metric_rtol=1e-7)
+    assert nfit == 20
+    s.trace_enable(False)
+    for chains in (1, 3, 0):
+        s.set_kpath_chains(chains)
+        fast = s.sequential_path(np.arange(1, 41), ic_type=3)
+        assert_untraced_path_matches_golden(fast, pre, X, 3, "configs[4] full size untraced, chains=%d" % chains,
+                                            beta_rtol=1e-5, metric_rtol=1e-7)
+        if chains == 3:
+            assert s.counters()["kpath_chains_last_path"] == 3
+    s.set_kpath_chains(0)
+    hooks(monkeypatch, cox_score="2pass")  # read when a session is created
+    with gpu.Session(X, status, data_type=3, model_type=4) as s2:
+        s2.trace_enable(True)
+        two = s2.sequential_path(np.arange(1, 21), ic_type=3)
+    assert_matches_golden(two["trace"], pre, "configs[4] at full size, 2-pass score", beta_rtol=1e-5, metric_rtol=1e-7)
+
+
 def test_cox_config_properties_at_full_size(gpu, cox_full, monkeypatch):
     s, out, support, (X, status), (n, p, kmax) = cox_full
     fits = out["trace"]["fits"]

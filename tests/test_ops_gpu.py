@@ -24,6 +24,23 @@ def test_xtv_matches_numpy(gpu, n, p):
     assert np.array_equal(got, gpu.op_xtv(x, v))
 
 
+@pytest.mark.parametrize("n,p,nc", [(97, 8, 2), (130, 33, 3), (1024, 131, 4), (2500, 100, 8), (5000, 257, 5), (9000, 300, 8)])
+def test_multi_chain_score_pass_is_bitwise_the_single_passes(gpu, n, p, nc):
+    """k_xtv_mc (round 6): one pass over X for nc chains' vectors leaves bitwise the sums of nc k_xtv launches -- the chunk
+    chains that share a pass walk exactly the path they walk on passes of their own."""
+    rng = np.random.default_rng(7 * n + p + nc)
+    x = rng.standard_normal((n, p))
+    vs = rng.standard_normal((nc, n))
+    hs = rng.uniform(0.1, 1.0, (nc, n))
+    got = gpu.op_xtv_multi(x, vs)
+    g1, g2 = gpu.op_xtv_multi(x, vs, hs)
+    for c in range(nc):
+        assert np.array_equal(got[c], gpu.op_xtv(x, vs[c])), c
+        w1, w2 = gpu.op_xtv(x, vs[c], hs[c])
+        assert np.array_equal(g1[c], w1) and np.array_equal(g2[c], w2), c
+        assert np.array_equal(g1[c], got[c])
+
+
 @pytest.mark.parametrize("length,k", [(8, 3), (8, 8), (1000, 1), (1000, 37), (10000, 200), (20000, 150), (32768, 254),
                                       (70000, 50), (100000, 200)])
 def test_topk_matches_oracle(gpu, length, k):
