@@ -581,7 +581,36 @@ int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbp
   HIPX(hipEventCreate(&e1));
   // variant 1 (what the solver runs): consecutive waves take consecutive column groups of one row block; 0 (round 3):
   // the row blocks of one column group
-  if (variant < 0 || variant > 1) return fail(BESSX_ERR_ARG, "op_cox_score_bench: variant 0 or 1");
+  // variant 10 + nc: the multi-chain kernel (k_cox_score1p_mc) with nc chains' vector sets per launch
+  const int mc = (variant >= 11 && variant <= 10 + COX_MC_MAX) ? variant - 10 : 0;
+  if (!mc && (variant < 0 || variant > 1)) return fail(BESSX_ERR_ARG, "op_cox_score_bench: variant 0, 1 or 11..14");
+  if (mc) {
+    double *vecs, *outs;
+    HIPX(sc.alloc(&vecs, (size_t)ld * 4 * mc));
+    HIPX(sc.alloc(&outs, ((size_t)5 * nrb * p + nrb) * mc));
+    HIPX(launch_fill(vecs, ld * 4 * mc, 0.5, nullptr));
+    CoxMc a = {};
+    a.nc = mc;
+    for (int c = 0; c < mc; c++) {
+      a.TH[c] = vecs + (size_t)(4 * c) * ld;
+      a.CU[c] = vecs + (size_t)(4 * c + 1) * ld;
+      a.CV[c] = vecs + (size_t)(4 * c + 2) * ld;
+      a.C2[c] = vecs + (size_t)(4 * c + 3) * ld;
+      a.out[c] = outs + ((size_t)5 * nrb * p + nrb) * c;
+    }
+    HIPX(launch_cox_score1p_mc(dX, ld, p, 8, nrb, a, nullptr));
+    HIPX(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < repeats; i++) HIPX(launch_cox_score1p_mc(dX, ld, p, 8, nrb, a, nullptr));
+    HIPX(hipEventRecord(e1, nullptr));
+    HIPX(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPX(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbps = 8.0 * (double)n * (double)p * repeats / ((double)ms * 1e-3) / 1e9;
+    if (avg_ms) *avg_ms = ms / repeats;
+    return BESSX_OK;
+  }
   cox_score_set_variant(variant);
   CoxBufs cb = {};
   cb.one_pass = 1;

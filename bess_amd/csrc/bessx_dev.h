@@ -316,6 +316,18 @@ struct CoxBufs {
   double fit_clamp;  // clamp of the linear predictor in the Newton step: 30 (src/Algorithm.h:1417-1422); cox_fit of the
                      // screening uses 50 (src/coxph.cpp:65-71)
 };
+// One pass over X for several chains' one-pass Cox scores (k_cox_score1p_mc): per chain the four n-vectors of
+// launch_cox_score_pass (one_pass form) and its output planes; ran (optional) receives the number of open gates.
+constexpr int COX_MC_MAX = 4;
+struct CoxMc {
+  const double *TH[COX_MC_MAX], *CU[COX_MC_MAX], *CV[COX_MC_MAX], *C2[COX_MC_MAX];
+  double *out[COX_MC_MAX];
+  const FitCtrl *ctrl[COX_MC_MAX];
+  int slot[COX_MC_MAX];
+  int nc;
+  int *ran;
+};
+hipError_t launch_cox_score1p_mc(const double *X, long ld, int p, int U, int nrb, const CoxMc &a, hipStream_t st);
 void cox_score_set_variant(int v);  // bench hook: the wave -> (column group, row block) map of k_cox_score1p (1 = default)
 int cox_hess_slab_rows(long ld);
 bool cox_hess_applies(int mt);

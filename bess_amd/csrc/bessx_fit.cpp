@@ -4,6 +4,35 @@
 
 namespace bessx {
 
+// The pass over X of one PDAS iteration -- K1 (LM, streaming form), K2 (logistic / Poisson: two accumulators), K3 (Cox
+// score) -- for slot `slot` of the fit on row set rs.  A chunk chain whose owner runs shared passes hands its vector set
+// to the owner's next multi-chain launch (bessx_kchunks.cpp: SharedPass; timed there); everybody else launches on its own
+// stream, timed by an event pair when the statistics are on.  kind: 0 LM, 1 GLM, 2 Cox.
+static int score_pass(bessx_session *s, int kind, int rs, int slot, std::vector<std::pair<size_t, bool>> &k1_pairs) {
+  if (rs == 0 && shared_pass_applies(s)) {
+    if (s->timing) k1_pairs.push_back({(size_t)-1, false});
+    if (kind == 2 && s->cox.one_pass)
+      return shared_pass_submit(s, nullptr, nullptr, s->part_rs[rs], nullptr, &s->cox, s->ctrl, slot);
+    if (kind != 2)
+      return shared_pass_submit(s, s->r_rs[rs], kind == 1 ? s->h_rs[rs] : nullptr, s->part_rs[rs],
+                                kind == 1 ? s->part2_rs[rs] : nullptr, nullptr, s->ctrl, slot);
+  }
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (int rc = k1_begin(s, &ea, &eb)) return rc;
+  hipError_t e;
+  if (kind == 2)
+    e = launch_cox_score_pass(s->X, s->ld, s->p, s->U, s->nrb, s->cox, s->part_rs[rs], s->part2_rs[rs], s->ctrl, slot, s->st);
+  else
+    e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], kind == 1 ? s->h_rs[rs] : nullptr, s->part_rs[rs],
+                   kind == 1 ? s->part2_rs[rs] : nullptr, s->ctrl, slot, s->st);
+  if (s->timing && e == hipSuccess) {
+    e = hipEventRecord(eb, s->st);
+    k1_pairs.push_back({s->ev_used - 2, false});
+  }
+  if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("score pass: ") + hipGetErrorString(e));
+  return 0;
+}
+
 // --------------------------------------------------------------------------------------------
 // Algorithm::fit (src/Algorithm.h:113-171), LM: GroupPdasLm::get_A / primary_model_fit (:1097-1135)
 // --------------------------------------------------------------------------------------------
@@ -20,13 +49,7 @@ int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, b
   if (!skip_k1) {
     // skip_k1: the partial sums of this row set were computed from exactly the coefficients this fit
     // starts from (the previous fit ended on a repeated active set) -- get_A would recompute them bit for bit.
-    hipEvent_t ea = nullptr, eb = nullptr;
-    if (int rc = k1_begin(s, &ea, &eb)) return rc;
-    e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], nullptr, s->part_rs[rs], nullptr, s->ctrl, slot, s->st);
-    if (s->timing && e == hipSuccess) {
-      e = hipEventRecord(eb, s->st);
-      k1_pairs.push_back({s->ev_used - 2, false});
-    }
+    if (int rc = score_pass(s, 0, rs, slot, k1_pairs)) return rc;
   } else if (s->timing) {
     k1_pairs.push_back({(size_t)-1, false});
   }
@@ -493,14 +516,7 @@ int enqueue_glm_head(bessx_session *s, int slot, int T0, double lambda, int rs, 
   if (int rc = glm_geometry(s, T0, &mt, &mp, &ntask, &ntiles, &rps, &nslab)) return rc;
   hipError_t e = hipSuccess;
   if (!skip_k1) {
-    hipEvent_t ea = nullptr, eb = nullptr;
-    if (int rc = k1_begin(s, &ea, &eb)) return rc;
-    e = launch_xtv(s->X, s->ld, s->p, s->U, s->r_rs[rs], s->h_rs[rs], s->part_rs[rs], s->part2_rs[rs], s->ctrl, slot,
-                   s->st);
-    if (s->timing && e == hipSuccess) {
-      e = hipEventRecord(eb, s->st);
-      k1_pairs.push_back({s->ev_used - 2, false});
-    }
+    if (int rc = score_pass(s, 1, rs, slot, k1_pairs)) return rc;
   } else if (s->timing) {
     k1_pairs.push_back({(size_t)-1, false});
   }
@@ -613,14 +629,7 @@ int enqueue_cox_head(bessx_session *s, int slot, int T0, double lambda, int rs, 
   const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
   hipError_t e = hipSuccess;
   if (!skip_k1) {
-    hipEvent_t ea = nullptr, eb = nullptr;
-    if (int rc = k1_begin(s, &ea, &eb)) return rc;
-    e = launch_cox_score_pass(s->X, s->ld, s->p, s->U, s->nrb, s->cox, s->part_rs[rs], s->part2_rs[rs], s->ctrl, slot,
-                              s->st);
-    if (s->timing && e == hipSuccess) {
-      e = hipEventRecord(eb, s->st);
-      k1_pairs.push_back({s->ev_used - 2, false});
-    }
+    if (int rc = score_pass(s, 2, rs, slot, k1_pairs)) return rc;
   } else if (s->timing) {
     k1_pairs.push_back({(size_t)-1, false});
   }

@@ -279,6 +279,9 @@ struct bessx_session {
   int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
   int kch_index = -1;                   // (chain context) its place among the owner's contexts
   unsigned long long kch_gen_seen = 0;  // (chain context) completed fills when this chain last queued a look-up
+  bool kch_sp_member = false;           // (chain context) its thread takes part in the owner's shared passes over X
+  int kch_sp_group = 0;                 // ... in this group of chains (the groups alternate on the pass stream)
+  long long sp_launches = 0, sp_chain_slots = 0, sp_partial = 0;  // shared passes: launches, open gates in them, batches cut short
   int *kch_slot_w = nullptr;            // (owner) the writer's slot map of staged fills, p ints
   hipStream_t kch_fill_st = nullptr;    // (owner) the stream the chains' staged fills run on (some compute units left out)
   hipEvent_t kch_ev = nullptr;          // (chain context) orders its fill list in front of the fill on kch_fill_st
@@ -466,6 +469,9 @@ void kchains_log(bessx_session *c, const char *what, int a, int b);  // (test ho
 void kchains_progress(bessx_session *c, int n);  // chain context: n candidates of its chunk are stored
 bool kchains_staged(const bessx_session *c);               // this round's fills are staged (nobody stands still)
 unsigned long long kchains_generation(bessx_session *c);   // completed fills of the owner's chains so far
+bool shared_pass_applies(const bessx_session *c);  // chain context whose passes over X go into the owner's multi-chain launches
+int shared_pass_submit(bessx_session *c, const double *v, const double *v2, double *part, double *part2,
+                       const CoxBufs *cox, const FitCtrl *ctrl, int slot);
 void kchains_free(bessx_session *s);
 void kchains_quiesce(bessx_session *s);
 int kchunks_prepare(bessx_session *s, int ns, bool link);

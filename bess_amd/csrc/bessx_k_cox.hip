@@ -361,6 +361,134 @@ __global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ 
   }
 }
 
+// The same pass for up to COX_MC_MAX chains at once (round 6, chunk chains that share their passes over X): the tile of X
+// is staged in LDS once and walked once per ACTIVE chain -- per chain exactly the walk above (rows bottom-up, the same
+// fma order, the same five sums per (row block, column) and P0 per row block), so every chain's sums are bitwise those
+// of a launch of its own.  The extra walks read the tile from LDS (16 KB per chain and tile against 128 B/clock) and cost
+// ~7 vector instructions per element: four chains keep the vector ALU at ~70 % of what the HBM stream allows.
+// (Every chain's vectors are kernel arguments of their own, `const double *__restrict__`, as in k_cox_score1p.)
+#define COX_MC_CHAIN_ARGS(i)                                                                                         \
+  const double *__restrict__ TH##i, const double *__restrict__ CU##i, const double *__restrict__ CV##i,              \
+      const double *__restrict__ C2##i, double *__restrict__ out##i, const FitCtrl *__restrict__ ctrl##i, int slot##i
+template <int U, int NC>
+__global__ void __launch_bounds__(256) k_cox_score1p_mc(const double *__restrict__ X, long ld, int p, int nrb,
+                                                        COX_MC_CHAIN_ARGS(0), COX_MC_CHAIN_ARGS(1), COX_MC_CHAIN_ARGS(2),
+                                                        COX_MC_CHAIN_ARGS(3), int *__restrict__ ran) {
+  constexpr int RW = 16, COLS = 64, RS = RW + 1, NSEG = RW / 2, CPI = 64 / NSEG, NIT = COLS / CPI;
+  __shared__ double tile[4][COLS * RS];
+  __shared__ __align__(16) double vecs[4][NC][RW][4];  // per wave and chain: (theta, u, v, c2) of the sub-tile's rows
+  struct Chains {  // (indexed by unrolled constants only)
+    const double *TH[4], *CU[4], *CV[4], *C2[4];
+    double *out[4];
+    const FitCtrl *ctrl[4];
+    int slot[4];
+  };
+  const Chains a = {{TH0, TH1, TH2, TH3}, {CU0, CU1, CU2, CU3}, {CV0, CV1, CV2, CV3}, {C20, C21, C22, C23},
+                    {out0, out1, out2, out3}, {ctrl0, ctrl1, ctrl2, ctrl3}, {slot0, slot1, slot2, slot3}};
+  bool on[NC];
+  int na = 0;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const FitCtrl *ct = a.ctrl[c];
+    on[c] = ct == nullptr || (!ct->done && ct->l == a.slot[c] - 1);
+    na += on[c] ? 1 : 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ran != nullptr) *ran = na;
+  if (na == 0) return;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long wid = (long)blockIdx.x * 4 + wv;
+  const int ncg = (p + COLS - 1) / COLS;
+  const long cg = wid % ncg;
+  const int rb = (int)(wid / ncg);
+  if (cg >= ncg || rb >= nrb) return;
+  const int j0 = (int)cg * COLS;
+  double loc[NC], g1[NC], g2[NC], p1[NC], p2[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) loc[c] = g1[c] = g2[c] = p1[c] = p2[c] = 0.0;
+  constexpr int NSUB = 128 * U / RW;
+  const long rbase = (long)rb * (128 * U);
+  const int c4 = lane / NSEG, seg = lane % NSEG;
+  // the sub-tile's rows of the chains' four n-vectors travel WITH the tile: lane l < 32 brings rows 2 (l % 8), + 1 of
+  // vector l / 8 of every chain (one 16-byte load per chain), stored row-major (theta, u, v, c2) per row, so that the walk
+  // reads a row's four values with two broadcast ds_read_b128 -- per-row scalar loads (k_cox_score1p) keep one chain's
+  // walk under the tile's load time but not three (5.3 / 5.8 / 9.4 / 11.8 ms per pass with 1 / 2 / 3 / 4 chains)
+  const int vq = (lane >> 3) & 3, vr = 2 * (lane & 7);
+  d2 nxt[NIT], nv[NC];
+  auto load_sub = [&](int sub) {
+    const long r0 = rbase + (long)sub * RW;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const double *t0 = a.TH[c], *t1 = a.CU[c], *t2 = a.CV[c], *t3 = a.C2[c];
+      const double *src = vq == 0 ? t0 : (vq == 1 ? t1 : (vq == 2 ? t2 : t3));
+      nv[c] = *reinterpret_cast<const d2 *>(src + r0 + vr);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      int j = min(j0 + CPI * it + c4, p - 1);
+      nxt[it] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(X + (size_t)j * ld + r0 + 2 * seg));
+    }
+  };
+  load_sub(NSUB - 1);
+  for (int sub = NSUB - 1; sub >= 0; sub--) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int o = (CPI * it + c4) * RS + 2 * seg;
+      tile[wv][o] = nxt[it].x;
+      tile[wv][o + 1] = nxt[it].y;
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        vecs[wv][c][vr][vq] = nv[c].x;
+        vecs[wv][c][vr + 1][vq] = nv[c].y;
+      }
+    }
+    if (sub > 0) load_sub(sub - 1);  // next tile's loads fly while this one is walked
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // rows outside, chains inside: the NC walks are independent dependency chains (a row's update is three dependent
+    // fp64 operations), so they hide each other's latency, and a row's value is read from the tile once.  Every chain of
+    // the launch is walked -- a chain whose gate is closed costs its arithmetic on whatever its vectors hold and is not
+    // written below.
+    for (int r = RW - 1; r >= 0; r--) {
+      const double x = tile[wv][lane * RS + r];
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const d2 tu = *reinterpret_cast<const d2 *>(&vecs[wv][c][r][0]), vc = *reinterpret_cast<const d2 *>(&vecs[wv][c][r][2]);
+        const double th = tu.x, u = tu.y, v = vc.x, c2 = vc.y;
+        loc[c] = fma(th, x, loc[c]);
+        g1[c] = fma(x, v, g1[c]);
+        g2[c] = fma(u * x, x, g2[c]);
+        const double m = c2 * loc[c];
+        p1[c] += m;
+        p2[c] = fma(m, loc[c], p2[c]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const size_t plane = (size_t)nrb * p;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    if (!on[c]) continue;
+    double *out = a.out[c];
+    if (j0 + lane < p) {
+      const size_t o = (size_t)rb * p + j0 + lane;
+      out[o] = loc[c];
+      out[plane + o] = p1[c];
+      out[2 * plane + o] = p2[c];
+      out[3 * plane + o] = g1[c];
+      out[4 * plane + o] = g2[c];
+    }
+    if (cg == 0) {  // P0 of this row block, by the wave of its first column group (fixed order)
+      double p0 = 0.0;
+      for (int r = lane; r < 128 * U; r += 64) p0 += a.C2[c][rbase + r];
+      p0 = wave_sum(p0);
+      if (lane == 0) out[5 * plane + rb] = p0;
+    }
+  }
+}
+
 // Folds the row blocks of k_cox_score1p's sums (carry in block order).  A block = 64 columns x 8 chunks of row blocks
 // (one wave per chunk; a thread walks ITS chunk of ITS column from the bottom); inside a chunk the carry is
 // car = off + lc with off = the total of the later chunks, so a chunk leaves A = sum [P2 + lc (2 P1 + lc P0)],
@@ -1224,6 +1352,37 @@ hipError_t launch_cox_state(const double *X, long ld, int n, const double *y, co
 
 static int g_cox_score_variant = 1;  // the wave -> (column group, row block) map (1 = round 4, 0 = round 3)
 void cox_score_set_variant(int v) { g_cox_score_variant = v & 1; }
+
+// the one-pass Cox score of up to COX_MC_MAX chains in ONE pass over X (k_cox_score1p_mc)
+template <int U>
+static hipError_t launch_cox_score1p_mc_u(const double *X, long ld, int p, int nrb, const CoxMc &a, hipStream_t st) {
+  const long nw = (long)nrb * ((p + 63) / 64);
+  const int nb = (int)((nw + 3) / 4);
+#define COX_MC_PASS(i) a.TH[i], a.CU[i], a.CV[i], a.C2[i], a.out[i], a.ctrl[i], a.slot[i]
+#define COX_MC_GO(NCC)                                                                                                \
+  hipLaunchKernelGGL((k_cox_score1p_mc<U, NCC>), dim3(nb), dim3(256), 0, st, X, ld, p, nrb, COX_MC_PASS(0), COX_MC_PASS(1), \
+                     COX_MC_PASS(2), COX_MC_PASS(3), a.ran)
+  switch (a.nc) {
+    case 1: COX_MC_GO(1); break;
+    case 2: COX_MC_GO(2); break;
+    case 3: COX_MC_GO(3); break;
+    default: COX_MC_GO(4); break;
+  }
+#undef COX_MC_GO
+#undef COX_MC_PASS
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+hipError_t launch_cox_score1p_mc(const double *X, long ld, int p, int U, int nrb, const CoxMc &a, hipStream_t st) {
+  if (a.nc < 1 || a.nc > COX_MC_MAX) return hipErrorInvalidValue;
+  switch (U) {
+    case 8: return launch_cox_score1p_mc_u<8>(X, ld, p, nrb, a, st);
+    case 4: return launch_cox_score1p_mc_u<4>(X, ld, p, nrb, a, st);
+    case 2: return launch_cox_score1p_mc_u<2>(X, ld, p, nrb, a, st);
+    default: return launch_cox_score1p_mc_u<1>(X, ld, p, nrb, a, st);
+  }
+}
 
 hipError_t launch_cox_score_pass(const double *X, long ld, int p, int U, int nrb, CoxBufs cb, double *part,
                                  double *part2, const FitCtrl *ctrl, int slot, hipStream_t st) {

@@ -201,19 +201,51 @@ __global__ void __launch_bounds__(256) k_xtv(const double *__restrict__ X, long 
 // second accumulator two chains are summed at a time: their dependent shuffle chains (6 ds_bpermute steps each) overlap.
 // Gate per chain like k_xtv's; a launch whose chains have all converged falls through after the gate loads.
 // ------------------------------------------------------------------------------------------
+// cross-lane moves of a double on the vector ALU (no LDS): a DPP row operation on both halves, and gfx950's lane swaps
+template <int CTRL>
+__device__ __forceinline__ double xl_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second: the sum of the two
+// results is a[l] + a[l + 32] in the lower half and b[l - 32] + b[l] in the upper half
+__device__ __forceinline__ double xl_add_swap32(double a, double b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+// v_permlane16_swap exchanges the odd rows (of 16 lanes) of its first operand with the even rows of its second: even rows
+// end with a[l] + a[l + 16], odd rows with b[l - 16] + b[l]
+__device__ __forceinline__ double xl_add_swap16(double a, double b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const auto rl = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+  return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+
 constexpr int XTV_MC_CPW = 32;    // columns per wave
 constexpr int XTV_MC_WAVES = 16;  // waves per block (512 columns)
 
 template <int U, bool TWO>
 __global__ void __launch_bounds__(64 * XTV_MC_WAVES) k_xtv_mc(const double *__restrict__ X, long ld, int p, int nrb, XtvMc a) {
-  extern __shared__ double sv[];  // [active chain][TWO ? 2 : 1][128 * U]
-  __shared__ int act[XTV_MC_MAX + 2];
+  // (16-byte alignment of the slices: behind a 40-byte static array the dynamic region started 8 bytes off and every
+  // ds_read_b128 was a misaligned access -- 15 B/clock of LDS bandwidth per compute unit instead of 128)
+  extern __shared__ __align__(16) double sv[];  // [active chain][TWO ? 2 : 1][128 * U]
+  __shared__ __align__(16) int act[XTV_MC_MAX + 4];
+  __shared__ __align__(16) const double *vsrc[2 * XTV_MC_MAX];  // where every staged slice comes from
   constexpr int RB = 128 * U, VPC = TWO ? 2 : 1, NT = 64 * XTV_MC_WAVES;
   if (threadIdx.x == 0) {
     int na = 0;
     for (int c = 0; c < a.nc; c++) {
       const FitCtrl *ct = a.ctrl[c];
-      if (ct == nullptr || (!ct->done && ct->l == a.slot[c] - 1)) act[na++] = c;
+      if (ct == nullptr || (!ct->done && ct->l == a.slot[c] - 1)) {
+        vsrc[na * VPC] = a.v[c];
+        if (TWO) vsrc[na * VPC + 1] = a.v2[c];
+        act[na++] = c;
+      }
     }
     act[XTV_MC_MAX] = na;
     if (blockIdx.x == 0 && a.ran != nullptr) *a.ran = na;
@@ -224,11 +256,22 @@ __global__ void __launch_bounds__(64 * XTV_MC_WAVES) k_xtv_mc(const double *__re
   const int nsp = (p + XTV_MC_WAVES * XTV_MC_CPW - 1) / (XTV_MC_WAVES * XTV_MC_CPW);
   const int rb = blockIdx.x / nsp, sp = blockIdx.x - rb * nsp;
   const long rbase = (long)rb * RB;
-  for (int i = threadIdx.x; i < na * VPC * (RB / 2); i += NT) {
-    const int w = i / (RB / 2), o = i - w * (RB / 2);
-    const int c = act[w / VPC];
-    const double *src = (TWO && (w & 1)) ? a.v2[c] : a.v[c];
-    reinterpret_cast<d2 *>(sv)[i] = *reinterpret_cast<const d2 *>(src + rbase + 2 * o);
+  {
+    // stage the slices: all of a thread's loads first (independent, in flight together), then its LDS stores
+    constexpr int PER = RB / 2, SPT = NT / PER;            // d2 per slice; slices per sweep of the block
+    constexpr int SWEEPS = (2 * XTV_MC_MAX + SPT - 1) / SPT;
+    const int sl0 = threadIdx.x / PER, o = threadIdx.x - sl0 * PER, nsl = na * VPC;
+    d2 tmp[SWEEPS];
+#pragma unroll
+    for (int k = 0; k < SWEEPS; k++) {
+      const int sl = sl0 + k * SPT;
+      if (sl < nsl) tmp[k] = *reinterpret_cast<const d2 *>(vsrc[sl] + rbase + 2 * o);
+    }
+#pragma unroll
+    for (int k = 0; k < SWEEPS; k++) {
+      const int sl = sl0 + k * SPT;
+      if (sl < nsl) reinterpret_cast<d2 *>(sv)[(size_t)sl * PER + o] = tmp[k];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -238,11 +281,17 @@ __global__ void __launch_bounds__(64 * XTV_MC_WAVES) k_xtv_mc(const double *__re
   const bool up = (lane & 32) != 0;
   const bool writer = (lane & 31) == 0;
   // sums of one chain's slice against the two columns in registers, folded over the lanes: column 0 ends in the lower
-  // half of the wave, column 1 in the upper half
+  // half of the wave, column 1 in the upper half.  The same pairs as k_xtv's butterfly (offsets 32, 16, 8, 4, 2, 1), but
+  // on the vector ALU alone: gfx950's v_permlane32_swap / v_permlane16_swap for the two steps across rows of 16 lanes,
+  // DPP row operations for the four inside a row -- the LDS pipeline is left to the slices' reads (12 ds_bpermute_b32
+  // per chain and pair of columns otherwise: measured 2-4 % slower at 8 chains, tools/xtv_multi_bench.py).
   auto fold = [&](double c0, double c1) {
-    double s = (up ? c1 : c0) + __shfl_xor(up ? c0 : c1, 32);
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    double s = xl_add_swap32(c0, c1);          // lanes < 32: c0[l] + c0[l + 32]; lanes >= 32: c1[l - 32] + c1[l]
+    s = xl_add_swap16(s, s);                   // + the value 16 lanes away
+    s += xl_dpp<0x128>(s);                     // xor 8: row_ror:8
+    s += xl_dpp<0x1b>(xl_dpp<0x141>(s));       // xor 4 = (xor 7 = row_half_mirror) then (xor 3 = quad_perm [3,2,1,0])
+    s += xl_dpp<0x4e>(s);                      // xor 2: quad_perm [2,3,0,1]
+    s += xl_dpp<0xb1>(s);                      // xor 1: quad_perm [1,0,3,2]
     return s;
   };
   for (int g = 0; g < XTV_MC_CPW && j0 + g < p; g += 2) {

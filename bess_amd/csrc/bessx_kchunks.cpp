@@ -20,10 +20,48 @@
 
 namespace bessx {
 
+// The chains' shared passes over X (round 6; the protocol is bessx_sync.h: PassRendezvous).  The chunk chains of the
+// streaming forms -- LM with score_mode 1, logistic, Poisson, Cox -- need X^T v (or the Cox score) for a vector of their own
+// at every PDAS iteration.  Issued per chain every one of them streams the whole of X (round 5: 153 / 220 / 241 / 251
+// passes per path of the four full-size configs, the passes of three or four chains side by side at 0.44-0.65 of the HBM
+// roof each).  Here a chain hands its vector set to the owner's next MULTI-CHAIN launch (k_xtv_mc, k_cox_score1p_mc: X is
+// loaded once, every active chain's sums are formed from it, bitwise those of a launch of its own) on the PASS STREAM:
+// the launch waits for an event every participant records on its own stream (its vectors are ready), every participant's
+// stream waits for the event recorded behind the launch.  A pass then serves every chain that is at its score pass --
+// the chains fall into step at the passes, and the count of chains is no longer bounded by what a pass per chain costs.
+// Two GROUPS of chains alternate on the pass stream (chain r belongs to group r mod 2; test hook kchunks_pass_groups=1|2):
+// while one group's pass runs, the other group's chains do what lies between two passes -- selection, Gram, solve,
+// residual, the IRLS / Newton steps, the host's read-back and the launches of the next slot -- so the passes follow each
+// other back to back instead of waiting for the slowest chain of a single lock-step.
+struct SharedPass {
+  static constexpr int GROUPS = 2;
+  PassRendezvous rdv[GROUPS];
+  int groups = 1;      // groups of this path
+  bool on = false;     // this path's chains share their passes
+  int kind = 0;        // 0: k_xtv_mc, one vector; 1: k_xtv_mc, two vectors (GLM); 2: k_cox_score1p_mc
+  int cap = XTV_MC_MAX;
+  hipStream_t st = nullptr;
+  std::mutex launch_mu;  // one group's (waits, launch, records) on the pass stream at a time
+  hipEvent_t ev_in[GROUPS][XTV_MC_MAX] = {};
+  static constexpr int RING = 8;
+  hipEvent_t ev_out[GROUPS][RING] = {};
+  XtvMc xq[GROUPS] = {};
+  CoxMc cq[GROUPS] = {};
+  int rc = 0;  // first launch error (reported by the path)
+  // statistics: HIP events around every launch on the pass stream, and how many gates were open in it
+  bool timing = false;
+  std::vector<hipEvent_t> tev;
+  size_t tused = 0;
+  int *ran = nullptr;  // device, RAN_CAP ints
+  static constexpr int RAN_CAP = 8192;
+  int launches = 0;
+};
+
 struct KChains {
   std::vector<bessx_session *> ctx;
   FoldPool pool;
   bool pool_started = false;
+  SharedPass sp;
   FillRendezvous rdv;  // the fill rendezvous (bessx_sync.h: built and hammered under ThreadSanitizer, tools/tsan)
   // candidates a chunk chain has stored so far / whether it has ended (read by its predecessor's early stitch)
   std::atomic<int> progress[10];
@@ -115,6 +153,196 @@ unsigned long long kchains_generation(bessx_session *c) { return c->kch_owner->k
 
 static void kchains_round(KChains *k, int chains, bool staged = false) { k->rdv.round(chains, staged); }
 
+// ---- shared passes -------------------------------------------------------------------------------------------------
+static void sp_free(SharedPass &sp) {
+  if (sp.st) (void)hipStreamDestroy(sp.st);
+  for (auto &grp : sp.ev_in)
+    for (auto &e : grp)
+      if (e) (void)hipEventDestroy(e);
+  for (auto &grp : sp.ev_out)
+    for (auto &e : grp)
+      if (e) (void)hipEventDestroy(e);
+  for (auto &e : sp.tev) (void)hipEventDestroy(e);
+  if (sp.ran) (void)hipFree(sp.ran);
+  sp.st = nullptr;
+  sp.ran = nullptr;
+  sp.tev.clear();
+  for (auto &grp : sp.ev_in)
+    for (auto &e : grp) e = nullptr;
+  for (auto &grp : sp.ev_out)
+    for (auto &e : grp) e = nullptr;
+}
+
+// stream, events and the gate counters of the pass stream; false: not to be had (the chains then keep their own passes)
+static bool sp_prepare(bessx_session *s, SharedPass &sp) {
+  if (sp.st) return true;
+  if (!ctx_stream_create(s->device, &sp.st)) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&sp.st, hipStreamNonBlocking, hi) != hipSuccess) {
+      (void)hipGetLastError();
+      sp.st = nullptr;
+      return false;
+    }
+  }
+  bool ok = true;
+  for (auto &grp : sp.ev_in)
+    for (auto &e : grp) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  for (auto &grp : sp.ev_out)
+    for (auto &e : grp) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void **>(&sp.ran), SharedPass::RAN_CAP * sizeof(int)) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    sp_free(sp);
+    return false;
+  }
+  return true;
+}
+
+// (under the rendezvous' lock) launch the n requests collected as batch g
+static void sp_launch(bessx_session *o, SharedPass &sp, int grp, int n, unsigned long long g) {
+  std::lock_guard<std::mutex> lk(sp.launch_mu);
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < n && e == hipSuccess; i++) e = hipStreamWaitEvent(sp.st, sp.ev_in[grp][i], 0);
+  int *ran = nullptr;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (sp.timing && sp.launches < SharedPass::RAN_CAP) {
+    while (sp.tev.size() < sp.tused + 2) {
+      hipEvent_t ev = nullptr;
+      if (hipEventCreate(&ev) != hipSuccess) break;
+      sp.tev.push_back(ev);
+    }
+    if (sp.tev.size() >= sp.tused + 2) {
+      ea = sp.tev[sp.tused];
+      eb = sp.tev[sp.tused + 1];
+      ran = sp.ran + sp.tused / 2;
+      sp.tused += 2;
+    }
+  }
+  if (ea && e == hipSuccess) e = hipEventRecord(ea, sp.st);
+  if (e == hipSuccess) {
+    if (sp.kind == 2) {
+      sp.cq[grp].nc = n;
+      sp.cq[grp].ran = ran;
+      e = launch_cox_score1p_mc(o->X, o->ld, o->p, o->U, o->nrb, sp.cq[grp], sp.st);
+    } else {
+      sp.xq[grp].nc = n;
+      sp.xq[grp].ran = ran;
+      e = launch_xtv_mc(o->X, o->ld, o->p, o->U, sp.xq[grp], sp.kind == 1, sp.st);
+    }
+  }
+  if (eb && e == hipSuccess) e = hipEventRecord(eb, sp.st);
+  if (e == hipSuccess) e = hipEventRecord(sp.ev_out[grp][g % SharedPass::RING], sp.st);
+  sp.launches++;
+  if (e != hipSuccess && sp.rc == 0) {
+    sp.rc = (int)e;
+    (void)hipGetLastError();
+  }
+}
+
+bool shared_pass_applies(const bessx_session *c) {
+  return c && c->kch_owner && c->kch_owner->kch && c->kch_owner->kch->sp.on && c->kch_sp_member;
+}
+
+// The pass over X of slot `slot` of chain context c's fit: its vectors go into the owner's next multi-chain launch.
+// Returns when that launch is queued and c's stream is ordered behind it.  v2 / part2: the second accumulator (GLM);
+// cox != nullptr: the one-pass Cox score (part = its output planes).
+int shared_pass_submit(bessx_session *c, const double *v, const double *v2, double *part, double *part2,
+                       const CoxBufs *cox, const FitCtrl *ctrl, int slot) {
+  bessx_session *o = c->kch_owner;
+  SharedPass &sp = o->kch->sp;
+  const int grp = c->kch_sp_group;
+  hipError_t e_in = hipSuccess, e_out = hipSuccess;
+  sp.rdv[grp].submit(
+      [&](int i) {
+        if (cox) {
+          CoxMc &q = sp.cq[grp];
+          q.TH[i] = cox->TH;
+          q.CU[i] = cox->CU;
+          q.CV[i] = cox->CV;
+          q.C2[i] = cox->C2;
+          q.out[i] = part;
+          q.ctrl[i] = ctrl;
+          q.slot[i] = slot;
+        } else {
+          XtvMc &q = sp.xq[grp];
+          q.v[i] = v;
+          q.v2[i] = v2;
+          q.part[i] = part;
+          q.part2[i] = part2;
+          q.ctrl[i] = ctrl;
+          q.slot[i] = slot;
+        }
+        e_in = hipEventRecord(sp.ev_in[grp][i], c->st);  // everything this chain has queued so far: its vectors are ready
+      },
+      [&](int n, unsigned long long g) { sp_launch(o, sp, grp, n, g); },
+      [&](unsigned long long g) { e_out = hipStreamWaitEvent(c->st, sp.ev_out[grp][g % SharedPass::RING], 0); });
+  if (e_in != hipSuccess || e_out != hipSuccess || sp.rc != 0)
+    return fail(BESSX_ERR_HIP, std::string("shared pass over X: ") +
+                                   hipGetErrorString(e_in != hipSuccess ? e_in : (e_out != hipSuccess ? e_out : (hipError_t)sp.rc)));
+  return 0;
+}
+
+// a chain context's thread stops / starts taking part in the shared passes (end of its job; a wait that is not for the
+// device).  Leaving while everybody else waits launches their batch.
+static void sp_leave(bessx_session *c) {
+  if (!c->kch_sp_member) return;
+  bessx_session *o = c->kch_owner;
+  SharedPass &sp = o->kch->sp;
+  c->kch_sp_member = false;
+  const int grp = c->kch_sp_group;
+  sp.rdv[grp].leave([&](int n, unsigned long long g) { sp_launch(o, sp, grp, n, g); });
+}
+
+static void sp_join(bessx_session *c) {
+  SharedPass &sp = c->kch_owner->kch->sp;
+  if (!sp.on || c->kch_sp_member) return;
+  sp.rdv[c->kch_sp_group].join();
+  c->kch_sp_member = true;
+}
+
+// a round of `members` chain threads starts (before any of them runs)
+static void sp_round(KChains *k, const std::vector<bessx_session *> &who) {
+  SharedPass &sp = k->sp;
+  for (bessx_session *c : k->ctx) c->kch_sp_member = false;
+  if (!sp.on) return;
+  int cnt[SharedPass::GROUPS] = {};
+  for (size_t i = 0; i < who.size(); i++) {
+    who[i]->kch_sp_member = true;
+    who[i]->kch_sp_group = (int)(i % (size_t)sp.groups);
+    cnt[who[i]->kch_sp_group]++;
+  }
+  for (int g = 0; g < SharedPass::GROUPS; g++) sp.rdv[g].reset(cnt[g]);
+}
+
+// after the path (every chain's stream is idle): the launches' times into the session's score-pass statistics
+static int sp_collect(bessx_session *s, SharedPass &sp) {
+  if (!sp.st) return 0;
+  HIPX(hipStreamSynchronize(sp.st));
+  const int nl = (int)(sp.tused / 2);
+  if (sp.timing && nl > 0) {
+    std::vector<int> ran((size_t)nl, 0);
+    HIPX(hipMemcpy(ran.data(), sp.ran, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < nl; i++) {
+      if (ran[(size_t)i] <= 0) continue;  // (every gate closed: the launch fell through)
+      float ms = 0.f;
+      HIPX(hipEventElapsedTime(&ms, sp.tev[(size_t)2 * i], sp.tev[(size_t)2 * i + 1]));
+      s->k1_seconds += (double)ms * 1e-3;
+      s->k1_launches += 1;
+      s->k1_bytes += 8.0 * (double)s->n * (double)s->p;
+      s->sp_chain_slots += ran[(size_t)i];
+    }
+  }
+  s->sp_launches += sp.launches;
+  for (auto &r : sp.rdv) {
+    s->sp_partial += (long long)r.partial;
+    r.partial = 0;
+  }
+  sp.tused = 0;
+  sp.launches = 0;
+  return 0;
+}
+
 static void kchains_leave(KChains *k, bool failed) { k->rdv.leave(failed); }
 
 void kchains_free(bessx_session *s) {
@@ -122,6 +350,7 @@ void kchains_free(bessx_session *s) {
   KChains *k = s->kch;
   if (k->pool_started) k->pool.stop();
   mc_free(k);
+  sp_free(k->sp);
   if (s->kch_slot_w) (void)hipFree(s->kch_slot_w);
   s->kch_slot_w = nullptr;
   if (s->kch_fill_st) (void)hipStreamDestroy(s->kch_fill_st);
@@ -155,10 +384,16 @@ static int chains_for(const bessx_session *s, int ns, bool link = false) {
       // iteration is a pass over X, and one chain's selection, Gram panel, solve and residual run beside another's pass
       // (tools/streaming_chains_bench.py, configs[1]: 190.1 ms as one chain, 168.7 / 173.5 / 162.3 ms with 2 / 3 / 4)
       C = (ns >= 48 && (double)s->n * s->p >= 1e8) ? (queues >= 8 ? 4 : 2) : 1;
-    else
+    else {
       // logistic / Poisson / Cox: one chain's IRLS or Newton steps (small kernels) run beside another's pass over X
       // (tools/glm_two_chains_probe.py: logistic at full size 155 -> 120 ms with 3 chains, Cox 1.86 -> 1.60 s)
       C = (ns >= 48 && (double)s->n * s->p >= 1e8) ? (queues >= 8 ? 3 : 2) : 1;
+      // round 6, shared passes (a pass serves every chain that is at its score pass; tools/shared_pass_sweep.py, full
+      // size): logistic 3 / 4 / 6 / 8 chains 85-90 / 90 / 87.5 / 83 ms, Poisson 92 / 90 / 82 / 84 ms per path -- 6; Cox
+      // 2 / 3 / 4 chains 1.21 / 1.04 / 1.11 s -- 3
+      const char *esh = test_hook("kchunks_shared_pass");
+      if (C == 3 && (!esh || std::atoi(esh) != 0) && s->model_type != 4 && ns >= 96) C = 6;
+    }
   }
   return std::max(1, std::min(std::min(C, 8), ns / 8));
 }
@@ -670,10 +905,15 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   if (s->model_type == 1) {
     for (int r = 1; r <= C; r++) bounds[r] = (int)((long)ns * r / C);
   } else {
+    // (chains that share their passes advance in step, one PDAS iteration per shared pass: equal lengths -- with the
+    // weights of round 5 the first chunk, the longest, ended 30 % after the others; test hook kchunks_len_div)
+    const char *esh = test_hook("kchunks_shared_pass");
+    double wdiv = (!esh || std::atoi(esh) != 0) ? 1e9 : 160.0;
+    if (const char *ew = test_hook("kchunks_len_div")) wdiv = std::max(1.0, std::atof(ew));
     double tot = 0.0;
     std::vector<double> cum((size_t)ns + 1, 0.0);
     for (int i = 0; i < ns; i++) {
-      tot += 1.0 + (double)seq[i] / 160.0;
+      tot += 1.0 + (double)seq[i] / wdiv;
       cum[(size_t)i + 1] = tot;
     }
     for (int r = 1; r < C; r++) {
@@ -843,6 +1083,22 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
   const int merged = pipeline ? -1 : mc_run_chunks(s, k, seq, ns, C, bounds, run, lambda, ic_type, width);
   if (merged > 0) return merged;
   kchains_round(k, C + (pipeline ? 1 : 0), staged);
+  {
+    // the chains of the streaming forms share their passes over X (SharedPass above; test hook kchunks_shared_pass=0:
+    // a pass per chain, as in round 5)
+    SharedPass &sp = k->sp;
+    const char *eh = test_hook("kchunks_shared_pass");
+    sp.kind = s->model_type == 1 ? 0 : (s->model_type == 4 ? 2 : 1);
+    sp.cap = sp.kind == 2 ? COX_MC_MAX : XTV_MC_MAX;
+    sp.groups = C >= 4 ? 2 : 1;
+    if (const char *eg = test_hook("kchunks_pass_groups")) sp.groups = std::max(1, std::min(SharedPass::GROUPS, std::atoi(eg)));
+    sp.on = !lm_cov && C >= 2 && (C + sp.groups - 1) / sp.groups <= sp.cap && (!eh || std::atoi(eh) != 0) &&
+            (sp.kind != 2 || s->cox.one_pass) && sp_prepare(s, sp);
+    sp.timing = s->timing;
+    sp.rc = 0;
+    for (auto &r : sp.rdv) r.timeout_s = std::min(0.05, s->wait_deadline_s);
+    sp_round(k, std::vector<bessx_session *>(k->ctx.begin(), k->ctx.begin() + C));
+  }
   struct Starts {  // (pipeline) which coarse fits are done
     std::mutex mu;
     std::condition_variable cv;
@@ -870,6 +1126,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     ChunkRun &q = run[(size_t)r], &t = early_st[(size_t)r];
     const int want = std::min(q.hi - q.lo, budget_of(r));
     const auto t0 = std::chrono::steady_clock::now();
+    sp_leave(c);  // (this wait is not for the device: the other chains' shared passes must not wait for this thread)
     while (k->progress[r].load(std::memory_order_acquire) < want && k->ended[r].load(std::memory_order_acquire) == 0) {
       kchains_safe_point(c);  // (a chain that waits for every other chain to stand still must not wait for this one)
       std::this_thread::sleep_for(std::chrono::microseconds(20));
@@ -898,6 +1155,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     t.chain.last_val = t.last_val.data();
     t.chain.last_cap = width;
     kchains_log(c, "early stitch of the next chunk", q.lo, rows);
+    sp_join(c);
     t.rc = context_begin(c, true);  // (its last fit's model IS the model the refit starts from)
     if (t.rc == 0) t.rc = sequential_path(c, seq + q.lo, want, &lambda, 1, ic_type, 0, &t.res, &t.chain);
     if (t.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) t.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
@@ -990,6 +1248,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     kchains_log(c, "chunk ends", q.lo, q.hi);
     if (r < 10) k->ended[r].store(q.rc ? 2 : 1, std::memory_order_release);
     if (early_on && q.rc == 0 && r + 1 < C) early_stitch(r + 1);
+    sp_leave(c);
     kchains_leave(k, q.rc != 0);
   };
   if (merged < 0) {
@@ -1054,6 +1313,7 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
       if (t.rc == 0 && hipStreamSynchronize(c->st) != hipSuccess) t.rc = fail(BESSX_ERR_HIP, "chunk chain: stream");
       if (t.rc) t.err = g_err;
       t.fits = c->n_fits;
+      sp_leave(c);
       kchains_leave(k, t.rc != 0);
     };
     int active = 0;
@@ -1061,6 +1321,12 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     if (active > 0) {
       if (int rc = writer_map_in_step()) return rc;
       kchains_round(k, active, staged);
+      {
+        std::vector<bessx_session *> who;
+        for (int r = 1; r < C; r++)
+          if (need[r] && !have[(size_t)r]) who.push_back(k->ctx[r]);
+        sp_round(k, who);
+      }
       if (!k->pool.run(stitch_job, s->wait_deadline_s)) return fail(BESSX_ERR_HIP, "chunk chains: a host thread did not come back");
     }
     bool any = false;
@@ -1135,6 +1401,10 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     s->kch_giveups++;
     if (s->kpath_chains == 0) s->kch_auto_off = true;
   }
+  for (bessx_session *c : k->ctx) c->kch_sp_member = false;
+  k->sp.on = false;
+  if (int rc = sp_collect(s, k->sp)) return rc;
+  if (k->sp.rc) return fail(BESSX_ERR_HIP, std::string("shared pass over X: ") + hipGetErrorString((hipError_t)k->sp.rc));
   const int R = (int)run.size();  // chunks of the result (fewer than C after a give-up)
   if (k->log_on) {
     kchains_log(s, "path ends", 0, 0);

@@ -1881,6 +1881,9 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 26: return (long long)(1e9 * s->panel_w_seconds[0]);
     case 27: return s->panel_w_launches[1];
     case 28: return (long long)(1e9 * s->panel_w_seconds[1]);
+    case 29: return s->sp_launches;
+    case 30: return s->sp_chain_slots;
+    case 31: return s->sp_partial;
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

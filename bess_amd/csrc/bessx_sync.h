@@ -242,4 +242,65 @@ struct FillRendezvous {
   }
 };
 
+// PassRendezvous -- chunk chains that SHARE their passes over X (round 6).  Every chain of the streaming forms needs
+// X^T v for a vector of its own at every PDAS iteration; instead of one launch per chain -- each streaming the whole of X
+// -- the chains hand their vector sets to the next multi-chain launch (k_xtv_mc / k_cox_score1p_mc).  A member that
+// submits blocks until the batch it went into has been LAUNCHED (not run: the launch is ordered after every
+// participant's earlier work by events); the batch is launched by the member that completes it (arrived == members), by a
+// member that leaves while everybody else is waiting, or -- after `timeout_s` -- by a waiting member with whoever is
+// there (a straggler then gets a launch of its own: slower, same sums).  What touches the device is handed in:
+//   add(i)        under the lock: put the caller's request into place i of the batch
+//   launch(n, g)  under the lock: launch the n requests of batch number g
+//   after(g)      under the lock, in every participant of batch g after its launch: order the caller's stream behind it
+// Invariants: a member has at most one request in flight; arrived <= members at every launch decision; batch numbers
+// are handed out in launch order.
+struct PassRendezvous {
+  std::mutex mu;
+  std::condition_variable cv;
+  int members = 0, arrived = 0;
+  unsigned long long gen = 0;
+  double timeout_s = 0.05;
+  unsigned long long partial = 0;  // batches launched on a timeout (statistics)
+
+  void reset(int m) {
+    std::lock_guard<std::mutex> lk(mu);
+    members = m;
+    arrived = 0;
+  }
+  template <class Launch>
+  void fire(Launch &launch) {  // (under the lock)
+    launch(arrived, gen);
+    arrived = 0;
+    gen++;
+    cv.notify_all();
+  }
+  template <class Add, class Launch, class After>
+  void submit(Add add, Launch launch, After after) {
+    std::unique_lock<std::mutex> lk(mu);
+    add(arrived);
+    arrived++;
+    const unsigned long long mine = gen;
+    if (arrived >= members) {
+      fire(launch);
+    } else {
+      const bool ok = bessx_timed_wait(cv, lk, timeout_s, [&] { return gen != mine; });
+      if (!ok && gen == mine) {
+        partial++;
+        fire(launch);
+      }
+    }
+    after(mine);
+  }
+  template <class Launch>
+  void leave(Launch launch) {
+    std::lock_guard<std::mutex> lk(mu);
+    members--;
+    if (arrived > 0 && arrived >= members) fire(launch);
+  }
+  void join() {
+    std::lock_guard<std::mutex> lk(mu);
+    members++;
+  }
+};
+
 #endif  // BESSX_SYNC_H

@@ -387,7 +387,8 @@ int bessx_op_xtv_bench(int n, int p, int variant, int repeats, double *gbps, dou
 /* ... and the multi-chain score pass: nc vector sets per launch (two != 0: with the second accumulator); GB/s counts the
  * 8*n*p bytes of X once per launch. */
 int bessx_op_xtv_multi_bench(int n, int p, int nc, int two, int repeats, double *gbps, double *avg_ms);
-/* The same for the one-pass Cox score kernel (k_cox_score1p, 8*n*p bytes per launch); variant 1 = the one the solver runs (wave map of round 4), 0 = round 3. */
+/* The same for the one-pass Cox score kernel (k_cox_score1p, 8*n*p bytes per launch); variant 1 = the one the solver runs
+ * (wave map of round 4), 0 = round 3; 10 + nc (nc = 1..4) = the multi-chain kernel k_cox_score1p_mc with nc vector sets. */
 int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbps, double *avg_ms);
 /* Device-to-device streaming copy rate in GB/s (read+write bytes / time): the measured HBM ceiling
  * quoted next to the spec peak in bench.py. */

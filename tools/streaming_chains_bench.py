@@ -35,4 +35,6 @@ for C in [1] + [int(v) for v in sys.argv[1:]]:
                       "whole_path_frac_of_hbm": round(st["launches"] / 3.0 * 4e9 / min(ts) / 8e12, 3),
                       "supports_equal": int(np.sum([np.array_equal(out["cand_support"][k], single["cand_support"][k]) for k in range(200)])),
                       "iterations_equal": int(np.sum(out["cand_iters"] == single["cand_iters"])),
-                      "stitch_refits": cnt["kpath_stitch_refits"], "chains_last_path": cnt["kpath_chains_last_path"]}), flush=True)
+                      "stitch_refits": cnt["kpath_stitch_refits"], "chains_last_path": cnt["kpath_chains_last_path"],
+                      "shared_pass_launches": cnt["shared_pass_launches"], "shared_pass_chain_slots": cnt["shared_pass_chain_slots"],
+                      "shared_pass_partial_batches": cnt["shared_pass_partial_batches"]}), flush=True)
