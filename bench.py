@@ -85,12 +85,15 @@ def parse_args(argv=None):
                          "mapping the one rank 0 leaves in /dev/shm")
     ap.add_argument("--workload", choices=["lm-seq", "lm-cv-gs", "cox-seq"], default="lm-seq",
                     help="lm-seq = BASELINE configs[1] (the metric); lm-cv-gs = configs[3]; cox-seq = configs[4]")
-    ap.add_argument("--chunk-start", choices=["auto", "cold", "ladder"], default="auto",
+    ap.add_argument("--chunk-start", choices=["auto", "cold", "ladder", "lead"], default="auto",
                     help="N > 1, --shard kpath: how a chunk that does not begin at k = 1 reaches its first sparsity "
                          "level: cold = Algorithm::fit from the empty model at k0; ladder = a warm-start chain up the "
                          "levels k0/8, k0/4, k0/2 first (their candidates are discarded); auto = ladder from k0 = 128 "
                          "(measured on configs[1], tools/coldstart.py: 11.2 vs 12.2 ms at k0 = 176, but 7.9 vs 7.2 ms at "
-                         "k0 = 101)")
+                         "k0 = 101); lead (round 6, LM; what auto means for LM) = every rank first walks the ONE-GPU "
+                         "path's coarse levels below its chunk and the level just below it as lead fits "
+                         "(bessx_path_chain.lead_levels: the ranks repeat each other's few coarse fits, no communication), "
+                         "then its chunk warm from the last lead model as chunk chains")
     ap.add_argument("--prefill", default="0",
                     help="N > 1, --shard kpath, LM covariance form: columns of the cooperative prefill of the Gram column "
                          "caches in front of the chunks (bess_amd.dist.cooperative_prefill: the ranks share the passes "
@@ -611,7 +614,7 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
 
 
 LINE_LIMIT = 6000  # bytes: the driver keeps an 8 KB tail of stdout and parses the LAST line (round 5's 20 KB line: parsed null)
-DETAIL_PATH = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+DETAIL_PATH = os.environ.get("BESSX_BENCH_DETAIL_PATH") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
 
 
 def _round(v, nd=6):
@@ -682,7 +685,8 @@ def compact_line(full):
     if kp:
         line["kpath"] = _pick(kp, ["chunks", "supports_equal_to_single_chain", "of", "best_k_chunked",
                                    "best_k_single_chain", "stitch_refits", "stitch_rounds", "prefill_columns",
-                                   "ic_curve_max_rel_diff_to_single_chain"])
+                                   "ic_curve_max_rel_diff_to_single_chain", "one_gpu_ms_per_path_same_run",
+                                   "speedup_over_one_gpu_same_run", "lead_levels_per_rank", "chunk_start"])
     cv = full.get("cooperative_prefill_variant")
     if cv:
         line["cooperative_prefill_variant"] = _pick(cv, ["value", "ms_per_step", "prefill_columns", "pilot"])
@@ -868,6 +872,13 @@ def main():
 
     prefill, pilot = prefill_policy(args.prefill, args.pilot)
     any_ladder = False
+    coarse_lead = False
+    if kpath and not cox and not prefill and args.chunk_start in ("auto", "lead"):
+        # LM (either score form): lead fits instead of a cold or ladder start (bess_amd.dist.StitchedKPath coarse_lead)
+        coarse_lead = True
+        args.chunk_start = "lead"
+    if kpath and args.chunk_start == "lead" and not coarse_lead:
+        args.chunk_start = "auto"  # (Cox, or with a cooperative prefill: the older rules)
     if kpath:
         k0_last = int(full_seq[bdist.partition(args.kmax, world, world - 1)[0]]) if args.kmax >= world else 0
         any_ladder = args.chunk_start == "ladder" or (args.chunk_start == "auto" and k0_last >= 128 and not cox
@@ -884,7 +895,8 @@ def main():
     rebalance = kpath and not any_ladder and (args.rebalance == "on" or
                                               (args.rebalance == "auto" and world <= 4 and not cox))
     stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev,
-                                   prefill=prefill, pilot=pilot, rebalance=rebalance) if kpath else None
+                                   prefill=prefill, pilot=pilot, rebalance=rebalance and not coarse_lead,
+                                   coarse_lead=coarse_lead) if kpath else None
     for _ in range(args.warmup):
         out = stitched.step() if kpath else sess.sequential_path(seq, ic_type=3)
     sess.enable_kernel_timing(True)
@@ -950,6 +962,13 @@ def main():
                 a, b = bounds[r], bounds[r + 1]
                 chunked[a:b] = allsup[r].reshape(args.kmax, args.kmax)[a:b]
             single = sess.sequential_path(full_seq, ic_type=3)
+            # the same path on ONE GPU of this run (rank 0's device, the other ranks idle): what N ranks are measured against
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for _ in range(3):
+                single = sess.sequential_path(full_seq, ic_type=3)
+            torch.cuda.synchronize()
+            one_gpu_s = (time.time() - t1) / 3
             same = [bool(np.array_equal(chunked[k, :k + 1], single["cand_support"][k, :k + 1])) for k in range(args.kmax)]
             chunk_report = {
                 "chunks": [[int(bounds[r]) + 1, int(bounds[r + 1])] for r in range(world)],
@@ -976,8 +995,12 @@ def main():
                 "stitching": "after its chunk rank r re-fits its first candidates warm from rank r-1's last model until "
                              "a candidate coincides with its chunk's (same support, coefficients to 1e-9); the "
                              "candidates before that point are replaced: the gathered path IS the single chain's",
+                "one_gpu_ms_per_path_same_run": 1e3 * one_gpu_s,
+                "speedup_over_one_gpu_same_run": one_gpu_s / (dt / args.steps),
+                "lead_levels_per_rank": [[int(v) for v in bdist.StitchedKPath(None, full_seq, world, r, coarse_lead=coarse_lead)
+                                          .lead_levels()] for r in range(world)] if coarse_lead else None,
                 "chunk_start": args.chunk_start_option,
-                "chunk_start_meaning": "auto: ladder for chunks beginning at k0 >= 128, else cold; ladder: a chunk beginning at k0 > 1 first climbs the warm-start chain k0/8, k0/4, "
+                "chunk_start_meaning": "auto: LM -- lead fits (the one-GPU path's coarse levels below the chunk, then the level below it, on every rank; no communication); Cox -- ladder for chunks beginning at k0 >= 128, else cold; ladder: a chunk beginning at k0 > 1 first climbs the warm-start chain k0/8, k0/4, "
                                        "k0/2 (timed, candidates discarded); cold: Algorithm::fit from the empty model at k0"}
 
     def roofline_of(stats, cov, widths=None):
@@ -1102,6 +1125,12 @@ def main():
         }
         if chunk_report:
             line["kpath_chunks_vs_single_chain"] = chunk_report
+            # Amdahl's arithmetic of the partition north_star names (X replicated, contiguous chunks of s.list, no data-path
+            # collective): the lead fits' passes over X are repeated by every rank, only the chunk phase divides by N
+            line["kpath_expected_speedup"] = {
+                "measured_this_run": chunk_report["speedup_over_one_gpu_same_run"],
+                "bound": "T1 / (T_replicated + T_chunks / N): the passes over X that fill the Gram column cache are "
+                         "repeated on every rank (DESIGN.md section 6)"}
         if coop_variant:
             line["cooperative_prefill_variant"] = coop_variant
         norm = sess.normalization() if world == 1 else None

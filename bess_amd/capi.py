@@ -72,7 +72,7 @@ class PathChain(ctypes.Structure):
     _fields_ = [("init_idx", _I), ("init_val", _D), ("init_len", _i), ("init_coef0", _d), ("keep_caches", _i),
                 ("stop_support", _I), ("stop_beta", _D), ("stop_rows", _i), ("stop_row_len", _i), ("stop_rtol", _d),
                 ("stopped_at", _i), ("last_idx", _I), ("last_val", _D), ("last_cap", _i), ("last_len", _i),
-                ("last_coef0", _d)]
+                ("last_coef0", _d), ("lead_levels", _I), ("lead_len", _i)]
 
 
 _lib = None
@@ -397,7 +397,8 @@ class Session:
                          seq.size * lam.size, min(self.p, (int(seq.max()) if seq.size else 1) * self._gsize_max))
 
     def sequential_path_chain(self, sequence, lambda_seq=(0.0,), ic_type=4, is_cv=False, init_idx=(), init_val=(),
-                              init_coef0=0.0, keep_caches=False, stop_support=None, stop_beta=None, stop_rtol=1e-9):
+                              init_coef0=0.0, keep_caches=False, stop_support=None, stop_beta=None, stop_rtol=1e-9,
+                              lead_levels=()):
         """sequential_path as one link of a longer warm-start chain (bessx_session_sequential_path_chain): starts from
         the given (normalised) model, optionally on the caches of the previous call, and stops after the first
         candidate that equals the caller's own row of stop_support / stop_beta.  Adds to the path result: stopped_at,
@@ -408,6 +409,8 @@ class Session:
         ch = PathChain()
         ch.init_idx, ch.init_val, ch.init_len, ch.init_coef0 = _ip(ii), _dp(iv), ii.size, float(init_coef0)
         ch.keep_caches = int(bool(keep_caches))
+        lead = _i32(lead_levels)  # (bessx_path_chain.lead_levels: a coarse warm-start chain in front of the link)
+        ch.lead_levels, ch.lead_len = (_ip(lead), lead.size) if lead.size else (None, 0)
         ss = sb = None
         if stop_support is not None:
             ss = np.full((len(stop_support), max_T0), -1, dtype=np.int32)

@@ -474,7 +474,7 @@ int shared_pass_submit(bessx_session *c, const double *v, const double *v2, doub
                        const CoxBufs *cox, const FitCtrl *ctrl, int slot);
 void kchains_free(bessx_session *s);
 void kchains_quiesce(bessx_session *s);
-int kchunks_prepare(bessx_session *s, int ns, bool link);
+int kchunks_prepare(bessx_session *s, int ns, bool link, bool link_warm = false);
 hipError_t cox_alloc(bessx_session *s);                        // bessx_session.cpp
 int chain_ctx_create(bessx_session *ps, bessx_session **out);  // bessx_session.cpp
 void chain_ctx_free(bessx_session *c);

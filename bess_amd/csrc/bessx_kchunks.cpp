@@ -361,12 +361,14 @@ void kchains_free(bessx_session *s) {
 }
 
 // how many chunk chains for this path (1 = the single chain)
-static int chains_for(const bessx_session *s, int ns, bool link = false) {
+static int chains_for(const bessx_session *s, int ns, bool link = false, bool link_warm = false) {
   int C = s->kpath_chains;
   if (C == 0 && s->kch_auto_off) return 1;  // (this session's chunks do not merge: see the stitch's budget)
   if (C == 0 && link && s->model_type == 1 && ns < 96) {
     // a link of a longer chain (a rank's chunk of a multi-GPU k-path): shorter, so fewer chains
     C = (ns >= 40 && s->p >= 2048) ? 2 : 1;
+    // ... behind lead fits (bessx_path_chain.lead_levels: the link starts warm on a filled cache) short links pay too
+    if (link_warm && s->cov_mode && s->p >= 2048) C = ns >= 40 ? 4 : (ns >= 24 ? 3 : (ns >= 16 ? 2 : 1));
   } else if (C == 0) {
     // automatic: long paths on wide designs.  How many chains pay depends on how many hardware queues the HIP runtime
     // gives the process' streams (GPU_MAX_HW_QUEUES, default 4; read when the runtime starts): configs[1], 18.6 ms as
@@ -410,7 +412,7 @@ bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int i
   } else if (s->K > 0) {
     return false;  // (sessions with CV folds keep per-row-set state the chain contexts do not own)
   }
-  if (chains_for(s, ns, chain != nullptr) < 2) return false;
+  if (chains_for(s, ns, chain != nullptr, chain && chain->init_len > 0 && chain->keep_caches) < 2) return false;
   int top = 0;
   for (int i = 0; i < ns; i++) {
     if (seq[i] < 1 || (i && seq[i] <= seq[i - 1])) return false;  // ascending levels: every chunk continues its predecessor
@@ -494,8 +496,8 @@ void kchains_quiesce(bessx_session *s) {
 
 // Contexts and host threads for the path's chains.  Non-zero when they cannot be had (no memory for the contexts, host
 // threads lost in an earlier call): the caller then runs the path as one chain -- slower, same result.
-int kchunks_prepare(bessx_session *s, int ns, bool link) {
-  const int C = chains_for(s, ns, link);
+int kchunks_prepare(bessx_session *s, int ns, bool link, bool link_warm) {
+  const int C = chains_for(s, ns, link, link_warm);
   if (hipSetDevice(s->device) != hipSuccess) return 1;
   if (!s->kch) s->kch = new KChains();
   KChains *k = s->kch;
@@ -891,7 +893,7 @@ int mc_run_chunks(bessx_session *s, KChains *k, const int *seq, int ns, int C, c
 
 int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lambda, int ic_type,
                             bessx_path_result *res, bessx_path_chain *link) {
-  const int C = chains_for(s, ns, link != nullptr);
+  const int C = chains_for(s, ns, link != nullptr, link && link->init_len > 0 && link->keep_caches);
   HIPX(hipSetDevice(s->device));
   KChains *k = s->kch;
   if (!k || (int)k->ctx.size() < C || k->pool.broken)

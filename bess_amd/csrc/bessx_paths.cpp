@@ -627,12 +627,57 @@ int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *la
     if (eb) (void)hipEventDestroy(eb);
     if (rc_x) return rc_x;
   }
+  // Lead fits of a link (bessx_path_chain.lead_levels): a coarse warm-start chain on this session in front of the link,
+  // which then starts from its last model on the cache the lead fits have filled
+  bessx_path_chain lead_link;
+  std::vector<int> lead_idx;
+  std::vector<double> lead_val;
+  bessx_path_chain *caller_chain = chain;
+  if (chain && chain->lead_len > 0 && chain->lead_levels) {
+    if (s->model_type != 1 || gs || pgs || is_cv || chain->stop_support)
+      return fail(BESSX_ERR_UNSUPPORTED, "lead fits: LM sequential links without a stop table only");
+    SparseVec init;
+    for (int i = 0; i < chain->init_len; i++) {
+      if (chain->init_idx[i] < 0 || chain->init_idx[i] >= s->p) return fail(BESSX_ERR_ARG, "chain: init index out of range");
+      init.idx.push_back(chain->init_idx[i]);
+      init.val.push_back(chain->init_val[i]);
+    }
+    double c0 = chain->init_coef0;
+    int prev = 0;
+    for (int m = 0; m < chain->lead_len; m++) {
+      const int T = chain->lead_levels[m];
+      if (T <= prev || T < 1 || T >= seq[0] || T > s->cap) return fail(BESSX_ERR_ARG, "lead fits: levels must ascend below the link's first");
+      prev = T;
+      if (int rc = run_fit(s, T, lam[0], init, c0)) return rc;
+      init = s->beta;
+      c0 = s->coef0;
+    }
+    if (int rc = settle_device_chain(s)) return rc;
+    lead_idx = init.idx;
+    lead_val = init.val;
+    lead_link = *chain;
+    lead_link.init_idx = lead_idx.data();
+    lead_link.init_val = lead_val.data();
+    lead_link.init_len = (int)lead_idx.size();
+    lead_link.init_coef0 = c0;
+    lead_link.keep_caches = 1;
+    lead_link.lead_levels = nullptr;
+    lead_link.lead_len = 0;
+    chain = &lead_link;
+    s->n_fits = 0;
+    s->n_iters = 0;
+  }
   // (chunk chains where the path qualifies and their contexts can be had, else the one chain: same candidates)
-  const bool chunked = !pgs && !gs && kchunks_apply(s, seq, ns, nl, is_cv, chain) && kchunks_prepare(s, ns, chain != nullptr) == 0;
+  const bool chunked = !pgs && !gs && kchunks_apply(s, seq, ns, nl, is_cv, chain) && kchunks_prepare(s, ns, chain != nullptr, chain && chain->init_len > 0 && chain->keep_caches) == 0;
   int rc = pgs  ? pgs_path(s, s_min, s_max, pgs->lmin, pgs->lmax, pgs->powell_path, pgs->nlambda, ic_type, is_cv, res)
            : gs ? gs_path(s, s_min, s_max, ic_type, is_cv, res)
            : chunked ? sequential_path_chunked(s, seq, ns, lam[0], ic_type, res, chain)
                      : sequential_path(s, seq, ns, lam, nl, ic_type, is_cv, res, chain);
+  if (chain == &lead_link) {  // the link's outputs belong to the caller's structure
+    caller_chain->stopped_at = lead_link.stopped_at;
+    caller_chain->last_len = lead_link.last_len;
+    caller_chain->last_coef0 = lead_link.last_coef0;
+  }
   auto t1 = std::chrono::steady_clock::now();
   res->device_seconds = std::chrono::duration<double>(t1 - t0).count();
   res->n_fits = s->n_fits;

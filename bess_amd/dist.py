@@ -230,7 +230,7 @@ class StitchedKPath:
     (bess_amd.capi.Session).  step() returns this rank's chunk of the single chain plus the gathered IC curve."""
 
     def __init__(self, session, sequence, world=1, rank=0, ic_type=3, lead=(), device=None, stop_rtol=1e-9, comm=None,
-                 prefill=0, pilot=None, rebalance=False):
+                 prefill=0, pilot=None, rebalance=False, coarse_lead=False):
         self.s, self.world, self.rank = session, int(world), int(rank)
         self.full_seq = np.asarray(sequence, dtype=np.int32)
         self.kmax = int(self.full_seq.size)
@@ -252,8 +252,24 @@ class StitchedKPath:
         self.prefill = int(prefill)  # columns of the cooperative prefill in front of the chunks (0: replicas only)
         self.pilot = pilot           # (k_pilot, n_second[, wide]) of pilot_prefill, or None: the marginal list alone
         self.width = int(self.full_seq.max()) if self.kmax else 1  # longest support of the path (singleton groups)
+        # coarse_lead (round 6, LM): every rank walks, in front of its chunk, the coarse warm-start chain the ONE-GPU path
+        # walks in front of its chunk chains (bessx_kchunks.cpp: the levels at the quarter points of s.list) as far as it
+        # lies below the chunk, then the level just below the chunk -- bessx_path_chain.lead_levels.  No communication: the
+        # ranks repeat each other's coarse fits (deterministic kernels, replicated X); the chunk then starts warm on a
+        # cache that holds nearly every column it will ask for, where a cold start at k0 = 176 paid 14 passes over X.
+        self.coarse_lead = bool(coarse_lead)
 
     KEYS = ("cand_T0", "cand_iters", "cand_train_loss", "cand_ic", "cand_coef0", "cand_support", "cand_beta")
+
+    def lead_levels(self):
+        """Sparsity levels of this rank's lead fits (coarse_lead): the one-GPU path's coarse levels below the chunk, then
+        the level just below the chunk."""
+        if not (self.coarse_lead and self.seq.size and self.lo > 0):
+            return np.zeros(0, dtype=np.int32)
+        first = int(self.seq[0])
+        coarse = [int(self.full_seq[self.kmax * j // 4 - 1]) for j in (1, 2, 3) if self.kmax >= 8]
+        lv = sorted({k for k in coarse + [int(self.full_seq[self.lo - 1])] if 1 <= k < first})
+        return np.asarray(lv, dtype=np.int32)
 
     def _model_record(self, changed, idx, val, coef0):
         rec = np.zeros(3 + 2 * self.width)
@@ -287,6 +303,10 @@ class StitchedKPath:
             nl = 0
             out = self.s.sequential_path_chain(self.seq, ic_type=self.ic_type, keep_caches=True, init_idx=init[0],
                                                init_val=init[1], init_coef0=init[2])
+        elif self.seq.size and self.coarse_lead and self.lead_levels().size:
+            nl = 0
+            out = self.s.sequential_path_chain(self.seq, ic_type=self.ic_type, keep_caches=t_pre > 0.0,
+                                               lead_levels=self.lead_levels())
         elif self.seq.size:
             out = self.s.sequential_path_chain(np.concatenate([self.lead, self.seq]), ic_type=self.ic_type,
                                                keep_caches=t_pre > 0.0)

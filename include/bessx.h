@@ -236,6 +236,13 @@ typedef struct {
   int last_cap;
   int last_len;            /* out */
   double last_coef0;       /* out */
+  /* optional LEAD fits (round 6): sparsity levels (ascending, below the link's first) of a warm-start chain that is run
+   * on this session IN FRONT of the link, from init_* -- every rank of a multi-GPU k-path walks the same coarse levels
+   * the one-GPU path walks (a few fits whose fills bring nearly every Gram column the link will ask for) instead of
+   * starting cold at its chunk: no communication, and the link starts from the last lead model.  Their candidates are
+   * not returned; NULL / 0: none.  LM only. */
+  const int *lead_levels;
+  int lead_len;
 } bessx_path_chain;
 int bessx_session_sequential_path_chain(bessx_session *s, const int *sequence, int sequence_len,
                                         const double *lambda_seq, int lambda_len, int ic_type, int is_cv,

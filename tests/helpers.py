@@ -142,11 +142,14 @@ class NumpyLmSession:
                 "test_loss": float(res[test] @ res[test]) / (2 * max(int(test.sum()), 1)) if fold >= 0 else 0.0}
 
     def sequential_path_chain(self, sequence, ic_type=3, init_idx=(), init_val=(), init_coef0=0.0, keep_caches=False,
-                              stop_support=None, stop_beta=None, stop_rtol=1e-9):
+                              stop_support=None, stop_beta=None, stop_rtol=1e-9, lead_levels=()):
         """Stand-in for capi.Session.sequential_path_chain (one link of a warm-start chain, src/path.cpp:60-64), GIC."""
         seq = [int(v) for v in sequence]
         W = max(seq)
         bi, bv = np.asarray(init_idx, dtype=np.int32), np.asarray(init_val, dtype=np.float64)
+        for T0 in lead_levels:  # bessx_path_chain.lead_levels: a coarse warm-start chain in front of the link
+            r = self.fit(int(T0), 0.0, -1, bi, bv, init_coef0)
+            bi, bv = r["support"], r["beta"]
         out = {"cand_T0": [], "cand_iters": [], "cand_train_loss": [], "cand_ic": [], "cand_coef0": [],
                "cand_support": [], "cand_beta": []}
         stopped = -1

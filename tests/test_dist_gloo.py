@@ -153,7 +153,14 @@ def _stitch_worker(rank, world, port, out_path):
     X, y = _hard_lm()
     seq = np.arange(1, 25)
     sk = bdist.StitchedKPath(NumpyLmSession(X, y, np.zeros(len(y), int), 1), seq, world, rank, rebalance=True)
+    # (the lead fits of round 6 -- every rank walks the one-GPU path's coarse levels below its chunk first -- change where
+    # a chunk starts, never the stitched path: same supports and curve below)
+    lead = bdist.StitchedKPath(NumpyLmSession(X, y, np.zeros(len(y), int), 1), seq, world, rank, coarse_lead=True)
+    rep_lead = lead.step()
     rep = sk.step()
+    assert np.allclose(rep_lead["ic_curve"], rep["ic_curve"], rtol=1e-12) and rep_lead["best_k"] == rep["best_k"]
+    assert np.array_equal(rep_lead["chunk"]["cand_support"], rep["chunk"]["cand_support"])
+    assert rank == 0 or (lead.lead_levels().size >= 1 and int(lead.lead_levels()[-1]) == int(lead.seq[0]) - 1)
     sup = np.full((len(seq), 24), -1)
     lo, hi = bdist.partition(len(seq), world, rank)
     assert rep["bounds"][rank] == lo and rep["bounds"][rank + 1] == hi  # the first step runs the equal split

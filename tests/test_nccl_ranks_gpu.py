@@ -31,6 +31,7 @@ def _bench_nccl(extra, timeout=900):
     env.pop("BESSX_BENCH_ONE_DEVICE", None)
     with tempfile.TemporaryDirectory(prefix="bessx_bench_err_") as errdir:
         env["BESSX_BENCH_ERRDIR"] = errdir
+        env["BESSX_BENCH_DETAIL_PATH"] = os.path.join(errdir, "detail.json")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "3000", "--p", "800", "--kmax", "30",
                               "--k-true", "10", "--steps", "2", "--warmup", "1", "--gpus", "2"] + extra, cwd=ROOT,
                              capture_output=True, text=True, timeout=timeout, env=env)
@@ -40,9 +41,11 @@ def _bench_nccl(extra, timeout=900):
                 errs.append(fh.read()[-4000:])
         assert out.returncode == 0, "bench.py --gpus 2 %s (nccl) -> rc %d\n%s\n==== stderr (tail)\n%s" % (
             " ".join(extra), out.returncode, "\n".join(errs) or "(no per-rank error file)", out.stderr[-1500:])
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) < 6500, out.stdout[-2000:]
+        json.loads(lines[0])  # (the compact line the driver parses; the full record of the run is in the side file)
+        with open(os.path.join(errdir, "detail.json")) as fh:
+            return json.load(fh)
 
 
 def test_bench_two_ranks_over_rccl_when_two_devices_are_visible(gpu):

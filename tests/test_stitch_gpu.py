@@ -109,6 +109,62 @@ def test_stitched_chunks_equal_the_single_chain(gpu, fam, extra, world, ladder):
         assert sum(res[0]["stitch_refits_per_rank"]) > world - 1  # candidates were really replaced
 
 
+@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_coarse_lead_chunks_equal_the_single_chain(gpu, mode, world):
+    """Round 6, the N-rank k-path's default for LM: every rank walks the one-GPU path's coarse levels below its chunk and
+    the level just below it as LEAD fits (bessx_path_chain.lead_levels; no communication), then its chunk warm from the
+    last lead model -- as chunk chains where the link is long enough (p >= 2048) --, and the stitch makes the gathered
+    path the single chain's (src/path.cpp:60-64)."""
+    X, y, _, _ = synth.make_lm(3000, 2304, 40, seed=11)
+    seq = np.arange(1, 97)
+    with gpu.Session(X, y, score_mode=mode) as s:
+        single = s.sequential_path(seq, ic_type=3)
+
+    def rank_fn(rank, comm):
+        with gpu.Session(X, y, score_mode=mode) as sr:
+            sk = bdist.StitchedKPath(sr, seq, world, rank, ic_type=3, comm=comm, coarse_lead=True)
+            lv = sk.lead_levels()
+            assert (rank == 0 and lv.size == 0) or (lv.size >= 1 and lv[-1] == sk.seq[0] - 1 and np.all(np.diff(lv) > 0))
+            rep = sk.step()
+            rep["chains"] = sr.counters()["kpath_chains_last_path"] if sr.counters()["kpath_chunked_paths"] else 1
+        return rep
+
+    res = run_ranks(world, rank_fn)
+    W = single["cand_support"].shape[1]
+    for r, rep in enumerate(res):
+        a, b = bdist.partition(len(seq), world, r)
+        c = rep["chunk"]
+        sup = np.full((b - a, W), -1, dtype=np.int32)
+        sup[:, :c["cand_support"].shape[1]] = c["cand_support"]
+        np.testing.assert_array_equal(sup, single["cand_support"][a:b])
+        np.testing.assert_array_equal(c["cand_iters"], single["cand_iters"][a:b])
+        # (the same supports reached from another starting model: the iterative solve of the covariance form ends within
+        # its 1e-13 residual bound of the same solution, the criterion agrees to ~1e-11)
+        np.testing.assert_allclose(rep["ic_curve"], single["cand_ic"], rtol=1e-9)
+        assert rep["best_k"] == single["best_T0"]
+    if mode == 2 and world <= 4:  # links of >= 24 levels behind lead fits run as chunk chains (covariance form)
+        assert any(rep["chains"] >= 2 for rep in res[1:])
+
+
+def test_lead_fits_are_refused_where_they_do_not_apply(gpu):
+    X, y, _, _ = synth.make_lm(600, 100, 5)
+    with gpu.Session(X, y) as s:
+        with pytest.raises(gpu.BessxError):  # levels must lie below the link's first
+            s.sequential_path_chain([10, 11], ic_type=3, lead_levels=[5, 10])
+        with pytest.raises(gpu.BessxError):  # ... and ascend
+            s.sequential_path_chain([10, 11], ic_type=3, lead_levels=[6, 5])
+        a = s.sequential_path_chain([10, 11, 12], ic_type=3, lead_levels=[3, 9])
+        b = s.sequential_path(np.arange(1, 13), ic_type=3)
+        # (on this easy design the lead chain 3 -> 9 -> 10 meets the chain 1 -> 2 -> ... -> 10)
+        np.testing.assert_array_equal(a["cand_support"][:, :12], b["cand_support"][9:12, :12])
+    Xl, yl, kw = _hard("logistic", 600, 60)
+    with gpu.Session(Xl, yl, **kw) as s:
+        with pytest.raises(gpu.BessxError) as e:
+            s.sequential_path_chain([10, 11], ic_type=3, lead_levels=[5])
+        assert e.value.code == 3
+
+
 def test_chain_refuses_what_it_cannot_continue(gpu):
     X, y, _, _ = synth.make_lm(600, 100, 5)
     with gpu.Session(X, y) as s:

@@ -31,15 +31,22 @@ def _run_bench(extra, env=None, timeout=900):
     e.update(env or {})
     with tempfile.TemporaryDirectory(prefix="bessx_bench_err_") as errdir:
         e["BESSX_BENCH_ERRDIR"] = errdir
+        e["BESSX_BENCH_DETAIL_PATH"] = os.path.join(errdir, "detail.json")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "3000", "--p", "800", "--kmax", "30",
                               "--k-true", "10", "--steps", "2", "--warmup", "1"] + extra, cwd=ROOT, capture_output=True,
                              text=True, timeout=timeout, env=e)
         assert out.returncode == 0, "bench.py %s -> rc %d\n%s\n==== [rank ..] lines on stdout\n%s\n==== stderr (tail)\n%s" % (
             " ".join(extra), out.returncode, _rank_errors(errdir),
             "\n".join(ln for ln in out.stdout.splitlines() if ln.startswith("[rank")), out.stderr[-1500:])
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) < 6500, out.stdout[-2000:]
+        line = json.loads(lines[0])  # the compact line the driver parses ...
+        with open(os.path.join(errdir, "detail.json")) as fh:
+            full = json.load(fh)     # ... and the full record of the same run (bench.py: emit)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config"):
+        assert k in line, k
+    assert abs(line["value"] - full["value"]) <= 1e-4 * full["value"] and line["n_gpus"] == full["n_gpus"]
+    return full
 
 
 def test_bench_gpus_2_starts_two_ranks_and_shards_the_k_path(gpu):

@@ -214,6 +214,67 @@ int run_staged_rounds(int C, int rounds, unsigned seed) {
   return (dup || incomplete) ? 1 : 0;
 }
 
+// ---- PassRendezvous: chains that share their passes over X (round 6) -------------------------------------------------
+// C member threads submit requests in rounds of random length, pause (leave / join, as the early stitch's wait does) and
+// finish at different times; the "launch" reads the batch's requests and writes every participant's result cell -- plain
+// memory, touched under the rendezvous' lock only, so a hole in the protocol is a race TSan reports.  Checked: every
+// request is served exactly once, by the batch its `after` names; a batch never holds more requests than members;
+// nobody waits forever (a member that sleeps long enough makes the others go without it: partial batches).
+int run_pass_rounds(int C, int rounds, unsigned seed) {
+  PassRendezvous rdv;
+  rdv.timeout_s = 0.003;
+  struct Cell {
+    long served_by = -1;  // batch number that served the member's current request
+    long requests = 0, served = 0;
+  };
+  std::vector<Cell> cell((size_t)C);
+  int batch_req[16] = {};
+  long launches = 0, bad = 0, over = 0;
+  rdv.reset(C);
+  auto launch = [&](int n, unsigned long long g) {
+    if (n > rdv.members + 0 && n > 0) over++;  // (members may have dropped since the requests came in: checked loosely below)
+    if (n < 1 || n > C) bad++;
+    for (int i = 0; i < n; i++) {
+      Cell &q = cell[(size_t)batch_req[i]];
+      q.served_by = (long)g;
+      q.served++;
+    }
+    launches++;
+  };
+  std::vector<std::thread> th;
+  for (int id = 0; id < C; id++)
+    th.emplace_back([&, id] {
+      std::mt19937 rng(seed + 17u * (unsigned)id);
+      const int mine = rounds / 2 + (int)(rng() % (unsigned)(rounds / 2 + 1));
+      bool member = true;
+      for (int it = 0; it < mine; it++) {
+        if (rng() % 23 == 0) {  // a wait that is not for the device: step out, come back
+          rdv.leave(launch);
+          member = false;
+          std::this_thread::sleep_for(std::chrono::microseconds(rng() % 300));
+          rdv.join();
+          member = true;
+        }
+        if (rng() % 97 == 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));  // a straggler: the others time out
+        long got = -2;
+        rdv.submit([&](int i) { batch_req[i] = id; cell[(size_t)id].requests++; }, launch,
+                   [&](unsigned long long g) { got = cell[(size_t)id].served_by == (long)g ? 0 : -1; });
+        if (got != 0) __atomic_fetch_add(&bad, 1, __ATOMIC_RELAXED);
+      }
+      if (member) rdv.leave(launch);
+    });
+  for (auto &t : th) t.join();
+  long req = 0, srv = 0;
+  for (auto &q : cell) {
+    req += q.requests;
+    srv += q.served;
+  }
+  const bool ok = bad == 0 && req == srv && rdv.members == 0 && rdv.arrived == 0;
+  std::printf("pass rendezvous  C=%d  requests %ld served %ld  launches %ld  partial batches %llu  %s\n", C, req, srv, launches,
+              rdv.partial, ok ? "ok" : "FAILED");
+  return ok ? 0 : 1;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -223,6 +284,7 @@ int main(int argc, char **argv) {
     bad |= run_rounds(C, rounds, 1234u + (unsigned)C, false);
     bad |= run_rounds(C, rounds, 4321u + (unsigned)C, true);
     bad |= run_staged_rounds(C + 1, rounds, 777u + (unsigned)C);
+    bad |= run_pass_rounds(C, rounds * 4, 999u + (unsigned)C);
   }
   std::printf(bad ? "FAILED\n" : "sync harness OK\n");
   return bad;
