@@ -387,6 +387,7 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
         sess.enable_kernel_timing(True)
         sess.score_pass_stats(reset=True)
         sess.submodel_steps(reset=True)
+        cnt0 = sess.counters()
         torch.cuda.synchronize()
         t0 = time.time()
         out = run()
@@ -424,6 +425,15 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
             "selected_k": int(out["best_T0"]), "criterion": float(out["ic"]),
         }
         cnt = sess.counters()
+        sp_l = cnt.get("shared_pass_launches", 0) - cnt0.get("shared_pass_launches", 0)
+        if sp_l > 0:
+            # round 6: the chunk chains share their passes over X (one multi-chain launch serves every chain at its score
+            # pass): passes_over_X counts those launches, chain slots the vector sets they served
+            rec["shared_passes"] = {"chains_served_per_pass": (cnt.get("shared_pass_chain_slots", 0) -
+                                                              cnt0.get("shared_pass_chain_slots", 0)) / max(passes, 1.0),
+                                    "launches_incl_fall_through": sp_l,
+                                    "batches_cut_short": cnt.get("shared_pass_partial_batches", 0) -
+                                    cnt0.get("shared_pass_partial_batches", 0)}
         overlapped = cnt.get("kpath_chunked_paths", 0) > 0 or cnt.get("cv_side_by_side_rounds", 0) > 0
         rec["time"]["chains_side_by_side"] = bool(overlapped)
         if not overlapped:
@@ -567,7 +577,8 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
                     "k_xtv_two_accumulators_hbm_bytes_per_pass")
     rec.update({"workload": "SURVEY 8f: Poisson PDAS + IRLS (warm-started), sequential path k=1..100, n=100000 p=5000, GIC; "
                             "pinned by tests/golden/fullsize_poisson.npz (compiled reference)",
-                "score_kernel_name": "k_xtv<.., two accumulators> (X^T g and X^2^T h in one pass)",
+                "score_kernel_name": "k_xtv_mc<8,true> (X^T g and X^2^T h of every chunk chain at its score pass, one pass over X; "
+                                     "single chain: k_xtv<8,16,true>)",
                 "submodel": "IRLS step = k_irls_gram + k_gram_reduce + k_chol (3 launches)", "setup_seconds": setup})
     res["poisson"] = rec
     t0 = time.time()
@@ -586,7 +597,8 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
                                    "sample": "failed: %r" % (e,)}
     del X, keep
     rec.update({"workload": "configs[2]: logistic PDAS + IRLS, sequential path k=1..100, n=100000 p=5000, GIC",
-                "score_kernel_name": "k_xtv<.., two accumulators> (X^T g and X^2^T h in one pass)",
+                "score_kernel_name": "k_xtv_mc<8,true> (X^T g and X^2^T h of every chunk chain at its score pass, one pass over X; "
+                                     "single chain: k_xtv<8,16,true>)",
                 "submodel": "IRLS step = k_irls_gram + k_gram_reduce + k_chol (3 launches)", "setup_seconds": setup})
     res["logistic"] = rec
     t0 = time.time()
@@ -605,7 +617,8 @@ def measure_other_configs(local_rank, X_lm, y_lm, cpu_budget=None):
                                    "sample": "failed: %r" % (e,)}
         del X
     rec.update({"workload": "configs[4]: Cox PDAS, sequential path k=1..150, n=200000 p=20000 (32 GB X), GIC",
-                "score_kernel_name": "k_cox_score1p (risk-set score, X read once)",
+                "score_kernel_name": "k_cox_score1p_mc (risk-set scores of every chunk chain at its score pass, X read once; "
+                                     "single chain: k_cox_score1p)",
                 "submodel": "Newton step = linear predictor update, 4 scan launches, k_cox_hess (both Grams + gradient in "
                             "one pass over the active columns), carries, reduction, k_chol, direction, 3 line-search "
                             "launches", "setup_seconds": setup})
@@ -706,6 +719,8 @@ def compact_line(full):
                 e["score_kernel_frac_alone"] = sc["score_kernel_frac_of_hbm"]
             if (rec.get("chunk_chains") or {}).get("chains") is not None:
                 e["chains"] = rec["chunk_chains"]["chains"]
+            if (rec.get("shared_passes") or {}).get("chains_served_per_pass") is not None:
+                e["chains_per_pass"] = rec["shared_passes"]["chains_served_per_pass"]
             c2 = rec.get("cpu_baseline") or {}
             if c2.get("value"):
                 e["cpu_baseline"] = {"value": c2["value"], "kind": c2.get("kind"), "cores": c2.get("cores")}
@@ -1018,8 +1033,13 @@ def main():
         if os.path.exists(tpath) and (args.n, args.p) == (50000, 10000):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("k_cov_panel_hbm_bytes_per_launch" if cov else "k_xtv_hbm_bytes_per_launch")
-                traffic_src = tj.get("source", "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)")
+                shared = (not cov) and stats.get("shared", False)
+                traffic = tj.get("k_cov_panel_hbm_bytes_per_launch" if cov else
+                                 ("k_xtv_mc_hbm_bytes_per_launch" if shared else "k_xtv_hbm_bytes_per_launch"))
+                traffic_src = "profiles/pmc_traffic.json: " + tj.get("round6", {}).get(
+                    "source", "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes") + " (counter passes are runs of " \
+                    "their own, not part of this one)"
+
             except Exception:
                 traffic = None
         kern = ("k_cov_panel_dp" if cov else ("k_cox_score1p" if cox else "k_xtv<8,16,false>"))
@@ -1214,7 +1234,17 @@ def main():
                                np.array_equal(o1["cand_support"], o2["cand_support"]) and
                                np.array_equal(o1["cand_iters"], o2["cand_iters"]))}
             s2.close()
+            shared = cnt2.get("shared_pass_launches", 0) > 0
+            st2["shared"] = shared
             roof2 = roofline_of(st2, False)
+            if shared:
+                # round 6: the chunk chains share their passes (k_xtv_mc: one launch streams X for every chain that is at its
+                # score pass).  Algorithmic bytes per launch: 8 n p + 16 n C (the C chains' vectors in, their row-block sums
+                # are p-vectors); passes per candidate count LAUNCHES, chain slots the vector sets served by them
+                slots = cnt2.get("shared_pass_chain_slots", 0) / float(max(st2["launches"], 1))
+                roof2["kernel"] = "k_xtv_mc<8,false> (X^T r of every chunk chain that is at its score pass, X read once)"
+                roof2["chains_served_per_launch"] = slots
+                roof2["algorithmic_bytes_per_launch"] = 8.0 * args.n * args.p + 16.0 * args.n * slots
             whole2 = st2["launches"] / float(args.steps) * 8.0 * args.n * args.p / d2 / 1e9 / HBM_PEAK_GBPS
             line["streaming_score_pass"] = {
                 "value": len(seq) / d2, "unit": "candidates/s", "steps": args.steps, "warmup": args.warmup,
@@ -1229,7 +1259,12 @@ def main():
             roof["streaming_candidates_per_s"] = len(seq) / d2
             roof["streaming_ms_per_step"] = 1e3 * d2
             roof["streaming_steps"] = args.steps
-            roof["streaming_kernel"] = "k_xtv<8,16,false> (X^T r, one pass over X per PDAS iteration)"
+            roof["streaming_kernel"] = ("k_xtv_mc<8,false> (one pass over X serves every chunk chain at its score pass)" if shared
+                                        else "k_xtv<8,16,false> (X^T r, one pass over X per PDAS iteration)")
+            if shared:
+                roof["streaming_chains_served_per_pass"] = roof2["chains_served_per_launch"]
+                roof["streaming_shared_kernel_frac"] = roof2["frac"]
+                roof["streaming_shared_kernel_avg_launch_ms"] = roof2["avg_launch_ms"]
             # the kernel against the HBM roof: with the device to itself (single chain) where the leg ran as chunk chains
             ksrc = single2["roofline"] if single2 else roof2
             roof["streaming_kernel_frac"] = ksrc["frac"]

@@ -29,10 +29,10 @@ namespace bessx {
 // the launch waits for an event every participant records on its own stream (its vectors are ready), every participant's
 // stream waits for the event recorded behind the launch.  A pass then serves every chain that is at its score pass --
 // the chains fall into step at the passes, and the count of chains is no longer bounded by what a pass per chain costs.
-// Two GROUPS of chains alternate on the pass stream (chain r belongs to group r mod 2; test hook kchunks_pass_groups=1|2):
-// while one group's pass runs, the other group's chains do what lies between two passes -- selection, Gram, solve,
-// residual, the IRLS / Newton steps, the host's read-back and the launches of the next slot -- so the passes follow each
-// other back to back instead of waiting for the slowest chain of a single lock-step.
+// Optionally two GROUPS of chains alternate on the pass stream (chain r belongs to group r mod 2; test hook
+// kchunks_pass_groups=2; default 1): while one group's pass runs, the other group's chains do what lies between two passes
+// -- selection, Gram, solve, residual, the IRLS / Newton steps, the host's read-back and the launches of the next slot.
+// Measured slower than the single lock-step (see sequential_path_chunked): kept as a hook.
 struct SharedPass {
   static constexpr int GROUPS = 2;
   PassRendezvous rdv[GROUPS];
@@ -1092,7 +1092,10 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     const char *eh = test_hook("kchunks_shared_pass");
     sp.kind = s->model_type == 1 ? 0 : (s->model_type == 4 ? 2 : 1);
     sp.cap = sp.kind == 2 ? COX_MC_MAX : XTV_MC_MAX;
-    sp.groups = C >= 4 ? 2 : 1;
+    // (one group: two alternating groups -- one group's selection / solve / IRLS steps under the other group's pass --
+    // were built and measured SLOWER, 131 against 91 ms on the streaming configs[1] path with 4 chains, 95 against 84 ms on
+    // logistic with 8: every pass then serves half the chains, and the small kernels run 3-8 x slower beside a pass)
+    sp.groups = 1;
     if (const char *eg = test_hook("kchunks_pass_groups")) sp.groups = std::max(1, std::min(SharedPass::GROUPS, std::atoi(eg)));
     sp.on = !lm_cov && C >= 2 && (C + sp.groups - 1) / sp.groups <= sp.cap && (!eh || std::atoi(eh) != 0) &&
             (sp.kind != 2 || s->cox.one_pass) && sp_prepare(s, sp);
