@@ -1360,7 +1360,7 @@ int algorithm_fit(bessx_session *s) {
   // exactly the model this fit starts from: no upload, no look-up of its columns, only the scores are formed again
   // (round 5; before, such a fit was set up from the host's copy: two copies, k_fit_begin and the six launches of a
   // slot-0 fill that finds nothing missing -- 19 times per configs[1] path).
-  const bool model_kept = cov && !use_cache && cc.model_only && cc.cov_layout && s->dev_state_rs == rs &&
+  bool model_kept = cov && !use_cache && cc.model_only && cc.cov_layout && s->dev_state_rs == rs &&
                           cc.coef0 == s->coef0_init && cc.beta.idx == s->beta_init.idx && cc.beta.val == s->beta_init.val &&
                           !s->trace.on && test_hook("model_kept") == nullptr;
   cc.valid = cc.model_only = false;
@@ -1397,6 +1397,7 @@ int algorithm_fit(bessx_session *s) {
       s->pend_on = false;
       s->dev_state_rs = -1;
       use_cache = false;
+      model_kept = false;  // (the device state is no longer trusted: the model is set up again from the host's copy)
       s->chain_mismatch++;
     }
   }

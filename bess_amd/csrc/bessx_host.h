@@ -279,6 +279,7 @@ struct bessx_session {
   int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
   int kch_index = -1;                   // (chain context) its place among the owner's contexts
   unsigned long long kch_gen_seen = 0;  // (chain context) completed fills when this chain last queued a look-up
+  bool kch_fill_tried = false;          // the fill stream of the staged fills was asked for once (there or not)
   bool kch_sp_member = false;           // (chain context) its thread takes part in the owner's shared passes over X
   int kch_sp_group = 0;                 // ... in this group of chains (the groups alternate on the pass stream)
   long long sp_launches = 0, sp_chain_slots = 0, sp_partial = 0;  // shared passes: launches, open gates in them, batches cut short
@@ -495,7 +496,8 @@ int publish_flush(bessx_session *s);
 int publish_launch(bessx_session *s, const PubArgs &pa);
 int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq);
 int publish_wait(bessx_session *s, int buf, unsigned long long want);
-bool ctx_stream_create(int device, hipStream_t *st, int leave_out = 0, int stride = 1);  // a stream with a hardware queue outside the runtime's pool
+bool ctx_stream_create(int device, hipStream_t *st, int leave_out = 0, int stride = 1);
+void ctx_stream_destroy(hipStream_t st);  // (a stream of ctx_stream_create, or any other: the own-queue count is kept)  // a stream with a hardware queue outside the runtime's pool
 bool ctx_streams_own_queue(int device);              // ... does that work on this device (asked once per process)
 int stream_wait_bounded(bessx_session *s, hipStream_t st, const char *what);  // hipStreamSynchronize with the deadline
 int read_results(bessx_session *s, int kcopy = -1);

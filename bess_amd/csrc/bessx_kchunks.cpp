@@ -155,7 +155,7 @@ static void kchains_round(KChains *k, int chains, bool staged = false) { k->rdv.
 
 // ---- shared passes -------------------------------------------------------------------------------------------------
 static void sp_free(SharedPass &sp) {
-  if (sp.st) (void)hipStreamDestroy(sp.st);
+  if (sp.st) ctx_stream_destroy(sp.st);
   for (auto &grp : sp.ev_in)
     for (auto &e : grp)
       if (e) (void)hipEventDestroy(e);
@@ -353,7 +353,7 @@ void kchains_free(bessx_session *s) {
   sp_free(k->sp);
   if (s->kch_slot_w) (void)hipFree(s->kch_slot_w);
   s->kch_slot_w = nullptr;
-  if (s->kch_fill_st) (void)hipStreamDestroy(s->kch_fill_st);
+  if (s->kch_fill_st) ctx_stream_destroy(s->kch_fill_st);
   s->kch_fill_st = nullptr;
   for (bessx_session *c : k->ctx) chain_ctx_free(c);
   if (!k->pool.broken) delete k;  // (a broken pool's threads may still touch it: leaked on purpose)
@@ -503,8 +503,11 @@ int kchunks_prepare(bessx_session *s, int ns, bool link, bool link_warm) {
   KChains *k = s->kch;
   if (k->pool.broken) return 1;
   k->rdv.deadline_s = s->wait_deadline_s;
-  // (LM, covariance form: one more context and host thread -- the coarse chain runs beside the chunks, see below)
-  const int extra = (s->model_type == 1 && s->cov_mode) ? 1 : 0;
+  // (LM, covariance form, only with the test hook kchunks_pipeline=1: one more context and host thread -- the coarse chain
+  // beside the chunks, see below.  Rounds 4-5 created them for every session: an idle thread woken for every round and
+  // a context's buffers and stream held for nothing)
+  const char *epl = test_hook("kchunks_pipeline");
+  const int extra = (s->model_type == 1 && s->cov_mode && epl && std::atoi(epl) != 0) ? 1 : 0;
   while ((int)k->ctx.size() < C + extra) {
     bessx_session *c = nullptr;
     if (chain_ctx_create(s, &c) != 0) {
@@ -950,7 +953,8 @@ int sequential_path_chunked(bessx_session *s, const int *seq, int ns, double lam
     s->kch_slot_w = nullptr;
     staged = pipeline = false;
   }
-  if (staged && !s->kch_fill_st) {
+  if (staged && !s->kch_fill_st && !s->kch_fill_tried) {
+    s->kch_fill_tried = true;  // (decided once per session: no unit to leave out, or no such stream to be had)
     // the fills' stream: every compute unit but a few (test hook kchunks_reserve=count[:stride of the mask bits]; 0: the
     // fills run on the filling chain's own stream)
     int leave = 16, stride = 1;

@@ -21,7 +21,7 @@ void fold_ctx_free(bessx_session *c) {
   if (c->res_buf[0]) (void)hipHostFree(c->res_buf[0]);
   if (c->pub_flag) (void)hipHostFree(c->pub_flag);
   if (c->stage_h) (void)hipHostFree(c->stage_h);
-  if (c->st) (void)hipStreamDestroy(c->st);
+  if (c->st) ctx_stream_destroy(c->st);
   delete c;
 }
 
@@ -157,7 +157,7 @@ void session_free(bessx_session *s) {
     if (q) (void)hipFree(q);
   if (s->stage_h) (void)hipHostFree(s->stage_h);
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
-  if (s->st) (void)hipStreamDestroy(s->st);
+  if (s->st) ctx_stream_destroy(s->st);
   delete s;
 }
 
@@ -277,9 +277,39 @@ int alloc_cov_cache(bessx_session *s, bool share_map) {
 // leave_out > 0: a stream that may NOT use `leave_out` of the compute units (mask bits 0, stride, 2 stride, ...): the
 // stream the chunk chains' fills run on -- the chains' own small kernels find those units free while a panel pass
 // occupies every other one (bessx_kchunks.cpp).
+// Streams of this kind hold a hardware queue each, outside the runtime's pool: a process (several sessions, several ranks
+// rehearsed on one device) must not take them without bound -- beyond OWN_QUEUE_CAP per process the callers get ordinary
+// pool streams (hipStreamNonBlocking, the parent's priority), which is what `false` has always meant to them.
+// (What such a stream is: hipExtStreamCreateWithCUMask has no flags argument -- the stream is a BLOCKING stream of normal
+// priority, i.e. it synchronises with work on the legacy null stream.  The library itself queues nothing on the null
+// stream inside a path call; a host that does -- torch's default stream is the null stream -- serialises with the chains.
+// INTEGRATION.md section 5.)
+static std::mutex g_own_mu;
+static std::vector<hipStream_t> g_own_streams;
+static constexpr size_t OWN_QUEUE_CAP = 24;
+
+void ctx_stream_destroy(hipStream_t st) {
+  if (!st) return;
+  {
+    std::lock_guard<std::mutex> lk(g_own_mu);
+    for (size_t i = 0; i < g_own_streams.size(); i++)
+      if (g_own_streams[i] == st) {
+        g_own_streams.erase(g_own_streams.begin() + (long)i);
+        break;
+      }
+  }
+  (void)hipStreamDestroy(st);
+}
+
 bool ctx_stream_create(int device, hipStream_t *st, int leave_out, int stride) {
   const char *hook = test_hook("ctx_streams");
   if (hook && std::string(hook) == "pool") return false;
+  {
+    size_t cap = OWN_QUEUE_CAP;
+    if (const char *ec = test_hook("ctx_streams_cap")) cap = (size_t)std::max(0, std::atoi(ec));
+    std::lock_guard<std::mutex> lk(g_own_mu);
+    if (g_own_streams.size() >= cap) return false;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) return false;
   std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
@@ -293,6 +323,8 @@ bool ctx_stream_create(int device, hipStream_t *st, int leave_out, int stride) {
     *st = nullptr;
     return false;
   }
+  std::lock_guard<std::mutex> lk(g_own_mu);
+  g_own_streams.push_back(*st);
   return true;
 }
 
@@ -306,7 +338,7 @@ bool ctx_streams_own_queue(int device) {
   if (known[(size_t)device] < 0) {
     hipStream_t st = nullptr;
     const bool ok = ctx_stream_create(device, &st);
-    if (ok) (void)hipStreamDestroy(st);
+    if (ok) ctx_stream_destroy(st);
     known[(size_t)device] = ok ? 1 : 0;
   }
   return known[(size_t)device] == 1;
@@ -632,9 +664,16 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   } while (0)
   HIPT(hipSetDevice(dev));
   {
-    int lo = 0, hi = 0;
-    HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
+    // The session's own stream: like the fit contexts' (ctx_stream_create: a hardware queue of its own, normal priority,
+    // blocking) so that the coarse chain, the fills and the chunk chains share ONE priority level (rounds 1-5: a pool
+    // stream of the highest priority, which the contexts' streams of round 5 no longer matched);
+    // BESSX_TEST_HOOKS=parent_stream=pool, or no such stream to be had: the pool stream of rounds 1-5.
+    const char *eps = test_hook("parent_stream");
+    if ((eps && std::string(eps) == "pool") || !ctx_stream_create(dev, &s->st)) {
+      int lo = 0, hi = 0;
+      HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
+    }
     HIPT(gram_lds_prepare());
     if (const char *ev = test_hook("irls_fuse")) s->irls_fuse = std::string(ev) == "1";
     s->irls_wfloor = g_marginal_fit_variant == 1 ? 0 : 1;

@@ -395,3 +395,71 @@ def test_fill_disciplines_of_the_chunk_chains_return_the_single_chain(gpu, monke
             assert cnt["kpath_chunked_paths"] == 3
             if variant == "pipeline":
                 assert cnt["kpath_chunk_fills"] >= 3  # (the coarse chain's fills count: it runs on a context too)
+
+
+@pytest.mark.parametrize("fam,chains", [("lm", 4), ("lm", 8), ("logistic", 6), ("poisson", 3), ("cox", 3), ("cox", 4)])
+def test_shared_passes_return_the_path_of_the_chains_own_passes(gpu, monkeypatch, fam, chains):
+    """Round 6: the chunk chains of the streaming forms hand their vector sets to ONE multi-chain launch per
+    pass (k_xtv_mc / k_cox_score1p_mc) instead of streaming X once per chain.  The multi-chain kernels leave bitwise the
+    sums of the single-chain kernels (tests/test_ops_gpu.py), so the same chains on passes of their own
+    (kchunks_shared_pass=0, round 5) walk the same path -- and both return the single chain's candidates.  Also as two
+    alternating groups.  (Coefficients are compared to 1e-8, not bitwise: which rows a chunk has stored when its
+    predecessor's early stitch looks at them depends on timing, and a replaced row agrees with the chunk's own to 1e-9.)"""
+    from helpers import hooks
+    if fam == "lm":
+        X, y, _, _ = synth.make_lm(3000, 900, 25, seed=21)
+        kw, top = dict(score_mode=1), 96
+    elif fam == "logistic":
+        X, y, _, _ = synth.make_logistic(3000, 600, 12, seed=22)
+        kw, top = dict(data_type=2, model_type=2), 60
+    elif fam == "poisson":
+        X, y, _, _ = synth.make_poisson(3000, 600, 12, seed=23)
+        kw, top = dict(data_type=2, model_type=3), 48
+    else:
+        X, _, y, _, _ = synth.make_cox(3000, 600, 12, seed=24)
+        kw, top = dict(data_type=3, model_type=4), 48
+    seq = np.arange(1, top + 1)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y, **kw) as s:
+        single = s.sequential_path(seq, ic_type=3)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", str(chains))
+    outs = {}
+    eq = 1000000000  # (equal chunk lengths in every variant: the same chunks start at the same levels)
+    for name, hk in (("own", dict(kchunks_shared_pass=0, kchunks_len_div=eq)),
+                     ("shared", dict(kchunks_shared_pass=1, kchunks_pass_groups=1, kchunks_len_div=eq)),
+                     ("groups", dict(kchunks_shared_pass=1, kchunks_pass_groups=2, kchunks_len_div=eq))):
+        hooks(monkeypatch, **hk)
+        with gpu.Session(X, y, **kw) as s:
+            s.enable_kernel_timing(True)
+            outs[name] = s.sequential_path(seq, ic_type=3)
+            again = s.sequential_path(seq, ic_type=3)
+            cnt = s.counters()
+            st = s.score_pass_stats()
+        assert cnt["kpath_chunked_paths"] == 2 and cnt["kpath_chains_last_path"] == chains
+        if name == "own":
+            assert cnt["shared_pass_launches"] == 0
+        else:
+            # the chains' passes were shared launches that served more vector sets than there were launches (passes of
+            # the session's own chain -- the tail after a stitch that gave up -- are counted in st, not here)
+            assert st["launches"] > 0 and cnt["shared_pass_launches"] > 0 and cnt["shared_pass_partial_batches"] == 0
+            assert cnt["shared_pass_chain_slots"] > cnt["shared_pass_launches"]
+        _same_path(again, outs[name])
+        _same_path(outs[name], outs["own"])
+        _same_path(outs[name], single)
+
+
+def test_fit_contexts_beyond_the_cap_of_own_queue_streams_fall_back_to_pool_streams(gpu, monkeypatch):
+    """Streams with a hardware queue of their own (hipExtStreamCreateWithCUMask) are capped per process
+    (bessx_session.cpp: OWN_QUEUE_CAP); beyond the cap a context gets an ordinary pool stream -- slower, same path."""
+    from helpers import hooks
+    X, y, _, _ = synth.make_lm(2500, 2304, 20, seed=11)
+    seq = np.arange(1, 97)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "1")
+    with gpu.Session(X, y) as s:
+        want = s.sequential_path(seq, ic_type=3)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "4")
+    for cap in (0, 2, 3):
+        hooks(monkeypatch, ctx_streams_cap=cap)
+        with gpu.Session(X, y) as s:
+            _same_path(s.sequential_path(seq, ic_type=3), want)
+            assert s.counters()["kpath_chains_last_path"] == 4
