@@ -116,6 +116,11 @@ def parse_args(argv=None):
     ap.add_argument("--rebalance", choices=["auto", "on", "off"], default="auto",
                     help="N > 1, k-path: after every step the chunk boundaries move towards equal time per rank "
                          "(bess_amd.dist.rebalance_bounds); auto = on up to 4 ranks (2 ranks: 13.7 -> 11.9 ms; no gain at 8)")
+    ap.add_argument("--comm", choices=["torch", "bessx"], default="torch",
+                    help="N > 1, k-path: the collectives of the step (all-gathers of the chunks' last models and of the IC "
+                         "curve) through torch.distributed (default; backend nccl = RCCL) or through the library's own "
+                         "communicator (bessx_comm_*: RCCL directly, what a C or R host has; its unique id is broadcast once "
+                         "through torch.distributed at start-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per timed segment")
     ap.add_argument("--shard", choices=["auto", "replica", "kpath"], default="auto",
@@ -662,7 +667,7 @@ def compact_line(full):
     line = {k: full[k] for k in keep}
     cfg = full.get("config", {})
     line["config"] = _pick(cfg, ["workload", "candidates_per_step", "score_pass", "headline_mode", "units_sharded",
-                                 "collective", "ranks_with_work", "streaming_mode"])
+                                 "collective", "communicator", "ranks_with_work", "streaming_mode"])
     roof = dict(full.get("roofline", {}))
     roof.pop("traffic_source", None)
     line["roofline"] = roof
@@ -909,9 +914,14 @@ def main():
     # (the same decision on every rank: a ladder start anywhere rules the moving boundaries out)
     rebalance = kpath and not any_ladder and (args.rebalance == "on" or
                                               (args.rebalance == "auto" and world <= 4 and not cox))
+    own_comm = None
+    if kpath and args.comm == "bessx":
+        ident = [bdist.BessxComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        own_comm = bdist.BessxComm(rank, world, ident[0], device=local_rank)
     stitched = bdist.StitchedKPath(sess, full_seq, world, rank, ic_type=3, lead=lead, device=comm_dev,
                                    prefill=prefill, pilot=pilot, rebalance=rebalance and not coarse_lead,
-                                   coarse_lead=coarse_lead) if kpath else None
+                                   coarse_lead=coarse_lead, comm=own_comm) if kpath else None
     for _ in range(args.warmup):
         out = stitched.step() if kpath else sess.sequential_path(seq, ic_type=3)
     sess.enable_kernel_timing(True)
@@ -1113,6 +1123,8 @@ def main():
                                       "models" + (" + one all_gather of Gram column blocks (cooperative prefill)"
                                                   if (kpath and prefill) else "")) if kpath else
                                      ("all_gather of the IC curve" if distributed else "none"),
+                       "communicator": ("bessx_comm (RCCL directly, behind the C ABI)" if (kpath and args.comm == "bessx") else
+                                        ("torch.distributed" if distributed else None)),
                        "score_pass": "covariance updates (cached Gram columns)" if covariance else "streaming",
                        "headline_mode": ("covariance form (Gram-cached: an exact re-formulation of the score pass, same "
                                          "candidates; NOT the streaming formulation SURVEY 8d's algorithmic bytes are "

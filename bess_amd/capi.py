@@ -34,6 +34,8 @@ SYMBOLS = [
     "bessx_session_cov_prefill_extend", "bessx_session_cov_state", "bessx_op_xtv", "bessx_op_topk", "bessx_op_gram",
     "bessx_op_chol_solve", "bessx_op_topk_bench", "bessx_op_chol_bench", "bessx_op_normalize", "bessx_op_stream_copy_gbps", "bessx_op_xtv_bench", "bessx_op_cox_score_bench",
     "bessx_op_xtv_multi", "bessx_op_xtv_multi_bench",
+    "bessx_comm_unique_id", "bessx_comm_init", "bessx_comm_rank", "bessx_comm_world", "bessx_comm_allgather_f64",
+    "bessx_comm_destroy",
 ]
 
 
@@ -141,6 +143,13 @@ def lib():
         L.bessx_op_normalize.argtypes = [_D, _i, _i, _D, _D, _i, _i, _i, _D, _D, _D]
         L.bessx_op_stream_copy_gbps.argtypes = [_ll, _i, _D]
         L.bessx_op_xtv_bench.argtypes = [_i, _i, _i, _i, _D, _D]
+        L.bessx_comm_unique_id.argtypes = [ctypes.c_char_p]
+        L.bessx_comm_init.argtypes = [ctypes.POINTER(_vp), _i, _i, ctypes.c_char_p, _i]
+        L.bessx_comm_rank.argtypes = [_vp]
+        L.bessx_comm_world.argtypes = [_vp]
+        L.bessx_comm_allgather_f64.argtypes = [_vp, _D, _i, _D]
+        L.bessx_comm_destroy.argtypes = [_vp]
+        L.bessx_comm_destroy.restype = None
         L.bessx_op_xtv_multi.argtypes = [_D, _i, _i, _i, _D, _D, _i, _D, _D]
         L.bessx_op_xtv_multi_bench.argtypes = [_i, _i, _i, _i, _i, _D, _D]
         L.bessx_op_topk_bench.argtypes = [_i, _i, _i, _i, _D]

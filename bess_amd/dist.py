@@ -132,6 +132,64 @@ class _TorchComm:
                 session.cov_prefill_import(a, b - a, blk[:(b - a) * 32 * p])
 
 
+class BessxComm:
+    """The library's own communicator (bessx_comm_*, include/bessx.h section 5: RCCL directly, no torch.distributed in
+    the data path) with the all_gather interface the sharded paths use -- what a C or R host has.  `unique_id`: the 128
+    bytes of rank 0's BessxComm.unique_id(), handed to the other ranks by the host (here: any broadcast the caller has;
+    bench.py --comm bessx uses torch's store once, at start-up).  Collective: every rank constructs it."""
+
+    def __init__(self, rank, world, unique_id, device=0):
+        import ctypes
+        from . import capi
+        self._capi, self._ct = capi, ctypes
+        self.rank, self.world = int(rank), int(world)
+        h = ctypes.c_void_p()
+        capi._check(capi.lib().bessx_comm_init(ctypes.byref(h), self.rank, self.world, bytes(unique_id), int(device)))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from . import capi
+        buf = ctypes.create_string_buffer(128)
+        capi._check(capi.lib().bessx_comm_unique_id(buf))
+        return buf.raw
+
+    def all_gather(self, mine, world):
+        assert world == self.world
+        mine = np.ascontiguousarray(mine, dtype=np.float64).ravel()
+        out = np.empty(self.world * mine.size)
+        D = self._ct.POINTER(self._ct.c_double)
+        self._capi._check(self._capi.lib().bessx_comm_allgather_f64(self._h, mine.ctypes.data_as(D), int(mine.size),
+                                                                    out.ctypes.data_as(D)))
+        return [out[r * mine.size:(r + 1) * mine.size].copy() for r in range(self.world)]
+
+    def exchange_blocks(self, session, world, rank, ng):
+        """The cooperative prefill's Gram column blocks through host arrays (the opt-in variant; the blocks could stay on
+        the device, as _TorchComm keeps them -- not needed by the default partition, which has no data-path collective)."""
+        p = session.p_kept
+        longest = -(-ng // world)
+        lo, hi = partition(ng, world, rank)
+        mine = np.zeros(longest * 32 * p)
+        if hi > lo:
+            mine[:(hi - lo) * 32 * p] = session.cov_prefill_export(lo, hi - lo)
+        for r, blk in enumerate(self.all_gather(mine, world)):
+            a, b = partition(ng, world, r)
+            if r != rank and b > a:
+                session.cov_prefill_import(a, b - a, blk[:(b - a) * 32 * p])
+
+    def close(self):
+        if self._h:
+            self._capi.lib().bessx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _share_and_exchange(session, world, rank, comm, ng):
     """This rank's contiguous share of the ng listed 32-column groups (one pass over X per group, two groups per pass with
     the pair kernel), then everybody's blocks to everybody."""

@@ -401,6 +401,24 @@ int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbp
  * quoted next to the spec peak in bench.py. */
 int bessx_op_stream_copy_gbps(long long bytes, int repeats, double *gbps);
 
+/* ---------------------------------------------------------------------------------------
+ * 5. A communicator for hosts without torch.distributed (round 6): the ONE collective the sharded paths need -- an
+ *    all-gather of small fp64 records (the IC / CV curve, 8 B per candidate; the k-chunks' last models; the fold fits'
+ *    records: SURVEY 8e) -- on RCCL directly.  One process per GPU; rank 0 calls bessx_comm_unique_id and the host hands
+ *    the 128 bytes to the other ranks by whatever it has (a file, MPI, a socket); every rank then calls bessx_comm_init
+ *    (collective: returns when all `world` ranks have called it).  RCCL is loaded when the first of these functions is
+ *    called (BESSX_ERR_UNSUPPORTED when it cannot be).  bess_amd.dist.BessxComm is the Python face of it.
+ * ------------------------------------------------------------------------------------- */
+#define BESSX_COMM_ID_BYTES 128
+typedef struct bessx_comm bessx_comm;
+int bessx_comm_unique_id(unsigned char *id /* BESSX_COMM_ID_BYTES */);
+int bessx_comm_init(bessx_comm **out, int rank, int world, const unsigned char *id, int device);
+int bessx_comm_rank(const bessx_comm *c);
+int bessx_comm_world(const bessx_comm *c);
+/* every rank's `count` doubles to every rank: recv[r * count .. (r + 1) * count) = rank r's send; host buffers */
+int bessx_comm_allgather_f64(bessx_comm *c, const double *send, int count, double *recv);
+void bessx_comm_destroy(bessx_comm *c);
+
 #ifdef __cplusplus
 }
 #endif

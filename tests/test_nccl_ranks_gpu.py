@@ -113,3 +113,49 @@ print("NCCL-OK")
     out = subprocess.run([sys.executable, "-c", code % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "NCCL-OK" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
+
+
+def test_the_librarys_own_communicator_at_world_one(gpu):
+    """bessx_comm_* (include/bessx.h section 5, round 6): RCCL behind the C ABI, loaded at run time -- a communicator of ONE
+    rank on the one GPU there is: unique id, init, all-gather of host records through the library's device buffers, and
+    the stitched k-path driven through it (what a C or R host has in place of torch.distributed).  In a process of its
+    own WITHOUT torch: the library must find RCCL by itself."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, faulthandler
+faulthandler.dump_traceback_later(90, exit=True)
+import numpy as np
+sys.path.insert(0, %r)
+from bess_amd import capi, synth, dist as bdist
+assert "torch" not in sys.modules
+ident = bdist.BessxComm.unique_id()
+assert len(ident) == 128
+comm = bdist.BessxComm(0, 1, ident, device=0)
+got = comm.all_gather(np.arange(7.0), 1)
+assert len(got) == 1 and np.array_equal(got[0], np.arange(7.0))
+big = comm.all_gather(np.linspace(0.0, 1.0, 5000), 1)          # (the device buffers grow)
+assert np.array_equal(big[0], np.linspace(0.0, 1.0, 5000))
+X, y, _, _ = synth.make_lm(1500, 400, 10)
+seq = np.arange(1, 25)
+with capi.Session(X, y) as s:
+    plain = s.sequential_path(seq, ic_type=3)
+    rep = bdist.StitchedKPath(s, seq, 1, 0, ic_type=3, comm=comm, coarse_lead=True).step()
+assert np.array_equal(rep["chunk"]["cand_support"], plain["cand_support"])
+np.testing.assert_allclose(rep["ic_curve"], plain["cand_ic"], rtol=1e-12)
+comm.close()
+print("BESSX-COMM-OK")
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))],
+                         capture_output=True, text=True, timeout=200, env=env)
+    assert out.returncode == 0 and "BESSX-COMM-OK" in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
+
+
+def test_bench_two_ranks_through_the_librarys_own_communicator_when_two_devices_are_visible(gpu):
+    if _devices() < 2:
+        pytest.skip("one device visible: two RCCL ranks need two")
+    d = _bench_nccl(["--comm", "bessx", "--no-cpu-baseline"])
+    rep = d["kpath_chunks_vs_single_chain"]
+    assert rep["supports_equal_to_single_chain"] == rep["of"] == 30 and "bessx_comm" in d["config"]["communicator"]
