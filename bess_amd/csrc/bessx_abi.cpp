@@ -583,7 +583,7 @@ int bessx_op_cox_score_bench(int n, int p, int variant, int repeats, double *gbp
   // the row blocks of one column group
   // variant 10 + nc: the multi-chain kernel (k_cox_score1p_mc) with nc chains' vector sets per launch
   const int mc = (variant >= 11 && variant <= 10 + COX_MC_MAX) ? variant - 10 : 0;
-  if (!mc && (variant < 0 || variant > 1)) return fail(BESSX_ERR_ARG, "op_cox_score_bench: variant 0, 1 or 11..14");
+  if (!mc && (variant < 0 || variant > 1)) return fail(BESSX_ERR_ARG, "op_cox_score_bench: variant 0, 1 or 11..16");
   if (mc) {
     double *vecs, *outs;
     HIPX(sc.alloc(&vecs, (size_t)ld * 4 * mc));

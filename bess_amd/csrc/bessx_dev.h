@@ -318,7 +318,7 @@ struct CoxBufs {
 };
 // One pass over X for several chains' one-pass Cox scores (k_cox_score1p_mc): per chain the four n-vectors of
 // launch_cox_score_pass (one_pass form) and its output planes; ran (optional) receives the number of open gates.
-constexpr int COX_MC_MAX = 4;
+constexpr int COX_MC_MAX = 6;
 struct CoxMc {
   const double *TH[COX_MC_MAX], *CU[COX_MC_MAX], *CV[COX_MC_MAX], *C2[COX_MC_MAX];
   double *out[COX_MC_MAX];

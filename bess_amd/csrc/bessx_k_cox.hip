@@ -373,18 +373,20 @@ __global__ void __launch_bounds__(256) k_cox_score1p(const double *__restrict__ 
 template <int U, int NC>
 __global__ void __launch_bounds__(256) k_cox_score1p_mc(const double *__restrict__ X, long ld, int p, int nrb,
                                                         COX_MC_CHAIN_ARGS(0), COX_MC_CHAIN_ARGS(1), COX_MC_CHAIN_ARGS(2),
-                                                        COX_MC_CHAIN_ARGS(3), int *__restrict__ ran) {
+                                                        COX_MC_CHAIN_ARGS(3), COX_MC_CHAIN_ARGS(4), COX_MC_CHAIN_ARGS(5),
+                                                        int *__restrict__ ran) {
   constexpr int RW = 16, COLS = 64, RS = RW + 1, NSEG = RW / 2, CPI = 64 / NSEG, NIT = COLS / CPI;
   __shared__ double tile[4][COLS * RS];
   __shared__ __align__(16) double vecs[4][NC][RW][4];  // per wave and chain: (theta, u, v, c2) of the sub-tile's rows
   struct Chains {  // (indexed by unrolled constants only)
-    const double *TH[4], *CU[4], *CV[4], *C2[4];
-    double *out[4];
-    const FitCtrl *ctrl[4];
-    int slot[4];
+    const double *TH[6], *CU[6], *CV[6], *C2[6];
+    double *out[6];
+    const FitCtrl *ctrl[6];
+    int slot[6];
   };
-  const Chains a = {{TH0, TH1, TH2, TH3}, {CU0, CU1, CU2, CU3}, {CV0, CV1, CV2, CV3}, {C20, C21, C22, C23},
-                    {out0, out1, out2, out3}, {ctrl0, ctrl1, ctrl2, ctrl3}, {slot0, slot1, slot2, slot3}};
+  const Chains a = {{TH0, TH1, TH2, TH3, TH4, TH5}, {CU0, CU1, CU2, CU3, CU4, CU5}, {CV0, CV1, CV2, CV3, CV4, CV5},
+                    {C20, C21, C22, C23, C24, C25}, {out0, out1, out2, out3, out4, out5},
+                    {ctrl0, ctrl1, ctrl2, ctrl3, ctrl4, ctrl5}, {slot0, slot1, slot2, slot3, slot4, slot5}};
   bool on[NC];
   int na = 0;
 #pragma unroll
@@ -1361,12 +1363,14 @@ static hipError_t launch_cox_score1p_mc_u(const double *X, long ld, int p, int n
 #define COX_MC_PASS(i) a.TH[i], a.CU[i], a.CV[i], a.C2[i], a.out[i], a.ctrl[i], a.slot[i]
 #define COX_MC_GO(NCC)                                                                                                \
   hipLaunchKernelGGL((k_cox_score1p_mc<U, NCC>), dim3(nb), dim3(256), 0, st, X, ld, p, nrb, COX_MC_PASS(0), COX_MC_PASS(1), \
-                     COX_MC_PASS(2), COX_MC_PASS(3), a.ran)
+                     COX_MC_PASS(2), COX_MC_PASS(3), COX_MC_PASS(4), COX_MC_PASS(5), a.ran)
   switch (a.nc) {
     case 1: COX_MC_GO(1); break;
     case 2: COX_MC_GO(2); break;
     case 3: COX_MC_GO(3); break;
-    default: COX_MC_GO(4); break;
+    case 4: COX_MC_GO(4); break;
+    case 5: COX_MC_GO(5); break;
+    default: COX_MC_GO(6); break;
   }
 #undef COX_MC_GO
 #undef COX_MC_PASS
