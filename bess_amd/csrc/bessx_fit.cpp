@@ -36,8 +36,12 @@ static int score_pass(bessx_session *s, int kind, int rs, int slot, std::vector<
 // --------------------------------------------------------------------------------------------
 // Algorithm::fit (src/Algorithm.h:113-171), LM: GroupPdasLm::get_A / primary_model_fit (:1097-1135)
 // --------------------------------------------------------------------------------------------
+// part: 0 = the whole PDAS iteration; 1 = its LIGHT part -- score pass, scores, selection, the comparison with the
+// previous active set and a commit that only records a REPEATED set (the normal end of a fit: 2 launches behind the
+// selection instead of the 9 of Gram, solve, commit and residual, which would all fall through); 2 = the rest of an
+// iteration whose light part found a NEW set (the host sees that the slot was not committed and queues it).
 int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
-                           std::vector<std::pair<size_t, bool>> &k1_pairs) {
+                           std::vector<std::pair<size_t, bool>> &k1_pairs, int part) {
   const int mt = (T0 + 1 + 15) / 16, mp = mt * 16;
   const int ntiles = mt * (mt + 1) / 2;
   const GramTask *tasks_full = nullptr;
@@ -46,18 +50,28 @@ int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, b
   gram_geometry(s, ntask, &rps, &nslab, ntiles, mt > 16);  // (the cached LM Gram keeps k_gram: gates 3 / 4)
   if ((size_t)nslab * ntiles * 256 > s->gpart_elems) return fail(BESSX_ERR_ARG, "gram workspace too small");
   hipError_t e = hipSuccess;
-  if (!skip_k1) {
-    // skip_k1: the partial sums of this row set were computed from exactly the coefficients this fit
-    // starts from (the previous fit ended on a repeated active set) -- get_A would recompute them bit for bit.
-    if (int rc = score_pass(s, 0, rs, slot, k1_pairs)) return rc;
-  } else if (s->timing) {
-    k1_pairs.push_back({(size_t)-1, false});
+  if (part != 2) {
+    if (!skip_k1) {
+      // skip_k1: the partial sums of this row set were computed from exactly the coefficients this fit
+      // starts from (the previous fit ended on a repeated active set) -- get_A would recompute them bit for bit.
+      if (int rc = score_pass(s, 0, rs, slot, k1_pairs)) return rc;
+    } else if (s->timing) {
+      k1_pairs.push_back({(size_t)-1, false});
+    }
+    if (e == hipSuccess)
+      e = launch_score(s->part_rs[rs], nullptr, s->nrb, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs],
+                       lambda, 0, s->always, s->bd, s->ctrl, slot, s->st);
+    if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
+    if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
   }
-  if (e == hipSuccess)
-    e = launch_score(s->part_rs[rs], nullptr, s->nrb, s->p, s->beta_dense, s->xtx[rs], (double)s->n_train[rs],
-                     lambda, 0, s->always, s->bd, s->ctrl, slot, s->st);
-  if (e == hipSuccess) e = launch_topk(s->bd, s->p, T0, s->A_new, s->cand, s->ctrl, slot, s->st, nullptr, nullptr, &s->tie);
-  if (e == hipSuccess) e = launch_gram_cols(s->A_new, T0, mp, 0, 0, s->gcols, s->ctrl, slot, s->A_cur, 1, s->st);
+  if (part == 1) {
+    // (wait_chain = 1: k_commit records a repeated set and otherwise stands back -- irls_done is never set for LM)
+    if (e == hipSuccess)
+      e = launch_commit(s->ctrl, slot, T0, s->A_new, s->sol, 0, 1, s->A_cur, s->b_cur, s->beta_dense, s->hist,
+                        s->hist_beta, s->hist_coef0, s->hist_stride, s->st, s->inA);
+    if (e != hipSuccess) return fail(BESSX_ERR_HIP, std::string("enqueue_lm_slot (light): ") + hipGetErrorString(e));
+    return 0;
+  }
   if (e == hipSuccess && mt > 16) {
     // beyond the register-resident solver: whole Gram every time, blocked Cholesky in global memory
     e = launch_gram(s->X, s->aux, s->ld, s->gcols, s->mask[rs], rps, tasks_full, ntask, nslab, s->gpart, ntiles, s->Gt,
@@ -1512,10 +1526,42 @@ int algorithm_fit(bessx_session *s) {
     // large systems: as many conjugate-gradient step launches per solve as the last solve took, and a few
     if ((T0 + 1 + 15) / 16 > 16 && hc->irls_last > 0) s->cgb_guess = std::max(12, std::min(64, hc->irls_last + 8));
   }
+  int pending_heavy = 0;  // the slot whose light part ran and found a NEW active set
   while (!glm && !cov) {
     int first = slot;
+    if (s->light_confirm && s->max_iter >= 2) {
+      // one whole iteration (or the rest of one whose light part did not commit) + the LIGHT part of the next one: a
+      // warm-started fit changes its set in the first iteration and confirms it in the second
+      std::vector<int> which;  // PDAS iteration of every pass queued in this batch
+      if (pending_heavy) {
+        if (int rc = enqueue_lm_slot(s, pending_heavy, T0, lambda, rs, false, k1_pairs, 2)) return rc;
+        pending_heavy = 0;
+      } else {
+        if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs, 0)) return rc;
+        which.push_back(slot++);
+      }
+      int light = 0;
+      if (slot <= s->max_iter) {
+        if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, false, k1_pairs, 1)) return rc;
+        light = slot;
+        which.push_back(slot++);
+      }
+      if (int rc = read_results(s, T0)) return rc;
+      // a pass ran iff its iteration was committed -- or is the light part that found a new set (l one short, not done)
+      for (size_t i = 0; i < k1_pairs.size() && i < which.size(); i++)
+        k1_pairs[i].second = which[i] <= hc->l || (which[i] == hc->l + 1 && which[i] == light && !hc->done);
+      if (int rc = k1_collect(s, k1_pairs)) return rc;
+      k1_pairs.clear();
+      if (hc->done) break;
+      if (light && hc->l < light) {
+        pending_heavy = light;  // (also at light == max_iter: the iteration still has to be finished)
+        continue;
+      }
+      if (slot > s->max_iter) break;
+      continue;
+    }
     for (int b = 0; b < batch && slot <= s->max_iter; b++, slot++)
-      if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
+      if (int rc = enqueue_lm_slot(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs, 0)) return rc;
     if (int rc = read_results(s, T0)) return rc;
     // slots first..l really ran K1; later ones fell through their gate
     for (size_t i = 0; i < k1_pairs.size(); i++) k1_pairs[i].second = (first + (int)i) <= hc->l;
@@ -1533,6 +1579,27 @@ int algorithm_fit(bessx_session *s) {
       if (int rc = enqueue_glm_head(s, slot, T0, lambda, rs, use_cache && slot == 1, k1_pairs)) return rc;
     }
     int t = cox ? 1 : 0, steps_used = 0;  // IRLS steps are numbered from 0, Newton steps from 1 (:1411)
+    // Round 6, the CONFIRMING iteration without its sub-model chain.  From the second PDAS iteration of a fit on, the new
+    // active set usually equals the previous one (the normal end of a fit, src/Algorithm.h:164-170; logistic and Cox
+    // re-fits of a repeated set reproduce the coefficients: same_prev) -- and the guessed batch of IRLS / Newton steps
+    // queued behind the head then falls through launch by launch: ~20 launches per logistic iteration, ~150 per Cox
+    // iteration, each a few microseconds of the command processor that the OTHER chains' kernels wait behind (the device
+    // advances about 2.5 chains of small kernels at a time).  So the tail goes in right behind the head: if the set
+    // repeated it commits (k_commit's record-and-stop branch) and the iteration is over after 2 launches; if not, it
+    // falls through (the chain has not run: irls_done = 0), one host round trip is spent, and the steps follow as before.
+    // (Poisson has no repeated-set shortcut -- its IRLS restarts from the updated intercept.)
+    if (slot >= 2 && (cox || s->model_type == 2) && s->light_confirm) {
+      if (int rc = cox ? enqueue_cox_tail(s, slot, T0, rs) : enqueue_glm_tail(s, slot, T0, rs)) return rc;
+      if (int rc = read_results(s, T0)) return rc;
+      if (hc->l == slot) {
+        for (size_t i = 0; i < k1_pairs.size(); i++) k1_pairs[i].second = true;
+        if (int rc = k1_collect(s, k1_pairs)) return rc;
+        k1_pairs.clear();
+        slot++;
+        if (hc->done) break;
+        continue;
+      }
+    }
     while (true) {
       int upto = std::min(tmax, t + std::max(2, s->irls_guess) - 1);
       for (; t <= upto; t++)

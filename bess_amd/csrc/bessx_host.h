@@ -279,6 +279,7 @@ struct bessx_session {
   int kpath_chains = 0;                 // 0 = automatic, 1 = one chain (off), C >= 2 = that many chunk chains
   int kch_index = -1;                   // (chain context) its place among the owner's contexts
   unsigned long long kch_gen_seen = 0;  // (chain context) completed fills when this chain last queued a look-up
+  bool light_confirm = true;            // GLM / Cox: the tail right behind the head of a PDAS iteration >= 2 (bessx_fit.cpp)
   bool kch_fill_tried = false;          // the fill stream of the staged fills was asked for once (there or not)
   bool kch_sp_member = false;           // (chain context) its thread takes part in the owner's shared passes over X
   int kch_sp_group = 0;                 // ... in this group of chains (the groups alternate on the pass stream)
@@ -448,7 +449,7 @@ int prepare_rowset(bessx_session *s, int rs);
 int cov_C_dev(const bessx_session *s);
 bool cov_speculates(const bessx_session *s);
 int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,
-                           std::vector<std::pair<size_t, bool>> &k1_pairs);
+                           std::vector<std::pair<size_t, bool>> &k1_pairs, int part = 0);
 int panel_variant_for(const bessx_session *s, int ng);
 int enqueue_cov_fill(bessx_session *s, int rs, int ngroups, int parked, const FitCtrl *gate = nullptr,
                             int gfirst = 0, bool compact = true, const int *slot_map = nullptr);

@@ -385,8 +385,13 @@ static int chains_for(const bessx_session *s, int ns, bool link = false, bool li
       // round 5: the STREAMING form of the LM score pass as chunk chains, like the IRLS / Newton families -- every PDAS
       // iteration is a pass over X, and one chain's selection, Gram panel, solve and residual run beside another's pass
       // (tools/streaming_chains_bench.py, configs[1]: 190.1 ms as one chain, 168.7 / 173.5 / 162.3 ms with 2 / 3 / 4)
+    {
       C = (ns >= 48 && (double)s->n * s->p >= 1e8) ? (queues >= 8 ? 4 : 2) : 1;
-    else {
+      // round 6, shared passes + the light confirming iteration: 8 chains share a pass at 0.75 ms (4: 0.71) -- configs[1]
+      // 79 ms per path with 8 chains, 87 with 4 (tools/shared_pass_sweep.py)
+      const char *esh = test_hook("kchunks_shared_pass");
+      if (C == 4 && (!esh || std::atoi(esh) != 0) && ns >= 128) C = 8;
+    } else {
       // logistic / Poisson / Cox: one chain's IRLS or Newton steps (small kernels) run beside another's pass over X
       // (tools/glm_two_chains_probe.py: logistic at full size 155 -> 120 ms with 3 chains, Cox 1.86 -> 1.60 s)
       C = (ns >= 48 && (double)s->n * s->p >= 1e8) ? (queues >= 8 ? 3 : 2) : 1;

@@ -676,6 +676,7 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
     }
     HIPT(gram_lds_prepare());
     if (const char *ev = test_hook("irls_fuse")) s->irls_fuse = std::string(ev) == "1";
+    if (const char *ev = test_hook("light_confirm")) s->light_confirm = std::string(ev) != "0";
     s->irls_wfloor = g_marginal_fit_variant == 1 ? 0 : 1;
   }
   const int n = pb->n;
