@@ -87,7 +87,7 @@ def untraced(gpu):
             cnt["chunked"] = cnt["kpath_chunked_paths"] - before  # did THIS path run as chunk chains?
             outs["covariance, chains=%s" % ("auto" if chains == 0 else chains)] = (out, cnt)
     with gpu.Session(X, y, score_mode=1) as s:
-        for chains in (0, 1):  # automatic (round 5: the streaming form runs as chunk chains too), one chain
+        for chains in (0, 1, 4):  # automatic (round 6: 8 chunk chains that share their passes over X), one chain, four
             s.set_kpath_chains(chains)
             before = s.counters()["kpath_chunked_paths"]
             out = s.sequential_path(np.arange(1, 201), ic_type=3)
@@ -98,7 +98,8 @@ def untraced(gpu):
 
 
 @pytest.mark.parametrize("which", ["covariance, chains=auto", "covariance, chains=1", "covariance, chains=4",
-                                   "covariance, chains=2", "streaming, chains=auto", "streaming, chains=1"])
+                                   "covariance, chains=2", "streaming, chains=auto", "streaming, chains=1",
+                                   "streaming, chains=4"])
 def test_benchmarked_path_matches_compiled_reference_at_full_size(untraced, which):
     X, outs = untraced
     out, counters = outs[which]
@@ -109,6 +110,8 @@ def test_benchmarked_path_matches_compiled_reference_at_full_size(untraced, whic
     if which in ("covariance, chains=1", "streaming, chains=1"):
         assert counters["chunked"] == 0
     if which in ("covariance, chains=auto", "streaming, chains=auto"):
-        assert counters["chunked"] == 1 and counters["kpath_chains_last_path"] == 4
-    if which in ("covariance, chains=4", "covariance, chains=2"):
+        assert counters["chunked"] == 1 and counters["kpath_chains_last_path"] == (4 if which.startswith("cov") else 8)
+    if which.startswith("streaming") and which[-1] != "1":  # the chains shared their passes
+        assert counters["shared_pass_chain_slots"] > counters["shared_pass_launches"] > 0
+    if which in ("covariance, chains=4", "covariance, chains=2", "streaming, chains=4"):
         assert counters["kpath_chains_last_path"] == int(which[-1]) and counters["chunked"] == 1
