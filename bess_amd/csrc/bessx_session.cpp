@@ -664,15 +664,17 @@ int bessx_session_create(bessx_session **out, const bessx_problem *pb) {
   } while (0)
   HIPT(hipSetDevice(dev));
   {
-    // The session's own stream: like the fit contexts' (ctx_stream_create: a hardware queue of its own, normal priority,
-    // blocking) so that the coarse chain, the fills and the chunk chains share ONE priority level (rounds 1-5: a pool
-    // stream of the highest priority, which the contexts' streams of round 5 no longer matched);
-    // BESSX_TEST_HOOKS=parent_stream=pool, or no such stream to be had: the pool stream of rounds 1-5.
+    // The session's own stream: an ordinary stream of the runtime's pool at NORMAL priority -- the level the fit contexts'
+    // streams have (hipExtStreamCreateWithCUMask takes no priority; rounds 1-5 created this one at the highest level,
+    // which the contexts' streams of round 5 no longer matched).  Not a stream with a queue of its own: creating and
+    // destroying one costs ~20 ms (tools/probe/cumask_stream_churn.hip) and a path measured the same either way
+    // (10.8-10.9 ms); BESSX_TEST_HOOKS=parent_stream=own / =high select the other two forms.
     const char *eps = test_hook("parent_stream");
-    if ((eps && std::string(eps) == "pool") || !ctx_stream_create(dev, &s->st)) {
+    if (!(eps && std::string(eps) == "own" && ctx_stream_create(dev, &s->st))) {
       int lo = 0, hi = 0;
       HIPT(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, hi));
+      const int normal = std::max(std::min(lo, hi), std::min(std::max(lo, hi), 0));
+      HIPT(hipStreamCreateWithPriority(&s->st, hipStreamDefault, (eps && std::string(eps) == "high") ? hi : normal));
     }
     HIPT(gram_lds_prepare());
     if (const char *ev = test_hook("irls_fuse")) s->irls_fuse = std::string(ev) == "1";
