@@ -306,7 +306,8 @@ class Session:
                  20: "kpath_merged_chunk_phases", 21: "kpath_chains_taken_over", 22: "kpath_coarse_us",
                  23: "kpath_chunks_us", 24: "kpath_stitch_us", 25: "panel_launches_one_group",
                  26: "panel_ns_one_group", 27: "panel_launches_two_groups", 28: "panel_ns_two_groups",
-                 29: "shared_pass_launches", 30: "shared_pass_chain_slots", 31: "shared_pass_partial_batches"}  # (4-6: mechanisms removed in round 3)
+                 29: "shared_pass_launches", 30: "shared_pass_chain_slots", 31: "shared_pass_partial_batches",
+                 32: "own_queue_streams_created_by_the_process"}  # (4-6: mechanisms removed in round 3)
         return {n: int(lib().bessx_session_counter(self._h, i)) for i, n in names.items()}
 
     def screening(self):

@@ -498,6 +498,7 @@ int publish_launch(bessx_session *s, const PubArgs &pa);
 int publish_enqueue(bessx_session *s, int kcopy, int buf, unsigned long long *seq);
 int publish_wait(bessx_session *s, int buf, unsigned long long want);
 bool ctx_stream_create(int device, hipStream_t *st, int leave_out = 0, int stride = 1);
+long long ctx_streams_created();
 void ctx_stream_destroy(hipStream_t st);  // (a stream of ctx_stream_create, or any other: the own-queue count is kept)  // a stream with a hardware queue outside the runtime's pool
 bool ctx_streams_own_queue(int device);              // ... does that work on this device (asked once per process)
 int stream_wait_bounded(bessx_session *s, hipStream_t st, const char *what);  // hipStreamSynchronize with the deadline

@@ -284,18 +284,32 @@ int alloc_cov_cache(bessx_session *s, bool share_map) {
 // priority, i.e. it synchronises with work on the legacy null stream.  The library itself queues nothing on the null
 // stream inside a path call; a host that does -- torch's default stream is the null stream -- serialises with the chains.
 // INTEGRATION.md section 5.)
+// Creating or destroying one costs ~20 ms (a hardware queue; tools/probe/cumask_stream_churn.hip), so a destroyed one is
+// kept IDLE for the next session of the process instead (a drop-in call -- bessx_pywrap_bess / bessx_bessCpp -- creates
+// a session per call: 4-9 such streams each time, 0.1-0.2 s, was what a repeated call paid for its chains).
+struct OwnStream {
+  hipStream_t st;
+  int device, leave_out, stride;
+  bool in_use;
+};
 static std::mutex g_own_mu;
-static std::vector<hipStream_t> g_own_streams;
+static std::vector<OwnStream> g_own_streams;  // in use and idle ones: all count against the cap
+static long long g_own_created = 0;           // streams of this kind the process has created so far (statistics)
+long long ctx_streams_created() {
+  std::lock_guard<std::mutex> lk(g_own_mu);
+  return g_own_created;
+}
 static constexpr size_t OWN_QUEUE_CAP = 24;
 
 void ctx_stream_destroy(hipStream_t st) {
   if (!st) return;
   {
     std::lock_guard<std::mutex> lk(g_own_mu);
-    for (size_t i = 0; i < g_own_streams.size(); i++)
-      if (g_own_streams[i] == st) {
-        g_own_streams.erase(g_own_streams.begin() + (long)i);
-        break;
+    for (auto &o : g_own_streams)
+      if (o.st == st && o.in_use) {
+        (void)hipStreamSynchronize(st);  // (nothing of the old owner is left on it)
+        o.in_use = false;
+        return;
       }
   }
   (void)hipStreamDestroy(st);
@@ -308,7 +322,25 @@ bool ctx_stream_create(int device, hipStream_t *st, int leave_out, int stride) {
     size_t cap = OWN_QUEUE_CAP;
     if (const char *ec = test_hook("ctx_streams_cap")) cap = (size_t)std::max(0, std::atoi(ec));
     std::lock_guard<std::mutex> lk(g_own_mu);
-    if (g_own_streams.size() >= cap) return false;
+    size_t busy = 0;
+    for (auto &o : g_own_streams) busy += o.in_use ? 1 : 0;
+    if (busy >= cap) return false;
+    for (auto &o : g_own_streams)
+      if (!o.in_use && o.device == device && o.leave_out == leave_out && o.stride == stride) {
+        o.in_use = true;
+        *st = o.st;
+        return true;
+      }
+    if (g_own_streams.size() >= std::max(cap, OWN_QUEUE_CAP)) {
+      // every slot is taken by streams of another shape: give an idle one back to the runtime
+      for (size_t i = 0; i < g_own_streams.size(); i++)
+        if (!g_own_streams[i].in_use) {
+          (void)hipStreamDestroy(g_own_streams[i].st);
+          g_own_streams.erase(g_own_streams.begin() + (long)i);
+          break;
+        }
+      if (g_own_streams.size() >= std::max(cap, OWN_QUEUE_CAP)) return false;
+    }
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) return false;
@@ -324,7 +356,8 @@ bool ctx_stream_create(int device, hipStream_t *st, int leave_out, int stride) {
     return false;
   }
   std::lock_guard<std::mutex> lk(g_own_mu);
-  g_own_streams.push_back(*st);
+  g_own_streams.push_back({*st, device, leave_out, stride, true});
+  g_own_created++;
   return true;
 }
 
@@ -1926,6 +1959,7 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 29: return s->sp_launches;
     case 30: return s->sp_chain_slots;
     case 31: return s->sp_partial;
+    case 32: return ctx_streams_created();
     case 10: {  // times the Gram column cache of the all-rows row set was started over since the last path started
       if (s->cov.empty()) return 0;
       int m[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -463,3 +463,22 @@ def test_fit_contexts_beyond_the_cap_of_own_queue_streams_fall_back_to_pool_stre
         with gpu.Session(X, y) as s:
             _same_path(s.sequential_path(seq, ic_type=3), want)
             assert s.counters()["kpath_chains_last_path"] == 4
+
+
+def test_streams_with_their_own_queue_are_recycled_across_sessions(gpu, monkeypatch):
+    """A stream with a hardware queue of its own costs ~20 ms to create and destroy (tools/probe/cumask_stream_churn.hip);
+    a session that ends leaves its streams idle for the next one of the process -- a drop-in call creates a session per
+    call, and its 4-9 chain contexts would pay that every time."""
+    X, y, _, _ = synth.make_lm(2500, 2304, 20, seed=11)
+    seq = np.arange(1, 97)
+    monkeypatch.setenv("BESSX_KPATH_CHAINS", "4")
+    created = []
+    outs = []
+    for _ in range(3):
+        with gpu.Session(X, y) as s:
+            outs.append(s.sequential_path(seq, ic_type=3))
+            assert s.counters()["kpath_chains_last_path"] == 4
+            created.append(s.counters()["own_queue_streams_created_by_the_process"])
+    assert created[1] == created[0] and created[2] == created[0]  # sessions 2 and 3 created none
+    _same_path(outs[1], outs[0])
+    _same_path(outs[2], outs[0])
