@@ -369,6 +369,13 @@ static int chains_for(const bessx_session *s, int ns, bool link = false, bool li
     C = (ns >= 40 && s->p >= 2048) ? 2 : 1;
     // ... behind lead fits (bessx_path_chain.lead_levels: the link starts warm on a filled cache) short links pay too
     if (link_warm && s->cov_mode && s->p >= 2048) C = ns >= 40 ? 4 : (ns >= 24 ? 3 : (ns >= 16 ? 2 : 1));
+  } else if (C == 0 && link && !(s->model_type == 1 && s->cov_mode) && ns < 48) {
+    // a short link of a multi-GPU k-path of the families whose every PDAS iteration is a pass over X: with shared passes
+    // (round 6) even 12-20 levels pay as 2-3 chains -- rank 4 of 8 of configs[4] (levels 77..95, cold) 208 / 186 / 154 ms
+    // with 1 / 2 / 3 chains (tools/cox_link_probe.py)
+    const char *esh = test_hook("kchunks_shared_pass");
+    const bool big = (double)s->n * s->p >= 1e8 && (!esh || std::atoi(esh) != 0) && ctx_streams_own_queue(s->device);
+    C = big ? (ns >= 18 ? 3 : (ns >= 12 ? 2 : 1)) : 1;
   } else if (C == 0) {
     // automatic: long paths on wide designs.  How many chains pay depends on how many hardware queues the HIP runtime
     // gives the process' streams (GPU_MAX_HW_QUEUES, default 4; read when the runtime starts): configs[1], 18.6 ms as
@@ -402,7 +409,10 @@ static int chains_for(const bessx_session *s, int ns, bool link = false, bool li
       if (C == 3 && (!esh || std::atoi(esh) != 0) && s->model_type != 4 && ns >= 96) C = 6;
     }
   }
-  return std::max(1, std::min(std::min(C, 8), ns / 8));
+  // (at least 8 candidates per chain; 6 for the families whose every iteration is a pass over X: a short link of a
+  // multi-GPU k-path there still pays to share its passes)
+  const bool streaming = !(s->model_type == 1 && s->cov_mode);
+  return std::max(1, std::min(std::min(C, 8), ns / (streaming ? 6 : 8)));
 }
 
 bool kchunks_apply(const bessx_session *s, const int *seq, int ns, int nl, int is_cv, const bessx_path_chain *chain) {
