@@ -371,11 +371,13 @@ static int chains_for(const bessx_session *s, int ns, bool link = false, bool li
     if (link_warm && s->cov_mode && s->p >= 2048) C = ns >= 40 ? 4 : (ns >= 24 ? 3 : (ns >= 16 ? 2 : 1));
   } else if (C == 0 && link && !(s->model_type == 1 && s->cov_mode) && ns < 48) {
     // a short link of a multi-GPU k-path of the families whose every PDAS iteration is a pass over X: with shared passes
-    // (round 6) even 12-20 levels pay as 2-3 chains -- rank 4 of 8 of configs[4] (levels 77..95, cold) 208 / 186 / 154 ms
-    // with 1 / 2 / 3 chains (tools/cox_link_probe.py)
+    // (round 6) 12-23 levels pay as 2-3 chains -- rank 4 of 8 of configs[4] (levels 77..95, cold) 208 / 186 / 154 ms
+    // with 1 / 2 / 3 chains (tools/cox_link_probe.py); every rank of 8: slowest 358 -> 320 ms.  Longer links do not
+    // (the 37-level links of 4 ranks: 267 / 178 / 277 ms either way, and the last one -- levels 114..150, beyond the
+    // planted support, where cold chunks wander and the stitch gives up -- 571 -> 740 ms): one chain from 24 levels on
     const char *esh = test_hook("kchunks_shared_pass");
     const bool big = (double)s->n * s->p >= 1e8 && (!esh || std::atoi(esh) != 0) && ctx_streams_own_queue(s->device);
-    C = big ? (ns >= 18 ? 3 : (ns >= 12 ? 2 : 1)) : 1;
+    C = (big && ns < 24) ? (ns >= 18 ? 3 : (ns >= 12 ? 2 : 1)) : 1;
   } else if (C == 0) {
     // automatic: long paths on wide designs.  How many chains pay depends on how many hardware queues the HIP runtime
     // gives the process' streams (GPU_MAX_HW_QUEUES, default 4; read when the runtime starts): configs[1], 18.6 ms as

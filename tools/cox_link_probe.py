@@ -11,7 +11,7 @@ lo, hi = bdist.partition(len(seq), world, rank)
 with capi.Session(X, st, data_type=3, model_type=4) as s:
     del X
     base = None
-    for C in (1, 2, 3):
+    for C in (0, 1, 3):
         s.set_kpath_chains(C)
         s.sequential_path_chain(seq[lo:hi], ic_type=3)
         ts = []
