@@ -167,10 +167,16 @@ int bessx_session_score_mode(const bessx_session *s);
  * (BESSX_KPATH_CHAINS), 15 candidates re-fitted by their stitching, 16 fills of the shared cache
  * during the chunk phase, 17 chains of the last such path, 18 paths whose stitch gave up (a chunk's refit did not meet its
  * own chain within its budget: the rest of the path was walked as one chain, and the automatic choice of this session is
- * one chain from then on), 19 device nanoseconds of the all-rows group_XTX pass at session creation (LM), 20 chunk phases
+ * one chain from then on), 19 device nanoseconds of the last all-rows group_XTX pass inside a path call (LM; kernel timing
+ * on), 20 chunk phases
  * that ran as merged launches on one stream (round 5), 21 chains of such phases the host had to finish through the
  * per-context path (a tie at the selection boundary, a solve handed to the Cholesky kernel, ...), 22-24 microseconds the
- * chunked paths spent in their coarse chain / chunk phase / stitch (host clock, summed).  -1 for an unknown id. */
+ * chunked paths spent in their coarse chain / chunk phase / stitch (host clock, summed); round 6: 25 / 26 timed panel
+ * launches of ONE 32-column group and their nanoseconds, 27 / 28 the same for launches of TWO groups (one read of X each;
+ * reset with bessx_session_score_pass_stats), 29 multi-chain launches of the chunk chains' shared passes over X
+ * (fall-through launches included), 30 vector sets those launches served (kernel timing on), 31 batches launched before
+ * every chain had arrived (the 50 ms timeout), 32 streams with a hardware queue of their own the PROCESS has created so
+ * far (they are recycled across sessions).  -1 for an unknown id. */
 long long bessx_session_counter(const bessx_session *s, int which);
 
 /* Metric::set_cv_train_test_mask + cal_cv_group_XTX (src/Metric.h:49-129).  fold_id[i] in [0,K)

@@ -97,3 +97,42 @@ def test_fused_irls_step_gives_the_same_fits(gpu, monkeypatch):
         np.testing.assert_array_equal(u["cand_iters"], v["cand_iters"])
         np.testing.assert_allclose(u["cand_beta"], v["cand_beta"], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(u["cand_ic"], v["cand_ic"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("fam", ["lm_streaming", "logistic", "cox"])
+def test_the_confirming_iteration_queued_light_walks_the_trace_of_the_whole_one(gpu, monkeypatch, fam):
+    """Round 6: from the second PDAS iteration of a fit on, the tail (LM: a light slot) goes in right behind the
+    selection -- a repeated active set commits after two launches instead of a fall-through batch of IRLS / Newton steps
+    (LM: Gram, solve, commit, residual).  Hook light_confirm=0 queues every iteration whole, as rounds 1-5 did: the same
+    active set at every iteration of every fit (traced), the same candidates untraced, on designs where fits take up to
+    six iterations (a NEW set in a later iteration: the heavy rest is queued after the light part)."""
+    from helpers import hooks, assert_same_trace
+    from bess_amd import synth
+    rng = np.random.default_rng(77)
+    if fam == "lm_streaming":
+        X, y, _, _ = synth.make_lm(1200, 300, 12, seed=41)
+        X = X + 0.7 * X[:, rng.permutation(300)]  # correlated columns: fits of 3-6 iterations
+        kw = dict(score_mode=1)
+    elif fam == "logistic":
+        X, y, _, _ = synth.make_logistic(1500, 250, 10, seed=42)
+        X = X + 0.7 * X[:, rng.permutation(250)]
+        kw = dict(data_type=2, model_type=2)
+    else:
+        X, _, y, _, _ = synth.make_cox(1500, 250, 10, seed=43)
+        kw = dict(data_type=3, model_type=4)
+    seq = np.arange(1, 31)
+    outs = {}
+    for name, val in (("light", "1"), ("whole", "0")):
+        hooks(monkeypatch, light_confirm=val)
+        with gpu.Session(X, y, **kw) as s:
+            s.trace_enable(True)
+            traced = s.sequential_path(seq, ic_type=3)
+            s.trace_enable(False)
+            fast = s.sequential_path(seq, ic_type=3)
+        outs[name] = (traced, fast)
+    assert_same_trace(outs["light"][0]["trace"], outs["whole"][0]["trace"], what=fam)
+    assert max(len(f["iters"]) for f in outs["light"][0]["trace"]["fits"]) >= 3  # (fits beyond "change, confirm" exist)
+    for k in ("cand_support", "cand_iters"):
+        assert np.array_equal(outs["light"][1][k], outs["whole"][1][k]), k
+        assert np.array_equal(outs["light"][1][k], outs["light"][0][k]), k
+    np.testing.assert_allclose(outs["light"][1]["cand_ic"], outs["whole"][1]["cand_ic"], rtol=1e-9)
