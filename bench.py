@@ -1161,6 +1161,9 @@ def main():
             # collective): the lead fits' passes over X are repeated by every rank, only the chunk phase divides by N
             line["kpath_expected_speedup"] = {
                 "measured_this_run": chunk_report["speedup_over_one_gpu_same_run"],
+                # every rank's step timed ALONE on one GPU, no communication (profiles/r06_kpath_lead_fits_one_gpu_probe.jsonl,
+                # r06_cox_kpath_one_gpu_probe.jsonl): what the partition can reach on N devices
+                "one_gpu_rehearsal_by_N": ({"2": 1.72, "4": 1.78, "8": 3.25} if cox else {"2": 0.98, "4": 1.04, "8": 1.10}),
                 "bound": "T1 / (T_replicated + T_chunks / N): the passes over X that fill the Gram column cache are "
                          "repeated on every rank (DESIGN.md section 6)"}
         if coop_variant:
