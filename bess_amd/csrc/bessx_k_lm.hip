@@ -1,5 +1,7 @@
 // bessx_k_lm.hip -- data preparation, the streaming score pass, the Gram kernels of the restricted fits, Algorithm::fit bookkeeping,
 // the LM residual, publication of the result block (+ their launchers)
+#include <atomic>
+
 #include "bessx_kdev.hpp"
 
 namespace bessx {
@@ -1182,13 +1184,17 @@ static hipError_t launch_xtv_mc_t(const double *X, long ld, int p, const XtvMc &
   const int nrb = (int)(ld / (128 * U));
   const int nsp = (p + XTV_MC_WAVES * XTV_MC_CPW - 1) / (XTV_MC_WAVES * XTV_MC_CPW);
   const size_t lds = (size_t)a.nc * (TWO ? 2 : 1) * 128 * U * sizeof(double);
-  static bool attr_done = false;  // dynamic LDS beyond 64 KB has to be requested once per kernel instance
-  if (!attr_done) {
+  // dynamic LDS beyond 64 KB has to be requested once per kernel instance AND device (a process may hold sessions on
+  // several devices; the flags are only ever set, a repeated request is harmless)
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_done[dev].load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xtv_mc<U, TWO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)((size_t)XTV_MC_MAX * (TWO ? 2 : 1) * 128 * U * sizeof(double)));
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL((k_xtv_mc<U, TWO>), dim3(nrb * nsp), dim3(64 * XTV_MC_WAVES), lds, st, X, ld, p, nrb, a);
   LAUNCH_CHECK();
