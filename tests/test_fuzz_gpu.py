@@ -1,4 +1,4 @@
-"""A fixed slice of the randomised differential test (tests/fuzz_parity.py): 150 random problems / option
+"""A fixed slice of the randomised differential test (tests/fuzz_parity.py): 120 random problems / option
 combinations, every PDAS iteration against the oracle."""
 import pytest
 
@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 def test_random_problems_match_the_oracle(gpu):
     import fuzz_parity
-    assert fuzz_parity.run(cases=150, seed=20260101, verbose=False) == 0
+    assert fuzz_parity.run(cases=120, seed=20260101, verbose=False) == 0
 
 
 def test_random_problems_with_chunk_chains_forced(gpu, monkeypatch):
@@ -16,7 +16,7 @@ def test_random_problems_with_chunk_chains_forced(gpu, monkeypatch):
     untraced call must walk the path the traced -- single-chain -- call and the oracle walked."""
     import fuzz_parity
     monkeypatch.setenv("BESSX_KPATH_CHAINS", "3")
-    assert fuzz_parity.run(cases=120, seed=5, verbose=False) == 0
+    assert fuzz_parity.run(cases=90, seed=5, verbose=False) == 0
 
 
 @pytest.mark.parametrize("hooks_", ["kchunks_merged=1", "panel=lds", "kchunks_merged=1,panel=lds", "kchunks_staged=0",
@@ -30,4 +30,4 @@ def test_random_problems_with_the_selectable_variants_forced(gpu, monkeypatch, h
     import fuzz_parity
     monkeypatch.setenv("BESSX_KPATH_CHAINS", "3")
     monkeypatch.setenv("BESSX_TEST_HOOKS", hooks_)
-    assert fuzz_parity.run(cases=60, seed=77, verbose=False) == 0
+    assert fuzz_parity.run(cases=45, seed=77, verbose=False) == 0
