@@ -16,10 +16,13 @@ with capi.Session(X, st, data_type=3, model_type=4) as s:
     single = s.sequential_path(seq, ic_type=3)
     one = time.time() - t0
     print(json.dumps({"one_gpu_ms_per_path": round(1e3 * one, 1)}), flush=True)
-    for world in worlds:
+    rounds = int(os.environ.get("BESSX_PROBE_REBALANCE", "0"))  # > 0: as many rebalancing steps (bdist.rebalance_bounds)
+    for world, it in [(w, i) for w in worlds for i in range(rounds + 1)]:
+        if it == 0:
+            bounds = [bdist.partition(len(seq), world, r)[0] for r in range(world)] + [len(seq)]
         rows = []
         for rank in range(world):
-            lo, hi = bdist.partition(len(seq), world, rank)
+            lo, hi = bounds[rank], bounds[rank + 1]
             best = None
             for rep in range(2):
                 s.set_kpath_chains(0)  # (a rank has a session of its own: the automatic choice afresh)
@@ -41,5 +44,7 @@ with capi.Session(X, st, data_type=3, model_type=4) as s:
             rows.append({"rank": rank, "levels": [int(seq[lo]), int(seq[hi - 1])], "chunk_ms": round(1e3 * best[0], 1),
                          "stitch_ms": round(1e3 * best[1], 1), "refits": best[2]})
         slow = max(r["chunk_ms"] + r["stitch_ms"] for r in rows)
-        print(json.dumps({"world": world, "slowest_rank_ms": round(slow, 1), "speedup_over_one_gpu": round(1e3 * one / slow, 2),
+        print(json.dumps({"world": world, "rebalancing_step": it, "bounds": [int(v) for v in bounds],
+                          "slowest_rank_ms": round(slow, 1), "speedup_over_one_gpu": round(1e3 * one / slow, 2),
                           "ranks": rows}), flush=True)
+        bounds = bdist.rebalance_bounds(bounds, [1e-3 * (r["chunk_ms"] + r["stitch_ms"]) for r in rows])
