@@ -295,6 +295,8 @@ struct bessx_session {
   int cov_panel_blocks = 0;             // workgroups of one panel pass with the slab count chosen at creation
   bool own_hw_queue = false;            // (fit contexts) the context's stream has a hardware queue outside the runtime's pool
   long long group_xtx_ns = 0;           // device time of the last all-rows group_XTX pass inside a path call (LM, timing on)
+  hipEvent_t xtx_ev[2] = {nullptr, nullptr};  // around the last such pass (read when counter 19 is asked for)
+  bool xtx_ev_pending = false;
   bool path_group_xtx = true;           // every cold path call redoes the all-rows group_XTX pass (src/path.cpp:37)
   long long kch_giveups = 0;            // paths whose stitch ran out of budget (the rest was walked as one chain)
   double kch_t[3] = {0, 0, 0};          // BESSX_DEBUG: seconds in the coarse chain / the chunks / the stitch
@@ -445,7 +447,7 @@ int gram_tasks_for(bessx_session *s, int mt, const GramTask **tasks, int *ntask)
 void gram_geometry(const bessx_session *s, int ntask, int *rows_per_slab, int *nslab, int ntiles = 0,
                           bool allow_lds = true);
 int upload_x(bessx_session *s, const double *x, int col_major);
-int prepare_rowset(bessx_session *s, int rs);
+int prepare_rowset(bessx_session *s, int rs, bool keep_yy = false);
 int cov_C_dev(const bessx_session *s);
 bool cov_speculates(const bessx_session *s);
 int enqueue_lm_slot(bessx_session *s, int slot, int T0, double lambda, int rs, bool skip_k1,

@@ -615,16 +615,22 @@ int run_path(bessx_session *s, bool gs, const int *seq, int ns, const double *la
     // and diag(X^T X) in one pass over X.  The result is the one the session already holds (same kernels, same order of
     // summation), so a path pays the reference's pass without changing a bit; BESSX_TEST_HOOKS=path_group_xtx=0 leaves
     // it to session creation (rounds 1-5).  Device time of the last one: bessx_session_counter 19.
-    hipEvent_t ea = nullptr, eb = nullptr;
-    const bool timed = s->timing && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
-    if (timed) (void)hipEventRecord(ea, s->st);
-    const int rc_x = prepare_rowset(s, 0);
-    if (timed && rc_x == 0 && hipEventRecord(eb, s->st) == hipSuccess && hipEventSynchronize(eb) == hipSuccess) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ea, eb) == hipSuccess) s->group_xtx_ns = (long long)(1e6 * (double)ms);
-    }
-    if (ea) (void)hipEventDestroy(ea);
-    if (eb) (void)hipEventDestroy(eb);
+    // (its result is the one the session holds -- nothing is read back, the host goes on queueing the first fit while the
+    // pass runs; with the kernel timing on, two events bracket it and counter 19 reads them when asked)
+    bool timed = s->timing;
+    for (int i = 0; i < 2 && timed; i++)
+      if (!s->xtx_ev[i] && hipEventCreate(&s->xtx_ev[i]) != hipSuccess) {
+        (void)hipGetLastError();
+        s->xtx_ev[i] = nullptr;
+        timed = false;
+      }
+    if (timed) (void)hipEventRecord(s->xtx_ev[0], s->st);
+    const int rc_x = prepare_rowset(s, 0, true);
+    if (timed && rc_x == 0 && hipEventRecord(s->xtx_ev[1], s->st) == hipSuccess) s->xtx_ev_pending = true;
+    // (covariance form: everything that reads X^T y / diag(X^T X) next runs on this stream -- the coarse chain -- and
+    // the chunk chains start behind a synchronisation of it.  Streaming form: chunk chains on streams of their own read
+    // them at once, so the pass is waited for -- 0.6 ms in a path of 80)
+    if (rc_x == 0 && !s->cov_mode) HIPX(hipStreamSynchronize(s->st));
     if (rc_x) return rc_x;
   }
   // Lead fits of a link (bessx_path_chain.lead_levels): a coarse warm-start chain on this session in front of the link,

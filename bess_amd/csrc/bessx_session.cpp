@@ -157,6 +157,8 @@ void session_free(bessx_session *s) {
     if (q) (void)hipFree(q);
   if (s->stage_h) (void)hipHostFree(s->stage_h);
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+  for (auto &ev : s->xtx_ev)
+    if (ev && !s->parent) (void)hipEventDestroy(ev);
   if (s->st) ctx_stream_destroy(s->st);
   delete s;
 }
@@ -526,14 +528,16 @@ int upload_x(bessx_session *s, const double *x, int col_major) {
 
 // X^T (m*y) and column sums of squares on a row set (group_XTX for 1x1 groups,
 // src/utilities.cpp:153-165 and src/Metric.h:108-129): one pass of the two-accumulator K1 kernel.
-int prepare_rowset(bessx_session *s, int rs) {
+// keep_yy: the row set was prepared before and y has not changed (a path call redoing the all-rows pass): the host's
+// copy of y.(m y) stands, so nothing is read back and the host does not wait for the pass
+int prepare_rowset(bessx_session *s, int rs, bool keep_yy) {
   const double *m = s->mask[rs];
   // tmpv = m*y (or y), v2 = m (or ones on data rows = aux column 1)
   if (launch_vec_mul(s->y, m, s->ld, s->tmpv, s->st) != hipSuccess) return fail(BESSX_ERR_HIP, "vec_mul");
   const double *v2 = m ? m : s->aux + s->ld;
   hipError_t e = launch_xtv(s->X, s->ld, s->p, s->U, s->tmpv, v2, s->part_rs[rs], s->part2, nullptr, 0, s->st);
   if (e == hipSuccess) e = launch_part_sum(s->part_rs[rs], s->nrb, s->p, s->xty[rs], s->st);
-  if (e == hipSuccess) {
+  if (e == hipSuccess && !(keep_yy && (int)s->yy_h.size() > rs)) {
     // y . (m y): the loss of an LM fit is y.y - beta.q - ridge |beta|^2 once (G + ridge I) beta = q is solved
     e = launch_dot(s->tmpv, s->y, s->ld, s->bd, s->st);  // bd is scratch here
     double v = 0.0;
@@ -1946,7 +1950,16 @@ long long bessx_session_counter(const bessx_session *s, int which) {
     case 16: return s->kch_chunk_fills;
     case 17: return s->kch_last_chains;
     case 18: return s->kch_giveups;
-    case 19: return s->group_xtx_ns;
+    case 19: {
+      if (s->xtx_ev_pending && s->xtx_ev[0] && s->xtx_ev[1]) {
+        float ms = 0.f;
+        bessx_session *w = const_cast<bessx_session *>(s);
+        if (hipEventSynchronize(s->xtx_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, s->xtx_ev[0], s->xtx_ev[1]) == hipSuccess)
+          w->group_xtx_ns = (long long)(1e6 * (double)ms);
+        w->xtx_ev_pending = false;
+      }
+      return s->group_xtx_ns;
+    }
     case 20: return s->kch_merged;
     case 21: return s->kch_takeovers;
     case 22: return (long long)(1e6 * s->kch_t[0]);
